@@ -1,0 +1,360 @@
+#!/usr/bin/env python3
+"""Generate the golden parity fixtures by RUNNING the reference (CDboyOne/IHGNN) on CPU.
+
+Here-only tooling: it needs ``/root/reference`` (absent on the GPU box) and is never imported by
+tests, ``bench.py`` or the product.  It contains no reference code - it imports the reference's
+modules by path, after stubbing the two third-party packages the image lacks:
+
+* ``torch_sparse``: ``SparseTensor.from_torch_sparse_coo_tensor(t).coalesce()`` + ``matmul`` =
+  ``torch.sparse.mm`` (unit-valued SpMM with sum reduction; version unpinned upstream).
+* ``dgl``: empty module (only the out-of-scope GAT layer touches it).
+
+The reference seeds nothing; every seed below is set by this harness.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz, *.json, f1_data/
+"""
+import hashlib
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = os.environ.get('IHGNN_REFERENCE', '/root/reference')
+sys.dont_write_bytecode = True
+
+
+def _install_stubs():
+    ts = types.ModuleType('torch_sparse')
+
+    class SparseTensor:
+        def __init__(self, t):
+            self.t = t
+
+        @classmethod
+        def from_torch_sparse_coo_tensor(cls, t):
+            return cls(t)
+
+        def coalesce(self):
+            return SparseTensor(self.t.coalesce())
+
+    ts.SparseTensor = SparseTensor
+    ts.matmul = lambda a, b: torch.sparse.mm(a.t, b)
+    sys.modules['torch_sparse'] = ts
+    sys.modules['dgl'] = types.ModuleType('dgl')
+
+
+_install_stubs()
+sys.path.insert(0, REFERENCE)
+sys.path.insert(1, REPO)
+
+from Dataset import GraphDataset, TestSearchLogDataLoader            # noqa: E402  (reference)
+from Helpers.Graph import PpsHyperGraph                                # noqa: E402  (reference)
+from Helpers.Metrics import Metrics, MetricsCollection                 # noqa: E402  (reference)
+from Helpers.ProcessController import ProcessController               # noqa: E402  (reference)
+from Models import RawGnn, IHGNNLayer, HGCNLayer, HemPredictionLayer   # noqa: E402  (reference)
+
+from ihgnn_amd import synth                                            # noqa: E402  (this repo)
+
+CPU = torch.device('cpu')
+torch.set_num_threads(4)
+
+
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def sd_numpy(module, prefix='sd.'):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def load_dataset(paths):
+    return GraphDataset(paths['fn_graph_info'], paths['fn_queries_multihot'], paths['fn_train_data'],
+                        PpsHyperGraph, 10, 0, CPU)
+
+
+# ---------------------------------------------------------------------------------------------
+# F1: tiny hand-made corpus -> graph tensors
+# ---------------------------------------------------------------------------------------------
+F1_ROWS = [
+    # (user, query, items, flags): multi-item logs, negatives, relevance 2 (clamped to 1),
+    # a duplicated (u,q,i), item 5 never interacted (degree -> 1e-8), user 4 never seen.
+    (0, 0, [0, 1], [1, 0]),
+    (1, 0, [2], [1]),
+    (0, 1, [0, 3, 4], [1, 1, 0]),
+    (2, 2, [1], [2]),
+    (3, 3, [4, 2], [0, 1]),
+    (0, 0, [0], [1]),
+    (1, 1, [3], [1]),
+    (2, 2, [1, 0], [1, 1]),
+    (3, 0, [5], [0]),
+    (3, 1, [2], [1]),
+    (1, 3, [4], [1]),
+    (2, 0, [3], [1]),
+]
+
+
+def f1_workload():
+    words = [[0, 1], [2], [3, 4, 5], [6, 1, 0, 2]]
+    offsets = np.cumsum([0] + [len(x) for x in words[:-1]])
+    w = synth.Workload(5, 4, 6, 7, np.zeros((0, 3), np.int64),
+                       np.array(sum(words, []), np.int64), np.array(offsets, np.int64),
+                       valid_logs=[(0, 1, [0, 3]), (2, 2, [1])],
+                       test_logs=[(1, 0, [2]), (3, 3, [2, 4]), (0, 0, [0])])
+    return w
+
+
+def make_f1():
+    w = f1_workload()
+    paths = synth.write_files(w, os.path.join(HERE, 'f1_data'), train_rows=F1_ROWS)
+    ds = load_dataset(paths)
+    g = ds.hypergraph
+    adj = g.Adjacency
+    out = dict(
+        I3=g.I3.numpy(), coo_indices=adj.indices().numpy(), coo_values=adj.values().numpy(),
+        VertexDegrees=g.VertexDegrees.numpy(), EdgeDegrees=g.EdgeDegrees.numpy(),
+        EdgeCount=np.int64(g.EdgeCount),
+        bag_input=ds.queries_for_embeddingbag.numpy(), bag_offsets=ds.queries_offset_for_embeddingbag.numpy(),
+        pos_uqif=np.array([p.uqif() for p in ds.pos_interactions], np.int64),
+        neg_uqi=np.array(ds.neg_interactions, np.int64),
+        counts=np.array([ds.user_count, ds.query_count, ds.item_count, ds.vocab_size, ds.node_count], np.int64),
+    )
+    for name in ('fn_valid_data', 'fn_test_data'):
+        loader = TestSearchLogDataLoader(paths[name], ds, CPU)
+        key = 'valid' if 'valid' in name else 'test'
+        out[f'{key}_uq'] = np.array([(l[0], l[1]) for l in loader.logs], np.int64)
+        out[f'{key}_items_flat'] = np.array(sum([l[2] for l in loader.logs], []), np.int64)
+        out[f'{key}_items_len'] = np.array([len(l[2]) for l in loader.logs], np.int64)
+    np.savez(os.path.join(HERE, 'f1_graph.npz'), **out)
+    return ds
+
+
+# ---------------------------------------------------------------------------------------------
+# F2: layer-level forward + backward
+# ---------------------------------------------------------------------------------------------
+def small_workload(seed=11, eval_logs=12):
+    return synth.draw(40, 20, 50, 30, 300, seed=seed, eval_logs=eval_logs)
+
+
+def layer_case(ds, d, kind, order, seed):
+    seed_all(seed)
+    if kind == 'ihgnn':
+        layer = IHGNNLayer(CPU, ds, d, d, order, False)
+    else:
+        layer = HGCNLayer(CPU, ds, d, d)
+    x = torch.randn(ds.node_count, d, requires_grad=True)
+    y = layer(x)
+    cot = torch.randn_like(y)
+    y.backward(cot)
+    rec = sd_numpy(layer)
+    rec.update(x=x.detach().numpy(), y=y.detach().numpy(), cot=cot.numpy(), dx=x.grad.numpy())
+    for name, p in layer.named_parameters():
+        rec['grad.' + name] = p.grad.numpy().copy()
+    return rec
+
+
+def make_f2(ds_tiny):
+    out = {}
+    w = small_workload()
+    small_dir = os.path.join('/tmp', 'ihgnn_golden_small')
+    ds_small = load_dataset(synth.write_files(w, small_dir))
+    np.savez(os.path.join(HERE, 'f2_small_workload.npz'), triples=w.triples, bag_words=w.bag_words,
+             bag_offsets=w.bag_offsets, counts=np.array([40, 20, 50, 30], np.int64))
+    for tag, ds, d in (('tiny_d8', ds_tiny, 8), ('small_d64', ds_small, 64)):
+        for kind, order in (('ihgnn', 1), ('ihgnn', 2), ('ihgnn', 3), ('hgcn', 0)):
+            rec = layer_case(ds, d, kind, order, seed=100 + order + d)
+            for k, v in rec.items():
+                out[f'{tag}.{kind}{order}.{k}'] = v
+    np.savez(os.path.join(HERE, 'f2_layers.npz'), **out)
+    return ds_small, w
+
+
+# ---------------------------------------------------------------------------------------------
+# F3: model-level forward / eval / loss / grads / one Adam step
+# ---------------------------------------------------------------------------------------------
+def make_f3(ds, tag_cases=(('ihgnn', IHGNNLayer, 2, 3, 8), ('hgcn', HGCNLayer, 2, 1, 8), ('ihgnn_o2', IHGNNLayer, 3, 2, 12))):
+    out = {}
+    for tag, layer_t, L, order, d in tag_cases:
+        seed_all(300 + d + L)
+        m = RawGnn(CPU, ds, d, layer_t, L, order, False, HemPredictionLayer, 0.5)
+        out.update({f'{tag}.{k}': v for k, v in sd_numpy(m).items()})
+        B = 64
+        u = torch.randint(0, ds.user_count, (B,))
+        q = torch.randint(0, ds.query_count, (B,))
+        i = torch.randint(0, ds.item_count, (B,))
+        flags = (torch.rand(B) < 0.3).float()
+        opt = torch.optim.Adam(m.parameters(), 1e-3, weight_decay=0)
+        scores = m(u, q, i)
+        loss = torch.nn.BCEWithLogitsLoss()(scores, flags)
+        loss.backward()
+        grads = {f'{tag}.grad.{n}': p.grad.numpy().copy() for n, p in m.named_parameters()}
+        opt.step()
+        out.update(grads)
+        out.update({f'{tag}.after.{k}': v for k, v in sd_numpy(m, '').items()})
+        out.update({f'{tag}.u': u.numpy(), f'{tag}.q': q.numpy(), f'{tag}.i': i.numpy(),
+                    f'{tag}.flags': flags.numpy(), f'{tag}.scores': scores.detach().numpy(),
+                    f'{tag}.loss': np.float64(loss.item()),
+                    f'{tag}.cfg': np.array([L, order, d], np.int64)})
+        # eval path on the pre-step weights
+        seed_all(300 + d + L)
+        m2 = RawGnn(CPU, ds, d, layer_t, L, order, False, HemPredictionLayer, 0.5)
+        with torch.no_grad():
+            m2.save_features_for_test()
+            feats = m2._saved_output_feature.numpy().copy()
+            ones = torch.ones(ds.item_count, dtype=torch.long)
+            ev = np.stack([m2(uu * ones, qq * ones, None).numpy() for uu, qq in ((0, 0), (3, 5), (39, 19))])
+            m2.clear_saved_feature()
+        out[f'{tag}.features'] = feats
+        out[f'{tag}.eval_uq'] = np.array([(0, 0), (3, 5), (39, 19)], np.int64)
+        out[f'{tag}.eval_scores'] = ev
+    np.savez(os.path.join(HERE, 'f3_model.npz'), **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# F4: metrics + epoch schedule known answers
+# ---------------------------------------------------------------------------------------------
+def make_f4():
+    rec = {}
+    scores = [0.15, 0.05, 0.25, 0.05, 0.05, 0.13, 0.08, 0.12, 0.05, 0.07]
+    truth = [0, 7, 9]
+    m = Metrics.calculate_on_all_items(torch.Tensor(scores), truth, [1, 1, 2], True)
+    rec['selfcheck'] = dict(scores=scores, truth=truth, hr=m.HitRatio_at10, ndcg=m.NDCG_at10, map=m.MAP_at10,
+                            idcg3=Metrics._get_idcg_for_all1(3), idcg_211=Metrics._get_idcg([2, 1, 1]))
+    m2, m3 = m.divide_and_get_new(0.5), m.divide_and_get_new(2)
+    c = MetricsCollection(True)
+    c.add(10, m, m), c.add(20, m2, m2), c.add(30, m3, m3)
+    rec['best_valid_epoch'] = c.get_valid_best(key=lambda x: x.NDCG_at10)[0]
+    rng = np.random.default_rng(4)
+    cases = []
+    for n_items, n_truth in ((50, 1), (50, 3), (200, 12), (30, 2), (1000, 5), (12, 4)):
+        s = rng.standard_normal(n_items).astype(np.float32)          # distinct with probability 1
+        t = sorted(int(x) for x in rng.choice(n_items, n_truth, replace=False))
+        mm = Metrics.calculate_on_all_items(torch.from_numpy(s), t, None, True)
+        cases.append(dict(scores=[float(x) for x in s], truth=t, hr=mm.HitRatio_at10, ndcg=mm.NDCG_at10, map=mm.MAP_at10))
+    # graded relevance branch
+    s = rng.standard_normal(40).astype(np.float32)
+    t, fl = [1, 5, 9, 20], [2, 1, 3, 1]
+    top = np.argsort(-s)[:3].tolist()
+    t[0], t[2] = int(top[0]), int(top[2])
+    mm = Metrics.calculate_on_all_items(torch.from_numpy(s), t, fl, False)
+    rec['graded'] = dict(scores=[float(x) for x in s], truth=t, flags=fl, hr=mm.HitRatio_at10, ndcg=mm.NDCG_at10, map=mm.MAP_at10)
+    rec['random_cases'] = cases
+
+    sched = []
+    pc = ProcessController(20, 5, 7, 2)
+    for epoch in pc:
+        sched.append(dict(epoch=epoch, test=bool(pc.ShouldTest()), store=bool(pc.ShouldStore())))
+    rec['schedule_20_5_7_2'] = sched
+    sched = []
+    pc = ProcessController(12, 1, 3, 3, 12, 1000000)
+    for epoch in pc:
+        sched.append(dict(epoch=epoch, test=bool(pc.ShouldTest()), store=bool(pc.ShouldStore())))
+    rec['schedule_12_1_3_3_store'] = sched
+    with open(os.path.join(HERE, 'f4_metrics.json'), 'w') as f:
+        json.dump(rec, f, indent=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# F5: config C1 (BASELINE.json configs[0]) - scores for one batch + sampled feature rows
+# ---------------------------------------------------------------------------------------------
+def make_f5():
+    out = {}
+    w = synth.draw_config('C1')
+    ds = load_dataset(synth.write_files(w, '/tmp/ihgnn_golden_c1'))
+    for tag, layer_t, order in (('ihgnn3', IHGNNLayer, 3), ('ihgnn1', IHGNNLayer, 1), ('hgcn', HGCNLayer, 1)):
+        seed_all(0)
+        m = RawGnn(CPU, ds, 64, layer_t, 1, order, False, HemPredictionLayer, 0.5)
+        if tag == 'ihgnn3':
+            out.update({f'{tag}.{k}': v for k, v in sd_numpy(m).items()})
+        else:  # embedding tables are drawn first from the same seed => identical; store the rest
+            out.update({f'{tag}.{k}': v for k, v in sd_numpy(m).items() if not k.startswith('sd.embeddings.')})
+            out[f'{tag}.emb_sha'] = np.frombuffer(hashlib.sha256(
+                m.embeddings.embedding_user.weight.detach().numpy().tobytes()).digest(), np.uint8)
+        rng = np.random.default_rng(50)
+        u = torch.from_numpy(rng.integers(0, 1000, 1100)); q = torch.from_numpy(rng.integers(0, 500, 1100))
+        i = torch.from_numpy(rng.integers(0, 1000, 1100))
+        with torch.no_grad():
+            scores = m(u, q, i)
+            m.save_features_for_test()
+            feats = m._saved_output_feature
+            rows = torch.from_numpy(rng.choice(ds.node_count, 64, replace=False))
+            out[f'{tag}.rows'] = rows.numpy()
+            out[f'{tag}.feat_rows'] = feats[rows].numpy()
+            out[f'{tag}.feat_colsum'] = feats.double().sum(0).numpy()
+            out[f'{tag}.feat_abssum'] = np.float64(feats.double().abs().sum().item())
+        out.update({f'{tag}.u': u.numpy(), f'{tag}.q': q.numpy(), f'{tag}.i': i.numpy(), f'{tag}.scores': scores.numpy()})
+    np.savez(os.path.join(HERE, 'f5_c1.npz'), **out)
+
+
+# ---------------------------------------------------------------------------------------------
+# F6: seeded short training run: loss curve + final ranking metrics
+# ---------------------------------------------------------------------------------------------
+def make_f6():
+    from torch.utils.data import DataLoader
+    w = synth.draw(60, 30, 80, 40, 600, seed=6, eval_logs=40)
+    paths = synth.write_files(w, '/tmp/ihgnn_golden_f6')
+    np.savez(os.path.join(HERE, 'f6_workload.npz'), triples=w.triples, bag_words=w.bag_words, bag_offsets=w.bag_offsets,
+             counts=np.array([60, 30, 80, 40], np.int64),
+             test_uq=np.array([(a, b) for a, b, _ in w.test_logs], np.int64),
+             test_items_flat=np.array(sum([c for _, _, c in w.test_logs], []), np.int64),
+             test_items_len=np.array([len(c) for _, _, c in w.test_logs], np.int64))
+    ds = load_dataset(paths)
+    out = {}
+    for tag, layer_t, L, order, d in (('ihgnn', IHGNNLayer, 2, 3, 16), ('hgcn', HGCNLayer, 2, 1, 16)):
+        seed_all(66)
+        m = RawGnn(CPU, ds, d, layer_t, L, order, False, HemPredictionLayer, 0.5)
+        out.update({f'{tag}.init.{k}': v for k, v in sd_numpy(m, '').items()})
+        loader = DataLoader(ds, 100, shuffle=True, collate_fn=GraphDataset.collate_fn)
+        opt = torch.optim.Adam(m.parameters(), 1e-3, weight_decay=0)
+        lossf = torch.nn.BCEWithLogitsLoss()
+        batches, losses = [], []
+        step = 0
+        while step < 48:
+            for pu, pq, pi, pf, nu, nq, ni, nf in loader:
+                u, q, i = torch.cat([pu, nu]), torch.cat([pq, nq]), torch.cat([pi, ni])
+                fl = torch.cat([pf, nf]).float()
+                loss = lossf(m(u, q, i), fl)
+                loss.backward(); opt.step(); opt.zero_grad()
+                batches.append(torch.stack([u, q, i, fl.long()]).numpy().astype(np.int16))
+                losses.append(loss.item())
+                step += 1
+                if step >= 48:
+                    break
+        out[f'{tag}.batches'] = np.stack(batches)
+        out[f'{tag}.losses'] = np.array(losses, np.float64)
+        test = TestSearchLogDataLoader(paths['fn_test_data'], ds, CPU)
+        total, n = Metrics(), 0
+        per_log = []
+        with torch.no_grad():
+            m.save_features_for_test()
+            for users, queries, items, _, all1 in test:
+                mm = Metrics.calculate_on_all_items(m(users, queries, None), items, None, all1)
+                total.add_to_self(mm); n += 1
+                per_log.append((mm.HitRatio_at10, mm.NDCG_at10, mm.MAP_at10))
+            m.clear_saved_feature()
+        avg = total.divide_and_get_new(n)
+        out[f'{tag}.metrics'] = np.array([avg.HitRatio_at10, avg.NDCG_at10, avg.MAP_at10], np.float64)
+        out[f'{tag}.metrics_per_log'] = np.array(per_log, np.float64)
+        out[f'{tag}.cfg'] = np.array([L, order, d], np.int64)
+        out.update({f'{tag}.final.{k}': v for k, v in sd_numpy(m, '').items()})
+    np.savez(os.path.join(HERE, 'f6_training.npz'), **out)
+
+
+if __name__ == '__main__':
+    ds_tiny = make_f1()
+    ds_small, _ = make_f2(ds_tiny)
+    make_f3(ds_small)
+    make_f4()
+    make_f5()
+    make_f6()
+    for fn in sorted(os.listdir(HERE)):
+        p = os.path.join(HERE, fn)
+        if os.path.isfile(p):
+            print(f'{os.path.getsize(p):>9d}  {fn}')
