@@ -1,0 +1,255 @@
+"""Training / evaluation data feeding the hypergraph path (reference ``Dataset.py``).
+
+``GraphDataset`` keeps the reference's constructor, attributes, ``__getitem__`` / ``collate_fn`` contract and
+lazy graph properties (``Dataset.py:11-293``) and adds ``from_arrays`` for in-memory synthetic corpora.
+Positive interactions are held as one ``[E,3]`` int64 array (file order = hyperedge order); the reference's
+list-of-namedtuples view is built only if somebody asks for ``pos_interactions``.
+"""
+from __future__ import annotations
+
+import random
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+from torch.utils.data import Dataset
+
+from .Helpers.Graph import Pps2DGraph, PpsGraph, PpsHyperGraph
+from .Helpers.IOHelper import IOHelper
+from .Helpers.SearchLog import PosInteraction, SearchLog
+from .Helpers.SearchLogCollection import SearchLogCollection
+
+Sample = Tuple[Tuple[int, int, int, int], List[int]]
+
+
+class GraphDataset(Dataset):
+    device: torch.device = None        # class attribute, as in the reference (Dataset.py:135): collate_fn is static
+
+    def __init__(self, fn_graph_info: str, fn_queries_multihot: str, fn_train_data: str, graph_type: type,
+                 random_negative_sample_size: int, non_random_negative_sample_size: int, device: torch.device):
+        super().__init__()
+        with open(fn_graph_info, 'r', encoding='utf-8') as f:
+            counts = [int(tok) for tok in f.readline().split()]
+        if len(counts) != 4:
+            raise ValueError(f'{fn_graph_info}: expected "users queries items vocabulary", got {counts}')
+
+        bag_words: List[int] = []
+        bag_offsets: List[int] = []
+        with open(fn_queries_multihot, 'r', encoding='utf-8') as f:
+            for line in f:
+                bag_offsets.append(len(bag_words))
+                bag_words.extend(int(tok) for tok in line.split())
+
+        logs = SearchLogCollection.read(fn_train_data)
+        triples: List[Tuple[int, int, int]] = []
+        negatives: List[Tuple[int, int, int]] = []
+        for log in logs:
+            for item, flag in zip(log.items, log.interactions):
+                (triples if flag > 0 else negatives).append((log.user, log.query, item))
+
+        self._setup(counts, np.asarray(bag_words, np.int64), np.asarray(bag_offsets, np.int64),
+                    np.asarray(triples, np.int64).reshape(-1, 3), graph_type,
+                    random_negative_sample_size, non_random_negative_sample_size, device)
+        self.search_logs = logs
+        self.neg_interactions = negatives
+        neg_of: Dict[Tuple[int, int], List[int]] = {}
+        for log in logs:
+            bucket = neg_of.setdefault((log.user, log.query), [])
+            bucket.extend(item for item, flag in zip(log.items, log.interactions) if flag <= 0)
+        self.neg_items_for_user_query_pair = neg_of
+
+        IOHelper.LogPrint(f'training set ready: {fn_train_data}')
+        IOHelper.LogPrint(f'users {self.user_count} | queries {self.query_count} | items {self.item_count} | '
+                          f'vocabulary {self.vocab_size} | logs {len(logs)} | hyperedges {len(self)} | {graph_type.__name__}')
+        if len(self):
+            IOHelper.LogPrint(f'{len(negatives) / len(self):.4f} logged negatives per positive')
+
+    @classmethod
+    def from_arrays(cls, user_count: int, query_count: int, item_count: int, vocab_size: int,
+                    bag_words: np.ndarray, bag_offsets: np.ndarray, triples: np.ndarray,
+                    graph_type: type = PpsHyperGraph, random_negative_sample_size: int = 10,
+                    non_random_negative_sample_size: int = 0, device: torch.device = torch.device('cuda:0')) -> 'GraphDataset':
+        """In-memory construction (synthetic corpora): ``bag_words`` are 0-based word ids, ``triples`` 0-based per type."""
+        self = cls.__new__(cls)
+        Dataset.__init__(self)
+        self._setup([user_count, query_count, item_count, vocab_size], np.asarray(bag_words, np.int64),
+                    np.asarray(bag_offsets, np.int64), np.asarray(triples, np.int64).reshape(-1, 3), graph_type,
+                    random_negative_sample_size, non_random_negative_sample_size, device)
+        self.search_logs = None
+        self.neg_interactions = []
+        self.neg_items_for_user_query_pair = {}
+        return self
+
+    def _setup(self, counts: Sequence[int], bag_words: np.ndarray, bag_offsets: np.ndarray, triples: np.ndarray,
+               graph_type: type, rand_neg: int, nonrand_neg: int, device: torch.device) -> None:
+        if graph_type not in (Pps2DGraph, PpsHyperGraph):
+            raise AssertionError(f'unsupported graph type: {graph_type}')
+        GraphDataset.device = device
+        self.graph_type = graph_type
+        self.rand_neg_sample_size = rand_neg
+        self.nonrand_neg_sample_size = nonrand_neg
+        self.neg_sample_size = rand_neg + nonrand_neg
+
+        self.user_count, self.query_count, self.item_count, self.vocab_size = (int(c) for c in counts)
+        self.node_count = self.user_count + self.query_count + self.item_count
+        self.query_start_index_in_graph = self.user_count
+        self.item_start_index_in_graph = self.user_count + self.query_count
+        if bag_offsets.shape[0] != self.query_count:
+            raise ValueError(f'{bag_offsets.shape[0]} query bags for {self.query_count} queries')
+
+        # ids are 0-based on disk; row 0 of every embedding table is padding, so stored id = index + 1
+        self.users_onehot = torch.arange(1, 1 + self.user_count, device=device)
+        self.items_onehot = torch.arange(1, 1 + self.item_count, device=device)
+        self.vocabulary_onehot = torch.arange(1, 1 + self.vocab_size, device=device)
+        self.bag_words_host = bag_words + 1
+        self.bag_offsets_host = bag_offsets
+        self.queries_for_embeddingbag = torch.from_numpy(self.bag_words_host).to(device)
+        self.queries_offset_for_embeddingbag = torch.from_numpy(bag_offsets).to(device)
+
+        self.pos_triples = np.ascontiguousarray(triples)
+        self._pos_interactions: Optional[List[PosInteraction]] = None
+        self._hgraph: Optional[PpsHyperGraph] = None
+        self._graph2d = None
+        self._bag_layout = None
+        self._queries_multihot = None
+
+    # -- lazily built views -----------------------------------------------------------------------
+    @property
+    def pos_interactions(self) -> List[PosInteraction]:
+        if self._pos_interactions is None:
+            if self.search_logs is not None:
+                self._pos_interactions = [p for log in self.search_logs for p in PosInteraction.from_search_log(log, True)]
+            else:
+                self._pos_interactions = [PosInteraction(u, q, '', i, 1, 1, 1, '') for u, q, i in self.pos_triples.tolist()]
+        return self._pos_interactions
+
+    @property
+    def queries_multihot(self) -> Tensor:
+        """Sparse ``[Q x V]`` row-normalised bag-of-words matrix (``Dataset.py:178-183``); unused by the models."""
+        if self._queries_multihot is None:
+            ends = np.append(self.bag_offsets_host[1:], self.bag_words_host.shape[0])
+            lens = ends - self.bag_offsets_host
+            rows = np.repeat(np.arange(self.query_count), lens)
+            vals = np.repeat(1.0 / np.maximum(lens, 1), lens).astype(np.float32)
+            self._queries_multihot = torch.sparse_coo_tensor(
+                np.stack([rows, self.bag_words_host - 1]), vals, (self.query_count, self.vocab_size)).coalesce().to(GraphDataset.device)
+        return self._queries_multihot
+
+    @property
+    def bag_layout(self):
+        """Device layout of the query bags for the HIP embedding-bag kernels."""
+        if self._bag_layout is None:
+            from .ops import BagLayout
+            self._bag_layout = BagLayout(self.bag_words_host, self.bag_offsets_host, self.vocab_size + 1, GraphDataset.device)
+        return self._bag_layout
+
+    @property
+    def hypergraph(self) -> PpsHyperGraph:
+        if self._hgraph is None:
+            self._hgraph = PpsHyperGraph.from_triples(self.pos_triples, self.node_count, self.user_count,
+                                                      self.query_count, GraphDataset.device)
+        return self._hgraph
+
+    @property
+    def graph2d(self) -> Pps2DGraph:
+        if self._graph2d is None:
+            self._graph2d = Pps2DGraph.from_interactions(self.pos_interactions, self.node_count, self.user_count,
+                                                         self.query_count, False, GraphDataset.device)
+        return self._graph2d
+
+    @property
+    def graph(self) -> PpsGraph:
+        return self.graph2d if self.graph_type == Pps2DGraph else self.hypergraph
+
+    # -- sampling ------------------------------------------------------------------------------------
+    def __len__(self) -> int:
+        return int(self.pos_triples.shape[0])
+
+    def __getitem__(self, index: int) -> Sample:
+        """One positive and its sampled negative items (``Dataset.py:107-119``): ``random.sample`` draws distinct
+        items per call and may hit the positive; logged negatives of the (user, query) pair come first if requested."""
+        u, q, i = (int(x) for x in self.pos_triples[index])
+        want_logged = self.nonrand_neg_sample_size
+        if want_logged == 0:
+            return (u, q, i, 1), random.sample(range(self.item_count), self.rand_neg_sample_size)
+        logged = self.neg_items_for_user_query_pair.get((u, q), [])
+        if len(logged) < want_logged:
+            return (u, q, i, 1), random.sample(range(self.item_count), self.neg_sample_size - len(logged)) + logged
+        chosen = random.sample(logged, want_logged)
+        return (u, q, i, 1), chosen + random.sample(range(self.item_count), self.rand_neg_sample_size)
+
+    @staticmethod
+    def collate_fn(data: List[Sample]) -> Tuple[Tensor, ...]:
+        """-> (users, queries, items, flags) of the positives then of the negatives, on ``GraphDataset.device``.
+
+        Everything is packed into one host array and crosses PCIe once (the reference builds eight tensors from
+        Python lists, one copy each, ``Dataset.py:282-291``)."""
+        n_pos = len(data)
+        n_neg = sum(len(negs) for _, negs in data)
+        pack = np.zeros((4, n_pos + n_neg), dtype=np.int64)
+        cursor = n_pos
+        for k, ((u, q, item, flag), negs) in enumerate(data):
+            pack[:, k] = (u, q, item, flag)
+            stop = cursor + len(negs)
+            pack[0, cursor:stop] = u
+            pack[1, cursor:stop] = q
+            pack[2, cursor:stop] = negs
+            cursor = stop
+        dev = torch.from_numpy(pack).to(GraphDataset.device)
+        pos, neg = dev[:, :n_pos], dev[:, n_pos:]
+        return pos[0], pos[1], pos[2], pos[3], neg[0], neg[1], neg[2], neg[3]
+
+    def sample_batches(self, batch_size: int, steps: int, seed: int = 0) -> Iterator[Tuple[Tensor, Tensor, Tensor, Tensor]]:
+        """Vectorised batch source for benchmarks: ``steps`` batches of ``batch_size`` positives (uniform with
+        replacement) each followed by ``rand_neg_sample_size`` uniform negatives; yields device tensors
+        ``(users, queries, items, labels)`` of ``batch_size * (1 + negatives)`` rows."""
+        rng = np.random.default_rng(seed)
+        k = self.rand_neg_sample_size
+        for _ in range(steps):
+            pick = rng.integers(0, len(self), batch_size)
+            pos = self.pos_triples[pick]
+            neg_items = rng.integers(0, self.item_count, batch_size * k)
+            users = np.concatenate([pos[:, 0], np.repeat(pos[:, 0], k)])
+            queries = np.concatenate([pos[:, 1], np.repeat(pos[:, 1], k)])
+            items = np.concatenate([pos[:, 2], neg_items])
+            labels = np.concatenate([np.ones(batch_size, np.float32), np.zeros(batch_size * k, np.float32)])
+            dev = GraphDataset.device
+            yield (torch.from_numpy(users).to(dev), torch.from_numpy(queries).to(dev),
+                   torch.from_numpy(items).to(dev), torch.from_numpy(labels).to(dev))
+
+
+class TestSearchLogDataLoader:
+    """Evaluation logs: every search with >= 1 positive, as (user, query, de-duplicated positive items).
+
+    Iteration yields the reference's 5-tuple (``Dataset.py:324-329``).  ``users`` / ``queries`` are length-``I``
+    index vectors like the reference's ``u * ones(I)``, but as stride-0 expansions of a single element, so the
+    model can tell "one (user, query) against every item" apart and score it as a matrix-vector product.
+    """
+    __test__ = False          # not a pytest class
+
+    def __init__(self, fn_search_log: str, dataset_train: GraphDataset, device: torch.device):
+        self.logs: List[Tuple[int, int, List[int], Optional[List[int]], bool]] = []
+        rows = 0
+        with open(fn_search_log, 'r', encoding='utf-8') as f:
+            next(f, None)
+            for line in f:
+                if not line.strip():
+                    continue
+                rows += 1
+                log = SearchLog.parse(line)
+                if sum(log.interactions) > 0:
+                    self.logs.append((log.user, log.query, log.get_interacted_items()[0], None, True))
+        self.item_count = dataset_train.item_count
+        self.device = device
+        IOHelper.LogPrint(f'evaluation set ready: {fn_search_log} ({rows} rows, {len(self.logs)} usable logs)')
+
+    def __len__(self) -> int:
+        return len(self.logs)
+
+    def __iter__(self):
+        if not self.logs:
+            return
+        uq = torch.tensor([(u, q) for u, q, *_ in self.logs], dtype=torch.long, device=self.device)
+        for k, (_, _, items, flags, all_1) in enumerate(self.logs):
+            yield uq[k, 0:1].expand(self.item_count), uq[k, 1:2].expand(self.item_count), items, flags, all_1

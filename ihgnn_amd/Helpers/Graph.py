@@ -1,0 +1,85 @@
+"""Graph objects handed from the dataset to the GNN layers (reference ``Helpers/Graph.py``).
+
+``PpsHyperGraph`` keeps the reference's attribute surface (``Adjacency``, ``I3``, ``VertexDegrees``,
+``EdgeDegrees``, ``EdgeCount``; ``Graph.py:84-92``) but what the layers actually consume is ``layout``: the
+int32 edge-major / node-major-CSR incidence built natively by ``ihg_build_csr`` (one counting sort on the
+host, instead of the reference's Python loop with one device op per interaction, ``Graph.py:107-118``).
+The reference-shaped tensors are materialised lazily, on first access, for callers that still want them.
+"""
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from ..layout import IncidenceLayout
+
+
+class PpsGraph:
+    """Base class of the graph containers."""
+
+
+class PpsHyperGraph(PpsGraph):
+    """One hyperedge per positive (user, query, item) interaction; duplicates stay distinct hyperedges."""
+
+    def __init__(self):
+        self.layout: Optional[IncidenceLayout] = None
+        self.EdgeCount = 0
+        self._adjacency = self._i3_long = self._edge_degrees = None
+
+    @classmethod
+    def from_triples(cls, triples: np.ndarray, node_count: int, user_count: int, query_count: int,
+                     device: torch.device) -> 'PpsHyperGraph':
+        """Build from an ``[E,3]`` array of 0-based per-type (user, query, item) ids."""
+        g = cls()
+        item_count = node_count - user_count - query_count
+        g.layout = IncidenceLayout(triples, user_count, query_count, item_count, device)
+        g.EdgeCount = g.layout.edge_count
+        return g
+
+    @classmethod
+    def from_interactions(cls, interactions: Iterable, node_count: int, user_count: int, query_count: int,
+                          device: torch.device) -> 'PpsHyperGraph':
+        """Reference entry point (``Graph.py:94-100``): ``interactions`` yield ``.uqif()`` tuples; flag <= 0 is skipped."""
+        rows = [(u, q, i) for u, q, i, flag in (p.uqif() for p in interactions) if flag > 0]
+        return cls.from_triples(np.asarray(rows, dtype=np.int64).reshape(-1, 3), node_count, user_count, query_count, device)
+
+    # -- reference-shaped views ---------------------------------------------------------------
+    @property
+    def VertexDegrees(self) -> Tensor:
+        """``[N,1]`` float degrees with isolated nodes at 1e-8 (``Graph.py:120,131``)."""
+        return self.layout.degree.view(-1, 1)
+
+    @property
+    def EdgeDegrees(self) -> Tensor:
+        if self._edge_degrees is None:
+            self._edge_degrees = torch.full((self.EdgeCount, 1), 3.0, dtype=torch.float32, device=self.layout.device)
+        return self._edge_degrees
+
+    @property
+    def I3(self) -> Tensor:
+        """``[E,3]`` int64 global member ids (``Graph.py:129``)."""
+        if self._i3_long is None:
+            self._i3_long = self.layout.i3.long()
+        return self._i3_long
+
+    @property
+    def Adjacency(self) -> Tensor:
+        """Coalesced ``[N x E]`` unit-valued sparse COO incidence (``Graph.py:123-128``)."""
+        if self._adjacency is None:
+            csr = self.layout.node_csr
+            lens = np.diff(csr.ptr_host.astype(np.int64))
+            rows = torch.from_numpy(np.repeat(np.arange(csr.n_rows, dtype=np.int64), lens))
+            cols = torch.from_numpy(csr.ids_host.astype(np.int64))
+            adj = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.ones(csr.nnz, dtype=torch.float32),
+                                          (csr.n_rows, self.EdgeCount)).coalesce()
+            self._adjacency = adj.to(self.layout.device)
+        return self._adjacency
+
+
+class Pps2DGraph(PpsGraph):
+    """Pairwise graph of the GCN / GAT baselines (``Graph.py:13-81``): outside this build's hot path."""
+
+    @classmethod
+    def from_interactions(cls, *args, **kwargs):
+        raise NotImplementedError('Pps2DGraph (GCN/GAT baselines) is not part of the MI355X hypergraph path yet')

@@ -1,0 +1,73 @@
+"""Hypergraph layers (reference ``Models/GnnLayers.py:118-236``): ``IHGNNLayer`` and ``HGCNLayer``.
+
+Constructor signatures, sub-module names (``feature_transform``, ``feature_interactor.aggregation``) and the
+absence of any non-linearity follow the reference; the sparse work runs in the HIP kernels of
+libihgnn_hip.so through :mod:`ihgnn_amd.ops` instead of ``torch_sparse.matmul``.  ``GCNLayer`` / ``GATLayer``
+(pairwise-graph baselines on DGL) are declared for the name tables only.
+"""
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import ops
+from .CommonLayers import FeatureInteractor
+
+
+class HGCNLayer(nn.Module):
+    """``Y = Dv^-1/2 H De^-1 H^T Dv^-1/2 (X W^T + b)``  (``GnnLayers.py:142-153``)."""
+
+    def __init__(self, device: torch.device, dataset, input_dimension: int, output_dimension: int):
+        super().__init__()
+        self.device = device
+        self.dataset = dataset
+        self.layout = dataset.hypergraph.layout
+        self.edge_scale = float(torch.tensor(3.0).pow(-1))      # De^-1 of a 3-uniform hypergraph, as fp32
+        self.feature_transform = nn.Linear(input_dimension, output_dimension)
+
+    def forward(self, input_features: Tensor) -> Tensor:
+        lay = self.layout
+        h = self.feature_transform(input_features)
+        edge_features = ops.edge_gather_sum(h, lay, node_scale=lay.inv_sqrt_deg, alpha=self.edge_scale)
+        return ops.node_segment_sum(edge_features, lay, out_scale=lay.inv_sqrt_deg)
+
+
+class IHGNNLayer(nn.Module):
+    """``Y = Dv^-1 H Interact(X W^T + b)``  (``GnnLayers.py:221-236``, phase-2 attention off)."""
+
+    def __init__(self, device: torch.device, dataset, input_dimension: int, output_dimension: int,
+                 feature_interaction_order: int, phase2_attention: bool):
+        super().__init__()
+        if feature_interaction_order not in (1, 2, 3):
+            raise AssertionError('feature interaction order must be 1, 2 or 3')
+        if phase2_attention:
+            raise NotImplementedError('phase-2 attention (DGL edge-softmax branch, GnnLayers.py:200-216) is outside '
+                                      'the MI355X hypergraph path; the reference driver hard-codes it off (Main.py:57)')
+        self.device = device
+        self.dataset = dataset
+        self.feature_interaction_order = feature_interaction_order
+        self.attention_phase2 = False
+        self.layout = dataset.hypergraph.layout
+        self.feature_interactor = FeatureInteractor(dataset=dataset, max_order=feature_interaction_order,
+                                                    node_feature_dimension=input_dimension,
+                                                    output_dimension=input_dimension)
+        self.feature_transform = nn.Linear(input_dimension, output_dimension)
+
+    def forward(self, input_features: Tensor) -> Tensor:
+        h = self.feature_transform(input_features)
+        edge_features = self.feature_interactor(h)
+        return ops.node_segment_sum(edge_features, self.layout, out_scale=self.layout.inv_deg)
+
+
+class _PairwiseBaseline(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError(f'{type(self).__name__} is a pairwise-graph baseline outside the MI355X hypergraph '
+                                  'path (SURVEY.md §8 f3); use IHGNNLayer or HGCNLayer')
+
+
+class GCNLayer(_PairwiseBaseline):
+    pass
+
+
+class GATLayer(_PairwiseBaseline):
+    pass

@@ -1,0 +1,87 @@
+"""The model (reference ``Models/RawGnn.py``): embeddings -> L hypergraph layers -> concat -> row gathers -> HEM.
+
+Same constructor keywords, ``forward(user_indices, query_indices, item_indices=None)``,
+``save_features_for_test`` / ``clear_saved_feature`` and state-dict keys (``embeddings.*``, ``gnn_{l}.*``,
+``prediction_layer.items_bias``) as the reference, so its driver and checkpoints carry over.
+"""
+from typing import Optional, Type
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ..Helpers.GlobalSettings import Gs
+from .EmbeddingLayers import EmbeddingLayer
+from .GnnLayers import GATLayer, GCNLayer, HGCNLayer, IHGNNLayer
+from .PredictionLayers import HemPredictionLayer
+
+
+class RawGnn(nn.Module):
+    _saved_output_feature: Optional[Tensor] = None
+
+    def __init__(self, device: torch.device, dataset, embedding_size: int, gnn_layer_type: Type,
+                 gnn_layer_count: int, feature_interaction_order: int, phase2_attention: bool,
+                 predictions: Type, lambda_muq: float):
+        super().__init__()
+        self.device = device
+        self.dataset = dataset
+        self.embedding_size = embedding_size
+        self.gnn_layer_type = gnn_layer_type
+        self.gnn_layer_count = gnn_layer_count
+        self.feature_interaction_order = feature_interaction_order
+        self.phase2_attention = phase2_attention
+        self.prediction_layer_type = predictions
+        self.output_feature_size = embedding_size * (1 + gnn_layer_count)
+
+        self.embeddings = EmbeddingLayer(dataset=dataset, embedding_size=embedding_size)
+
+        self.gnns = []
+        for depth in range(gnn_layer_count):
+            if gnn_layer_type is IHGNNLayer:
+                # only the first layer interacts at the requested order; deeper layers are first-order (RawGnn.py:76-78)
+                order = feature_interaction_order if depth == 0 else min(feature_interaction_order, 1)
+                layer = IHGNNLayer(device=device, dataset=dataset, input_dimension=embedding_size,
+                                   output_dimension=embedding_size, feature_interaction_order=order,
+                                   phase2_attention=phase2_attention)
+            elif gnn_layer_type in (HGCNLayer, GCNLayer, GATLayer):
+                layer = gnn_layer_type(device=device, dataset=dataset, input_dimension=embedding_size,
+                                       output_dimension=embedding_size)
+            else:
+                raise NotImplementedError(f'unsupported GNN layer type: {gnn_layer_type}')
+            self.gnns.append(layer)
+            self.add_module(f'gnn_{depth}', layer)
+
+        if predictions is not HemPredictionLayer:
+            raise NotImplementedError(f'unsupported prediction layer type: {predictions}')
+        self.prediction_layer = HemPredictionLayer(feature_dimension=self.output_feature_size, lambda_muq=lambda_muq,
+                                                   item_count=dataset.item_count)
+
+    def propagate(self) -> Tensor:
+        """Full-graph propagation: ``[N, d*(L+1)]`` = input embeddings and every layer's output side by side."""
+        x = torch.cat(self.embeddings(None, None, None))
+        outputs = [x]
+        for layer in self.gnns:
+            x = layer(x)
+            outputs.append(x)
+        return torch.cat(outputs, 1)
+
+    def forward(self, user_indices: Tensor, query_indices: Tensor, item_indices: Optional[Tensor] = None) -> Tensor:
+        """Indices are 0-based per type.  ``item_indices=None`` scores the given (user, query) against every item."""
+        features = self._saved_output_feature if self._saved_output_feature is not None else self.propagate()
+        ds = self.dataset
+        if item_indices is None:
+            item_feature = features[ds.item_start_index_in_graph:]
+            if user_indices.dim() == 1 and user_indices.numel() > 1 and user_indices.stride(0) == 0 and query_indices.stride(0) == 0:
+                user_indices, query_indices = user_indices[:1], query_indices[:1]      # one pair broadcast over all items
+        else:
+            item_feature = features[item_indices + ds.item_start_index_in_graph]
+        user_feature = features[user_indices]
+        query_feature = features[query_indices + ds.query_start_index_in_graph]
+        return self.prediction_layer(user_feature, query_feature, item_feature, item_indices)
+
+    def save_features_for_test(self) -> None:
+        """Cache one propagation for the evaluation loop (call under ``torch.no_grad()``)."""
+        self._saved_output_feature = self.propagate()
+
+    def clear_saved_feature(self) -> None:
+        self._saved_output_feature = None

@@ -1,0 +1,84 @@
+"""ctypes binding of libihgnn_hip.so (C ABI: include/ihgnn_hip.h).
+
+There is exactly one implementation of the hot path - the HIP library.  If it cannot be loaded the
+first call raises; nothing in this package falls back to PyTorch or CPU code.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_void_p
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
+
+ABI_VERSION = 1
+
+OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
+SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
+
+_i64p, _i32p, _f32p = POINTER(c_int64), POINTER(c_int32), POINTER(c_float)
+
+# name -> (restype, argtypes); mirrors include/ihgnn_hip.h line by line.  Device pointers travel as
+# c_void_p (tensor.data_ptr()); host-side builders take real typed pointers.
+SIGNATURES = {
+    'ihg_abi_version': (c_int32, []),
+    'ihg_last_error_string': (c_char_p, []),
+    'ihg_build_csr': (ctypes.c_int, [_i64p, c_int64, c_int64, c_int64, c_int64, _i32p, _i32p, _i32p, _f32p]),
+    'ihg_transpose_csr': (ctypes.c_int, [_i32p, _i32p, c_int64, c_int64, _i32p, _i32p]),
+    'ihg_edge_gather_sum': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float,
+                                           c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    'ihg_node_segment_sum': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                            c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
+    'ihg_node_segment_sum_heavy': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32,
+                                                  c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                                  c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    'ihg_bag_mean_fwd': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                        c_int64, c_int32, c_void_p]),
+    'ihg_bag_mean_bwd': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                        c_int64, c_int32, c_void_p]),
+    'ihg_interact_fwd': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
+                                        c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    'ihg_interact_bwd_workspace_bytes': (c_int64, [c_int64, c_int32, c_int32]),
+    'ihg_interact_bwd': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64,
+                                        c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class IhgnnHipError(RuntimeError):
+    """A libihgnn_hip entry point returned a non-zero status."""
+
+
+def load() -> ctypes.CDLL:
+    """Bind the library (once).  Raises if it is missing, stale in ABI, or lacks a declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IhgnnHipError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(hipcc --offload-arch=gfx950).  ihgnn_amd has no CPU or PyTorch fallback for this path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise IhgnnHipError(f'{LIB_PATH} does not export {name} (declared in include/ihgnn_hip.h)') from exc
+        fn.restype, fn.argtypes = restype, argtypes
+    got = lib.ihg_abi_version()
+    if got != ABI_VERSION:
+        raise IhgnnHipError(f'{LIB_PATH} has ABI version {got}, this package needs {ABI_VERSION}: rebuild it')
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ihg_last_error_string().decode('utf-8', 'replace')
+
+
+def check(status: int, what: str) -> None:
+    if status != OK:
+        raise IhgnnHipError(f'{what} failed with status {status}: {last_error()}')

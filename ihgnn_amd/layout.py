@@ -1,0 +1,139 @@
+"""HBM-resident incidence layouts consumed by the HIP kernels.
+
+* :class:`Csr` - a row -> id-list structure (``ptr[n_rows+1]``, ``ids[nnz]``, int32) plus the split-row
+  plan for skewed rows (rows longer than ``heavy_threshold`` are cut into ``heavy_chunk``-sized segments
+  summed by separate lane groups; see ``ihg_node_segment_sum_heavy``).
+* :class:`IncidenceLayout` - the (user, query, item) hypergraph: ``i3[E,3]`` edge-major member ids (fixed
+  arity, so no edge-side row pointer) and the node-major CSR, built by the native ``ihg_build_csr``.
+
+Replaces the coalesced COO ``Adjacency`` + int64 ``I3`` of ``Helpers/Graph.py:94-134`` (reference) as the
+thing kernels read; 12 B of int32 ids per hyperedge on each side instead of 48 B of int64 COO.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+HEAVY_THRESHOLD = 1024     # rows longer than this are split ...
+HEAVY_CHUNK = 512          # ... into segments of this many ids
+
+
+def _as_ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+class Csr:
+    """Device-resident CSR with an optional split-row plan."""
+
+    def __init__(self, ptr_host: np.ndarray, ids_host: np.ndarray, device: torch.device,
+                 heavy_threshold: int = HEAVY_THRESHOLD, heavy_chunk: int = HEAVY_CHUNK):
+        ptr_host = np.ascontiguousarray(ptr_host, dtype=np.int32)
+        ids_host = np.ascontiguousarray(ids_host, dtype=np.int32)
+        self.n_rows = int(ptr_host.shape[0] - 1)
+        self.nnz = int(ids_host.shape[0])
+        self.device = device
+        self.ptr_host, self.ids_host = ptr_host, ids_host
+        self.ptr = torch.from_numpy(ptr_host).to(device)
+        self.ids = torch.from_numpy(ids_host).to(device)
+        self.heavy_threshold = int(heavy_threshold)
+        self._plan_heavy(int(heavy_chunk))
+        self._partials: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    def _plan_heavy(self, chunk: int) -> None:
+        lens = np.diff(self.ptr_host.astype(np.int64))
+        heavy = np.nonzero(lens > self.heavy_threshold)[0] if self.heavy_threshold > 0 else np.zeros(0, np.int64)
+        self.n_heavy = int(heavy.shape[0])
+        self.max_row_len = int(lens.max()) if lens.size else 0
+        if self.n_heavy == 0:
+            self.n_segments = 0
+            self.heavy_rows = self.heavy_segptr = self.seg_begin = self.seg_end = None
+            return
+        seg_counts = (lens[heavy] + chunk - 1) // chunk
+        segptr = np.zeros(self.n_heavy + 1, np.int64)
+        np.cumsum(seg_counts, out=segptr[1:])
+        self.n_segments = int(segptr[-1])
+        owner = np.repeat(np.arange(self.n_heavy), seg_counts)
+        within = np.arange(self.n_segments) - segptr[owner]
+        begin = self.ptr_host[heavy][owner].astype(np.int64) + within * chunk
+        end = np.minimum(begin + chunk, self.ptr_host[heavy + 1][owner].astype(np.int64))
+        dev = self.device
+        self.heavy_rows = torch.from_numpy(heavy.astype(np.int32)).to(dev)
+        self.heavy_segptr = torch.from_numpy(segptr.astype(np.int32)).to(dev)
+        self.seg_begin = torch.from_numpy(begin.astype(np.int32)).to(dev)
+        self.seg_end = torch.from_numpy(end.astype(np.int32)).to(dev)
+
+    def partials(self, dim: int) -> torch.Tensor:
+        """Workspace for the split-row partial sums (allocated once per feature width)."""
+        key = (self.n_segments, dim)
+        buf = self._partials.get(key)
+        if buf is None:
+            buf = torch.empty(max(self.n_segments, 1), dim, dtype=torch.float32, device=self.device)
+            self._partials[key] = buf
+        return buf
+
+    def row_slice(self, begin: int, end: int) -> 'CsrRows':
+        return CsrRows(self, begin, end)
+
+    def transpose(self, n_cols: int) -> 'Csr':
+        lib = _lib.load()
+        t_ptr = np.empty(n_cols + 1, np.int32)
+        t_rows = np.empty(max(self.nnz, 1), np.int32)
+        _lib.check(lib.ihg_transpose_csr(_as_ptr(self.ptr_host, ctypes.c_int32), _as_ptr(self.ids_host, ctypes.c_int32),
+                                         self.n_rows, n_cols, _as_ptr(t_ptr, ctypes.c_int32), _as_ptr(t_rows, ctypes.c_int32)),
+                   'ihg_transpose_csr')
+        return Csr(t_ptr, t_rows[:self.nnz], self.device, self.heavy_threshold)
+
+
+class CsrRows:
+    """Rows [begin, end) of a :class:`Csr` (``ptr`` offsets are absolute, so a pointer bump suffices).
+
+    Heavy rows inside the slice are processed in place by the light kernel (threshold disabled): slices are
+    only used for the per-type passes of the interactive backward, whose source differs per node type.
+    """
+
+    def __init__(self, parent: Csr, begin: int, end: int):
+        self.parent, self.begin, self.end = parent, begin, end
+        self.n_rows = end - begin
+        self.ptr = parent.ptr[begin:end + 1]
+        self.ids = parent.ids
+        self.device = parent.device
+        self.heavy_threshold = 0
+        self.n_heavy = 0
+
+
+class IncidenceLayout:
+    """The (user, query, item) hypergraph in kernel layout."""
+
+    def __init__(self, triples: np.ndarray, user_count: int, query_count: int, item_count: int, device: torch.device,
+                 heavy_threshold: int = HEAVY_THRESHOLD):
+        lib = _lib.load()
+        triples = np.ascontiguousarray(np.asarray(triples, dtype=np.int64).reshape(-1, 3))
+        self.user_count, self.query_count, self.item_count = int(user_count), int(query_count), int(item_count)
+        self.node_count = n = self.user_count + self.query_count + self.item_count
+        self.edge_count = e = int(triples.shape[0])
+        self.device = device
+        i3 = np.empty((max(e, 1), 3), np.int32)
+        rowptr = np.empty(n + 1, np.int32)
+        edge_ids = np.empty(max(3 * e, 1), np.int32)
+        degree = np.empty(max(n, 1), np.float32)
+        _lib.check(lib.ihg_build_csr(_as_ptr(triples, ctypes.c_int64), e, self.user_count, self.query_count, self.item_count,
+                                     _as_ptr(i3, ctypes.c_int32), _as_ptr(rowptr, ctypes.c_int32),
+                                     _as_ptr(edge_ids, ctypes.c_int32), _as_ptr(degree, ctypes.c_float)),
+                   'ihg_build_csr')
+        self.i3_host = i3[:e]
+        self.i3 = torch.from_numpy(self.i3_host).to(device)
+        self.node_csr = Csr(rowptr, edge_ids[:3 * e], device, heavy_threshold)
+        deg = torch.from_numpy(degree[:n].copy())
+        self.degree = deg.to(device)                       # Graph.py:120 semantics (isolated -> 1e-8)
+        isolated = deg < 0.5
+        # Same CPU float ops as the reference (GnnLayers.py:133,187) so the scale factors are bit-identical;
+        # isolated nodes get 0 instead of 1e8 / 1e4: their sums are empty, so every output is unchanged.
+        self.inv_deg = torch.where(isolated, torch.zeros_like(deg), deg.pow(-1)).to(device)
+        self.inv_sqrt_deg = torch.where(isolated, torch.zeros_like(deg), deg.pow(-0.5)).to(device)
+        u, q = self.user_count, self.query_count
+        self.type_rows = (self.node_csr.row_slice(0, u), self.node_csr.row_slice(u, u + q), self.node_csr.row_slice(u + q, n))

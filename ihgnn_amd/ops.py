@@ -1,0 +1,234 @@
+"""Differentiable operators of the hypergraph path, each a thin ``torch.autograd.Function`` over the C ABI.
+
+PyTorch is plumbing here (device memory, current stream, autograd tape); every forward and backward below
+is one or two launches of a hand-written gfx950 kernel in libihgnn_hip.so.  Tensors must live on the GPU:
+there is no CPU implementation to fall back to.
+
+Operator               forward kernel              backward kernel(s)
+---------------------  --------------------------  ------------------------------------------------
+edge_gather_sum  (K5)  ihg_edge_gather_sum         ihg_node_segment_sum   (its transpose)
+node_segment_sum (K7)  ihg_node_segment_sum[_heavy] ihg_edge_gather_sum    (its transpose)
+bag_mean         (K2)  ihg_bag_mean_fwd            ihg_bag_mean_bwd
+interact     (K5+K6)   ihg_interact_fwd            ihg_interact_bwd + 4x ihg_node_segment_sum
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Union
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from . import profiler
+from .layout import Csr, CsrRows, IncidenceLayout
+
+_void = ctypes.c_void_p
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else _void(t.data_ptr())
+
+
+def _stream():
+    return _void(torch.cuda.current_stream().cuda_stream)
+
+
+def _rows(t: Tensor, name: str) -> Tensor:
+    """A 2-D fp32 GPU tensor whose rows are contiguous (any row stride); copies only if it must."""
+    if not t.is_cuda:
+        raise _lib.IhgnnHipError(f'{name} must be a GPU tensor: ihgnn_amd has no CPU path (got device {t.device})')
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise TypeError(f'{name} must be a 2-D float32 tensor, got {tuple(t.shape)} {t.dtype}')
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: Tensor) -> int:
+    return int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
+
+
+# ---------------------------------------------------------------------------------------------
+# raw launches (no autograd)
+# ---------------------------------------------------------------------------------------------
+def edge_gather_sum_raw(src: Tensor, i3: Tensor, node_scale: Optional[Tensor] = None, bias: Optional[Tensor] = None,
+                        alpha: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    src = _rows(src, 'src')
+    n_edges, dim = int(i3.shape[0]), int(src.shape[1])
+    if out is None:
+        out = torch.empty(n_edges, dim, dtype=torch.float32, device=src.device)
+    with profiler.kernel('edge_gather_sum', n_edges, dim):
+        _lib.check(lib.ihg_edge_gather_sum(_ptr(src), _ld(src), _ptr(i3), _ptr(node_scale), _ptr(bias), float(alpha),
+                                           _ptr(out), _ld(out), n_edges, dim, _stream()), 'ihg_edge_gather_sum')
+    return out
+
+
+def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optional[Tensor] = None,
+                         out_scale: Optional[Tensor] = None, mode: int = _lib.SCALE_NONE,
+                         out: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    src = _rows(src, 'src')
+    dim = int(src.shape[1])
+    if out is None:
+        out = torch.empty(csr.n_rows, dim, dtype=torch.float32, device=src.device)
+    threshold = csr.heavy_threshold if csr.n_heavy > 0 else 0
+    with profiler.kernel('node_segment_sum', csr.n_rows, dim):
+        _lib.check(lib.ihg_node_segment_sum(_ptr(src), _ld(src), _ptr(csr.ptr), _ptr(csr.ids), _ptr(src_scale), _ptr(out_scale),
+                                            mode, _ptr(out), _ld(out), csr.n_rows, dim, threshold, _stream()),
+                   'ihg_node_segment_sum')
+    if csr.n_heavy > 0:
+        with profiler.kernel('node_segment_sum_heavy', csr.n_heavy, dim):
+            _lib.check(lib.ihg_node_segment_sum_heavy(
+                _ptr(src), _ld(src), _ptr(csr.ids), _ptr(src_scale), _ptr(out_scale), mode,
+                _ptr(csr.seg_begin), _ptr(csr.seg_end), csr.n_segments, _ptr(csr.heavy_rows), _ptr(csr.heavy_segptr),
+                csr.n_heavy, _ptr(csr.partials(dim)), _ptr(out), _ld(out), dim, _stream()), 'ihg_node_segment_sum_heavy')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# K5 / K7 as a transposed pair
+# ---------------------------------------------------------------------------------------------
+class _EdgeGatherSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src: Tensor, layout: IncidenceLayout, node_scale: Optional[Tensor], alpha: float) -> Tensor:
+        ctx.layout, ctx.node_scale, ctx.alpha = layout, node_scale, alpha
+        return edge_gather_sum_raw(src, layout.i3, node_scale, None, alpha)
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        scale = ctx.node_scale
+        if ctx.alpha != 1.0:
+            scale = (scale * ctx.alpha) if scale is not None else torch.full(
+                (ctx.layout.node_count,), ctx.alpha, dtype=torch.float32, device=grad_out.device)
+        mode = _lib.SCALE_NONE if scale is None else _lib.SCALE_MULTIPLY
+        return node_segment_sum_raw(grad_out, ctx.layout.node_csr, None, scale, mode), None, None, None
+
+
+class _NodeSegmentSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor]) -> Tensor:
+        ctx.layout, ctx.out_scale = layout, out_scale
+        mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
+        return node_segment_sum_raw(src, layout.node_csr, None, out_scale, mode)
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        return edge_gather_sum_raw(grad_out, ctx.layout.i3, ctx.out_scale, None, 1.0), None, None
+
+
+def edge_gather_sum(src: Tensor, layout: IncidenceLayout, node_scale: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
+    """node -> hyperedge: ``out[e] = alpha * sum_{v in e} node_scale[v] * src[v]``  (``[N,d] -> [E,d]``)."""
+    return _EdgeGatherSum.apply(src, layout, node_scale, float(alpha))
+
+
+def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor] = None) -> Tensor:
+    """hyperedge -> node: ``out[v] = out_scale[v] * sum_{e containing v} src[e]``  (``[E,d] -> [N,d]``)."""
+    return _NodeSegmentSum.apply(src, layout, out_scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# K2 query embedding bag (mean)
+# ---------------------------------------------------------------------------------------------
+class BagLayout:
+    """Query -> word-row lists (``nn.EmbeddingBag`` input/offsets of Dataset.py:161-186) and their transpose."""
+
+    def __init__(self, bag_input, bag_offsets, table_rows: int, device: torch.device):
+        import numpy as np
+        words = np.ascontiguousarray(np.asarray(bag_input, dtype=np.int64).reshape(-1))
+        offsets = np.asarray(bag_offsets, dtype=np.int64).reshape(-1)
+        if words.size and (words.min() < 0 or words.max() >= table_rows):
+            raise ValueError('bag word id outside the embedding table')
+        ptr = np.append(offsets, words.shape[0]).astype(np.int32)
+        self.n_bags, self.table_rows = int(offsets.shape[0]), int(table_rows)
+        self.bags = Csr(ptr, words.astype(np.int32), device, heavy_threshold=0)
+        self.words_of = self.bags.transpose(table_rows)
+        lens = np.diff(ptr.astype(np.int64)).astype(np.float32)
+        self.bag_len = torch.from_numpy(lens).to(device)
+        inv = np.where(lens > 0, 1.0 / np.maximum(lens, 1), 0).astype(np.float32)
+        self.inv_len = torch.from_numpy(inv).to(device)
+
+
+class _BagMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table: Tensor, bag: BagLayout) -> Tensor:
+        lib = _lib.load()
+        ctx.bag = bag
+        table = _rows(table, 'table')
+        dim = int(table.shape[1])
+        out = torch.empty(bag.n_bags, dim, dtype=torch.float32, device=table.device)
+        with profiler.kernel('bag_mean_fwd', bag.n_bags, dim):
+            _lib.check(lib.ihg_bag_mean_fwd(_ptr(table), _ld(table), _ptr(bag.bags.ptr), _ptr(bag.bags.ids), _ptr(bag.bag_len),
+                                            _ptr(out), _ld(out), bag.n_bags, dim, _stream()), 'ihg_bag_mean_fwd')
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        lib = _lib.load()
+        bag = ctx.bag
+        grad_out = _rows(grad_out, 'grad_out')
+        dim = int(grad_out.shape[1])
+        dtable = torch.empty(bag.table_rows, dim, dtype=torch.float32, device=grad_out.device)
+        with profiler.kernel('bag_mean_bwd', bag.table_rows, dim):
+            _lib.check(lib.ihg_bag_mean_bwd(_ptr(grad_out), _ld(grad_out), _ptr(bag.words_of.ptr), _ptr(bag.words_of.ids),
+                                            _ptr(bag.inv_len), _ptr(dtable), _ld(dtable), bag.table_rows, dim, _stream()),
+                       'ihg_bag_mean_bwd')
+        return dtable, None
+
+
+def bag_mean(table: Tensor, bag: BagLayout) -> Tensor:
+    """``nn.EmbeddingBag(mode='mean')`` over every query: ``[V+1,d] -> [Q,d]``."""
+    return _BagMean.apply(table, bag)
+
+
+# ---------------------------------------------------------------------------------------------
+# K5+K6 interactive step (orders 2 and 3)
+# ---------------------------------------------------------------------------------------------
+class _Interact(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: int) -> Tensor:
+        lib = _lib.load()
+        h, p = _rows(h, 'h'), _rows(p, 'p')
+        w = _rows(w, 'w')
+        dim = int(h.shape[1])
+        out = torch.empty(layout.edge_count, dim, dtype=torch.float32, device=h.device)
+        with profiler.kernel('interact_fwd', layout.edge_count, dim):
+            _lib.check(lib.ihg_interact_fwd(_ptr(h), _ld(h), _ptr(p), _ld(p), _ptr(layout.i3), _ptr(w), _ld(w), order,
+                                            _ptr(out), _ld(out), layout.edge_count, dim, _stream()), 'ihg_interact_fwd')
+        ctx.save_for_backward(h, w)
+        ctx.layout, ctx.order = layout, order
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        lib = _lib.load()
+        h, w = ctx.saved_tensors
+        layout, order = ctx.layout, ctx.order
+        grad_out = _rows(grad_out, 'grad_out')
+        n_edges, dim = layout.edge_count, int(h.shape[1])
+        g = torch.empty(n_edges, 3 * dim, dtype=torch.float32, device=h.device)
+        dw = torch.zeros_like(w)
+        ws_bytes = int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order))
+        ws = torch.empty(max(ws_bytes, 4) // 4 + 1, dtype=torch.float32, device=h.device)
+        with profiler.kernel('interact_bwd', n_edges, dim):
+            _lib.check(lib.ihg_interact_bwd(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(grad_out), _ld(grad_out),
+                                            _ptr(g), _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4, n_edges, dim, _stream()),
+                       'ihg_interact_bwd')
+        # member gradients back to nodes: node type t reads slot t of g (users/queries/items are contiguous id ranges)
+        dh = torch.empty(layout.node_count, dim, dtype=torch.float32, device=h.device)
+        starts = (0, layout.user_count, layout.user_count + layout.query_count)
+        for slot, rows in enumerate(layout.type_rows):
+            if rows.n_rows:
+                node_segment_sum_raw(g[:, slot * dim:(slot + 1) * dim], rows, out=dh[starts[slot]:starts[slot] + rows.n_rows])
+        dp = node_segment_sum_raw(grad_out, layout.node_csr)
+        return dh, dp, dw, None, None
+
+
+def interact(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: int) -> Tensor:
+    """Interactive node -> hyperedge step: first-order part from ``p`` (hoisted), products contracted with ``w``."""
+    if order not in (2, 3):
+        raise ValueError('interact handles interaction orders 2 and 3; order 1 is edge_gather_sum on the hoisted features')
+    return _Interact.apply(h, p, w, layout, int(order))

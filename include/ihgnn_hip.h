@@ -1,0 +1,155 @@
+/*
+ * ihgnn_hip.h - C ABI of libihgnn_hip.so: the MI355X (gfx950) hypergraph message-passing path of IHGNN.
+ *
+ * This is the drop-in boundary.  The reference reaches this path through PyTorch
+ * modules plus one third-party operator (torch_sparse.matmul); each entry point below names the
+ * reference interface it replaces (paths relative to the CDboyOne/IHGNN checkout).
+ *
+ * Conventions for every device entry point:
+ *   - plain pointers and sizes only; all device buffers are caller-owned, row-major fp32 / int32;
+ *   - `ld_*` is the row stride in ELEMENTS (lets a layer read/write a column slice of the [N, D] feature
+ *     matrix in place);
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call returns at once:
+ *     no allocation, no synchronisation, no host<->device copies (graph-capturable);
+ *   - return value: 0 on success, negative IHG_ERR_* otherwise; ihg_last_error_string() describes the
+ *     last failure on the calling thread.
+ *   - Rows whose base address and stride are 16-byte aligned with dim % 4 == 0 take the 16-B/lane path;
+ *     anything else is still computed (4-B/lane path), never rejected.
+ */
+#ifndef IHGNN_HIP_H
+#define IHGNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IHG_OK                0
+#define IHG_ERR_INVALID      -1   /* bad argument (null pointer, negative size, unsupported order, ...) */
+#define IHG_ERR_LAUNCH       -2   /* HIP runtime reported an error at launch */
+#define IHG_ERR_WORKSPACE    -3   /* caller-provided workspace too small */
+
+#define IHG_SCALE_NONE        0
+#define IHG_SCALE_MULTIPLY    1   /* out[r] = scale[r] * sum   (Dv^-1, Dv^-1/2) */
+#define IHG_SCALE_DIVIDE      2   /* out[r] = sum / scale[r]   (EmbeddingBag 'mean': scale = bag length) */
+
+typedef void* ihg_stream_t;       /* hipStream_t */
+
+/* Version of this ABI; bumped on any signature change. */
+int32_t ihg_abi_version(void);
+
+/* Text of the last error raised on this thread ("" if none). */
+const char* ihg_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * HOST: hypergraph incidence layout.   Replaces PpsHyperGraph.from_interactions
+ * (Helpers/Graph.py:94-134) and torch_sparse's SparseTensor...coalesce() (Models/GnnLayers.py:190).
+ *
+ * triples[e] = (user, query, item), 0-based per type, in file order (one hyperedge per positive
+ * interaction; duplicates stay distinct).  Outputs, all host buffers sized by the caller:
+ *   i3       [E,3]  global node ids  u, q+U, i+U+Q                     (Graph.py:110-111,117,129)
+ *   rowptr   [N+1]  node-major CSR offsets; edge_ids [3E] hyperedge ids, ascending inside a node
+ *                   (= the coalesced COO order of Graph.py:123-128)
+ *   degree   [N]    incident hyperedges, 0 replaced by 1e-8             (Graph.py:112,120)
+ * Returns IHG_ERR_INVALID if a triple is out of range.
+ */
+int ihg_build_csr(const int64_t* triples, int64_t n_edges,
+                  int64_t n_users, int64_t n_queries, int64_t n_items,
+                  int32_t* i3, int32_t* rowptr, int32_t* edge_ids, float* degree);
+
+/* HOST: invert any CSR (row -> sorted list of column ids) into its transpose.  Used for the
+ * EmbeddingBag backward (word -> bags containing it).  Replaces the autograd-generated
+ * _embedding_bag_dense_backward of Models/EmbeddingLayers.py:79.
+ *   ptr [n_rows+1], ids [nnz]  ->  t_ptr [n_cols+1], t_rows [nnz] (ascending row inside a column)
+ */
+int ihg_transpose_csr(const int32_t* ptr, const int32_t* ids, int64_t n_rows, int64_t n_cols,
+                      int32_t* t_ptr, int32_t* t_rows);
+
+/* ------------------------------------------------------------------------------------------------
+ * DEVICE: node -> hyperedge gather-sum (K5, first-order / HGCN form).
+ *   out[e,:] = alpha * ( s(i3[e,0])*src[i3[e,0],:] + s(i3[e,1])*src[i3[e,1],:] + s(i3[e,2])*src[i3[e,2],:] ) + bias
+ * with s(v) = node_scale[v] (or 1 if node_scale == NULL) and bias optional [dim].
+ * Replaces: node_features[I3] gather + Linear of FeatureInteractor order 1 (Models/CommonLayers.py:60-66,
+ * after hoisting the Linear to node level), thsp.matmul(incidence_t, x) * De^-1 of HGCNLayer
+ * (Models/GnnLayers.py:148-149), and the autograd backward of thsp.matmul(incidence, .) (GnnLayers.py:233).
+ */
+int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3,
+                        const float* node_scale, const float* bias, float alpha,
+                        float* out, int64_t ld_out, int64_t n_edges, int32_t dim, ihg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DEVICE: hyperedge -> node segment-sum (K7 + K8).
+ *   out[r,:] = scale_op( sum_{k in [rowptr[r], rowptr[r+1])} w(ids[k]) * src[ids[k],:] , out_scale[r] )
+ * with w(j) = src_scale[j] (or 1).  Rows longer than `heavy_threshold` entries are SKIPPED here and must be
+ * finished by ihg_node_segment_sum_heavy (pass heavy_threshold <= 0 to process every row here).
+ * Replaces: thsp.matmul(self.incidence, edge_features) and Dv^-1 * / Dv^-1/2 * (Models/GnnLayers.py:151-152,
+ * 233-234), nn.EmbeddingBag(mode='mean') (Models/EmbeddingLayers.py:79, via ihg_bag_mean_fwd), and the
+ * index_put(accumulate) backward of the three row gathers (Models/CommonLayers.py:70-72).
+ */
+int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids,
+                         const float* src_scale, const float* out_scale, int32_t out_scale_mode,
+                         float* out, int64_t ld_out, int64_t n_rows, int32_t dim,
+                         int32_t heavy_threshold, ihg_stream_t stream);
+
+/* Split-row companion for skewed (power-law) degree distributions.  The host cuts every row longer than the
+ * threshold into segments [seg_begin, seg_end) of the `ids` array; each segment is summed by its own lane
+ * group into partials[s,:] (workspace, n_segments x dim floats), then each heavy row adds its partials in
+ * segment order (bitwise reproducible, no float atomics) and applies out_scale.
+ *   heavy_rows [n_heavy] row ids; heavy_segptr [n_heavy+1] offsets into the segment arrays.
+ */
+int ihg_node_segment_sum_heavy(const float* src, int64_t ld_src, const int32_t* ids,
+                               const float* src_scale, const float* out_scale, int32_t out_scale_mode,
+                               const int32_t* seg_begin, const int32_t* seg_end, int64_t n_segments,
+                               const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy,
+                               float* partials, float* out, int64_t ld_out, int32_t dim, ihg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DEVICE: query embedding bag, mode='mean' (K2).  Replaces nn.EmbeddingBag(mode='mean') forward/backward,
+ * Models/EmbeddingLayers.py:79,100-104.  `words` are row ids into `table` (already +1 shifted, Dataset.py:168).
+ *   fwd: out[q,:]  = ( sum_{k in bag q} table[words[k],:] ) / len(q)          (0 for an empty bag)
+ *   bwd: dtable[w,:] = sum_{entries k with words[k]==w} dout[bag(k),:] * inv_len[bag(k)]
+ *        given the transposed CSR (word_ptr [n_table_rows+1], word_bags [nnz]) from ihg_transpose_csr.
+ */
+int ihg_bag_mean_fwd(const float* table, int64_t ld_table, const int32_t* bag_ptr, const int32_t* words,
+                     const float* bag_len, float* out, int64_t ld_out, int64_t n_bags, int32_t dim,
+                     ihg_stream_t stream);
+int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr, const int32_t* word_bags,
+                     const float* inv_len, float* dtable, int64_t ld_dtable, int64_t n_table_rows, int32_t dim,
+                     ihg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DEVICE: interactive (order 2 / 3) node -> hyperedge step (K5 + K6 fused).
+ * Replaces FeatureInteractor.forward orders 2 and 3 (Models/CommonLayers.py:70-85): the [E, k*d]
+ * concatenation is never materialised.
+ *
+ *   fwd: out[e,:] = p[u,:] + p[q,:] + p[i,:]
+ *                 + W_uq (h[u]*h[q]) + W_qi (h[q]*h[i]) + W_iu (h[i]*h[u]) [+ W_uqi (h[u]*h[q]*h[i])]
+ *        (u,q,i) = i3[e,:];  w is the reference's aggregation.weight, row-major [dim, k*dim] with
+ *        k = 6 (order 2) or 7 (order 3); only its product blocks (columns >= 3*dim) are read here.  The
+ *        first-order blocks and the bias are hoisted to node level by the caller:
+ *        p[v,:] = W_type(v) h[v,:] (+ bias on user rows), N*d*d flops instead of E*3*d*d.
+ *   bwd: given dout [E, dim]:
+ *        g[e,s,:]  (s = 0,1,2 for u,q,i; [E,3,dim] contiguous) = d loss / d h[member s of e] through the
+ *                   product terms only; the caller finishes with ihg_node_segment_sum per node type.
+ *        dw[:, 3*dim:]  = gradient of the product blocks of w (first-order columns are left untouched).
+ *        `workspace` must hold ihg_interact_bwd_workspace_bytes(...) bytes (per-workgroup partial dW slabs,
+ *        reduced in a fixed order - bitwise reproducible).
+ */
+int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3,
+                     const float* w, int64_t ld_w, int32_t order,
+                     float* out, int64_t ld_out, int64_t n_edges, int32_t dim, ihg_stream_t stream);
+
+int64_t ihg_interact_bwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order);
+
+int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3,
+                     const float* w, int64_t ld_w, int32_t order,
+                     const float* dout, int64_t ld_dout,
+                     float* g, float* dw, int64_t ld_dw,
+                     void* workspace, int64_t workspace_bytes,
+                     int64_t n_edges, int32_t dim, ihg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IHGNN_HIP_H */

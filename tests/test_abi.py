@@ -1,0 +1,70 @@
+"""The C-ABI shared library: loads, exports exactly what include/ihgnn_hip.h declares, rejects bad arguments with
+an error string, and the product refuses to run without it or on CPU tensors.  No GPU kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import REPO
+from ihgnn_amd import _lib
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, 'include', 'ihgnn_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ihg_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), f'{name} declared in include/ihgnn_hip.h but not exported'
+    assert _lib.load().ihg_abi_version() == _lib.ABI_VERSION
+
+
+def test_bad_arguments_return_codes_and_messages():
+    lib = _lib.load()
+    assert lib.ihg_edge_gather_sum(None, 4, None, None, None, 1.0, None, 4, 5, 4, None) == _lib.ERR_INVALID
+    assert 'null pointer' in _lib.last_error()
+    assert lib.ihg_edge_gather_sum(None, 2, None, None, None, 1.0, None, 4, 5, 4, None) == _lib.ERR_INVALID   # ld < dim
+    assert lib.ihg_node_segment_sum(None, 4, None, None, None, None, 7, None, 4, 3, 4, 0, None) == _lib.ERR_INVALID
+    assert 'out_scale_mode' in _lib.last_error()
+    assert lib.ihg_interact_fwd(None, 4, None, 4, None, None, 28, 1, None, 4, 3, 4, None) == _lib.ERR_INVALID
+    assert 'order' in _lib.last_error()
+    assert lib.ihg_interact_fwd(None, 4, None, 4, None, None, 8, 3, None, 4, 3, 4, None) == _lib.ERR_INVALID   # ld_w < 7*dim
+    # empty problems are fine and launch nothing
+    assert lib.ihg_edge_gather_sum(None, 4, None, None, None, 1.0, None, 4, 0, 4, None) == _lib.OK
+    assert lib.ihg_node_segment_sum(None, 4, None, None, None, None, 0, None, 4, 0, 4, 0, None) == _lib.OK
+    with pytest.raises(_lib.IhgnnHipError, match='status -1'):
+        _lib.check(_lib.ERR_INVALID, 'probe')
+
+
+def test_missing_library_is_a_hard_error(monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libihgnn_hip.so')
+    with pytest.raises(_lib.IhgnnHipError, match='no CPU or PyTorch fallback'):
+        _lib.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    from ihgnn_amd import ops
+    from ihgnn_amd.layout import IncidenceLayout
+    import numpy as np
+    lay = IncidenceLayout(np.array([[0, 0, 0], [1, 0, 1]]), 2, 1, 2, torch.device('cpu'))
+    with pytest.raises(_lib.IhgnnHipError, match='no CPU path'):
+        ops.edge_gather_sum(torch.zeros(5, 4), lay)
+    with pytest.raises(_lib.IhgnnHipError, match='no CPU path'):
+        ops.node_segment_sum(torch.zeros(2, 4), lay)
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, 'ihgnn_amd')):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.cpp', '.h')):
+                assert 'oracle' not in open(os.path.join(root, fn)).read(), f'{fn} mentions the oracle'

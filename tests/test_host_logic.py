@@ -1,0 +1,211 @@
+"""CPU tests of the host side: file parsing, graph layout (native ihg_build_csr), samplers, metrics, schedule,
+CLI - against the reference-generated fixtures.  No GPU compute is called anywhere in this file."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from ihgnn_amd import synth
+from ihgnn_amd.Dataset import GraphDataset, TestSearchLogDataLoader
+from ihgnn_amd.Helpers.ArgsParser import parse_args
+from ihgnn_amd.Helpers.Graph import PpsHyperGraph
+from ihgnn_amd.Helpers.Metrics import Metrics, MetricsCollection
+from ihgnn_amd.Helpers.ProcessController import ProcessController
+from ihgnn_amd.Helpers.SearchLog import PosInteraction, SearchLog
+from ihgnn_amd.layout import Csr, IncidenceLayout
+
+CPU = torch.device('cpu')
+F1 = os.path.join(GOLDEN, 'f1_data')
+
+
+@pytest.fixture(scope='module')
+def f1():
+    z = np.load(os.path.join(GOLDEN, 'f1_graph.npz'))
+    ds = GraphDataset(os.path.join(F1, 'graph_info.txt'), os.path.join(F1, 'queries_multihot.txt'),
+                      os.path.join(F1, 'train_data.csv'), PpsHyperGraph, 10, 0, CPU)
+    return z, ds
+
+
+def test_dataset_parses_reference_files(f1):
+    z, ds = f1
+    assert [ds.user_count, ds.query_count, ds.item_count, ds.vocab_size, ds.node_count] == z['counts'].tolist()
+    assert ds.query_start_index_in_graph == 5 and ds.item_start_index_in_graph == 9
+    np.testing.assert_array_equal(ds.queries_for_embeddingbag.numpy(), z['bag_input'])
+    np.testing.assert_array_equal(ds.queries_offset_for_embeddingbag.numpy(), z['bag_offsets'])
+    np.testing.assert_array_equal(np.array([p.uqif() for p in ds.pos_interactions]), z['pos_uqif'])
+    np.testing.assert_array_equal(np.array(ds.neg_interactions), z['neg_uqi'])
+    np.testing.assert_array_equal(ds.users_onehot.numpy(), np.arange(1, 6))
+    assert len(ds) == len(z['pos_uqif'])
+
+
+def test_hypergraph_matches_reference(f1):
+    z, ds = f1
+    g = ds.hypergraph
+    assert g is ds.graph and g.EdgeCount == int(z['EdgeCount'])
+    np.testing.assert_array_equal(g.I3.numpy(), z['I3'])
+    np.testing.assert_array_equal(g.Adjacency.indices().numpy(), z['coo_indices'])
+    np.testing.assert_array_equal(g.Adjacency.values().numpy(), z['coo_values'])
+    np.testing.assert_array_equal(g.VertexDegrees.numpy(), z['VertexDegrees'])
+    np.testing.assert_array_equal(g.EdgeDegrees.numpy(), z['EdgeDegrees'])
+    lay = g.layout
+    # kernel-side scale factors: bit-identical to the reference's pow() where a node has edges, 0 where it has none
+    deg = torch.from_numpy(z['VertexDegrees'][:, 0])
+    alive = deg > 0.5
+    assert torch.equal(lay.inv_deg[alive], deg.pow(-1)[alive]) and torch.equal(lay.inv_sqrt_deg[alive], deg.pow(-0.5)[alive])
+    assert (lay.inv_deg[~alive] == 0).all() and (~alive).sum() == 2
+
+
+def test_csr_is_node_major_sorted_and_complete():
+    w = synth.draw(50, 20, 70, 30, 2000, seed=3, distribution='powerlaw')
+    lay = IncidenceLayout(w.triples, 50, 20, 70, CPU, heavy_threshold=64)
+    ptr, ids = lay.node_csr.ptr_host, lay.node_csr.ids_host
+    i3 = lay.i3_host
+    assert ptr[0] == 0 and ptr[-1] == 3 * 2000 and (np.diff(ptr) >= 0).all()
+    for v in range(140):
+        mine = ids[ptr[v]:ptr[v + 1]]
+        assert (np.diff(mine) > 0).all()                        # ascending hyperedge ids, no duplicates
+        assert all(v in i3[e] for e in mine)
+    assert np.array_equal(np.bincount(i3.reshape(-1), minlength=140), np.diff(ptr))
+    # split-row plan covers exactly the heavy rows, segment by segment
+    csr = lay.node_csr
+    assert csr.n_heavy == int((np.diff(ptr) > 64).sum()) > 0
+    segptr = csr.heavy_segptr.numpy()
+    for h, row in enumerate(csr.heavy_rows.numpy()):
+        b, e = csr.seg_begin.numpy()[segptr[h]:segptr[h + 1]], csr.seg_end.numpy()[segptr[h]:segptr[h + 1]]
+        assert b[0] == ptr[row] and e[-1] == ptr[row + 1] and (b[1:] == e[:-1]).all() and ((e - b) <= 512).all()
+
+
+def test_build_csr_rejects_bad_ids():
+    from ihgnn_amd._lib import IhgnnHipError
+    with pytest.raises(IhgnnHipError, match='out of range'):
+        IncidenceLayout(np.array([[0, 0, 9]]), 2, 2, 3, CPU)
+
+
+def test_transpose_csr():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 6, 40)
+    ptr = np.zeros(41, np.int32); ptr[1:] = np.cumsum(lens)
+    ids = rng.integers(0, 17, ptr[-1]).astype(np.int32)
+    t = Csr(ptr, ids, CPU).transpose(17)
+    dense = np.zeros((40, 17), np.int64)
+    for r in range(40):
+        for c in ids[ptr[r]:ptr[r + 1]]:
+            dense[r, c] += 1
+    for c in range(17):
+        rows = t.ids_host[t.ptr_host[c]:t.ptr_host[c + 1]]
+        assert (np.diff(rows) >= 0).all()
+        assert np.array_equal(np.bincount(rows, minlength=40), dense[:, c])
+
+
+def test_eval_loader_matches_reference(f1):
+    z, ds = f1
+    for key, fn in (('valid', 'valid_data.csv'), ('test', 'test_data.csv')):
+        loader = TestSearchLogDataLoader(os.path.join(F1, fn), ds, CPU)
+        assert np.array_equal(np.array([(l[0], l[1]) for l in loader.logs]), z[f'{key}_uq'])
+        assert sum([l[2] for l in loader.logs], []) == z[f'{key}_items_flat'].tolist()
+        for (users, queries, items, flags, all1), (u, q) in zip(loader, z[f'{key}_uq']):
+            assert users.shape == (ds.item_count,) and (users == u).all() and (queries == q).all()
+            assert flags is None and all1 is True
+
+
+def test_getitem_and_collate_follow_reference_contract(f1):
+    _, ds = f1
+    ds10 = GraphDataset.from_arrays(5, 4, 60, 7, ds.bag_words_host - 1, ds.bag_offsets_host, ds.pos_triples, device=CPU)
+    random.seed(5)
+    (u, q, i, flag), negs = ds10[2]
+    random.seed(5)
+    assert negs == random.sample(range(60), 10) and len(set(negs)) == 10 and flag == 1
+    assert (u, q, i) == tuple(ds.pos_triples[2])
+    ds6 = GraphDataset.from_arrays(5, 4, 60, 7, ds.bag_words_host - 1, ds.bag_offsets_host, ds.pos_triples,
+                                   random_negative_sample_size=3, device=CPU)
+    batch = [ds6[k] for k in (0, 3, 5)]
+    out = GraphDataset.collate_fn(batch)
+    assert len(out) == 8 and all(t.dtype == torch.int64 for t in out)
+    pu, pq, pi, pf, nu, nq, ni, nf = out
+    assert pu.tolist() == [b[0][0] for b in batch] and pf.tolist() == [1, 1, 1]
+    assert nu.tolist() == sum([[b[0][0]] * 3 for b in batch], []) and nq.tolist() == sum([[b[0][1]] * 3 for b in batch], [])
+    assert ni.tolist() == sum([b[1] for b in batch], []) and nf.tolist() == [0] * 9
+
+
+def test_logged_negative_sampling(f1):
+    _, ds = f1
+    ds2 = GraphDataset(os.path.join(F1, 'graph_info.txt'), os.path.join(F1, 'queries_multihot.txt'),
+                       os.path.join(F1, 'train_data.csv'), PpsHyperGraph, 2, 1, CPU)
+    assert ds2.neg_items_for_user_query_pair[(0, 0)] == [1] and ds2.neg_items_for_user_query_pair[(0, 1)] == [4]
+    (_, _, _, _), negs = ds2[0]                # (0,0) has one logged negative -> it is taken, then 2 random
+    assert negs[0] == 1 and len(negs) == 3
+    (_, _, _, _), negs = ds2[1]                # (1,0) has none -> 3 random
+    assert len(negs) == 3
+
+
+def test_search_log_roundtrip_and_relevance_policy():
+    row = '17,3,1400000000,42 7 42,1 1 1,1 2 3,2 0 1,1400000000 NA 1400000001'
+    log = SearchLog.parse(row)
+    assert (log.user, log.query, log.items, log.interactions) == (17, 3, [42, 7, 42], [2, 0, 1])
+    assert log.tostr() == row
+    assert log.get_interacted_items() == ([42], [1], True)
+    assert log.get_interacted_items('max') == ([42], [2], False)
+    pos = PosInteraction.from_search_log(log, treat_all_1=True)
+    assert [p.uqif() for p in pos] == [(17, 3, 42, 1), (17, 3, 42, 1)]
+    assert [p.uqif() for p in PosInteraction.from_search_log(log, False)] == [(17, 3, 42, 2), (17, 3, 42, 1)]
+    with pytest.raises(ValueError):
+        SearchLog.parse('1,2,3')
+
+
+def test_metrics_known_answers():
+    rec = json.load(open(os.path.join(GOLDEN, 'f4_metrics.json')))
+    sc = rec['selfcheck']
+    m = Metrics.calculate_on_all_items(torch.tensor(sc['scores']), sc['truth'], [1, 1, 2], True)
+    assert m.to_string(no_title=True) == '1.0000 0.6653 0.5000'         # Helpers/Metrics.py __main__ self-check
+    assert abs(Metrics._get_idcg_for_all1(3) - sc['idcg3']) < 1e-15 and abs(Metrics._get_idcg([2, 1, 1]) - sc['idcg_211']) < 1e-15
+    for c in rec['random_cases']:
+        m = Metrics.calculate_on_all_items(torch.tensor(c['scores']), c['truth'], None, True)
+        assert (abs(m.HitRatio_at10 - c['hr']), abs(m.NDCG_at10 - c['ndcg']), abs(m.MAP_at10 - c['map'])) < (1e-12,) * 3
+    c = rec['graded']
+    m = Metrics.calculate_on_all_items(torch.tensor(c['scores']), c['truth'], c['flags'], False)
+    assert (abs(m.HitRatio_at10 - c['hr']), abs(m.NDCG_at10 - c['ndcg']), abs(m.MAP_at10 - c['map'])) < (1e-12,) * 3
+    m1 = Metrics.calculate_on_all_items(torch.tensor(sc['scores']), sc['truth'], None, True)
+    col = MetricsCollection(True)
+    col.add(10, m1, m1), col.add(20, m1.divide_and_get_new(0.5), m1.divide_and_get_new(0.5)), col.add(30, m1.divide_and_get_new(2), m1.divide_and_get_new(2))
+    assert col.get_valid_best(key=lambda x: x.NDCG_at10)[0] == rec['best_valid_epoch'] == 20
+    with pytest.raises(ValueError):
+        col.add(40, m1)
+
+
+@pytest.mark.parametrize('key,args', [('schedule_20_5_7_2', (20, 5, 7, 2)), ('schedule_12_1_3_3_store', (12, 1, 3, 3, 12, 1000000))])
+def test_process_controller_schedule(key, args):
+    rec = json.load(open(os.path.join(GOLDEN, 'f4_metrics.json')))
+    pc = ProcessController(*args)
+    got = [dict(epoch=e, test=pc.ShouldTest(), store=pc.ShouldStore()) for e in pc]
+    assert got == rec[key] and len(pc) == args[0]
+
+
+def test_cli_flags_and_aliases():
+    a = parse_args(['--ds', 'Amazon/X/', '--gnn', 'hgcn', '--gnns', '3', '--fo', '2', '--emb', '64', '-c', '-m', '--ec', '7',
+                    '--est', '2', '--etf', '1', '-d', '1', '--cp', 'latest'])
+    assert (a.dataset, a.gnn, a.gnns, a.feature_order, a.embedding_size) == ('Amazon/X/', 'hgcn', 3, 2, 64)
+    assert a.storecheckpoint and a.storemetrics and (a.epoch_count, a.epoch_start_test, a.epoch_test_frequency) == (7, 2, 1)
+    assert a.device == '1' and a.checkpoint == 'latest'
+    d = parse_args([])
+    assert (d.epoch_count, d.gnns, d.feature_order, d.embedding_size, d.completeness, d.checkpoint) == (0, 0, 0, 0, 'uqi', '')
+    from ihgnn_amd.Models import parse_gnn_layer, IHGNNLayer, HGCNLayer
+    assert parse_gnn_layer['IHGNN'] is parse_gnn_layer['ihgnn'] is parse_gnn_layer['IHGNNLayer'] is IHGNNLayer
+    assert parse_gnn_layer['hgcn'] is HGCNLayer and parse_gnn_layer[''] is None
+
+
+def test_synthetic_workload_is_deterministic_and_file_roundtrips(tmp_path):
+    a, b = synth.draw_config('C1'), synth.draw_config('C1')
+    assert np.array_equal(a.triples, b.triples) and a.edge_count == 20000 and a.node_count == 2500
+    w = synth.draw(12, 6, 15, 9, 80, seed=1, eval_logs=5)
+    paths = synth.write_files(w, str(tmp_path))
+    ds = GraphDataset(paths['fn_graph_info'], paths['fn_queries_multihot'], paths['fn_train_data'], PpsHyperGraph, 10, 0, CPU)
+    assert np.array_equal(ds.pos_triples, w.triples) and np.array_equal(ds.bag_words_host - 1, w.bag_words)
+    mem = GraphDataset.from_arrays(12, 6, 15, 9, w.bag_words, w.bag_offsets, w.triples, device=CPU)
+    assert np.array_equal(mem.hypergraph.layout.i3_host, ds.hypergraph.layout.i3_host)
+    p = synth.draw(1000, 100, 1000, 50, 20000, seed=2, distribution='powerlaw', exponent=1.2)
+    deg = np.bincount(p.triples[:, 0], minlength=1000)
+    assert deg.max() > 20 * np.median(deg[deg > 0])              # genuinely skewed
