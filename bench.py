@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the hypergraph message-passing hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2] [--no-cpu-baseline]
+
+Metric (BASELINE.json / SURVEY.md §8 d1): hyperedges aggregated per second = E * L * steps / wall time, where one
+"hyperedge aggregated" is one hyperedge taken through one layer's node->hyperedge and hyperedge->node phases.
+A step is one FULL training step of RawGnn (full-graph propagation forward, BCE loss on a 1100-row batch, backward,
+gradient all-reduce when N > 1, Adam) - nothing is skipped inside the timed region.  Inputs (graph layout, weights,
+pre-drawn batches) are resident in HBM before the clock starts.  With N > 1 every rank holds a full replica and its
+own batches (weak scaling) and the value is the aggregate over ranks.
+
+One JSON line is printed by rank 0, carrying `roofline` (node->hyperedge gather-sum kernel K5 against the HBM
+roofline, timed with HIP events on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle =
+the reference's PyTorch-CPU op sequence, timed on this box's host cores on a bounded sub-sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy bandwidth is ~6290
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='C2', help='synth.CONFIGS key (C1 | C2 | C3 | C5)')
+    ap.add_argument('--order', type=int, default=3)
+    ap.add_argument('--layer', default='ihgnn', choices=['ihgnn', 'hgcn'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-scale', type=float, default=0.125, help='fraction of the workload the CPU baseline runs on')
+    ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket kernels with HIP events')
+    return ap.parse_args()
+
+
+def build_model(ds, dev, layer, layers, order, dim):
+    from ihgnn_amd.Models import HGCNLayer, HemPredictionLayer, IHGNNLayer, RawGnn
+    torch.manual_seed(0)
+    layer_t = IHGNNLayer if layer == 'ihgnn' else HGCNLayer
+    return RawGnn(dev, ds, dim, layer_t, layers, order, False, HemPredictionLayer, 0.5).to(dev)
+
+
+def cpu_baseline(config, layer, layers, order, dim, scale):
+    """Time the oracle's full training step on the host cores, on a `scale` sub-sample of the workload."""
+    from ihgnn_amd import synth
+    from oracle import ihgnn_ref as ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    w = synth.draw_config(config, scale=scale)
+    g = ref.HyperGraph(w.triples, w.user_count, w.query_count, w.item_count)
+    torch.manual_seed(0)
+    m = ref.OracleRawGnn(g, torch.from_numpy(w.bag_words + 1), torch.from_numpy(w.bag_offsets), w.vocab_size, dim, layer, layers, order)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.1, 0.1)
+    opt = torch.optim.Adam(m.parameters(), 1e-3)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    rng = np.random.default_rng(1)
+
+    def step():
+        u = torch.from_numpy(rng.integers(0, w.user_count, 1100)); q = torch.from_numpy(rng.integers(0, w.query_count, 1100))
+        i = torch.from_numpy(rng.integers(0, w.item_count, 1100))
+        y = torch.cat([torch.ones(100), torch.zeros(1000)])
+        loss = lossf(m(u, q, i), y)
+        loss.backward(); opt.step(); opt.zero_grad()
+
+    step()                                   # warm-up (allocator, thread pool)
+    t0 = time.perf_counter(); n = 0
+    while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 20):
+        step(); n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=w.edge_count * layers * n / dt, unit='hyperedges/s', cores=cores, kind='port',
+                sample=f'{n} full training steps of the PyTorch-CPU oracle (reference op sequence) on a {scale:g}x sub-sample of '
+                       f'{config} (E={w.edge_count}, N={w.node_count}), {cores} threads, torch {torch.__version__}',
+                ms_per_step=1e3 * dt / n)
+
+
+def main():
+    args = parse()
+    from ihgnn_amd import distributed as ihg_dist, profiler, synth
+    from ihgnn_amd.Dataset import GraphDataset
+
+    rank, local_rank, world = ihg_dist.init_from_env('nccl' if args.gpus > 1 else None)
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    dev = torch.device(f'cuda:{local_rank}')
+    torch.cuda.set_device(dev)
+
+    cfg = synth.CONFIGS[args.config]
+    dim, layers = cfg['dim'], cfg['layers']
+    w = synth.draw_config(args.config)
+    ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets,
+                                  w.triples, device=dev)
+    model = build_model(ds, dev, args.layer, layers, args.order, dim)
+    _ = ds.hypergraph.layout
+    opt = torch.optim.Adam(model.parameters(), 1e-3, weight_decay=0)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    sync = ihg_dist.GradientSync(model.parameters()) if world > 1 else None
+    if sync is not None:
+        sync.broadcast_parameters(0)
+    batches = list(ds.sample_batches(100, args.steps + args.warmup, seed=1000 + rank))
+
+    def step(k):
+        u, q, i, y = batches[k]
+        loss = lossf(model(u, q, i), y)
+        loss.backward()
+        if sync is not None:
+            sync.average_gradients()
+        opt.step()
+        if sync is not None:
+            sync.zero_grad()
+        else:
+            opt.zero_grad()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    if not args.no_kernel_events:
+        profiler.start()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        last = step(k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    profiler.stop()
+    kernels = profiler.summary() if not args.no_kernel_events else {}
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # forward-only propagation (the save_features_for_test path), reported beside the headline
+    with torch.no_grad():
+        model.propagate(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(args.steps, 5)):
+            model.propagate()
+        torch.cuda.synchronize()
+        fwd_elapsed = (time.perf_counter() - t1) / max(args.steps, 5)
+
+    if rank != 0:
+        return
+    E, N = w.edge_count, w.node_count
+    value = world * E * layers * args.steps / elapsed
+    k5_bytes = E * (16 * dim + 12)                       # 3 ids + 3 row reads + 1 row write per hyperedge
+    roofline = None
+    if 'edge_gather_sum' in kernels:
+        k5 = kernels['edge_gather_sum']
+        achieved = k5_bytes / (k5['avg_us'] * 1e-6) / 1e9
+        roofline = dict(bound='hbm', kernel='edge_gather_sum (K5 node->hyperedge gather-sum)', achieved=round(achieved, 1),
+                        peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        bytes_per_launch=k5_bytes, avg_us=round(k5['avg_us'], 2), launches=k5['launches'],
+                        hyperedges_per_s=round(E / (k5['avg_us'] * 1e-6), 1))
+    out = {
+        'metric': 'hyperedges_aggregated_per_sec', 'value': round(value, 1), 'unit': 'hyperedges/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{args.config}: size-matched synthetic stand-in for BASELINE configs[1] (Amazon-Electronics subset; the '
+                               f'corpus is not in the image), U={w.user_count} Q={w.query_count} I={w.item_count} E={E}, power-law members, '
+                               f'dim={dim}, {layers}x{args.layer} layers, interaction order {args.order}, batch 100 pos + 1000 neg',
+                   'step': 'full training step: propagate fwd + BCE + bwd + Adam' + (' + RCCL grad all-reduce' if world > 1 else ''),
+                   'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}'},
+        'fwd_only_hyperedges_per_s': round(E * layers / fwd_elapsed, 1), 'fwd_only_ms': round(1e3 * fwd_elapsed, 4),
+        'final_loss': round(float(last.item()), 6),
+        'roofline': roofline,
+        'kernels_us': {name: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] / args.steps} for name, v in kernels.items()},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args.config, args.layer, layers, args.order, dim, args.cpu_scale)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

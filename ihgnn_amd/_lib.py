@@ -10,6 +10,12 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_void_p
 from typing import Optional
 
+# torch ships its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must be in the process
+# BEFORE libihgnn_hip.so is opened, so that the library's DT_NEEDED entry resolves to that same runtime: kernels are
+# then enqueued on torch's streams, against torch's allocations, by one runtime.  Two runtimes in one process see
+# "no ROCm-capable device".
+import torch  # noqa: F401  (side effect: loads the HIP runtime)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 

@@ -326,7 +326,7 @@ def test_full_size_properties_c2_shape():
     y = torch.randn(lay.edge_count, d, device=dev())
     ky = ops.node_segment_sum_raw(y, lay.node_csr)
     lhs, rhs = (a.double() * y.double()).sum(), (x1.double() * ky.double()).sum()
-    assert abs(lhs - rhs) / abs(lhs) <= 1e-6
+    assert abs(lhs - rhs) / abs(lhs) <= 1e-5       # both sides carry fp32 round-off of ~4e5 x 64 products
     ones = torch.ones(lay.edge_count, 4, device=dev())
     deg = ops.node_segment_sum_raw(ones, lay.node_csr)[:, 0]
     assert torch.equal(deg, torch.where(lay.degree < 0.5, torch.zeros_like(lay.degree), lay.degree))
