@@ -10,6 +10,7 @@
 //   flight together.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -366,6 +367,318 @@ __global__ __launch_bounds__(kBlockThreads) void interact_bwd_weight_generic_ker
     }
 }
 
+
+// ================================================================================================
+// Interactive step on the matrix cores (exact fp32: v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain).
+//
+//   fwd      C[e][j]        = sum_b sum_c z_b[e][c] * W[j][(3+b)d + c]          (+ hoisted first-order rows)
+//   members  dz_b[e][c]     = sum_j dout[e][j] * W[j][(3+b)d + c]    -> g[e, slot, c] by the product rule
+//   weights  dW[j][(3+b)d+c]= sum_e dout[e][j] * z_b[e][c]
+//
+// A 32x32x2 MFMA takes ONE float per lane per operand: lane l gives A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
+// The contraction index may be visited in any order as long as A and B agree, so in fwd / members lane-half h of
+// MFMA step s (s = 0..3) is given k = 8t + 4h + s: each lane then needs 4 CONSECUTIVE k per operand, i.e. one
+// ds_read_b128 (A side, gathered rows staged in LDS with a 16-B row pad -> conflict-free) and one 16-B global load
+// (B side) per 4 MFMAs.  The weights are re-packed once per call into that fragment order (pack_weights_kernel,
+// <= 1 MB) so that every B load of a wave is one contiguous, fully coalesced 1 KiB from L2.
+// z_b is never stored: it is formed in registers from the three staged member rows right before the MFMAs.
+// ================================================================================================
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kRowPad = 4;       // floats; breaks the power-of-two row stride for ds_read_b128
+
+// wp_fwd[jt][b][t][lane][4] = W[32jt + (lane&31)][(3+b)d + 8t + 4(lane>>5) + s]        (k runs along c)
+// wp_bwd[ct][b][t][lane][4] = W[8t + 4(lane>>5) + s][(3+b)d + 32ct + (lane&31)]        (k runs along j)
+__global__ __launch_bounds__(kBlockThreads) void pack_weights_kernel(const float* __restrict__ w, int64_t ld_w, int d, int nblk,
+                                                                     float* __restrict__ wp_fwd, float* __restrict__ wp_bwd) {
+    const int t_count = d / 8;
+    const int total = (d / 32) * nblk * t_count * kWave;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & (kWave - 1);
+        const int t = (idx >> 6) % t_count;
+        const int b = ((idx >> 6) / t_count) % nblk;
+        const int xt = (idx >> 6) / (t_count * nblk);
+        const int r = lane & 31, half = lane >> 5;
+        if (wp_fwd != nullptr) {
+            const float* src = w + static_cast<int64_t>(32 * xt + r) * ld_w + static_cast<int64_t>(3 + b) * d + 8 * t + 4 * half;
+            *reinterpret_cast<float4*>(wp_fwd + static_cast<int64_t>(idx) * 4) = make_float4(src[0], src[1], src[2], src[3]);
+        }
+        if (wp_bwd != nullptr) {
+            const float* src = w + static_cast<int64_t>(8 * t + 4 * half) * ld_w + static_cast<int64_t>(3 + b) * d + 32 * xt + r;
+            *reinterpret_cast<float4*>(wp_bwd + static_cast<int64_t>(idx) * 4) = make_float4(src[0], src[ld_w], src[2 * ld_w], src[3 * ld_w]);
+        }
+    }
+}
+
+template <int D> struct TileShape {
+    static constexpr int KC = D < 64 ? D : 64;             // staged column chunk of the member rows
+    static constexpr int ET = D == 32 ? 4 : 2;             // 32-edge tiles per workgroup tile
+    static constexpr int TE = ET * 32;
+    static constexpr int NJ = D == 32 ? 1 : D / 64;        // 32-wide output column tiles per wave
+    static constexpr int STRIDE = KC + kRowPad;
+};
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+template <int D, int NBLK>
+__global__ __launch_bounds__(kBlockThreads) void interact_fwd_mfma_kernel(
+    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
+    const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
+    using S = TileShape<D>;
+    __shared__ __attribute__((aligned(16))) float tile[3][S::TE][S::STRIDE];
+    __shared__ int ids[S::TE][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int et = D == 32 ? wave : (wave & 1);
+    const int jt0 = D == 32 ? 0 : (wave >> 1);
+    const int row = et * 32 + (lane & 31), half = lane >> 5;
+    const int64_t n_tiles = (n_edges + S::TE - 1) / S::TE;
+    const v4f* wp4 = reinterpret_cast<const v4f*>(wp);
+
+    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+        const int64_t e_base = tile_id * S::TE;
+        __syncthreads();                                      // previous tile's epilogue is done with ids[]
+        for (int k = tid; k < S::TE * 3; k += kBlockThreads) {
+            const int64_t pos = e_base * 3 + k;
+            (&ids[0][0])[k] = pos < n_edges * 3 ? i3[pos] : 0;
+        }
+        v16f acc[S::NJ];
+#pragma unroll
+        for (int x = 0; x < S::NJ; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+        for (int kc = 0; kc < D / S::KC; ++kc) {
+            __syncthreads();                                  // ids visible; previous chunk's reads finished
+            constexpr int V4_PER_ROW = S::KC / 4;
+            constexpr int LOADS = 3 * S::TE * V4_PER_ROW / kBlockThreads;
+            float4 stage[LOADS];
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4_PER_ROW, r = (idx / V4_PER_ROW) % S::TE, m = idx / (V4_PER_ROW * S::TE);
+                stage[x] = *reinterpret_cast<const float4*>(h + static_cast<int64_t>(ids[r][m]) * ld_h + kc * S::KC + c4 * 4);
+            }
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4_PER_ROW, r = (idx / V4_PER_ROW) % S::TE, m = idx / (V4_PER_ROW * S::TE);
+                *reinterpret_cast<float4*>(&tile[m][r][c4 * 4]) = stage[x];
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int t = 0; t < S::KC / 8; ++t) {
+                const int col = 8 * t + 4 * half;
+                const v4f au = *reinterpret_cast<const v4f*>(&tile[0][row][col]);
+                const v4f aq = *reinterpret_cast<const v4f*>(&tile[1][row][col]);
+                const v4f ai = *reinterpret_cast<const v4f*>(&tile[2][row][col]);
+                v4f z[4];
+                z[0] = au * aq;
+                z[1] = aq * ai;
+                z[2] = ai * au;
+                z[3] = z[0] * ai;
+                const int tg = kc * (S::KC / 8) + t;
+#pragma unroll
+                for (int x = 0; x < S::NJ; ++x) {
+                    const int jt = jt0 + 2 * x;
+                    v4f bf[NBLK];
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) bf[b] = wp4[(static_cast<int64_t>(jt * NBLK + b) * (D / 8) + tg) * kWave + lane];
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[b][s], bf[b][s], acc[x], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: add the hoisted first-order rows and store
+#pragma unroll
+        for (int x = 0; x < S::NJ; ++x) {
+            const int j = (jt0 + 2 * x) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = et * 32 + acc_row(r, lane);
+                const int64_t e = e_base + er;
+                if (e < n_edges) {
+                    const float first = (p[static_cast<int64_t>(ids[er][0]) * ld_p + j] + p[static_cast<int64_t>(ids[er][1]) * ld_p + j]) +
+                                        p[static_cast<int64_t>(ids[er][2]) * ld_p + j];
+                    out[e * ld_out + j] = acc[x][r] + first;
+                }
+            }
+        }
+    }
+}
+
+// members: one workgroup tile = TE consecutive hyperedges; the dout rows are streamed (not gathered) into LDS at full
+// width, each wave then runs its (edge tile, column tile) jobs one after the other with NBLK accumulators.
+template <int D, int NBLK>
+__global__ __launch_bounds__(kBlockThreads) void interact_bwd_members_mfma_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g, int64_t n_edges) {
+    constexpr int ET = D == 32 ? 4 : 2, TE = ET * 32, STRIDE = D + kRowPad, JOBS = ET * (D / 32);
+    __shared__ __attribute__((aligned(16))) float dtile[TE][STRIDE];
+    __shared__ int ids[TE][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const v4f* wq4 = reinterpret_cast<const v4f*>(wq);
+
+    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+        const int64_t e_base = tile_id * TE;
+        __syncthreads();
+        for (int k = tid; k < TE * 3; k += kBlockThreads) {
+            const int64_t pos = e_base * 3 + k;
+            (&ids[0][0])[k] = pos < n_edges * 3 ? i3[pos] : 0;
+        }
+        constexpr int V4_PER_ROW = D / 4;
+        for (int idx = tid; idx < TE * V4_PER_ROW; idx += kBlockThreads) {
+            const int c4 = idx % V4_PER_ROW, r = idx / V4_PER_ROW;
+            const int64_t e = e_base + r;
+            const float4 v = e < n_edges ? *reinterpret_cast<const float4*>(dout + e * ld_dout + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&dtile[r][c4 * 4]) = v;
+        }
+        __syncthreads();
+        for (int job = wave; job < JOBS; job += kWavesPerBlock) {
+            const int et = job % ET, ct = job / ET;
+            const int row = et * 32 + (lane & 31);
+            v16f acc[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll 2
+            for (int t = 0; t < D / 8; ++t) {
+                const v4f a = *reinterpret_cast<const v4f*>(&dtile[row][8 * t + 4 * half]);
+                v4f bf[NBLK];
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) bf[b] = wq4[(static_cast<int64_t>(ct * NBLK + b) * (D / 8) + t) * kWave + lane];
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[b][s], acc[b], 0, 0, 0);
+            }
+            const int c = ct * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = et * 32 + acc_row(r, lane);
+                const int64_t e = e_base + er;
+                if (e < n_edges) {
+                    const float a = h[static_cast<int64_t>(ids[er][0]) * ld_h + c];
+                    const float b = h[static_cast<int64_t>(ids[er][1]) * ld_h + c];
+                    const float dd = h[static_cast<int64_t>(ids[er][2]) * ld_h + c];
+                    const float z_uq = acc[0][r], z_qi = acc[1][r], z_iu = acc[2][r];
+                    const float z_uqi = NBLK == 4 ? acc[NBLK - 1][r] : 0.f;
+                    float* ge = g + e * 3 * D + c;
+                    ge[0] = z_uq * b + z_iu * dd + z_uqi * (b * dd);
+                    ge[D] = z_uq * a + z_qi * dd + z_uqi * (a * dd);
+                    ge[2 * D] = z_qi * b + z_iu * a + z_uqi * (a * b);
+                }
+            }
+        }
+    }
+}
+
+// weights: workgroup (x, y) owns the SW x (NBLK*SW) sub-block y = (js, cs) of dW for the hyperedge tiles x, x + gridDim.x, ...
+// and keeps it in MFMA accumulators for the whole sweep (contraction index = hyperedge, 2 per MFMA); it ends by writing
+// its partial sub-block into slab x, and slab_reduce_kernel adds the slabs in index order (bitwise reproducible).
+template <int SW, int NBLK>
+__global__ __launch_bounds__(kBlockThreads) void interact_bwd_weight_mfma_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ dout, int64_t ld_dout,
+    float* __restrict__ slabs, int64_t n_edges, int d) {
+    constexpr int TE = 64;
+    constexpr int WT = SW / 32;                       // 32-wide tiles per side of the sub-block (2 for SW = 64, 1 for 32)
+    constexpr int TILES = WT * WT * NBLK;             // accumulator tiles of the sub-block
+    constexpr int PER_WAVE = (TILES + kWavesPerBlock - 1) / kWavesPerBlock;
+    __shared__ __attribute__((aligned(16))) float dtile[TE][SW];
+    __shared__ __attribute__((aligned(16))) float mtile[3][TE][SW];
+    __shared__ int ids[TE][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int subs = d / SW;
+    const int js = blockIdx.y / subs, cs = blockIdx.y % subs;
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    // wave -> (jt, ct) pair, all NBLK blocks (SW = 64: 4 pairs, one per wave); SW = 32: one pair, block b = wave
+    const int jt = WT == 2 ? (wave & 1) : 0, ct = WT == 2 ? (wave >> 1) : 0;
+    v16f acc[PER_WAVE];
+#pragma unroll
+    for (int x = 0; x < PER_WAVE; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+        const int64_t e_base = tile_id * TE;
+        __syncthreads();
+        for (int k = tid; k < TE * 3; k += kBlockThreads) {
+            const int64_t pos = e_base * 3 + k;
+            (&ids[0][0])[k] = pos < n_edges * 3 ? i3[pos] : 0;
+        }
+        __syncthreads();
+        constexpr int V4_PER_ROW = SW / 4;
+        for (int idx = tid; idx < TE * V4_PER_ROW; idx += kBlockThreads) {
+            const int c4 = idx % V4_PER_ROW, r = idx / V4_PER_ROW;
+            const int64_t e = e_base + r;
+            const float4 v = e < n_edges ? *reinterpret_cast<const float4*>(dout + e * ld_dout + js * SW + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&dtile[r][c4 * 4]) = v;
+        }
+        for (int idx = tid; idx < 3 * TE * V4_PER_ROW; idx += kBlockThreads) {
+            const int c4 = idx % V4_PER_ROW, r = (idx / V4_PER_ROW) % TE, m = idx / (V4_PER_ROW * TE);
+            *reinterpret_cast<float4*>(&mtile[m][r][c4 * 4]) =
+                *reinterpret_cast<const float4*>(h + static_cast<int64_t>(ids[r][m]) * ld_h + cs * SW + c4 * 4);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < TE / 2; ++kk) {
+            const int e = 2 * kk + half;
+            const float a = dtile[e][jt * 32 + l31];
+            const float hu = mtile[0][e][ct * 32 + l31], hq = mtile[1][e][ct * 32 + l31], hi = mtile[2][e][ct * 32 + l31];
+            float z[4];
+            z[0] = hu * hq;
+            z[1] = hq * hi;
+            z[2] = hi * hu;
+            z[3] = z[0] * hi;
+            if (WT == 2) {
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z[b], acc[b], 0, 0, 0);
+            } else {
+                const float zb = wave == 0 ? z[0] : wave == 1 ? z[1] : wave == 2 ? z[2] : z[3];
+                if (wave < NBLK) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, zb, acc[0], 0, 0, 0);
+            }
+        }
+    }
+    // slab[x] is a full [d][NBLK*d] matrix; element (j, b*d + c)
+    float* slab = slabs + static_cast<int64_t>(blockIdx.x) * d * NBLK * d;
+#pragma unroll
+    for (int x = 0; x < PER_WAVE; ++x) {
+        const int b = WT == 2 ? x : wave;
+        if (b >= NBLK) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = js * SW + jt * 32 + acc_row(r, lane);
+            const int c = cs * SW + ct * 32 + l31;
+            slab[static_cast<int64_t>(j) * NBLK * d + b * d + c] = acc[x][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int d, int nblk,
+                                                                    float* __restrict__ dw, int64_t ld_dw) {
+    const int width = nblk * d;
+    const int total = d * width;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int s = 0; s < n_slabs; ++s) acc += slabs[static_cast<int64_t>(s) * total + idx];
+        const int j = idx / width, col = idx - j * width;
+        dw[static_cast<int64_t>(j) * ld_dw + 3 * static_cast<int64_t>(d) + col] = acc;
+    }
+}
+
+inline bool mfma_dim(int dim) { return dim == 32 || dim == 64 || dim == 128 || dim == 256; }
+inline int64_t packed_weight_floats(int dim, int order) { return static_cast<int64_t>(order == 3 ? 4 : 3) * dim * dim; }
+inline int weight_slabs(int dim) {
+    const int subs = dim >= 64 ? (dim / 64) * (dim / 64) : 1;
+    int n = 512 / subs;
+    return n < 8 ? 8 : n;
+}
+constexpr int kFwdGrid = 256 * 3;
+
 // ------------------------------------------------------------------------------------------------
 // Dispatch helpers
 // ------------------------------------------------------------------------------------------------
@@ -461,6 +774,51 @@ inline bool scale_mode_ok(int mode, const float* scale) {
     return (mode == IHG_SCALE_MULTIPLY || mode == IHG_SCALE_DIVIDE) && scale != nullptr;
 }
 
+template <int NBLK>
+void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* wp,
+                              float* out, int64_t ld_out, int64_t n_edges, hipStream_t s) {
+#define IHG_FWD(D)                                                                                                          \
+    {                                                                                                                       \
+        const int64_t tiles = (n_edges + TileShape<D>::TE - 1) / TileShape<D>::TE;                                          \
+        const int grid = static_cast<int>(std::min<int64_t>(tiles, kFwdGrid));                                              \
+        hipLaunchKernelGGL((interact_fwd_mfma_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges); \
+    }
+    switch (dim) {
+        case 32: IHG_FWD(32) break;
+        case 64: IHG_FWD(64) break;
+        case 128: IHG_FWD(128) break;
+        default: IHG_FWD(256) break;
+    }
+#undef IHG_FWD
+}
+
+template <int NBLK>
+void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* wq, const float* dout, int64_t ld_dout,
+                              float* g, float* slabs, float* dw, int64_t ld_dw, int64_t n_edges, hipStream_t s) {
+#define IHG_MEM(D)                                                                                                          \
+    {                                                                                                                       \
+        constexpr int TE = D == 32 ? 128 : 64;                                                                              \
+        const int grid = static_cast<int>(std::min<int64_t>((n_edges + TE - 1) / TE, kFwdGrid));                            \
+        hipLaunchKernelGGL((interact_bwd_members_mfma_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
+    }
+    switch (dim) {
+        case 32: IHG_MEM(32) break;
+        case 64: IHG_MEM(64) break;
+        case 128: IHG_MEM(128) break;
+        default: IHG_MEM(256) break;
+    }
+#undef IHG_MEM
+    const int n_slabs = static_cast<int>(std::min<int64_t>(weight_slabs(dim), (n_edges + 63) / 64));
+    if (dim == 32) {
+        hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<32, NBLK>), dim3(n_slabs, 1), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
+    } else {
+        const int subs = (dim / 64) * (dim / 64);
+        hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<64, NBLK>), dim3(n_slabs, subs), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
+    }
+    const int total = dim * NBLK * dim;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((total + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, slabs, n_slabs, dim, NBLK, dw, ld_dw);
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -468,7 +826,7 @@ inline bool scale_mode_ok(int mode, const float* scale) {
 // =================================================================================================
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 1; }
+int32_t ihg_abi_version(void) { return 2; }
 
 const char* ihg_last_error_string(void) { return g_error; }
 
@@ -572,8 +930,15 @@ int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr
     return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, inv_len, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, stream);
 }
 
+int64_t ihg_interact_fwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order) {
+    (void)n_edges;
+    if (!mfma_dim(dim) || (order != 2 && order != 3)) return 0;
+    return packed_weight_floats(dim, order) * static_cast<int64_t>(sizeof(float));
+}
+
 int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w,
-                     int32_t order, float* out, int64_t ld_out, int64_t n_edges, int32_t dim, ihg_stream_t stream) {
+                     int32_t order, float* out, int64_t ld_out, void* workspace, int64_t workspace_bytes, int64_t n_edges,
+                     int32_t dim, ihg_stream_t stream) {
     if (order != 2 && order != 3) return fail(IHG_ERR_INVALID, "ihg_interact_fwd: order must be 2 or 3, got %d", order);
     const int k = order == 3 ? 7 : 6;
     if (n_edges < 0 || dim <= 0 || ld_h < dim || ld_out < dim || ld_w < static_cast<int64_t>(k) * dim || (p != nullptr && ld_p < dim))
@@ -581,6 +946,19 @@ int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p,
     if (n_edges == 0) return IHG_OK;
     if (h == nullptr || i3 == nullptr || w == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_interact_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool tiled = mfma_dim(dim) && p != nullptr && ld_h % 4 == 0 && ld_w % 4 == 0 && aligned16(h) && aligned16(w) && workspace != nullptr &&
+                       aligned16(workspace);
+    if (tiled) {
+        if (workspace_bytes < ihg_interact_fwd_workspace_bytes(n_edges, dim, order)) return fail(IHG_ERR_WORKSPACE, "ihg_interact_fwd: workspace too small");
+        float* wp = static_cast<float*>(workspace);
+        const int nblk = order == 3 ? 4 : 3;
+        const int pack_items = (dim / 32) * nblk * (dim / 8) * kWave;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wp,
+                           static_cast<float*>(nullptr));
+        if (nblk == 4) launch_interact_fwd_mfma<4>(dim, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges, s);
+        else launch_interact_fwd_mfma<3>(dim, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges, s);
+        return check_launch("ihg_interact_fwd");
+    }
     const int64_t total = n_edges * dim;
     const int grid = static_cast<int>(std::min<int64_t>((total + kBlockThreads - 1) / kBlockThreads, kMaxBlocks * 4));
     hipLaunchKernelGGL(interact_fwd_generic_kernel, dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, p, ld_p, i3, w, ld_w, order, out, ld_out, n_edges, dim);
@@ -588,8 +966,10 @@ int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p,
 }
 
 int64_t ihg_interact_bwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order) {
-    (void)n_edges; (void)dim; (void)order;
-    return 0;
+    (void)n_edges;
+    if (!mfma_dim(dim) || (order != 2 && order != 3)) return 0;
+    const int64_t w_floats = packed_weight_floats(dim, order);
+    return (w_floats + static_cast<int64_t>(weight_slabs(dim)) * w_floats) * static_cast<int64_t>(sizeof(float));
 }
 
 int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
@@ -599,11 +979,23 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const floa
     const int k = order == 3 ? 7 : 6;
     if (n_edges < 0 || dim <= 0 || ld_h < dim || ld_dout < dim || ld_w < static_cast<int64_t>(k) * dim || ld_dw < static_cast<int64_t>(k) * dim)
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd: bad size");
-    if (workspace_bytes < ihg_interact_bwd_workspace_bytes(n_edges, dim, order)) return fail(IHG_ERR_WORKSPACE, "ihg_interact_bwd: workspace too small");
-    (void)workspace;
     if (h == nullptr || i3 == nullptr || w == nullptr || dout == nullptr || g == nullptr || dw == nullptr)
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool tiled = mfma_dim(dim) && n_edges > 0 && ld_h % 4 == 0 && ld_w % 4 == 0 && ld_dout % 4 == 0 && aligned16(h) && aligned16(w) &&
+                       aligned16(dout) && workspace != nullptr && aligned16(workspace);
+    if (tiled) {
+        if (workspace_bytes < ihg_interact_bwd_workspace_bytes(n_edges, dim, order)) return fail(IHG_ERR_WORKSPACE, "ihg_interact_bwd: workspace too small");
+        const int nblk = order == 3 ? 4 : 3;
+        float* wq = static_cast<float*>(workspace);
+        float* slabs = wq + packed_weight_floats(dim, order);
+        const int pack_items = (dim / 32) * nblk * (dim / 8) * kWave;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk,
+                           static_cast<float*>(nullptr), wq);
+        if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s);
+        else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s);
+        return check_launch("ihg_interact_bwd");
+    }
     if (n_edges > 0) {
         const int64_t total = n_edges * dim;
         const int grid = static_cast<int>(std::min<int64_t>((total + kBlockThreads - 1) / kBlockThreads, kMaxBlocks * 4));

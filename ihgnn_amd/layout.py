@@ -79,6 +79,15 @@ class Csr:
     def row_slice(self, begin: int, end: int) -> 'CsrRows':
         return CsrRows(self, begin, end)
 
+    def with_ids(self, ids_host: np.ndarray) -> 'Csr':
+        """Same rows, row pointer and split-row plan, different id payload (shares every device array but ``ids``)."""
+        other = Csr.__new__(Csr)
+        other.__dict__.update(self.__dict__)
+        other.ids_host = np.ascontiguousarray(ids_host, dtype=np.int32)
+        other.ids = torch.from_numpy(other.ids_host).to(self.device)
+        other._partials = self._partials
+        return other
+
     def transpose(self, n_cols: int) -> 'Csr':
         lib = _lib.load()
         t_ptr = np.empty(n_cols + 1, np.int32)
@@ -137,3 +146,10 @@ class IncidenceLayout:
         self.inv_sqrt_deg = torch.where(isolated, torch.zeros_like(deg), deg.pow(-0.5)).to(device)
         u, q = self.user_count, self.query_count
         self.type_rows = (self.node_csr.row_slice(0, u), self.node_csr.row_slice(u, u + q), self.node_csr.row_slice(u + q, n))
+        # member_csr: for node v and incident hyperedge e, the row of v's OWN slot in an [E,3,d] per-member buffer
+        # (3e + type(v)); lets the interactive backward scatter-add all three member gradients in one K7 launch.
+        lens = np.diff(rowptr.astype(np.int64))
+        slot_of_node = np.zeros(n, np.int32)
+        slot_of_node[u:u + q] = 1
+        slot_of_node[u + q:] = 2
+        self.member_csr = self.node_csr.with_ids(edge_ids[:3 * e] * 3 + np.repeat(slot_of_node, lens))

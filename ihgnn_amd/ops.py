@@ -51,6 +51,11 @@ def _ld(t: Tensor) -> int:
     return int(t.stride(0)) if t.shape[0] > 1 else int(t.shape[1])
 
 
+def _workspace(n_bytes: int, device: torch.device) -> Tensor:
+    """Scratch for one launch (torch's caching allocator hands back the same block step after step)."""
+    return torch.empty(max(n_bytes, 16) // 4, dtype=torch.float32, device=device)
+
+
 # ---------------------------------------------------------------------------------------------
 # raw launches (no autograd)
 # ---------------------------------------------------------------------------------------------
@@ -195,9 +200,11 @@ class _Interact(torch.autograd.Function):
         w = _rows(w, 'w')
         dim = int(h.shape[1])
         out = torch.empty(layout.edge_count, dim, dtype=torch.float32, device=h.device)
+        ws = _workspace(int(lib.ihg_interact_fwd_workspace_bytes(layout.edge_count, dim, order)), h.device)
         with profiler.kernel('interact_fwd', layout.edge_count, dim):
             _lib.check(lib.ihg_interact_fwd(_ptr(h), _ld(h), _ptr(p), _ld(p), _ptr(layout.i3), _ptr(w), _ld(w), order,
-                                            _ptr(out), _ld(out), layout.edge_count, dim, _stream()), 'ihg_interact_fwd')
+                                            _ptr(out), _ld(out), _ptr(ws), ws.numel() * 4, layout.edge_count, dim, _stream()),
+                       'ihg_interact_fwd')
         ctx.save_for_backward(h, w)
         ctx.layout, ctx.order = layout, order
         return out
@@ -211,18 +218,14 @@ class _Interact(torch.autograd.Function):
         n_edges, dim = layout.edge_count, int(h.shape[1])
         g = torch.empty(n_edges, 3 * dim, dtype=torch.float32, device=h.device)
         dw = torch.zeros_like(w)
-        ws_bytes = int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order))
-        ws = torch.empty(max(ws_bytes, 4) // 4 + 1, dtype=torch.float32, device=h.device)
+        ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
         with profiler.kernel('interact_bwd', n_edges, dim):
             _lib.check(lib.ihg_interact_bwd(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(grad_out), _ld(grad_out),
                                             _ptr(g), _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4, n_edges, dim, _stream()),
                        'ihg_interact_bwd')
         # member gradients back to nodes: node type t reads slot t of g (users/queries/items are contiguous id ranges)
-        dh = torch.empty(layout.node_count, dim, dtype=torch.float32, device=h.device)
-        starts = (0, layout.user_count, layout.user_count + layout.query_count)
-        for slot, rows in enumerate(layout.type_rows):
-            if rows.n_rows:
-                node_segment_sum_raw(g[:, slot * dim:(slot + 1) * dim], rows, out=dh[starts[slot]:starts[slot] + rows.n_rows])
+        # member gradients back to nodes: (node v, hyperedge e) reads row 3e + type(v) of g viewed as [3E, d]
+        dh = node_segment_sum_raw(g.view(3 * n_edges, dim), layout.member_csr)
         dp = node_segment_sum_raw(grad_out, layout.node_csr)
         return dh, dp, dw, None, None
 

@@ -135,10 +135,17 @@ int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr
  *        dw[:, 3*dim:]  = gradient of the product blocks of w (first-order columns are left untouched).
  *        `workspace` must hold ihg_interact_bwd_workspace_bytes(...) bytes (per-workgroup partial dW slabs,
  *        reduced in a fixed order - bitwise reproducible).
+ *   Both directions take a caller-owned, 16-byte aligned device `workspace` of ihg_interact_{fwd,bwd}_workspace_bytes
+ *   bytes: the product blocks of w re-packed into MFMA fragment order (+ the dW slabs for bwd).  For dim in
+ *   {32, 64, 128, 256} with 16-byte aligned rows the contraction runs on the matrix cores in exact fp32
+ *   (v_mfma_f32_32x32x2_f32); every other shape takes a scalar kernel with the same results.
  */
+int64_t ihg_interact_fwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order);
+
 int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3,
                      const float* w, int64_t ld_w, int32_t order,
-                     float* out, int64_t ld_out, int64_t n_edges, int32_t dim, ihg_stream_t stream);
+                     float* out, int64_t ld_out, void* workspace, int64_t workspace_bytes,
+                     int64_t n_edges, int32_t dim, ihg_stream_t stream);
 
 int64_t ihg_interact_bwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order);
 
