@@ -32,6 +32,8 @@ class FeatureInteractor(nn.Module):
         """Node-level image of the u / q / i blocks (+ bias, carried by the user rows: one user per hyperedge)."""
         d = self.node_feature_dimension
         w, b = self.aggregation.weight, self.aggregation.bias
+        if ops.node_linear_supported(node_features, w):
+            return ops.node_linear(node_features, w, b, self.dataset.hypergraph.layout, typed=True, bias_mask=0b001)
         u_end = self.dataset.query_start_index_in_graph
         q_end = self.dataset.item_start_index_in_graph
         return torch.cat([F.linear(node_features[:u_end], w[:, :d], b),

@@ -13,6 +13,13 @@ from .. import ops
 from .CommonLayers import FeatureInteractor
 
 
+def _transform(linear: nn.Linear, x: Tensor, layout) -> Tensor:
+    """``nn.Linear`` on every node row: the HIP row-GEMM when the shape allows, torch/rocBLAS otherwise."""
+    if linear.in_features == linear.out_features and ops.node_linear_supported(x, linear.weight):
+        return ops.node_linear(x, linear.weight, linear.bias, layout)
+    return linear(x)
+
+
 class HGCNLayer(nn.Module):
     """``Y = Dv^-1/2 H De^-1 H^T Dv^-1/2 (X W^T + b)``  (``GnnLayers.py:142-153``)."""
 
@@ -26,7 +33,7 @@ class HGCNLayer(nn.Module):
 
     def forward(self, input_features: Tensor) -> Tensor:
         lay = self.layout
-        h = self.feature_transform(input_features)
+        h = _transform(self.feature_transform, input_features, lay)
         edge_features = ops.edge_gather_sum(h, lay, node_scale=lay.inv_sqrt_deg, alpha=self.edge_scale)
         return ops.node_segment_sum(edge_features, lay, out_scale=lay.inv_sqrt_deg)
 
@@ -53,7 +60,7 @@ class IHGNNLayer(nn.Module):
         self.feature_transform = nn.Linear(input_dimension, output_dimension)
 
     def forward(self, input_features: Tensor) -> Tensor:
-        h = self.feature_transform(input_features)
+        h = _transform(self.feature_transform, input_features, self.layout)
         edge_features = self.feature_interactor(h)
         return ops.node_segment_sum(edge_features, self.layout, out_scale=self.layout.inv_deg)
 

@@ -190,6 +190,74 @@ def bag_mean(table: Tensor, bag: BagLayout) -> Tensor:
 
 
 # ---------------------------------------------------------------------------------------------
+# K4: node-level dense transforms (feature_transform and the hoisted u / q / i blocks of the aggregation)
+# ---------------------------------------------------------------------------------------------
+def node_linear_supported(x: Tensor, w: Tensor) -> bool:
+    """True when the MFMA row-GEMM kernels take this shape (d in {32,64,128,256}, 16-B aligned rows)."""
+    d = int(x.shape[1])
+    return (x.is_cuda and d in (32, 64, 128, 256) and x.dtype == torch.float32 and w.dtype == torch.float32
+            and x.stride(-1) == 1 and w.stride(-1) == 1 and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and int(w.shape[0]) == d)
+
+
+def _type_begin(layout: IncidenceLayout):
+    tb = getattr(layout, '_type_begin_c', None)
+    if tb is None:
+        u, q = layout.user_count, layout.query_count
+        tb = (ctypes.c_int64 * 4)(0, u, u + q, layout.node_count)
+        layout._type_begin_c = tb
+    return tb
+
+
+class _NodeLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, typed: bool, bias_mask: int) -> Tensor:
+        lib = _lib.load()
+        x = _rows(x, 'x')
+        dim = int(x.shape[1])
+        out = torch.empty(x.shape[0], dim, dtype=torch.float32, device=x.device)
+        ws = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), x.device)
+        stride = dim if typed else 0
+        with profiler.kernel('node_linear_fwd', x.shape[0], dim):
+            _lib.check(lib.ihg_node_linear_fwd(_ptr(x), _ld(x), _ptr(w), int(w.stride(0)), stride, _ptr(bias), bias_mask, _type_begin(layout),
+                                               _ptr(out), _ld(out), _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.layout, ctx.typed, ctx.bias_mask, ctx.has_bias = layout, typed, bias_mask, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        g = _rows(grad_out, 'grad_out')
+        if g.stride(0) % 4 or g.data_ptr() % 16:
+            g = g.contiguous()
+        dim = int(x.shape[1])
+        stride = dim if ctx.typed else 0
+        tb = _type_begin(ctx.layout)
+        ws = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), x.device)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            with profiler.kernel('node_linear_bwd_input', x.shape[0], dim):
+                _lib.check(lib.ihg_node_linear_bwd_input(_ptr(g), _ld(g), _ptr(w), int(w.stride(0)), stride, tb, _ptr(dx), _ld(dx),
+                                                         _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_bwd_input')
+        dw = torch.zeros_like(w) if w.shape[1] != dim else torch.empty_like(w)      # product-block columns of a [d, k*d] weight stay 0
+        dbias = torch.empty(dim, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        with profiler.kernel('node_linear_bwd_weight', x.shape[0], dim):
+            _lib.check(lib.ihg_node_linear_bwd_weight(_ptr(g), _ld(g), _ptr(x), _ld(x), tb, _ptr(dw), int(dw.stride(0)), stride,
+                                                      _ptr(dbias), ctx.bias_mask, _ptr(ws), ws.numel() * 4, dim, _stream()),
+                       'ihg_node_linear_bwd_weight')
+        return dx, dw, dbias, None, None, None
+
+
+def node_linear(x: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, typed: bool = False, bias_mask: int = 0b111) -> Tensor:
+    """``out[v] = x[v] @ W_type(v).T (+ bias)``.  ``typed=False``: one ``[d,d]`` weight for every node; ``typed=True``:
+    ``w`` is ``[d, k*d]`` and node type t uses its column block ``w[:, t*d:(t+1)*d]``; bias is added to the types in ``bias_mask``."""
+    return _NodeLinear.apply(x, w, bias, layout, bool(typed), int(bias_mask))
+
+
+# ---------------------------------------------------------------------------------------------
 # K5+K6 interactive step (orders 2 and 3)
 # ---------------------------------------------------------------------------------------------
 class _Interact(torch.autograd.Function):

@@ -148,6 +148,35 @@ def test_bag_mean_forward_backward(dim):
     assert (tg.grad[0] == 0).all()                        # padding row never indexed
 
 
+@pytest.mark.parametrize('dim', [32, 64, 128, 256])
+@pytest.mark.parametrize('typed', [False, True])
+def test_node_linear_forward_backward(dim, typed):
+    """Row-GEMM kernels (feature_transform / hoisted first-order blocks) vs torch CPU autograd."""
+    from ihgnn_amd import ops
+    U, Q, I = 70, 9, 131                                  # ranges that are not multiples of the 64-row tile
+    _, lay = make_layout(U, Q, I, 50, seed=dim)
+    gen = torch.Generator().manual_seed(dim + typed)
+    x = torch.randn(lay.node_count, dim, generator=gen)
+    w = torch.randn(dim, 7 * dim if typed else dim, generator=gen) / np.sqrt(dim)
+    b = torch.randn(dim, generator=gen)
+    cot = torch.randn(lay.node_count, dim, generator=gen)
+    xc, wc, bc = (t.clone().requires_grad_(True) for t in (x, w, b))
+    if typed:
+        want = torch.cat([torch.nn.functional.linear(xc[:U], wc[:, :dim], bc), torch.nn.functional.linear(xc[U:U + Q], wc[:, dim:2 * dim]),
+                          torch.nn.functional.linear(xc[U + Q:], wc[:, 2 * dim:3 * dim])])
+    else:
+        want = torch.nn.functional.linear(xc, wc, bc)
+    want.backward(cot)
+    xg, wg, bg = (t.clone().to(dev()).requires_grad_(True) for t in (x, w, b))
+    assert ops.node_linear_supported(xg, wg)
+    got = ops.node_linear(xg, wg, bg, lay, typed=typed, bias_mask=0b001 if typed else 0b111)
+    got.backward(cot.to(dev()))
+    assert rel(got, want) <= RTOL_SUM * 2
+    assert rel(xg.grad, xc.grad) <= RTOL_SUM * 2 and rel(wg.grad, wc.grad) <= RTOL and rel(bg.grad, bc.grad) <= RTOL
+    if typed:
+        assert (wg.grad[:, 3 * dim:] == 0).all()
+
+
 @pytest.mark.parametrize('dim,order', [(8, 2), (8, 3), (12, 3), (32, 2), (32, 3), (64, 2), (64, 3), (128, 3)])
 def test_interact_forward_backward(dim, order):
     from ihgnn_amd import ops
