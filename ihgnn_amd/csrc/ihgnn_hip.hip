@@ -206,17 +206,21 @@ __device__ __forceinline__ void apply_out_scale(Frag<VEC>& acc, const float* out
 template <int VEC, int G>
 __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
     const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ids,
-    const float* __restrict__ src_scale, const float* __restrict__ out_scale, int mode,
+    const int32_t* __restrict__ row_order, const float* __restrict__ src_scale, const float* __restrict__ out_scale, int mode,
     float* __restrict__ out, int64_t ld_out, int64_t n_rows, int dim_vec, int heavy_threshold) {
     constexpr int GPW = kWave / G;
     const int lane = threadIdx.x & (kWave - 1);
     const int lig = lane & (G - 1);
     const int grp = lane / G;
     for (int64_t r0 = global_wave_id() * GPW; r0 < n_rows; r0 += global_wave_count() * GPW) {
-        const int64_t r = r0 + grp;
+        // row_order lists the rows by decreasing length: the groups of one wave then walk lists of (almost) equal
+        // length, and the longest lists start first.
+        int64_t r = r0 + grp;
+        const bool valid = r < n_rows;
+        if (valid && row_order != nullptr) r = row_order[r];
         int begin = 0, len = 0;
         bool heavy = false;
-        if (r < n_rows) {
+        if (valid) {
             begin = rowptr[r];
             len = rowptr[r + 1] - begin;
             if (heavy_threshold > 0 && len > heavy_threshold) { heavy = true; len = 0; }
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
             const int c = ci * G + lig;
             const int col = c < dim_vec ? c : -1;
             Frag<VEC> acc = accumulate_list<VEC, G>(src, ld_src, ids, src_scale, begin, len, wave_len, lane, col);
-            if (r < n_rows && !heavy && col >= 0) {
+            if (valid && !heavy && col >= 0) {
                 apply_out_scale<VEC>(acc, out_scale, mode, r);
                 acc.store(out + r * ld_out + col * VEC);
             }
@@ -260,24 +264,43 @@ __global__ __launch_bounds__(kBlockThreads) void heavy_partial_kernel(
     }
 }
 
+// One workgroup per heavy row: its 256/G lane groups take the row's partials round-robin (4 loads in flight each), the
+// per-group sums are combined through LDS in group order - a fixed summation tree, so the result is bitwise reproducible.
 template <int VEC, int G>
 __global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
     const float* __restrict__ partials, const int32_t* __restrict__ heavy_rows, const int32_t* __restrict__ heavy_segptr,
     int64_t n_heavy, const float* __restrict__ out_scale, int mode, float* __restrict__ out, int64_t ld_out, int dim, int dim_vec) {
-    constexpr int GPW = kWave / G;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int lig = lane & (G - 1);
-    const int grp = lane / G;
-    for (int64_t h0 = global_wave_id() * GPW; h0 < n_heavy; h0 += global_wave_count() * GPW) {
-        const int64_t h = h0 + grp;
-        if (h >= n_heavy) continue;
+    constexpr int GROUPS = kBlockThreads / G;
+    __shared__ __attribute__((aligned(16))) float red[GROUPS][G * VEC];
+    const int lig = threadIdx.x & (G - 1);
+    const int grp = threadIdx.x / G;
+    for (int64_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         const int64_t row = heavy_rows[h];
         const int s_begin = heavy_segptr[h], s_end = heavy_segptr[h + 1];
-        for (int c = lig; c < dim_vec; c += G) {
+        for (int c0 = 0; c0 < dim_vec; c0 += G) {
+            const int c = c0 + lig;
             Frag<VEC> acc = Frag<VEC>::zero();
-            for (int s = s_begin; s < s_end; ++s) acc.add(Frag<VEC>::load(partials + static_cast<int64_t>(s) * dim + c * VEC));
-            apply_out_scale<VEC>(acc, out_scale, mode, row);
-            acc.store(out + row * ld_out + c * VEC);
+            if (c < dim_vec) {
+                int sgm = s_begin + grp;
+                for (; sgm + 3 * GROUPS < s_end; sgm += 4 * GROUPS) {
+                    const Frag<VEC> a0 = Frag<VEC>::load(partials + static_cast<int64_t>(sgm) * dim + c * VEC);
+                    const Frag<VEC> a1 = Frag<VEC>::load(partials + static_cast<int64_t>(sgm + GROUPS) * dim + c * VEC);
+                    const Frag<VEC> a2 = Frag<VEC>::load(partials + static_cast<int64_t>(sgm + 2 * GROUPS) * dim + c * VEC);
+                    const Frag<VEC> a3 = Frag<VEC>::load(partials + static_cast<int64_t>(sgm + 3 * GROUPS) * dim + c * VEC);
+                    acc.add(a0); acc.add(a1); acc.add(a2); acc.add(a3);
+                }
+                for (; sgm < s_end; sgm += GROUPS) acc.add(Frag<VEC>::load(partials + static_cast<int64_t>(sgm) * dim + c * VEC));
+                acc.store(&red[grp][lig * VEC]);
+            }
+            __syncthreads();
+            if (grp == 0 && c < dim_vec) {
+                Frag<VEC> total = Frag<VEC>::load(&red[0][lig * VEC]);
+                const int used = s_end - s_begin < GROUPS ? s_end - s_begin : GROUPS;
+                for (int g2 = 1; g2 < used; ++g2) total.add(Frag<VEC>::load(&red[g2][lig * VEC]));
+                apply_out_scale<VEC>(total, out_scale, mode, row);
+                total.store(out + row * ld_out + c * VEC);
+            }
+            __syncthreads();
         }
     }
 }
@@ -658,18 +681,44 @@ __global__ __launch_bounds__(kBlockThreads) void interact_bwd_weight_mfma_kernel
     }
 }
 
+
+// Sum `n_slabs` slabs of `total` floats each at element `idx`: the workgroup's 4 waves take the slabs round-robin with 8
+// loads in flight per lane, then combine through LDS in wave order (fixed tree => bitwise reproducible).
+// Must be called by all 256 threads of a block with idx = blockIdx.x * 64 + (threadIdx.x & 63); returns the sum to wave 0.
+__device__ __forceinline__ float slab_sum(const float* __restrict__ slabs, int n_slabs, int64_t total, int64_t idx, bool live) {
+    __shared__ float part[kWavesPerBlock][kWave];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
+    if (live) {
+        int sl = wave;
+        for (; sl + 7 * kWavesPerBlock < n_slabs; sl += 8 * kWavesPerBlock) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += slabs[static_cast<int64_t>(sl + u * kWavesPerBlock) * total + idx];
+        }
+        for (; sl < n_slabs; sl += kWavesPerBlock) a[0] += slabs[static_cast<int64_t>(sl) * total + idx];
+    }
+    part[wave][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    const float sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    __syncthreads();
+    return sum;
+}
+
 __global__ __launch_bounds__(kBlockThreads) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int d, int nblk,
                                                                     float* __restrict__ dw, int64_t ld_dw) {
     const int width = nblk * d;
-    const int total = d * width;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        float acc = 0.f;
-        for (int s = 0; s < n_slabs; ++s) acc += slabs[static_cast<int64_t>(s) * total + idx];
-        const int j = idx / width, col = idx - j * width;
-        dw[static_cast<int64_t>(j) * ld_dw + 3 * static_cast<int64_t>(d) + col] = acc;
+    const int64_t total = static_cast<int64_t>(d) * width;
+    for (int64_t base = static_cast<int64_t>(blockIdx.x) * kWave; base < total; base += static_cast<int64_t>(gridDim.x) * kWave) {
+        const int64_t idx = base + (threadIdx.x & 63);
+        const float acc = slab_sum(slabs, n_slabs, total, idx, idx < total);
+        if ((threadIdx.x >> 6) == 0 && idx < total) {
+            const int j = static_cast<int>(idx / width), col = static_cast<int>(idx - static_cast<int64_t>(j) * width);
+            dw[static_cast<int64_t>(j) * ld_dw + 3 * static_cast<int64_t>(d) + col] = acc;
+        }
     }
 }
-
 
 // ================================================================================================
 // Node-level dense transforms (K4 and the hoisted first-order blocks): out[v] = x[v] * W_type(v)^T (+ bias).
@@ -819,23 +868,29 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_kernel(const 
 __global__ __launch_bounds__(kBlockThreads) void dense_slab_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
                                                                           int n_slabs, int n_types, int d, float* __restrict__ dw, int64_t ld_dw,
                                                                           int64_t dw_type_stride, float* __restrict__ dbias, int bias_mask) {
-    const int per_type = d * d;
-    const int total = per_type * n_types + d;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        if (idx < per_type * n_types) {
-            const int type = idx / per_type, rem = idx - type * per_type;
-            float acc = 0.f;
-            for (int s2 = 0; s2 < n_slabs; ++s2) acc += slabs[(static_cast<int64_t>(type) * n_slabs + s2) * per_type + rem];
-            const int c = rem / d, j = rem - c * d;
-            dw[static_cast<int64_t>(c) * ld_dw + type * dw_type_stride + j] = acc;
-        } else if (dbias != nullptr) {
-            const int c = idx - per_type * n_types;
+    const int64_t per_type = static_cast<int64_t>(d) * d;
+    const int64_t w_items = per_type * n_types;
+    const int64_t total = w_items + d;
+    for (int64_t base = static_cast<int64_t>(blockIdx.x) * kWave; base < total; base += static_cast<int64_t>(gridDim.x) * kWave) {
+        const int64_t idx = base + (threadIdx.x & 63);
+        const bool first_wave = (threadIdx.x >> 6) == 0;
+        if (base < w_items) {                               // w_items is a multiple of 64: a block never straddles the two parts
+            const int type = static_cast<int>(idx / per_type);
+            const int64_t rem = idx - type * per_type;
+            const float acc = slab_sum(slabs + static_cast<int64_t>(type) * n_slabs * per_type, n_slabs, per_type, rem, idx < w_items);
+            if (first_wave && idx < w_items) {
+                const int c = static_cast<int>(rem / d), j = static_cast<int>(rem - static_cast<int64_t>(c) * d);
+                dw[static_cast<int64_t>(c) * ld_dw + type * dw_type_stride + j] = acc;
+            }
+        } else {
+            const int c = static_cast<int>(idx - w_items);
             float acc = 0.f;
             for (int type = 0; type < n_types; ++type) {
-                if (n_types > 1 && !((bias_mask >> type) & 1)) continue;
-                for (int s2 = 0; s2 < n_slabs; ++s2) acc += bias_slabs[(static_cast<int64_t>(type) * n_slabs + s2) * d + c];
+                const bool use = n_types == 1 || ((bias_mask >> type) & 1);
+                const float part = slab_sum(bias_slabs + static_cast<int64_t>(type) * n_slabs * d, n_slabs, d, c, use && c < d);
+                acc += part;
             }
-            dbias[c] = acc;
+            if (first_wave && c < d && dbias != nullptr) dbias[c] = acc;
         }
     }
 }
@@ -919,26 +974,26 @@ int launch_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, 
 }
 
 template <int VEC, int G>
-void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const float* src_scale,
-                          const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim_vec,
+void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
+                          const float* src_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim_vec,
                           int heavy_threshold, hipStream_t stream) {
     constexpr int GPW = kWave / G;
     const int grid = grid_for_waves((n_rows + GPW - 1) / GPW);
     hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr,
-                       ids, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold);
+                       ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold);
 }
 
 template <int VEC>
-int launch_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const float* src_scale,
-                       const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
+int launch_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
+                       const float* src_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
                        int heavy_threshold, hipStream_t stream) {
     const int dim_vec = dim / VEC;
     switch (group_lanes(dim_vec)) {
-        case 4: launch_segment_sum_g<VEC, 4>(src, ld_src, rowptr, ids, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
-        case 8: launch_segment_sum_g<VEC, 8>(src, ld_src, rowptr, ids, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
-        case 16: launch_segment_sum_g<VEC, 16>(src, ld_src, rowptr, ids, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
-        case 32: launch_segment_sum_g<VEC, 32>(src, ld_src, rowptr, ids, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
-        default: launch_segment_sum_g<VEC, 64>(src, ld_src, rowptr, ids, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
+        case 4: launch_segment_sum_g<VEC, 4>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
+        case 8: launch_segment_sum_g<VEC, 8>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
+        case 16: launch_segment_sum_g<VEC, 16>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
+        case 32: launch_segment_sum_g<VEC, 32>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
+        default: launch_segment_sum_g<VEC, 64>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
     }
     return check_launch("ihg_node_segment_sum");
 }
@@ -951,7 +1006,7 @@ void launch_heavy_g(const float* src, int64_t ld_src, const int32_t* ids, const 
     constexpr int GPW = kWave / G;
     hipLaunchKernelGGL((heavy_partial_kernel<VEC, G>), dim3(grid_for_waves((n_segments + GPW - 1) / GPW)), dim3(kBlockThreads), 0,
                        stream, src, ld_src, ids, src_scale, seg_begin, seg_end, n_segments, partials, dim, dim_vec);
-    hipLaunchKernelGGL((heavy_finish_kernel<VEC, G>), dim3(grid_for_waves((n_heavy + GPW - 1) / GPW)), dim3(kBlockThreads), 0,
+    hipLaunchKernelGGL((heavy_finish_kernel<VEC, G>), dim3(static_cast<int>(std::min<int64_t>(n_heavy, kMaxBlocks * 4))), dim3(kBlockThreads), 0,
                        stream, partials, heavy_rows, heavy_segptr, n_heavy, out_scale, mode, out, ld_out, dim, dim_vec);
 }
 
@@ -1020,7 +1075,7 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
         hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<64, NBLK>), dim3(n_slabs, subs), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
     }
     const int total = dim * NBLK * dim;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((total + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, slabs, n_slabs, dim, NBLK, dw, ld_dw);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, n_slabs, dim, NBLK, dw, ld_dw);
 }
 
 }  // namespace
@@ -1030,7 +1085,7 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
 // =================================================================================================
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 3; }
+int32_t ihg_abi_version(void) { return 4; }
 
 const char* ihg_last_error_string(void) { return g_error; }
 
@@ -1093,17 +1148,17 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, con
                 : launch_edge_gather_sum<1>(src, ld_src, i3, node_scale, bias, alpha, out, ld_out, n_edges, dim, s);
 }
 
-int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const float* src_scale,
-                         const float* out_scale, int32_t out_scale_mode, float* out, int64_t ld_out, int64_t n_rows, int32_t dim,
-                         int32_t heavy_threshold, ihg_stream_t stream) {
+int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
+                         const float* src_scale, const float* out_scale, int32_t out_scale_mode, float* out, int64_t ld_out,
+                         int64_t n_rows, int32_t dim, int32_t heavy_threshold, ihg_stream_t stream) {
     if (n_rows < 0 || dim <= 0 || ld_src < dim || ld_out < dim) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad size");
     if (!scale_mode_ok(out_scale_mode, out_scale)) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad out_scale_mode %d", out_scale_mode);
     if (n_rows == 0) return IHG_OK;
     if (src == nullptr || rowptr == nullptr || ids == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out);
-    return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, src_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, s)
-                : launch_segment_sum<1>(src, ld_src, rowptr, ids, src_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, s);
+    return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, s)
+                : launch_segment_sum<1>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, s);
 }
 
 int ihg_node_segment_sum_heavy(const float* src, int64_t ld_src, const int32_t* ids, const float* src_scale, const float* out_scale,
@@ -1125,13 +1180,13 @@ int ihg_node_segment_sum_heavy(const float* src, int64_t ld_src, const int32_t* 
 int ihg_bag_mean_fwd(const float* table, int64_t ld_table, const int32_t* bag_ptr, const int32_t* words, const float* bag_len,
                      float* out, int64_t ld_out, int64_t n_bags, int32_t dim, ihg_stream_t stream) {
     if (bag_len == nullptr && n_bags > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_fwd: null bag_len");
-    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, stream);
+    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, stream);
 }
 
 int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr, const int32_t* word_bags, const float* inv_len,
                      float* dtable, int64_t ld_dtable, int64_t n_table_rows, int32_t dim, ihg_stream_t stream) {
     if (inv_len == nullptr && n_table_rows > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_bwd: null inv_len");
-    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, inv_len, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, stream);
+    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, nullptr, inv_len, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, stream);
 }
 
 int64_t ihg_interact_fwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order) {
@@ -1271,7 +1326,7 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
                            n_types == 1 ? 1 : 0, slabs, bias_slabs, dim);
     }
     const int total = dim * dim * n_types + dim;
-    hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((total + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, slabs, bias_slabs,
+    hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, bias_slabs,
                        kDenseSlabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask);
     return check_launch("ihg_node_linear_bwd_weight");
 }

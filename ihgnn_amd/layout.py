@@ -19,8 +19,8 @@ import torch
 
 from . import _lib
 
-HEAVY_THRESHOLD = 1024     # rows longer than this are split ...
-HEAVY_CHUNK = 512          # ... into segments of this many ids
+HEAVY_THRESHOLD = 128      # rows longer than this are split ...
+HEAVY_CHUNK = 128          # ... into segments of this many ids (bounds every lane group's serial chain)
 
 
 def _as_ptr(a: np.ndarray, ctype):
@@ -42,6 +42,7 @@ class Csr:
         self.ids = torch.from_numpy(ids_host).to(device)
         self.heavy_threshold = int(heavy_threshold)
         self._plan_heavy(int(heavy_chunk))
+        self._plan_order()
         self._partials: Dict[Tuple[int, int], torch.Tensor] = {}
 
     def _plan_heavy(self, chunk: int) -> None:
@@ -66,6 +67,18 @@ class Csr:
         self.heavy_segptr = torch.from_numpy(segptr.astype(np.int32)).to(dev)
         self.seg_begin = torch.from_numpy(begin.astype(np.int32)).to(dev)
         self.seg_end = torch.from_numpy(end.astype(np.int32)).to(dev)
+
+    def _plan_order(self) -> None:
+        """Rows by decreasing length (stable), heavy rows last: equal-length neighbours share a wave."""
+        lens = np.diff(self.ptr_host.astype(np.int64))
+        if self.n_rows < 2 or lens.max(initial=0) == lens.min(initial=0):
+            self.row_order = None
+            return
+        key = lens.copy()
+        if self.heavy_threshold > 0:
+            key[lens > self.heavy_threshold] = -1          # skipped by the light kernel anyway
+        order = np.argsort(-key, kind='stable').astype(np.int32)
+        self.row_order = torch.from_numpy(order).to(self.device)
 
     def partials(self, dim: int) -> torch.Tensor:
         """Workspace for the split-row partial sums (allocated once per feature width)."""
@@ -113,6 +126,7 @@ class CsrRows:
         self.device = parent.device
         self.heavy_threshold = 0
         self.n_heavy = 0
+        self.row_order = None
 
 
 class IncidenceLayout:

@@ -82,7 +82,7 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
         out = torch.empty(csr.n_rows, dim, dtype=torch.float32, device=src.device)
     threshold = csr.heavy_threshold if csr.n_heavy > 0 else 0
     with profiler.kernel('node_segment_sum', csr.n_rows, dim):
-        _lib.check(lib.ihg_node_segment_sum(_ptr(src), _ld(src), _ptr(csr.ptr), _ptr(csr.ids), _ptr(src_scale), _ptr(out_scale),
+        _lib.check(lib.ihg_node_segment_sum(_ptr(src), _ld(src), _ptr(csr.ptr), _ptr(csr.ids), _ptr(csr.row_order), _ptr(src_scale), _ptr(out_scale),
                                             mode, _ptr(out), _ld(out), csr.n_rows, dim, threshold, _stream()),
                    'ihg_node_segment_sum')
     if csr.n_heavy > 0:

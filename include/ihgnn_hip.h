@@ -83,11 +83,14 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3,
  *   out[r,:] = scale_op( sum_{k in [rowptr[r], rowptr[r+1])} w(ids[k]) * src[ids[k],:] , out_scale[r] )
  * with w(j) = src_scale[j] (or 1).  Rows longer than `heavy_threshold` entries are SKIPPED here and must be
  * finished by ihg_node_segment_sum_heavy (pass heavy_threshold <= 0 to process every row here).
+ * `row_order` (optional, [n_rows]) is the order in which rows are handed to lane groups - a permutation sorted by
+ * decreasing row length keeps the groups of one wave equally busy; NULL = natural order.  Results do not depend on it.
  * Replaces: thsp.matmul(self.incidence, edge_features) and Dv^-1 * / Dv^-1/2 * (Models/GnnLayers.py:151-152,
  * 233-234), nn.EmbeddingBag(mode='mean') (Models/EmbeddingLayers.py:79, via ihg_bag_mean_fwd), and the
  * index_put(accumulate) backward of the three row gathers (Models/CommonLayers.py:70-72).
  */
 int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids,
+                         const int32_t* row_order,
                          const float* src_scale, const float* out_scale, int32_t out_scale_mode,
                          float* out, int64_t ld_out, int64_t n_rows, int32_t dim,
                          int32_t heavy_threshold, ihg_stream_t stream);

@@ -76,7 +76,7 @@ def test_csr_is_node_major_sorted_and_complete():
     segptr = csr.heavy_segptr.numpy()
     for h, row in enumerate(csr.heavy_rows.numpy()):
         b, e = csr.seg_begin.numpy()[segptr[h]:segptr[h + 1]], csr.seg_end.numpy()[segptr[h]:segptr[h + 1]]
-        assert b[0] == ptr[row] and e[-1] == ptr[row + 1] and (b[1:] == e[:-1]).all() and ((e - b) <= 512).all()
+        assert b[0] == ptr[row] and e[-1] == ptr[row + 1] and (b[1:] == e[:-1]).all() and ((e - b) <= 128).all()
 
 
 def test_build_csr_rejects_bad_ids():
