@@ -602,18 +602,22 @@ __global__ __launch_bounds__(kBlockThreads) void interact_bwd_members_mfma_kerne
 
 // weights: workgroup (x, y) owns the SW x (NBLK*SW) sub-block y = (js, cs) of dW for the hyperedge tiles x, x + gridDim.x, ...
 // and keeps it in MFMA accumulators for the whole sweep (contraction index = hyperedge, 2 per MFMA); it ends by writing
-// its partial sub-block into slab x, and slab_reduce_kernel adds the slabs in index order (bitwise reproducible).
+// its partial sub-block into slab x, and slab_reduce_kernel adds the slabs in a fixed order (bitwise reproducible).
+// Software pipeline: the rows of tile n+1 are fetched into registers while tile n is multiplied out of LDS, so the
+// gather latency (ids -> rows, two dependent trips) hides behind 32 MFMA steps.
 template <int SW, int NBLK>
-__global__ __launch_bounds__(kBlockThreads) void interact_bwd_weight_mfma_kernel(
+__global__ __launch_bounds__(kBlockThreads, 2) void interact_bwd_weight_mfma_kernel(
     const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ dout, int64_t ld_dout,
     float* __restrict__ slabs, int64_t n_edges, int d) {
     constexpr int TE = 64;
     constexpr int WT = SW / 32;                       // 32-wide tiles per side of the sub-block (2 for SW = 64, 1 for 32)
     constexpr int TILES = WT * WT * NBLK;             // accumulator tiles of the sub-block
     constexpr int PER_WAVE = (TILES + kWavesPerBlock - 1) / kWavesPerBlock;
+    constexpr int V4_PER_ROW = SW / 4;
+    constexpr int D_LOADS = TE * V4_PER_ROW / kBlockThreads;          // dout tile float4s per thread
+    constexpr int M_LOADS = 3 * TE * V4_PER_ROW / kBlockThreads;      // member-row float4s per thread
     __shared__ __attribute__((aligned(16))) float dtile[TE][SW];
     __shared__ __attribute__((aligned(16))) float mtile[3][TE][SW];
-    __shared__ int ids[TE][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int subs = d / SW;
     const int js = blockIdx.y / subs, cs = blockIdx.y % subs;
@@ -626,45 +630,65 @@ __global__ __launch_bounds__(kBlockThreads) void interact_bwd_weight_mfma_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
-    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
-        const int64_t e_base = tile_id * TE;
-        __syncthreads();
-        for (int k = tid; k < TE * 3; k += kBlockThreads) {
-            const int64_t pos = e_base * 3 + k;
-            (&ids[0][0])[k] = pos < n_edges * 3 ? i3[pos] : 0;
-        }
-        __syncthreads();
-        constexpr int V4_PER_ROW = SW / 4;
-        for (int idx = tid; idx < TE * V4_PER_ROW; idx += kBlockThreads) {
-            const int c4 = idx % V4_PER_ROW, r = idx / V4_PER_ROW;
-            const int64_t e = e_base + r;
-            const float4 v = e < n_edges ? *reinterpret_cast<const float4*>(dout + e * ld_dout + js * SW + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&dtile[r][c4 * 4]) = v;
-        }
-        for (int idx = tid; idx < 3 * TE * V4_PER_ROW; idx += kBlockThreads) {
-            const int c4 = idx % V4_PER_ROW, r = (idx / V4_PER_ROW) % TE, m = idx / (V4_PER_ROW * TE);
-            *reinterpret_cast<float4*>(&mtile[m][r][c4 * 4]) =
-                *reinterpret_cast<const float4*>(h + static_cast<int64_t>(ids[r][m]) * ld_h + cs * SW + c4 * 4);
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int kk = 0; kk < TE / 2; ++kk) {
-            const int e = 2 * kk + half;
-            const float a = dtile[e][jt * 32 + l31];
-            const float hu = mtile[0][e][ct * 32 + l31], hq = mtile[1][e][ct * 32 + l31], hi = mtile[2][e][ct * 32 + l31];
-            float z[4];
-            z[0] = hu * hq;
-            z[1] = hq * hi;
-            z[2] = hi * hu;
-            z[3] = z[0] * hi;
-            if (WT == 2) {
+    v4f dreg[D_LOADS], mreg[M_LOADS];
+    int64_t cur = -1, nxt = blockIdx.x;
+    while (true) {
+        if (cur >= 0) {
+            __syncthreads();                              // everyone is done reading the previous tile
 #pragma unroll
-                for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z[b], acc[b], 0, 0, 0);
-            } else {
-                const float zb = wave == 0 ? z[0] : wave == 1 ? z[1] : wave == 2 ? z[2] : z[3];
-                if (wave < NBLK) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, zb, acc[0], 0, 0, 0);
+            for (int x = 0; x < D_LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&dtile[idx / V4_PER_ROW][(idx % V4_PER_ROW) * 4]) = dreg[x];
+            }
+#pragma unroll
+            for (int x = 0; x < M_LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&mtile[idx / (V4_PER_ROW * TE)][(idx / V4_PER_ROW) % TE][(idx % V4_PER_ROW) * 4]) = mreg[x];
+            }
+            __syncthreads();
+        }
+        const bool have_next = nxt < n_tiles;
+        if (have_next) {                                  // the one fetch site: rows of tile `nxt` -> registers
+            const int64_t e_base = nxt * TE;
+#pragma unroll
+            for (int x = 0; x < D_LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4_PER_ROW, r = idx / V4_PER_ROW;
+                const int64_t e = e_base + r;
+                dreg[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + js * SW + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int x = 0; x < M_LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4_PER_ROW, r = (idx / V4_PER_ROW) % TE, m = idx / (V4_PER_ROW * TE);
+                const int64_t e = e_base + r;
+                const int64_t node = e < n_edges ? i3[e * 3 + m] : 0;
+                mreg[x] = *reinterpret_cast<const v4f*>(h + node * ld_h + cs * SW + c4 * 4);
             }
         }
+        if (cur >= 0) {
+#pragma unroll 4
+            for (int kk = 0; kk < TE / 2; ++kk) {
+                const int e = 2 * kk + half;
+                const float a = dtile[e][jt * 32 + l31];
+                const float hu = mtile[0][e][ct * 32 + l31], hq = mtile[1][e][ct * 32 + l31], hi = mtile[2][e][ct * 32 + l31];
+                float z[4];
+                z[0] = hu * hq;
+                z[1] = hq * hi;
+                z[2] = hi * hu;
+                z[3] = z[0] * hi;
+                if (WT == 2) {
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z[b], acc[b], 0, 0, 0);
+                } else {
+                    const float zb = wave == 0 ? z[0] : wave == 1 ? z[1] : wave == 2 ? z[2] : z[3];
+                    if (wave < NBLK) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, zb, acc[0], 0, 0, 0);
+                }
+            }
+        }
+        if (!have_next) break;
+        cur = nxt;
+        nxt += gridDim.x;
     }
     // slab[x] is a full [d][NBLK*d] matrix; element (j, b*d + c)
     float* slab = slabs + static_cast<int64_t>(blockIdx.x) * d * NBLK * d;
@@ -680,7 +704,6 @@ __global__ __launch_bounds__(kBlockThreads) void interact_bwd_weight_mfma_kernel
         }
     }
 }
-
 
 // Sum `n_slabs` slabs of `total` floats each at element `idx`: the workgroup's 4 waves take the slabs round-robin with 8
 // loads in flight per lane, then combine through LDS in wave order (fixed tree => bitwise reproducible).
@@ -805,12 +828,13 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_kernel(const float* __
 }
 
 // grid = (slabs, (d/SW)^2 sub-blocks, weight types).  Slab layout: [type][slab][d][d] then bias part [type][slab][d].
+// Same register-prefetch pipeline as the interactive weight-gradient kernel.
 template <int SW>
 __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_kernel(const float* __restrict__ dout, int64_t ld_dout,
                                                                           const float* __restrict__ x, int64_t ld_x, TypePlan plan,
                                                                           int single_weight, float* __restrict__ slabs,
                                                                           float* __restrict__ bias_slabs, int d) {
-    constexpr int TE = 64, WT = SW / 32;
+    constexpr int TE = 64, WT = SW / 32, V4_PER_ROW = SW / 4, LOADS = TE * V4_PER_ROW / kBlockThreads;
     __shared__ __attribute__((aligned(16))) float dtile[TE][SW];
     __shared__ __attribute__((aligned(16))) float xtile[TE][SW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -827,33 +851,50 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_kernel(const 
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float colsum = 0.f;
 
-    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
-        const int64_t r_base = r_begin + tile_id * TE;
-        __syncthreads();
-        constexpr int V4_PER_ROW = SW / 4;
-        for (int idx = tid; idx < TE * V4_PER_ROW; idx += kBlockThreads) {
-            const int c4 = idx % V4_PER_ROW, r = idx / V4_PER_ROW;
-            const int64_t v = r_base + r;
-            const bool live = v < r_end;
-            *reinterpret_cast<float4*>(&dtile[r][c4 * 4]) =
-                live ? *reinterpret_cast<const float4*>(dout + v * ld_dout + js * SW + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&xtile[r][c4 * 4]) =
-                live ? *reinterpret_cast<const float4*>(x + v * ld_x + cs * SW + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dreg[LOADS], xreg[LOADS];
+    int64_t cur = -1, nxt = blockIdx.x;
+    while (true) {
+        if (cur >= 0) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                const int idx = tid + kBlockThreads * k;
+                *reinterpret_cast<float4*>(&dtile[idx / V4_PER_ROW][(idx % V4_PER_ROW) * 4]) = dreg[k];
+                *reinterpret_cast<float4*>(&xtile[idx / V4_PER_ROW][(idx % V4_PER_ROW) * 4]) = xreg[k];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (active) {
-#pragma unroll 4
-            for (int kk = 0; kk < TE / 2; ++kk) {
-                const int e = 2 * kk + half;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dtile[e][jt * 32 + l31], xtile[e][ct * 32 + l31], acc, 0, 0, 0);
+        const bool have_next = nxt < n_tiles;
+        if (have_next) {
+            const int64_t r_base = r_begin + nxt * TE;
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                const int idx = tid + kBlockThreads * k;
+                const int c4 = idx % V4_PER_ROW, r = idx / V4_PER_ROW;
+                const int64_t v = r_base + r;
+                const bool live = v < r_end;
+                dreg[k] = live ? *reinterpret_cast<const float4*>(dout + v * ld_dout + js * SW + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xreg[k] = live ? *reinterpret_cast<const float4*>(x + v * ld_x + cs * SW + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        if (cs == 0 && tid < SW) {
-            float part = 0.f;
+        if (cur >= 0) {
+            if (active) {
+#pragma unroll 4
+                for (int kk = 0; kk < TE / 2; ++kk) {
+                    const int e = 2 * kk + half;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dtile[e][jt * 32 + l31], xtile[e][ct * 32 + l31], acc, 0, 0, 0);
+                }
+            }
+            if (cs == 0 && tid < SW) {
+                float part = 0.f;
 #pragma unroll 8
-            for (int r = 0; r < TE; ++r) part += dtile[r][tid];
-            colsum += part;
+                for (int r = 0; r < TE; ++r) part += dtile[r][tid];
+                colsum += part;
+            }
         }
+        if (!have_next) break;
+        cur = nxt;
+        nxt += gridDim.x;
     }
     const int n_slabs = gridDim.x;
     float* slab = slabs + (static_cast<int64_t>(type) * n_slabs + blockIdx.x) * d * d;
@@ -906,7 +947,7 @@ inline TypePlan make_plan(const int64_t* type_begin, int tile_rows) {
     plan.tile_prefix[3] = acc;
     return plan;
 }
-constexpr int kDenseSlabs = 96;
+constexpr int kDenseSlabs = 256;
 
 int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose,
                     const float* bias, int bias_mask, const int64_t* type_begin, float* out, int64_t ld_out, float* pk, hipStream_t s) {
