@@ -600,6 +600,201 @@ __global__ __launch_bounds__(kBlockThreads) void interact_bwd_members_mfma_kerne
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined forms of the forward and member-gradient kernels for D <= 64 (a whole member row is one staged chunk).
+// Per workgroup iteration: [barrier] registers -> LDS (tile n) [barrier]; issue the row gathers of tile n+1 into
+// registers; multiply tile n out of LDS.  The gathers (ids -> rows: two dependent trips to memory) complete behind 128
+// MFMAs per wave instead of in front of them; the epilogue operands (hoisted first-order sums / member rows) ride the
+// same prefetch and are read back from LDS, so the only global traffic inside the compute phase is the packed-weight
+// stream (double-buffered one k-step ahead) and the result stores.
+// ------------------------------------------------------------------------------------------------
+template <int D, int NBLK>
+__global__ __launch_bounds__(kBlockThreads, 2) void interact_fwd_pipe_kernel(
+    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
+    const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
+    static_assert(D == 32 || D == 64, "pipelined form stages whole rows");
+    using S = TileShape<D>;
+    constexpr int V4 = D / 4, LOADS = 3 * S::TE * V4 / kBlockThreads, PL = LOADS / 3, T_STEPS = D / 8;
+    __shared__ __attribute__((aligned(16))) float tile[3][S::TE][S::STRIDE];
+    __shared__ __attribute__((aligned(16))) float psum[S::TE][D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int et = D == 32 ? wave : (wave & 1);
+    const int jt = D == 32 ? 0 : (wave >> 1);
+    const int row = et * 32 + (lane & 31), half = lane >> 5;
+    const int64_t n_tiles = (n_edges + S::TE - 1) / S::TE;
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wp) + static_cast<int64_t>(jt) * NBLK * T_STEPS * kWave + lane;
+
+    v4f hreg[LOADS], preg[LOADS];
+    int64_t cur = -1, nxt = blockIdx.x;
+    while (true) {
+        if (cur >= 0) {
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&tile[idx / (V4 * S::TE)][(idx / V4) % S::TE][(idx % V4) * 4]) = hreg[x];
+            }
+#pragma unroll
+            for (int x = 0; x < PL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&psum[idx / V4][(idx % V4) * 4]) = (preg[x] + preg[x + PL]) + preg[x + 2 * PL];
+            }
+            __syncthreads();
+        }
+        const bool have_next = nxt < n_tiles;
+        if (have_next) {
+            const int64_t e_base = nxt * S::TE;
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4, r = (idx / V4) % S::TE, m = idx / (V4 * S::TE);
+                const int64_t e = e_base + r;
+                const int64_t node = e < n_edges ? i3[e * 3 + m] : 0;
+                hreg[x] = *reinterpret_cast<const v4f*>(h + node * ld_h + c4 * 4);
+                preg[x] = *reinterpret_cast<const v4f*>(p + node * ld_p + c4 * 4);
+            }
+        }
+        if (cur >= 0) {
+            v16f acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            v4f bcur[NBLK], bnext[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) bcur[b] = wfrag[(b * T_STEPS) * kWave];
+#pragma unroll
+            for (int t = 0; t < T_STEPS; ++t) {
+                if (t + 1 < T_STEPS) {
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) bnext[b] = wfrag[(b * T_STEPS + t + 1) * kWave];
+                }
+                const int col = 8 * t + 4 * half;
+                const v4f au = *reinterpret_cast<const v4f*>(&tile[0][row][col]);
+                const v4f aq = *reinterpret_cast<const v4f*>(&tile[1][row][col]);
+                const v4f ai = *reinterpret_cast<const v4f*>(&tile[2][row][col]);
+                v4f z[4];
+                z[0] = au * aq;
+                z[1] = aq * ai;
+                z[2] = ai * au;
+                z[3] = z[0] * ai;
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z[b][s2], bcur[b][s2], acc, 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) bcur[b] = bnext[b];
+            }
+            const int j = jt * 32 + (lane & 31);
+            const int64_t e_base = cur * S::TE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = et * 32 + acc_row(r, lane);
+                const int64_t e = e_base + er;
+                if (e < n_edges) out[e * ld_out + j] = acc[r] + psum[er][j];
+            }
+        }
+        if (!have_next) break;
+        cur = nxt;
+        nxt += gridDim.x;
+    }
+}
+
+template <int D, int NBLK>
+__global__ __launch_bounds__(kBlockThreads, 2) void interact_bwd_members_pipe_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g, int64_t n_edges) {
+    static_assert(D == 32 || D == 64, "pipelined form stages whole rows");
+    constexpr int ET = D == 32 ? 4 : 2, TE = ET * 32, STRIDE = D + kRowPad, V4 = D / 4, T_STEPS = D / 8;
+    constexpr int DL = TE * V4 / kBlockThreads, HL = 3 * DL;
+    __shared__ __attribute__((aligned(16))) float dtile[TE][STRIDE];
+    __shared__ __attribute__((aligned(16))) float htile[3][TE][D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int et = wave % ET, ct = wave / ET;             // ET * (D/32) == 4 jobs: one per wave
+    const int row = et * 32 + (lane & 31);
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wq) + static_cast<int64_t>(ct) * NBLK * T_STEPS * kWave + lane;
+
+    v4f dreg[DL], hreg[HL];
+    int64_t cur = -1, nxt = blockIdx.x;
+    while (true) {
+        if (cur >= 0) {
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&dtile[idx / V4][(idx % V4) * 4]) = dreg[x];
+            }
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&htile[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hreg[x];
+            }
+            __syncthreads();
+        }
+        const bool have_next = nxt < n_tiles;
+        if (have_next) {
+            const int64_t e_base = nxt * TE;
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + idx / V4;
+                dreg[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4, r = (idx / V4) % TE, m = idx / (V4 * TE);
+                const int64_t e = e_base + r;
+                const int64_t node = e < n_edges ? i3[e * 3 + m] : 0;
+                hreg[x] = *reinterpret_cast<const v4f*>(h + node * ld_h + c4 * 4);
+            }
+        }
+        if (cur >= 0) {
+            v16f acc[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+            v4f bcur[NBLK], bnext[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) bcur[b] = wfrag[(b * T_STEPS) * kWave];
+#pragma unroll
+            for (int t = 0; t < T_STEPS; ++t) {
+                if (t + 1 < T_STEPS) {
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) bnext[b] = wfrag[(b * T_STEPS + t + 1) * kWave];
+                }
+                const v4f a = *reinterpret_cast<const v4f*>(&dtile[row][8 * t + 4 * half]);
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bcur[b][s2], acc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) bcur[b] = bnext[b];
+            }
+            const int c = ct * 32 + (lane & 31);
+            const int64_t e_base = cur * TE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = et * 32 + acc_row(r, lane);
+                const int64_t e = e_base + er;
+                if (e < n_edges) {
+                    const float a = htile[0][er][c], b = htile[1][er][c], dd = htile[2][er][c];
+                    const float z_uq = acc[0][r], z_qi = acc[1][r], z_iu = acc[2][r];
+                    const float z_uqi = NBLK == 4 ? acc[NBLK - 1][r] : 0.f;
+                    float* ge = g + e * 3 * D + c;
+                    ge[0] = z_uq * b + z_iu * dd + z_uqi * (b * dd);
+                    ge[D] = z_uq * a + z_qi * dd + z_uqi * (a * dd);
+                    ge[2 * D] = z_qi * b + z_iu * a + z_uqi * (a * b);
+                }
+            }
+        }
+        if (!have_next) break;
+        cur = nxt;
+        nxt += gridDim.x;
+    }
+}
+
 // weights: workgroup (x, y) owns the SW x (NBLK*SW) sub-block y = (js, cs) of dW for the hyperedge tiles x, x + gridDim.x, ...
 // and keeps it in MFMA accumulators for the whole sweep (contraction index = hyperedge, 2 per MFMA); it ends by writing
 // its partial sub-block into slab x, and slab_reduce_kernel adds the slabs in a fixed order (bitwise reproducible).
@@ -978,6 +1173,7 @@ inline int weight_slabs(int dim) {
     return n < 8 ? 8 : n;
 }
 constexpr int kFwdGrid = 256 * 3;
+constexpr int kPipeGrid = 256 * 2;      // LDS (65-68 KB) admits two pipelined workgroups per CU
 
 // ------------------------------------------------------------------------------------------------
 // Dispatch helpers
@@ -1083,13 +1279,20 @@ void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float
         const int grid = static_cast<int>(std::min<int64_t>(tiles, kFwdGrid));                                              \
         hipLaunchKernelGGL((interact_fwd_mfma_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges); \
     }
+#define IHG_FWD_PIPE(D)                                                                                                     \
+    {                                                                                                                       \
+        const int64_t tiles = (n_edges + TileShape<D>::TE - 1) / TileShape<D>::TE;                                          \
+        const int grid = static_cast<int>(std::min<int64_t>(tiles, kPipeGrid));                                             \
+        hipLaunchKernelGGL((interact_fwd_pipe_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges); \
+    }
     switch (dim) {
-        case 32: IHG_FWD(32) break;
-        case 64: IHG_FWD(64) break;
+        case 32: IHG_FWD_PIPE(32) break;
+        case 64: IHG_FWD_PIPE(64) break;
         case 128: IHG_FWD(128) break;
         default: IHG_FWD(256) break;
     }
 #undef IHG_FWD
+#undef IHG_FWD_PIPE
 }
 
 template <int NBLK>
@@ -1101,13 +1304,20 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + TE - 1) / TE, kFwdGrid));                            \
         hipLaunchKernelGGL((interact_bwd_members_mfma_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
     }
+#define IHG_MEM_PIPE(D)                                                                                                     \
+    {                                                                                                                       \
+        constexpr int TE = D == 32 ? 128 : 64;                                                                              \
+        const int grid = static_cast<int>(std::min<int64_t>((n_edges + TE - 1) / TE, kPipeGrid));                           \
+        hipLaunchKernelGGL((interact_bwd_members_pipe_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
+    }
     switch (dim) {
-        case 32: IHG_MEM(32) break;
-        case 64: IHG_MEM(64) break;
+        case 32: IHG_MEM_PIPE(32) break;
+        case 64: IHG_MEM_PIPE(64) break;
         case 128: IHG_MEM(128) break;
         default: IHG_MEM(256) break;
     }
 #undef IHG_MEM
+#undef IHG_MEM_PIPE
     const int n_slabs = static_cast<int>(std::min<int64_t>(weight_slabs(dim), (n_edges + 63) / 64));
     if (dim == 32) {
         hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<32, NBLK>), dim3(n_slabs, 1), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
