@@ -795,6 +795,339 @@ __global__ __launch_bounds__(kBlockThreads, 2) void interact_bwd_members_pipe_ke
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised forms for D <= 64: one 512-thread workgroup per CU, persistent over hyperedge tiles.
+//   waves 4-7 (one per SIMD)  LOADERS:   gather the member rows (and the epilogue operands) of tile n+2 into registers,
+//                                         drop tile n+1 into the other half of a double-buffered LDS image;
+//   waves 0-3 (one per SIMD)  CONSUMERS: multiply tile n out of LDS on the matrix cores; the weight fragments they need
+//                                         (128 VGPRs at D = 64) are loaded ONCE per kernel and stay in registers.
+// One workgroup barrier per tile.  vmcnt retires loads in issue order, so a wave that both prefetches rows and streams
+// weight fragments stalls its MFMAs behind its own prefetch; splitting the roles gives each role its own counter and
+// leaves the consumers with no loads at all in steady state - their stream is LDS reads, MFMAs and result stores.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWsThreads = 512;
+
+template <int D, int NBLK>
+__global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
+    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
+    const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
+    static_assert(D == 32 || D == 64, "wave-specialised form stages whole rows");
+    using S = TileShape<D>;
+    constexpr int V4 = D / 4, LOADS = 3 * S::TE * V4 / kBlockThreads, PL = LOADS / 3, T_STEPS = D / 8;
+    struct Buffer {
+        float tile[3][S::TE][S::STRIDE];
+        float psum[S::TE][D];
+    };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    const int64_t n_tiles = (n_edges + S::TE - 1) / S::TE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    if (wave >= 4) {
+        // ---------------- loaders ----------------
+        // Member rows run two tiles ahead (registers A / B), the first-order rows one tile ahead: they are issued FIRST
+        // in a trip, so the in-order wait that the next tile's ids need anyway also retires them.
+        const int tid = threadIdx.x - kBlockThreads;
+        v4f ha[LOADS], hb[LOADS], pr[LOADS];
+        int na[LOADS], nb[LOADS];
+        auto load_ids = [&](int64_t tile_id, int (&node)[LOADS]) {
+            const int64_t e_base = tile_id * S::TE;
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + (idx / V4) % S::TE;
+                node[x] = e < n_edges ? i3[e * 3 + idx / (V4 * S::TE)] : 0;
+            }
+        };
+        auto issue_rows = [&](const float* __restrict__ base, int64_t ld, const int (&node)[LOADS], v4f (&dst)[LOADS]) {
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                dst[x] = *reinterpret_cast<const v4f*>(base + static_cast<int64_t>(node[x]) * ld + (idx % V4) * 4);
+            }
+        };
+        auto deposit = [&](Buffer& b, const v4f (&hr)[LOADS]) {
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.tile[idx / (V4 * S::TE)][(idx / V4) % S::TE][(idx % V4) * 4]) = hr[x];
+            }
+#pragma unroll
+            for (int x = 0; x < PL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.psum[idx / V4][(idx % V4) * 4]) = (pr[x] + pr[x + PL]) + pr[x + 2 * PL];
+            }
+        };
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) {
+            load_ids(t, na);
+            issue_rows(h, ld_h, na, ha);
+        }
+        while (t < n_tiles) {
+            issue_rows(p, ld_p, na, pr);
+            if (t + gridDim.x < n_tiles) {
+                load_ids(t + gridDim.x, nb);
+                issue_rows(h, ld_h, nb, hb);
+            }
+            deposit(buf[0], ha);
+            __syncthreads();
+            t += gridDim.x;
+            if (t >= n_tiles) break;
+            issue_rows(p, ld_p, nb, pr);
+            if (t + gridDim.x < n_tiles) {
+                load_ids(t + gridDim.x, na);
+                issue_rows(h, ld_h, na, ha);
+            }
+            deposit(buf[1], hb);
+            __syncthreads();
+            t += gridDim.x;
+        }
+        return;
+    }
+    // ---------------- consumers ----------------
+    const int et = D == 32 ? wave : (wave & 1);
+    const int jt = D == 32 ? 0 : (wave >> 1);
+    const int row = et * 32 + (lane & 31), half = lane >> 5;
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wp) + static_cast<int64_t>(jt) * NBLK * T_STEPS * kWave + lane;
+    v4f wreg[NBLK][T_STEPS];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int ts = 0; ts < T_STEPS; ++ts) wreg[b][ts] = wfrag[(b * T_STEPS + ts) * kWave];
+    const int j = jt * 32 + (lane & 31);
+    int which = 0;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
+        __syncthreads();
+        const Buffer& b = buf[which];
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ts = 0; ts < T_STEPS; ++ts) {
+            const int col = 8 * ts + 4 * half;
+            const v4f au = *reinterpret_cast<const v4f*>(&b.tile[0][row][col]);
+            const v4f aq = *reinterpret_cast<const v4f*>(&b.tile[1][row][col]);
+            const v4f ai = *reinterpret_cast<const v4f*>(&b.tile[2][row][col]);
+            v4f z[4];
+            z[0] = au * aq;
+            z[1] = aq * ai;
+            z[2] = ai * au;
+            z[3] = z[0] * ai;
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z[bk][s2], wreg[bk][ts][s2], acc, 0, 0, 0);
+        }
+        const int64_t e_base = t * S::TE;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int er = et * 32 + acc_row(r, lane);
+            const int64_t e = e_base + er;
+            if (e < n_edges) out[e * ld_out + j] = acc[r] + b.psum[er][j];
+        }
+    }
+}
+
+template <int D, int NBLK>
+__global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g, int64_t n_edges) {
+    static_assert(D == 32 || D == 64, "wave-specialised form stages whole rows");
+    constexpr int ET = D == 32 ? 4 : 2, TE = ET * 32, STRIDE = D + kRowPad, V4 = D / 4, T_STEPS = D / 8;
+    constexpr int DL = TE * V4 / kBlockThreads, HL = 3 * DL;
+    struct Buffer {
+        float dtile[TE][STRIDE];
+        float htile[3][TE][D];
+    };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    if (wave >= 4) {
+        const int tid = threadIdx.x - kBlockThreads;
+        v4f da[DL], ha[HL], db[DL], hb[HL];
+        auto issue = [&](int64_t tile_id, v4f (&dr)[DL], v4f (&hr)[HL]) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + idx / V4;
+                dr[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4, r = (idx / V4) % TE, m = idx / (V4 * TE);
+                const int64_t e = e_base + r;
+                const int64_t node = e < n_edges ? i3[e * 3 + m] : 0;
+                hr[x] = *reinterpret_cast<const v4f*>(h + node * ld_h + c4 * 4);
+            }
+        };
+        auto deposit = [&](Buffer& b, const v4f (&dr)[DL], const v4f (&hr)[HL]) {
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.dtile[idx / V4][(idx % V4) * 4]) = dr[x];
+            }
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.htile[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hr[x];
+            }
+        };
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) issue(t, da, ha);
+        while (t < n_tiles) {
+            if (t + gridDim.x < n_tiles) issue(t + gridDim.x, db, hb);
+            deposit(buf[0], da, ha);
+            __syncthreads();
+            t += gridDim.x;
+            if (t >= n_tiles) break;
+            if (t + gridDim.x < n_tiles) issue(t + gridDim.x, da, ha);
+            deposit(buf[1], db, hb);
+            __syncthreads();
+            t += gridDim.x;
+        }
+        return;
+    }
+    const int et = wave % ET, ct = wave / ET;
+    const int row = et * 32 + (lane & 31), half = lane >> 5;
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wq) + static_cast<int64_t>(ct) * NBLK * T_STEPS * kWave + lane;
+    v4f wreg[NBLK][T_STEPS];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int ts = 0; ts < T_STEPS; ++ts) wreg[b][ts] = wfrag[(b * T_STEPS + ts) * kWave];
+    const int c = ct * 32 + (lane & 31);
+    int which = 0;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
+        __syncthreads();
+        const Buffer& b = buf[which];
+        v16f acc[NBLK];
+#pragma unroll
+        for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bk][r] = 0.f;
+#pragma unroll
+        for (int ts = 0; ts < T_STEPS; ++ts) {
+            const v4f a = *reinterpret_cast<const v4f*>(&b.dtile[row][8 * ts + 4 * half]);
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wreg[bk][ts][s2], acc[bk], 0, 0, 0);
+        }
+        const int64_t e_base = t * TE;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int er = et * 32 + acc_row(r, lane);
+            const int64_t e = e_base + er;
+            if (e < n_edges) {
+                const float a = b.htile[0][er][c], bq = b.htile[1][er][c], dd = b.htile[2][er][c];
+                const float z_uq = acc[0][r], z_qi = acc[1][r], z_iu = acc[2][r];
+                const float z_uqi = NBLK == 4 ? acc[NBLK - 1][r] : 0.f;
+                float* ge = g + e * 3 * D + c;
+                ge[0] = z_uq * bq + z_iu * dd + z_uqi * (bq * dd);
+                ge[D] = z_uq * a + z_qi * dd + z_uqi * (a * dd);
+                ge[2 * D] = z_qi * bq + z_iu * a + z_uqi * (a * bq);
+            }
+        }
+    }
+}
+
+// dW at D = 64 (one 64 x 64 x NBLK sub-block = the whole matrix): same roles; consumers hold NBLK accumulator tiles.
+template <int NBLK>
+__global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ dout, int64_t ld_dout,
+    float* __restrict__ slabs, int64_t n_edges) {
+    constexpr int D = 64, TE = 64, V4 = D / 4, DL = TE * V4 / kBlockThreads, HL = 3 * DL;
+    struct Buffer {
+        float dtile[TE][D];
+        float mtile[3][TE][D];
+    };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    if (wave >= 4) {
+        const int tid = threadIdx.x - kBlockThreads;
+        v4f da[DL], ha[HL], db[DL], hb[HL];
+        auto issue = [&](int64_t tile_id, v4f (&dr)[DL], v4f (&hr)[HL]) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + idx / V4;
+                dr[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4, r = (idx / V4) % TE, m = idx / (V4 * TE);
+                const int64_t e = e_base + r;
+                const int64_t node = e < n_edges ? i3[e * 3 + m] : 0;
+                hr[x] = *reinterpret_cast<const v4f*>(h + node * ld_h + c4 * 4);
+            }
+        };
+        auto deposit = [&](Buffer& b, const v4f (&dr)[DL], const v4f (&hr)[HL]) {
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.dtile[idx / V4][(idx % V4) * 4]) = dr[x];
+            }
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.mtile[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hr[x];
+            }
+        };
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) issue(t, da, ha);
+        while (t < n_tiles) {
+            if (t + gridDim.x < n_tiles) issue(t + gridDim.x, db, hb);
+            deposit(buf[0], da, ha);
+            __syncthreads();
+            t += gridDim.x;
+            if (t >= n_tiles) break;
+            if (t + gridDim.x < n_tiles) issue(t + gridDim.x, da, ha);
+            deposit(buf[1], db, hb);
+            __syncthreads();
+            t += gridDim.x;
+        }
+        return;
+    }
+    const int half = lane >> 5, l31 = lane & 31;
+    const int jt = wave & 1, ct = wave >> 1;
+    v16f acc[NBLK];
+#pragma unroll
+    for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[bk][r] = 0.f;
+    int which = 0;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
+        __syncthreads();
+        const Buffer& b = buf[which];
+#pragma unroll 8
+        for (int kk = 0; kk < TE / 2; ++kk) {
+            const int e = 2 * kk + half;
+            const float a = b.dtile[e][jt * 32 + l31];
+            const float hu = b.mtile[0][e][ct * 32 + l31], hq = b.mtile[1][e][ct * 32 + l31], hi = b.mtile[2][e][ct * 32 + l31];
+            float z[4];
+            z[0] = hu * hq;
+            z[1] = hq * hi;
+            z[2] = hi * hu;
+            z[3] = z[0] * hi;
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z[bk], acc[bk], 0, 0, 0);
+        }
+    }
+    float* slab = slabs + static_cast<int64_t>(blockIdx.x) * D * NBLK * D;
+#pragma unroll
+    for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            slab[static_cast<int64_t>(jt * 32 + acc_row(r, lane)) * NBLK * D + bk * D + ct * 32 + l31] = acc[bk][r];
+}
+
 // weights: workgroup (x, y) owns the SW x (NBLK*SW) sub-block y = (js, cs) of dW for the hyperedge tiles x, x + gridDim.x, ...
 // and keeps it in MFMA accumulators for the whole sweep (contraction index = hyperedge, 2 per MFMA); it ends by writing
 // its partial sub-block into slab x, and slab_reduce_kernel adds the slabs in a fixed order (bitwise reproducible).
@@ -1173,7 +1506,7 @@ inline int weight_slabs(int dim) {
     return n < 8 ? 8 : n;
 }
 constexpr int kFwdGrid = 256 * 3;
-constexpr int kPipeGrid = 256 * 2;      // LDS (65-68 KB) admits two pipelined workgroups per CU
+constexpr int kPipeGrid = 256;          // wave-specialised kernels: one 512-thread workgroup per CU
 
 // ------------------------------------------------------------------------------------------------
 // Dispatch helpers
@@ -1283,7 +1616,7 @@ void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float
     {                                                                                                                       \
         const int64_t tiles = (n_edges + TileShape<D>::TE - 1) / TileShape<D>::TE;                                          \
         const int grid = static_cast<int>(std::min<int64_t>(tiles, kPipeGrid));                                             \
-        hipLaunchKernelGGL((interact_fwd_pipe_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges); \
+        hipLaunchKernelGGL((interact_fwd_ws_kernel<D, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges); \
     }
     switch (dim) {
         case 32: IHG_FWD_PIPE(32) break;
@@ -1308,7 +1641,7 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     {                                                                                                                       \
         constexpr int TE = D == 32 ? 128 : 64;                                                                              \
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + TE - 1) / TE, kPipeGrid));                           \
-        hipLaunchKernelGGL((interact_bwd_members_pipe_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
+        hipLaunchKernelGGL((interact_bwd_members_ws_kernel<D, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
     }
     switch (dim) {
         case 32: IHG_MEM_PIPE(32) break;
@@ -1318,8 +1651,10 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     }
 #undef IHG_MEM
 #undef IHG_MEM_PIPE
-    const int n_slabs = static_cast<int>(std::min<int64_t>(weight_slabs(dim), (n_edges + 63) / 64));
-    if (dim == 32) {
+    const int n_slabs = static_cast<int>(std::min<int64_t>(dim == 64 ? kPipeGrid : weight_slabs(dim), (n_edges + 63) / 64));
+    if (dim == 64) {
+        hipLaunchKernelGGL((interact_bwd_weight_ws_kernel<NBLK>), dim3(n_slabs), dim3(kWsThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
+    } else if (dim == 32) {
         hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<32, NBLK>), dim3(n_slabs, 1), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
     } else {
         const int subs = (dim / 64) * (dim / 64);
