@@ -825,28 +825,39 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
 
     if (wave >= 4) {
         // ---------------- loaders ----------------
-        // Member rows run two tiles ahead (registers A / B), the first-order rows one tile ahead: they are issued FIRST
-        // in a trip, so the in-order wait that the next tile's ids need anyway also retires them.
+        // Schedule per trip (tile T is deposited while the consumers multiply the previous one):
+        //   deposit rows(T)  ->  issue rows(T+g) with the ids fetched a trip ago  ->  issue ids(T+2g)  ->  barrier.
+        // vmcnt retires in issue order, so every wait in a trip is for loads that were issued a whole trip earlier.
         const int tid = threadIdx.x - kBlockThreads;
-        v4f ha[LOADS], hb[LOADS], pr[LOADS];
-        int na[LOADS], nb[LOADS];
-        auto load_ids = [&](int64_t tile_id, int (&node)[LOADS]) {
+        const int64_t g = gridDim.x;
+        v4f hr[LOADS], pr[LOADS];
+        int node[LOADS], node_next[LOADS];
+        auto load_ids = [&](int64_t tile_id, int (&dst)[LOADS]) {
             const int64_t e_base = tile_id * S::TE;
 #pragma unroll
             for (int x = 0; x < LOADS; ++x) {
                 const int idx = tid + kBlockThreads * x;
                 const int64_t e = e_base + (idx / V4) % S::TE;
-                node[x] = e < n_edges ? i3[e * 3 + idx / (V4 * S::TE)] : 0;
+                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * S::TE)] : 0;
             }
         };
-        auto issue_rows = [&](const float* __restrict__ base, int64_t ld, const int (&node)[LOADS], v4f (&dst)[LOADS]) {
+        auto issue_rows = [&](const int (&src)[LOADS]) {
 #pragma unroll
             for (int x = 0; x < LOADS; ++x) {
                 const int idx = tid + kBlockThreads * x;
-                dst[x] = *reinterpret_cast<const v4f*>(base + static_cast<int64_t>(node[x]) * ld + (idx % V4) * 4);
+                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + (idx % V4) * 4);
+                pr[x] = *reinterpret_cast<const v4f*>(p + static_cast<int64_t>(src[x]) * ld_p + (idx % V4) * 4);
             }
         };
-        auto deposit = [&](Buffer& b, const v4f (&hr)[LOADS]) {
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) {
+            load_ids(t, node);
+            issue_rows(node);
+        }
+        if (t + g < n_tiles) load_ids(t + g, node_next);
+        int which = 0;
+        while (t < n_tiles) {
+            Buffer& b = buf[which];
 #pragma unroll
             for (int x = 0; x < LOADS; ++x) {
                 const int idx = tid + kBlockThreads * x;
@@ -857,30 +868,11 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
                 const int idx = tid + kBlockThreads * x;
                 *reinterpret_cast<v4f*>(&b.psum[idx / V4][(idx % V4) * 4]) = (pr[x] + pr[x + PL]) + pr[x + 2 * PL];
             }
-        };
-        int64_t t = blockIdx.x;
-        if (t < n_tiles) {
-            load_ids(t, na);
-            issue_rows(h, ld_h, na, ha);
-        }
-        while (t < n_tiles) {
-            issue_rows(p, ld_p, na, pr);
-            if (t + gridDim.x < n_tiles) {
-                load_ids(t + gridDim.x, nb);
-                issue_rows(h, ld_h, nb, hb);
-            }
-            deposit(buf[0], ha);
+            if (t + g < n_tiles) issue_rows(node_next);
+            if (t + 2 * g < n_tiles) load_ids(t + 2 * g, node_next);
             __syncthreads();
-            t += gridDim.x;
-            if (t >= n_tiles) break;
-            issue_rows(p, ld_p, nb, pr);
-            if (t + gridDim.x < n_tiles) {
-                load_ids(t + gridDim.x, na);
-                issue_rows(h, ld_h, na, ha);
-            }
-            deposit(buf[1], hb);
-            __syncthreads();
-            t += gridDim.x;
+            t += g;
+            which ^= 1;
         }
         return;
     }
@@ -944,9 +936,21 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
     if (wave >= 4) {
+        // loaders: deposit rows(T) -> issue rows(T+g) with ids fetched a trip ago -> issue ids(T+2g) -> barrier
         const int tid = threadIdx.x - kBlockThreads;
-        v4f da[DL], ha[HL], db[DL], hb[HL];
-        auto issue = [&](int64_t tile_id, v4f (&dr)[DL], v4f (&hr)[HL]) {
+        const int64_t g = gridDim.x;
+        v4f dr[DL], hr[HL];
+        int node[HL], node_next[HL];
+        auto load_ids = [&](int64_t tile_id, int (&dst)[HL]) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + (idx / V4) % TE;
+                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * TE)] : 0;
+            }
+        };
+        auto issue_rows = [&](int64_t tile_id, const int (&src)[HL]) {
             const int64_t e_base = tile_id * TE;
 #pragma unroll
             for (int x = 0; x < DL; ++x) {
@@ -957,13 +961,18 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
 #pragma unroll
             for (int x = 0; x < HL; ++x) {
                 const int idx = tid + kBlockThreads * x;
-                const int c4 = idx % V4, r = (idx / V4) % TE, m = idx / (V4 * TE);
-                const int64_t e = e_base + r;
-                const int64_t node = e < n_edges ? i3[e * 3 + m] : 0;
-                hr[x] = *reinterpret_cast<const v4f*>(h + node * ld_h + c4 * 4);
+                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + (idx % V4) * 4);
             }
         };
-        auto deposit = [&](Buffer& b, const v4f (&dr)[DL], const v4f (&hr)[HL]) {
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) {
+            load_ids(t, node);
+            issue_rows(t, node);
+        }
+        if (t + g < n_tiles) load_ids(t + g, node_next);
+        int which = 0;
+        while (t < n_tiles) {
+            Buffer& b = buf[which];
 #pragma unroll
             for (int x = 0; x < DL; ++x) {
                 const int idx = tid + kBlockThreads * x;
@@ -974,19 +983,11 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
                 const int idx = tid + kBlockThreads * x;
                 *reinterpret_cast<v4f*>(&b.htile[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hr[x];
             }
-        };
-        int64_t t = blockIdx.x;
-        if (t < n_tiles) issue(t, da, ha);
-        while (t < n_tiles) {
-            if (t + gridDim.x < n_tiles) issue(t + gridDim.x, db, hb);
-            deposit(buf[0], da, ha);
+            if (t + g < n_tiles) issue_rows(t + g, node_next);
+            if (t + 2 * g < n_tiles) load_ids(t + 2 * g, node_next);
             __syncthreads();
-            t += gridDim.x;
-            if (t >= n_tiles) break;
-            if (t + gridDim.x < n_tiles) issue(t + gridDim.x, da, ha);
-            deposit(buf[1], db, hb);
-            __syncthreads();
-            t += gridDim.x;
+            t += g;
+            which ^= 1;
         }
         return;
     }
@@ -1049,9 +1050,21 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
     if (wave >= 4) {
+        // loaders: deposit rows(T) -> issue rows(T+g) with ids fetched a trip ago -> issue ids(T+2g) -> barrier
         const int tid = threadIdx.x - kBlockThreads;
-        v4f da[DL], ha[HL], db[DL], hb[HL];
-        auto issue = [&](int64_t tile_id, v4f (&dr)[DL], v4f (&hr)[HL]) {
+        const int64_t g = gridDim.x;
+        v4f dr[DL], hr[HL];
+        int node[HL], node_next[HL];
+        auto load_ids = [&](int64_t tile_id, int (&dst)[HL]) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + (idx / V4) % TE;
+                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * TE)] : 0;
+            }
+        };
+        auto issue_rows = [&](int64_t tile_id, const int (&src)[HL]) {
             const int64_t e_base = tile_id * TE;
 #pragma unroll
             for (int x = 0; x < DL; ++x) {
@@ -1062,13 +1075,18 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
 #pragma unroll
             for (int x = 0; x < HL; ++x) {
                 const int idx = tid + kBlockThreads * x;
-                const int c4 = idx % V4, r = (idx / V4) % TE, m = idx / (V4 * TE);
-                const int64_t e = e_base + r;
-                const int64_t node = e < n_edges ? i3[e * 3 + m] : 0;
-                hr[x] = *reinterpret_cast<const v4f*>(h + node * ld_h + c4 * 4);
+                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + (idx % V4) * 4);
             }
         };
-        auto deposit = [&](Buffer& b, const v4f (&dr)[DL], const v4f (&hr)[HL]) {
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) {
+            load_ids(t, node);
+            issue_rows(t, node);
+        }
+        if (t + g < n_tiles) load_ids(t + g, node_next);
+        int which = 0;
+        while (t < n_tiles) {
+            Buffer& b = buf[which];
 #pragma unroll
             for (int x = 0; x < DL; ++x) {
                 const int idx = tid + kBlockThreads * x;
@@ -1079,19 +1097,11 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
                 const int idx = tid + kBlockThreads * x;
                 *reinterpret_cast<v4f*>(&b.mtile[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hr[x];
             }
-        };
-        int64_t t = blockIdx.x;
-        if (t < n_tiles) issue(t, da, ha);
-        while (t < n_tiles) {
-            if (t + gridDim.x < n_tiles) issue(t + gridDim.x, db, hb);
-            deposit(buf[0], da, ha);
+            if (t + g < n_tiles) issue_rows(t + g, node_next);
+            if (t + 2 * g < n_tiles) load_ids(t + 2 * g, node_next);
             __syncthreads();
-            t += gridDim.x;
-            if (t >= n_tiles) break;
-            if (t + gridDim.x < n_tiles) issue(t + gridDim.x, da, ha);
-            deposit(buf[1], db, hb);
-            __syncthreads();
-            t += gridDim.x;
+            t += g;
+            which ^= 1;
         }
         return;
     }
