@@ -203,63 +203,50 @@ __device__ __forceinline__ void apply_out_scale(Frag<VEC>& acc, const float* out
     }
 }
 
+// Work list of one launch: first the fixed-length segments of the split (heavy) rows, then the light rows in `row_order`
+// (decreasing length).  Unit u < n_segments writes partials[u]; unit u >= n_segments writes its output row.
 template <int VEC, int G>
 __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
     const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ids,
     const int32_t* __restrict__ row_order, const float* __restrict__ src_scale, const float* __restrict__ out_scale, int mode,
-    float* __restrict__ out, int64_t ld_out, int64_t n_rows, int dim_vec, int heavy_threshold) {
+    float* __restrict__ out, int64_t ld_out, int64_t n_rows, int dim, int dim_vec, int heavy_threshold,
+    const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments, float* __restrict__ partials) {
     constexpr int GPW = kWave / G;
     const int lane = threadIdx.x & (kWave - 1);
     const int lig = lane & (G - 1);
     const int grp = lane / G;
-    for (int64_t r0 = global_wave_id() * GPW; r0 < n_rows; r0 += global_wave_count() * GPW) {
-        // row_order lists the rows by decreasing length: the groups of one wave then walk lists of (almost) equal
-        // length, and the longest lists start first.
-        int64_t r = r0 + grp;
-        const bool valid = r < n_rows;
-        if (valid && row_order != nullptr) r = row_order[r];
+    const int64_t n_units = n_segments + n_rows;
+    for (int64_t u0 = global_wave_id() * GPW; u0 < n_units; u0 += global_wave_count() * GPW) {
+        const int64_t u = u0 + grp;
         int begin = 0, len = 0;
-        bool heavy = false;
-        if (valid) {
+        float* dst = nullptr;
+        int64_t scale_row = -1;
+        if (u < n_segments) {
+            begin = seg_begin[u];
+            len = seg_end[u] - begin;
+            dst = partials + u * dim;
+        } else if (u < n_units) {
+            int64_t r = u - n_segments;
+            if (row_order != nullptr) r = row_order[r];
             begin = rowptr[r];
             len = rowptr[r + 1] - begin;
-            if (heavy_threshold > 0 && len > heavy_threshold) { heavy = true; len = 0; }
-        }
-        const int wave_len = wave_max_over_groups<G>(len);
-        const int col_iters = (dim_vec + G - 1) / G;
-        for (int ci = 0; ci < col_iters; ++ci) {
-            const int c = ci * G + lig;
-            const int col = c < dim_vec ? c : -1;
-            Frag<VEC> acc = accumulate_list<VEC, G>(src, ld_src, ids, src_scale, begin, len, wave_len, lane, col);
-            if (valid && !heavy && col >= 0) {
-                apply_out_scale<VEC>(acc, out_scale, mode, r);
-                acc.store(out + r * ld_out + col * VEC);
+            if (heavy_threshold > 0 && len > heavy_threshold) {
+                len = 0;                                    // finished from the partials
+            } else {
+                dst = out + r * ld_out;
+                scale_row = r;
             }
         }
-    }
-}
-
-// Split rows: one group per segment -> partials[s,:]; then one group per heavy row adds its partials in order.
-template <int VEC, int G>
-__global__ __launch_bounds__(kBlockThreads) void heavy_partial_kernel(
-    const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ ids, const float* __restrict__ src_scale,
-    const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments,
-    float* __restrict__ partials, int dim, int dim_vec) {
-    constexpr int GPW = kWave / G;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int lig = lane & (G - 1);
-    const int grp = lane / G;
-    for (int64_t s0 = global_wave_id() * GPW; s0 < n_segments; s0 += global_wave_count() * GPW) {
-        const int64_t s = s0 + grp;
-        int begin = 0, len = 0;
-        if (s < n_segments) { begin = seg_begin[s]; len = seg_end[s] - begin; }
         const int wave_len = wave_max_over_groups<G>(len);
         const int col_iters = (dim_vec + G - 1) / G;
         for (int ci = 0; ci < col_iters; ++ci) {
             const int c = ci * G + lig;
             const int col = c < dim_vec ? c : -1;
             Frag<VEC> acc = accumulate_list<VEC, G>(src, ld_src, ids, src_scale, begin, len, wave_len, lane, col);
-            if (s < n_segments && col >= 0) acc.store(partials + s * dim + col * VEC);
+            if (dst != nullptr && col >= 0) {
+                if (scale_row >= 0) apply_out_scale<VEC>(acc, out_scale, mode, scale_row);
+                acc.store(dst + col * VEC);
+            }
         }
     }
 }
@@ -1553,59 +1540,46 @@ int launch_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, 
     return check_launch("ihg_edge_gather_sum");
 }
 
+struct HeavyPlan {
+    const int32_t* seg_begin;
+    const int32_t* seg_end;
+    int64_t n_segments;
+    const int32_t* heavy_rows;
+    const int32_t* heavy_segptr;
+    int64_t n_heavy;
+    float* partials;
+};
+
 template <int VEC, int G>
 void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
-                          const float* src_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim_vec,
-                          int heavy_threshold, hipStream_t stream) {
+                          const float* src_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
+                          int heavy_threshold, const HeavyPlan& hp, hipStream_t stream) {
     constexpr int GPW = kWave / G;
-    const int grid = grid_for_waves((n_rows + GPW - 1) / GPW);
-    hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr,
-                       ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold);
+    const int dim_vec = dim / VEC;
+    const int grid = grid_for_waves((n_rows + hp.n_segments + GPW - 1) / GPW);
+    hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr, ids, row_order,
+                       src_scale, out_scale, mode, out, ld_out, n_rows, dim, dim_vec, heavy_threshold, hp.seg_begin, hp.seg_end,
+                       hp.n_segments, hp.partials);
+    if (hp.n_heavy > 0)
+        hipLaunchKernelGGL((heavy_finish_kernel<VEC, G>), dim3(static_cast<int>(std::min<int64_t>(hp.n_heavy, kMaxBlocks * 4))),
+                           dim3(kBlockThreads), 0, stream, hp.partials, hp.heavy_rows, hp.heavy_segptr, hp.n_heavy, out_scale, mode, out,
+                           ld_out, dim, dim_vec);
 }
 
 template <int VEC>
 int launch_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
                        const float* src_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
-                       int heavy_threshold, hipStream_t stream) {
-    const int dim_vec = dim / VEC;
-    switch (group_lanes(dim_vec)) {
-        case 4: launch_segment_sum_g<VEC, 4>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
-        case 8: launch_segment_sum_g<VEC, 8>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
-        case 16: launch_segment_sum_g<VEC, 16>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
-        case 32: launch_segment_sum_g<VEC, 32>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
-        default: launch_segment_sum_g<VEC, 64>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim_vec, heavy_threshold, stream); break;
+                       int heavy_threshold, const HeavyPlan& hp, hipStream_t stream) {
+#define IHG_K7(G) launch_segment_sum_g<VEC, G>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim, heavy_threshold, hp, stream)
+    switch (group_lanes(dim / VEC)) {
+        case 4: IHG_K7(4); break;
+        case 8: IHG_K7(8); break;
+        case 16: IHG_K7(16); break;
+        case 32: IHG_K7(32); break;
+        default: IHG_K7(64); break;
     }
+#undef IHG_K7
     return check_launch("ihg_node_segment_sum");
-}
-
-template <int VEC, int G>
-void launch_heavy_g(const float* src, int64_t ld_src, const int32_t* ids, const float* src_scale, const float* out_scale, int mode,
-                    const int32_t* seg_begin, const int32_t* seg_end, int64_t n_segments, const int32_t* heavy_rows,
-                    const int32_t* heavy_segptr, int64_t n_heavy, float* partials, float* out, int64_t ld_out, int dim,
-                    int dim_vec, hipStream_t stream) {
-    constexpr int GPW = kWave / G;
-    hipLaunchKernelGGL((heavy_partial_kernel<VEC, G>), dim3(grid_for_waves((n_segments + GPW - 1) / GPW)), dim3(kBlockThreads), 0,
-                       stream, src, ld_src, ids, src_scale, seg_begin, seg_end, n_segments, partials, dim, dim_vec);
-    hipLaunchKernelGGL((heavy_finish_kernel<VEC, G>), dim3(static_cast<int>(std::min<int64_t>(n_heavy, kMaxBlocks * 4))), dim3(kBlockThreads), 0,
-                       stream, partials, heavy_rows, heavy_segptr, n_heavy, out_scale, mode, out, ld_out, dim, dim_vec);
-}
-
-template <int VEC>
-int launch_heavy(const float* src, int64_t ld_src, const int32_t* ids, const float* src_scale, const float* out_scale, int mode,
-                 const int32_t* seg_begin, const int32_t* seg_end, int64_t n_segments, const int32_t* heavy_rows,
-                 const int32_t* heavy_segptr, int64_t n_heavy, float* partials, float* out, int64_t ld_out, int dim,
-                 hipStream_t stream) {
-    const int dim_vec = dim / VEC;
-#define IHG_HEAVY(G) launch_heavy_g<VEC, G>(src, ld_src, ids, src_scale, out_scale, mode, seg_begin, seg_end, n_segments, heavy_rows, heavy_segptr, n_heavy, partials, out, ld_out, dim, dim_vec, stream)
-    switch (group_lanes(dim_vec)) {
-        case 4: IHG_HEAVY(4); break;
-        case 8: IHG_HEAVY(8); break;
-        case 16: IHG_HEAVY(16); break;
-        case 32: IHG_HEAVY(32); break;
-        default: IHG_HEAVY(64); break;
-    }
-#undef IHG_HEAVY
-    return check_launch("ihg_node_segment_sum_heavy");
 }
 
 inline bool scale_mode_ok(int mode, const float* scale) {
@@ -1681,7 +1655,7 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
 // =================================================================================================
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 4; }
+int32_t ihg_abi_version(void) { return 5; }
 
 const char* ihg_last_error_string(void) { return g_error; }
 
@@ -1746,43 +1720,36 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, con
 
 int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
                          const float* src_scale, const float* out_scale, int32_t out_scale_mode, float* out, int64_t ld_out,
-                         int64_t n_rows, int32_t dim, int32_t heavy_threshold, ihg_stream_t stream) {
-    if (n_rows < 0 || dim <= 0 || ld_src < dim || ld_out < dim) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad size");
+                         int64_t n_rows, int32_t dim, int32_t heavy_threshold, const int32_t* seg_begin, const int32_t* seg_end,
+                         int64_t n_segments, const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy, float* partials,
+                         ihg_stream_t stream) {
+    if (n_rows < 0 || dim <= 0 || ld_src < dim || ld_out < dim || n_segments < 0 || n_heavy < 0) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad size");
     if (!scale_mode_ok(out_scale_mode, out_scale)) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad out_scale_mode %d", out_scale_mode);
     if (n_rows == 0) return IHG_OK;
     if (src == nullptr || rowptr == nullptr || ids == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: null pointer");
+    if (n_heavy > 0 && (heavy_threshold <= 0 || seg_begin == nullptr || seg_end == nullptr || heavy_rows == nullptr || heavy_segptr == nullptr || partials == nullptr))
+        return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: incomplete split-row plan");
+    if (n_heavy == 0) {
+        n_segments = 0;
+        heavy_threshold = 0;
+    }
+    const HeavyPlan hp{seg_begin, seg_end, n_segments, heavy_rows, heavy_segptr, n_heavy, partials};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out);
-    return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, s)
-                : launch_segment_sum<1>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, s);
-}
-
-int ihg_node_segment_sum_heavy(const float* src, int64_t ld_src, const int32_t* ids, const float* src_scale, const float* out_scale,
-                               int32_t out_scale_mode, const int32_t* seg_begin, const int32_t* seg_end, int64_t n_segments,
-                               const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy, float* partials,
-                               float* out, int64_t ld_out, int32_t dim, ihg_stream_t stream) {
-    if (n_segments < 0 || n_heavy < 0 || dim <= 0 || ld_src < dim || ld_out < dim) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum_heavy: bad size");
-    if (!scale_mode_ok(out_scale_mode, out_scale)) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum_heavy: bad out_scale_mode %d", out_scale_mode);
-    if (n_heavy == 0) return IHG_OK;
-    if (src == nullptr || ids == nullptr || seg_begin == nullptr || seg_end == nullptr || heavy_rows == nullptr || heavy_segptr == nullptr ||
-        partials == nullptr || out == nullptr)
-        return fail(IHG_ERR_INVALID, "ihg_node_segment_sum_heavy: null pointer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out) && aligned16(partials);
-    return wide ? launch_heavy<4>(src, ld_src, ids, src_scale, out_scale, out_scale_mode, seg_begin, seg_end, n_segments, heavy_rows, heavy_segptr, n_heavy, partials, out, ld_out, dim, s)
-                : launch_heavy<1>(src, ld_src, ids, src_scale, out_scale, out_scale_mode, seg_begin, seg_end, n_segments, heavy_rows, heavy_segptr, n_heavy, partials, out, ld_out, dim, s);
+    const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out) && (n_heavy == 0 || aligned16(partials));
+    return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, s)
+                : launch_segment_sum<1>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, s);
 }
 
 int ihg_bag_mean_fwd(const float* table, int64_t ld_table, const int32_t* bag_ptr, const int32_t* words, const float* bag_len,
                      float* out, int64_t ld_out, int64_t n_bags, int32_t dim, ihg_stream_t stream) {
     if (bag_len == nullptr && n_bags > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_fwd: null bag_len");
-    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, stream);
+    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, stream);
 }
 
 int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr, const int32_t* word_bags, const float* inv_len,
                      float* dtable, int64_t ld_dtable, int64_t n_table_rows, int32_t dim, ihg_stream_t stream) {
     if (inv_len == nullptr && n_table_rows > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_bwd: null inv_len");
-    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, nullptr, inv_len, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, stream);
+    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, nullptr, inv_len, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, stream);
 }
 
 int64_t ihg_interact_fwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order) {

@@ -126,6 +126,7 @@ class CsrRows:
         self.device = parent.device
         self.heavy_threshold = 0
         self.n_heavy = 0
+        self.n_segments = 0
         self.row_order = None
 
 

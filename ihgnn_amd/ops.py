@@ -7,7 +7,7 @@ there is no CPU implementation to fall back to.
 Operator               forward kernel              backward kernel(s)
 ---------------------  --------------------------  ------------------------------------------------
 edge_gather_sum  (K5)  ihg_edge_gather_sum         ihg_node_segment_sum   (its transpose)
-node_segment_sum (K7)  ihg_node_segment_sum[_heavy] ihg_edge_gather_sum    (its transpose)
+node_segment_sum (K7)  ihg_node_segment_sum         ihg_edge_gather_sum    (its transpose)
 bag_mean         (K2)  ihg_bag_mean_fwd            ihg_bag_mean_bwd
 interact     (K5+K6)   ihg_interact_fwd            ihg_interact_bwd + 4x ihg_node_segment_sum
 """
@@ -80,17 +80,14 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
     dim = int(src.shape[1])
     if out is None:
         out = torch.empty(csr.n_rows, dim, dtype=torch.float32, device=src.device)
-    threshold = csr.heavy_threshold if csr.n_heavy > 0 else 0
+    heavy = csr.n_heavy > 0
     with profiler.kernel('node_segment_sum', csr.n_rows, dim):
-        _lib.check(lib.ihg_node_segment_sum(_ptr(src), _ld(src), _ptr(csr.ptr), _ptr(csr.ids), _ptr(csr.row_order), _ptr(src_scale), _ptr(out_scale),
-                                            mode, _ptr(out), _ld(out), csr.n_rows, dim, threshold, _stream()),
-                   'ihg_node_segment_sum')
-    if csr.n_heavy > 0:
-        with profiler.kernel('node_segment_sum_heavy', csr.n_heavy, dim):
-            _lib.check(lib.ihg_node_segment_sum_heavy(
-                _ptr(src), _ld(src), _ptr(csr.ids), _ptr(src_scale), _ptr(out_scale), mode,
-                _ptr(csr.seg_begin), _ptr(csr.seg_end), csr.n_segments, _ptr(csr.heavy_rows), _ptr(csr.heavy_segptr),
-                csr.n_heavy, _ptr(csr.partials(dim)), _ptr(out), _ld(out), dim, _stream()), 'ihg_node_segment_sum_heavy')
+        _lib.check(lib.ihg_node_segment_sum(
+            _ptr(src), _ld(src), _ptr(csr.ptr), _ptr(csr.ids), _ptr(csr.row_order), _ptr(src_scale), _ptr(out_scale), mode,
+            _ptr(out), _ld(out), csr.n_rows, dim, csr.heavy_threshold if heavy else 0,
+            _ptr(csr.seg_begin) if heavy else None, _ptr(csr.seg_end) if heavy else None, csr.n_segments if heavy else 0,
+            _ptr(csr.heavy_rows) if heavy else None, _ptr(csr.heavy_segptr) if heavy else None, csr.n_heavy,
+            _ptr(csr.partials(dim)) if heavy else None, _stream()), 'ihg_node_segment_sum')
     return out
 
 

@@ -81,8 +81,8 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3,
 /* ------------------------------------------------------------------------------------------------
  * DEVICE: hyperedge -> node segment-sum (K7 + K8).
  *   out[r,:] = scale_op( sum_{k in [rowptr[r], rowptr[r+1])} w(ids[k]) * src[ids[k],:] , out_scale[r] )
- * with w(j) = src_scale[j] (or 1).  Rows longer than `heavy_threshold` entries are SKIPPED here and must be
- * finished by ihg_node_segment_sum_heavy (pass heavy_threshold <= 0 to process every row here).
+ * with w(j) = src_scale[j] (or 1).  Rows longer than `heavy_threshold` entries go through the split-row plan below
+ * (pass n_heavy = 0 to sum every row with a single lane group).
  * `row_order` (optional, [n_rows]) is the order in which rows are handed to lane groups - a permutation sorted by
  * decreasing row length keeps the groups of one wave equally busy; NULL = natural order.  Results do not depend on it.
  * Replaces: thsp.matmul(self.incidence, edge_features) and Dv^-1 * / Dv^-1/2 * (Models/GnnLayers.py:151-152,
@@ -93,19 +93,16 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
                          const int32_t* row_order,
                          const float* src_scale, const float* out_scale, int32_t out_scale_mode,
                          float* out, int64_t ld_out, int64_t n_rows, int32_t dim,
-                         int32_t heavy_threshold, ihg_stream_t stream);
-
-/* Split-row companion for skewed (power-law) degree distributions.  The host cuts every row longer than the
- * threshold into segments [seg_begin, seg_end) of the `ids` array; each segment is summed by its own lane
- * group into partials[s,:] (workspace, n_segments x dim floats), then each heavy row adds its partials in
- * segment order (bitwise reproducible, no float atomics) and applies out_scale.
- *   heavy_rows [n_heavy] row ids; heavy_segptr [n_heavy+1] offsets into the segment arrays.
+                         int32_t heavy_threshold,
+                         const int32_t* seg_begin, const int32_t* seg_end, int64_t n_segments,
+                         const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy,
+                         float* partials, ihg_stream_t stream);
+/* Split rows (skewed / power-law degree distributions): the host cuts every row longer than `heavy_threshold` into
+ * segments [seg_begin, seg_end) of the `ids` array.  The SAME launch sums every segment with its own lane group into
+ * partials[s,:] (workspace, n_segments x dim floats) next to the light rows, then a second small kernel adds each heavy
+ * row's partials in a fixed order (bitwise reproducible, no float atomics) and applies out_scale.
+ *   heavy_rows [n_heavy] row ids; heavy_segptr [n_heavy+1] offsets into the segment arrays.  n_heavy == 0: no plan.
  */
-int ihg_node_segment_sum_heavy(const float* src, int64_t ld_src, const int32_t* ids,
-                               const float* src_scale, const float* out_scale, int32_t out_scale_mode,
-                               const int32_t* seg_begin, const int32_t* seg_end, int64_t n_segments,
-                               const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy,
-                               float* partials, float* out, int64_t ld_out, int32_t dim, ihg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DEVICE: query embedding bag, mode='mean' (K2).  Replaces nn.EmbeddingBag(mode='mean') forward/backward,
