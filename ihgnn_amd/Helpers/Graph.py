@@ -58,21 +58,22 @@ class PpsHyperGraph(PpsGraph):
 
     @property
     def I3(self) -> Tensor:
-        """``[E,3]`` int64 global member ids (``Graph.py:129``)."""
+        """``[E,3]`` int64 global member ids in FILE order (``Graph.py:129``); the kernels' own copy is ``layout.i3``."""
         if self._i3_long is None:
-            self._i3_long = self.layout.i3.long()
+            lay = self.layout
+            offs = np.array([0, lay.user_count, lay.user_count + lay.query_count], dtype=np.int64)
+            self._i3_long = torch.from_numpy(lay.triples_file_order + offs).to(lay.device)
         return self._i3_long
 
     @property
     def Adjacency(self) -> Tensor:
-        """Coalesced ``[N x E]`` unit-valued sparse COO incidence (``Graph.py:123-128``)."""
+        """Coalesced ``[N x E]`` unit-valued sparse COO incidence with file-order hyperedge numbering (``Graph.py:123-128``)."""
         if self._adjacency is None:
-            csr = self.layout.node_csr
-            lens = np.diff(csr.ptr_host.astype(np.int64))
-            rows = torch.from_numpy(np.repeat(np.arange(csr.n_rows, dtype=np.int64), lens))
-            cols = torch.from_numpy(csr.ids_host.astype(np.int64))
-            adj = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.ones(csr.nnz, dtype=torch.float32),
-                                          (csr.n_rows, self.EdgeCount)).coalesce()
+            i3 = self.I3.cpu()
+            rows = i3.reshape(-1)
+            cols = torch.arange(self.EdgeCount, dtype=torch.int64).repeat_interleave(3)
+            adj = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.ones(3 * self.EdgeCount, dtype=torch.float32),
+                                          (self.layout.node_count, self.EdgeCount)).coalesce()
             self._adjacency = adj.to(self.layout.device)
         return self._adjacency
 

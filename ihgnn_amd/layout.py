@@ -19,8 +19,10 @@ import torch
 
 from . import _lib
 
-HEAVY_THRESHOLD = 128      # rows longer than this are split ...
-HEAVY_CHUNK = 128          # ... into segments of this many ids (bounds every lane group's serial chain)
+import os
+
+HEAVY_THRESHOLD = int(os.environ.get('IHG_HEAVY_THRESHOLD', 256))   # rows longer than this are split ...
+HEAVY_CHUNK = int(os.environ.get('IHG_HEAVY_CHUNK', 128))           # ... into segments of this many ids (bounds every lane group's serial chain)
 
 
 def _as_ptr(a: np.ndarray, ctype):
@@ -134,9 +136,22 @@ class IncidenceLayout:
     """The (user, query, item) hypergraph in kernel layout."""
 
     def __init__(self, triples: np.ndarray, user_count: int, query_count: int, item_count: int, device: torch.device,
-                 heavy_threshold: int = HEAVY_THRESHOLD):
+                 heavy_threshold: int = HEAVY_THRESHOLD, edge_order: str = os.environ.get('IHG_EDGE_ORDER', 'user')):
+        """``edge_order='user'`` renumbers the hyperedges by (user, file position) inside this layout: consecutive
+        hyperedges then share their user row (the largest node table) and every user's incidence list is one contiguous
+        run of edge-feature rows.  Hyperedge numbering is internal to the kernels - nothing outside the layout sees it
+        (``triples_file_order`` keeps the caller's order); results are order-independent up to fp32 re-association of
+        the per-node sums.  ``edge_order='file'`` keeps the reference's numbering (Graph.py:107-118)."""
         lib = _lib.load()
         triples = np.ascontiguousarray(np.asarray(triples, dtype=np.int64).reshape(-1, 3))
+        self.triples_file_order = triples
+        if edge_order == 'user' and triples.shape[0] > 1:
+            self.edge_perm = np.argsort(triples[:, 0], kind='stable')        # new position -> file position
+            triples = np.ascontiguousarray(triples[self.edge_perm])
+        elif edge_order in ('user', 'file'):
+            self.edge_perm = None
+        else:
+            raise ValueError(f'unknown edge_order {edge_order!r}')
         self.user_count, self.query_count, self.item_count = int(user_count), int(query_count), int(item_count)
         self.node_count = n = self.user_count + self.query_count + self.item_count
         self.edge_count = e = int(triples.shape[0])

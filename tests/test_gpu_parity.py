@@ -27,11 +27,11 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def make_layout(U, Q, I, E, seed, distribution='uniform', heavy_threshold=1024):
+def make_layout(U, Q, I, E, seed, distribution='uniform', heavy_threshold=1024, edge_order='file'):
     from ihgnn_amd import synth
     from ihgnn_amd.layout import IncidenceLayout
     w = synth.draw(U, Q, I, 10, E, seed=seed, distribution=distribution, exponent=1.3)
-    return w, IncidenceLayout(w.triples, U, Q, I, dev(), heavy_threshold=heavy_threshold)
+    return w, IncidenceLayout(w.triples, U, Q, I, dev(), heavy_threshold=heavy_threshold, edge_order=edge_order)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -146,6 +146,26 @@ def test_bag_mean_forward_backward(dim):
     got.backward(cot.to(dev()))
     assert rel(got, want) <= RTOL_SUM and rel(tg.grad, table.grad) <= RTOL_SUM
     assert (tg.grad[0] == 0).all()                        # padding row never indexed
+
+
+def test_user_ordered_hyperedge_numbering_is_equivalent():
+    """The layout's internal renumbering (hyperedges sorted by user) only permutes edge-feature rows."""
+    from ihgnn_amd import ops
+    w, by_file = make_layout(40, 7, 60, 900, seed=3, edge_order='file')
+    _, by_user = make_layout(40, 7, 60, 900, seed=3, edge_order='user')
+    perm = torch.from_numpy(by_user.edge_perm).to(dev())
+    assert by_file.edge_perm is None and (np.diff(by_user.i3_host[:, 0]) >= 0).all()
+    x = torch.randn(by_file.node_count, 64, device=dev())
+    ef_file = ops.edge_gather_sum_raw(x, by_file.i3)
+    ef_user = ops.edge_gather_sum_raw(x, by_user.i3)
+    assert torch.equal(ef_user, ef_file[perm])
+    y_file = ops.node_segment_sum_raw(ef_file, by_file.node_csr, None, by_file.inv_deg, 1)
+    y_user = ops.node_segment_sum_raw(ef_user, by_user.node_csr, None, by_user.inv_deg, 1)
+    assert rel(y_user, y_file) <= RTOL_SUM
+    wa = torch.randn(64, 7 * 64, device=dev()) / 20
+    out_file = ops.interact(x, x, wa, by_file, 3)
+    out_user = ops.interact(x, x, wa, by_user, 3)
+    assert rel(out_user, out_file[perm]) <= RTOL_SUM
 
 
 @pytest.mark.parametrize('dim', [32, 64, 128, 256])

@@ -62,6 +62,7 @@ def test_hypergraph_matches_reference(f1):
 def test_csr_is_node_major_sorted_and_complete():
     w = synth.draw(50, 20, 70, 30, 2000, seed=3, distribution='powerlaw')
     lay = IncidenceLayout(w.triples, 50, 20, 70, CPU, heavy_threshold=64)
+    assert (np.diff(lay.i3_host[:, 0]) >= 0).all() and np.array_equal(lay.i3_host[:, 0], w.triples[lay.edge_perm, 0])   # renumbered by user
     ptr, ids = lay.node_csr.ptr_host, lay.node_csr.ids_host
     i3 = lay.i3_host
     assert ptr[0] == 0 and ptr[-1] == 3 * 2000 and (np.diff(ptr) >= 0).all()
