@@ -878,9 +878,12 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
         __syncthreads();
         const Buffer& b = buf[which];
-        v16f acc;
+        // one accumulator per product block: consecutive MFMAs are independent, the four partial tiles are added at the end
+        v16f acc4[NBLK];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc4[bk][r] = 0.f;
 #pragma unroll
         for (int ts = 0; ts < T_STEPS; ++ts) {
             const int col = 8 * ts + 4 * half;
@@ -893,10 +896,14 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
             z[2] = ai * au;
             z[3] = z[0] * ai;
 #pragma unroll
-            for (int bk = 0; bk < NBLK; ++bk)
+            for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z[bk][s2], wreg[bk][ts][s2], acc, 0, 0, 0);
+                for (int bk = 0; bk < NBLK; ++bk)
+                    acc4[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[bk][s2], wreg[bk][ts][s2], acc4[bk], 0, 0, 0);
         }
+        v16f acc;
+        if (NBLK == 4) acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[NBLK - 1]);
+        else acc = (acc4[0] + acc4[1]) + acc4[2];
         const int64_t e_base = t * S::TE;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1000,9 +1007,9 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
         for (int ts = 0; ts < T_STEPS; ++ts) {
             const v4f a = *reinterpret_cast<const v4f*>(&b.dtile[row][8 * ts + 4 * half]);
 #pragma unroll
-            for (int bk = 0; bk < NBLK; ++bk)
+            for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wreg[bk][ts][s2], acc[bk], 0, 0, 0);
+                for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wreg[bk][ts][s2], acc[bk], 0, 0, 0);
         }
         const int64_t e_base = t * TE;
 #pragma unroll
