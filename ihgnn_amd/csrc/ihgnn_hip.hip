@@ -878,38 +878,44 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
     for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
         __syncthreads();
         const Buffer& b = buf[which];
-        // one accumulator per product block: consecutive MFMAs are independent, the four partial tiles are added at the end
-        v16f acc4[NBLK];
+        v16f acc;
 #pragma unroll
-        for (int bk = 0; bk < NBLK; ++bk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc4[bk][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // A operands one k-step ahead of the MFMAs that use them: the LDS round trip hides behind 16 MFMAs
+        v4f au = *reinterpret_cast<const v4f*>(&b.tile[0][row][4 * half]);
+        v4f aq = *reinterpret_cast<const v4f*>(&b.tile[1][row][4 * half]);
+        v4f ai = *reinterpret_cast<const v4f*>(&b.tile[2][row][4 * half]);
 #pragma unroll
         for (int ts = 0; ts < T_STEPS; ++ts) {
-            const int col = 8 * ts + 4 * half;
-            const v4f au = *reinterpret_cast<const v4f*>(&b.tile[0][row][col]);
-            const v4f aq = *reinterpret_cast<const v4f*>(&b.tile[1][row][col]);
-            const v4f ai = *reinterpret_cast<const v4f*>(&b.tile[2][row][col]);
             v4f z[4];
             z[0] = au * aq;
             z[1] = aq * ai;
             z[2] = ai * au;
             z[3] = z[0] * ai;
+            if (ts + 1 < T_STEPS) {
+                const int col = 8 * (ts + 1) + 4 * half;
+                au = *reinterpret_cast<const v4f*>(&b.tile[0][row][col]);
+                aq = *reinterpret_cast<const v4f*>(&b.tile[1][row][col]);
+                ai = *reinterpret_cast<const v4f*>(&b.tile[2][row][col]);
+            }
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
+            for (int bk = 0; bk < NBLK; ++bk)
 #pragma unroll
-                for (int bk = 0; bk < NBLK; ++bk)
-                    acc4[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[bk][s2], wreg[bk][ts][s2], acc4[bk], 0, 0, 0);
+                for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z[bk][s2], wreg[bk][ts][s2], acc, 0, 0, 0);
         }
-        v16f acc;
-        if (NBLK == 4) acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[NBLK - 1]);
-        else acc = (acc4[0] + acc4[1]) + acc4[2];
+        // epilogue: all 16 first-order sums are read from LDS in one batch, then added and stored
         const int64_t e_base = t * S::TE;
+        float first[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int er = et * 32 + acc_row(r, lane);
-            const int64_t e = e_base + er;
-            if (e < n_edges) out[e * ld_out + j] = acc[r] + b.psum[er][j];
+        for (int r = 0; r < 16; ++r) first[r] = b.psum[et * 32 + acc_row(r, lane)][j];
+        float* orow = out + (e_base + et * 32) * ld_out + j;
+        if (e_base + S::TE <= n_edges) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[r] + first[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (e_base + et * 32 + acc_row(r, lane) < n_edges) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[r] + first[r];
         }
     }
 }
@@ -1003,27 +1009,44 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
         for (int bk = 0; bk < NBLK; ++bk)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[bk][r] = 0.f;
+        v4f a = *reinterpret_cast<const v4f*>(&b.dtile[row][4 * half]);
 #pragma unroll
         for (int ts = 0; ts < T_STEPS; ++ts) {
-            const v4f a = *reinterpret_cast<const v4f*>(&b.dtile[row][8 * ts + 4 * half]);
+            const v4f a_now = a;
+            if (ts + 1 < T_STEPS) a = *reinterpret_cast<const v4f*>(&b.dtile[row][8 * (ts + 1) + 4 * half]);
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-                for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], wreg[bk][ts][s2], acc[bk], 0, 0, 0);
+                for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_now[s2], wreg[bk][ts][s2], acc[bk], 0, 0, 0);
         }
+        // epilogue in batches of four rows: 12 LDS reads in flight, then the product rule and 12 stores
         const int64_t e_base = t * TE;
+        const bool full = e_base + TE <= n_edges;
+        float* gbase = g + (e_base + et * 32) * 3 * D + c;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int er = et * 32 + acc_row(r, lane);
-            const int64_t e = e_base + er;
-            if (e < n_edges) {
-                const float a = b.htile[0][er][c], bq = b.htile[1][er][c], dd = b.htile[2][er][c];
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+            float hu[4], hq[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int er = et * 32 + acc_row(r0 + k, lane);
+                hu[k] = b.htile[0][er][c];
+                hq[k] = b.htile[1][er][c];
+                hi[k] = b.htile[2][er][c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = r0 + k;
                 const float z_uq = acc[0][r], z_qi = acc[1][r], z_iu = acc[2][r];
                 const float z_uqi = NBLK == 4 ? acc[NBLK - 1][r] : 0.f;
-                float* ge = g + e * 3 * D + c;
-                ge[0] = z_uq * bq + z_iu * dd + z_uqi * (bq * dd);
-                ge[D] = z_uq * a + z_qi * dd + z_uqi * (a * dd);
-                ge[2 * D] = z_qi * bq + z_iu * a + z_uqi * (a * bq);
+                const float gu = z_uq * hq[k] + z_iu * hi[k] + z_uqi * (hq[k] * hi[k]);
+                const float gq = z_uq * hu[k] + z_qi * hi[k] + z_uqi * (hu[k] * hi[k]);
+                const float gi = z_qi * hq[k] + z_iu * hu[k] + z_uqi * (hu[k] * hq[k]);
+                if (full || e_base + et * 32 + acc_row(r, lane) < n_edges) {
+                    float* ge = gbase + static_cast<int64_t>(acc_row(r, lane)) * 3 * D;
+                    ge[0] = gu;
+                    ge[D] = gq;
+                    ge[2 * D] = gi;
+                }
             }
         }
     }
