@@ -1335,50 +1335,104 @@ __global__ __launch_bounds__(kBlockThreads) void pack_dense_kernel(const float* 
     }
 }
 
+// Register-prefetch pipeline: the rows of tile n+1 are fetched while tile n is multiplied.  vmcnt retires in issue order, so
+// the (tiny, cache-resident) weight fragments of the current tile are pulled into registers BEFORE the prefetch is issued;
+// D = 256 would need 512 registers for that and keeps the plain fetch-then-multiply order.
 template <int D>
 __global__ __launch_bounds__(kBlockThreads) void row_gemm_kernel(const float* __restrict__ in, int64_t ld_in, const float* __restrict__ pk,
                                                                  int64_t pk_type_stride, const float* __restrict__ bias, int bias_mask,
                                                                  TypePlan plan, float* __restrict__ out, int64_t ld_out) {
     constexpr int ET = D == 32 ? 4 : 2, TE = ET * 32, STRIDE = D + kRowPad, JOBS = ET * (D / 32);
+    constexpr int V4_PER_ROW = D / 4, LOADS = TE * V4_PER_ROW / kBlockThreads, T_STEPS = D / 8;
+    constexpr int JOBS_PER_WAVE = JOBS / kWavesPerBlock;
+    constexpr bool HOLD_B = D <= 128;
     __shared__ __attribute__((aligned(16))) float xt[TE][STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int total_tiles = plan.tile_prefix[3];
-    for (int tile_id = blockIdx.x; tile_id < total_tiles; tile_id += gridDim.x) {
-        const int type = tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0);
-        const int64_t r_base = plan.begin[type] + static_cast<int64_t>(tile_id - plan.tile_prefix[type]) * TE;
-        const int64_t r_end = plan.begin[type + 1];
-        const v4f* pk4 = reinterpret_cast<const v4f*>(pk + type * pk_type_stride);
-        __syncthreads();
-        constexpr int V4_PER_ROW = D / 4;
-        for (int idx = tid; idx < TE * V4_PER_ROW; idx += kBlockThreads) {
-            const int c4 = idx % V4_PER_ROW, r = idx / V4_PER_ROW;
-            const int64_t v = r_base + r;
-            const float4 val = v < r_end ? *reinterpret_cast<const float4*>(in + v * ld_in + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&xt[r][c4 * 4]) = val;
-        }
-        __syncthreads();
-        const bool with_bias = bias != nullptr && ((bias_mask >> type) & 1);
-        for (int job = wave; job < JOBS; job += kWavesPerBlock) {
-            const int et = job % ET, ct = job / ET;
-            const int row = et * 32 + (lane & 31);
-            v16f acc;
+    auto tile_type = [&](int tile_id) { return tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0); };
+
+    v4f xreg[LOADS];
+    v4f breg[HOLD_B ? JOBS_PER_WAVE : 1][HOLD_B ? T_STEPS : 1];
+    int cur = -1, nxt = blockIdx.x;
+    while (true) {
+        if (cur >= 0) {
+            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 4
-            for (int t = 0; t < D / 8; ++t) {
-                const v4f a = *reinterpret_cast<const v4f*>(&xt[row][8 * t + 4 * half]);
-                const v4f b = pk4[(static_cast<int64_t>(ct) * (D / 8) + t) * kWave + lane];
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2], acc, 0, 0, 0);
+            for (int k = 0; k < LOADS; ++k) {
+                const int idx = tid + kBlockThreads * k;
+                *reinterpret_cast<v4f*>(&xt[idx / V4_PER_ROW][(idx % V4_PER_ROW) * 4]) = xreg[k];
             }
-            const int c = ct * 32 + (lane & 31);
-            const float bv = with_bias ? bias[c] : 0.f;
+            __syncthreads();
+            if (HOLD_B) {
+                const v4f* pk4 = reinterpret_cast<const v4f*>(pk + tile_type(cur) * pk_type_stride) + lane;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t v = r_base + et * 32 + acc_row(r, lane);
-                if (v < r_end) out[v * ld_out + c] = acc[r] + bv;
+                for (int jw = 0; jw < JOBS_PER_WAVE; ++jw) {
+                    const int ct = (wave + jw * kWavesPerBlock) / ET;
+#pragma unroll
+                    for (int t = 0; t < T_STEPS; ++t) breg[jw][t] = pk4[(static_cast<int64_t>(ct) * T_STEPS + t) * kWave];
+                }
             }
         }
+        const bool have_next = nxt < total_tiles;
+        if (have_next && (HOLD_B || cur < 0)) {
+            const int type = tile_type(nxt);
+            const int64_t r_base = plan.begin[type] + static_cast<int64_t>(nxt - plan.tile_prefix[type]) * TE;
+            const int64_t r_end = plan.begin[type + 1];
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                const int idx = tid + kBlockThreads * k;
+                const int64_t v = r_base + idx / V4_PER_ROW;
+                xreg[k] = v < r_end ? *reinterpret_cast<const v4f*>(in + v * ld_in + (idx % V4_PER_ROW) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (cur >= 0) {
+            const int type = tile_type(cur);
+            const int64_t r_base = plan.begin[type] + static_cast<int64_t>(cur - plan.tile_prefix[type]) * TE;
+            const int64_t r_end = plan.begin[type + 1];
+            const v4f* pk4 = reinterpret_cast<const v4f*>(pk + type * pk_type_stride) + lane;
+            const bool with_bias = bias != nullptr && ((bias_mask >> type) & 1);
+#pragma unroll
+            for (int jw = 0; jw < JOBS_PER_WAVE; ++jw) {
+                const int job = wave + jw * kWavesPerBlock;
+                const int et = job % ET, ct = job / ET;
+                const int row = et * 32 + (lane & 31);
+                v16f acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < T_STEPS; ++t) {
+                    const v4f a = *reinterpret_cast<const v4f*>(&xt[row][8 * t + 4 * half]);
+                    const v4f bf = HOLD_B ? breg[HOLD_B ? jw : 0][HOLD_B ? t : 0] : pk4[(static_cast<int64_t>(ct) * T_STEPS + t) * kWave];
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bf[s2], acc, 0, 0, 0);
+                }
+                const int c = ct * 32 + (lane & 31);
+                const float bv = with_bias ? bias[c] : 0.f;
+                float* orow = out + (r_base + et * 32) * ld_out + c;
+                if (r_base + TE <= r_end) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[r] + bv;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (r_base + et * 32 + acc_row(r, lane) < r_end) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[r] + bv;
+                }
+            }
+        }
+        if (!HOLD_B && cur >= 0 && have_next) {           // plain order for D = 256: fetch the next tile after the multiply
+            const int type = tile_type(nxt);
+            const int64_t r_base = plan.begin[type] + static_cast<int64_t>(nxt - plan.tile_prefix[type]) * TE;
+            const int64_t r_end = plan.begin[type + 1];
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                const int idx = tid + kBlockThreads * k;
+                const int64_t v = r_base + idx / V4_PER_ROW;
+                xreg[k] = v < r_end ? *reinterpret_cast<const v4f*>(in + v * ld_in + (idx % V4_PER_ROW) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (!have_next) break;
+        cur = nxt;
+        nxt += gridDim.x;
     }
 }
 
