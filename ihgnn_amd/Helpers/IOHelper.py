@@ -11,6 +11,7 @@ _ANSI = re.compile('\033\\[0;*[0-9]*m')
 class IOHelper:
     log_filename = None
     _warned = False
+    quiet = False                      # set on non-chief ranks of a multi-process run
 
     @staticmethod
     def GetAllContent(filename, encoding='utf-8'):
@@ -47,6 +48,8 @@ class IOHelper:
 
     @staticmethod
     def LogPrint(message_no_endline='', put_time_in_single_line=False):
+        if IOHelper.quiet:
+            return
         text = message_no_endline
         if text != '':
             body = text.lstrip('\n')

@@ -31,29 +31,61 @@ def print_network_parameters(module: nn.Module, name_filter: Optional[str] = Non
                               f'std={p.std().item():<7.3f} | absmean={p.abs().mean().item():<7.3f}')
 
 
+def _evaluate_batched(model, logs, item_count: int, device: torch.device, indices) -> List[Tuple[int, Metrics]]:
+    """Top-10 of many searches per launch: one ``[C, D] x [D, I]`` GEMM + ``topk`` per chunk, one D2H copy per chunk
+    (the reference scores one log at a time and syncs on every one, ``TrainTestHelper.py:58-67``, ``Metrics.py:60-61``)."""
+    out: List[Tuple[int, Metrics]] = []
+    chunk = max(1, min(2048, (1 << 28) // max(item_count, 1)))
+    k = min(10, item_count)
+    for lo in range(0, len(indices), chunk):
+        part = indices[lo:lo + chunk]
+        uq = torch.tensor([(logs[i][0], logs[i][1]) for i in part], dtype=torch.long, device=device)
+        top = model.score_all_items(uq[:, 0], uq[:, 1]).topk(k, dim=1, largest=True, sorted=True).indices.tolist()
+        for i, row in zip(part, top):
+            _, _, items, flags, all_1 = logs[i]
+            out.append((i, Metrics.from_top_indices(row, items, flags, all_1)))
+    return out
+
+
 def test_and_get_avg_metrics(model, dataset_train: GraphDataset, dataloader: TestSearchLogDataLoader,
                              get_long_tail_stat: bool = False) -> Tuple[Optional[List[Optional[Metrics]]], Metrics, float]:
-    """-> (per-user average metrics or None, average over all usable logs, seconds)."""
+    """-> (per-user average metrics or None, average over all usable logs, seconds).
+
+    Logs are independent units: in a multi-process run each rank scores its contiguous share and the three metric sums
+    and the count are all-reduced, so every rank returns the global average."""
+    import torch.distributed as dist
+    from .. import distributed as ihg_dist
     started = time.time()
-    total, counted = Metrics(), 0
+    logs = dataloader.logs
+    device = dataloader.device
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    mine = list(ihg_dist.shard_range(len(logs), rank, world))
     per_user: List[List[Metrics]] = [[] for _ in range(dataset_train.user_count)] if get_long_tail_stat else []
+    total = Metrics()
     with torch.no_grad():
         model.save_features_for_test()
         try:
-            for users, queries, items_interacted, flags_interacted, flags_all_1 in dataloader:
-                scores = model(users, queries, None)
-                m = Metrics.calculate_on_all_items(scores, items_interacted, flags_interacted, flags_all_1)
-                if m is None:
-                    continue
-                total.add_to_self(m)
-                counted += 1
-                if get_long_tail_stat:
-                    per_user[int(users[0])].append(m)
+            if hasattr(model, 'score_all_items') and not Gs.Prediction.use_cosine_similarity:
+                scored = _evaluate_batched(model, logs, dataset_train.item_count, device, mine)
+            else:
+                scored = []
+                for i in mine:
+                    u, q, items, flags, all_1 = logs[i]
+                    users = torch.tensor([u], device=device).expand(dataset_train.item_count)
+                    queries = torch.tensor([q], device=device).expand(dataset_train.item_count)
+                    scored.append((i, Metrics.calculate_on_all_items(model(users, queries, None), items, flags, all_1)))
         finally:
             model.clear_saved_feature()
-    average = total.divide_and_get_new(max(counted, 1))
+    for i, m in scored:
+        total.add_to_self(m)
+        if get_long_tail_stat:
+            per_user[logs[i][0]].append(m)
+    sums = ihg_dist.all_reduce_sums([total.HitRatio_at10, total.NDCG_at10, total.MAP_at10, float(len(scored))], device)
+    counted = int(round(sums[3]))
+    average = Metrics(sums[0], sums[1], sums[2]).divide_and_get_new(max(counted, 1))
     user_avgs = None
-    if get_long_tail_stat:
+    if get_long_tail_stat:                                  # per-user breakdown covers this rank's share of the logs
         user_avgs = []
         for ms in per_user:
             if not ms:

@@ -69,6 +69,7 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
         IOHelper.StartLogging(os.path.join(result_dir, f'{stamp}_train_log.txt' if args.storemetrics else 'train_log.txt'))
     else:
         IOHelper.StartLogging(None)
+        IOHelper.quiet = True
     say = IOHelper.LogPrint if chief else (lambda *a, **k: None)
 
     say(f'device {device} | ranks {world} | batch {Gs.batch_size} | lr {Gs.learning_rate} | emb {Gs.embedding_size} | '
@@ -132,10 +133,10 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
             fn = os.path.join(result_dir, time.strftime(f'checkpoint_%y%m%d-%H%M%S_epoch{pc.CurrentEpoch}', time.localtime()))
             say(f'\ncheckpoint -> {fn}')
             torch.save({'epoch_count': pc.CurrentEpoch, 'model': model.state_dict(), 'optimizer': optimizer.state_dict()}, fn)
-        if chief and pc.ShouldTest():
+        if pc.ShouldTest():
             say('\nevaluating on the TEST set ...')
             per_user, m_test, t_test = test_and_get_avg_metrics(model, dataset_train, dataloader_test, bool(Gs.long_tail_stat_fn))
-            if Gs.long_tail_stat_fn:
+            if chief and Gs.long_tail_stat_fn:
                 with open(os.path.join(result_dir, Gs.long_tail_stat_fn), 'w', encoding='utf-8') as f:
                     for user, m in enumerate(per_user):
                         seen = int((dataset_train.pos_triples[:, 0] == user).sum())
@@ -149,7 +150,7 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
             else:
                 history.add(pc.CurrentEpoch, m_test)
                 pc.AddTestTime(t_test)
-            if args.storemetrics:
+            if chief and args.storemetrics:
                 with open(fn_metrics, 'a', encoding='utf-8') as f:
                     f.write(f'Epoch {pc.CurrentEpoch} Avg loss {avg_loss:.4f}\n{m_test.to_string()}\n')
 

@@ -79,6 +79,18 @@ class RawGnn(nn.Module):
         query_feature = features[query_indices + ds.query_start_index_in_graph]
         return self.prediction_layer(user_feature, query_feature, item_feature, item_indices)
 
+    def score_all_items(self, user_indices: Tensor, query_indices: Tensor) -> Tensor:
+        """Scores of ``C`` (user, query) pairs against every item in one GEMM: ``[C] x [C] -> [C, I]``.
+
+        Same arithmetic as ``forward(u * ones(I), q * ones(I), None)`` per pair (``RawGnn.py:124-137`` +
+        ``PredictionLayers.py:35-43``), batched: ``(lam*F[q] + (1-lam)*F[u]) @ F_items^T + bias``."""
+        features = self._saved_output_feature if self._saved_output_feature is not None else self.propagate()
+        ds, head = self.dataset, self.prediction_layer
+        item_feature = features[ds.item_start_index_in_graph:]
+        lam = head.lambda_muq
+        mixed = lam * features[query_indices + ds.query_start_index_in_graph] + (1 - lam) * features[user_indices]
+        return torch.addmm(head.items_bias.unsqueeze(0), mixed, item_feature.t())
+
     def save_features_for_test(self) -> None:
         """Cache one propagation for the evaluation loop (call under ``torch.no_grad()``)."""
         self._saved_output_feature = self.propagate()

@@ -380,3 +380,50 @@ def test_full_size_properties_c2_shape():
     deg = ops.node_segment_sum_raw(ones, lay.node_csr)[:, 0]
     assert torch.equal(deg, torch.where(lay.degree < 0.5, torch.zeros_like(lay.degree), lay.degree))
     assert torch.equal(ops.edge_gather_sum_raw(torch.ones(lay.node_count, 4, device=dev()), lay.i3), torch.full((lay.edge_count, 4), 3.0, device=dev()))
+
+
+def test_batched_evaluation_equals_per_log_scoring(tmp_path):
+    """f1: the GEMM + top-k evaluation loop gives the same metrics as scoring one log at a time."""
+    from ihgnn_amd import synth
+    from ihgnn_amd.Dataset import GraphDataset, TestSearchLogDataLoader
+    from ihgnn_amd.Helpers.Graph import PpsHyperGraph
+    from ihgnn_amd.Helpers.Metrics import Metrics
+    from ihgnn_amd.Helpers.TrainTestHelper import test_and_get_avg_metrics
+    w = synth.draw(80, 25, 120, 30, 900, seed=12, eval_logs=60)
+    paths = synth.write_files(w, str(tmp_path))
+    ds = GraphDataset(paths['fn_graph_info'], paths['fn_queries_multihot'], paths['fn_train_data'], PpsHyperGraph, 10, 0, dev())
+    loader = TestSearchLogDataLoader(paths['fn_test_data'], ds, dev())
+    torch.manual_seed(1)
+    m = build_model(ds, 'ihgnn', 2, 3, 32)
+    _, avg, _ = test_and_get_avg_metrics(m, ds, loader)
+    acc = Metrics()
+    with torch.no_grad():
+        m.save_features_for_test()
+        for users, queries, items, flags, all1 in loader:
+            acc.add_to_self(Metrics.calculate_on_all_items(m(users, queries, None), items, flags, all1))
+        one = m(*[t for t in list(loader)[0][:2]], None)
+        batched = m.score_all_items(torch.tensor([loader.logs[0][0]], device=dev()), torch.tensor([loader.logs[0][1]], device=dev()))[0]
+        m.clear_saved_feature()
+    want = acc.divide_and_get_new(len(loader))
+    assert rel(batched, one) <= RTOL
+    np.testing.assert_allclose([avg.HitRatio_at10, avg.NDCG_at10, avg.MAP_at10], [want.HitRatio_at10, want.NDCG_at10, want.MAP_at10], atol=1e-9)
+
+
+def test_driver_end_to_end(tmp_path, monkeypatch):
+    """The reference's CLI drives the whole thing: files -> dataset -> model -> epochs -> eval -> checkpoint -> resume."""
+    from ihgnn_amd import synth
+    from ihgnn_amd import Main as driver
+    w = synth.draw(60, 20, 80, 25, 500, seed=4, eval_logs=30)
+    data_root = tmp_path / 'Data' / 'Synth' / 'Tiny'
+    synth.write_files(w, str(data_root))
+    monkeypatch.chdir(tmp_path)
+    hist = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '3', '--est', '2',
+                        '--etf', '1', '-c', '-m'])
+    epochs = [e for e, _ in hist.iter_epoch_test()]
+    assert epochs == [2, 3]
+    result_dir = tmp_path / 'Results' / 'Synth-Tiny-RawGnn-2IHGNNLayer-O3-emb32'
+    names = sorted(os.listdir(result_dir))
+    assert any(n.startswith('checkpoint_') and n.endswith('_epoch3') for n in names) and any(n.endswith('_metrics.txt') for n in names)
+    resumed = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '1', '--est', '1',
+                           '--cp', 'latest'])
+    assert [e for e, _ in resumed.iter_epoch_test()] == [4]            # resumes at epoch_count + 1 (Main.py:207-208)
