@@ -56,19 +56,34 @@ class RawGnn(nn.Module):
         self.prediction_layer = HemPredictionLayer(feature_dimension=self.output_feature_size, lambda_muq=lambda_muq,
                                                    item_count=dataset.item_count)
 
-    def propagate(self) -> Tensor:
-        """Full-graph propagation: ``[N, d*(L+1)]`` = input embeddings and every layer's output side by side."""
+    def propagate_layers(self):
+        """Full-graph propagation: the list ``[X0, X1, ..., XL]`` of ``[N, d]`` node features (input embeddings and every
+        layer's output)."""
         x = torch.cat(self.embeddings(None, None, None))
         outputs = [x]
         for layer in self.gnns:
             x = layer(x)
             outputs.append(x)
-        return torch.cat(outputs, 1)
+        return outputs
+
+    def propagate(self) -> Tensor:
+        """``[N, d*(L+1)]``: all layer outputs side by side (``RawGnn.py:122``)."""
+        return torch.cat(self.propagate_layers(), 1)
 
     def forward(self, user_indices: Tensor, query_indices: Tensor, item_indices: Optional[Tensor] = None) -> Tensor:
         """Indices are 0-based per type.  ``item_indices=None`` scores the given (user, query) against every item."""
-        features = self._saved_output_feature if self._saved_output_feature is not None else self.propagate()
         ds = self.dataset
+        if self._saved_output_feature is None and item_indices is not None:
+            # Training step.  The reference concatenates all layer outputs into [N, D] and gathers three [B, D] row sets
+            # from it (RawGnn.py:122-131); here the 3B rows are gathered from each layer's [N, d] output with ONE index
+            # op and concatenated afterwards ([3B, D] instead of [N, D]): same values, and the backward is one
+            # scatter per layer instead of three dense [N, D] gradients that autograd would have to add up.
+            rows = torch.cat([user_indices, query_indices + ds.query_start_index_in_graph,
+                              item_indices + ds.item_start_index_in_graph])
+            picked = torch.cat([x[rows] for x in self.propagate_layers()], 1)
+            b = user_indices.shape[0]
+            return self.prediction_layer(picked[:b], picked[b:2 * b], picked[2 * b:], item_indices)
+        features = self._saved_output_feature if self._saved_output_feature is not None else self.propagate()
         if item_indices is None:
             item_feature = features[ds.item_start_index_in_graph:]
             if user_indices.dim() == 1 and user_indices.numel() > 1 and user_indices.stride(0) == 0 and query_indices.stride(0) == 0:
