@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-scale', type=float, default=0.125, help='fraction of the workload the CPU baseline runs on')
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket kernels with HIP events')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for smoke tests)')
+    ap.add_argument('--device', type=int, default=-1, help='force every rank onto this GPU ordinal (single-GPU smoke test of the N-rank path)')
     return ap.parse_args()
 
 
@@ -104,10 +106,10 @@ def main():
     from ihgnn_amd import distributed as ihg_dist, profiler, synth
     from ihgnn_amd.Dataset import GraphDataset
 
-    rank, local_rank, world = ihg_dist.init_from_env('nccl' if args.gpus > 1 else None)
+    rank, local_rank, world = ihg_dist.init_from_env(args.backend if args.gpus > 1 else None)
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
-    dev = torch.device(f'cuda:{local_rank}')
+    dev = torch.device(f'cuda:{args.device if args.device >= 0 else local_rank}')
     torch.cuda.set_device(dev)
 
     cfg = synth.CONFIGS[args.config]

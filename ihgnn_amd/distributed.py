@@ -29,7 +29,7 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
+        if backend == 'nccl' and local < torch.cuda.device_count():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
