@@ -154,8 +154,8 @@ class GraphDataset(Dataset):
     @property
     def graph2d(self) -> Pps2DGraph:
         if self._graph2d is None:
-            self._graph2d = Pps2DGraph.from_interactions(self.pos_interactions, self.node_count, self.user_count,
-                                                         self.query_count, False, GraphDataset.device)
+            self._graph2d = Pps2DGraph.from_triples(self.pos_triples, self.node_count, self.user_count, self.query_count,
+                                                    False, GraphDataset.device)
         return self._graph2d
 
     @property

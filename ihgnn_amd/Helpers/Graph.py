@@ -79,8 +79,44 @@ class PpsHyperGraph(PpsGraph):
 
 
 class Pps2DGraph(PpsGraph):
-    """Pairwise graph of the GCN / GAT baselines (``Graph.py:13-81``): outside this build's hot path."""
+    """Pairwise graph of the GCN baseline (``Graph.py:13-81``): every positive interaction links its members pairwise
+    (which pairs: ``Gs.graph_completeness``), both directions, duplicate links summed.  Kernel layout in ``layout``
+    (symmetric weighted CSR from the native ``ihg_build_pair_csr``); ``Adjacency`` / ``VertexDegrees`` are the
+    reference-shaped views."""
+
+    def __init__(self):
+        self.layout = None
+        self._adjacency = None
 
     @classmethod
-    def from_interactions(cls, *args, **kwargs):
-        raise NotImplementedError('Pps2DGraph (GCN/GAT baselines) is not part of the MI355X hypergraph path yet')
+    def from_triples(cls, triples: np.ndarray, node_count: int, user_count: int, query_count: int, use_self_connection: bool,
+                     device: torch.device, completeness: Optional[str] = None) -> 'Pps2DGraph':
+        from ..layout import PairLayout
+        from .GlobalSettings import Gs
+        g = cls()
+        g.layout = PairLayout(triples, user_count, query_count, node_count - user_count - query_count, device,
+                              completeness or Gs.graph_completeness, use_self_connection)
+        return g
+
+    @classmethod
+    def from_interactions(cls, interactions: Iterable, node_count: int, user_count: int, query_count: int,
+                          use_self_connection: bool, device: torch.device) -> 'Pps2DGraph':
+        rows = [(u, q, i) for u, q, i, flag in (p.uqif() for p in interactions) if flag > 0]
+        return cls.from_triples(np.asarray(rows, dtype=np.int64).reshape(-1, 3), node_count, user_count, query_count,
+                                use_self_connection, device)
+
+    @property
+    def VertexDegrees(self) -> Tensor:
+        return self.layout.degree.view(-1, 1)
+
+    @property
+    def Adjacency(self) -> Tensor:
+        if self._adjacency is None:
+            csr = self.layout.csr
+            lens = np.diff(csr.ptr_host.astype(np.int64))
+            rows = torch.from_numpy(np.repeat(np.arange(csr.n_rows, dtype=np.int64), lens))
+            cols = torch.from_numpy(csr.ids_host.astype(np.int64))
+            n = self.layout.node_count
+            self._adjacency = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.from_numpy(self.layout.values_host),
+                                                      (n, n)).coalesce().to(self.layout.device)
+        return self._adjacency

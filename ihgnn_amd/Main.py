@@ -17,12 +17,12 @@ from . import distributed as ihg_dist
 from .Dataset import GraphDataset, TestSearchLogDataLoader
 from .Helpers.ArgsParser import parse_args
 from .Helpers.GlobalSettings import Gs
-from .Helpers.Graph import PpsHyperGraph
+from .Helpers.Graph import Pps2DGraph, PpsHyperGraph
 from .Helpers.IOHelper import IOHelper
 from .Helpers.Metrics import Metrics, MetricsCollection
 from .Helpers.ProcessController import ProcessController
 from .Helpers.TrainTestHelper import print_network_parameters, test_and_get_avg_metrics, train_and_get_avg_loss
-from .Models import HGCNLayer, HemPredictionLayer, IHGNNLayer, RawGnn, parse_gnn_layer, parse_model_type
+from .Models import GCNLayer, HGCNLayer, HemPredictionLayer, IHGNNLayer, RawGnn, parse_gnn_layer, parse_model_type
 
 DEFAULT_DATASET = 'AlibabaAir/Complete5Core/'
 
@@ -50,7 +50,7 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
     if (parse_model_type[args.model] or RawGnn) is not RawGnn:
         raise NotImplementedError('only the RawGnn model is part of this build')
     layer_type = parse_gnn_layer[args.gnn] or IHGNNLayer
-    if layer_type not in (IHGNNLayer, HGCNLayer):
+    if layer_type not in (IHGNNLayer, HGCNLayer, GCNLayer):
         raise NotImplementedError(f'{layer_type.__name__} is outside the MI355X hypergraph path')
     layer_count = args.gnns or 2
     order = args.feature_order or 3
@@ -82,7 +82,7 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
         fn_graph_info=os.path.join(data_dir, 'graph_info.txt'),
         fn_queries_multihot=os.path.join(data_dir, 'queries_multihot.txt'),
         fn_train_data=os.path.join(data_dir, 'train_data.csv'),
-        graph_type=PpsHyperGraph,
+        graph_type=Pps2DGraph if layer_type is GCNLayer else PpsHyperGraph,
         random_negative_sample_size=Gs.random_negative_sample_size,
         non_random_negative_sample_size=Gs.non_random_negative_sample_size,
         device=device)

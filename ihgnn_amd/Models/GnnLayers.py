@@ -2,8 +2,9 @@
 
 Constructor signatures, sub-module names (``feature_transform``, ``feature_interactor.aggregation``) and the
 absence of any non-linearity follow the reference; the sparse work runs in the HIP kernels of
-libihgnn_hip.so through :mod:`ihgnn_amd.ops` instead of ``torch_sparse.matmul``.  ``GCNLayer`` / ``GATLayer``
-(pairwise-graph baselines on DGL) are declared for the name tables only.
+libihgnn_hip.so through :mod:`ihgnn_amd.ops` instead of ``torch_sparse.matmul``.
+``GCNLayer`` (pairwise-graph baseline) runs on the same segment-sum kernel over a weighted CSR; ``GATLayer`` (DGL) is
+declared for the name tables only.
 """
 import torch
 import torch.nn as nn
@@ -65,16 +66,29 @@ class IHGNNLayer(nn.Module):
         return ops.node_segment_sum(edge_features, self.layout, out_scale=self.layout.inv_deg)
 
 
-class _PairwiseBaseline(nn.Module):
+class GCNLayer(nn.Module):
+    """``Y = D^-1/2 A D^-1/2 (X W^T + b)`` over the pairwise graph (``GnnLayers.py:9-45``).
+
+    The reference orders transform and propagation by which side is narrower (``GnnLayers.py:33-43``); both orders are
+    kept.  Propagation is the weighted-CSR form of the K7 kernel with both ``D^-1/2`` scalings fused in."""
+
+    def __init__(self, device: torch.device, dataset, input_dimension: int, output_dimension: int):
+        super().__init__()
+        self.device = device
+        self.dataset = dataset
+        self.input_dimension = input_dimension
+        self.output_dimension = output_dimension
+        self.graph = dataset.graph2d.layout
+        self.feature_transform = nn.Linear(input_dimension, output_dimension)
+
+    def forward(self, input_features: Tensor) -> Tensor:
+        if self.input_dimension >= self.output_dimension:
+            return ops.pair_spmm(_transform(self.feature_transform, input_features, self.graph), self.graph)
+        return self.feature_transform(ops.pair_spmm(input_features, self.graph))
+
+
+class GATLayer(nn.Module):
     def __init__(self, *args, **kwargs):
         super().__init__()
-        raise NotImplementedError(f'{type(self).__name__} is a pairwise-graph baseline outside the MI355X hypergraph '
-                                  'path (SURVEY.md §8 f3); use IHGNNLayer or HGCNLayer')
-
-
-class GCNLayer(_PairwiseBaseline):
-    pass
-
-
-class GATLayer(_PairwiseBaseline):
-    pass
+        raise NotImplementedError('GATLayer (DGL edge-softmax baseline, GnnLayers.py:48-115) is outside the MI355X hypergraph '
+                                  'path (SURVEY.md §2); use IHGNNLayer, HGCNLayer or GCNLayer')

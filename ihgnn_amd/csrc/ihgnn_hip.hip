@@ -152,6 +152,7 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
 template <int VEC, int G>
 __device__ __forceinline__ Frag<VEC> accumulate_list(const float* __restrict__ src, int64_t ld_src,
                                                      const int32_t* __restrict__ ids, const float* __restrict__ src_scale,
+                                                     const float* __restrict__ entry_scale,
                                                      int begin, int len, int wave_max_len, int lane, int col) {
     constexpr int UNR = G < 8 ? G : 8;
     const int lig = lane & (G - 1);
@@ -160,7 +161,8 @@ __device__ __forceinline__ Frag<VEC> accumulate_list(const float* __restrict__ s
     for (int base = 0; base < wave_max_len; base += G) {
         const bool have = base + lig < len;
         const int my_id = have ? ids[begin + base + lig] : -1;
-        const float my_w = (src_scale != nullptr && have) ? src_scale[my_id] : 1.f;
+        float my_w = (src_scale != nullptr && have) ? src_scale[my_id] : 1.f;
+        if (entry_scale != nullptr && have) my_w *= entry_scale[begin + base + lig];
 #pragma unroll 1
         for (int j = 0; j < G; j += UNR) {
             if (base + j >= wave_max_len) break;      // wave-uniform: nothing left in any group
@@ -208,7 +210,8 @@ __device__ __forceinline__ void apply_out_scale(Frag<VEC>& acc, const float* out
 template <int VEC, int G>
 __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
     const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ids,
-    const int32_t* __restrict__ row_order, const float* __restrict__ src_scale, const float* __restrict__ out_scale, int mode,
+    const int32_t* __restrict__ row_order, const float* __restrict__ src_scale, const float* __restrict__ entry_scale,
+    const float* __restrict__ out_scale, int mode,
     float* __restrict__ out, int64_t ld_out, int64_t n_rows, int dim, int dim_vec, int heavy_threshold,
     const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments, float* __restrict__ partials) {
     constexpr int GPW = kWave / G;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
         for (int ci = 0; ci < col_iters; ++ci) {
             const int c = ci * G + lig;
             const int col = c < dim_vec ? c : -1;
-            Frag<VEC> acc = accumulate_list<VEC, G>(src, ld_src, ids, src_scale, begin, len, wave_len, lane, col);
+            Frag<VEC> acc = accumulate_list<VEC, G>(src, ld_src, ids, src_scale, entry_scale, begin, len, wave_len, lane, col);
             if (dst != nullptr && col >= 0) {
                 if (scale_row >= 0) apply_out_scale<VEC>(acc, out_scale, mode, scale_row);
                 acc.store(dst + col * VEC);
@@ -1636,13 +1639,13 @@ struct HeavyPlan {
 
 template <int VEC, int G>
 void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
-                          const float* src_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
+                          const float* src_scale, const float* entry_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
                           int heavy_threshold, const HeavyPlan& hp, hipStream_t stream) {
     constexpr int GPW = kWave / G;
     const int dim_vec = dim / VEC;
     const int grid = grid_for_waves((n_rows + hp.n_segments + GPW - 1) / GPW);
     hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr, ids, row_order,
-                       src_scale, out_scale, mode, out, ld_out, n_rows, dim, dim_vec, heavy_threshold, hp.seg_begin, hp.seg_end,
+                       src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, dim_vec, heavy_threshold, hp.seg_begin, hp.seg_end,
                        hp.n_segments, hp.partials);
     if (hp.n_heavy > 0)
         hipLaunchKernelGGL((heavy_finish_kernel<VEC, G>), dim3(static_cast<int>(std::min<int64_t>(hp.n_heavy, kMaxBlocks * 4))),
@@ -1652,9 +1655,9 @@ void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowpt
 
 template <int VEC>
 int launch_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
-                       const float* src_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
+                       const float* src_scale, const float* entry_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
                        int heavy_threshold, const HeavyPlan& hp, hipStream_t stream) {
-#define IHG_K7(G) launch_segment_sum_g<VEC, G>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, mode, out, ld_out, n_rows, dim, heavy_threshold, hp, stream)
+#define IHG_K7(G) launch_segment_sum_g<VEC, G>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, heavy_threshold, hp, stream)
     switch (group_lanes(dim / VEC)) {
         case 4: IHG_K7(4); break;
         case 8: IHG_K7(8); break;
@@ -1739,7 +1742,7 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
 // =================================================================================================
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 5; }
+int32_t ihg_abi_version(void) { return 6; }
 
 const char* ihg_last_error_string(void) { return g_error; }
 
@@ -1775,6 +1778,62 @@ int ihg_build_csr(const int64_t* triples, int64_t n_edges, int64_t n_users, int6
     return IHG_OK;
 }
 
+
+int ihg_build_pair_csr(const int64_t* triples, int64_t n_edges, int64_t n_users, int64_t n_queries, int64_t n_items,
+                       int32_t completeness, int32_t self_loops, int32_t* rowptr, int32_t* cols, float* vals, float* degree,
+                       int64_t capacity, int64_t* nnz_out) {
+    if (n_edges < 0 || n_users < 0 || n_queries < 0 || n_items < 0 || completeness < 0 || completeness > 3)
+        return fail(IHG_ERR_INVALID, "ihg_build_pair_csr: bad argument");
+    const int64_t n_nodes = n_users + n_queries + n_items;
+    if (rowptr == nullptr || degree == nullptr || nnz_out == nullptr || (n_edges > 0 && (triples == nullptr || cols == nullptr || vals == nullptr)))
+        return fail(IHG_ERR_INVALID, "ihg_build_pair_csr: null buffer");
+    if (n_nodes >= INT32_MAX) return fail(IHG_ERR_INVALID, "ihg_build_pair_csr: graph exceeds int32 indexing");
+    // member pairs joined by one interaction (Helpers/Graph.py:40-63): uqi = all three pairs, otherwise a single pair
+    static const int kPairs[4][3][2] = {{{0, 1}, {1, 2}, {2, 0}}, {{0, 1}, {0, 1}, {0, 1}}, {{0, 2}, {0, 2}, {0, 2}}, {{1, 2}, {1, 2}, {1, 2}}};
+    const int n_pairs = completeness == 0 ? 3 : 1;
+    const int64_t offset[3] = {0, n_users, n_users + n_queries};
+    const int64_t limit[3] = {n_users, n_queries, n_items};
+    std::vector<uint64_t> keys;
+    keys.reserve(static_cast<size_t>(n_edges) * n_pairs * 2 + (self_loops ? n_nodes : 0));
+    std::vector<float> deg(static_cast<size_t>(n_nodes), self_loops ? 1.f : 0.f);
+    if (self_loops)
+        for (int64_t v = 0; v < n_nodes; ++v) keys.push_back((static_cast<uint64_t>(v) << 32) | static_cast<uint64_t>(v));
+    for (int64_t e = 0; e < n_edges; ++e) {
+        int64_t node[3];
+        for (int m = 0; m < 3; ++m) {
+            const int64_t local = triples[e * 3 + m];
+            if (local < 0 || local >= limit[m]) return fail(IHG_ERR_INVALID, "ihg_build_pair_csr: interaction %lld member %d out of range", (long long)e, m);
+            node[m] = local + offset[m];
+        }
+        for (int k = 0; k < n_pairs; ++k) {
+            const uint64_t a = static_cast<uint64_t>(node[kPairs[completeness][k][0]]), b = static_cast<uint64_t>(node[kPairs[completeness][k][1]]);
+            keys.push_back((a << 32) | b);
+            keys.push_back((b << 32) | a);
+            deg[a] += 1.f;                                   // Graph.py:48,54,60,66: +2 per member for uqi, +1 per pair member otherwise
+            deg[b] += 1.f;
+        }
+    }
+    std::sort(keys.begin(), keys.end());
+    std::memset(rowptr, 0, sizeof(int32_t) * static_cast<size_t>(n_nodes + 1));
+    int64_t nnz = 0;
+    for (size_t k = 0; k < keys.size();) {
+        size_t j = k;
+        while (j < keys.size() && keys[j] == keys[k]) ++j;   // duplicates are summed by coalesce() (Graph.py:73-79)
+        if (nnz >= capacity) return fail(IHG_ERR_WORKSPACE, "ihg_build_pair_csr: capacity %lld too small", (long long)capacity);
+        cols[nnz] = static_cast<int32_t>(keys[k] & 0xffffffffu);
+        vals[nnz] = static_cast<float>(j - k);
+        ++rowptr[(keys[k] >> 32) + 1];
+        ++nnz;
+        k = j;
+    }
+    for (int64_t v = 0; v < n_nodes; ++v) {
+        rowptr[v + 1] += rowptr[v];
+        degree[v] = (!self_loops && deg[v] == 0.f) ? 1e-8f : deg[v];
+    }
+    *nnz_out = nnz;
+    return IHG_OK;
+}
+
 int ihg_transpose_csr(const int32_t* ptr, const int32_t* ids, int64_t n_rows, int64_t n_cols, int32_t* t_ptr, int32_t* t_rows) {
     if (n_rows < 0 || n_cols < 0 || ptr == nullptr || t_ptr == nullptr) return fail(IHG_ERR_INVALID, "ihg_transpose_csr: bad argument");
     const int64_t nnz = ptr[n_rows];
@@ -1803,7 +1862,7 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, con
 }
 
 int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
-                         const float* src_scale, const float* out_scale, int32_t out_scale_mode, float* out, int64_t ld_out,
+                         const float* src_scale, const float* entry_scale, const float* out_scale, int32_t out_scale_mode, float* out, int64_t ld_out,
                          int64_t n_rows, int32_t dim, int32_t heavy_threshold, const int32_t* seg_begin, const int32_t* seg_end,
                          int64_t n_segments, const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy, float* partials,
                          ihg_stream_t stream) {
@@ -1820,20 +1879,20 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
     const HeavyPlan hp{seg_begin, seg_end, n_segments, heavy_rows, heavy_segptr, n_heavy, partials};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out) && (n_heavy == 0 || aligned16(partials));
-    return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, s)
-                : launch_segment_sum<1>(src, ld_src, rowptr, ids, row_order, src_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, s);
+    return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, s)
+                : launch_segment_sum<1>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, s);
 }
 
 int ihg_bag_mean_fwd(const float* table, int64_t ld_table, const int32_t* bag_ptr, const int32_t* words, const float* bag_len,
                      float* out, int64_t ld_out, int64_t n_bags, int32_t dim, ihg_stream_t stream) {
     if (bag_len == nullptr && n_bags > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_fwd: null bag_len");
-    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, stream);
+    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, nullptr, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, stream);
 }
 
 int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr, const int32_t* word_bags, const float* inv_len,
                      float* dtable, int64_t ld_dtable, int64_t n_table_rows, int32_t dim, ihg_stream_t stream) {
     if (inv_len == nullptr && n_table_rows > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_bwd: null inv_len");
-    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, nullptr, inv_len, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, stream);
+    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, nullptr, inv_len, nullptr, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, stream);
 }
 
 int64_t ihg_interact_fwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order) {

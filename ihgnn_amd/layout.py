@@ -183,3 +183,39 @@ class IncidenceLayout:
         slot_of_node[u:u + q] = 1
         slot_of_node[u + q:] = 2
         self.member_csr = self.node_csr.with_ids(edge_ids[:3 * e] * 3 + np.repeat(slot_of_node, lens))
+
+
+COMPLETENESS = {'uqi': 0, 'uq': 1, 'ui': 2, 'qi': 3}
+
+
+class PairLayout:
+    """Pairwise (user-query-item) graph of the GCN baseline in kernel layout: symmetric weighted CSR + ``D^-1/2``."""
+
+    def __init__(self, triples: np.ndarray, user_count: int, query_count: int, item_count: int, device: torch.device,
+                 completeness: str = 'uqi', self_loops: bool = False, heavy_threshold: int = HEAVY_THRESHOLD):
+        lib = _lib.load()
+        if completeness not in COMPLETENESS:
+            raise ValueError(f'unknown graph completeness {completeness!r}')
+        triples = np.ascontiguousarray(np.asarray(triples, dtype=np.int64).reshape(-1, 3))
+        e = int(triples.shape[0])
+        self.node_count = n = int(user_count + query_count + item_count)
+        self.user_count, self.query_count, self.item_count = int(user_count), int(query_count), int(item_count)
+        cap = 6 * e + n + 1
+        rowptr = np.empty(n + 1, np.int32)
+        cols = np.empty(cap, np.int32)
+        vals = np.empty(cap, np.float32)
+        degree = np.empty(max(n, 1), np.float32)
+        nnz = ctypes.c_int64(0)
+        _lib.check(lib.ihg_build_pair_csr(_as_ptr(triples, ctypes.c_int64), e, self.user_count, self.query_count, self.item_count,
+                                          COMPLETENESS[completeness], int(bool(self_loops)), _as_ptr(rowptr, ctypes.c_int32),
+                                          _as_ptr(cols, ctypes.c_int32), _as_ptr(vals, ctypes.c_float), _as_ptr(degree, ctypes.c_float),
+                                          cap, ctypes.byref(nnz)), 'ihg_build_pair_csr')
+        k = int(nnz.value)
+        self.device = device
+        self.csr = Csr(rowptr, cols[:k], device, heavy_threshold)
+        self.values_host = vals[:k].copy()
+        self.values = torch.from_numpy(self.values_host).to(device)
+        deg = torch.from_numpy(degree[:n].copy())
+        self.degree = deg.to(device)
+        isolated = deg < 0.5
+        self.inv_sqrt_deg = torch.where(isolated, torch.zeros_like(deg), deg.pow(-0.5)).to(device)

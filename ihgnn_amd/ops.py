@@ -74,7 +74,7 @@ def edge_gather_sum_raw(src: Tensor, i3: Tensor, node_scale: Optional[Tensor] = 
 
 def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optional[Tensor] = None,
                          out_scale: Optional[Tensor] = None, mode: int = _lib.SCALE_NONE,
-                         out: Optional[Tensor] = None) -> Tensor:
+                         out: Optional[Tensor] = None, entry_scale: Optional[Tensor] = None) -> Tensor:
     lib = _lib.load()
     src = _rows(src, 'src')
     dim = int(src.shape[1])
@@ -83,7 +83,7 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
     heavy = csr.n_heavy > 0
     with profiler.kernel('node_segment_sum', csr.n_rows, dim):
         _lib.check(lib.ihg_node_segment_sum(
-            _ptr(src), _ld(src), _ptr(csr.ptr), _ptr(csr.ids), _ptr(csr.row_order), _ptr(src_scale), _ptr(out_scale), mode,
+            _ptr(src), _ld(src), _ptr(csr.ptr), _ptr(csr.ids), _ptr(csr.row_order), _ptr(src_scale), _ptr(entry_scale), _ptr(out_scale), mode,
             _ptr(out), _ld(out), csr.n_rows, dim, csr.heavy_threshold if heavy else 0,
             _ptr(csr.seg_begin) if heavy else None, _ptr(csr.seg_end) if heavy else None, csr.n_segments if heavy else 0,
             _ptr(csr.heavy_rows) if heavy else None, _ptr(csr.heavy_segptr) if heavy else None, csr.n_heavy,
@@ -130,6 +130,25 @@ def edge_gather_sum(src: Tensor, layout: IncidenceLayout, node_scale: Optional[T
 def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor] = None) -> Tensor:
     """hyperedge -> node: ``out[v] = out_scale[v] * sum_{e containing v} src[e]``  (``[E,d] -> [N,d]``)."""
     return _NodeSegmentSum.apply(src, layout, out_scale)
+
+
+class _PairSpmm(torch.autograd.Function):
+    """``out = Ds (A (Ds x))`` for a symmetric weighted adjacency: its own transpose, so backward is the same launch."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, graph) -> Tensor:
+        ctx.graph = graph
+        return node_segment_sum_raw(x, graph.csr, graph.inv_sqrt_deg, graph.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=graph.values)
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        g = ctx.graph
+        return node_segment_sum_raw(grad_out, g.csr, g.inv_sqrt_deg, g.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=g.values), None
+
+
+def pair_spmm(x: Tensor, graph) -> Tensor:
+    """GCN propagation ``D^-1/2 A D^-1/2 x`` over a :class:`ihgnn_amd.layout.PairLayout` (``GnnLayers.py:35-38``)."""
+    return _PairSpmm.apply(x, graph)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -58,6 +58,16 @@ int ihg_build_csr(const int64_t* triples, int64_t n_edges,
                   int64_t n_users, int64_t n_queries, int64_t n_items,
                   int32_t* i3, int32_t* rowptr, int32_t* edge_ids, float* degree);
 
+/* HOST: pairwise graph of the GCN baseline.  Replaces Pps2DGraph.from_interactions (Helpers/Graph.py:19-81) and the
+ * coalesce() of its adjacency.  completeness: 0 = uqi (u-q, q-i, i-u per interaction), 1 = uq, 2 = ui, 3 = qi
+ * (Graph.py:40-63; every pair is stored in both directions).  Output: CSR of the symmetric [N x N] adjacency with
+ * duplicate pairs SUMMED into `vals`, `degree` = entries per node before coalescing (+1 with self loops), 0 -> 1e-8
+ * without self loops (Graph.py:68-69).  `cols`/`vals` must hold `capacity` >= 6E (+N) entries; *nnz_out = entries used.
+ */
+int ihg_build_pair_csr(const int64_t* triples, int64_t n_edges, int64_t n_users, int64_t n_queries, int64_t n_items,
+                       int32_t completeness, int32_t self_loops,
+                       int32_t* rowptr, int32_t* cols, float* vals, float* degree, int64_t capacity, int64_t* nnz_out);
+
 /* HOST: invert any CSR (row -> sorted list of column ids) into its transpose.  Used for the
  * EmbeddingBag backward (word -> bags containing it).  Replaces the autograd-generated
  * _embedding_bag_dense_backward of Models/EmbeddingLayers.py:79.
@@ -81,7 +91,8 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3,
 /* ------------------------------------------------------------------------------------------------
  * DEVICE: hyperedge -> node segment-sum (K7 + K8).
  *   out[r,:] = scale_op( sum_{k in [rowptr[r], rowptr[r+1])} w(ids[k]) * src[ids[k],:] , out_scale[r] )
- * with w(j) = src_scale[j] (or 1).  Rows longer than `heavy_threshold` entries go through the split-row plan below
+ * with w(ids[k]) = src_scale[ids[k]] (or 1), times entry_scale[k] when given (values of a weighted CSR: the pairwise
+ * adjacency of GCNLayer, Models/GnnLayers.py:37-41).  Rows longer than `heavy_threshold` entries go through the split-row plan below
  * (pass n_heavy = 0 to sum every row with a single lane group).
  * `row_order` (optional, [n_rows]) is the order in which rows are handed to lane groups - a permutation sorted by
  * decreasing row length keeps the groups of one wave equally busy; NULL = natural order.  Results do not depend on it.
@@ -91,7 +102,8 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3,
  */
 int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids,
                          const int32_t* row_order,
-                         const float* src_scale, const float* out_scale, int32_t out_scale_mode,
+                         const float* src_scale, const float* entry_scale,
+                         const float* out_scale, int32_t out_scale_mode,
                          float* out, int64_t ld_out, int64_t n_rows, int32_t dim,
                          int32_t heavy_threshold,
                          const int32_t* seg_begin, const int32_t* seg_end, int64_t n_segments,

@@ -63,6 +63,29 @@ class HyperGraph:
         return g
 
 
+class PairGraph:
+    """Pairwise graph as ``Pps2DGraph.from_interactions`` builds it (Helpers/Graph.py:19-81), no self connections."""
+
+    PAIRS = {'uqi': ((0, 1), (1, 2), (2, 0)), 'uq': ((0, 1),), 'ui': ((0, 2),), 'qi': ((1, 2),)}
+
+    def __init__(self, triples: np.ndarray, user_count: int, query_count: int, item_count: int, completeness: str = 'uqi'):
+        triples = np.asarray(triples, dtype=np.int64).reshape(-1, 3)
+        self.user_count, self.query_count, self.item_count = user_count, query_count, item_count
+        self.node_count = n = user_count + query_count + item_count
+        nodes = triples + np.array([0, user_count, user_count + query_count], dtype=np.int64)       # Graph.py:38-39
+        rows, cols = [], []
+        deg = np.zeros(n, dtype=np.float64)
+        for a, b in self.PAIRS[completeness]:                                                        # Graph.py:40-63
+            rows += [nodes[:, a], nodes[:, b]]
+            cols += [nodes[:, b], nodes[:, a]]
+            np.add.at(deg, nodes[:, a], 1.0)
+            np.add.at(deg, nodes[:, b], 1.0)
+        deg[deg == 0] = 1e-8                                                                          # Graph.py:68-69
+        idx = torch.from_numpy(np.stack([np.concatenate(rows), np.concatenate(cols)])) if len(triples) else torch.zeros(2, 0, dtype=torch.long)
+        self.Adjacency = torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1]), (n, n)).coalesce()   # Graph.py:72-78: duplicates summed
+        self.VertexDegrees = torch.from_numpy(deg).float().view(-1, 1)
+
+
 # ---------------------------------------------------------------------------------------------
 # Embeddings (Models/EmbeddingLayers.py:51-91)
 # ---------------------------------------------------------------------------------------------
@@ -109,6 +132,14 @@ def hgcn_layer(x: Tensor, g: HyperGraph, w: Tensor, b: Tensor) -> Tensor:
     return dv * torch.sparse.mm(g.Adjacency, ef)                 # :151-152
 
 
+def gcn_layer(x: Tensor, g: PairGraph, w: Tensor, b: Tensor) -> Tensor:
+    """GCNLayer.forward (Models/GnnLayers.py:28-45)."""
+    dv = g.VertexDegrees.pow(-0.5)                               # :24
+    if w.shape[1] >= w.shape[0]:                                 # :33-37  transform first when it does not widen
+        return dv * torch.sparse.mm(g.Adjacency, dv * F.linear(x, w, b))
+    return F.linear(dv * torch.sparse.mm(g.Adjacency, dv * x), w, b)     # :38-43
+
+
 def hem_score(user_f: Tensor, query_f: Tensor, item_f: Tensor, items_bias: Tensor, lam: float) -> Tensor:
     """HemPredictionLayer.forward (Models/PredictionLayers.py:21-44), dot-product branch."""
     m_uq = lam * query_f + (1 - lam) * user_f                    # :35
@@ -121,7 +152,7 @@ class OracleRawGnn(nn.Module):
     def __init__(self, g: HyperGraph, bag_input: Tensor, bag_offsets: Tensor, vocab_size: int, dim: int,
                  layer_kind: str, layer_count: int, order: int, lam: float = 0.5, dtype: torch.dtype = torch.float32):
         super().__init__()
-        assert layer_kind in ('ihgnn', 'hgcn')
+        assert layer_kind in ('ihgnn', 'hgcn', 'gcn')
         self.g, self.bag_input, self.bag_offsets = g, bag_input, bag_offsets
         self.kind, self.layer_count, self.lam, self.dim = layer_kind, layer_count, lam, dim
         # RawGnn.py:76-78: only layer 0 keeps the requested interaction order
@@ -145,6 +176,7 @@ class OracleRawGnn(nn.Module):
             self.key_of[attr] = key
             self.register_parameter(attr, nn.Parameter(torch.zeros(shape, dtype=dtype)))
         self._saved: Optional[Tensor] = None
+        self.pair_graph: Optional[PairGraph] = None            # set by the caller for layer_kind == 'gcn'
 
     # -- state-dict in the reference's key space -------------------------------------------
     def load_reference_state(self, sd: Dict[str, np.ndarray]) -> None:
@@ -172,8 +204,10 @@ class OracleRawGnn(nn.Module):
             if self.kind == 'ihgnn':
                 x = ihgnn_layer(x, self.g, wt, bt, self.P(f'gnn_{l}.feature_interactor.aggregation.weight'),
                                 self.P(f'gnn_{l}.feature_interactor.aggregation.bias'), self.orders[l])
-            else:
+            elif self.kind == 'hgcn':
                 x = hgcn_layer(x, self.g, wt, bt)
+            else:
+                x = gcn_layer(x, self.pair_graph, wt, bt)
             outs.append(x)
         return torch.cat(outs, 1)
 

@@ -54,10 +54,11 @@ sys.path.insert(0, REFERENCE)
 sys.path.insert(1, REPO)
 
 from Dataset import GraphDataset, TestSearchLogDataLoader            # noqa: E402  (reference)
-from Helpers.Graph import PpsHyperGraph                                # noqa: E402  (reference)
+from Helpers.Graph import PpsHyperGraph, Pps2DGraph                    # noqa: E402  (reference)
+from Helpers.GlobalSettings import Gs                                  # noqa: E402  (reference)
 from Helpers.Metrics import Metrics, MetricsCollection                 # noqa: E402  (reference)
 from Helpers.ProcessController import ProcessController               # noqa: E402  (reference)
-from Models import RawGnn, IHGNNLayer, HGCNLayer, HemPredictionLayer   # noqa: E402  (reference)
+from Models import RawGnn, IHGNNLayer, HGCNLayer, GCNLayer, HemPredictionLayer   # noqa: E402  (reference)
 
 from ihgnn_amd import synth                                            # noqa: E402  (this repo)
 
@@ -347,6 +348,49 @@ def make_f6():
     np.savez(os.path.join(HERE, 'f6_training.npz'), **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# F7: GCN baseline over the pairwise graph
+# ---------------------------------------------------------------------------------------------
+def make_f7():
+    out = {}
+    w = small_workload()
+    paths = synth.write_files(w, '/tmp/ihgnn_golden_small2d')
+    tiny = {k: os.path.join(HERE, 'f1_data', v) for k, v in dict(fn_graph_info='graph_info.txt', fn_queries_multihot='queries_multihot.txt',
+                                                                  fn_train_data='train_data.csv').items()}
+    for tag, pth, d, mode in (('tiny_uqi', tiny, 8, 'uqi'), ('small_uqi', paths, 64, 'uqi'), ('small_ui', paths, 32, 'ui'), ('tiny_qi', tiny, 8, 'qi')):
+        Gs.graph_completeness = mode
+        ds = GraphDataset(pth['fn_graph_info'], pth['fn_queries_multihot'], pth['fn_train_data'], Pps2DGraph, 10, 0, CPU)
+        g = ds.graph2d
+        out[f'{tag}.adj_indices'] = g.Adjacency.indices().numpy()
+        out[f'{tag}.adj_values'] = g.Adjacency.values().numpy()
+        out[f'{tag}.degrees'] = g.VertexDegrees.numpy()
+        seed_all(700 + d)
+        layer = GCNLayer(CPU, ds, d, d)
+        x = torch.randn(ds.node_count, d, requires_grad=True)
+        y = layer(x)
+        cot = torch.randn_like(y)
+        y.backward(cot)
+        out.update({f'{tag}.{k}': v for k, v in sd_numpy(layer).items()})
+        out.update({f'{tag}.x': x.detach().numpy(), f'{tag}.y': y.detach().numpy(), f'{tag}.cot': cot.numpy(), f'{tag}.dx': x.grad.numpy()})
+        for name, p in layer.named_parameters():
+            out[f'{tag}.grad.{name}'] = p.grad.numpy().copy()
+    # model level: RawGnn with two GCN layers on the small workload
+    Gs.graph_completeness = 'uqi'
+    ds = GraphDataset(paths['fn_graph_info'], paths['fn_queries_multihot'], paths['fn_train_data'], Pps2DGraph, 10, 0, CPU)
+    seed_all(777)
+    m = RawGnn(CPU, ds, 16, GCNLayer, 2, 1, False, HemPredictionLayer, 0.5)
+    out.update({f'model.{k}': v for k, v in sd_numpy(m).items()})
+    u = torch.randint(0, ds.user_count, (64,)); q = torch.randint(0, ds.query_count, (64,)); i = torch.randint(0, ds.item_count, (64,))
+    flags = (torch.rand(64) < 0.3).float()
+    scores = m(u, q, i)
+    loss = torch.nn.BCEWithLogitsLoss()(scores, flags)
+    loss.backward()
+    out.update({f'model.grad.{n}': p.grad.numpy().copy() for n, p in m.named_parameters()})
+    out.update({'model.u': u.numpy(), 'model.q': q.numpy(), 'model.i': i.numpy(), 'model.flags': flags.numpy(),
+                'model.scores': scores.detach().numpy(), 'model.loss': np.float64(loss.item())})
+    np.savez(os.path.join(HERE, 'f7_gcn.npz'), **out)
+
+
 if __name__ == '__main__':
     ds_tiny = make_f1()
     ds_small, _ = make_f2(ds_tiny)
@@ -354,6 +398,7 @@ if __name__ == '__main__':
     make_f4()
     make_f5()
     make_f6()
+    make_f7()
     for fn in sorted(os.listdir(HERE)):
         p = os.path.join(HERE, fn)
         if os.path.isfile(p):

@@ -427,3 +427,46 @@ def test_driver_end_to_end(tmp_path, monkeypatch):
     resumed = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '1', '--est', '1',
                            '--cp', 'latest'])
     assert [e for e, _ in resumed.iter_epoch_test()] == [4]            # resumes at epoch_count + 1 (Main.py:207-208)
+
+
+@pytest.mark.parametrize('tag,d,mode', [('tiny_uqi', 8, 'uqi'), ('small_uqi', 64, 'uqi'), ('small_ui', 32, 'ui'), ('tiny_qi', 8, 'qi')])
+def test_f7_gcn_layer_matches_reference(tag, d, mode):
+    """f3: GCNLayer over the pairwise graph = the K7 kernel on a weighted CSR with both D^-1/2 scalings fused."""
+    from ihgnn_amd.Helpers.GlobalSettings import Gs
+    from ihgnn_amd.Helpers.Graph import Pps2DGraph
+    from ihgnn_amd.Models import GCNLayer
+    z = np.load(os.path.join(GOLDEN, 'f7_gcn.npz'))
+    Gs.graph_completeness = mode
+    try:
+        ds = tiny_dataset() if tag.startswith('tiny') else dataset_from_npz(np.load(os.path.join(GOLDEN, 'f2_small_workload.npz')))
+        ds.graph_type = Pps2DGraph
+        layer = GCNLayer(dev(), ds, d, d)
+    finally:
+        Gs.graph_completeness = 'uqi'
+    layer.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f'{tag}.sd.')})
+    layer.to(dev())
+    x = torch.from_numpy(z[f'{tag}.x']).to(dev()).requires_grad_(True)
+    y = layer(x)
+    y.backward(torch.from_numpy(z[f'{tag}.cot']).to(dev()))
+    assert rel(y, z[f'{tag}.y']) <= RTOL and rel(x.grad, z[f'{tag}.dx']) <= RTOL
+    for name, p in layer.named_parameters():
+        assert rel(p.grad, z[f'{tag}.grad.{name}']) <= RTOL, name
+
+
+def test_f7_gcn_model_matches_reference():
+    from ihgnn_amd.Helpers.Graph import Pps2DGraph
+    from ihgnn_amd.Models import GCNLayer, HemPredictionLayer, RawGnn
+    z = np.load(os.path.join(GOLDEN, 'f7_gcn.npz'))
+    ds = dataset_from_npz(np.load(os.path.join(GOLDEN, 'f2_small_workload.npz')))
+    ds.graph_type = Pps2DGraph
+    m = RawGnn(dev(), ds, 16, GCNLayer, 2, 1, False, HemPredictionLayer, 0.5).to(dev())
+    sd = {k[len('model.sd.'):]: torch.from_numpy(z[k]) for k in z.files if k.startswith('model.sd.')}
+    assert set(sd) == set(m.state_dict())
+    m.load_state_dict(sd)
+    u, q, i = (torch.from_numpy(z[f'model.{k}']).to(dev()) for k in 'uqi')
+    scores = m(u, q, i)
+    loss = torch.nn.BCEWithLogitsLoss()(scores, torch.from_numpy(z['model.flags']).to(dev()))
+    loss.backward()
+    assert rel(scores, z['model.scores']) <= RTOL and abs(loss.item() - float(z['model.loss'])) <= 1e-6
+    for name, p in m.named_parameters():
+        assert rel(p.grad, z[f'model.grad.{name}']) <= 2e-5, name

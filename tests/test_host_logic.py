@@ -210,3 +210,22 @@ def test_synthetic_workload_is_deterministic_and_file_roundtrips(tmp_path):
     p = synth.draw(1000, 100, 1000, 50, 20000, seed=2, distribution='powerlaw', exponent=1.2)
     deg = np.bincount(p.triples[:, 0], minlength=1000)
     assert deg.max() > 20 * np.median(deg[deg > 0])              # genuinely skewed
+
+
+@pytest.mark.parametrize('tag,mode', [('tiny_uqi', 'uqi'), ('tiny_qi', 'qi'), ('small_uqi', 'uqi'), ('small_ui', 'ui')])
+def test_pairwise_graph_matches_reference(f1, tag, mode):
+    """Pps2DGraph via the native ihg_build_pair_csr: coalesced adjacency (duplicates summed) and degrees (fixture F7)."""
+    from ihgnn_amd.Helpers.Graph import Pps2DGraph
+    z = np.load(os.path.join(GOLDEN, 'f7_gcn.npz'))
+    if tag.startswith('tiny'):
+        triples, (U, Q, I) = f1[1].pos_triples, (5, 4, 6)
+    else:
+        w = np.load(os.path.join(GOLDEN, 'f2_small_workload.npz'))
+        triples, (U, Q, I) = w['triples'], (40, 20, 50)
+    g = Pps2DGraph.from_triples(triples, U + Q + I, U, Q, False, CPU, completeness=mode)
+    np.testing.assert_array_equal(g.Adjacency.indices().numpy(), z[f'{tag}.adj_indices'])
+    np.testing.assert_array_equal(g.Adjacency.values().numpy(), z[f'{tag}.adj_values'])
+    np.testing.assert_array_equal(g.VertexDegrees.numpy(), z[f'{tag}.degrees'])
+    looped = Pps2DGraph.from_triples(triples, U + Q + I, U, Q, True, CPU, completeness=mode)      # Graph.py:27-29
+    assert torch.equal(looped.VertexDegrees[:, 0], torch.where(g.VertexDegrees[:, 0] < 0.5, torch.ones(U + Q + I), g.VertexDegrees[:, 0] + 1))
+    assert looped.layout.csr.nnz == g.layout.csr.nnz + U + Q + I

@@ -189,3 +189,47 @@ def test_f6_training_curve_and_metrics(tag):
             acc += ref.ranking_metrics(m(int(uu) * ones, int(qq) * ones, None), items)
     # north_star acceptance: HR@10 / NDCG@10 within +-0.002 of the reference
     np.testing.assert_allclose(acc / len(w['test_uq']), z[f'{tag}.metrics'], atol=2e-3)
+
+
+F7_CASES = [('tiny_uqi', 8, 'uqi'), ('small_uqi', 64, 'uqi'), ('small_ui', 32, 'ui'), ('tiny_qi', 8, 'qi')]
+
+
+def pair_graph(tag, mode):
+    if tag.startswith('tiny'):
+        z, _ = f1_graph()
+        U, Q, I, V, N = (int(x) for x in z['counts'])
+        return ref.PairGraph(z['pos_uqif'][:, :3], U, Q, I, mode)
+    w = np.load(os.path.join(GOLDEN, 'f2_small_workload.npz'))
+    U, Q, I, V = (int(x) for x in w['counts'])
+    return ref.PairGraph(w['triples'], U, Q, I, mode)
+
+
+@pytest.mark.parametrize('tag,d,mode', F7_CASES)
+def test_f7_gcn_layer(tag, d, mode):
+    z = np.load(os.path.join(GOLDEN, 'f7_gcn.npz'))
+    g = pair_graph(tag, mode)
+    np.testing.assert_array_equal(g.Adjacency.indices().numpy(), z[f'{tag}.adj_indices'])
+    np.testing.assert_array_equal(g.Adjacency.values().numpy(), z[f'{tag}.adj_values'])
+    np.testing.assert_array_equal(g.VertexDegrees.numpy(), z[f'{tag}.degrees'])
+    t = lambda k: torch.from_numpy(z[f'{tag}.{k}']).clone().requires_grad_(True)
+    x, w, b = t('x'), t('sd.feature_transform.weight'), t('sd.feature_transform.bias')
+    y = ref.gcn_layer(x, g, w, b)
+    y.backward(torch.from_numpy(z[f'{tag}.cot']))
+    assert rel_err(y.detach().numpy(), z[f'{tag}.y']) <= RTOL and rel_err(x.grad.numpy(), z[f'{tag}.dx']) <= RTOL
+    assert rel_err(w.grad.numpy(), z[f'{tag}.grad.feature_transform.weight']) <= RTOL
+    assert rel_err(b.grad.numpy(), z[f'{tag}.grad.feature_transform.bias']) <= RTOL
+
+
+def test_f7_gcn_model():
+    z = np.load(os.path.join(GOLDEN, 'f7_gcn.npz'))
+    w, g = small_graph()
+    m = ref.OracleRawGnn(g, torch.from_numpy(w['bag_words'] + 1), torch.from_numpy(w['bag_offsets']), int(w['counts'][3]), 16, 'gcn', 2, 1)
+    m.pair_graph = pair_graph('small', 'uqi')
+    m.load_reference_state({k[len('model.sd.'):]: z[k] for k in z.files if k.startswith('model.sd.')})
+    u, q, i = (torch.from_numpy(z[f'model.{k}']) for k in 'uqi')
+    scores = m(u, q, i)
+    loss = torch.nn.BCEWithLogitsLoss()(scores, torch.from_numpy(z['model.flags']))
+    loss.backward()
+    assert rel_err(scores.detach().numpy(), z['model.scores']) <= RTOL and abs(loss.item() - float(z['model.loss'])) <= 1e-6
+    for key, gr in m.reference_grads().items():
+        assert rel_err(gr.numpy(), z[f'model.grad.{key}']) <= 5e-6, key
