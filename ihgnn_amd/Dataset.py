@@ -7,6 +7,7 @@ list-of-namedtuples view is built only if somebody asks for ``pos_interactions``
 """
 from __future__ import annotations
 
+import os
 import random
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
@@ -21,6 +22,23 @@ from .Helpers.SearchLog import PosInteraction, SearchLog
 from .Helpers.SearchLogCollection import SearchLogCollection
 
 Sample = Tuple[Tuple[int, int, int, int], List[int]]
+
+
+def parse_search_logs(filename: str) -> Tuple[int, np.ndarray, np.ndarray]:
+    """Native two-pass parse of a search-log CSV -> (row count, positive ``[P,3]``, negative ``[M,3]`` (user, query, item))."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    path = os.fsencode(filename)
+    n_logs, n_pos, n_neg = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.ihg_parse_search_logs(path, ctypes.byref(n_logs), ctypes.byref(n_pos), ctypes.byref(n_neg), None, 0, None, 0),
+               'ihg_parse_search_logs')
+    pos = np.empty((max(n_pos.value, 1), 3), np.int64)
+    neg = np.empty((max(n_neg.value, 1), 3), np.int64)
+    as_ptr = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    _lib.check(lib.ihg_parse_search_logs(path, ctypes.byref(n_logs), ctypes.byref(n_pos), ctypes.byref(n_neg),
+                                         as_ptr(pos), n_pos.value, as_ptr(neg), n_neg.value), 'ihg_parse_search_logs')
+    return int(n_logs.value), pos[:n_pos.value], neg[:n_neg.value]
 
 
 class GraphDataset(Dataset):
@@ -41,27 +59,18 @@ class GraphDataset(Dataset):
                 bag_offsets.append(len(bag_words))
                 bag_words.extend(int(tok) for tok in line.split())
 
-        logs = SearchLogCollection.read(fn_train_data)
-        triples: List[Tuple[int, int, int]] = []
-        negatives: List[Tuple[int, int, int]] = []
-        for log in logs:
-            for item, flag in zip(log.items, log.interactions):
-                (triples if flag > 0 else negatives).append((log.user, log.query, item))
-
-        self._setup(counts, np.asarray(bag_words, np.int64), np.asarray(bag_offsets, np.int64),
-                    np.asarray(triples, np.int64).reshape(-1, 3), graph_type,
+        n_logs, triples, negatives = parse_search_logs(fn_train_data)
+        self._setup(counts, np.asarray(bag_words, np.int64), np.asarray(bag_offsets, np.int64), triples, graph_type,
                     random_negative_sample_size, non_random_negative_sample_size, device)
-        self.search_logs = logs
-        self.neg_interactions = negatives
-        neg_of: Dict[Tuple[int, int], List[int]] = {}
-        for log in logs:
-            bucket = neg_of.setdefault((log.user, log.query), [])
-            bucket.extend(item for item, flag in zip(log.items, log.interactions) if flag <= 0)
-        self.neg_items_for_user_query_pair = neg_of
+        self._fn_train_data = fn_train_data
+        self._search_logs = None
+        self._neg_triples = negatives
+        self._neg_interactions = None
+        self._neg_of = None
 
         IOHelper.LogPrint(f'training set ready: {fn_train_data}')
         IOHelper.LogPrint(f'users {self.user_count} | queries {self.query_count} | items {self.item_count} | '
-                          f'vocabulary {self.vocab_size} | logs {len(logs)} | hyperedges {len(self)} | {graph_type.__name__}')
+                          f'vocabulary {self.vocab_size} | logs {n_logs} | hyperedges {len(self)} | {graph_type.__name__}')
         if len(self):
             IOHelper.LogPrint(f'{len(negatives) / len(self):.4f} logged negatives per positive')
 
@@ -76,9 +85,11 @@ class GraphDataset(Dataset):
         self._setup([user_count, query_count, item_count, vocab_size], np.asarray(bag_words, np.int64),
                     np.asarray(bag_offsets, np.int64), np.asarray(triples, np.int64).reshape(-1, 3), graph_type,
                     random_negative_sample_size, non_random_negative_sample_size, device)
-        self.search_logs = None
-        self.neg_interactions = []
-        self.neg_items_for_user_query_pair = {}
+        self._fn_train_data = None
+        self._search_logs = None
+        self._neg_triples = np.zeros((0, 3), np.int64)
+        self._neg_interactions = None
+        self._neg_of = None
         return self
 
     def _setup(self, counts: Sequence[int], bag_words: np.ndarray, bag_offsets: np.ndarray, triples: np.ndarray,
@@ -115,6 +126,31 @@ class GraphDataset(Dataset):
         self._queries_multihot = None
 
     # -- lazily built views -----------------------------------------------------------------------
+    @property
+    def search_logs(self) -> Optional[SearchLogCollection]:
+        """The parsed rows as the reference keeps them (``Dataset.py:192``); only materialised if somebody asks."""
+        if self._search_logs is None and self._fn_train_data is not None:
+            self._search_logs = SearchLogCollection.read(self._fn_train_data)
+        return self._search_logs
+
+    @property
+    def neg_interactions(self) -> List[Tuple[int, int, int]]:
+        if self._neg_interactions is None:
+            self._neg_interactions = [tuple(r) for r in self._neg_triples.tolist()]
+        return self._neg_interactions
+
+    @property
+    def neg_items_for_user_query_pair(self) -> Dict[Tuple[int, int], List[int]]:
+        """(user, query) -> logged negative items in file order; every logged pair has an entry (``Dataset.py:201-210``)."""
+        if self._neg_of is None:
+            table: Dict[Tuple[int, int], List[int]] = {}
+            if self.search_logs is not None:
+                for log in self.search_logs:
+                    bucket = table.setdefault((log.user, log.query), [])
+                    bucket.extend(item for item, flag in zip(log.items, log.interactions) if flag <= 0)
+            self._neg_of = table
+        return self._neg_of
+
     @property
     def pos_interactions(self) -> List[PosInteraction]:
         if self._pos_interactions is None:

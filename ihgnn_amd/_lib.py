@@ -19,7 +19,7 @@ import torch  # noqa: F401  (side effect: loads the HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
@@ -32,6 +32,7 @@ SIGNATURES = {
     'ihg_abi_version': (c_int32, []),
     'ihg_last_error_string': (c_char_p, []),
     'ihg_build_csr': (ctypes.c_int, [_i64p, c_int64, c_int64, c_int64, c_int64, _i32p, _i32p, _i32p, _f32p]),
+    'ihg_parse_search_logs': (ctypes.c_int, [c_char_p, _i64p, _i64p, _i64p, _i64p, c_int64, _i64p, c_int64]),
     'ihg_build_pair_csr': (ctypes.c_int, [_i64p, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32, _i32p, _i32p, _f32p, _f32p,
                                           c_int64, _i64p]),
     'ihg_transpose_csr': (ctypes.c_int, [_i32p, _i32p, c_int64, c_int64, _i32p, _i32p]),

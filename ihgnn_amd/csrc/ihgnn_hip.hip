@@ -1735,6 +1735,22 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, n_slabs, dim, NBLK, dw, ld_dw);
 }
 
+// Parses the space-separated integers of one CSV field into `out`; returns false on a malformed token.
+bool parse_int_list(const char* p, const char* end, std::vector<int64_t>& out) {
+    out.clear();
+    while (p < end) {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+        if (p >= end) break;
+        bool neg = false;
+        if (*p == '-' || *p == '+') { neg = *p == '-'; ++p; }
+        if (p >= end || *p < '0' || *p > '9') return false;
+        int64_t v = 0;
+        while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+        out.push_back(neg ? -v : v);
+    }
+    return true;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1742,7 +1758,7 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
 // =================================================================================================
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 6; }
+int32_t ihg_abi_version(void) { return 7; }
 
 const char* ihg_last_error_string(void) { return g_error; }
 
@@ -1831,6 +1847,80 @@ int ihg_build_pair_csr(const int64_t* triples, int64_t n_edges, int64_t n_users,
         degree[v] = (!self_loops && deg[v] == 0.f) ? 1e-8f : deg[v];
     }
     *nnz_out = nnz;
+    return IHG_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// HOST: search-log CSV ingestion.
+// ------------------------------------------------------------------------------------------------
+
+int ihg_parse_search_logs(const char* path, int64_t* n_logs, int64_t* n_pos, int64_t* n_neg, int64_t* pos, int64_t pos_capacity,
+                          int64_t* neg, int64_t neg_capacity) {
+    if (path == nullptr || n_logs == nullptr || n_pos == nullptr || n_neg == nullptr) return fail(IHG_ERR_INVALID, "ihg_parse_search_logs: null argument");
+    FILE* f = std::fopen(path, "rb");
+    if (f == nullptr) return fail(IHG_ERR_INVALID, "ihg_parse_search_logs: cannot open %s", path);
+    std::fseek(f, 0, SEEK_END);
+    const long size = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<char> text(static_cast<size_t>(size > 0 ? size : 0) + 1);
+    const size_t got = size > 0 ? std::fread(text.data(), 1, static_cast<size_t>(size), f) : 0;
+    std::fclose(f);
+    text[got] = '\n';
+    const char* p = text.data();
+    const char* const end = p + got + 1;
+    while (p < end && *p != '\n') ++p;                      // header line (SearchLogCollection.py:28)
+    ++p;
+    int64_t logs = 0, pcount = 0, ncount = 0, line_no = 1;
+    std::vector<int64_t> items, flags, scalar;
+    while (p < end) {
+        const char* eol = p;
+        while (eol < end && *eol != '\n') ++eol;
+        ++line_no;
+        const char* q = p;
+        bool blank = true;
+        for (const char* c = p; c < eol; ++c)
+            if (*c != ' ' && *c != '\r' && *c != '\t') { blank = false; break; }
+        if (!blank) {
+            const char* field[9];
+            int n_fields = 0;
+            field[n_fields++] = q;
+            for (const char* c = q; c < eol && n_fields < 9; ++c)
+                if (*c == ',') field[n_fields++] = c + 1;
+            int commas = 0;
+            for (const char* c = q; c < eol; ++c) commas += *c == ',';
+            if (commas != 7) return fail(IHG_ERR_INVALID, "ihg_parse_search_logs: %s line %lld has %d columns, expected 8", path, (long long)line_no, commas + 1);
+            field[8] = eol + 1;
+            auto fend = [&](int k) { return field[k + 1] - 1; };
+            if (!parse_int_list(field[0], fend(0), scalar) || scalar.size() != 1) return fail(IHG_ERR_INVALID, "ihg_parse_search_logs: %s line %lld: bad user id", path, (long long)line_no);
+            const int64_t user = scalar[0];
+            if (!parse_int_list(field[1], fend(1), scalar) || scalar.size() != 1) return fail(IHG_ERR_INVALID, "ihg_parse_search_logs: %s line %lld: bad query id", path, (long long)line_no);
+            const int64_t query = scalar[0];
+            if (!parse_int_list(field[3], fend(3), items) || !parse_int_list(field[6], fend(6), flags))
+                return fail(IHG_ERR_INVALID, "ihg_parse_search_logs: %s line %lld: bad item / interaction list", path, (long long)line_no);
+            const size_t n = items.size() < flags.size() ? items.size() : flags.size();
+            for (size_t k = 0; k < n; ++k) {
+                if (flags[k] > 0) {
+                    if (pos != nullptr) {
+                        if (pcount >= pos_capacity) return fail(IHG_ERR_WORKSPACE, "ihg_parse_search_logs: positive buffer too small");
+                        pos[pcount * 3] = user; pos[pcount * 3 + 1] = query; pos[pcount * 3 + 2] = items[k];
+                    }
+                    ++pcount;
+                } else {
+                    if (neg != nullptr) {
+                        if (ncount >= neg_capacity) return fail(IHG_ERR_WORKSPACE, "ihg_parse_search_logs: negative buffer too small");
+                        neg[ncount * 3] = user; neg[ncount * 3 + 1] = query; neg[ncount * 3 + 2] = items[k];
+                    }
+                    ++ncount;
+                }
+            }
+            ++logs;
+        }
+        p = eol + 1;
+    }
+    *n_logs = logs;
+    *n_pos = pcount;
+    *n_neg = ncount;
     return IHG_OK;
 }
 

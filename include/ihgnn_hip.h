@@ -58,6 +58,16 @@ int ihg_build_csr(const int64_t* triples, int64_t n_edges,
                   int64_t n_users, int64_t n_queries, int64_t n_items,
                   int32_t* i3, int32_t* rowptr, int32_t* edge_ids, float* degree);
 
+/* HOST: search-log CSV ingestion.  Replaces SearchLogCollection.read + SearchLog.parse + the positive / negative split
+ * of GraphDataset.__init__ (Helpers/SearchLogCollection.py:25-32, Helpers/SearchLog.py:63-71, Dataset.py:195-213) for the
+ * quantities the graph needs.  File: one header line, then rows `user,query,search_time,items,pages,positions,
+ * interactions,times` whose list fields are space-separated; item k of a row is a positive interaction when
+ * interactions[k] > 0.  Pass pos == neg == NULL to count (n_logs / n_pos / n_neg), then call again with buffers of
+ * [n_pos,3] / [n_neg,3] int64 to receive the (user, query, item) triples in file order.  neg may stay NULL.
+ */
+int ihg_parse_search_logs(const char* path, int64_t* n_logs, int64_t* n_pos, int64_t* n_neg,
+                          int64_t* pos, int64_t pos_capacity, int64_t* neg, int64_t neg_capacity);
+
 /* HOST: pairwise graph of the GCN baseline.  Replaces Pps2DGraph.from_interactions (Helpers/Graph.py:19-81) and the
  * coalesce() of its adjacency.  completeness: 0 = uqi (u-q, q-i, i-u per interaction), 1 = uq, 2 = ui, 3 = qi
  * (Graph.py:40-63; every pair is stored in both directions).  Output: CSR of the symmetric [N x N] adjacency with

@@ -229,3 +229,35 @@ def test_pairwise_graph_matches_reference(f1, tag, mode):
     looped = Pps2DGraph.from_triples(triples, U + Q + I, U, Q, True, CPU, completeness=mode)      # Graph.py:27-29
     assert torch.equal(looped.VertexDegrees[:, 0], torch.where(g.VertexDegrees[:, 0] < 0.5, torch.ones(U + Q + I), g.VertexDegrees[:, 0] + 1))
     assert looped.layout.csr.nnz == g.layout.csr.nnz + U + Q + I
+
+
+def test_native_search_log_parser_matches_python_parser(tmp_path):
+    """f4: ihg_parse_search_logs == SearchLog.parse + positive/negative split, on the hand-made fixture and a random file."""
+    from ihgnn_amd.Dataset import parse_search_logs
+    from ihgnn_amd.Helpers.SearchLogCollection import SearchLogCollection
+    from ihgnn_amd._lib import IhgnnHipError
+    rng = np.random.default_rng(3)
+    fn = tmp_path / 'logs.csv'
+    with open(fn, 'w') as f:
+        f.write(synth.CSV_HEADER + '\n')
+        for r in range(500):
+            n = int(rng.integers(1, 7))
+            items, flags = rng.integers(0, 1000, n), rng.integers(0, 3, n)
+            f.write(f'{rng.integers(0, 50)},{rng.integers(0, 20)},1400000000,' + ' '.join(map(str, items)) + ',' + ' '.join(['1'] * n) + ',' +
+                    ' '.join(map(str, range(n))) + ',' + ' '.join(map(str, flags)) + ',' + ' '.join(['NA'] * n) + '\n')
+        f.write('\n')                                   # trailing blank line is ignored
+    for path in (str(fn), os.path.join(F1, 'train_data.csv')):
+        n_logs, pos, neg = parse_search_logs(path)
+        logs = SearchLogCollection.read(path)
+        want_pos = [(l.user, l.query, i) for l in logs for i, fl in zip(l.items, l.interactions) if fl > 0]
+        want_neg = [(l.user, l.query, i) for l in logs for i, fl in zip(l.items, l.interactions) if fl <= 0]
+        assert n_logs == len(logs) and pos.tolist() == [list(t) for t in want_pos] and neg.tolist() == [list(t) for t in want_neg]
+    bad = tmp_path / 'bad.csv'
+    bad.write_text(synth.CSV_HEADER + '\n1,2,3,4 5,1 1,1 2,1 0\n')          # 7 columns
+    with pytest.raises(IhgnnHipError, match='line 2 has 7 columns'):
+        parse_search_logs(str(bad))
+    bad.write_text(synth.CSV_HEADER + '\n1,2,3,4 x,1 1,1 2,1 0,NA NA\n')
+    with pytest.raises(IhgnnHipError, match='bad item'):
+        parse_search_logs(str(bad))
+    with pytest.raises(IhgnnHipError, match='cannot open'):
+        parse_search_logs(str(tmp_path / 'missing.csv'))
