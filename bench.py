@@ -196,6 +196,15 @@ def main():
                         traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected (profiles/r1/pmc_traffic.json)' if traffic else None,
                         bytes_per_launch=k5_bytes, avg_us=round(k5['avg_us'], 2), launches=k5['launches'],
                         hyperedges_per_s=round(E / (k5['avg_us'] * 1e-6), 1))
+    k7_roof = None
+    if 'node_segment_sum' in kernels:
+        # the forward/backward K7 launches over the [E,d] edge features (the [3E,d] member pass has the same byte count)
+        k7_bytes = E * (12 * dim + 12) + N * (4 * dim + 8)
+        k7 = kernels['node_segment_sum']
+        k7_achieved = k7_bytes / (k7['avg_us'] * 1e-6) / 1e9
+        k7_roof = dict(bound='hbm', kernel='node_segment_sum (K7 hyperedge->node segment-sum, split rows included)', achieved=round(k7_achieved, 1),
+                       peak=HBM_PEAK_GBS, unit='GB/s', frac=round(k7_achieved / HBM_PEAK_GBS, 4), bytes_per_launch=k7_bytes,
+                       avg_us=round(k7['avg_us'], 2), launches=k7['launches'])
     out = {
         'metric': 'hyperedges_aggregated_per_sec', 'value': round(value, 1), 'unit': 'hyperedges/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
@@ -208,6 +217,7 @@ def main():
         'fwd_only_hyperedges_per_s': round(E * layers / fwd_elapsed, 1), 'fwd_only_ms': round(1e3 * fwd_elapsed, 4),
         'final_loss': round(float(last.item()), 6),
         'roofline': roofline,
+        'roofline_hyperedge_to_node': k7_roof,
         'kernels_us': {name: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] / args.steps} for name, v in kernels.items()},
     }
     if world == 1 and not args.no_cpu_baseline:
