@@ -30,13 +30,14 @@ class HGCNLayer(nn.Module):
         self.dataset = dataset
         self.layout = dataset.hypergraph.layout
         self.edge_scale = float(torch.tensor(3.0).pow(-1))      # De^-1 of a 3-uniform hypergraph, as fp32
+        self.out_scale = self.layout.inv_sqrt_deg * self.edge_scale
         self.feature_transform = nn.Linear(input_dimension, output_dimension)
 
     def forward(self, input_features: Tensor) -> Tensor:
         lay = self.layout
         h = _transform(self.feature_transform, input_features, lay)
-        edge_features = ops.edge_gather_sum(h, lay, node_scale=lay.inv_sqrt_deg, alpha=self.edge_scale)
-        return ops.node_segment_sum(edge_features, lay, out_scale=lay.inv_sqrt_deg)
+        # node -> hyperedge -> node in one two-hop pass over the node table: Dv^-1/2 on the way in, Dv^-1/2 De^-1 on the way out
+        return ops.node_two_hop(h, lay, in_scale=lay.inv_sqrt_deg, out_scale=self.out_scale)
 
 
 class IHGNNLayer(nn.Module):
@@ -62,6 +63,9 @@ class IHGNNLayer(nn.Module):
 
     def forward(self, input_features: Tensor) -> Tensor:
         h = _transform(self.feature_transform, input_features, self.layout)
+        if self.feature_interaction_order == 1:
+            # first-order layer: hoisted node-level blocks, then node -> hyperedge -> node fused into one two-hop pass
+            return ops.node_two_hop(self.feature_interactor.first_order(h), self.layout, out_scale=self.layout.inv_deg)
         edge_features = self.feature_interactor(h)
         return ops.node_segment_sum(edge_features, self.layout, out_scale=self.layout.inv_deg)
 

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (side effect: loads the HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
@@ -40,7 +40,7 @@ SIGNATURES = {
                                            c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'ihg_node_segment_sum': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                             c_void_p, c_int64, c_int64, c_int32, c_int32,
-                                            c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+                                            c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'ihg_bag_mean_fwd': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                         c_int64, c_int32, c_void_p]),
     'ihg_bag_mean_bwd': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
     const int32_t* __restrict__ row_order, const float* __restrict__ src_scale, const float* __restrict__ entry_scale,
     const float* __restrict__ out_scale, int mode,
     float* __restrict__ out, int64_t ld_out, int64_t n_rows, int dim, int dim_vec, int heavy_threshold,
-    const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments, float* __restrict__ partials) {
+    const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments, float* __restrict__ partials,
+    const float* __restrict__ self_weight) {
     constexpr int GPW = kWave / G;
     const int lane = threadIdx.x & (kWave - 1);
     const int lig = lane & (G - 1);
@@ -247,7 +248,12 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
             const int col = c < dim_vec ? c : -1;
             Frag<VEC> acc = accumulate_list<VEC, G>(src, ld_src, ids, src_scale, entry_scale, begin, len, wave_len, lane, col);
             if (dst != nullptr && col >= 0) {
-                if (scale_row >= 0) apply_out_scale<VEC>(acc, out_scale, mode, scale_row);
+                if (scale_row >= 0) {
+                    if (self_weight != nullptr)             // square operators: the row's own source row, weighted
+                        acc.add_scaled(Frag<VEC>::load(src + scale_row * ld_src + col * VEC),
+                                       self_weight[scale_row] * (src_scale != nullptr ? src_scale[scale_row] : 1.f));
+                    apply_out_scale<VEC>(acc, out_scale, mode, scale_row);
+                }
                 acc.store(dst + col * VEC);
             }
         }
@@ -259,7 +265,8 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
 template <int VEC, int G>
 __global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
     const float* __restrict__ partials, const int32_t* __restrict__ heavy_rows, const int32_t* __restrict__ heavy_segptr,
-    int64_t n_heavy, const float* __restrict__ out_scale, int mode, float* __restrict__ out, int64_t ld_out, int dim, int dim_vec) {
+    int64_t n_heavy, const float* __restrict__ out_scale, int mode, float* __restrict__ out, int64_t ld_out, int dim, int dim_vec,
+    const float* __restrict__ src, int64_t ld_src, const float* __restrict__ src_scale, const float* __restrict__ self_weight) {
     constexpr int GROUPS = kBlockThreads / G;
     __shared__ __attribute__((aligned(16))) float red[GROUPS][G * VEC];
     const int lig = threadIdx.x & (G - 1);
@@ -287,6 +294,8 @@ __global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
                 Frag<VEC> total = Frag<VEC>::load(&red[0][lig * VEC]);
                 const int used = s_end - s_begin < GROUPS ? s_end - s_begin : GROUPS;
                 for (int g2 = 1; g2 < used; ++g2) total.add(Frag<VEC>::load(&red[g2][lig * VEC]));
+                if (self_weight != nullptr)
+                    total.add_scaled(Frag<VEC>::load(src + row * ld_src + c * VEC), self_weight[row] * (src_scale != nullptr ? src_scale[row] : 1.f));
                 apply_out_scale<VEC>(total, out_scale, mode, row);
                 total.store(out + row * ld_out + c * VEC);
             }
@@ -1640,24 +1649,24 @@ struct HeavyPlan {
 template <int VEC, int G>
 void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
                           const float* src_scale, const float* entry_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
-                          int heavy_threshold, const HeavyPlan& hp, hipStream_t stream) {
+                          int heavy_threshold, const HeavyPlan& hp, const float* self_weight, hipStream_t stream) {
     constexpr int GPW = kWave / G;
     const int dim_vec = dim / VEC;
     const int grid = grid_for_waves((n_rows + hp.n_segments + GPW - 1) / GPW);
     hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr, ids, row_order,
                        src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, dim_vec, heavy_threshold, hp.seg_begin, hp.seg_end,
-                       hp.n_segments, hp.partials);
+                       hp.n_segments, hp.partials, self_weight);
     if (hp.n_heavy > 0)
         hipLaunchKernelGGL((heavy_finish_kernel<VEC, G>), dim3(static_cast<int>(std::min<int64_t>(hp.n_heavy, kMaxBlocks * 4))),
                            dim3(kBlockThreads), 0, stream, hp.partials, hp.heavy_rows, hp.heavy_segptr, hp.n_heavy, out_scale, mode, out,
-                           ld_out, dim, dim_vec);
+                           ld_out, dim, dim_vec, src, ld_src, src_scale, self_weight);
 }
 
 template <int VEC>
 int launch_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
                        const float* src_scale, const float* entry_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
-                       int heavy_threshold, const HeavyPlan& hp, hipStream_t stream) {
-#define IHG_K7(G) launch_segment_sum_g<VEC, G>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, heavy_threshold, hp, stream)
+                       int heavy_threshold, const HeavyPlan& hp, const float* self_weight, hipStream_t stream) {
+#define IHG_K7(G) launch_segment_sum_g<VEC, G>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, heavy_threshold, hp, self_weight, stream)
     switch (group_lanes(dim / VEC)) {
         case 4: IHG_K7(4); break;
         case 8: IHG_K7(8); break;
@@ -1758,7 +1767,7 @@ bool parse_int_list(const char* p, const char* end, std::vector<int64_t>& out) {
 // =================================================================================================
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 7; }
+int32_t ihg_abi_version(void) { return 8; }
 
 const char* ihg_last_error_string(void) { return g_error; }
 
@@ -1955,7 +1964,7 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
                          const float* src_scale, const float* entry_scale, const float* out_scale, int32_t out_scale_mode, float* out, int64_t ld_out,
                          int64_t n_rows, int32_t dim, int32_t heavy_threshold, const int32_t* seg_begin, const int32_t* seg_end,
                          int64_t n_segments, const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy, float* partials,
-                         ihg_stream_t stream) {
+                         const float* self_weight, ihg_stream_t stream) {
     if (n_rows < 0 || dim <= 0 || ld_src < dim || ld_out < dim || n_segments < 0 || n_heavy < 0) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad size");
     if (!scale_mode_ok(out_scale_mode, out_scale)) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad out_scale_mode %d", out_scale_mode);
     if (n_rows == 0) return IHG_OK;
@@ -1969,20 +1978,20 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
     const HeavyPlan hp{seg_begin, seg_end, n_segments, heavy_rows, heavy_segptr, n_heavy, partials};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out) && (n_heavy == 0 || aligned16(partials));
-    return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, s)
-                : launch_segment_sum<1>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, s);
+    return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, self_weight, s)
+                : launch_segment_sum<1>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, self_weight, s);
 }
 
 int ihg_bag_mean_fwd(const float* table, int64_t ld_table, const int32_t* bag_ptr, const int32_t* words, const float* bag_len,
                      float* out, int64_t ld_out, int64_t n_bags, int32_t dim, ihg_stream_t stream) {
     if (bag_len == nullptr && n_bags > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_fwd: null bag_len");
-    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, nullptr, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, stream);
+    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, nullptr, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, stream);
 }
 
 int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr, const int32_t* word_bags, const float* inv_len,
                      float* dtable, int64_t ld_dtable, int64_t n_table_rows, int32_t dim, ihg_stream_t stream) {
     if (inv_len == nullptr && n_table_rows > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_bwd: null inv_len");
-    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, nullptr, inv_len, nullptr, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, stream);
+    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, nullptr, inv_len, nullptr, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, stream);
 }
 
 int64_t ihg_interact_fwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order) {

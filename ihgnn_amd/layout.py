@@ -182,7 +182,17 @@ class IncidenceLayout:
         slot_of_node = np.zeros(n, np.int32)
         slot_of_node[u:u + q] = 1
         slot_of_node[u + q:] = 2
-        self.member_csr = self.node_csr.with_ids(edge_ids[:3 * e] * 3 + np.repeat(slot_of_node, lens))
+        slot_of_entry = np.repeat(slot_of_node, lens)
+        self.member_csr = self.node_csr.with_ids(edge_ids[:3 * e] * 3 + slot_of_entry)
+        # hop2_csr: node v -> the OTHER two members of each of its hyperedges (2 ids per incidence); together with
+        # self_weight = deg(v) for the node's own row it is the two-hop operator H H^T, read straight from the node table.
+        inc = i3[:e][edge_ids[:3 * e]]                                   # [3E, 3] members of every incident hyperedge
+        first = np.where(slot_of_entry == 0, 1, 0)
+        second = np.where(slot_of_entry == 2, 1, 2)
+        rows = np.arange(3 * e)
+        others = np.stack([inc[rows, first], inc[rows, second]], axis=1).reshape(-1).astype(np.int32)
+        self.hop2_csr = Csr((rowptr.astype(np.int64) * 2).astype(np.int32), others, device, heavy_threshold)
+        self.self_weight = torch.where(isolated, torch.zeros_like(deg), deg).to(device)
 
 
 COMPLETENESS = {'uqi': 0, 'uq': 1, 'ui': 2, 'qi': 3}

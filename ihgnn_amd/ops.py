@@ -74,7 +74,8 @@ def edge_gather_sum_raw(src: Tensor, i3: Tensor, node_scale: Optional[Tensor] = 
 
 def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optional[Tensor] = None,
                          out_scale: Optional[Tensor] = None, mode: int = _lib.SCALE_NONE,
-                         out: Optional[Tensor] = None, entry_scale: Optional[Tensor] = None) -> Tensor:
+                         out: Optional[Tensor] = None, entry_scale: Optional[Tensor] = None,
+                         self_weight: Optional[Tensor] = None) -> Tensor:
     lib = _lib.load()
     src = _rows(src, 'src')
     dim = int(src.shape[1])
@@ -87,7 +88,7 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
             _ptr(out), _ld(out), csr.n_rows, dim, csr.heavy_threshold if heavy else 0,
             _ptr(csr.seg_begin) if heavy else None, _ptr(csr.seg_end) if heavy else None, csr.n_segments if heavy else 0,
             _ptr(csr.heavy_rows) if heavy else None, _ptr(csr.heavy_segptr) if heavy else None, csr.n_heavy,
-            _ptr(csr.partials(dim)) if heavy else None, _stream()), 'ihg_node_segment_sum')
+            _ptr(csr.partials(dim)) if heavy else None, _ptr(self_weight), _stream()), 'ihg_node_segment_sum')
     return out
 
 
@@ -130,6 +131,30 @@ def edge_gather_sum(src: Tensor, layout: IncidenceLayout, node_scale: Optional[T
 def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor] = None) -> Tensor:
     """hyperedge -> node: ``out[v] = out_scale[v] * sum_{e containing v} src[e]``  (``[E,d] -> [N,d]``)."""
     return _NodeSegmentSum.apply(src, layout, out_scale)
+
+
+class _TwoHop(torch.autograd.Function):
+    """``out = Do * (H H^T) (Di * x)``: node -> hyperedge -> node in ONE pass over the node table (no ``[E,d]`` round trip).
+
+    ``H H^T`` is symmetric, so the backward is the same launch with the two diagonal scalings swapped."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor], out_scale: Optional[Tensor]) -> Tensor:
+        ctx.layout, ctx.in_scale, ctx.out_scale = layout, in_scale, out_scale
+        mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
+        return node_segment_sum_raw(x, layout.hop2_csr, in_scale, out_scale, mode, self_weight=layout.self_weight)
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        lay = ctx.layout
+        mode = _lib.SCALE_NONE if ctx.in_scale is None else _lib.SCALE_MULTIPLY
+        return node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight), None, None, None
+
+
+def node_two_hop(x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None) -> Tensor:
+    """``out[v] = out_scale[v] * sum_{e containing v} sum_{w in e} in_scale[w] * x[w]`` - the first-order
+    node -> hyperedge -> node step (K5 followed by K7) without materialising the hyperedge features."""
+    return _TwoHop.apply(x, layout, in_scale, out_scale)
 
 
 class _PairSpmm(torch.autograd.Function):

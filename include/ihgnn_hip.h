@@ -104,6 +104,9 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3,
  * with w(ids[k]) = src_scale[ids[k]] (or 1), times entry_scale[k] when given (values of a weighted CSR: the pairwise
  * adjacency of GCNLayer, Models/GnnLayers.py:37-41).  Rows longer than `heavy_threshold` entries go through the split-row plan below
  * (pass n_heavy = 0 to sum every row with a single lane group).
+ * `self_weight` (optional, [n_rows], only for square operators whose ids index the same table as the output rows) adds
+ * self_weight[r] * w(r) * src[r,:] to row r before the output scale: the diagonal of a two-hop (node -> hyperedge -> node)
+ * operator, whose off-diagonal part is then listed without the row's own id.
  * `row_order` (optional, [n_rows]) is the order in which rows are handed to lane groups - a permutation sorted by
  * decreasing row length keeps the groups of one wave equally busy; NULL = natural order.  Results do not depend on it.
  * Replaces: thsp.matmul(self.incidence, edge_features) and Dv^-1 * / Dv^-1/2 * (Models/GnnLayers.py:151-152,
@@ -118,7 +121,7 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
                          int32_t heavy_threshold,
                          const int32_t* seg_begin, const int32_t* seg_end, int64_t n_segments,
                          const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy,
-                         float* partials, ihg_stream_t stream);
+                         float* partials, const float* self_weight, ihg_stream_t stream);
 /* Split rows (skewed / power-law degree distributions): the host cuts every row longer than `heavy_threshold` into
  * segments [seg_begin, seg_end) of the `ids` array.  The SAME launch sums every segment with its own lane group into
  * partials[s,:] (workspace, n_segments x dim floats) next to the light rows, then a second small kernel adds each heavy

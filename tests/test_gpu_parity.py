@@ -148,6 +148,25 @@ def test_bag_mean_forward_backward(dim):
     assert (tg.grad[0] == 0).all()                        # padding row never indexed
 
 
+@pytest.mark.parametrize('dim', [8, 64, 256])
+def test_two_hop_equals_gather_then_segment_sum(dim):
+    """The fused first-order pass (K7 on the two-hop CSR + self term) against K5 followed by K7, forward and backward,
+    on a skewed graph so that split rows and the finish kernel's self term are exercised."""
+    from ihgnn_amd import ops
+    _, lay = make_layout(300, 40, 500, 30000, seed=11, distribution='powerlaw', heavy_threshold=96, edge_order='user')
+    assert lay.hop2_csr.n_heavy > 5
+    x = torch.randn(lay.node_count, dim, device=dev())
+    cot = torch.randn(lay.node_count, dim, device=dev())
+    for in_scale, out_scale in ((None, lay.inv_deg), (lay.inv_sqrt_deg, lay.inv_sqrt_deg * 0.5), (None, None)):
+        xa = x.clone().requires_grad_(True)
+        ya = ops.node_segment_sum(ops.edge_gather_sum(xa, lay, node_scale=in_scale), lay, out_scale=out_scale)
+        ya.backward(cot)
+        xb = x.clone().requires_grad_(True)
+        yb = ops.node_two_hop(xb, lay, in_scale, out_scale)
+        yb.backward(cot)
+        assert rel(yb, ya) <= RTOL_SUM * 2 and rel(xb.grad, xa.grad) <= RTOL_SUM * 2
+
+
 def test_user_ordered_hyperedge_numbering_is_equivalent():
     """The layout's internal renumbering (hyperedges sorted by user) only permutes edge-feature rows."""
     from ihgnn_amd import ops
