@@ -80,9 +80,14 @@ class RawGnn(nn.Module):
             # scatter per layer instead of three dense [N, D] gradients that autograd would have to add up.
             rows = torch.cat([user_indices, query_indices + ds.query_start_index_in_graph,
                               item_indices + ds.item_start_index_in_graph])
-            picked = torch.cat([x[rows] for x in self.propagate_layers()], 1)
+            layers = self.propagate_layers()
+            head = self.prediction_layer
+            if layers[0].is_cuda and not Gs.Prediction.use_cosine_similarity and len(layers) <= 8:
+                from .. import ops
+                return ops.hem_score(layers, rows, item_indices, head.items_bias, head.lambda_muq)      # fused batch tail
+            picked = torch.cat([x[rows] for x in layers], 1)
             b = user_indices.shape[0]
-            return self.prediction_layer(picked[:b], picked[b:2 * b], picked[2 * b:], item_indices)
+            return head(picked[:b], picked[b:2 * b], picked[2 * b:], item_indices)
         features = self._saved_output_feature if self._saved_output_feature is not None else self.propagate()
         if item_indices is None:
             item_feature = features[ds.item_start_index_in_graph:]

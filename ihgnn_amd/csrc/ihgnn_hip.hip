@@ -1601,6 +1601,61 @@ inline int weight_slabs(int dim) {
 constexpr int kFwdGrid = 256 * 3;
 constexpr int kPipeGrid = 256;          // wave-specialised kernels: one 512-thread workgroup per CU
 
+
+// ================================================================================================
+// Batch tail (HEM scoring head over the concatenated layer outputs, Models/PredictionLayers.py:21-44 after
+// Models/RawGnn.py:122-131): one wave per batch row, lanes over the columns of every layer output; no [N, D] concat.
+//   fwd  score[r] = sum_l sum_c X_l[item_r][c] * (lam * X_l[query_r][c] + (1 - lam) * X_l[user_r][c]) + bias[item_r]
+//   bwd  rowgrad[0B + r] = ds (1 - lam) X[item_r]   (w.r.t. the user row),   rowgrad[1B + r] = ds lam X[item_r]   (query row),
+//        rowgrad[2B + r] = ds (lam X[query_r] + (1 - lam) X[user_r])   (item row); [3B, L1*d] dense and conflict-free -
+//        the caller adds duplicate rows with one deterministic scatter.
+// ================================================================================================
+struct LayerPtrs {
+    const float* x[8];
+};
+
+__global__ __launch_bounds__(kBlockThreads) void hem_score_fwd_kernel(LayerPtrs layers, int n_layers, int64_t ld, int dim,
+                                                                      const int64_t* __restrict__ rows, const int64_t* __restrict__ items,
+                                                                      const float* __restrict__ bias, float lam, float* __restrict__ scores,
+                                                                      int64_t batch) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = global_wave_id(); r < batch; r += global_wave_count()) {
+        const int64_t u = rows[r], q = rows[batch + r], it = rows[2 * batch + r];
+        float acc = 0.f;
+        for (int l = 0; l < n_layers; ++l) {
+            const float* x = layers.x[l];
+            for (int c = lane; c < dim; c += kWave) {
+                const float m = lam * x[q * ld + c] + (1.f - lam) * x[u * ld + c];
+                acc += x[it * ld + c] * m;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) scores[r] = acc + bias[items[r]];
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs layers, int n_layers, int64_t ld, int dim,
+                                                                      const int64_t* __restrict__ rows, const float* __restrict__ dscores,
+                                                                      float lam, float* __restrict__ rowgrad, int64_t batch) {
+    const int lane = threadIdx.x & 63;
+    const int64_t width = static_cast<int64_t>(n_layers) * dim;
+    for (int64_t r = global_wave_id(); r < batch; r += global_wave_count()) {
+        const int64_t u = rows[r], q = rows[batch + r], it = rows[2 * batch + r];
+        const float ds = dscores[r];
+        for (int l = 0; l < n_layers; ++l) {
+            const float* x = layers.x[l];
+            for (int c = lane; c < dim; c += kWave) {
+                const float xu = x[u * ld + c], xq = x[q * ld + c], xi = x[it * ld + c];
+                const int64_t col = static_cast<int64_t>(l) * dim + c;
+                rowgrad[r * width + col] = ds * (1.f - lam) * xi;
+                rowgrad[(batch + r) * width + col] = ds * lam * xi;
+                rowgrad[(2 * batch + r) * width + col] = ds * (lam * xq + (1.f - lam) * xu);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Dispatch helpers
 // ------------------------------------------------------------------------------------------------
@@ -1767,7 +1822,7 @@ bool parse_int_list(const char* p, const char* end, std::vector<int64_t>& out) {
 // =================================================================================================
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 8; }
+int32_t ihg_abi_version(void) { return 9; }
 
 const char* ihg_last_error_string(void) { return g_error; }
 
@@ -2134,6 +2189,39 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, bias_slabs,
                        kDenseSlabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask);
     return check_launch("ihg_node_linear_bwd_weight");
+}
+
+
+static int hem_common_check(const char* what, const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const int64_t* rows, int64_t batch) {
+    if (n_layers < 1 || n_layers > 8) return fail(IHG_ERR_INVALID, "%s: 1..8 layer outputs supported, got %d", what, n_layers);
+    if (layers == nullptr || rows == nullptr || dim <= 0 || ld < dim || batch < 0) return fail(IHG_ERR_INVALID, "%s: bad argument", what);
+    for (int l = 0; l < n_layers; ++l)
+        if (layers[l] == nullptr) return fail(IHG_ERR_INVALID, "%s: null layer pointer", what);
+    return IHG_OK;
+}
+
+int ihg_hem_score_fwd(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const int64_t* rows, const int64_t* items,
+                      const float* bias, float lambda_muq, float* scores, int64_t batch, ihg_stream_t stream) {
+    if (int rc = hem_common_check("ihg_hem_score_fwd", layers, n_layers, ld, dim, rows, batch)) return rc;
+    if (batch == 0) return IHG_OK;
+    if (items == nullptr || bias == nullptr || scores == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd: null pointer");
+    LayerPtrs lp{};
+    for (int l = 0; l < n_layers; ++l) lp.x[l] = layers[l];
+    hipLaunchKernelGGL(hem_score_fwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers, ld,
+                       dim, rows, items, bias, lambda_muq, scores, batch);
+    return check_launch("ihg_hem_score_fwd");
+}
+
+int ihg_hem_score_bwd(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const int64_t* rows, const float* dscores,
+                      float lambda_muq, float* rowgrad, int64_t batch, ihg_stream_t stream) {
+    if (int rc = hem_common_check("ihg_hem_score_bwd", layers, n_layers, ld, dim, rows, batch)) return rc;
+    if (batch == 0) return IHG_OK;
+    if (dscores == nullptr || rowgrad == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd: null pointer");
+    LayerPtrs lp{};
+    for (int l = 0; l < n_layers; ++l) lp.x[l] = layers[l];
+    hipLaunchKernelGGL(hem_score_bwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers, ld,
+                       dim, rows, dscores, lambda_muq, rowgrad, batch);
+    return check_launch("ihg_hem_score_bwd");
 }
 
 }  // extern "C"

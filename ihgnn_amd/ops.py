@@ -344,3 +344,51 @@ def interact(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: in
     if order not in (2, 3):
         raise ValueError('interact handles interaction orders 2 and 3; order 1 is edge_gather_sum on the hoisted features')
     return _Interact.apply(h, p, w, layout, int(order))
+
+
+# ---------------------------------------------------------------------------------------------
+# Batch tail: HEM scores of a training batch straight from the layer outputs
+# ---------------------------------------------------------------------------------------------
+class _HemScore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows: Tensor, items: Tensor, bias: Tensor, lam: float, *layers: Tensor) -> Tensor:
+        lib = _lib.load()
+        layers = tuple(_rows(x, 'layer output') for x in layers)
+        ld = _ld(layers[0])
+        if any(_ld(x) != ld or x.shape != layers[0].shape for x in layers):
+            layers = tuple(x.contiguous() for x in layers)
+            ld = _ld(layers[0])
+        batch, dim = int(items.shape[0]), int(layers[0].shape[1])
+        ptrs = (ctypes.c_void_p * len(layers))(*[x.data_ptr() for x in layers])
+        scores = torch.empty(batch, dtype=torch.float32, device=bias.device)
+        with profiler.kernel('hem_score_fwd', batch, dim):
+            _lib.check(lib.ihg_hem_score_fwd(ptrs, len(layers), ld, dim, _ptr(rows), _ptr(items), _ptr(bias), float(lam), _ptr(scores), batch,
+                                             _stream()), 'ihg_hem_score_fwd')
+        ctx.save_for_backward(rows, items, bias, *layers)
+        ctx.lam = float(lam)
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores: Tensor):
+        lib = _lib.load()
+        rows, items, bias, *layers = ctx.saved_tensors
+        batch, dim, n_layers = int(items.shape[0]), int(layers[0].shape[1]), len(layers)
+        dscores = dscores.contiguous()
+        ptrs = (ctypes.c_void_p * n_layers)(*[x.data_ptr() for x in layers])
+        rowgrad = torch.empty(3 * batch, n_layers * dim, dtype=torch.float32, device=bias.device)
+        with profiler.kernel('hem_score_bwd', batch, dim):
+            _lib.check(lib.ihg_hem_score_bwd(ptrs, n_layers, _ld(layers[0]), dim, _ptr(rows), _ptr(dscores), ctx.lam, _ptr(rowgrad), batch,
+                                             _stream()), 'ihg_hem_score_bwd')
+        # one deterministic scatter for all layers: duplicate rows (a user appears once per negative) are summed by index_put
+        n_nodes = int(layers[0].shape[0])
+        dense = torch.zeros(n_nodes, n_layers * dim, dtype=torch.float32, device=bias.device)
+        dense.index_put_((rows,), rowgrad, accumulate=True)
+        dbias = torch.zeros_like(bias).index_put_((items,), dscores, accumulate=True)
+        grads = tuple(dense[:, l * dim:(l + 1) * dim] for l in range(n_layers))
+        return (None, None, dbias, None) + grads
+
+
+def hem_score(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float) -> Tensor:
+    """HEM scores of a batch: ``rows`` = global node rows of users, queries, items (``[3B]`` int64), ``items`` = 0-based item
+    ids (``[B]``), ``layers`` = the ``[N,d]`` outputs ``X_0..X_L`` whose concatenation the reference scores on."""
+    return _HemScore.apply(rows, items, bias, float(lam), *layers)

@@ -209,6 +209,25 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
                                float* dbias, int32_t bias_type_mask,
                                void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DEVICE: batch tail - HEM scoring head over the layer outputs.
+ * Replaces torch.cat(gnn_outputs, 1) + the three row gathers of RawGnn.forward (Models/RawGnn.py:122-131) and
+ * HemPredictionLayer.forward (Models/PredictionLayers.py:30-43, dot-product branch) for a training batch, and their
+ * autograd backward up to (not including) the scatter of duplicate rows.
+ *   layers   HOST array of n_layers (<= 8) device pointers, layer l = [N, dim] with row stride ld
+ *   rows     device int64 [3*batch]: global node rows of the batch's users, then queries, then items
+ *   items    device int64 [batch]: 0-based item ids (index into bias [I])
+ *   fwd      scores[r] = sum_l <X_l[item_r], lambda*X_l[query_r] + (1-lambda)*X_l[user_r]> + bias[items[r]]
+ *   bwd      rowgrad [3*batch, n_layers*dim]: gradient contribution of batch row r to its user / query / item row
+ *            (blocks 0 / 1 / 2), for the upstream gradient dscores[batch]; d bias[items[r]] += dscores[r] is left to the caller.
+ */
+int ihg_hem_score_fwd(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim,
+                      const int64_t* rows, const int64_t* items, const float* bias, float lambda_muq,
+                      float* scores, int64_t batch, ihg_stream_t stream);
+int ihg_hem_score_bwd(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim,
+                      const int64_t* rows, const float* dscores, float lambda_muq,
+                      float* rowgrad, int64_t batch, ihg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
