@@ -131,10 +131,11 @@ def main():
     if sync is not None:
         sync.broadcast_parameters(0)
     batches = list(ds.sample_batches(100, args.steps + args.warmup, seed=1000 + rank))
+    fused_loss = model.supports_fused_loss(lossf)
 
     def step(k):
         u, q, i, y = batches[k]
-        loss = lossf(model(u, q, i), y)
+        loss = model.bce_loss(u, q, i, y) if fused_loss else lossf(model(u, q, i), y)       # what train_and_get_avg_loss does
         loss.backward()
         if sync is not None:
             sync.average_gradients()

@@ -113,7 +113,10 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
         positives += len(p_u)
         users, queries, items = torch.cat([p_u, n_u]), torch.cat([p_q, n_q]), torch.cat([p_i, n_i])
         flags = torch.cat([p_f, n_f]).float()
-        loss = loss_function(model(users, queries, items), flags)
+        if getattr(model, 'supports_fused_loss', None) and model.supports_fused_loss(loss_function):
+            loss = model.bce_loss(users, queries, items, flags)
+        else:
+            loss = loss_function(model(users, queries, items), flags)
         loss_sum += loss.detach()
         loss.backward()
         if grad_sync is not None:

@@ -84,7 +84,7 @@ class RawGnn(nn.Module):
             head = self.prediction_layer
             if layers[0].is_cuda and not Gs.Prediction.use_cosine_similarity and len(layers) <= 8:
                 from .. import ops
-                return ops.hem_score(layers, rows, item_indices, head.items_bias, head.lambda_muq)      # fused batch tail
+                return ops.hem_score(layers, rows, item_indices, head.items_bias, head.lambda_muq, ds.item_start_index_in_graph)      # fused batch tail
             picked = torch.cat([x[rows] for x in layers], 1)
             b = user_indices.shape[0]
             return head(picked[:b], picked[b:2 * b], picked[2 * b:], item_indices)
@@ -98,6 +98,20 @@ class RawGnn(nn.Module):
         user_feature = features[user_indices]
         query_feature = features[query_indices + ds.query_start_index_in_graph]
         return self.prediction_layer(user_feature, query_feature, item_feature, item_indices)
+
+    def bce_loss(self, user_indices: Tensor, query_indices: Tensor, item_indices: Tensor, labels: Tensor) -> Tensor:
+        """``nn.BCEWithLogitsLoss()(self(u, q, i), labels)`` with scoring, loss and their backward fused into the batch-tail
+        kernels (the training loops use it when the loss function is a plain ``BCEWithLogitsLoss``)."""
+        from .. import ops
+        ds, head = self.dataset, self.prediction_layer
+        rows = torch.cat([user_indices, query_indices + ds.query_start_index_in_graph, item_indices + ds.item_start_index_in_graph])
+        return ops.hem_bce_loss(self.propagate_layers(), rows, item_indices, labels, head.items_bias, head.lambda_muq,
+                                ds.item_start_index_in_graph)
+
+    def supports_fused_loss(self, loss_function) -> bool:
+        return (isinstance(loss_function, nn.BCEWithLogitsLoss) and loss_function.reduction == 'mean' and loss_function.weight is None
+                and loss_function.pos_weight is None and self._saved_output_feature is None and not Gs.Prediction.use_cosine_similarity
+                and len(self.gnns) + 1 <= 8 and next(self.parameters()).is_cuda)
 
     def score_all_items(self, user_indices: Tensor, query_indices: Tensor) -> Tensor:
         """Scores of ``C`` (user, query) pairs against every item in one GEMM: ``[C] x [C] -> [C, I]``.

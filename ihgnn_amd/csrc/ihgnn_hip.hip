@@ -1637,12 +1637,18 @@ __global__ __launch_bounds__(kBlockThreads) void hem_score_fwd_kernel(LayerPtrs 
 
 __global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs layers, int n_layers, int64_t ld, int dim,
                                                                       const int64_t* __restrict__ rows, const float* __restrict__ dscores,
-                                                                      float lam, float* __restrict__ rowgrad, int64_t batch) {
+                                                                      float grad_scale, float lam, float* __restrict__ rowgrad, int64_t width,
+                                                                      int64_t batch) {
     const int lane = threadIdx.x & 63;
-    const int64_t width = static_cast<int64_t>(n_layers) * dim;
     for (int64_t r = global_wave_id(); r < batch; r += global_wave_count()) {
         const int64_t u = rows[r], q = rows[batch + r], it = rows[2 * batch + r];
-        const float ds = dscores[r];
+        const float ds = dscores[r] * grad_scale;
+        if (lane == 0 && width > static_cast<int64_t>(n_layers) * dim) {       // optional extra column: d bias, carried by the item row
+            const int64_t col = static_cast<int64_t>(n_layers) * dim;
+            rowgrad[r * width + col] = 0.f;
+            rowgrad[(batch + r) * width + col] = 0.f;
+            rowgrad[(2 * batch + r) * width + col] = ds;
+        }
         for (int l = 0; l < n_layers; ++l) {
             const float* x = layers.x[l];
             for (int c = lane; c < dim; c += kWave) {
@@ -1652,6 +1658,103 @@ __global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs 
                 rowgrad[(batch + r) * width + col] = ds * lam * xi;
                 rowgrad[(2 * batch + r) * width + col] = ds * (lam * xq + (1.f - lam) * xu);
             }
+        }
+    }
+}
+
+
+
+constexpr int kScatterMax = 8192;
+constexpr int kScatterThreads = 1024;
+
+// Mean binary cross-entropy with logits over a batch and its gradient, one workgroup, fixed reduction tree
+// (nn.BCEWithLogitsLoss(), Main.py:191): loss = mean(max(s,0) - s*y + log1p(exp(-|s|))), dscores = (sigmoid(s) - y) / n.
+__global__ __launch_bounds__(kScatterThreads) void bce_with_logits_kernel(const float* __restrict__ scores, const float* __restrict__ labels, int n,
+                                                                          float* __restrict__ loss, float* __restrict__ dscores) {
+    __shared__ float part[kScatterThreads];
+    float acc = 0.f;
+    const float inv_n = 1.f / static_cast<float>(n);
+    for (int k = threadIdx.x; k < n; k += kScatterThreads) {
+        const float sc = scores[k], y = labels[k];
+        const float e = expf(-fabsf(sc));
+        acc += fmaxf(sc, 0.f) - sc * y + log1pf(e);
+        const float sig = sc >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        dscores[k] = (sig - y) * inv_n;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = kScatterThreads / 2; off > 0; off >>= 1) {
+        if (static_cast<int>(threadIdx.x) < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = part[0] * inv_n;
+}
+
+// Deterministic scatter-add of a small batch of rows (n <= 8192) into a large dense matrix, without atomics and without a
+// device-wide sort: ONE workgroup sorts the n keys (destination row << 20 | batch position) in LDS with a bitonic network,
+// marks the runs of equal destination rows and numbers them with a prefix sum; then one wave per run adds the run's rows in
+// batch order and writes the destination row once.  Replaces index_put_(accumulate=True) (bounds checks, radix sort, scatter).
+
+__global__ __launch_bounds__(kScatterThreads) void batch_scatter_plan_kernel(const int64_t* __restrict__ rows, int n, int m /* pow2 >= n */,
+                                                                             int32_t* __restrict__ order, int32_t* __restrict__ run_ptr,
+                                                                             int32_t* __restrict__ run_row, int32_t* __restrict__ n_runs) {
+    __shared__ unsigned long long key[kScatterMax];
+    __shared__ int scan[kScatterMax];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < m; k += kScatterThreads)
+        key[k] = k < n ? ((static_cast<unsigned long long>(rows[k]) << 20) | static_cast<unsigned long long>(k)) : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= m; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int k = tid; k < m / 2; k += kScatterThreads) {
+                const int lo = 2 * k - (k & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int k = tid; k < m; k += kScatterThreads) scan[k] = (k < n && (k == 0 || (key[k] >> 20) != (key[k - 1] >> 20))) ? 1 : 0;
+    __syncthreads();
+    for (int off = 1; off < m; off <<= 1) {                  // inclusive Hillis-Steele scan over the run-start flags
+        int v[kScatterMax / kScatterThreads];
+        int c = 0;
+        for (int k = tid; k < m; k += kScatterThreads) v[c++] = k >= off ? scan[k - off] : 0;
+        __syncthreads();
+        c = 0;
+        for (int k = tid; k < m; k += kScatterThreads) scan[k] += v[c++];
+        __syncthreads();
+    }
+    for (int k = tid; k < n; k += kScatterThreads) {
+        order[k] = static_cast<int32_t>(key[k] & 0xFFFFFu);
+        const bool start = k == 0 || (key[k] >> 20) != (key[k - 1] >> 20);
+        if (start) {
+            run_ptr[scan[k] - 1] = k;
+            run_row[scan[k] - 1] = static_cast<int32_t>(key[k] >> 20);
+        }
+    }
+    if (tid == 0) {
+        const int runs = n > 0 ? scan[n - 1] : 0;
+        run_ptr[runs] = n;
+        *n_runs = runs;
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void batch_scatter_sum_kernel(const float* __restrict__ rowgrad, int64_t ld_rowgrad, int width,
+                                                                          const int32_t* __restrict__ order, const int32_t* __restrict__ run_ptr,
+                                                                          const int32_t* __restrict__ run_row, const int32_t* __restrict__ n_runs,
+                                                                          float* __restrict__ dense, int64_t ld_dense, int n) {
+    const int lane = threadIdx.x & 63;
+    const int runs = *n_runs;
+    for (int64_t run = global_wave_id(); run < runs; run += global_wave_count()) {
+        const int begin = run_ptr[run], end = run_ptr[run + 1];
+        float* dst = dense + static_cast<int64_t>(run_row[run]) * ld_dense;
+        for (int c = lane; c < width; c += kWave) {
+            float acc = 0.f;
+            for (int k = begin; k < end; ++k) acc += rowgrad[static_cast<int64_t>(order[k]) * ld_rowgrad + c];
+            dst[c] += acc;
         }
     }
 }
@@ -1822,7 +1925,7 @@ bool parse_int_list(const char* p, const char* end, std::vector<int64_t>& out) {
 // =================================================================================================
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 9; }
+int32_t ihg_abi_version(void) { return 11; }
 
 const char* ihg_last_error_string(void) { return g_error; }
 
@@ -2213,15 +2316,49 @@ int ihg_hem_score_fwd(const float* const* layers, int32_t n_layers, int64_t ld, 
 }
 
 int ihg_hem_score_bwd(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const int64_t* rows, const float* dscores,
-                      float lambda_muq, float* rowgrad, int64_t batch, ihg_stream_t stream) {
+                      float grad_scale, float lambda_muq, float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream) {
     if (int rc = hem_common_check("ihg_hem_score_bwd", layers, n_layers, ld, dim, rows, batch)) return rc;
     if (batch == 0) return IHG_OK;
-    if (dscores == nullptr || rowgrad == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd: null pointer");
+    if (dscores == nullptr || rowgrad == nullptr || ld_rowgrad < static_cast<int64_t>(n_layers) * dim) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd: null pointer or short row stride");
     LayerPtrs lp{};
     for (int l = 0; l < n_layers; ++l) lp.x[l] = layers[l];
     hipLaunchKernelGGL(hem_score_bwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers, ld,
-                       dim, rows, dscores, lambda_muq, rowgrad, batch);
+                       dim, rows, dscores, grad_scale, lambda_muq, rowgrad, ld_rowgrad, batch);
     return check_launch("ihg_hem_score_bwd");
+}
+
+int ihg_bce_with_logits(const float* scores, const float* labels, int64_t n, float* loss, float* dscores, ihg_stream_t stream) {
+    if (n <= 0 || n > (1 << 24) || scores == nullptr || labels == nullptr || loss == nullptr || dscores == nullptr)
+        return fail(IHG_ERR_INVALID, "ihg_bce_with_logits: bad argument");
+    hipLaunchKernelGGL(bce_with_logits_kernel, dim3(1), dim3(kScatterThreads), 0, static_cast<hipStream_t>(stream), scores, labels, static_cast<int>(n), loss, dscores);
+    return check_launch("ihg_bce_with_logits");
+}
+
+
+int64_t ihg_batch_scatter_workspace_bytes(int64_t n_rows) {
+    if (n_rows < 0 || n_rows > kScatterMax) return -1;
+    return static_cast<int64_t>(sizeof(int32_t)) * (3 * n_rows + 16);
+}
+
+int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows, float* dense,
+                          int64_t ld_dense, void* workspace, int64_t workspace_bytes, ihg_stream_t stream) {
+    if (n_rows < 0 || n_rows > kScatterMax) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: 0..%d rows supported, got %lld", kScatterMax, (long long)n_rows);
+    if (width <= 0 || ld_rowgrad < width || ld_dense < width) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: bad width / stride");
+    if (n_rows == 0) return IHG_OK;
+    if (rowgrad == nullptr || rows == nullptr || dense == nullptr || workspace == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: null pointer");
+    if (workspace_bytes < ihg_batch_scatter_workspace_bytes(n_rows)) return fail(IHG_ERR_WORKSPACE, "ihg_batch_scatter_add: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int32_t* ws = static_cast<int32_t*>(workspace);
+    int32_t* n_runs = ws;                       // [1] (+7 pad)
+    int32_t* order = ws + 8;                    // [n]
+    int32_t* run_ptr = order + n_rows;          // [n + 1]
+    int32_t* run_row = run_ptr + n_rows + 1;    // [n]
+    int m = 2;
+    while (m < n_rows) m <<= 1;
+    hipLaunchKernelGGL(batch_scatter_plan_kernel, dim3(1), dim3(kScatterThreads), 0, s, rows, static_cast<int>(n_rows), m, order, run_ptr, run_row, n_runs);
+    hipLaunchKernelGGL(batch_scatter_sum_kernel, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, s, rowgrad, ld_rowgrad, width, order, run_ptr,
+                       run_row, n_runs, dense, ld_dense, static_cast<int>(n_rows));
+    return check_launch("ihg_batch_scatter_add");
 }
 
 }  // extern "C"

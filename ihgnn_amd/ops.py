@@ -349,46 +349,97 @@ def interact(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: in
 # ---------------------------------------------------------------------------------------------
 # Batch tail: HEM scores of a training batch straight from the layer outputs
 # ---------------------------------------------------------------------------------------------
+def _hem_backward(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float, item_row_offset: int):
+    """Shared backward of the batch tail: per-row gradients (one kernel), then ONE deterministic scatter that also carries
+    d bias in an extra column of the item rows.  -> (d bias, grads of the layer outputs as column slices of one buffer)."""
+    lib = _lib.load()
+    batch, dim, n_layers = int(items.shape[0]), int(layers[0].shape[1]), len(layers)
+    width = n_layers * dim
+    ld = width + 4                                           # pad keeps every row 16-byte aligned
+    n_nodes = int(layers[0].shape[0])
+    ptrs = (ctypes.c_void_p * n_layers)(*[x.data_ptr() for x in layers])
+    rowgrad = torch.empty(3 * batch, ld, dtype=torch.float32, device=bias.device)
+    with profiler.kernel('hem_score_bwd', batch, dim):
+        _lib.check(lib.ihg_hem_score_bwd(ptrs, n_layers, _ld(layers[0]), dim, _ptr(rows), _ptr(dscores), float(grad_scale), float(lam),
+                                         _ptr(rowgrad), ld, batch, _stream()), 'ihg_hem_score_bwd')
+    dense = torch.zeros(n_nodes, ld, dtype=torch.float32, device=bias.device)
+    ws_bytes = int(lib.ihg_batch_scatter_workspace_bytes(3 * batch))
+    if ws_bytes >= 0:
+        ws = _workspace(ws_bytes, bias.device)
+        with profiler.kernel('batch_scatter_add', 3 * batch, width + 1):
+            _lib.check(lib.ihg_batch_scatter_add(_ptr(rowgrad), ld, width + 1, _ptr(rows), 3 * batch, _ptr(dense), ld, _ptr(ws), ws.numel() * 4,
+                                                 _stream()), 'ihg_batch_scatter_add')
+    else:                                                    # batches beyond the in-LDS sort: torch's sort-based scatter
+        dense.index_put_((rows,), rowgrad, accumulate=True)
+    dbias = dense[item_row_offset:item_row_offset + bias.shape[0], width]
+    return dbias, tuple(dense[:, l * dim:(l + 1) * dim] for l in range(n_layers))
+
+
+def _same_layout(layers):
+    layers = tuple(_rows(x, 'layer output') for x in layers)
+    ld = _ld(layers[0])
+    if any(_ld(x) != ld or x.shape != layers[0].shape for x in layers):
+        layers = tuple(x.contiguous() for x in layers)
+    return layers
+
+
 class _HemScore(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rows: Tensor, items: Tensor, bias: Tensor, lam: float, *layers: Tensor) -> Tensor:
+    def forward(ctx, rows: Tensor, items: Tensor, bias: Tensor, lam: float, item_row_offset: int, *layers: Tensor) -> Tensor:
         lib = _lib.load()
-        layers = tuple(_rows(x, 'layer output') for x in layers)
-        ld = _ld(layers[0])
-        if any(_ld(x) != ld or x.shape != layers[0].shape for x in layers):
-            layers = tuple(x.contiguous() for x in layers)
-            ld = _ld(layers[0])
+        layers = _same_layout(layers)
         batch, dim = int(items.shape[0]), int(layers[0].shape[1])
         ptrs = (ctypes.c_void_p * len(layers))(*[x.data_ptr() for x in layers])
         scores = torch.empty(batch, dtype=torch.float32, device=bias.device)
         with profiler.kernel('hem_score_fwd', batch, dim):
-            _lib.check(lib.ihg_hem_score_fwd(ptrs, len(layers), ld, dim, _ptr(rows), _ptr(items), _ptr(bias), float(lam), _ptr(scores), batch,
-                                             _stream()), 'ihg_hem_score_fwd')
+            _lib.check(lib.ihg_hem_score_fwd(ptrs, len(layers), _ld(layers[0]), dim, _ptr(rows), _ptr(items), _ptr(bias), float(lam), _ptr(scores),
+                                             batch, _stream()), 'ihg_hem_score_fwd')
         ctx.save_for_backward(rows, items, bias, *layers)
-        ctx.lam = float(lam)
+        ctx.lam, ctx.offset = float(lam), int(item_row_offset)
         return scores
 
     @staticmethod
     def backward(ctx, dscores: Tensor):
-        lib = _lib.load()
         rows, items, bias, *layers = ctx.saved_tensors
-        batch, dim, n_layers = int(items.shape[0]), int(layers[0].shape[1]), len(layers)
-        dscores = dscores.contiguous()
-        ptrs = (ctypes.c_void_p * n_layers)(*[x.data_ptr() for x in layers])
-        rowgrad = torch.empty(3 * batch, n_layers * dim, dtype=torch.float32, device=bias.device)
-        with profiler.kernel('hem_score_bwd', batch, dim):
-            _lib.check(lib.ihg_hem_score_bwd(ptrs, n_layers, _ld(layers[0]), dim, _ptr(rows), _ptr(dscores), ctx.lam, _ptr(rowgrad), batch,
-                                             _stream()), 'ihg_hem_score_bwd')
-        # one deterministic scatter for all layers: duplicate rows (a user appears once per negative) are summed by index_put
-        n_nodes = int(layers[0].shape[0])
-        dense = torch.zeros(n_nodes, n_layers * dim, dtype=torch.float32, device=bias.device)
-        dense.index_put_((rows,), rowgrad, accumulate=True)
-        dbias = torch.zeros_like(bias).index_put_((items,), dscores, accumulate=True)
-        grads = tuple(dense[:, l * dim:(l + 1) * dim] for l in range(n_layers))
-        return (None, None, dbias, None) + grads
+        dbias, grads = _hem_backward(layers, rows, items, bias, ctx.lam, dscores.contiguous(), 1.0, ctx.offset)
+        return (None, None, dbias, None, None) + grads
 
 
-def hem_score(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float) -> Tensor:
+class _HemBceLoss(torch.autograd.Function):
+    """Scores + mean BCE-with-logits in the forward; d loss / d scores is produced there too, so the backward starts at the
+    per-row gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int, *layers: Tensor) -> Tensor:
+        lib = _lib.load()
+        layers = _same_layout(layers)
+        batch, dim = int(items.shape[0]), int(layers[0].shape[1])
+        ptrs = (ctypes.c_void_p * len(layers))(*[x.data_ptr() for x in layers])
+        scores = torch.empty(batch, dtype=torch.float32, device=bias.device)
+        dscores = torch.empty(batch, dtype=torch.float32, device=bias.device)
+        loss = torch.empty((), dtype=torch.float32, device=bias.device)
+        labels = labels.to(torch.float32).contiguous()
+        with profiler.kernel('hem_score_fwd', batch, dim):
+            _lib.check(lib.ihg_hem_score_fwd(ptrs, len(layers), _ld(layers[0]), dim, _ptr(rows), _ptr(items), _ptr(bias), float(lam), _ptr(scores),
+                                             batch, _stream()), 'ihg_hem_score_fwd')
+            _lib.check(lib.ihg_bce_with_logits(_ptr(scores), _ptr(labels), batch, _ptr(loss), _ptr(dscores), _stream()), 'ihg_bce_with_logits')
+        ctx.save_for_backward(rows, items, bias, dscores, *layers)
+        ctx.lam, ctx.offset = float(lam), int(item_row_offset)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss: Tensor):
+        rows, items, bias, dscores, *layers = ctx.saved_tensors
+        dbias, grads = _hem_backward(layers, rows, items, bias, ctx.lam, dscores, float(grad_loss), ctx.offset)
+        return (None, None, None, dbias, None, None) + grads
+
+
+def hem_score(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, item_row_offset: int) -> Tensor:
     """HEM scores of a batch: ``rows`` = global node rows of users, queries, items (``[3B]`` int64), ``items`` = 0-based item
     ids (``[B]``), ``layers`` = the ``[N,d]`` outputs ``X_0..X_L`` whose concatenation the reference scores on."""
-    return _HemScore.apply(rows, items, bias, float(lam), *layers)
+    return _HemScore.apply(rows, items, bias, float(lam), int(item_row_offset), *layers)
+
+
+def hem_bce_loss(layers, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int) -> Tensor:
+    """``nn.BCEWithLogitsLoss()(hem_score(...), labels)`` as one differentiable op (scalar)."""
+    return _HemBceLoss.apply(rows, items, labels, bias, float(lam), int(item_row_offset), *layers)
