@@ -1664,7 +1664,6 @@ __global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs 
 
 
 
-constexpr int kScatterMax = 8192;
 constexpr int kScatterThreads = 1024;
 
 // Mean binary cross-entropy with logits over a batch and its gradient, one workgroup, fixed reduction tree
@@ -1690,71 +1689,48 @@ __global__ __launch_bounds__(kScatterThreads) void bce_with_logits_kernel(const 
     if (threadIdx.x == 0) *loss = part[0] * inv_n;
 }
 
-// Deterministic scatter-add of a small batch of rows (n <= 8192) into a large dense matrix, without atomics and without a
-// device-wide sort: ONE workgroup sorts the n keys (destination row << 20 | batch position) in LDS with a bitonic network,
-// marks the runs of equal destination rows and numbers them with a prefix sum; then one wave per run adds the run's rows in
-// batch order and writes the destination row once.  Replaces index_put_(accumulate=True) (bounds checks, radix sort, scatter).
+// Deterministic scatter-add of a small batch of rows into a large dense matrix: dense[rows[k], :] += rowgrad[k, :], duplicates
+// summed in batch order, no atomics, no sort.  One wave per batch position k: it scans rows[0..k) for an earlier occurrence of
+// its destination (ballot over 64 ids at a time; the id array is a few KB and cache-resident) and retires if there is one;
+// otherwise it is the leader of that destination, walks rows[k..n) in order and adds every matching batch row, then writes the
+// destination row once.  O(n^2 / 64) wave-steps in total - microseconds for the few thousand rows of a training batch; replaces
+// index_put_(accumulate=True) (bounds checks, device radix sort, scatter kernel).
+constexpr int kScatterMax = 16384;
 
-__global__ __launch_bounds__(kScatterThreads) void batch_scatter_plan_kernel(const int64_t* __restrict__ rows, int n, int m /* pow2 >= n */,
-                                                                             int32_t* __restrict__ order, int32_t* __restrict__ run_ptr,
-                                                                             int32_t* __restrict__ run_row, int32_t* __restrict__ n_runs) {
-    __shared__ unsigned long long key[kScatterMax];
-    __shared__ int scan[kScatterMax];
-    const int tid = threadIdx.x;
-    for (int k = tid; k < m; k += kScatterThreads)
-        key[k] = k < n ? ((static_cast<unsigned long long>(rows[k]) << 20) | static_cast<unsigned long long>(k)) : ~0ull;
-    __syncthreads();
-    for (int size = 2; size <= m; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int k = tid; k < m / 2; k += kScatterThreads) {
-                const int lo = 2 * k - (k & (stride - 1));
-                const int hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const unsigned long long a = key[lo], b = key[hi];
-                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
-            }
-            __syncthreads();
-        }
-    }
-    for (int k = tid; k < m; k += kScatterThreads) scan[k] = (k < n && (k == 0 || (key[k] >> 20) != (key[k - 1] >> 20))) ? 1 : 0;
-    __syncthreads();
-    for (int off = 1; off < m; off <<= 1) {                  // inclusive Hillis-Steele scan over the run-start flags
-        int v[kScatterMax / kScatterThreads];
-        int c = 0;
-        for (int k = tid; k < m; k += kScatterThreads) v[c++] = k >= off ? scan[k - off] : 0;
-        __syncthreads();
-        c = 0;
-        for (int k = tid; k < m; k += kScatterThreads) scan[k] += v[c++];
-        __syncthreads();
-    }
-    for (int k = tid; k < n; k += kScatterThreads) {
-        order[k] = static_cast<int32_t>(key[k] & 0xFFFFFu);
-        const bool start = k == 0 || (key[k] >> 20) != (key[k - 1] >> 20);
-        if (start) {
-            run_ptr[scan[k] - 1] = k;
-            run_row[scan[k] - 1] = static_cast<int32_t>(key[k] >> 20);
-        }
-    }
-    if (tid == 0) {
-        const int runs = n > 0 ? scan[n - 1] : 0;
-        run_ptr[runs] = n;
-        *n_runs = runs;
-    }
-}
-
-__global__ __launch_bounds__(kBlockThreads) void batch_scatter_sum_kernel(const float* __restrict__ rowgrad, int64_t ld_rowgrad, int width,
-                                                                          const int32_t* __restrict__ order, const int32_t* __restrict__ run_ptr,
-                                                                          const int32_t* __restrict__ run_row, const int32_t* __restrict__ n_runs,
-                                                                          float* __restrict__ dense, int64_t ld_dense, int n) {
+__global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(const float* __restrict__ rowgrad, int64_t ld_rowgrad, int width,
+                                                                      const int64_t* __restrict__ rows, int n, float* __restrict__ dense,
+                                                                      int64_t ld_dense) {
     const int lane = threadIdx.x & 63;
-    const int runs = *n_runs;
-    for (int64_t run = global_wave_id(); run < runs; run += global_wave_count()) {
-        const int begin = run_ptr[run], end = run_ptr[run + 1];
-        float* dst = dense + static_cast<int64_t>(run_row[run]) * ld_dense;
-        for (int c = lane; c < width; c += kWave) {
-            float acc = 0.f;
-            for (int k = begin; k < end; ++k) acc += rowgrad[static_cast<int64_t>(order[k]) * ld_rowgrad + c];
-            dst[c] += acc;
+    for (int64_t k = global_wave_id(); k < n; k += global_wave_count()) {
+        const int64_t mine = rows[k];
+        bool follower = false;
+        for (int base = 0; base < k; base += kWave) {
+            const int j = base + lane;
+            if (__ballot(j < k && rows[j] == mine) != 0ull) { follower = true; break; }
+        }
+        if (follower) continue;
+        for (int c0 = 0; c0 < width; c0 += 4 * kWave) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int base = static_cast<int>(k) & ~(kWave - 1); base < n; base += kWave) {
+                const int j = base + lane;
+                unsigned long long mask = __ballot(j >= k && j < n && rows[j] == mine);
+                while (mask != 0ull) {
+                    const int bit = __ffsll(static_cast<long long>(mask)) - 1;
+                    mask &= mask - 1;
+                    const float* src = rowgrad + static_cast<int64_t>(base + bit) * ld_rowgrad;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = c0 + q * kWave + lane;
+                        if (c < width) acc[q] += src[c];
+                    }
+                }
+            }
+            float* dst = dense + mine * ld_dense;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + q * kWave + lane;
+                if (c < width) dst[c] += acc[q];
+            }
         }
     }
 }
@@ -2336,28 +2312,18 @@ int ihg_bce_with_logits(const float* scores, const float* labels, int64_t n, flo
 
 
 int64_t ihg_batch_scatter_workspace_bytes(int64_t n_rows) {
-    if (n_rows < 0 || n_rows > kScatterMax) return -1;
-    return static_cast<int64_t>(sizeof(int32_t)) * (3 * n_rows + 16);
+    return (n_rows < 0 || n_rows > kScatterMax) ? -1 : 0;
 }
 
 int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows, float* dense,
                           int64_t ld_dense, void* workspace, int64_t workspace_bytes, ihg_stream_t stream) {
+    (void)workspace; (void)workspace_bytes;
     if (n_rows < 0 || n_rows > kScatterMax) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: 0..%d rows supported, got %lld", kScatterMax, (long long)n_rows);
     if (width <= 0 || ld_rowgrad < width || ld_dense < width) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: bad width / stride");
     if (n_rows == 0) return IHG_OK;
-    if (rowgrad == nullptr || rows == nullptr || dense == nullptr || workspace == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: null pointer");
-    if (workspace_bytes < ihg_batch_scatter_workspace_bytes(n_rows)) return fail(IHG_ERR_WORKSPACE, "ihg_batch_scatter_add: workspace too small");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    int32_t* ws = static_cast<int32_t*>(workspace);
-    int32_t* n_runs = ws;                       // [1] (+7 pad)
-    int32_t* order = ws + 8;                    // [n]
-    int32_t* run_ptr = order + n_rows;          // [n + 1]
-    int32_t* run_row = run_ptr + n_rows + 1;    // [n]
-    int m = 2;
-    while (m < n_rows) m <<= 1;
-    hipLaunchKernelGGL(batch_scatter_plan_kernel, dim3(1), dim3(kScatterThreads), 0, s, rows, static_cast<int>(n_rows), m, order, run_ptr, run_row, n_runs);
-    hipLaunchKernelGGL(batch_scatter_sum_kernel, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, s, rowgrad, ld_rowgrad, width, order, run_ptr,
-                       run_row, n_runs, dense, ld_dense, static_cast<int>(n_rows));
+    if (rowgrad == nullptr || rows == nullptr || dense == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: null pointer");
+    hipLaunchKernelGGL(batch_scatter_kernel, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad, ld_rowgrad,
+                       width, rows, static_cast<int>(n_rows), dense, ld_dense);
     return check_launch("ihg_batch_scatter_add");
 }
 
