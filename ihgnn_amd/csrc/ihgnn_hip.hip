@@ -1700,20 +1700,23 @@ constexpr int kScatterMax = 16384;
 __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(const float* __restrict__ rowgrad, int64_t ld_rowgrad, int width,
                                                                       const int64_t* __restrict__ rows, int n, float* __restrict__ dense,
                                                                       int64_t ld_dense) {
+    __shared__ int32_t key[kScatterMax];                    // every workgroup keeps the whole id list in LDS (<= 64 KiB)
+    for (int k = threadIdx.x; k < n; k += kBlockThreads) key[k] = static_cast<int32_t>(rows[k]);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     for (int64_t k = global_wave_id(); k < n; k += global_wave_count()) {
-        const int64_t mine = rows[k];
+        const int32_t mine = key[k];
         bool follower = false;
         for (int base = 0; base < k; base += kWave) {
             const int j = base + lane;
-            if (__ballot(j < k && rows[j] == mine) != 0ull) { follower = true; break; }
+            if (__ballot(j < k && key[j] == mine) != 0ull) { follower = true; break; }
         }
         if (follower) continue;
         for (int c0 = 0; c0 < width; c0 += 4 * kWave) {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int base = static_cast<int>(k) & ~(kWave - 1); base < n; base += kWave) {
                 const int j = base + lane;
-                unsigned long long mask = __ballot(j >= k && j < n && rows[j] == mine);
+                unsigned long long mask = __ballot(j >= k && j < n && key[j] == mine);
                 while (mask != 0ull) {
                     const int bit = __ffsll(static_cast<long long>(mask)) - 1;
                     mask &= mask - 1;
@@ -1725,7 +1728,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(const floa
                     }
                 }
             }
-            float* dst = dense + mine * ld_dense;
+            float* dst = dense + static_cast<int64_t>(mine) * ld_dense;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = c0 + q * kWave + lane;

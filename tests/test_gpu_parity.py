@@ -500,11 +500,12 @@ def test_batch_scatter_add_matches_index_put(n, width):
     gen = torch.Generator().manual_seed(n)
     rows = torch.randint(0, max(2, n // 3), (n,), generator=gen).to(dev())          # many duplicates
     rowgrad = torch.randn(n, width + 3, generator=gen).to(dev())
-    want = torch.zeros(5000, width + 7, device=dev())
+    n_dense = max(5000, n)
+    want = torch.zeros(n_dense, width + 7, device=dev())
     want[:, :width].index_put_((rows,), rowgrad[:, :width], accumulate=True)
     outs = []
     for _ in range(2):
-        dense = torch.zeros(5000, width + 7, device=dev())
+        dense = torch.zeros(n_dense, width + 7, device=dev())
         ws = torch.empty(int(lib.ihg_batch_scatter_workspace_bytes(n)) // 4 + 4, dtype=torch.float32, device=dev())
         _lib.check(lib.ihg_batch_scatter_add(ops._ptr(rowgrad), rowgrad.stride(0), width, ops._ptr(rows), n, ops._ptr(dense), dense.stride(0),
                                              ops._ptr(ws), ws.numel() * 4, ops._stream()), 'scatter')
