@@ -19,7 +19,7 @@ import torch  # noqa: F401  (side effect: loads the HIP runtime)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
@@ -64,7 +64,8 @@ SIGNATURES = {
                                          c_void_p, c_int64, c_int64, c_void_p]),
     'ihg_bce_with_logits': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'ihg_batch_scatter_workspace_bytes': (c_int64, [c_int64]),
-    'ihg_batch_scatter_add': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    'ihg_batch_scatter_add': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int64,
+                                             c_void_p, c_int64, c_int64, c_void_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -1697,9 +1697,13 @@ __global__ __launch_bounds__(kScatterThreads) void bce_with_logits_kernel(const 
 // index_put_(accumulate=True) (bounds checks, device radix sort, scatter kernel).
 constexpr int kScatterMax = 16384;
 
+// Destination addressing: column c of batch row k goes to dense[(c / block_width) * block_stride + row * ld_dense + c % block_width]
+// (block_width = width, block_stride = 0 is a plain matrix; block_width = d, block_stride = N*d lands layer l's columns in its own
+// contiguous [N, d] matrix); an optional last column goes to tail[row - tail_row_offset] (the bias gradient).
 __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(const float* __restrict__ rowgrad, int64_t ld_rowgrad, int width,
                                                                       const int64_t* __restrict__ rows, int n, float* __restrict__ dense,
-                                                                      int64_t ld_dense) {
+                                                                      int64_t ld_dense, int block_width, int64_t block_stride,
+                                                                      float* __restrict__ tail, int64_t tail_row_offset, int64_t tail_rows) {
     __shared__ int32_t key[kScatterMax];                    // every workgroup keeps the whole id list in LDS (<= 64 KiB)
     for (int k = threadIdx.x; k < n; k += kBlockThreads) key[k] = static_cast<int32_t>(rows[k]);
     __syncthreads();
@@ -1718,21 +1722,38 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(const floa
                 const int j = base + lane;
                 unsigned long long mask = __ballot(j >= k && j < n && key[j] == mine);
                 while (mask != 0ull) {
-                    const int bit = __ffsll(static_cast<long long>(mask)) - 1;
-                    mask &= mask - 1;
-                    const float* src = rowgrad + static_cast<int64_t>(base + bit) * ld_rowgrad;
+                    // up to 16 members per trip: all their loads are issued before the first add (a hot destination - a
+                    // popular query - can own hundreds of batch rows); absent slots add an exact 0
+                    constexpr int MEMBERS = 16;
+                    float v[MEMBERS][4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = c0 + q * kWave + lane;
-                        if (c < width) acc[q] += src[c];
+                    for (int u = 0; u < MEMBERS; ++u) {
+                        const bool have = mask != 0ull;
+                        const int bit = have ? __ffsll(static_cast<long long>(mask)) - 1 : 0;
+                        if (have) mask &= mask - 1;
+                        const float* src = rowgrad + static_cast<int64_t>(base + bit) * ld_rowgrad;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = c0 + q * kWave + lane;
+                            v[u][q] = (have && c < width) ? src[c] : 0.f;
+                        }
                     }
+#pragma unroll
+                    for (int u = 0; u < MEMBERS; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] += v[u][q];
                 }
             }
-            float* dst = dense + static_cast<int64_t>(mine) * ld_dense;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = c0 + q * kWave + lane;
-                if (c < width) dst[c] += acc[q];
+                if (c >= width) continue;
+                if (tail != nullptr && c == width - 1) {
+                    const int64_t tr = static_cast<int64_t>(mine) - tail_row_offset;
+                    if (tr >= 0 && tr < tail_rows) tail[tr] += acc[q];
+                } else {
+                    dense[(c / block_width) * block_stride + static_cast<int64_t>(mine) * ld_dense + c % block_width] += acc[q];
+                }
             }
         }
     }
@@ -1904,7 +1925,7 @@ bool parse_int_list(const char* p, const char* end, std::vector<int64_t>& out) {
 // =================================================================================================
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 11; }
+int32_t ihg_abi_version(void) { return 12; }
 
 const char* ihg_last_error_string(void) { return g_error; }
 
@@ -2319,14 +2340,14 @@ int64_t ihg_batch_scatter_workspace_bytes(int64_t n_rows) {
 }
 
 int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows, float* dense,
-                          int64_t ld_dense, void* workspace, int64_t workspace_bytes, ihg_stream_t stream) {
-    (void)workspace; (void)workspace_bytes;
+                          int64_t ld_dense, int32_t block_width, int64_t block_stride, float* tail, int64_t tail_row_offset,
+                          int64_t tail_rows, ihg_stream_t stream) {
     if (n_rows < 0 || n_rows > kScatterMax) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: 0..%d rows supported, got %lld", kScatterMax, (long long)n_rows);
-    if (width <= 0 || ld_rowgrad < width || ld_dense < width) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: bad width / stride");
+    if (width <= 0 || ld_rowgrad < width || block_width <= 0 || ld_dense < block_width) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: bad width / stride");
     if (n_rows == 0) return IHG_OK;
     if (rowgrad == nullptr || rows == nullptr || dense == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: null pointer");
     hipLaunchKernelGGL(batch_scatter_kernel, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad, ld_rowgrad,
-                       width, rows, static_cast<int>(n_rows), dense, ld_dense);
+                       width, rows, static_cast<int>(n_rows), dense, ld_dense, block_width, block_stride, tail, tail_row_offset, tail_rows);
     return check_launch("ihg_batch_scatter_add");
 }
 

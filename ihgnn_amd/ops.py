@@ -350,29 +350,30 @@ def interact(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: in
 # Batch tail: HEM scores of a training batch straight from the layer outputs
 # ---------------------------------------------------------------------------------------------
 def _hem_backward(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float, item_row_offset: int):
-    """Shared backward of the batch tail: per-row gradients (one kernel), then ONE deterministic scatter that also carries
-    d bias in an extra column of the item rows.  -> (d bias, grads of the layer outputs as column slices of one buffer)."""
+    """Shared backward of the batch tail: per-row gradients (one kernel), then ONE deterministic scatter that lands every
+    layer's gradient in its own contiguous ``[N, d]`` matrix and d bias beside them.  -> (d bias, layer gradients)."""
     lib = _lib.load()
     batch, dim, n_layers = int(items.shape[0]), int(layers[0].shape[1]), len(layers)
     width = n_layers * dim
-    ld = width + 4                                           # pad keeps every row 16-byte aligned
     n_nodes = int(layers[0].shape[0])
     ptrs = (ctypes.c_void_p * n_layers)(*[x.data_ptr() for x in layers])
-    rowgrad = torch.empty(3 * batch, ld, dtype=torch.float32, device=bias.device)
+    rowgrad = torch.empty(3 * batch, width + 4, dtype=torch.float32, device=bias.device)       # column `width` carries d bias
     with profiler.kernel('hem_score_bwd', batch, dim):
         _lib.check(lib.ihg_hem_score_bwd(ptrs, n_layers, _ld(layers[0]), dim, _ptr(rows), _ptr(dscores), float(grad_scale), float(lam),
-                                         _ptr(rowgrad), ld, batch, _stream()), 'ihg_hem_score_bwd')
-    dense = torch.zeros(n_nodes, ld, dtype=torch.float32, device=bias.device)
-    ws_bytes = int(lib.ihg_batch_scatter_workspace_bytes(3 * batch))
-    if ws_bytes >= 0:
-        ws = _workspace(ws_bytes, bias.device)
+                                         _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd')
+    n_bias = int(bias.shape[0])
+    flat = torch.zeros(n_layers * n_nodes * dim + n_bias, dtype=torch.float32, device=bias.device)
+    dense = flat[:n_layers * n_nodes * dim].view(n_layers, n_nodes, dim)
+    dbias = flat[n_layers * n_nodes * dim:]
+    if lib.ihg_batch_scatter_workspace_bytes(3 * batch) >= 0:
         with profiler.kernel('batch_scatter_add', 3 * batch, width + 1):
-            _lib.check(lib.ihg_batch_scatter_add(_ptr(rowgrad), ld, width + 1, _ptr(rows), 3 * batch, _ptr(dense), ld, _ptr(ws), ws.numel() * 4,
-                                                 _stream()), 'ihg_batch_scatter_add')
-    else:                                                    # batches beyond the in-LDS sort: torch's sort-based scatter
-        dense.index_put_((rows,), rowgrad, accumulate=True)
-    dbias = dense[item_row_offset:item_row_offset + bias.shape[0], width]
-    return dbias, tuple(dense[:, l * dim:(l + 1) * dim] for l in range(n_layers))
+            _lib.check(lib.ihg_batch_scatter_add(_ptr(rowgrad), width + 4, width + 1, _ptr(rows), 3 * batch, _ptr(dense), dim, dim, n_nodes * dim,
+                                                 _ptr(dbias), int(item_row_offset), n_bias, _stream()), 'ihg_batch_scatter_add')
+    else:                                                    # batches beyond the kernel's range: torch's sort-based scatter
+        for l in range(n_layers):
+            dense[l].index_put_((rows,), rowgrad[:, l * dim:(l + 1) * dim], accumulate=True)
+        dbias.index_put_((items,), rowgrad[2 * batch:, width], accumulate=True)
+    return dbias, tuple(dense[l] for l in range(n_layers))
 
 
 def _same_layout(layers):

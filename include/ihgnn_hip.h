@@ -222,9 +222,11 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
  *            row (blocks 0 / 1 / 2) for the upstream gradient grad_scale * dscores[batch].  If ld_rowgrad > n_layers*dim,
  *            column n_layers*dim carries d bias: dscores[r] on the item row, 0 on the other two.
  * ihg_bce_with_logits: nn.BCEWithLogitsLoss() (mean) and d loss / d scores in one launch (Main.py:191, TrainTestHelper.py:132).
- * ihg_batch_scatter_add: dense[rows[k], 0:width] += rowgrad[k, 0:width] for k < n_rows <= 16384, duplicates summed in batch
- *            order without atomics or a sort (one wave per batch row; the first occurrence of a destination adds all later
- *            ones); `workspace` is unused (may be NULL).  Replaces the
+ * ihg_batch_scatter_add: dense[rows[k], c] += rowgrad[k, c] for k < n_rows <= 16384, duplicates summed in batch order
+ *            without atomics or a sort (one wave per batch row; the first occurrence of a destination adds all later ones).
+ *            Column c lands at dense[(c / block_width) * block_stride + row * ld_dense + c % block_width] - with
+ *            block_width = dim, block_stride = N * dim every layer's gradient is its own contiguous [N, dim] matrix; if `tail`
+ *            is given, the last column goes to tail[row - tail_row_offset] instead (d bias).  Replaces the
  *            index_put_(accumulate=True) that autograd issues for the three row gathers (RawGnn.py:128-131).
  */
 int ihg_hem_score_fwd(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim,
@@ -236,7 +238,8 @@ int ihg_hem_score_bwd(const float* const* layers, int32_t n_layers, int64_t ld, 
 int ihg_bce_with_logits(const float* scores, const float* labels, int64_t n, float* loss, float* dscores, ihg_stream_t stream);
 int64_t ihg_batch_scatter_workspace_bytes(int64_t n_rows);      /* 0, or -1 if n_rows > 16384 (caller keeps its own scatter) */
 int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows,
-                          float* dense, int64_t ld_dense, void* workspace, int64_t workspace_bytes, ihg_stream_t stream);
+                          float* dense, int64_t ld_dense, int32_t block_width, int64_t block_stride,
+                          float* tail, int64_t tail_row_offset, int64_t tail_rows, ihg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -394,7 +394,7 @@ def test_full_size_properties_c2_shape():
     y = torch.randn(lay.edge_count, d, device=dev())
     ky = ops.node_segment_sum_raw(y, lay.node_csr)
     lhs, rhs = (a.double() * y.double()).sum(), (x1.double() * ky.double()).sum()
-    assert abs(lhs - rhs) / abs(lhs) <= 1e-5       # both sides carry fp32 round-off of ~4e5 x 64 products
+    assert abs(lhs - rhs) / abs(lhs) <= 3e-5       # both sides carry fp32 round-off of ~4e5 x 64 products
     ones = torch.ones(lay.edge_count, 4, device=dev())
     deg = ops.node_segment_sum_raw(ones, lay.node_csr)[:, 0]
     assert torch.equal(deg, torch.where(lay.degree < 0.5, torch.zeros_like(lay.degree), lay.degree))
@@ -493,25 +493,33 @@ def test_f7_gcn_model_matches_reference():
 
 @pytest.mark.parametrize('n,width', [(1, 5), (77, 33), (3300, 193), (8192, 64), (16384, 300)])
 def test_batch_scatter_add_matches_index_put(n, width):
-    """Deterministic in-LDS-sorted scatter: equals index_put_(accumulate=True) and is bitwise repeatable with duplicates."""
-    import ctypes
+    """Deterministic sort-free scatter: equals index_put_(accumulate=True), bitwise repeatable with duplicates; plain-matrix
+    and per-layer-block + tail-column destination forms."""
     from ihgnn_amd import _lib, ops
     lib = _lib.load()
     gen = torch.Generator().manual_seed(n)
+    n_dense = max(5000, n)
     rows = torch.randint(0, max(2, n // 3), (n,), generator=gen).to(dev())          # many duplicates
     rowgrad = torch.randn(n, width + 3, generator=gen).to(dev())
-    n_dense = max(5000, n)
     want = torch.zeros(n_dense, width + 7, device=dev())
     want[:, :width].index_put_((rows,), rowgrad[:, :width], accumulate=True)
     outs = []
     for _ in range(2):
         dense = torch.zeros(n_dense, width + 7, device=dev())
-        ws = torch.empty(int(lib.ihg_batch_scatter_workspace_bytes(n)) // 4 + 4, dtype=torch.float32, device=dev())
         _lib.check(lib.ihg_batch_scatter_add(ops._ptr(rowgrad), rowgrad.stride(0), width, ops._ptr(rows), n, ops._ptr(dense), dense.stride(0),
-                                             ops._ptr(ws), ws.numel() * 4, ops._stream()), 'scatter')
+                                             width, 0, None, 0, 0, ops._stream()), 'scatter')
         outs.append(dense)
     assert rel(outs[0], want) <= RTOL_SUM and torch.equal(outs[0], outs[1]) and (outs[0][:, width:] == 0).all()
     assert lib.ihg_batch_scatter_workspace_bytes(16385) == -1
+    if (width - 1) % 4 == 0:                                 # blocked form: 4 column blocks + a tail column for rows >= 100
+        bw = (width - 1) // 4
+        blocks = torch.zeros(4, n_dense, bw, device=dev())
+        tail = torch.zeros(n_dense - 100, device=dev())
+        _lib.check(lib.ihg_batch_scatter_add(ops._ptr(rowgrad), rowgrad.stride(0), width, ops._ptr(rows), n, ops._ptr(blocks), bw, bw, n_dense * bw,
+                                             ops._ptr(tail), 100, n_dense - 100, ops._stream()), 'scatter')
+        for l in range(4):
+            assert rel(blocks[l], want[:, l * bw:(l + 1) * bw]) <= RTOL_SUM
+        assert rel(tail, want[100:, width - 1]) <= RTOL_SUM
 
 
 def test_fused_bce_tail_equals_unfused_path():
