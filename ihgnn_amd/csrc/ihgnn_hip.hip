@@ -1064,11 +1064,282 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
     }
 }
 
-// dW at D = 64 (one 64 x 64 x NBLK sub-block = the whole matrix): same roles; consumers hold NBLK accumulator tiles.
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised forward / member-gradient kernels for D = 128.  The weight fragments no longer fit in registers
+// (512 VGPRs), so the consumers stream them from L2 (packed, one k-step ahead) - which is harmless for a wave that issues no
+// other loads - while the loaders gather the member rows in 64-column chunks into a double-buffered LDS image; a tile is
+// NCH = D/64 trips, the accumulators live across them.
+// ------------------------------------------------------------------------------------------------
+template <int D, int NBLK>
+__global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_wsbig_kernel(
+    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
+    const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
+    static_assert(D == 128, "chunked wave-specialised form");
+    constexpr int KC = 64, NCH = D / KC, TE = 64, NJ = D / 64, V4 = KC / 4, LOADS = 3 * TE * V4 / kBlockThreads, T_STEPS = KC / 8;
+    constexpr int TG = D / 8, PV4 = D / 4, PLOADS = 3 * TE * PV4 / kBlockThreads, PL = PLOADS / 3, STRIDE = KC + kRowPad;
+    __shared__ __attribute__((aligned(16))) float tile[2][3][TE][STRIDE];
+    __shared__ __attribute__((aligned(16))) float psum[TE][D];
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t g = gridDim.x;
+
+    if (wave >= 4) {
+        // loaders.  Trip s = (tile, chunk): deposit chunk s, then issue [ids of the next tile (chunk 0 only)] -> rows of
+        // chunk s+1 -> [first-order rows of this tile (last-but-one chunk)]; psum(T) is deposited with the last chunk.
+        const int tid = threadIdx.x - kBlockThreads;
+        v4f hr[LOADS], pr[PLOADS];
+        int node[LOADS], node_next[LOADS];
+        auto load_ids = [&](int64_t tile_id, int (&dst)[LOADS]) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + (idx / V4) % TE;
+                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * TE)] : 0;
+            }
+        };
+        auto issue_chunk = [&](const int (&src)[LOADS], int kc) {
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + kc * KC + (idx % V4) * 4);
+            }
+        };
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) {
+            load_ids(t, node);
+            issue_chunk(node, 0);
+        }
+        int trip = 0;
+        while (t < n_tiles) {
+#pragma unroll
+            for (int kc = 0; kc < NCH; ++kc, ++trip) {
+                float (*dst)[TE][STRIDE] = tile[trip & 1];
+#pragma unroll
+                for (int x = 0; x < LOADS; ++x) {
+                    const int idx = tid + kBlockThreads * x;
+                    *reinterpret_cast<v4f*>(&dst[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hr[x];
+                }
+                if (kc == NCH - 1) {
+#pragma unroll
+                    for (int x = 0; x < PL; ++x) {
+                        const int idx = tid + kBlockThreads * x;
+                        *reinterpret_cast<v4f*>(&psum[idx / PV4][(idx % PV4) * 4]) = (pr[x] + pr[x + PL]) + pr[x + 2 * PL];
+                    }
+                }
+                if (kc == 0 && t + g < n_tiles) load_ids(t + g, node_next);
+                if (kc + 1 < NCH) {
+                    issue_chunk(node, kc + 1);
+                } else if (t + g < n_tiles) {
+                    issue_chunk(node_next, 0);
+                }
+                if (kc == NCH - 2) {
+                    // first-order rows of this tile, full width: the thread's (row, member) pairs are those of its chunk loads
+#pragma unroll
+                    for (int x = 0; x < PLOADS; ++x) {
+                        const int idx = tid + kBlockThreads * x;
+                        const int c4 = idx % PV4, r = (idx / PV4) % TE, m = idx / (PV4 * TE);
+                        const int64_t e = t * TE + r;
+                        const int64_t nd = e < n_edges ? i3[e * 3 + m] : 0;
+                        pr[x] = *reinterpret_cast<const v4f*>(p + nd * ld_p + c4 * 4);
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) node[x] = node_next[x];
+            t += g;
+        }
+        return;
+    }
+    // consumers: (et, jt0 + 2x) output tiles, accumulators across the NCH chunk trips of a tile
+    const int et = wave & 1, jt0 = wave >> 1;
+    const int row = et * 32 + (lane & 31), half = lane >> 5;
+    const v4f* wp_base = reinterpret_cast<const v4f*>(wp) + lane;
+    int trip = 0;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += g) {
+        v16f acc[NJ];
+#pragma unroll
+        for (int x = 0; x < NJ; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+        // the fragment addresses are the same for every tile; an opaque zero keeps the compiler from hoisting all 64 loads out
+        // of the tile loop (which lands them in scratch: 512 registers' worth)
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const v4f* wp4 = wp_base + opaque;
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc, ++trip) {
+            __syncthreads();
+            const float (*src)[TE][STRIDE] = tile[trip & 1];
+            v4f bcur[NJ][NBLK], bnext[NJ][NBLK];
+#pragma unroll
+            for (int x = 0; x < NJ; ++x)
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) bcur[x][b] = wp4[(static_cast<int64_t>((jt0 + 2 * x) * NBLK + b) * TG + kc * T_STEPS) * kWave];
+#pragma unroll
+            for (int ts = 0; ts < T_STEPS; ++ts) {
+                if (ts + 1 < T_STEPS) {
+#pragma unroll
+                    for (int x = 0; x < NJ; ++x)
+#pragma unroll
+                        for (int b = 0; b < NBLK; ++b)
+                            bnext[x][b] = wp4[(static_cast<int64_t>((jt0 + 2 * x) * NBLK + b) * TG + kc * T_STEPS + ts + 1) * kWave];
+                }
+                const int col = 8 * ts + 4 * half;
+                const v4f au = *reinterpret_cast<const v4f*>(&src[0][row][col]);
+                const v4f aq = *reinterpret_cast<const v4f*>(&src[1][row][col]);
+                const v4f ai = *reinterpret_cast<const v4f*>(&src[2][row][col]);
+                v4f z[4];
+                z[0] = au * aq;
+                z[1] = aq * ai;
+                z[2] = ai * au;
+                z[3] = z[0] * ai;
+#pragma unroll
+                for (int x = 0; x < NJ; ++x)
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[b][s2], bcur[x][b][s2], acc[x], 0, 0, 0);
+#pragma unroll
+                for (int x = 0; x < NJ; ++x)
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) bcur[x][b] = bnext[x][b];
+            }
+        }
+        const int64_t e_base = t * TE;
+        const bool full = e_base + TE <= n_edges;
+#pragma unroll
+        for (int x = 0; x < NJ; ++x) {
+            const int j = (jt0 + 2 * x) * 32 + (lane & 31);
+            float first[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) first[r] = psum[et * 32 + acc_row(r, lane)][j];
+            float* orow = out + (e_base + et * 32) * ld_out + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (full || e_base + et * 32 + acc_row(r, lane) < n_edges) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[x][r] + first[r];
+        }
+    }
+}
+
+template <int D, int NBLK>
+__global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_wsbig_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g_out, int64_t n_edges) {
+    static_assert(D == 128, "chunked wave-specialised form");
+    constexpr int TE = 64, STRIDE = D + kRowPad, V4 = D / 4, DL = TE * V4 / kBlockThreads, T_STEPS = D / 8, JOBS = 2 * (D / 32);
+    __shared__ __attribute__((aligned(16))) float dtile[2][TE][STRIDE];
+    __shared__ int ids[2][TE][3];
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t g = gridDim.x;
+
+    if (wave >= 4) {
+        // loaders: the dout rows are a plain stream; one tile of lead in registers
+        const int tid = threadIdx.x - kBlockThreads;
+        v4f dr[DL];
+        int my_id = 0;
+        auto issue = [&](int64_t tile_id) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + idx / V4;
+                dr[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+            const int64_t pos = e_base * 3 + tid;
+            my_id = (tid < TE * 3 && pos < n_edges * 3) ? i3[pos] : 0;
+        };
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) issue(t);
+        int which = 0;
+        while (t < n_tiles) {
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&dtile[which][idx / V4][(idx % V4) * 4]) = dr[x];
+            }
+            if (tid < TE * 3) (&ids[which][0][0])[tid] = my_id;
+            if (t + g < n_tiles) issue(t + g);
+            __syncthreads();
+            t += g;
+            which ^= 1;
+        }
+        return;
+    }
+    const int half = lane >> 5;
+    const v4f* wq4 = reinterpret_cast<const v4f*>(wq) + lane;
+    int which = 0;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += g, which ^= 1) {
+        __syncthreads();
+        const int64_t e_base = t * TE;
+        const bool full = e_base + TE <= n_edges;
+        for (int job = wave; job < JOBS; job += 4) {
+            const int et = job & 1, ct = job >> 1;
+            const int row = et * 32 + (lane & 31);
+            const int c = ct * 32 + (lane & 31);
+            v16f acc[NBLK];
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[bk][r] = 0.f;
+            // weight fragments two k-steps ahead; the member values of the epilogue are requested right behind the first two
+            // fragment sets, so they arrive under the MFMAs instead of in front of the stores
+            v4f b0[NBLK], b1[NBLK], b2[NBLK];
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk) {
+                b0[bk] = wq4[(static_cast<int64_t>(ct * NBLK + bk) * T_STEPS + 0) * kWave];
+                b1[bk] = wq4[(static_cast<int64_t>(ct * NBLK + bk) * T_STEPS + 1) * kWave];
+            }
+            float hu[16], hq[16], hi[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = et * 32 + acc_row(r, lane);
+                hu[r] = h[static_cast<int64_t>(ids[which][er][0]) * ld_h + c];
+                hq[r] = h[static_cast<int64_t>(ids[which][er][1]) * ld_h + c];
+                hi[r] = h[static_cast<int64_t>(ids[which][er][2]) * ld_h + c];
+            }
+#pragma unroll
+            for (int ts = 0; ts < T_STEPS; ++ts) {
+                if (ts + 2 < T_STEPS) {
+#pragma unroll
+                    for (int bk = 0; bk < NBLK; ++bk) b2[bk] = wq4[(static_cast<int64_t>(ct * NBLK + bk) * T_STEPS + ts + 2) * kWave];
+                }
+                const v4f a = *reinterpret_cast<const v4f*>(&dtile[which][row][8 * ts + 4 * half]);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b0[bk][s2], acc[bk], 0, 0, 0);
+#pragma unroll
+                for (int bk = 0; bk < NBLK; ++bk) {
+                    b0[bk] = b1[bk];
+                    b1[bk] = b2[bk];
+                }
+            }
+            float* gbase = g_out + (e_base + et * 32) * 3 * D + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z_uq = acc[0][r], z_qi = acc[1][r], z_iu = acc[2][r];
+                const float z_uqi = NBLK == 4 ? acc[NBLK - 1][r] : 0.f;
+                if (full || e_base + et * 32 + acc_row(r, lane) < n_edges) {
+                    float* ge = gbase + static_cast<int64_t>(acc_row(r, lane)) * 3 * D;
+                    ge[0] = z_uq * hq[r] + z_iu * hi[r] + z_uqi * (hq[r] * hi[r]);
+                    ge[D] = z_uq * hu[r] + z_qi * hi[r] + z_uqi * (hu[r] * hi[r]);
+                    ge[2 * D] = z_qi * hq[r] + z_iu * hu[r] + z_uqi * (hu[r] * hq[r]);
+                }
+            }
+        }
+    }
+}
+
+// dW, same roles: workgroup (x, y) owns the 64 x 64 x NBLK sub-block y = (js, cs) of the d x NBLK*d gradient (d a multiple of 64)
+// for the hyperedge tiles x, x + gridDim.x, ...; its loaders fetch the matching 64-column slices of dout and of the member rows.
 template <int NBLK>
 __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
     const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ dout, int64_t ld_dout,
-    float* __restrict__ slabs, int64_t n_edges) {
+    float* __restrict__ slabs, int64_t n_edges, int d) {
     constexpr int D = 64, TE = 64, V4 = D / 4, DL = TE * V4 / kBlockThreads, HL = 3 * DL;
     struct Buffer {
         float dtile[TE][D];
@@ -1077,6 +1348,8 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
     __shared__ __attribute__((aligned(16))) Buffer buf[2];
     const int64_t n_tiles = (n_edges + TE - 1) / TE;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int subs = d / D;
+    const int js = blockIdx.y / subs, cs = blockIdx.y % subs;
 
     if (wave >= 4) {
         // loaders: deposit rows(T) -> issue rows(T+g) with ids fetched a trip ago -> issue ids(T+2g) -> barrier
@@ -1099,12 +1372,12 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
             for (int x = 0; x < DL; ++x) {
                 const int idx = tid + kBlockThreads * x;
                 const int64_t e = e_base + idx / V4;
-                dr[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+                dr[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + js * D + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int x = 0; x < HL; ++x) {
                 const int idx = tid + kBlockThreads * x;
-                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + (idx % V4) * 4);
+                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + cs * D + (idx % V4) * 4);
             }
         };
         int64_t t = blockIdx.x;
@@ -1159,12 +1432,12 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
             for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z[bk], acc[bk], 0, 0, 0);
         }
     }
-    float* slab = slabs + static_cast<int64_t>(blockIdx.x) * D * NBLK * D;
+    float* slab = slabs + static_cast<int64_t>(blockIdx.x) * d * NBLK * d;          // slab x: a full [d][NBLK*d] matrix
 #pragma unroll
     for (int bk = 0; bk < NBLK; ++bk)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            slab[static_cast<int64_t>(jt * 32 + acc_row(r, lane)) * NBLK * D + bk * D + ct * 32 + l31] = acc[bk][r];
+            slab[static_cast<int64_t>(js * D + jt * 32 + acc_row(r, lane)) * NBLK * d + bk * d + cs * D + ct * 32 + l31] = acc[bk][r];
 }
 
 // weights: workgroup (x, y) owns the SW x (NBLK*SW) sub-block y = (js, cs) of dW for the hyperedge tiles x, x + gridDim.x, ...
@@ -1859,7 +2132,10 @@ void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float
     switch (dim) {
         case 32: IHG_FWD_PIPE(32) break;
         case 64: IHG_FWD_PIPE(64) break;
-        case 128: IHG_FWD(128) break;
+        case 128: {
+            const int grid = static_cast<int>(std::min<int64_t>((n_edges + 63) / 64, kPipeGrid));
+            hipLaunchKernelGGL((interact_fwd_wsbig_kernel<128, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges);
+        } break;
         default: IHG_FWD(256) break;
     }
 #undef IHG_FWD
@@ -1884,19 +2160,20 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     switch (dim) {
         case 32: IHG_MEM_PIPE(32) break;
         case 64: IHG_MEM_PIPE(64) break;
-        case 128: IHG_MEM(128) break;
+        case 128: {
+            const int grid = static_cast<int>(std::min<int64_t>((n_edges + 63) / 64, kPipeGrid));
+            hipLaunchKernelGGL((interact_bwd_members_wsbig_kernel<128, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges);
+        } break;
         default: IHG_MEM(256) break;
     }
 #undef IHG_MEM
 #undef IHG_MEM_PIPE
-    const int n_slabs = static_cast<int>(std::min<int64_t>(dim == 64 ? kPipeGrid : weight_slabs(dim), (n_edges + 63) / 64));
-    if (dim == 64) {
-        hipLaunchKernelGGL((interact_bwd_weight_ws_kernel<NBLK>), dim3(n_slabs), dim3(kWsThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
-    } else if (dim == 32) {
-        hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<32, NBLK>), dim3(n_slabs, 1), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
+    const int subs_ws = (dim / 64) * (dim / 64);
+    const int n_slabs = static_cast<int>(std::min<int64_t>(dim >= 64 ? std::max(kPipeGrid / subs_ws, 8) : weight_slabs(dim), (n_edges + 63) / 64));
+    if (dim >= 64) {
+        hipLaunchKernelGGL((interact_bwd_weight_ws_kernel<NBLK>), dim3(n_slabs, subs_ws), dim3(kWsThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
     } else {
-        const int subs = (dim / 64) * (dim / 64);
-        hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<64, NBLK>), dim3(n_slabs, subs), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
+        hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<32, NBLK>), dim3(n_slabs, 1), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
     }
     const int total = dim * NBLK * dim;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, n_slabs, dim, NBLK, dw, ld_dw);
