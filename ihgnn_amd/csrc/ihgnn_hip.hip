@@ -1066,164 +1066,12 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
 
 
 // ------------------------------------------------------------------------------------------------
-// Wave-specialised forward / member-gradient kernels for D = 128.  The weight fragments no longer fit in registers
-// (512 VGPRs), so the consumers stream them from L2 (packed, one k-step ahead) - which is harmless for a wave that issues no
-// other loads - while the loaders gather the member rows in 64-column chunks into a double-buffered LDS image; a tile is
-// NCH = D/64 trips, the accumulators live across them.
+// Wave-specialised member-gradient kernel for D = 128.  The weight fragments no longer fit in registers (512 VGPRs), so the
+// consumers stream them from L2 (packed, two k-steps ahead) while the loaders stream the dout rows into a double-buffered LDS
+// image; the member values of the product rule are requested by the consumers right behind the first fragments of a job, so
+// they arrive under the MFMAs.  (A chunked wave-specialised FORWARD for D = 128 was built and measured equal to the plain
+// MFMA tiling - 3.45 vs 3.41 ms at E = 2.2 M - so the forward keeps the plain kernel at this width.)
 // ------------------------------------------------------------------------------------------------
-template <int D, int NBLK>
-__global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_wsbig_kernel(
-    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
-    const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
-    static_assert(D == 128, "chunked wave-specialised form");
-    constexpr int KC = 64, NCH = D / KC, TE = 64, NJ = D / 64, V4 = KC / 4, LOADS = 3 * TE * V4 / kBlockThreads, T_STEPS = KC / 8;
-    constexpr int TG = D / 8, PV4 = D / 4, PLOADS = 3 * TE * PV4 / kBlockThreads, PL = PLOADS / 3, STRIDE = KC + kRowPad;
-    __shared__ __attribute__((aligned(16))) float tile[2][3][TE][STRIDE];
-    __shared__ __attribute__((aligned(16))) float psum[TE][D];
-    const int64_t n_tiles = (n_edges + TE - 1) / TE;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t g = gridDim.x;
-
-    if (wave >= 4) {
-        // loaders.  Trip s = (tile, chunk): deposit chunk s, then issue [ids of the next tile (chunk 0 only)] -> rows of
-        // chunk s+1 -> [first-order rows of this tile (last-but-one chunk)]; psum(T) is deposited with the last chunk.
-        const int tid = threadIdx.x - kBlockThreads;
-        v4f hr[LOADS], pr[PLOADS];
-        int node[LOADS], node_next[LOADS];
-        auto load_ids = [&](int64_t tile_id, int (&dst)[LOADS]) {
-            const int64_t e_base = tile_id * TE;
-#pragma unroll
-            for (int x = 0; x < LOADS; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                const int64_t e = e_base + (idx / V4) % TE;
-                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * TE)] : 0;
-            }
-        };
-        auto issue_chunk = [&](const int (&src)[LOADS], int kc) {
-#pragma unroll
-            for (int x = 0; x < LOADS; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + kc * KC + (idx % V4) * 4);
-            }
-        };
-        int64_t t = blockIdx.x;
-        if (t < n_tiles) {
-            load_ids(t, node);
-            issue_chunk(node, 0);
-        }
-        int trip = 0;
-        while (t < n_tiles) {
-#pragma unroll
-            for (int kc = 0; kc < NCH; ++kc, ++trip) {
-                float (*dst)[TE][STRIDE] = tile[trip & 1];
-#pragma unroll
-                for (int x = 0; x < LOADS; ++x) {
-                    const int idx = tid + kBlockThreads * x;
-                    *reinterpret_cast<v4f*>(&dst[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hr[x];
-                }
-                if (kc == NCH - 1) {
-#pragma unroll
-                    for (int x = 0; x < PL; ++x) {
-                        const int idx = tid + kBlockThreads * x;
-                        *reinterpret_cast<v4f*>(&psum[idx / PV4][(idx % PV4) * 4]) = (pr[x] + pr[x + PL]) + pr[x + 2 * PL];
-                    }
-                }
-                if (kc == 0 && t + g < n_tiles) load_ids(t + g, node_next);
-                if (kc + 1 < NCH) {
-                    issue_chunk(node, kc + 1);
-                } else if (t + g < n_tiles) {
-                    issue_chunk(node_next, 0);
-                }
-                if (kc == NCH - 2) {
-                    // first-order rows of this tile, full width: the thread's (row, member) pairs are those of its chunk loads
-#pragma unroll
-                    for (int x = 0; x < PLOADS; ++x) {
-                        const int idx = tid + kBlockThreads * x;
-                        const int c4 = idx % PV4, r = (idx / PV4) % TE, m = idx / (PV4 * TE);
-                        const int64_t e = t * TE + r;
-                        const int64_t nd = e < n_edges ? i3[e * 3 + m] : 0;
-                        pr[x] = *reinterpret_cast<const v4f*>(p + nd * ld_p + c4 * 4);
-                    }
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int x = 0; x < LOADS; ++x) node[x] = node_next[x];
-            t += g;
-        }
-        return;
-    }
-    // consumers: (et, jt0 + 2x) output tiles, accumulators across the NCH chunk trips of a tile
-    const int et = wave & 1, jt0 = wave >> 1;
-    const int row = et * 32 + (lane & 31), half = lane >> 5;
-    const v4f* wp_base = reinterpret_cast<const v4f*>(wp) + lane;
-    int trip = 0;
-    for (int64_t t = blockIdx.x; t < n_tiles; t += g) {
-        v16f acc[NJ];
-#pragma unroll
-        for (int x = 0; x < NJ; ++x)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-        // the fragment addresses are the same for every tile; an opaque zero keeps the compiler from hoisting all 64 loads out
-        // of the tile loop (which lands them in scratch: 512 registers' worth)
-        int opaque = 0;
-        asm volatile("" : "+s"(opaque));
-        const v4f* wp4 = wp_base + opaque;
-#pragma unroll
-        for (int kc = 0; kc < NCH; ++kc, ++trip) {
-            __syncthreads();
-            const float (*src)[TE][STRIDE] = tile[trip & 1];
-            v4f bcur[NJ][NBLK], bnext[NJ][NBLK];
-#pragma unroll
-            for (int x = 0; x < NJ; ++x)
-#pragma unroll
-                for (int b = 0; b < NBLK; ++b) bcur[x][b] = wp4[(static_cast<int64_t>((jt0 + 2 * x) * NBLK + b) * TG + kc * T_STEPS) * kWave];
-#pragma unroll
-            for (int ts = 0; ts < T_STEPS; ++ts) {
-                if (ts + 1 < T_STEPS) {
-#pragma unroll
-                    for (int x = 0; x < NJ; ++x)
-#pragma unroll
-                        for (int b = 0; b < NBLK; ++b)
-                            bnext[x][b] = wp4[(static_cast<int64_t>((jt0 + 2 * x) * NBLK + b) * TG + kc * T_STEPS + ts + 1) * kWave];
-                }
-                const int col = 8 * ts + 4 * half;
-                const v4f au = *reinterpret_cast<const v4f*>(&src[0][row][col]);
-                const v4f aq = *reinterpret_cast<const v4f*>(&src[1][row][col]);
-                const v4f ai = *reinterpret_cast<const v4f*>(&src[2][row][col]);
-                v4f z[4];
-                z[0] = au * aq;
-                z[1] = aq * ai;
-                z[2] = ai * au;
-                z[3] = z[0] * ai;
-#pragma unroll
-                for (int x = 0; x < NJ; ++x)
-#pragma unroll
-                    for (int b = 0; b < NBLK; ++b)
-#pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[b][s2], bcur[x][b][s2], acc[x], 0, 0, 0);
-#pragma unroll
-                for (int x = 0; x < NJ; ++x)
-#pragma unroll
-                    for (int b = 0; b < NBLK; ++b) bcur[x][b] = bnext[x][b];
-            }
-        }
-        const int64_t e_base = t * TE;
-        const bool full = e_base + TE <= n_edges;
-#pragma unroll
-        for (int x = 0; x < NJ; ++x) {
-            const int j = (jt0 + 2 * x) * 32 + (lane & 31);
-            float first[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) first[r] = psum[et * 32 + acc_row(r, lane)][j];
-            float* orow = out + (e_base + et * 32) * ld_out + j;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (full || e_base + et * 32 + acc_row(r, lane) < n_edges) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[x][r] + first[r];
-        }
-    }
-}
-
 template <int D, int NBLK>
 __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_wsbig_kernel(
     const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
@@ -2132,10 +1980,7 @@ void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float
     switch (dim) {
         case 32: IHG_FWD_PIPE(32) break;
         case 64: IHG_FWD_PIPE(64) break;
-        case 128: {
-            const int grid = static_cast<int>(std::min<int64_t>((n_edges + 63) / 64, kPipeGrid));
-            hipLaunchKernelGGL((interact_fwd_wsbig_kernel<128, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges);
-        } break;
+        case 128: IHG_FWD(128) break;
         default: IHG_FWD(256) break;
     }
 #undef IHG_FWD
