@@ -10,8 +10,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(CSRC, 'libihgnn_hip.so')
-SOURCES = [os.path.join(CSRC, 'ihgnn_hip.hip')]
-HEADERS = [os.path.join(REPO, 'include', 'ihgnn_hip.h')]
+SOURCES = [os.path.join(CSRC, name) for name in ('host.hip', 'aggregate.hip', 'interact.hip', 'dense.hip', 'tail.hip')]
+HEADERS = [os.path.join(REPO, 'include', 'ihgnn_hip.h'), os.path.join(CSRC, 'common.hpp')]
 ARCH = 'gfx950'
 
 
@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
     cmd = [hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wall',
-           '-Wno-unused-function', '-I', os.path.join(REPO, 'include'), '-o', LIB] + SOURCES
+           '-Wno-unused-function', '-I', os.path.join(REPO, 'include'), '-I', CSRC, '-o', LIB] + SOURCES
     if verbose:
         cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
     proc = subprocess.run(cmd, capture_output=True, text=True)

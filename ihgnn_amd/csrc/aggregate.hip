@@ -1,0 +1,367 @@
+// aggregate.hip - the two HBM-bound aggregation kernels: K5 node -> hyperedge gather-sum, K7 hyperedge -> node segment-sum
+// (also: embedding-bag mean, scatter-add backward, two-hop first-order pass, weighted-CSR GCN propagation).
+//
+// Layout idea shared by both: a feature row of `dim` floats is owned by a GROUP of G = dim/4 lanes (16 B per lane, so one group
+// instruction moves one whole row and one wave instruction moves 64/G rows = 1 KiB), every lane keeps its own 4 columns in
+// registers for the whole reduction (no cross-lane adds), and the only cross-lane traffic is the index stream: indices are
+// fetched once per wave with a single coalesced load and handed to their group with wavefront shuffles (ds_bpermute), so the
+// dependent row gathers of several hyperedges are in flight together.
+#include "common.hpp"
+
+namespace {
+
+// ================================================================================================
+// K5  node -> hyperedge gather-sum
+//   G lanes own one hyperedge row; a wave works on EPW = (64/G)*U consecutive hyperedges per iteration:
+//   one coalesced load brings their 3*EPW member ids (<= 64 ints), shuffles hand each group its ids, then
+//   3*U independent row gathers per lane are issued before the first add.  Group g takes hyperedges
+//   e0 + g + (64/G)*t so that each store instruction of the wave writes (64/G) consecutive rows = 1 KiB.
+// ================================================================================================
+template <int VEC, int G, int U>
+__global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
+    const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ i3,
+    const float* __restrict__ node_scale, const float* __restrict__ bias, float alpha,
+    float* __restrict__ out, int64_t ld_out, int64_t n_edges, int dim_vec) {
+    constexpr int GPW = kWave / G;
+    constexpr int EPW = GPW * U;
+    static_assert(EPW * 3 <= kWave, "member ids of one wave iteration must fit one coalesced load");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int lig = lane & (G - 1);
+    const int grp = lane / G;
+    const int64_t n_ids = n_edges * 3;
+
+    for (int64_t e0 = global_wave_id() * EPW; e0 < n_edges; e0 += global_wave_count() * EPW) {
+        const int64_t pos = e0 * 3 + lane;
+        const bool have = lane < EPW * 3 && pos < n_ids;
+        const int my_id = have ? i3[pos] : 0;
+        const float my_scale = (node_scale != nullptr && have) ? node_scale[my_id] : 1.f;
+
+        int ids[U][3];
+        float sc[U][3];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int from = (grp + GPW * t) * 3 + m;
+                ids[t][m] = __shfl(my_id, from);
+                sc[t][m] = __shfl(my_scale, from);
+            }
+        }
+        for (int c = lig; c < dim_vec; c += G) {
+            Frag<VEC> rows[U][3];
+#pragma unroll
+            for (int t = 0; t < U; ++t) {
+                const bool live = e0 + grp + GPW * t < n_edges;
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                    rows[t][m] = live ? Frag<VEC>::load(src + static_cast<int64_t>(ids[t][m]) * ld_src + c * VEC)
+                                      : Frag<VEC>::zero();
+            }
+            Frag<VEC> b = bias != nullptr ? Frag<VEC>::load(bias + c * VEC) : Frag<VEC>::zero();
+#pragma unroll
+            for (int t = 0; t < U; ++t) {
+                const int64_t e = e0 + grp + GPW * t;
+                if (e >= n_edges) continue;
+                Frag<VEC> acc = Frag<VEC>::zero();
+                acc.add_scaled(rows[t][0], sc[t][0]);      // (u + q) + i, the order of a row-major SpMM row
+                acc.add_scaled(rows[t][1], sc[t][1]);
+                acc.add_scaled(rows[t][2], sc[t][2]);
+                acc.mul(alpha);
+                acc.add(b);
+                acc.store(out + e * ld_out + c * VEC);
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// K7  hyperedge -> node segment-sum (also: EmbeddingBag mean forward/backward, scatter-add backward)
+//   G lanes own one output row and walk its id list in chunks of G ids: one coalesced id load per chunk,
+//   shuffles broadcast each id inside the group, UNR row gathers in flight per lane, adds in list order.
+//   The chunk loop is made wave-uniform with a cross-group max so the shuffles always run converged.
+// ================================================================================================
+template <int VEC, int G>
+__device__ __forceinline__ Frag<VEC> accumulate_list(const float* __restrict__ src, int64_t ld_src,
+                                                     const int32_t* __restrict__ ids, const float* __restrict__ src_scale,
+                                                     const float* __restrict__ entry_scale,
+                                                     int begin, int len, int wave_max_len, int lane, int col) {
+    constexpr int UNR = G < 8 ? G : 8;
+    const int lig = lane & (G - 1);
+    const int group_base = lane & ~(G - 1);
+    Frag<VEC> acc = Frag<VEC>::zero();
+    for (int base = 0; base < wave_max_len; base += G) {
+        const bool have = base + lig < len;
+        const int my_id = have ? ids[begin + base + lig] : -1;
+        float my_w = (src_scale != nullptr && have) ? src_scale[my_id] : 1.f;
+        if (entry_scale != nullptr && have) my_w *= entry_scale[begin + base + lig];
+#pragma unroll 1
+        for (int j = 0; j < G; j += UNR) {
+            if (base + j >= wave_max_len) break;      // wave-uniform: nothing left in any group
+            int id[UNR];
+            float w[UNR];
+            Frag<VEC> row[UNR];
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) {
+                id[k] = __shfl(my_id, group_base + j + k);
+                w[k] = __shfl(my_w, group_base + j + k);
+            }
+#pragma unroll
+            for (int k = 0; k < UNR; ++k)
+                row[k] = (id[k] >= 0 && col >= 0) ? Frag<VEC>::load(src + static_cast<int64_t>(id[k]) * ld_src + col * VEC)
+                                                  : Frag<VEC>::zero();
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) acc.add_scaled(row[k], w[k]);
+        }
+    }
+    return acc;
+}
+
+template <int G>
+__device__ __forceinline__ int wave_max_over_groups(int v) {
+#pragma unroll
+    for (int o = kWave / 2; o >= G; o >>= 1) {
+        const int other = __shfl_xor(v, o);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+template <int VEC>
+__device__ __forceinline__ void apply_out_scale(Frag<VEC>& acc, const float* out_scale, int mode, int64_t row) {
+    if (mode == IHG_SCALE_MULTIPLY) {
+        acc.mul(out_scale[row]);
+    } else if (mode == IHG_SCALE_DIVIDE) {
+        const float s = out_scale[row];
+        if (s != 0.f) acc.div(s);
+    }
+}
+
+// Work list of one launch: first the fixed-length segments of the split (heavy) rows, then the light rows in `row_order`
+// (decreasing length).  Unit u < n_segments writes partials[u]; unit u >= n_segments writes its output row.
+template <int VEC, int G>
+__global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
+    const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ids,
+    const int32_t* __restrict__ row_order, const float* __restrict__ src_scale, const float* __restrict__ entry_scale,
+    const float* __restrict__ out_scale, int mode,
+    float* __restrict__ out, int64_t ld_out, int64_t n_rows, int dim, int dim_vec, int heavy_threshold,
+    const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments, float* __restrict__ partials,
+    const float* __restrict__ self_weight) {
+    constexpr int GPW = kWave / G;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int lig = lane & (G - 1);
+    const int grp = lane / G;
+    const int64_t n_units = n_segments + n_rows;
+    for (int64_t u0 = global_wave_id() * GPW; u0 < n_units; u0 += global_wave_count() * GPW) {
+        const int64_t u = u0 + grp;
+        int begin = 0, len = 0;
+        float* dst = nullptr;
+        int64_t scale_row = -1;
+        if (u < n_segments) {
+            begin = seg_begin[u];
+            len = seg_end[u] - begin;
+            dst = partials + u * dim;
+        } else if (u < n_units) {
+            int64_t r = u - n_segments;
+            if (row_order != nullptr) r = row_order[r];
+            begin = rowptr[r];
+            len = rowptr[r + 1] - begin;
+            if (heavy_threshold > 0 && len > heavy_threshold) {
+                len = 0;                                    // finished from the partials
+            } else {
+                dst = out + r * ld_out;
+                scale_row = r;
+            }
+        }
+        const int wave_len = wave_max_over_groups<G>(len);
+        const int col_iters = (dim_vec + G - 1) / G;
+        for (int ci = 0; ci < col_iters; ++ci) {
+            const int c = ci * G + lig;
+            const int col = c < dim_vec ? c : -1;
+            Frag<VEC> acc = accumulate_list<VEC, G>(src, ld_src, ids, src_scale, entry_scale, begin, len, wave_len, lane, col);
+            if (dst != nullptr && col >= 0) {
+                if (scale_row >= 0) {
+                    if (self_weight != nullptr)             // square operators: the row's own source row, weighted
+                        acc.add_scaled(Frag<VEC>::load(src + scale_row * ld_src + col * VEC),
+                                       self_weight[scale_row] * (src_scale != nullptr ? src_scale[scale_row] : 1.f));
+                    apply_out_scale<VEC>(acc, out_scale, mode, scale_row);
+                }
+                acc.store(dst + col * VEC);
+            }
+        }
+    }
+}
+
+// One workgroup per heavy row: its 256/G lane groups take the row's partials round-robin (4 loads in flight each), the
+// per-group sums are combined through LDS in group order - a fixed summation tree, so the result is bitwise reproducible.
+template <int VEC, int G>
+__global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
+    const float* __restrict__ partials, const int32_t* __restrict__ heavy_rows, const int32_t* __restrict__ heavy_segptr,
+    int64_t n_heavy, const float* __restrict__ out_scale, int mode, float* __restrict__ out, int64_t ld_out, int dim, int dim_vec,
+    const float* __restrict__ src, int64_t ld_src, const float* __restrict__ src_scale, const float* __restrict__ self_weight) {
+    constexpr int GROUPS = kBlockThreads / G;
+    __shared__ __attribute__((aligned(16))) float red[GROUPS][G * VEC];
+    const int lig = threadIdx.x & (G - 1);
+    const int grp = threadIdx.x / G;
+    for (int64_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const int64_t row = heavy_rows[h];
+        const int s_begin = heavy_segptr[h], s_end = heavy_segptr[h + 1];
+        for (int c0 = 0; c0 < dim_vec; c0 += G) {
+            const int c = c0 + lig;
+            Frag<VEC> acc = Frag<VEC>::zero();
+            if (c < dim_vec) {
+                int sgm = s_begin + grp;
+                for (; sgm + 3 * GROUPS < s_end; sgm += 4 * GROUPS) {
+                    const Frag<VEC> a0 = Frag<VEC>::load(partials + static_cast<int64_t>(sgm) * dim + c * VEC);
+                    const Frag<VEC> a1 = Frag<VEC>::load(partials + static_cast<int64_t>(sgm + GROUPS) * dim + c * VEC);
+                    const Frag<VEC> a2 = Frag<VEC>::load(partials + static_cast<int64_t>(sgm + 2 * GROUPS) * dim + c * VEC);
+                    const Frag<VEC> a3 = Frag<VEC>::load(partials + static_cast<int64_t>(sgm + 3 * GROUPS) * dim + c * VEC);
+                    acc.add(a0); acc.add(a1); acc.add(a2); acc.add(a3);
+                }
+                for (; sgm < s_end; sgm += GROUPS) acc.add(Frag<VEC>::load(partials + static_cast<int64_t>(sgm) * dim + c * VEC));
+                acc.store(&red[grp][lig * VEC]);
+            }
+            __syncthreads();
+            if (grp == 0 && c < dim_vec) {
+                Frag<VEC> total = Frag<VEC>::load(&red[0][lig * VEC]);
+                const int used = s_end - s_begin < GROUPS ? s_end - s_begin : GROUPS;
+                for (int g2 = 1; g2 < used; ++g2) total.add(Frag<VEC>::load(&red[g2][lig * VEC]));
+                if (self_weight != nullptr)
+                    total.add_scaled(Frag<VEC>::load(src + row * ld_src + c * VEC), self_weight[row] * (src_scale != nullptr ? src_scale[row] : 1.f));
+                apply_out_scale<VEC>(total, out_scale, mode, row);
+                total.store(out + row * ld_out + c * VEC);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dispatch helpers
+// ------------------------------------------------------------------------------------------------
+
+// Smallest power of two >= n, clamped to [4, 64].
+inline int group_lanes(int n) {
+    int g = 4;
+    while (g < n && g < kWave) g <<= 1;
+    return g;
+}
+
+template <int VEC>
+int launch_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, const float* node_scale, const float* bias,
+                           float alpha, float* out, int64_t ld_out, int64_t n_edges, int dim, hipStream_t stream) {
+    const int dim_vec = dim / VEC;
+    const int g = group_lanes(dim_vec);
+#define IHG_LAUNCH_K5(G, U)                                                                                         \
+    {                                                                                                               \
+        constexpr int EPW = (kWave / G) * U;                                                                        \
+        const int grid = grid_for_waves((n_edges + EPW - 1) / EPW);                                                 \
+        hipLaunchKernelGGL((edge_gather_sum_kernel<VEC, G, U>), dim3(grid), dim3(kBlockThreads), 0, stream, src,    \
+                           ld_src, i3, node_scale, bias, alpha, out, ld_out, n_edges, dim_vec);                     \
+    }
+    switch (g) {
+        case 4: IHG_LAUNCH_K5(4, 1) break;
+        case 8: IHG_LAUNCH_K5(8, 2) break;
+        case 16: IHG_LAUNCH_K5(16, 4) break;
+        case 32: IHG_LAUNCH_K5(32, 4) break;
+        default: IHG_LAUNCH_K5(64, 4) break;
+    }
+#undef IHG_LAUNCH_K5
+    return check_launch("ihg_edge_gather_sum");
+}
+
+struct HeavyPlan {
+    const int32_t* seg_begin;
+    const int32_t* seg_end;
+    int64_t n_segments;
+    const int32_t* heavy_rows;
+    const int32_t* heavy_segptr;
+    int64_t n_heavy;
+    float* partials;
+};
+
+template <int VEC, int G>
+void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
+                          const float* src_scale, const float* entry_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
+                          int heavy_threshold, const HeavyPlan& hp, const float* self_weight, hipStream_t stream) {
+    constexpr int GPW = kWave / G;
+    const int dim_vec = dim / VEC;
+    const int grid = grid_for_waves((n_rows + hp.n_segments + GPW - 1) / GPW);
+    hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr, ids, row_order,
+                       src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, dim_vec, heavy_threshold, hp.seg_begin, hp.seg_end,
+                       hp.n_segments, hp.partials, self_weight);
+    if (hp.n_heavy > 0)
+        hipLaunchKernelGGL((heavy_finish_kernel<VEC, G>), dim3(static_cast<int>(std::min<int64_t>(hp.n_heavy, kMaxBlocks * 4))),
+                           dim3(kBlockThreads), 0, stream, hp.partials, hp.heavy_rows, hp.heavy_segptr, hp.n_heavy, out_scale, mode, out,
+                           ld_out, dim, dim_vec, src, ld_src, src_scale, self_weight);
+}
+
+template <int VEC>
+int launch_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
+                       const float* src_scale, const float* entry_scale, const float* out_scale, int mode, float* out, int64_t ld_out, int64_t n_rows, int dim,
+                       int heavy_threshold, const HeavyPlan& hp, const float* self_weight, hipStream_t stream) {
+#define IHG_K7(G) launch_segment_sum_g<VEC, G>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, heavy_threshold, hp, self_weight, stream)
+    switch (group_lanes(dim / VEC)) {
+        case 4: IHG_K7(4); break;
+        case 8: IHG_K7(8); break;
+        case 16: IHG_K7(16); break;
+        case 32: IHG_K7(32); break;
+        default: IHG_K7(64); break;
+    }
+#undef IHG_K7
+    return check_launch("ihg_node_segment_sum");
+}
+
+inline bool scale_mode_ok(int mode, const float* scale) {
+    if (mode == IHG_SCALE_NONE) return true;
+    return (mode == IHG_SCALE_MULTIPLY || mode == IHG_SCALE_DIVIDE) && scale != nullptr;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, const float* node_scale, const float* bias,
+                        float alpha, float* out, int64_t ld_out, int64_t n_edges, int32_t dim, ihg_stream_t stream) {
+    if (n_edges < 0 || dim <= 0 || ld_src < dim || ld_out < dim) return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum: bad size (E=%lld dim=%d ld_src=%lld ld_out=%lld)", (long long)n_edges, dim, (long long)ld_src, (long long)ld_out);
+    if (n_edges == 0) return IHG_OK;
+    if (src == nullptr || i3 == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out) && (bias == nullptr || aligned16(bias));
+    return wide ? launch_edge_gather_sum<4>(src, ld_src, i3, node_scale, bias, alpha, out, ld_out, n_edges, dim, s)
+                : launch_edge_gather_sum<1>(src, ld_src, i3, node_scale, bias, alpha, out, ld_out, n_edges, dim, s);
+}
+
+int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,
+                         const float* src_scale, const float* entry_scale, const float* out_scale, int32_t out_scale_mode, float* out, int64_t ld_out,
+                         int64_t n_rows, int32_t dim, int32_t heavy_threshold, const int32_t* seg_begin, const int32_t* seg_end,
+                         int64_t n_segments, const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy, float* partials,
+                         const float* self_weight, ihg_stream_t stream) {
+    if (n_rows < 0 || dim <= 0 || ld_src < dim || ld_out < dim || n_segments < 0 || n_heavy < 0) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad size");
+    if (!scale_mode_ok(out_scale_mode, out_scale)) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad out_scale_mode %d", out_scale_mode);
+    if (n_rows == 0) return IHG_OK;
+    if (src == nullptr || rowptr == nullptr || ids == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: null pointer");
+    if (n_heavy > 0 && (heavy_threshold <= 0 || seg_begin == nullptr || seg_end == nullptr || heavy_rows == nullptr || heavy_segptr == nullptr || partials == nullptr))
+        return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: incomplete split-row plan");
+    if (n_heavy == 0) {
+        n_segments = 0;
+        heavy_threshold = 0;
+    }
+    const HeavyPlan hp{seg_begin, seg_end, n_segments, heavy_rows, heavy_segptr, n_heavy, partials};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out) && (n_heavy == 0 || aligned16(partials));
+    return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, self_weight, s)
+                : launch_segment_sum<1>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, self_weight, s);
+}
+
+int ihg_bag_mean_fwd(const float* table, int64_t ld_table, const int32_t* bag_ptr, const int32_t* words, const float* bag_len,
+                     float* out, int64_t ld_out, int64_t n_bags, int32_t dim, ihg_stream_t stream) {
+    if (bag_len == nullptr && n_bags > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_fwd: null bag_len");
+    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, nullptr, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, stream);
+}
+
+int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr, const int32_t* word_bags, const float* inv_len,
+                     float* dtable, int64_t ld_dtable, int64_t n_table_rows, int32_t dim, ihg_stream_t stream) {
+    if (inv_len == nullptr && n_table_rows > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_bwd: null inv_len");
+    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, nullptr, inv_len, nullptr, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, stream);
+}
+}  // extern "C"

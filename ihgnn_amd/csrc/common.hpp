@@ -1,0 +1,111 @@
+// common.hpp - shared pieces of libihgnn_hip (gfx950 only, wave = 64).  Everything here has internal linkage per translation unit
+// except the thread-local error buffer, which lives in host.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ihgnn_hip.h"
+
+extern thread_local char ihg_error_buffer[512];
+
+namespace {
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ihg_error_buffer, sizeof(ihg_error_buffer), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int check_launch(const char* what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(IHG_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(err));
+    return IHG_OK;
+}
+
+constexpr int kWave = 64;
+constexpr int kBlockThreads = 256;
+constexpr int kWavesPerBlock = kBlockThreads / kWave;
+constexpr int kMaxBlocks = 256 * 8;   // 256 CUs x 8 resident 256-thread blocks: grid-stride beyond that
+
+inline int grid_for_waves(int64_t waves) {
+    int64_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    return static_cast<int>(blocks);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row fragments: VEC = 4 -> one float4 (16 B) per lane per row, VEC = 1 -> one float.
+// ------------------------------------------------------------------------------------------------
+template <int VEC> struct Frag;
+template <> struct Frag<4> {
+    float4 v;
+    __device__ static Frag zero() { return {make_float4(0.f, 0.f, 0.f, 0.f)}; }
+    __device__ static Frag load(const float* p) { return {*reinterpret_cast<const float4*>(p)}; }
+    __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ void add_scaled(const Frag& o, float s) { v.x += s * o.v.x; v.y += s * o.v.y; v.z += s * o.v.z; v.w += s * o.v.w; }
+    __device__ void add(const Frag& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
+    __device__ void mul(float s) { v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+    __device__ void div(float s) { v.x /= s; v.y /= s; v.z /= s; v.w /= s; }
+};
+template <> struct Frag<1> {
+    float v;
+    __device__ static Frag zero() { return {0.f}; }
+    __device__ static Frag load(const float* p) { return {*p}; }
+    __device__ void store(float* p) const { *p = v; }
+    __device__ void add_scaled(const Frag& o, float s) { v += s * o.v; }
+    __device__ void add(const Frag& o) { v += o.v; }
+    __device__ void mul(float s) { v *= s; }
+    __device__ void div(float s) { v /= s; }
+};
+
+__device__ __forceinline__ int64_t global_wave_id() {
+    return static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+}
+__device__ __forceinline__ int64_t global_wave_count() { return static_cast<int64_t>(gridDim.x) * kWavesPerBlock; }
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kRowPad = 4;       // floats; breaks the power-of-two row stride for ds_read_b128
+
+// row of accumulator register r in lane `lane` of a 32x32 MFMA result (column = lane & 31)
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// Sum `n_slabs` slabs of `total` floats each at element `idx`: the workgroup's 4 waves take the slabs round-robin with 8
+// loads in flight per lane, then combine through LDS in wave order (fixed tree => bitwise reproducible).
+// Must be called by all 256 threads of a block with idx = blockIdx.x * 64 + (threadIdx.x & 63); returns the sum to wave 0.
+__device__ __forceinline__ float slab_sum(const float* __restrict__ slabs, int n_slabs, int64_t total, int64_t idx, bool live) {
+    __shared__ float part[kWavesPerBlock][kWave];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
+    if (live) {
+        int sl = wave;
+        for (; sl + 7 * kWavesPerBlock < n_slabs; sl += 8 * kWavesPerBlock) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += slabs[static_cast<int64_t>(sl + u * kWavesPerBlock) * total + idx];
+        }
+        for (; sl < n_slabs; sl += kWavesPerBlock) a[0] += slabs[static_cast<int64_t>(sl) * total + idx];
+    }
+    part[wave][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    const float sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    __syncthreads();
+    return sum;
+}
+
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool mfma_dim(int dim) { return dim == 32 || dim == 64 || dim == 128 || dim == 256; }
+
+}  // namespace

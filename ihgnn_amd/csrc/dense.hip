@@ -1,0 +1,356 @@
+// dense.hip - node-level dense transforms (feature_transform and the hoisted first-order blocks): typed row GEMM, its input
+// gradient and its weight / bias gradient.
+#include "common.hpp"
+
+namespace {
+
+// ================================================================================================
+// Node-level dense transforms (K4 and the hoisted first-order blocks): out[v] = x[v] * W_type(v)^T (+ bias).
+// Nodes are typed by contiguous id ranges (users | queries | items); a layer either uses one weight for every row
+// (feature_transform) or one d x d block per type (the u / q / i blocks of aggregation.weight).  All three kernels
+// are HBM-bound streams over [N, d]; the matrix cores only keep the arithmetic out of the way:
+//   row_gemm_kernel        out[v][n]   = sum_k in[v][k] * B_t[k][n] (+ bias[n])     fwd (B = W^T) and input-grad (B = W)
+//   dense_weight_grad      dW_t[c][j]  = sum_{v in t} dout[v][c] * x[v][j],  db[c] = sum_v dout[v][c]
+// ================================================================================================
+struct TypePlan {
+    int64_t begin[4];        // row ranges of the three node types: [begin[t], begin[t+1])
+    int tile_prefix[4];      // cumulative workgroup tiles per type
+};
+
+// pk[type][xt][t][lane][4]:  transpose == 0:  W_t[32xt + r][8t + 4h + s]     (B[k][n] = W[n][k],  out = in * W^T)
+//                            transpose == 1:  W_t[8t + 4h + s][32xt + r]     (B[k][n] = W[k][n],  out = in * W)
+// with W_t[a][b] = w[a * ld_w + t * type_stride + b], r = lane & 31, h = lane >> 5.
+__global__ __launch_bounds__(kBlockThreads) void pack_dense_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride,
+                                                                   int n_types, int d, int transpose, float* __restrict__ pk) {
+    const int t_count = d / 8;
+    const int per_type = (d / 32) * t_count * kWave;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < per_type * n_types; idx += gridDim.x * blockDim.x) {
+        const int type = idx / per_type, rem = idx - type * per_type;
+        const int lane = rem & (kWave - 1), t = (rem >> 6) % t_count, xt = (rem >> 6) / t_count;
+        const int r = lane & 31, half = lane >> 5;
+        const float* wt = w + type * type_stride;
+        float4 v;
+        if (transpose == 0) {
+            const float* src = wt + static_cast<int64_t>(32 * xt + r) * ld_w + 8 * t + 4 * half;
+            v = make_float4(src[0], src[1], src[2], src[3]);
+        } else {
+            const float* src = wt + static_cast<int64_t>(8 * t + 4 * half) * ld_w + 32 * xt + r;
+            v = make_float4(src[0], src[ld_w], src[2 * ld_w], src[3 * ld_w]);
+        }
+        *reinterpret_cast<float4*>(pk + static_cast<int64_t>(idx) * 4) = v;
+    }
+}
+
+// Register-prefetch pipeline: the rows of tile n+1 are fetched while tile n is multiplied.  vmcnt retires in issue order, so
+// the (tiny, cache-resident) weight fragments of the current tile are pulled into registers BEFORE the prefetch is issued;
+// D = 256 would need 512 registers for that and keeps the plain fetch-then-multiply order.
+template <int D>
+__global__ __launch_bounds__(kBlockThreads) void row_gemm_kernel(const float* __restrict__ in, int64_t ld_in, const float* __restrict__ pk,
+                                                                 int64_t pk_type_stride, const float* __restrict__ bias, int bias_mask,
+                                                                 TypePlan plan, float* __restrict__ out, int64_t ld_out) {
+    constexpr int ET = D == 32 ? 4 : 2, TE = ET * 32, STRIDE = D + kRowPad, JOBS = ET * (D / 32);
+    constexpr int V4_PER_ROW = D / 4, LOADS = TE * V4_PER_ROW / kBlockThreads, T_STEPS = D / 8;
+    constexpr int JOBS_PER_WAVE = JOBS / kWavesPerBlock;
+    constexpr bool HOLD_B = D <= 128;
+    __shared__ __attribute__((aligned(16))) float xt[TE][STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int total_tiles = plan.tile_prefix[3];
+    auto tile_type = [&](int tile_id) { return tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0); };
+
+    v4f xreg[LOADS];
+    v4f breg[HOLD_B ? JOBS_PER_WAVE : 1][HOLD_B ? T_STEPS : 1];
+    int cur = -1, nxt = blockIdx.x;
+    while (true) {
+        if (cur >= 0) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                const int idx = tid + kBlockThreads * k;
+                *reinterpret_cast<v4f*>(&xt[idx / V4_PER_ROW][(idx % V4_PER_ROW) * 4]) = xreg[k];
+            }
+            __syncthreads();
+            if (HOLD_B) {
+                const v4f* pk4 = reinterpret_cast<const v4f*>(pk + tile_type(cur) * pk_type_stride) + lane;
+#pragma unroll
+                for (int jw = 0; jw < JOBS_PER_WAVE; ++jw) {
+                    const int ct = (wave + jw * kWavesPerBlock) / ET;
+#pragma unroll
+                    for (int t = 0; t < T_STEPS; ++t) breg[jw][t] = pk4[(static_cast<int64_t>(ct) * T_STEPS + t) * kWave];
+                }
+            }
+        }
+        const bool have_next = nxt < total_tiles;
+        if (have_next && (HOLD_B || cur < 0)) {
+            const int type = tile_type(nxt);
+            const int64_t r_base = plan.begin[type] + static_cast<int64_t>(nxt - plan.tile_prefix[type]) * TE;
+            const int64_t r_end = plan.begin[type + 1];
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                const int idx = tid + kBlockThreads * k;
+                const int64_t v = r_base + idx / V4_PER_ROW;
+                xreg[k] = v < r_end ? *reinterpret_cast<const v4f*>(in + v * ld_in + (idx % V4_PER_ROW) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (cur >= 0) {
+            const int type = tile_type(cur);
+            const int64_t r_base = plan.begin[type] + static_cast<int64_t>(cur - plan.tile_prefix[type]) * TE;
+            const int64_t r_end = plan.begin[type + 1];
+            const v4f* pk4 = reinterpret_cast<const v4f*>(pk + type * pk_type_stride) + lane;
+            const bool with_bias = bias != nullptr && ((bias_mask >> type) & 1);
+#pragma unroll
+            for (int jw = 0; jw < JOBS_PER_WAVE; ++jw) {
+                const int job = wave + jw * kWavesPerBlock;
+                const int et = job % ET, ct = job / ET;
+                const int row = et * 32 + (lane & 31);
+                v16f acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < T_STEPS; ++t) {
+                    const v4f a = *reinterpret_cast<const v4f*>(&xt[row][8 * t + 4 * half]);
+                    const v4f bf = HOLD_B ? breg[HOLD_B ? jw : 0][HOLD_B ? t : 0] : pk4[(static_cast<int64_t>(ct) * T_STEPS + t) * kWave];
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bf[s2], acc, 0, 0, 0);
+                }
+                const int c = ct * 32 + (lane & 31);
+                const float bv = with_bias ? bias[c] : 0.f;
+                float* orow = out + (r_base + et * 32) * ld_out + c;
+                if (r_base + TE <= r_end) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[r] + bv;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (r_base + et * 32 + acc_row(r, lane) < r_end) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[r] + bv;
+                }
+            }
+        }
+        if (!HOLD_B && cur >= 0 && have_next) {           // plain order for D = 256: fetch the next tile after the multiply
+            const int type = tile_type(nxt);
+            const int64_t r_base = plan.begin[type] + static_cast<int64_t>(nxt - plan.tile_prefix[type]) * TE;
+            const int64_t r_end = plan.begin[type + 1];
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                const int idx = tid + kBlockThreads * k;
+                const int64_t v = r_base + idx / V4_PER_ROW;
+                xreg[k] = v < r_end ? *reinterpret_cast<const v4f*>(in + v * ld_in + (idx % V4_PER_ROW) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (!have_next) break;
+        cur = nxt;
+        nxt += gridDim.x;
+    }
+}
+
+// grid = (slabs, (d/SW)^2 sub-blocks, weight types).  Slab layout: [type][slab][d][d] then bias part [type][slab][d].
+// Same register-prefetch pipeline as the interactive weight-gradient kernel.
+template <int SW>
+__global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_kernel(const float* __restrict__ dout, int64_t ld_dout,
+                                                                          const float* __restrict__ x, int64_t ld_x, TypePlan plan,
+                                                                          int single_weight, float* __restrict__ slabs,
+                                                                          float* __restrict__ bias_slabs, int d) {
+    constexpr int TE = 64, WT = SW / 32, V4_PER_ROW = SW / 4, LOADS = TE * V4_PER_ROW / kBlockThreads;
+    __shared__ __attribute__((aligned(16))) float dtile[TE][SW];
+    __shared__ __attribute__((aligned(16))) float xtile[TE][SW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int subs = d / SW;
+    const int js = blockIdx.y / subs, cs = blockIdx.y % subs;
+    const int type = blockIdx.z;
+    const int64_t r_begin = single_weight ? plan.begin[0] : plan.begin[type];
+    const int64_t r_end = single_weight ? plan.begin[3] : plan.begin[type + 1];
+    const int64_t n_tiles = (r_end - r_begin + TE - 1) / TE;
+    const int jt = WT == 2 ? (wave & 1) : 0, ct = WT == 2 ? (wave >> 1) : 0;
+    const bool active = WT == 2 || wave == 0;
+    v16f acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float colsum = 0.f;
+
+    float4 dreg[LOADS], xreg[LOADS];
+    int64_t cur = -1, nxt = blockIdx.x;
+    while (true) {
+        if (cur >= 0) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                const int idx = tid + kBlockThreads * k;
+                *reinterpret_cast<float4*>(&dtile[idx / V4_PER_ROW][(idx % V4_PER_ROW) * 4]) = dreg[k];
+                *reinterpret_cast<float4*>(&xtile[idx / V4_PER_ROW][(idx % V4_PER_ROW) * 4]) = xreg[k];
+            }
+            __syncthreads();
+        }
+        const bool have_next = nxt < n_tiles;
+        if (have_next) {
+            const int64_t r_base = r_begin + nxt * TE;
+#pragma unroll
+            for (int k = 0; k < LOADS; ++k) {
+                const int idx = tid + kBlockThreads * k;
+                const int c4 = idx % V4_PER_ROW, r = idx / V4_PER_ROW;
+                const int64_t v = r_base + r;
+                const bool live = v < r_end;
+                dreg[k] = live ? *reinterpret_cast<const float4*>(dout + v * ld_dout + js * SW + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xreg[k] = live ? *reinterpret_cast<const float4*>(x + v * ld_x + cs * SW + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (cur >= 0) {
+            if (active) {
+#pragma unroll 4
+                for (int kk = 0; kk < TE / 2; ++kk) {
+                    const int e = 2 * kk + half;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dtile[e][jt * 32 + l31], xtile[e][ct * 32 + l31], acc, 0, 0, 0);
+                }
+            }
+            if (cs == 0 && tid < SW) {
+                float part = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < TE; ++r) part += dtile[r][tid];
+                colsum += part;
+            }
+        }
+        if (!have_next) break;
+        cur = nxt;
+        nxt += gridDim.x;
+    }
+    const int n_slabs = gridDim.x;
+    float* slab = slabs + (static_cast<int64_t>(type) * n_slabs + blockIdx.x) * d * d;
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            slab[static_cast<int64_t>(js * SW + jt * 32 + acc_row(r, lane)) * d + cs * SW + ct * 32 + l31] = acc[r];
+    }
+    if (cs == 0 && tid < SW) bias_slabs[(static_cast<int64_t>(type) * n_slabs + blockIdx.x) * d + js * SW + tid] = colsum;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void dense_slab_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
+                                                                          int n_slabs, int n_types, int d, float* __restrict__ dw, int64_t ld_dw,
+                                                                          int64_t dw_type_stride, float* __restrict__ dbias, int bias_mask) {
+    const int64_t per_type = static_cast<int64_t>(d) * d;
+    const int64_t w_items = per_type * n_types;
+    const int64_t total = w_items + d;
+    for (int64_t base = static_cast<int64_t>(blockIdx.x) * kWave; base < total; base += static_cast<int64_t>(gridDim.x) * kWave) {
+        const int64_t idx = base + (threadIdx.x & 63);
+        const bool first_wave = (threadIdx.x >> 6) == 0;
+        if (base < w_items) {                               // w_items is a multiple of 64: a block never straddles the two parts
+            const int type = static_cast<int>(idx / per_type);
+            const int64_t rem = idx - type * per_type;
+            const float acc = slab_sum(slabs + static_cast<int64_t>(type) * n_slabs * per_type, n_slabs, per_type, rem, idx < w_items);
+            if (first_wave && idx < w_items) {
+                const int c = static_cast<int>(rem / d), j = static_cast<int>(rem - static_cast<int64_t>(c) * d);
+                dw[static_cast<int64_t>(c) * ld_dw + type * dw_type_stride + j] = acc;
+            }
+        } else {
+            const int c = static_cast<int>(idx - w_items);
+            float acc = 0.f;
+            for (int type = 0; type < n_types; ++type) {
+                const bool use = n_types == 1 || ((bias_mask >> type) & 1);
+                const float part = slab_sum(bias_slabs + static_cast<int64_t>(type) * n_slabs * d, n_slabs, d, c, use && c < d);
+                acc += part;
+            }
+            if (first_wave && c < d && dbias != nullptr) dbias[c] = acc;
+        }
+    }
+}
+
+inline TypePlan make_plan(const int64_t* type_begin, int tile_rows) {
+    TypePlan plan;
+    int acc = 0;
+    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
+    for (int t = 0; t < 3; ++t) {
+        plan.tile_prefix[t] = acc;
+        acc += static_cast<int>((type_begin[t + 1] - type_begin[t] + tile_rows - 1) / tile_rows);
+    }
+    plan.tile_prefix[3] = acc;
+    return plan;
+}
+constexpr int kDenseSlabs = 256;
+
+int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose,
+                    const float* bias, int bias_mask, const int64_t* type_begin, float* out, int64_t ld_out, float* pk, hipStream_t s) {
+    const int n_types = w_type_stride == 0 ? 1 : 3;
+    const int pack_items = n_types * (dim / 32) * (dim / 8) * kWave;
+    hipLaunchKernelGGL(pack_dense_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride,
+                       n_types, dim, transpose, pk);
+    const int64_t pk_type_stride = n_types == 1 ? 0 : static_cast<int64_t>(dim) * dim;
+    const TypePlan plan = make_plan(type_begin, dim == 32 ? 128 : 64);
+    if (plan.tile_prefix[3] == 0) return IHG_OK;
+    const int grid = std::min(plan.tile_prefix[3], 256 * 4);
+#define IHG_RG(D) hipLaunchKernelGGL((row_gemm_kernel<D>), dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, pk_type_stride, bias, bias_mask, plan, out, ld_out)
+    switch (dim) {
+        case 32: IHG_RG(32); break;
+        case 64: IHG_RG(64); break;
+        case 128: IHG_RG(128); break;
+        default: IHG_RG(256); break;
+    }
+#undef IHG_RG
+    return IHG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ihg_node_linear_workspace_bytes(int32_t dim) {
+    if (!mfma_dim(dim)) return -1;
+    const int64_t packed = 3LL * dim * dim;
+    const int64_t slabs = 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
+    return (packed + slabs) * static_cast<int64_t>(sizeof(float));
+}
+
+static int node_linear_common_check(const char* what, int32_t dim, int64_t ld_a, int64_t ld_b, int64_t ld_w, const int64_t* type_begin,
+                                    const void* workspace, int64_t workspace_bytes) {
+    if (!mfma_dim(dim)) return fail(IHG_ERR_INVALID, "%s: dim %d is not one of 32/64/128/256", what, dim);
+    if (type_begin == nullptr || workspace == nullptr) return fail(IHG_ERR_INVALID, "%s: null pointer", what);
+    if (ld_a < dim || ld_b < dim || ld_w < dim || ld_a % 4 || ld_b % 4) return fail(IHG_ERR_INVALID, "%s: bad leading dimension", what);
+    if (!(type_begin[0] <= type_begin[1] && type_begin[1] <= type_begin[2] && type_begin[2] <= type_begin[3])) return fail(IHG_ERR_INVALID, "%s: type ranges not ascending", what);
+    if (workspace_bytes < ihg_node_linear_workspace_bytes(dim)) return fail(IHG_ERR_WORKSPACE, "%s: workspace too small", what);
+    if (!aligned16(workspace)) return fail(IHG_ERR_INVALID, "%s: workspace not 16-byte aligned", what);
+    return IHG_OK;
+}
+
+int ihg_node_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, int64_t w_type_stride, const float* bias,
+                        int32_t bias_type_mask, const int64_t* type_begin, float* out, int64_t ld_out, void* workspace,
+                        int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
+    if (int rc = node_linear_common_check("ihg_node_linear_fwd", dim, ld_x, ld_out, ld_w, type_begin, workspace, workspace_bytes)) return rc;
+    if (type_begin[3] == type_begin[0]) return IHG_OK;
+    if (x == nullptr || w == nullptr || out == nullptr || !aligned16(x)) return fail(IHG_ERR_INVALID, "ihg_node_linear_fwd: null or unaligned pointer");
+    launch_row_gemm(dim, x, ld_x, w, ld_w, w_type_stride, 0, bias, bias_type_mask, type_begin, out, ld_out, static_cast<float*>(workspace),
+                    static_cast<hipStream_t>(stream));
+    return check_launch("ihg_node_linear_fwd");
+}
+
+int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w, int64_t ld_w, int64_t w_type_stride,
+                              const int64_t* type_begin, float* dx, int64_t ld_dx, void* workspace, int64_t workspace_bytes,
+                              int32_t dim, ihg_stream_t stream) {
+    if (int rc = node_linear_common_check("ihg_node_linear_bwd_input", dim, ld_dout, ld_dx, ld_w, type_begin, workspace, workspace_bytes)) return rc;
+    if (type_begin[3] == type_begin[0]) return IHG_OK;
+    if (dout == nullptr || w == nullptr || dx == nullptr || !aligned16(dout)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_input: null or unaligned pointer");
+    launch_row_gemm(dim, dout, ld_dout, w, ld_w, w_type_stride, 1, nullptr, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace),
+                    static_cast<hipStream_t>(stream));
+    return check_launch("ihg_node_linear_bwd_input");
+}
+
+int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin,
+                               float* dw, int64_t ld_dw, int64_t dw_type_stride, float* dbias, int32_t bias_type_mask,
+                               void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
+    if (int rc = node_linear_common_check("ihg_node_linear_bwd_weight", dim, ld_dout, ld_x, ld_dw, type_begin, workspace, workspace_bytes)) return rc;
+    if (dout == nullptr || x == nullptr || dw == nullptr || !aligned16(dout) || !aligned16(x)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: null or unaligned pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int n_types = dw_type_stride == 0 ? 1 : 3;
+    float* slabs = static_cast<float*>(workspace) + 3LL * dim * dim;
+    float* bias_slabs = slabs + 3LL * kDenseSlabs * dim * dim;
+    const TypePlan plan = make_plan(type_begin, 64);
+    if (dim == 32) {
+        hipLaunchKernelGGL((dense_weight_grad_kernel<32>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+                           n_types == 1 ? 1 : 0, slabs, bias_slabs, dim);
+    } else {
+        const int subs = (dim / 64) * (dim / 64);
+        hipLaunchKernelGGL((dense_weight_grad_kernel<64>), dim3(kDenseSlabs, subs, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+                           n_types == 1 ? 1 : 0, slabs, bias_slabs, dim);
+    }
+    const int total = dim * dim * n_types + dim;
+    hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, bias_slabs,
+                       kDenseSlabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask);
+    return check_launch("ihg_node_linear_bwd_weight");
+}
+
+}  // extern "C"

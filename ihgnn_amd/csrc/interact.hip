@@ -1,0 +1,1063 @@
+// interact.hip - the interactive (order 2 / 3) node -> hyperedge step and its backward on the matrix cores (exact fp32 MFMA),
+// plus the one-thread-per-output kernels that take every other shape.
+#include "common.hpp"
+
+namespace {
+
+// ================================================================================================
+// Interactive step, generic form (any dim / stride).  One thread per output element; correct for every
+// shape, used when the MFMA-tiled kernels' shape constraints do not hold.
+// ================================================================================================
+__global__ __launch_bounds__(kBlockThreads) void interact_fwd_generic_kernel(
+    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
+    const float* __restrict__ w, int64_t ld_w, int order, float* __restrict__ out, int64_t ld_out, int64_t n_edges, int dim) {
+    const int64_t total = n_edges * dim;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t e = idx / dim;
+        const int j = static_cast<int>(idx - e * dim);
+        const int64_t u = i3[e * 3], q = i3[e * 3 + 1], i = i3[e * 3 + 2];
+        float acc = 0.f;
+        if (p != nullptr) acc = (p[u * ld_p + j] + p[q * ld_p + j]) + p[i * ld_p + j];
+        const float* wj = w + j * ld_w + 3 * static_cast<int64_t>(dim);
+        const float* hu = h + u * ld_h;
+        const float* hq = h + q * ld_h;
+        const float* hi = h + i * ld_h;
+        for (int c = 0; c < dim; ++c) {
+            const float a = hu[c], b = hq[c], d = hi[c];
+            const float uq = a * b;
+            acc += wj[c] * uq;
+            acc += wj[dim + c] * (b * d);
+            acc += wj[2 * dim + c] * (d * a);
+            if (order == 3) acc += wj[3 * dim + c] * (uq * d);
+        }
+        out[e * ld_out + j] = acc;
+    }
+}
+
+// g[e, s, c]: gradient w.r.t. member s's transformed feature through the product terms.
+__global__ __launch_bounds__(kBlockThreads) void interact_bwd_members_generic_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ w, int64_t ld_w,
+    int order, const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g, int64_t n_edges, int dim) {
+    const int64_t total = n_edges * dim;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t e = idx / dim;
+        const int c = static_cast<int>(idx - e * dim);
+        const int64_t u = i3[e * 3], q = i3[e * 3 + 1], i = i3[e * 3 + 2];
+        const float* de = dout + e * ld_dout;
+        float z_uq = 0.f, z_qi = 0.f, z_iu = 0.f, z_uqi = 0.f;
+        for (int j = 0; j < dim; ++j) {
+            const float* wj = w + j * ld_w + 3 * static_cast<int64_t>(dim) + c;
+            const float d = de[j];
+            z_uq += d * wj[0];
+            z_qi += d * wj[dim];
+            z_iu += d * wj[2 * dim];
+            if (order == 3) z_uqi += d * wj[3 * dim];
+        }
+        const float a = h[u * ld_h + c], b = h[q * ld_h + c], d = h[i * ld_h + c];
+        float* ge = g + e * 3 * dim + c;
+        ge[0] = z_uq * b + z_iu * d + z_uqi * (b * d);
+        ge[dim] = z_uq * a + z_qi * d + z_uqi * (a * d);
+        ge[2 * dim] = z_qi * b + z_iu * a + z_uqi * (a * b);
+    }
+}
+
+// dW[j, (3+blk)*dim + c] = sum_e dout[e, j] * z_blk[e, c]; one thread per weight element, edges in order.
+__global__ __launch_bounds__(kBlockThreads) void interact_bwd_weight_generic_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, int order,
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ dw, int64_t ld_dw, int64_t n_edges, int dim) {
+    const int blocks = order == 3 ? 4 : 3;
+    const int64_t total = static_cast<int64_t>(dim) * blocks * dim;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
+         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int c = static_cast<int>(idx % dim);
+        const int blk = static_cast<int>((idx / dim) % blocks);
+        const int j = static_cast<int>(idx / (static_cast<int64_t>(dim) * blocks));
+        float acc = 0.f;
+        for (int64_t e = 0; e < n_edges; ++e) {
+            const int64_t u = i3[e * 3], q = i3[e * 3 + 1], i = i3[e * 3 + 2];
+            const float a = h[u * ld_h + c], b = h[q * ld_h + c], d = h[i * ld_h + c];
+            float z;
+            if (blk == 0) z = a * b;
+            else if (blk == 1) z = b * d;
+            else if (blk == 2) z = d * a;
+            else z = (a * b) * d;
+            acc += dout[e * ld_dout + j] * z;
+        }
+        dw[j * ld_dw + (3 + blk) * static_cast<int64_t>(dim) + c] = acc;
+    }
+}
+
+
+// ================================================================================================
+// Interactive step on the matrix cores (exact fp32: v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain).
+//
+//   fwd      C[e][j]        = sum_b sum_c z_b[e][c] * W[j][(3+b)d + c]          (+ hoisted first-order rows)
+//   members  dz_b[e][c]     = sum_j dout[e][j] * W[j][(3+b)d + c]    -> g[e, slot, c] by the product rule
+//   weights  dW[j][(3+b)d+c]= sum_e dout[e][j] * z_b[e][c]
+//
+// A 32x32x2 MFMA takes ONE float per lane per operand: lane l gives A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
+// The contraction index may be visited in any order as long as A and B agree, so in fwd / members lane-half h of
+// MFMA step s (s = 0..3) is given k = 8t + 4h + s: each lane then needs 4 CONSECUTIVE k per operand, i.e. one
+// ds_read_b128 (A side, gathered rows staged in LDS with a 16-B row pad -> conflict-free) and one 16-B global load
+// (B side) per 4 MFMAs.  The weights are re-packed once per call into that fragment order (pack_weights_kernel,
+// <= 1 MB) so that every B load of a wave is one contiguous, fully coalesced 1 KiB from L2.
+// z_b is never stored: it is formed in registers from the three staged member rows right before the MFMAs.
+// ================================================================================================
+
+// wp_fwd[jt][b][t][lane][4] = W[32jt + (lane&31)][(3+b)d + 8t + 4(lane>>5) + s]        (k runs along c)
+// wp_bwd[ct][b][t][lane][4] = W[8t + 4(lane>>5) + s][(3+b)d + 32ct + (lane&31)]        (k runs along j)
+__global__ __launch_bounds__(kBlockThreads) void pack_weights_kernel(const float* __restrict__ w, int64_t ld_w, int d, int nblk,
+                                                                     float* __restrict__ wp_fwd, float* __restrict__ wp_bwd) {
+    const int t_count = d / 8;
+    const int total = (d / 32) * nblk * t_count * kWave;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & (kWave - 1);
+        const int t = (idx >> 6) % t_count;
+        const int b = ((idx >> 6) / t_count) % nblk;
+        const int xt = (idx >> 6) / (t_count * nblk);
+        const int r = lane & 31, half = lane >> 5;
+        if (wp_fwd != nullptr) {
+            const float* src = w + static_cast<int64_t>(32 * xt + r) * ld_w + static_cast<int64_t>(3 + b) * d + 8 * t + 4 * half;
+            *reinterpret_cast<float4*>(wp_fwd + static_cast<int64_t>(idx) * 4) = make_float4(src[0], src[1], src[2], src[3]);
+        }
+        if (wp_bwd != nullptr) {
+            const float* src = w + static_cast<int64_t>(8 * t + 4 * half) * ld_w + static_cast<int64_t>(3 + b) * d + 32 * xt + r;
+            *reinterpret_cast<float4*>(wp_bwd + static_cast<int64_t>(idx) * 4) = make_float4(src[0], src[ld_w], src[2 * ld_w], src[3 * ld_w]);
+        }
+    }
+}
+
+template <int D> struct TileShape {
+    static constexpr int KC = D < 64 ? D : 64;             // staged column chunk of the member rows
+    static constexpr int ET = D == 32 ? 4 : 2;             // 32-edge tiles per workgroup tile
+    static constexpr int TE = ET * 32;
+    static constexpr int NJ = D == 32 ? 1 : D / 64;        // 32-wide output column tiles per wave
+    static constexpr int STRIDE = KC + kRowPad;
+};
+
+
+template <int D, int NBLK>
+__global__ __launch_bounds__(kBlockThreads) void interact_fwd_mfma_kernel(
+    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
+    const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
+    using S = TileShape<D>;
+    __shared__ __attribute__((aligned(16))) float tile[3][S::TE][S::STRIDE];
+    __shared__ int ids[S::TE][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int et = D == 32 ? wave : (wave & 1);
+    const int jt0 = D == 32 ? 0 : (wave >> 1);
+    const int row = et * 32 + (lane & 31), half = lane >> 5;
+    const int64_t n_tiles = (n_edges + S::TE - 1) / S::TE;
+    const v4f* wp4 = reinterpret_cast<const v4f*>(wp);
+
+    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+        const int64_t e_base = tile_id * S::TE;
+        __syncthreads();                                      // previous tile's epilogue is done with ids[]
+        for (int k = tid; k < S::TE * 3; k += kBlockThreads) {
+            const int64_t pos = e_base * 3 + k;
+            (&ids[0][0])[k] = pos < n_edges * 3 ? i3[pos] : 0;
+        }
+        v16f acc[S::NJ];
+#pragma unroll
+        for (int x = 0; x < S::NJ; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+        for (int kc = 0; kc < D / S::KC; ++kc) {
+            __syncthreads();                                  // ids visible; previous chunk's reads finished
+            constexpr int V4_PER_ROW = S::KC / 4;
+            constexpr int LOADS = 3 * S::TE * V4_PER_ROW / kBlockThreads;
+            float4 stage[LOADS];
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4_PER_ROW, r = (idx / V4_PER_ROW) % S::TE, m = idx / (V4_PER_ROW * S::TE);
+                stage[x] = *reinterpret_cast<const float4*>(h + static_cast<int64_t>(ids[r][m]) * ld_h + kc * S::KC + c4 * 4);
+            }
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4_PER_ROW, r = (idx / V4_PER_ROW) % S::TE, m = idx / (V4_PER_ROW * S::TE);
+                *reinterpret_cast<float4*>(&tile[m][r][c4 * 4]) = stage[x];
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int t = 0; t < S::KC / 8; ++t) {
+                const int col = 8 * t + 4 * half;
+                const v4f au = *reinterpret_cast<const v4f*>(&tile[0][row][col]);
+                const v4f aq = *reinterpret_cast<const v4f*>(&tile[1][row][col]);
+                const v4f ai = *reinterpret_cast<const v4f*>(&tile[2][row][col]);
+                v4f z[4];
+                z[0] = au * aq;
+                z[1] = aq * ai;
+                z[2] = ai * au;
+                z[3] = z[0] * ai;
+                const int tg = kc * (S::KC / 8) + t;
+#pragma unroll
+                for (int x = 0; x < S::NJ; ++x) {
+                    const int jt = jt0 + 2 * x;
+                    v4f bf[NBLK];
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) bf[b] = wp4[(static_cast<int64_t>(jt * NBLK + b) * (D / 8) + tg) * kWave + lane];
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(z[b][s], bf[b][s], acc[x], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: add the hoisted first-order rows and store
+#pragma unroll
+        for (int x = 0; x < S::NJ; ++x) {
+            const int j = (jt0 + 2 * x) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = et * 32 + acc_row(r, lane);
+                const int64_t e = e_base + er;
+                if (e < n_edges) {
+                    const float first = (p[static_cast<int64_t>(ids[er][0]) * ld_p + j] + p[static_cast<int64_t>(ids[er][1]) * ld_p + j]) +
+                                        p[static_cast<int64_t>(ids[er][2]) * ld_p + j];
+                    out[e * ld_out + j] = acc[x][r] + first;
+                }
+            }
+        }
+    }
+}
+
+// members: one workgroup tile = TE consecutive hyperedges; the dout rows are streamed (not gathered) into LDS at full
+// width, each wave then runs its (edge tile, column tile) jobs one after the other with NBLK accumulators.
+template <int D, int NBLK>
+__global__ __launch_bounds__(kBlockThreads) void interact_bwd_members_mfma_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g, int64_t n_edges) {
+    constexpr int ET = D == 32 ? 4 : 2, TE = ET * 32, STRIDE = D + kRowPad, JOBS = ET * (D / 32);
+    __shared__ __attribute__((aligned(16))) float dtile[TE][STRIDE];
+    __shared__ int ids[TE][3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const v4f* wq4 = reinterpret_cast<const v4f*>(wq);
+
+    for (int64_t tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+        const int64_t e_base = tile_id * TE;
+        __syncthreads();
+        for (int k = tid; k < TE * 3; k += kBlockThreads) {
+            const int64_t pos = e_base * 3 + k;
+            (&ids[0][0])[k] = pos < n_edges * 3 ? i3[pos] : 0;
+        }
+        constexpr int V4_PER_ROW = D / 4;
+        for (int idx = tid; idx < TE * V4_PER_ROW; idx += kBlockThreads) {
+            const int c4 = idx % V4_PER_ROW, r = idx / V4_PER_ROW;
+            const int64_t e = e_base + r;
+            const float4 v = e < n_edges ? *reinterpret_cast<const float4*>(dout + e * ld_dout + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&dtile[r][c4 * 4]) = v;
+        }
+        __syncthreads();
+        for (int job = wave; job < JOBS; job += kWavesPerBlock) {
+            const int et = job % ET, ct = job / ET;
+            const int row = et * 32 + (lane & 31);
+            v16f acc[NBLK];
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll 2
+            for (int t = 0; t < D / 8; ++t) {
+                const v4f a = *reinterpret_cast<const v4f*>(&dtile[row][8 * t + 4 * half]);
+                v4f bf[NBLK];
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) bf[b] = wq4[(static_cast<int64_t>(ct * NBLK + b) * (D / 8) + t) * kWave + lane];
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[b][s], acc[b], 0, 0, 0);
+            }
+            const int c = ct * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = et * 32 + acc_row(r, lane);
+                const int64_t e = e_base + er;
+                if (e < n_edges) {
+                    const float a = h[static_cast<int64_t>(ids[er][0]) * ld_h + c];
+                    const float b = h[static_cast<int64_t>(ids[er][1]) * ld_h + c];
+                    const float dd = h[static_cast<int64_t>(ids[er][2]) * ld_h + c];
+                    const float z_uq = acc[0][r], z_qi = acc[1][r], z_iu = acc[2][r];
+                    const float z_uqi = NBLK == 4 ? acc[NBLK - 1][r] : 0.f;
+                    float* ge = g + e * 3 * D + c;
+                    ge[0] = z_uq * b + z_iu * dd + z_uqi * (b * dd);
+                    ge[D] = z_uq * a + z_qi * dd + z_uqi * (a * dd);
+                    ge[2 * D] = z_qi * b + z_iu * a + z_uqi * (a * b);
+                }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised forms for D <= 64: one 512-thread workgroup per CU, persistent over hyperedge tiles.
+//   waves 4-7 (one per SIMD)  LOADERS:   gather the member rows (and the epilogue operands) of tile n+2 into registers,
+//                                         drop tile n+1 into the other half of a double-buffered LDS image;
+//   waves 0-3 (one per SIMD)  CONSUMERS: multiply tile n out of LDS on the matrix cores; the weight fragments they need
+//                                         (128 VGPRs at D = 64) are loaded ONCE per kernel and stay in registers.
+// One workgroup barrier per tile.  vmcnt retires loads in issue order, so a wave that both prefetches rows and streams
+// weight fragments stalls its MFMAs behind its own prefetch; splitting the roles gives each role its own counter and
+// leaves the consumers with no loads at all in steady state - their stream is LDS reads, MFMAs and result stores.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWsThreads = 512;
+
+template <int D, int NBLK>
+__global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
+    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
+    const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
+    static_assert(D == 32 || D == 64, "wave-specialised form stages whole rows");
+    using S = TileShape<D>;
+    constexpr int V4 = D / 4, LOADS = 3 * S::TE * V4 / kBlockThreads, PL = LOADS / 3, T_STEPS = D / 8;
+    struct Buffer {
+        float tile[3][S::TE][S::STRIDE];
+        float psum[S::TE][D];
+    };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    const int64_t n_tiles = (n_edges + S::TE - 1) / S::TE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    if (wave >= 4) {
+        // ---------------- loaders ----------------
+        // Schedule per trip (tile T is deposited while the consumers multiply the previous one):
+        //   deposit rows(T)  ->  issue rows(T+g) with the ids fetched a trip ago  ->  issue ids(T+2g)  ->  barrier.
+        // vmcnt retires in issue order, so every wait in a trip is for loads that were issued a whole trip earlier.
+        const int tid = threadIdx.x - kBlockThreads;
+        const int64_t g = gridDim.x;
+        v4f hr[LOADS], pr[LOADS];
+        int node[LOADS], node_next[LOADS];
+        auto load_ids = [&](int64_t tile_id, int (&dst)[LOADS]) {
+            const int64_t e_base = tile_id * S::TE;
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + (idx / V4) % S::TE;
+                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * S::TE)] : 0;
+            }
+        };
+        auto issue_rows = [&](const int (&src)[LOADS]) {
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + (idx % V4) * 4);
+                pr[x] = *reinterpret_cast<const v4f*>(p + static_cast<int64_t>(src[x]) * ld_p + (idx % V4) * 4);
+            }
+        };
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) {
+            load_ids(t, node);
+            issue_rows(node);
+        }
+        if (t + g < n_tiles) load_ids(t + g, node_next);
+        int which = 0;
+        while (t < n_tiles) {
+            Buffer& b = buf[which];
+#pragma unroll
+            for (int x = 0; x < LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.tile[idx / (V4 * S::TE)][(idx / V4) % S::TE][(idx % V4) * 4]) = hr[x];
+            }
+#pragma unroll
+            for (int x = 0; x < PL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.psum[idx / V4][(idx % V4) * 4]) = (pr[x] + pr[x + PL]) + pr[x + 2 * PL];
+            }
+            if (t + g < n_tiles) issue_rows(node_next);
+            if (t + 2 * g < n_tiles) load_ids(t + 2 * g, node_next);
+            __syncthreads();
+            t += g;
+            which ^= 1;
+        }
+        return;
+    }
+    // ---------------- consumers ----------------
+    const int et = D == 32 ? wave : (wave & 1);
+    const int jt = D == 32 ? 0 : (wave >> 1);
+    const int row = et * 32 + (lane & 31), half = lane >> 5;
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wp) + static_cast<int64_t>(jt) * NBLK * T_STEPS * kWave + lane;
+    v4f wreg[NBLK][T_STEPS];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int ts = 0; ts < T_STEPS; ++ts) wreg[b][ts] = wfrag[(b * T_STEPS + ts) * kWave];
+    const int j = jt * 32 + (lane & 31);
+    int which = 0;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
+        __syncthreads();
+        const Buffer& b = buf[which];
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // A operands one k-step ahead of the MFMAs that use them: the LDS round trip hides behind 16 MFMAs
+        v4f au = *reinterpret_cast<const v4f*>(&b.tile[0][row][4 * half]);
+        v4f aq = *reinterpret_cast<const v4f*>(&b.tile[1][row][4 * half]);
+        v4f ai = *reinterpret_cast<const v4f*>(&b.tile[2][row][4 * half]);
+#pragma unroll
+        for (int ts = 0; ts < T_STEPS; ++ts) {
+            v4f z[4];
+            z[0] = au * aq;
+            z[1] = aq * ai;
+            z[2] = ai * au;
+            z[3] = z[0] * ai;
+            if (ts + 1 < T_STEPS) {
+                const int col = 8 * (ts + 1) + 4 * half;
+                au = *reinterpret_cast<const v4f*>(&b.tile[0][row][col]);
+                aq = *reinterpret_cast<const v4f*>(&b.tile[1][row][col]);
+                ai = *reinterpret_cast<const v4f*>(&b.tile[2][row][col]);
+            }
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z[bk][s2], wreg[bk][ts][s2], acc, 0, 0, 0);
+        }
+        // epilogue: all 16 first-order sums are read from LDS in one batch, then added and stored
+        const int64_t e_base = t * S::TE;
+        float first[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) first[r] = b.psum[et * 32 + acc_row(r, lane)][j];
+        float* orow = out + (e_base + et * 32) * ld_out + j;
+        if (e_base + S::TE <= n_edges) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[r] + first[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (e_base + et * 32 + acc_row(r, lane) < n_edges) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[r] + first[r];
+        }
+    }
+}
+
+template <int D, int NBLK>
+__global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g, int64_t n_edges) {
+    static_assert(D == 32 || D == 64, "wave-specialised form stages whole rows");
+    constexpr int ET = D == 32 ? 4 : 2, TE = ET * 32, STRIDE = D + kRowPad, V4 = D / 4, T_STEPS = D / 8;
+    constexpr int DL = TE * V4 / kBlockThreads, HL = 3 * DL;
+    struct Buffer {
+        float dtile[TE][STRIDE];
+        float htile[3][TE][D];
+    };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    if (wave >= 4) {
+        // loaders: deposit rows(T) -> issue rows(T+g) with ids fetched a trip ago -> issue ids(T+2g) -> barrier
+        const int tid = threadIdx.x - kBlockThreads;
+        const int64_t g = gridDim.x;
+        v4f dr[DL], hr[HL];
+        int node[HL], node_next[HL];
+        auto load_ids = [&](int64_t tile_id, int (&dst)[HL]) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + (idx / V4) % TE;
+                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * TE)] : 0;
+            }
+        };
+        auto issue_rows = [&](int64_t tile_id, const int (&src)[HL]) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + idx / V4;
+                dr[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + (idx % V4) * 4);
+            }
+        };
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) {
+            load_ids(t, node);
+            issue_rows(t, node);
+        }
+        if (t + g < n_tiles) load_ids(t + g, node_next);
+        int which = 0;
+        while (t < n_tiles) {
+            Buffer& b = buf[which];
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.dtile[idx / V4][(idx % V4) * 4]) = dr[x];
+            }
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.htile[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hr[x];
+            }
+            if (t + g < n_tiles) issue_rows(t + g, node_next);
+            if (t + 2 * g < n_tiles) load_ids(t + 2 * g, node_next);
+            __syncthreads();
+            t += g;
+            which ^= 1;
+        }
+        return;
+    }
+    const int et = wave % ET, ct = wave / ET;
+    const int row = et * 32 + (lane & 31), half = lane >> 5;
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wq) + static_cast<int64_t>(ct) * NBLK * T_STEPS * kWave + lane;
+    v4f wreg[NBLK][T_STEPS];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int ts = 0; ts < T_STEPS; ++ts) wreg[b][ts] = wfrag[(b * T_STEPS + ts) * kWave];
+    const int c = ct * 32 + (lane & 31);
+    int which = 0;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
+        __syncthreads();
+        const Buffer& b = buf[which];
+        v16f acc[NBLK];
+#pragma unroll
+        for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[bk][r] = 0.f;
+        v4f a = *reinterpret_cast<const v4f*>(&b.dtile[row][4 * half]);
+#pragma unroll
+        for (int ts = 0; ts < T_STEPS; ++ts) {
+            const v4f a_now = a;
+            if (ts + 1 < T_STEPS) a = *reinterpret_cast<const v4f*>(&b.dtile[row][8 * (ts + 1) + 4 * half]);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_now[s2], wreg[bk][ts][s2], acc[bk], 0, 0, 0);
+        }
+        // epilogue in batches of four rows: 12 LDS reads in flight, then the product rule and 12 stores
+        const int64_t e_base = t * TE;
+        const bool full = e_base + TE <= n_edges;
+        float* gbase = g + (e_base + et * 32) * 3 * D + c;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+            float hu[4], hq[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int er = et * 32 + acc_row(r0 + k, lane);
+                hu[k] = b.htile[0][er][c];
+                hq[k] = b.htile[1][er][c];
+                hi[k] = b.htile[2][er][c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = r0 + k;
+                const float z_uq = acc[0][r], z_qi = acc[1][r], z_iu = acc[2][r];
+                const float z_uqi = NBLK == 4 ? acc[NBLK - 1][r] : 0.f;
+                const float gu = z_uq * hq[k] + z_iu * hi[k] + z_uqi * (hq[k] * hi[k]);
+                const float gq = z_uq * hu[k] + z_qi * hi[k] + z_uqi * (hu[k] * hi[k]);
+                const float gi = z_qi * hq[k] + z_iu * hu[k] + z_uqi * (hu[k] * hq[k]);
+                if (full || e_base + et * 32 + acc_row(r, lane) < n_edges) {
+                    float* ge = gbase + static_cast<int64_t>(acc_row(r, lane)) * 3 * D;
+                    ge[0] = gu;
+                    ge[D] = gq;
+                    ge[2 * D] = gi;
+                }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised member-gradient kernel for D = 128.  The weight fragments no longer fit in registers (512 VGPRs), so the
+// consumers stream them from L2 (packed, two k-steps ahead) while the loaders stream the dout rows into a double-buffered LDS
+// image; the member values of the product rule are requested by the consumers right behind the first fragments of a job, so
+// they arrive under the MFMAs.  (A chunked wave-specialised FORWARD for D = 128 was built and measured equal to the plain
+// MFMA tiling - 3.45 vs 3.41 ms at E = 2.2 M - so the forward keeps the plain kernel at this width.)
+// ------------------------------------------------------------------------------------------------
+template <int D, int NBLK>
+__global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_wsbig_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g_out, int64_t n_edges) {
+    static_assert(D == 128, "chunked wave-specialised form");
+    constexpr int TE = 64, STRIDE = D + kRowPad, V4 = D / 4, DL = TE * V4 / kBlockThreads, T_STEPS = D / 8, JOBS = 2 * (D / 32);
+    __shared__ __attribute__((aligned(16))) float dtile[2][TE][STRIDE];
+    __shared__ int ids[2][TE][3];
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t g = gridDim.x;
+
+    if (wave >= 4) {
+        // loaders: the dout rows are a plain stream; one tile of lead in registers
+        const int tid = threadIdx.x - kBlockThreads;
+        v4f dr[DL];
+        int my_id = 0;
+        auto issue = [&](int64_t tile_id) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + idx / V4;
+                dr[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+            const int64_t pos = e_base * 3 + tid;
+            my_id = (tid < TE * 3 && pos < n_edges * 3) ? i3[pos] : 0;
+        };
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) issue(t);
+        int which = 0;
+        while (t < n_tiles) {
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&dtile[which][idx / V4][(idx % V4) * 4]) = dr[x];
+            }
+            if (tid < TE * 3) (&ids[which][0][0])[tid] = my_id;
+            if (t + g < n_tiles) issue(t + g);
+            __syncthreads();
+            t += g;
+            which ^= 1;
+        }
+        return;
+    }
+    const int half = lane >> 5;
+    const v4f* wq4 = reinterpret_cast<const v4f*>(wq) + lane;
+    int which = 0;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += g, which ^= 1) {
+        __syncthreads();
+        const int64_t e_base = t * TE;
+        const bool full = e_base + TE <= n_edges;
+        for (int job = wave; job < JOBS; job += 4) {
+            const int et = job & 1, ct = job >> 1;
+            const int row = et * 32 + (lane & 31);
+            const int c = ct * 32 + (lane & 31);
+            v16f acc[NBLK];
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[bk][r] = 0.f;
+            // weight fragments two k-steps ahead; the member values of the epilogue are requested right behind the first two
+            // fragment sets, so they arrive under the MFMAs instead of in front of the stores
+            v4f b0[NBLK], b1[NBLK], b2[NBLK];
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk) {
+                b0[bk] = wq4[(static_cast<int64_t>(ct * NBLK + bk) * T_STEPS + 0) * kWave];
+                b1[bk] = wq4[(static_cast<int64_t>(ct * NBLK + bk) * T_STEPS + 1) * kWave];
+            }
+            float hu[16], hq[16], hi[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int er = et * 32 + acc_row(r, lane);
+                hu[r] = h[static_cast<int64_t>(ids[which][er][0]) * ld_h + c];
+                hq[r] = h[static_cast<int64_t>(ids[which][er][1]) * ld_h + c];
+                hi[r] = h[static_cast<int64_t>(ids[which][er][2]) * ld_h + c];
+            }
+#pragma unroll
+            for (int ts = 0; ts < T_STEPS; ++ts) {
+                if (ts + 2 < T_STEPS) {
+#pragma unroll
+                    for (int bk = 0; bk < NBLK; ++bk) b2[bk] = wq4[(static_cast<int64_t>(ct * NBLK + bk) * T_STEPS + ts + 2) * kWave];
+                }
+                const v4f a = *reinterpret_cast<const v4f*>(&dtile[which][row][8 * ts + 4 * half]);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b0[bk][s2], acc[bk], 0, 0, 0);
+#pragma unroll
+                for (int bk = 0; bk < NBLK; ++bk) {
+                    b0[bk] = b1[bk];
+                    b1[bk] = b2[bk];
+                }
+            }
+            float* gbase = g_out + (e_base + et * 32) * 3 * D + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float z_uq = acc[0][r], z_qi = acc[1][r], z_iu = acc[2][r];
+                const float z_uqi = NBLK == 4 ? acc[NBLK - 1][r] : 0.f;
+                if (full || e_base + et * 32 + acc_row(r, lane) < n_edges) {
+                    float* ge = gbase + static_cast<int64_t>(acc_row(r, lane)) * 3 * D;
+                    ge[0] = z_uq * hq[r] + z_iu * hi[r] + z_uqi * (hq[r] * hi[r]);
+                    ge[D] = z_uq * hu[r] + z_qi * hi[r] + z_uqi * (hu[r] * hi[r]);
+                    ge[2 * D] = z_qi * hq[r] + z_iu * hu[r] + z_uqi * (hu[r] * hq[r]);
+                }
+            }
+        }
+    }
+}
+
+// dW, same roles: workgroup (x, y) owns the 64 x 64 x NBLK sub-block y = (js, cs) of the d x NBLK*d gradient (d a multiple of 64)
+// for the hyperedge tiles x, x + gridDim.x, ...; its loaders fetch the matching 64-column slices of dout and of the member rows.
+template <int NBLK>
+__global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ dout, int64_t ld_dout,
+    float* __restrict__ slabs, int64_t n_edges, int d) {
+    constexpr int D = 64, TE = 64, V4 = D / 4, DL = TE * V4 / kBlockThreads, HL = 3 * DL;
+    struct Buffer {
+        float dtile[TE][D];
+        float mtile[3][TE][D];
+    };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int subs = d / D;
+    const int js = blockIdx.y / subs, cs = blockIdx.y % subs;
+
+    if (wave >= 4) {
+        // loaders: deposit rows(T) -> issue rows(T+g) with ids fetched a trip ago -> issue ids(T+2g) -> barrier
+        const int tid = threadIdx.x - kBlockThreads;
+        const int64_t g = gridDim.x;
+        v4f dr[DL], hr[HL];
+        int node[HL], node_next[HL];
+        auto load_ids = [&](int64_t tile_id, int (&dst)[HL]) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + (idx / V4) % TE;
+                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * TE)] : 0;
+            }
+        };
+        auto issue_rows = [&](int64_t tile_id, const int (&src)[HL]) {
+            const int64_t e_base = tile_id * TE;
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int64_t e = e_base + idx / V4;
+                dr[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + js * D + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + cs * D + (idx % V4) * 4);
+            }
+        };
+        int64_t t = blockIdx.x;
+        if (t < n_tiles) {
+            load_ids(t, node);
+            issue_rows(t, node);
+        }
+        if (t + g < n_tiles) load_ids(t + g, node_next);
+        int which = 0;
+        while (t < n_tiles) {
+            Buffer& b = buf[which];
+#pragma unroll
+            for (int x = 0; x < DL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.dtile[idx / V4][(idx % V4) * 4]) = dr[x];
+            }
+#pragma unroll
+            for (int x = 0; x < HL; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&b.mtile[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hr[x];
+            }
+            if (t + g < n_tiles) issue_rows(t + g, node_next);
+            if (t + 2 * g < n_tiles) load_ids(t + 2 * g, node_next);
+            __syncthreads();
+            t += g;
+            which ^= 1;
+        }
+        return;
+    }
+    const int half = lane >> 5, l31 = lane & 31;
+    const int jt = wave & 1, ct = wave >> 1;
+    v16f acc[NBLK];
+#pragma unroll
+    for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[bk][r] = 0.f;
+    int which = 0;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
+        __syncthreads();
+        const Buffer& b = buf[which];
+#pragma unroll 8
+        for (int kk = 0; kk < TE / 2; ++kk) {
+            const int e = 2 * kk + half;
+            const float a = b.dtile[e][jt * 32 + l31];
+            const float hu = b.mtile[0][e][ct * 32 + l31], hq = b.mtile[1][e][ct * 32 + l31], hi = b.mtile[2][e][ct * 32 + l31];
+            float z[4];
+            z[0] = hu * hq;
+            z[1] = hq * hi;
+            z[2] = hi * hu;
+            z[3] = z[0] * hi;
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z[bk], acc[bk], 0, 0, 0);
+        }
+    }
+    float* slab = slabs + static_cast<int64_t>(blockIdx.x) * d * NBLK * d;          // slab x: a full [d][NBLK*d] matrix
+#pragma unroll
+    for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            slab[static_cast<int64_t>(js * D + jt * 32 + acc_row(r, lane)) * NBLK * d + bk * d + cs * D + ct * 32 + l31] = acc[bk][r];
+}
+
+// weights: workgroup (x, y) owns the SW x (NBLK*SW) sub-block y = (js, cs) of dW for the hyperedge tiles x, x + gridDim.x, ...
+// and keeps it in MFMA accumulators for the whole sweep (contraction index = hyperedge, 2 per MFMA); it ends by writing
+// its partial sub-block into slab x, and slab_reduce_kernel adds the slabs in a fixed order (bitwise reproducible).
+// Software pipeline: the rows of tile n+1 are fetched into registers while tile n is multiplied out of LDS, so the
+// gather latency (ids -> rows, two dependent trips) hides behind 32 MFMA steps.
+template <int SW, int NBLK>
+__global__ __launch_bounds__(kBlockThreads, 2) void interact_bwd_weight_mfma_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ dout, int64_t ld_dout,
+    float* __restrict__ slabs, int64_t n_edges, int d) {
+    constexpr int TE = 64;
+    constexpr int WT = SW / 32;                       // 32-wide tiles per side of the sub-block (2 for SW = 64, 1 for 32)
+    constexpr int TILES = WT * WT * NBLK;             // accumulator tiles of the sub-block
+    constexpr int PER_WAVE = (TILES + kWavesPerBlock - 1) / kWavesPerBlock;
+    constexpr int V4_PER_ROW = SW / 4;
+    constexpr int D_LOADS = TE * V4_PER_ROW / kBlockThreads;          // dout tile float4s per thread
+    constexpr int M_LOADS = 3 * TE * V4_PER_ROW / kBlockThreads;      // member-row float4s per thread
+    __shared__ __attribute__((aligned(16))) float dtile[TE][SW];
+    __shared__ __attribute__((aligned(16))) float mtile[3][TE][SW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int subs = d / SW;
+    const int js = blockIdx.y / subs, cs = blockIdx.y % subs;
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    // wave -> (jt, ct) pair, all NBLK blocks (SW = 64: 4 pairs, one per wave); SW = 32: one pair, block b = wave
+    const int jt = WT == 2 ? (wave & 1) : 0, ct = WT == 2 ? (wave >> 1) : 0;
+    v16f acc[PER_WAVE];
+#pragma unroll
+    for (int x = 0; x < PER_WAVE; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    v4f dreg[D_LOADS], mreg[M_LOADS];
+    int64_t cur = -1, nxt = blockIdx.x;
+    while (true) {
+        if (cur >= 0) {
+            __syncthreads();                              // everyone is done reading the previous tile
+#pragma unroll
+            for (int x = 0; x < D_LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&dtile[idx / V4_PER_ROW][(idx % V4_PER_ROW) * 4]) = dreg[x];
+            }
+#pragma unroll
+            for (int x = 0; x < M_LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                *reinterpret_cast<v4f*>(&mtile[idx / (V4_PER_ROW * TE)][(idx / V4_PER_ROW) % TE][(idx % V4_PER_ROW) * 4]) = mreg[x];
+            }
+            __syncthreads();
+        }
+        const bool have_next = nxt < n_tiles;
+        if (have_next) {                                  // the one fetch site: rows of tile `nxt` -> registers
+            const int64_t e_base = nxt * TE;
+#pragma unroll
+            for (int x = 0; x < D_LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4_PER_ROW, r = idx / V4_PER_ROW;
+                const int64_t e = e_base + r;
+                dreg[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + js * SW + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int x = 0; x < M_LOADS; ++x) {
+                const int idx = tid + kBlockThreads * x;
+                const int c4 = idx % V4_PER_ROW, r = (idx / V4_PER_ROW) % TE, m = idx / (V4_PER_ROW * TE);
+                const int64_t e = e_base + r;
+                const int64_t node = e < n_edges ? i3[e * 3 + m] : 0;
+                mreg[x] = *reinterpret_cast<const v4f*>(h + node * ld_h + cs * SW + c4 * 4);
+            }
+        }
+        if (cur >= 0) {
+#pragma unroll 4
+            for (int kk = 0; kk < TE / 2; ++kk) {
+                const int e = 2 * kk + half;
+                const float a = dtile[e][jt * 32 + l31];
+                const float hu = mtile[0][e][ct * 32 + l31], hq = mtile[1][e][ct * 32 + l31], hi = mtile[2][e][ct * 32 + l31];
+                float z[4];
+                z[0] = hu * hq;
+                z[1] = hq * hi;
+                z[2] = hi * hu;
+                z[3] = z[0] * hi;
+                if (WT == 2) {
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z[b], acc[b], 0, 0, 0);
+                } else {
+                    const float zb = wave == 0 ? z[0] : wave == 1 ? z[1] : wave == 2 ? z[2] : z[3];
+                    if (wave < NBLK) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, zb, acc[0], 0, 0, 0);
+                }
+            }
+        }
+        if (!have_next) break;
+        cur = nxt;
+        nxt += gridDim.x;
+    }
+    // slab[x] is a full [d][NBLK*d] matrix; element (j, b*d + c)
+    float* slab = slabs + static_cast<int64_t>(blockIdx.x) * d * NBLK * d;
+#pragma unroll
+    for (int x = 0; x < PER_WAVE; ++x) {
+        const int b = WT == 2 ? x : wave;
+        if (b >= NBLK) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = js * SW + jt * 32 + acc_row(r, lane);
+            const int c = cs * SW + ct * 32 + l31;
+            slab[static_cast<int64_t>(j) * NBLK * d + b * d + c] = acc[x][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int d, int nblk,
+                                                                    float* __restrict__ dw, int64_t ld_dw) {
+    const int width = nblk * d;
+    const int64_t total = static_cast<int64_t>(d) * width;
+    for (int64_t base = static_cast<int64_t>(blockIdx.x) * kWave; base < total; base += static_cast<int64_t>(gridDim.x) * kWave) {
+        const int64_t idx = base + (threadIdx.x & 63);
+        const float acc = slab_sum(slabs, n_slabs, total, idx, idx < total);
+        if ((threadIdx.x >> 6) == 0 && idx < total) {
+            const int j = static_cast<int>(idx / width), col = static_cast<int>(idx - static_cast<int64_t>(j) * width);
+            dw[static_cast<int64_t>(j) * ld_dw + 3 * static_cast<int64_t>(d) + col] = acc;
+        }
+    }
+}
+
+inline int64_t packed_weight_floats(int dim, int order) { return static_cast<int64_t>(order == 3 ? 4 : 3) * dim * dim; }
+inline int weight_slabs(int dim) {
+    const int subs = dim >= 64 ? (dim / 64) * (dim / 64) : 1;
+    int n = 512 / subs;
+    return n < 8 ? 8 : n;
+}
+constexpr int kFwdGrid = 256 * 3;
+constexpr int kPipeGrid = 256;          // wave-specialised kernels: one 512-thread workgroup per CU
+
+
+template <int NBLK>
+void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* wp,
+                              float* out, int64_t ld_out, int64_t n_edges, hipStream_t s) {
+#define IHG_FWD(D)                                                                                                          \
+    {                                                                                                                       \
+        const int64_t tiles = (n_edges + TileShape<D>::TE - 1) / TileShape<D>::TE;                                          \
+        const int grid = static_cast<int>(std::min<int64_t>(tiles, kFwdGrid));                                              \
+        hipLaunchKernelGGL((interact_fwd_mfma_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges); \
+    }
+#define IHG_FWD_PIPE(D)                                                                                                     \
+    {                                                                                                                       \
+        const int64_t tiles = (n_edges + TileShape<D>::TE - 1) / TileShape<D>::TE;                                          \
+        const int grid = static_cast<int>(std::min<int64_t>(tiles, kPipeGrid));                                             \
+        hipLaunchKernelGGL((interact_fwd_ws_kernel<D, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges); \
+    }
+    switch (dim) {
+        case 32: IHG_FWD_PIPE(32) break;
+        case 64: IHG_FWD_PIPE(64) break;
+        case 128: IHG_FWD(128) break;
+        default: IHG_FWD(256) break;
+    }
+#undef IHG_FWD
+#undef IHG_FWD_PIPE
+}
+
+template <int NBLK>
+void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* wq, const float* dout, int64_t ld_dout,
+                              float* g, float* slabs, float* dw, int64_t ld_dw, int64_t n_edges, hipStream_t s) {
+#define IHG_MEM(D)                                                                                                          \
+    {                                                                                                                       \
+        constexpr int TE = D == 32 ? 128 : 64;                                                                              \
+        const int grid = static_cast<int>(std::min<int64_t>((n_edges + TE - 1) / TE, kFwdGrid));                            \
+        hipLaunchKernelGGL((interact_bwd_members_mfma_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
+    }
+#define IHG_MEM_PIPE(D)                                                                                                     \
+    {                                                                                                                       \
+        constexpr int TE = D == 32 ? 128 : 64;                                                                              \
+        const int grid = static_cast<int>(std::min<int64_t>((n_edges + TE - 1) / TE, kPipeGrid));                           \
+        hipLaunchKernelGGL((interact_bwd_members_ws_kernel<D, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
+    }
+    switch (dim) {
+        case 32: IHG_MEM_PIPE(32) break;
+        case 64: IHG_MEM_PIPE(64) break;
+        case 128: {
+            const int grid = static_cast<int>(std::min<int64_t>((n_edges + 63) / 64, kPipeGrid));
+            hipLaunchKernelGGL((interact_bwd_members_wsbig_kernel<128, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges);
+        } break;
+        default: IHG_MEM(256) break;
+    }
+#undef IHG_MEM
+#undef IHG_MEM_PIPE
+    const int subs_ws = (dim / 64) * (dim / 64);
+    const int n_slabs = static_cast<int>(std::min<int64_t>(dim >= 64 ? std::max(kPipeGrid / subs_ws, 8) : weight_slabs(dim), (n_edges + 63) / 64));
+    if (dim >= 64) {
+        hipLaunchKernelGGL((interact_bwd_weight_ws_kernel<NBLK>), dim3(n_slabs, subs_ws), dim3(kWsThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
+    } else {
+        hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<32, NBLK>), dim3(n_slabs, 1), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
+    }
+    const int total = dim * NBLK * dim;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, n_slabs, dim, NBLK, dw, ld_dw);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ihg_interact_fwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order) {
+    (void)n_edges;
+    if (!mfma_dim(dim) || (order != 2 && order != 3)) return 0;
+    return packed_weight_floats(dim, order) * static_cast<int64_t>(sizeof(float));
+}
+
+int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w,
+                     int32_t order, float* out, int64_t ld_out, void* workspace, int64_t workspace_bytes, int64_t n_edges,
+                     int32_t dim, ihg_stream_t stream) {
+    if (order != 2 && order != 3) return fail(IHG_ERR_INVALID, "ihg_interact_fwd: order must be 2 or 3, got %d", order);
+    const int k = order == 3 ? 7 : 6;
+    if (n_edges < 0 || dim <= 0 || ld_h < dim || ld_out < dim || ld_w < static_cast<int64_t>(k) * dim || (p != nullptr && ld_p < dim))
+        return fail(IHG_ERR_INVALID, "ihg_interact_fwd: bad size");
+    if (n_edges == 0) return IHG_OK;
+    if (h == nullptr || i3 == nullptr || w == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_interact_fwd: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool tiled = mfma_dim(dim) && p != nullptr && ld_h % 4 == 0 && ld_w % 4 == 0 && aligned16(h) && aligned16(w) && workspace != nullptr &&
+                       aligned16(workspace);
+    if (tiled) {
+        if (workspace_bytes < ihg_interact_fwd_workspace_bytes(n_edges, dim, order)) return fail(IHG_ERR_WORKSPACE, "ihg_interact_fwd: workspace too small");
+        float* wp = static_cast<float*>(workspace);
+        const int nblk = order == 3 ? 4 : 3;
+        const int pack_items = (dim / 32) * nblk * (dim / 8) * kWave;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wp,
+                           static_cast<float*>(nullptr));
+        if (nblk == 4) launch_interact_fwd_mfma<4>(dim, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges, s);
+        else launch_interact_fwd_mfma<3>(dim, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges, s);
+        return check_launch("ihg_interact_fwd");
+    }
+    const int64_t total = n_edges * dim;
+    const int grid = static_cast<int>(std::min<int64_t>((total + kBlockThreads - 1) / kBlockThreads, kMaxBlocks * 4));
+    hipLaunchKernelGGL(interact_fwd_generic_kernel, dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, p, ld_p, i3, w, ld_w, order, out, ld_out, n_edges, dim);
+    return check_launch("ihg_interact_fwd");
+}
+
+int64_t ihg_interact_bwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order) {
+    (void)n_edges;
+    if (!mfma_dim(dim) || (order != 2 && order != 3)) return 0;
+    const int64_t w_floats = packed_weight_floats(dim, order);
+    return (w_floats + static_cast<int64_t>(weight_slabs(dim)) * w_floats) * static_cast<int64_t>(sizeof(float));
+}
+
+int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
+                     const float* dout, int64_t ld_dout, float* g, float* dw, int64_t ld_dw, void* workspace,
+                     int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream) {
+    if (order != 2 && order != 3) return fail(IHG_ERR_INVALID, "ihg_interact_bwd: order must be 2 or 3, got %d", order);
+    const int k = order == 3 ? 7 : 6;
+    if (n_edges < 0 || dim <= 0 || ld_h < dim || ld_dout < dim || ld_w < static_cast<int64_t>(k) * dim || ld_dw < static_cast<int64_t>(k) * dim)
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd: bad size");
+    if (h == nullptr || i3 == nullptr || w == nullptr || dout == nullptr || g == nullptr || dw == nullptr)
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool tiled = mfma_dim(dim) && n_edges > 0 && ld_h % 4 == 0 && ld_w % 4 == 0 && ld_dout % 4 == 0 && aligned16(h) && aligned16(w) &&
+                       aligned16(dout) && workspace != nullptr && aligned16(workspace);
+    if (tiled) {
+        if (workspace_bytes < ihg_interact_bwd_workspace_bytes(n_edges, dim, order)) return fail(IHG_ERR_WORKSPACE, "ihg_interact_bwd: workspace too small");
+        const int nblk = order == 3 ? 4 : 3;
+        float* wq = static_cast<float*>(workspace);
+        float* slabs = wq + packed_weight_floats(dim, order);
+        const int pack_items = (dim / 32) * nblk * (dim / 8) * kWave;
+        hipLaunchKernelGGL(pack_weights_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk,
+                           static_cast<float*>(nullptr), wq);
+        if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s);
+        else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s);
+        return check_launch("ihg_interact_bwd");
+    }
+    if (n_edges > 0) {
+        const int64_t total = n_edges * dim;
+        const int grid = static_cast<int>(std::min<int64_t>((total + kBlockThreads - 1) / kBlockThreads, kMaxBlocks * 4));
+        hipLaunchKernelGGL(interact_bwd_members_generic_kernel, dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, w, ld_w, order, dout, ld_dout, g, n_edges, dim);
+    }
+    const int64_t wtotal = static_cast<int64_t>(dim) * (order == 3 ? 4 : 3) * dim;
+    const int wgrid = static_cast<int>(std::min<int64_t>((wtotal + kBlockThreads - 1) / kBlockThreads, kMaxBlocks * 4));
+    hipLaunchKernelGGL(interact_bwd_weight_generic_kernel, dim3(wgrid), dim3(kBlockThreads), 0, s, h, ld_h, i3, order, dout, ld_dout, dw, ld_dw, n_edges, dim);
+    return check_launch("ihg_interact_bwd");
+}
+
+}  // extern "C"

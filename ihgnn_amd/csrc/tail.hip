@@ -1,0 +1,223 @@
+// tail.hip - the batch tail: HEM scores straight from the layer outputs, BCE-with-logits, per-row gradients and the
+// deterministic sort-free scatter of duplicate rows.
+#include "common.hpp"
+
+namespace {
+
+// ================================================================================================
+// Batch tail (HEM scoring head over the concatenated layer outputs, Models/PredictionLayers.py:21-44 after
+// Models/RawGnn.py:122-131): one wave per batch row, lanes over the columns of every layer output; no [N, D] concat.
+//   fwd  score[r] = sum_l sum_c X_l[item_r][c] * (lam * X_l[query_r][c] + (1 - lam) * X_l[user_r][c]) + bias[item_r]
+//   bwd  rowgrad[0B + r] = ds (1 - lam) X[item_r]   (w.r.t. the user row),   rowgrad[1B + r] = ds lam X[item_r]   (query row),
+//        rowgrad[2B + r] = ds (lam X[query_r] + (1 - lam) X[user_r])   (item row); [3B, L1*d] dense and conflict-free -
+//        the caller adds duplicate rows with one deterministic scatter.
+// ================================================================================================
+struct LayerPtrs {
+    const float* x[8];
+};
+
+__global__ __launch_bounds__(kBlockThreads) void hem_score_fwd_kernel(LayerPtrs layers, int n_layers, int64_t ld, int dim,
+                                                                      const int64_t* __restrict__ rows, const int64_t* __restrict__ items,
+                                                                      const float* __restrict__ bias, float lam, float* __restrict__ scores,
+                                                                      int64_t batch) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = global_wave_id(); r < batch; r += global_wave_count()) {
+        const int64_t u = rows[r], q = rows[batch + r], it = rows[2 * batch + r];
+        float acc = 0.f;
+        for (int l = 0; l < n_layers; ++l) {
+            const float* x = layers.x[l];
+            for (int c = lane; c < dim; c += kWave) {
+                const float m = lam * x[q * ld + c] + (1.f - lam) * x[u * ld + c];
+                acc += x[it * ld + c] * m;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) scores[r] = acc + bias[items[r]];
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs layers, int n_layers, int64_t ld, int dim,
+                                                                      const int64_t* __restrict__ rows, const float* __restrict__ dscores,
+                                                                      float grad_scale, float lam, float* __restrict__ rowgrad, int64_t width,
+                                                                      int64_t batch) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = global_wave_id(); r < batch; r += global_wave_count()) {
+        const int64_t u = rows[r], q = rows[batch + r], it = rows[2 * batch + r];
+        const float ds = dscores[r] * grad_scale;
+        if (lane == 0 && width > static_cast<int64_t>(n_layers) * dim) {       // optional extra column: d bias, carried by the item row
+            const int64_t col = static_cast<int64_t>(n_layers) * dim;
+            rowgrad[r * width + col] = 0.f;
+            rowgrad[(batch + r) * width + col] = 0.f;
+            rowgrad[(2 * batch + r) * width + col] = ds;
+        }
+        for (int l = 0; l < n_layers; ++l) {
+            const float* x = layers.x[l];
+            for (int c = lane; c < dim; c += kWave) {
+                const float xu = x[u * ld + c], xq = x[q * ld + c], xi = x[it * ld + c];
+                const int64_t col = static_cast<int64_t>(l) * dim + c;
+                rowgrad[r * width + col] = ds * (1.f - lam) * xi;
+                rowgrad[(batch + r) * width + col] = ds * lam * xi;
+                rowgrad[(2 * batch + r) * width + col] = ds * (lam * xq + (1.f - lam) * xu);
+            }
+        }
+    }
+}
+
+
+
+constexpr int kScatterThreads = 1024;
+
+// Mean binary cross-entropy with logits over a batch and its gradient, one workgroup, fixed reduction tree
+// (nn.BCEWithLogitsLoss(), Main.py:191): loss = mean(max(s,0) - s*y + log1p(exp(-|s|))), dscores = (sigmoid(s) - y) / n.
+__global__ __launch_bounds__(kScatterThreads) void bce_with_logits_kernel(const float* __restrict__ scores, const float* __restrict__ labels, int n,
+                                                                          float* __restrict__ loss, float* __restrict__ dscores) {
+    __shared__ float part[kScatterThreads];
+    float acc = 0.f;
+    const float inv_n = 1.f / static_cast<float>(n);
+    for (int k = threadIdx.x; k < n; k += kScatterThreads) {
+        const float sc = scores[k], y = labels[k];
+        const float e = expf(-fabsf(sc));
+        acc += fmaxf(sc, 0.f) - sc * y + log1pf(e);
+        const float sig = sc >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        dscores[k] = (sig - y) * inv_n;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = kScatterThreads / 2; off > 0; off >>= 1) {
+        if (static_cast<int>(threadIdx.x) < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = part[0] * inv_n;
+}
+
+// Deterministic scatter-add of a small batch of rows into a large dense matrix: dense[rows[k], :] += rowgrad[k, :], duplicates
+// summed in batch order, no atomics, no sort.  One wave per batch position k: it scans rows[0..k) for an earlier occurrence of
+// its destination (ballot over 64 ids at a time; the id array is a few KB and cache-resident) and retires if there is one;
+// otherwise it is the leader of that destination, walks rows[k..n) in order and adds every matching batch row, then writes the
+// destination row once.  O(n^2 / 64) wave-steps in total - microseconds for the few thousand rows of a training batch; replaces
+// index_put_(accumulate=True) (bounds checks, device radix sort, scatter kernel).
+constexpr int kScatterMax = 16384;
+
+// Destination addressing: column c of batch row k goes to dense[(c / block_width) * block_stride + row * ld_dense + c % block_width]
+// (block_width = width, block_stride = 0 is a plain matrix; block_width = d, block_stride = N*d lands layer l's columns in its own
+// contiguous [N, d] matrix); an optional last column goes to tail[row - tail_row_offset] (the bias gradient).
+__global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(const float* __restrict__ rowgrad, int64_t ld_rowgrad, int width,
+                                                                      const int64_t* __restrict__ rows, int n, float* __restrict__ dense,
+                                                                      int64_t ld_dense, int block_width, int64_t block_stride,
+                                                                      float* __restrict__ tail, int64_t tail_row_offset, int64_t tail_rows) {
+    __shared__ int32_t key[kScatterMax];                    // every workgroup keeps the whole id list in LDS (<= 64 KiB)
+    for (int k = threadIdx.x; k < n; k += kBlockThreads) key[k] = static_cast<int32_t>(rows[k]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int64_t k = global_wave_id(); k < n; k += global_wave_count()) {
+        const int32_t mine = key[k];
+        bool follower = false;
+        for (int base = 0; base < k; base += kWave) {
+            const int j = base + lane;
+            if (__ballot(j < k && key[j] == mine) != 0ull) { follower = true; break; }
+        }
+        if (follower) continue;
+        for (int c0 = 0; c0 < width; c0 += 4 * kWave) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int base = static_cast<int>(k) & ~(kWave - 1); base < n; base += kWave) {
+                const int j = base + lane;
+                unsigned long long mask = __ballot(j >= k && j < n && key[j] == mine);
+                while (mask != 0ull) {
+                    // up to 16 members per trip: all their loads are issued before the first add (a hot destination - a
+                    // popular query - can own hundreds of batch rows); absent slots add an exact 0
+                    constexpr int MEMBERS = 16;
+                    float v[MEMBERS][4];
+#pragma unroll
+                    for (int u = 0; u < MEMBERS; ++u) {
+                        const bool have = mask != 0ull;
+                        const int bit = have ? __ffsll(static_cast<long long>(mask)) - 1 : 0;
+                        if (have) mask &= mask - 1;
+                        const float* src = rowgrad + static_cast<int64_t>(base + bit) * ld_rowgrad;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = c0 + q * kWave + lane;
+                            v[u][q] = (have && c < width) ? src[c] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < MEMBERS; ++u)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] += v[u][q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + q * kWave + lane;
+                if (c >= width) continue;
+                if (tail != nullptr && c == width - 1) {
+                    const int64_t tr = static_cast<int64_t>(mine) - tail_row_offset;
+                    if (tr >= 0 && tr < tail_rows) tail[tr] += acc[q];
+                } else {
+                    dense[(c / block_width) * block_stride + static_cast<int64_t>(mine) * ld_dense + c % block_width] += acc[q];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+static int hem_common_check(const char* what, const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const int64_t* rows, int64_t batch) {
+    if (n_layers < 1 || n_layers > 8) return fail(IHG_ERR_INVALID, "%s: 1..8 layer outputs supported, got %d", what, n_layers);
+    if (layers == nullptr || rows == nullptr || dim <= 0 || ld < dim || batch < 0) return fail(IHG_ERR_INVALID, "%s: bad argument", what);
+    for (int l = 0; l < n_layers; ++l)
+        if (layers[l] == nullptr) return fail(IHG_ERR_INVALID, "%s: null layer pointer", what);
+    return IHG_OK;
+}
+
+int ihg_hem_score_fwd(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const int64_t* rows, const int64_t* items,
+                      const float* bias, float lambda_muq, float* scores, int64_t batch, ihg_stream_t stream) {
+    if (int rc = hem_common_check("ihg_hem_score_fwd", layers, n_layers, ld, dim, rows, batch)) return rc;
+    if (batch == 0) return IHG_OK;
+    if (items == nullptr || bias == nullptr || scores == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd: null pointer");
+    LayerPtrs lp{};
+    for (int l = 0; l < n_layers; ++l) lp.x[l] = layers[l];
+    hipLaunchKernelGGL(hem_score_fwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers, ld,
+                       dim, rows, items, bias, lambda_muq, scores, batch);
+    return check_launch("ihg_hem_score_fwd");
+}
+
+int ihg_hem_score_bwd(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const int64_t* rows, const float* dscores,
+                      float grad_scale, float lambda_muq, float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream) {
+    if (int rc = hem_common_check("ihg_hem_score_bwd", layers, n_layers, ld, dim, rows, batch)) return rc;
+    if (batch == 0) return IHG_OK;
+    if (dscores == nullptr || rowgrad == nullptr || ld_rowgrad < static_cast<int64_t>(n_layers) * dim) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd: null pointer or short row stride");
+    LayerPtrs lp{};
+    for (int l = 0; l < n_layers; ++l) lp.x[l] = layers[l];
+    hipLaunchKernelGGL(hem_score_bwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers, ld,
+                       dim, rows, dscores, grad_scale, lambda_muq, rowgrad, ld_rowgrad, batch);
+    return check_launch("ihg_hem_score_bwd");
+}
+
+int ihg_bce_with_logits(const float* scores, const float* labels, int64_t n, float* loss, float* dscores, ihg_stream_t stream) {
+    if (n <= 0 || n > (1 << 24) || scores == nullptr || labels == nullptr || loss == nullptr || dscores == nullptr)
+        return fail(IHG_ERR_INVALID, "ihg_bce_with_logits: bad argument");
+    hipLaunchKernelGGL(bce_with_logits_kernel, dim3(1), dim3(kScatterThreads), 0, static_cast<hipStream_t>(stream), scores, labels, static_cast<int>(n), loss, dscores);
+    return check_launch("ihg_bce_with_logits");
+}
+
+
+int64_t ihg_batch_scatter_workspace_bytes(int64_t n_rows) {
+    return (n_rows < 0 || n_rows > kScatterMax) ? -1 : 0;
+}
+
+int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows, float* dense,
+                          int64_t ld_dense, int32_t block_width, int64_t block_stride, float* tail, int64_t tail_row_offset,
+                          int64_t tail_rows, ihg_stream_t stream) {
+    if (n_rows < 0 || n_rows > kScatterMax) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: 0..%d rows supported, got %lld", kScatterMax, (long long)n_rows);
+    if (width <= 0 || ld_rowgrad < width || block_width <= 0 || ld_dense < block_width) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: bad width / stride");
+    if (n_rows == 0) return IHG_OK;
+    if (rowgrad == nullptr || rows == nullptr || dense == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: null pointer");
+    hipLaunchKernelGGL(batch_scatter_kernel, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad, ld_rowgrad,
+                       width, rows, static_cast<int>(n_rows), dense, ld_dense, block_width, block_stride, tail, tail_row_offset, tail_rows);
+    return check_launch("ihg_batch_scatter_add");
+}
+}  // extern "C"
