@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-scale', type=float, default=0.125, help='fraction of the workload the CPU baseline runs on')
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket kernels with HIP events')
+    ap.add_argument('--scale', type=float, default=1.0, help='shrink every count of the workload (exploratory runs of the big configs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for smoke tests)')
     ap.add_argument('--device', type=int, default=-1, help='force every rank onto this GPU ordinal (single-GPU smoke test of the N-rank path)')
     return ap.parse_args()
@@ -120,7 +121,7 @@ def main():
 
     cfg = synth.CONFIGS[args.config]
     dim, layers = cfg['dim'], cfg['layers']
-    w = synth.draw_config(args.config)
+    w = synth.draw_config(args.config, scale=args.scale)
     ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets,
                                   w.triples, device=dev)
     model = build_model(ds, dev, args.layer, layers, args.order, dim)
@@ -210,7 +211,7 @@ def main():
         'metric': 'hyperedges_aggregated_per_sec', 'value': round(value, 1), 'unit': 'hyperedges/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': WORKLOAD_NOTES.get(args.config, args.config) +
+        'config': {'workload': WORKLOAD_NOTES.get(args.config, args.config) + (f' SCALED x{args.scale:g};' if args.scale != 1.0 else '') +
                                f' U={w.user_count} Q={w.query_count} I={w.item_count} E={E}, {cfg["distribution"]} members, '
                                f'dim={dim}, {layers}x{args.layer} layers, interaction order {args.order}, batch 100 pos + 1000 neg',
                    'step': 'full training step: propagate fwd + BCE + bwd + Adam' + (' + RCCL grad all-reduce' if world > 1 else ''),
