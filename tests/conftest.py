@@ -12,6 +12,12 @@ GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The C-ABI library is a build artefact (git-ignored): make sure it exists and is current before any test binds it.
+    from ihgnn_amd import build as hip_build
+    try:
+        hip_build.build()
+    except RuntimeError as exc:                      # no hipcc here: tests that need the library will say so themselves
+        print(f'[conftest] could not build libihgnn_hip.so: {exc}')
 
 
 def pytest_collection_modifyitems(config, items):
