@@ -307,71 +307,114 @@ __global__ __launch_bounds__(kBlockThreads) void interact_bwd_members_mfma_kerne
 // ------------------------------------------------------------------------------------------------
 constexpr int kWsThreads = 512;
 
+// One 1-KiB piece of an LDS image filled straight from global memory (no staging registers, no ds_write): lane l's 16 bytes
+// land at lds_piece + 16*l, the source address is per lane.
+__device__ __forceinline__ void lds_dma16(const float* src, float* lds_piece) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+}
+
 template <int D, int NBLK>
 __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
     const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
     const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
     static_assert(D == 32 || D == 64, "wave-specialised form stages whole rows");
     using S = TileShape<D>;
-    constexpr int V4 = D / 4, LOADS = 3 * S::TE * V4 / kBlockThreads, PL = LOADS / 3, T_STEPS = D / 8;
+    constexpr int V4 = D / 4, T_STEPS = D / 8;
+    constexpr int RPP = kWave / V4;                       // member rows per 1-KiB piece
+    constexpr int PIECES = 3 * S::TE / RPP / 4;           // pieces per loader wave per tile
+    constexpr int PL = S::TE * V4 / kBlockThreads;        // result vectors per loader thread per tile
+    constexpr int OSTRIDE = D + 8;                        // result rows: the two lane halves of one accumulator store land 32 banks apart
+    // Member rows sit UNPADDED in LDS (a DMA piece is lane-linear), 16-byte chunk c of row r at position c ^ (r % V4):
+    // the swizzle is applied to the source address here and to the ds_read_b128 address in the consumers.
     struct Buffer {
-        float tile[3][S::TE][S::STRIDE];
-        float psum[S::TE][D];
+        float tile[3][S::TE][D];
+        float prod[S::TE][OSTRIDE];     // product-block sums of the tile, handed back to the loaders for the epilogue
     };
     __shared__ __attribute__((aligned(16))) Buffer buf[2];
     const int64_t n_tiles = (n_edges + S::TE - 1) / S::TE;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t g = gridDim.x;
+    // tiles this workgroup owns: blockIdx.x, +g, +2g ...; trip k lands tile k in LDS, multiplies tile k-1, writes out tile k-2
+    const int n_my = blockIdx.x < n_tiles ? static_cast<int>((n_tiles - blockIdx.x + g - 1) / g) : 0;
 
     if (wave >= 4) {
-        // ---------------- loaders ----------------
-        // Schedule per trip (tile T is deposited while the consumers multiply the previous one):
-        //   deposit rows(T)  ->  issue rows(T+g) with the ids fetched a trip ago  ->  issue ids(T+2g)  ->  barrier.
-        // vmcnt retires in issue order, so every wait in a trip is for loads that were issued a whole trip earlier.
-        const int tid = threadIdx.x - kBlockThreads;
-        const int64_t g = gridDim.x;
-        v4f hr[LOADS], pr[LOADS];
-        int node[LOADS], node_next[LOADS];
-        auto load_ids = [&](int64_t tile_id, int (&dst)[LOADS]) {
-            const int64_t e_base = tile_id * S::TE;
+        // ---------------- loaders (and epilogue) ----------------
+        // Trip k: pick up the product sums of tile k-2 -> start the DMA of the member rows of tile k into the buffer tile k-2 just
+        // left -> issue its first-order rows and the ids of tile k+1 -> store tile k-2 -> barrier (which waits for the DMA).
+        // The consumers never touch global memory inside the loop and nothing is staged through ds_write_b128.
+        // A loader shares its SIMD with a consumer that issues MFMAs back to back, and gets few issue slots: the stream below is
+        // kept to one 32x32->64-bit multiply-add per address, wave-uniform values stay in scalar registers.
+        const int lw = __builtin_amdgcn_readfirstlane(wave) - 4;
+        const int sub = lane / V4, chunk = lane % V4;      // row inside a piece, 16-byte chunk inside the row
+        constexpr int QP = S::TE / 4 / RPP;                // pieces per member per loader wave (its TE/4 rows, RPP per piece)
+        static_assert(QP == PL && PIECES == 3 * QP, "piece and result mappings coincide");
+        // Piece x = m * QP + q of this wave: member m of tile rows wrow0 + q * RPP ... + RPP - 1; this lane: row + sub, chunk.
+        // The same thread therefore sees all three members of "its" rows: it also gathers their first-order rows, and
+        // writes their results.
+        const int wrow0 = lw * (S::TE / 4);                // wave-uniform
+        const int row0 = wrow0 + sub;
+        const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u, p_row_bytes = static_cast<uint32_t>(ld_p) * 4u;
+        const char* hsrc[QP];                              // per-lane source of chunk position `chunk` of a row of piece q (swizzled)
 #pragma unroll
-            for (int x = 0; x < LOADS; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                const int64_t e = e_base + (idx / V4) % S::TE;
-                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * S::TE)] : 0;
+        for (int q = 0; q < QP; ++q) hsrc[q] = reinterpret_cast<const char*>(h) + ((chunk ^ ((row0 + q * RPP) % V4)) * 16);
+        const char* psrc = reinterpret_cast<const char*>(p) + chunk * 16;
+        int node[PIECES];
+        v4f pr[PIECES], first_a[PL], first_b[PL];
+        auto load_ids = [&](int64_t tile_id) {
+            const int64_t e0 = tile_id * S::TE + row0;
+            const int32_t* idp = i3 + e0 * 3;
+            if (tile_id * S::TE + S::TE <= n_edges) {      // whole tile: constant offsets from one address
+#pragma unroll
+                for (int x = 0; x < PIECES; ++x) node[x] = idp[(x % QP) * RPP * 3 + x / QP];
+            } else {
+#pragma unroll
+                for (int x = 0; x < PIECES; ++x) node[x] = e0 + (x % QP) * RPP < n_edges ? idp[(x % QP) * RPP * 3 + x / QP] : 0;
             }
         };
-        auto issue_rows = [&](const int (&src)[LOADS]) {
+        auto start_loads = [&](Buffer& b) {
 #pragma unroll
-            for (int x = 0; x < LOADS; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + (idx % V4) * 4);
-                pr[x] = *reinterpret_cast<const v4f*>(p + static_cast<int64_t>(src[x]) * ld_p + (idx % V4) * 4);
+            for (int x = 0; x < PIECES; ++x)
+                lds_dma16(reinterpret_cast<const float*>(hsrc[x % QP] + static_cast<uint64_t>(static_cast<uint32_t>(node[x])) * h_row_bytes),
+                          &b.tile[x / QP][wrow0 + (x % QP) * RPP][0]);
+#pragma unroll
+            for (int x = 0; x < PIECES; ++x)
+                pr[x] = *reinterpret_cast<const v4f*>(psrc + static_cast<uint64_t>(static_cast<uint32_t>(node[x])) * p_row_bytes);
+        };
+        auto write_out = [&](int64_t tile_id, const v4f (&prod)[PL], const v4f (&first)[PL]) {
+            const int64_t e0 = tile_id * S::TE + row0;
+            float* dst = out + e0 * ld_out + chunk * 4;
+            if (tile_id * S::TE + S::TE <= n_edges) {
+#pragma unroll
+                for (int q = 0; q < PL; ++q) *reinterpret_cast<v4f*>(dst + q * RPP * ld_out) = prod[q] + first[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < PL; ++q)
+                    if (e0 + q * RPP < n_edges) *reinterpret_cast<v4f*>(dst + q * RPP * ld_out) = prod[q] + first[q];
             }
         };
-        int64_t t = blockIdx.x;
-        if (t < n_tiles) {
-            load_ids(t, node);
-            issue_rows(node);
-        }
-        if (t + g < n_tiles) load_ids(t + g, node_next);
-        int which = 0;
-        while (t < n_tiles) {
-            Buffer& b = buf[which];
+        const int64_t t0 = blockIdx.x;
+        if (n_my > 0) load_ids(t0);
+        for (int k = 0; k <= n_my; ++k) {
+            Buffer& b = buf[k & 1];
+            v4f prod[PL];
 #pragma unroll
-            for (int x = 0; x < LOADS; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                *reinterpret_cast<v4f*>(&b.tile[idx / (V4 * S::TE)][(idx / V4) % S::TE][(idx % V4) * 4]) = hr[x];
-            }
+            for (int q = 0; q < PL; ++q) prod[q] = *reinterpret_cast<const v4f*>(&b.prod[row0 + q * RPP][chunk * 4]);
+            if (k < n_my) start_loads(b);                  // the ids of tile k arrived before the last barrier
+            if (k + 1 < n_my) load_ids(t0 + (k + 1) * g);
+            if (k >= 2) write_out(t0 + (k - 2) * g, prod, first_a);
 #pragma unroll
-            for (int x = 0; x < PL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                *reinterpret_cast<v4f*>(&b.psum[idx / V4][(idx % V4) * 4]) = (pr[x] + pr[x + PL]) + pr[x + 2 * PL];
+            for (int q = 0; q < PL; ++q) {
+                first_a[q] = first_b[q];
+                first_b[q] = (pr[q] + pr[q + QP]) + pr[q + 2 * QP];
             }
-            if (t + g < n_tiles) issue_rows(node_next);
-            if (t + 2 * g < n_tiles) load_ids(t + 2 * g, node_next);
             __syncthreads();
-            t += g;
-            which ^= 1;
+        }
+        if (n_my >= 1) {
+            const Buffer& b = buf[(n_my - 1) & 1];
+            v4f prod[PL];
+#pragma unroll
+            for (int q = 0; q < PL; ++q) prod[q] = *reinterpret_cast<const v4f*>(&b.prod[row0 + q * RPP][chunk * 4]);
+            write_out(t0 + (n_my - 1) * g, prod, first_a);
         }
         return;
     }
@@ -379,6 +422,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
     const int et = D == 32 ? wave : (wave & 1);
     const int jt = D == 32 ? 0 : (wave >> 1);
     const int row = et * 32 + (lane & 31), half = lane >> 5;
+    const int swz = (row % V4) ^ half;                    // chunk 2 ts + half of this row sits at position swz ^ 2 ts
     const v4f* wfrag = reinterpret_cast<const v4f*>(wp) + static_cast<int64_t>(jt) * NBLK * T_STEPS * kWave + lane;
     v4f wreg[NBLK][T_STEPS];
 #pragma unroll
@@ -386,17 +430,17 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
 #pragma unroll
         for (int ts = 0; ts < T_STEPS; ++ts) wreg[b][ts] = wfrag[(b * T_STEPS + ts) * kWave];
     const int j = jt * 32 + (lane & 31);
-    int which = 0;
-    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
-        __syncthreads();
-        const Buffer& b = buf[which];
+    __syncthreads();
+    for (int k = 0; k < n_my; ++k) {
+        Buffer& b = buf[k & 1];
         v16f acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // A operands one k-step ahead of the MFMAs that use them: the LDS round trip hides behind 16 MFMAs
-        v4f au = *reinterpret_cast<const v4f*>(&b.tile[0][row][4 * half]);
-        v4f aq = *reinterpret_cast<const v4f*>(&b.tile[1][row][4 * half]);
-        v4f ai = *reinterpret_cast<const v4f*>(&b.tile[2][row][4 * half]);
+        // A operands one k-step ahead of the MFMAs that use them: the LDS round trip hides behind 16 MFMAs.  The scheduling
+        // fences keep the compiler from sinking the reads down to their first use (it does, and exposes the LDS latency).
+        v4f au = *reinterpret_cast<const v4f*>(&b.tile[0][row][4 * swz]);
+        v4f aq = *reinterpret_cast<const v4f*>(&b.tile[1][row][4 * swz]);
+        v4f ai = *reinterpret_cast<const v4f*>(&b.tile[2][row][4 * swz]);
 #pragma unroll
         for (int ts = 0; ts < T_STEPS; ++ts) {
             v4f z[4];
@@ -404,31 +448,23 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
             z[1] = aq * ai;
             z[2] = ai * au;
             z[3] = z[0] * ai;
+            __builtin_amdgcn_sched_barrier(0);
             if (ts + 1 < T_STEPS) {
-                const int col = 8 * (ts + 1) + 4 * half;
+                const int col = 4 * (swz ^ (2 * (ts + 1)));
                 au = *reinterpret_cast<const v4f*>(&b.tile[0][row][col]);
                 aq = *reinterpret_cast<const v4f*>(&b.tile[1][row][col]);
                 ai = *reinterpret_cast<const v4f*>(&b.tile[2][row][col]);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int bk = 0; bk < NBLK; ++bk)
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(z[bk][s2], wreg[bk][ts][s2], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // epilogue: all 16 first-order sums are read from LDS in one batch, then added and stored
-        const int64_t e_base = t * S::TE;
-        float first[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) first[r] = b.psum[et * 32 + acc_row(r, lane)][j];
-        float* orow = out + (e_base + et * 32) * ld_out + j;
-        if (e_base + S::TE <= n_edges) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[r] + first[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (e_base + et * 32 + acc_row(r, lane) < n_edges) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_out] = acc[r] + first[r];
-        }
+        for (int r = 0; r < 16; ++r) b.prod[et * 32 + acc_row(r, lane)][j] = acc[r];
+        __syncthreads();
     }
 }
 
@@ -932,9 +968,15 @@ void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float
         const int grid = static_cast<int>(std::min<int64_t>(tiles, kPipeGrid));                                             \
         hipLaunchKernelGGL((interact_fwd_ws_kernel<D, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges); \
     }
+    // the wave-specialised form moves first-order rows and results as 16-byte vectors and forms addresses as 32x32-bit products
+    const bool vector_io = aligned16(p) && aligned16(out) && ld_p % 4 == 0 && ld_out % 4 == 0 && ld_h < (int64_t{1} << 30) && ld_p < (int64_t{1} << 30);
     switch (dim) {
-        case 32: IHG_FWD_PIPE(32) break;
-        case 64: IHG_FWD_PIPE(64) break;
+        case 32:
+            if (vector_io) IHG_FWD_PIPE(32) else IHG_FWD(32)
+            break;
+        case 64:
+            if (vector_io) IHG_FWD_PIPE(64) else IHG_FWD(64)
+            break;
         case 128: IHG_FWD(128) break;
         default: IHG_FWD(256) break;
     }

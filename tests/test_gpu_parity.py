@@ -243,6 +243,40 @@ def test_interact_forward_backward(dim, order):
     assert rel(hg.grad, hc.grad) <= RTOL and rel(wg.grad, wc.grad) <= RTOL and rel(bg.grad, bc.grad) <= RTOL
 
 
+@pytest.mark.parametrize('dim,order,edges', [(64, 3, 3 * 256 * 64 + 37), (64, 2, 2 * 256 * 64 + 64), (32, 3, 2 * 256 * 128 + 5)])
+def test_interact_persistent_tiles_and_strided_rows(dim, order, edges):
+    """More tiles than workgroups (every workgroup walks several tiles, the last one partial) and member / first-order rows
+    that are column slices of one wider table (row stride 2 d + 8): the pipelined kernels against the oracle."""
+    from ihgnn_amd import ops
+    from oracle import ihgnn_ref as ref
+    U, Q, I = 301, 17, 211
+    w_, lay = make_layout(U, Q, I, edges, seed=dim + order + 1)
+    g = ref.HyperGraph(w_.triples, U, Q, I)
+    k = 6 if order == 2 else 7
+    gen = torch.Generator().manual_seed(dim * order + 7)
+    h = torch.randn(lay.node_count, dim, generator=gen)
+    w = torch.randn(dim, k * dim, generator=gen) / np.sqrt(k * dim)
+    b = torch.randn(dim, generator=gen)
+    cot = torch.randn(lay.edge_count, dim, generator=gen) / 8
+    hc, wc = (t.clone().requires_grad_(True) for t in (h, w))
+    want = ref.feature_interactor(hc, g.I3, wc, b, order)
+    want.backward(cot)
+
+    table = torch.zeros(lay.node_count, 2 * dim + 8, device=dev())
+    table[:, :dim] = h.to(dev())
+    hg = table[:, :dim].requires_grad_(True)
+    wg = w.clone().to(dev()).requires_grad_(True)
+    first = torch.cat([torch.nn.functional.linear(hg[:U], wg[:, :dim], b.to(dev())),
+                       torch.nn.functional.linear(hg[U:U + Q], wg[:, dim:2 * dim]),
+                       torch.nn.functional.linear(hg[U + Q:], wg[:, 2 * dim:3 * dim])])
+    pg = torch.zeros(lay.node_count, 2 * dim + 8, device=dev())[:, dim + 8:]
+    pg.copy_(first)                                        # strided rows that still carry the graph back to hg / wg
+    got = ops.interact(hg, pg, wg, lay, order)
+    got.backward(cot.to(dev()))
+    assert rel(got, want) <= RTOL
+    assert rel(hg.grad, hc.grad) <= RTOL and rel(wg.grad, wc.grad) <= RTOL
+
+
 # ---------------------------------------------------------------------------------------------
 # layer level: reference fixtures F2
 # ---------------------------------------------------------------------------------------------
