@@ -307,6 +307,11 @@ __global__ __launch_bounds__(kBlockThreads) void interact_bwd_members_mfma_kerne
 // ------------------------------------------------------------------------------------------------
 constexpr int kWsThreads = 512;
 
+// Position swizzle of an unpadded LDS row image read with ds_read_b128 as an MFMA A operand: 16-byte chunk c of row r sits at
+// position c ^ tile_swizzle(r).  The 16 lanes one LDS cycle serves hold 16 different rows; the swizzle spreads them over all
+// 64 banks (256-byte rows: r % 16; 128-byte rows alternate bank halves by themselves, so (r / 2) % 8).
+template <int D> __device__ __forceinline__ int tile_swizzle(int r) { return D == 64 ? (r & 15) : ((r >> 1) & 7); }
+
 // One 1-KiB piece of an LDS image filled straight from global memory (no staging registers, no ds_write): lane l's 16 bytes
 // land at lds_piece + 16*l, the source address is per lane.
 __device__ __forceinline__ void lds_dma16(const float* src, float* lds_piece) {
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
     constexpr int PIECES = 3 * S::TE / RPP / 4;           // pieces per loader wave per tile
     constexpr int PL = S::TE * V4 / kBlockThreads;        // result vectors per loader thread per tile
     constexpr int OSTRIDE = D + 8;                        // result rows: the two lane halves of one accumulator store land 32 banks apart
-    // Member rows sit UNPADDED in LDS (a DMA piece is lane-linear), 16-byte chunk c of row r at position c ^ (r % V4):
+    // Member rows sit UNPADDED in LDS (a DMA piece is lane-linear), 16-byte chunk c of row r at position c ^ tile_swizzle(r):
     // the swizzle is applied to the source address here and to the ds_read_b128 address in the consumers.
     struct Buffer {
         float tile[3][S::TE][D];
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
         const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u, p_row_bytes = static_cast<uint32_t>(ld_p) * 4u;
         const char* hsrc[QP];                              // per-lane source of chunk position `chunk` of a row of piece q (swizzled)
 #pragma unroll
-        for (int q = 0; q < QP; ++q) hsrc[q] = reinterpret_cast<const char*>(h) + ((chunk ^ ((row0 + q * RPP) % V4)) * 16);
+        for (int q = 0; q < QP; ++q) hsrc[q] = reinterpret_cast<const char*>(h) + ((chunk ^ tile_swizzle<D>(row0 + q * RPP)) * 16);
         const char* psrc = reinterpret_cast<const char*>(p) + chunk * 16;
         int node[PIECES];
         v4f pr[PIECES], first_a[PL], first_b[PL];
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
     const int et = D == 32 ? wave : (wave & 1);
     const int jt = D == 32 ? 0 : (wave >> 1);
     const int row = et * 32 + (lane & 31), half = lane >> 5;
-    const int swz = (row % V4) ^ half;                    // chunk 2 ts + half of this row sits at position swz ^ 2 ts
+    const int swz = tile_swizzle<D>(row) ^ half;          // chunk 2 ts + half of this row sits at position swz ^ 2 ts
     const v4f* wfrag = reinterpret_cast<const v4f*>(wp) + static_cast<int64_t>(jt) * NBLK * T_STEPS * kWave + lane;
     v4f wreg[NBLK][T_STEPS];
 #pragma unroll
@@ -473,74 +478,88 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
     const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
     const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g, int64_t n_edges) {
     static_assert(D == 32 || D == 64, "wave-specialised form stages whole rows");
-    constexpr int ET = D == 32 ? 4 : 2, TE = ET * 32, STRIDE = D + kRowPad, V4 = D / 4, T_STEPS = D / 8;
-    constexpr int DL = TE * V4 / kBlockThreads, HL = 3 * DL;
+    constexpr int ET = D == 32 ? 4 : 2, TE = ET * 32, V4 = D / 4, T_STEPS = D / 8;
+    constexpr int RPP = kWave / V4;                       // rows per 1-KiB DMA piece
+    constexpr int QP = TE / 4 / RPP;                      // pieces per row block of one loader wave
+    // Same trip structure as the forward kernel: the loaders fill dtile (dout rows, swizzled like the forward's member rows:
+    // it is the MFMA A operand) and htile (member rows, plain) by DMA; the consumers overwrite htile IN PLACE with the member
+    // gradients of the product rule (every (row, column) element is read and written by the one lane that owns it), and the
+    // loaders stream those rows out as 16-byte vectors two trips later.
     struct Buffer {
-        float dtile[TE][STRIDE];
+        float dtile[TE][D];
         float htile[3][TE][D];
     };
     __shared__ __attribute__((aligned(16))) Buffer buf[2];
     const int64_t n_tiles = (n_edges + TE - 1) / TE;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t grid = gridDim.x;
+    const int n_my = blockIdx.x < n_tiles ? static_cast<int>((n_tiles - blockIdx.x + grid - 1) / grid) : 0;
 
     if (wave >= 4) {
-        // loaders: deposit rows(T) -> issue rows(T+g) with ids fetched a trip ago -> issue ids(T+2g) -> barrier
-        const int tid = threadIdx.x - kBlockThreads;
-        const int64_t g = gridDim.x;
-        v4f dr[DL], hr[HL];
-        int node[HL], node_next[HL];
-        auto load_ids = [&](int64_t tile_id, int (&dst)[HL]) {
-            const int64_t e_base = tile_id * TE;
+        const int lw = __builtin_amdgcn_readfirstlane(wave) - 4;
+        const int sub = lane / V4, chunk = lane % V4;
+        const int wrow0 = lw * (TE / 4), row0 = wrow0 + sub;
+        const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u;
+        const char* hsrc = reinterpret_cast<const char*>(h) + chunk * 16;
+        int node[3 * QP];
+        auto load_ids = [&](int64_t tile_id) {
+            const int64_t e0 = tile_id * TE + row0;
+            const int32_t* idp = i3 + e0 * 3;
+            if (tile_id * TE + TE <= n_edges) {
 #pragma unroll
-            for (int x = 0; x < HL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                const int64_t e = e_base + (idx / V4) % TE;
-                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * TE)] : 0;
+                for (int x = 0; x < 3 * QP; ++x) node[x] = idp[(x % QP) * RPP * 3 + x / QP];
+            } else {
+#pragma unroll
+                for (int x = 0; x < 3 * QP; ++x) node[x] = e0 + (x % QP) * RPP < n_edges ? idp[(x % QP) * RPP * 3 + x / QP] : 0;
             }
         };
-        auto issue_rows = [&](int64_t tile_id, const int (&src)[HL]) {
-            const int64_t e_base = tile_id * TE;
+        auto start_loads = [&](Buffer& b, int64_t tile_id) {
+            const int64_t e0 = tile_id * TE + row0;
 #pragma unroll
-            for (int x = 0; x < DL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                const int64_t e = e_base + idx / V4;
-                dr[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < QP; ++q) {                 // dout rows: a stream; rows past the end re-read the last one
+                const int r = row0 + q * RPP;
+                int64_t e = e0 + q * RPP;
+                e = e < n_edges ? e : n_edges - 1;
+                lds_dma16(dout + e * ld_dout + (chunk ^ tile_swizzle<D>(r)) * 4, &b.dtile[wrow0 + q * RPP][0]);
             }
 #pragma unroll
-            for (int x = 0; x < HL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + (idx % V4) * 4);
-            }
+            for (int x = 0; x < 3 * QP; ++x)
+                lds_dma16(reinterpret_cast<const float*>(hsrc + static_cast<uint64_t>(static_cast<uint32_t>(node[x])) * h_row_bytes),
+                          &b.htile[x / QP][wrow0 + (x % QP) * RPP][0]);
         };
-        int64_t t = blockIdx.x;
-        if (t < n_tiles) {
-            load_ids(t, node);
-            issue_rows(t, node);
-        }
-        if (t + g < n_tiles) load_ids(t + g, node_next);
-        int which = 0;
-        while (t < n_tiles) {
-            Buffer& b = buf[which];
+        v4f gout[3 * QP];
+        auto pick_up = [&](const Buffer& b) {
 #pragma unroll
-            for (int x = 0; x < DL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                *reinterpret_cast<v4f*>(&b.dtile[idx / V4][(idx % V4) * 4]) = dr[x];
-            }
+            for (int x = 0; x < 3 * QP; ++x) gout[x] = *reinterpret_cast<const v4f*>(&b.htile[x / QP][row0 + (x % QP) * RPP][chunk * 4]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are in registers before a DMA may overwrite them
+        };
+        auto write_out = [&](int64_t tile_id) {
+            const int64_t e0 = tile_id * TE + row0;
+            float* dst = g + e0 * (3 * D) + chunk * 4;
+            const bool full = tile_id * TE + TE <= n_edges;
 #pragma unroll
-            for (int x = 0; x < HL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                *reinterpret_cast<v4f*>(&b.htile[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hr[x];
-            }
-            if (t + g < n_tiles) issue_rows(t + g, node_next);
-            if (t + 2 * g < n_tiles) load_ids(t + 2 * g, node_next);
+            for (int x = 0; x < 3 * QP; ++x)
+                if (full || e0 + (x % QP) * RPP < n_edges) *reinterpret_cast<v4f*>(dst + (x % QP) * RPP * (3 * D) + (x / QP) * D) = gout[x];
+        };
+        const int64_t t0 = blockIdx.x;
+        if (n_my > 0) load_ids(t0);
+        for (int k = 0; k <= n_my; ++k) {
+            Buffer& b = buf[k & 1];
+            if (k >= 2) pick_up(b);
+            if (k < n_my) start_loads(b, t0 + k * grid);   // the ids of tile k arrived before the last barrier
+            if (k + 1 < n_my) load_ids(t0 + (k + 1) * grid);
+            if (k >= 2) write_out(t0 + (k - 2) * grid);
             __syncthreads();
-            t += g;
-            which ^= 1;
+        }
+        if (n_my >= 1) {
+            pick_up(buf[(n_my - 1) & 1]);
+            write_out(t0 + (n_my - 1) * grid);
         }
         return;
     }
     const int et = wave % ET, ct = wave / ET;
     const int row = et * 32 + (lane & 31), half = lane >> 5;
+    const int swz = tile_swizzle<D>(row) ^ half;          // chunk 2 ts + half of this row sits at position swz ^ 2 ts
     const v4f* wfrag = reinterpret_cast<const v4f*>(wq) + static_cast<int64_t>(ct) * NBLK * T_STEPS * kWave + lane;
     v4f wreg[NBLK][T_STEPS];
 #pragma unroll
@@ -548,55 +567,50 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
 #pragma unroll
         for (int ts = 0; ts < T_STEPS; ++ts) wreg[b][ts] = wfrag[(b * T_STEPS + ts) * kWave];
     const int c = ct * 32 + (lane & 31);
-    int which = 0;
-    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
-        __syncthreads();
-        const Buffer& b = buf[which];
+    __syncthreads();
+    for (int k = 0; k < n_my; ++k) {
+        Buffer& b = buf[k & 1];
         v16f acc[NBLK];
 #pragma unroll
         for (int bk = 0; bk < NBLK; ++bk)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[bk][r] = 0.f;
-        v4f a = *reinterpret_cast<const v4f*>(&b.dtile[row][4 * half]);
+        v4f a = *reinterpret_cast<const v4f*>(&b.dtile[row][4 * swz]);
 #pragma unroll
         for (int ts = 0; ts < T_STEPS; ++ts) {
             const v4f a_now = a;
-            if (ts + 1 < T_STEPS) a = *reinterpret_cast<const v4f*>(&b.dtile[row][8 * (ts + 1) + 4 * half]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ts + 1 < T_STEPS) a = *reinterpret_cast<const v4f*>(&b.dtile[row][4 * (swz ^ (2 * (ts + 1)))]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
                 for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_now[s2], wreg[bk][ts][s2], acc[bk], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // epilogue in batches of four rows: 12 LDS reads in flight, then the product rule and 12 stores
-        const int64_t e_base = t * TE;
-        const bool full = e_base + TE <= n_edges;
-        float* gbase = g + (e_base + et * 32) * 3 * D + c;
+        // epilogue in batches of four rows: 12 LDS reads in flight, then the product rule, results back over the member values
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += 4) {
             float hu[4], hq[4], hi[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int er = et * 32 + acc_row(r0 + k, lane);
-                hu[k] = b.htile[0][er][c];
-                hq[k] = b.htile[1][er][c];
-                hi[k] = b.htile[2][er][c];
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int er = et * 32 + acc_row(r0 + k4, lane);
+                hu[k4] = b.htile[0][er][c];
+                hq[k4] = b.htile[1][er][c];
+                hi[k4] = b.htile[2][er][c];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = r0 + k;
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int r = r0 + k4;
+                const int er = et * 32 + acc_row(r, lane);
                 const float z_uq = acc[0][r], z_qi = acc[1][r], z_iu = acc[2][r];
                 const float z_uqi = NBLK == 4 ? acc[NBLK - 1][r] : 0.f;
-                const float gu = z_uq * hq[k] + z_iu * hi[k] + z_uqi * (hq[k] * hi[k]);
-                const float gq = z_uq * hu[k] + z_qi * hi[k] + z_uqi * (hu[k] * hi[k]);
-                const float gi = z_qi * hq[k] + z_iu * hu[k] + z_uqi * (hu[k] * hq[k]);
-                if (full || e_base + et * 32 + acc_row(r, lane) < n_edges) {
-                    float* ge = gbase + static_cast<int64_t>(acc_row(r, lane)) * 3 * D;
-                    ge[0] = gu;
-                    ge[D] = gq;
-                    ge[2 * D] = gi;
-                }
+                b.htile[0][er][c] = z_uq * hq[k4] + z_iu * hi[k4] + z_uqi * (hq[k4] * hi[k4]);
+                b.htile[1][er][c] = z_uq * hu[k4] + z_qi * hi[k4] + z_uqi * (hu[k4] * hi[k4]);
+                b.htile[2][er][c] = z_qi * hq[k4] + z_iu * hu[k4] + z_uqi * (hu[k4] * hq[k4]);
             }
         }
+        __syncthreads();
     }
 }
 
@@ -999,9 +1013,14 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + TE - 1) / TE, kPipeGrid));                           \
         hipLaunchKernelGGL((interact_bwd_members_ws_kernel<D, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
     }
+    const bool vector_io = aligned16(g) && ld_h < (int64_t{1} << 30);     // the pipelined form stores g as 16-byte vectors
     switch (dim) {
-        case 32: IHG_MEM_PIPE(32) break;
-        case 64: IHG_MEM_PIPE(64) break;
+        case 32:
+            if (vector_io) IHG_MEM_PIPE(32) else IHG_MEM(32)
+            break;
+        case 64:
+            if (vector_io) IHG_MEM_PIPE(64) else IHG_MEM(64)
+            break;
         case 128: {
             const int grid = static_cast<int>(std::min<int64_t>((n_edges + 63) / 64, kPipeGrid));
             hipLaunchKernelGGL((interact_bwd_members_wsbig_kernel<128, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges);
