@@ -56,14 +56,21 @@ class RawGnn(nn.Module):
         self.prediction_layer = HemPredictionLayer(feature_dimension=self.output_feature_size, lambda_muq=lambda_muq,
                                                    item_count=dataset.item_count)
 
-    def propagate_layers(self):
+    def propagate_layers(self, tail_gradients=None):
         """Full-graph propagation: the list ``[X0, X1, ..., XL]`` of ``[N, d]`` node features (input embeddings and every
-        layer's output)."""
+        layer's output).  With ``tail_gradients`` (an ``ops.TailGradients``) every output is tapped: the returned tensors
+        are the batch tail's halves, whose gradients travel through the holder instead of dense ``[N, d]`` tensors."""
         x = torch.cat(self.embeddings(None, None, None))
-        outputs = [x]
-        for layer in self.gnns:
-            x = layer(x)
-            outputs.append(x)
+        outputs = []
+        for depth in range(len(self.gnns) + 1):
+            if depth > 0:
+                x = self.gnns[depth - 1](x)
+            if tail_gradients is not None:
+                from .. import ops
+                x, for_tail = ops.tap(x, tail_gradients, depth)
+                outputs.append(for_tail)
+            else:
+                outputs.append(x)
         return outputs
 
     def propagate(self) -> Tensor:
@@ -105,8 +112,9 @@ class RawGnn(nn.Module):
         from .. import ops
         ds, head = self.dataset, self.prediction_layer
         rows = torch.cat([user_indices, query_indices + ds.query_start_index_in_graph, item_indices + ds.item_start_index_in_graph])
-        return ops.hem_bce_loss(self.propagate_layers(), rows, item_indices, labels, head.items_bias, head.lambda_muq,
-                                ds.item_start_index_in_graph)
+        holder = ops.TailGradients() if torch.is_grad_enabled() else None
+        return ops.hem_bce_loss(self.propagate_layers(holder), rows, item_indices, labels, head.items_bias, head.lambda_muq,
+                                ds.item_start_index_in_graph, holder)
 
     def supports_fused_loss(self, loss_function) -> bool:
         return (isinstance(loss_function, nn.BCEWithLogitsLoss) and loss_function.reduction == 'mean' and loss_function.weight is None

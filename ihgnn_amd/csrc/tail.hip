@@ -102,10 +102,15 @@ constexpr int kScatterMax = 16384;
 // Destination addressing: column c of batch row k goes to dense[(c / block_width) * block_stride + row * ld_dense + c % block_width]
 // (block_width = width, block_stride = 0 is a plain matrix; block_width = d, block_stride = N*d lands layer l's columns in its own
 // contiguous [N, d] matrix); an optional last column goes to tail[row - tail_row_offset] (the bias gradient).
-__global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(const float* __restrict__ rowgrad, int64_t ld_rowgrad, int width,
+// COMBINE: nothing is scattered; the sum over a destination's batch rows replaces the FIRST of them in rowgrad itself (a row
+// is read by the wave of its destination's first occurrence only, which is also its only writer) and leader[k] says whether
+// batch row k is such a first occurrence.  batch_rows_add_kernel then adds leader rows wherever they are needed.
+template <bool COMBINE>
+__global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(float* __restrict__ rowgrad, int64_t ld_rowgrad, int width,
                                                                       const int64_t* __restrict__ rows, int n, float* __restrict__ dense,
                                                                       int64_t ld_dense, int block_width, int64_t block_stride,
-                                                                      float* __restrict__ tail, int64_t tail_row_offset, int64_t tail_rows) {
+                                                                      float* __restrict__ tail, int64_t tail_row_offset, int64_t tail_rows,
+                                                                      int32_t* __restrict__ leader) {
     __shared__ int32_t key[kScatterMax];                    // every workgroup keeps the whole id list in LDS (<= 64 KiB)
     for (int k = threadIdx.x; k < n; k += kBlockThreads) key[k] = static_cast<int32_t>(rows[k]);
     __syncthreads();
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(const floa
             const int j = base + lane;
             if (__ballot(j < k && key[j] == mine) != 0ull) { follower = true; break; }
         }
+        if (COMBINE && lane == 0) leader[k] = follower ? 0 : 1;
         if (follower) continue;
         for (int c0 = 0; c0 < width; c0 += 4 * kWave) {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -150,7 +156,9 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(const floa
             for (int q = 0; q < 4; ++q) {
                 const int c = c0 + q * kWave + lane;
                 if (c >= width) continue;
-                if (tail != nullptr && c == width - 1) {
+                if (COMBINE) {
+                    rowgrad[k * ld_rowgrad + c] = acc[q];
+                } else if (tail != nullptr && c == width - 1) {
                     const int64_t tr = static_cast<int64_t>(mine) - tail_row_offset;
                     if (tr >= 0 && tr < tail_rows) tail[tr] += acc[q];
                 } else {
@@ -158,6 +166,25 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(const floa
                 }
             }
         }
+    }
+}
+
+// dense[rows[k], 0:width] += src[k, 0:width] for the leader rows of a combined batch (no two leaders share a destination);
+// with `tail`, the single column src[k, 0] goes to tail[rows[k] - tail_row_offset] instead.
+__global__ __launch_bounds__(kBlockThreads) void batch_rows_add_kernel(const float* __restrict__ src, int64_t ld_src, int width,
+                                                                       const int64_t* __restrict__ rows, const int32_t* __restrict__ leader, int n,
+                                                                       float* __restrict__ dense, int64_t ld_dense, float* __restrict__ tail,
+                                                                       int64_t tail_row_offset, int64_t tail_rows) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t k = global_wave_id(); k < n; k += global_wave_count()) {
+        if (leader[k] == 0) continue;
+        const int64_t row = rows[k];
+        if (tail != nullptr) {
+            const int64_t tr = row - tail_row_offset;
+            if (lane == 0 && tr >= 0 && tr < tail_rows) tail[tr] += src[k * ld_src];
+            continue;
+        }
+        for (int c = lane; c < width; c += kWave) dense[row * ld_dense + c] += src[k * ld_src + c];
     }
 }
 
@@ -216,8 +243,31 @@ int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t widt
     if (width <= 0 || ld_rowgrad < width || block_width <= 0 || ld_dense < block_width) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: bad width / stride");
     if (n_rows == 0) return IHG_OK;
     if (rowgrad == nullptr || rows == nullptr || dense == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: null pointer");
-    hipLaunchKernelGGL(batch_scatter_kernel, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad, ld_rowgrad,
-                       width, rows, static_cast<int>(n_rows), dense, ld_dense, block_width, block_stride, tail, tail_row_offset, tail_rows);
+    hipLaunchKernelGGL(batch_scatter_kernel<false>, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+                       const_cast<float*>(rowgrad), ld_rowgrad, width, rows, static_cast<int>(n_rows), dense, ld_dense, block_width, block_stride, tail,
+                       tail_row_offset, tail_rows, static_cast<int32_t*>(nullptr));
     return check_launch("ihg_batch_scatter_add");
+}
+
+int ihg_batch_combine(float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows, int32_t* leader, ihg_stream_t stream) {
+    if (n_rows < 0 || n_rows > kScatterMax) return fail(IHG_ERR_INVALID, "ihg_batch_combine: 0..%d rows supported, got %lld", kScatterMax, (long long)n_rows);
+    if (width <= 0 || ld_rowgrad < width) return fail(IHG_ERR_INVALID, "ihg_batch_combine: bad width / stride");
+    if (n_rows == 0) return IHG_OK;
+    if (rowgrad == nullptr || rows == nullptr || leader == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_combine: null pointer");
+    hipLaunchKernelGGL(batch_scatter_kernel<true>, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad,
+                       ld_rowgrad, width, rows, static_cast<int>(n_rows), static_cast<float*>(nullptr), int64_t{0}, 1, int64_t{0},
+                       static_cast<float*>(nullptr), int64_t{0}, int64_t{0}, leader);
+    return check_launch("ihg_batch_combine");
+}
+
+int ihg_batch_rows_add(const float* src, int64_t ld_src, int32_t width, const int64_t* rows, const int32_t* leader, int64_t n_rows, float* dense,
+                       int64_t ld_dense, float* tail, int64_t tail_row_offset, int64_t tail_rows, ihg_stream_t stream) {
+    if (n_rows < 0 || width <= 0 || ld_src < width) return fail(IHG_ERR_INVALID, "ihg_batch_rows_add: bad size");
+    if (n_rows == 0) return IHG_OK;
+    if (src == nullptr || rows == nullptr || leader == nullptr || (dense == nullptr && tail == nullptr) || (dense != nullptr && ld_dense < width))
+        return fail(IHG_ERR_INVALID, "ihg_batch_rows_add: null pointer or short row stride");
+    hipLaunchKernelGGL(batch_rows_add_kernel, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), src, ld_src, width,
+                       rows, leader, static_cast<int>(n_rows), dense, ld_dense, tail, tail_row_offset, tail_rows);
+    return check_launch("ihg_batch_rows_add");
 }
 }  // extern "C"

@@ -349,18 +349,51 @@ def interact(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: in
 # ---------------------------------------------------------------------------------------------
 # Batch tail: HEM scores of a training batch straight from the layer outputs
 # ---------------------------------------------------------------------------------------------
+def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float):
+    """Per-batch-row gradients of the tail: ``[3B, (L+1) d + 4]``, layer l in columns ``l d .. (l+1) d``, d bias in column ``(L+1) d``."""
+    lib = _lib.load()
+    batch, dim, n_layers = int(items.shape[0]), int(layers[0].shape[1]), len(layers)
+    width = n_layers * dim
+    ptrs = (ctypes.c_void_p * n_layers)(*[x.data_ptr() for x in layers])
+    rowgrad = torch.empty(3 * batch, width + 4, dtype=torch.float32, device=bias.device)
+    with profiler.kernel('hem_score_bwd', batch, dim):
+        _lib.check(lib.ihg_hem_score_bwd(ptrs, n_layers, _ld(layers[0]), dim, _ptr(rows), _ptr(dscores), float(grad_scale), float(lam),
+                                         _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd')
+    return rowgrad
+
+
+def _scatter_rows(rowgrad: Tensor, col0: int, width: int, rows: Tensor, dense: Optional[Tensor], tail: Optional[Tensor] = None, tail_offset: int = 0):
+    """``dense[rows[k]] += rowgrad[k, col0 : col0 + width]`` (duplicates combined in a fixed order; deterministic).  With
+    ``tail``: the LAST of the ``width`` columns goes to ``tail[rows[k] - tail_offset]`` instead."""
+    lib = _lib.load()
+    n = int(rows.shape[0])
+    src = rowgrad[:, col0:]
+    target = dense if dense is not None else tail
+    block = int(dense.shape[1]) if dense is not None else 1
+    if lib.ihg_batch_scatter_workspace_bytes(n) >= 0:
+        with profiler.kernel('batch_scatter_add', n, width):
+            _lib.check(lib.ihg_batch_scatter_add(_ptr(src), int(rowgrad.stride(0)), width, _ptr(rows), n, _ptr(target), _ld(target) if dense is not None else 1,
+                                                 block, 0, _ptr(tail), int(tail_offset), int(tail.shape[0]) if tail is not None else 0, _stream()),
+                       'ihg_batch_scatter_add')
+        return
+    # batches beyond the kernel's range: torch's sort-based scatter
+    body = width - (1 if tail is not None else 0)
+    if dense is not None and body > 0:
+        dense.index_put_((rows,), rowgrad[:, col0:col0 + body], accumulate=True)
+    if tail is not None:
+        local = rows - tail_offset
+        keep = (local >= 0) & (local < tail.shape[0])
+        tail.index_put_((local[keep],), rowgrad[:, col0 + width - 1][keep], accumulate=True)
+
+
 def _hem_backward(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float, item_row_offset: int):
-    """Shared backward of the batch tail: per-row gradients (one kernel), then ONE deterministic scatter that lands every
+    """Backward of the batch tail without taps: per-row gradients (one kernel), then ONE deterministic scatter that lands every
     layer's gradient in its own contiguous ``[N, d]`` matrix and d bias beside them.  -> (d bias, layer gradients)."""
     lib = _lib.load()
     batch, dim, n_layers = int(items.shape[0]), int(layers[0].shape[1]), len(layers)
     width = n_layers * dim
     n_nodes = int(layers[0].shape[0])
-    ptrs = (ctypes.c_void_p * n_layers)(*[x.data_ptr() for x in layers])
-    rowgrad = torch.empty(3 * batch, width + 4, dtype=torch.float32, device=bias.device)       # column `width` carries d bias
-    with profiler.kernel('hem_score_bwd', batch, dim):
-        _lib.check(lib.ihg_hem_score_bwd(ptrs, n_layers, _ld(layers[0]), dim, _ptr(rows), _ptr(dscores), float(grad_scale), float(lam),
-                                         _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd')
+    rowgrad = _hem_row_gradients(layers, rows, items, bias, lam, dscores, grad_scale)
     n_bias = int(bias.shape[0])
     flat = torch.zeros(n_layers * n_nodes * dim + n_bias, dtype=torch.float32, device=bias.device)
     dense = flat[:n_layers * n_nodes * dim].view(n_layers, n_nodes, dim)
@@ -369,11 +402,77 @@ def _hem_backward(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float,
         with profiler.kernel('batch_scatter_add', 3 * batch, width + 1):
             _lib.check(lib.ihg_batch_scatter_add(_ptr(rowgrad), width + 4, width + 1, _ptr(rows), 3 * batch, _ptr(dense), dim, dim, n_nodes * dim,
                                                  _ptr(dbias), int(item_row_offset), n_bias, _stream()), 'ihg_batch_scatter_add')
-    else:                                                    # batches beyond the kernel's range: torch's sort-based scatter
+    else:
         for l in range(n_layers):
-            dense[l].index_put_((rows,), rowgrad[:, l * dim:(l + 1) * dim], accumulate=True)
-        dbias.index_put_((items,), rowgrad[2 * batch:, width], accumulate=True)
+            _scatter_rows(rowgrad, l * dim, dim, rows, dense[l])
+        _scatter_rows(rowgrad, width, 1, rows, None, dbias, item_row_offset)
     return dbias, tuple(dense[l] for l in range(n_layers))
+
+
+class TailGradients:
+    """Side channel from the batch tail's backward to the taps on the layer outputs (one per training step).
+
+    A layer output ``X_l`` feeds the next layer AND the batch tail; the tail's gradient for it has 3B non-zero rows out of N.
+    Handing autograd a dense ``[N, d]`` tensor per layer costs a zero fill plus one full add per layer; instead the tail's
+    backward leaves its ``[3B, .]`` row gradients here and every ``tap`` adds its own columns into the gradient that came
+    down from the next layer, in place."""
+
+    def __init__(self):
+        self.rows: Optional[Tensor] = None
+        self.rowgrad: Optional[Tensor] = None      # [3B, .], rows of equal destination already summed into their first occurrence
+        self.leader: Optional[Tensor] = None       # int32 [3B]: 1 on those first occurrences (None: rowgrad is not combined)
+
+    def add_into(self, dense: Optional[Tensor], col0: int, width: int, tail: Optional[Tensor] = None, tail_offset: int = 0) -> None:
+        """``dense[rows[k]] += rowgrad[k, col0 : col0 + width]`` (or ``tail[rows[k] - tail_offset] += rowgrad[k, col0]``)."""
+        if self.leader is None:
+            _scatter_rows(self.rowgrad, col0, width, self.rows, dense, tail, tail_offset)
+            return
+        lib = _lib.load()
+        n = int(self.rows.shape[0])
+        src = self.rowgrad[:, col0:]
+        with profiler.kernel('batch_rows_add', n, width):
+            _lib.check(lib.ihg_batch_rows_add(_ptr(src), int(self.rowgrad.stride(0)), width, _ptr(self.rows), _ptr(self.leader), n, _ptr(dense),
+                                              _ld(dense) if dense is not None else 0, _ptr(tail), int(tail_offset),
+                                              int(tail.shape[0]) if tail is not None else 0, _stream()), 'ihg_batch_rows_add')
+
+
+class _Tap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, holder: TailGradients, index: int):
+        ctx.holder, ctx.index = holder, int(index)
+        ctx.shape, ctx.device = tuple(x.shape), x.device
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_next: Optional[Tensor], g_tail: Optional[Tensor]):
+        holder, (n, dim) = ctx.holder, ctx.shape
+        if holder.rowgrad is None:                           # the tail did not run a backward through this holder
+            if g_next is None or g_tail is None:
+                return (g_next if g_next is not None else g_tail), None, None
+            return g_next + g_tail, None, None
+        if g_next is None:
+            g = torch.zeros(n, dim, dtype=torch.float32, device=ctx.device)
+        else:
+            g = g_next if (g_next.is_contiguous() and g_next.dtype == torch.float32) else g_next.contiguous().float()
+        holder.add_into(g, ctx.index * dim, dim)
+        return g, None, None
+
+
+def tap(x: Tensor, holder: TailGradients, index: int):
+    """``(x for the next layer, x for the batch tail)``: same values; see ``TailGradients``."""
+    return _Tap.apply(x, holder, int(index))
+
+
+_ZERO_SCALARS = {}
+
+
+def _zero_like_expanded(shape, device: torch.device) -> Tensor:
+    """A zero tensor of ``shape`` that owns one element (stride 0): placeholder gradient, never read."""
+    z = _ZERO_SCALARS.get(device)
+    if z is None:
+        z = _ZERO_SCALARS[device] = torch.zeros((), dtype=torch.float32, device=device)
+    return z.expand(*shape)
 
 
 def _same_layout(layers):
@@ -408,10 +507,11 @@ class _HemScore(torch.autograd.Function):
 
 class _HemBceLoss(torch.autograd.Function):
     """Scores + mean BCE-with-logits in the forward; d loss / d scores is produced there too, so the backward starts at the
-    per-row gradient kernel."""
+    per-row gradient kernel.  With a ``TailGradients`` holder the layer gradients leave through the taps (placeholders are
+    returned here); without one they are returned dense."""
 
     @staticmethod
-    def forward(ctx, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int, *layers: Tensor) -> Tensor:
+    def forward(ctx, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int, holder, *layers: Tensor) -> Tensor:
         lib = _lib.load()
         layers = _same_layout(layers)
         batch, dim = int(items.shape[0]), int(layers[0].shape[1])
@@ -425,14 +525,28 @@ class _HemBceLoss(torch.autograd.Function):
                                              batch, _stream()), 'ihg_hem_score_fwd')
             _lib.check(lib.ihg_bce_with_logits(_ptr(scores), _ptr(labels), batch, _ptr(loss), _ptr(dscores), _stream()), 'ihg_bce_with_logits')
         ctx.save_for_backward(rows, items, bias, dscores, *layers)
-        ctx.lam, ctx.offset = float(lam), int(item_row_offset)
+        ctx.lam, ctx.offset, ctx.holder = float(lam), int(item_row_offset), holder
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss: Tensor):
         rows, items, bias, dscores, *layers = ctx.saved_tensors
-        dbias, grads = _hem_backward(layers, rows, items, bias, ctx.lam, dscores, float(grad_loss), ctx.offset)
-        return (None, None, None, dbias, None, None) + grads
+        if ctx.holder is None:
+            dbias, grads = _hem_backward(layers, rows, items, bias, ctx.lam, dscores * grad_loss, 1.0, ctx.offset)
+            return (None, None, None, dbias, None, None, None) + grads
+        holder = ctx.holder
+        rowgrad = _hem_row_gradients(layers, rows, items, bias, ctx.lam, dscores * grad_loss, 1.0)     # no host read of grad_loss: no sync
+        holder.rows, holder.rowgrad, holder.leader = rows, rowgrad, None
+        lib = _lib.load()
+        n, width = int(rows.shape[0]), len(layers) * int(layers[0].shape[1])
+        if lib.ihg_batch_scatter_workspace_bytes(n) >= 0:    # one pass sums duplicate destinations; the taps then add plain rows
+            holder.leader = torch.empty(n, dtype=torch.int32, device=rows.device)
+            with profiler.kernel('batch_combine', n, width + 1):
+                _lib.check(lib.ihg_batch_combine(_ptr(rowgrad), int(rowgrad.stride(0)), width + 1, _ptr(rows), n, _ptr(holder.leader), _stream()),
+                           'ihg_batch_combine')
+        dbias = torch.zeros_like(bias)
+        holder.add_into(None, width, 1, dbias, ctx.offset)
+        return (None, None, None, dbias, None, None, None) + tuple(_zero_like_expanded(x.shape, x.device) for x in layers)
 
 
 def hem_score(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, item_row_offset: int) -> Tensor:
@@ -441,6 +555,8 @@ def hem_score(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, ite
     return _HemScore.apply(rows, items, bias, float(lam), int(item_row_offset), *layers)
 
 
-def hem_bce_loss(layers, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int) -> Tensor:
-    """``nn.BCEWithLogitsLoss()(hem_score(...), labels)`` as one differentiable op (scalar)."""
-    return _HemBceLoss.apply(rows, items, labels, bias, float(lam), int(item_row_offset), *layers)
+def hem_bce_loss(layers, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int,
+                 holder: Optional[TailGradients] = None) -> Tensor:
+    """``nn.BCEWithLogitsLoss()(hem_score(...), labels)`` as one differentiable op (scalar).  ``holder``: the layers are the
+    tail halves of ``tap`` outputs made with this holder, and their gradients travel through it (see ``TailGradients``)."""
+    return _HemBceLoss.apply(rows, items, labels, bias, float(lam), int(item_row_offset), holder, *layers)

@@ -556,6 +556,37 @@ def test_batch_scatter_add_matches_index_put(n, width):
         assert rel(tail, want[100:, width - 1]) <= RTOL_SUM
 
 
+@pytest.mark.parametrize('n,width', [(1, 5), (700, 65), (3300, 193), (16384, 33)])
+def test_batch_combine_then_rows_add(n, width):
+    """Two-stage form of the scatter: duplicates are summed into their first occurrence in place, then leader rows are added
+    into (several) non-zero destinations; equals index_put_(accumulate=True) on top of the old contents, bitwise repeatable."""
+    from ihgnn_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(n + width)
+    n_dense = max(5000, n)
+    rows = torch.randint(0, max(2, n // 3), (n,), generator=gen).to(dev())
+    rowgrad = torch.randn(n, width + 3, generator=gen).to(dev())
+    base = torch.randn(n_dense, width - 1, generator=gen).to(dev())
+    want = base.clone().index_put_((rows,), rowgrad[:, :width - 1], accumulate=True)
+    want_tail = torch.zeros(n_dense, device=dev()).index_put_((rows,), rowgrad[:, width - 1], accumulate=True)[100:]
+    outs = []
+    for _ in range(2):
+        combined, leader = rowgrad.clone(), torch.full((n,), -1, dtype=torch.int32, device=dev())
+        _lib.check(lib.ihg_batch_combine(ops._ptr(combined), combined.stride(0), width, ops._ptr(rows), n, ops._ptr(leader), ops._stream()), 'combine')
+        assert int(leader.sum()) == int(rows.unique().numel()) and bool(((leader == 0) | (leader == 1)).all())
+        dense, tail = base.clone(), torch.zeros(n_dense - 100, device=dev())
+        half = (width - 1) // 2
+        for col0, w_ in ((0, half), (half, width - 1 - half)):               # two column windows, as two layers would take them
+            if w_ > 0:
+                _lib.check(lib.ihg_batch_rows_add(ops._ptr(combined[:, col0:]), combined.stride(0), w_, ops._ptr(rows), ops._ptr(leader), n,
+                                                  ops._ptr(dense[:, col0:]), dense.stride(0), None, 0, 0, ops._stream()), 'rows_add')
+        _lib.check(lib.ihg_batch_rows_add(ops._ptr(combined[:, width - 1:]), combined.stride(0), 1, ops._ptr(rows), ops._ptr(leader), n, None, 0,
+                                          ops._ptr(tail), 100, n_dense - 100, ops._stream()), 'rows_add tail')
+        outs.append((dense, tail))
+    assert rel(outs[0][0], want) <= RTOL_SUM and rel(outs[0][1], want_tail) <= RTOL_SUM
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_fused_bce_tail_equals_unfused_path():
     """model.bce_loss (scores + BCE + per-row gradients + one scatter) against BCEWithLogitsLoss()(model(u,q,i), y)."""
     from ihgnn_amd import synth
