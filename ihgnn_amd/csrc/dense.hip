@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlockThreads) void pack_dense_kernel(const float* 
 template <int D>
 __global__ __launch_bounds__(kBlockThreads) void row_gemm_kernel(const float* __restrict__ in, int64_t ld_in, const float* __restrict__ pk,
                                                                  int64_t pk_type_stride, const float* __restrict__ bias, int bias_mask,
-                                                                 TypePlan plan, float* __restrict__ out, int64_t ld_out) {
+                                                                 int64_t bias_type_stride, TypePlan plan, float* __restrict__ out, int64_t ld_out) {
     constexpr int ET = D == 32 ? 4 : 2, TE = ET * 32, STRIDE = D + kRowPad, JOBS = ET * (D / 32);
     constexpr int V4_PER_ROW = D / 4, LOADS = TE * V4_PER_ROW / kBlockThreads, T_STEPS = D / 8;
     constexpr int JOBS_PER_WAVE = JOBS / kWavesPerBlock;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_kernel(const float* __
                     for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bf[s2], acc, 0, 0, 0);
                 }
                 const int c = ct * 32 + (lane & 31);
-                const float bv = with_bias ? bias[c] : 0.f;
+                const float bv = with_bias ? bias[type * bias_type_stride + c] : 0.f;
                 float* orow = out + (r_base + et * 32) * ld_out + c;
                 if (r_base + TE <= r_end) {
 #pragma unroll
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_kernel(const 
 
 __global__ __launch_bounds__(kBlockThreads) void dense_slab_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
                                                                           int n_slabs, int n_types, int d, float* __restrict__ dw, int64_t ld_dw,
-                                                                          int64_t dw_type_stride, float* __restrict__ dbias, int bias_mask) {
+                                                                          int64_t dw_type_stride, float* __restrict__ dbias, int bias_mask,
+                                                                          int64_t dbias_type_stride) {
     const int64_t per_type = static_cast<int64_t>(d) * d;
     const int64_t w_items = per_type * n_types;
     const int64_t total = w_items + d;
@@ -245,8 +246,9 @@ __global__ __launch_bounds__(kBlockThreads) void dense_slab_reduce_kernel(const 
                 const bool use = n_types == 1 || ((bias_mask >> type) & 1);
                 const float part = slab_sum(bias_slabs + static_cast<int64_t>(type) * n_slabs * d, n_slabs, d, c, use && c < d);
                 acc += part;
+                if (dbias_type_stride != 0 && first_wave && c < d && dbias != nullptr) dbias[type * dbias_type_stride + c] = use ? part : 0.f;
             }
-            if (first_wave && c < d && dbias != nullptr) dbias[c] = acc;
+            if (dbias_type_stride == 0 && first_wave && c < d && dbias != nullptr) dbias[c] = acc;
         }
     }
 }
@@ -265,7 +267,8 @@ inline TypePlan make_plan(const int64_t* type_begin, int tile_rows) {
 constexpr int kDenseSlabs = 256;
 
 int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose,
-                    const float* bias, int bias_mask, const int64_t* type_begin, float* out, int64_t ld_out, float* pk, hipStream_t s) {
+                    const float* bias, int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, float* pk,
+                    hipStream_t s) {
     const int n_types = w_type_stride == 0 ? 1 : 3;
     const int pack_items = n_types * (dim / 32) * (dim / 8) * kWave;
     hipLaunchKernelGGL(pack_dense_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride,
@@ -274,7 +277,7 @@ int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int
     const TypePlan plan = make_plan(type_begin, dim == 32 ? 128 : 64);
     if (plan.tile_prefix[3] == 0) return IHG_OK;
     const int grid = std::min(plan.tile_prefix[3], 256 * 4);
-#define IHG_RG(D) hipLaunchKernelGGL((row_gemm_kernel<D>), dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, pk_type_stride, bias, bias_mask, plan, out, ld_out)
+#define IHG_RG(D) hipLaunchKernelGGL((row_gemm_kernel<D>), dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, pk_type_stride, bias, bias_mask, bias_type_stride, plan, out, ld_out)
     switch (dim) {
         case 32: IHG_RG(32); break;
         case 64: IHG_RG(64); break;
@@ -308,13 +311,13 @@ static int node_linear_common_check(const char* what, int32_t dim, int64_t ld_a,
 }
 
 int ihg_node_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, int64_t w_type_stride, const float* bias,
-                        int32_t bias_type_mask, const int64_t* type_begin, float* out, int64_t ld_out, void* workspace,
+                        int32_t bias_type_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, void* workspace,
                         int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
     if (int rc = node_linear_common_check("ihg_node_linear_fwd", dim, ld_x, ld_out, ld_w, type_begin, workspace, workspace_bytes)) return rc;
     if (type_begin[3] == type_begin[0]) return IHG_OK;
     if (x == nullptr || w == nullptr || out == nullptr || !aligned16(x)) return fail(IHG_ERR_INVALID, "ihg_node_linear_fwd: null or unaligned pointer");
-    launch_row_gemm(dim, x, ld_x, w, ld_w, w_type_stride, 0, bias, bias_type_mask, type_begin, out, ld_out, static_cast<float*>(workspace),
-                    static_cast<hipStream_t>(stream));
+    launch_row_gemm(dim, x, ld_x, w, ld_w, w_type_stride, 0, bias, bias_type_mask, bias_type_stride, type_begin, out, ld_out,
+                    static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
     return check_launch("ihg_node_linear_fwd");
 }
 
@@ -324,13 +327,13 @@ int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w
     if (int rc = node_linear_common_check("ihg_node_linear_bwd_input", dim, ld_dout, ld_dx, ld_w, type_begin, workspace, workspace_bytes)) return rc;
     if (type_begin[3] == type_begin[0]) return IHG_OK;
     if (dout == nullptr || w == nullptr || dx == nullptr || !aligned16(dout)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_input: null or unaligned pointer");
-    launch_row_gemm(dim, dout, ld_dout, w, ld_w, w_type_stride, 1, nullptr, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace),
+    launch_row_gemm(dim, dout, ld_dout, w, ld_w, w_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace),
                     static_cast<hipStream_t>(stream));
     return check_launch("ihg_node_linear_bwd_input");
 }
 
 int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin,
-                               float* dw, int64_t ld_dw, int64_t dw_type_stride, float* dbias, int32_t bias_type_mask,
+                               float* dw, int64_t ld_dw, int64_t dw_type_stride, float* dbias, int32_t bias_type_mask, int64_t dbias_type_stride,
                                void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
     if (int rc = node_linear_common_check("ihg_node_linear_bwd_weight", dim, ld_dout, ld_x, ld_dw, type_begin, workspace, workspace_bytes)) return rc;
     if (dout == nullptr || x == nullptr || dw == nullptr || !aligned16(dout) || !aligned16(x)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: null or unaligned pointer");
@@ -349,7 +352,7 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     }
     const int total = dim * dim * n_types + dim;
     hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, bias_slabs,
-                       kDenseSlabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask);
+                       kDenseSlabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask, n_types == 1 ? int64_t{0} : dbias_type_stride);
     return check_launch("ihg_node_linear_bwd_weight");
 }
 

@@ -259,11 +259,17 @@ class _NodeLinear(torch.autograd.Function):
         out = torch.empty(x.shape[0], dim, dtype=torch.float32, device=x.device)
         ws = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), x.device)
         stride = dim if typed else 0
+        per_type_bias = bias is not None and bias.dim() == 2                       # [3, d]: one bias vector per node type
+        if per_type_bias:
+            if not typed or tuple(bias.shape) != (3, dim):
+                raise ValueError(f'a per-type bias is [3, {dim}] and needs typed weights, got {tuple(bias.shape)}')
+            bias = bias.contiguous()
         with profiler.kernel('node_linear_fwd', x.shape[0], dim):
-            _lib.check(lib.ihg_node_linear_fwd(_ptr(x), _ld(x), _ptr(w), int(w.stride(0)), stride, _ptr(bias), bias_mask, _type_begin(layout),
-                                               _ptr(out), _ld(out), _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_fwd')
+            _lib.check(lib.ihg_node_linear_fwd(_ptr(x), _ld(x), _ptr(w), int(w.stride(0)), stride, _ptr(bias), bias_mask, dim if per_type_bias else 0,
+                                               _type_begin(layout), _ptr(out), _ld(out), _ptr(ws), ws.numel() * 4, dim, _stream()),
+                       'ihg_node_linear_fwd')
         ctx.save_for_backward(x, w)
-        ctx.layout, ctx.typed, ctx.bias_mask, ctx.has_bias = layout, typed, bias_mask, bias is not None
+        ctx.layout, ctx.typed, ctx.bias_mask, ctx.has_bias, ctx.per_type_bias = layout, typed, bias_mask, bias is not None, per_type_bias
         return out
 
     @staticmethod
@@ -283,18 +289,21 @@ class _NodeLinear(torch.autograd.Function):
             with profiler.kernel('node_linear_bwd_input', x.shape[0], dim):
                 _lib.check(lib.ihg_node_linear_bwd_input(_ptr(g), _ld(g), _ptr(w), int(w.stride(0)), stride, tb, _ptr(dx), _ld(dx),
                                                          _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_bwd_input')
-        dw = torch.zeros_like(w) if w.shape[1] != dim else torch.empty_like(w)      # product-block columns of a [d, k*d] weight stay 0
-        dbias = torch.empty(dim, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        dw = torch.zeros_like(w) if w.shape[1] != dim * (3 if ctx.typed else 1) else torch.empty_like(w)   # product-block columns of a [d, k*d] weight stay 0
+        dbias = None
+        if ctx.has_bias:
+            dbias = torch.empty((3, dim) if ctx.per_type_bias else (dim,), dtype=torch.float32, device=x.device)
         with profiler.kernel('node_linear_bwd_weight', x.shape[0], dim):
             _lib.check(lib.ihg_node_linear_bwd_weight(_ptr(g), _ld(g), _ptr(x), _ld(x), tb, _ptr(dw), int(dw.stride(0)), stride,
-                                                      _ptr(dbias), ctx.bias_mask, _ptr(ws), ws.numel() * 4, dim, _stream()),
-                       'ihg_node_linear_bwd_weight')
+                                                      _ptr(dbias), ctx.bias_mask, dim if ctx.per_type_bias else 0, _ptr(ws), ws.numel() * 4, dim,
+                                                      _stream()), 'ihg_node_linear_bwd_weight')
         return dx, dw, dbias, None, None, None
 
 
 def node_linear(x: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, typed: bool = False, bias_mask: int = 0b111) -> Tensor:
     """``out[v] = x[v] @ W_type(v).T (+ bias)``.  ``typed=False``: one ``[d,d]`` weight for every node; ``typed=True``:
-    ``w`` is ``[d, k*d]`` and node type t uses its column block ``w[:, t*d:(t+1)*d]``; bias is added to the types in ``bias_mask``."""
+    ``w`` is ``[d, k*d]`` and node type t uses its column block ``w[:, t*d:(t+1)*d]``; a ``[d]`` bias is added to the types in
+    ``bias_mask``, a ``[3, d]`` bias gives every (masked) type its own vector."""
     return _NodeLinear.apply(x, w, bias, layout, bool(typed), int(bias_mask))
 
 

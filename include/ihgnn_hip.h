@@ -189,16 +189,18 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3,
  *
  * Nodes are typed by contiguous row ranges: type t = rows [type_begin[t], type_begin[t+1]), t = 0,1,2 (host int64[4]).
  * W_t[c][j] = w[c * ld_w + t * w_type_stride + j]; w_type_stride == 0 means one weight for every row.
- *   fwd        out[v,:] = x[v,:] * W_t^T  (+ bias if bit t of bias_type_mask is set)
+ *   fwd        out[v,:] = x[v,:] * W_t^T  (+ bias_t if bit t of bias_type_mask is set; bias_t = bias + t * bias_type_stride,
+ *              stride 0 = one bias vector shared by the masked types)
  *   bwd_input  dx[v,:]  = dout[v,:] * W_t
  *   bwd_weight dW_t     = sum_{v in t} dout[v,:]^T x[v,:]      (one dW over all rows if dw_type_stride == 0)
- *              dbias[c] = sum over rows of the masked types of dout[v,c]     (dbias may be NULL)
+ *              dbias[c] = sum over rows of the masked types of dout[v,c]     (dbias may be NULL); with dbias_type_stride != 0
+ *              (typed weights only) every type gets its own sum at dbias + t * dbias_type_stride, 0 for unmasked types
  * dim must be 32, 64, 128 or 256 with 16-byte aligned rows (ihg_node_linear_workspace_bytes returns -1 otherwise;
  * callers then keep their own GEMM).  `workspace`: ihg_node_linear_workspace_bytes(dim) bytes, 16-byte aligned.
  */
 int64_t ihg_node_linear_workspace_bytes(int32_t dim);
 int ihg_node_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, int64_t w_type_stride,
-                        const float* bias, int32_t bias_type_mask, const int64_t* type_begin,
+                        const float* bias, int32_t bias_type_mask, int64_t bias_type_stride, const int64_t* type_begin,
                         float* out, int64_t ld_out, void* workspace, int64_t workspace_bytes,
                         int32_t dim, ihg_stream_t stream);
 int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w, int64_t ld_w, int64_t w_type_stride,
@@ -206,7 +208,7 @@ int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w
                               void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream);
 int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* x, int64_t ld_x,
                                const int64_t* type_begin, float* dw, int64_t ld_dw, int64_t dw_type_stride,
-                               float* dbias, int32_t bias_type_mask,
+                               float* dbias, int32_t bias_type_mask, int64_t dbias_type_stride,
                                void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -216,6 +216,28 @@ def test_node_linear_forward_backward(dim, typed):
         assert (wg.grad[:, 3 * dim:] == 0).all()
 
 
+@pytest.mark.parametrize('dim', [32, 64, 128])
+def test_node_linear_with_per_type_bias(dim):
+    """Typed weights with one bias vector per node type (the composed first-order layer): forward and all gradients vs torch."""
+    from ihgnn_amd import ops
+    U, Q, I = 70, 9, 131
+    _, lay = make_layout(U, Q, I, 50, seed=dim + 3)
+    gen = torch.Generator().manual_seed(dim + 11)
+    x = torch.randn(lay.node_count, dim, generator=gen)
+    w = torch.randn(dim, 3 * dim, generator=gen) / np.sqrt(dim)
+    b = torch.randn(3, dim, generator=gen)
+    cot = torch.randn(lay.node_count, dim, generator=gen)
+    xc, wc, bc = (t.clone().requires_grad_(True) for t in (x, w, b))
+    want = torch.cat([torch.nn.functional.linear(xc[:U], wc[:, :dim], bc[0]), torch.nn.functional.linear(xc[U:U + Q], wc[:, dim:2 * dim], bc[1]),
+                      torch.nn.functional.linear(xc[U + Q:], wc[:, 2 * dim:], bc[2])])
+    want.backward(cot)
+    xg, wg, bg = (t.clone().to(dev()).requires_grad_(True) for t in (x, w, b))
+    got = ops.node_linear(xg, wg, bg, lay, typed=True, bias_mask=0b111)
+    got.backward(cot.to(dev()))
+    assert rel(got, want) <= RTOL_SUM * 2
+    assert rel(xg.grad, xc.grad) <= RTOL_SUM * 2 and rel(wg.grad, wc.grad) <= RTOL and rel(bg.grad, bc.grad) <= RTOL
+
+
 @pytest.mark.parametrize('dim,order', [(8, 2), (8, 3), (12, 3), (32, 2), (32, 3), (64, 2), (64, 3), (128, 3)])
 def test_interact_forward_backward(dim, order):
     from ihgnn_amd import ops
