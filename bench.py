@@ -126,7 +126,8 @@ def main():
                                   w.triples, device=dev)
     model = build_model(ds, dev, args.layer, layers, args.order, dim)
     _ = ds.hypergraph.layout
-    opt = torch.optim.Adam(model.parameters(), 1e-3, weight_decay=0, fused=True)     # same update rule, one kernel
+    from ihgnn_amd.optim import Adam
+    opt = Adam(model.parameters(), 1e-3, weight_decay=0)     # torch.optim.Adam's update rule, one HIP launch
     lossf = torch.nn.BCEWithLogitsLoss()
     sync = ihg_dist.GradientSync(model.parameters()) if world > 1 else None
     if sync is not None:

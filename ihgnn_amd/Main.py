@@ -94,7 +94,8 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
                    gnn_layer_count=layer_count, predictions=HemPredictionLayer, lambda_muq=Gs.lambda_muq_for_hem,
                    feature_interaction_order=order, phase2_attention=False).to(device)
     loss_function = nn.BCEWithLogitsLoss().to(device)
-    optimizer = torch.optim.Adam(model.parameters(), Gs.learning_rate, weight_decay=Gs.weight_decay, fused=True)
+    from .optim import Adam
+    optimizer = Adam(model.parameters(), Gs.learning_rate, weight_decay=Gs.weight_decay)      # torch.optim.Adam's rule (Main.py:192), one launch
 
     epoch_start = 1
     if args.checkpoint:

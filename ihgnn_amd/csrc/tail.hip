@@ -188,6 +188,67 @@ __global__ __launch_bounds__(kBlockThreads) void batch_rows_add_kernel(const flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Adam over a list of tensors in one launch (pointer table passed by value): a pure stream, 7 passes of 4 bytes per parameter.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAdamMaxTensors = 24;
+constexpr int kAdamChunk = 4096;                            // elements per workgroup trip
+
+struct AdamTable {
+    float* param[kAdamMaxTensors];
+    const float* grad[kAdamMaxTensors];
+    float* exp_avg[kAdamMaxTensors];
+    float* exp_avg_sq[kAdamMaxTensors];
+    int64_t chunk_begin[kAdamMaxTensors + 1];               // prefix of ceil(n / kAdamChunk)
+    int64_t count[kAdamMaxTensors];
+    int n_tensors;
+};
+
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float beta1, float beta2, float eps, float weight_decay,
+                                            float step_size, float bias2_sqrt) {
+    g = weight_decay != 0.f ? g + weight_decay * p : g;
+    m = m + (g - m) * (1.f - beta1);                        // torch's lerp form
+    v = beta2 * v + (1.f - beta2) * g * g;
+    const float denom = sqrtf(v) / bias2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void adam_kernel(AdamTable tab, float beta1, float beta2, float eps, float weight_decay, float step_size,
+                                                             float bias2_sqrt) {
+    const int64_t total_chunks = tab.chunk_begin[tab.n_tensors];
+    for (int64_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+        int t = 0;
+        while (chunk >= tab.chunk_begin[t + 1]) ++t;
+        const int64_t base = (chunk - tab.chunk_begin[t]) * kAdamChunk;
+        const int64_t n = tab.count[t];
+        float* __restrict__ p = tab.param[t];
+        const float* __restrict__ g = tab.grad[t];
+        float* __restrict__ m = tab.exp_avg[t];
+        float* __restrict__ v = tab.exp_avg_sq[t];
+        const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+        if (vec && base + kAdamChunk <= n) {
+#pragma unroll
+            for (int k = 0; k < kAdamChunk / (4 * kBlockThreads); ++k) {
+                const int64_t i = base + (threadIdx.x + k * kBlockThreads) * 4;
+                v4f pv = *reinterpret_cast<const v4f*>(p + i), mv = *reinterpret_cast<const v4f*>(m + i), vv = *reinterpret_cast<const v4f*>(v + i);
+                const v4f gv = *reinterpret_cast<const v4f*>(g + i);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float pc = pv[c], mc = mv[c], vc = vv[c];
+                    adam_update(pc, gv[c], mc, vc, beta1, beta2, eps, weight_decay, step_size, bias2_sqrt);
+                    pv[c] = pc; mv[c] = mc; vv[c] = vc;
+                }
+                *reinterpret_cast<v4f*>(p + i) = pv;
+                *reinterpret_cast<v4f*>(m + i) = mv;
+                *reinterpret_cast<v4f*>(v + i) = vv;
+            }
+        } else {
+            for (int64_t i = base + threadIdx.x; i < base + kAdamChunk && i < n; i += kBlockThreads)
+                adam_update(p[i], g[i], m[i], v[i], beta1, beta2, eps, weight_decay, step_size, bias2_sqrt);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -269,5 +330,37 @@ int ihg_batch_rows_add(const float* src, int64_t ld_src, int32_t width, const in
     hipLaunchKernelGGL(batch_rows_add_kernel, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), src, ld_src, width,
                        rows, leader, static_cast<int>(n_rows), dense, ld_dense, tail, tail_row_offset, tail_rows);
     return check_launch("ihg_batch_rows_add");
+}
+
+int ihg_adam_step(const ihg_adam_tensor* tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t step, ihg_stream_t stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && tensors == nullptr) || step < 1) return fail(IHG_ERR_INVALID, "ihg_adam_step: bad argument");
+    const double bias1 = 1.0 - std::pow(static_cast<double>(beta1), static_cast<double>(step));
+    const double bias2 = 1.0 - std::pow(static_cast<double>(beta2), static_cast<double>(step));
+    const float step_size = static_cast<float>(static_cast<double>(lr) / bias1);
+    const float bias2_sqrt = static_cast<float>(std::sqrt(bias2));
+    for (int first = 0; first < n_tensors; first += kAdamMaxTensors) {
+        AdamTable tab{};
+        int64_t chunks = 0;
+        int used = 0;
+        for (int t = first; t < n_tensors && used < kAdamMaxTensors; ++t) {
+            const ihg_adam_tensor& a = tensors[t];
+            if (a.count < 0 || (a.count > 0 && (a.param == nullptr || a.grad == nullptr || a.exp_avg == nullptr || a.exp_avg_sq == nullptr)))
+                return fail(IHG_ERR_INVALID, "ihg_adam_step: tensor %d has a null pointer or a negative count", t);
+            if (a.count == 0) continue;
+            tab.param[used] = a.param; tab.grad[used] = a.grad; tab.exp_avg[used] = a.exp_avg; tab.exp_avg_sq[used] = a.exp_avg_sq;
+            tab.count[used] = a.count;
+            tab.chunk_begin[used] = chunks;
+            chunks += (a.count + kAdamChunk - 1) / kAdamChunk;
+            ++used;
+        }
+        tab.chunk_begin[used] = chunks;
+        tab.n_tensors = used;
+        if (used == 0) continue;
+        const int grid = static_cast<int>(std::min<int64_t>(chunks, 256 * 16));
+        hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), tab, beta1, beta2, eps, weight_decay,
+                           step_size, bias2_sqrt);
+    }
+    return check_launch("ihg_adam_step");
 }
 }  // extern "C"

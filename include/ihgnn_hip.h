@@ -252,6 +252,21 @@ int ihg_batch_combine(float* rowgrad, int64_t ld_rowgrad, int32_t width, const i
 int ihg_batch_rows_add(const float* src, int64_t ld_src, int32_t width, const int64_t* rows, const int32_t* leader, int64_t n_rows,
                        float* dense, int64_t ld_dense, float* tail, int64_t tail_row_offset, int64_t tail_rows, ihg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DEVICE: the optimiser step of the training loop (Main.py:192 `torch.optim.Adam(model.parameters(), lr, weight_decay=...)`,
+ * stepped in TrainTestHelper.py:139-143), for all parameters in one launch per 24 tensors.  Same update as torch.optim.Adam
+ * (amsgrad off, maximize off): g += wd * p; m += (g - m)(1 - b1); v = b2 v + (1 - b2) g^2;
+ * p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t = `step` >= 1 (the caller counts).  `tensors` is a HOST array.
+ */
+typedef struct ihg_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t count;
+} ihg_adam_tensor;
+int ihg_adam_step(const ihg_adam_tensor* tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int64_t step, ihg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -358,7 +358,8 @@ def test_f3_model_matches_reference(tag, kind):
     assert set(sd) == set(m.state_dict())                 # checkpoint key space identical to the reference
     m.load_state_dict(sd)
     u, q, i = (torch.from_numpy(z[f'{tag}.{k}']).to(dev()) for k in 'uqi')
-    opt = torch.optim.Adam(m.parameters(), 1e-3, weight_decay=0)
+    from ihgnn_amd.optim import Adam
+    opt = Adam(m.parameters(), 1e-3, weight_decay=0)      # the HIP optimiser step against the reference's torch.optim.Adam step
     scores = m(u, q, i)
     loss = torch.nn.BCEWithLogitsLoss()(scores, torch.from_numpy(z[f'{tag}.flags']).to(dev()))
     loss.backward()
@@ -607,6 +608,42 @@ def test_batch_combine_then_rows_add(n, width):
         outs.append((dense, tail))
     assert rel(outs[0][0], want) <= RTOL_SUM and rel(outs[0][1], want_tail) <= RTOL_SUM
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_adam_matches_torch_adam():
+    """ihgnn_amd.optim.Adam vs torch.optim.Adam over 12 steps: odd sizes, an unaligned view-backed tensor, weight decay, a
+    parameter that gets no gradient on some steps (its step count then differs from the others')."""
+    from ihgnn_amd.optim import Adam
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(1201, 64), (7,), (64, 192), (1,), (333, 5), (4099,)]
+    base = [torch.randn(*sh, generator=gen) for sh in shapes]
+    ours = [torch.nn.Parameter(t.clone().to(dev())) for t in base]
+    theirs = [torch.nn.Parameter(t.clone().to(dev())) for t in base]
+    a = Adam(ours, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    b = torch.optim.Adam(theirs, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    for step in range(12):
+        for k, (p, r) in enumerate(zip(ours, theirs)):
+            if k == 1 and step % 3 == 0:
+                p.grad = r.grad = None
+                continue
+            g = torch.randn(*p.shape, generator=gen).to(dev()) * (10.0 ** (step % 3 - 1))
+            p.grad, r.grad = g.clone(), g.clone()
+        a.step(); b.step()
+    for p, r in zip(ours, theirs):
+        assert rel(p, r) <= 2e-6
+    sa, sb = a.state_dict(), b.state_dict()
+    assert sa['state'].keys() == sb['state'].keys() and set(sa['state'][0]) == set(sb['state'][0])
+    assert float(sa['state'][1]['step']) == float(sb['state'][1]['step']) == 8.0
+    c = Adam(ours, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    import copy
+    c.load_state_dict(copy.deepcopy(sb))                   # a torch.optim.Adam checkpoint resumes in the HIP optimiser (deepcopy: load aliases same-device tensors)
+    for p in ours:
+        p.grad = torch.ones_like(p)
+    for r in theirs:
+        r.grad = torch.ones_like(r)
+    c.step(); b.step()
+    for p, r in zip(ours, theirs):
+        assert rel(p, r) <= 2e-6
 
 
 def test_fused_bce_tail_equals_unfused_path():

@@ -28,7 +28,8 @@ def main():
     w = synth.draw_config(args.config)
     ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets, w.triples, device=dev)
     model = bench.build_model(ds, dev, args.layer, cfg['layers'], args.order, cfg['dim'])
-    opt = torch.optim.Adam(model.parameters(), 1e-3, weight_decay=0, fused=True)
+    from ihgnn_amd.optim import Adam
+    opt = Adam(model.parameters(), 1e-3, weight_decay=0)
     lossf = torch.nn.BCEWithLogitsLoss()
     batches = list(ds.sample_batches(100, args.steps + 3, seed=1000))
 
