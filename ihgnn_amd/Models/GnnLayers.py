@@ -73,15 +73,14 @@ class IHGNNLayer(nn.Module):
         """``first_order(feature_transform(x))``.  With no non-linearity between them (``GnnLayers.py:224-227`` +
         ``CommonLayers.py:60-66``) the two linear maps of a first-order layer compose: node type t sees
         ``x (A_t W)^T + (A_t b + [t = user] c)``, one typed row-GEMM over ``[N, d]`` instead of two (and one instead of two in
-        each backward direction); the ``[d, d]`` products are formed per call.  Same reassociation class as the hoisting itself:
+        each backward direction); the ``[d, d]`` products are formed per call by a tiny kernel (``ihg_compose_first_order_fwd``).  Same reassociation class as the hoisting itself:
         <= 5e-7 relative against the reference's order of operations."""
         lin, agg = self.feature_transform, self.feature_interactor.aggregation
         d = lin.in_features
-        if not (lin.in_features == lin.out_features and agg.weight.shape[1] == 3 * d and ops.node_linear_supported(x, lin.weight)):
+        if not (lin.in_features == lin.out_features and agg.out_features == d and agg.weight.shape[1] == 3 * d and lin.bias is not None
+                and ops.node_linear_supported(x, lin.weight)):
             return self.feature_interactor.first_order(_transform(lin, x, self.layout))
-        blocks = agg.weight.view(agg.out_features, 3, d).transpose(0, 1)           # [3, d_out, d]: A_u, A_q, A_i
-        weight = torch.matmul(blocks, lin.weight).transpose(0, 1).reshape(agg.out_features, 3 * d)      # [d_out, 3 d]: A_t W side by side
-        bias = torch.matmul(blocks, lin.bias) + torch.cat([agg.bias.unsqueeze(0), agg.bias.new_zeros(2, agg.out_features)])
+        weight, bias = ops.compose_first_order(agg.weight, agg.bias, lin.weight, lin.bias)      # [d, 3 d]: A_t W side by side; [3, d]
         return ops.node_linear(x, weight, bias, self.layout, typed=True, bias_mask=0b111)
 
 

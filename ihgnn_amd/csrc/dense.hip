@@ -288,6 +288,83 @@ int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int
     return IHG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Composition of the two linear maps of a first-order layer (tiny: 3 d^3 multiply-adds; one thread per output element,
+// sums in index order).  A = aggregation.weight [d, 3d] (blocks A_u | A_q | A_i), c its bias, W / b = feature_transform.
+//   fwd:  We[i][t d + j] = sum_k A[i][t d + k] W[k][j]        be[t][i] = sum_k A[i][t d + k] b[k] + (t == 0 ? c[i] : 0)
+//   bwd:  dA[i][t d + k] = sum_j dWe[i][t d + j] W[k][j] + dbe[t][i] b[k]      dW[k][j] = sum_t sum_i A[i][t d + k] dWe[i][t d + j]
+//         db[k] = sum_t sum_i A[i][t d + k] dbe[t][i]                           dc[i] = dbe[0][i]
+// ------------------------------------------------------------------------------------------------
+// sum_k x[k * sx] * y[k * sy], k < n: eight loads of each operand in flight, four partial sums combined in a fixed order
+__device__ __forceinline__ float strided_dot(const float* __restrict__ x, int64_t sx, const float* __restrict__ y, int64_t sy, int n) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+        float xv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            xv[u] = x[(k + u) * sx];
+            yv[u] = y[(k + u) * sy];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u & 3] += xv[u] * yv[u];
+    }
+    for (; k < n; ++k) acc[k & 3] += x[k * sx] * y[k * sy];
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void compose_fwd_kernel(const float* __restrict__ a, int64_t ld_a, const float* __restrict__ c,
+                                                                    const float* __restrict__ w, int64_t ld_w, const float* __restrict__ b,
+                                                                    float* __restrict__ we, int64_t ld_we, float* __restrict__ be, int d) {
+    const int64_t n_w = 3LL * d * d, total = n_w + 3LL * d;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; idx < total; idx += static_cast<int64_t>(gridDim.x) * kBlockThreads) {
+        if (idx < n_w) {                                    // lanes run over j: W rows coalesced, the A element is a broadcast
+            const int i = static_cast<int>(idx / (3 * d)), col = static_cast<int>(idx % (3 * d)), t = col / d, j = col % d;
+            we[i * ld_we + col] = strided_dot(a + i * ld_a + t * d, 1, w + j, ld_w, d);
+        } else {
+            const int r = static_cast<int>(idx - n_w), t = r / d, i = r % d;
+            be[r] = strided_dot(a + i * ld_a + t * d, 1, b, 1, d) + (t == 0 && c != nullptr ? c[i] : 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void compose_bwd_kernel(const float* __restrict__ a, int64_t ld_a, const float* __restrict__ w, int64_t ld_w,
+                                                                    const float* __restrict__ b, const float* __restrict__ dwe, int64_t ld_dwe,
+                                                                    const float* __restrict__ dbe, float* __restrict__ da, int64_t ld_da,
+                                                                    float* __restrict__ dc, float* __restrict__ dw, int64_t ld_dw,
+                                                                    float* __restrict__ db, int d) {
+    // part 1, one WAVE per element of dA (both operands are contiguous in the summation index j: lanes run over j)
+    const int lane = threadIdx.x & 63;
+    const int64_t n_a = 3LL * d * d;
+    for (int64_t o = global_wave_id(); o < n_a; o += global_wave_count()) {
+        const int i = static_cast<int>(o / (3 * d)), col = static_cast<int>(o % (3 * d)), t = col / d, k = col % d;
+        const float* grow = dwe + i * ld_dwe + t * d;
+        const float* wrow = w + k * ld_w;
+        float acc = 0.f;
+        for (int j = lane; j < d; j += kWave) acc += grow[j] * wrow[j];
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);      // butterfly: every lane ends with the same, order-fixed sum
+        if (lane == 0) da[i * ld_da + col] = acc + dbe[t * d + i] * b[k];
+    }
+    // part 2, one THREAD per element of dW / db / dc (lanes run over the output column: coalesced rows, broadcast scalars)
+    const int64_t n_w = static_cast<int64_t>(d) * d, total = n_w + 2LL * d;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; idx < total; idx += static_cast<int64_t>(gridDim.x) * kBlockThreads) {
+        if (idx < n_w) {
+            const int k = static_cast<int>(idx / d), j = static_cast<int>(idx % d);
+            float acc = 0.f;
+            for (int t = 0; t < 3; ++t) acc += strided_dot(a + t * d + k, ld_a, dwe + t * d + j, ld_dwe, d);
+            dw[k * ld_dw + j] = acc;
+        } else if (idx < n_w + d) {
+            const int k = static_cast<int>(idx - n_w);
+            float acc = 0.f;
+            for (int t = 0; t < 3; ++t) acc += strided_dot(a + t * d + k, ld_a, dbe + t * d, 1, d);
+            db[k] = acc;
+        } else {
+            const int i = static_cast<int>(idx - n_w - d);
+            if (dc != nullptr) dc[i] = dbe[i];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -356,4 +433,27 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     return check_launch("ihg_node_linear_bwd_weight");
 }
 
+
+int ihg_compose_first_order_fwd(const float* a, int64_t ld_a, const float* c, const float* w, int64_t ld_w, const float* b, float* w_eff,
+                                int64_t ld_w_eff, float* b_eff, int32_t dim, ihg_stream_t stream) {
+    if (dim <= 0 || dim > 1024 || ld_a < 3LL * dim || ld_w < dim || ld_w_eff < 3LL * dim) return fail(IHG_ERR_INVALID, "ihg_compose_first_order_fwd: bad size");
+    if (a == nullptr || w == nullptr || b == nullptr || w_eff == nullptr || b_eff == nullptr) return fail(IHG_ERR_INVALID, "ihg_compose_first_order_fwd: null pointer");
+    const int64_t total = 3LL * dim * dim + 3LL * dim;
+    hipLaunchKernelGGL(compose_fwd_kernel, dim3(static_cast<int>((total + kBlockThreads - 1) / kBlockThreads)), dim3(kBlockThreads), 0,
+                       static_cast<hipStream_t>(stream), a, ld_a, c, w, ld_w, b, w_eff, ld_w_eff, b_eff, dim);
+    return check_launch("ihg_compose_first_order_fwd");
+}
+
+int ihg_compose_first_order_bwd(const float* a, int64_t ld_a, const float* w, int64_t ld_w, const float* b, const float* dw_eff, int64_t ld_dw_eff,
+                                const float* db_eff, float* da, int64_t ld_da, float* dc, float* dw, int64_t ld_dw, float* db, int32_t dim,
+                                ihg_stream_t stream) {
+    if (dim <= 0 || dim > 1024 || ld_a < 3LL * dim || ld_w < dim || ld_dw_eff < 3LL * dim || ld_da < 3LL * dim || ld_dw < dim)
+        return fail(IHG_ERR_INVALID, "ihg_compose_first_order_bwd: bad size");
+    if (a == nullptr || w == nullptr || b == nullptr || dw_eff == nullptr || db_eff == nullptr || da == nullptr || dw == nullptr || db == nullptr)
+        return fail(IHG_ERR_INVALID, "ihg_compose_first_order_bwd: null pointer");
+    const int64_t waves = 3LL * dim * dim;                 // one wave per dA element; the thread-per-element part needs far fewer blocks
+    hipLaunchKernelGGL(compose_bwd_kernel, dim3(static_cast<int>(std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 16))), dim3(kBlockThreads), 0,
+                       static_cast<hipStream_t>(stream), a, ld_a, w, ld_w, b, dw_eff, ld_dw_eff, db_eff, da, ld_da, dc, dw, ld_dw, db, dim);
+    return check_launch("ihg_compose_first_order_bwd");
+}
 }  // extern "C"

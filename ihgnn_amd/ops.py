@@ -300,6 +300,43 @@ class _NodeLinear(torch.autograd.Function):
         return dx, dw, dbias, None, None, None
 
 
+class _ComposeFirstOrder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a: Tensor, c: Optional[Tensor], w: Tensor, b: Tensor):
+        lib = _lib.load()
+        a, w = _rows(a, 'aggregation weight'), _rows(w, 'transform weight')
+        b = b.contiguous()
+        c = c.contiguous() if c is not None else None
+        dim = int(w.shape[0])
+        w_eff = torch.empty(dim, 3 * dim, dtype=torch.float32, device=w.device)
+        b_eff = torch.empty(3, dim, dtype=torch.float32, device=w.device)
+        _lib.check(lib.ihg_compose_first_order_fwd(_ptr(a), _ld(a), _ptr(c), _ptr(w), _ld(w), _ptr(b), _ptr(w_eff), 3 * dim, _ptr(b_eff), dim, _stream()),
+                   'ihg_compose_first_order_fwd')
+        ctx.save_for_backward(a, w, b)
+        ctx.has_c = c is not None
+        return w_eff, b_eff
+
+    @staticmethod
+    def backward(ctx, dw_eff: Tensor, db_eff: Tensor):
+        lib = _lib.load()
+        a, w, b = ctx.saved_tensors
+        dim = int(w.shape[0])
+        dw_eff, db_eff = _rows(dw_eff, 'dw_eff'), db_eff.contiguous()
+        da, dw, db = torch.empty_like(a), torch.empty_like(w), torch.empty_like(b)
+        dc = torch.empty(dim, dtype=torch.float32, device=w.device) if ctx.has_c else None
+        _lib.check(lib.ihg_compose_first_order_bwd(_ptr(a), _ld(a), _ptr(w), _ld(w), _ptr(b), _ptr(dw_eff), _ld(dw_eff), _ptr(db_eff), _ptr(da), _ld(da),
+                                                   _ptr(dc), _ptr(dw), _ld(dw), _ptr(db), dim, _stream()), 'ihg_compose_first_order_bwd')
+        return da, dc, dw, db
+
+
+def compose_first_order(a: Tensor, c: Optional[Tensor], w: Tensor, b: Tensor):
+    """``(W_eff [d, 3d], b_eff [3, d])`` of ``first_order(linear(x; w, b); a, c)``: ``W_eff = [A_u w | A_q w | A_i w]``,
+    ``b_eff[t] = A_t b`` (+ ``c`` for users).  Differentiable in all four arguments."""
+    if tuple(a.shape) != (w.shape[0], 3 * w.shape[0]) or w.shape[0] != w.shape[1]:
+        raise ValueError(f'compose_first_order takes a [d, 3d] block weight and a [d, d] transform, got {tuple(a.shape)} and {tuple(w.shape)}')
+    return _ComposeFirstOrder.apply(a, c, w, b)
+
+
 def node_linear(x: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, typed: bool = False, bias_mask: int = 0b111) -> Tensor:
     """``out[v] = x[v] @ W_type(v).T (+ bias)``.  ``typed=False``: one ``[d,d]`` weight for every node; ``typed=True``:
     ``w`` is ``[d, k*d]`` and node type t uses its column block ``w[:, t*d:(t+1)*d]``; a ``[d]`` bias is added to the types in

@@ -253,6 +253,22 @@ int ihg_batch_rows_add(const float* src, int64_t ld_src, int32_t width, const in
                        float* dense, int64_t ld_dense, float* tail, int64_t tail_row_offset, int64_t tail_rows, ihg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * DEVICE: composition of the two linear maps of a first-order layer - `feature_transform` (W [d,d], b; Models/GnnLayers.py:224)
+ * followed by the first-order blocks of `aggregation` (A [d,3d] = A_u | A_q | A_i, bias c; Models/CommonLayers.py:60-66) with
+ * nothing non-linear between them: node type t sees x (A_t W)^T + (A_t b + [t == user] c), which is what
+ * ihg_node_linear_fwd then applies in one pass (typed weights, per-type bias).
+ *   fwd   w_eff[i][t d + j] = sum_k A[i][t d + k] W[k][j]      b_eff[t][i] = sum_k A[i][t d + k] b[k] + (t == 0 ? c[i] : 0)
+ *   bwd   gradients of both outputs back to A (da [d,3d]), c (dc, may be NULL), W (dw [d,d]) and b (db)
+ * Tiny (3 d^3 multiply-adds), one thread per output element, sums in index order.
+ */
+int ihg_compose_first_order_fwd(const float* a, int64_t ld_a, const float* c, const float* w, int64_t ld_w, const float* b,
+                                float* w_eff, int64_t ld_w_eff, float* b_eff, int32_t dim, ihg_stream_t stream);
+int ihg_compose_first_order_bwd(const float* a, int64_t ld_a, const float* w, int64_t ld_w, const float* b,
+                                const float* dw_eff, int64_t ld_dw_eff, const float* db_eff,
+                                float* da, int64_t ld_da, float* dc, float* dw, int64_t ld_dw, float* db,
+                                int32_t dim, ihg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * DEVICE: the optimiser step of the training loop (Main.py:192 `torch.optim.Adam(model.parameters(), lr, weight_decay=...)`,
  * stepped in TrainTestHelper.py:139-143), for all parameters in one launch per 24 tensors.  Same update as torch.optim.Adam
  * (amsgrad off, maximize off): g += wd * p; m += (g - m)(1 - b1); v = b2 v + (1 - b2) g^2;

@@ -216,6 +216,28 @@ def test_node_linear_forward_backward(dim, typed):
         assert (wg.grad[:, 3 * dim:] == 0).all()
 
 
+@pytest.mark.parametrize('dim', [8, 64, 96])
+def test_compose_first_order_matches_torch(dim):
+    """W_eff = [A_u W | A_q W | A_i W], b_eff = A_t b (+ c on users) and their gradients to A, c, W, b against torch matmul."""
+    from ihgnn_amd import ops
+    gen = torch.Generator().manual_seed(dim)
+    a, c = torch.randn(dim, 3 * dim, generator=gen) / np.sqrt(dim), torch.randn(dim, generator=gen)
+    w, b = torch.randn(dim, dim, generator=gen) / np.sqrt(dim), torch.randn(dim, generator=gen)
+    cot_w, cot_b = torch.randn(dim, 3 * dim, generator=gen), torch.randn(3, dim, generator=gen)
+    ref = [t.clone().requires_grad_(True) for t in (a, c, w, b)]
+    blocks = ref[0].view(dim, 3, dim).transpose(0, 1)
+    want_w = torch.matmul(blocks, ref[2]).transpose(0, 1).reshape(dim, 3 * dim)
+    want_b = torch.matmul(blocks, ref[3]) + torch.cat([ref[1].unsqueeze(0), torch.zeros(2, dim)])
+    (want_w * cot_w).sum().backward(retain_graph=True)
+    (want_b * cot_b).sum().backward()
+    got = [t.clone().to(dev()).requires_grad_(True) for t in (a, c, w, b)]
+    w_eff, b_eff = ops.compose_first_order(*got)
+    ((w_eff * cot_w.to(dev())).sum() + (b_eff * cot_b.to(dev())).sum()).backward()
+    assert rel(w_eff, want_w) <= RTOL and rel(b_eff, want_b) <= RTOL
+    for g, r in zip(got, ref):
+        assert rel(g.grad, r.grad) <= RTOL
+
+
 @pytest.mark.parametrize('dim', [32, 64, 128])
 def test_node_linear_with_per_type_bias(dim):
     """Typed weights with one bias vector per node type (the composed first-order layer): forward and all gradients vs torch."""
