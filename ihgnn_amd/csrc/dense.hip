@@ -144,13 +144,18 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_kernel(const float* __
 
 // grid = (slabs, (d/SW)^2 sub-blocks, weight types).  Slab layout: [type][slab][d][d] then bias part [type][slab][d].
 // Same register-prefetch pipeline as the interactive weight-gradient kernel.
-template <int SW>
+// FUSE_DX (d == SW == 64): the dout tile is in LDS anyway, so the input gradient dx = dout * W_type of the same rows is
+// computed here too (weight fragments in registers for the whole kernel) and the separate row-GEMM launch over dout goes away.
+template <int SW, bool FUSE_DX>
 __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_kernel(const float* __restrict__ dout, int64_t ld_dout,
                                                                           const float* __restrict__ x, int64_t ld_x, TypePlan plan,
                                                                           int single_weight, float* __restrict__ slabs,
-                                                                          float* __restrict__ bias_slabs, int d) {
+                                                                          float* __restrict__ bias_slabs, int d, const float* __restrict__ w,
+                                                                          int64_t ld_w, int64_t w_type_stride, float* __restrict__ dx, int64_t ld_dx) {
+    static_assert(!FUSE_DX || SW == 64, "the fused input gradient covers whole 64-wide rows");
     constexpr int TE = 64, WT = SW / 32, V4_PER_ROW = SW / 4, LOADS = TE * V4_PER_ROW / kBlockThreads;
-    __shared__ __attribute__((aligned(16))) float dtile[TE][SW];
+    constexpr int DSTRIDE = FUSE_DX ? SW + kRowPad : SW;      // padded rows for the ds_read_b128 A-operand reads of the dx product
+    __shared__ __attribute__((aligned(16))) float dtile[TE][DSTRIDE];
     __shared__ __attribute__((aligned(16))) float xtile[TE][SW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int subs = d / SW;
@@ -165,6 +170,16 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_kernel(const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float colsum = 0.f;
+    // dx job of this wave: rows et * 32 ..., columns cx * 32 ...; B[k][n] = W_type[k][n], k-order 8 t + 4 half + s as in row_gemm_kernel
+    const int et = wave & 1, cx = wave >> 1;
+    v4f breg[FUSE_DX ? SW / 8 : 1];
+    if (FUSE_DX) {
+        const float* wt = w + type * w_type_stride + cx * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < SW / 8; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) breg[t][s2] = wt[static_cast<int64_t>(8 * t + 4 * half + s2) * ld_w];
+    }
 
     float4 dreg[LOADS], xreg[LOADS];
     int64_t cur = -1, nxt = blockIdx.x;
@@ -205,6 +220,27 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_kernel(const 
 #pragma unroll 8
                 for (int r = 0; r < TE; ++r) part += dtile[r][tid];
                 colsum += part;
+            }
+            if (FUSE_DX) {
+                v16f gx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gx[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < SW / 8; ++t) {
+                    const v4f av = *reinterpret_cast<const v4f*>(&dtile[et * 32 + l31][8 * t + 4 * half]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) gx = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], breg[FUSE_DX ? t : 0][s2], gx, 0, 0, 0);
+                }
+                const int64_t r_base = r_begin + cur * TE;
+                float* orow = dx + (r_base + et * 32) * ld_dx + cx * 32 + l31;
+                if (r_base + TE <= r_end) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_dx] = gx[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (r_base + et * 32 + acc_row(r, lane) < r_end) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_dx] = gx[r];
+                }
             }
         }
         if (!have_next) break;
@@ -411,28 +447,40 @@ int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w
 
 int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin,
                                float* dw, int64_t ld_dw, int64_t dw_type_stride, float* dbias, int32_t bias_type_mask, int64_t dbias_type_stride,
+                               const float* w, int64_t ld_w, float* dx, int64_t ld_dx,
                                void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
     if (int rc = node_linear_common_check("ihg_node_linear_bwd_weight", dim, ld_dout, ld_x, ld_dw, type_begin, workspace, workspace_bytes)) return rc;
     if (dout == nullptr || x == nullptr || dw == nullptr || !aligned16(dout) || !aligned16(x)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: null or unaligned pointer");
+    if (dx != nullptr && (w == nullptr || ld_w < dim || ld_dx < dim)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx needs w and row strides >= dim");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_types = dw_type_stride == 0 ? 1 : 3;
     float* slabs = static_cast<float*>(workspace) + 3LL * dim * dim;
     float* bias_slabs = slabs + 3LL * kDenseSlabs * dim * dim;
     const TypePlan plan = make_plan(type_begin, 64);
-    if (dim == 32) {
-        hipLaunchKernelGGL((dense_weight_grad_kernel<32>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                           n_types == 1 ? 1 : 0, slabs, bias_slabs, dim);
+    // weights of type t are the column block t of w exactly as for dw: w_type_stride == dw_type_stride
+    if (dim == 64 && dx != nullptr) {
+        hipLaunchKernelGGL((dense_weight_grad_kernel<64, true>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+                           n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, w, ld_w, dw_type_stride, dx, ld_dx);
     } else {
-        const int subs = (dim / 64) * (dim / 64);
-        hipLaunchKernelGGL((dense_weight_grad_kernel<64>), dim3(kDenseSlabs, subs, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                           n_types == 1 ? 1 : 0, slabs, bias_slabs, dim);
+        if (dx != nullptr) {                               // other widths: the row-GEMM pass over dout stays a launch of its own
+            launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace), s);
+        }
+        if (dim == 32) {
+            hipLaunchKernelGGL((dense_weight_grad_kernel<32, false>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+                               n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, static_cast<const float*>(nullptr), int64_t{0}, int64_t{0},
+                               static_cast<float*>(nullptr), int64_t{0});
+        } else {
+            const int subs = (dim / 64) * (dim / 64);
+            hipLaunchKernelGGL((dense_weight_grad_kernel<64, false>), dim3(kDenseSlabs, subs, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+                               n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, static_cast<const float*>(nullptr), int64_t{0}, int64_t{0},
+                               static_cast<float*>(nullptr), int64_t{0});
+        }
     }
     const int total = dim * dim * n_types + dim;
     hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, bias_slabs,
                        kDenseSlabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask, n_types == 1 ? int64_t{0} : dbias_type_stride);
     return check_launch("ihg_node_linear_bwd_weight");
 }
-
 
 int ihg_compose_first_order_fwd(const float* a, int64_t ld_a, const float* c, const float* w, int64_t ld_w, const float* b, float* w_eff,
                                 int64_t ld_w_eff, float* b_eff, int32_t dim, ihg_stream_t stream) {

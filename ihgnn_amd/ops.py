@@ -283,20 +283,17 @@ class _NodeLinear(torch.autograd.Function):
         stride = dim if ctx.typed else 0
         tb = _type_begin(ctx.layout)
         ws = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), x.device)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            with profiler.kernel('node_linear_bwd_input', x.shape[0], dim):
-                _lib.check(lib.ihg_node_linear_bwd_input(_ptr(g), _ld(g), _ptr(w), int(w.stride(0)), stride, tb, _ptr(dx), _ld(dx),
-                                                         _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_bwd_input')
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = torch.zeros_like(w) if w.shape[1] != dim * (3 if ctx.typed else 1) else torch.empty_like(w)   # product-block columns of a [d, k*d] weight stay 0
         dbias = None
         if ctx.has_bias:
             dbias = torch.empty((3, dim) if ctx.per_type_bias else (dim,), dtype=torch.float32, device=x.device)
-        with profiler.kernel('node_linear_bwd_weight', x.shape[0], dim):
+        # one call: the weight / bias gradient, and the input gradient from the same pass over grad_out where the width allows
+        with profiler.kernel('node_linear_bwd', x.shape[0], dim):
             _lib.check(lib.ihg_node_linear_bwd_weight(_ptr(g), _ld(g), _ptr(x), _ld(x), tb, _ptr(dw), int(dw.stride(0)), stride,
-                                                      _ptr(dbias), ctx.bias_mask, dim if ctx.per_type_bias else 0, _ptr(ws), ws.numel() * 4, dim,
-                                                      _stream()), 'ihg_node_linear_bwd_weight')
+                                                      _ptr(dbias), ctx.bias_mask, dim if ctx.per_type_bias else 0,
+                                                      _ptr(w), int(w.stride(0)), _ptr(dx), _ld(dx) if dx is not None else 0,
+                                                      _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_bwd_weight')
         return dx, dw, dbias, None, None, None
 
 
