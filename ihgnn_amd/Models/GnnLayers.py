@@ -6,6 +6,8 @@ libihgnn_hip.so through :mod:`ihgnn_amd.ops` instead of ``torch_sparse.matmul``.
 ``GCNLayer`` (pairwise-graph baseline) runs on the same segment-sum kernel over a weighted CSR; ``GATLayer`` (DGL) is
 declared for the name tables only.
 """
+from typing import Optional
+
 import torch
 import torch.nn as nn
 from torch import Tensor
@@ -33,11 +35,13 @@ class HGCNLayer(nn.Module):
         self.out_scale = self.layout.inv_sqrt_deg * self.edge_scale
         self.feature_transform = nn.Linear(input_dimension, output_dimension)
 
-    def forward(self, input_features: Tensor) -> Tensor:
+    def forward(self, input_features: Tensor, output_rows: Optional[Tensor] = None) -> Tensor:
+        """``output_rows`` (int32 node rows, not in the reference signature): the caller reads only these rows of the result
+        (last layer of a training step); other rows may be left unwritten."""
         lay = self.layout
         h = _transform(self.feature_transform, input_features, lay)
         # node -> hyperedge -> node in one two-hop pass over the node table: Dv^-1/2 on the way in, Dv^-1/2 De^-1 on the way out
-        return ops.node_two_hop(h, lay, in_scale=lay.inv_sqrt_deg, out_scale=self.out_scale)
+        return ops.node_two_hop(h, lay, in_scale=lay.inv_sqrt_deg, out_scale=self.out_scale, rows=output_rows)
 
 
 class IHGNNLayer(nn.Module):
@@ -61,13 +65,14 @@ class IHGNNLayer(nn.Module):
                                                     output_dimension=input_dimension)
         self.feature_transform = nn.Linear(input_dimension, output_dimension)
 
-    def forward(self, input_features: Tensor) -> Tensor:
+    def forward(self, input_features: Tensor, output_rows: Optional[Tensor] = None) -> Tensor:
+        """``output_rows``: as in ``HGCNLayer.forward``."""
         if self.feature_interaction_order == 1:
             # first-order layer: hoisted node-level blocks, then node -> hyperedge -> node fused into one two-hop pass
-            return ops.node_two_hop(self._first_order_of_input(input_features), self.layout, out_scale=self.layout.inv_deg)
+            return ops.node_two_hop(self._first_order_of_input(input_features), self.layout, out_scale=self.layout.inv_deg, rows=output_rows)
         h = _transform(self.feature_transform, input_features, self.layout)
         edge_features = self.feature_interactor(h)
-        return ops.node_segment_sum(edge_features, self.layout, out_scale=self.layout.inv_deg)
+        return ops.node_segment_sum(edge_features, self.layout, out_scale=self.layout.inv_deg, rows=output_rows)
 
     def _first_order_of_input(self, x: Tensor) -> Tensor:
         """``first_order(feature_transform(x))``.  With no non-linearity between them (``GnnLayers.py:224-227`` +

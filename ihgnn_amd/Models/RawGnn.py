@@ -56,15 +56,25 @@ class RawGnn(nn.Module):
         self.prediction_layer = HemPredictionLayer(feature_dimension=self.output_feature_size, lambda_muq=lambda_muq,
                                                    item_count=dataset.item_count)
 
-    def propagate_layers(self, tail_gradients=None):
+    # bce_loss: evaluate the last layer's hyperedge -> node pass only at the rows the loss reads (same loss, same gradients)
+    batch_rows_only_last_layer = True
+
+    def propagate_layers(self, tail_gradients=None, batch_rows=None):
         """Full-graph propagation: the list ``[X0, X1, ..., XL]`` of ``[N, d]`` node features (input embeddings and every
         layer's output).  With ``tail_gradients`` (an ``ops.TailGradients``) every output is tapped: the returned tensors
-        are the batch tail's halves, whose gradients travel through the holder instead of dense ``[N, d]`` tensors."""
+        are the batch tail's halves, whose gradients travel through the holder instead of dense ``[N, d]`` tensors.
+        ``batch_rows`` (int64 node rows): nobody reads ``XL`` outside these rows (a training step scores the batch only), so
+        the last hypergraph layer computes just them (plus the split rows of its plan) and leaves the rest unwritten."""
         x = torch.cat(self.embeddings(None, None, None))
         outputs = []
-        for depth in range(len(self.gnns) + 1):
+        last = len(self.gnns)
+        for depth in range(last + 1):
             if depth > 0:
-                x = self.gnns[depth - 1](x)
+                layer = self.gnns[depth - 1]
+                if depth == last and batch_rows is not None and isinstance(layer, (IHGNNLayer, HGCNLayer)):
+                    x = layer(x, output_rows=batch_rows.to(torch.int32))
+                else:
+                    x = layer(x)
             if tail_gradients is not None:
                 from .. import ops
                 x, for_tail = ops.tap(x, tail_gradients, depth)
@@ -113,7 +123,8 @@ class RawGnn(nn.Module):
         ds, head = self.dataset, self.prediction_layer
         rows = torch.cat([user_indices, query_indices + ds.query_start_index_in_graph, item_indices + ds.item_start_index_in_graph])
         holder = ops.TailGradients() if torch.is_grad_enabled() else None
-        return ops.hem_bce_loss(self.propagate_layers(holder), rows, item_indices, labels, head.items_bias, head.lambda_muq,
+        return ops.hem_bce_loss(self.propagate_layers(holder, rows if self.batch_rows_only_last_layer else None), rows, item_indices, labels,
+                                head.items_bias, head.lambda_muq,
                                 ds.item_start_index_in_graph, holder)
 
     def supports_fused_loss(self, loss_function) -> bool:

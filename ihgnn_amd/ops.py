@@ -75,17 +75,22 @@ def edge_gather_sum_raw(src: Tensor, i3: Tensor, node_scale: Optional[Tensor] = 
 def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optional[Tensor] = None,
                          out_scale: Optional[Tensor] = None, mode: int = _lib.SCALE_NONE,
                          out: Optional[Tensor] = None, entry_scale: Optional[Tensor] = None,
-                         self_weight: Optional[Tensor] = None) -> Tensor:
+                         self_weight: Optional[Tensor] = None, rows: Optional[Tensor] = None) -> Tensor:
+    """``rows`` (int32, device): only these output rows are needed.  The split rows of the plan are always computed; of the
+    others only the listed ones are, and the rest of ``out`` is left unwritten."""
     lib = _lib.load()
     src = _rows(src, 'src')
     dim = int(src.shape[1])
     if out is None:
         out = torch.empty(csr.n_rows, dim, dtype=torch.float32, device=src.device)
     heavy = csr.n_heavy > 0
-    with profiler.kernel('node_segment_sum', csr.n_rows, dim):
+    if rows is not None and rows.dtype != torch.int32:
+        raise TypeError('rows must be an int32 tensor')
+    order, n_light = (rows, int(rows.shape[0])) if rows is not None else (csr.row_order, csr.n_rows)
+    with profiler.kernel('node_segment_sum' if rows is None else 'node_segment_sum_rows', n_light, dim):
         _lib.check(lib.ihg_node_segment_sum(
-            _ptr(src), _ld(src), _ptr(csr.ptr), _ptr(csr.ids), _ptr(csr.row_order), _ptr(src_scale), _ptr(entry_scale), _ptr(out_scale), mode,
-            _ptr(out), _ld(out), csr.n_rows, dim, csr.heavy_threshold if heavy else 0,
+            _ptr(src), _ld(src), _ptr(csr.ptr), _ptr(csr.ids), _ptr(order), _ptr(src_scale), _ptr(entry_scale), _ptr(out_scale), mode,
+            _ptr(out), _ld(out), n_light, dim, csr.heavy_threshold if heavy else 0,
             _ptr(csr.seg_begin) if heavy else None, _ptr(csr.seg_end) if heavy else None, csr.n_segments if heavy else 0,
             _ptr(csr.heavy_rows) if heavy else None, _ptr(csr.heavy_segptr) if heavy else None, csr.n_heavy,
             _ptr(csr.partials(dim)) if heavy else None, _ptr(self_weight), _stream()), 'ihg_node_segment_sum')
@@ -113,14 +118,14 @@ class _EdgeGatherSum(torch.autograd.Function):
 
 class _NodeSegmentSum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor]) -> Tensor:
+    def forward(ctx, src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor], rows: Optional[Tensor]) -> Tensor:
         ctx.layout, ctx.out_scale = layout, out_scale
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(src, layout.node_csr, None, out_scale, mode)
+        return node_segment_sum_raw(src, layout.node_csr, None, out_scale, mode, rows=rows)
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
-        return edge_gather_sum_raw(grad_out, ctx.layout.i3, ctx.out_scale, None, 1.0), None, None
+        return edge_gather_sum_raw(grad_out, ctx.layout.i3, ctx.out_scale, None, 1.0), None, None, None
 
 
 def edge_gather_sum(src: Tensor, layout: IncidenceLayout, node_scale: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
@@ -128,9 +133,13 @@ def edge_gather_sum(src: Tensor, layout: IncidenceLayout, node_scale: Optional[T
     return _EdgeGatherSum.apply(src, layout, node_scale, float(alpha))
 
 
-def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor] = None) -> Tensor:
-    """hyperedge -> node: ``out[v] = out_scale[v] * sum_{e containing v} src[e]``  (``[E,d] -> [N,d]``)."""
-    return _NodeSegmentSum.apply(src, layout, out_scale)
+def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor] = None, rows: Optional[Tensor] = None) -> Tensor:
+    """hyperedge -> node: ``out[v] = out_scale[v] * sum_{e containing v} src[e]``  (``[E,d] -> [N,d]``).
+
+    ``rows`` (int32): the caller reads only these rows of the result (the batch rows of the last layer's output in a training
+    step); rows outside the list and outside the split-row plan are left UNWRITTEN.  The gradient must then be zero outside
+    ``rows`` too - which it is when only those rows were read."""
+    return _NodeSegmentSum.apply(src, layout, out_scale, rows)
 
 
 class _TwoHop(torch.autograd.Function):
@@ -139,22 +148,24 @@ class _TwoHop(torch.autograd.Function):
     ``H H^T`` is symmetric, so the backward is the same launch with the two diagonal scalings swapped."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor], out_scale: Optional[Tensor]) -> Tensor:
+    def forward(ctx, x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor], out_scale: Optional[Tensor], rows: Optional[Tensor]) -> Tensor:
         ctx.layout, ctx.in_scale, ctx.out_scale = layout, in_scale, out_scale
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(x, layout.hop2_csr, in_scale, out_scale, mode, self_weight=layout.self_weight)
+        return node_segment_sum_raw(x, layout.hop2_csr, in_scale, out_scale, mode, self_weight=layout.self_weight, rows=rows)
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         lay = ctx.layout
         mode = _lib.SCALE_NONE if ctx.in_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight), None, None, None
+        return node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight), None, None, None, None
 
 
-def node_two_hop(x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None) -> Tensor:
+def node_two_hop(x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None,
+                 rows: Optional[Tensor] = None) -> Tensor:
     """``out[v] = out_scale[v] * sum_{e containing v} sum_{w in e} in_scale[w] * x[w]`` - the first-order
-    node -> hyperedge -> node step (K5 followed by K7) without materialising the hyperedge features."""
-    return _TwoHop.apply(x, layout, in_scale, out_scale)
+    node -> hyperedge -> node step (K5 followed by K7) without materialising the hyperedge features.  ``rows``: as in
+    ``node_segment_sum``."""
+    return _TwoHop.apply(x, layout, in_scale, out_scale, rows)
 
 
 class _PairSpmm(torch.autograd.Function):

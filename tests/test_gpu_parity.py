@@ -216,6 +216,23 @@ def test_node_linear_forward_backward(dim, typed):
         assert (wg.grad[:, 3 * dim:] == 0).all()
 
 
+def test_row_subset_outputs_equal_full_outputs():
+    """hyperedge -> node and two-hop passes restricted to a row list (the last layer of a training step): the listed rows and
+    the split rows are bitwise what the full pass writes."""
+    from ihgnn_amd import ops
+    w_, lay = make_layout(120, 6, 90, 9000, seed=77)                    # 6 queries over 9000 hyperedges: split rows exist
+    assert lay.node_csr.n_heavy > 0 and lay.hop2_csr.n_heavy > 0
+    gen = torch.Generator().manual_seed(5)
+    ef = torch.randn(lay.edge_count, 64, generator=gen).to(dev())
+    x = torch.randn(lay.node_count, 64, generator=gen).to(dev())
+    rows = torch.randint(0, lay.node_count, (300,), generator=gen).to(dev())
+    rows[:6] = torch.arange(120, 126, device=dev())                       # the query rows (heavy) among them
+    r32 = rows.to(torch.int32)
+    for full, part in ((ops.node_segment_sum(ef, lay, lay.inv_deg), ops.node_segment_sum(ef, lay, lay.inv_deg, rows=r32)),
+                       (ops.node_two_hop(x, lay, out_scale=lay.inv_deg), ops.node_two_hop(x, lay, out_scale=lay.inv_deg, rows=r32))):
+        assert torch.equal(full[rows], part[rows])
+
+
 @pytest.mark.parametrize('dim', [8, 64, 96])
 def test_compose_first_order_matches_torch(dim):
     """W_eff = [A_u W | A_q W | A_i W], b_eff = A_t b (+ c on users) and their gradients to A, c, W, b against torch matmul."""
