@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
 template <int VEC, int G>
 __device__ __forceinline__ Frag<VEC> accumulate_list(const float* __restrict__ src, int64_t ld_src,
                                                      const int32_t* __restrict__ ids, const float* __restrict__ src_scale,
-                                                     const float* __restrict__ entry_scale,
+                                                     const float* __restrict__ entry_scale, const uint8_t* __restrict__ src_mask,
                                                      int begin, int len, int wave_max_len, int lane, int col) {
     constexpr int UNR = G < 8 ? G : 8;
     const int lig = lane & (G - 1);
@@ -91,9 +91,11 @@ __device__ __forceinline__ Frag<VEC> accumulate_list(const float* __restrict__ s
     Frag<VEC> acc = Frag<VEC>::zero();
     for (int base = 0; base < wave_max_len; base += G) {
         const bool have = base + lig < len;
-        const int my_id = have ? ids[begin + base + lig] : -1;
-        float my_w = (src_scale != nullptr && have) ? src_scale[my_id] : 1.f;
-        if (entry_scale != nullptr && have) my_w *= entry_scale[begin + base + lig];
+        int my_id = have ? ids[begin + base + lig] : -1;
+        if (src_mask != nullptr && have && src_mask[my_id] == 0) my_id = -1;      // a source row known to be zero: not fetched
+        const bool live = my_id >= 0;
+        float my_w = (src_scale != nullptr && live) ? src_scale[my_id] : 1.f;
+        if (entry_scale != nullptr && live) my_w *= entry_scale[begin + base + lig];
 #pragma unroll 1
         for (int j = 0; j < G; j += UNR) {
             if (base + j >= wave_max_len) break;      // wave-uniform: nothing left in any group
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
     const float* __restrict__ out_scale, int mode,
     float* __restrict__ out, int64_t ld_out, int64_t n_rows, int dim, int dim_vec, int heavy_threshold,
     const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments, float* __restrict__ partials,
-    const float* __restrict__ self_weight) {
+    const float* __restrict__ self_weight, const uint8_t* __restrict__ src_mask) {
     constexpr int GPW = kWave / G;
     const int lane = threadIdx.x & (kWave - 1);
     const int lig = lane & (G - 1);
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
         for (int ci = 0; ci < col_iters; ++ci) {
             const int c = ci * G + lig;
             const int col = c < dim_vec ? c : -1;
-            Frag<VEC> acc = accumulate_list<VEC, G>(src, ld_src, ids, src_scale, entry_scale, begin, len, wave_len, lane, col);
+            Frag<VEC> acc = accumulate_list<VEC, G>(src, ld_src, ids, src_scale, entry_scale, src_mask, begin, len, wave_len, lane, col);
             if (dst != nullptr && col >= 0) {
                 if (scale_row >= 0) {
                     if (self_weight != nullptr)             // square operators: the row's own source row, weighted
@@ -277,6 +279,7 @@ struct HeavyPlan {
     const int32_t* heavy_segptr;
     int64_t n_heavy;
     float* partials;
+    const uint8_t* src_mask;      // optional: source rows with a 0 here are known to be zero and are not fetched
 };
 
 template <int VEC, int G>
@@ -288,7 +291,7 @@ void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowpt
     const int grid = grid_for_waves((n_rows + hp.n_segments + GPW - 1) / GPW);
     hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr, ids, row_order,
                        src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, dim_vec, heavy_threshold, hp.seg_begin, hp.seg_end,
-                       hp.n_segments, hp.partials, self_weight);
+                       hp.n_segments, hp.partials, self_weight, hp.src_mask);
     if (hp.n_heavy > 0)
         hipLaunchKernelGGL((heavy_finish_kernel<VEC, G>), dim3(static_cast<int>(std::min<int64_t>(hp.n_heavy, kMaxBlocks * 4))),
                            dim3(kBlockThreads), 0, stream, hp.partials, hp.heavy_rows, hp.heavy_segptr, hp.n_heavy, out_scale, mode, out,
@@ -335,7 +338,7 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
                          const float* src_scale, const float* entry_scale, const float* out_scale, int32_t out_scale_mode, float* out, int64_t ld_out,
                          int64_t n_rows, int32_t dim, int32_t heavy_threshold, const int32_t* seg_begin, const int32_t* seg_end,
                          int64_t n_segments, const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy, float* partials,
-                         const float* self_weight, ihg_stream_t stream) {
+                         const float* self_weight, const uint8_t* src_mask, ihg_stream_t stream) {
     if (n_rows < 0 || dim <= 0 || ld_src < dim || ld_out < dim || n_segments < 0 || n_heavy < 0) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad size");
     if (!scale_mode_ok(out_scale_mode, out_scale)) return fail(IHG_ERR_INVALID, "ihg_node_segment_sum: bad out_scale_mode %d", out_scale_mode);
     if (n_rows == 0) return IHG_OK;
@@ -346,7 +349,7 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
         n_segments = 0;
         heavy_threshold = 0;
     }
-    const HeavyPlan hp{seg_begin, seg_end, n_segments, heavy_rows, heavy_segptr, n_heavy, partials};
+    const HeavyPlan hp{seg_begin, seg_end, n_segments, heavy_rows, heavy_segptr, n_heavy, partials, src_mask};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out) && (n_heavy == 0 || aligned16(partials));
     return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, self_weight, s)
@@ -356,12 +359,12 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
 int ihg_bag_mean_fwd(const float* table, int64_t ld_table, const int32_t* bag_ptr, const int32_t* words, const float* bag_len,
                      float* out, int64_t ld_out, int64_t n_bags, int32_t dim, ihg_stream_t stream) {
     if (bag_len == nullptr && n_bags > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_fwd: null bag_len");
-    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, nullptr, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, stream);
+    return ihg_node_segment_sum(table, ld_table, bag_ptr, words, nullptr, nullptr, nullptr, bag_len, IHG_SCALE_DIVIDE, out, ld_out, n_bags, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }
 
 int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr, const int32_t* word_bags, const float* inv_len,
                      float* dtable, int64_t ld_dtable, int64_t n_table_rows, int32_t dim, ihg_stream_t stream) {
     if (inv_len == nullptr && n_table_rows > 0) return fail(IHG_ERR_INVALID, "ihg_bag_mean_bwd: null inv_len");
-    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, nullptr, inv_len, nullptr, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, stream);
+    return ihg_node_segment_sum(dout, ld_dout, word_ptr, word_bags, nullptr, inv_len, nullptr, nullptr, IHG_SCALE_NONE, dtable, ld_dtable, n_table_rows, dim, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }
 }  // extern "C"

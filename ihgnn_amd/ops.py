@@ -75,9 +75,10 @@ def edge_gather_sum_raw(src: Tensor, i3: Tensor, node_scale: Optional[Tensor] = 
 def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optional[Tensor] = None,
                          out_scale: Optional[Tensor] = None, mode: int = _lib.SCALE_NONE,
                          out: Optional[Tensor] = None, entry_scale: Optional[Tensor] = None,
-                         self_weight: Optional[Tensor] = None, rows: Optional[Tensor] = None) -> Tensor:
+                         self_weight: Optional[Tensor] = None, rows: Optional[Tensor] = None, src_mask: Optional[Tensor] = None) -> Tensor:
     """``rows`` (int32, device): only these output rows are needed.  The split rows of the plan are always computed; of the
-    others only the listed ones are, and the rest of ``out`` is left unwritten."""
+    others only the listed ones are, and the rest of ``out`` is left unwritten.  ``src_mask`` (uint8 per source row): rows with a 0
+    are all-zero and are not fetched."""
     lib = _lib.load()
     src = _rows(src, 'src')
     dim = int(src.shape[1])
@@ -93,7 +94,7 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
             _ptr(out), _ld(out), n_light, dim, csr.heavy_threshold if heavy else 0,
             _ptr(csr.seg_begin) if heavy else None, _ptr(csr.seg_end) if heavy else None, csr.n_segments if heavy else 0,
             _ptr(csr.heavy_rows) if heavy else None, _ptr(csr.heavy_segptr) if heavy else None, csr.n_heavy,
-            _ptr(csr.partials(dim)) if heavy else None, _ptr(self_weight), _stream()), 'ihg_node_segment_sum')
+            _ptr(csr.partials(dim)) if heavy else None, _ptr(self_weight), _ptr(src_mask), _stream()), 'ihg_node_segment_sum')
     return out
 
 
@@ -149,7 +150,7 @@ class _TwoHop(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor], out_scale: Optional[Tensor], rows: Optional[Tensor]) -> Tensor:
-        ctx.layout, ctx.in_scale, ctx.out_scale = layout, in_scale, out_scale
+        ctx.layout, ctx.in_scale, ctx.out_scale, ctx.rows = layout, in_scale, out_scale, rows
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
         return node_segment_sum_raw(x, layout.hop2_csr, in_scale, out_scale, mode, self_weight=layout.self_weight, rows=rows)
 
@@ -157,7 +158,14 @@ class _TwoHop(torch.autograd.Function):
     def backward(ctx, grad_out: Tensor):
         lay = ctx.layout
         mode = _lib.SCALE_NONE if ctx.in_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight), None, None, None, None
+        mask = None
+        if ctx.rows is not None:
+            # only `rows` of the output were read, so grad_out is zero elsewhere: the pull skips the gathers of those zero rows
+            # (two thirds of them - every neighbour that is not a query - and the ones that would miss the cache)
+            mask = torch.zeros(lay.node_count, dtype=torch.uint8, device=grad_out.device)
+            mask.index_fill_(0, ctx.rows.long(), 1)
+        return (node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight, src_mask=mask),
+                None, None, None, None)
 
 
 def node_two_hop(x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None,

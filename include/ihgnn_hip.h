@@ -109,6 +109,10 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3,
  * operator, whose off-diagonal part is then listed without the row's own id.
  * `row_order` (optional, [n_rows]) is the order in which rows are handed to lane groups - a permutation sorted by
  * decreasing row length keeps the groups of one wave equally busy; NULL = natural order.  Results do not depend on it.
+ * It may also be a SUBSET of the rows (n_rows = its length; rowptr is still indexed by row id): only those rows, and the
+ * rows of the split-row plan, are written - the last layer of a training step, whose output is read at the batch rows only.
+ * `src_mask` (optional, one byte per source row): rows with a 0 are known to be all-zero and are not fetched (the gradient
+ * of that last layer's output is zero outside the batch rows).
  * Replaces: thsp.matmul(self.incidence, edge_features) and Dv^-1 * / Dv^-1/2 * (Models/GnnLayers.py:151-152,
  * 233-234), nn.EmbeddingBag(mode='mean') (Models/EmbeddingLayers.py:79, via ihg_bag_mean_fwd), and the
  * index_put(accumulate) backward of the three row gathers (Models/CommonLayers.py:70-72).
@@ -121,7 +125,7 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
                          int32_t heavy_threshold,
                          const int32_t* seg_begin, const int32_t* seg_end, int64_t n_segments,
                          const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy,
-                         float* partials, const float* self_weight, ihg_stream_t stream);
+                         float* partials, const float* self_weight, const uint8_t* src_mask, ihg_stream_t stream);
 /* Split rows (skewed / power-law degree distributions): the host cuts every row longer than `heavy_threshold` into
  * segments [seg_begin, seg_end) of the `ids` array.  The SAME launch sums every segment with its own lane group into
  * partials[s,:] (workspace, n_segments x dim floats) next to the light rows, then a second small kernel adds each heavy
