@@ -42,6 +42,7 @@ class GradientSync:
         self.params: List[torch.nn.Parameter] = [p for p in parameters if p.requires_grad]
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._use_avg = None
         if not self.params:
             self.flat = None
             return
@@ -78,6 +79,14 @@ class GradientSync:
             return
         self._reattach()
         if self.world_size > 1:
+            if self._use_avg is None:
+                self._use_avg = dist.get_backend(self.group) == 'nccl'
+            if self._use_avg:                                # RCCL averages inside the collective: no second pass over the buffer
+                try:
+                    dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+                    return
+                except (RuntimeError, ValueError):           # a build without ncclAvg says so before anything is enqueued
+                    self._use_avg = False
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(self.world_size)
 
