@@ -42,6 +42,8 @@ class FeatureInteractor(nn.Module):
 
     def forward(self, node_features: Tensor) -> Tensor:
         layout = self.dataset.hypergraph.layout
+        if self.max_order > 1 and ops.interact_from_nodes_supported(node_features, self.aggregation.weight):
+            return ops.interact_from_nodes(node_features, self.aggregation.weight, self.aggregation.bias, layout, self.max_order)
         hoisted = self.first_order(node_features)
         if self.max_order == 1:
             return ops.edge_gather_sum(hoisted, layout)

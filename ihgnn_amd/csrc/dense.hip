@@ -151,7 +151,8 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_kernel(const 
                                                                           const float* __restrict__ x, int64_t ld_x, TypePlan plan,
                                                                           int single_weight, float* __restrict__ slabs,
                                                                           float* __restrict__ bias_slabs, int d, const float* __restrict__ w,
-                                                                          int64_t ld_w, int64_t w_type_stride, float* __restrict__ dx, int64_t ld_dx) {
+                                                                          int64_t ld_w, int64_t w_type_stride, float* __restrict__ dx, int64_t ld_dx,
+                                                                          int dx_accumulate) {
     static_assert(!FUSE_DX || SW == 64, "the fused input gradient covers whole 64-wide rows");
     constexpr int TE = 64, WT = SW / 32, V4_PER_ROW = SW / 4, LOADS = TE * V4_PER_ROW / kBlockThreads;
     constexpr int DSTRIDE = FUSE_DX ? SW + kRowPad : SW;      // padded rows for the ds_read_b128 A-operand reads of the dx product
@@ -233,6 +234,14 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_kernel(const 
                 }
                 const int64_t r_base = r_begin + cur * TE;
                 float* orow = dx + (r_base + et * 32) * ld_dx + cx * 32 + l31;
+                if (dx_accumulate) {                        // dx already holds another contribution to the same gradient
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        old[r] = r_base + et * 32 + acc_row(r, lane) < r_end ? orow[static_cast<int64_t>(acc_row(r, lane)) * ld_dx] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) gx[r] += old[r];
+                }
                 if (r_base + TE <= r_end) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) orow[static_cast<int64_t>(acc_row(r, lane)) * ld_dx] = gx[r];
@@ -447,11 +456,12 @@ int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w
 
 int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin,
                                float* dw, int64_t ld_dw, int64_t dw_type_stride, float* dbias, int32_t bias_type_mask, int64_t dbias_type_stride,
-                               const float* w, int64_t ld_w, float* dx, int64_t ld_dx,
+                               const float* w, int64_t ld_w, float* dx, int64_t ld_dx, int32_t dx_accumulate,
                                void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
     if (int rc = node_linear_common_check("ihg_node_linear_bwd_weight", dim, ld_dout, ld_x, ld_dw, type_begin, workspace, workspace_bytes)) return rc;
     if (dout == nullptr || x == nullptr || dw == nullptr || !aligned16(dout) || !aligned16(x)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: null or unaligned pointer");
     if (dx != nullptr && (w == nullptr || ld_w < dim || ld_dx < dim)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx needs w and row strides >= dim");
+    if (dx_accumulate && (dx == nullptr || dim != 64)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate needs dx and dim 64 (the fused kernel)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_types = dw_type_stride == 0 ? 1 : 3;
     float* slabs = static_cast<float*>(workspace) + 3LL * dim * dim;
@@ -460,7 +470,7 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     // weights of type t are the column block t of w exactly as for dw: w_type_stride == dw_type_stride
     if (dim == 64 && dx != nullptr) {
         hipLaunchKernelGGL((dense_weight_grad_kernel<64, true>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                           n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, w, ld_w, dw_type_stride, dx, ld_dx);
+                           n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, w, ld_w, dw_type_stride, dx, ld_dx, dx_accumulate);
     } else {
         if (dx != nullptr) {                               // other widths: the row-GEMM pass over dout stays a launch of its own
             launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace), s);
@@ -468,12 +478,12 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
         if (dim == 32) {
             hipLaunchKernelGGL((dense_weight_grad_kernel<32, false>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
                                n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, static_cast<const float*>(nullptr), int64_t{0}, int64_t{0},
-                               static_cast<float*>(nullptr), int64_t{0});
+                               static_cast<float*>(nullptr), int64_t{0}, 0);
         } else {
             const int subs = (dim / 64) * (dim / 64);
             hipLaunchKernelGGL((dense_weight_grad_kernel<64, false>), dim3(kDenseSlabs, subs, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
                                n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, static_cast<const float*>(nullptr), int64_t{0}, int64_t{0},
-                               static_cast<float*>(nullptr), int64_t{0});
+                               static_cast<float*>(nullptr), int64_t{0}, 0);
         }
     }
     const int total = dim * dim * n_types + dim;

@@ -311,7 +311,7 @@ class _NodeLinear(torch.autograd.Function):
         with profiler.kernel('node_linear_bwd', x.shape[0], dim):
             _lib.check(lib.ihg_node_linear_bwd_weight(_ptr(g), _ld(g), _ptr(x), _ld(x), tb, _ptr(dw), int(dw.stride(0)), stride,
                                                       _ptr(dbias), ctx.bias_mask, dim if ctx.per_type_bias else 0,
-                                                      _ptr(w), int(w.stride(0)), _ptr(dx), _ld(dx) if dx is not None else 0,
+                                                      _ptr(w), int(w.stride(0)), _ptr(dx), _ld(dx) if dx is not None else 0, 0,
                                                       _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_bwd_weight')
         return dx, dw, dbias, None, None, None
 
@@ -399,6 +399,69 @@ class _Interact(torch.autograd.Function):
         dh = node_segment_sum_raw(g.view(3 * n_edges, dim), layout.member_csr)
         dp = node_segment_sum_raw(grad_out, layout.node_csr)
         return dh, dp, dw, None, None
+
+
+class _InteractFromNodes(torch.autograd.Function):
+    """First-order blocks (typed row-GEMM) + product blocks (MFMA interact kernel) of ``FeatureInteractor`` as ONE autograd
+    node, so that in the backward the first-order path's contribution to ``d h`` is accumulated by the kernel into the member
+    gradients' scatter result (no separate ``[N, d]`` add) and both halves of ``d aggregation.weight`` land in one tensor."""
+
+    @staticmethod
+    def forward(ctx, h: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, order: int) -> Tensor:
+        lib = _lib.load()
+        h, w = _rows(h, 'h'), _rows(w, 'w')
+        dim = int(h.shape[1])
+        p = torch.empty_like(h)
+        ws = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)
+        with profiler.kernel('node_linear_fwd', h.shape[0], dim):
+            _lib.check(lib.ihg_node_linear_fwd(_ptr(h), _ld(h), _ptr(w), int(w.stride(0)), dim, _ptr(bias), 0b001, 0, _type_begin(layout),
+                                               _ptr(p), _ld(p), _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_fwd')
+        out = torch.empty(layout.edge_count, dim, dtype=torch.float32, device=h.device)
+        ws2 = _workspace(int(lib.ihg_interact_fwd_workspace_bytes(layout.edge_count, dim, order)), h.device)
+        with profiler.kernel('interact_fwd', layout.edge_count, dim):
+            _lib.check(lib.ihg_interact_fwd(_ptr(h), _ld(h), _ptr(p), _ld(p), _ptr(layout.i3), _ptr(w), _ld(w), order,
+                                            _ptr(out), _ld(out), _ptr(ws2), ws2.numel() * 4, layout.edge_count, dim, _stream()),
+                       'ihg_interact_fwd')
+        ctx.save_for_backward(h, w)
+        ctx.layout, ctx.order, ctx.has_bias = layout, order, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        lib = _lib.load()
+        h, w = ctx.saved_tensors
+        layout, order = ctx.layout, ctx.order
+        grad_out = _rows(grad_out, 'grad_out')
+        n_edges, dim = layout.edge_count, int(h.shape[1])
+        g = torch.empty(n_edges, 3 * dim, dtype=torch.float32, device=h.device)
+        dw = torch.empty_like(w)                               # product blocks from the interact kernels, first-order blocks from the row-GEMM pass
+        ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
+        with profiler.kernel('interact_bwd', n_edges, dim):
+            _lib.check(lib.ihg_interact_bwd(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(grad_out), _ld(grad_out),
+                                            _ptr(g), _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4, n_edges, dim, _stream()),
+                       'ihg_interact_bwd')
+        dh = node_segment_sum_raw(g.view(3 * n_edges, dim), layout.member_csr)      # (node v, hyperedge e) reads row 3e + type(v)
+        dp = node_segment_sum_raw(grad_out, layout.node_csr)
+        dbias = torch.empty(dim, dtype=torch.float32, device=h.device) if ctx.has_bias else None
+        ws2 = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)
+        with profiler.kernel('node_linear_bwd', h.shape[0], dim):
+            _lib.check(lib.ihg_node_linear_bwd_weight(_ptr(dp), _ld(dp), _ptr(h), _ld(h), _type_begin(layout), _ptr(dw), int(dw.stride(0)), dim,
+                                                      _ptr(dbias), 0b001, 0, _ptr(w), int(w.stride(0)), _ptr(dh), _ld(dh), 1,
+                                                      _ptr(ws2), ws2.numel() * 4, dim, _stream()), 'ihg_node_linear_bwd_weight')
+        return dh, dw, dbias, None, None
+
+
+def interact_from_nodes_supported(h: Tensor, w: Tensor) -> bool:
+    """The one-node form needs the fused row-GEMM backward (d = 64, aligned rows) and the tiled interact kernels."""
+    return node_linear_supported(h, w) and int(h.shape[1]) == 64 and h.is_contiguous()
+
+
+def interact_from_nodes(h: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, order: int) -> Tensor:
+    """``FeatureInteractor`` of order 2 / 3 from the node features: ``out[e] = sum_m (h[m] A_m^T) + c + sum_b W_b z_b[e]``
+    with ``w = [A_u | A_q | A_i | W_uq | W_qi | W_iu (| W_uqi)]`` (``CommonLayers.py:70-85``)."""
+    if order not in (2, 3):
+        raise ValueError('interact_from_nodes handles interaction orders 2 and 3')
+    return _InteractFromNodes.apply(h, w, bias, layout, int(order))
 
 
 def interact(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: int) -> Tensor:

@@ -200,7 +200,8 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3,
  *              dbias[c] = sum over rows of the masked types of dout[v,c]     (dbias may be NULL); with dbias_type_stride != 0
  *              (typed weights only) every type gets its own sum at dbias + t * dbias_type_stride, 0 for unmasked types.
  *              With dx != NULL the call also produces bwd_input's result (w typed exactly like dw: block t at column
- *              t * dw_type_stride); at dim 64 both come from one pass over dout, otherwise it runs the bwd_input launch itself
+ *              t * dw_type_stride); at dim 64 both come from one pass over dout, otherwise it runs the bwd_input launch itself.
+ *              dx_accumulate != 0 (dim 64 only): dx += instead of dx = (a second contribution to the same gradient)
  * dim must be 32, 64, 128 or 256 with 16-byte aligned rows (ihg_node_linear_workspace_bytes returns -1 otherwise;
  * callers then keep their own GEMM).  `workspace`: ihg_node_linear_workspace_bytes(dim) bytes, 16-byte aligned.
  */
@@ -215,7 +216,7 @@ int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w
 int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* x, int64_t ld_x,
                                const int64_t* type_begin, float* dw, int64_t ld_dw, int64_t dw_type_stride,
                                float* dbias, int32_t bias_type_mask, int64_t dbias_type_stride,
-                               const float* w, int64_t ld_w, float* dx, int64_t ld_dx,
+                               const float* w, int64_t ld_w, float* dx, int64_t ld_dx, int32_t dx_accumulate,
                                void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
