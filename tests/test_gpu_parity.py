@@ -444,9 +444,12 @@ def test_f5_config_c1_matches_reference(tag, kind, order):
         assert rel(feats.double().sum(0), z[f'{tag}.feat_colsum']) <= 1e-4
 
 
+@pytest.mark.parametrize('path', ['module_calls', 'fused_step'])
 @pytest.mark.parametrize('tag', ['ihgnn', 'hgcn'])
-def test_f6_training_curve_and_ranking_metrics(tag):
-    """48 Adam steps on the reference's own batch sequence: loss curve, then HR@10 / NDCG@10 / MAP@10 within 0.002."""
+def test_f6_training_curve_and_ranking_metrics(tag, path):
+    """48 Adam steps on the reference's own batch sequence: loss curve, then HR@10 / NDCG@10 / MAP@10 within 0.002.
+    ``module_calls``: the reference's call sequence (model(u, q, i), BCEWithLogitsLoss, torch.optim.Adam); ``fused_step``: what
+    Main.py and bench.py run (model.bce_loss with taps, last layer at the batch rows, masked last backward, the HIP Adam step)."""
     from ihgnn_amd.Helpers.Metrics import Metrics
     z = np.load(os.path.join(GOLDEN, 'f6_training.npz'))
     w = np.load(os.path.join(GOLDEN, 'f6_workload.npz'))
@@ -454,12 +457,17 @@ def test_f6_training_curve_and_ranking_metrics(tag):
     L, order, d = (int(v) for v in z[f'{tag}.cfg'])
     m = build_model(ds, tag, L, order, d)
     m.load_state_dict({k[len(tag) + 6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f'{tag}.init.')})
-    opt = torch.optim.Adam(m.parameters(), 1e-3, weight_decay=0)
+    if path == 'fused_step':
+        from ihgnn_amd.optim import Adam
+        opt = Adam(m.parameters(), 1e-3, weight_decay=0)
+    else:
+        opt = torch.optim.Adam(m.parameters(), 1e-3, weight_decay=0)
     lossf = torch.nn.BCEWithLogitsLoss()
+    assert m.supports_fused_loss(lossf)
     losses = []
     for b in z[f'{tag}.batches']:
         u, q, i, fl = (torch.from_numpy(b[k].astype(np.int64)).to(dev()) for k in range(4))
-        loss = lossf(m(u, q, i), fl.float())
+        loss = m.bce_loss(u, q, i, fl.float()) if path == 'fused_step' else lossf(m(u, q, i), fl.float())
         loss.backward(); opt.step(); opt.zero_grad()
         losses.append(loss.item())
     np.testing.assert_allclose(losses, z[f'{tag}.losses'], rtol=1e-4)
