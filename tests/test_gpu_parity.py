@@ -505,6 +505,47 @@ def test_full_size_properties_c2_shape():
     assert torch.equal(ops.edge_gather_sum_raw(torch.ones(lay.node_count, 4, device=dev()), lay.i3), torch.full((lay.edge_count, 4), 3.0, device=dev()))
 
 
+def test_full_size_properties_bench_workload():
+    """The bench.py workload itself (C2 stand-in, E = 1.35 M, N = 256 k, d = 64; the oracle would need minutes): identities that
+    hold at any size - the two-hop pass equals K5 followed by K7, the interact kernels are linear in the product weights
+    (Euler: <dW, W> = <out - first-order part, cotangent>), their first-order gradient is K7 of the cotangent, and a row-restricted
+    pass reproduces the full one on its rows."""
+    from ihgnn_amd import ops, synth
+    from ihgnn_amd.layout import IncidenceLayout
+    w_ = synth.draw_config('C2')
+    lay = IncidenceLayout(w_.triples, w_.user_count, w_.query_count, w_.item_count, dev())
+    assert lay.edge_count == 1350000
+    d = 64
+    gen = torch.Generator(device=dev()).manual_seed(11)
+    x = torch.randn(lay.node_count, d, device=dev(), generator=gen)
+    two = ops.node_two_hop(x, lay, out_scale=lay.inv_deg)
+    via_edges = ops.node_segment_sum_raw(ops.edge_gather_sum_raw(x, lay.i3), lay.node_csr, None, lay.inv_deg, 1)
+    assert rel(two, via_edges) <= RTOL_SUM * 4
+    rows = torch.randint(0, lay.node_count, (3300,), device=dev(), generator=gen)
+    part = ops.node_two_hop(x, lay, out_scale=lay.inv_deg, rows=rows.to(torch.int32))
+    assert torch.equal(part[rows], two[rows])
+
+    h = (x / 4).requires_grad_(True)
+    p = torch.randn(lay.node_count, d, device=dev(), generator=gen).requires_grad_(True)
+    wgt = (torch.randn(d, 7 * d, device=dev(), generator=gen) / 21).requires_grad_(True)
+    cot = torch.randn(lay.edge_count, d, device=dev(), generator=gen) / 8
+    out = ops.interact(h, p, wgt, lay, 3)
+    out.backward(cot)
+    first = ops.edge_gather_sum_raw(p.detach(), lay.i3)
+    lhs = (wgt.grad[:, 3 * d:].double() * wgt.detach()[:, 3 * d:].double()).sum()
+    rhs = ((out.detach() - first).double() * cot.double()).sum()
+    assert abs(lhs - rhs) / abs(rhs) <= 1e-4           # two fp32 sums of ~1e8 terms each
+    assert bool((wgt.grad[:, :3 * d] == 0).all())
+    assert rel(p.grad, ops.node_segment_sum_raw(cot, lay.node_csr)) <= RTOL_SUM
+    # Euler again for the member gradient: out's product part is homogeneous of degree 2 (uq, qi, iu) and 3 (uqi) in h
+    wz = wgt.detach().clone(); wz[:, 6 * d:] = 0        # drop the cubic block: then <dh, h> = 2 <product part, cotangent>
+    h2 = h.detach().clone().requires_grad_(True)
+    out2 = ops.interact(h2, p.detach(), wz, lay, 3)
+    out2.backward(cot)
+    assert abs((h2.grad.double() * h2.detach().double()).sum() - 2 * ((out2.detach() - first).double() * cot.double()).sum()) \
+        / abs(2 * ((out2.detach() - first).double() * cot.double()).sum()) <= 1e-4
+
+
 def test_batched_evaluation_equals_per_log_scoring(tmp_path):
     """f1: the GEMM + top-k evaluation loop gives the same metrics as scoring one log at a time."""
     from ihgnn_amd import synth
