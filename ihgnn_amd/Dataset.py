@@ -232,7 +232,7 @@ class GraphDataset(Dataset):
             pack[1, cursor:stop] = q
             pack[2, cursor:stop] = negs
             cursor = stop
-        dev = torch.from_numpy(pack).to(GraphDataset.device)
+        dev = _to_device_async(pack, GraphDataset.device)
         pos, neg = dev[:, :n_pos], dev[:, n_pos:]
         return pos[0], pos[1], pos[2], pos[3], neg[0], neg[1], neg[2], neg[3]
 
@@ -253,6 +253,53 @@ class GraphDataset(Dataset):
             dev = GraphDataset.device
             yield (torch.from_numpy(users).to(dev), torch.from_numpy(queries).to(dev),
                    torch.from_numpy(items).to(dev), torch.from_numpy(labels).to(dev))
+
+
+class _PinnedRing:
+    """A few page-locked staging buffers reused round-robin: a pageable ``.to(device)`` blocks the host until every kernel
+    queued before it has run, which serialises the training loop with the GPU once per step; a pinned, non-blocking copy does
+    not.  A slot is reused only after the copy that last read it has executed (event per slot)."""
+
+    SLOTS = 4
+
+    def __init__(self):
+        self.buffers = [None] * self.SLOTS
+        self.events = [None] * self.SLOTS
+        self.cursor = 0
+
+    def stage(self, array: np.ndarray) -> Tensor:
+        k = self.cursor
+        self.cursor = (k + 1) % self.SLOTS
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        n = array.size
+        buf = self.buffers[k]
+        if buf is None or buf.numel() < n or buf.dtype != torch.from_numpy(array).dtype:
+            buf = self.buffers[k] = torch.empty(max(n, 4096), dtype=torch.from_numpy(array).dtype).pin_memory()
+        view = buf[:n].view(array.shape)
+        view.copy_(torch.from_numpy(array))
+        return view
+
+    def mark(self, k_stream_event) -> None:
+        self.events[(self.cursor - 1) % self.SLOTS] = k_stream_event
+
+
+_RING = None
+
+
+def _to_device_async(array: np.ndarray, device: torch.device) -> Tensor:
+    """Host array -> device tensor without stalling the host behind the GPU's queue (see ``_PinnedRing``)."""
+    global _RING
+    if device.type != 'cuda':
+        return torch.from_numpy(array).to(device)
+    if _RING is None:
+        _RING = _PinnedRing()
+    staged = _RING.stage(np.ascontiguousarray(array))
+    out = staged.to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    _RING.mark(ev)
+    return out
 
 
 class TestSearchLogDataLoader:
