@@ -738,7 +738,12 @@ template <int NBLK>
 __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
     const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ dout, int64_t ld_dout,
     float* __restrict__ slabs, int64_t n_edges, int d) {
-    constexpr int D = 64, TE = 64, V4 = D / 4, DL = TE * V4 / kBlockThreads, HL = 3 * DL;
+    constexpr int D = 64, TE = 64, V4 = D / 4;
+    constexpr int RPP = kWave / V4;                       // rows per 1-KiB DMA piece
+    constexpr int QP = TE / 4 / RPP;                      // pieces per row block of one loader wave
+    // Both tiles are read by the consumers one float per lane with the lanes running over columns (conflict-free as they lie):
+    // plain row images, filled by DMA.  Trip structure as in the forward kernel, with nothing to hand back - the accumulators
+    // stay in the consumers' registers for the whole sweep.
     struct Buffer {
         float dtile[TE][D];
         float mtile[3][TE][D];
@@ -748,60 +753,59 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int subs = d / D;
     const int js = blockIdx.y / subs, cs = blockIdx.y % subs;
+    const int64_t grid = gridDim.x;
+    const int n_my = blockIdx.x < n_tiles ? static_cast<int>((n_tiles - blockIdx.x + grid - 1) / grid) : 0;
 
     if (wave >= 4) {
-        // loaders: deposit rows(T) -> issue rows(T+g) with ids fetched a trip ago -> issue ids(T+2g) -> barrier
-        const int tid = threadIdx.x - kBlockThreads;
-        const int64_t g = gridDim.x;
-        v4f dr[DL], hr[HL];
-        int node[HL], node_next[HL];
-        auto load_ids = [&](int64_t tile_id, int (&dst)[HL]) {
-            const int64_t e_base = tile_id * TE;
+        // loaders: start the DMA of tile k (ids fetched a trip ago) -> fetch the ids of tile k+1 -> barrier (waits for the DMA)
+        const int lw = __builtin_amdgcn_readfirstlane(wave) - 4;
+        const int sub = lane / V4, chunk = lane % V4;
+        const int wrow0 = lw * (TE / 4), row0 = wrow0 + sub;
+        const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u;
+        const char* hsrc = reinterpret_cast<const char*>(h + cs * D) + chunk * 16;
+        const float* dsrc = dout + js * D + chunk * 4;
+        int node[3 * QP];
+        auto load_ids = [&](int64_t tile_id) {
+            const int64_t e0 = tile_id * TE + row0;
+            const int32_t* idp = i3 + e0 * 3;
+            if (tile_id * TE + TE <= n_edges) {
 #pragma unroll
-            for (int x = 0; x < HL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                const int64_t e = e_base + (idx / V4) % TE;
-                dst[x] = e < n_edges ? i3[e * 3 + idx / (V4 * TE)] : 0;
+                for (int x = 0; x < 3 * QP; ++x) node[x] = idp[(x % QP) * RPP * 3 + x / QP];
+            } else {
+#pragma unroll
+                for (int x = 0; x < 3 * QP; ++x) node[x] = e0 + (x % QP) * RPP < n_edges ? idp[(x % QP) * RPP * 3 + x / QP] : -1;
             }
         };
-        auto issue_rows = [&](int64_t tile_id, const int (&src)[HL]) {
-            const int64_t e_base = tile_id * TE;
+        auto start_loads = [&](Buffer& b, int64_t tile_id) {
+            const int64_t e0 = tile_id * TE + row0;
+            const bool full = tile_id * TE + TE <= n_edges;
 #pragma unroll
-            for (int x = 0; x < DL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                const int64_t e = e_base + idx / V4;
-                dr[x] = e < n_edges ? *reinterpret_cast<const v4f*>(dout + e * ld_dout + js * D + (idx % V4) * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < QP; ++q) {
+                const int64_t e = e0 + q * RPP;
+                if (full || e < n_edges) lds_dma16(dsrc + e * ld_dout, &b.dtile[wrow0 + q * RPP][0]);
             }
 #pragma unroll
-            for (int x = 0; x < HL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                hr[x] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(src[x]) * ld_h + cs * D + (idx % V4) * 4);
+            for (int x = 0; x < 3 * QP; ++x)
+                if (full || node[x] >= 0)
+                    lds_dma16(reinterpret_cast<const float*>(hsrc + static_cast<uint64_t>(static_cast<uint32_t>(node[x])) * h_row_bytes),
+                              &b.mtile[x / QP][wrow0 + (x % QP) * RPP][0]);
+            if (!full) {
+                // rows past the end must contribute exact zeros to the contraction over hyperedges: lanes of missing rows (EXEC-masked
+                // out of the DMA above) clear their 16 bytes of the dout image by hand
+#pragma unroll
+                for (int q = 0; q < QP; ++q)
+                    if (e0 + q * RPP >= n_edges) *reinterpret_cast<v4f*>(&b.dtile[row0 + q * RPP][chunk * 4]) = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int x = 0; x < 3 * QP; ++x)
+                    if (node[x] < 0) *reinterpret_cast<v4f*>(&b.mtile[x / QP][row0 + (x % QP) * RPP][chunk * 4]) = v4f{0.f, 0.f, 0.f, 0.f};
             }
         };
-        int64_t t = blockIdx.x;
-        if (t < n_tiles) {
-            load_ids(t, node);
-            issue_rows(t, node);
-        }
-        if (t + g < n_tiles) load_ids(t + g, node_next);
-        int which = 0;
-        while (t < n_tiles) {
-            Buffer& b = buf[which];
-#pragma unroll
-            for (int x = 0; x < DL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                *reinterpret_cast<v4f*>(&b.dtile[idx / V4][(idx % V4) * 4]) = dr[x];
-            }
-#pragma unroll
-            for (int x = 0; x < HL; ++x) {
-                const int idx = tid + kBlockThreads * x;
-                *reinterpret_cast<v4f*>(&b.mtile[idx / (V4 * TE)][(idx / V4) % TE][(idx % V4) * 4]) = hr[x];
-            }
-            if (t + g < n_tiles) issue_rows(t + g, node_next);
-            if (t + 2 * g < n_tiles) load_ids(t + 2 * g, node_next);
+        const int64_t t0 = blockIdx.x;
+        if (n_my > 0) load_ids(t0);
+        for (int k = 0; k <= n_my; ++k) {
+            if (k < n_my) start_loads(buf[k & 1], t0 + k * grid);
+            if (k + 1 < n_my) load_ids(t0 + (k + 1) * grid);
             __syncthreads();
-            t += g;
-            which ^= 1;
         }
         return;
     }
@@ -812,10 +816,9 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
     for (int bk = 0; bk < NBLK; ++bk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[bk][r] = 0.f;
-    int which = 0;
-    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x, which ^= 1) {
-        __syncthreads();
-        const Buffer& b = buf[which];
+    __syncthreads();
+    for (int k = 0; k < n_my; ++k) {
+        const Buffer& b = buf[k & 1];
 #pragma unroll 8
         for (int kk = 0; kk < TE / 2; ++kk) {
             const int e = 2 * kk + half;
@@ -829,6 +832,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_weight_ws_kernel(
 #pragma unroll
             for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z[bk], acc[bk], 0, 0, 0);
         }
+        __syncthreads();
     }
     float* slab = slabs + static_cast<int64_t>(blockIdx.x) * d * NBLK * d;          // slab x: a full [d][NBLK*d] matrix
 #pragma unroll
@@ -1031,8 +1035,10 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
 #undef IHG_MEM_PIPE
     const int subs_ws = (dim / 64) * (dim / 64);
     const int n_slabs = static_cast<int>(std::min<int64_t>(dim >= 64 ? std::max(kPipeGrid / subs_ws, 8) : weight_slabs(dim), (n_edges + 63) / 64));
-    if (dim >= 64) {
+    if (dim >= 64 && ld_h < (int64_t{1} << 30)) {
         hipLaunchKernelGGL((interact_bwd_weight_ws_kernel<NBLK>), dim3(n_slabs, subs_ws), dim3(kWsThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
+    } else if (dim >= 64) {                                  // row strides beyond 32-bit byte offsets: the plain tiling
+        hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<64, NBLK>), dim3(n_slabs, subs_ws), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
     } else {
         hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<32, NBLK>), dim3(n_slabs, 1), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
     }
