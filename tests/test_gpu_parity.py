@@ -546,6 +546,36 @@ def test_full_size_properties_bench_workload():
         / abs(2 * ((out2.detach() - first).double() * cot.double()).sum()) <= 1e-4
 
 
+def test_integration_md_binding_stub_runs():
+    """The ctypes stub INTEGRATION.md shows a maintainer of the reference (section 2) is executed as written, against the
+    built library: SpmmSum.apply == torch.sparse.mm(incidence, x) * Dv^-1, and its backward == the transposed product."""
+    import re
+    from ihgnn_amd import _lib
+    text = open(os.path.join(os.path.dirname(GOLDEN), '..', 'INTEGRATION.md')).read()
+    block = re.search(r"```python\n# Helpers/IhgnnHip.py.*?```", text, re.S).group(0)
+    code = block[len('```python\n'):-3].replace("ctypes.CDLL('libihgnn_hip.so')", f"ctypes.CDLL({_lib.LIB_PATH!r})")
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    U, Q, I, E, d = 40, 7, 30, 500, 16
+    gen = torch.Generator().manual_seed(2)
+    triples = torch.stack([torch.randint(0, U, (E,), generator=gen), torch.randint(0, Q, (E,), generator=gen),
+                           torch.randint(0, I, (E,), generator=gen)], 1).numpy()
+    inc = ns['Incidence'](triples, U, Q, I, dev())
+    rows = torch.from_numpy(triples + np.array([0, U, U + Q])).reshape(-1)
+    cols = torch.arange(E).repeat_interleave(3)
+    dense = torch.zeros(U + Q + I, E)
+    dense.index_put_((rows, cols), torch.ones(3 * E), accumulate=True)
+    deg = dense.sum(1)
+    inv = torch.where(deg > 0, 1 / deg, torch.zeros_like(deg))
+    x = torch.randn(E, d, generator=gen)
+    xg = x.clone().to(dev()).requires_grad_(True)
+    out = ns['SpmmSum'].apply(xg, inc, inv.to(dev()))
+    cot = torch.randn(U + Q + I, d, generator=gen)
+    out.backward(cot.to(dev()))
+    assert rel(out, inv[:, None] * (dense @ x)) <= RTOL_SUM
+    assert rel(xg.grad, dense.t() @ (inv[:, None] * cot)) <= RTOL_SUM
+
+
 def test_batched_evaluation_equals_per_log_scoring(tmp_path):
     """f1: the GEMM + top-k evaluation loop gives the same metrics as scoring one log at a time."""
     from ihgnn_amd import synth
