@@ -195,6 +195,30 @@ class IncidenceLayout:
         self.self_weight = torch.where(isolated, torch.zeros_like(deg), deg).to(device)
 
 
+    def member_csr_chunks(self, n_chunks: int):
+        """``[(e0, e1, Csr)]``: the member lists of ``member_csr`` cut by hyperedge range, ids rebased to the chunk
+        (``3 (e - e0) + type(v)``).  For the interactive backward when the ``[E, 3, d]`` member-gradient buffer has to be produced
+        in pieces (config C5 on one GPU); built on first use and kept."""
+        cache = self.__dict__.setdefault('_member_chunks', {})
+        if n_chunks not in cache:
+            e = self.edge_count
+            step = -(-e // n_chunks)
+            step = -(-step // 128) * 128                     # whole tiles of either tile size
+            mid = self.member_csr.ids_host.astype(np.int64)
+            lens = np.diff(self.member_csr.ptr_host.astype(np.int64))
+            row_of_entry = np.repeat(np.arange(self.node_count, dtype=np.int64), lens)
+            chunks = []
+            for e0 in range(0, e, step):
+                e1 = min(e0 + step, e)
+                pick = (mid >= 3 * e0) & (mid < 3 * e1)
+                counts = np.bincount(row_of_entry[pick], minlength=self.node_count)
+                ptr = np.zeros(self.node_count + 1, np.int64)
+                np.cumsum(counts, out=ptr[1:])
+                chunks.append((e0, e1, Csr(ptr.astype(np.int32), (mid[pick] - 3 * e0).astype(np.int32), self.device, self.member_csr.heavy_threshold)))
+            cache[n_chunks] = chunks
+        return cache[n_chunks]
+
+
 COMPLETENESS = {'uqi': 0, 'uq': 1, 'ui': 2, 'qi': 3}
 
 

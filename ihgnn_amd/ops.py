@@ -363,6 +363,40 @@ def node_linear(x: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceL
 # ---------------------------------------------------------------------------------------------
 # K5+K6 interactive step (orders 2 and 3)
 # ---------------------------------------------------------------------------------------------
+# the [E, 3, d] member-gradient buffer of the interactive backward is produced in hyperedge chunks beyond this many bytes
+MEMBER_BUFFER_LIMIT_BYTES = 48 << 30
+
+
+def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: IncidenceLayout, order: int, dw: Tensor) -> Tensor:
+    """Product-block weight gradient into ``dw`` (its columns from ``3 d`` on) and the member gradients scattered to nodes
+    (returned).  One pass when the ``[E, 3, d]`` buffer fits ``MEMBER_BUFFER_LIMIT_BYTES``, otherwise hyperedge chunks, each with
+    its own member lists (``IncidenceLayout.member_csr_chunks``): same sums, associated chunk by chunk."""
+    lib = _lib.load()
+    n_edges, dim = layout.edge_count, int(h.shape[1])
+    n_chunks = max(1, -(-(n_edges * 3 * dim * 4) // MEMBER_BUFFER_LIMIT_BYTES))
+    if n_chunks == 1:
+        parts = [(0, n_edges, layout.member_csr)]
+    else:
+        parts = layout.member_csr_chunks(n_chunks)
+    dh = None
+    for index, (e0, e1, csr) in enumerate(parts):
+        n = e1 - e0
+        g = torch.empty(n, 3 * dim, dtype=torch.float32, device=h.device)
+        dw_part = dw if index == 0 else torch.empty_like(dw)
+        ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n, dim, order)), h.device)
+        go = grad_out[e0:e1]
+        with profiler.kernel('interact_bwd', n, dim):
+            _lib.check(lib.ihg_interact_bwd(_ptr(h), _ld(h), _ptr(layout.i3[e0:e1]), _ptr(w), _ld(w), order, _ptr(go), _ld(grad_out),
+                                            _ptr(g), _ptr(dw_part), _ld(dw_part), _ptr(ws), ws.numel() * 4, n, dim, _stream()),
+                       'ihg_interact_bwd')
+        if index > 0:
+            dw[:, 3 * dim:].add_(dw_part[:, 3 * dim:])
+        part = node_segment_sum_raw(g.view(3 * n, dim), csr)       # (node v, hyperedge e) reads row 3 (e - e0) + type(v)
+        del g
+        dh = part if dh is None else dh.add_(part)
+    return dh
+
+
 class _Interact(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: int) -> Tensor:
@@ -387,16 +421,8 @@ class _Interact(torch.autograd.Function):
         layout, order = ctx.layout, ctx.order
         grad_out = _rows(grad_out, 'grad_out')
         n_edges, dim = layout.edge_count, int(h.shape[1])
-        g = torch.empty(n_edges, 3 * dim, dtype=torch.float32, device=h.device)
         dw = torch.zeros_like(w)
-        ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
-        with profiler.kernel('interact_bwd', n_edges, dim):
-            _lib.check(lib.ihg_interact_bwd(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(grad_out), _ld(grad_out),
-                                            _ptr(g), _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4, n_edges, dim, _stream()),
-                       'ihg_interact_bwd')
-        # member gradients back to nodes: node type t reads slot t of g (users/queries/items are contiguous id ranges)
-        # member gradients back to nodes: (node v, hyperedge e) reads row 3e + type(v) of g viewed as [3E, d]
-        dh = node_segment_sum_raw(g.view(3 * n_edges, dim), layout.member_csr)
+        dh = _interact_backward(h, w, grad_out, layout, order, dw)
         dp = node_segment_sum_raw(grad_out, layout.node_csr)
         return dh, dp, dw, None, None
 
@@ -433,14 +459,8 @@ class _InteractFromNodes(torch.autograd.Function):
         layout, order = ctx.layout, ctx.order
         grad_out = _rows(grad_out, 'grad_out')
         n_edges, dim = layout.edge_count, int(h.shape[1])
-        g = torch.empty(n_edges, 3 * dim, dtype=torch.float32, device=h.device)
         dw = torch.empty_like(w)                               # product blocks from the interact kernels, first-order blocks from the row-GEMM pass
-        ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
-        with profiler.kernel('interact_bwd', n_edges, dim):
-            _lib.check(lib.ihg_interact_bwd(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(grad_out), _ld(grad_out),
-                                            _ptr(g), _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4, n_edges, dim, _stream()),
-                       'ihg_interact_bwd')
-        dh = node_segment_sum_raw(g.view(3 * n_edges, dim), layout.member_csr)      # (node v, hyperedge e) reads row 3e + type(v)
+        dh = _interact_backward(h, w, grad_out, layout, order, dw)
         dp = node_segment_sum_raw(grad_out, layout.node_csr)
         dbias = torch.empty(dim, dtype=torch.float32, device=h.device) if ctx.has_bias else None
         ws2 = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)

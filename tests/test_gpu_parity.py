@@ -338,6 +338,28 @@ def test_interact_persistent_tiles_and_strided_rows(dim, order, edges):
     assert rel(hg.grad, hc.grad) <= RTOL and rel(wg.grad, wc.grad) <= RTOL
 
 
+@pytest.mark.parametrize('dim', [12, 64])
+def test_interact_backward_in_hyperedge_chunks(dim, monkeypatch):
+    """The [E, 3, d] member-gradient buffer produced in three hyperedge chunks (what config C5 needs on one GPU): gradients
+    equal the one-pass ones up to the association of the chunk sums."""
+    from ihgnn_amd import ops
+    w_, lay = make_layout(150, 9, 120, 2000, seed=dim)
+    gen = torch.Generator().manual_seed(dim)
+    h = torch.randn(lay.node_count, dim, generator=gen).to(dev())
+    p = torch.randn(lay.node_count, dim, generator=gen).to(dev())
+    w = (torch.randn(dim, 7 * dim, generator=gen) / np.sqrt(7 * dim)).to(dev())
+    cot = torch.randn(lay.edge_count, dim, generator=gen).to(dev())
+    grads = []
+    for limit in (ops.MEMBER_BUFFER_LIMIT_BYTES, 2000 * 3 * dim * 4 // 3 + 1):
+        monkeypatch.setattr(ops, 'MEMBER_BUFFER_LIMIT_BYTES', limit)
+        hg, pg, wg = (t.clone().requires_grad_(True) for t in (h, p, w))
+        ops.interact(hg, pg, wg, lay, 3).backward(cot)
+        grads.append((hg.grad, pg.grad, wg.grad))
+    assert len(lay.member_csr_chunks(3)) == 3
+    for one, many in zip(*grads):
+        assert rel(many, one) <= 2e-6
+
+
 # ---------------------------------------------------------------------------------------------
 # layer level: reference fixtures F2
 # ---------------------------------------------------------------------------------------------
