@@ -70,3 +70,15 @@ def test_product_never_imports_the_oracle():
         for fn in files:
             if fn.endswith(('.py', '.hip', '.cpp', '.h')):
                 assert 'oracle' not in open(os.path.join(root, fn)).read(), f'{fn} mentions the oracle'
+
+
+def test_header_is_plain_c():
+    """include/ihgnn_hip.h is the contract for non-Python callers: it must compile as C99 and as C++ on its own."""
+    import shutil
+    import subprocess
+    header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'ihgnn_hip.h')
+    for compiler, lang in (('gcc', ['-x', 'c', '-std=c99']), ('g++', ['-x', 'c++'])):
+        if shutil.which(compiler) is None:
+            pytest.skip(f'{compiler} not installed')
+        proc = subprocess.run([compiler, '-fsyntax-only', '-Wall', '-Werror'] + lang + [header], capture_output=True, text=True)
+        assert proc.returncode == 0, proc.stderr
