@@ -239,6 +239,21 @@ def main():
                        peak=HBM_PEAK_GBS, unit='GB/s', frac=round(k7_achieved / HBM_PEAK_GBS, 4), bytes_per_launch=k7_bytes,
                        avg_us=round(k7['avg_us'], 2), launches=k7['launches'],
                        measured='instrumented pass after the timed region (every launch bracketed)')
+    mfma_roof = None
+    if args.layer == 'ihgnn' and args.order in (2, 3) and 'interact_fwd' in table and 'interact_bwd' in table:
+        # the order-2/3 contraction of layer 0 is the only MFMA-bound piece: 2 m d^2 flop per hyperedge forward
+        # (m product blocks after hoisting), twice that backward (member gradients + weight gradients), against fp32 MFMA
+        m_blocks = 4 if args.order == 3 else 3
+        flops_fwd = 2.0 * m_blocks * dim * dim * E
+        f, bw = table['interact_fwd'], table['interact_bwd']
+        bwd_us = bw['avg_us'] * bw['launches'] / table_steps        # the backward may run in several hyperedge chunks
+        mfma_roof = dict(bound='mfma', kernel='interact_fwd + interact_bwd (order-%d product blocks of layer 0)' % args.order,
+                         peak=157.3, unit='TFLOP/s', dtype='f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32)',
+                         forward=dict(achieved=round(flops_fwd / (f['avg_us'] * 1e-6) / 1e12, 1), frac=round(flops_fwd / (f['avg_us'] * 1e-6) / 157.3e12, 4),
+                                      flops_per_launch=flops_fwd, avg_us=round(f['avg_us'], 2)),
+                         backward=dict(achieved=round(2 * flops_fwd / (bwd_us * 1e-6) / 1e12, 1), frac=round(2 * flops_fwd / (bwd_us * 1e-6) / 157.3e12, 4),
+                                       flops_per_step=2 * flops_fwd, us_per_step=round(bwd_us, 2)),
+                         measured='instrumented pass after the timed region (every launch bracketed)')
     out = {
         'metric': 'hyperedges_aggregated_per_sec', 'value': round(value, 1), 'unit': 'hyperedges/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
@@ -255,6 +270,7 @@ def main():
         'final_loss': round(float(last.item()), 6),
         'roofline': roofline,
         'roofline_hyperedge_to_node': k7_roof,
+        'roofline_interaction': mfma_roof,
         'kernels_us': {name: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] / table_steps} for name, v in table.items()},
         'kernels_us_note': f'HIP events around every launch, {table_steps} untimed steps after the timed region; the timed region brackets K5 only',
     }
