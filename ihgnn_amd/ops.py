@@ -460,8 +460,10 @@ class _InteractFromNodes(torch.autograd.Function):
         grad_out = _rows(grad_out, 'grad_out')
         n_edges, dim = layout.edge_count, int(h.shape[1])
         dw = torch.empty_like(w)                               # product blocks from the interact kernels, first-order blocks from the row-GEMM pass
-        dh = _interact_backward(h, w, grad_out, layout, order, dw)
+        # the scatter of grad_out goes first: K5 has just written it, so most of its 256-byte rows are still in the Infinity Cache
+        # for these random reads; the interact kernels read it as a stream and do not care
         dp = node_segment_sum_raw(grad_out, layout.node_csr)
+        dh = _interact_backward(h, w, grad_out, layout, order, dw)
         dbias = torch.empty(dim, dtype=torch.float32, device=h.device) if ctx.has_bias else None
         ws2 = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)
         with profiler.kernel('node_linear_bwd', h.shape[0], dim):
