@@ -35,6 +35,13 @@ class EmbeddingLayer(nn.Module):
                 item_indices: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
         return self.embed_user(user_indices), self.embed_query(query_indices), self.embed_item(item_indices)
 
+    def all_nodes(self) -> Tensor:
+        """``torch.cat(self(None, None, None))`` as one op (``RawGnn.py:112-113``): ``[U+Q+I, d]``."""
+        w = self.embedding_bag_vocabulary.weight
+        if w.is_cuda and Gs.Query.transform == Gsv.mean:
+            return ops.embed_all_nodes(self.embedding_user.weight, self.embedding_item.weight, w, self.dataset.bag_layout)
+        return torch.cat(self(None, None, None))
+
     def embed_user(self, user_indices: Optional[Tensor] = None) -> Tensor:
         w = self.embedding_user.weight
         return w[1:] if user_indices is None else w[user_indices + 1]

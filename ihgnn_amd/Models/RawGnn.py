@@ -65,7 +65,7 @@ class RawGnn(nn.Module):
         are the batch tail's halves, whose gradients travel through the holder instead of dense ``[N, d]`` tensors.
         ``batch_rows`` (int64 node rows): nobody reads ``XL`` outside these rows (a training step scores the batch only), so
         the last hypergraph layer computes just them (plus the split rows of its plan) and leaves the rest unwritten."""
-        x = torch.cat(self.embeddings(None, None, None))
+        x = self.embeddings.all_nodes()
         outputs = []
         last = len(self.gnns)
         for depth in range(last + 1):

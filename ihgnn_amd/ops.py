@@ -249,6 +249,53 @@ def bag_mean(table: Tensor, bag: BagLayout) -> Tensor:
     return _BagMean.apply(table, bag)
 
 
+class _EmbedAllNodes(torch.autograd.Function):
+    """``X0 = [user table rows 1.. ; bag means of the query words ; item table rows 1..]`` assembled in one buffer (the bag
+    kernel writes its rows in place), with a backward that hands each table its gradient without a full-size zero fill."""
+
+    @staticmethod
+    def forward(ctx, user_table: Tensor, item_table: Tensor, word_table: Tensor, bag: BagLayout) -> Tensor:
+        lib = _lib.load()
+        word_table = _rows(word_table, 'word table')
+        u, q, i = int(user_table.shape[0]) - 1, bag.n_bags, int(item_table.shape[0]) - 1
+        dim = int(word_table.shape[1])
+        x = torch.empty(u + q + i, dim, dtype=torch.float32, device=word_table.device)
+        x[:u].copy_(user_table[1:])
+        x[u + q:].copy_(item_table[1:])
+        rows = x[u:u + q]
+        if q > 0:
+            with profiler.kernel('bag_mean_fwd', q, dim):
+                _lib.check(lib.ihg_bag_mean_fwd(_ptr(word_table), _ld(word_table), _ptr(bag.bags.ptr), _ptr(bag.bags.ids), _ptr(bag.bag_len),
+                                                _ptr(rows), dim, q, dim, _stream()), 'ihg_bag_mean_fwd')
+        ctx.bag, ctx.counts = bag, (u, q, i)
+        return x
+
+    @staticmethod
+    def backward(ctx, grad: Tensor):
+        lib = _lib.load()
+        bag, (u, q, i) = ctx.bag, ctx.counts
+        grad = _rows(grad, 'grad')
+        dim = int(grad.shape[1])
+        d_user = torch.empty(u + 1, dim, dtype=torch.float32, device=grad.device)
+        d_user[0].zero_()                                     # the padding row gets no gradient
+        d_user[1:].copy_(grad[:u])
+        d_item = torch.empty(i + 1, dim, dtype=torch.float32, device=grad.device)
+        d_item[0].zero_()
+        d_item[1:].copy_(grad[u + q:])
+        d_word = torch.empty(bag.table_rows, dim, dtype=torch.float32, device=grad.device)
+        g_q = grad[u:u + q]
+        with profiler.kernel('bag_mean_bwd', bag.table_rows, dim):
+            _lib.check(lib.ihg_bag_mean_bwd(_ptr(g_q), _ld(grad), _ptr(bag.words_of.ptr), _ptr(bag.words_of.ids),
+                                            _ptr(bag.inv_len), _ptr(d_word), dim, bag.table_rows, dim, _stream()), 'ihg_bag_mean_bwd')
+        return d_user, d_item, d_word, None
+
+
+def embed_all_nodes(user_table: Tensor, item_table: Tensor, word_table: Tensor, bag: BagLayout) -> Tensor:
+    """The full-graph input features ``EmbeddingLayer(None, None, None)`` concatenated (``RawGnn.py:112-113``): ``[U+Q+I, d]``
+    from the ``[U+1, d]`` / ``[I+1, d]`` tables (row 0 = padding) and the ``[V+1, d]`` word table."""
+    return _EmbedAllNodes.apply(user_table, item_table, word_table, bag)
+
+
 # ---------------------------------------------------------------------------------------------
 # K4: node-level dense transforms (feature_transform and the hoisted u / q / i blocks of the aggregation)
 # ---------------------------------------------------------------------------------------------
