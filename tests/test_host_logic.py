@@ -80,6 +80,23 @@ def test_csr_is_node_major_sorted_and_complete():
         assert b[0] == ptr[row] and e[-1] == ptr[row + 1] and (b[1:] == e[:-1]).all() and ((e - b) <= 128).all()
 
 
+def test_member_lists_cut_by_hyperedge_range_partition_the_full_lists():
+    """``member_csr_chunks`` (the interactive backward in pieces): every chunk's lists are the full list's entries of that
+    hyperedge range, rebased; chunk boundaries are whole tiles; nothing is lost or repeated."""
+    w = synth.draw(50, 20, 70, 30, 2000, seed=4, distribution='powerlaw')
+    lay = IncidenceLayout(w.triples, 50, 20, 70, CPU, heavy_threshold=64)
+    full_ptr, full_ids = lay.member_csr.ptr_host, lay.member_csr.ids_host
+    chunks = lay.member_csr_chunks(3)
+    assert [c[0] for c in chunks] == [0, 768, 1536] and chunks[-1][1] == 2000 and all(c[0] % 128 == 0 for c in chunks)
+    assert lay.member_csr_chunks(3) is chunks                                    # built once
+    for v in range(140):
+        mine = full_ids[full_ptr[v]:full_ptr[v + 1]]
+        pieces = [csr.ids_host[csr.ptr_host[v]:csr.ptr_host[v + 1]].astype(np.int64) + 3 * e0 for e0, _, csr in chunks]
+        assert np.array_equal(np.concatenate(pieces), mine)
+        for (e0, e1, _), piece in zip(chunks, pieces):
+            assert ((piece // 3 >= e0) & (piece // 3 < e1)).all()
+
+
 def test_build_csr_rejects_bad_ids():
     from ihgnn_amd._lib import IhgnnHipError
     with pytest.raises(IhgnnHipError, match='out of range'):
