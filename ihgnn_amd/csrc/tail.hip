@@ -110,15 +110,19 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(float* __r
                                                                       const int64_t* __restrict__ rows, int n, float* __restrict__ dense,
                                                                       int64_t ld_dense, int block_width, int64_t block_stride,
                                                                       float* __restrict__ tail, int64_t tail_row_offset, int64_t tail_rows,
-                                                                      int32_t* __restrict__ leader) {
+                                                                      int32_t* __restrict__ leader, int block_rows) {
+    // block_rows: rows of different consecutive blocks of this many batch rows never share a destination (the user / query / item
+    // thirds of a batch address disjoint node ranges), so a wave only scans its own block; n = one block is the general case
     __shared__ int32_t key[kScatterMax];                    // every workgroup keeps the whole id list in LDS (<= 64 KiB)
     for (int k = threadIdx.x; k < n; k += kBlockThreads) key[k] = static_cast<int32_t>(rows[k]);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     for (int64_t k = global_wave_id(); k < n; k += global_wave_count()) {
         const int32_t mine = key[k];
+        const int lo = static_cast<int>(k) / block_rows * block_rows;
+        const int hi = lo + block_rows < n ? lo + block_rows : n;
         bool follower = false;
-        for (int base = 0; base < k; base += kWave) {
+        for (int base = lo; base < k; base += kWave) {
             const int j = base + lane;
             if (__ballot(j < k && key[j] == mine) != 0ull) { follower = true; break; }
         }
@@ -126,9 +130,9 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(float* __r
         if (follower) continue;
         for (int c0 = 0; c0 < width; c0 += 4 * kWave) {
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int base = static_cast<int>(k) & ~(kWave - 1); base < n; base += kWave) {
+            for (int base = static_cast<int>(k) & ~(kWave - 1); base < hi; base += kWave) {
                 const int j = base + lane;
-                unsigned long long mask = __ballot(j >= k && j < n && key[j] == mine);
+                unsigned long long mask = __ballot(j >= k && j < hi && key[j] == mine);
                 while (mask != 0ull) {
                     // up to 16 members per trip: all their loads are issued before the first add (a hot destination - a
                     // popular query - can own hundreds of batch rows); absent slots add an exact 0
@@ -306,18 +310,20 @@ int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t widt
     if (rowgrad == nullptr || rows == nullptr || dense == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: null pointer");
     hipLaunchKernelGGL(batch_scatter_kernel<false>, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
                        const_cast<float*>(rowgrad), ld_rowgrad, width, rows, static_cast<int>(n_rows), dense, ld_dense, block_width, block_stride, tail,
-                       tail_row_offset, tail_rows, static_cast<int32_t*>(nullptr));
+                       tail_row_offset, tail_rows, static_cast<int32_t*>(nullptr), static_cast<int>(n_rows));
     return check_launch("ihg_batch_scatter_add");
 }
 
-int ihg_batch_combine(float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows, int32_t* leader, ihg_stream_t stream) {
+int ihg_batch_combine(float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows, int64_t disjoint_block_rows,
+                      int32_t* leader, ihg_stream_t stream) {
     if (n_rows < 0 || n_rows > kScatterMax) return fail(IHG_ERR_INVALID, "ihg_batch_combine: 0..%d rows supported, got %lld", kScatterMax, (long long)n_rows);
     if (width <= 0 || ld_rowgrad < width) return fail(IHG_ERR_INVALID, "ihg_batch_combine: bad width / stride");
     if (n_rows == 0) return IHG_OK;
     if (rowgrad == nullptr || rows == nullptr || leader == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_combine: null pointer");
+    if (disjoint_block_rows <= 0 || disjoint_block_rows > n_rows) disjoint_block_rows = n_rows;
     hipLaunchKernelGGL(batch_scatter_kernel<true>, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad,
                        ld_rowgrad, width, rows, static_cast<int>(n_rows), static_cast<float*>(nullptr), int64_t{0}, 1, int64_t{0},
-                       static_cast<float*>(nullptr), int64_t{0}, int64_t{0}, leader);
+                       static_cast<float*>(nullptr), int64_t{0}, int64_t{0}, leader, static_cast<int>(disjoint_block_rows));
     return check_launch("ihg_batch_combine");
 }
 

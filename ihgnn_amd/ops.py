@@ -736,7 +736,7 @@ class _HemBceLoss(torch.autograd.Function):
         if lib.ihg_batch_scatter_workspace_bytes(n) >= 0:    # one pass sums duplicate destinations; the taps then add plain rows
             holder.leader = torch.empty(n, dtype=torch.int32, device=rows.device)
             with profiler.kernel('batch_combine', n, width + 1):
-                _lib.check(lib.ihg_batch_combine(_ptr(rowgrad), int(rowgrad.stride(0)), width + 1, _ptr(rows), n, _ptr(holder.leader), _stream()),
+                _lib.check(lib.ihg_batch_combine(_ptr(rowgrad), int(rowgrad.stride(0)), width + 1, _ptr(rows), n, n // 3, _ptr(holder.leader), _stream()),
                            'ihg_batch_combine')
         dbias = torch.zeros_like(bias)
         holder.add_into(None, width, 1, dbias, ctx.offset)

@@ -254,9 +254,11 @@ int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t widt
  * per layer output, as the backward reaches it): ihg_batch_combine sums the rows of equal destination INTO the first of them,
  * in place, and sets leader[k] = 1 on those first occurrences (0 elsewhere); ihg_batch_rows_add then does
  * dense[rows[k], 0:width] += src[k, 0:width] over the leader rows (src = any column window of the combined rowgrad), or, with
- * `tail`, tail[rows[k] - tail_row_offset] += src[k, 0].  Leaders have distinct destinations: no atomics, fixed order. */
-int ihg_batch_combine(float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows, int32_t* leader,
-                      ihg_stream_t stream);
+ * `tail`, tail[rows[k] - tail_row_offset] += src[k, 0].  Leaders have distinct destinations: no atomics, fixed order.
+ * disjoint_block_rows (0 = n_rows): consecutive blocks of that many batch rows are known not to share destinations - the user,
+ * query and item thirds of a batch - so equal destinations are only looked for inside a block. */
+int ihg_batch_combine(float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows,
+                      int64_t disjoint_block_rows, int32_t* leader, ihg_stream_t stream);
 int ihg_batch_rows_add(const float* src, int64_t ld_src, int32_t width, const int64_t* rows, const int32_t* leader, int64_t n_rows,
                        float* dense, int64_t ld_dense, float* tail, int64_t tail_row_offset, int64_t tail_rows, ihg_stream_t stream);
 

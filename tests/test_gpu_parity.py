@@ -761,7 +761,7 @@ def test_batch_combine_then_rows_add(n, width):
     outs = []
     for _ in range(2):
         combined, leader = rowgrad.clone(), torch.full((n,), -1, dtype=torch.int32, device=dev())
-        _lib.check(lib.ihg_batch_combine(ops._ptr(combined), combined.stride(0), width, ops._ptr(rows), n, ops._ptr(leader), ops._stream()), 'combine')
+        _lib.check(lib.ihg_batch_combine(ops._ptr(combined), combined.stride(0), width, ops._ptr(rows), n, 0, ops._ptr(leader), ops._stream()), 'combine')
         assert int(leader.sum()) == int(rows.unique().numel()) and bool(((leader == 0) | (leader == 1)).all())
         dense, tail = base.clone(), torch.zeros(n_dense - 100, device=dev())
         half = (width - 1) // 2
@@ -810,6 +810,26 @@ def test_adam_matches_torch_adam():
     c.step(); b.step()
     for p, r in zip(ours, theirs):
         assert rel(p, r) <= 2e-6
+
+
+def test_batch_combine_with_disjoint_thirds():
+    """The user / query / item thirds of a batch address disjoint node ranges: telling the combine pass so (it then looks for equal
+    destinations inside a third only) changes neither the sums nor the leaders."""
+    from ihgnn_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(4)
+    b, width = 1100, 193
+    rows = torch.cat([torch.randint(0, 300, (b,), generator=gen), 300 + torch.randint(0, 40, (b,), generator=gen),
+                      340 + torch.randint(0, 500, (b,), generator=gen)]).to(dev())
+    rowgrad = torch.randn(3 * b, width + 3, generator=gen).to(dev())
+    outs = []
+    for block in (0, b):
+        combined, leader = rowgrad.clone(), torch.full((3 * b,), -1, dtype=torch.int32, device=dev())
+        _lib.check(lib.ihg_batch_combine(ops._ptr(combined), combined.stride(0), width, ops._ptr(rows), 3 * b, block, ops._ptr(leader), ops._stream()), 'combine')
+        outs.append((combined, leader))
+    assert torch.equal(outs[0][1], outs[1][1])
+    lead = outs[0][1].bool()
+    assert torch.equal(outs[0][0][lead][:, :width], outs[1][0][lead][:, :width])
 
 
 def test_fused_bce_tail_equals_unfused_path():
