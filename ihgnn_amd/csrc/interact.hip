@@ -968,6 +968,18 @@ inline int weight_slabs(int dim) {
     return n < 8 ? 8 : n;
 }
 constexpr int kFwdGrid = 256 * 3;
+
+// Persistent grid of a plain (one role) tiling: as many workgroups as are resident at once - a larger grid runs in rounds, and
+// the workgroups of the last round start when the others have already walked their whole share of the tiles.
+template <typename Kernel>
+int resident_grid(Kernel kernel) {
+    int per_cu = 0, device = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlockThreads, 0) != hipSuccess || per_cu < 1) return kFwdGrid;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&device) == hipSuccess && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    return per_cu * cus;
+}
 constexpr int kPipeGrid = 256;          // wave-specialised kernels: one 512-thread workgroup per CU
 
 
@@ -977,7 +989,8 @@ void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float
 #define IHG_FWD(D)                                                                                                          \
     {                                                                                                                       \
         const int64_t tiles = (n_edges + TileShape<D>::TE - 1) / TileShape<D>::TE;                                          \
-        const int grid = static_cast<int>(std::min<int64_t>(tiles, kFwdGrid));                                              \
+        static const int resident = resident_grid(interact_fwd_mfma_kernel<D, NBLK>);                                       \
+        const int grid = static_cast<int>(std::min<int64_t>(tiles, resident));                                              \
         hipLaunchKernelGGL((interact_fwd_mfma_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges); \
     }
 #define IHG_FWD_PIPE(D)                                                                                                     \
@@ -1008,7 +1021,8 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
 #define IHG_MEM(D)                                                                                                          \
     {                                                                                                                       \
         constexpr int TE = D == 32 ? 128 : 64;                                                                              \
-        const int grid = static_cast<int>(std::min<int64_t>((n_edges + TE - 1) / TE, kFwdGrid));                            \
+        static const int resident = resident_grid(interact_bwd_members_mfma_kernel<D, NBLK>);                               \
+        const int grid = static_cast<int>(std::min<int64_t>((n_edges + TE - 1) / TE, resident));                            \
         hipLaunchKernelGGL((interact_bwd_members_mfma_kernel<D, NBLK>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
     }
 #define IHG_MEM_PIPE(D)                                                                                                     \
