@@ -1,22 +1,38 @@
 #!/usr/bin/env python3
 """Benchmark of the hypergraph message-passing hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--no-cpu-baseline]
 
 Metric (BASELINE.json / SURVEY.md §8 d1): hyperedges aggregated per second = E * L * steps / wall time, where one
 "hyperedge aggregated" is one hyperedge taken through one layer's node->hyperedge and hyperedge->node phases.
-A step is one FULL training step of RawGnn (full-graph propagation forward, BCE loss on a 1100-row batch, backward,
-gradient all-reduce when N > 1, Adam) - nothing is skipped inside the timed region.  Inputs (graph layout, weights,
-pre-drawn batches) are resident in HBM before the clock starts.  With N > 1 every rank holds a full replica and its
-own batches (weak scaling) and the value is the aggregate over ranks.
+A step is one FULL training step of RawGnn (full-graph propagation forward over every row of every layer, BCE loss on a
+1100-row batch, backward, gradient all-reduce when N > 1, Adam) - nothing is skipped inside the timed region.  Inputs
+(graph layout, weights, pre-drawn batches) are resident in HBM before the clock starts.  With N > 1 every rank holds a
+full replica and its own batches (weak scaling) and the value is the aggregate over ranks.
 
-One JSON line is printed by rank 0, carrying `roofline` (node->hyperedge gather-sum kernel K5 against the HBM
-roofline, timed with HIP events on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle =
-the reference's PyTorch-CPU op sequence, timed on this box's host cores on a bounded sub-sample).
+Workload: the largest BASELINE config that fits one GPU's step budget, C3 (CIKM-Cup-2016 stand-in: d = 128, 3 layers; it is
+also the per-GPU replica shape of C4).  --config C2 / C1 / C5 select the others (C5 on one GPU takes ~1.1 s per step).
+
+`--gpus N` without a torchrun environment launches itself: the parent starts N child processes (one per GPU) BEFORE it
+touches the GPU and forwards rank 0's JSON line; under `python -m torch.distributed.run` it uses the ranks it was given.
+
+One JSON line is printed by rank 0.  It carries
+  roofline                    K5 (node->hyperedge gather-sum) against the HBM roofline: `achieved` = COMPULSORY HBM bytes per launch
+                              (every touched node row once + the [E,d] store + the ids) / the kernel's average duration measured with
+                              HIP events on the launch stream inside the timed region; `algorithmic_gbs` = the SURVEY §8 d3 byte model
+                              (16 d + 12 B per hyperedge, row re-reads counted - they are served by L2 / Infinity Cache, so this rate
+                              may exceed the HBM peak and is NOT used for `frac`); `traffic` = PMC-measured HBM bytes per launch
+                              (profiles/r2/pmc_traffic_<config>.json) when committed for this exact workload;
+  roofline_hyperedge_to_node  one object per K7 launch role (edge features -> nodes, member gradients -> nodes, two-hop ...), each with
+                              its own byte counts;
+  roofline_interaction        the order-2/3 contraction (fp32 MFMA) - the kernels that own most of a C3 / C5 step;
+  cpu_baseline                the CPU oracle (= the reference's PyTorch-CPU op sequence) timed on this box's host cores on a stated
+                              sub-sample of the same config.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,37 +40,69 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 WORKLOAD_NOTES = {
     'C1': 'C1 = BASELINE configs[0]: synthetic 1k-user / 1k-item / 500-query hypergraph (the reference\'s CPU-runnable case);',
     'C2': 'C2: size-matched synthetic stand-in for BASELINE configs[1] (Amazon-Electronics subset; the corpus is not in the image);',
-    'C3': 'C3: size-matched synthetic stand-in for BASELINE configs[2] (CIKM-Cup-2016 Track 2; the corpus is not in the image);',
+    'C3': 'C3: size-matched synthetic stand-in for BASELINE configs[2] (CIKM-Cup-2016 Track 2, dim 128, 3 layers; the corpus is not in the image; '
+          'also the per-GPU replica shape of configs[3]);',
     'C5': 'C5 = BASELINE configs[4]: synthetic power-law 10M-node / 50M-hyperedge hypergraph;',
 }
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy bandwidth is ~6290
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a float4 streaming copy reaches ~6290
+MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', default='C2', help='synth.CONFIGS key (C1 | C2 | C3 | C5)')
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='C3', help='synth.CONFIGS key (C1 | C2 | C3 | C5)')
     ap.add_argument('--order', type=int, default=3)
     ap.add_argument('--layer', default='ihgnn', choices=['ihgnn', 'hgcn'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-scale', type=float, default=0.125, help='fraction of the workload the CPU baseline runs on')
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket kernels with HIP events')
+    ap.add_argument('--no-extras', action='store_true', help='skip the untimed extra passes (per-kernel table, restricted last layer, forward only)')
     ap.add_argument('--scale', type=float, default=1.0, help='shrink every count of the workload (exploratory runs of the big configs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for smoke tests)')
     ap.add_argument('--device', type=int, default=-1, help='force every rank onto this GPU ordinal (single-GPU smoke test of the N-rank path)')
+    ap.add_argument('--sync', default='bucketed', choices=['flat', 'bucketed', 'sharded'],
+                    help='gradient exchange for --gpus > 1: one flat all-reduce | per-bucket all-reduces from a side stream | reduce-scatter + sharded Adam + all-gather')
     return ap.parse_args()
 
 
+def launch_ranks(args) -> int:
+    """Parent of a self-launched N-rank run.  Nothing here initialises the GPU: the children do."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    children = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                         stdout=None if rank == 0 else subprocess.DEVNULL))
+    codes = []
+    deadline = None
+    while children:
+        for c in list(children):
+            rc = c.poll()
+            if rc is None:
+                continue
+            children.remove(c)
+            codes.append(rc)
+            if rc != 0 and deadline is None:
+                deadline = time.time() + 30          # a rank died: give the others a moment, then stop them (they would wait forever)
+        if deadline is not None and time.time() > deadline:
+            for c in children:
+                c.kill()
+        time.sleep(0.05)
+    return max(abs(c) for c in codes) if codes else 1
+
+
 def build_model(ds, dev, layer, layers, order, dim):
+    import torch
     from ihgnn_amd.Models import HGCNLayer, HemPredictionLayer, IHGNNLayer, RawGnn
     torch.manual_seed(0)
     layer_t = IHGNNLayer if layer == 'ihgnn' else HGCNLayer
@@ -62,10 +110,12 @@ def build_model(ds, dev, layer, layers, order, dim):
 
 
 def cpu_baseline(config, layer, layers, order, dim, scale):
-    """Time the oracle's full training step on the host cores, on a `scale` sub-sample of the workload.
+    """Time the oracle's full training step on the host cores, on a `scale` sub-sample of the SAME config (every count scaled).
 
     PyTorch-CPU does not scale to hundreds of threads on this op mix, so a few thread counts are probed with one step
     each and the fastest is used for the timed run (`cores` reports that count)."""
+    import numpy as np
+    import torch
     from ihgnn_amd import synth
     from oracle import ihgnn_ref as ref
     host = os.cpu_count() or 1
@@ -103,19 +153,53 @@ def cpu_baseline(config, layer, layers, order, dim, scale):
     dt = time.perf_counter() - t0
     return dict(value=w.edge_count * layers * n / dt, unit='hyperedges/s', cores=cores, kind='port',
                 sample=f'{n} full training steps of the PyTorch-CPU oracle (reference op sequence) on a {scale:g}x sub-sample of '
-                       f'{config} (E={w.edge_count}, N={w.node_count}); {cores} threads = fastest of {sorted(probes)} probed on a '
-                       f'{host}-core host, torch {torch.__version__}',
+                       f'{config} (every count scaled: E={w.edge_count}, N={w.node_count}, d={dim}, {layers} layers); {cores} threads = fastest of '
+                       f'{sorted(probes)} probed on a {host}-core host, torch {torch.__version__}',
                 ms_per_step=1e3 * dt / n)
+
+
+def k7_roles(table, E, N, dim, layout, table_steps):
+    """One roofline object per K7 launch role.  Bytes per launch:
+         algorithmic  = every gathered row counted (12 d + 12 per incidence triple + (N/E)(4 d + 8) per output row)
+         compulsory   = every source row once + the ids + the output rows (what must cross the HBM pins at least once)."""
+    row = 4 * dim
+    n_src_edges = E * row
+    roles = {
+        # name: (source rows, gathers, id bytes, what)
+        'k7.edges_to_nodes': (E, 3 * E, 12 * E, 'forward of the interactive layer: [E,d] hyperedge features -> [N,d] (x Dv^-1)'),
+        'k7.first_order_gradient': (E, 3 * E, 12 * E, 'backward: [E,d] cotangent -> d P0 [N,d]'),
+        'k7.member_gradients': (3 * E, 3 * E, 12 * E, 'backward: [E,3,d] member gradients -> d H [N,d] (every row read exactly once)'),
+        'k7.two_hop': (N, 6 * E + N, 24 * E, 'first-order layer forward: node table -> node table over hop2_csr (no [E,d] intermediate)'),
+        'k7.two_hop_bwd': (N, 6 * E + N, 24 * E, 'first-order layer backward (same operator, scalings swapped)'),
+        'k7.edges_to_nodes_bwd_of_k5': (E, 3 * E, 12 * E, 'backward of a K5 launch'),
+    }
+    out = {}
+    for name, (src_rows, gathers, id_bytes, what) in roles.items():
+        if name not in table:
+            continue
+        t = table[name]['avg_us'] * 1e-6
+        algorithmic = gathers * row + id_bytes + N * (row + 8)
+        compulsory = src_rows * row + id_bytes + N * (row + 8)
+        out[name] = dict(what=what, avg_us=round(table[name]['avg_us'], 2), launches_per_step=table[name]['launches'] / table_steps,
+                         compulsory_bytes=compulsory, achieved=round(compulsory / t / 1e9, 1), frac=round(compulsory / t / 1e9 / HBM_PEAK_GBS, 4),
+                         algorithmic_bytes=algorithmic, algorithmic_gbs=round(algorithmic / t / 1e9, 1))
+    return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     from ihgnn_amd import distributed as ihg_dist, profiler, synth
     from ihgnn_amd.Dataset import GraphDataset
 
     rank, local_rank, world = ihg_dist.init_from_env(args.backend if args.gpus > 1 else None)
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     dev = torch.device(f'cuda:{args.device if args.device >= 0 else local_rank}')
     torch.cuda.set_device(dev)
 
@@ -125,15 +209,18 @@ def main():
     ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets,
                                   w.triples, device=dev)
     model = build_model(ds, dev, args.layer, layers, args.order, dim)
-    _ = ds.hypergraph.layout
+    layout = ds.hypergraph.layout
     from ihgnn_amd.optim import Adam
-    opt = Adam(model.parameters(), 1e-3, weight_decay=0)     # torch.optim.Adam's update rule, one HIP launch
     lossf = torch.nn.BCEWithLogitsLoss()
-    sync = ihg_dist.GradientSync(model.parameters()) if world > 1 else None
-    if sync is not None:
+    sync = None
+    if world > 1:
+        sync = ihg_dist.make_gradient_sync(model, args.sync)
         sync.broadcast_parameters(0)
+    opt = sync.optimizer(1e-3) if (sync is not None and sync.owns_optimizer) else Adam(model.parameters(), 1e-3, weight_decay=0)
     batches = list(ds.sample_batches(100, args.steps + args.warmup, seed=1000 + rank))
     fused_loss = model.supports_fused_loss(lossf)
+    # headline = the step with every layer evaluated over ALL rows (each hyperedge through both phases of each layer)
+    model.batch_rows_only_last_layer = False
 
     def step(k):
         u, q, i, y = batches[k]
@@ -153,10 +240,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for k in range(args.warmup):
         step(k)
     # Inside the timed region only the roofline kernel (K5) is bracketed by HIP events: a pair of timing events costs a few
-    # microseconds of stream time, and bracketing all ~35 launches of a step would inflate it by ~7 %.
+    # microseconds of stream time, and bracketing all launches of a step would inflate it.
     if not args.no_kernel_events:
         profiler.start(only={'edge_gather_sum'})
     fence()
@@ -164,81 +258,77 @@ def main():
     for k in range(args.warmup, args.warmup + args.steps):
         last = step(k)
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     profiler.stop()
     kernels = profiler.summary() if not args.no_kernel_events else {}
-    # per-kernel table (and the K7 figure): a second, untimed pass over the same batches with every launch bracketed
-    table_steps = min(args.steps, 10)
-    table = {}
-    if not args.no_kernel_events:
-        profiler.start()
-        for k in range(args.warmup, args.warmup + table_steps):
+    final_loss = float(last.item())
+
+    table, table_steps, restricted_elapsed, fwd_elapsed = {}, min(args.steps, 5), None, None
+    if not args.no_extras:
+        # per-kernel table (K7 roles, MFMA kernels): a second, untimed pass over the same batches with every launch bracketed
+        if not args.no_kernel_events:
+            profiler.start()
+            for k in range(args.warmup, args.warmup + table_steps):
+                step(k)
+            fence()
+            profiler.stop()
+            table = profiler.summary()
+        # the same step with the last layer's hyperedge -> node pass evaluated only at the rows the loss reads (split rows + the 3B
+        # batch rows): identical loss and gradients, what the training loop runs by default; reported beside the headline
+        model.batch_rows_only_last_layer = True
+        for k in range(2):
             step(k)
         fence()
-        profiler.stop()
-        table = profiler.summary()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # the same step with the last layer's hyperedge -> node pass over ALL rows (the default evaluates it at the rows the loss
-    # reads - all split rows plus the 3B batch rows - which changes neither the loss nor any gradient), reported beside the headline
-    model.batch_rows_only_last_layer = False
-    for k in range(2):
-        step(k)
-    fence()
-    t2 = time.perf_counter()
-    full_steps = min(args.steps, 10)
-    for k in range(args.warmup, args.warmup + full_steps):
-        step(k)
-    fence()
-    full_elapsed = (time.perf_counter() - t2) / full_steps
-    if world > 1:
-        t = torch.tensor([full_elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        full_elapsed = float(t.item())
-    model.batch_rows_only_last_layer = True
-
-    # forward-only propagation (the save_features_for_test path), reported beside the headline
-    with torch.no_grad():
-        model.propagate(); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(max(args.steps, 5)):
-            model.propagate()
-        torch.cuda.synchronize()
-        fwd_elapsed = (time.perf_counter() - t1) / max(args.steps, 5)
+        t2 = time.perf_counter()
+        n_r = min(args.steps, 10)
+        for k in range(args.warmup, args.warmup + n_r):
+            step(k)
+        fence()
+        restricted_elapsed = max_over_ranks((time.perf_counter() - t2) / n_r)
+        model.batch_rows_only_last_layer = False
+        # forward-only propagation (the save_features_for_test path)
+        with torch.no_grad():
+            model.propagate(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_f = max(min(args.steps, 10), 3)
+            for _ in range(n_f):
+                model.propagate()
+            torch.cuda.synchronize()
+            fwd_elapsed = (time.perf_counter() - t1) / n_f
 
     if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     E, N = w.edge_count, w.node_count
     value = world * E * layers * args.steps / elapsed
-    k5_bytes = E * (16 * dim + 12)                       # 3 ids + 3 row reads + 1 row write per hyperedge
+    row = 4 * dim
+    touched = int((layout.degree > 0.5).sum().item())
+    k5_compulsory = touched * row + E * row + 12 * E          # every touched node row once + the [E,d] store + the ids
+    k5_algorithmic = E * (16 * dim + 12)                       # 3 ids + 3 row reads + 1 row write per hyperedge
     roofline = None
-    traffic = None                                       # HBM bytes per K5 launch from the committed PMC passes (profiles/)
-    pmc_file = os.path.join(REPO, 'profiles', 'r1', 'pmc_traffic.json')
-    if os.path.exists(pmc_file):
-        pmc = json.load(open(pmc_file))
-        if (pmc.get('workload'), pmc.get('dim'), pmc.get('edges')) == (args.config, dim, E):
-            traffic = pmc['edge_gather_sum']['hbm_bytes_per_launch']
+    traffic = traffic_source = None                            # HBM bytes per K5 launch from the committed PMC passes (profiles/)
+    for pmc_file in (os.path.join(REPO, 'profiles', 'r2', f'pmc_traffic_{args.config}.json'), os.path.join(REPO, 'profiles', 'r1', 'pmc_traffic.json')):
+        if os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            if (pmc.get('workload'), pmc.get('dim'), pmc.get('edges')) == (args.config, dim, E) and 'edge_gather_sum' in pmc:
+                traffic = pmc['edge_gather_sum']['hbm_bytes_per_launch']
+                traffic_source = f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled (gfx950) ({os.path.relpath(pmc_file, REPO)})'
+                break
     if 'edge_gather_sum' in kernels:
         k5 = kernels['edge_gather_sum']
-        achieved = k5_bytes / (k5['avg_us'] * 1e-6) / 1e9
-        roofline = dict(bound='hbm', kernel='edge_gather_sum (K5 node->hyperedge gather-sum)', achieved=round(achieved, 1),
-                        peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                        traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected (profiles/r1/pmc_traffic.json)' if traffic else None,
-                        bytes_per_launch=k5_bytes, avg_us=round(k5['avg_us'], 2), launches=k5['launches'],
-                        hyperedges_per_s=round(E / (k5['avg_us'] * 1e-6), 1))
-    k7_roof = None
-    if 'node_segment_sum' in table:
-        # the forward/backward K7 launches over the [E,d] edge features (the [3E,d] member pass has the same byte count)
-        k7_bytes = E * (12 * dim + 12) + N * (4 * dim + 8)
-        k7 = table['node_segment_sum']
-        k7_achieved = k7_bytes / (k7['avg_us'] * 1e-6) / 1e9
-        k7_roof = dict(bound='hbm', kernel='node_segment_sum (K7 hyperedge->node segment-sum, split rows included)', achieved=round(k7_achieved, 1),
-                       peak=HBM_PEAK_GBS, unit='GB/s', frac=round(k7_achieved / HBM_PEAK_GBS, 4), bytes_per_launch=k7_bytes,
-                       avg_us=round(k7['avg_us'], 2), launches=k7['launches'],
-                       measured='instrumented pass after the timed region (every launch bracketed)')
+        t = k5['avg_us'] * 1e-6
+        achieved = k5_compulsory / t / 1e9
+        roofline = dict(bound='hbm', kernel='edge_gather_sum (K5 node->hyperedge gather-sum; first-order hyperedge features and the backward of K7)',
+                        achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
+                        bytes='compulsory HBM bytes per launch: touched node rows once + [E,d] store + ids', bytes_per_launch=k5_compulsory,
+                        algorithmic_bytes_per_launch=k5_algorithmic, algorithmic_gbs=round(k5_algorithmic / t / 1e9, 1),
+                        algorithmic_note='16 d + 12 B per hyperedge (SURVEY §8 d3) counts three row gathers per hyperedge; repeats are served by L2 / '
+                                         'Infinity Cache, so this rate is not an HBM rate and may exceed the peak',
+                        traffic=traffic, traffic_gbs=round(traffic / t / 1e9, 1) if traffic else None, traffic_source=traffic_source,
+                        avg_us=round(k5['avg_us'], 2), launches=k5['launches'], hyperedges_per_s=round(E / t, 1),
+                        measured='HIP events on the launch stream, inside the timed region')
     mfma_roof = None
     if args.layer == 'ihgnn' and args.order in (2, 3) and 'interact_fwd' in table and 'interact_bwd' in table:
         # the order-2/3 contraction of layer 0 is the only MFMA-bound piece: 2 m d^2 flop per hyperedge forward
@@ -248,11 +338,12 @@ def main():
         f, bw = table['interact_fwd'], table['interact_bwd']
         bwd_us = bw['avg_us'] * bw['launches'] / table_steps        # the backward may run in several hyperedge chunks
         mfma_roof = dict(bound='mfma', kernel='interact_fwd + interact_bwd (order-%d product blocks of layer 0)' % args.order,
-                         peak=157.3, unit='TFLOP/s', dtype='f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32)',
-                         forward=dict(achieved=round(flops_fwd / (f['avg_us'] * 1e-6) / 1e12, 1), frac=round(flops_fwd / (f['avg_us'] * 1e-6) / 157.3e12, 4),
+                         peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', dtype='f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32)',
+                         forward=dict(achieved=round(flops_fwd / (f['avg_us'] * 1e-6) / 1e12, 1), frac=round(flops_fwd / (f['avg_us'] * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 4),
                                       flops_per_launch=flops_fwd, avg_us=round(f['avg_us'], 2)),
-                         backward=dict(achieved=round(2 * flops_fwd / (bwd_us * 1e-6) / 1e12, 1), frac=round(2 * flops_fwd / (bwd_us * 1e-6) / 157.3e12, 4),
+                         backward=dict(achieved=round(2 * flops_fwd / (bwd_us * 1e-6) / 1e12, 1), frac=round(2 * flops_fwd / (bwd_us * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 4),
                                        flops_per_step=2 * flops_fwd, us_per_step=round(bwd_us, 2)),
+                         share_of_step=round((f['avg_us'] + bwd_us) * 1e-3 / (1e3 * elapsed / args.steps), 3),
                          measured='instrumented pass after the timed region (every launch bracketed)')
     out = {
         'metric': 'hyperedges_aggregated_per_sec', 'value': round(value, 1), 'unit': 'hyperedges/s',
@@ -261,22 +352,31 @@ def main():
         'config': {'workload': WORKLOAD_NOTES.get(args.config, args.config) + (f' SCALED x{args.scale:g};' if args.scale != 1.0 else '') +
                                f' U={w.user_count} Q={w.query_count} I={w.item_count} E={E}, {cfg["distribution"]} members, '
                                f'dim={dim}, {layers}x{args.layer} layers, interaction order {args.order}, batch 100 pos + 1000 neg',
-                   'step': 'full training step: propagate fwd + BCE + bwd + Adam' + (' + RCCL grad all-reduce' if world > 1 else '') +
-                           '; the last layer\'s hyperedge->node pass is evaluated at the rows the loss reads (split rows + batch rows): same loss '
-                           'and gradients; full_last_layer_* = the same step with that pass over all rows',
+                   'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd + Adam' +
+                           (f' + RCCL gradient exchange ({args.sync})' if world > 1 else ''),
                    'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}'},
-        'full_last_layer_ms_per_step': round(1e3 * full_elapsed, 4), 'full_last_layer_value': round(world * E * layers / full_elapsed, 1),
-        'fwd_only_hyperedges_per_s': round(E * layers / fwd_elapsed, 1), 'fwd_only_ms': round(1e3 * fwd_elapsed, 4),
-        'final_loss': round(float(last.item()), 6),
+        'final_loss': round(final_loss, 6),
         'roofline': roofline,
-        'roofline_hyperedge_to_node': k7_roof,
+        'roofline_hyperedge_to_node': k7_roles(table, E, N, dim, layout, table_steps) or None,
         'roofline_interaction': mfma_roof,
-        'kernels_us': {name: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] / table_steps} for name, v in table.items()},
-        'kernels_us_note': f'HIP events around every launch, {table_steps} untimed steps after the timed region; the timed region brackets K5 only',
     }
+    if restricted_elapsed is not None:
+        out['batch_rows_last_layer_ms_per_step'] = round(1e3 * restricted_elapsed, 4)
+        out['batch_rows_last_layer_value'] = round(world * E * layers / restricted_elapsed, 1)
+        out['batch_rows_last_layer_note'] = ('same step with the last layer\'s hyperedge->node pass evaluated only at the rows the loss reads '
+                                             '(identical loss and gradients; the training loop\'s default); NOT the headline')
+    if fwd_elapsed is not None:
+        out['fwd_only_hyperedges_per_s'] = round(E * layers / fwd_elapsed, 1)
+        out['fwd_only_ms'] = round(1e3 * fwd_elapsed, 4)
+    if table:
+        out['kernels_us'] = {name: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] / table_steps} for name, v in table.items()}
+        out['kernels_us_note'] = f'HIP events around every launch, {table_steps} untimed steps after the timed region; the timed region brackets K5 only'
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.config, args.layer, layers, args.order, dim, args.cpu_scale)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -85,16 +85,17 @@ def test_and_get_avg_metrics(model, dataset_train: GraphDataset, dataloader: Tes
     counted = int(round(sums[3]))
     average = Metrics(sums[0], sums[1], sums[2]).divide_and_get_new(max(counted, 1))
     user_avgs = None
-    if get_long_tail_stat:                                  # per-user breakdown covers this rank's share of the logs
-        user_avgs = []
-        for ms in per_user:
-            if not ms:
-                user_avgs.append(None)
-                continue
-            acc = Metrics()
+    if get_long_tail_stat:                                  # per-user sums and counts, added up over the ranks' shares of the logs
+        table = torch.zeros(dataset_train.user_count, 4, dtype=torch.float64)
+        for user, ms in enumerate(per_user):
             for m in ms:
-                acc.add_to_self(m)
-            user_avgs.append(acc.divide_and_get_new(len(ms)))
+                table[user] += torch.tensor([m.HitRatio_at10, m.NDCG_at10, m.MAP_at10, 1.0], dtype=torch.float64)
+        if world > 1:
+            table = table.to(device)
+            dist.all_reduce(table, op=dist.ReduceOp.SUM)
+            table = table.cpu()
+        user_avgs = [None if row[3] < 0.5 else Metrics(row[0], row[1], row[2]).divide_and_get_new(int(round(row[3])))
+                     for row in table.tolist()]
     seconds = time.time() - started
     IOHelper.LogPrint(f'evaluation done in {seconds:<.2f} s over {counted} usable search logs.')
     IOHelper.LogPrint(average.to_string(highlight=True), put_time_in_single_line=True)
@@ -109,6 +110,9 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
     started = time.time()
     loss_sum = torch.zeros((), dtype=torch.float32, device=device)
     batches = positives = 0
+    sampler = getattr(dataloader_train, 'batch_sampler', None)
+    if hasattr(sampler, 'set_epoch'):
+        sampler.set_epoch(pc.CurrentEpoch)                  # data parallel: a fresh shared permutation per epoch (ShardedBatchSampler)
     for p_u, p_q, p_i, p_f, n_u, n_q, n_i, n_f in dataloader_train:
         positives += len(p_u)
         users, queries, items = torch.cat([p_u, n_u]), torch.cat([p_q, n_q]), torch.cat([p_i, n_i])
@@ -128,6 +132,10 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
             optimizer.zero_grad()
         batches += 1
     avg_loss = loss_sum.item() / max(batches, 1)
+    if grad_sync is not None and grad_sync.world_size > 1:  # every rank reports (and schedules its learning rate on) the global average
+        from .. import distributed as ihg_dist
+        total, count = ihg_dist.all_reduce_sums([avg_loss * batches, float(batches)], device)
+        avg_loss = total / max(count, 1.0)
     seconds = time.time() - started
     IOHelper.LogPrint(f'[Epoch \033[0;44m{pc.CurrentEpoch:>2d}/{pc.EndEpoch - 1}\033[0m] average loss '
                       f'\033[0;45m{avg_loss:<.4f}\033[0m on {positives} interactions in {seconds:<.2f} s '

@@ -86,7 +86,15 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
         random_negative_sample_size=Gs.random_negative_sample_size,
         non_random_negative_sample_size=Gs.non_random_negative_sample_size,
         device=device)
-    dataloader_train = DataLoader(dataset_train, Gs.batch_size, shuffle=True, collate_fn=GraphDataset.collate_fn)
+    if world > 1:
+        # data parallel: the ranks split every epoch's permutation between them (same number of steps on every rank, each row once
+        # per epoch) and draw their negatives from differently seeded generators; global batch = batch_size x ranks
+        import random
+        random.seed(0x5eed + 7919 * rank)
+        sampler = ihg_dist.ShardedBatchSampler(len(dataset_train), Gs.batch_size, rank, world, shuffle=True, seed=0)
+        dataloader_train = DataLoader(dataset_train, batch_sampler=sampler, collate_fn=GraphDataset.collate_fn)
+    else:
+        dataloader_train = DataLoader(dataset_train, Gs.batch_size, shuffle=True, collate_fn=GraphDataset.collate_fn)
     dataloader_valid = TestSearchLogDataLoader(os.path.join(data_dir, 'valid_data.csv'), dataset_train, device)
     dataloader_test = TestSearchLogDataLoader(os.path.join(data_dir, 'test_data.csv'), dataset_train, device)
 

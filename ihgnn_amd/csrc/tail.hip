@@ -345,11 +345,11 @@ int ihg_adam_step(const ihg_adam_tensor* tensors, int32_t n_tensors, float lr, f
     const double bias2 = 1.0 - std::pow(static_cast<double>(beta2), static_cast<double>(step));
     const float step_size = static_cast<float>(static_cast<double>(lr) / bias1);
     const float bias2_sqrt = static_cast<float>(std::sqrt(bias2));
-    for (int first = 0; first < n_tensors; first += kAdamMaxTensors) {
+    for (int t = 0; t < n_tensors;) {                        // one launch per kAdamMaxTensors NON-EMPTY tensors; t is the only cursor
         AdamTable tab{};
         int64_t chunks = 0;
         int used = 0;
-        for (int t = first; t < n_tensors && used < kAdamMaxTensors; ++t) {
+        for (; t < n_tensors && used < kAdamMaxTensors; ++t) {
             const ihg_adam_tensor& a = tensors[t];
             if (a.count < 0 || (a.count > 0 && (a.param == nullptr || a.grad == nullptr || a.exp_avg == nullptr || a.exp_avg_sq == nullptr)))
                 return fail(IHG_ERR_INVALID, "ihg_adam_step: tensor %d has a null pointer or a negative count", t);

@@ -38,6 +38,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
 class GradientSync:
     """Flat gradient buffer + one averaging all-reduce per step."""
 
+    owns_optimizer = False
+
     def __init__(self, parameters: Iterable[torch.nn.Parameter], group=None):
         self.params: List[torch.nn.Parameter] = [p for p in parameters if p.requires_grad]
         self.group = group
@@ -95,6 +97,232 @@ class GradientSync:
         if self.world_size > 1:
             for p in self.params:
                 dist.broadcast(p.data, src=src, group=self.group)
+
+
+class BucketedGradientSync(GradientSync):
+    """``GradientSync`` whose flat buffer is cut into buckets, each all-reduced from RCCL's own stream as soon as the backward has
+    produced it, so the exchange overlaps the rest of the backward instead of starting after its last kernel.
+
+    Bucket order = the order the backward finishes them: first the dense parameters (prediction bias, layer weights - ready while
+    the propagation's backward is still running), then one bucket per embedding table (produced by the very last kernels of the
+    step; 99 % of the bytes, so they stay exposed - see DESIGN.md §7 for the expected exposed time per config).  A bucket is
+    launched by the ``post_accumulate_grad`` hook of its last parameter (``async_op=True``: the collective waits for the
+    producing kernels through an event, not the host); ``average_gradients`` waits for all of them.  Result identical to the flat
+    all-reduce (same sums, element by element)."""
+
+    def __init__(self, named_parameters, group=None):
+        named = [(n, p) for n, p in named_parameters if p.requires_grad]
+        tables = [(n, p) for n, p in named if '.embedding' in n or n.startswith('embedding')]
+        dense = [(n, p) for n, p in named if (n, p) not in tables]
+        ordered = dense + tables
+        super().__init__([p for _, p in ordered], group)
+        self.buckets = []                                    # (begin, end) element ranges of the flat buffer
+        offset = 0
+        groups = ([dense] if dense else []) + [[t] for t in tables]
+        self._bucket_of = {}
+        for index, members in enumerate(groups):
+            n = sum(p.numel() for _, p in members)
+            self.buckets.append((offset, offset + n))
+            offset += n
+            for _, p in members:
+                self._bucket_of[p] = index
+        self._pending = [0] * len(self.buckets)
+        self._works = []
+        self._launched = [False] * len(self.buckets)
+        self._arm()
+        if self.world_size > 1:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _arm(self) -> None:
+        counts = [0] * len(self.buckets)
+        for p in self.params:
+            counts[self._bucket_of[p]] += 1
+        self._pending = counts
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def _launch(self, index: int) -> None:
+        begin, end = self.buckets[index]
+        piece = self.flat[begin:end]
+        if self._use_avg is None:
+            self._use_avg = dist.get_backend(self.group) == 'nccl'
+        op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
+        self._works.append((dist.all_reduce(piece, op=op, group=self.group, async_op=True), piece))
+        self._launched[index] = True
+
+    def _on_grad(self, p) -> None:
+        index = self._bucket_of[p]
+        view_ok = p.grad is not None and self.flat.data_ptr() <= p.grad.data_ptr() < self.flat.data_ptr() + self.flat.numel() * 4
+        if not view_ok:                                      # someone detached the view (set_to_none): exchange everything at the end
+            self._pending[index] = -1
+            return
+        self._pending[index] -= 1
+        if self._pending[index] == 0:
+            self._launch(index)
+
+    def average_gradients(self):
+        if self.flat is None or self.world_size == 1:
+            return
+        self._reattach()
+        for index in range(len(self.buckets)):               # buckets whose hooks did not all fire (unused parameters, detached views)
+            if not self._launched[index]:
+                self._launch(index)
+        for work, piece in self._works:
+            work.wait()                                      # the current stream waits for the collective; the host does not
+            if not self._use_avg:
+                piece.div_(self.world_size)
+        self._arm()
+
+
+class _ShardOptimizer:
+    def __init__(self, sync: 'ShardedGradientSync', lr: float, weight_decay: float):
+        self.sync = sync
+        shard = torch.nn.Parameter(sync.param_shard)
+        shard.grad = sync.grad_shard
+        self.shard = shard
+        if shard.is_cuda:
+            from .optim import Adam
+            self.inner = Adam([shard], lr, weight_decay=weight_decay)
+        else:
+            self.inner = torch.optim.Adam([shard], lr, weight_decay=weight_decay)
+        self.param_groups = self.inner.param_groups
+
+    def step(self):
+        self.shard.grad = self.sync.grad_shard
+        self.inner.step()
+        self.sync.gather_parameters()
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.sync.zero_grad()
+
+    def state_dict(self):
+        return self.inner.state_dict()
+
+    def load_state_dict(self, state):
+        self.inner.load_state_dict(state)
+
+
+class ShardedGradientSync(GradientSync):
+    """Reduce-scatter -> Adam on this rank's 1/W shard -> all-gather of the parameters (for config C5's ~10 GB of
+    gradients): the same bytes cross xGMI as in an all-reduce, but each rank keeps and updates only 1/W of the Adam state
+    (2 x 10 GB -> 2 x 1.25 GB at W = 8) and streams 1/W of the update.  Parameters live in one flat buffer (module parameters are
+    views of it), padded to a multiple of W.  Adam is elementwise, so the result equals the replicated update bit for bit given
+    the same averaged gradient.  ``optimizer(lr)`` returns the step object to use in place of ``Adam(model.parameters())``."""
+
+    owns_optimizer = True
+
+    def __init__(self, parameters, group=None):
+        super().__init__(parameters, group)
+        w = self.world_size
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        total = self.flat.numel()
+        self.padded = -(-total // w) * w
+        ref = self.params[0]
+        grads = torch.zeros(self.padded, dtype=ref.dtype, device=ref.device)
+        self.flat = grads[:total]
+        self._grads_padded = grads
+        self.flat_params = torch.zeros(self.padded, dtype=ref.dtype, device=ref.device)
+        offset = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.flat_params[offset:offset + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_params[offset:offset + n].view_as(p)
+                p.grad = self.flat[offset:offset + n].view_as(p)
+                offset += n
+        share = self.padded // w
+        self.shard_range = (rank * share, (rank + 1) * share)
+        self.param_shard = self.flat_params[self.shard_range[0]:self.shard_range[1]]
+        self.grad_shard = torch.zeros(share, dtype=ref.dtype, device=ref.device)
+
+    def optimizer(self, lr: float, weight_decay: float = 0.0) -> _ShardOptimizer:
+        return _ShardOptimizer(self, lr, weight_decay)
+
+    def average_gradients(self):
+        self._reattach()
+        lo, hi = self.shard_range
+        if self.world_size == 1:
+            self.grad_shard.copy_(self._grads_padded[lo:hi])
+            return
+        backend = dist.get_backend(self.group)
+        if backend == 'nccl':
+            try:
+                dist.reduce_scatter_tensor(self.grad_shard, self._grads_padded, op=dist.ReduceOp.AVG, group=self.group)
+                return
+            except (RuntimeError, ValueError):
+                pass
+        if backend == 'nccl':
+            dist.reduce_scatter_tensor(self.grad_shard, self._grads_padded, op=dist.ReduceOp.SUM, group=self.group)
+            self.grad_shard.div_(self.world_size)
+            return
+        dist.all_reduce(self._grads_padded, op=dist.ReduceOp.SUM, group=self.group)      # gloo (CPU tests): no reduce-scatter
+        torch.div(self._grads_padded[lo:hi], self.world_size, out=self.grad_shard)
+
+    def gather_parameters(self) -> None:
+        if self.world_size > 1:
+            dist.all_gather_into_tensor(self.flat_params, self.param_shard.clone(), group=self.group)
+
+    def zero_grad(self) -> None:
+        self._grads_padded.zero_()
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        if self.world_size > 1:
+            dist.broadcast(self.flat_params, src=src, group=self.group)
+
+
+def make_gradient_sync(model: torch.nn.Module, mode: str = 'bucketed', group=None) -> GradientSync:
+    """``flat`` | ``bucketed`` | ``sharded`` gradient exchange for a model (see the three classes above)."""
+    if mode == 'flat':
+        return GradientSync(model.parameters(), group)
+    if mode == 'bucketed':
+        return BucketedGradientSync(model.named_parameters(), group)
+    if mode == 'sharded':
+        return ShardedGradientSync(model.parameters(), group)
+    raise ValueError(f'unknown gradient sync mode {mode!r}')
+
+
+class ShardedBatchSampler:
+    """Batch sampler of the data-parallel training loop: every epoch is ONE permutation of the dataset shared by all ranks
+    (a function of ``seed`` and the epoch), rank r takes positions ``r, r + W, r + 2W, ...`` of it, and every rank cuts its
+    share into the SAME number of batches (sizes differ by at most one row), so the ranks issue the same number of gradient
+    all-reduces and the union of all ranks' batches covers the epoch exactly once - no padding, no duplicates.
+
+    With one rank and ``shuffle=True`` this is ``DataLoader(batch_size=B, shuffle=True)``'s batching (full batches, a shorter
+    last one) over its own permutation.  Global batch = ``B * W`` rows per step (the learning rate is left as configured)."""
+
+    def __init__(self, n_items: int, batch_size: int, rank: int = 0, world_size: int = 1, shuffle: bool = True, seed: int = 0):
+        if n_items < world_size:
+            raise ValueError(f'{n_items} training rows cannot be sharded over {world_size} ranks')
+        self.n_items, self.batch_size, self.rank, self.world_size = int(n_items), int(batch_size), int(rank), int(world_size)
+        self.shuffle, self.seed, self.epoch = bool(shuffle), int(seed), 0
+        largest_share = -(-self.n_items // self.world_size)
+        self.n_batches = -(-largest_share // self.batch_size)
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def __len__(self) -> int:
+        return self.n_batches
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed * 1_000_003 + self.epoch)
+            order = torch.randperm(self.n_items, generator=g)
+        else:
+            order = torch.arange(self.n_items)
+        mine = order[self.rank::self.world_size].tolist()
+        if self.world_size == 1:
+            for lo in range(0, len(mine), self.batch_size):
+                yield mine[lo:lo + self.batch_size]
+            return
+        base, extra = divmod(len(mine), self.n_batches)
+        lo = 0
+        for b in range(self.n_batches):
+            hi = lo + base + (1 if b < extra else 0)
+            yield mine[lo:hi]
+            lo = hi
 
 
 def shard_range(n_items: int, rank: int, world_size: int) -> range:

@@ -75,8 +75,10 @@ def edge_gather_sum_raw(src: Tensor, i3: Tensor, node_scale: Optional[Tensor] = 
 def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optional[Tensor] = None,
                          out_scale: Optional[Tensor] = None, mode: int = _lib.SCALE_NONE,
                          out: Optional[Tensor] = None, entry_scale: Optional[Tensor] = None,
-                         self_weight: Optional[Tensor] = None, rows: Optional[Tensor] = None, src_mask: Optional[Tensor] = None) -> Tensor:
-    """``rows`` (int32, device): only these output rows are needed.  The split rows of the plan are always computed; of the
+                         self_weight: Optional[Tensor] = None, rows: Optional[Tensor] = None, src_mask: Optional[Tensor] = None,
+                         role: Optional[str] = None) -> Tensor:
+    """``role`` names the launch for the profiler (one kernel, several jobs with different byte counts: ``bench.py`` reports each).
+    ``rows`` (int32, device): only these output rows are needed.  The split rows of the plan are always computed; of the
     others only the listed ones are, and the rest of ``out`` is left unwritten.  ``src_mask`` (uint8 per source row): rows with a 0
     are all-zero and are not fetched."""
     lib = _lib.load()
@@ -88,7 +90,7 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
     if rows is not None and rows.dtype != torch.int32:
         raise TypeError('rows must be an int32 tensor')
     order, n_light = (rows, int(rows.shape[0])) if rows is not None else (csr.row_order, csr.n_rows)
-    with profiler.kernel('node_segment_sum' if rows is None else 'node_segment_sum_rows', n_light, dim):
+    with profiler.kernel((role or 'node_segment_sum') + ('' if rows is None else '_rows'), n_light, dim):
         _lib.check(lib.ihg_node_segment_sum(
             _ptr(src), _ld(src), _ptr(csr.ptr), _ptr(csr.ids), _ptr(order), _ptr(src_scale), _ptr(entry_scale), _ptr(out_scale), mode,
             _ptr(out), _ld(out), n_light, dim, csr.heavy_threshold if heavy else 0,
@@ -114,7 +116,7 @@ class _EdgeGatherSum(torch.autograd.Function):
             scale = (scale * ctx.alpha) if scale is not None else torch.full(
                 (ctx.layout.node_count,), ctx.alpha, dtype=torch.float32, device=grad_out.device)
         mode = _lib.SCALE_NONE if scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(grad_out, ctx.layout.node_csr, None, scale, mode), None, None, None
+        return node_segment_sum_raw(grad_out, ctx.layout.node_csr, None, scale, mode, role='k7.edges_to_nodes_bwd_of_k5'), None, None, None
 
 
 class _NodeSegmentSum(torch.autograd.Function):
@@ -122,7 +124,7 @@ class _NodeSegmentSum(torch.autograd.Function):
     def forward(ctx, src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor], rows: Optional[Tensor]) -> Tensor:
         ctx.layout, ctx.out_scale = layout, out_scale
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(src, layout.node_csr, None, out_scale, mode, rows=rows)
+        return node_segment_sum_raw(src, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes')
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
@@ -152,7 +154,7 @@ class _TwoHop(torch.autograd.Function):
     def forward(ctx, x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor], out_scale: Optional[Tensor], rows: Optional[Tensor]) -> Tensor:
         ctx.layout, ctx.in_scale, ctx.out_scale, ctx.rows = layout, in_scale, out_scale, rows
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(x, layout.hop2_csr, in_scale, out_scale, mode, self_weight=layout.self_weight, rows=rows)
+        return node_segment_sum_raw(x, layout.hop2_csr, in_scale, out_scale, mode, self_weight=layout.self_weight, rows=rows, role='k7.two_hop')
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
@@ -164,7 +166,8 @@ class _TwoHop(torch.autograd.Function):
             # (two thirds of them - every neighbour that is not a query - and the ones that would miss the cache)
             mask = torch.zeros(lay.node_count, dtype=torch.uint8, device=grad_out.device)
             mask.index_fill_(0, ctx.rows.long(), 1)
-        return (node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight, src_mask=mask),
+        return (node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight, src_mask=mask,
+                                     role='k7.two_hop_bwd' if mask is None else 'k7.two_hop_bwd_masked'),
                 None, None, None, None)
 
 
@@ -182,12 +185,12 @@ class _PairSpmm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, graph) -> Tensor:
         ctx.graph = graph
-        return node_segment_sum_raw(x, graph.csr, graph.inv_sqrt_deg, graph.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=graph.values)
+        return node_segment_sum_raw(x, graph.csr, graph.inv_sqrt_deg, graph.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=graph.values, role='k7.pair_graph')
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         g = ctx.graph
-        return node_segment_sum_raw(grad_out, g.csr, g.inv_sqrt_deg, g.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=g.values), None
+        return node_segment_sum_raw(grad_out, g.csr, g.inv_sqrt_deg, g.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=g.values, role='k7.pair_graph'), None
 
 
 def pair_spmm(x: Tensor, graph) -> Tensor:
@@ -438,7 +441,7 @@ def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: Incidence
                        'ihg_interact_bwd')
         if index > 0:
             dw[:, 3 * dim:].add_(dw_part[:, 3 * dim:])
-        part = node_segment_sum_raw(g.view(3 * n, dim), csr)       # (node v, hyperedge e) reads row 3 (e - e0) + type(v)
+        part = node_segment_sum_raw(g.view(3 * n, dim), csr, role='k7.member_gradients')       # (node v, hyperedge e) reads row 3 (e - e0) + type(v)
         del g
         dh = part if dh is None else dh.add_(part)
     return dh
@@ -470,7 +473,7 @@ class _Interact(torch.autograd.Function):
         n_edges, dim = layout.edge_count, int(h.shape[1])
         dw = torch.zeros_like(w)
         dh = _interact_backward(h, w, grad_out, layout, order, dw)
-        dp = node_segment_sum_raw(grad_out, layout.node_csr)
+        dp = node_segment_sum_raw(grad_out, layout.node_csr, role='k7.first_order_gradient')
         return dh, dp, dw, None, None
 
 
@@ -509,7 +512,7 @@ class _InteractFromNodes(torch.autograd.Function):
         dw = torch.empty_like(w)                               # product blocks from the interact kernels, first-order blocks from the row-GEMM pass
         # the scatter of grad_out goes first: K5 has just written it, so most of its 256-byte rows are still in the Infinity Cache
         # for these random reads; the interact kernels read it as a stream and do not care
-        dp = node_segment_sum_raw(grad_out, layout.node_csr)
+        dp = node_segment_sum_raw(grad_out, layout.node_csr, role='k7.first_order_gradient')
         dh = _interact_backward(h, w, grad_out, layout, order, dw)
         dbias = torch.empty(dim, dtype=torch.float32, device=h.device) if ctx.has_bias else None
         ws2 = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)

@@ -46,6 +46,8 @@ class Adam(Optimizer):
                     state['step'] = torch.tensor(0.0)                      # host-side counter, as torch keeps it for non-capturable Adam
                     state['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                if torch.is_tensor(state['step']) and state['step'].is_cuda:   # a checkpoint loaded with map_location=device: keep the
+                    state['step'] = state['step'].cpu()                        # counter on the host (int() below would sync every step)
                 state['step'] += 1
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 by_step.setdefault(int(state['step']), []).append((p, grad, state))

@@ -36,3 +36,27 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name))
     return load
+
+
+def f8_case(tag):
+    """Wide-model fixture F8 (``tests/golden/f8_wide_models.npz``): ``(cfg, state dict as numpy, fixture)`` with the weights
+    regenerated from the seed the generator used (``tests/golden/seeded_weights.py``)."""
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    from seeded_weights import seeded_state
+    z = np.load(os.path.join(GOLDEN, 'f8_wide_models.npz'))
+    L, order, d, seed = (int(v) for v in z[f'{tag}.cfg'])
+    shapes = [(str(k), tuple(int(x) for x in str(s).split(';'))) for k, s in zip(z[f'{tag}.keys'], z[f'{tag}.shapes'])]
+    return (L, order, d), seeded_state(shapes, seed), z
+
+
+def f8_gradient_error(z, tag, name, grad):
+    """max relative deviation of a parameter gradient from what F8 keeps of it (full, or every 4th row + row/col sums)."""
+    g = np.asarray(grad, np.float64)
+    pre = f'{tag}.grad.{name}.'
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    if pre + 'full' in z.files:
+        return rel(g, z[pre + 'full'].astype(np.float64))
+    return max(rel(g[::4], z[pre + 'rows4'].astype(np.float64)), rel(g.sum(1), z[pre + 'rowsum']), rel(g.sum(0), z[pre + 'colsum']))

@@ -391,7 +391,51 @@ def make_f7():
     np.savez(os.path.join(HERE, 'f7_gcn.npz'), **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# F8: wide models - BASELINE configs[2]/[3] shape (d = 128, 3 layers, orders 3 and 2) and configs[4] shape (d = 256, 2 layers)
+# on the small graph.  Weights come from tests/golden/seeded_weights.py (regenerated by the tests), so the fixture holds
+# only inputs and the reference's outputs.
+# ---------------------------------------------------------------------------------------------
+F8_CASES = (('d128_o3', 3, 3, 128, 801), ('d128_o2', 3, 2, 128, 802), ('d256_o3', 2, 3, 256, 803))
+
+
+def make_f8(ds):
+    sys.path.insert(0, HERE)
+    from seeded_weights import big_gradient_digest, seeded_state
+    out = {}
+    for tag, L, order, d, seed in F8_CASES:
+        seed_all(seed)
+        m = RawGnn(CPU, ds, d, IHGNNLayer, L, order, False, HemPredictionLayer, 0.5)
+        shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state(shapes, seed).items()})
+        rng = np.random.default_rng(seed + 1)
+        B = 96
+        u = torch.from_numpy(rng.integers(0, ds.user_count, B)); q = torch.from_numpy(rng.integers(0, ds.query_count, B))
+        i = torch.from_numpy(rng.integers(0, ds.item_count, B))
+        flags = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32))
+        scores = m(u, q, i)
+        loss = torch.nn.BCEWithLogitsLoss()(scores, flags)
+        loss.backward()
+        for n, p in m.named_parameters():
+            for part, v in big_gradient_digest(p.grad.numpy()).items():
+                out[f'{tag}.grad.{n}.{part}'] = v
+        with torch.no_grad():
+            m.save_features_for_test()
+            out[f'{tag}.features'] = m._saved_output_feature.numpy().copy()
+            m.clear_saved_feature()
+        out[f'{tag}.keys'] = np.array([k for k, _ in shapes])
+        out[f'{tag}.shapes'] = np.array([';'.join(map(str, s)) for _, s in shapes])
+        out.update({f'{tag}.u': u.numpy(), f'{tag}.q': q.numpy(), f'{tag}.i': i.numpy(), f'{tag}.flags': flags.numpy(),
+                    f'{tag}.scores': scores.detach().numpy(), f'{tag}.loss': np.float64(loss.item()),
+                    f'{tag}.cfg': np.array([L, order, d, seed], np.int64)})
+    np.savez(os.path.join(HERE, 'f8_wide_models.npz'), **out)
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['f8']:                       # add the wide-model fixture without rewriting the others
+        w = small_workload()
+        make_f8(load_dataset(synth.write_files(w, os.path.join('/tmp', 'ihgnn_golden_small'))))
+        sys.exit(0)
     ds_tiny = make_f1()
     ds_small, _ = make_f2(ds_tiny)
     make_f3(ds_small)
@@ -399,6 +443,7 @@ if __name__ == '__main__':
     make_f5()
     make_f6()
     make_f7()
+    make_f8(ds_small)
     for fn in sorted(os.listdir(HERE)):
         p = os.path.join(HERE, fn)
         if os.path.isfile(p):

@@ -277,7 +277,7 @@ def test_node_linear_with_per_type_bias(dim):
     assert rel(xg.grad, xc.grad) <= RTOL_SUM * 2 and rel(wg.grad, wc.grad) <= RTOL and rel(bg.grad, bc.grad) <= RTOL
 
 
-@pytest.mark.parametrize('dim,order', [(8, 2), (8, 3), (12, 3), (32, 2), (32, 3), (64, 2), (64, 3), (128, 3)])
+@pytest.mark.parametrize('dim,order', [(8, 2), (8, 3), (12, 3), (32, 2), (32, 3), (64, 2), (64, 3), (128, 2), (128, 3), (256, 2), (256, 3)])
 def test_interact_forward_backward(dim, order):
     from ihgnn_amd import ops
     from oracle import ihgnn_ref as ref
@@ -304,7 +304,10 @@ def test_interact_forward_backward(dim, order):
     assert rel(hg.grad, hc.grad) <= RTOL and rel(wg.grad, wc.grad) <= RTOL and rel(bg.grad, bc.grad) <= RTOL
 
 
-@pytest.mark.parametrize('dim,order,edges', [(64, 3, 3 * 256 * 64 + 37), (64, 2, 2 * 256 * 64 + 64), (32, 3, 2 * 256 * 128 + 5)])
+@pytest.mark.parametrize('dim,order,edges', [(64, 3, 3 * 256 * 64 + 37), (64, 2, 2 * 256 * 64 + 64), (32, 3, 2 * 256 * 128 + 5),
+                                             # d = 128 / 256 (configs C3-C5): more 64-hyperedge tiles than any grid these kernels launch
+                                             # (<= 4 workgroups per CU x 256 CUs), partial last tile
+                                             (128, 3, 1100 * 64 + 37), (128, 2, 1030 * 64 + 1), (256, 3, 1100 * 64 + 37), (256, 2, 1025 * 64 + 63)])
 def test_interact_persistent_tiles_and_strided_rows(dim, order, edges):
     """More tiles than workgroups (every workgroup walks several tiles, the last one partial) and member / first-order rows
     that are column slices of one wider table (row stride 2 d + 8): the pipelined kernels against the oracle."""
@@ -338,7 +341,7 @@ def test_interact_persistent_tiles_and_strided_rows(dim, order, edges):
     assert rel(hg.grad, hc.grad) <= RTOL and rel(wg.grad, wc.grad) <= RTOL
 
 
-@pytest.mark.parametrize('dim', [12, 64])
+@pytest.mark.parametrize('dim', [12, 64, 128, 256])
 def test_interact_backward_in_hyperedge_chunks(dim, monkeypatch):
     """The [E, 3, d] member-gradient buffer produced in three hyperedge chunks (what config C5 needs on one GPU): gradients
     equal the one-pass ones up to the association of the chunk sums."""
@@ -358,6 +361,13 @@ def test_interact_backward_in_hyperedge_chunks(dim, monkeypatch):
     assert len(lay.member_csr_chunks(3)) == 3
     for one, many in zip(*grads):
         assert rel(many, one) <= 2e-6
+    # and against the oracle (the first-order part enters through p, which is an independent input here)
+    from oracle import ihgnn_ref as ref
+    g = ref.HyperGraph(w_.triples, 150, 9, 120)
+    hc, wc = h.cpu().requires_grad_(True), w.cpu().requires_grad_(True)
+    wz = torch.cat([torch.zeros(dim, 3 * dim), wc[:, 3 * dim:]], 1)
+    ref.feature_interactor(hc, torch.from_numpy(lay.i3_host.astype(np.int64)), wz, torch.zeros(dim), 3).backward(cot.cpu())
+    assert rel(grads[1][0], hc.grad) <= RTOL and rel(grads[1][2][:, 3 * dim:], wc.grad[:, 3 * dim:]) <= RTOL
 
 
 # ---------------------------------------------------------------------------------------------
@@ -445,6 +455,35 @@ def test_f3_model_matches_reference(tag, kind):
         m.clear_saved_feature()
 
 
+@pytest.mark.parametrize('path', ['module_calls', 'fused_step'])
+@pytest.mark.parametrize('tag', ['d128_o3', 'd128_o2', 'd256_o3'])
+def test_f8_wide_models_match_reference(tag, path):
+    """The model shapes of BASELINE configs[2]/[3] (d = 128, 3 layers; interaction orders 3 and 2) and configs[4] (d = 256,
+    2 layers) on the small graph, against outputs of the reference itself (fixture F8): scores, loss, every parameter gradient,
+    the propagated features - through the module calls and through the fused training step."""
+    from conftest import f8_case, f8_gradient_error
+    (L, order, d), sd, z = f8_case(tag)
+    ds = dataset_from_npz(np.load(os.path.join(GOLDEN, 'f2_small_workload.npz')))
+    m = build_model(ds, 'ihgnn', L, order, d)
+    assert set(sd) == set(m.state_dict())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    u, q, i = (torch.from_numpy(z[f'{tag}.{k}']).to(dev()) for k in 'uqi')
+    flags = torch.from_numpy(z[f'{tag}.flags']).to(dev())
+    if path == 'module_calls':
+        scores = m(u, q, i)
+        assert rel(scores, z[f'{tag}.scores']) <= RTOL
+        loss = torch.nn.BCEWithLogitsLoss()(scores, flags)
+    else:
+        assert m.supports_fused_loss(torch.nn.BCEWithLogitsLoss())
+        loss = m.bce_loss(u, q, i, flags)
+    loss.backward()
+    assert abs(loss.item() - float(z[f'{tag}.loss'])) <= 2e-6
+    for name, p in m.named_parameters():
+        assert f8_gradient_error(z, tag, name, p.grad.cpu().numpy()) <= 2e-5, name
+    with torch.no_grad():
+        assert rel(m.propagate(), z[f'{tag}.features']) <= RTOL
+
+
 @pytest.mark.parametrize('tag,kind,order', [('ihgnn3', 'ihgnn', 3), ('ihgnn1', 'ihgnn', 1), ('hgcn', 'hgcn', 1)])
 def test_f5_config_c1_matches_reference(tag, kind, order):
     """BASELINE.json configs[0]: 1k users / 1k items / 500 queries, dim 64, 1 layer."""
@@ -527,17 +566,22 @@ def test_full_size_properties_c2_shape():
     assert torch.equal(ops.edge_gather_sum_raw(torch.ones(lay.node_count, 4, device=dev()), lay.i3), torch.full((lay.edge_count, 4), 3.0, device=dev()))
 
 
-def test_full_size_properties_bench_workload():
-    """The bench.py workload itself (C2 stand-in, E = 1.35 M, N = 256 k, d = 64; the oracle would need minutes): identities that
-    hold at any size - the two-hop pass equals K5 followed by K7, the interact kernels are linear in the product weights
-    (Euler: <dW, W> = <out - first-order part, cotangent>), their first-order gradient is K7 of the cotangent, and a row-restricted
-    pass reproduces the full one on its rows."""
+@pytest.mark.parametrize('config,scale,order', [('C2', 1.0, 3), ('C3', 1.0, 3), ('C3', 1.0, 2), ('C5', 0.05, 3)])
+def test_full_size_properties_bench_workload(config, scale, order):
+    """The bench.py workloads themselves - C2 stand-in (E = 1.35 M, d = 64), C3 stand-in (E = 2.2 M, d = 128, = the per-GPU
+    replica of C4) and C5 x 0.05 (E = 2.5 M, N = 500 k, d = 256, power-law) - where the oracle over the whole graph would need
+    minutes.  Identities that hold at any size: the two-hop pass equals K5 followed by K7, the interact kernels are linear in the
+    product weights (Euler: <dW, W> = <out - first-order part, cotangent>), their first-order gradient is K7 of the cotangent, a
+    row-restricted pass reproduces the full one on its rows.  And the ORACLE on sub-samples: the interactive step is evaluated
+    per hyperedge, so 4096 sampled hyperedges are compared with the oracle exactly; node gradients are compared on sampled nodes
+    through the oracle restricted to their incident hyperedges."""
     from ihgnn_amd import ops, synth
     from ihgnn_amd.layout import IncidenceLayout
-    w_ = synth.draw_config('C2')
+    from oracle import ihgnn_ref as ref
+    w_ = synth.draw_config(config, scale=scale)
     lay = IncidenceLayout(w_.triples, w_.user_count, w_.query_count, w_.item_count, dev())
-    assert lay.edge_count == 1350000
-    d = 64
+    d = synth.CONFIGS[config]['dim']
+    k = 7 if order == 3 else 6
     gen = torch.Generator(device=dev()).manual_seed(11)
     x = torch.randn(lay.node_count, d, device=dev(), generator=gen)
     two = ops.node_two_hop(x, lay, out_scale=lay.inv_deg)
@@ -546,12 +590,13 @@ def test_full_size_properties_bench_workload():
     rows = torch.randint(0, lay.node_count, (3300,), device=dev(), generator=gen)
     part = ops.node_two_hop(x, lay, out_scale=lay.inv_deg, rows=rows.to(torch.int32))
     assert torch.equal(part[rows], two[rows])
+    del two, via_edges, part
 
     h = (x / 4).requires_grad_(True)
     p = torch.randn(lay.node_count, d, device=dev(), generator=gen).requires_grad_(True)
-    wgt = (torch.randn(d, 7 * d, device=dev(), generator=gen) / 21).requires_grad_(True)
+    wgt = (torch.randn(d, k * d, device=dev(), generator=gen) / (3 * np.sqrt(k * d / 7))).requires_grad_(True)
     cot = torch.randn(lay.edge_count, d, device=dev(), generator=gen) / 8
-    out = ops.interact(h, p, wgt, lay, 3)
+    out = ops.interact(h, p, wgt, lay, order)
     out.backward(cot)
     first = ops.edge_gather_sum_raw(p.detach(), lay.i3)
     lhs = (wgt.grad[:, 3 * d:].double() * wgt.detach()[:, 3 * d:].double()).sum()
@@ -559,13 +604,39 @@ def test_full_size_properties_bench_workload():
     assert abs(lhs - rhs) / abs(rhs) <= 1e-4           # two fp32 sums of ~1e8 terms each
     assert bool((wgt.grad[:, :3 * d] == 0).all())
     assert rel(p.grad, ops.node_segment_sum_raw(cot, lay.node_csr)) <= RTOL_SUM
+
+    # oracle, forward: sampled hyperedges (first tile, last partial tile and random ones)
+    E = lay.edge_count
+    pick = torch.cat([torch.arange(0, 64), torch.arange(E - 70, E), torch.randint(0, E, (4096,))]).unique()
+    i3s = torch.from_numpy(lay.i3_host[pick.numpy()].astype(np.int64))
+    hc, pc, wc = h.detach().cpu(), p.detach().cpu(), wgt.detach().cpu()
+    wz = torch.cat([torch.zeros(d, 3 * d), wc[:, 3 * d:]], 1)
+    want = ref.feature_interactor(hc, i3s, wz, torch.zeros(d), order) + (pc[i3s[:, 0]] + pc[i3s[:, 1]]) + pc[i3s[:, 2]]
+    assert rel(out.detach()[pick.to(dev())], want) <= RTOL
+    # oracle, backward: d h on sampled nodes of moderate degree = the oracle's gradient over exactly their incident hyperedges
+    ptr = lay.node_csr.ptr_host.astype(np.int64)
+    deg = np.diff(ptr)
+    rng = np.random.default_rng(3)
+    cand = np.nonzero((deg > 0) & (deg <= 64))[0]
+    nodes = np.concatenate([rng.choice(cand[cand < lay.user_count], 40), rng.choice(cand[cand >= lay.user_count + lay.query_count], 40),
+                            np.nonzero(deg > 0)[0][lay.user_count <= np.nonzero(deg > 0)[0]][:8]])      # users, items, a few queries (long lists)
+    nodes = nodes[deg[nodes] <= 20_000]
+    edges = np.unique(np.concatenate([lay.node_csr.ids_host[ptr[v]:ptr[v + 1]] for v in nodes]).astype(np.int64))
+    hs = hc.clone().requires_grad_(True)
+    i3e = torch.from_numpy(lay.i3_host[edges].astype(np.int64))
+    ref.feature_interactor(hs, i3e, wz, torch.zeros(d), order).backward(cot[torch.from_numpy(edges).to(dev())].cpu())
+    got = h.grad[torch.from_numpy(nodes).to(dev())].cpu()
+    assert rel(got, hs.grad[nodes]) <= RTOL
+
     # Euler again for the member gradient: out's product part is homogeneous of degree 2 (uq, qi, iu) and 3 (uqi) in h
-    wz = wgt.detach().clone(); wz[:, 6 * d:] = 0        # drop the cubic block: then <dh, h> = 2 <product part, cotangent>
+    wzd = wgt.detach().clone()
+    if order == 3:
+        wzd[:, 6 * d:] = 0                              # drop the cubic block: then <dh, h> = 2 <product part, cotangent>
     h2 = h.detach().clone().requires_grad_(True)
-    out2 = ops.interact(h2, p.detach(), wz, lay, 3)
+    out2 = ops.interact(h2, p.detach(), wzd, lay, order)
     out2.backward(cot)
-    assert abs((h2.grad.double() * h2.detach().double()).sum() - 2 * ((out2.detach() - first).double() * cot.double()).sum()) \
-        / abs(2 * ((out2.detach() - first).double() * cot.double()).sum()) <= 1e-4
+    twice = 2 * ((out2.detach() - first).double() * cot.double()).sum()
+    assert abs((h2.grad.double() * h2.detach().double()).sum() - twice) / abs(twice) <= 1e-4
 
 
 def test_integration_md_binding_stub_runs():

@@ -117,6 +117,26 @@ def test_f3_eval_path(tag, kind):
         m.clear_saved_feature()
 
 
+@pytest.mark.parametrize('tag', ['d128_o3', 'd128_o2', 'd256_o3'])
+def test_f8_wide_models(tag):
+    """BASELINE configs[2..4] shapes (d = 128 x 3 layers, d = 256 x 2 layers) on the small graph, from the reference."""
+    from conftest import f8_case, f8_gradient_error
+    (L, order, d), sd, z = f8_case(tag)
+    w, g = small_graph()
+    m = ref.OracleRawGnn(g, torch.from_numpy(w['bag_words'] + 1), torch.from_numpy(w['bag_offsets']), int(w['counts'][3]), d, 'ihgnn', L, order)
+    m.load_reference_state(sd)
+    u, q, i = (torch.from_numpy(z[f'{tag}.{k}']) for k in 'uqi')
+    scores = m(u, q, i)
+    loss = torch.nn.BCEWithLogitsLoss()(scores, torch.from_numpy(z[f'{tag}.flags']))
+    loss.backward()
+    assert rel_err(scores.detach().numpy(), z[f'{tag}.scores']) <= RTOL
+    assert abs(loss.item() - float(z[f'{tag}.loss'])) <= 1e-6
+    for key, gr in m.reference_grads().items():
+        assert f8_gradient_error(z, tag, key, gr.numpy()) <= 5e-6, key
+    with torch.no_grad():
+        assert rel_err(m.propagate().numpy(), z[f'{tag}.features']) <= RTOL
+
+
 def test_f4_metrics_known_answers():
     rec = json.load(open(os.path.join(GOLDEN, 'f4_metrics.json')))
     sc = rec['selfcheck']
