@@ -42,23 +42,25 @@ def _batch():
     return u, q, i, y
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode='flat'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     got_rank, _, got_world = ihg_dist.init_from_env('gloo')
     assert (got_rank, got_world) == (rank, world)
     torch.set_num_threads(1)
     model = _make_model(seed=100 + rank)                    # replicas start DIFFERENT ...
-    sync = ihg_dist.GradientSync(model.parameters())
+    sync = ihg_dist.make_gradient_sync(model, mode)
     sync.broadcast_parameters(0)                            # ... and are made identical to rank 0
     u, q, i, y = _batch()
     rows = ihg_dist.shard_range(64, rank, world)
     sl = slice(rows.start, rows.stop)
-    opt = torch.optim.Adam(model.parameters(), 1e-2)
+    opt = sync.optimizer(1e-2) if sync.owns_optimizer else torch.optim.Adam(model.parameters(), 1e-2)
     lossf = torch.nn.BCEWithLogitsLoss()
     for _ in range(2):                                      # two steps: the .grad views must survive zero_grad
         loss = lossf(model(u[sl], q[sl], i[sl]), y[sl])
         loss.backward()
         assert all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in sync.params)      # grads live in the flat buffer
+        if mode == 'bucketed':
+            assert all(sync._launched), 'every bucket was launched by its hook during the backward'
         sync.average_gradients()
         opt.step()
         sync.zero_grad()
@@ -69,9 +71,12 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_training_equals_single_rank_on_union_batch(tmp_path):
+@pytest.mark.parametrize('mode', ['flat', 'bucketed', 'sharded'])
+def test_two_rank_training_equals_single_rank_on_union_batch(tmp_path, mode):
+    """flat = one all-reduce; bucketed = per-bucket all-reduces launched from the backward hooks; sharded = reduce-scatter, Adam on the
+    rank's shard, all-gather of the parameters.  All three: replicas stay identical and equal the 1-rank run on the union batch."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
     r0, r1 = (torch.load(tmp_path / f'rank{k}.pt') for k in (0, 1))
     for k in r0:
         assert torch.equal(r0[k], r1[k]), f'replicas diverged on {k}'
@@ -107,3 +112,30 @@ def test_gradient_sync_single_process_is_transparent():
     sync.average_gradients()                                 # ... and they are re-attached here
     assert all(torch.equal(p.grad, w) for p, w in zip(lin.parameters(), want))
     assert lin.weight.grad.data_ptr() == sync.flat.data_ptr()
+
+
+def test_bucketed_sync_layout_puts_dense_parameters_first():
+    model = _make_model(seed=1)
+    sync = ihg_dist.BucketedGradientSync(model.named_parameters())
+    sizes = [e - b for b, e in sync.buckets]
+    tables = [p.numel() for n, p in model.named_parameters() if 'embedding' in n]
+    assert sizes[1:] == tables and sizes[0] == sum(p.numel() for n, p in model.named_parameters() if 'embedding' not in n)
+    assert sum(sizes) == sync.flat.numel()
+
+
+def test_sharded_batch_sampler_covers_each_epoch_exactly_once():
+    for n, batch, world in ((1000, 100, 1), (1001, 100, 2), (1234, 100, 8), (99, 100, 2), (807, 50, 3)):
+        for epoch in (0, 1):
+            per_rank = []
+            for rank in range(world):
+                s = ihg_dist.ShardedBatchSampler(n, batch, rank, world, shuffle=True, seed=3)
+                s.set_epoch(epoch)
+                batches = list(s)
+                assert len(batches) == len(s) and all(0 < len(b) <= batch for b in batches)
+                per_rank.append(batches)
+            assert len({len(b) for b in per_rank}) == 1                   # same number of steps (= all-reduces) on every rank
+            seen = sorted(x for batches in per_rank for b in batches for x in b)
+            assert seen == list(range(n))                                # every training row exactly once per epoch
+        first = [list(ihg_dist.ShardedBatchSampler(n, batch, 0, world, seed=3))]
+        s2 = ihg_dist.ShardedBatchSampler(n, batch, 0, world, seed=3); s2.set_epoch(1)
+        assert n < 3 or first[0] != list(s2)                             # a fresh permutation per epoch

@@ -930,3 +930,32 @@ def test_fused_bce_tail_equals_unfused_path():
     o.load_reference_state({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()})
     lo = torch.nn.BCEWithLogitsLoss()(o(u.cpu(), q.cpu(), i.cpu()), y.cpu())
     assert abs(lo.item() - lb.item()) <= 1e-5 * abs(lo.item())
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-rank path on one GPU: the HIP model, N ranks == 1 rank on the union batch; bench.py launches itself
+# ---------------------------------------------------------------------------------------------
+def _run(cmd, timeout=600):
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable] + cmd, cwd=repo, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize('sync', ['flat', 'bucketed', 'sharded'])
+def test_two_ranks_of_the_hip_model_equal_one_rank_on_the_union_batch(sync):
+    """Two processes on GPU 0 (gloo moves the buffers; RCCL refuses two ranks per GPU), each a full replica on its half of a
+    global batch, gradient exchange `sync`: parameters after two steps equal the 1-rank run on the whole batch."""
+    r = _run(['tools/two_rank_check.py', '--ranks', '2', '--sync', sync, '--device', '0', '--backend', 'gloo'])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'OK' in r.stdout
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun: the parent starts two rank processes and rank 0 prints the JSON line."""
+    import json
+    r = _run(['bench.py', '--gpus', '2', '--device', '0', '--backend', 'gloo', '--config', 'C1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['config']['parallelism'] == 'dp2' and line['value'] > 0
+    assert 0 < line['roofline']['frac'] <= 1

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""N ranks of the HIP model == 1 rank on the union batch, runnable on ONE GPU.
+
+    python tools/two_rank_check.py [--ranks 2] [--sync flat|bucketed|sharded] [--device 0] [--backend gloo]
+
+The parent starts the rank processes before touching the GPU (as bench.py does).  Every rank builds the same RawGnn replica on
+GPU `--device` (RCCL refuses two ranks on one GPU, so the single-GPU form uses gloo; on a multi-GPU node pass `--backend nccl
+--device -1`), trains two steps on its slice of one global batch with the chosen gradient exchange, and rank 0 then repeats the
+two steps alone on the whole batch and compares every parameter.  Exit code 0 = equal within 2e-5 relative.
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ranks', type=int, default=2)
+    ap.add_argument('--sync', default='bucketed')
+    ap.add_argument('--device', type=int, default=0)
+    ap.add_argument('--backend', default='gloo')
+    ap.add_argument('--dim', type=int, default=64)
+    args = ap.parse_args()
+    if 'WORLD_SIZE' not in os.environ:
+        import socket
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                 env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.ranks), MASTER_ADDR='127.0.0.1',
+                                          MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')) for r in range(args.ranks)]
+        codes = [k.wait() for k in kids]
+        raise SystemExit(max(abs(c) for c in codes))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ihgnn_amd import distributed as ihg_dist, synth
+    from ihgnn_amd.Dataset import GraphDataset
+    from ihgnn_amd.Models import HemPredictionLayer, IHGNNLayer, RawGnn
+    from ihgnn_amd.optim import Adam
+
+    rank, local, world = ihg_dist.init_from_env(args.backend)
+    dev = torch.device(f'cuda:{args.device if args.device >= 0 else local}')
+    torch.cuda.set_device(dev)
+    w = synth.draw(300, 40, 200, 50, 4000, seed=21)
+    ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets, w.triples, device=dev)
+
+    def replica():
+        torch.manual_seed(5)
+        return RawGnn(dev, ds, args.dim, IHGNNLayer, 2, 3, False, HemPredictionLayer, 0.5).to(dev)
+
+    rng = np.random.default_rng(8)
+    B = 64 * world
+    u, q, i = (torch.from_numpy(rng.integers(0, n, B)).to(dev) for n in (300, 40, 200))
+    y = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32)).to(dev)
+
+    model = replica()
+    sync = ihg_dist.make_gradient_sync(model, args.sync)
+    sync.broadcast_parameters(0)
+    opt = sync.optimizer(1e-3) if sync.owns_optimizer else Adam(model.parameters(), 1e-3)
+    rows = ihg_dist.shard_range(B, rank, world)
+    sl = slice(rows.start, rows.stop)
+    for _ in range(2):
+        model.bce_loss(u[sl], q[sl], i[sl], y[sl]).backward()
+        sync.average_gradients()
+        opt.step()
+        sync.zero_grad()
+    torch.cuda.synchronize()
+    ok = True
+    if rank == 0:
+        alone = replica()
+        opt1 = Adam(alone.parameters(), 1e-3)
+        for _ in range(2):
+            alone.bce_loss(u, q, i, y).backward()
+            opt1.step(); opt1.zero_grad()
+        worst = 0.0
+        for (name, a), (_, b) in zip(model.state_dict().items(), alone.state_dict().items()):
+            err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+            worst = max(worst, err)
+            if err > 2e-5:
+                ok = False
+                print(f'MISMATCH {name}: {err:.3e}', flush=True)
+        print(f'two_rank_check: sync={args.sync} ranks={world} worst relative deviation {worst:.3e} -> {"OK" if ok else "FAIL"}', flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    raise SystemExit(0 if ok else 1)
+
+
+if __name__ == '__main__':
+    main()
