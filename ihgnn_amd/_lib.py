@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # IHGNN_HIP_LIBRARY points at another build of the same ABI (A/B timing of kernel variants); default: the in-tree library
 LIB_PATH = os.environ.get('IHGNN_HIP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
@@ -73,6 +73,9 @@ SIGNATURES = {
                                                    c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
     'ihg_adam_step': (ctypes.c_int, [c_void_p, c_int32, c_float, c_float, c_float, c_float, c_float, c_int64, c_void_p]),
     'ihg_batch_combine': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    'ihg_score_topk_workspace_bytes': (c_int64, [c_int64, c_int64]),
+    'ihg_score_topk': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_int64,
+                                      c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'ihg_batch_rows_add': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                           c_void_p]),
 }

@@ -732,6 +732,343 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_wsbig_kern
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Strip kernels (D = 128: configs C3 / C4).  Eight waves and no loader role: wave w owns the 16-column strip w of the result with
+// the WHOLE contraction index, so its weight fragments (NBLK * D/16 float4 = 128 VGPRs) are loaded once per kernel and stay in
+// registers - nothing is streamed from L2 inside the loop (the plain tilings above re-fetch 256 KB of packed weights per tile).
+// v_mfma_f32_16x16x4_f32 (A[l&15][k = l>>4], B[k = l>>4][l&15], D: column l&15, rows 4 (l>>4) + r): lane group kq = l>>4 of MFMA
+// step s of k-group g is given k = 16 g + 4 kq + s, so a lane needs 4 CONSECUTIVE k per operand: one ds_read_b128 per staged row
+// per k-group feeds 4 x NBLK MFMAs.  Tiles of 32 hyperedges (two 16-row MFMA tiles = two independent accumulator chains per
+// wave), double-buffered LDS image filled by LDS-DMA which every wave issues for itself right after the barrier that opens the
+// PREVIOUS tile's MFMA phase, so a fill has a whole MFMA phase (~16 k cycles) to land; two workgroup barriers per tile.
+// Rows sit unpadded in LDS, 16-byte chunk c of row r at position c ^ (r & 15) (conflict-free ds_read_b128 for this lane map;
+// the swizzle is applied to the DMA's per-lane SOURCE address).
+// ------------------------------------------------------------------------------------------------
+constexpr int kStripTE = 32;
+
+// ws_fwd[strip][b][g][lane][4] = W[16 strip + (lane&15)][(3+b)d + 16 g + 4 (lane>>4) + s]        (k runs along c)
+// ws_bwd[strip][b][g][lane][4] = W[16 g + 4 (lane>>4) + s][(3+b)d + 16 strip + (lane&15)]        (k runs along j)
+__global__ __launch_bounds__(kBlockThreads) void pack_weights_strip_kernel(const float* __restrict__ w, int64_t ld_w, int d, int nblk,
+                                                                           float* __restrict__ ws_fwd, float* __restrict__ ws_bwd) {
+    const int kg = d / 16;
+    const int total = (d / 16) * nblk * kg * kWave;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & (kWave - 1);
+        const int g = (idx >> 6) % kg;
+        const int b = ((idx >> 6) / kg) % nblk;
+        const int strip = (idx >> 6) / (kg * nblk);
+        const int c = lane & 15, kq = lane >> 4;
+        if (ws_fwd != nullptr) {
+            const float* src = w + static_cast<int64_t>(16 * strip + c) * ld_w + static_cast<int64_t>(3 + b) * d + 16 * g + 4 * kq;
+            *reinterpret_cast<float4*>(ws_fwd + static_cast<int64_t>(idx) * 4) = make_float4(src[0], src[1], src[2], src[3]);
+        }
+        if (ws_bwd != nullptr) {
+            const float* src = w + static_cast<int64_t>(16 * g + 4 * kq) * ld_w + static_cast<int64_t>(3 + b) * d + 16 * strip + c;
+            *reinterpret_cast<float4*>(ws_bwd + static_cast<int64_t>(idx) * 4) = make_float4(src[0], src[ld_w], src[2 * ld_w], src[3 * ld_w]);
+        }
+    }
+}
+
+template <int D, int NBLK>
+__global__ __launch_bounds__(kWsThreads) void interact_fwd_strip_kernel(
+    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
+    const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
+    static_assert(D == 128, "eight 16-column strips");
+    constexpr int TE = kStripTE, V4 = D / 4, KG = D / 16, RT = TE / 16;
+    constexpr int ROWS_PER_PIECE = kWave / V4;                            // 2 rows of 512 B per 1-KiB DMA piece
+    constexpr int PIECES_PER_MEMBER = TE / ROWS_PER_PIECE;                // 16
+    constexpr int PIECES = 3 * PIECES_PER_MEMBER / 8;                     // 6 per wave per tile
+    constexpr int OSTRIDE = D + 4;                                        // accumulator rows r and r + 4 of one store land 16 banks apart
+    struct Buffer { float tile[3][TE][D]; };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    __shared__ __attribute__((aligned(16))) float prod[TE][OSTRIDE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int64_t grid = gridDim.x;
+    const int n_my = blockIdx.x < n_tiles ? static_cast<int>((n_tiles - blockIdx.x + grid - 1) / grid) : 0;
+    if (n_my == 0) return;
+    const int64_t t0 = blockIdx.x;
+
+    // this wave's weight fragments, resident for the whole kernel
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wp) + static_cast<int64_t>(wave) * NBLK * KG * kWave + lane;
+    v4f wreg[NBLK][KG];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int gk = 0; gk < KG; ++gk) wreg[b][gk] = wfrag[(b * KG + gk) * kWave];
+
+    // DMA pieces of this wave: piece x = wave * PIECES + k -> member x / 16, rows 2 (x % 16) and + 1; lane: row + (lane >> 5), chunk lane & 31.
+    // Lane-dependent values are re-derived from `tl` (an opaque copy of the thread id) wherever they are used: kept in registers
+    // across the MFMA phase they push the weight fragments out.
+    const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u;
+    const char* hbytes = reinterpret_cast<const char*>(h);
+    int tl = tid;
+    int node_dma[PIECES];
+    auto load_dma_ids = [&](int64_t tile_id) {
+        const int prow = (tl >> 5) & 1;
+#pragma unroll
+        for (int k = 0; k < PIECES; ++k) {
+            const int x = wave * PIECES + k;
+            const int64_t e = tile_id * TE + 2 * (x & (PIECES_PER_MEMBER - 1)) + prow;
+            node_dma[k] = e < n_edges ? i3[e * 3 + (x >> 4)] : 0;
+        }
+    };
+    auto issue_dma = [&](Buffer& b) {
+        const int prow = (tl >> 5) & 1, pchunk = tl & 31;
+#pragma unroll
+        for (int k = 0; k < PIECES; ++k) {
+            const int x = wave * PIECES + k;
+            const int r0 = 2 * (x & (PIECES_PER_MEMBER - 1));
+            const int swz = (pchunk ^ ((r0 + prow) & 15)) * 16;
+            lds_dma16(reinterpret_cast<const float*>(hbytes + static_cast<uint64_t>(static_cast<uint32_t>(node_dma[k])) * h_row_bytes + swz),
+                      &b.tile[x >> 4][r0][0]);
+        }
+    };
+    // epilogue mapping: thread -> hyperedge row tid >> 4, columns 4 (tid & 15) .. + 3 and 64 + the same
+    int node_p[3];
+    auto load_p_ids = [&](int64_t tile_id) {
+        const int64_t e = tile_id * TE + (tl >> 4);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) node_p[m] = e < n_edges ? i3[e * 3 + m] : 0;
+    };
+
+    load_dma_ids(t0);
+    load_p_ids(t0);
+    issue_dma(buf[0]);
+    if (n_my > 1) load_dma_ids(t0 + grid);
+
+    for (int k = 0; k < n_my; ++k) {
+        const int64_t tile_id = t0 + k * grid;
+        Buffer& b = buf[k & 1];
+        asm volatile("" : "+v"(tl));
+        const int arow = tl & 15, kq = (tl >> 4) & 3;
+        const int erow = tl >> 4, ecol = (tl & 15) * 4;
+        // the fill of tile k was issued a whole MFMA phase ago (k = 0: just now); the two youngest operations are the result stores
+        // of tile k - 1, which need not have retired
+        if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __syncthreads();
+        if (k + 1 < n_my) issue_dma(buf[(k + 1) & 1]);                      // that buffer's last reader was tile k - 1's MFMA phase
+        v4f first[2];
+        {
+            v4f pr[3][2];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float* src = p + static_cast<int64_t>(node_p[m]) * ld_p + ecol;
+                pr[m][0] = *reinterpret_cast<const v4f*>(src);
+                pr[m][1] = *reinterpret_cast<const v4f*>(src + 64);
+            }
+            if (k + 2 < n_my) load_dma_ids(t0 + (k + 2) * grid);
+            if (k + 1 < n_my) load_p_ids(t0 + (k + 1) * grid);
+            first[0] = (pr[0][0] + pr[1][0]) + pr[2][0];
+            first[1] = (pr[0][1] + pr[1][1]) + pr[2][1];
+        }
+        v4f acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = v4f{0.f, 0.f, 0.f, 0.f};
+        // One (k-group, row tile) step = 3 ds_read_b128 + 4 products + 4 NBLK MFMAs on one accumulator chain; the chain's 40-cycle
+        // dependent latency against the 32-cycle issue interval is covered by the SIMD's other wave.  The member rows of the NEXT
+        // step are read before this step's MFMAs (the scheduling fences keep the compiler from sinking or hoisting them further,
+        // which costs either the LDS latency or the registers of several steps' operands).
+        // byte offset of chunk (4 g + kq) ^ arow of row arow = lane_off ^ (g << 6): ONE address register, re-derived per step (the
+        // empty asm keeps the compiler from hoisting sixteen of them out of the tile loop, which spills the weight fragments)
+        int lane_off = arow * (D * 4) + ((kq ^ arow) << 4);
+        asm volatile("" : "+v"(lane_off));
+        const char* tbase = reinterpret_cast<const char*>(&b.tile[0][0][0]);
+        auto member_chunk = [&](int m, int rt, int gk) {
+            return *reinterpret_cast<const v4f*>(tbase + (lane_off ^ (gk << 6)) + (m * TE + rt * 16) * (D * 4));
+        };
+        v4f au = member_chunk(0, 0, 0), aq = member_chunk(1, 0, 0), ai = member_chunk(2, 0, 0);
+#pragma unroll
+        for (int step = 0; step < KG * RT; ++step) {
+            const int gk = step / RT, rt = step % RT;
+            v4f z[4];
+            z[0] = au * aq;
+            z[1] = aq * ai;
+            z[2] = ai * au;
+            z[3] = z[0] * ai;
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < KG * RT) {
+                const int gn = (step + 1) / RT, rn = (step + 1) % RT;
+                au = member_chunk(0, rn, gn);
+                aq = member_chunk(1, rn, gn);
+                ai = member_chunk(2, rn, gn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[bk][s2], wreg[bk][gk][s2], acc[rt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) prod[rt * 16 + 4 * kq + r][16 * wave + arow] = acc[rt][r];
+        __syncthreads();
+        const int64_t e = tile_id * TE + erow;
+        const v4f s0 = *reinterpret_cast<const v4f*>(&prod[erow][ecol]) + first[0];
+        const v4f s1 = *reinterpret_cast<const v4f*>(&prod[erow][64 + ecol]) + first[1];
+        if (e < n_edges) {
+            float* dst = out + e * ld_out + ecol;
+            *reinterpret_cast<v4f*>(dst) = s0;
+            *reinterpret_cast<v4f*>(dst + 64) = s1;
+        }
+    }
+}
+
+// Member gradients, same layout: the loaders' job of the D <= 64 kernel is done by every wave for its own rows.  A operand = the
+// dout rows (a stream, swizzled like the forward's member rows), the member rows sit beside them as they lie; every wave owns a
+// 16-column strip of all NBLK product blocks (NBLK x 2 accumulators), applies the product rule to its own (row, column) elements
+// IN PLACE in the member tile, and after the second barrier each wave streams the rows it will refill out as 16-byte vectors.
+template <int D, int NBLK>
+__global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g_out, int64_t n_edges) {
+    static_assert(D == 128, "eight 16-column strips");
+    constexpr int TE = kStripTE, V4 = D / 4, KG = D / 16, RT = TE / 16;
+    constexpr int ROWS_PER_PIECE = kWave / V4;                            // 2
+    constexpr int PIECES_PER_MEMBER = TE / ROWS_PER_PIECE;                // 16
+    constexpr int HP = 3 * PIECES_PER_MEMBER / 8;                         // 6 member-row pieces per wave per tile
+    constexpr int DP = PIECES_PER_MEMBER / 8;                             // 2 dout pieces per wave per tile
+    struct Buffer {
+        float dtile[TE][D];
+        float htile[3][TE][D];
+    };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int64_t grid = gridDim.x;
+    const int n_my = blockIdx.x < n_tiles ? static_cast<int>((n_tiles - blockIdx.x + grid - 1) / grid) : 0;
+    if (n_my == 0) return;
+    const int64_t t0 = blockIdx.x;
+
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wq) + static_cast<int64_t>(wave) * NBLK * KG * kWave + lane;
+    v4f wreg[NBLK][KG];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int gk = 0; gk < KG; ++gk) wreg[b][gk] = wfrag[(b * KG + gk) * kWave];
+
+    const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u;
+    int tl = tid;                                                        // opaque copy of the thread id, see the forward kernel
+    int node_dma[HP];
+    auto load_dma_ids = [&](int64_t tile_id) {
+        const int prow = (tl >> 5) & 1;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const int x = wave * HP + k;
+            const int64_t e = tile_id * TE + 2 * (x & (PIECES_PER_MEMBER - 1)) + prow;
+            node_dma[k] = e < n_edges ? i3[e * 3 + (x >> 4)] : 0;
+        }
+    };
+    auto issue_dma = [&](Buffer& b, int64_t tile_id) {
+        const int prow = (tl >> 5) & 1, pchunk = tl & 31;
+        const char* hbytes = reinterpret_cast<const char*>(h) + pchunk * 16;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {                                   // dout rows: a stream; rows past the end re-read the last one
+            const int r0 = 2 * (wave * DP + k);
+            int64_t e = tile_id * TE + r0 + prow;
+            e = e < n_edges ? e : n_edges - 1;
+            lds_dma16(dout + e * ld_dout + (pchunk ^ ((r0 + prow) & 15)) * 4, &b.dtile[r0][0]);
+        }
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const int x = wave * HP + k;
+            lds_dma16(reinterpret_cast<const float*>(hbytes + static_cast<uint64_t>(static_cast<uint32_t>(node_dma[k])) * h_row_bytes),
+                      &b.htile[x >> 4][2 * (x & (PIECES_PER_MEMBER - 1))][0]);
+        }
+    };
+
+    load_dma_ids(t0);
+    issue_dma(buf[0], t0);
+    if (n_my > 1) load_dma_ids(t0 + grid);
+
+    for (int k = 0; k < n_my; ++k) {
+        const int64_t tile_id = t0 + k * grid;
+        Buffer& b = buf[k & 1];
+        asm volatile("" : "+v"(tl));
+        const int arow = tl & 15, kq = (tl >> 4) & 3;
+        const int col = 16 * wave + arow;
+        const int prow = (tl >> 5) & 1, pchunk = tl & 31;
+        // everything but the HP member-gradient stores of tile k - 1 (the youngest operations) has to have landed
+        if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        static_assert(HP == 6, "the wait above counts the stores of one tile");
+        __syncthreads();
+        if (k + 1 < n_my) issue_dma(buf[(k + 1) & 1], t0 + (k + 1) * grid);   // last read: the store-out of tile k - 1, before this barrier
+        if (k + 2 < n_my) load_dma_ids(t0 + (k + 2) * grid);
+        v4f acc[RT][NBLK];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk) acc[rt][bk] = v4f{0.f, 0.f, 0.f, 0.f};
+        int lane_off = arow * (D * 4) + ((kq ^ arow) << 4);              // see the forward kernel
+        asm volatile("" : "+v"(lane_off));
+        const char* dbase = reinterpret_cast<const char*>(&b.dtile[0][0]);
+        v4f a[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const v4f*>(dbase + lane_off + rt * 16 * (D * 4));
+#pragma unroll
+        for (int gk = 0; gk < KG; ++gk) {
+            v4f a_now[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a_now[rt] = a[rt];
+            __builtin_amdgcn_sched_barrier(0);
+            if (gk + 1 < KG) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const v4f*>(dbase + (lane_off ^ ((gk + 1) << 6)) + rt * 16 * (D * 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][bk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_now[rt][s2], wreg[bk][gk][s2], acc[rt][bk], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // product rule on this lane's own (row, column) elements, results over the member values
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float hu[4], hq[4], hi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int er = rt * 16 + 4 * kq + r;
+                hu[r] = b.htile[0][er][col];
+                hq[r] = b.htile[1][er][col];
+                hi[r] = b.htile[2][er][col];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int er = rt * 16 + 4 * kq + r;
+                const float z_uq = acc[rt][0][r], z_qi = acc[rt][1][r], z_iu = acc[rt][2][r];
+                const float z_uqi = NBLK == 4 ? acc[rt][NBLK - 1][r] : 0.f;
+                b.htile[0][er][col] = z_uq * hq[r] + z_iu * hi[r] + z_uqi * (hq[r] * hi[r]);
+                b.htile[1][er][col] = z_uq * hu[r] + z_qi * hi[r] + z_uqi * (hu[r] * hi[r]);
+                b.htile[2][er][col] = z_qi * hq[r] + z_iu * hu[r] + z_uqi * (hu[r] * hq[r]);
+            }
+        }
+        __syncthreads();
+        // store-out: the rows this wave fills by DMA, as they lie
+        v4f gv[HP];
+#pragma unroll
+        for (int kk = 0; kk < HP; ++kk) {
+            const int x = wave * HP + kk;
+            gv[kk] = *reinterpret_cast<const v4f*>(&b.htile[x >> 4][2 * (x & (PIECES_PER_MEMBER - 1)) + prow][pchunk * 4]);
+        }
+        const bool full = tile_id * TE + TE <= n_edges;
+#pragma unroll
+        for (int kk = 0; kk < HP; ++kk) {
+            const int x = wave * HP + kk;
+            const int64_t e = tile_id * TE + 2 * (x & (PIECES_PER_MEMBER - 1)) + prow;
+            if (full || e < n_edges) *reinterpret_cast<v4f*>(g_out + e * (3 * D) + (x >> 4) * D + pchunk * 4) = gv[kk];
+        }
+    }
+}
+
 // dW, same roles: workgroup (x, y) owns the 64 x 64 x NBLK sub-block y = (js, cs) of the d x NBLK*d gradient (d a multiple of 64)
 // for the hyperedge tiles x, x + gridDim.x, ...; its loaders fetch the matching 64-column slices of dout and of the member rows.
 template <int NBLK>
@@ -968,6 +1305,7 @@ inline int weight_slabs(int dim) {
     return n < 8 ? 8 : n;
 }
 constexpr int kFwdGrid = 256 * 3;
+constexpr int kPipeGrid = 256;          // wave-specialised and strip kernels: one 512-thread workgroup per CU
 
 // Persistent grid of a plain (one role) tiling: as many workgroups as are resident at once - a larger grid runs in rounds, and
 // the workgroups of the last round start when the others have already walked their whole share of the tiles.
@@ -980,12 +1318,22 @@ int resident_grid(Kernel kernel) {
         cus = prop.multiProcessorCount;
     return per_cu * cus;
 }
-constexpr int kPipeGrid = 256;          // wave-specialised kernels: one 512-thread workgroup per CU
 
+
+// the strip kernels (D = 128) move rows as 16-byte vectors and form addresses as 32 x 32-bit products
+inline bool strip_fwd_ok(int dim, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h) {
+    return dim == 128 && aligned16(p) && aligned16(out) && ld_p % 4 == 0 && ld_out % 4 == 0 && ld_h < (int64_t{1} << 30);
+}
+inline bool strip_bwd_ok(int dim, const float* g, int64_t ld_h) { return dim == 128 && aligned16(g) && ld_h < (int64_t{1} << 30); }
 
 template <int NBLK>
 void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* wp,
                               float* out, int64_t ld_out, int64_t n_edges, hipStream_t s) {
+    if (strip_fwd_ok(dim, p, ld_p, out, ld_out, ld_h)) {                    // wp is strip-packed (the caller asked strip_fwd_ok too)
+        const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGrid));
+        hipLaunchKernelGGL((interact_fwd_strip_kernel<128, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges);
+        return;
+    }
 #define IHG_FWD(D)                                                                                                          \
     {                                                                                                                       \
         const int64_t tiles = (n_edges + TileShape<D>::TE - 1) / TileShape<D>::TE;                                          \
@@ -1032,6 +1380,10 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
         hipLaunchKernelGGL((interact_bwd_members_ws_kernel<D, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
     }
     const bool vector_io = aligned16(g) && ld_h < (int64_t{1} << 30);     // the pipelined form stores g as 16-byte vectors
+    if (strip_bwd_ok(dim, g, ld_h)) {                                    // wq is strip-packed
+        const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGrid));
+        hipLaunchKernelGGL((interact_bwd_members_strip_kernel<128, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges);
+    } else
     switch (dim) {
         case 32:
             if (vector_io) IHG_MEM_PIPE(32) else IHG_MEM(32)
@@ -1087,8 +1439,12 @@ int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p,
         float* wp = static_cast<float*>(workspace);
         const int nblk = order == 3 ? 4 : 3;
         const int pack_items = (dim / 32) * nblk * (dim / 8) * kWave;
-        hipLaunchKernelGGL(pack_weights_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wp,
-                           static_cast<float*>(nullptr));
+        if (strip_fwd_ok(dim, p, ld_p, out, ld_out, ld_h))
+            hipLaunchKernelGGL(pack_weights_strip_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wp,
+                               static_cast<float*>(nullptr));
+        else
+            hipLaunchKernelGGL(pack_weights_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wp,
+                               static_cast<float*>(nullptr));
         if (nblk == 4) launch_interact_fwd_mfma<4>(dim, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges, s);
         else launch_interact_fwd_mfma<3>(dim, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges, s);
         return check_launch("ihg_interact_fwd");
@@ -1124,8 +1480,12 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const floa
         float* wq = static_cast<float*>(workspace);
         float* slabs = wq + packed_weight_floats(dim, order);
         const int pack_items = (dim / 32) * nblk * (dim / 8) * kWave;
-        hipLaunchKernelGGL(pack_weights_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk,
-                           static_cast<float*>(nullptr), wq);
+        if (strip_bwd_ok(dim, g, ld_h))
+            hipLaunchKernelGGL(pack_weights_strip_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk,
+                               static_cast<float*>(nullptr), wq);
+        else
+            hipLaunchKernelGGL(pack_weights_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk,
+                               static_cast<float*>(nullptr), wq);
         if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s);
         else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s);
         return check_launch("ihg_interact_bwd");

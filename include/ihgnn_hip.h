@@ -294,6 +294,23 @@ typedef struct ihg_adam_tensor {
 int ihg_adam_step(const ihg_adam_tensor* tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, ihg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DEVICE: evaluation scoring with a running top-k.  Replaces, for `n_pairs` search logs at once, the per-log
+ * sequence RawGnn.forward(u * ones(I), q * ones(I), None) (Models/RawGnn.py:124-137) -> HemPredictionLayer.forward
+ * (Models/PredictionLayers.py:35-43) -> torch.sort(scores, descending=True)[:10] (Helpers/Metrics.py:60-61):
+ *   score[c][i] = sum_k features[item_row0 + i][k] * (lambda * features[query_row0 + queries[c]][k] + (1 - lambda) * features[users[c]][k])
+ *                 + item_bias[i]
+ *   top_items[c][0..k) = the k items of highest score, best first; equal scores in ascending item order (a stable descending
+ *   sort; the reference's sort is unstable on ties); top_scores[c][0..k) their scores.  With fewer than k items the tail is -1.
+ * `features` is the cached [N, dim] propagation output (rows 16-byte aligned, dim % 4 == 0, dim <= 1272); k <= 10.
+ * The [n_pairs, n_items] score matrix is never stored: fp32 MFMA tiles are reduced to per-lane top-k lists in registers.
+ * Workspace: ihg_score_topk_workspace_bytes(n_pairs, n_items) bytes (partial lists).
+ */
+int64_t ihg_score_topk_workspace_bytes(int64_t n_pairs, int64_t n_items);
+int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query_row0, int64_t item_row0, int64_t n_items,
+                   const float* item_bias, const int64_t* users, const int64_t* queries, float lambda_muq, int64_t n_pairs,
+                   int32_t k, float* top_scores, int32_t* top_items, void* workspace, int64_t workspace_bytes, ihg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
