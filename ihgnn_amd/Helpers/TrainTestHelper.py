@@ -32,15 +32,20 @@ def print_network_parameters(module: nn.Module, name_filter: Optional[str] = Non
 
 
 def _evaluate_batched(model, logs, item_count: int, device: torch.device, indices) -> List[Tuple[int, Metrics]]:
-    """Top-10 of many searches per launch: one ``[C, D] x [D, I]`` GEMM + ``topk`` per chunk, one D2H copy per chunk
-    (the reference scores one log at a time and syncs on every one, ``TrainTestHelper.py:58-67``, ``Metrics.py:60-61``)."""
+    """Top-10 of many searches per launch (``ihg_score_topk``: scores on the matrix cores, running top-10 in registers, no
+    ``[C, I]`` matrix), one D2H copy per chunk (the reference scores one log at a time and syncs on every one,
+    ``TrainTestHelper.py:58-67``, ``Metrics.py:60-61``)."""
     out: List[Tuple[int, Metrics]] = []
-    chunk = max(1, min(2048, (1 << 28) // max(item_count, 1)))
+    fused = hasattr(model, 'top_items')
+    chunk = 8192 if fused else max(1, min(2048, (1 << 28) // max(item_count, 1)))
     k = min(10, item_count)
     for lo in range(0, len(indices), chunk):
         part = indices[lo:lo + chunk]
         uq = torch.tensor([(logs[i][0], logs[i][1]) for i in part], dtype=torch.long, device=device)
-        top = model.score_all_items(uq[:, 0], uq[:, 1]).topk(k, dim=1, largest=True, sorted=True).indices.tolist()
+        if fused:                                           # HIP kernel: fp32-MFMA scores reduced to a running top-10 on chip
+            top = model.top_items(uq[:, 0], uq[:, 1], k)[0].tolist()
+        else:
+            top = model.score_all_items(uq[:, 0], uq[:, 1]).topk(k, dim=1, largest=True, sorted=True).indices.tolist()
         for i, row in zip(part, top):
             _, _, items, flags, all_1 = logs[i]
             out.append((i, Metrics.from_top_indices(row, items, flags, all_1)))

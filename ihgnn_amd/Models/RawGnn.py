@@ -144,6 +144,21 @@ class RawGnn(nn.Module):
         mixed = lam * features[query_indices + ds.query_start_index_in_graph] + (1 - lam) * features[user_indices]
         return torch.addmm(head.items_bias.unsqueeze(0), mixed, item_feature.t())
 
+    def top_items(self, user_indices: Tensor, query_indices: Tensor, k: int = 10):
+        """``(items [C, k] int32, scores [C, k])``: the ``k`` best items of each (user, query) pair over the whole catalogue, best
+        first - what ``Metrics.calculate_on_all_items`` keeps of ``forward(u, q, None)`` (``Metrics.py:60-61``) - from the fused
+        HIP scoring + running top-k kernel; the ``[C, I]`` scores are never stored.  Ties: ascending item id."""
+        from .. import ops
+        features = self._saved_output_feature if self._saved_output_feature is not None else self.propagate()
+        ds, head = self.dataset, self.prediction_layer
+        k = min(k, ds.item_count)
+        if not ops.score_topk_supported(features) or k > 10:
+            scores = self.score_all_items(user_indices, query_indices)          # odd widths (d % 4 != 0): rocBLAS + a stable sort
+            order = torch.sort(scores, dim=1, descending=True, stable=True).indices[:, :k]
+            return order.to(torch.int32), torch.gather(scores, 1, order)
+        return ops.score_topk(features, user_indices, query_indices, ds.query_start_index_in_graph, ds.item_start_index_in_graph,
+                              head.items_bias, head.lambda_muq, k)
+
     def save_features_for_test(self) -> None:
         """Cache one propagation for the evaluation loop (call under ``torch.no_grad()``)."""
         self._saved_output_feature = self.propagate()

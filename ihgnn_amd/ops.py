@@ -746,6 +746,35 @@ class _HemBceLoss(torch.autograd.Function):
         return (None, None, None, dbias, None, None, None) + tuple(_zero_like_expanded(x.shape, x.device) for x in layers)
 
 
+def score_topk_supported(features: Tensor) -> bool:
+    """True when ``ihg_score_topk`` takes this feature matrix (16-byte aligned rows, width a multiple of 4 and at most 1272)."""
+    return (features.is_cuda and features.dtype == torch.float32 and features.dim() == 2 and features.stride(1) == 1 and features.shape[1] % 4 == 0
+            and features.stride(0) % 4 == 0 and features.data_ptr() % 16 == 0 and features.shape[1] <= 1272)
+
+
+def score_topk(features: Tensor, users: Tensor, queries: Tensor, query_row0: int, item_row0: int, item_bias: Tensor, lam: float, k: int = 10):
+    """Evaluation scoring: for every (user, query) pair the ``k`` best items over ALL items and their HEM scores,
+    ``(top_items [C, k] int32, top_scores [C, k])``, best first, ties in ascending item order; the ``[C, I]`` score matrix is
+    never materialised.  ``features`` = the cached ``[N, D]`` propagation output; items are its rows from ``item_row0`` on."""
+    lib = _lib.load()
+    if not score_topk_supported(features):
+        raise _lib.IhgnnHipError(f'ihg_score_topk needs a float32 GPU feature matrix with 16-byte aligned rows and width % 4 == 0, got '
+                                 f'{tuple(features.shape)} {features.dtype} on {features.device}')
+    n_pairs = int(users.shape[0])
+    n_items = int(features.shape[0]) - int(item_row0)
+    users = users.to(device=features.device, dtype=torch.int64).contiguous()
+    queries = queries.to(device=features.device, dtype=torch.int64).contiguous()
+    bias = item_bias.detach().to(torch.float32).contiguous()
+    top_scores = torch.empty(n_pairs, k, dtype=torch.float32, device=features.device)
+    top_items = torch.empty(n_pairs, k, dtype=torch.int32, device=features.device)
+    ws = _workspace(int(lib.ihg_score_topk_workspace_bytes(n_pairs, n_items)), features.device)
+    with profiler.kernel('score_topk', n_pairs, int(features.shape[1])):
+        _lib.check(lib.ihg_score_topk(_ptr(features), _ld(features), int(features.shape[1]), int(query_row0), int(item_row0), n_items, _ptr(bias),
+                                      _ptr(users), _ptr(queries), float(lam), n_pairs, int(k), _ptr(top_scores), _ptr(top_items), _ptr(ws),
+                                      ws.numel() * 4, _stream()), 'ihg_score_topk')
+    return top_items, top_scores
+
+
 def hem_score(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, item_row_offset: int) -> Tensor:
     """HEM scores of a batch: ``rows`` = global node rows of users, queries, items (``[3B]`` int64), ``items`` = 0-based item
     ids (``[B]``), ``layers`` = the ``[N,d]`` outputs ``X_0..X_L`` whose concatenation the reference scores on."""

@@ -696,7 +696,7 @@ def test_training_steps_are_bitwise_reproducible(kind):
 
 
 def test_batched_evaluation_equals_per_log_scoring(tmp_path):
-    """f1: the GEMM + top-k evaluation loop gives the same metrics as scoring one log at a time."""
+    """f1: the evaluation loop over the fused scoring + top-10 kernel gives the same metrics as scoring one log at a time."""
     from ihgnn_amd import synth
     from ihgnn_amd.Dataset import GraphDataset, TestSearchLogDataLoader
     from ihgnn_amd.Helpers.Graph import PpsHyperGraph
@@ -720,6 +720,67 @@ def test_batched_evaluation_equals_per_log_scoring(tmp_path):
     want = acc.divide_and_get_new(len(loader))
     assert rel(batched, one) <= RTOL
     np.testing.assert_allclose([avg.HitRatio_at10, avg.NDCG_at10, avg.MAP_at10], [want.HitRatio_at10, want.NDCG_at10, want.MAP_at10], atol=1e-9)
+
+
+@pytest.mark.parametrize('dim,n_items,n_pairs', [(64, 257, 5), (36, 31, 40), (192, 70001, 97), (512, 4100, 33), (128, 7, 3), (768, 1200, 64)])
+def test_score_topk_matches_oracle(dim, n_items, n_pairs):
+    """f1: the fused scoring + running top-10 kernel against the oracle's HEM scores of every item (PredictionLayers.py:35-43) sorted
+    as Metrics.calculate_on_all_items does (Metrics.py:60-61) - widths with dim % 8 == 4, item counts off the 32-item tile, fewer
+    than ten items, pair counts off the 32-pair block, enough items for several item slices per pair block."""
+    from ihgnn_amd import ops
+    from oracle import ihgnn_ref as ref
+    U, Q = 50, 20
+    gen = torch.Generator().manual_seed(dim + n_items)
+    feats = torch.randn(U + Q + n_items, dim, generator=gen) / np.sqrt(dim)
+    bias = torch.randn(n_items, generator=gen)
+    users = torch.randint(0, U, (n_pairs,), generator=gen)
+    queries = torch.randint(0, Q, (n_pairs,), generator=gen)
+    k = min(10, n_items)
+    items, scores = ops.score_topk(feats.to(dev()), users.to(dev()), queries.to(dev()), U, U + Q, bias.to(dev()), 0.5, k)
+    items, scores = items.cpu().long(), scores.cpu()
+    for c in range(n_pairs):
+        want = ref.hem_score(feats[users[c]].expand(n_items, dim), feats[U + queries[c]].expand(n_items, dim), feats[U + Q:], bias, 0.5)
+        order = torch.sort(want, descending=True, stable=True).indices[:k]
+        assert rel(scores[c], want[order]) <= RTOL
+        assert rel(want[items[c]], want[order]) <= RTOL          # the kernel's items ARE the best k (up to fp32 near-ties)
+        assert len(set(items[c].tolist())) == k
+        gap = (want[order][:-1] - want[order][1:]).abs().min().item() if k > 1 else 1.0
+        if gap > 1e-4 * want.abs().max().item():                 # no near-tie among the top k: same items in the same order
+            assert items[c].tolist() == order.tolist()
+
+
+def test_score_topk_ties_and_ranking_metrics():
+    """Equal scores come out in ascending item order (a stable descending sort; the reference's sort is unstable there), and the
+    metrics computed from the kernel's top-10 equal the oracle's ranking_metrics over all item scores (Metrics.py:46-109)."""
+    from ihgnn_amd import ops
+    from ihgnn_amd.Helpers.Metrics import Metrics
+    from oracle import ihgnn_ref as ref
+    U, Q, I, D = 9, 5, 300, 96
+    gen = torch.Generator().manual_seed(5)
+    feats = torch.randn(U + Q + I, D, generator=gen) / 8
+    bias = torch.randn(I, generator=gen)
+    dup = [17, 3, 250, 131, 64, 65]                          # six items with identical rows and bias -> bit-equal scores for every pair
+    feats[U + Q + torch.tensor(dup)] = feats[U + Q + 17] * 3  # and large enough to sit in the top ten
+    bias[torch.tensor(dup)] = 2.0
+    users, queries = torch.arange(U), torch.arange(U) % Q
+    items, scores = ops.score_topk(feats.to(dev()), users.to(dev()), queries.to(dev()), U, U + Q, bias.to(dev()), 0.5, 10)
+    items, scores = items.cpu(), scores.cpu()
+    for c in range(U):
+        want = ref.hem_score(feats[users[c]].expand(I, D), feats[U + queries[c]].expand(I, D), feats[U + Q:], bias, 0.5)
+        order = torch.sort(want, descending=True, stable=True).indices[:10].tolist()
+        got = items[c].tolist()
+        tied = [i for i in got if i in dup]
+        assert tied == sorted(tied)                              # ties in ascending item order
+        if set(dup) <= set(order):
+            assert got == order                                  # and then the whole list equals the stable sort
+        # metrics: ground truth outside the tied group (the reference's unstable sort, restated by the oracle, may order the tied
+        # items differently, and with a tied item in the truth set its own NDCG / MAP depend on that order)
+        clear = [i for i in order if i not in dup]
+        truth = sorted({clear[0], clear[-1], 299} - set(dup))
+        if got == order:
+            hr, ndcg, ap = ref.ranking_metrics(want, truth)
+            m = Metrics.from_top_indices(got, truth, None, True)
+            assert abs(m.HitRatio_at10 - hr) < 1e-12 and abs(m.NDCG_at10 - ndcg) < 1e-12 and abs(m.MAP_at10 - ap) < 1e-12
 
 
 def test_driver_end_to_end(tmp_path, monkeypatch):
