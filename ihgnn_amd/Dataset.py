@@ -16,7 +16,7 @@ import torch
 from torch import Tensor
 from torch.utils.data import Dataset
 
-from .Helpers.Graph import Pps2DGraph, PpsGraph, PpsHyperGraph
+from .Helpers.Graph import Pps2DGraph, PpsGraph, PpsHyperGraph, PpsLogHyperGraph
 from .Helpers.IOHelper import IOHelper
 from .Helpers.SearchLog import PosInteraction, SearchLog
 from .Helpers.SearchLogCollection import SearchLogCollection
@@ -24,21 +24,50 @@ from .Helpers.SearchLogCollection import SearchLogCollection
 Sample = Tuple[Tuple[int, int, int, int], List[int]]
 
 
-def parse_search_logs(filename: str) -> Tuple[int, np.ndarray, np.ndarray]:
-    """Native two-pass parse of a search-log CSV -> (row count, positive ``[P,3]``, negative ``[M,3]`` (user, query, item))."""
+def parse_search_logs(filename: str, with_rows: bool = False):
+    """Native two-pass parse of a search-log CSV -> (row count, positive ``[P,3]``, negative ``[M,3]`` (user, query, item));
+    ``with_rows`` appends the 0-based row of every positive (``[P]`` int64: positives of one search log share it)."""
     import ctypes
     from . import _lib
     lib = _lib.load()
     path = os.fsencode(filename)
     n_logs, n_pos, n_neg = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
-    _lib.check(lib.ihg_parse_search_logs(path, ctypes.byref(n_logs), ctypes.byref(n_pos), ctypes.byref(n_neg), None, 0, None, 0),
+    _lib.check(lib.ihg_parse_search_logs(path, ctypes.byref(n_logs), ctypes.byref(n_pos), ctypes.byref(n_neg), None, 0, None, 0, None),
                'ihg_parse_search_logs')
     pos = np.empty((max(n_pos.value, 1), 3), np.int64)
     neg = np.empty((max(n_neg.value, 1), 3), np.int64)
+    rows = np.empty(max(n_pos.value, 1), np.int64)
     as_ptr = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
     _lib.check(lib.ihg_parse_search_logs(path, ctypes.byref(n_logs), ctypes.byref(n_pos), ctypes.byref(n_neg),
-                                         as_ptr(pos), n_pos.value, as_ptr(neg), n_neg.value), 'ihg_parse_search_logs')
-    return int(n_logs.value), pos[:n_pos.value], neg[:n_neg.value]
+                                         as_ptr(pos), n_pos.value, as_ptr(neg), n_neg.value, as_ptr(rows)), 'ihg_parse_search_logs')
+    out = (int(n_logs.value), pos[:n_pos.value], neg[:n_neg.value])
+    return out + (rows[:n_pos.value],) if with_rows else out
+
+
+def read_graph_info(filename: str) -> List[int]:
+    """``graph_info.txt`` -> ``[users, queries, items, vocabulary]`` (native reader; ``Dataset.py:143-147`` of the reference)."""
+    import ctypes
+    from . import _lib
+    counts = (ctypes.c_int64 * 4)()
+    _lib.check(_lib.load().ihg_read_graph_info(os.fsencode(filename), counts), 'ihg_read_graph_info')
+    return [int(c) for c in counts]
+
+
+def read_query_bags(filename: str) -> Tuple[np.ndarray, np.ndarray]:
+    """``queries_multihot.txt`` -> (flat 0-based word ids, start offset of every query) (native two-pass reader;
+    ``Dataset.py:165-176`` of the reference)."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    path = os.fsencode(filename)
+    n_q, n_w = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.ihg_read_query_bags(path, ctypes.byref(n_q), ctypes.byref(n_w), None, 0, None, 0), 'ihg_read_query_bags')
+    offsets = np.empty(max(n_q.value, 1), np.int64)
+    words = np.empty(max(n_w.value, 1), np.int64)
+    as_ptr = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    _lib.check(lib.ihg_read_query_bags(path, ctypes.byref(n_q), ctypes.byref(n_w), as_ptr(offsets), n_q.value, as_ptr(words), n_w.value),
+               'ihg_read_query_bags')
+    return words[:n_w.value], offsets[:n_q.value]
 
 
 class GraphDataset(Dataset):
@@ -47,21 +76,12 @@ class GraphDataset(Dataset):
     def __init__(self, fn_graph_info: str, fn_queries_multihot: str, fn_train_data: str, graph_type: type,
                  random_negative_sample_size: int, non_random_negative_sample_size: int, device: torch.device):
         super().__init__()
-        with open(fn_graph_info, 'r', encoding='utf-8') as f:
-            counts = [int(tok) for tok in f.readline().split()]
-        if len(counts) != 4:
-            raise ValueError(f'{fn_graph_info}: expected "users queries items vocabulary", got {counts}')
-
-        bag_words: List[int] = []
-        bag_offsets: List[int] = []
-        with open(fn_queries_multihot, 'r', encoding='utf-8') as f:
-            for line in f:
-                bag_offsets.append(len(bag_words))
-                bag_words.extend(int(tok) for tok in line.split())
-
-        n_logs, triples, negatives = parse_search_logs(fn_train_data)
-        self._setup(counts, np.asarray(bag_words, np.int64), np.asarray(bag_offsets, np.int64), triples, graph_type,
+        counts = read_graph_info(fn_graph_info)                      # the three input files go through the native readers
+        bag_words, bag_offsets = read_query_bags(fn_queries_multihot)
+        n_logs, triples, negatives, rows = parse_search_logs(fn_train_data, with_rows=True)
+        self._setup(counts, bag_words, bag_offsets, triples, graph_type,
                     random_negative_sample_size, non_random_negative_sample_size, device)
+        self.pos_log = rows
         self._fn_train_data = fn_train_data
         self._search_logs = None
         self._neg_triples = negatives
@@ -78,13 +98,17 @@ class GraphDataset(Dataset):
     def from_arrays(cls, user_count: int, query_count: int, item_count: int, vocab_size: int,
                     bag_words: np.ndarray, bag_offsets: np.ndarray, triples: np.ndarray,
                     graph_type: type = PpsHyperGraph, random_negative_sample_size: int = 10,
-                    non_random_negative_sample_size: int = 0, device: torch.device = torch.device('cuda:0')) -> 'GraphDataset':
-        """In-memory construction (synthetic corpora): ``bag_words`` are 0-based word ids, ``triples`` 0-based per type."""
+                    non_random_negative_sample_size: int = 0, device: torch.device = torch.device('cuda:0'),
+                    pos_log: Optional[np.ndarray] = None) -> 'GraphDataset':
+        """In-memory construction (synthetic corpora): ``bag_words`` are 0-based word ids, ``triples`` 0-based per type;
+        ``pos_log[e]`` = the search log hyperedge ``e`` came from (default: one log per positive)."""
         self = cls.__new__(cls)
         Dataset.__init__(self)
         self._setup([user_count, query_count, item_count, vocab_size], np.asarray(bag_words, np.int64),
                     np.asarray(bag_offsets, np.int64), np.asarray(triples, np.int64).reshape(-1, 3), graph_type,
                     random_negative_sample_size, non_random_negative_sample_size, device)
+        if pos_log is not None:
+            self.pos_log = np.ascontiguousarray(pos_log, dtype=np.int64)
         self._fn_train_data = None
         self._search_logs = None
         self._neg_triples = np.zeros((0, 3), np.int64)
@@ -94,7 +118,7 @@ class GraphDataset(Dataset):
 
     def _setup(self, counts: Sequence[int], bag_words: np.ndarray, bag_offsets: np.ndarray, triples: np.ndarray,
                graph_type: type, rand_neg: int, nonrand_neg: int, device: torch.device) -> None:
-        if graph_type not in (Pps2DGraph, PpsHyperGraph):
+        if graph_type not in (Pps2DGraph, PpsHyperGraph, PpsLogHyperGraph):
             raise AssertionError(f'unsupported graph type: {graph_type}')
         GraphDataset.device = device
         self.graph_type = graph_type
@@ -121,6 +145,8 @@ class GraphDataset(Dataset):
         self.pos_triples = np.ascontiguousarray(triples)
         self._pos_interactions: Optional[List[PosInteraction]] = None
         self._hgraph: Optional[PpsHyperGraph] = None
+        self._hloggraph: Optional[PpsLogHyperGraph] = None
+        self.pos_log = np.arange(self.pos_triples.shape[0], dtype=np.int64)      # search log (file row) of every positive; from_arrays: one each
         self._graph2d = None
         self._bag_layout = None
         self._queries_multihot = None
@@ -195,8 +221,18 @@ class GraphDataset(Dataset):
         return self._graph2d
 
     @property
+    def hypergraph_log(self) -> PpsLogHyperGraph:
+        """One variable-arity hyperedge per search log with a positive (``Dataset.py:98-103``, ``Graph.py:138-189``)."""
+        if self._hloggraph is None:
+            self._hloggraph = PpsLogHyperGraph.from_positives(self.pos_triples, self.pos_log, self.node_count, self.user_count,
+                                                              self.query_count, GraphDataset.device)
+        return self._hloggraph
+
+    @property
     def graph(self) -> PpsGraph:
-        return self.graph2d if self.graph_type == Pps2DGraph else self.hypergraph
+        if self.graph_type == Pps2DGraph:
+            return self.graph2d
+        return self.hypergraph_log if self.graph_type == PpsLogHyperGraph else self.hypergraph
 
     # -- sampling ------------------------------------------------------------------------------------
     def __len__(self) -> int:

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 from torch import Tensor
 
-from ..layout import IncidenceLayout
+from ..layout import IncidenceLayout, LogHyperLayout
 
 
 class PpsGraph:
@@ -75,6 +75,59 @@ class PpsHyperGraph(PpsGraph):
             adj = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.ones(3 * self.EdgeCount, dtype=torch.float32),
                                           (self.layout.node_count, self.EdgeCount)).coalesce()
             self._adjacency = adj.to(self.layout.device)
+        return self._adjacency
+
+
+class PpsLogHyperGraph(PpsGraph):
+    """One hyperedge of VARIABLE arity per search log with at least one positive: members = user, query and every positive item
+    of the log (``Graph.py:138-189``).  Kernel layout in ``layout`` (edge-major and node-major CSR with values, from the native
+    ``ihg_build_log_hypergraph``); ``Adjacency`` / ``VertexDegrees`` / ``EdgeDegrees`` are the reference-shaped views.  Only
+    ``HGCNLayer`` runs on it (it has no ``I3``, which ``IHGNNLayer`` needs - as in the reference)."""
+
+    def __init__(self):
+        self.layout: Optional[LogHyperLayout] = None
+        self.EdgeCount = 0
+        self._adjacency = None
+
+    @classmethod
+    def from_positives(cls, triples: np.ndarray, pos_log: np.ndarray, node_count: int, user_count: int, query_count: int,
+                       device: torch.device) -> 'PpsLogHyperGraph':
+        """``triples [P,3]`` 0-based (user, query, item) positives in file order, ``pos_log [P]`` their search-log row."""
+        g = cls()
+        g.layout = LogHyperLayout(triples, pos_log, user_count, query_count, node_count - user_count - query_count, device)
+        g.EdgeCount = g.layout.edge_count
+        return g
+
+    @classmethod
+    def from_search_logs(cls, logs: Iterable, node_count: int, user_count: int, query_count: int, device: torch.device) -> 'PpsLogHyperGraph':
+        """Reference entry point (``Graph.py:149-155``): ``logs`` yield objects with ``user``, ``query``, ``items``, ``interactions``."""
+        rows, owner = [], []
+        for k, log in enumerate(logs):
+            for item, flag in zip(log.items, log.interactions):
+                if flag > 0:
+                    rows.append((log.user, log.query, item))
+                    owner.append(k)
+        return cls.from_positives(np.asarray(rows, dtype=np.int64).reshape(-1, 3), np.asarray(owner, dtype=np.int64), node_count,
+                                  user_count, query_count, device)
+
+    @property
+    def VertexDegrees(self) -> Tensor:
+        return self.layout.degree.view(-1, 1)
+
+    @property
+    def EdgeDegrees(self) -> Tensor:
+        return self.layout.edge_degree.view(-1, 1)
+
+    @property
+    def Adjacency(self) -> Tensor:
+        """Coalesced ``[N x E]`` sparse COO incidence (``Graph.py:178-184``; a repeated item of a log has value 2)."""
+        if self._adjacency is None:
+            csr = self.layout.node_csr
+            lens = np.diff(csr.ptr_host.astype(np.int64))
+            rows = torch.from_numpy(np.repeat(np.arange(csr.n_rows, dtype=np.int64), lens))
+            cols = torch.from_numpy(csr.ids_host.astype(np.int64))
+            self._adjacency = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.from_numpy(self.layout.node_values_host),
+                                                      (self.layout.node_count, self.EdgeCount)).coalesce().to(self.layout.device)
         return self._adjacency
 
 

@@ -30,15 +30,25 @@ class HGCNLayer(nn.Module):
         super().__init__()
         self.device = device
         self.dataset = dataset
-        self.layout = dataset.hypergraph.layout
-        self.edge_scale = float(torch.tensor(3.0).pow(-1))      # De^-1 of a 3-uniform hypergraph, as fp32
-        self.out_scale = self.layout.inv_sqrt_deg * self.edge_scale
+        from ..layout import LogHyperLayout
+        graph = dataset.graph if getattr(dataset, 'graph_type', None) is not None else dataset.hypergraph      # GnnLayers.py:131
+        self.layout = graph.layout
+        self.general = isinstance(self.layout, LogHyperLayout)  # per-search-log hyperedges of variable arity (PpsLogHyperGraph)
+        if not self.general:
+            self.edge_scale = float(torch.tensor(3.0).pow(-1))      # De^-1 of a 3-uniform hypergraph, as fp32
+            self.out_scale = self.layout.inv_sqrt_deg * self.edge_scale
         self.feature_transform = nn.Linear(input_dimension, output_dimension)
 
     def forward(self, input_features: Tensor, output_rows: Optional[Tensor] = None) -> Tensor:
         """``output_rows`` (int32 node rows, not in the reference signature): the caller reads only these rows of the result
         (last layer of a training step); other rows may be left unwritten."""
         lay = self.layout
+        if self.general:
+            # general incidence: node -> hyperedge (x Dv^-1/2 in, De^-1 out), hyperedge -> node (x Dv^-1/2 out): two K7 launches
+            h = self.feature_transform(input_features) if not ops.node_linear_supported(input_features, self.feature_transform.weight) \
+                else ops.node_linear(input_features, self.feature_transform.weight, self.feature_transform.bias, lay)
+            edge_features = ops.hyper_node_to_edge(h, lay, src_scale=lay.inv_sqrt_deg, out_scale=lay.inv_edge_degree)
+            return ops.hyper_edge_to_node(edge_features, lay, out_scale=lay.inv_sqrt_deg)
         h = _transform(self.feature_transform, input_features, lay)
         # node -> hyperedge -> node in one two-hop pass over the node table: Dv^-1/2 on the way in, Dv^-1/2 De^-1 on the way out
         return ops.node_two_hop(h, lay, in_scale=lay.inv_sqrt_deg, out_scale=self.out_scale, rows=output_rows)

@@ -33,7 +33,11 @@ SIGNATURES = {
     'ihg_abi_version': (c_int32, []),
     'ihg_last_error_string': (c_char_p, []),
     'ihg_build_csr': (ctypes.c_int, [_i64p, c_int64, c_int64, c_int64, c_int64, _i32p, _i32p, _i32p, _f32p]),
-    'ihg_parse_search_logs': (ctypes.c_int, [c_char_p, _i64p, _i64p, _i64p, _i64p, c_int64, _i64p, c_int64]),
+    'ihg_parse_search_logs': (ctypes.c_int, [c_char_p, _i64p, _i64p, _i64p, _i64p, c_int64, _i64p, c_int64, _i64p]),
+    'ihg_read_graph_info': (ctypes.c_int, [c_char_p, _i64p]),
+    'ihg_read_query_bags': (ctypes.c_int, [c_char_p, _i64p, _i64p, _i64p, c_int64, _i64p, c_int64]),
+    'ihg_build_log_hypergraph': (ctypes.c_int, [_i64p, _i64p, c_int64, c_int64, c_int64, c_int64, _i32p, _i32p, _f32p, _f32p, _i32p, _i32p, _f32p, _f32p,
+                                                _i64p, _i64p]),
     'ihg_build_pair_csr': (ctypes.c_int, [_i64p, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32, _i32p, _i32p, _f32p, _f32p,
                                           c_int64, _i64p]),
     'ihg_transpose_csr': (ctypes.c_int, [_i32p, _i32p, c_int64, c_int64, _i32p, _i32p]),

@@ -124,7 +124,7 @@ int ihg_build_pair_csr(const int64_t* triples, int64_t n_edges, int64_t n_users,
 // ------------------------------------------------------------------------------------------------
 
 int ihg_parse_search_logs(const char* path, int64_t* n_logs, int64_t* n_pos, int64_t* n_neg, int64_t* pos, int64_t pos_capacity,
-                          int64_t* neg, int64_t neg_capacity) {
+                          int64_t* neg, int64_t neg_capacity, int64_t* pos_log) {
     if (path == nullptr || n_logs == nullptr || n_pos == nullptr || n_neg == nullptr) return fail(IHG_ERR_INVALID, "ihg_parse_search_logs: null argument");
     FILE* f = std::fopen(path, "rb");
     if (f == nullptr) return fail(IHG_ERR_INVALID, "ihg_parse_search_logs: cannot open %s", path);
@@ -172,6 +172,7 @@ int ihg_parse_search_logs(const char* path, int64_t* n_logs, int64_t* n_pos, int
                     if (pos != nullptr) {
                         if (pcount >= pos_capacity) return fail(IHG_ERR_WORKSPACE, "ihg_parse_search_logs: positive buffer too small");
                         pos[pcount * 3] = user; pos[pcount * 3 + 1] = query; pos[pcount * 3 + 2] = items[k];
+                        if (pos_log != nullptr) pos_log[pcount] = logs;
                     }
                     ++pcount;
                 } else {
@@ -189,6 +190,137 @@ int ihg_parse_search_logs(const char* path, int64_t* n_logs, int64_t* n_pos, int
     *n_logs = logs;
     *n_pos = pcount;
     *n_neg = ncount;
+    return IHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HOST: the two small text files of a corpus.
+// ------------------------------------------------------------------------------------------------
+namespace {
+bool slurp(const char* path, std::vector<char>& text) {
+    FILE* f = std::fopen(path, "rb");
+    if (f == nullptr) return false;
+    std::fseek(f, 0, SEEK_END);
+    const long size = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    text.resize(static_cast<size_t>(size > 0 ? size : 0) + 1);
+    const size_t got = size > 0 ? std::fread(text.data(), 1, static_cast<size_t>(size), f) : 0;
+    std::fclose(f);
+    text[got] = '\n';
+    text.resize(got + 1);
+    return true;
+}
+}  // namespace
+
+int ihg_read_graph_info(const char* path, int64_t* counts) {
+    if (path == nullptr || counts == nullptr) return fail(IHG_ERR_INVALID, "ihg_read_graph_info: null argument");
+    std::vector<char> text;
+    if (!slurp(path, text)) return fail(IHG_ERR_INVALID, "ihg_read_graph_info: cannot open %s", path);
+    const char* p = text.data();
+    const char* eol = p;
+    while (*eol != '\n') ++eol;
+    std::vector<int64_t> v;
+    if (!parse_int_list(p, eol, v) || v.size() != 4)
+        return fail(IHG_ERR_INVALID, "ihg_read_graph_info: %s: expected \"users queries items vocabulary\" on the first line", path);
+    for (int k = 0; k < 4; ++k) {
+        if (v[k] < 0) return fail(IHG_ERR_INVALID, "ihg_read_graph_info: %s: negative count", path);
+        counts[k] = v[k];
+    }
+    return IHG_OK;
+}
+
+int ihg_read_query_bags(const char* path, int64_t* n_queries, int64_t* n_words, int64_t* offsets, int64_t offsets_capacity, int64_t* words,
+                        int64_t words_capacity) {
+    if (path == nullptr || n_queries == nullptr || n_words == nullptr) return fail(IHG_ERR_INVALID, "ihg_read_query_bags: null argument");
+    std::vector<char> text;
+    if (!slurp(path, text)) return fail(IHG_ERR_INVALID, "ihg_read_query_bags: cannot open %s", path);
+    const char* p = text.data();
+    const char* const end = p + text.size();
+    if (text.size() >= 2 && text[text.size() - 2] == '\n') {}         // file ends with a newline: the sentinel added by slurp is an empty tail
+    int64_t q = 0, w = 0;
+    std::vector<int64_t> line;
+    while (p < end) {
+        const char* eol = p;
+        while (eol < end && *eol != '\n') ++eol;
+        if (eol + 1 >= end && eol == p) break;                         // the empty tail behind the last newline is not a query
+        if (!parse_int_list(p, eol, line)) return fail(IHG_ERR_INVALID, "ihg_read_query_bags: %s line %lld: bad word id", path, (long long)(q + 1));
+        if (offsets != nullptr) {
+            if (q >= offsets_capacity) return fail(IHG_ERR_WORKSPACE, "ihg_read_query_bags: offsets buffer too small");
+            offsets[q] = w;
+        }
+        if (words != nullptr) {
+            if (w + static_cast<int64_t>(line.size()) > words_capacity) return fail(IHG_ERR_WORKSPACE, "ihg_read_query_bags: words buffer too small");
+            for (size_t k = 0; k < line.size(); ++k) words[w + static_cast<int64_t>(k)] = line[k];
+        }
+        w += static_cast<int64_t>(line.size());
+        ++q;
+        p = eol + 1;
+    }
+    *n_queries = q;
+    *n_words = w;
+    return IHG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HOST: per-search-log hypergraph (variable arity).
+// ------------------------------------------------------------------------------------------------
+int ihg_build_log_hypergraph(const int64_t* pos, const int64_t* pos_log, int64_t n_pos, int64_t n_users, int64_t n_queries, int64_t n_items,
+                             int32_t* edge_ptr, int32_t* edge_nodes, float* edge_vals, float* edge_degree, int32_t* node_ptr,
+                             int32_t* node_edges, float* node_vals, float* node_degree, int64_t* n_edges_out, int64_t* nnz_out) {
+    if (n_pos < 0 || n_users < 0 || n_queries < 0 || n_items < 0) return fail(IHG_ERR_INVALID, "ihg_build_log_hypergraph: negative size");
+    const int64_t n_nodes = n_users + n_queries + n_items;
+    if (n_nodes >= INT32_MAX || n_pos * 3 >= INT32_MAX) return fail(IHG_ERR_INVALID, "ihg_build_log_hypergraph: graph exceeds int32 indexing");
+    if (edge_ptr == nullptr || node_ptr == nullptr || node_degree == nullptr || n_edges_out == nullptr || nnz_out == nullptr ||
+        (n_pos > 0 && (pos == nullptr || pos_log == nullptr || edge_nodes == nullptr || edge_vals == nullptr || edge_degree == nullptr ||
+                       node_edges == nullptr || node_vals == nullptr)))
+        return fail(IHG_ERR_INVALID, "ihg_build_log_hypergraph: null buffer");
+    int64_t n_edges = 0, nnz = 0;
+    edge_ptr[0] = 0;
+    std::vector<int32_t> members;
+    std::memset(node_ptr, 0, sizeof(int32_t) * static_cast<size_t>(n_nodes + 1));
+    for (int64_t k = 0; k < n_pos;) {
+        int64_t j = k;
+        while (j < n_pos && pos_log[j] == pos_log[k]) ++j;             // positives of one search log are consecutive
+        const int64_t u = pos[k * 3], q = pos[k * 3 + 1];
+        if (u < 0 || u >= n_users || q < 0 || q >= n_queries)
+            return fail(IHG_ERR_INVALID, "ihg_build_log_hypergraph: log %lld: user / query id out of range", (long long)pos_log[k]);
+        members.clear();
+        for (int64_t t = k; t < j; ++t) {
+            const int64_t item = pos[t * 3 + 2];
+            if (pos[t * 3] != u || pos[t * 3 + 1] != q) return fail(IHG_ERR_INVALID, "ihg_build_log_hypergraph: log %lld changes its user / query", (long long)pos_log[k]);
+            if (item < 0 || item >= n_items) return fail(IHG_ERR_INVALID, "ihg_build_log_hypergraph: log %lld: item id out of range", (long long)pos_log[k]);
+            members.push_back(static_cast<int32_t>(item + n_users + n_queries));
+        }
+        std::sort(members.begin(), members.end());
+        // edge = [u, q + U, items ...] (Graph.py:160-162); a repeated item is one entry of value 2 after coalesce() (Graph.py:178-184)
+        edge_nodes[nnz] = static_cast<int32_t>(u); edge_vals[nnz++] = 1.f;
+        edge_nodes[nnz] = static_cast<int32_t>(q + n_users); edge_vals[nnz++] = 1.f;
+        for (size_t t = 0; t < members.size();) {
+            size_t r = t;
+            while (r < members.size() && members[r] == members[t]) ++r;
+            edge_nodes[nnz] = members[t];
+            edge_vals[nnz++] = static_cast<float>(r - t);
+            t = r;
+        }
+        edge_degree[n_edges] = static_cast<float>(2 + members.size());     // len(nodes), repeats counted (Graph.py:167)
+        for (int64_t t = edge_ptr[n_edges]; t < nnz; ++t) ++node_ptr[edge_nodes[t] + 1];
+        edge_ptr[++n_edges] = static_cast<int32_t>(nnz);
+        k = j;
+    }
+    for (int64_t v = 0; v < n_nodes; ++v) {
+        const int32_t d = node_ptr[v + 1];                             // vertex_degrees[nodes] += 1: once per edge the node is in (Graph.py:166)
+        node_degree[v] = d == 0 ? 1e-8f : static_cast<float>(d);
+        node_ptr[v + 1] = node_ptr[v] + d;
+    }
+    std::vector<int32_t> cursor(node_ptr, node_ptr + n_nodes);
+    for (int64_t e = 0; e < n_edges; ++e)
+        for (int32_t t = edge_ptr[e]; t < edge_ptr[e + 1]; ++t) {
+            const int32_t slot = cursor[edge_nodes[t]]++;
+            node_edges[slot] = static_cast<int32_t>(e);
+            node_vals[slot] = edge_vals[t];
+        }
+    *n_edges_out = n_edges;
+    *nnz_out = nnz;
     return IHG_OK;
 }
 

@@ -219,6 +219,56 @@ class IncidenceLayout:
         return cache[n_chunks]
 
 
+class LogHyperLayout:
+    """General hypergraph incidence in kernel layout: hyperedges of any arity, both orientations as CSR with per-entry values
+    (edge-major: hyperedge -> member nodes, the node->hyperedge gather; node-major: node -> incident hyperedges, the
+    hyperedge->node gather).  Both run on the K7 segment-sum kernel, whose split-row plan and length-sorted row order are the
+    degree-bucketed treatment of the long member / incidence lists.  Built by the native ``ihg_build_log_hypergraph``."""
+
+    def __init__(self, triples: np.ndarray, pos_log: np.ndarray, user_count: int, query_count: int, item_count: int, device: torch.device,
+                 heavy_threshold: int = HEAVY_THRESHOLD):
+        lib = _lib.load()
+        triples = np.ascontiguousarray(np.asarray(triples, dtype=np.int64).reshape(-1, 3))
+        pos_log = np.ascontiguousarray(np.asarray(pos_log, dtype=np.int64).reshape(-1))
+        if pos_log.shape[0] != triples.shape[0]:
+            raise ValueError('one search-log row per positive is required')
+        p = int(triples.shape[0])
+        self.user_count, self.query_count, self.item_count = int(user_count), int(query_count), int(item_count)
+        self.node_count = n = self.user_count + self.query_count + self.item_count
+        self.device = device
+        edge_ptr = np.empty(p + 1, np.int32)
+        edge_nodes = np.empty(max(3 * p, 1), np.int32)
+        edge_vals = np.empty(max(3 * p, 1), np.float32)
+        edge_degree = np.empty(max(p, 1), np.float32)
+        node_ptr = np.empty(n + 1, np.int32)
+        node_edges = np.empty(max(3 * p, 1), np.int32)
+        node_vals = np.empty(max(3 * p, 1), np.float32)
+        node_degree = np.empty(max(n, 1), np.float32)
+        n_edges, nnz = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(lib.ihg_build_log_hypergraph(_as_ptr(triples, ctypes.c_int64), _as_ptr(pos_log, ctypes.c_int64), p, self.user_count,
+                                                self.query_count, self.item_count, _as_ptr(edge_ptr, ctypes.c_int32),
+                                                _as_ptr(edge_nodes, ctypes.c_int32), _as_ptr(edge_vals, ctypes.c_float),
+                                                _as_ptr(edge_degree, ctypes.c_float), _as_ptr(node_ptr, ctypes.c_int32),
+                                                _as_ptr(node_edges, ctypes.c_int32), _as_ptr(node_vals, ctypes.c_float),
+                                                _as_ptr(node_degree, ctypes.c_float), ctypes.byref(n_edges), ctypes.byref(nnz)),
+                   'ihg_build_log_hypergraph')
+        e, k = int(n_edges.value), int(nnz.value)
+        self.edge_count, self.nnz = e, k
+        self.edge_csr = Csr(edge_ptr[:e + 1], edge_nodes[:k], device, heavy_threshold)          # rows = hyperedges, ids = member nodes
+        self.node_csr = Csr(node_ptr, node_edges[:k], device, heavy_threshold)                    # rows = nodes, ids = hyperedges
+        self.edge_values_host, self.node_values_host = edge_vals[:k].copy(), node_vals[:k].copy()
+        unit = bool((self.edge_values_host == 1.0).all())
+        self.edge_values = None if unit else torch.from_numpy(self.edge_values_host).to(device)   # unit incidence: no value stream
+        self.node_values = None if unit else torch.from_numpy(self.node_values_host).to(device)
+        deg = torch.from_numpy(node_degree[:n].copy())
+        self.degree = deg.to(device)
+        isolated = deg < 0.5
+        self.inv_sqrt_deg = torch.where(isolated, torch.zeros_like(deg), deg.pow(-0.5)).to(device)       # GnnLayers.py:133
+        edeg = torch.from_numpy(edge_degree[:e].copy())
+        self.edge_degree = edeg.to(device)
+        self.inv_edge_degree = edeg.pow(-1).to(device)                                                    # GnnLayers.py:134
+
+
 COMPLETENESS = {'uqi': 0, 'uq': 1, 'ui': 2, 'qi': 3}
 
 

@@ -193,6 +193,35 @@ class _PairSpmm(torch.autograd.Function):
         return node_segment_sum_raw(grad_out, g.csr, g.inv_sqrt_deg, g.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=g.values, role='k7.pair_graph'), None
 
 
+class _CsrSpmm(torch.autograd.Function):
+    """``out = Do (A (Ds x))`` for a sparse ``A`` given as CSR over its rows together with the CSR of its transpose: the backward
+    is the same launch over the transpose with the two scalings swapped."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, csr, csr_t, values, values_t, src_scale, out_scale, role: str) -> Tensor:
+        ctx.args = (csr, csr_t, values, values_t, src_scale, out_scale, role)
+        mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
+        return node_segment_sum_raw(x, csr, src_scale, out_scale, mode, entry_scale=values, role=role)
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        csr, csr_t, values, values_t, src_scale, out_scale, role = ctx.args
+        mode = _lib.SCALE_NONE if src_scale is None else _lib.SCALE_MULTIPLY
+        return (node_segment_sum_raw(grad_out, csr_t, out_scale, src_scale, mode, entry_scale=values_t, role=role + '_bwd'),) + (None,) * 7
+
+
+def hyper_node_to_edge(x: Tensor, layout, src_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None) -> Tensor:
+    """node -> hyperedge over a general (variable-arity) incidence: ``out[e] = out_scale[e] * sum_{v in e} val(v,e) src_scale[v] x[v]``
+    (``thsp.matmul(incidence_t, .)``, ``GnnLayers.py:148``) - ``layout`` is a :class:`ihgnn_amd.layout.LogHyperLayout`."""
+    return _CsrSpmm.apply(x, layout.edge_csr, layout.node_csr, layout.edge_values, layout.node_values, src_scale, out_scale, 'k7.hyper_node_to_edge')
+
+
+def hyper_edge_to_node(x: Tensor, layout, src_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None) -> Tensor:
+    """hyperedge -> node over a general incidence: ``out[v] = out_scale[v] * sum_{e containing v} val(v,e) src_scale[e] x[e]``
+    (``thsp.matmul(incidence, .)``, ``GnnLayers.py:151``)."""
+    return _CsrSpmm.apply(x, layout.node_csr, layout.edge_csr, layout.node_values, layout.edge_values, src_scale, out_scale, 'k7.hyper_edge_to_node')
+
+
 def pair_spmm(x: Tensor, graph) -> Tensor:
     """GCN propagation ``D^-1/2 A D^-1/2 x`` over a :class:`ihgnn_amd.layout.PairLayout` (``GnnLayers.py:35-38``)."""
     return _PairSpmm.apply(x, graph)

@@ -64,9 +64,35 @@ int ihg_build_csr(const int64_t* triples, int64_t n_edges,
  * interactions,times` whose list fields are space-separated; item k of a row is a positive interaction when
  * interactions[k] > 0.  Pass pos == neg == NULL to count (n_logs / n_pos / n_neg), then call again with buffers of
  * [n_pos,3] / [n_neg,3] int64 to receive the (user, query, item) triples in file order.  neg may stay NULL.
+ * pos_log (may be NULL; [n_pos] int64): the 0-based row of each positive - rows with several positives are the
+ * variable-arity hyperedges of ihg_build_log_hypergraph.
  */
 int ihg_parse_search_logs(const char* path, int64_t* n_logs, int64_t* n_pos, int64_t* n_neg,
-                          int64_t* pos, int64_t pos_capacity, int64_t* neg, int64_t neg_capacity);
+                          int64_t* pos, int64_t pos_capacity, int64_t* neg, int64_t neg_capacity, int64_t* pos_log);
+
+/* HOST: `graph_info.txt` (one line "users queries items vocabulary", Dataset.py:143-147) -> counts[4]. */
+int ihg_read_graph_info(const char* path, int64_t* counts);
+
+/* HOST: `queries_multihot.txt` (line r = space-separated 0-based word ids of query r, Dataset.py:165-176; an empty line is a
+ * query without words).  Two-pass like the CSV parser: offsets == words == NULL counts; then offsets[n_queries] = start of each
+ * query's words in words[n_words] (the nn.EmbeddingBag input / offsets of Dataset.py:161-186, before the +1 padding shift).
+ */
+int ihg_read_query_bags(const char* path, int64_t* n_queries, int64_t* n_words, int64_t* offsets, int64_t offsets_capacity,
+                        int64_t* words, int64_t words_capacity);
+
+/* HOST: per-search-log hypergraph.  Replaces PpsLogHyperGraph.from_search_logs (Helpers/Graph.py:138-189): one hyperedge of
+ * VARIABLE arity per search log with >= 1 positive, members [user, query + U, positive items + U + Q].  Input: the positives
+ * and their row numbers as ihg_parse_search_logs returns them (positives of one log consecutive).  Output, caller-sized
+ * (n_edges <= n_pos, nnz <= 3 n_pos): the incidence in BOTH orientations as CSR with values -
+ *   edge_ptr [n_edges+1], edge_nodes / edge_vals [nnz]   edge-major (members ascending; a repeated item is one entry of value 2,
+ *                                                        as coalesce() sums duplicates, Graph.py:178-184)
+ *   node_ptr [N+1], node_edges / node_vals [nnz]         node-major, hyperedge ids ascending (= the coalesced COO order)
+ *   edge_degree [n_edges] = len(members) with repeats (Graph.py:167), node_degree [N] = hyperedges containing the node, 0 -> 1e-8
+ *   (Graph.py:166,171).
+ */
+int ihg_build_log_hypergraph(const int64_t* pos, const int64_t* pos_log, int64_t n_pos, int64_t n_users, int64_t n_queries, int64_t n_items,
+                             int32_t* edge_ptr, int32_t* edge_nodes, float* edge_vals, float* edge_degree, int32_t* node_ptr,
+                             int32_t* node_edges, float* node_vals, float* node_degree, int64_t* n_edges_out, int64_t* nnz_out);
 
 /* HOST: pairwise graph of the GCN baseline.  Replaces Pps2DGraph.from_interactions (Helpers/Graph.py:19-81) and the
  * coalesce() of its adjacency.  completeness: 0 = uqi (u-q, q-i, i-u per interaction), 1 = uq, 2 = ui, 3 = qi

@@ -63,6 +63,34 @@ class HyperGraph:
         return g
 
 
+class LogHyperGraph:
+    """Per-search-log hypergraph as ``PpsLogHyperGraph.from_search_logs`` builds it (Helpers/Graph.py:138-189): one hyperedge per log
+    with >= 1 positive, members [user, query + U, positive items + U + Q]; ``logs`` = iterable of (user, query, items, flags)."""
+
+    def __init__(self, logs, user_count: int, query_count: int, item_count: int):
+        self.user_count, self.query_count, self.item_count = user_count, query_count, item_count
+        self.node_count = n = user_count + query_count + item_count
+        rows, cols, edge_degrees = [], [], []
+        deg = np.zeros(n, dtype=np.float64)
+        edge = 0
+        for u, q, items, flags in logs:
+            nodes = [u, q + user_count] + [i + user_count + query_count for i, f in zip(items, flags) if f > 0]   # Graph.py:160-162
+            if len(nodes) == 2:                                                                                   # :163
+                continue
+            deg[np.array(nodes)] += 1                    # :166  (fancy-index += : once per distinct node)
+            edge_degrees.append(len(nodes))              # :167
+            rows += nodes
+            cols += [edge] * len(nodes)
+            edge += 1
+        deg[deg == 0] = 1e-8                             # :171
+        self.edge_count = edge
+        idx = torch.tensor([rows, cols], dtype=torch.int64) if rows else torch.zeros(2, 0, dtype=torch.int64)
+        self.Adjacency = torch.sparse_coo_tensor(idx, torch.ones(len(rows)), (n, edge)).coalesce()      # :174-181: duplicates summed
+        self.AdjacencyT = self.Adjacency.t().coalesce()
+        self.VertexDegrees = torch.from_numpy(deg).float().view(-1, 1)
+        self.EdgeDegrees = torch.tensor(edge_degrees, dtype=torch.float32).view(-1, 1)
+
+
 class PairGraph:
     """Pairwise graph as ``Pps2DGraph.from_interactions`` builds it (Helpers/Graph.py:19-81), no self connections."""
 

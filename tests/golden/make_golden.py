@@ -54,7 +54,7 @@ sys.path.insert(0, REFERENCE)
 sys.path.insert(1, REPO)
 
 from Dataset import GraphDataset, TestSearchLogDataLoader            # noqa: E402  (reference)
-from Helpers.Graph import PpsHyperGraph, Pps2DGraph                    # noqa: E402  (reference)
+from Helpers.Graph import PpsHyperGraph, Pps2DGraph, PpsLogHyperGraph  # noqa: E402  (reference)
 from Helpers.GlobalSettings import Gs                                  # noqa: E402  (reference)
 from Helpers.Metrics import Metrics, MetricsCollection                 # noqa: E402  (reference)
 from Helpers.ProcessController import ProcessController               # noqa: E402  (reference)
@@ -431,7 +431,66 @@ def make_f8(ds):
     np.savez(os.path.join(HERE, 'f8_wide_models.npz'), **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# F9: per-search-log hypergraph (variable arity): graph tensors, HGCN layer, RawGnn over it
+# ---------------------------------------------------------------------------------------------
+def f9_rows():
+    rng = np.random.default_rng(99)
+    rows = []
+    for r in range(140):
+        n = int(rng.integers(1, 5))
+        items = [int(x) for x in rng.integers(0, 40, n)]
+        flags = [int(x) for x in rng.integers(0, 3, n)]
+        if r == 7:
+            items, flags = [5, 9, 5], [1, 1, 2]          # a repeated positive item inside one log -> incidence value 2
+        if r == 11:
+            flags = [0] * n                               # a log without positives makes no hyperedge
+        rows.append((int(rng.integers(0, 30)), int(rng.integers(0, 12)), items, flags))
+    return rows
+
+
+def make_f9():
+    w = synth.draw(30, 12, 40, 20, 0, seed=9)
+    data_dir = os.path.join(HERE, 'f9_data')
+    paths = synth.write_files(w, data_dir, train_rows=f9_rows())
+    for extra in ('valid_data.csv', 'test_data.csv'):
+        os.remove(os.path.join(data_dir, extra))
+    ds = GraphDataset(paths['fn_graph_info'], paths['fn_queries_multihot'], paths['fn_train_data'], PpsLogHyperGraph, 10, 0, CPU)
+    g = ds.graph
+    out = dict(adj_indices=g.Adjacency.indices().numpy(), adj_values=g.Adjacency.values().numpy(), VertexDegrees=g.VertexDegrees.numpy(),
+               EdgeDegrees=g.EdgeDegrees.numpy(), EdgeCount=np.int64(g.EdgeCount),
+               pos_uqif=np.array([p.uqif() for p in ds.pos_interactions], np.int64), neg_uqi=np.array(ds.neg_interactions, np.int64),
+               bag_input=ds.queries_for_embeddingbag.numpy(), bag_offsets=ds.queries_offset_for_embeddingbag.numpy(),
+               counts=np.array([ds.user_count, ds.query_count, ds.item_count, ds.vocab_size], np.int64))
+    for d in (16, 64):
+        seed_all(900 + d)
+        layer = HGCNLayer(CPU, ds, d, d)
+        x = torch.randn(ds.node_count, d, requires_grad=True)
+        y = layer(x)
+        cot = torch.randn_like(y)
+        y.backward(cot)
+        out.update({f'd{d}.{k}': v for k, v in sd_numpy(layer).items()})
+        out.update({f'd{d}.x': x.detach().numpy(), f'd{d}.y': y.detach().numpy(), f'd{d}.cot': cot.numpy(), f'd{d}.dx': x.grad.numpy()})
+        for name, p in layer.named_parameters():
+            out[f'd{d}.grad.{name}'] = p.grad.numpy().copy()
+    seed_all(909)
+    m = RawGnn(CPU, ds, 16, HGCNLayer, 2, 1, False, HemPredictionLayer, 0.5)
+    out.update({f'model.{k}': v for k, v in sd_numpy(m).items()})
+    u = torch.randint(0, ds.user_count, (64,)); q = torch.randint(0, ds.query_count, (64,)); i = torch.randint(0, ds.item_count, (64,))
+    flags = (torch.rand(64) < 0.3).float()
+    scores = m(u, q, i)
+    loss = torch.nn.BCEWithLogitsLoss()(scores, flags)
+    loss.backward()
+    out.update({f'model.grad.{n}': p.grad.numpy().copy() for n, p in m.named_parameters()})
+    out.update({'model.u': u.numpy(), 'model.q': q.numpy(), 'model.i': i.numpy(), 'model.flags': flags.numpy(),
+                'model.scores': scores.detach().numpy(), 'model.loss': np.float64(loss.item())})
+    np.savez(os.path.join(HERE, 'f9_log_hypergraph.npz'), **out)
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['f9']:
+        make_f9()
+        sys.exit(0)
     if sys.argv[1:] == ['f8']:                       # add the wide-model fixture without rewriting the others
         w = small_workload()
         make_f8(load_dataset(synth.write_files(w, os.path.join('/tmp', 'ihgnn_golden_small'))))
@@ -444,6 +503,7 @@ if __name__ == '__main__':
     make_f6()
     make_f7()
     make_f8(ds_small)
+    make_f9()
     for fn in sorted(os.listdir(HERE)):
         p = os.path.join(HERE, fn)
         if os.path.isfile(p):

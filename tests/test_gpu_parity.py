@@ -846,6 +846,82 @@ def test_f7_gcn_model_matches_reference():
         assert rel(p.grad, z[f'model.grad.{name}']) <= 2e-5, name
 
 
+def f9_dataset():
+    from ihgnn_amd.Dataset import GraphDataset
+    from ihgnn_amd.Helpers.Graph import PpsLogHyperGraph
+    d = os.path.join(GOLDEN, 'f9_data')
+    return GraphDataset(os.path.join(d, 'graph_info.txt'), os.path.join(d, 'queries_multihot.txt'), os.path.join(d, 'train_data.csv'),
+                        PpsLogHyperGraph, 10, 0, dev())
+
+
+@pytest.mark.parametrize('d', [16, 64])
+def test_f9_hgcn_over_search_log_hyperedges_matches_reference(d):
+    """f4: HGCNLayer over the per-search-log hypergraph (variable arity, one repeated member of value 2) against the reference's
+    PpsLogHyperGraph + HGCNLayer (fixture F9): forward, input gradient, parameter gradients."""
+    from ihgnn_amd.Models import HGCNLayer
+    z = np.load(os.path.join(GOLDEN, 'f9_log_hypergraph.npz'))
+    ds = f9_dataset()
+    layer = HGCNLayer(dev(), ds, d, d)
+    pre = f'd{d}.'
+    layer.load_state_dict({k[len(pre) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre + 'sd.')})
+    layer.to(dev())
+    x = torch.from_numpy(z[pre + 'x']).to(dev()).requires_grad_(True)
+    y = layer(x)
+    y.backward(torch.from_numpy(z[pre + 'cot']).to(dev()))
+    assert rel(y, z[pre + 'y']) <= RTOL and rel(x.grad, z[pre + 'dx']) <= RTOL
+    for name, p in layer.named_parameters():
+        assert rel(p.grad, z[pre + 'grad.' + name]) <= RTOL, name
+
+
+def test_f9_model_over_search_log_hyperedges_matches_reference():
+    from ihgnn_amd.Models import HGCNLayer, HemPredictionLayer, RawGnn
+    z = np.load(os.path.join(GOLDEN, 'f9_log_hypergraph.npz'))
+    ds = f9_dataset()
+    m = RawGnn(dev(), ds, 16, HGCNLayer, 2, 1, False, HemPredictionLayer, 0.5).to(dev())
+    m.load_state_dict({k[len('model.sd.'):]: torch.from_numpy(z[k]) for k in z.files if k.startswith('model.sd.')})
+    u, q, i = (torch.from_numpy(z[f'model.{k}']).to(dev()) for k in 'uqi')
+    for fused in (False, True):
+        m.zero_grad()
+        flags = torch.from_numpy(z['model.flags']).to(dev())
+        if fused:
+            loss = m.bce_loss(u, q, i, flags)
+        else:
+            scores = m(u, q, i)
+            assert rel(scores, z['model.scores']) <= RTOL
+            loss = torch.nn.BCEWithLogitsLoss()(scores, flags)
+        loss.backward()
+        assert abs(loss.item() - float(z['model.loss'])) <= 1e-6
+        for name, p in m.named_parameters():
+            assert rel(p.grad, z[f'model.grad.{name}']) <= 2e-5, name
+
+
+def test_general_hypergraph_kernels_at_scale():
+    """Variable-arity incidence at a size the oracle cannot take: power-law log lengths (split rows on both sides); the two
+    orientations are adjoint, <node->edge x, y> = <x, edge->node y>, and on unit incidence edge->node of ones is the degree."""
+    from ihgnn_amd import ops
+    from ihgnn_amd.layout import LogHyperLayout
+    rng = np.random.default_rng(4)
+    U, Q, I, L = 20000, 500, 30000, 120000
+    lens = np.minimum(rng.zipf(1.6, L), 400)
+    owner = np.repeat(np.arange(L), lens)
+    u_of, q_of = rng.integers(0, U, L), rng.integers(0, Q, L)
+    triples = np.stack([u_of[owner], q_of[owner], rng.integers(0, I, owner.shape[0])], 1)
+    lay = LogHyperLayout(triples, owner, U, Q, I, dev())
+    assert lay.edge_csr.n_heavy > 0 and lay.node_csr.n_heavy > 0
+    d = 64
+    x = torch.randn(lay.node_count, d, device=dev())
+    y = torch.randn(lay.edge_count, d, device=dev())
+    ex = ops.hyper_node_to_edge(x, lay, src_scale=lay.inv_sqrt_deg, out_scale=lay.inv_edge_degree)
+    ny = ops.hyper_edge_to_node(y, lay, src_scale=lay.inv_edge_degree, out_scale=lay.inv_sqrt_deg)
+    lhs, rhs = (ex.double() * y.double()).sum(), (x.double() * ny.double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) <= 3e-5
+    vals = lay.node_values if lay.node_values is not None else torch.ones(lay.nnz, device=dev())
+    want = torch.zeros(lay.node_count, device=dev()).index_add_(0, torch.repeat_interleave(
+        torch.arange(lay.node_count, device=dev()), torch.from_numpy(np.diff(lay.node_csr.ptr_host.astype(np.int64))).to(dev())), vals)
+    got = ops.hyper_edge_to_node(torch.ones(lay.edge_count, 4, device=dev()), lay)[:, 0]
+    assert rel(got, want) <= RTOL_SUM
+
+
 @pytest.mark.parametrize('n,width', [(1, 5), (77, 33), (3300, 193), (8192, 64), (16384, 300)])
 def test_batch_scatter_add_matches_index_put(n, width):
     """Deterministic sort-free scatter: equals index_put_(accumulate=True), bitwise repeatable with duplicates; plain-matrix

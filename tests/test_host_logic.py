@@ -278,3 +278,66 @@ def test_native_search_log_parser_matches_python_parser(tmp_path):
         parse_search_logs(str(bad))
     with pytest.raises(IhgnnHipError, match='cannot open'):
         parse_search_logs(str(tmp_path / 'missing.csv'))
+
+
+def test_native_readers_and_parser_match_the_reference_outputs():
+    """f4: the three native readers against what the REFERENCE's own loaders produced from the same files (fixtures F1 and F9:
+    `pos_uqif`, `neg_uqi`, EmbeddingBag input / offsets, counts), not against this repo's Python parser."""
+    from ihgnn_amd.Dataset import parse_search_logs, read_graph_info, read_query_bags
+    for data, fixture in ((F1, 'f1_graph.npz'), (os.path.join(GOLDEN, 'f9_data'), 'f9_log_hypergraph.npz')):
+        z = np.load(os.path.join(GOLDEN, fixture))
+        n_logs, pos, neg, rows = parse_search_logs(os.path.join(data, 'train_data.csv'), with_rows=True)
+        np.testing.assert_array_equal(pos, z['pos_uqif'][:, :3])
+        np.testing.assert_array_equal(neg, z['neg_uqi'])
+        assert rows.shape[0] == pos.shape[0] and (np.diff(rows) >= 0).all() and rows.max() < n_logs
+        assert read_graph_info(os.path.join(data, 'graph_info.txt')) == [int(x) for x in z['counts'][:4]]
+        words, offsets = read_query_bags(os.path.join(data, 'queries_multihot.txt'))
+        np.testing.assert_array_equal(words + 1, z['bag_input'])           # Dataset.py:168: ids shifted past the padding row
+        np.testing.assert_array_equal(offsets, z['bag_offsets'])
+
+
+def test_query_bag_reader_edge_cases(tmp_path):
+    from ihgnn_amd.Dataset import read_graph_info, read_query_bags
+    from ihgnn_amd._lib import IhgnnHipError
+    fn = tmp_path / 'q.txt'
+    fn.write_text('3 1 2\n\n7\n')                                       # a query without words in the middle, newline at the end
+    words, offsets = read_query_bags(str(fn))
+    assert words.tolist() == [3, 1, 2, 7] and offsets.tolist() == [0, 3, 3]
+    fn.write_text('3 1 2\n5')                                             # no trailing newline
+    words, offsets = read_query_bags(str(fn))
+    assert words.tolist() == [3, 1, 2, 5] and offsets.tolist() == [0, 3]
+    fn.write_text('3 x\n')
+    with pytest.raises(IhgnnHipError, match='bad word id'):
+        read_query_bags(str(fn))
+    info = tmp_path / 'g.txt'
+    info.write_text('5 4 6\n')
+    with pytest.raises(IhgnnHipError, match='users queries items vocabulary'):
+        read_graph_info(str(info))
+
+
+def test_log_hypergraph_matches_reference():
+    """f4: the native per-search-log hypergraph builder against the reference's PpsLogHyperGraph tensors (fixture F9), bit for bit:
+    coalesced incidence (one entry of value 2 for the repeated item), vertex degrees, edge degrees = arity."""
+    from ihgnn_amd.Dataset import GraphDataset
+    from ihgnn_amd.Helpers.Graph import PpsLogHyperGraph
+    z = np.load(os.path.join(GOLDEN, 'f9_log_hypergraph.npz'))
+    d = os.path.join(GOLDEN, 'f9_data')
+    ds = GraphDataset(os.path.join(d, 'graph_info.txt'), os.path.join(d, 'queries_multihot.txt'), os.path.join(d, 'train_data.csv'),
+                      PpsLogHyperGraph, 10, 0, CPU)
+    g = ds.graph
+    assert isinstance(g, PpsLogHyperGraph) and g.EdgeCount == int(z['EdgeCount'])
+    np.testing.assert_array_equal(g.Adjacency.indices().numpy(), z['adj_indices'])
+    np.testing.assert_array_equal(g.Adjacency.values().numpy(), z['adj_values'])
+    np.testing.assert_array_equal(g.VertexDegrees.numpy(), z['VertexDegrees'])
+    np.testing.assert_array_equal(g.EdgeDegrees.numpy(), z['EdgeDegrees'])
+    lay = g.layout
+    assert lay.edge_values is not None and float(lay.edge_values_host.max()) == 2.0
+    # the two orientations describe the same matrix
+    e_rows = np.repeat(np.arange(lay.edge_count), np.diff(lay.edge_csr.ptr_host))
+    a = sorted(zip(lay.edge_csr.ids_host.tolist(), e_rows.tolist(), lay.edge_values_host.tolist()))
+    n_rows = np.repeat(np.arange(lay.node_count), np.diff(lay.node_csr.ptr_host))
+    b = sorted(zip(n_rows.tolist(), lay.node_csr.ids_host.tolist(), lay.node_values_host.tolist()))
+    assert a == b
+    # the entry point the reference's dataset calls
+    g2 = PpsLogHyperGraph.from_search_logs(ds.search_logs, ds.node_count, ds.user_count, ds.query_count, CPU)
+    np.testing.assert_array_equal(g2.Adjacency.indices().numpy(), z['adj_indices'])

@@ -137,6 +137,48 @@ def test_f8_wide_models(tag):
         assert rel_err(m.propagate().numpy(), z[f'{tag}.features']) <= RTOL
 
 
+def f9_logs():
+    """The rows of tests/golden/f9_data/train_data.csv as (user, query, items, flags) - parsed here in a few lines of Python so that
+    the oracle test depends on nothing under ihgnn_amd."""
+    rows = []
+    with open(os.path.join(GOLDEN, 'f9_data', 'train_data.csv')) as f:
+        next(f)
+        for line in f:
+            c = line.rstrip('\n').split(',')
+            rows.append((int(c[0]), int(c[1]), [int(x) for x in c[3].split()], [int(x) for x in c[6].split()]))
+    return rows
+
+
+def test_f9_log_hypergraph_and_hgcn():
+    """Variable-arity hyperedges (one per search log): graph tensors, HGCN layer forward / backward, RawGnn over it."""
+    z = np.load(os.path.join(GOLDEN, 'f9_log_hypergraph.npz'))
+    U, Q, I, V = (int(x) for x in z['counts'])
+    g = ref.LogHyperGraph(f9_logs(), U, Q, I)
+    assert g.edge_count == int(z['EdgeCount'])
+    np.testing.assert_array_equal(g.Adjacency.indices().numpy(), z['adj_indices'])
+    np.testing.assert_array_equal(g.Adjacency.values().numpy(), z['adj_values'])
+    np.testing.assert_array_equal(g.VertexDegrees.numpy(), z['VertexDegrees'])
+    np.testing.assert_array_equal(g.EdgeDegrees.numpy(), z['EdgeDegrees'])
+    assert z['adj_values'].max() == 2.0                      # the repeated item of one log
+    for d in (16, 64):
+        x = torch.from_numpy(z[f'd{d}.x']).requires_grad_(True)
+        w = torch.from_numpy(z[f'd{d}.sd.feature_transform.weight']).requires_grad_(True)
+        b = torch.from_numpy(z[f'd{d}.sd.feature_transform.bias']).requires_grad_(True)
+        y = ref.hgcn_layer(x, g, w, b)
+        y.backward(torch.from_numpy(z[f'd{d}.cot']))
+        assert rel_err(y.detach().numpy(), z[f'd{d}.y']) <= RTOL and rel_err(x.grad.numpy(), z[f'd{d}.dx']) <= RTOL
+        assert rel_err(w.grad.numpy(), z[f'd{d}.grad.feature_transform.weight']) <= RTOL
+        assert rel_err(b.grad.numpy(), z[f'd{d}.grad.feature_transform.bias']) <= RTOL
+    m = ref.OracleRawGnn(g, torch.from_numpy(z['bag_input']), torch.from_numpy(z['bag_offsets']), V, 16, 'hgcn', 2, 1)
+    m.load_reference_state({k[len('model.sd.'):]: z[k] for k in z.files if k.startswith('model.sd.')})
+    scores = m(*(torch.from_numpy(z[f'model.{k}']) for k in 'uqi'))
+    loss = torch.nn.BCEWithLogitsLoss()(scores, torch.from_numpy(z['model.flags']))
+    loss.backward()
+    assert rel_err(scores.detach().numpy(), z['model.scores']) <= RTOL and abs(loss.item() - float(z['model.loss'])) <= 1e-6
+    for key, gr in m.reference_grads().items():
+        assert rel_err(gr.numpy(), z[f'model.grad.{key}']) <= 5e-6, key
+
+
 def test_f4_metrics_known_answers():
     rec = json.load(open(os.path.join(GOLDEN, 'f4_metrics.json')))
     sc = rec['selfcheck']
