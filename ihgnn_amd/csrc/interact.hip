@@ -774,15 +774,18 @@ __global__ __launch_bounds__(kWsThreads) void interact_fwd_strip_kernel(
     const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
     const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
     static_assert(D == 128, "eight 16-column strips");
-    constexpr int TE = kStripTE, V4 = D / 4, KG = D / 16, RT = TE / 16;
+    constexpr int TE = kStripTE, V4 = D / 4, KG = D / 16, RT = TE / 16, STEPS = KG * RT;
     constexpr int ROWS_PER_PIECE = kWave / V4;                            // 2 rows of 512 B per 1-KiB DMA piece
     constexpr int PIECES_PER_MEMBER = TE / ROWS_PER_PIECE;                // 16
     constexpr int PIECES = 3 * PIECES_PER_MEMBER / 8;                     // 6 per wave per tile
     constexpr int OSTRIDE = D + 4;                                        // accumulator rows r and r + 4 of one store land 16 banks apart
     struct Buffer { float tile[3][TE][D]; };
     __shared__ __attribute__((aligned(16))) Buffer buf[2];
-    __shared__ __attribute__((aligned(16))) float prod[TE][OSTRIDE];
-    const int tid = threadIdx.x, lane = tid & 63;
+    // product sums of a tile, handed from the MFMA layout to the row-wise epilogue; two images because the epilogue of tile k runs
+    // INSIDE the MFMA phase of tile k + 1 (one barrier per tile, no phase in which the matrix pipe only waits for stores)
+    __shared__ __attribute__((aligned(16))) float prod[2][TE][OSTRIDE];
+    __shared__ int ids[3][3 * TE];                                        // ring over tiles (tile_id % 3)
+    const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t n_tiles = (n_edges + TE - 1) / TE;
     const int64_t grid = gridDim.x;
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(kWsThreads) void interact_fwd_strip_kernel(
     const int64_t t0 = blockIdx.x;
 
     // this wave's weight fragments, resident for the whole kernel
-    const v4f* wfrag = reinterpret_cast<const v4f*>(wp) + static_cast<int64_t>(wave) * NBLK * KG * kWave + lane;
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wp) + static_cast<int64_t>(wave) * NBLK * KG * kWave + (tid & 63);
     v4f wreg[NBLK][KG];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b)
@@ -804,66 +807,75 @@ __global__ __launch_bounds__(kWsThreads) void interact_fwd_strip_kernel(
     const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u;
     const char* hbytes = reinterpret_cast<const char*>(h);
     int tl = tid;
-    int node_dma[PIECES];
-    auto load_dma_ids = [&](int64_t tile_id) {
-        const int prow = (tl >> 5) & 1;
-#pragma unroll
-        for (int k = 0; k < PIECES; ++k) {
-            const int x = wave * PIECES + k;
-            const int64_t e = tile_id * TE + 2 * (x & (PIECES_PER_MEMBER - 1)) + prow;
-            node_dma[k] = e < n_edges ? i3[e * 3 + (x >> 4)] : 0;
+    // Ids: the 3 TE member ids of a tile are contiguous in i3; waves 0 and 1 fetch them with one coalesced load each two tiles ahead
+    // and park them in a small LDS ring (slot = local tile number % 3), every wave then picks the handful it needs with ds_read_b32:
+    // 2 vector-memory instructions per tile and workgroup instead of 9 scattered ones per WAVE (each memory instruction issued
+    // beside the MFMA stream costs the matrix pipe time).
+    auto ring_of = [&](int k) { return ids[k % 3]; };
+    auto fetch_ids = [&](int k) {
+        const int lane = tl & 63;
+        if (wave < 2 && (wave == 0 || lane < 32)) {
+            const int j = wave * 64 + lane;
+            const int64_t pos = (t0 + k * grid) * (3 * TE) + j;
+            ring_of(k)[j] = pos < n_edges * 3 ? i3[pos] : 0;
         }
     };
-    auto issue_dma = [&](Buffer& b) {
+    auto issue_dma = [&](Buffer& b, int k) {
         const int prow = (tl >> 5) & 1, pchunk = tl & 31;
+        const int* idk = ring_of(k);
 #pragma unroll
-        for (int k = 0; k < PIECES; ++k) {
-            const int x = wave * PIECES + k;
+        for (int kk = 0; kk < PIECES; ++kk) {
+            const int x = wave * PIECES + kk;
             const int r0 = 2 * (x & (PIECES_PER_MEMBER - 1));
             const int swz = (pchunk ^ ((r0 + prow) & 15)) * 16;
-            lds_dma16(reinterpret_cast<const float*>(hbytes + static_cast<uint64_t>(static_cast<uint32_t>(node_dma[k])) * h_row_bytes + swz),
-                      &b.tile[x >> 4][r0][0]);
+            const int node = idk[(r0 + prow) * 3 + (x >> 4)];
+            lds_dma16(reinterpret_cast<const float*>(hbytes + static_cast<uint64_t>(static_cast<uint32_t>(node)) * h_row_bytes + swz), &b.tile[x >> 4][r0][0]);
         }
     };
     // epilogue mapping: thread -> hyperedge row tid >> 4, columns 4 (tid & 15) .. + 3 and 64 + the same
-    int node_p[3];
-    auto load_p_ids = [&](int64_t tile_id) {
-        const int64_t e = tile_id * TE + (tl >> 4);
+    v4f first[2], first_prev[2], pr[3][2];
+    auto load_first_order_rows = [&](int k) {
+        const int* idk = ring_of(k) + (tl >> 4) * 3;
+        const int ecol = (tl & 15) * 4;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) node_p[m] = e < n_edges ? i3[e * 3 + m] : 0;
+        for (int m = 0; m < 3; ++m) {
+            const float* src = p + static_cast<int64_t>(idk[m]) * ld_p + ecol;
+            pr[m][0] = *reinterpret_cast<const v4f*>(src);
+            pr[m][1] = *reinterpret_cast<const v4f*>(src + 64);
+        }
+    };
+    auto write_out = [&](int64_t tile_id, const float (*pimg)[OSTRIDE]) {
+        const int erow = tl >> 4, ecol = (tl & 15) * 4;
+        const int64_t e = tile_id * TE + erow;
+        const v4f s0 = *reinterpret_cast<const v4f*>(&pimg[erow][ecol]) + first_prev[0];
+        const v4f s1 = *reinterpret_cast<const v4f*>(&pimg[erow][64 + ecol]) + first_prev[1];
+        if (e < n_edges) {
+            float* dst = out + e * ld_out + ecol;
+            *reinterpret_cast<v4f*>(dst) = s0;
+            *reinterpret_cast<v4f*>(dst + 64) = s1;
+        }
     };
 
-    load_dma_ids(t0);
-    load_p_ids(t0);
-    issue_dma(buf[0]);
-    if (n_my > 1) load_dma_ids(t0 + grid);
+    fetch_ids(0);
+    if (n_my > 1) fetch_ids(1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue_dma(buf[0], 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
+    // Phase k (between two barriers) of a wave = the MFMAs of tile k with, somewhere inside, its SERVICE block: start the fill of
+    // tile k + 1 -> finish tile k - 1 (product sums from LDS + first-order rows, 16-byte stores) -> request the first-order rows of
+    // tile k (-> fetch the ids of tile k + 2).  The two waves of a SIMD run the service block half a phase apart (waves 0-3 at the
+    // start, waves 4-7 after half of their MFMAs), so one wave's memory instructions issue beside the other wave's MFMAs instead
+    // of both leaving the matrix pipe idle at the same time.  At the end: product sums to LDS, wait for everything this wave has
+    // in flight, barrier.
+    const bool late = wave >= 4;
     for (int k = 0; k < n_my; ++k) {
         const int64_t tile_id = t0 + k * grid;
         Buffer& b = buf[k & 1];
         asm volatile("" : "+v"(tl));
         const int arow = tl & 15, kq = (tl >> 4) & 3;
-        const int erow = tl >> 4, ecol = (tl & 15) * 4;
-        // the fill of tile k was issued a whole MFMA phase ago (k = 0: just now); the two youngest operations are the result stores
-        // of tile k - 1, which need not have retired
-        if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __syncthreads();
-        if (k + 1 < n_my) issue_dma(buf[(k + 1) & 1]);                      // that buffer's last reader was tile k - 1's MFMA phase
-        v4f first[2];
-        {
-            v4f pr[3][2];
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const float* src = p + static_cast<int64_t>(node_p[m]) * ld_p + ecol;
-                pr[m][0] = *reinterpret_cast<const v4f*>(src);
-                pr[m][1] = *reinterpret_cast<const v4f*>(src + 64);
-            }
-            if (k + 2 < n_my) load_dma_ids(t0 + (k + 2) * grid);
-            if (k + 1 < n_my) load_p_ids(t0 + (k + 1) * grid);
-            first[0] = (pr[0][0] + pr[1][0]) + pr[2][0];
-            first[1] = (pr[0][1] + pr[1][1]) + pr[2][1];
-        }
         v4f acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = v4f{0.f, 0.f, 0.f, 0.f};
@@ -881,19 +893,33 @@ __global__ __launch_bounds__(kWsThreads) void interact_fwd_strip_kernel(
         };
         v4f au = member_chunk(0, 0, 0), aq = member_chunk(1, 0, 0), ai = member_chunk(2, 0, 0);
 #pragma unroll
-        for (int step = 0; step < KG * RT; ++step) {
+        for (int step = 0; step < STEPS; ++step) {
             const int gk = step / RT, rt = step % RT;
+            if (step == 0 || step == STEPS / 2) {
+                if (late == (step != 0)) {                                  // wave-uniform
+                    if (k + 1 < n_my) issue_dma(buf[(k + 1) & 1], k + 1);   // that buffer's last reader was tile k - 1's MFMA phase
+                    if (k > 0) write_out(tile_id - grid, prod[(k - 1) & 1]);
+                    load_first_order_rows(k);
+                    if (k + 2 < n_my) fetch_ids(k + 2);                     // slot (k + 2) % 3 = (k - 1) % 3: last read in phase k - 1
+                }
+            }
             v4f z[4];
             z[0] = au * aq;
             z[1] = aq * ai;
             z[2] = ai * au;
             z[3] = z[0] * ai;
             __builtin_amdgcn_sched_barrier(0);
-            if (step + 1 < KG * RT) {
+            if (step + 1 < STEPS) {
                 const int gn = (step + 1) / RT, rn = (step + 1) % RT;
                 au = member_chunk(0, rn, gn);
                 aq = member_chunk(1, rn, gn);
                 ai = member_chunk(2, rn, gn);
+            }
+            if (step == 5 || step == STEPS / 2 + 5) {
+                if (late == (step != 5)) {                                  // the first-order rows have arrived by now: 24 registers -> 8
+                    first[0] = (pr[0][0] + pr[1][0]) + pr[2][0];
+                    first[1] = (pr[0][1] + pr[1][1]) + pr[2][1];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -902,26 +928,25 @@ __global__ __launch_bounds__(kWsThreads) void interact_fwd_strip_kernel(
                 for (int s2 = 0; s2 < 4; ++s2) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(z[bk][s2], wreg[bk][gk][s2], acc[rt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        float (*pimg)[OSTRIDE] = prod[k & 1];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) prod[rt * 16 + 4 * kq + r][16 * wave + arow] = acc[rt][r];
+            for (int r = 0; r < 4; ++r) pimg[rt * 16 + 4 * kq + r][16 * wave + arow] = acc[rt][r];
+        first_prev[0] = first[0];
+        first_prev[1] = first[1];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int64_t e = tile_id * TE + erow;
-        const v4f s0 = *reinterpret_cast<const v4f*>(&prod[erow][ecol]) + first[0];
-        const v4f s1 = *reinterpret_cast<const v4f*>(&prod[erow][64 + ecol]) + first[1];
-        if (e < n_edges) {
-            float* dst = out + e * ld_out + ecol;
-            *reinterpret_cast<v4f*>(dst) = s0;
-            *reinterpret_cast<v4f*>(dst + 64) = s1;
-        }
     }
+    asm volatile("" : "+v"(tl));
+    write_out(t0 + (n_my - 1) * grid, prod[(n_my - 1) & 1]);
 }
 
 // Member gradients, same layout: the loaders' job of the D <= 64 kernel is done by every wave for its own rows.  A operand = the
 // dout rows (a stream, swizzled like the forward's member rows), the member rows sit beside them as they lie; every wave owns a
 // 16-column strip of all NBLK product blocks (NBLK x 2 accumulators), applies the product rule to its own (row, column) elements
-// IN PLACE in the member tile, and after the second barrier each wave streams the rows it will refill out as 16-byte vectors.
+// IN PLACE in the member tile, and - one barrier later, inside the next tile's MFMA phase - streams the rows it will refill out
+// as 16-byte vectors.
 template <int D, int NBLK>
 __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
     const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
@@ -937,7 +962,8 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
         float htile[3][TE][D];
     };
     __shared__ __attribute__((aligned(16))) Buffer buf[2];
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ int ids[3][3 * TE];                                        // ring over this workgroup's tiles (local tile number % 3)
+    const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t n_tiles = (n_edges + TE - 1) / TE;
     const int64_t grid = gridDim.x;
@@ -945,7 +971,7 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
     if (n_my == 0) return;
     const int64_t t0 = blockIdx.x;
 
-    const v4f* wfrag = reinterpret_cast<const v4f*>(wq) + static_cast<int64_t>(wave) * NBLK * KG * kWave + lane;
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wq) + static_cast<int64_t>(wave) * NBLK * KG * kWave + (tid & 63);
     v4f wreg[NBLK][KG];
 #pragma unroll
     for (int b = 0; b < NBLK; ++b)
@@ -954,52 +980,76 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
 
     const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u;
     int tl = tid;                                                        // opaque copy of the thread id, see the forward kernel
-    int node_dma[HP];
-    auto load_dma_ids = [&](int64_t tile_id) {
-        const int prow = (tl >> 5) & 1;
-#pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            const int x = wave * HP + k;
-            const int64_t e = tile_id * TE + 2 * (x & (PIECES_PER_MEMBER - 1)) + prow;
-            node_dma[k] = e < n_edges ? i3[e * 3 + (x >> 4)] : 0;
+    auto fetch_ids = [&](int k) {                                        // see the forward kernel
+        const int lane = tl & 63;
+        if (wave < 2 && (wave == 0 || lane < 32)) {
+            const int j = wave * 64 + lane;
+            const int64_t pos = (t0 + k * grid) * (3 * TE) + j;
+            ids[k % 3][j] = pos < n_edges * 3 ? i3[pos] : 0;
         }
     };
-    auto issue_dma = [&](Buffer& b, int64_t tile_id) {
+    auto issue_dma = [&](Buffer& b, int k) {
+        const int64_t tile_id = t0 + k * grid;
         const int prow = (tl >> 5) & 1, pchunk = tl & 31;
         const char* hbytes = reinterpret_cast<const char*>(h) + pchunk * 16;
+        const int* idk = ids[k % 3];
 #pragma unroll
-        for (int k = 0; k < DP; ++k) {                                   // dout rows: a stream; rows past the end re-read the last one
-            const int r0 = 2 * (wave * DP + k);
+        for (int kk = 0; kk < DP; ++kk) {                                // dout rows: a stream; rows past the end re-read the last one
+            const int r0 = 2 * (wave * DP + kk);
             int64_t e = tile_id * TE + r0 + prow;
             e = e < n_edges ? e : n_edges - 1;
             lds_dma16(dout + e * ld_dout + (pchunk ^ ((r0 + prow) & 15)) * 4, &b.dtile[r0][0]);
         }
 #pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            const int x = wave * HP + k;
-            lds_dma16(reinterpret_cast<const float*>(hbytes + static_cast<uint64_t>(static_cast<uint32_t>(node_dma[k])) * h_row_bytes),
-                      &b.htile[x >> 4][2 * (x & (PIECES_PER_MEMBER - 1))][0]);
+        for (int kk = 0; kk < HP; ++kk) {
+            const int x = wave * HP + kk;
+            const int r0 = 2 * (x & (PIECES_PER_MEMBER - 1));
+            const int node = idk[(r0 + prow) * 3 + (x >> 4)];
+            lds_dma16(reinterpret_cast<const float*>(hbytes + static_cast<uint64_t>(static_cast<uint32_t>(node)) * h_row_bytes), &b.htile[x >> 4][r0][0]);
+        }
+    };
+    // the member-gradient rows of a finished tile: picked up from LDS by the wave that refills exactly these rows (so its own DMA
+    // may follow its own reads without a barrier), then stored as they lie
+    v4f gv[HP];
+    auto pick_up = [&](const Buffer& b) {
+        const int prow = (tl >> 5) & 1, pchunk = tl & 31;
+#pragma unroll
+        for (int kk = 0; kk < HP; ++kk) {
+            const int x = wave * HP + kk;
+            gv[kk] = *reinterpret_cast<const v4f*>(&b.htile[x >> 4][2 * (x & (PIECES_PER_MEMBER - 1)) + prow][pchunk * 4]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // in registers before a DMA may overwrite the rows
+    };
+    auto store_out = [&](int64_t tile_id) {
+        const int prow = (tl >> 5) & 1, pchunk = tl & 31;
+        const bool full = tile_id * TE + TE <= n_edges;
+#pragma unroll
+        for (int kk = 0; kk < HP; ++kk) {
+            const int x = wave * HP + kk;
+            const int64_t e = tile_id * TE + 2 * (x & (PIECES_PER_MEMBER - 1)) + prow;
+            if (full || e < n_edges) *reinterpret_cast<v4f*>(g_out + e * (3 * D) + (x >> 4) * D + pchunk * 4) = gv[kk];
         }
     };
 
-    load_dma_ids(t0);
-    issue_dma(buf[0], t0);
-    if (n_my > 1) load_dma_ids(t0 + grid);
+    fetch_ids(0);
+    if (n_my > 1) fetch_ids(1);
+    if (n_my > 2) fetch_ids(2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue_dma(buf[0], 0);
+    if (n_my > 1) issue_dma(buf[1], 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
+    // Phase k of a wave = the MFMAs of tile k with its service block inside (waves 0-3: at the start, waves 4-7: after half of the
+    // MFMAs - see the forward kernel): stream out tile k - 1, refill its buffer with tile k + 1, fetch the ids of tile k + 2.  Then the
+    // product rule in place, wait for this wave's outstanding operations, barrier.
+    const bool late = wave >= 4;
     for (int k = 0; k < n_my; ++k) {
-        const int64_t tile_id = t0 + k * grid;
         Buffer& b = buf[k & 1];
         asm volatile("" : "+v"(tl));
         const int arow = tl & 15, kq = (tl >> 4) & 3;
         const int col = 16 * wave + arow;
-        const int prow = (tl >> 5) & 1, pchunk = tl & 31;
-        // everything but the HP member-gradient stores of tile k - 1 (the youngest operations) has to have landed
-        if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        static_assert(HP == 6, "the wait above counts the stores of one tile");
-        __syncthreads();
-        if (k + 1 < n_my) issue_dma(buf[(k + 1) & 1], t0 + (k + 1) * grid);   // last read: the store-out of tile k - 1, before this barrier
-        if (k + 2 < n_my) load_dma_ids(t0 + (k + 2) * grid);
         v4f acc[RT][NBLK];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -1013,6 +1063,15 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
         for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const v4f*>(dbase + lane_off + rt * 16 * (D * 4));
 #pragma unroll
         for (int gk = 0; gk < KG; ++gk) {
+            if (gk == 0 || gk == KG / 2) {
+                if (late == (gk != 0) && k > 0) {                          // wave-uniform
+                    Buffer& done = buf[(k - 1) & 1];
+                    pick_up(done);
+                    if (k + 1 < n_my) issue_dma(done, k + 1);
+                    store_out(t0 + (k - 1) * grid);
+                    if (k + 2 < n_my) fetch_ids(k + 2);                    // ring slot of tile k - 1, whose ids were last read in phase k - 1... by this wave's own DMA above
+                }
+            }
             v4f a_now[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) a_now[rt] = a[rt];
@@ -1051,22 +1110,12 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
                 b.htile[2][er][col] = z_qi * hq[r] + z_iu * hu[r] + z_uqi * (hu[r] * hq[r]);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // store-out: the rows this wave fills by DMA, as they lie
-        v4f gv[HP];
-#pragma unroll
-        for (int kk = 0; kk < HP; ++kk) {
-            const int x = wave * HP + kk;
-            gv[kk] = *reinterpret_cast<const v4f*>(&b.htile[x >> 4][2 * (x & (PIECES_PER_MEMBER - 1)) + prow][pchunk * 4]);
-        }
-        const bool full = tile_id * TE + TE <= n_edges;
-#pragma unroll
-        for (int kk = 0; kk < HP; ++kk) {
-            const int x = wave * HP + kk;
-            const int64_t e = tile_id * TE + 2 * (x & (PIECES_PER_MEMBER - 1)) + prow;
-            if (full || e < n_edges) *reinterpret_cast<v4f*>(g_out + e * (3 * D) + (x >> 4) * D + pchunk * 4) = gv[kk];
-        }
     }
+    asm volatile("" : "+v"(tl));
+    pick_up(buf[(n_my - 1) & 1]);
+    store_out(t0 + (n_my - 1) * grid);
 }
 
 // dW, same roles: workgroup (x, y) owns the 64 x 64 x NBLK sub-block y = (js, cs) of the d x NBLK*d gradient (d a multiple of 64)
