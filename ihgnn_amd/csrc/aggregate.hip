@@ -14,8 +14,11 @@ namespace {
 // K5  node -> hyperedge gather-sum
 //   G lanes own one hyperedge row; a wave works on EPW = (64/G)*U consecutive hyperedges per iteration:
 //   one coalesced load brings their 3*EPW member ids (<= 64 ints), shuffles hand each group its ids, then
-//   3*U independent row gathers per lane are issued before the first add.  Group g takes hyperedges
-//   e0 + g + (64/G)*t so that each store instruction of the wave writes (64/G) consecutive rows = 1 KiB.
+//   up to 3*U independent row gathers per lane are issued before the first add.  Group g takes the U CONSECUTIVE
+//   hyperedges e0 + g U .. + U - 1: the layout numbers hyperedges by user, so neighbours usually share their user
+//   row, which is then fetched once and reused from registers (a third of the gathers at ~10 hyperedges per user).
+//   The [E, d] result is written once and not re-read by this kernel: non-temporal stores, so the stream does not
+//   evict the node table from L2 / Infinity Cache (C3: 540 -> 460 us; C2: 160 -> 131 us).
 // ================================================================================================
 template <int VEC, int G, int U>
 __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
         for (int t = 0; t < U; ++t) {
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                const int from = (grp + GPW * t) * 3 + m;
+                const int from = (grp * U + t) * 3 + m;
                 ids[t][m] = __shfl(my_id, from);
                 sc[t][m] = __shfl(my_scale, from);
             }
@@ -51,16 +54,21 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
             Frag<VEC> rows[U][3];
 #pragma unroll
             for (int t = 0; t < U; ++t) {
-                const bool live = e0 + grp + GPW * t < n_edges;
+                const bool live = e0 + grp * U + t < n_edges;
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
+                for (int m = 0; m < 3; ++m) {
+                    if (m == 0 && t > 0 && ids[t][0] == ids[t - 1][0]) {
+                        rows[t][0] = rows[t - 1][0];                    // same user as the previous hyperedge: row already here
+                        continue;
+                    }
                     rows[t][m] = live ? Frag<VEC>::load(src + static_cast<int64_t>(ids[t][m]) * ld_src + c * VEC)
                                       : Frag<VEC>::zero();
+                }
             }
             Frag<VEC> b = bias != nullptr ? Frag<VEC>::load(bias + c * VEC) : Frag<VEC>::zero();
 #pragma unroll
             for (int t = 0; t < U; ++t) {
-                const int64_t e = e0 + grp + GPW * t;
+                const int64_t e = e0 + grp * U + t;
                 if (e >= n_edges) continue;
                 Frag<VEC> acc = Frag<VEC>::zero();
                 acc.add_scaled(rows[t][0], sc[t][0]);      // (u + q) + i, the order of a row-major SpMM row
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
                 acc.add_scaled(rows[t][2], sc[t][2]);
                 acc.mul(alpha);
                 acc.add(b);
-                acc.store(out + e * ld_out + c * VEC);
+                acc.store_stream(out + e * ld_out + c * VEC);
             }
         }
     }

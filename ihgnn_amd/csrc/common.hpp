@@ -51,6 +51,11 @@ template <> struct Frag<4> {
     __device__ static Frag zero() { return {make_float4(0.f, 0.f, 0.f, 0.f)}; }
     __device__ static Frag load(const float* p) { return {*reinterpret_cast<const float4*>(p)}; }
     __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    // write-once output that nobody re-reads soon: non-temporal, so the stream does not push the gathered table out of the caches
+    __device__ void store_stream(float* p) const {
+        typedef float vec4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(vec4{v.x, v.y, v.z, v.w}, reinterpret_cast<vec4*>(p));
+    }
     __device__ void add_scaled(const Frag& o, float s) { v.x += s * o.v.x; v.y += s * o.v.y; v.z += s * o.v.z; v.w += s * o.v.w; }
     __device__ void add(const Frag& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
     __device__ void mul(float s) { v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
@@ -61,6 +66,7 @@ template <> struct Frag<1> {
     __device__ static Frag zero() { return {0.f}; }
     __device__ static Frag load(const float* p) { return {*p}; }
     __device__ void store(float* p) const { *p = v; }
+    __device__ void store_stream(float* p) const { __builtin_nontemporal_store(v, p); }
     __device__ void add_scaled(const Frag& o, float s) { v += s * o.v; }
     __device__ void add(const Frag& o) { v += o.v; }
     __device__ void mul(float s) { v *= s; }
@@ -74,6 +80,9 @@ __device__ __forceinline__ int64_t global_wave_count() { return static_cast<int6
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+
+// 16-byte store of a value that is written once and not re-read by this kernel (streams of hyperedge rows): non-temporal
+__device__ __forceinline__ void store_stream4(float* p, v4f v) { __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p)); }
 
 constexpr int kRowPad = 4;       // floats; breaks the power-of-two row stride for ds_read_b128
 

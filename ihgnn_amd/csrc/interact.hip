@@ -318,6 +318,14 @@ __device__ __forceinline__ void lds_dma16(const float* src, float* lds_piece) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
 }
 
+__device__ __forceinline__ void edge_row_store(float* p, v4f v) {
+#ifdef IHG_PLAIN_EDGE_OUT
+    *reinterpret_cast<v4f*>(p) = v;
+#else
+    store_stream4(p, v);
+#endif
+}
+
 template <int D, int NBLK>
 __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
     const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
@@ -390,11 +398,11 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_fwd_ws_kernel(
             float* dst = out + e0 * ld_out + chunk * 4;
             if (tile_id * S::TE + S::TE <= n_edges) {
 #pragma unroll
-                for (int q = 0; q < PL; ++q) *reinterpret_cast<v4f*>(dst + q * RPP * ld_out) = prod[q] + first[q];
+                for (int q = 0; q < PL; ++q) edge_row_store(dst + q * RPP * ld_out, prod[q] + first[q]);
             } else {
 #pragma unroll
                 for (int q = 0; q < PL; ++q)
-                    if (e0 + q * RPP < n_edges) *reinterpret_cast<v4f*>(dst + q * RPP * ld_out) = prod[q] + first[q];
+                    if (e0 + q * RPP < n_edges) edge_row_store(dst + q * RPP * ld_out, prod[q] + first[q]);
             }
         };
         const int64_t t0 = blockIdx.x;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void interact_bwd_members_ws_kernel(
             const bool full = tile_id * TE + TE <= n_edges;
 #pragma unroll
             for (int x = 0; x < 3 * QP; ++x)
-                if (full || e0 + (x % QP) * RPP < n_edges) *reinterpret_cast<v4f*>(dst + (x % QP) * RPP * (3 * D) + (x / QP) * D) = gout[x];
+                if (full || e0 + (x % QP) * RPP < n_edges) store_stream4(dst + (x % QP) * RPP * (3 * D) + (x / QP) * D, gout[x]);
         };
         const int64_t t0 = blockIdx.x;
         if (n_my > 0) load_ids(t0);
@@ -851,8 +859,13 @@ __global__ __launch_bounds__(kWsThreads) void interact_fwd_strip_kernel(
         const v4f s1 = *reinterpret_cast<const v4f*>(&pimg[erow][64 + ecol]) + first_prev[1];
         if (e < n_edges) {
             float* dst = out + e * ld_out + ecol;
+#ifdef IHG_PLAIN_EDGE_OUT
             *reinterpret_cast<v4f*>(dst) = s0;
             *reinterpret_cast<v4f*>(dst + 64) = s1;
+#else
+            store_stream4(dst, s0);
+            store_stream4(dst + 64, s1);
+#endif
         }
     };
 
@@ -1027,7 +1040,7 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
         for (int kk = 0; kk < HP; ++kk) {
             const int x = wave * HP + kk;
             const int64_t e = tile_id * TE + 2 * (x & (PIECES_PER_MEMBER - 1)) + prow;
-            if (full || e < n_edges) *reinterpret_cast<v4f*>(g_out + e * (3 * D) + (x >> 4) * D + pchunk * 4) = gv[kk];
+            if (full || e < n_edges) store_stream4(g_out + e * (3 * D) + (x >> 4) * D + pchunk * 4, gv[kk]);
         }
     };
 
@@ -1116,6 +1129,140 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
     asm volatile("" : "+v"(tl));
     pick_up(buf[(n_my - 1) & 1]);
     store_out(t0 + (n_my - 1) * grid);
+}
+
+// Weight gradient in the strip style (D = 128): dW[j][(3+b)d + c] = sum_e dout[e][j] z_b[e][c] - the contraction index is the
+// hyperedge, so the whole [d x NBLK d] gradient of a workgroup's hyperedges stays in accumulators for the entire sweep: wave w owns
+// rows 16 w .. 16 w + 15 and all NBLK * d columns (NBLK * 8 accumulator tiles = 128 VGPRs), there is no per-tile epilogue and
+// nothing leaves the CU until the end (one [d x NBLK d] slab per workgroup, summed by slab_reduce_kernel in a fixed order).
+// MFMA step (g, s) takes the 4 hyperedges 16 g + 4 s + kq (kq = lane >> 4): A = dout[e][16 w + (lane & 15)] (one ds_read_b32 for
+// 32 MFMAs), B = z_b[e][8 c + m] with c = lane & 15 for accumulator tile (b, m): a lane reads columns 8 c .. 8 c + 7 of the three
+// member rows of ITS hyperedge (two ds_read_b128 each) and forms the 8 x NBLK products from them.  Member rows are stored with
+// 16-byte chunk p at position p ^ (row & 1): the four rows of a step then cover all 64 banks in every ds_read_b128 phase.
+template <int D, int NBLK>
+__global__ __launch_bounds__(kWsThreads) void interact_bwd_weight_strip_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ dout, int64_t ld_dout,
+    float* __restrict__ slabs, int64_t n_edges) {
+    static_assert(D == 128, "eight 16-row strips");
+    constexpr int TE = kStripTE, V4 = D / 4;
+    constexpr int ROWS_PER_PIECE = kWave / V4;                            // 2
+    constexpr int PIECES_PER_MEMBER = TE / ROWS_PER_PIECE;                // 16
+    constexpr int HP = 3 * PIECES_PER_MEMBER / 8;                         // 6 member-row pieces per wave per tile
+    constexpr int DP = PIECES_PER_MEMBER / 8;                             // 2 dout pieces per wave per tile
+    constexpr int MT = D / 16;                                            // 8 accumulator tiles per product block
+    struct Buffer {
+        float dtile[TE][D];
+        float mtile[3][TE][D];
+    };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    __shared__ int ids[3][3 * TE];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int64_t grid = gridDim.x;
+    const int n_my = blockIdx.x < n_tiles ? static_cast<int>((n_tiles - blockIdx.x + grid - 1) / grid) : 0;
+    const int64_t t0 = blockIdx.x;
+    const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u;
+    int tl = tid;
+    auto fetch_ids = [&](int k) {                                        // see interact_fwd_strip_kernel
+        const int lane = tl & 63;
+        if (wave < 2 && (wave == 0 || lane < 32)) {
+            const int j = wave * 64 + lane;
+            const int64_t pos = (t0 + k * grid) * (3 * TE) + j;
+            ids[k % 3][j] = pos < n_edges * 3 ? i3[pos] : 0;
+        }
+    };
+    auto issue_dma = [&](Buffer& b, int k) {
+        const int64_t tile_id = t0 + k * grid;
+        const int prow = (tl >> 5) & 1, pchunk = tl & 31;
+        const int* idk = ids[k % 3];
+#pragma unroll
+        for (int kk = 0; kk < DP; ++kk) {                                // dout rows as they lie; rows past the end re-read the last one (masked at use)
+            const int r0 = 2 * (wave * DP + kk);
+            int64_t e = tile_id * TE + r0 + prow;
+            e = e < n_edges ? e : n_edges - 1;
+            lds_dma16(dout + e * ld_dout + pchunk * 4, &b.dtile[r0][0]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < HP; ++kk) {
+            const int x = wave * HP + kk;
+            const int r0 = 2 * (x & (PIECES_PER_MEMBER - 1));
+            const int node = idk[(r0 + prow) * 3 + (x >> 4)];
+            const char* src = reinterpret_cast<const char*>(h) + static_cast<uint64_t>(static_cast<uint32_t>(node)) * h_row_bytes + ((pchunk ^ prow) << 4);
+            lds_dma16(reinterpret_cast<const float*>(src), &b.mtile[x >> 4][r0][0]);     // r0 even: (row & 1) == prow
+        }
+    };
+    v4f acc[NBLK][MT];
+#pragma unroll
+    for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[bk][m] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    if (n_my > 0) {
+        fetch_ids(0);
+        if (n_my > 1) fetch_ids(1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue_dma(buf[0], 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const bool late = wave >= 4;
+    for (int k = 0; k < n_my; ++k) {
+        const int64_t tile_id = t0 + k * grid;
+        const Buffer& b = buf[k & 1];
+        asm volatile("" : "+v"(tl));
+        const int c = tl & 15, kq = (tl >> 4) & 3;
+        const bool full = tile_id * TE + TE <= n_edges;
+        // per step the lane's hyperedge row is 4 step + kq: its dout element and the 32 bytes 8 c .. 8 c + 7 of each member row
+        int a_off = kq * (D * 4) + (16 * wave + c) * 4;
+        int m_off = kq * (D * 4) + (((2 * c) ^ (kq & 1)) << 4);          // chunk 2 c of a row of parity kq & 1; chunk 2 c + 1 sits at the position ^ 1
+        asm volatile("" : "+v"(a_off), "+v"(m_off));
+        const char* dbase = reinterpret_cast<const char*>(&b.dtile[0][0]);
+        const char* mbase = reinterpret_cast<const char*>(&b.mtile[0][0][0]);
+#pragma unroll
+        for (int step = 0; step < TE / 4; ++step) {
+            if (step == 0 || step == TE / 8) {
+                if (late == (step != 0)) {                                  // service block, half a phase apart on the two waves of a SIMD
+                    if (k + 1 < n_my) issue_dma(buf[(k + 1) & 1], k + 1);
+                    if (k + 2 < n_my) fetch_ids(k + 2);
+                }
+            }
+            const int row_bytes = step * 4 * (D * 4);
+            float a = *reinterpret_cast<const float*>(dbase + a_off + row_bytes);
+            if (!full && tile_id * TE + 4 * step + kq >= n_edges) a = 0.f;  // rows past the end contribute exact zeros
+            v4f mu[2], mq[2], mi[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                mu[x] = *reinterpret_cast<const v4f*>(mbase + ((m_off + row_bytes) ^ (x << 4)));
+                mq[x] = *reinterpret_cast<const v4f*>(mbase + ((m_off + row_bytes) ^ (x << 4)) + TE * D * 4);
+                mi[x] = *reinterpret_cast<const v4f*>(mbase + ((m_off + row_bytes) ^ (x << 4)) + 2 * TE * D * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk) {
+                v4f z[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+                    z[x] = bk == 0 ? mu[x] * mq[x] : bk == 1 ? mq[x] * mi[x] : bk == 2 ? mi[x] * mu[x] : (mu[x] * mq[x]) * mi[x];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[bk][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, z[m >> 2][m & 3], acc[bk][m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // slab of this workgroup: element (j, b * D + col); accumulator tile (b, m): column lane & 15 -> col 8 c + m, rows 4 kq + r
+    float* slab = slabs + static_cast<int64_t>(blockIdx.x) * D * NBLK * D;
+    const int c = tid & 15, kq = (tid >> 4) & 3;
+#pragma unroll
+    for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[static_cast<int64_t>(16 * wave + 4 * kq + r) * NBLK * D + bk * D + 8 * c + m] = acc[bk][m][r];
 }
 
 // dW, same roles: workgroup (x, y) owns the 64 x 64 x NBLK sub-block y = (js, cs) of the d x NBLK*d gradient (d a multiple of 64)
@@ -1347,8 +1494,10 @@ __global__ __launch_bounds__(kBlockThreads) void slab_reduce_kernel(const float*
     }
 }
 
+constexpr int kPipeGridSlabs = 256;
 inline int64_t packed_weight_floats(int dim, int order) { return static_cast<int64_t>(order == 3 ? 4 : 3) * dim * dim; }
 inline int weight_slabs(int dim) {
+    if (dim == 128) return kPipeGridSlabs;                  // interact_bwd_weight_strip_kernel: one full slab per workgroup
     const int subs = dim >= 64 ? (dim / 64) * (dim / 64) : 1;
     int n = 512 / subs;
     return n < 8 ? 8 : n;
@@ -1449,8 +1598,11 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
 #undef IHG_MEM
 #undef IHG_MEM_PIPE
     const int subs_ws = (dim / 64) * (dim / 64);
-    const int n_slabs = static_cast<int>(std::min<int64_t>(dim >= 64 ? std::max(kPipeGrid / subs_ws, 8) : weight_slabs(dim), (n_edges + 63) / 64));
-    if (dim >= 64 && ld_h < (int64_t{1} << 30)) {
+    int n_slabs = static_cast<int>(std::min<int64_t>(dim >= 64 ? std::max(kPipeGrid / subs_ws, 8) : weight_slabs(dim), (n_edges + 63) / 64));
+    if (dim == 128 && ld_h < (int64_t{1} << 30)) {
+        n_slabs = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGridSlabs));
+        hipLaunchKernelGGL((interact_bwd_weight_strip_kernel<128, NBLK>), dim3(n_slabs), dim3(kWsThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
+    } else if (dim >= 64 && ld_h < (int64_t{1} << 30)) {
         hipLaunchKernelGGL((interact_bwd_weight_ws_kernel<NBLK>), dim3(n_slabs, subs_ws), dim3(kWsThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
     } else if (dim >= 64) {                                  // row strides beyond 32-bit byte offsets: the plain tiling
         hipLaunchKernelGGL((interact_bwd_weight_mfma_kernel<64, NBLK>), dim3(n_slabs, subs_ws), dim3(kBlockThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges, dim);
