@@ -186,6 +186,42 @@ def k7_roles(table, E, N, dim, layout, table_steps):
     return out
 
 
+def gather_stress(dev, rounds=6):
+    """K5 where every row gather really is an HBM access: uniform members over a node table far larger than the Infinity Cache
+    (4.2 M nodes x 64 floats = 1.07 GB, E = 4 M hyperedges, d = 64).  Here the SURVEY §8 d3 byte model (16 d + 12 B per hyperedge)
+    is also (almost) the compulsory traffic, so algorithmic rate = HBM rate; the microarch guide's figure for random whole rows
+    gathered into registers from a buffer far larger than the Infinity Cache is 5.5-5.8 TB/s."""
+    import numpy as np
+    import torch
+    from ihgnn_amd import ops
+    n_nodes, n_edges, dim = 4_200_000, 4_000_000, 64
+    rng = np.random.default_rng(77)
+    i3 = torch.from_numpy(rng.integers(0, n_nodes, (n_edges, 3), dtype=np.int64).astype(np.int32)).to(dev)
+    x = torch.randn(n_nodes, dim, device=dev)
+    out = torch.empty(n_edges, dim, device=dev)
+    flush = torch.empty(96 << 20, device=dev)                   # 384 MB written between launches: nothing of x survives in the caches
+    times = []
+    for r in range(rounds + 1):
+        flush.fill_(float(r))
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ops.edge_gather_sum_raw(x, i3, out=out)
+        b.record()
+        torch.cuda.synchronize()
+        if r:
+            times.append(a.elapsed_time(b) * 1e-3)
+    t = sum(times) / len(times)
+    touched = int(torch.unique(i3.reshape(-1)).numel())
+    algorithmic = n_edges * (16 * dim + 12)
+    compulsory = touched * 4 * dim + n_edges * 4 * dim + 12 * n_edges
+    return dict(bound='hbm', kernel='edge_gather_sum (K5) on an HBM-resident table', workload=f'uniform members, N={n_nodes} (table {n_nodes * dim * 4 / 1e9:.2f} GB), E={n_edges}, d={dim}',
+                avg_us=round(t * 1e6, 1), launches=len(times), algorithmic_bytes_per_launch=algorithmic, achieved=round(algorithmic / t / 1e9, 1),
+                peak=HBM_PEAK_GBS, unit='GB/s', frac=round(algorithmic / t / 1e9 / HBM_PEAK_GBS, 4), compulsory_bytes_per_launch=compulsory,
+                compulsory_gbs=round(compulsory / t / 1e9, 1), hyperedges_per_s=round(n_edges / t, 1),
+                note='every gathered row is counted: with 3 uniform draws per hyperedge from 4.2 M rows a row is re-read 2.9 times on average, at random '
+                     'distances in a 1.07 GB table (Infinity Cache 256 MB): the algorithmic rate is an HBM + cache-hit mix, the compulsory rate the floor')
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -263,7 +299,7 @@ def main():
     kernels = profiler.summary() if not args.no_kernel_events else {}
     final_loss = float(last.item())
 
-    table, table_steps, restricted_elapsed, fwd_elapsed = {}, min(args.steps, 5), None, None
+    table, table_steps, restricted_elapsed, fwd_elapsed, stress = {}, min(args.steps, 5), None, None, None
     if not args.no_extras:
         # per-kernel table (K7 roles, MFMA kernels): a second, untimed pass over the same batches with every launch bracketed
         if not args.no_kernel_events:
@@ -295,6 +331,7 @@ def main():
                 model.propagate()
             torch.cuda.synchronize()
             fwd_elapsed = (time.perf_counter() - t1) / n_f
+        stress = gather_stress(dev) if rank == 0 else None
 
     if rank != 0:
         if world > 1:
@@ -368,6 +405,8 @@ def main():
     if fwd_elapsed is not None:
         out['fwd_only_hyperedges_per_s'] = round(E * layers / fwd_elapsed, 1)
         out['fwd_only_ms'] = round(1e3 * fwd_elapsed, 4)
+    if stress is not None:
+        out['roofline_gather_stress'] = stress
     if table:
         out['kernels_us'] = {name: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] / table_steps} for name, v in table.items()}
         out['kernels_us_note'] = f'HIP events around every launch, {table_steps} untimed steps after the timed region; the timed region brackets K5 only'

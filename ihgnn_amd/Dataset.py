@@ -272,6 +272,41 @@ class GraphDataset(Dataset):
         pos, neg = dev[:, :n_pos], dev[:, n_pos:]
         return pos[0], pos[1], pos[2], pos[3], neg[0], neg[1], neg[2], neg[3]
 
+    def device_batches(self, batch_size: int, epoch: int = 0, seed: int = 0, rank: int = 0, world_size: int = 1):
+        """One epoch of training batches produced ON THE DEVICE: the positives are a device-side permutation of the hyperedges
+        (this rank's share of it when ``world_size`` > 1), the ``rand_neg_sample_size`` negatives of every positive come from
+        ``ihg_sample_negatives`` (distinct within a sample, uniform over the catalogue, may hit the positive - the semantics of
+        ``random.sample(range(I), k)``, ``Dataset.py:107-109``).  Yields the 8-tuple of ``collate_fn`` (positives then negatives;
+        users, queries, items, flags) with no host -> device copy and no host-side sampling per step.  Logged (non-random)
+        negatives are a host-side table and are not drawn here."""
+        import ctypes
+        from . import _lib
+        if self.nonrand_neg_sample_size:
+            raise ValueError('device_batches draws random negatives only (non_random_negative_sample_size must be 0)')
+        lib = _lib.load()
+        dev = GraphDataset.device
+        if getattr(self, '_pos_device', None) is None:
+            self._pos_device = torch.from_numpy(self.pos_triples).to(dev)
+        k = self.rand_neg_sample_size
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed * 1_000_003 + epoch)
+        order = torch.randperm(len(self), device=dev, generator=gen)[rank::world_size]
+        n_batches = -(-(-(-len(self) // world_size)) // batch_size)
+        base, extra = divmod(int(order.shape[0]), n_batches)
+        lo = 0
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for b in range(n_batches):
+            hi = lo + base + (1 if b < extra else 0)
+            pos = self._pos_device[order[lo:hi]]
+            lo = hi
+            n = int(pos.shape[0])
+            neg_items = torch.empty(n, k, dtype=torch.int64, device=dev)
+            _lib.check(lib.ihg_sample_negatives(seed * 7919 + rank, (epoch << 32) + b, n, self.item_count, k, ctypes.c_void_p(neg_items.data_ptr()), stream),
+                       'ihg_sample_negatives')
+            ones = torch.ones(n, dtype=torch.int64, device=dev)
+            yield (pos[:, 0], pos[:, 1], pos[:, 2], ones, pos[:, 0].repeat_interleave(k), pos[:, 1].repeat_interleave(k),
+                   neg_items.reshape(-1), torch.zeros(n * k, dtype=torch.int64, device=dev))
+
     def sample_batches(self, batch_size: int, steps: int, seed: int = 0) -> Iterator[Tuple[Tensor, Tensor, Tensor, Tensor]]:
         """Vectorised batch source for benchmarks: ``steps`` batches of ``batch_size`` positives (uniform with
         replacement) each followed by ``rand_neg_sample_size`` uniform negatives; yields device tensors
@@ -289,6 +324,25 @@ class GraphDataset(Dataset):
             dev = GraphDataset.device
             yield (torch.from_numpy(users).to(dev), torch.from_numpy(queries).to(dev),
                    torch.from_numpy(items).to(dev), torch.from_numpy(labels).to(dev))
+
+
+class DeviceBatchLoader:
+    """Training-batch source that never leaves the GPU (``GraphDataset.device_batches``): drop-in for the ``DataLoader`` of the
+    training loop (iterating yields the ``collate_fn`` 8-tuple; ``batch_sampler.set_epoch`` selects the epoch's permutation)."""
+
+    def __init__(self, dataset: GraphDataset, batch_size: int, rank: int = 0, world_size: int = 1, seed: int = 0):
+        self.dataset, self.batch_size, self.rank, self.world_size, self.seed = dataset, batch_size, rank, world_size, seed
+        self.epoch = 0
+        self.batch_sampler = self
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def __len__(self) -> int:
+        return -(-(-(-len(self.dataset) // self.world_size)) // self.batch_size)
+
+    def __iter__(self):
+        return self.dataset.device_batches(self.batch_size, self.epoch, self.seed, self.rank, self.world_size)
 
 
 class _PinnedRing:

@@ -21,6 +21,8 @@ _FLAGS = (
     ('longtail', ('--longtail',), str, '', 'per-user long-tail statistics file name'),
     ('device', ('--device', '-d'), str, '', 'GPU ordinal ("0" = cuda:0)'),
     ('embedding_size', ('--embedding_size', '--emb'), int, 0, 'embedding width (0 = Gs.embedding_size)'),
+    # not in the reference: batches (positive permutation + negative sampling) produced on the GPU instead of by DataLoader + random.sample
+    ('device_sampling', ('--device_sampling',), 'flag', False, 'draw training batches on the device (same distribution, different random stream)'),
 )
 
 

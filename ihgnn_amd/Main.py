@@ -86,7 +86,10 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
         random_negative_sample_size=Gs.random_negative_sample_size,
         non_random_negative_sample_size=Gs.non_random_negative_sample_size,
         device=device)
-    if world > 1:
+    if args.device_sampling:
+        from .Dataset import DeviceBatchLoader
+        dataloader_train = DeviceBatchLoader(dataset_train, Gs.batch_size, rank, world)
+    elif world > 1:
         # data parallel: the ranks split every epoch's permutation between them (same number of steps on every rank, each row once
         # per epoch) and draw their negatives from differently seeded generators; global batch = batch_size x ranks
         import random

@@ -17,7 +17,8 @@ from .CommonLayers import FeatureInteractor
 
 
 def _transform(linear: nn.Linear, x: Tensor, layout) -> Tensor:
-    """``nn.Linear`` on every node row: the HIP row-GEMM when the shape allows, torch/rocBLAS otherwise."""
+    """``nn.Linear`` (square) on every node row through the HIP node-level kernels (MFMA row-GEMM for d in {32,64,128,256},
+    the any-width kernel otherwise); only a rectangular transform - which RawGnn never builds - is left to torch."""
     if linear.in_features == linear.out_features and ops.node_linear_supported(x, linear.weight):
         return ops.node_linear(x, linear.weight, linear.bias, layout)
     return linear(x)

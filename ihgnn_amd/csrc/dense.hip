@@ -410,12 +410,87 @@ __global__ __launch_bounds__(kBlockThreads) void compose_bwd_kernel(const float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Any-width forms of the three node-level products (d not in {32, 64, 128, 256}, or rows that are not 16-byte aligned): one thread
+// per output element, sums in index order.  Correct for every shape; the tiled kernels above are the fast path.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int type_of_row(const TypePlan& plan, int64_t v) { return v >= plan.begin[2] ? 2 : (v >= plan.begin[1] ? 1 : 0); }
+
+// transpose == 0: out[v][n] = sum_k in[v][k] W_t[n][k] (+ bias);   transpose == 1: out[v][k] = sum_n in[v][n] W_t[n][k]
+__global__ __launch_bounds__(kBlockThreads) void row_gemm_generic_kernel(const float* __restrict__ in, int64_t ld_in, const float* __restrict__ w, int64_t ld_w,
+                                                                         int64_t w_type_stride, int transpose, const float* __restrict__ bias, int bias_mask,
+                                                                         int64_t bias_type_stride, TypePlan plan, float* __restrict__ out, int64_t ld_out, int d) {
+    const int64_t rows = plan.begin[3] - plan.begin[0];
+    const int64_t total = rows * d;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t v = plan.begin[0] + idx / d;
+        const int n = static_cast<int>(idx % d);
+        const int type = type_of_row(plan, v);
+        const float* wt = w + type * w_type_stride;
+        const float* row = in + v * ld_in;
+        float acc = 0.f;
+        if (transpose == 0) {
+            for (int k = 0; k < d; ++k) acc += row[k] * wt[static_cast<int64_t>(n) * ld_w + k];
+            if (bias != nullptr && ((bias_mask >> type) & 1)) acc += bias[type * bias_type_stride + n];
+        } else {
+            for (int k = 0; k < d; ++k) acc += row[k] * wt[static_cast<int64_t>(k) * ld_w + n];
+        }
+        out[v * ld_out + n] = acc;
+    }
+}
+
+// dW_t[c][j] = sum_{v in t} dout[v][c] x[v][j]; the bias part as dense_slab_reduce_kernel writes it
+__global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_generic_kernel(const float* __restrict__ dout, int64_t ld_dout, const float* __restrict__ x,
+                                                                                  int64_t ld_x, TypePlan plan, int n_types, int d, float* __restrict__ dw,
+                                                                                  int64_t ld_dw, int64_t dw_type_stride, float* __restrict__ dbias,
+                                                                                  int bias_mask, int64_t dbias_type_stride) {
+    const int64_t per_type = static_cast<int64_t>(d) * d;
+    const int64_t total = per_type * n_types + d;
+    for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        if (idx < per_type * n_types) {
+            const int type = static_cast<int>(idx / per_type);
+            const int c = static_cast<int>((idx % per_type) / d), j = static_cast<int>(idx % d);
+            const int64_t v0 = n_types == 1 ? plan.begin[0] : plan.begin[type], v1 = n_types == 1 ? plan.begin[3] : plan.begin[type + 1];
+            float acc = 0.f;
+            for (int64_t v = v0; v < v1; ++v) acc += dout[v * ld_dout + c] * x[v * ld_x + j];
+            dw[static_cast<int64_t>(c) * ld_dw + type * dw_type_stride + j] = acc;
+        } else if (dbias != nullptr) {
+            const int c = static_cast<int>(idx - per_type * n_types);
+            float all = 0.f;
+            for (int type = 0; type < 3; ++type) {
+                const bool use = n_types == 1 || ((bias_mask >> type) & 1);
+                float part = 0.f;
+                if (use)
+                    for (int64_t v = plan.begin[type]; v < plan.begin[type + 1]; ++v) part += dout[v * ld_dout + c];
+                all += part;
+                if (n_types != 1 && dbias_type_stride != 0) dbias[type * dbias_type_stride + c] = part;
+            }
+            if (n_types == 1 || dbias_type_stride == 0) dbias[c] = all;
+        }
+    }
+}
+
+inline bool tiled_node_linear(int dim, int64_t ld_a, int64_t ld_b, const void* a, const void* workspace) {
+    return mfma_dim(dim) && ld_a % 4 == 0 && ld_b % 4 == 0 && aligned16(a) && workspace != nullptr && aligned16(workspace);
+}
+
+inline void launch_row_gemm_generic(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose,
+                                    const float* bias, int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out,
+                                    hipStream_t s) {
+    const TypePlan plan = make_plan(type_begin, 64);
+    const int64_t total = (type_begin[3] - type_begin[0]) * dim;
+    const int grid = static_cast<int>(std::min<int64_t>((total + kBlockThreads - 1) / kBlockThreads, kMaxBlocks * 4));
+    hipLaunchKernelGGL(row_gemm_generic_kernel, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask,
+                       bias_type_stride, plan, out, ld_out, dim);
+}
+
 }  // namespace
 
 extern "C" {
 
 int64_t ihg_node_linear_workspace_bytes(int32_t dim) {
-    if (!mfma_dim(dim)) return -1;
+    if (dim <= 0) return -1;
+    if (!mfma_dim(dim)) return 0;                           // any-width kernels: no packed weights, no slabs
     const int64_t packed = 3LL * dim * dim;
     const int64_t slabs = 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
     return (packed + slabs) * static_cast<int64_t>(sizeof(float));
@@ -423,9 +498,10 @@ int64_t ihg_node_linear_workspace_bytes(int32_t dim) {
 
 static int node_linear_common_check(const char* what, int32_t dim, int64_t ld_a, int64_t ld_b, int64_t ld_w, const int64_t* type_begin,
                                     const void* workspace, int64_t workspace_bytes) {
-    if (!mfma_dim(dim)) return fail(IHG_ERR_INVALID, "%s: dim %d is not one of 32/64/128/256", what, dim);
-    if (type_begin == nullptr || workspace == nullptr) return fail(IHG_ERR_INVALID, "%s: null pointer", what);
-    if (ld_a < dim || ld_b < dim || ld_w < dim || ld_a % 4 || ld_b % 4) return fail(IHG_ERR_INVALID, "%s: bad leading dimension", what);
+    if (dim <= 0) return fail(IHG_ERR_INVALID, "%s: dim %d", what, dim);
+    if (type_begin == nullptr) return fail(IHG_ERR_INVALID, "%s: null pointer", what);
+    if (ld_a < dim || ld_b < dim || ld_w < dim) return fail(IHG_ERR_INVALID, "%s: bad leading dimension", what);
+    if (!mfma_dim(dim) || ld_a % 4 || ld_b % 4 || workspace == nullptr) return IHG_OK;        // the any-width kernels take it from here
     if (!(type_begin[0] <= type_begin[1] && type_begin[1] <= type_begin[2] && type_begin[2] <= type_begin[3])) return fail(IHG_ERR_INVALID, "%s: type ranges not ascending", what);
     if (workspace_bytes < ihg_node_linear_workspace_bytes(dim)) return fail(IHG_ERR_WORKSPACE, "%s: workspace too small", what);
     if (!aligned16(workspace)) return fail(IHG_ERR_INVALID, "%s: workspace not 16-byte aligned", what);
@@ -437,9 +513,13 @@ int ihg_node_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld
                         int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
     if (int rc = node_linear_common_check("ihg_node_linear_fwd", dim, ld_x, ld_out, ld_w, type_begin, workspace, workspace_bytes)) return rc;
     if (type_begin[3] == type_begin[0]) return IHG_OK;
-    if (x == nullptr || w == nullptr || out == nullptr || !aligned16(x)) return fail(IHG_ERR_INVALID, "ihg_node_linear_fwd: null or unaligned pointer");
-    launch_row_gemm(dim, x, ld_x, w, ld_w, w_type_stride, 0, bias, bias_type_mask, bias_type_stride, type_begin, out, ld_out,
-                    static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
+    if (x == nullptr || w == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_linear_fwd: null pointer");
+    if (tiled_node_linear(dim, ld_x, ld_out, x, workspace))
+        launch_row_gemm(dim, x, ld_x, w, ld_w, w_type_stride, 0, bias, bias_type_mask, bias_type_stride, type_begin, out, ld_out,
+                        static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
+    else
+        launch_row_gemm_generic(dim, x, ld_x, w, ld_w, w_type_stride, 0, bias, bias_type_mask, bias_type_stride, type_begin, out, ld_out,
+                                static_cast<hipStream_t>(stream));
     return check_launch("ihg_node_linear_fwd");
 }
 
@@ -448,9 +528,12 @@ int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w
                               int32_t dim, ihg_stream_t stream) {
     if (int rc = node_linear_common_check("ihg_node_linear_bwd_input", dim, ld_dout, ld_dx, ld_w, type_begin, workspace, workspace_bytes)) return rc;
     if (type_begin[3] == type_begin[0]) return IHG_OK;
-    if (dout == nullptr || w == nullptr || dx == nullptr || !aligned16(dout)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_input: null or unaligned pointer");
-    launch_row_gemm(dim, dout, ld_dout, w, ld_w, w_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace),
-                    static_cast<hipStream_t>(stream));
+    if (dout == nullptr || w == nullptr || dx == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_input: null pointer");
+    if (tiled_node_linear(dim, ld_dout, ld_dx, dout, workspace))
+        launch_row_gemm(dim, dout, ld_dout, w, ld_w, w_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace),
+                        static_cast<hipStream_t>(stream));
+    else
+        launch_row_gemm_generic(dim, dout, ld_dout, w, ld_w, w_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<hipStream_t>(stream));
     return check_launch("ihg_node_linear_bwd_input");
 }
 
@@ -459,11 +542,19 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
                                const float* w, int64_t ld_w, float* dx, int64_t ld_dx, int32_t dx_accumulate,
                                void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
     if (int rc = node_linear_common_check("ihg_node_linear_bwd_weight", dim, ld_dout, ld_x, ld_dw, type_begin, workspace, workspace_bytes)) return rc;
-    if (dout == nullptr || x == nullptr || dw == nullptr || !aligned16(dout) || !aligned16(x)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: null or unaligned pointer");
+    if (dout == nullptr || x == nullptr || dw == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: null pointer");
     if (dx != nullptr && (w == nullptr || ld_w < dim || ld_dx < dim)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx needs w and row strides >= dim");
     if (dx_accumulate && (dx == nullptr || dim != 64)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate needs dx and dim 64 (the fused kernel)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_types = dw_type_stride == 0 ? 1 : 3;
+    if (!tiled_node_linear(dim, ld_dout, ld_x, dout, workspace) || !aligned16(x) || (dx != nullptr && ld_dx % 4)) {
+        if (dx != nullptr) launch_row_gemm_generic(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, s);
+        const int64_t total = static_cast<int64_t>(dim) * dim * n_types + dim;
+        hipLaunchKernelGGL(dense_weight_grad_generic_kernel, dim3(static_cast<int>(std::min<int64_t>((total + kBlockThreads - 1) / kBlockThreads, kMaxBlocks))),
+                           dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, make_plan(type_begin, 64), n_types, dim, dw, ld_dw, dw_type_stride, dbias,
+                           bias_type_mask, n_types == 1 ? int64_t{0} : dbias_type_stride);
+        return check_launch("ihg_node_linear_bwd_weight");
+    }
     float* slabs = static_cast<float*>(workspace) + 3LL * dim * dim;
     float* bias_slabs = slabs + 3LL * kDenseSlabs * dim * dim;
     const TypePlan plan = make_plan(type_begin, 64);

@@ -255,7 +255,55 @@ __global__ __launch_bounds__(kBlockThreads) void adam_kernel(AdamTable tab, floa
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// Negative sampling on the device: `random.sample(range(n_items), k)` per positive (Dataset.py:107-109) - k DISTINCT
+// items, uniform over the catalogue, the positive itself not excluded.  Counter-based generator: draw (row, slot, attempt) is a
+// pure function of (seed, batch counter), so a run is reproducible whatever the launch geometry; a repeated item inside a
+// sample is rejected and redrawn (k <= 16, so the check is a register scan).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {                  // splitmix64 finaliser
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+constexpr int kSampleMax = 16;
+
+__global__ __launch_bounds__(kBlockThreads) void sample_negatives_kernel(uint64_t seed, uint64_t counter, int64_t n_rows, int64_t n_items, int k,
+                                                                         int64_t* __restrict__ out) {
+    for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n_rows; row += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        int64_t picked[kSampleMax];
+        const uint64_t key = mix64(seed ^ mix64(counter)) ^ mix64(static_cast<uint64_t>(row) * 0xD1B54A32D192ED03ull);
+        uint64_t attempt = 0;
+#pragma unroll 1
+        for (int slot = 0; slot < k; ++slot) {
+            int64_t item;
+            bool fresh;
+            do {
+                const uint64_t r = mix64(key + (attempt++) * 0x2545F4914F6CDD1Dull);
+                item = static_cast<int64_t>(__umul64hi(r, static_cast<uint64_t>(n_items)));      // uniform on [0, n_items) up to 2^-64 n_items
+                fresh = true;
+                for (int j = 0; j < slot; ++j) fresh = fresh && picked[j] != item;
+            } while (!fresh);
+            picked[slot] = item;
+            out[row * k + slot] = item;
+        }
+    }
+}
+
 extern "C" {
+
+int ihg_sample_negatives(uint64_t seed, uint64_t counter, int64_t n_rows, int64_t n_items, int32_t k, int64_t* out, ihg_stream_t stream) {
+    if (n_rows < 0 || n_items <= 0 || k <= 0 || k > kSampleMax || k > n_items)
+        return fail(IHG_ERR_INVALID, "ihg_sample_negatives: need 1 <= k <= min(%d, n_items)", kSampleMax);
+    if (n_rows == 0) return IHG_OK;
+    if (out == nullptr) return fail(IHG_ERR_INVALID, "ihg_sample_negatives: null pointer");
+    const int grid = static_cast<int>(std::min<int64_t>((n_rows + kBlockThreads - 1) / kBlockThreads, kMaxBlocks));
+    hipLaunchKernelGGL(sample_negatives_kernel, dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), seed, counter, n_rows, n_items, k, out);
+    return check_launch("ihg_sample_negatives");
+}
+
 
 static int hem_common_check(const char* what, const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const int64_t* rows, int64_t batch) {
     if (n_layers < 1 || n_layers > 8) return fail(IHG_ERR_INVALID, "%s: 1..8 layer outputs supported, got %d", what, n_layers);

@@ -332,11 +332,18 @@ def embed_all_nodes(user_table: Tensor, item_table: Tensor, word_table: Tensor, 
 # K4: node-level dense transforms (feature_transform and the hoisted u / q / i blocks of the aggregation)
 # ---------------------------------------------------------------------------------------------
 def node_linear_supported(x: Tensor, w: Tensor) -> bool:
-    """True when the MFMA row-GEMM kernels take this shape (d in {32,64,128,256}, 16-B aligned rows)."""
+    """True when the HIP node-level transform kernels take this input: fp32 GPU rows of any width (d in {32,64,128,256} with
+    16-byte aligned rows runs on the MFMA row-GEMM, everything else on the any-width kernels of the same library)."""
     d = int(x.shape[1])
-    return (x.is_cuda and d in (32, 64, 128, 256) and x.dtype == torch.float32 and w.dtype == torch.float32
-            and x.stride(-1) == 1 and w.stride(-1) == 1 and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
-            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and int(w.shape[0]) == d)
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and w.dtype == torch.float32 and x.stride(-1) == 1 and w.stride(-1) == 1
+            and int(w.shape[0]) == d and int(w.shape[1]) >= d)
+
+
+def node_linear_tiled(x: Tensor, w: Tensor) -> bool:
+    """The MFMA row-GEMM form applies (what the fused one-node interactive path builds on)."""
+    d = int(x.shape[1])
+    return (node_linear_supported(x, w) and d in (32, 64, 128, 256) and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
 def _type_begin(layout: IncidenceLayout):
@@ -554,7 +561,7 @@ class _InteractFromNodes(torch.autograd.Function):
 
 def interact_from_nodes_supported(h: Tensor, w: Tensor) -> bool:
     """The one-node form needs the fused row-GEMM backward (d = 64, aligned rows) and the tiled interact kernels."""
-    return node_linear_supported(h, w) and int(h.shape[1]) == 64 and h.is_contiguous()
+    return node_linear_tiled(h, w) and int(h.shape[1]) == 64 and h.is_contiguous()
 
 
 def interact_from_nodes(h: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, order: int) -> Tensor:
@@ -588,28 +595,24 @@ def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: f
     return rowgrad
 
 
+SCATTER_CHUNK_ROWS = 16384          # rows one ihg_batch_scatter_add launch combines (its id list lives in LDS)
+
+
 def _scatter_rows(rowgrad: Tensor, col0: int, width: int, rows: Tensor, dense: Optional[Tensor], tail: Optional[Tensor] = None, tail_offset: int = 0):
     """``dense[rows[k]] += rowgrad[k, col0 : col0 + width]`` (duplicates combined in a fixed order; deterministic).  With
-    ``tail``: the LAST of the ``width`` columns goes to ``tail[rows[k] - tail_offset]`` instead."""
+    ``tail``: the LAST of the ``width`` columns goes to ``tail[rows[k] - tail_offset]`` instead.  Batches beyond one launch's
+    capacity go through in row chunks, in order (same sums, associated chunk by chunk)."""
     lib = _lib.load()
     n = int(rows.shape[0])
-    src = rowgrad[:, col0:]
     target = dense if dense is not None else tail
     block = int(dense.shape[1]) if dense is not None else 1
-    if lib.ihg_batch_scatter_workspace_bytes(n) >= 0:
-        with profiler.kernel('batch_scatter_add', n, width):
-            _lib.check(lib.ihg_batch_scatter_add(_ptr(src), int(rowgrad.stride(0)), width, _ptr(rows), n, _ptr(target), _ld(target) if dense is not None else 1,
-                                                 block, 0, _ptr(tail), int(tail_offset), int(tail.shape[0]) if tail is not None else 0, _stream()),
-                       'ihg_batch_scatter_add')
-        return
-    # batches beyond the kernel's range: torch's sort-based scatter
-    body = width - (1 if tail is not None else 0)
-    if dense is not None and body > 0:
-        dense.index_put_((rows,), rowgrad[:, col0:col0 + body], accumulate=True)
-    if tail is not None:
-        local = rows - tail_offset
-        keep = (local >= 0) & (local < tail.shape[0])
-        tail.index_put_((local[keep],), rowgrad[:, col0 + width - 1][keep], accumulate=True)
+    for lo in range(0, n, SCATTER_CHUNK_ROWS):
+        hi = min(lo + SCATTER_CHUNK_ROWS, n)
+        src = rowgrad[lo:hi, col0:]
+        with profiler.kernel('batch_scatter_add', hi - lo, width):
+            _lib.check(lib.ihg_batch_scatter_add(_ptr(src), int(rowgrad.stride(0)), width, _ptr(rows[lo:hi]), hi - lo, _ptr(target),
+                                                 _ld(target) if dense is not None else 1, block, 0, _ptr(tail), int(tail_offset),
+                                                 int(tail.shape[0]) if tail is not None else 0, _stream()), 'ihg_batch_scatter_add')
 
 
 def _hem_backward(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float, item_row_offset: int):
@@ -624,14 +627,11 @@ def _hem_backward(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float,
     flat = torch.zeros(n_layers * n_nodes * dim + n_bias, dtype=torch.float32, device=bias.device)
     dense = flat[:n_layers * n_nodes * dim].view(n_layers, n_nodes, dim)
     dbias = flat[n_layers * n_nodes * dim:]
-    if lib.ihg_batch_scatter_workspace_bytes(3 * batch) >= 0:
-        with profiler.kernel('batch_scatter_add', 3 * batch, width + 1):
-            _lib.check(lib.ihg_batch_scatter_add(_ptr(rowgrad), width + 4, width + 1, _ptr(rows), 3 * batch, _ptr(dense), dim, dim, n_nodes * dim,
+    for lo in range(0, 3 * batch, SCATTER_CHUNK_ROWS):        # one launch lands every layer's block and the bias column; big batches in row chunks
+        hi = min(lo + SCATTER_CHUNK_ROWS, 3 * batch)
+        with profiler.kernel('batch_scatter_add', hi - lo, width + 1):
+            _lib.check(lib.ihg_batch_scatter_add(_ptr(rowgrad[lo:hi]), width + 4, width + 1, _ptr(rows[lo:hi]), hi - lo, _ptr(dense), dim, dim, n_nodes * dim,
                                                  _ptr(dbias), int(item_row_offset), n_bias, _stream()), 'ihg_batch_scatter_add')
-    else:
-        for l in range(n_layers):
-            _scatter_rows(rowgrad, l * dim, dim, rows, dense[l])
-        _scatter_rows(rowgrad, width, 1, rows, None, dbias, item_row_offset)
     return dbias, tuple(dense[l] for l in range(n_layers))
 
 

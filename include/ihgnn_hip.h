@@ -321,6 +321,14 @@ int ihg_adam_step(const ihg_adam_tensor* tensors, int32_t n_tensors, float lr, f
                   float weight_decay, int64_t step, ihg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * DEVICE: negative sampling of a training batch.  Replaces `random.sample(range(item_count), k)` per positive in
+ * GraphDataset.__getitem__ (Dataset.py:107-109): out[row][0..k) = k DISTINCT item ids, uniform over [0, n_items), the positive
+ * itself not excluded (as in the reference).  A pure function of (seed, counter, row): the caller advances `counter` per batch.
+ * Not the reference's Mersenne-Twister stream - same distribution, different draws.  k <= 16.
+ */
+int ihg_sample_negatives(uint64_t seed, uint64_t counter, int64_t n_rows, int64_t n_items, int32_t k, int64_t* out, ihg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * DEVICE: evaluation scoring with a running top-k.  Replaces, for `n_pairs` search logs at once, the per-log
  * sequence RawGnn.forward(u * ones(I), q * ones(I), None) (Models/RawGnn.py:124-137) -> HemPredictionLayer.forward
  * (Models/PredictionLayers.py:35-43) -> torch.sort(scores, descending=True)[:10] (Helpers/Metrics.py:60-61):

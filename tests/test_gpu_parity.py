@@ -187,7 +187,7 @@ def test_user_ordered_hyperedge_numbering_is_equivalent():
     assert rel(out_user, out_file[perm]) <= RTOL_SUM
 
 
-@pytest.mark.parametrize('dim', [32, 64, 128, 256])
+@pytest.mark.parametrize('dim', [32, 64, 128, 256, 8, 12, 100])
 @pytest.mark.parametrize('typed', [False, True])
 def test_node_linear_forward_backward(dim, typed):
     """Row-GEMM kernels (feature_transform / hoisted first-order blocks) vs torch CPU autograd."""
@@ -255,7 +255,7 @@ def test_compose_first_order_matches_torch(dim):
         assert rel(g.grad, r.grad) <= RTOL
 
 
-@pytest.mark.parametrize('dim', [32, 64, 128])
+@pytest.mark.parametrize('dim', [32, 64, 128, 12])
 def test_node_linear_with_per_type_bias(dim):
     """Typed weights with one bias vector per node type (the composed first-order layer): forward and all gradients vs torch."""
     from ihgnn_amd import ops
@@ -922,6 +922,20 @@ def test_general_hypergraph_kernels_at_scale():
     assert rel(got, want) <= RTOL_SUM
 
 
+def test_scatter_rows_beyond_one_launch_goes_in_row_chunks():
+    """Batches larger than one ihg_batch_scatter_add launch takes (16,384 rows): ops._scatter_rows feeds it row chunks, in order."""
+    from ihgnn_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    n, width = 40000, 17
+    rows = torch.randint(0, 9000, (n,), generator=gen).to(dev())
+    rowgrad = torch.randn(n, width + 3, generator=gen).to(dev())
+    want = torch.zeros(9000, width, device=dev()).index_put_((rows,), rowgrad[:, 2:2 + width], accumulate=True)
+    got = [torch.zeros(9000, width, device=dev()) for _ in range(2)]
+    for g in got:
+        ops._scatter_rows(rowgrad, 2, width, rows, g)
+    assert rel(got[0], want) <= RTOL_SUM * 2 and torch.equal(got[0], got[1])
+
+
 @pytest.mark.parametrize('n,width', [(1, 5), (77, 33), (3300, 193), (8192, 64), (16384, 300)])
 def test_batch_scatter_add_matches_index_put(n, width):
     """Deterministic sort-free scatter: equals index_put_(accumulate=True), bitwise repeatable with duplicates; plain-matrix
@@ -1096,3 +1110,67 @@ def test_bench_launches_its_own_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['parallelism'] == 'dp2' and line['value'] > 0
     assert 0 < line['roofline']['frac'] <= 1
+
+
+def test_device_negative_sampling_has_random_sample_semantics():
+    """f2: `ihg_sample_negatives` = `random.sample(range(I), k)` per positive (Dataset.py:107-109): k distinct items per row, every
+    item equally likely, the positive not excluded, reproducible from (seed, counter), different for another counter."""
+    import ctypes
+    from ihgnn_amd import _lib
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def draw(seed, counter, rows, items, k):
+        out = torch.empty(rows, k, dtype=torch.int64, device=dev())
+        _lib.check(lib.ihg_sample_negatives(seed, counter, rows, items, k, ctypes.c_void_p(out.data_ptr()), stream), 'ihg_sample_negatives')
+        return out.cpu().numpy()
+
+    a = draw(5, 1, 20000, 50, 10)
+    assert a.min() >= 0 and a.max() < 50
+    assert all(len(set(r)) == 10 for r in a.tolist())                       # without replacement inside a sample
+    counts = np.bincount(a.reshape(-1), minlength=50)
+    expected = a.size / 50
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    assert chi2 < 49 + 6 * np.sqrt(2 * 49)                                  # uniform over the catalogue (chi-square, 49 dof, +6 sigma)
+    np.testing.assert_array_equal(a, draw(5, 1, 20000, 50, 10))             # a pure function of (seed, counter, row)
+    assert (a != draw(5, 2, 20000, 50, 10)).mean() > 0.5 and (a != draw(6, 1, 20000, 50, 10)).mean() > 0.5
+    full = draw(1, 0, 300, 10, 10)                                          # k == I: every sample is a permutation of the catalogue
+    assert all(sorted(r) == list(range(10)) for r in full.tolist())
+    first = draw(9, 9, 100000, 1000, 1)[:, 0]                               # position 0 alone is uniform too
+    c1 = np.bincount(first, minlength=1000)
+    assert ((c1 - 100) ** 2 / 100).sum() < 999 + 6 * np.sqrt(2 * 999)
+    with pytest.raises(_lib.IhgnnHipError):
+        draw(1, 1, 4, 5, 6)                                                 # k > I cannot be distinct
+
+
+def test_device_batches_cover_the_epoch_and_train():
+    """The device-side batch source: every positive exactly once per epoch (also split over two ranks), negatives in range and
+    distinct per positive, tuple layout of collate_fn - and a training epoch driven by it lowers the loss."""
+    from ihgnn_amd import synth
+    from ihgnn_amd.Dataset import DeviceBatchLoader, GraphDataset
+    w = synth.draw(60, 30, 80, 40, 1000, seed=6)
+    ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets, w.triples, device=dev())
+    seen = []
+    for rank in range(2):
+        loader = DeviceBatchLoader(ds, 100, rank, 2)
+        loader.set_epoch(3)
+        batches = list(loader)
+        assert len(batches) == len(loader) == 5
+        for pu, pq, pi, pf, nu, nq, ni, nf in batches:
+            assert pu.is_cuda and len(nu) == 10 * len(pu) and bool((pf == 1).all()) and bool((nf == 0).all())
+            assert torch.equal(nu.view(-1, 10)[:, 0], pu) and torch.equal(nq.view(-1, 10)[:, 3], pq)
+            assert int(ni.min()) >= 0 and int(ni.max()) < 80 and all(len(set(r)) == 10 for r in ni.view(-1, 10).tolist())
+            seen += torch.stack([pu, pq, pi], 1).tolist()
+    assert sorted(seen) == sorted(w.triples.tolist())
+    m = build_model(ds, 'ihgnn', 2, 3, 32)
+    from ihgnn_amd.optim import Adam
+    opt = Adam(m.parameters(), 1e-2)
+    loader = DeviceBatchLoader(ds, 100)
+    losses = []
+    for epoch in range(3):
+        loader.set_epoch(epoch)
+        for pu, pq, pi, pf, nu, nq, ni, nf in loader:
+            loss = m.bce_loss(torch.cat([pu, nu]), torch.cat([pq, nq]), torch.cat([pi, ni]), torch.cat([pf, nf]).float())
+            loss.backward(); opt.step(); opt.zero_grad()
+            losses.append(loss.item())
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
