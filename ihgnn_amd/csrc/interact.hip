@@ -1131,6 +1131,271 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
     store_out(t0 + (n_my - 1) * grid);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Strip kernels for D = 256 (config C5).  A 16-column strip with the whole contraction index would need 256 weight registers, so
+// a workgroup takes a QUARTER of the output columns (blockIdx.y; 4 strips) and splits the contraction index in two: wave = (strip,
+// k-half), 128 weight registers each, partial sums meet in the epilogue (the product rule of the member-gradient kernel is linear
+// in the contracted values, so its partial results simply add).  Tiles of 16 hyperedges (48 KB of member rows per buffer).  The
+// four column quarters of one tile range sit on one XCD (grid.x is a multiple of 8 and workgroups are dealt round-robin by their
+// linear id), so three of the four fetches of a member row hit that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStrip256TE = 16;
+constexpr int kStrip256Grid = 64;           // workgroups per column quarter (x 4 quarters = one per CU)
+
+template <int NBLK>
+__global__ __launch_bounds__(kWsThreads) void interact_fwd_strip256_kernel(
+    const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p, const int32_t* __restrict__ i3,
+    const float* __restrict__ wp, float* __restrict__ out, int64_t ld_out, int64_t n_edges) {
+    constexpr int D = 256, TE = kStrip256TE, CW = 64, KG = D / 16, KGW = KG / 2, OSTRIDE = CW + 4, PIECES = 3 * TE / 8;
+    struct Buffer { float tile[3][TE][D]; };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    __shared__ __attribute__((aligned(16))) float prod[2][2][TE][OSTRIDE];       // [tile parity][k-half]
+    __shared__ int ids[3][3 * TE];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = wave & 3, kpart = wave >> 2;
+    const int cbase = blockIdx.y * CW;
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int64_t grid = gridDim.x;
+    const int n_my = blockIdx.x < n_tiles ? static_cast<int>((n_tiles - blockIdx.x + grid - 1) / grid) : 0;
+    if (n_my == 0) return;
+    const int64_t t0 = blockIdx.x;
+
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wp) + (static_cast<int64_t>(blockIdx.y * 4 + strip) * NBLK * KG + kpart * KGW) * kWave + (tid & 63);
+    v4f wreg[NBLK][KGW];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int gk = 0; gk < KGW; ++gk) wreg[b][gk] = wfrag[(b * KG + gk) * kWave];
+
+    const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u;
+    const char* hbytes = reinterpret_cast<const char*>(h);
+    int tl = tid;
+    auto fetch_ids = [&](int k) {
+        const int lane = tl & 63;
+        if (wave == 0 && lane < 3 * TE) {
+            const int64_t pos = (t0 + k * grid) * (3 * TE) + lane;
+            ids[k % 3][lane] = pos < n_edges * 3 ? i3[pos] : 0;
+        }
+    };
+    auto issue_dma = [&](Buffer& b, int k) {                             // one 1-KiB piece = one member row
+        const int pchunk = tl & 63;
+        const int* idk = ids[k % 3];
+#pragma unroll
+        for (int kk = 0; kk < PIECES; ++kk) {
+            const int x = wave * PIECES + kk, m = x >> 4, row = x & 15;
+            const int node = idk[row * 3 + m];
+            lds_dma16(reinterpret_cast<const float*>(hbytes + static_cast<uint64_t>(static_cast<uint32_t>(node)) * h_row_bytes + ((pchunk ^ row) << 4)),
+                      &b.tile[m][row][0]);
+        }
+    };
+    // epilogue (threads 0-255 = waves 0-3): hyperedge row tid >> 4, columns cbase + 4 (tid & 15) .. + 3
+    v4f first, first_prev, pr[3];
+    auto load_first_order_rows = [&](int k) {
+        const int* idk = ids[k % 3] + (tl >> 4) * 3;
+        const int ecol = cbase + (tl & 15) * 4;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) pr[m] = *reinterpret_cast<const v4f*>(p + static_cast<int64_t>(idk[m]) * ld_p + ecol);
+    };
+    auto write_out = [&](int64_t tile_id, const float (*pimg)[TE][OSTRIDE]) {
+        const int erow = tl >> 4, ecol = (tl & 15) * 4;
+        const int64_t e = tile_id * TE + erow;
+        const v4f sum = (*reinterpret_cast<const v4f*>(&pimg[0][erow][ecol]) + *reinterpret_cast<const v4f*>(&pimg[1][erow][ecol])) + first_prev;
+        if (e < n_edges) edge_row_store(out + e * ld_out + cbase + ecol, sum);
+    };
+
+    fetch_ids(0);
+    if (n_my > 1) fetch_ids(1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue_dma(buf[0], 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const bool late = wave >= 4;                                          // = the second k-half: its service block sits half a phase later
+    for (int k = 0; k < n_my; ++k) {
+        const int64_t tile_id = t0 + k * grid;
+        Buffer& b = buf[k & 1];
+        asm volatile("" : "+v"(tl));
+        const int arow = tl & 15, kq = (tl >> 4) & 3;
+        v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+        int lane_off = (arow * (D * 4) + ((kq ^ arow) << 4)) ^ (kpart * KGW << 6);
+        asm volatile("" : "+v"(lane_off));
+        const char* tbase = reinterpret_cast<const char*>(&b.tile[0][0][0]);
+        auto member_chunk = [&](int m, int gk) { return *reinterpret_cast<const v4f*>(tbase + (lane_off ^ (gk << 6)) + m * TE * (D * 4)); };
+        v4f au = member_chunk(0, 0), aq = member_chunk(1, 0), ai = member_chunk(2, 0);
+#pragma unroll
+        for (int gk = 0; gk < KGW; ++gk) {
+            if (gk == 0 || gk == KGW / 2) {
+                if (late == (gk != 0)) {
+                    if (k + 1 < n_my) issue_dma(buf[(k + 1) & 1], k + 1);
+                    if (!late) {
+                        if (k > 0) write_out(tile_id - grid, prod[(k - 1) & 1]);
+                        load_first_order_rows(k);
+                        if (k + 2 < n_my) fetch_ids(k + 2);
+                    }
+                }
+            }
+            v4f z[4];
+            z[0] = au * aq;
+            z[1] = aq * ai;
+            z[2] = ai * au;
+            z[3] = z[0] * ai;
+            __builtin_amdgcn_sched_barrier(0);
+            if (gk + 1 < KGW) {
+                au = member_chunk(0, gk + 1);
+                aq = member_chunk(1, gk + 1);
+                ai = member_chunk(2, gk + 1);
+            }
+            if (gk == 4 && !late) first = (pr[0] + pr[1]) + pr[2];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bk = 0; bk < NBLK; ++bk)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(z[bk][s2], wreg[bk][gk][s2], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) prod[k & 1][kpart][4 * kq + r][16 * strip + arow] = acc[r];
+        first_prev = first;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    asm volatile("" : "+v"(tl));
+    if (!late) write_out(t0 + (n_my - 1) * grid, prod[(n_my - 1) & 1]);
+}
+
+template <int NBLK>
+__global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip256_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g_out, int64_t n_edges) {
+    constexpr int D = 256, TE = kStrip256TE, CW = 64, KG = D / 16, KGW = KG / 2;
+    struct Buffer {
+        float dtile[TE][D];              // dout rows, whole (the contraction runs over all 256 columns), swizzled
+        float htile[3][TE][CW];          // member rows, this workgroup's column quarter only
+    };
+    __shared__ __attribute__((aligned(16))) Buffer buf[2];
+    __shared__ __attribute__((aligned(16))) float gimg[2][2][3][TE][CW];  // [tile parity][k-half]: partial member gradients
+    __shared__ int ids[3][3 * TE];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = wave & 3, kpart = wave >> 2;
+    const int cbase = blockIdx.y * CW;
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int64_t grid = gridDim.x;
+    const int n_my = blockIdx.x < n_tiles ? static_cast<int>((n_tiles - blockIdx.x + grid - 1) / grid) : 0;
+    if (n_my == 0) return;
+    const int64_t t0 = blockIdx.x;
+
+    const v4f* wfrag = reinterpret_cast<const v4f*>(wq) + (static_cast<int64_t>(blockIdx.y * 4 + strip) * NBLK * KG + kpart * KGW) * kWave + (tid & 63);
+    v4f wreg[NBLK][KGW];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int gk = 0; gk < KGW; ++gk) wreg[b][gk] = wfrag[(b * KG + gk) * kWave];
+
+    const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u;
+    int tl = tid;
+    auto fetch_ids = [&](int k) {
+        const int lane = tl & 63;
+        if (wave == 0 && lane < 3 * TE) {
+            const int64_t pos = (t0 + k * grid) * (3 * TE) + lane;
+            ids[k % 3][lane] = pos < n_edges * 3 ? i3[pos] : 0;
+        }
+    };
+    // 28 pieces per tile: 16 dout rows (1 KiB each) and 12 pieces of 4 member-row quarters (4 x 256 B); piece x = wave + 8 kk
+    auto issue_dma = [&](Buffer& b, int k) {
+        const int64_t tile_id = t0 + k * grid;
+        const int lane = tl & 63;
+        const int* idk = ids[k % 3];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int x = wave + 8 * kk;
+            if (x < TE) {
+                int64_t e = tile_id * TE + x;
+                e = e < n_edges ? e : n_edges - 1;
+                lds_dma16(dout + e * ld_dout + ((lane ^ (x & 15)) << 2), &b.dtile[x][0]);
+            } else if (x < TE + 12) {
+                const int y = x - TE, m = y >> 2, row = 4 * (y & 3) + (lane >> 4);
+                const int node = idk[row * 3 + m];
+                lds_dma16(reinterpret_cast<const float*>(reinterpret_cast<const char*>(h) + static_cast<uint64_t>(static_cast<uint32_t>(node)) * h_row_bytes +
+                                                         (cbase + (lane & 15) * 4) * 4), &b.htile[m][4 * (y & 3)][0]);
+            }
+        }
+    };
+    // finished tile: sum of the two k-halves, 768 16-byte vectors -> threads take idx = tid and tid + 512 (< 768)
+    auto store_out = [&](int64_t tile_id, const float (*img)[3][TE][CW]) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int idx = tl + 512 * half;
+            if (idx < 3 * TE * (CW / 4)) {
+                const int m = idx / (TE * (CW / 4)), row = (idx / (CW / 4)) % TE, c4 = idx % (CW / 4);
+                const v4f v = *reinterpret_cast<const v4f*>(&img[0][m][row][c4 * 4]) + *reinterpret_cast<const v4f*>(&img[1][m][row][c4 * 4]);
+                const int64_t e = tile_id * TE + row;
+                if (e < n_edges) store_stream4(g_out + e * (3 * D) + m * D + cbase + c4 * 4, v);
+            }
+        }
+    };
+
+    fetch_ids(0);
+    if (n_my > 1) fetch_ids(1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    issue_dma(buf[0], 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const bool late = wave >= 4;
+    for (int k = 0; k < n_my; ++k) {
+        Buffer& b = buf[k & 1];
+        asm volatile("" : "+v"(tl));
+        const int arow = tl & 15, kq = (tl >> 4) & 3;
+        const int col = 16 * strip + arow;
+        v4f acc[NBLK];
+#pragma unroll
+        for (int bk = 0; bk < NBLK; ++bk) acc[bk] = v4f{0.f, 0.f, 0.f, 0.f};
+        int lane_off = (arow * (D * 4) + ((kq ^ arow) << 4)) ^ (kpart * KGW << 6);
+        asm volatile("" : "+v"(lane_off));
+        const char* dbase = reinterpret_cast<const char*>(&b.dtile[0][0]);
+        v4f a = *reinterpret_cast<const v4f*>(dbase + lane_off);
+#pragma unroll
+        for (int gk = 0; gk < KGW; ++gk) {
+            if (gk == 0 || gk == KGW / 2) {
+                if (late == (gk != 0)) {
+                    if (k + 1 < n_my) issue_dma(buf[(k + 1) & 1], k + 1);
+                    if (k > 0) store_out(t0 + (k - 1) * grid, gimg[(k - 1) & 1]);
+                    if (k + 2 < n_my) fetch_ids(k + 2);
+                }
+            }
+            const v4f a_now = a;
+            __builtin_amdgcn_sched_barrier(0);
+            if (gk + 1 < KGW) a = *reinterpret_cast<const v4f*>(dbase + (lane_off ^ ((gk + 1) << 6)));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int bk = 0; bk < NBLK; ++bk) acc[bk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_now[s2], wreg[bk][gk][s2], acc[bk], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // product rule on this wave's PARTIAL contractions (it is linear in them): partial member gradients of its (row, column) elements
+        float (*img)[TE][CW] = gimg[k & 1][kpart];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int er = 4 * kq + r;
+            const float hu = b.htile[0][er][col], hq = b.htile[1][er][col], hi = b.htile[2][er][col];
+            const float z_uq = acc[0][r], z_qi = acc[1][r], z_iu = acc[2][r];
+            const float z_uqi = NBLK == 4 ? acc[NBLK - 1][r] : 0.f;
+            img[0][er][col] = z_uq * hq + z_iu * hi + z_uqi * (hq * hi);
+            img[1][er][col] = z_uq * hu + z_qi * hi + z_uqi * (hu * hi);
+            img[2][er][col] = z_qi * hq + z_iu * hu + z_uqi * (hu * hq);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    asm volatile("" : "+v"(tl));
+    store_out(t0 + (n_my - 1) * grid, gimg[(n_my - 1) & 1]);
+}
+
 // Weight gradient in the strip style (D = 128): dW[j][(3+b)d + c] = sum_e dout[e][j] z_b[e][c] - the contraction index is the
 // hyperedge, so the whole [d x NBLK d] gradient of a workgroup's hyperedges stays in accumulators for the entire sweep: wave w owns
 // rows 16 w .. 16 w + 15 and all NBLK * d columns (NBLK * 8 accumulator tiles = 128 VGPRs), there is no per-tile epilogue and
@@ -1520,14 +1785,19 @@ int resident_grid(Kernel kernel) {
 
 // the strip kernels (D = 128) move rows as 16-byte vectors and form addresses as 32 x 32-bit products
 inline bool strip_fwd_ok(int dim, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h) {
-    return dim == 128 && aligned16(p) && aligned16(out) && ld_p % 4 == 0 && ld_out % 4 == 0 && ld_h < (int64_t{1} << 30);
+    return (dim == 128 || dim == 256) && aligned16(p) && aligned16(out) && ld_p % 4 == 0 && ld_out % 4 == 0 && ld_h < (int64_t{1} << 30);
 }
-inline bool strip_bwd_ok(int dim, const float* g, int64_t ld_h) { return dim == 128 && aligned16(g) && ld_h < (int64_t{1} << 30); }
+inline bool strip_bwd_ok(int dim, const float* g, int64_t ld_h) { return (dim == 128 || dim == 256) && aligned16(g) && ld_h < (int64_t{1} << 30); }
 
 template <int NBLK>
 void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* wp,
                               float* out, int64_t ld_out, int64_t n_edges, hipStream_t s) {
     if (strip_fwd_ok(dim, p, ld_p, out, ld_out, ld_h)) {                    // wp is strip-packed (the caller asked strip_fwd_ok too)
+        if (dim == 256) {
+            const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStrip256TE - 1) / kStrip256TE, kStrip256Grid));
+            hipLaunchKernelGGL((interact_fwd_strip256_kernel<NBLK>), dim3(grid, 4), dim3(kWsThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges);
+            return;
+        }
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGrid));
         hipLaunchKernelGGL((interact_fwd_strip_kernel<128, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, p, ld_p, i3, wp, out, ld_out, n_edges);
         return;
@@ -1578,7 +1848,10 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
         hipLaunchKernelGGL((interact_bwd_members_ws_kernel<D, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
     }
     const bool vector_io = aligned16(g) && ld_h < (int64_t{1} << 30);     // the pipelined form stores g as 16-byte vectors
-    if (strip_bwd_ok(dim, g, ld_h)) {                                    // wq is strip-packed
+    if (strip_bwd_ok(dim, g, ld_h) && dim == 256) {                      // wq is strip-packed
+        const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStrip256TE - 1) / kStrip256TE, kStrip256Grid));
+        hipLaunchKernelGGL((interact_bwd_members_strip256_kernel<NBLK>), dim3(grid, 4), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges);
+    } else if (strip_bwd_ok(dim, g, ld_h)) {
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGrid));
         hipLaunchKernelGGL((interact_bwd_members_strip_kernel<128, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges);
     } else

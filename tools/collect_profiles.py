@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Turn what tools/profile_round.sh left under gpurun_out/<tag>/ into the committed summaries under profiles/<round>/.
+
+    python tools/collect_profiles.py gpurun_out/<tag> profiles/r2 <prefix> [--config C3]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+
+def main():
+    src, dst, prefix = sys.argv[1:4]
+    config = sys.argv[sys.argv.index('--config') + 1] if '--config' in sys.argv else 'C3'
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f'{prefix}_kernel_stats.csv'))
+    for name in ('bench_under_rocprof.json', 'bench_default.json'):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, f'{prefix}_{name}'))
+    fetch, write = os.path.join(src, 'pmc_FETCH_SIZE'), os.path.join(src, 'pmc_WRITE_SIZE')
+    if os.path.isdir(fetch) and os.path.isdir(write):
+        here = os.path.dirname(os.path.abspath(__file__))
+        table = json.loads(subprocess.run([sys.executable, os.path.join(here, 'pmc_summary.py'), fetch, write, '--skip', '2'], capture_output=True, text=True, check=True).stdout)
+        bench = json.load(open(os.path.join(src, 'pmc_FETCH_SIZE.json')))
+        out = dict(command='rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline '
+                           '--no-extras --no-kernel-events   (one pass per counter, in situ: every kernel of the training step)',
+                   notes='KiB counters; FETCH_SIZE doubled (gfx950 counts 128-B requests of wide reads as 64 B); both counters sit at the L2 <-> fabric '
+                         'boundary, so Infinity-Cache hits are included: hbm_bytes_per_launch is L2-miss traffic, an upper bound of the HBM bytes',
+                   workload=config, dim=bench['config']['dim'], edges=bench['config']['edges'], kernels=table)
+        for key, v in table.items():
+            if key.startswith('edge_gather_sum_kernel'):
+                out['edge_gather_sum'] = dict(hbm_bytes_per_launch=v['hbm_bytes_per_launch'], avg_us_under_pmc=v['avg_us_under_pmc'])
+        json.dump(out, open(os.path.join(dst, f'pmc_traffic_{config}.json'), 'w'), indent=1)
+        for d, c in ((fetch, 'fetch_size'), (write, 'write_size')):
+            f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
+            shutil.copy(f, os.path.join(dst, f'{prefix}_pmc_{c}.csv'))
+    mf = glob.glob(os.path.join(src, 'pmc_mfma', '**', '*counter_collection.csv'), recursive=True)
+    if mf:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(mf[0])):
+            name = r['Kernel_Name'].replace('(anonymous namespace)::', '')
+            name = (name[5:] if name.startswith('void ') else name).split('(')[0]
+            if 'interact' in name:
+                agg[name][r['Counter_Name']].append((float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
+        out = dict(command='rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 tools/kbench.py --config '
+                           f'{config} --rounds 3 --ops interact', notes='GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs', kernels={})
+        for name, c in agg.items():
+            busy = sum(v for v, _ in c['SQ_VALU_MFMA_BUSY_CYCLES']) / len(c['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024
+            gui = sum(v for v, _ in c['GRBM_GUI_ACTIVE']) / len(c['GRBM_GUI_ACTIVE']) / 8
+            us = sum(t for _, t in c['GRBM_GUI_ACTIVE']) / len(c['GRBM_GUI_ACTIVE'])
+            out['kernels'][name] = dict(mfma_busy_cycles_per_simd=round(busy), gpu_cycles_per_xcd=round(gui), mfma_busy_fraction=round(busy / gui, 4),
+                                        avg_us_under_pmc=round(us, 1), clock_ghz=round(gui / us / 1e3, 3))
+        json.dump(out, open(os.path.join(dst, f'{prefix}_pmc_mfma.json'), 'w'), indent=1)
+        shutil.copy(mf[0], os.path.join(dst, f'{prefix}_pmc_mfma.csv'))
+    print(sorted(os.listdir(dst)))
+
+
+if __name__ == '__main__':
+    main()

@@ -21,11 +21,12 @@ def main():
     ap.add_argument('--dim', type=int, default=0)
     ap.add_argument('--order', type=int, default=3)
     ap.add_argument('--ops', default='k5,k7,interact,linear')
+    ap.add_argument('--scale', type=float, default=1.0)
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     cfg = synth.CONFIGS[args.config]
     d = args.dim or cfg['dim']
-    w = synth.draw_config(args.config)
+    w = synth.draw_config(args.config, scale=args.scale)
     lay = IncidenceLayout(w.triples, w.user_count, w.query_count, w.item_count, dev)
     E, N = lay.edge_count, lay.node_count
     print(f'{args.config}: N={N} E={E} d={d} heavy_rows={lay.node_csr.n_heavy} segments={lay.node_csr.n_segments}')
