@@ -363,7 +363,10 @@ def main():
                         algorithmic_bytes_per_launch=k5_algorithmic, algorithmic_gbs=round(k5_algorithmic / t / 1e9, 1),
                         algorithmic_note='16 d + 12 B per hyperedge (SURVEY §8 d3) counts three row gathers per hyperedge; repeats are served by L2 / '
                                          'Infinity Cache, so this rate is not an HBM rate and may exceed the peak',
-                        traffic=traffic, traffic_gbs=round(traffic / t / 1e9, 1) if traffic else None, traffic_source=traffic_source,
+                        traffic=traffic, traffic_gbs=round(traffic / t / 1e9, 1) if traffic else None,
+                        traffic_frac=round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if traffic else None, traffic_source=traffic_source,
+                        traffic_note='FETCH_SIZE / WRITE_SIZE count at the L2 <-> fabric boundary: L2-miss bytes, Infinity-Cache hits included - an upper '
+                                     'bound of the HBM bytes; traffic above the compulsory bytes = rows re-fetched after leaving L2' if traffic else None,
                         avg_us=round(k5['avg_us'], 2), launches=k5['launches'], hyperedges_per_s=round(E / t, 1),
                         measured='HIP events on the launch stream, inside the timed region')
     mfma_roof = None
