@@ -309,12 +309,157 @@ inline TypePlan make_plan(const int64_t* type_begin, int tile_rows) {
     plan.tile_prefix[3] = acc;
     return plan;
 }
+// ------------------------------------------------------------------------------------------------
+// Row GEMM in the strip style (D = 128), cf. interact.hip: eight waves, wave w owns the 16 output columns 16 w .. with the whole
+// contraction index - its weight fragments (8 float4 = 32 VGPRs per node type) stay in registers, the input rows come in by
+// LDS-DMA (tiles of 64 rows, double-buffered, swizzled for the ds_read_b128 A-operand reads), v_mfma_f32_16x16x4_f32 with four
+// independent accumulator tiles per wave, results leave through an LDS image as whole 16-byte-per-lane rows.  One barrier per
+// tile; the stores of tile k - 1 and the fill of tile k + 1 are issued inside the MFMA phase of tile k, half a phase apart on
+// the two waves of a SIMD.
+// pk_strip[type][strip][g][lane][4]:  transpose == 0:  W_t[16 strip + (lane & 15)][16 g + 4 (lane >> 4) + s]     (out = in * W^T)
+//                                     transpose == 1:  W_t[16 g + 4 (lane >> 4) + s][16 strip + (lane & 15)]     (out = in * W)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads) void pack_dense_strip_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride,
+                                                                         int n_types, int d, int transpose, float* __restrict__ pk) {
+    const int kg = d / 16;
+    const int per_type = (d / 16) * kg * kWave;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < per_type * n_types; idx += gridDim.x * blockDim.x) {
+        const int type = idx / per_type, rem = idx - type * per_type;
+        const int lane = rem & (kWave - 1), g = (rem >> 6) % kg, strip = (rem >> 6) / kg;
+        const int c = lane & 15, kq = lane >> 4;
+        const float* wt = w + type * type_stride;
+        float4 v;
+        if (transpose == 0) {
+            const float* src = wt + static_cast<int64_t>(16 * strip + c) * ld_w + 16 * g + 4 * kq;
+            v = make_float4(src[0], src[1], src[2], src[3]);
+        } else {
+            const float* src = wt + static_cast<int64_t>(16 * g + 4 * kq) * ld_w + 16 * strip + c;
+            v = make_float4(src[0], src[ld_w], src[2 * ld_w], src[3 * ld_w]);
+        }
+        *reinterpret_cast<float4*>(pk + static_cast<int64_t>(idx) * 4) = v;
+    }
+}
+
+__device__ __forceinline__ void dense_lds_dma16(const float* src, float* lds_piece) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+}
+
+template <int D, int TE>
+__global__ __launch_bounds__(512, 4) void row_gemm_strip_kernel(const float* __restrict__ in, int64_t ld_in, const float* __restrict__ pk,
+                                                             int64_t pk_type_stride, const float* __restrict__ bias, int bias_mask,
+                                                             int64_t bias_type_stride, TypePlan plan, float* __restrict__ out, int64_t ld_out) {
+    static_assert(D == 128, "eight 16-column strips");
+    constexpr int RT = TE / 16, KG = D / 16, OSTRIDE = D + 4, PIECES = TE * D * 4 / 1024 / 8;     // DMA pieces per wave per tile (TE = 32: 2)
+    __shared__ __attribute__((aligned(16))) float xt[2][TE][D];
+    __shared__ __attribute__((aligned(16))) float ot[2][TE][OSTRIDE];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total_tiles = plan.tile_prefix[3];
+    const int grid = gridDim.x;
+    const int n_my = static_cast<int>(blockIdx.x) < total_tiles ? (total_tiles - static_cast<int>(blockIdx.x) + grid - 1) / grid : 0;
+    if (n_my == 0) return;
+    auto tile_type = [&](int tile_id) { return tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0); };
+    auto tile_rows = [&](int tile_id, int64_t& r_base, int64_t& r_end) {
+        const int type = tile_type(tile_id);
+        r_base = plan.begin[type] + static_cast<int64_t>(tile_id - plan.tile_prefix[type]) * TE;
+        r_end = plan.begin[type + 1];
+    };
+    int tl = tid;
+    auto issue_dma = [&](int k) {
+        int64_t r_base, r_end;
+        tile_rows(static_cast<int>(blockIdx.x) + k * grid, r_base, r_end);
+        const int prow = (tl >> 5) & 1, pchunk = tl & 31;
+#pragma unroll
+        for (int kk = 0; kk < PIECES; ++kk) {
+            const int r0 = 2 * (wave * PIECES + kk);
+            int64_t v = r_base + r0 + prow;
+            v = v < r_end ? v : r_end - 1;                               // rows past the type's end re-read its last row (never stored)
+            dense_lds_dma16(in + v * ld_in + ((pchunk ^ ((r0 + prow) & 15)) << 2), &xt[k & 1][r0][0]);
+        }
+    };
+    auto store_out = [&](int k) {
+        int64_t r_base, r_end;
+        const int tile_id = static_cast<int>(blockIdx.x) + k * grid;
+        tile_rows(tile_id, r_base, r_end);
+        const int type = tile_type(tile_id);
+        const bool with_bias = bias != nullptr && ((bias_mask >> type) & 1);
+        const int c4 = (tl & 31) * 4;
+        v4f bv = v4f{0.f, 0.f, 0.f, 0.f};
+        if (with_bias) bv = *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + c4);
+#pragma unroll
+        for (int x = 0; x < TE / 16; ++x) {
+            const int row = (tl >> 5) + 16 * x;                          // 512 threads = 16 rows x 32 vectors per pass
+            const v4f v = *reinterpret_cast<const v4f*>(&ot[k & 1][row][c4]) + bv;
+            if (r_base + row < r_end) *reinterpret_cast<v4f*>(out + (r_base + row) * ld_out + c4) = v;
+        }
+    };
+    v4f wreg[KG];
+    int cur_type = -1;
+    issue_dma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool late = wave >= 4;
+    for (int k = 0; k < n_my; ++k) {
+        const int tile_id = static_cast<int>(blockIdx.x) + k * grid;
+        const int type = tile_type(tile_id);
+        if (type != cur_type) {                                           // at most three times per kernel: tiles are ordered by type
+            const v4f* pk4 = reinterpret_cast<const v4f*>(pk + type * pk_type_stride) + static_cast<int64_t>(wave) * KG * kWave + (tid & 63);
+#pragma unroll
+            for (int g = 0; g < KG; ++g) wreg[g] = pk4[g * kWave];
+            cur_type = type;
+        }
+        asm volatile("" : "+v"(tl));
+        const int arow = tl & 15, kq = (tl >> 4) & 3;
+        int lane_off = arow * (D * 4) + ((kq ^ arow) << 4);
+        asm volatile("" : "+v"(lane_off));
+        const char* xbase = reinterpret_cast<const char*>(&xt[k & 1][0][0]);
+        v4f acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            if (g == 0 || g == KG / 2) {
+                if (late == (g != 0)) {
+                    if (k + 1 < n_my) issue_dma(k + 1);                     // that buffer's last reader was tile k - 1
+                    if (k > 0) store_out(k - 1);
+                }
+            }
+            v4f a[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const v4f*>(xbase + (lane_off ^ (g << 6)) + rt * 16 * (D * 4));
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][s2], wreg[g][s2], acc[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ot[k & 1][rt * 16 + 4 * kq + r][16 * wave + arow] = acc[rt][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    asm volatile("" : "+v"(tl));
+    store_out(n_my - 1);
+}
+
 constexpr int kDenseSlabs = 256;
 
 int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose,
                     const float* bias, int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, float* pk,
                     hipStream_t s) {
     const int n_types = w_type_stride == 0 ? 1 : 3;
+    if (dim == 128 && aligned16(out) && ld_out % 4 == 0 && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0))) {
+        const int items = n_types * (dim / 16) * (dim / 16) * kWave;
+        hipLaunchKernelGGL(pack_dense_strip_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride,
+                           n_types, dim, transpose, pk);
+        // tiles of 32 rows, two workgroups per CU (66 KB of LDS each): a pure stream over [N, d] wants bytes in flight more than big tiles
+        const TypePlan plan = make_plan(type_begin, 32);
+        if (plan.tile_prefix[3] == 0) return IHG_OK;
+        hipLaunchKernelGGL((row_gemm_strip_kernel<128, 32>), dim3(std::min(plan.tile_prefix[3], 512)), dim3(512), 0, s, in, ld_in, pk,
+                           n_types == 1 ? int64_t{0} : static_cast<int64_t>(dim) * dim, bias, bias_mask, bias_type_stride, plan, out, ld_out);
+        return IHG_OK;
+    }
     const int pack_items = n_types * (dim / 32) * (dim / 8) * kWave;
     hipLaunchKernelGGL(pack_dense_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride,
                        n_types, dim, transpose, pk);
