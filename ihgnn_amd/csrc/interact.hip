@@ -960,29 +960,52 @@ __global__ __launch_bounds__(kWsThreads) void interact_fwd_strip_kernel(
 // 16-column strip of all NBLK product blocks (NBLK x 2 accumulators), applies the product rule to its own (row, column) elements
 // IN PLACE in the member tile, and - one barrier later, inside the next tile's MFMA phase - streams the rows it will refill out
 // as 16-byte vectors.
-template <int D, int NBLK>
+// UR ("user reduced", needs hyperedges sorted by user - the layout's numbering): the user-slot gradients are NOT written to the
+// member buffer.  Consecutive hyperedges of one user are summed on chip - waves 6 and 7 (one thread per column) walk the user-slot
+// rows of every finished tile in hyperedge order, carrying (user, running sum) in registers from tile to tile, which is why a
+// workgroup then takes a CONTIGUOUS range of tiles - and a finished run goes straight to dh[user]; only the first and the last run
+// of a workgroup's range (which may continue in the neighbours) go to a small boundary table that user_boundary_fixup_kernel adds
+// up in workgroup order.  The member buffer shrinks to [E, 2, d] (query, item): a third less stored here and a third less read by
+// the K7 pass that follows.  Same sums as K7 over the user's incidence list, in the same (hyperedge) order.
+template <int D, int NBLK, bool UR>
 __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
     const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const float* __restrict__ wq,
-    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g_out, int64_t n_edges) {
+    const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ g_out, int64_t n_edges,
+    float* __restrict__ dh_user, int64_t ld_dh, float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user) {
     static_assert(D == 128, "eight 16-column strips");
     constexpr int TE = kStripTE, V4 = D / 4, KG = D / 16, RT = TE / 16;
     constexpr int ROWS_PER_PIECE = kWave / V4;                            // 2
     constexpr int PIECES_PER_MEMBER = TE / ROWS_PER_PIECE;                // 16
-    constexpr int HP = 3 * PIECES_PER_MEMBER / 8;                         // 6 member-row pieces per wave per tile
-    constexpr int DP = PIECES_PER_MEMBER / 8;                             // 2 dout pieces per wave per tile
+    constexpr int NP = UR ? 11 : 8;                                       // DMA pieces per wave per tile: 16 dout + 48 member pieces over 8 (UR: 6) waves
+    // plain: member rows of a tile (3 images) beside its dout rows, double-buffered.  UR: the user-slot image is read by the two walker
+    // waves half a phase after the barrier and over ALL rows, so it cannot be refilled by either of them while the other may still be
+    // walking: it lives in a ring of three of its own (slot = local tile % 3, refilled one phase after it was walked).
+    constexpr int HM = UR ? 2 : 3;
     struct Buffer {
         float dtile[TE][D];
-        float htile[3][TE][D];
+        float htile[HM][TE][D];
     };
     __shared__ __attribute__((aligned(16))) Buffer buf[2];
-    __shared__ int ids[3][3 * TE];                                        // ring over this workgroup's tiles (local tile number % 3)
+    __shared__ __attribute__((aligned(16))) float utile[UR ? 3 : 1][TE][D];
+    auto member_rows = [&](int m, int k) -> float (*)[D] {               // image of member m of local tile k
+        if (UR) return m == 0 ? utile[k % 3] : buf[k & 1].htile[m - 1];
+        return buf[k & 1].htile[m];
+    };
+    __shared__ int ids[4][3 * TE];                                        // ring over this workgroup's tiles (local tile number & 3)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t n_tiles = (n_edges + TE - 1) / TE;
     const int64_t grid = gridDim.x;
-    const int n_my = blockIdx.x < n_tiles ? static_cast<int>((n_tiles - blockIdx.x + grid - 1) / grid) : 0;
-    if (n_my == 0) return;
-    const int64_t t0 = blockIdx.x;
+    // plain: tiles blockIdx.x, + grid, ...;  UR: the contiguous range [blockIdx.x * per, ...) so that a user's run stays in one workgroup
+    const int64_t per = (n_tiles + grid - 1) / grid;
+    const int64_t t0 = UR ? static_cast<int64_t>(blockIdx.x) * per : blockIdx.x;
+    const int64_t t_step = UR ? 1 : grid;
+    const int n_my = UR ? static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(per, n_tiles - t0)))
+                        : (blockIdx.x < n_tiles ? static_cast<int>((n_tiles - blockIdx.x + grid - 1) / grid) : 0);
+    if (n_my == 0) {
+        if (UR && tid == 0) bnd_user[2 * blockIdx.x] = bnd_user[2 * blockIdx.x + 1] = -1;
+        return;
+    }
 
     const v4f* wfrag = reinterpret_cast<const v4f*>(wq) + static_cast<int64_t>(wave) * NBLK * KG * kWave + (tid & 63);
     v4f wreg[NBLK][KG];
@@ -997,50 +1020,111 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
         const int lane = tl & 63;
         if (wave < 2 && (wave == 0 || lane < 32)) {
             const int j = wave * 64 + lane;
-            const int64_t pos = (t0 + k * grid) * (3 * TE) + j;
-            ids[k % 3][j] = pos < n_edges * 3 ? i3[pos] : 0;
+            const int64_t pos = (t0 + k * t_step) * (3 * TE) + j;
+            ids[k & 3][j] = pos < n_edges * 3 ? i3[pos] : 0;
         }
     };
-    auto issue_dma = [&](Buffer& b, int k) {
-        const int64_t tile_id = t0 + k * grid;
+    // Piece kk of this wave: member m (-1: a dout piece, -2: none), rows r0, r0 + 1.  plain: 2 dout + 6 member pieces per wave;
+    // UR: waves 6 and 7 walk the user slot instead and move nothing, waves 0-5 share all 64 pieces (the user image's ring slot of tile
+    // k + 1 was last walked a phase ago, so anybody may refill it).
+    auto piece = [&](int kk, int& m, int& r0) {
+        if (UR) {
+            const int y = kk * 6 + wave;
+            if (wave >= 6 || y >= 4 * PIECES_PER_MEMBER) {
+                m = -2;
+                r0 = 0;
+            } else {
+                m = (y >> 4) - 1;
+                r0 = 2 * (y & (PIECES_PER_MEMBER - 1));
+            }
+        } else if (kk < 2) {
+            m = -1;
+            r0 = 2 * (wave * 2 + kk);
+        } else {
+            const int x = wave * 6 + (kk - 2);
+            m = x >> 4;
+            r0 = 2 * (x & (PIECES_PER_MEMBER - 1));
+        }
+    };
+    auto issue_dma = [&](int k) {
+        Buffer& b = buf[k & 1];
+        const int64_t tile_id = t0 + k * t_step;
         const int prow = (tl >> 5) & 1, pchunk = tl & 31;
         const char* hbytes = reinterpret_cast<const char*>(h) + pchunk * 16;
-        const int* idk = ids[k % 3];
+        const int* idk = ids[k & 3];
 #pragma unroll
-        for (int kk = 0; kk < DP; ++kk) {                                // dout rows: a stream; rows past the end re-read the last one
-            const int r0 = 2 * (wave * DP + kk);
-            int64_t e = tile_id * TE + r0 + prow;
-            e = e < n_edges ? e : n_edges - 1;
-            lds_dma16(dout + e * ld_dout + (pchunk ^ ((r0 + prow) & 15)) * 4, &b.dtile[r0][0]);
-        }
-#pragma unroll
-        for (int kk = 0; kk < HP; ++kk) {
-            const int x = wave * HP + kk;
-            const int r0 = 2 * (x & (PIECES_PER_MEMBER - 1));
-            const int node = idk[(r0 + prow) * 3 + (x >> 4)];
-            lds_dma16(reinterpret_cast<const float*>(hbytes + static_cast<uint64_t>(static_cast<uint32_t>(node)) * h_row_bytes), &b.htile[x >> 4][r0][0]);
+        for (int kk = 0; kk < NP; ++kk) {
+            int m, r0;
+            piece(kk, m, r0);
+            if (m == -2) continue;
+            if (m < 0) {                                                 // dout rows: a stream; rows past the end re-read the last one
+                int64_t e = tile_id * TE + r0 + prow;
+                e = e < n_edges ? e : n_edges - 1;
+                lds_dma16(dout + e * ld_dout + (pchunk ^ ((r0 + prow) & 15)) * 4, &b.dtile[r0][0]);
+            } else {
+                const int node = idk[(r0 + prow) * 3 + m];
+                lds_dma16(reinterpret_cast<const float*>(hbytes + static_cast<uint64_t>(static_cast<uint32_t>(node)) * h_row_bytes), &member_rows(m, k)[r0][0]);
+            }
         }
     };
     // the member-gradient rows of a finished tile: picked up from LDS by the wave that refills exactly these rows (so its own DMA
-    // may follow its own reads without a barrier), then stored as they lie
-    v4f gv[HP];
-    auto pick_up = [&](const Buffer& b) {
-        const int prow = (tl >> 5) & 1, pchunk = tl & 31;
-#pragma unroll
-        for (int kk = 0; kk < HP; ++kk) {
-            const int x = wave * HP + kk;
-            gv[kk] = *reinterpret_cast<const v4f*>(&b.htile[x >> 4][2 * (x & (PIECES_PER_MEMBER - 1)) + prow][pchunk * 4]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // in registers before a DMA may overwrite the rows
-    };
-    auto store_out = [&](int64_t tile_id) {
+    // may follow its own reads without a barrier) and stored as they lie; two batches of four pieces keep the register cost at 16
+    auto stream_out = [&](int k) {
+        const int64_t tile_id = t0 + k * t_step;
         const int prow = (tl >> 5) & 1, pchunk = tl & 31;
         const bool full = tile_id * TE + TE <= n_edges;
 #pragma unroll
-        for (int kk = 0; kk < HP; ++kk) {
-            const int x = wave * HP + kk;
-            const int64_t e = tile_id * TE + 2 * (x & (PIECES_PER_MEMBER - 1)) + prow;
-            if (full || e < n_edges) store_stream4(g_out + e * (3 * D) + (x >> 4) * D + pchunk * 4, gv[kk]);
+        for (int k0 = 0; k0 < NP; k0 += 4) {
+            v4f gv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4 && k0 + kk < NP; ++kk) {
+                int m, r0;
+                piece(k0 + kk, m, r0);
+                if (m >= (UR ? 1 : 0)) gv[kk] = *reinterpret_cast<const v4f*>(&member_rows(m, k)[r0 + prow][pchunk * 4]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4 && k0 + kk < NP; ++kk) {
+                int m, r0;
+                piece(k0 + kk, m, r0);
+                const int64_t e = tile_id * TE + r0 + prow;
+                if (m >= (UR ? 1 : 0) && (full || e < n_edges))
+                    store_stream4(UR ? g_out + e * (2 * D) + (m - 1) * D + pchunk * 4 : g_out + e * (3 * D) + m * D + pchunk * 4, gv[kk]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // every row is in registers (or gone) before a DMA may overwrite it
+    };
+    // UR, waves 6-7: thread -> column; the running sum of the current user's run survives from tile to tile in registers.  The run's
+    // destination row is a (scalar) pointer: dh[user], or - for the first run of the range, which may have begun in the previous
+    // workgroup - the workgroup's first slot of the boundary table.
+    int cur_user = -1, first_user = -1;
+    float run_sum = 0.f;
+    float* run_dst = UR ? bnd_val + (2 * blockIdx.x) * D : nullptr;
+    auto walk_user_slot = [&](int k) {
+        const float (*urows)[D] = utile[k % 3];
+        const int c = tl - 6 * kWave, lane = tl & 63;
+        const int* idk = ids[k & 3];
+        const int64_t e0 = (t0 + k * t_step) * TE;
+        const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - e0));
+        // where the runs start is the same for every column: one ballot over the tile's user ids gives it as a scalar bit mask, so the
+        // per-column walk is straight-line code (one scalar branch per row, taken only where a run ends), all 32 values in flight at once
+        const int r = lane < rows ? lane : rows - 1;
+        const int my_uid = idk[r * 3];
+        const int prev_uid = r == 0 ? cur_user : idk[(r - 1) * 3];
+        const uint64_t new_run = __ballot(lane < rows && my_uid != prev_uid);
+        float v[TE];
+#pragma unroll
+        for (int x = 0; x < TE; ++x) v[x] = x < rows ? urows[x][c] : 0.f;
+#pragma unroll
+        for (int x = 0; x < TE; ++x) {
+            if ((new_run >> x) & 1) {
+                const int user = __builtin_amdgcn_readlane(my_uid, x);
+                if (cur_user >= 0) run_dst[c] = run_sum;                 // the finished run
+                else first_user = user;
+                if (cur_user >= 0) run_dst = dh_user + static_cast<int64_t>(user) * ld_dh;
+                cur_user = user;
+                run_sum = 0.f;
+            }
+            run_sum += v[x];
         }
     };
 
@@ -1049,8 +1133,8 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
     if (n_my > 2) fetch_ids(2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    issue_dma(buf[0], 0);
-    if (n_my > 1) issue_dma(buf[1], 1);
+    issue_dma(0);
+    if (n_my > 1) issue_dma(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -1076,13 +1160,17 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
         for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const v4f*>(dbase + lane_off + rt * 16 * (D * 4));
 #pragma unroll
         for (int gk = 0; gk < KG; ++gk) {
-            if (gk == 0 || gk == KG / 2) {
-                if (late == (gk != 0) && k > 0) {                          // wave-uniform
-                    Buffer& done = buf[(k - 1) & 1];
-                    pick_up(done);
-                    if (k + 1 < n_my) issue_dma(done, k + 1);
-                    store_out(t0 + (k - 1) * grid);
-                    if (k + 2 < n_my) fetch_ids(k + 2);                    // ring slot of tile k - 1, whose ids were last read in phase k - 1... by this wave's own DMA above
+            if (gk == 0 && !late && k > 0) {                               // wave-uniform
+                stream_out(k - 1);
+                if (k + 1 < n_my) issue_dma(k + 1);                        // the buffer tile k - 1 leaves
+                if (k + 2 < n_my) fetch_ids(k + 2);                        // ring slot (k + 2) & 3 = (k - 2) & 3: tile k - 2 is long finished
+            }
+            if (gk == KG / 2 && late && k > 0) {
+                if (UR && wave >= 6) {
+                    walk_user_slot(k - 1);
+                } else {
+                    stream_out(k - 1);
+                    if (k + 1 < n_my) issue_dma(k + 1);
                 }
             }
             v4f a_now[RT];
@@ -1109,26 +1197,63 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int er = rt * 16 + 4 * kq + r;
-                hu[r] = b.htile[0][er][col];
-                hq[r] = b.htile[1][er][col];
-                hi[r] = b.htile[2][er][col];
+                hu[r] = member_rows(0, k)[er][col];
+                hq[r] = member_rows(1, k)[er][col];
+                hi[r] = member_rows(2, k)[er][col];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int er = rt * 16 + 4 * kq + r;
                 const float z_uq = acc[rt][0][r], z_qi = acc[rt][1][r], z_iu = acc[rt][2][r];
                 const float z_uqi = NBLK == 4 ? acc[rt][NBLK - 1][r] : 0.f;
-                b.htile[0][er][col] = z_uq * hq[r] + z_iu * hi[r] + z_uqi * (hq[r] * hi[r]);
-                b.htile[1][er][col] = z_uq * hu[r] + z_qi * hi[r] + z_uqi * (hu[r] * hi[r]);
-                b.htile[2][er][col] = z_qi * hq[r] + z_iu * hu[r] + z_uqi * (hu[r] * hq[r]);
+                member_rows(0, k)[er][col] = z_uq * hq[r] + z_iu * hi[r] + z_uqi * (hq[r] * hi[r]);
+                member_rows(1, k)[er][col] = z_uq * hu[r] + z_qi * hi[r] + z_uqi * (hu[r] * hi[r]);
+                member_rows(2, k)[er][col] = z_qi * hq[r] + z_iu * hu[r] + z_uqi * (hu[r] * hq[r]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     asm volatile("" : "+v"(tl));
-    pick_up(buf[(n_my - 1) & 1]);
-    store_out(t0 + (n_my - 1) * grid);
+    if (UR && wave >= 6) {
+        const int c = tl - 6 * kWave;
+        walk_user_slot(n_my - 1);
+        // The last run of the range may continue in the next workgroup: it goes to the second boundary slot - unless it IS the first
+        // run (a range inside one user's run), which still points at the first slot.
+        const bool one_run = run_dst == bnd_val + (2 * blockIdx.x) * D;
+        if (cur_user >= 0) {
+            if (one_run) run_dst[c] = run_sum;
+            else bnd_val[(2 * blockIdx.x + 1) * D + c] = run_sum;
+        }
+        if (c == 0) {
+            bnd_user[2 * blockIdx.x] = first_user;
+            bnd_user[2 * blockIdx.x + 1] = (cur_user >= 0 && !one_run) ? cur_user : -1;
+        }
+    } else {
+        stream_out(n_my - 1);
+    }
+}
+
+// adds up the boundary runs of interact_bwd_members_strip_kernel<.., UR> in workgroup order: one thread per column
+__global__ __launch_bounds__(128) void user_boundary_fixup_kernel(const float* __restrict__ bnd_val, const int32_t* __restrict__ bnd_user, int n_entries, int d,
+                                                                  float* __restrict__ dh_user, int64_t ld_dh) {
+    const int c = threadIdx.x;
+    if (c >= d) return;
+    int user = -1;
+    float acc = 0.f;
+    for (int k = 0; k < n_entries; ++k) {
+        const int u = bnd_user[k];
+        if (u < 0) continue;
+        const float v = bnd_val[static_cast<int64_t>(k) * d + c];
+        if (u == user) {
+            acc += v;
+        } else {
+            if (user >= 0) dh_user[static_cast<int64_t>(user) * ld_dh + c] = acc;
+            user = u;
+            acc = v;
+        }
+    }
+    if (user >= 0) dh_user[static_cast<int64_t>(user) * ld_dh + c] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1833,7 +1958,8 @@ void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float
 
 template <int NBLK>
 void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* wq, const float* dout, int64_t ld_dout,
-                              float* g, float* slabs, float* dw, int64_t ld_dw, int64_t n_edges, hipStream_t s) {
+                              float* g, float* slabs, float* dw, int64_t ld_dw, int64_t n_edges, hipStream_t s,
+                              float* dh_user = nullptr, int64_t ld_dh = 0, float* bnd_val = nullptr, int32_t* bnd_user = nullptr) {
 #define IHG_MEM(D)                                                                                                          \
     {                                                                                                                       \
         constexpr int TE = D == 32 ? 128 : 64;                                                                              \
@@ -1851,9 +1977,15 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     if (strip_bwd_ok(dim, g, ld_h) && dim == 256) {                      // wq is strip-packed
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStrip256TE - 1) / kStrip256TE, kStrip256Grid));
         hipLaunchKernelGGL((interact_bwd_members_strip256_kernel<NBLK>), dim3(grid, 4), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges);
+    } else if (strip_bwd_ok(dim, g, ld_h) && dh_user != nullptr) {       // user-reduced form: g is [E, 2, d]
+        const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGrid));
+        hipLaunchKernelGGL((interact_bwd_members_strip_kernel<128, NBLK, true>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges,
+                           dh_user, ld_dh, bnd_val, bnd_user);
+        hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(1), dim3(128), 0, s, bnd_val, bnd_user, 2 * grid, dim, dh_user, ld_dh);
     } else if (strip_bwd_ok(dim, g, ld_h)) {
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGrid));
-        hipLaunchKernelGGL((interact_bwd_members_strip_kernel<128, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges);
+        hipLaunchKernelGGL((interact_bwd_members_strip_kernel<128, NBLK, false>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges,
+                           static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
     } else
     switch (dim) {
         case 32:
@@ -1933,7 +2065,38 @@ int64_t ihg_interact_bwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t o
     (void)n_edges;
     if (!mfma_dim(dim) || (order != 2 && order != 3)) return 0;
     const int64_t w_floats = packed_weight_floats(dim, order);
-    return (w_floats + static_cast<int64_t>(weight_slabs(dim)) * w_floats) * static_cast<int64_t>(sizeof(float));
+    const int64_t boundary = dim == 128 ? (2LL * kPipeGrid * dim + 2LL * kPipeGrid) : 0;      // user-reduced form: boundary runs + their users
+    return (w_floats + static_cast<int64_t>(weight_slabs(dim)) * w_floats + boundary) * static_cast<int64_t>(sizeof(float));
+}
+
+int32_t ihg_interact_bwd_user_reduced_supported(int32_t dim, int32_t order, int64_t ld_h) {
+    return dim == 128 && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_h < (int64_t{1} << 30) ? 1 : 0;
+}
+
+int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
+                                  const float* dout, int64_t ld_dout, float* g2, float* dh, int64_t ld_dh, float* dw, int64_t ld_dw,
+                                  void* workspace, int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream) {
+    if (!ihg_interact_bwd_user_reduced_supported(dim, order, ld_h)) return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced: shape not supported (ask ihg_interact_bwd_user_reduced_supported)");
+    const int k = order == 3 ? 7 : 6;
+    if (n_edges <= 0 || ld_h < dim || ld_dout < dim || ld_dh < dim || ld_w < static_cast<int64_t>(k) * dim || ld_dw < static_cast<int64_t>(k) * dim)
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced: bad size");
+    if (h == nullptr || i3 == nullptr || w == nullptr || dout == nullptr || g2 == nullptr || dh == nullptr || dw == nullptr || workspace == nullptr)
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced: null pointer");
+    if (ld_w % 4 || ld_dout % 4 || !aligned16(h) || !aligned16(w) || !aligned16(dout) || !aligned16(g2) || !aligned16(workspace))
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced: rows must be 16-byte aligned");
+    if (workspace_bytes < ihg_interact_bwd_workspace_bytes(n_edges, dim, order)) return fail(IHG_ERR_WORKSPACE, "ihg_interact_bwd_user_reduced: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblk = order == 3 ? 4 : 3;
+    float* wq = static_cast<float*>(workspace);
+    float* slabs = wq + packed_weight_floats(dim, order);
+    float* bnd_val = slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order);
+    int32_t* bnd_user = reinterpret_cast<int32_t*>(bnd_val + 2LL * kPipeGrid * dim);
+    const int pack_items = (dim / 16) * nblk * (dim / 16) * kWave;
+    hipLaunchKernelGGL(pack_weights_strip_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk,
+                       static_cast<float*>(nullptr), wq);
+    if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user);
+    else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user);
+    return check_launch("ihg_interact_bwd_user_reduced");
 }
 
 int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,

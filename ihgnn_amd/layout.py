@@ -184,6 +184,11 @@ class IncidenceLayout:
         slot_of_node[u + q:] = 2
         slot_of_entry = np.repeat(slot_of_node, lens)
         self.member_csr = self.node_csr.with_ids(edge_ids[:3 * e] * 3 + slot_of_entry)
+        # user-reduced form of the interactive backward (ihg_interact_bwd_user_reduced): the kernel sums the user slot on chip, so the
+        # member buffer is [E, 2, d] (query, item) and only query / item nodes have lists: row of (node v, hyperedge e) = 2 e + type(v) - 1
+        self.user_sorted = bool(e == 0 or (np.diff(i3[:e, 0]) >= 0).all())
+        self._member_qi = None
+        self._rowptr_host, self._edge_ids_host, self._slot_of_entry = rowptr, edge_ids[:3 * e], slot_of_entry
         # hop2_csr: node v -> the OTHER two members of each of its hyperedges (2 ids per incidence); together with
         # self_weight = deg(v) for the node's own row it is the two-hop operator H H^T, read straight from the node table.
         inc = i3[:e][edge_ids[:3 * e]]                                   # [3E, 3] members of every incident hyperedge
@@ -194,6 +199,22 @@ class IncidenceLayout:
         self.hop2_csr = Csr((rowptr.astype(np.int64) * 2).astype(np.int32), others, device, heavy_threshold)
         self.self_weight = torch.where(isolated, torch.zeros_like(deg), deg).to(device)
 
+
+    def member_csr_qi(self):
+        """``(Csr, rows)``: the member lists of the query and item nodes over an ``[E, 2, d]`` buffer (user rows are empty) and the
+        int32 device list of those nodes, longest list first - what K7 walks after ``ihg_interact_bwd_user_reduced``."""
+        if self._member_qi is None:
+            u, n = self.user_count, self.node_count
+            ptr = self._rowptr_host.astype(np.int64)
+            first = ptr[u]
+            ptr2 = np.zeros(n + 1, np.int64)
+            ptr2[u:] = ptr[u:] - first
+            ids2 = self._edge_ids_host[first:].astype(np.int64) * 2 + (self._slot_of_entry[first:].astype(np.int64) - 1)
+            csr = Csr(ptr2.astype(np.int32), ids2.astype(np.int32), self.device, self.node_csr.heavy_threshold)
+            lens = np.diff(ptr2)[u:]
+            rows = (u + np.argsort(-lens, kind='stable')).astype(np.int32)
+            self._member_qi = (csr, torch.from_numpy(rows).to(self.device))
+        return self._member_qi
 
     def member_csr_chunks(self, n_chunks: int):
         """``[(e0, e1, Csr)]``: the member lists of ``member_csr`` cut by hyperedge range, ids rebased to the chunk

@@ -451,6 +451,8 @@ def node_linear(x: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceL
 # ---------------------------------------------------------------------------------------------
 # the [E, 3, d] member-gradient buffer of the interactive backward is produced in hyperedge chunks beyond this many bytes
 MEMBER_BUFFER_LIMIT_BYTES = 48 << 30
+import os as _os
+USER_REDUCED_BACKWARD = _os.environ.get('IHG_USER_REDUCED', '1') != '0'      # use ihg_interact_bwd_user_reduced where the library offers it (tests compare the two forms)
 
 
 def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: IncidenceLayout, order: int, dw: Tensor) -> Tensor:
@@ -460,6 +462,22 @@ def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: Incidence
     lib = _lib.load()
     n_edges, dim = layout.edge_count, int(h.shape[1])
     n_chunks = max(1, -(-(n_edges * 3 * dim * 4) // MEMBER_BUFFER_LIMIT_BYTES))
+    if (n_chunks == 1 and USER_REDUCED_BACKWARD and n_edges > 0 and getattr(layout, 'user_sorted', False)
+            and lib.ihg_interact_bwd_user_reduced_supported(dim, order, _ld(h)) and h.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and _ld(w) % 4 == 0 and _ld(grad_out) % 4 == 0 and grad_out.data_ptr() % 16 == 0):
+        # hyperedges are numbered by user: the kernel sums the user slot on chip and writes dh[users] itself; only the query and item
+        # slots go through the member buffer ([E, 2, d]) and the K7 pass
+        csr_qi, qi_rows = layout.member_csr_qi()
+        g2 = torch.empty(n_edges, 2 * dim, dtype=torch.float32, device=h.device)
+        dh = torch.empty(layout.node_count, dim, dtype=torch.float32, device=h.device)
+        dh[:layout.user_count].zero_()                             # users without hyperedges are not written by the kernel
+        ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
+        with profiler.kernel('interact_bwd', n_edges, dim):
+            _lib.check(lib.ihg_interact_bwd_user_reduced(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(grad_out), _ld(grad_out), _ptr(g2),
+                                                         _ptr(dh), dim, _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4, n_edges, dim, _stream()),
+                       'ihg_interact_bwd_user_reduced')
+        node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients')
+        return dh
     if n_chunks == 1:
         parts = [(0, n_edges, layout.member_csr)]
     else:

@@ -211,6 +211,18 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3,
                      void* workspace, int64_t workspace_bytes,
                      int64_t n_edges, int32_t dim, ihg_stream_t stream);
 
+/* The same backward with the USER slot of the member gradients reduced on chip (hyperedges must be numbered so that i3[:,0] is
+ * non-decreasing, i.e. sorted by user, as ihgnn_amd's layout numbers them): g2 is [n_edges, 2, dim] (query slot, item slot) and
+ * rows [0, n_users) of dh receive, for every user with hyperedges, the sum of its user-slot gradients in hyperedge order - exactly
+ * what ihg_node_segment_sum over the user's incidence list would have produced from the [n_edges, 3, dim] buffer.  Rows of users
+ * without hyperedges are not written (pre-zero them).  A third less written here and a third less read by the K7 pass over g2.
+ * Available where ihg_interact_bwd_user_reduced_supported says so (dim 128); workspace as for ihg_interact_bwd.
+ */
+int32_t ihg_interact_bwd_user_reduced_supported(int32_t dim, int32_t order, int64_t ld_h);
+int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
+                                  const float* dout, int64_t ld_dout, float* g2, float* dh, int64_t ld_dh, float* dw, int64_t ld_dw,
+                                  void* workspace, int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * DEVICE: node-level dense transforms (K4 and the hoisted first-order blocks of K6).
  * Replaces nn.Linear(d, d) `feature_transform` (Models/GnnLayers.py:145, 224) and the u / q / i column blocks of

@@ -341,6 +341,37 @@ def test_interact_persistent_tiles_and_strided_rows(dim, order, edges):
     assert rel(hg.grad, hc.grad) <= RTOL and rel(wg.grad, wc.grad) <= RTOL
 
 
+@pytest.mark.parametrize('order,edges,users', [(3, 700 * 32 + 5, 301), (2, 300 * 32, 7), (3, 40, 3), (3, 9000, 5000)])
+def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, monkeypatch):
+    """d = 128 with hyperedges numbered by user: the member-gradient kernel sums the user slot on chip (runs inside a tile, across
+    tiles, across workgroups - 7 users over 9,600 hyperedges put one user's run in several workgroups - users without hyperedges)
+    and writes dh[users] itself, the [E, 2, d] buffer carries the other two slots.  Against the oracle and against the [E, 3, d] form."""
+    from ihgnn_amd import ops
+    from oracle import ihgnn_ref as ref
+    dim, Q, I = 128, 17, 211
+    w_, lay = make_layout(users, Q, I, edges, seed=order + edges, edge_order='user')
+    assert lay.user_sorted
+    gen = torch.Generator().manual_seed(edges)
+    h = torch.randn(lay.node_count, dim, generator=gen)
+    k = 6 if order == 2 else 7
+    w = torch.randn(dim, k * dim, generator=gen) / np.sqrt(k * dim)
+    p = torch.randn(lay.node_count, dim, generator=gen)
+    cot = torch.randn(lay.edge_count, dim, generator=gen) / 8
+    grads = {}
+    for reduced in (True, False):
+        monkeypatch.setattr(ops, 'USER_REDUCED_BACKWARD', reduced)
+        hg, pg, wg = (t.clone().to(dev()).requires_grad_(True) for t in (h, p, w))
+        ops.interact(hg, pg, wg, lay, order).backward(cot.to(dev()))
+        grads[reduced] = (hg.grad, wg.grad)
+    assert rel(grads[True][0], grads[False][0]) <= RTOL_SUM and torch.equal(grads[True][1], grads[False][1])
+    hc, wc = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    wz = torch.cat([torch.zeros(dim, 3 * dim), wc[:, 3 * dim:]], 1)
+    ref.feature_interactor(hc, torch.from_numpy(lay.i3_host.astype(np.int64)), wz, torch.zeros(dim), order).backward(cot)
+    assert rel(grads[True][0], hc.grad) <= RTOL and rel(grads[True][1][:, 3 * dim:], wc.grad[:, 3 * dim:]) <= RTOL
+    isolated = torch.from_numpy(np.diff(lay.node_csr.ptr_host)[:users] == 0)
+    assert bool((grads[True][0][:users][isolated.to(dev())] == 0).all())
+
+
 @pytest.mark.parametrize('dim', [12, 64, 128, 256])
 def test_interact_backward_in_hyperedge_chunks(dim, monkeypatch):
     """The [E, 3, d] member-gradient buffer produced in three hyperedge chunks (what config C5 needs on one GPU): gradients
