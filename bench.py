@@ -169,6 +169,8 @@ def k7_roles(table, E, N, dim, layout, table_steps):
         'k7.edges_to_nodes': (E, 3 * E, 12 * E, 'forward of the interactive layer: [E,d] hyperedge features -> [N,d] (x Dv^-1)'),
         'k7.first_order_gradient': (E, 3 * E, 12 * E, 'backward: [E,d] cotangent -> d P0 [N,d]'),
         'k7.member_gradients': (3 * E, 3 * E, 12 * E, 'backward: [E,3,d] member gradients -> d H [N,d] (every row read exactly once)'),
+        'k7.member_gradients_rows': (2 * E, 2 * E, 8 * E, 'backward: [E,2,d] query / item member gradients -> d H rows of queries and items (the user slot '
+                                                          'was summed on chip by the member-gradient kernel); every row read exactly once'),
         'k7.two_hop': (N, 6 * E + N, 24 * E, 'first-order layer forward: node table -> node table over hop2_csr (no [E,d] intermediate)'),
         'k7.two_hop_bwd': (N, 6 * E + N, 24 * E, 'first-order layer backward (same operator, scalings swapped)'),
         'k7.edges_to_nodes_bwd_of_k5': (E, 3 * E, 12 * E, 'backward of a K5 launch'),
