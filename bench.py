@@ -301,7 +301,7 @@ def main():
     kernels = profiler.summary() if not args.no_kernel_events else {}
     final_loss = float(last.item())
 
-    table, table_steps, restricted_elapsed, fwd_elapsed, stress = {}, min(args.steps, 5), None, None, None
+    table, table_steps, restricted_elapsed, fwd_elapsed, stress, eval_stats = {}, min(args.steps, 5), None, None, None, None
     if not args.no_extras:
         # per-kernel table (K7 roles, MFMA kernels): a second, untimed pass over the same batches with every launch bracketed
         if not args.no_kernel_events:
@@ -334,6 +334,26 @@ def main():
             torch.cuda.synchronize()
             fwd_elapsed = (time.perf_counter() - t1) / n_f
         stress = gather_stress(dev) if rank == 0 else None
+        # evaluation: cached propagation + fused scoring / running top-10 of 4,096 (user, query) pairs against every item
+        eval_stats = None
+        if rank == 0:
+            with torch.no_grad():
+                model.save_features_for_test()
+                rng = np.random.default_rng(3)
+                eu = torch.from_numpy(rng.integers(0, w.user_count, 4096)).to(dev)
+                eq = torch.from_numpy(rng.integers(0, w.query_count, 4096)).to(dev)
+                model.top_items(eu, eq)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for _ in range(3):
+                    model.top_items(eu, eq)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t3) / 3
+                model.clear_saved_feature()
+            flops = 2.0 * 4096 * dim * (layers + 1) * w.item_count
+            eval_stats = dict(pairs=4096, items=w.item_count, width=dim * (layers + 1), ms=round(1e3 * dt, 3), logs_per_s=round(4096 / dt, 1),
+                              tflops=round(flops / dt / 1e12, 1), frac_of_f32_mfma_peak=round(flops / dt / 1e12 / MFMA_F32_PEAK_TF, 4),
+                              kernel='ihg_score_topk: fp32-MFMA HEM scores of every (pair, item) + running top-10 per pair, no [pairs, items] matrix')
 
     if rank != 0:
         if world > 1:
@@ -412,6 +432,8 @@ def main():
         out['fwd_only_ms'] = round(1e3 * fwd_elapsed, 4)
     if stress is not None:
         out['roofline_gather_stress'] = stress
+    if eval_stats is not None:
+        out['evaluation_top10'] = eval_stats
     if table:
         out['kernels_us'] = {name: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] / table_steps} for name, v in table.items()}
         out['kernels_us_note'] = f'HIP events around every launch, {table_steps} untimed steps after the timed region; the timed region brackets K5 only'
