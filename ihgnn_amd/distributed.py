@@ -147,8 +147,15 @@ class BucketedGradientSync(GradientSync):
         piece = self.flat[begin:end]
         if self._use_avg is None:
             self._use_avg = dist.get_backend(self.group) == 'nccl'
-        op = dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM
-        self._works.append((dist.all_reduce(piece, op=op, group=self.group, async_op=True), piece))
+        work = None
+        if self._use_avg:
+            try:
+                work = dist.all_reduce(piece, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            except (RuntimeError, ValueError):               # a build without ncclAvg says so before anything is enqueued
+                self._use_avg = False
+        if work is None:
+            work = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append((work, piece, self._use_avg))
         self._launched[index] = True
 
     def _on_grad(self, p) -> None:
@@ -168,9 +175,9 @@ class BucketedGradientSync(GradientSync):
         for index in range(len(self.buckets)):               # buckets whose hooks did not all fire (unused parameters, detached views)
             if not self._launched[index]:
                 self._launch(index)
-        for work, piece in self._works:
+        for work, piece, averaged in self._works:
             work.wait()                                      # the current stream waits for the collective; the host does not
-            if not self._use_avg:
+            if not averaged:
                 piece.div_(self.world_size)
         self._arm()
 
