@@ -1,6 +1,7 @@
 // interact.hip - the interactive (order 2 / 3) node -> hyperedge step and its backward on the matrix cores (exact fp32 MFMA),
 // plus the one-thread-per-output kernels that take every other shape.
 #include "common.hpp"
+#include "split.hpp"
 
 namespace {
 
@@ -1959,7 +1960,8 @@ void launch_interact_fwd_mfma(int dim, const float* h, int64_t ld_h, const float
 template <int NBLK>
 void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* wq, const float* dout, int64_t ld_dout,
                               float* g, float* slabs, float* dw, int64_t ld_dw, int64_t n_edges, hipStream_t s,
-                              float* dh_user = nullptr, int64_t ld_dh = 0, float* bnd_val = nullptr, int32_t* bnd_user = nullptr) {
+                              float* dh_user = nullptr, int64_t ld_dh = 0, float* bnd_val = nullptr, int32_t* bnd_user = nullptr,
+                              const float* w_raw = nullptr, int64_t ld_w = 0, void* planes = nullptr) {
 #define IHG_MEM(D)                                                                                                          \
     {                                                                                                                       \
         constexpr int TE = D == 32 ? 128 : 64;                                                                              \
@@ -1977,6 +1979,10 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     if (strip_bwd_ok(dim, g, ld_h) && dim == 256) {                      // wq is strip-packed
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStrip256TE - 1) / kStrip256TE, kStrip256Grid));
         hipLaunchKernelGGL((interact_bwd_members_strip256_kernel<NBLK>), dim3(grid, 4), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges);
+    } else if (planes != nullptr && split_members_ok(dim, NBLK == 4 ? 3 : 2, g, ld_h, ld_dout, dout)) {   // bf16-split contraction, either form of g
+        int entries = 0;
+        launch_members_split(h, ld_h, i3, w_raw, ld_w, planes, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, &entries, s);
+        if (dh_user != nullptr) hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(1), dim3(128), 0, s, bnd_val, bnd_user, entries, dim, dh_user, ld_dh);
     } else if (strip_bwd_ok(dim, g, ld_h) && dh_user != nullptr) {       // user-reduced form: g is [E, 2, d]
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGrid));
         hipLaunchKernelGGL((interact_bwd_members_strip_kernel<128, NBLK, true>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges,
@@ -2066,7 +2072,7 @@ int64_t ihg_interact_bwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t o
     if (!mfma_dim(dim) || (order != 2 && order != 3)) return 0;
     const int64_t w_floats = packed_weight_floats(dim, order);
     const int64_t boundary = dim == 128 ? (2LL * kPipeGrid * dim + 2LL * kPipeGrid) : 0;      // user-reduced form: boundary runs + their users
-    return (w_floats + static_cast<int64_t>(weight_slabs(dim)) * w_floats + boundary) * static_cast<int64_t>(sizeof(float));
+    return (w_floats + static_cast<int64_t>(weight_slabs(dim)) * w_floats + boundary + split_plane_floats(dim, order)) * static_cast<int64_t>(sizeof(float));
 }
 
 int32_t ihg_interact_bwd_user_reduced_supported(int32_t dim, int32_t order, int64_t ld_h) {
@@ -2091,10 +2097,11 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
     float* slabs = wq + packed_weight_floats(dim, order);
     float* bnd_val = slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order);
     int32_t* bnd_user = reinterpret_cast<int32_t*>(bnd_val + 2LL * kPipeGrid * dim);
+    void* planes = bnd_user + 2LL * kPipeGrid;
     const int pack_items = (dim / 16) * nblk * (dim / 16) * kWave;
     hipLaunchKernelGGL(pack_weights_strip_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk,
                        static_cast<float*>(nullptr), wq);
-    if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user);
+    if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes);
     else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user);
     return check_launch("ihg_interact_bwd_user_reduced");
 }
@@ -2123,7 +2130,9 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const floa
         else
             hipLaunchKernelGGL(pack_weights_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk,
                                static_cast<float*>(nullptr), wq);
-        if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s);
+        // the bf16 planes of the split contraction sit behind the boundary table (only d = 128 has either)
+        void* planes = dim == 128 ? static_cast<void*>(slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order) + 2LL * kPipeGrid * dim + 2LL * kPipeGrid) : nullptr;
+        if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s, nullptr, 0, nullptr, nullptr, w, ld_w, planes);
         else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s);
         return check_launch("ihg_interact_bwd");
     }

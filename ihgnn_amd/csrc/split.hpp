@@ -1,0 +1,19 @@
+// split.hpp - internal interface of interact_split.hip: the interactive step's contractions for d = 128, order 3, with every fp32
+// operand taken apart EXACTLY into three bf16 terms (x = hi + mid + lo) and the products accumulated in fp32 on the bf16 matrix
+// pipe.  Not part of the C ABI: interact.hip chooses between these and its fp32-MFMA kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#define IHG_INTERNAL __attribute__((visibility("hidden")))
+
+// floats of workspace the weight planes of one direction take (three bf16 per weight)
+IHG_INTERNAL int64_t split_plane_floats(int dim, int order);
+IHG_INTERNAL bool split_arith_enabled();                       // IHG_INTERACT_ARITH != "f32"
+IHG_INTERNAL bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout);
+
+// member gradients; dh_user == nullptr: g is [E, 3, d], else the user-reduced form (g is [E, 2, d], boundary table as in interact.hip)
+IHG_INTERNAL void launch_members_split(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
+                                       int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
+                                       int* n_boundary_entries, hipStream_t s);
