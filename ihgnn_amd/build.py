@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(CSRC, 'libihgnn_hip.so')
-SOURCES = [os.path.join(CSRC, name) for name in ('host.hip', 'aggregate.hip', 'interact.hip', 'interact_split.hip', 'dense.hip', 'tail.hip', 'eval.hip')]
+SOURCES = [os.path.join(CSRC, name) for name in ('host.hip', 'aggregate.hip', 'interact.hip', 'split_arith.hip', 'dense.hip', 'tail.hip', 'eval.hip')]
 HEADERS = [os.path.join(REPO, 'include', 'ihgnn_hip.h'), os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'split.hpp')]
 ARCH = 'gfx950'
 

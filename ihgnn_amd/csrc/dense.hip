@@ -1,6 +1,7 @@
 // dense.hip - node-level dense transforms (feature_transform and the hoisted first-order blocks): typed row GEMM, its input
 // gradient and its weight / bias gradient.
 #include "common.hpp"
+#include "split.hpp"
 
 namespace {
 
@@ -449,6 +450,11 @@ int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int
                     const float* bias, int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, float* pk,
                     hipStream_t s) {
     const int n_types = w_type_stride == 0 ? 1 : 3;
+    if (split_row_gemm_ok(dim, out, ld_out, bias, bias_type_stride)) {   // the bf16 planes sit behind the slabs (see ihg_node_linear_workspace_bytes)
+        void* planes = pk + 3LL * dim * dim + 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
+        launch_row_gemm_split(in, ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin, out, ld_out, planes, s);
+        return IHG_OK;
+    }
     if (dim == 128 && aligned16(out) && ld_out % 4 == 0 && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0))) {
         const int items = n_types * (dim / 16) * (dim / 16) * kWave;
         hipLaunchKernelGGL(pack_dense_strip_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride,
@@ -638,7 +644,7 @@ int64_t ihg_node_linear_workspace_bytes(int32_t dim) {
     if (!mfma_dim(dim)) return 0;                           // any-width kernels: no packed weights, no slabs
     const int64_t packed = 3LL * dim * dim;
     const int64_t slabs = 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
-    return (packed + slabs) * static_cast<int64_t>(sizeof(float));
+    return (packed + slabs + split_dense_plane_floats(dim)) * static_cast<int64_t>(sizeof(float));
 }
 
 static int node_linear_common_check(const char* what, int32_t dim, int64_t ld_a, int64_t ld_b, int64_t ld_w, const int64_t* type_begin,

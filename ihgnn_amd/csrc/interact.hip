@@ -1235,26 +1235,28 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
     }
 }
 
-// adds up the boundary runs of interact_bwd_members_strip_kernel<.., UR> in workgroup order: one thread per column
+// Adds up the boundary runs of the user-reduced member-gradient kernels in workgroup order.  One workgroup per table entry: the entry
+// that opens a user's run (the valid entry before it belongs to another user) walks on while the following entries carry the same
+// user - nearly always one or two - and writes dh[user]; every other workgroup leaves at once.  Same order of additions as a single
+// walk over the table.
 __global__ __launch_bounds__(128) void user_boundary_fixup_kernel(const float* __restrict__ bnd_val, const int32_t* __restrict__ bnd_user, int n_entries, int d,
                                                                   float* __restrict__ dh_user, int64_t ld_dh) {
-    const int c = threadIdx.x;
-    if (c >= d) return;
-    int user = -1;
-    float acc = 0.f;
-    for (int k = 0; k < n_entries; ++k) {
+    const int k0 = blockIdx.x, c = threadIdx.x;
+    const int user = bnd_user[k0];
+    if (user < 0 || c >= d) return;
+    for (int k = k0 - 1; k >= 0; --k) {
+        const int u = bnd_user[k];
+        if (u == user) return;                    // an earlier entry opens this run
+        if (u >= 0) break;
+    }
+    float acc = bnd_val[static_cast<int64_t>(k0) * d + c];
+    for (int k = k0 + 1; k < n_entries; ++k) {
         const int u = bnd_user[k];
         if (u < 0) continue;
-        const float v = bnd_val[static_cast<int64_t>(k) * d + c];
-        if (u == user) {
-            acc += v;
-        } else {
-            if (user >= 0) dh_user[static_cast<int64_t>(user) * ld_dh + c] = acc;
-            user = u;
-            acc = v;
-        }
+        if (u != user) break;
+        acc += bnd_val[static_cast<int64_t>(k) * d + c];
     }
-    if (user >= 0) dh_user[static_cast<int64_t>(user) * ld_dh + c] = acc;
+    dh_user[static_cast<int64_t>(user) * ld_dh + c] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1982,12 +1984,12 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     } else if (planes != nullptr && split_members_ok(dim, NBLK == 4 ? 3 : 2, g, ld_h, ld_dout, dout)) {   // bf16-split contraction, either form of g
         int entries = 0;
         launch_members_split(h, ld_h, i3, w_raw, ld_w, planes, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, &entries, s);
-        if (dh_user != nullptr) hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(1), dim3(128), 0, s, bnd_val, bnd_user, entries, dim, dh_user, ld_dh);
+        if (dh_user != nullptr) hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(entries), dim3(128), 0, s, bnd_val, bnd_user, entries, dim, dh_user, ld_dh);
     } else if (strip_bwd_ok(dim, g, ld_h) && dh_user != nullptr) {       // user-reduced form: g is [E, 2, d]
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGrid));
         hipLaunchKernelGGL((interact_bwd_members_strip_kernel<128, NBLK, true>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges,
                            dh_user, ld_dh, bnd_val, bnd_user);
-        hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(1), dim3(128), 0, s, bnd_val, bnd_user, 2 * grid, dim, dh_user, ld_dh);
+        hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(2 * grid), dim3(128), 0, s, bnd_val, bnd_user, 2 * grid, dim, dh_user, ld_dh);
     } else if (strip_bwd_ok(dim, g, ld_h)) {
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGrid));
         hipLaunchKernelGGL((interact_bwd_members_strip_kernel<128, NBLK, false>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges,

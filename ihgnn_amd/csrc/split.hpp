@@ -1,4 +1,4 @@
-// split.hpp - internal interface of interact_split.hip: the interactive step's contractions for d = 128, order 3, with every fp32
+// split.hpp - internal interface of split_arith.hip: the interactive step's contractions for d = 128, order 3, with every fp32
 // operand taken apart EXACTLY into three bf16 terms (x = hi + mid + lo) and the products accumulated in fp32 on the bf16 matrix
 // pipe.  Not part of the C ABI: interact.hip chooses between these and its fp32-MFMA kernels.
 #pragma once
@@ -17,3 +17,9 @@ IHG_INTERNAL bool split_members_ok(int dim, int order, const float* g, int64_t l
 IHG_INTERNAL void launch_members_split(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
                                        int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
                                        int* n_boundary_entries, hipStream_t s);
+
+// node-level row GEMM (d = 128): out = in W_t^T (transpose == 0) or in W_t (transpose == 1), rows grouped by node type
+IHG_INTERNAL int64_t split_dense_plane_floats(int dim);
+IHG_INTERNAL bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* bias, int64_t bias_type_stride);
+IHG_INTERNAL void launch_row_gemm_split(const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
+                                        int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s);

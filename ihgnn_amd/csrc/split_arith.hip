@@ -1,0 +1,534 @@
+// split_arith.hip - contractions of the d = 128 path (interactive step, order 3; node-level linear maps) on the bf16 matrix pipe at
+// fp32 accuracy.
+//
+// Every fp32 operand x is taken apart EXACTLY into three bf16 terms, x = hi + mid + lo (hi = the top 16 bits of x, mid = the top
+// 16 bits of x - hi, lo = the rest: 8 + 8 + 8 significand bits, both subtractions exact), and a product a b is accumulated in fp32
+// as the six partial products hi hi + hi mid + mid hi + hi lo + mid mid + lo hi, smallest first.  Each partial product of two
+// bf16 values is exact in fp32; the three that are left out are below 2^-26 |a b|, a quarter of the rounding error of ONE fp32
+// multiply-add.  Measured against fp64 the result is as close as the fp32-MFMA kernels' (tests/test_gpu_parity.py holds both to
+// the same 1e-5 bar, tools/split_probe.hip has the standalone rate measurement): v_mfma_f32_16x16x32_bf16 runs 16 x the rate of
+// v_mfma_f32_16x16x4_f32, six of them replace eight -> the same contraction in ~ 0.4 of the matrix-pipe time.
+//
+// Three bf16 planes of the weights are 1.5 x their fp32 size: 384 KB, more than one workgroup's registers can keep beside the
+// accumulators.  So a workgroup is FOUR waves and owns a QUARTER of the output columns (96 weight registers per wave), two
+// workgroups share a CU and overlap each other's load / matrix / store phases; the four quarters of one tile range sit on one
+// XCD (workgroups are dealt to XCDs round-robin by their linear id), so three of the four reads of a streamed row hit that L2.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.hpp"
+#include "split.hpp"
+
+namespace {
+
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+constexpr int kSplitTE = 32;            // hyperedges per tile
+constexpr int kSplitRanges = 128;       // contiguous tile ranges (x 2 column halves = 256 workgroups, one per CU)
+constexpr int kSplitThreads = 512;
+
+__device__ __forceinline__ unsigned pack_hi(float a, float b) {          // {top half of b, top half of a}
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// eight consecutive k of one row / column -> the three bf16 planes of that MFMA fragment
+struct Planes {
+    v4u p[3];
+};
+__device__ __forceinline__ Planes split8(v4f x0, v4f x1) {
+    Planes out;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const v4f x = half == 0 ? x0 : x1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float a = x[2 * i], b = x[2 * i + 1];
+            const float ra = a - top16(a), rb = b - top16(b);
+            const float la = ra - top16(ra), lb = rb - top16(rb);
+            out.p[0][2 * half + i] = pack_hi(a, b);
+            out.p[1][2 * half + i] = pack_hi(ra, rb);
+            out.p[2][2 * half + i] = pack_hi(la, lb);
+        }
+    }
+    return out;
+}
+
+// partial products in accumulation order (A plane, B plane): smallest first
+__device__ constexpr int kTermA[6] = {0, 2, 1, 0, 1, 0};
+__device__ constexpr int kTermB[6] = {2, 0, 1, 1, 0, 0};
+
+// planes of the member-gradient contraction dz_b[e][c] = sum_j dout[e][j] W[j][(3+b)d + c]   (k runs along j):
+// wsp[qtr][b][kb][ct][plane][lane][8], element i = plane of W[32 kb + 8 (lane>>4) + i][(3+b) d + 32 qtr + 16 ct + (lane&15)]
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(const float* __restrict__ w, int64_t ld_w, v4u* __restrict__ wsp) {
+    constexpr int D = 128, NBLK = 4;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * NBLK * 4 * 2 * kWave) return;
+    const int lane = idx & 63, ct = (idx >> 6) & 1, kb = (idx >> 7) & 3, b = (idx >> 9) & 3, qtr = idx >> 11;
+    const float* src = w + static_cast<int64_t>(32 * kb + 8 * (lane >> 4)) * ld_w + (3 + b) * D + 32 * qtr + 16 * ct + (lane & 15);
+    v4f x0, x1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x0[i] = src[i * ld_w];
+        x1[i] = src[(4 + i) * ld_w];
+    }
+    const Planes pl = split8(x0, x1);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wsp[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
+}
+
+// Member gradients.  A workgroup is eight waves and owns HALF of the columns: wave (b, g) contracts the dout rows with block b's
+// weights for 32 columns (the weight planes of a half are 192 KB = 96 registers per wave), 96 MFMAs per tile of 32 hyperedges.
+// An MFMA leaves about half of its 16 issue cycles to other instructions, and everything else a tile needs is placed there, in ONE
+// basic block with the MFMAs of tile k (steady state, the scheduler is told to alternate):
+//   - the split of tile k + 1's dout rows (each thread 8 values, requested two tiles ahead, three 16-byte LDS writes; 16-byte chunk o
+//     of row r at o ^ (r & 15): conflict-free ds_read_b128 for the fragments; images double-buffered),
+//   - the product rule of tile k - 1: the four blocks' contractions meet in an LDS image (the MFMA is issued as W^T x dout^T so that a
+//     lane holds 4 consecutive COLUMNS of one hyperedge: 16-byte writes and reads), every thread combines 4 columns of one hyperedge
+//     with the member values it requested a tile earlier,
+//   - UR (hyperedges numbered by user): the scan of tile k - 2's user-slot gradients, which are not stored per hyperedge: wave w takes
+//     columns 8 w .. 8 w + 7 of the half and forms the runs' inclusive sums row by row (straight-line: a run start only resets the
+//     running sum through a scalar factor); a short loop after the MFMAs stores the few finished runs (interact.hip describes the
+//     scheme and its boundary table, which is indexed by tile range here and shared by the two column halves).
+// One barrier per tile.  The two halves of a tile range sit on one XCD, so the second read of a dout row hits that L2.
+template <bool UR>
+__global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const v4u* __restrict__ wsp, const float* __restrict__ dout,
+    int64_t ld_dout, float* __restrict__ g_out, int64_t n_edges, float* __restrict__ dh_user, int64_t ld_dh, float* __restrict__ bnd_val,
+    int32_t* __restrict__ bnd_user) {
+    constexpr int TE = kSplitTE, D = 128, HC = 64, DZ = HC + 4, UT = TE + 4, GS = UR ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][256];
+    __shared__ __attribute__((aligned(16))) float dzimg[2][4][TE][DZ];
+    __shared__ __attribute__((aligned(16))) float utile[UR ? 2 : 1][UR ? HC : 1][UT];     // transposed: [column][row]
+    __shared__ int ids[8][3 * TE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int half = (bid >> 3) & 1, range = (bid & 7) + 8 * (bid >> 4);
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int64_t per = (n_tiles + kSplitRanges - 1) / kSplitRanges;
+    const int64_t t0 = range * per;
+    const int n_my = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(per, n_tiles - t0)));
+    if (n_my == 0) {
+        if (UR && half == 0 && tid == 0) bnd_user[2 * range] = bnd_user[2 * range + 1] = -1;
+        return;
+    }
+    const int blk = wave & 3, cg = wave >> 2;
+
+    v8s wreg[4][2][3];
+    {
+        const v4u* wf = wsp + static_cast<int64_t>(((2 * half + cg) * 4 + blk) * 24) * kWave + lane;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wreg[kb][ct][p] = __builtin_bit_cast(v8s, wf[((kb * 2 + ct) * 3 + p) * kWave]);
+    }
+
+    const int row = tid >> 4, o = tid & 15;      // staging role: dout row, octet of it;  epilogue role: hyperedge row, 4 columns of the half
+    const int64_t last_pos = n_edges * 3 - 1;
+    auto fetch_id = [&](int k) { return i3[std::min<int64_t>((t0 + k) * (3 * TE) + tid, last_pos)]; };   // (only threads < 96 use it)
+    auto load_dout = [&](int k, v4f (&dr)[2]) {
+        const int64_t e = std::min<int64_t>((t0 + k) * TE + row, n_edges - 1);
+        const float* src = dout + e * ld_dout + 8 * o;
+        dr[0] = *reinterpret_cast<const v4f*>(src);
+        dr[1] = *reinterpret_cast<const v4f*>(src + 4);
+    };
+    const int chunk = (o ^ (row & 15)) << 4;
+    auto load_members = [&](int k, v4f (&hm)[3]) {
+        const int* idk = ids[k & 7] + row * 3;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) hm[m] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(idk[m]) * ld_h + HC * half + 4 * o);
+    };
+
+    // UR state: every wave carries the same (user, destination) and its own columns' running sums from tile to tile
+    int cur_user = -1, first_user = -1;
+    float run_sum = 0.f, carry_prev = 0.f;
+    float* const first_slot = UR ? bnd_val + static_cast<int64_t>(2 * range) * D : nullptr;
+    float* run_dst = first_slot;
+    const int ucol = 8 * wave + (lane & 7), colg = HC * half + ucol;
+    uint64_t walk_mask = 0;
+    int walk_uid = 0;
+    auto scan_prelude = [&](int k) {                                     // tile k >= 0: where its runs start, as a scalar bit mask
+        const int* idk = ids[k & 7];
+        const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + k) * TE));
+        const int r = lane < rows ? lane : rows - 1;
+        walk_uid = idk[r * 3];
+        const int prev_uid = r == 0 ? cur_user : idk[(r - 1) * 3];
+        walk_mask = __ballot(lane < rows && walk_uid != prev_uid);
+        carry_prev = run_sum;
+    };
+    // four rows of the scan (rows past the end hold zeros): inclusive sums of the runs, back into the image
+    auto scan_rows = [&](float* col, int x0, v4f v) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float keep = (walk_mask >> (x0 + x)) & 1 ? 0.f : 1.f;
+            run_sum = run_sum * keep + v[x];
+            v[x] = run_sum;
+        }
+        *reinterpret_cast<v4f*>(col + x0) = v;
+    };
+    auto emit_user_runs = [&](int k) {                                   // the finished runs: one short iteration per run start in the tile
+        uint64_t m = walk_mask;
+        const float* col = utile[k & 1][ucol];
+        while (m != 0) {
+            const int x = __builtin_ctzll(m);
+            m &= m - 1;
+            const int user = __builtin_amdgcn_readlane(walk_uid, x);
+            if (cur_user >= 0) {
+                const float done = x == 0 ? carry_prev : col[x - 1];     // the finished run: its sum up to the row before
+                if (lane < 8) run_dst[colg] = done;
+                run_dst = dh_user + static_cast<int64_t>(user) * ld_dh;
+            } else {
+                first_user = user;
+            }
+            cur_user = user;
+        }
+    };
+
+    if (tid < 3 * TE) {
+        ids[0][tid] = fetch_id(0);
+        if (n_my > 1) ids[1][tid] = fetch_id(1);
+    }
+    v4f dr0[2], dr1[2], hm0[3], hm1[3];                                  // dout values of tile m live in dr<m & 1>, member values in hm<m & 1>
+    load_dout(0, dr0);
+    if (n_my > 1) load_dout(1, dr1);
+    {
+        const Planes p0 = split8(dr0[0], dr0[1]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[0][p][row][chunk]) = p0.p[p];
+    }
+    __syncthreads();
+
+    const int arow = lane & 15, kq = lane >> 4;
+    // Phase k: matrix work of tile k, split of tile k + 1 (`use`), product rule of tile k - 1 (`hm_prev`), scan of tile k - 2; requests
+    // the member values of tile k (`hm_cur`) and the dout values of tile k + 2 (`fill`).  STEADY: all four tiles exist and are whole.
+    auto phase = [&](auto steady_tag, int k, v4f (&use)[2], v4f (&fill)[2], v4f (&hm_cur)[3], v4f (&hm_prev)[3]) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const bool has_tile = STEADY || k < n_my, has_prev = STEADY || (k >= 1 && k - 1 < n_my), has_scan = UR && (STEADY || (k >= 2 && k - 2 < n_my));
+        if (has_tile) load_members(k, hm_cur);
+        if (STEADY || k + 2 < n_my) load_dout(k + 2, fill);
+        int id_next = 0;
+        if ((STEADY || k + 2 < n_my) && tid < 3 * TE) id_next = fetch_id(k + 2);
+        if (has_scan) scan_prelude(k - 2);
+
+        v4f acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* pbase = &planes[k & 1][0][0][0];
+        auto fragment = [&](int step, v8s (&a)[3]) {
+            const int kb = step >> 1, rt = step & 1;
+            const unsigned char* src = pbase + (16 * rt + arow) * 256 + (((4 * kb + kq) ^ arow) << 4);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * 256));
+        };
+        float* ucolp = utile[k & 1][ucol];                               // (k - 2) & 1
+        const float (*dz)[TE][DZ] = dzimg[(k - 1) & 1];
+        v4f g_u, g_q, g_i, z_uq, z_qi, z_iu, z_uqi, sv, svn;
+        v8s a[3], an[3];
+        v4u sp[3];
+        fragment(0, a);
+        if (has_scan) sv = *reinterpret_cast<const v4f*>(ucolp);
+        if (has_tile) {
+            // Every step: 12 MFMAs and, in their issue shadow, a slice of the other three jobs - steps 0-3 split one pair of dout values
+            // each, step 3 fetches tile k - 1's contractions, steps 4-7 apply the product rule to one of the thread's 4 columns each, every
+            // step scans 4 rows.  The fences keep a step's instructions together, the group barriers alternate them with the MFMAs.
+#pragma unroll
+            for (int step = 0; step < 8; ++step) {
+                const int kb = step >> 1, rt = step & 1;
+                if (step + 1 < 8) fragment(step + 1, an);
+                if (has_scan) {
+                    if (step + 1 < 8) svn = *reinterpret_cast<const v4f*>(ucolp + 4 * (step + 1));
+                    scan_rows(ucolp, 4 * step, sv);
+                }
+                if (step < 4) {   // two of the eight dout values of the next tile -> one dword of each plane
+                    const float xa = use[step >> 1][2 * (step & 1)], xb = use[step >> 1][2 * (step & 1) + 1];
+                    const float ra = xa - top16(xa), rb = xb - top16(xb);
+                    const float la = ra - top16(ra), lb = rb - top16(rb);
+                    sp[0][step] = pack_hi(xa, xb);
+                    sp[1][step] = pack_hi(ra, rb);
+                    sp[2][step] = pack_hi(la, lb);
+                }
+                if (step == 3) {
+                    z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][4 * o]);
+                    z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][4 * o]);
+                    z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][4 * o]);
+                    z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][4 * o]);
+                }
+                if (step >= 4) {
+                    const int i = step - 4;
+                    const float hu = hm_prev[0][i], hq = hm_prev[1][i], hi = hm_prev[2][i];
+                    g_u[i] = z_uq[i] * hq + z_iu[i] * hi + z_uqi[i] * (hq * hi);
+                    g_q[i] = z_uq[i] * hu + z_qi[i] * hi + z_uqi[i] * (hu * hi);
+                    g_i[i] = z_qi[i] * hq + z_iu[i] * hu + z_uqi[i] * (hu * hq);
+                }
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][ct][kTermB[term]], a[kTermA[term]], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x6, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = an[p];
+                sv = svn;
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk]) = sp[p];    // (past the last tile: nobody reads it)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) *reinterpret_cast<v4f*>(&dzimg[k & 1][blk][16 * rt + arow][32 * cg + 16 * ct + 4 * kq]) = acc[rt][ct];
+        } else {
+            // the phases after the last tile: only the product rule and the scan are left
+            z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][4 * o]);
+            z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][4 * o]);
+            z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][4 * o]);
+            z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][4 * o]);
+            const v4f hu = hm_prev[0], hq = hm_prev[1], hi = hm_prev[2];
+            g_u = z_uq * hq + z_iu * hi + z_uqi * (hq * hi);
+            g_q = z_uq * hu + z_qi * hi + z_uqi * (hu * hi);
+            g_i = z_qi * hq + z_iu * hu + z_uqi * (hu * hq);
+            if (has_scan) {
+#pragma unroll
+                for (int x0 = 0; x0 < TE; x0 += 4) scan_rows(ucolp, x0, *reinterpret_cast<const v4f*>(ucolp + x0));
+            }
+        }
+        if ((STEADY || k + 2 < n_my) && tid < 3 * TE) ids[(k + 2) & 7][tid] = id_next;
+        if (has_prev) {
+            const int64_t e = (t0 + k - 1) * TE + row;
+            const bool live = STEADY || e < n_edges;
+            if (UR) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) utile[(k - 1) & 1][4 * o + i][row] = live ? g_u[i] : 0.f;
+            }
+            if (live) {
+                float* dst = g_out + e * (GS * D) + HC * half + 4 * o;
+                if (!UR) {
+                    store_stream4(dst, g_u);
+                    dst += D;
+                }
+                store_stream4(dst, g_q);
+                store_stream4(dst + D, g_i);
+            }
+        }
+        if (has_scan) emit_user_runs(k - 2);
+        __syncthreads();
+    };
+    const int n_phases = n_my + (UR ? 2 : 1);
+    const bool whole = (t0 + n_my) * TE <= n_edges;                      // this range's last tile is complete
+    for (int k = 0; k < n_phases; k += 2) {
+        const bool steady0 = k >= 2 && k + 2 < n_my && (whole || k - 1 < n_my - 1);
+        if (steady0) phase(std::true_type{}, k, dr1, dr0, hm0, hm1);
+        else phase(std::false_type{}, k, dr1, dr0, hm0, hm1);
+        if (k + 1 < n_phases) {
+            const bool steady1 = k + 1 >= 2 && k + 3 < n_my && (whole || k < n_my - 1);
+            if (steady1) phase(std::true_type{}, k + 1, dr0, dr1, hm1, hm0);
+            else phase(std::false_type{}, k + 1, dr0, dr1, hm1, hm0);
+        }
+    }
+    if (UR) {
+        // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
+        const bool one_run = run_dst == first_slot;
+        if (cur_user >= 0 && lane < 8) {
+            if (one_run) run_dst[colg] = run_sum;
+            else bnd_val[static_cast<int64_t>(2 * range + 1) * D + colg] = run_sum;
+        }
+        if (half == 0 && tid == 0) {
+            bnd_user[2 * range] = first_user;
+            bnd_user[2 * range + 1] = (cur_user >= 0 && !one_run) ? cur_user : -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row GEMM (node-level linear maps, d = 128): out[v] = in[v] W_t^T (+ bias_t), rows grouped by node type.  A stream over [N, d] - 1 KB
+// of traffic per row against 32 K multiply-adds - that the fp32 matrix pipe cannot feed at HBM speed and the bf16 pipe can.
+// Eight waves, wave w owns output columns 16 w .. with the whole contraction index (its weight planes: 48 registers per node type,
+// reloaded at the at most two type changes of a workgroup's tile sequence); tiles of 32 rows come in through registers two tiles
+// ahead (each thread 8 values), are split inside the previous tile's matrix phase and laid down as three bf16 images like the
+// member-gradient kernel's; the MFMA is issued as W x in^T, so a lane ends up with 4 consecutive columns of one row and stores
+// them straight from the accumulator.  One barrier per tile, two workgroups per CU.
+// pk[type][strip][kb][plane][lane][8]: element i = plane of Wt[k = 32 kb + 8 (lane >> 4) + i][c = 16 strip + (lane & 15)],
+//                                       Wt[k][c] = W_t[c][k] (transpose == 0, out = in W^T) or W_t[k][c] (transpose == 1, out = in W)
+// ------------------------------------------------------------------------------------------------
+struct RowTiles {
+    int64_t begin[4];
+    int tile_prefix[4];
+};
+
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride, int n_types,
+                                                                          int transpose, v4u* __restrict__ pk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_types * 8 * 4 * kWave) return;
+    const int lane = idx & 63, kb = (idx >> 6) & 3, strip = (idx >> 8) & 7, type = idx >> 11;
+    const int c = 16 * strip + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
+    const float* wt = w + type * type_stride;
+    v4f x0, x1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x0[i] = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k0 + i] : wt[static_cast<int64_t>(k0 + i) * ld_w + c];
+        x1[i] = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k0 + 4 + i] : wt[static_cast<int64_t>(k0 + 4 + i) * ld_w + c];
+    }
+    const Planes pl = split8(x0, x1);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pk[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
+}
+
+__global__ __launch_bounds__(512, 4) void row_gemm_split_kernel(const float* __restrict__ in, int64_t ld_in, const v4u* __restrict__ pk, int64_t pk_type_stride,
+                                                                const float* __restrict__ bias, int bias_mask, int64_t bias_type_stride, RowTiles plan,
+                                                                float* __restrict__ out, int64_t ld_out) {
+    constexpr int TE = 32;
+    __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total_tiles = plan.tile_prefix[3];
+    const int grid = gridDim.x;
+    const int n_my = static_cast<int>(blockIdx.x) < total_tiles ? (total_tiles - static_cast<int>(blockIdx.x) + grid - 1) / grid : 0;
+    if (n_my == 0) return;
+    auto tile_type = [&](int tile_id) { return tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0); };
+    auto tile_rows = [&](int k, int64_t& r_base, int64_t& r_end) {
+        const int tile_id = static_cast<int>(blockIdx.x) + k * grid;
+        const int type = tile_type(tile_id);
+        r_base = plan.begin[type] + static_cast<int64_t>(tile_id - plan.tile_prefix[type]) * TE;
+        r_end = plan.begin[type + 1];
+        return type;
+    };
+    const int row = tid >> 4, o = tid & 15;
+    const int chunk = (o ^ (row & 15)) << 4;
+    auto load_rows = [&](int k, v4f (&dr)[2]) {
+        int64_t r_base, r_end;
+        tile_rows(k, r_base, r_end);
+        const int64_t v = std::min(r_base + row, r_end - 1);             // rows past the type's end re-read its last row (never stored)
+        const float* src = in + v * ld_in + 8 * o;
+        dr[0] = *reinterpret_cast<const v4f*>(src);
+        dr[1] = *reinterpret_cast<const v4f*>(src + 4);
+    };
+    v4f dr0[2], dr1[2];
+    load_rows(0, dr0);
+    if (n_my > 1) load_rows(1, dr1);
+    {
+        const Planes p0 = split8(dr0[0], dr0[1]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[0][p][row][chunk]) = p0.p[p];
+    }
+    __syncthreads();
+
+    v8s wreg[4][3];
+    int cur_type = -1;
+    const int arow = lane & 15, kq = lane >> 4;
+    auto phase = [&](int k, v4f (&use)[2], v4f (&fill)[2]) {
+        int64_t r_base, r_end;
+        const int type = tile_rows(k, r_base, r_end);
+        if (type != cur_type) {
+            const v4u* wf = pk + type * pk_type_stride + static_cast<int64_t>(wave) * 12 * kWave + lane;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wreg[kb][p] = __builtin_bit_cast(v8s, wf[(kb * 3 + p) * kWave]);
+            cur_type = type;
+        }
+        if (k + 2 < n_my) load_rows(k + 2, fill);
+        v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+        const unsigned char* pbase = &planes[k & 1][0][0][0];
+        v4u sp[3];
+#pragma unroll
+        for (int step = 0; step < 8; ++step) {
+            const int kb = step >> 1, rt = step & 1;
+            v8s a[3];
+            const unsigned char* src = pbase + (16 * rt + arow) * 256 + (((4 * kb + kq) ^ arow) << 4);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * 256));
+            if (step < 4) {   // two of the eight values of the next tile's row piece -> one dword of each plane
+                const float xa = use[step >> 1][2 * (step & 1)], xb = use[step >> 1][2 * (step & 1) + 1];
+                const float ra = xa - top16(xa), rb = xb - top16(xb);
+                const float la = ra - top16(ra), lb = rb - top16(rb);
+                sp[0][step] = pack_hi(xa, xb);
+                sp[1][step] = pack_hi(ra, rb);
+                sp[2][step] = pack_hi(la, lb);
+            }
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][kTermB[term]], a[kTermA[term]], acc[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk]) = sp[p];        // (past the last tile: nobody reads it)
+        const int c4 = 16 * wave + 4 * kq;
+        v4f bv = v4f{0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr && ((bias_mask >> type) & 1)) bv = *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + c4);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int64_t v = r_base + 16 * rt + arow;
+            if (v < r_end) *reinterpret_cast<v4f*>(out + v * ld_out + c4) = acc[rt] + bv;
+        }
+        __syncthreads();
+    };
+    for (int k = 0; k < n_my; k += 2) {
+        phase(k, dr1, dr0);
+        if (k + 1 < n_my) phase(k + 1, dr0, dr1);
+    }
+}
+
+}  // namespace
+
+int64_t split_plane_floats(int dim, int order) { return dim == 128 && order == 3 ? (3LL * 4 * dim * dim) / 2 : 0; }
+
+bool split_arith_enabled() {
+    static const bool enabled = [] {
+        const char* v = std::getenv("IHG_INTERACT_ARITH");
+        return v == nullptr || std::strcmp(v, "f32") != 0;
+    }();
+    return enabled;
+}
+
+bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout) {
+    return split_arith_enabled() && dim == 128 && order == 3 && aligned16(g) && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
+}
+
+void launch_members_split(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
+                          int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
+                          int* n_boundary_entries, hipStream_t s) {
+    v4u* wsp = static_cast<v4u*>(planes);
+    hipLaunchKernelGGL(pack_planes_members_kernel, dim3(4 * 4 * 4 * 2 * kWave / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, wsp);
+    const int grid = 2 * kSplitRanges;
+    if (dh_user != nullptr)
+        hipLaunchKernelGGL(interact_bwd_members_split_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user,
+                           ld_dh, bnd_val, bnd_user);
+    else
+        hipLaunchKernelGGL(interact_bwd_members_split_kernel<false>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
+                           static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
+    if (n_boundary_entries != nullptr) *n_boundary_entries = 2 * kSplitRanges;
+}
+
+int64_t split_dense_plane_floats(int dim) { return dim == 128 ? (3LL * 3 * dim * dim) / 2 : 0; }
+
+bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* bias, int64_t bias_type_stride) {
+    return split_arith_enabled() && dim == 128 && aligned16(out) && ld_out % 4 == 0 && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0));
+}
+
+void launch_row_gemm_split(const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
+                           int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s) {
+    const int n_types = w_type_stride == 0 ? 1 : 3;
+    v4u* pk = static_cast<v4u*>(planes);
+    hipLaunchKernelGGL(pack_planes_dense_kernel, dim3((n_types * 8 * 4 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w,
+                       w_type_stride, n_types, transpose, pk);
+    RowTiles plan;
+    int acc = 0;
+    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
+    for (int t = 0; t < 3; ++t) {
+        plan.tile_prefix[t] = acc;
+        acc += static_cast<int>((type_begin[t + 1] - type_begin[t] + 31) / 32);
+    }
+    plan.tile_prefix[3] = acc;
+    if (acc == 0) return;
+    hipLaunchKernelGGL(row_gemm_split_kernel, dim3(std::min(acc, 512)), dim3(512), 0, s, in, ld_in, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 3 * kWave}, bias,
+                       bias_mask, bias_type_stride, plan, out, ld_out);
+}
