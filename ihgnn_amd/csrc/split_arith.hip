@@ -150,13 +150,19 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_kern
     float* run_dst = first_slot;
     const int ucol = 8 * wave + (lane & 7), colg = HC * half + ucol;
     uint64_t walk_mask = 0;
-    int walk_uid = 0;
-    auto scan_prelude = [&](int k) {                                     // tile k >= 0: where its runs start, as a scalar bit mask
+    int walk_uid = 0, pf_uid = 0, pf_prev = 0;
+    // the user ids of tile k's rows (lane -> row, clamped) are read from the id ring a phase ahead, inside the matrix phase
+    auto prefetch_uids = [&](int k) {
         const int* idk = ids[k & 7];
-        const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + k) * TE));
+        const int rows = k < 0 ? 1 : static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + k) * TE));
         const int r = lane < rows ? lane : rows - 1;
-        walk_uid = idk[r * 3];
-        const int prev_uid = r == 0 ? cur_user : idk[(r - 1) * 3];
+        pf_uid = idk[r * 3];
+        pf_prev = idk[(r == 0 ? 0 : r - 1) * 3];
+    };
+    auto scan_prelude = [&](int k) {                                     // tile k >= 0: where its runs start, as a scalar bit mask
+        const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + k) * TE));
+        walk_uid = pf_uid;
+        const int prev_uid = lane == 0 ? cur_user : pf_prev;
         walk_mask = __ballot(lane < rows && walk_uid != prev_uid);
         carry_prev = run_sum;
     };
@@ -170,21 +176,34 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_kern
         }
         *reinterpret_cast<v4f*>(col + x0) = v;
     };
-    auto emit_user_runs = [&](int k) {                                   // the finished runs: one short iteration per run start in the tile
+    // the finished runs, four run starts at a time (their sums are fetched together: one LDS round trip per batch)
+    auto emit_user_runs = [&](int k) {
         uint64_t m = walk_mask;
         const float* col = utile[k & 1][ucol];
         while (m != 0) {
-            const int x = __builtin_ctzll(m);
-            m &= m - 1;
-            const int user = __builtin_amdgcn_readlane(walk_uid, x);
-            if (cur_user >= 0) {
-                const float done = x == 0 ? carry_prev : col[x - 1];     // the finished run: its sum up to the row before
-                if (lane < 8) run_dst[colg] = done;
-                run_dst = dh_user + static_cast<int64_t>(user) * ld_dh;
-            } else {
-                first_user = user;
+            int x[4];
+            bool have[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                have[i] = m != 0;
+                x[i] = have[i] ? __builtin_ctzll(m) : 1;
+                m = have[i] ? m & (m - 1) : 0;
             }
-            cur_user = user;
+            float done[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) done[i] = col[x[i] == 0 ? 0 : x[i] - 1];   // the sum up to the row before the start
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!have[i]) continue;
+                const int user = __builtin_amdgcn_readlane(walk_uid, x[i]);
+                if (cur_user >= 0) {
+                    if (lane < 8) run_dst[colg] = x[i] == 0 ? carry_prev : done[i];
+                    run_dst = dh_user + static_cast<int64_t>(user) * ld_dh;
+                } else {
+                    first_user = user;
+                }
+                cur_user = user;
+            }
         }
     };
 
@@ -253,6 +272,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_kern
                     sp[1][step] = pack_hi(ra, rb);
                     sp[2][step] = pack_hi(la, lb);
                 }
+                if (UR && step == 6) prefetch_uids(k - 1);
                 if (step == 3) {
                     z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][4 * o]);
                     z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][4 * o]);
@@ -301,7 +321,12 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_kern
 #pragma unroll
                 for (int x0 = 0; x0 < TE; x0 += 4) scan_rows(ucolp, x0, *reinterpret_cast<const v4f*>(ucolp + x0));
             }
+            if (UR) prefetch_uids(k - 1);
         }
+        // Everything this phase requested has had a whole matrix phase to arrive: take delivery HERE, before the stores below are
+        // issued.  The memory counter is in order - the first use of these registers in the next phase would otherwise wait for the
+        // stores as well, a store round trip exposed at the start of every phase with the matrix pipe idle.
+        asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(hm_cur[0]), "+v"(hm_cur[1]), "+v"(hm_cur[2]));
         if ((STEADY || k + 2 < n_my) && tid < 3 * TE) ids[(k + 2) & 7][tid] = id_next;
         if (has_prev) {
             const int64_t e = (t0 + k - 1) * TE + row;
@@ -461,6 +486,7 @@ __global__ __launch_bounds__(512, 4) void row_gemm_split_kernel(const float* __r
         }
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk]) = sp[p];        // (past the last tile: nobody reads it)
+        asm volatile("" : "+v"(fill[0]), "+v"(fill[1]));                  // delivery of the next-but-one tile's rows before the stores (see the member-gradient kernel)
         const int c4 = 16 * wave + 4 * kq;
         v4f bv = v4f{0.f, 0.f, 0.f, 0.f};
         if (bias != nullptr && ((bias_mask >> type) & 1)) bv = *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + c4);
