@@ -2012,7 +2012,9 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
 #undef IHG_MEM_PIPE
     const int subs_ws = (dim / 64) * (dim / 64);
     int n_slabs = static_cast<int>(std::min<int64_t>(dim >= 64 ? std::max(kPipeGrid / subs_ws, 8) : weight_slabs(dim), (n_edges + 63) / 64));
-    if (dim == 128 && ld_h < (int64_t{1} << 30)) {
+    if (split_weight_ok(dim, NBLK == 4 ? 3 : 2, ld_h, ld_dout, dout)) {      // bf16-split contraction
+        n_slabs = launch_weight_split(h, ld_h, i3, dout, ld_dout, slabs, n_edges, s);
+    } else if (dim == 128 && ld_h < (int64_t{1} << 30)) {
         n_slabs = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGridSlabs));
         hipLaunchKernelGGL((interact_bwd_weight_strip_kernel<128, NBLK>), dim3(n_slabs), dim3(kWsThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
     } else if (dim >= 64 && ld_h < (int64_t{1} << 30)) {

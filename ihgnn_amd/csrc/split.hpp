@@ -18,6 +18,10 @@ IHG_INTERNAL void launch_members_split(const float* h, int64_t ld_h, const int32
                                        int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
                                        int* n_boundary_entries, hipStream_t s);
 
+// weight gradients into slabs [range][j][b d + c] (interact.hip's slab layout); returns the number of slabs written
+IHG_INTERNAL bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout);
+IHG_INTERNAL int launch_weight_split(const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s);
+
 // node-level row GEMM (d = 128): out = in W_t^T (transpose == 0) or in W_t (transpose == 1), rows grouped by node type
 IHG_INTERNAL int64_t split_dense_plane_floats(int dim);
 IHG_INTERNAL bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* bias, int64_t bias_type_stride);

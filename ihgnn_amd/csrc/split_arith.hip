@@ -375,6 +375,193 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_kern
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradients dW_b[j][c] = sum_e dout[e][j] z_b[e][c].  The contraction runs over the hyperedges, both operands are streams:
+// per tile of 32 hyperedges (one MFMA k-block) every thread splits 8 dout values and the 16 products z_b of one hyperedge's 4
+// columns (of a column HALF: the two halves of a tile range are two workgroups on one XCD) and lays them down as bf16 images, ROW-major
+// as they come ([hyperedge][column], 16-byte chunk ch of a row at ch ^ (((row & 3) << 2) | ((row >> 2) & 3)) within each 256-byte
+// segment); the MFMA operands need 8 consecutive HYPEREDGES of one column per lane, which ds_read_b64_tr_b16 delivers from those
+// images (lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. of a 4 x 16 block and receives column `lane` of its 4
+// rows; with this swizzle the reads of a half wave - two blocks 8 rows apart - are conflict-free).  Wave (jq, b) keeps the 64 x 64
+// block (j half jq, product block b) of the half's gradient in 16 accumulator tiles for the whole kernel; nothing leaves the CU
+// until the end (one slab per tile range, summed by interact.hip's slab_reduce_kernel in a fixed order).  One barrier per tile:
+// the split of tile k + 1 is spread over the MFMAs of tile k, rows are requested two tiles ahead.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tr_swizzle(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ v8s read_tr_fragment(const unsigned char* lo, const unsigned char* hi) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)lo);
+    const v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)hi);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
+                                                                                  const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ slabs,
+                                                                                  int64_t n_edges) {
+    constexpr int TE = kSplitTE, D = 128, HC = 64, NBLK = 4;
+    constexpr int DPL = TE * 256, ZPL = TE * 512;                        // bytes of one plane of the dout / product images
+    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][256];
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][512];
+    __shared__ int ids[8][3 * TE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int half = (bid >> 3) & 1, range = (bid & 7) + 8 * (bid >> 4);
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int64_t per = (n_tiles + kSplitRanges - 1) / kSplitRanges;
+    const int64_t t0 = range * per;
+    const int n_my = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(per, n_tiles - t0)));
+    const int jq = wave & 1, blk = wave >> 1;
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[jt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const int row = tid >> 4, o = tid & 15;                              // staging role: hyperedge row; 8 dout columns 8 o .., 4 member columns 4 o ..
+    const int64_t last_pos = n_edges * 3 - 1;
+    auto fetch_id = [&](int k) { return i3[std::min<int64_t>((t0 + k) * (3 * TE) + tid, last_pos)]; };
+    struct Rows {
+        v4f d[2], m[3];
+    };
+    auto load_rows = [&](int k, Rows& r) {
+        const int64_t e = (t0 + k) * TE + row;
+        const float* src = dout + std::min<int64_t>(e, n_edges - 1) * ld_dout + 8 * o;
+        r.d[0] = *reinterpret_cast<const v4f*>(src);
+        r.d[1] = *reinterpret_cast<const v4f*>(src + 4);
+        if (e >= n_edges) r.d[0] = r.d[1] = v4f{0.f, 0.f, 0.f, 0.f};    // hyperedges past the end contribute nothing
+        const int* idk = ids[k & 7] + row * 3;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) r.m[m] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(idk[m]) * ld_h + HC * half + 4 * o);
+    };
+    const int swz = tr_swizzle(row);
+    const int d_off = row * 256 + ((o ^ swz) << 4);                      // this thread's 16 bytes of a dout image
+    // its 8 bytes of block b of a product image: columns b * 64 + 4 o .. -> segment b >> 1, chunk 8 (b & 1) + (o >> 1), half o & 1
+    auto z_off = [&](int b) { return row * 512 + 256 * (b >> 1) + (((8 * (b & 1) + (o >> 1)) ^ swz) << 4) + 8 * (o & 1); };
+    // one staged tile -> images `buf`, in 16 slices (the caller spreads them over its MFMAs): slices 0-3 the dout pairs, slice 4 + 3 b + i
+    // pair i of block b (i = 2: the block's 8 bytes are complete and written)
+    v4u dsp[3];
+    unsigned zsp[3][2];
+    float zb[4];
+    auto split_slice = [&](int slice, const Rows& r, int buf) {
+        auto pair = [&](float xa, float xb, unsigned (&out)[3]) {
+            const float ra = xa - top16(xa), rb = xb - top16(xb);
+            const float la = ra - top16(ra), lb = rb - top16(rb);
+            out[0] = pack_hi(xa, xb);
+            out[1] = pack_hi(ra, rb);
+            out[2] = pack_hi(la, lb);
+        };
+        if (slice < 4) {
+            unsigned w[3];
+            pair(r.d[slice >> 1][2 * (slice & 1)], r.d[slice >> 1][2 * (slice & 1) + 1], w);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dsp[p][slice] = w[p];
+            if (slice == 3) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + d_off) = dsp[p];
+            }
+        } else {
+            const int b = (slice - 4) / 3, i = (slice - 4) % 3;
+            if (i == 0) {
+                const v4f u = r.m[0], q = r.m[1], it = r.m[2];
+                const v4f z = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) zb[x] = z[x];
+            }
+            if (i < 2) {
+                unsigned w[3];
+                pair(zb[2 * i], zb[2 * i + 1], w);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) zsp[p][i] = w[p];
+            } else {
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + p * ZPL + z_off(b)) = v2u{zsp[p][0], zsp[p][1]};
+            }
+        }
+    };
+
+    if (n_my > 0) {
+        if (tid < 3 * TE) {
+            ids[0][tid] = fetch_id(0);
+            if (n_my > 1) ids[1][tid] = fetch_id(1);
+            if (n_my > 2) ids[2][tid] = fetch_id(2);
+        }
+        __syncthreads();
+        Rows r0, r1;                                                     // rows of tile m live in r<m & 1> until they are split
+        load_rows(0, r0);
+        if (n_my > 1) load_rows(1, r1);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) split_slice(s, r0, 0);
+        __syncthreads();
+
+        // transposed-read addresses: lane 4 q + p of group g supplies row 8 g + q (+ 4), chunk c0 + (p >> 1), half p & 1; the operand tile
+        // (jt / ct) moves the chunk by 2 -> one XOR on the address
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const int rlo = 8 * g + q, rhi = rlo + 4;
+        auto a_addr = [&](int r, int jt) { return r * 256 + ((((8 * jq + (pp >> 1)) ^ tr_swizzle(r)) << 4) ^ (jt << 5)) + 8 * (pp & 1); };
+        auto b_addr = [&](int r, int ct) { return r * 512 + 256 * (blk >> 1) + ((((8 * (blk & 1) + (pp >> 1)) ^ tr_swizzle(r)) << 4) ^ (ct << 5)) + 8 * (pp & 1); };
+        const int a_lo = a_addr(rlo, 0), a_hi = a_addr(rhi, 0), b_lo = b_addr(rlo, 0), b_hi = b_addr(rhi, 0);
+
+        auto phase = [&](auto parity, int k, Rows& use, Rows& fill) {
+            constexpr int BUF = decltype(parity)::value;
+            if (k + 2 < n_my) load_rows(k + 2, fill);
+            int id_next = 0;
+            if (k + 3 < n_my && tid < 3 * TE) id_next = fetch_id(k + 3);
+            const unsigned char* dp = &dplanes[BUF][0][0][0];
+            const unsigned char* zp = &zplanes[BUF][0][0][0];
+            v8s a[4][3];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[jt][p] = read_tr_fragment(dp + p * DPL + (a_lo ^ (jt << 5)), dp + p * DPL + (a_hi ^ (jt << 5)));
+            v8s b[3], bn[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[p] = read_tr_fragment(zp + p * ZPL + b_lo, zp + p * ZPL + b_hi);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (ct + 1 < 4) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(zp + p * ZPL + (b_lo ^ ((ct + 1) << 5)), zp + p * ZPL + (b_hi ^ ((ct + 1) << 5)));
+                }
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    split_slice(4 * ct + jt, use, BUF ^ 1);               // (past the last tile: nobody reads those images)
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+                        acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jt][kTermA[term]], b[kTermB[term]], acc[jt][ct], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x6, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = bn[p];
+            }
+            if (k + 3 < n_my && tid < 3 * TE) ids[(k + 3) & 7][tid] = id_next;
+            __syncthreads();
+        };
+        for (int k = 0; k < n_my; k += 2) {
+            phase(std::integral_constant<int, 0>{}, k, r1, r0);
+            if (k + 1 < n_my) phase(std::integral_constant<int, 1>{}, k + 1, r0, r1);
+        }
+    }
+    // slab of this tile range: element (j, b * D + col); accumulator tile (jt, ct): column lane & 15 -> col 64 half + 16 ct + .., rows 4 (lane >> 4) + r
+    float* slab = slabs + static_cast<int64_t>(range) * D * NBLK * D;
+    const int c = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[static_cast<int64_t>(64 * jq + 16 * jt + 4 * kq + r) * NBLK * D + blk * D + HC * half + 16 * ct + c] = acc[jt][ct][r];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row GEMM (node-level linear maps, d = 128): out[v] = in[v] W_t^T (+ bias_t), rows grouped by node type.  A stream over [N, d] - 1 KB
 // of traffic per row against 32 K multiply-adds - that the fp32 matrix pipe cannot feed at HBM speed and the bf16 pipe can.
 // Eight waves, wave w owns output columns 16 w .. with the whole contraction index (its weight planes: 48 registers per node type,
@@ -557,4 +744,13 @@ void launch_row_gemm_split(const float* in, int64_t ld_in, const float* w, int64
     if (acc == 0) return;
     hipLaunchKernelGGL(row_gemm_split_kernel, dim3(std::min(acc, 512)), dim3(512), 0, s, in, ld_in, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 3 * kWave}, bias,
                        bias_mask, bias_type_stride, plan, out, ld_out);
+}
+
+bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout) {
+    return split_arith_enabled() && dim == 128 && order == 3 && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
+}
+
+int launch_weight_split(const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s) {
+    hipLaunchKernelGGL(interact_bwd_weight_split_kernel, dim3(2 * kSplitRanges), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
+    return kSplitRanges;                                                 // slabs written (every range writes one, empty ranges zeros)
 }
