@@ -487,6 +487,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_kerne
             ids[0][tid] = fetch_id(0);
             if (n_my > 1) ids[1][tid] = fetch_id(1);
             if (n_my > 2) ids[2][tid] = fetch_id(2);
+            if (n_my > 3) ids[3][tid] = fetch_id(3);
         }
         __syncthreads();
         Rows r0, r1;                                                     // rows of tile m live in r<m & 1> until they are split
@@ -504,11 +505,13 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_kerne
         auto b_addr = [&](int r, int ct) { return r * 512 + 256 * (blk >> 1) + ((((8 * (blk & 1) + (pp >> 1)) ^ tr_swizzle(r)) << 4) ^ (ct << 5)) + 8 * (pp & 1); };
         const int a_lo = a_addr(rlo, 0), a_hi = a_addr(rhi, 0), b_lo = b_addr(rlo, 0), b_hi = b_addr(rhi, 0);
 
+        int id_carry = 0;
         auto phase = [&](auto parity, int k, Rows& use, Rows& fill) {
             constexpr int BUF = decltype(parity)::value;
+            // ids requested in the previous phase (tile k + 3) reach the ring now - nothing is waited for at the end of a phase
+            if (k >= 1 && k + 3 < n_my && tid < 3 * TE) ids[(k + 3) & 7][tid] = id_carry;
             if (k + 2 < n_my) load_rows(k + 2, fill);
-            int id_next = 0;
-            if (k + 3 < n_my && tid < 3 * TE) id_next = fetch_id(k + 3);
+            if (k + 4 < n_my && tid < 3 * TE) id_carry = fetch_id(k + 4);
             const unsigned char* dp = &dplanes[BUF][0][0][0];
             const unsigned char* zp = &zplanes[BUF][0][0][0];
             v8s a[4][3];
@@ -526,22 +529,28 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_kerne
                     for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(zp + p * ZPL + (b_lo ^ ((ct + 1) << 5)), zp + p * ZPL + (b_hi ^ ((ct + 1) << 5)));
                 }
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    split_slice(4 * ct + jt, use, BUF ^ 1);               // (past the last tile: nobody reads those images)
+                for (int jt = 0; jt < 4; ++jt) split_slice(4 * ct + jt, use, BUF ^ 1);   // (past the last tile: nobody reads those images)
+                // the four accumulator tiles of this column tile take turns: a dependent MFMA is four issues away
 #pragma unroll
-                    for (int term = 0; term < 6; ++term)
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt)
                         acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jt][kTermA[term]], b[kTermB[term]], acc[jt][ct], 0, 0, 0);
+#ifndef IHG_X_NOGROUPS
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x6, 2, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 24; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x6, 2, 0);
                 }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) b[p] = bn[p];
             }
-            if (k + 3 < n_my && tid < 3 * TE) ids[(k + 3) & 7][tid] = id_next;
+            // take delivery of the requested rows here, a whole matrix phase after the request: left to the compiler, the waits land in
+            // the middle of the NEXT phase's MFMA stream with conservative counts (the counter is in order and this phase's requests
+            // are behind them)
+            asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.m[0]), "+v"(fill.m[1]), "+v"(fill.m[2]));
             __syncthreads();
         };
         for (int k = 0; k < n_my; k += 2) {

@@ -71,6 +71,48 @@ __global__ __launch_bounds__(512) void probe(const float* __restrict__ members, 
     }
     const int m0 = blk == 0 ? 0 : (blk == 1 ? 1 : (blk == 2 ? 2 : 0));
     const int m1 = blk == 0 ? 1 : (blk == 1 ? 2 : (blk == 2 ? 0 : 1));
+    if (MODE == 5 || MODE == 6 || MODE == 7) {
+        // wave-specialised: waves 0-3 issue MFMAs only (192 per tile), waves 4-7 only products + splits (8 fragments' worth per tile);
+        // MODE 6: the MFMA waves alone, MODE 7: the split waves alone
+        float sink = 0.f;
+        v8s keep = fixed.p[0];
+        for (int t = 0; t < tiles; ++t) {
+            asm volatile("" ::: "memory");
+            if (wave < 4) {
+                if (MODE != 7) {
+#pragma unroll
+                    for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                            for (int kb = 0; kb < 2; ++kb) {
+                                constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                                    for (int ct = 0; ct < 4; ++ct)
+                                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fixed.p[TA[term]], w[kb][ct][TB[term]], acc[rt][ct], 0, 0, 0);
+                            }
+                }
+            } else if (MODE != 6) {
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    const int row = 16 * (f & 1) + arow;
+                    const int c4 = (8 * f + 8 * kq) >> 2 & 31;
+                    const int s0 = ((c4 ^ (row & 15)) << 2) & 127, s1 = (((c4 + 1) ^ (row & 15)) << 2) & 127;
+                    const v4f u0 = *reinterpret_cast<const v4f*>(&tile[0][row][s0]), u1 = *reinterpret_cast<const v4f*>(&tile[0][row][s1]);
+                    const v4f q0 = *reinterpret_cast<const v4f*>(&tile[1][row][s0]), q1 = *reinterpret_cast<const v4f*>(&tile[1][row][s1]);
+                    float z[8];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { z[i] = u0[i] * q0[i]; z[4 + i] = u1[i] * q1[i]; }
+                    const Planes a = split8(z);
+                    keep ^= a.p[0] ^ a.p[1] ^ a.p[2];
+                }
+                *reinterpret_cast<v8s*>(&part[wave][arow][4 * kq]) = keep;
+            }
+        }
+        if (sink == 1.f) out[1] = sink;
+    } else
     for (int t = 0; t < tiles; ++t) {
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -148,6 +190,8 @@ int main() {
     hipMemcpy(members, hm.data(), hm.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(wplanes, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     const float m1 = run<1>(members, wplanes, out, tiles), m3 = run<3>(members, wplanes, out, tiles), m4 = run<4>(members, wplanes, out, tiles);
+    const float m5 = run<5>(members, wplanes, out, tiles), m6 = run<6>(members, wplanes, out, tiles), m7 = run<7>(members, wplanes, out, tiles);
+    printf("{\"specialised_both_ms\": %.4f, \"mfma_waves_alone_ms\": %.4f, \"split_waves_alone_ms\": %.4f}\n", m5, m6, m7);
     const double mfma = 256.0 * 8 * tiles * 96;             // MFMAs per launch
     printf("{\"tiles_per_workgroup\": %d, \"mfma_only_ms\": %.4f, \"with_split_ms\": %.4f, \"with_split_and_barrier_ms\": %.4f, "
            "\"mfma_only_cycles_per_mfma_per_simd_at_2.1GHz\": %.2f}\n",
