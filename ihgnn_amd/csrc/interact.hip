@@ -2035,7 +2035,7 @@ extern "C" {
 int64_t ihg_interact_fwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order) {
     (void)n_edges;
     if (!mfma_dim(dim) || (order != 2 && order != 3)) return 0;
-    return packed_weight_floats(dim, order) * static_cast<int64_t>(sizeof(float));
+    return (packed_weight_floats(dim, order) + split_plane_floats(dim, order)) * static_cast<int64_t>(sizeof(float));
 }
 
 int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w,
@@ -2054,6 +2054,10 @@ int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p,
         if (workspace_bytes < ihg_interact_fwd_workspace_bytes(n_edges, dim, order)) return fail(IHG_ERR_WORKSPACE, "ihg_interact_fwd: workspace too small");
         float* wp = static_cast<float*>(workspace);
         const int nblk = order == 3 ? 4 : 3;
+        if (split_fwd_ok(dim, order, p, ld_p, out, ld_out, ld_h)) {       // bf16-split contraction; its planes sit behind the fp32-packed weights
+            launch_fwd_split(h, ld_h, p, ld_p, i3, w, ld_w, wp + packed_weight_floats(dim, order), out, ld_out, n_edges, s);
+            return check_launch("ihg_interact_fwd");
+        }
         const int pack_items = (dim / 32) * nblk * (dim / 8) * kWave;
         if (strip_fwd_ok(dim, p, ld_p, out, ld_out, ld_h))
             hipLaunchKernelGGL(pack_weights_strip_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wp,
