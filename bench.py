@@ -25,7 +25,8 @@ One JSON line is printed by rank 0.  It carries
                               (profiles/r2/pmc_traffic_<config>.json) when committed for this exact workload;
   roofline_hyperedge_to_node  one object per K7 launch role (edge features -> nodes, member gradients -> nodes, two-hop ...), each with
                               its own byte counts;
-  roofline_interaction        the order-2/3 contraction (fp32 MFMA) - the kernels that own most of a C3 / C5 step;
+  roofline_interaction        the order-2/3 contraction - the kernels that own most of a C3 / C5 step - against the matrix-core peak of the
+                              arithmetic it runs in (fp32 MFMA, or for d = 128 / order 3 the bf16 peak / 6: six bf16 products per multiply);
   cpu_baseline                the CPU oracle (= the reference's PyTorch-CPU op sequence) timed on this box's host cores on a stated
                               sub-sample of the same config.
 """
@@ -49,6 +50,12 @@ WORKLOAD_NOTES = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a float4 streaming copy reaches ~6290
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md); the split arithmetic spends six bf16 products per fp32 multiply
+
+
+def split_arithmetic(dim, order):
+    """True when the library runs this shape's contractions through three exact bf16 terms per operand (csrc/split_arith.hip)."""
+    return dim == 128 and order == 3 and os.environ.get('IHG_INTERACT_ARITH') != 'f32'
 
 
 def parse():
@@ -301,7 +308,7 @@ def main():
     kernels = profiler.summary() if not args.no_kernel_events else {}
     final_loss = float(last.item())
 
-    table, table_steps, restricted_elapsed, fwd_elapsed, stress, eval_stats = {}, min(args.steps, 5), None, None, None, None
+    table, table_steps, restricted_elapsed, fwd_elapsed, stress, eval_stats, f32_elapsed = {}, min(args.steps, 5), None, None, None, None, None
     if not args.no_extras:
         # per-kernel table (K7 roles, MFMA kernels): a second, untimed pass over the same batches with every launch bracketed
         if not args.no_kernel_events:
@@ -311,6 +318,19 @@ def main():
             fence()
             profiler.stop()
             table = profiler.summary()
+        # the same step with the d = 128 contractions on the fp32-MFMA kernels (the library reads the switch at every call)
+        if split_arithmetic(dim, args.order):
+            os.environ['IHG_INTERACT_ARITH'] = 'f32'
+            for k in range(2):
+                step(k)
+            fence()
+            t3 = time.perf_counter()
+            n_3 = min(args.steps, 10)
+            for k in range(args.warmup, args.warmup + n_3):
+                step(k)
+            fence()
+            f32_elapsed = max_over_ranks((time.perf_counter() - t3) / n_3)
+            del os.environ['IHG_INTERACT_ARITH']
         # the same step with the last layer's hyperedge -> node pass evaluated only at the rows the loss reads (split rows + the 3B
         # batch rows): identical loss and gradients, what the training loop runs by default; reported beside the headline
         model.batch_rows_only_last_layer = True
@@ -399,11 +419,19 @@ def main():
         flops_fwd = 2.0 * m_blocks * dim * dim * E
         f, bw = table['interact_fwd'], table['interact_bwd']
         bwd_us = bw['avg_us'] * bw['launches'] / table_steps        # the backward may run in several hyperedge chunks
+        split = split_arithmetic(dim, args.order)
+        peak = MFMA_BF16_PEAK_TF / 6 if split else MFMA_F32_PEAK_TF
         mfma_roof = dict(bound='mfma', kernel='interact_fwd + interact_bwd (order-%d product blocks of layer 0)' % args.order,
-                         peak=MFMA_F32_PEAK_TF, unit='TFLOP/s', dtype='f32 in / f32 accumulate (v_mfma_f32_32x32x2_f32)',
-                         forward=dict(achieved=round(flops_fwd / (f['avg_us'] * 1e-6) / 1e12, 1), frac=round(flops_fwd / (f['avg_us'] * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 4),
+                         peak=round(peak, 1), unit='TFLOP/s',
+                         dtype=('f32 operands taken apart exactly into three bf16 terms, six v_mfma_f32_16x16x32_bf16 products per multiply, f32 accumulate: '
+                                'peak = dense bf16 MFMA peak / 6, flops counted as fp32 multiply-adds') if split else
+                               'f32 in / f32 accumulate (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)',
+                         f32_mfma_peak=MFMA_F32_PEAK_TF,
+                         forward=dict(achieved=round(flops_fwd / (f['avg_us'] * 1e-6) / 1e12, 1), frac=round(flops_fwd / (f['avg_us'] * 1e-6) / (peak * 1e12), 4),
+                                      vs_f32_mfma_peak=round(flops_fwd / (f['avg_us'] * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 3),
                                       flops_per_launch=flops_fwd, avg_us=round(f['avg_us'], 2)),
-                         backward=dict(achieved=round(2 * flops_fwd / (bwd_us * 1e-6) / 1e12, 1), frac=round(2 * flops_fwd / (bwd_us * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 4),
+                         backward=dict(achieved=round(2 * flops_fwd / (bwd_us * 1e-6) / 1e12, 1), frac=round(2 * flops_fwd / (bwd_us * 1e-6) / (peak * 1e12), 4),
+                                       vs_f32_mfma_peak=round(2 * flops_fwd / (bwd_us * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 3),
                                        flops_per_step=2 * flops_fwd, us_per_step=round(bwd_us, 2)),
                          share_of_step=round((f['avg_us'] + bwd_us) * 1e-3 / (1e3 * elapsed / args.steps), 3),
                          measured='instrumented pass after the timed region (every launch bracketed)')
@@ -416,7 +444,10 @@ def main():
                                f'dim={dim}, {layers}x{args.layer} layers, interaction order {args.order}, batch 100 pos + 1000 neg',
                    'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd + Adam' +
                            (f' + RCCL gradient exchange ({args.sync})' if world > 1 else ''),
-                   'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}'},
+                   'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
+                   'arithmetic': ('f32 results; the d = 128 / order 3 contractions and node-level row GEMMs multiply through three exact bf16 terms per '
+                                  'operand (six bf16 MFMA products, f32 accumulation; error <= the fp32-MFMA kernels\' - tests/test_gpu_parity.py); '
+                                  'IHG_INTERACT_ARITH=f32 selects the fp32-MFMA kernels') if split_arithmetic(dim, args.order) else 'f32 (fp32 MFMA / VALU)'},
         'final_loss': round(final_loss, 6),
         'roofline': roofline,
         'roofline_hyperedge_to_node': k7_roles(table, E, N, dim, layout, table_steps) or None,
@@ -427,6 +458,9 @@ def main():
         out['batch_rows_last_layer_value'] = round(world * E * layers / restricted_elapsed, 1)
         out['batch_rows_last_layer_note'] = ('same step with the last layer\'s hyperedge->node pass evaluated only at the rows the loss reads '
                                              '(identical loss and gradients; the training loop\'s default); NOT the headline')
+    if f32_elapsed is not None:
+        out['fp32_mfma_kernels_ms_per_step'] = round(1e3 * f32_elapsed, 4)
+        out['fp32_mfma_kernels_note'] = 'same full step with IHG_INTERACT_ARITH=f32 (fp32-MFMA contractions instead of the bf16-split ones); NOT the headline'
     if fwd_elapsed is not None:
         out['fwd_only_hyperedges_per_s'] = round(E * layers / fwd_elapsed, 1)
         out['fwd_only_ms'] = round(1e3 * fwd_elapsed, 4)

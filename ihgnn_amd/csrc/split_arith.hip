@@ -853,12 +853,9 @@ __global__ __launch_bounds__(512, 4) void row_gemm_split_kernel(const float* __r
 
 int64_t split_plane_floats(int dim, int order) { return dim == 128 && order == 3 ? (3LL * 4 * dim * dim) / 2 : 0; }
 
-bool split_arith_enabled() {
-    static const bool enabled = [] {
-        const char* v = std::getenv("IHG_INTERACT_ARITH");
-        return v == nullptr || std::strcmp(v, "f32") != 0;
-    }();
-    return enabled;
+bool split_arith_enabled() {                                             // read at every call: tests and the bench switch it in-process
+    const char* v = std::getenv("IHG_INTERACT_ARITH");
+    return v == nullptr || std::strcmp(v, "f32") != 0;
 }
 
 bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout) {

@@ -372,6 +372,55 @@ def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, monkey
     assert bool((grads[True][0][:users][isolated.to(dev())] == 0).all())
 
 
+@pytest.mark.parametrize('which', ['forward_backward', 'persistent', 'user_slot'])
+def test_interact_fp32_mfma_kernels_stay_covered(which, monkeypatch):
+    """d = 128, order 3 runs on the bf16-split kernels by default; IHG_INTERACT_ARITH=f32 (read by the library at every call) selects
+    the fp32-MFMA strip kernels, which must keep passing the same cases."""
+    monkeypatch.setenv('IHG_INTERACT_ARITH', 'f32')
+    if which == 'forward_backward':
+        test_interact_forward_backward(128, 3)
+    elif which == 'persistent':
+        test_interact_persistent_tiles_and_strided_rows(128, 3, 1100 * 64 + 37)
+    else:
+        test_interact_backward_user_slot_reduced_on_chip(3, 700 * 32 + 5, 301, monkeypatch)
+
+
+def test_split_arithmetic_is_as_accurate_as_fp32_mfma(monkeypatch):
+    """The d = 128 / order 3 contractions through three exact bf16 terms per operand (six bf16 MFMA products, fp32 accumulation) against
+    the same op in float64: the error must not exceed the fp32-MFMA kernels' own (both are far inside the 1e-5 bar).  Also the
+    node-level row GEMM, which takes the same arithmetic."""
+    from ihgnn_amd import ops
+    from oracle import ihgnn_ref as ref
+    dim, order, U, Q, I, E = 128, 3, 301, 17, 211, 9000
+    w_, lay = make_layout(U, Q, I, E, seed=5, edge_order='user')
+    gen = torch.Generator().manual_seed(11)
+    h = torch.randn(lay.node_count, dim, generator=gen)
+    w = torch.randn(dim, 7 * dim, generator=gen) / np.sqrt(7 * dim)
+    b = torch.randn(dim, generator=gen)
+    cot = torch.randn(lay.edge_count, dim, generator=gen) / 8
+    h64, w64 = h.double().requires_grad_(True), w.double().requires_grad_(True)
+    want = ref.feature_interactor(h64, torch.from_numpy(lay.i3_host.astype(np.int64)), w64, b.double(), order)
+    want.backward(cot.double())
+    wl = torch.randn(dim, dim, generator=gen) / np.sqrt(dim)
+    lin64 = h.double() @ wl.double().T
+
+    def run():
+        hg, wg = h.clone().to(dev()).requires_grad_(True), w.clone().to(dev()).requires_grad_(True)
+        first = torch.cat([torch.nn.functional.linear(hg[:U], wg[:, :dim], b.to(dev())), torch.nn.functional.linear(hg[U:U + Q], wg[:, dim:2 * dim]),
+                           torch.nn.functional.linear(hg[U + Q:], wg[:, 2 * dim:3 * dim])])
+        got = ops.interact(hg, first, wg, lay, order)
+        got.backward(cot.to(dev()))
+        lin = ops.node_linear(h.to(dev()), wl.to(dev()), None, lay)
+        return [rel(got.double(), want), rel(hg.grad.double(), h64.grad), rel(wg.grad.double(), w64.grad), rel(lin.double(), lin64)]
+
+    monkeypatch.setenv('IHG_INTERACT_ARITH', 'f32')
+    err_f32 = run()
+    monkeypatch.delenv('IHG_INTERACT_ARITH')
+    err_split = run()
+    for es, ef in zip(err_split, err_f32):
+        assert es <= RTOL / 5 and es <= max(2 * ef, 5e-7), (err_split, err_f32)
+
+
 @pytest.mark.parametrize('dim', [12, 64, 128, 256])
 def test_interact_backward_in_hyperedge_chunks(dim, monkeypatch):
     """The [E, 3, d] member-gradient buffer produced in three hyperedge chunks (what config C5 needs on one GPU): gradients
