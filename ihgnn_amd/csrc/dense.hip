@@ -452,7 +452,7 @@ int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int
     const int n_types = w_type_stride == 0 ? 1 : 3;
     if (split_row_gemm_ok(dim, out, ld_out, bias, bias_type_stride)) {   // the bf16 planes sit behind the slabs (see ihg_node_linear_workspace_bytes)
         void* planes = pk + 3LL * dim * dim + 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
-        launch_row_gemm_split(in, ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin, out, ld_out, planes, s);
+        launch_row_gemm_split(dim, in, ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin, out, ld_out, planes, s);
         return IHG_OK;
     }
     if (dim == 128 && aligned16(out) && ld_out % 4 == 0 && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0))) {

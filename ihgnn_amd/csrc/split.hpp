@@ -27,8 +27,8 @@ IHG_INTERNAL void launch_fwd_split(const float* h, int64_t ld_h, const float* p,
 IHG_INTERNAL bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout);
 IHG_INTERNAL int launch_weight_split(const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s);
 
-// node-level row GEMM (d = 128): out = in W_t^T (transpose == 0) or in W_t (transpose == 1), rows grouped by node type
+// node-level row GEMM (d = 128, 256): out = in W_t^T (transpose == 0) or in W_t (transpose == 1), rows grouped by node type
 IHG_INTERNAL int64_t split_dense_plane_floats(int dim);
 IHG_INTERNAL bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* bias, int64_t bias_type_stride);
-IHG_INTERNAL void launch_row_gemm_split(const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
+IHG_INTERNAL void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
                                         int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s);

@@ -736,11 +736,12 @@ struct RowTiles {
     int tile_prefix[4];
 };
 
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride, int n_types,
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride, int n_types, int d,
                                                                           int transpose, v4u* __restrict__ pk) {
+    const int kbs = d / 32, strips = d / 16;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_types * 8 * 4 * kWave) return;
-    const int lane = idx & 63, kb = (idx >> 6) & 3, strip = (idx >> 8) & 7, type = idx >> 11;
+    if (idx >= n_types * strips * kbs * kWave) return;
+    const int lane = idx & 63, kb = (idx >> 6) % kbs, strip = ((idx >> 6) / kbs) % strips, type = (idx >> 6) / (kbs * strips);
     const int c = 16 * strip + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
     const float* wt = w + type * type_stride;
     v4f x0, x1;
@@ -754,55 +755,65 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_kernel(const 
     for (int p = 0; p < 3; ++p) pk[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
 }
 
-__global__ __launch_bounds__(512, 4) void row_gemm_split_kernel(const float* __restrict__ in, int64_t ld_in, const v4u* __restrict__ pk, int64_t pk_type_stride,
-                                                                const float* __restrict__ bias, int bias_mask, int64_t bias_type_stride, RowTiles plan,
-                                                                float* __restrict__ out, int64_t ld_out) {
-    constexpr int TE = 32;
-    __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][256];
+// D = 128: one workgroup covers all columns, two workgroups per CU.  D = 256: a workgroup covers a column HALF (96 weight registers per
+// wave), the two halves of a tile sequence are two workgroups on one XCD (the second read of a row hits that L2), one workgroup per CU.
+template <int D>
+__global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(const float* __restrict__ in, int64_t ld_in, const v4u* __restrict__ pk,
+                                                                             int64_t pk_type_stride, const float* __restrict__ bias, int bias_mask,
+                                                                             int64_t bias_type_stride, RowTiles plan, float* __restrict__ out, int64_t ld_out) {
+    constexpr int TE = 32, KB = D / 32, OCT = D / 128, HALVES = D / 128, RB = 2 * D, STEPS = 2 * KB;
+    __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][RB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int total_tiles = plan.tile_prefix[3];
-    const int grid = gridDim.x;
-    const int n_my = static_cast<int>(blockIdx.x) < total_tiles ? (total_tiles - static_cast<int>(blockIdx.x) + grid - 1) / grid : 0;
+    const int bid = blockIdx.x;
+    const int half = HALVES == 1 ? 0 : (bid >> 3) & 1;
+    const int seq = HALVES == 1 ? bid : (bid & 7) + 8 * (bid >> 4);
+    const int n_seq = gridDim.x / HALVES;
+    const int n_my = seq < total_tiles ? (total_tiles - seq + n_seq - 1) / n_seq : 0;
     if (n_my == 0) return;
     auto tile_type = [&](int tile_id) { return tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0); };
     auto tile_rows = [&](int k, int64_t& r_base, int64_t& r_end) {
-        const int tile_id = static_cast<int>(blockIdx.x) + k * grid;
+        const int tile_id = seq + k * n_seq;
         const int type = tile_type(tile_id);
         r_base = plan.begin[type] + static_cast<int64_t>(tile_id - plan.tile_prefix[type]) * TE;
         r_end = plan.begin[type + 1];
         return type;
     };
-    const int row = tid >> 4, o = tid & 15;
+    const int row = tid >> 4, o = tid & 15;                              // staging role: row, octets o (and o + 16) of it
     const int chunk = (o ^ (row & 15)) << 4;
-    auto load_rows = [&](int k, v4f (&dr)[2]) {
+    auto load_rows = [&](int k, v4f (&dr)[2 * OCT]) {
         int64_t r_base, r_end;
         tile_rows(k, r_base, r_end);
         const int64_t v = std::min(r_base + row, r_end - 1);             // rows past the type's end re-read its last row (never stored)
         const float* src = in + v * ld_in + 8 * o;
-        dr[0] = *reinterpret_cast<const v4f*>(src);
-        dr[1] = *reinterpret_cast<const v4f*>(src + 4);
+#pragma unroll
+        for (int x = 0; x < OCT; ++x) {
+            dr[2 * x] = *reinterpret_cast<const v4f*>(src + 128 * x);
+            dr[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 128 * x + 4);
+        }
     };
-    v4f dr0[2], dr1[2];
+    v4f dr0[2 * OCT], dr1[2 * OCT];
     load_rows(0, dr0);
     if (n_my > 1) load_rows(1, dr1);
-    {
-        const Planes p0 = split8(dr0[0], dr0[1]);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[0][p][row][chunk]) = p0.p[p];
+    for (int x = 0; x < OCT; ++x) {
+        const Planes p0 = split8(dr0[2 * x], dr0[2 * x + 1]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[0][p][row][chunk + 256 * x]) = p0.p[p];
     }
     __syncthreads();
 
-    v8s wreg[4][3];
+    v8s wreg[KB][3];
     int cur_type = -1;
     const int arow = lane & 15, kq = lane >> 4;
-    auto phase = [&](int k, v4f (&use)[2], v4f (&fill)[2]) {
+    auto phase = [&](int k, v4f (&use)[2 * OCT], v4f (&fill)[2 * OCT]) {
         int64_t r_base, r_end;
         const int type = tile_rows(k, r_base, r_end);
         if (type != cur_type) {
-            const v4u* wf = pk + type * pk_type_stride + static_cast<int64_t>(wave) * 12 * kWave + lane;
+            const v4u* wf = pk + type * pk_type_stride + static_cast<int64_t>(8 * half + wave) * (KB * 3) * kWave + lane;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wreg[kb][p] = __builtin_bit_cast(v8s, wf[(kb * 3 + p) * kWave]);
             cur_type = type;
@@ -810,30 +821,35 @@ __global__ __launch_bounds__(512, 4) void row_gemm_split_kernel(const float* __r
         if (k + 2 < n_my) load_rows(k + 2, fill);
         v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
         const unsigned char* pbase = &planes[k & 1][0][0][0];
-        v4u sp[3];
+        v4u sp[OCT][3];
 #pragma unroll
-        for (int step = 0; step < 8; ++step) {
+        for (int step = 0; step < STEPS; ++step) {
             const int kb = step >> 1, rt = step & 1;
             v8s a[3];
-            const unsigned char* src = pbase + (16 * rt + arow) * 256 + (((4 * kb + kq) ^ arow) << 4);
+            const unsigned char* src = pbase + (16 * rt + arow) * RB + (((4 * kb + kq) ^ arow) << 4);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * 256));
-            if (step < 4) {   // two of the eight values of the next tile's row piece -> one dword of each plane
-                const float xa = use[step >> 1][2 * (step & 1)], xb = use[step >> 1][2 * (step & 1) + 1];
+            for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * RB));
+            if (step < 4 * OCT) {   // two values of the next tile's row piece -> one dword of each plane
+                const int x = step >> 2, pr = step & 3;
+                const float xa = use[2 * x + (pr >> 1)][2 * (pr & 1)], xb = use[2 * x + (pr >> 1)][2 * (pr & 1) + 1];
                 const float ra = xa - top16(xa), rb = xb - top16(xb);
                 const float la = ra - top16(ra), lb = rb - top16(rb);
-                sp[0][step] = pack_hi(xa, xb);
-                sp[1][step] = pack_hi(ra, rb);
-                sp[2][step] = pack_hi(la, lb);
+                sp[x][0][pr] = pack_hi(xa, xb);
+                sp[x][1][pr] = pack_hi(ra, rb);
+                sp[x][2][pr] = pack_hi(la, lb);
             }
 #pragma unroll
             for (int term = 0; term < 6; ++term)
                 acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][kTermB[term]], a[kTermA[term]], acc[rt], 0, 0, 0);
         }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk]) = sp[p];        // (past the last tile: nobody reads it)
-        asm volatile("" : "+v"(fill[0]), "+v"(fill[1]));                  // delivery of the next-but-one tile's rows before the stores (see the member-gradient kernel)
-        const int c4 = 16 * wave + 4 * kq;
+        for (int x = 0; x < OCT; ++x)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk + 256 * x]) = sp[x][p];     // (past the last tile: nobody reads it)
+        // delivery of the next-but-one tile's rows before the stores (see the member-gradient kernel)
+        if (OCT == 1) asm volatile("" : "+v"(fill[0]), "+v"(fill[1]));
+        else asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * OCT - 2]), "+v"(fill[2 * OCT - 1]));
+        const int c4 = 128 * half + 16 * wave + 4 * kq;
         v4f bv = v4f{0.f, 0.f, 0.f, 0.f};
         if (bias != nullptr && ((bias_mask >> type) & 1)) bv = *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + c4);
 #pragma unroll
@@ -877,18 +893,19 @@ void launch_members_split(const float* h, int64_t ld_h, const int32_t* i3, const
     if (n_boundary_entries != nullptr) *n_boundary_entries = 2 * kSplitRanges;
 }
 
-int64_t split_dense_plane_floats(int dim) { return dim == 128 ? (3LL * 3 * dim * dim) / 2 : 0; }
+int64_t split_dense_plane_floats(int dim) { return dim == 128 || dim == 256 ? (3LL * 3 * dim * dim) / 2 : 0; }
 
 bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* bias, int64_t bias_type_stride) {
-    return split_arith_enabled() && dim == 128 && aligned16(out) && ld_out % 4 == 0 && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0));
+    return split_arith_enabled() && (dim == 128 || dim == 256) && aligned16(out) && ld_out % 4 == 0 && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0));
 }
 
-void launch_row_gemm_split(const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
+void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
                            int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s) {
     const int n_types = w_type_stride == 0 ? 1 : 3;
     v4u* pk = static_cast<v4u*>(planes);
-    hipLaunchKernelGGL(pack_planes_dense_kernel, dim3((n_types * 8 * 4 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w,
-                       w_type_stride, n_types, transpose, pk);
+    const int items = n_types * (dim / 16) * (dim / 32) * kWave;
+    hipLaunchKernelGGL(pack_planes_dense_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types, dim,
+                       transpose, pk);
     RowTiles plan;
     int acc = 0;
     for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
@@ -898,8 +915,15 @@ void launch_row_gemm_split(const float* in, int64_t ld_in, const float* w, int64
     }
     plan.tile_prefix[3] = acc;
     if (acc == 0) return;
-    hipLaunchKernelGGL(row_gemm_split_kernel, dim3(std::min(acc, 512)), dim3(512), 0, s, in, ld_in, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 3 * kWave}, bias,
-                       bias_mask, bias_type_stride, plan, out, ld_out);
+    const int64_t pk_type_stride = n_types == 1 ? int64_t{0} : static_cast<int64_t>(dim / 16) * (dim / 32) * 3 * kWave;
+    if (dim == 128) {
+        hipLaunchKernelGGL(row_gemm_split_kernel<128>, dim3(std::min(acc, 512)), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, bias, bias_mask, bias_type_stride, plan,
+                           out, ld_out);
+    } else {
+        const int n_seq = std::min((acc + 7) / 8 * 8, 256);              // tile sequences: a multiple of 8, so that both halves of one land on one XCD
+        hipLaunchKernelGGL(row_gemm_split_kernel<256>, dim3(2 * n_seq), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, bias, bias_mask, bias_type_stride, plan, out,
+                           ld_out);
+    }
 }
 
 bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout) {
