@@ -710,7 +710,11 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     float* bias_slabs = slabs + 3LL * kDenseSlabs * dim * dim;
     const TypePlan plan = make_plan(type_begin, 64);
     // weights of type t are the column block t of w exactly as for dw: w_type_stride == dw_type_stride
-    if (dim == 64 && dx != nullptr) {
+    int n_slabs = kDenseSlabs;
+    if (split_dense_weight_ok(dim, dout, ld_dout, x, ld_x)) {             // bf16-split contraction (d = 128, 256); the input gradient stays a row-GEMM launch
+        if (dx != nullptr) launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace), s);
+        n_slabs = launch_dense_weight_split(dim, dout, ld_dout, x, ld_x, type_begin, n_types, slabs, bias_slabs, s);
+    } else if (dim == 64 && dx != nullptr) {
         hipLaunchKernelGGL((dense_weight_grad_kernel<64, true>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
                            n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, w, ld_w, dw_type_stride, dx, ld_dx, dx_accumulate);
     } else {
@@ -730,7 +734,7 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     }
     const int total = dim * dim * n_types + dim;
     hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, bias_slabs,
-                       kDenseSlabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask, n_types == 1 ? int64_t{0} : dbias_type_stride);
+                       n_slabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask, n_types == 1 ? int64_t{0} : dbias_type_stride);
     return check_launch("ihg_node_linear_bwd_weight");
 }
 

@@ -32,3 +32,8 @@ IHG_INTERNAL int64_t split_dense_plane_floats(int dim);
 IHG_INTERNAL bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* bias, int64_t bias_type_stride);
 IHG_INTERNAL void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
                                         int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s);
+
+// weight / bias gradient of the node-level linear maps into dense.hip's slabs ([type][slab][d][d], [type][slab][d]); returns the slabs per type
+IHG_INTERNAL bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x);
+IHG_INTERNAL int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin, int n_types,
+                                           float* slabs, float* bias_slabs, hipStream_t s);

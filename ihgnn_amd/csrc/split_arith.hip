@@ -865,6 +865,175 @@ __global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the node-level linear maps: dW_t[i][j] = sum_{v of type t} dout[v][i] x[v][j], dbias_t[i] = sum_v dout[v][i].
+// Same shape of problem as the interactive weight gradient (both operands are streams, the contraction runs over the rows), same
+// machinery: row-major bf16 images with the transposed-read swizzle, ds_read_b64_tr_b16 fragments, accumulators resident for the
+// whole sweep, one slab per tile sequence (dense.hip's layout and reduction).  D = 128: a workgroup owns the whole 128 x 128 gradient
+// (wave = 2 x 4 accumulator tiles); D = 256: a workgroup owns a column half (wave = 4 x 4 tiles), both halves of a tile sequence on
+// one XCD.  The column sums of dout ride along in the staging threads' registers.  grid = (sequences x halves, 1, node types).
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(const float* __restrict__ dout, int64_t ld_dout, const float* __restrict__ x,
+                                                                                int64_t ld_x, RowTiles plan, int single_weight, float* __restrict__ slabs,
+                                                                                float* __restrict__ bias_slabs) {
+    constexpr int TE = 32, HALVES = D / 128, DOCT = D / 128, IT = D / 64, DRB = 2 * D;     // dout image rows: 2 D bytes, x image rows: 256 bytes (128 columns)
+    constexpr int DPL = TE * DRB, XPL = TE * 256;
+    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][DRB];
+    __shared__ __attribute__((aligned(16))) unsigned char xplanes[2][3][TE][256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x, type = blockIdx.z;
+    const int half = HALVES == 1 ? 0 : (bid >> 3) & 1;
+    const int seq = HALVES == 1 ? bid : (bid & 7) + 8 * (bid >> 4);
+    const int n_seq = gridDim.x / HALVES;
+    const int64_t r_begin = single_weight ? plan.begin[0] : plan.begin[type];
+    const int64_t r_end = single_weight ? plan.begin[3] : plan.begin[type + 1];
+    const int64_t n_tiles = (r_end - r_begin + TE - 1) / TE;
+    const int n_my = seq < n_tiles ? static_cast<int>((n_tiles - seq + n_seq - 1) / n_seq) : 0;
+    const int iq = wave & 3, jh = wave >> 2;
+
+    v4f acc[IT][4];
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[it][jt] = v4f{0.f, 0.f, 0.f, 0.f};
+    v4f bsum[2 * DOCT];
+#pragma unroll
+    for (int i = 0; i < 2 * DOCT; ++i) bsum[i] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const int row = tid >> 4, o = tid & 15;                              // staging role: row; dout columns 8 o .. (and 128 + 8 o ..), x columns 128 half + 8 o ..
+    struct Rows {
+        v4f d[2 * DOCT], x[2];
+    };
+    auto load_rows = [&](int k, Rows& r) {
+        const int64_t v = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE + row;
+        const bool live = v < r_end;
+        const int64_t vc = live ? v : r_end - 1;
+        const float* ds = dout + vc * ld_dout + 8 * o;
+        const float* xs = x + vc * ld_x + 128 * half + 8 * o;
+#pragma unroll
+        for (int i = 0; i < DOCT; ++i) {
+            r.d[2 * i] = *reinterpret_cast<const v4f*>(ds + 128 * i);
+            r.d[2 * i + 1] = *reinterpret_cast<const v4f*>(ds + 128 * i + 4);
+        }
+        r.x[0] = *reinterpret_cast<const v4f*>(xs);
+        r.x[1] = *reinterpret_cast<const v4f*>(xs + 4);
+        if (!live) {                                                     // rows past the type's end contribute nothing
+#pragma unroll
+            for (int i = 0; i < 2 * DOCT; ++i) r.d[i] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    const int swz = tr_swizzle(row);
+    const int st_off = row * 256 + ((o ^ swz) << 4);                     // 16 bytes of a 256-byte segment of this thread's row
+    // a staged tile -> images `buf`, one pair of values per slice: slices 0 .. 4 DOCT - 1 dout (the column sums ride along), then 4 of x
+    v4u sp[3];
+    auto split_slice = [&](int slice, const Rows& r, int buf, bool counted) {
+        const bool is_x = slice >= 4 * DOCT;
+        const int s = is_x ? slice - 4 * DOCT : slice, oct = s >> 2, pr = s & 3;
+        const v4f v = is_x ? r.x[pr >> 1] : r.d[2 * oct + (pr >> 1)];
+        const float xa = v[2 * (pr & 1)], xb = v[2 * (pr & 1) + 1];
+        const float ra = xa - top16(xa), rb = xb - top16(xb);
+        const float la = ra - top16(ra), lb = rb - top16(rb);
+        sp[0][pr] = pack_hi(xa, xb);
+        sp[1][pr] = pack_hi(ra, rb);
+        sp[2][pr] = pack_hi(la, lb);
+        if (!is_x && (pr & 1) == 1 && counted) bsum[2 * oct + (pr >> 1)] += v;
+        if (pr == 3) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if (is_x) *reinterpret_cast<v4u*>(&xplanes[buf][0][0][0] + p * XPL + st_off) = sp[p];
+                else *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + row * (DRB - 256) + 256 * oct + st_off) = sp[p];
+            }
+        }
+    };
+    constexpr int SLICES = 4 * DOCT + 4, STEPS = IT * 4;
+
+    if (n_my > 0) {
+        Rows r0, r1;
+        load_rows(0, r0);
+        if (n_my > 1) load_rows(1, r1);
+#pragma unroll
+        for (int s2 = 0; s2 < SLICES; ++s2) split_slice(s2, r0, 0, true);
+        __syncthreads();
+
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const int rlo = 8 * g + q, rhi = rlo + 4;
+        // dout columns (output rows i): tile IT iq + it -> byte 32 (IT iq + it) + 8 pp of a DRB-byte row, 256-byte segments swizzled separately
+        auto a_addr = [&](int r, int it) {
+            const int tile = IT * iq + it, seg = tile >> 3, ch = 2 * (tile & 7) + (pp >> 1);
+            return r * DRB + 256 * seg + ((ch ^ tr_swizzle(r)) << 4) + 8 * (pp & 1);
+        };
+        auto b_addr = [&](int r, int jt) { return r * 256 + (((8 * jh + 2 * jt + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
+
+        auto phase = [&](auto parity, int k, Rows& use, Rows& fill) {
+            constexpr int BUF = decltype(parity)::value;
+            if (k + 2 < n_my) load_rows(k + 2, fill);
+            const unsigned char* dp = &dplanes[BUF][0][0][0];
+            const unsigned char* xp = &xplanes[BUF][0][0][0];
+            v8s a[IT][3];
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[it][p] = read_tr_fragment(dp + p * DPL + a_addr(rlo, it), dp + p * DPL + a_addr(rhi, it));
+            v8s b[3], bn[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[p] = read_tr_fragment(xp + p * XPL + b_addr(rlo, 0), xp + p * XPL + b_addr(rhi, 0));
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                if (jt + 1 < 4) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(xp + p * XPL + b_addr(rlo, jt + 1), xp + p * XPL + b_addr(rhi, jt + 1));
+                }
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int step = jt * IT + it;                       // the next tile's split, spread over this tile's MFMA groups
+#pragma unroll
+                    for (int s2 = step * SLICES / STEPS; s2 < (step + 1) * SLICES / STEPS; ++s2) split_slice(s2, use, BUF ^ 1, k + 1 < n_my);   // (past the last tile: stale rows, nobody reads those images)
+                }
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int it = 0; it < IT; ++it)
+                        acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it][kTermA[term]], b[kTermB[term]], acc[it][jt], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = bn[p];
+            }
+            if (DOCT == 1) asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
+            else asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.d[2 * DOCT - 2]), "+v"(fill.d[2 * DOCT - 1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
+            __syncthreads();
+        };
+        for (int k = 0; k < n_my; k += 2) {
+            phase(std::integral_constant<int, 0>{}, k, r1, r0);
+            if (k + 1 < n_my) phase(std::integral_constant<int, 1>{}, k + 1, r0, r1);
+        }
+    }
+    // slab [type][sequence][i][j]; accumulator tile (it, jt): row i = 16 (IT iq + it) + 4 (lane >> 4) + r, column j = 128 half + 64 jh + 16 jt + (lane & 15)
+    float* slab = slabs + (static_cast<int64_t>(type) * n_seq + seq) * D * D;
+    const int c = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[static_cast<int64_t>(16 * (IT * iq + it) + 4 * kq + r) * D + 128 * half + 64 * jh + 16 * jt + c] = acc[it][jt][r];
+    // column sums of dout: the 32 staging rows of a column meet in LDS (the images are free now) and are added in row order
+    float* red = reinterpret_cast<float*>(&dplanes[0][0][0][0]);        // [32][D] floats = 4 KB .. 32 KB
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DOCT; ++i) {
+        *reinterpret_cast<v4f*>(red + row * D + 128 * i + 8 * o) = bsum[2 * i];
+        *reinterpret_cast<v4f*>(red + row * D + 128 * i + 8 * o + 4) = bsum[2 * i + 1];
+    }
+    __syncthreads();
+    if (half == 0 && tid < D) {
+        float sum = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < TE; ++r) sum += red[r * D + tid];
+        bias_slabs[(static_cast<int64_t>(type) * n_seq + seq) * D + tid] = sum;
+    }
+}
+
 }  // namespace
 
 int64_t split_plane_floats(int dim, int order) { return dim == 128 && order == 3 ? (3LL * 4 * dim * dim) / 2 : 0; }
@@ -945,4 +1114,25 @@ void launch_fwd_split(const float* h, int64_t ld_h, const float* p, int64_t ld_p
     v4u* wsp = static_cast<v4u*>(planes);
     hipLaunchKernelGGL(pack_planes_fwd_kernel, dim3(2 * 8 * 4 * 2 * kWave / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, wsp);
     hipLaunchKernelGGL(interact_fwd_split_kernel, dim3(2 * kSplitRanges), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
+}
+
+bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x) {
+    return split_arith_enabled() && (dim == 128 || dim == 256) && aligned16(dout) && aligned16(x) && ld_dout % 4 == 0 && ld_x % 4 == 0;
+}
+
+int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs,
+                              float* bias_slabs, hipStream_t s) {
+    RowTiles plan;
+    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
+    for (int t = 0; t < 4; ++t) plan.tile_prefix[t] = 0;                 // (the kernel takes its tiles from the row ranges)
+    if (dim == 128) {
+        const int n_seq = 256;
+        hipLaunchKernelGGL(dense_weight_grad_split_kernel<128>, dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0,
+                           slabs, bias_slabs);
+        return n_seq;
+    }
+    const int n_seq = 128;
+    hipLaunchKernelGGL(dense_weight_grad_split_kernel<256>, dim3(2 * n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0,
+                       slabs, bias_slabs);
+    return n_seq;
 }
