@@ -33,10 +33,19 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
     const int grp = lane / G;
     const int64_t n_ids = n_edges * 3;
 
-    for (int64_t e0 = global_wave_id() * EPW; e0 < n_edges; e0 += global_wave_count() * EPW) {
+    // the member ids of the NEXT iteration are requested before this iteration's rows: the id -> row dependency then costs one memory
+    // round trip per iteration instead of two
+    const int64_t stride = global_wave_count() * EPW;
+    int64_t e0 = global_wave_id() * EPW;
+    int next_id = (lane < EPW * 3 && e0 * 3 + lane < n_ids) ? i3[e0 * 3 + lane] : 0;
+    for (; e0 < n_edges; e0 += stride) {
         const int64_t pos = e0 * 3 + lane;
         const bool have = lane < EPW * 3 && pos < n_ids;
-        const int my_id = have ? i3[pos] : 0;
+        const int my_id = next_id;
+        {
+            const int64_t npos = pos + stride * 3;
+            next_id = (lane < EPW * 3 && npos < n_ids) ? i3[npos] : 0;
+        }
         const float my_scale = (node_scale != nullptr && have) ? node_scale[my_id] : 1.f;
 
         int ids[U][3];
