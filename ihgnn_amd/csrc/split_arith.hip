@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_kern
         };
         float* ucolp = utile[k & 1][ucol];                               // (k - 2) & 1
         const float (*dz)[TE][DZ] = dzimg[(k - 1) & 1];
-        v4f g_u, g_q, g_i, z_uq, z_qi, z_iu, z_uqi, sv, svn;
+        v4f g_u, g_q, g_i, z_uq, z_qi, z_iu, z_uqi, sv = v4f{0.f, 0.f, 0.f, 0.f}, svn = sv;
         v8s a[3], an[3];
         v4u sp[3];
         fragment(0, a);
@@ -526,15 +526,14 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kernel(const
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradients dW_b[j][c] = sum_e dout[e][j] z_b[e][c].  The contraction runs over the hyperedges, both operands are streams:
-// per tile of 32 hyperedges (one MFMA k-block) every thread splits 8 dout values and the 16 products z_b of one hyperedge's 4
-// columns (of a column HALF: the two halves of a tile range are two workgroups on one XCD) and lays them down as bf16 images, ROW-major
+// per tile of 32 hyperedges (one MFMA k-block) the dout values and the products z_b of a column HALF (the two halves of a tile range
+// are two workgroups on one XCD) are split and laid down as bf16 images, ROW-major
 // as they come ([hyperedge][column], 16-byte chunk ch of a row at ch ^ (((row & 3) << 2) | ((row >> 2) & 3)) within each 256-byte
 // segment); the MFMA operands need 8 consecutive HYPEREDGES of one column per lane, which ds_read_b64_tr_b16 delivers from those
 // images (lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. of a 4 x 16 block and receives column `lane` of its 4
-// rows; with this swizzle the reads of a half wave - two blocks 8 rows apart - are conflict-free).  Wave (jq, b) keeps the 64 x 64
-// block (j half jq, product block b) of the half's gradient in 16 accumulator tiles for the whole kernel; nothing leaves the CU
-// until the end (one slab per tile range, summed by interact.hip's slab_reduce_kernel in a fixed order).  One barrier per tile:
-// the split of tile k + 1 is spread over the MFMAs of tile k, rows are requested two tiles ahead.
+// rows; with this swizzle the reads of a half wave - two blocks 8 rows apart - are conflict-free).  The gradient stays in
+// accumulators for the whole kernel; nothing leaves the CU until the end (one slab per tile range, summed by interact.hip's
+// slab_reduce_kernel in a fixed order).  One barrier per tile, images double-buffered, rows requested two tiles ahead.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tr_swizzle(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -545,11 +544,17 @@ __device__ __forceinline__ v8s read_tr_fragment(const unsigned char* lo, const u
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
-                                                                                  const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ slabs,
-                                                                                  int64_t n_edges) {
+// The two jobs sit on different waves: waves 0-3 (one per SIMD) only read fragments and issue MFMAs - 192 per tile, block b = wave, all
+// eight 16-row tiles of dout columns - and waves 4-7 (their SIMD partners) only request, multiply, split and lay down the next tile.
+// An in-order wave that does both stalls its MFMA stream on every wait of the staging work (that form measured 1,880 us against
+// 1,710 on the same box); apart, the matrix waves run at the one-wave-per-SIMD rate (tools/split_probe.hip: 17.6 instead of 21
+// cycles per MFMA) and part of the split waves' vector instructions falls into the issue cycles the MFMAs leave.  Alone, the matrix
+// waves would take 1,350 us and the split waves 1,035.
+__global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
+                                                                                     const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ slabs,
+                                                                                     int64_t n_edges) {
     constexpr int TE = kSplitTE, D = 128, HC = 64, NBLK = 4;
-    constexpr int DPL = TE * 256, ZPL = TE * 512;                        // bytes of one plane of the dout / product images
+    constexpr int DPL = TE * 256, ZPL = TE * 512;
     __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][256];
     __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][512];
     __shared__ int ids[8][3 * TE];
@@ -561,161 +566,153 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_kerne
     const int64_t per = (n_tiles + kSplitRanges - 1) / kSplitRanges;
     const int64_t t0 = range * per;
     const int n_my = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(per, n_tiles - t0)));
-    const int jq = wave & 1, blk = wave >> 1;
 
-    v4f acc[4][4];
+    if (wave >= 4) {
+        // ---------------- split waves: 256 threads, thread -> hyperedge row, dout octets o and o + 8, member columns 4 o .. and 32 + 4 o ..
+        const int st = tid - 256, row = st >> 3, o = st & 7;
+        const int64_t last_pos = n_edges * 3 - 1;
+        auto fetch_id = [&](int k) { return i3[std::min<int64_t>((t0 + k) * (3 * TE) + st, last_pos)]; };     // (st < 96)
+        struct Rows {
+            v4f d[4], m[2][3];
+        };
+        auto load_rows = [&](int k, Rows& r) {
+            const int64_t e = (t0 + k) * TE + row;
+            const float* src = dout + std::min<int64_t>(e, n_edges - 1) * ld_dout + 8 * o;
+            r.d[0] = *reinterpret_cast<const v4f*>(src);
+            r.d[1] = *reinterpret_cast<const v4f*>(src + 4);
+            r.d[2] = *reinterpret_cast<const v4f*>(src + 64);
+            r.d[3] = *reinterpret_cast<const v4f*>(src + 68);
+            if (e >= n_edges) r.d[0] = r.d[1] = r.d[2] = r.d[3] = v4f{0.f, 0.f, 0.f, 0.f};
+            const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+            for (int m = 0; m < 3; ++m) {
+                const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + HC * half + 4 * o;
+                r.m[0][m] = *reinterpret_cast<const v4f*>(hp);
+                r.m[1][m] = *reinterpret_cast<const v4f*>(hp + 32);
+            }
+        };
+        const int swz = tr_swizzle(row);
+        auto split_tile = [&](const Rows& r, int buf) {
+            auto pair = [&](float xa, float xb, unsigned (&out)[3]) {
+                const float ra = xa - top16(xa), rb = xb - top16(xb);
+                const float la = ra - top16(ra), lb = rb - top16(rb);
+                out[0] = pack_hi(xa, xb);
+                out[1] = pack_hi(ra, rb);
+                out[2] = pack_hi(la, lb);
+            };
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {                                // dout octets o + 8 x
+                v4u sp[3];
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    unsigned w[3];
+                    pair(r.d[2 * x + (pr >> 1)][2 * (pr & 1)], r.d[2 * x + (pr >> 1)][2 * (pr & 1) + 1], w);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) sp[p][pr] = w[p];
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + row * 256 + (((o + 8 * x) ^ swz) << 4)) = sp[p];
+            }
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {                                // member column groups 4 (o + 8 x) ..
+                const int og = o + 8 * x;
+                const v4f u = r.m[x][0], q = r.m[x][1], it = r.m[x][2];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const v4f z = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    unsigned w0[3], w1[3];
+                    pair(z[0], z[1], w0);
+                    pair(z[2], z[3], w1);
+                    const int off = row * 512 + 256 * (b >> 1) + (((8 * (b & 1) + (og >> 1)) ^ swz) << 4) + 8 * (og & 1);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + p * ZPL + off) = v2u{w0[p], w1[p]};
+                }
+            }
+        };
+        if (n_my > 0) {
+            if (st < 3 * TE) {
+                ids[0][st] = fetch_id(0);
+                if (n_my > 1) ids[1][st] = fetch_id(1);
+                if (n_my > 2) ids[2][st] = fetch_id(2);
+                if (n_my > 3) ids[3][st] = fetch_id(3);
+            }
+            // (only the split waves read the id ring: a barrier among themselves would do; the workgroup barrier keeps the counts equal)
+            __syncthreads();
+            Rows r0, r1;
+            load_rows(0, r0);
+            if (n_my > 1) load_rows(1, r1);
+            split_tile(r0, 0);
+            __syncthreads();
+            int id_carry = 0;
+            auto phase = [&](int k, Rows& use, Rows& fill) {
+                if (k >= 1 && k + 3 < n_my && st < 3 * TE) ids[(k + 3) & 7][st] = id_carry;
+                if (k + 2 < n_my) load_rows(k + 2, fill);
+                if (k + 4 < n_my && st < 3 * TE) id_carry = fetch_id(k + 4);
+                if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
+                __syncthreads();
+            };
+            for (int k = 0; k < n_my; k += 2) {
+                phase(k, r1, r0);
+                if (k + 1 < n_my) phase(k + 1, r0, r1);
+            }
+        }
+        return;
+    }
+
+    // ---------------- matrix waves: wave = product block, 8 x 4 accumulator tiles (all 128 dout columns x the block's 64 columns of the half)
+    const int blk = wave;
+    v4f acc[8][4];
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[jt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
-
-    const int row = tid >> 4, o = tid & 15;                              // staging role: hyperedge row; 8 dout columns 8 o .., 4 member columns 4 o ..
-    const int64_t last_pos = n_edges * 3 - 1;
-    auto fetch_id = [&](int k) { return i3[std::min<int64_t>((t0 + k) * (3 * TE) + tid, last_pos)]; };
-    struct Rows {
-        v4f d[2], m[3];
-    };
-    auto load_rows = [&](int k, Rows& r) {
-        const int64_t e = (t0 + k) * TE + row;
-        const float* src = dout + std::min<int64_t>(e, n_edges - 1) * ld_dout + 8 * o;
-        r.d[0] = *reinterpret_cast<const v4f*>(src);
-        r.d[1] = *reinterpret_cast<const v4f*>(src + 4);
-        if (e >= n_edges) r.d[0] = r.d[1] = v4f{0.f, 0.f, 0.f, 0.f};    // hyperedges past the end contribute nothing
-        const int* idk = ids[k & 7] + row * 3;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) r.m[m] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(idk[m]) * ld_h + HC * half + 4 * o);
-    };
-    const int swz = tr_swizzle(row);
-    const int d_off = row * 256 + ((o ^ swz) << 4);                      // this thread's 16 bytes of a dout image
-    // its 8 bytes of block b of a product image: columns b * 64 + 4 o .. -> segment b >> 1, chunk 8 (b & 1) + (o >> 1), half o & 1
-    auto z_off = [&](int b) { return row * 512 + 256 * (b >> 1) + (((8 * (b & 1) + (o >> 1)) ^ swz) << 4) + 8 * (o & 1); };
-    // one staged tile -> images `buf`, in 16 slices (the caller spreads them over its MFMAs): slices 0-3 the dout pairs, slice 4 + 3 b + i
-    // pair i of block b (i = 2: the block's 8 bytes are complete and written)
-    v4u dsp[3];
-    unsigned zsp[3][2];
-    float zb[4];
-    auto split_slice = [&](int slice, const Rows& r, int buf) {
-        auto pair = [&](float xa, float xb, unsigned (&out)[3]) {
-            const float ra = xa - top16(xa), rb = xb - top16(xb);     // (packed v_pk_add_f32 subtractions measured 4-6 % slower beside the MFMAs)
-            const float la = ra - top16(ra), lb = rb - top16(rb);
-            out[0] = pack_hi(xa, xb);
-            out[1] = pack_hi(ra, rb);
-            out[2] = pack_hi(la, lb);
-        };
-        if (slice < 4) {
-            unsigned w[3];
-            pair(r.d[slice >> 1][2 * (slice & 1)], r.d[slice >> 1][2 * (slice & 1) + 1], w);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) dsp[p][slice] = w[p];
-            if (slice == 3) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + d_off) = dsp[p];
-            }
-        } else {
-            const int b = (slice - 4) / 3, i = (slice - 4) % 3;
-            if (i == 0) {
-                const v4f u = r.m[0], q = r.m[1], it = r.m[2];
-                const v4f z = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) zb[x] = z[x];
-            }
-            if (i < 2) {
-                unsigned w[3];
-                pair(zb[2 * i], zb[2 * i + 1], w);
-#pragma unroll
-                for (int p = 0; p < 3; ++p) zsp[p][i] = w[p];
-            } else {
-                typedef unsigned v2u __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + p * ZPL + z_off(b)) = v2u{zsp[p][0], zsp[p][1]};
-            }
-        }
-    };
-
     if (n_my > 0) {
-        if (tid < 3 * TE) {
-            ids[0][tid] = fetch_id(0);
-            if (n_my > 1) ids[1][tid] = fetch_id(1);
-            if (n_my > 2) ids[2][tid] = fetch_id(2);
-            if (n_my > 3) ids[3][tid] = fetch_id(3);
-        }
         __syncthreads();
-        Rows r0, r1;                                                     // rows of tile m live in r<m & 1> until they are split
-        load_rows(0, r0);
-        if (n_my > 1) load_rows(1, r1);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) split_slice(s, r0, 0);
         __syncthreads();
-
-        // transposed-read addresses: lane 4 q + p of group g supplies row 8 g + q (+ 4), chunk c0 + (p >> 1), half p & 1; the operand tile
-        // (jt / ct) moves the chunk by 2 -> one XOR on the address
         const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
         const int rlo = 8 * g + q, rhi = rlo + 4;
-        auto a_addr = [&](int r, int jt) { return r * 256 + ((((8 * jq + (pp >> 1)) ^ tr_swizzle(r)) << 4) ^ (jt << 5)) + 8 * (pp & 1); };
-        auto b_addr = [&](int r, int ct) { return r * 512 + 256 * (blk >> 1) + ((((8 * (blk & 1) + (pp >> 1)) ^ tr_swizzle(r)) << 4) ^ (ct << 5)) + 8 * (pp & 1); };
-        const int a_lo = a_addr(rlo, 0), a_hi = a_addr(rhi, 0), b_lo = b_addr(rlo, 0), b_hi = b_addr(rhi, 0);
-
-        int id_carry = 0;
-        auto phase = [&](auto parity, int k, Rows& use, Rows& fill) {
-            constexpr int BUF = decltype(parity)::value;
-            // ids requested in the previous phase (tile k + 3) reach the ring now - nothing is waited for at the end of a phase
-            if (k >= 1 && k + 3 < n_my && tid < 3 * TE) ids[(k + 3) & 7][tid] = id_carry;
-            if (k + 2 < n_my) load_rows(k + 2, fill);
-            if (k + 4 < n_my && tid < 3 * TE) id_carry = fetch_id(k + 4);
-            const unsigned char* dp = &dplanes[BUF][0][0][0];
-            const unsigned char* zp = &zplanes[BUF][0][0][0];
-            v8s a[4][3];
+        auto a_addr = [&](int r, int jt) { return r * 256 + ((((2 * jt + (pp >> 1))) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
+        auto b_addr = [&](int r, int ct) { return r * 512 + 256 * (blk >> 1) + (((8 * (blk & 1) + 2 * ct + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
+        for (int k = 0; k < n_my; ++k) {
+            const unsigned char* dp = &dplanes[k & 1][0][0][0];
+            const unsigned char* zp = &zplanes[k & 1][0][0][0];
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+            for (int jh = 0; jh < 2; ++jh) {
+                v8s a[4][3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[jt][p] = read_tr_fragment(dp + p * DPL + (a_lo ^ (jt << 5)), dp + p * DPL + (a_hi ^ (jt << 5)));
-            v8s b[3], bn[3];
+                for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[p] = read_tr_fragment(zp + p * ZPL + b_lo, zp + p * ZPL + b_hi);
+                    for (int p = 0; p < 3; ++p) a[jt][p] = read_tr_fragment(dp + p * DPL + a_addr(rlo, 4 * jh + jt), dp + p * DPL + a_addr(rhi, 4 * jh + jt));
+                v8s b[3], bn[3];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                if (ct + 1 < 4) {
+                for (int p = 0; p < 3; ++p) b[p] = read_tr_fragment(zp + p * ZPL + b_addr(rlo, 0), zp + p * ZPL + b_addr(rhi, 0));
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(zp + p * ZPL + (b_lo ^ ((ct + 1) << 5)), zp + p * ZPL + (b_hi ^ ((ct + 1) << 5)));
+                for (int ct = 0; ct < 4; ++ct) {
+                    if (ct + 1 < 4) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(zp + p * ZPL + b_addr(rlo, ct + 1), zp + p * ZPL + b_addr(rhi, ct + 1));
+                    }
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int jt = 0; jt < 4; ++jt)
+                            acc[4 * jh + jt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jt][kTermA[term]], b[kTermB[term]], acc[4 * jh + jt][ct], 0, 0, 0);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[p] = bn[p];
                 }
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) split_slice(4 * ct + jt, use, BUF ^ 1);   // (past the last tile: nobody reads those images)
-                // the four accumulator tiles of this column tile take turns: a dependent MFMA is four issues away
-#pragma unroll
-                for (int term = 0; term < 6; ++term)
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt)
-                        acc[jt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jt][kTermA[term]], b[kTermB[term]], acc[jt][ct], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 24; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x6, 2, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = bn[p];
             }
-            // take delivery of the requested rows here, a whole matrix phase after the request: left to the compiler, the waits land in
-            // the middle of the NEXT phase's MFMA stream with conservative counts (the counter is in order and this phase's requests
-            // are behind them)
-            asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.m[0]), "+v"(fill.m[1]), "+v"(fill.m[2]));
             __syncthreads();
-        };
-        for (int k = 0; k < n_my; k += 2) {
-            phase(std::integral_constant<int, 0>{}, k, r1, r0);
-            if (k + 1 < n_my) phase(std::integral_constant<int, 1>{}, k + 1, r0, r1);
         }
     }
-    // slab of this tile range: element (j, b * D + col); accumulator tile (jt, ct): column lane & 15 -> col 64 half + 16 ct + .., rows 4 (lane >> 4) + r
     float* slab = slabs + static_cast<int64_t>(range) * D * NBLK * D;
     const int c = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < 8; ++jt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                slab[static_cast<int64_t>(64 * jq + 16 * jt + 4 * kq + r) * NBLK * D + blk * D + HC * half + 16 * ct + c] = acc[jt][ct][r];
+            for (int r = 0; r < 4; ++r) slab[static_cast<int64_t>(16 * jt + 4 * kq + r) * NBLK * D + blk * D + HC * half + 16 * ct + c] = acc[jt][ct][r];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1098,7 +1095,7 @@ bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const fl
 }
 
 int launch_weight_split(const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s) {
-    hipLaunchKernelGGL(interact_bwd_weight_split_kernel, dim3(2 * kSplitRanges), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
+    hipLaunchKernelGGL(interact_bwd_weight_split_ws_kernel, dim3(2 * kSplitRanges), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
     return kSplitRanges;                                                 // slabs written (every range writes one, empty ranges zeros)
 }
 
