@@ -10,9 +10,10 @@
 // v_mfma_f32_16x16x4_f32, six of them replace eight -> the same contraction in ~ 0.4 of the matrix-pipe time.
 //
 // Three bf16 planes of the weights are 1.5 x their fp32 size: 384 KB, more than one workgroup's registers can keep beside the
-// accumulators.  So a workgroup is FOUR waves and owns a QUARTER of the output columns (96 weight registers per wave), two
-// workgroups share a CU and overlap each other's load / matrix / store phases; the four quarters of one tile range sit on one
-// XCD (workgroups are dealt to XCDs round-robin by their linear id), so three of the four reads of a streamed row hit that L2.
+// accumulators.  So a workgroup owns HALF of one index (output columns, or the contraction index); the two halves of one tile range
+// sit on one XCD (workgroups are dealt to XCDs round-robin by their linear id), so the second read of a streamed row hits that L2.
+// What bounds these kernels is not the matrix pipe but the vector instructions of the split (5.5 per element) and of forming the
+// products: the pipe is 0.4-0.5 busy (DESIGN.md section 4 has the ladder, the probes and the counters).
 #include <cstdlib>
 #include <type_traits>
 
@@ -78,25 +79,31 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
     for (int p = 0; p < 3; ++p) wsp[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
 }
 
-// Member gradients.  A workgroup is eight waves and owns HALF of the columns: wave (b, g) contracts the dout rows with block b's
-// weights for 32 columns (the weight planes of a half are 192 KB = 96 registers per wave), 96 MFMAs per tile of 32 hyperedges.
-// An MFMA leaves about half of its 16 issue cycles to other instructions, and everything else a tile needs is placed there, in ONE
-// basic block with the MFMAs of tile k (steady state, the scheduler is told to alternate):
-//   - the split of tile k + 1's dout rows (each thread 8 values, requested two tiles ahead, three 16-byte LDS writes; 16-byte chunk o
-//     of row r at o ^ (r & 15): conflict-free ds_read_b128 for the fragments; images double-buffered),
-//   - the product rule of tile k - 1: the four blocks' contractions meet in an LDS image (the MFMA is issued as W^T x dout^T so that a
-//     lane holds 4 consecutive COLUMNS of one hyperedge: 16-byte writes and reads), every thread combines 4 columns of one hyperedge
-//     with the member values it requested a tile earlier,
-//   - UR (hyperedges numbered by user): the scan of tile k - 2's user-slot gradients, which are not stored per hyperedge: wave w takes
-//     columns 8 w .. 8 w + 7 of the half and forms the runs' inclusive sums row by row (straight-line: a run start only resets the
-//     running sum through a scalar factor); a short loop after the MFMAs stores the few finished runs (interact.hip describes the
-//     scheme and its boundary table, which is indexed by tile range here and shared by the two column halves).
-// One barrier per tile.  The two halves of a tile range sit on one XCD, so the second read of a dout row hits that L2.
+// Member gradients dz_b = dout W_b, then the product rule.  A workgroup owns HALF of the columns (its weight planes: 192 KB) and its eight
+// waves have two jobs, one of each per SIMD:
+//   - waves 0-3, the matrix waves: wave = product block b, the half's 64 columns x the tile's 32 hyperedges, 192 MFMAs per tile, weight
+//     planes resident (192 registers).  They read the dout fragments from three bf16 images (16-byte chunk o of row r at o ^ (r & 15):
+//     conflict-free ds_read_b128) and issue the MFMA as W^T x dout^T, so that a lane holds 4 consecutive COLUMNS of one hyperedge and the
+//     four blocks' contractions go to an LDS image in 16-byte pieces.
+//   - waves 4-7, the service waves (256 threads): request rows two tiles ahead (dout: 16 values per thread; member values: 4 columns x 2 of
+//     one hyperedge), split the next tile's dout values into the images, apply the product rule to the previous tile (contractions from
+//     the image, member values from registers) and store.  Requested rows are taken delivery of (an opaque asm use) at the END of the phase
+//     that requested them, before the barrier: the memory counter is in order, and left to the compiler the waits land in the next
+//     phase's stream behind that phase's own requests and stores.
+// An in-order wave that does both jobs stalls its MFMA stream on every wait of the service work (that form: 1,520 us, this one 1,370,
+// same box, kbench scale).  Images, contraction image and id ring are double-buffered: one barrier per tile.  The two halves of a tile
+// range sit on one XCD, so the second read of a dout row hits that L2.
+// UR (hyperedges numbered by user; g is [E, 2, d]): the user-slot gradient is not stored per hyperedge.  The product rule leaves it in a
+// transposed LDS image [column][row]; a phase later service wave w scans columns 16 w .. 16 w + 15 row by row (inclusive sums of the runs: a
+// run start, known from one ballot over the tile's user ids, resets the running sum through a scalar factor), then stores the few
+// finished runs (their sums fetched four at a time) to dh[user].  (user, destination, running sums) are carried from tile to tile, which
+// is why a workgroup takes a CONTIGUOUS tile range; the first and the last run of a range may continue in the neighbours and go to the
+// boundary table that interact.hip's user_boundary_fixup_kernel adds up (indexed by tile range here, shared by the two halves).
 template <bool UR>
-__global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_kernel(
-    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3, const v4u* __restrict__ wsp, const float* __restrict__ dout,
-    int64_t ld_dout, float* __restrict__ g_out, int64_t n_edges, float* __restrict__ dh_user, int64_t ld_dh, float* __restrict__ bnd_val,
-    int32_t* __restrict__ bnd_user) {
+__global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
+                                                                                      const v4u* __restrict__ wsp, const float* __restrict__ dout, int64_t ld_dout,
+                                                                                      float* __restrict__ g_out, int64_t n_edges, float* __restrict__ dh_user,
+                                                                                      int64_t ld_dh, float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user) {
     constexpr int TE = kSplitTE, D = 128, HC = 64, DZ = HC + 4, UT = TE + 4, GS = UR ? 2 : 3;
     __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][256];
     __shared__ __attribute__((aligned(16))) float dzimg[2][4][TE][DZ];
@@ -114,263 +121,212 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_kern
         if (UR && half == 0 && tid == 0) bnd_user[2 * range] = bnd_user[2 * range + 1] = -1;
         return;
     }
-    const int blk = wave & 3, cg = wave >> 2;
+    const int n_phases = n_my + (UR ? 2 : 1);
 
-    v8s wreg[4][2][3];
-    {
-        const v4u* wf = wsp + static_cast<int64_t>(((2 * half + cg) * 4 + blk) * 24) * kWave + lane;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) wreg[kb][ct][p] = __builtin_bit_cast(v8s, wf[((kb * 2 + ct) * 3 + p) * kWave]);
-    }
-
-    const int row = tid >> 4, o = tid & 15;      // staging role: dout row, octet of it;  epilogue role: hyperedge row, 4 columns of the half
-    const int64_t last_pos = n_edges * 3 - 1;
-    auto fetch_id = [&](int k) { return i3[std::min<int64_t>((t0 + k) * (3 * TE) + tid, last_pos)]; };   // (only threads < 96 use it)
-    auto load_dout = [&](int k, v4f (&dr)[2]) {
-        const int64_t e = std::min<int64_t>((t0 + k) * TE + row, n_edges - 1);
-        const float* src = dout + e * ld_dout + 8 * o;
-        dr[0] = *reinterpret_cast<const v4f*>(src);
-        dr[1] = *reinterpret_cast<const v4f*>(src + 4);
-    };
-    const int chunk = (o ^ (row & 15)) << 4;
-    auto load_members = [&](int k, v4f (&hm)[3]) {
-        const int* idk = ids[k & 7] + row * 3;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) hm[m] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(idk[m]) * ld_h + HC * half + 4 * o);
-    };
-
-    // UR state: every wave carries the same (user, destination) and its own columns' running sums from tile to tile
-    int cur_user = -1, first_user = -1;
-    float run_sum = 0.f, carry_prev = 0.f;
-    float* const first_slot = UR ? bnd_val + static_cast<int64_t>(2 * range) * D : nullptr;
-    float* run_dst = first_slot;
-    const int ucol = 8 * wave + (lane & 7), colg = HC * half + ucol;
-    uint64_t walk_mask = 0;
-    int walk_uid = 0, pf_uid = 0, pf_prev = 0;
-    // the user ids of tile k's rows (lane -> row, clamped) are read from the id ring a phase ahead, inside the matrix phase
-    auto prefetch_uids = [&](int k) {
-        const int* idk = ids[k & 7];
-        const int rows = k < 0 ? 1 : static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + k) * TE));
-        const int r = lane < rows ? lane : rows - 1;
-        pf_uid = idk[r * 3];
-        pf_prev = idk[(r == 0 ? 0 : r - 1) * 3];
-    };
-    auto scan_prelude = [&](int k) {                                     // tile k >= 0: where its runs start, as a scalar bit mask
-        const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + k) * TE));
-        walk_uid = pf_uid;
-        const int prev_uid = lane == 0 ? cur_user : pf_prev;
-        walk_mask = __ballot(lane < rows && walk_uid != prev_uid);
-        carry_prev = run_sum;
-    };
-    // four rows of the scan (rows past the end hold zeros): inclusive sums of the runs, back into the image
-    auto scan_rows = [&](float* col, int x0, v4f v) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float keep = (walk_mask >> (x0 + x)) & 1 ? 0.f : 1.f;
-            run_sum = run_sum * keep + v[x];
-            v[x] = run_sum;
-        }
-        *reinterpret_cast<v4f*>(col + x0) = v;
-    };
-    // the finished runs, four run starts at a time (their sums are fetched together: one LDS round trip per batch)
-    auto emit_user_runs = [&](int k) {
-        uint64_t m = walk_mask;
-        const float* col = utile[k & 1][ucol];
-        while (m != 0) {
-            int x[4];
-            bool have[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                have[i] = m != 0;
-                x[i] = have[i] ? __builtin_ctzll(m) : 1;
-                m = have[i] ? m & (m - 1) : 0;
-            }
-            float done[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) done[i] = col[x[i] == 0 ? 0 : x[i] - 1];   // the sum up to the row before the start
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (!have[i]) continue;
-                const int user = __builtin_amdgcn_readlane(walk_uid, x[i]);
-                if (cur_user >= 0) {
-                    if (lane < 8) run_dst[colg] = x[i] == 0 ? carry_prev : done[i];
-                    run_dst = dh_user + static_cast<int64_t>(user) * ld_dh;
-                } else {
-                    first_user = user;
-                }
-                cur_user = user;
-            }
-        }
-    };
-
-    if (tid < 3 * TE) {
-        ids[0][tid] = fetch_id(0);
-        if (n_my > 1) ids[1][tid] = fetch_id(1);
-    }
-    v4f dr0[2], dr1[2], hm0[3], hm1[3];                                  // dout values of tile m live in dr<m & 1>, member values in hm<m & 1>
-    load_dout(0, dr0);
-    if (n_my > 1) load_dout(1, dr1);
-    {
-        const Planes p0 = split8(dr0[0], dr0[1]);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[0][p][row][chunk]) = p0.p[p];
-    }
-    __syncthreads();
-
-    const int arow = lane & 15, kq = lane >> 4;
-    // Phase k: matrix work of tile k, split of tile k + 1 (`use`), product rule of tile k - 1 (`hm_prev`), scan of tile k - 2; requests
-    // the member values of tile k (`hm_cur`) and the dout values of tile k + 2 (`fill`).  STEADY: all four tiles exist and are whole.
-    auto phase = [&](auto steady_tag, int k, v4f (&use)[2], v4f (&fill)[2], v4f (&hm_cur)[3], v4f (&hm_prev)[3]) {
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        const bool has_tile = STEADY || k < n_my, has_prev = STEADY || (k >= 1 && k - 1 < n_my), has_scan = UR && (STEADY || (k >= 2 && k - 2 < n_my));
-        if (has_tile) load_members(k, hm_cur);
-        if (STEADY || k + 2 < n_my) load_dout(k + 2, fill);
-        int id_next = 0;
-        if ((STEADY || k + 2 < n_my) && tid < 3 * TE) id_next = fetch_id(k + 2);
-        if (has_scan) scan_prelude(k - 2);
-
-        v4f acc[2][2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
-        const unsigned char* pbase = &planes[k & 1][0][0][0];
-        auto fragment = [&](int step, v8s (&a)[3]) {
-            const int kb = step >> 1, rt = step & 1;
-            const unsigned char* src = pbase + (16 * rt + arow) * 256 + (((4 * kb + kq) ^ arow) << 4);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * 256));
+    if (wave >= 4) {
+        // ---------------- service waves: 256 threads, thread -> hyperedge row, dout octets o and o + 8, member / gradient columns 4 o .. and 32 + 4 o ..
+        const int st = tid - 256, row = st >> 3, o = st & 7;
+        const int64_t last_pos = n_edges * 3 - 1;
+        auto fetch_id = [&](int k) { return i3[std::min<int64_t>((t0 + k) * (3 * TE) + st, last_pos)]; };     // (st < 96)
+        auto load_dout = [&](int k, v4f (&dr)[4]) {
+            const float* src = dout + std::min<int64_t>((t0 + k) * TE + row, n_edges - 1) * ld_dout + 8 * o;
+            dr[0] = *reinterpret_cast<const v4f*>(src);
+            dr[1] = *reinterpret_cast<const v4f*>(src + 4);
+            dr[2] = *reinterpret_cast<const v4f*>(src + 64);
+            dr[3] = *reinterpret_cast<const v4f*>(src + 68);
         };
-        float* ucolp = utile[k & 1][ucol];                               // (k - 2) & 1
-        const float (*dz)[TE][DZ] = dzimg[(k - 1) & 1];
-        v4f g_u, g_q, g_i, z_uq, z_qi, z_iu, z_uqi, sv = v4f{0.f, 0.f, 0.f, 0.f}, svn = sv;
-        v8s a[3], an[3];
-        v4u sp[3];
-        fragment(0, a);
-        if (has_scan) sv = *reinterpret_cast<const v4f*>(ucolp);
-        if (has_tile) {
-            // Every step: 12 MFMAs and, in their issue shadow, a slice of the other three jobs - steps 0-3 split one pair of dout values
-            // each, step 3 fetches tile k - 1's contractions, steps 4-7 apply the product rule to one of the thread's 4 columns each, every
-            // step scans 4 rows.  The fences keep a step's instructions together, the group barriers alternate them with the MFMAs.
+        auto load_members = [&](int k, v4f (&hm)[2][3]) {
+            const int* idk = ids[k & 7] + row * 3;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + HC * half + 4 * o;
+                hm[0][m] = *reinterpret_cast<const v4f*>(hp);
+                hm[1][m] = *reinterpret_cast<const v4f*>(hp + 32);
+            }
+        };
+        const int swz = row & 15;
+        auto split_tile = [&](const v4f (&dr)[4], int buf) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const Planes pl = split8(dr[2 * x], dr[2 * x + 1]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[buf][p][row][((o + 8 * x) ^ swz) << 4]) = pl.p[p];
+            }
+        };
+        // product rule of tile k - 1 (its contractions in dzimg[(k - 1) & 1], its member values in hm) and the stores
+        auto epilogue = [&](int k, const v4f (&hm)[2][3]) {
+            const float (*dz)[TE][DZ] = dzimg[(k - 1) & 1];
+            const int64_t e = (t0 + k - 1) * TE + row;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int c = 4 * o + 32 * x;
+                const v4f z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][c]), z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][c]);
+                const v4f z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][c]), z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][c]);
+                const v4f hu = hm[x][0], hq = hm[x][1], hi = hm[x][2];
+                const v4f g_u = z_uq * hq + z_iu * hi + z_uqi * (hq * hi);
+                const v4f g_q = z_uq * hu + z_qi * hi + z_uqi * (hu * hi);
+                const v4f g_i = z_qi * hq + z_iu * hu + z_uqi * (hu * hq);
+                const bool live = e < n_edges;
+                if (UR) {                                                // rows past the end hold zeros for the scan
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) utile[(k - 1) & 1][c + i][row] = live ? g_u[i] : 0.f;
+                }
+                if (live) {
+                    float* dst = g_out + e * (GS * D) + HC * half + c;
+                    if (!UR) {
+                        store_stream4(dst, g_u);
+                        dst += D;
+                    }
+                    store_stream4(dst, g_q);
+                    store_stream4(dst + D, g_i);
+                }
+            }
+        };
+        // UR: service wave w scans columns 16 w .. 16 w + 15 of the half (lane & 15; the other lanes repeat them) of the tile whose product
+        // rule ran a phase ago, carrying (user, destination, running sums) from tile to tile; see the kernel above for the scheme
+        int cur_user = -1, first_user = -1;
+        float run_sum = 0.f, carry_prev = 0.f;
+        float* const first_slot = UR ? bnd_val + static_cast<int64_t>(2 * range) * D : nullptr;
+        float* run_dst = first_slot;
+        const int ucol = 16 * (wave - 4) + (lane & 15), colg = HC * half + ucol;
+        auto scan_and_emit = [&](int k) {                                // tile k, 0 <= k < n_my
+            const int* idk = ids[k & 7];
+            const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + k) * TE));
+            const int r = lane < rows ? lane : rows - 1;
+            const int uid = idk[r * 3];
+            const int prev_uid = r == 0 ? cur_user : idk[(r - 1) * 3];
+            const uint64_t mask = __ballot(lane < rows && uid != prev_uid);
+            carry_prev = run_sum;
+            float* col = utile[k & 1][ucol];
+#pragma unroll
+            for (int x0 = 0; x0 < TE; x0 += 4) {
+                v4f v = *reinterpret_cast<const v4f*>(col + x0);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const float keep = (mask >> (x0 + x)) & 1 ? 0.f : 1.f;
+                    run_sum = run_sum * keep + v[x];
+                    v[x] = run_sum;
+                }
+                *reinterpret_cast<v4f*>(col + x0) = v;
+            }
+            uint64_t m = mask;
+            while (m != 0) {                                             // the finished runs, four run starts at a time
+                int x[4];
+                bool have[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    have[i] = m != 0;
+                    x[i] = have[i] ? __builtin_ctzll(m) : 1;
+                    m = have[i] ? m & (m - 1) : 0;
+                }
+                float done[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) done[i] = col[x[i] == 0 ? 0 : x[i] - 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!have[i]) continue;
+                    const int user = __builtin_amdgcn_readlane(uid, x[i]);
+                    if (cur_user >= 0) {
+                        if (lane < 16) run_dst[colg] = x[i] == 0 ? carry_prev : done[i];
+                        run_dst = dh_user + static_cast<int64_t>(user) * ld_dh;
+                    } else {
+                        first_user = user;
+                    }
+                    cur_user = user;
+                }
+            }
+        };
+        if (st < 3 * TE) {
+            ids[0][st] = fetch_id(0);
+            if (n_my > 1) ids[1][st] = fetch_id(1);
+            if (n_my > 2) ids[2][st] = fetch_id(2);
+        }
+        __syncthreads();
+        v4f dr0[4], dr1[4], hm0[2][3], hm1[2][3];                        // dout values of tile m in dr<m & 1>, member values in hm<m & 1>
+        load_dout(0, dr0);
+        if (n_my > 1) load_dout(1, dr1);
+        split_tile(dr0, 0);
+        __syncthreads();
+        int id_carry = 0;
+        auto phase = [&](int k, v4f (&use)[4], v4f (&fill)[4], v4f (&hm_cur)[2][3], v4f (&hm_prev)[2][3]) {
+            if (k >= 1 && k + 2 < n_my && st < 3 * TE) ids[(k + 2) & 7][st] = id_carry;     // requested in the previous phase
+            if (k < n_my) load_members(k, hm_cur);
+            if (k + 2 < n_my) load_dout(k + 2, fill);
+            if (k + 3 < n_my && st < 3 * TE) id_carry = fetch_id(k + 3);
+            if (k >= 1 && k - 1 < n_my) epilogue(k, hm_prev);
+            if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
+            if (UR && k >= 2) scan_and_emit(k - 2);
+            // delivery of this phase's requests before the barrier (a whole matrix phase after they were issued)
+            asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2]), "+v"(fill[3]));
+            asm volatile("" : "+v"(hm_cur[0][0]), "+v"(hm_cur[0][1]), "+v"(hm_cur[0][2]), "+v"(hm_cur[1][0]), "+v"(hm_cur[1][1]), "+v"(hm_cur[1][2]));
+            __syncthreads();
+        };
+        for (int k = 0; k < n_phases; k += 2) {
+            phase(k, dr1, dr0, hm0, hm1);
+            if (k + 1 < n_phases) phase(k + 1, dr0, dr1, hm1, hm0);
+        }
+        if (UR) {
+            // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
+            const bool one_run = run_dst == first_slot;
+            if (cur_user >= 0 && lane < 16) {
+                if (one_run) run_dst[colg] = run_sum;
+                else bnd_val[static_cast<int64_t>(2 * range + 1) * D + colg] = run_sum;
+            }
+            if (half == 0 && st == 0) {
+                bnd_user[2 * range] = first_user;
+                bnd_user[2 * range + 1] = (cur_user >= 0 && !one_run) ? cur_user : -1;
+            }
+        }
+        return;
+    }
+
+    // ---------------- matrix waves: wave = product block, the half's four 16-column tiles, both row tiles
+    const int blk = wave;
+    v8s wreg[4][4][3];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                wreg[kb][ct][p] = __builtin_bit_cast(v8s, wsp[(static_cast<int64_t>(((2 * half + (ct >> 1)) * 4 + blk) * 24) + (kb * 2 + (ct & 1)) * 3 + p) * kWave + lane]);
+    __syncthreads();
+    __syncthreads();
+    const int arow = lane & 15, kq = lane >> 4;
+    for (int k = 0; k < n_phases; ++k) {
+        if (k < n_my) {
+            v4f acc[2][4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
+            const unsigned char* pbase = &planes[k & 1][0][0][0];
+            auto fragment = [&](int step, v8s (&a)[3]) {
+                const int kb = step >> 1, rt = step & 1;
+                const unsigned char* src = pbase + (16 * rt + arow) * 256 + (((4 * kb + kq) ^ arow) << 4);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * 256));
+            };
+            v8s a[3], an[3];
+            fragment(0, a);
 #pragma unroll
             for (int step = 0; step < 8; ++step) {
                 const int kb = step >> 1, rt = step & 1;
                 if (step + 1 < 8) fragment(step + 1, an);
-                if (has_scan) {
-                    if (step + 1 < 8) svn = *reinterpret_cast<const v4f*>(ucolp + 4 * (step + 1));
-                    scan_rows(ucolp, 4 * step, sv);
-                }
-                if (step < 4) {   // two of the eight dout values of the next tile -> one dword of each plane
-                    const float xa = use[step >> 1][2 * (step & 1)], xb = use[step >> 1][2 * (step & 1) + 1];
-                    const float ra = xa - top16(xa), rb = xb - top16(xb);
-                    const float la = ra - top16(ra), lb = rb - top16(rb);
-                    sp[0][step] = pack_hi(xa, xb);
-                    sp[1][step] = pack_hi(ra, rb);
-                    sp[2][step] = pack_hi(la, lb);
-                }
-                if (UR && step == 6) prefetch_uids(k - 1);
-                if (step == 3) {
-                    z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][4 * o]);
-                    z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][4 * o]);
-                    z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][4 * o]);
-                    z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][4 * o]);
-                }
-                if (step >= 4) {
-                    const int i = step - 4;
-                    const float hu = hm_prev[0][i], hq = hm_prev[1][i], hi = hm_prev[2][i];
-                    g_u[i] = z_uq[i] * hq + z_iu[i] * hi + z_uqi[i] * (hq * hi);
-                    g_q[i] = z_uq[i] * hu + z_qi[i] * hi + z_uqi[i] * (hu * hi);
-                    g_i[i] = z_qi[i] * hq + z_iu[i] * hu + z_uqi[i] * (hu * hq);
-                }
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
+                    for (int ct = 0; ct < 4; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][ct][kTermB[term]], a[kTermA[term]], acc[rt][ct], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x6, 2, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
                 for (int p = 0; p < 3; ++p) a[p] = an[p];
-                sv = svn;
             }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk]) = sp[p];    // (past the last tile: nobody reads it)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) *reinterpret_cast<v4f*>(&dzimg[k & 1][blk][16 * rt + arow][32 * cg + 16 * ct + 4 * kq]) = acc[rt][ct];
-        } else {
-            // the phases after the last tile: only the product rule and the scan are left
-            z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][4 * o]);
-            z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][4 * o]);
-            z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][4 * o]);
-            z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][4 * o]);
-            const v4f hu = hm_prev[0], hq = hm_prev[1], hi = hm_prev[2];
-            g_u = z_uq * hq + z_iu * hi + z_uqi * (hq * hi);
-            g_q = z_uq * hu + z_qi * hi + z_uqi * (hu * hi);
-            g_i = z_qi * hq + z_iu * hu + z_uqi * (hu * hq);
-            if (has_scan) {
-#pragma unroll
-                for (int x0 = 0; x0 < TE; x0 += 4) scan_rows(ucolp, x0, *reinterpret_cast<const v4f*>(ucolp + x0));
-            }
-            if (UR) prefetch_uids(k - 1);
+                for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<v4f*>(&dzimg[k & 1][blk][16 * rt + arow][16 * ct + 4 * kq]) = acc[rt][ct];
         }
-        // Everything this phase requested has had a whole matrix phase to arrive: take delivery HERE, before the stores below are
-        // issued.  The memory counter is in order - the first use of these registers in the next phase would otherwise wait for the
-        // stores as well, a store round trip exposed at the start of every phase with the matrix pipe idle.
-        asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(hm_cur[0]), "+v"(hm_cur[1]), "+v"(hm_cur[2]));
-        if ((STEADY || k + 2 < n_my) && tid < 3 * TE) ids[(k + 2) & 7][tid] = id_next;
-        if (has_prev) {
-            const int64_t e = (t0 + k - 1) * TE + row;
-            const bool live = STEADY || e < n_edges;
-            if (UR) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) utile[(k - 1) & 1][4 * o + i][row] = live ? g_u[i] : 0.f;
-            }
-            if (live) {
-                float* dst = g_out + e * (GS * D) + HC * half + 4 * o;
-                if (!UR) {
-                    store_stream4(dst, g_u);
-                    dst += D;
-                }
-                store_stream4(dst, g_q);
-                store_stream4(dst + D, g_i);
-            }
-        }
-        if (has_scan) emit_user_runs(k - 2);
         __syncthreads();
-    };
-    const int n_phases = n_my + (UR ? 2 : 1);
-    const bool whole = (t0 + n_my) * TE <= n_edges;                      // this range's last tile is complete
-    for (int k = 0; k < n_phases; k += 2) {
-        const bool steady0 = k >= 2 && k + 2 < n_my && (whole || k - 1 < n_my - 1);
-        if (steady0) phase(std::true_type{}, k, dr1, dr0, hm0, hm1);
-        else phase(std::false_type{}, k, dr1, dr0, hm0, hm1);
-        if (k + 1 < n_phases) {
-            const bool steady1 = k + 1 >= 2 && k + 3 < n_my && (whole || k < n_my - 1);
-            if (steady1) phase(std::true_type{}, k + 1, dr0, dr1, hm1, hm0);
-            else phase(std::false_type{}, k + 1, dr0, dr1, hm1, hm0);
-        }
-    }
-    if (UR) {
-        // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
-        const bool one_run = run_dst == first_slot;
-        if (cur_user >= 0 && lane < 8) {
-            if (one_run) run_dst[colg] = run_sum;
-            else bnd_val[static_cast<int64_t>(2 * range + 1) * D + colg] = run_sum;
-        }
-        if (half == 0 && tid == 0) {
-            bnd_user[2 * range] = first_user;
-            bnd_user[2 * range + 1] = (cur_user >= 0 && !one_run) ? cur_user : -1;
-        }
     }
 }
 
@@ -1049,10 +1005,10 @@ void launch_members_split(const float* h, int64_t ld_h, const int32_t* i3, const
     hipLaunchKernelGGL(pack_planes_members_kernel, dim3(4 * 4 * 4 * 2 * kWave / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, wsp);
     const int grid = 2 * kSplitRanges;
     if (dh_user != nullptr)
-        hipLaunchKernelGGL(interact_bwd_members_split_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user,
+        hipLaunchKernelGGL(interact_bwd_members_split_ws_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user,
                            ld_dh, bnd_val, bnd_user);
     else
-        hipLaunchKernelGGL(interact_bwd_members_split_kernel<false>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
+        hipLaunchKernelGGL(interact_bwd_members_split_ws_kernel<false>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
                            static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
     if (n_boundary_entries != nullptr) *n_boundary_entries = 2 * kSplitRanges;
 }

@@ -452,17 +452,10 @@ def node_linear(x: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceL
 # the [E, 3, d] member-gradient buffer of the interactive backward is produced in hyperedge chunks beyond this many bytes
 MEMBER_BUFFER_LIMIT_BYTES = 48 << 30
 import os as _os
-# ihg_interact_bwd_user_reduced (user slot summed on chip, [E, 2, d] member buffer) where the library offers it: True / False, or None =
-# where it is the faster form - with the fp32-MFMA kernels (C3: -0.05 ms per step), not with the bf16-split ones, whose vector pipe is the
-# bound and pays 0.5 ms for the scan against 0.3 ms saved in K7.  IHG_USER_REDUCED=1 / 0 forces it; tests compare the forms.
-USER_REDUCED_BACKWARD = {'1': True, '0': False}.get(_os.environ.get('IHG_USER_REDUCED', ''), None)
-
-
-def _user_reduced_wanted(dim: int, order: int) -> bool:
-    if USER_REDUCED_BACKWARD is not None:
-        return USER_REDUCED_BACKWARD
-    split_arithmetic = dim == 128 and order == 3 and _os.environ.get('IHG_INTERACT_ARITH') != 'f32'
-    return not split_arithmetic
+# use ihg_interact_bwd_user_reduced (user slot summed on chip, [E, 2, d] member buffer) where the library offers it; IHG_USER_REDUCED=0
+# keeps the [E, 3, d] form (C3: the same step time with the bf16-split kernels - the scan costs their service waves what K7 saves - and
+# 1.1 GB less written and read per step; -0.05 ms with the fp32-MFMA kernels).  Tests compare the two forms.
+USER_REDUCED_BACKWARD = _os.environ.get('IHG_USER_REDUCED', '1') != '0'
 
 
 def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: IncidenceLayout, order: int, dw: Tensor) -> Tensor:
@@ -472,7 +465,7 @@ def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: Incidence
     lib = _lib.load()
     n_edges, dim = layout.edge_count, int(h.shape[1])
     n_chunks = max(1, -(-(n_edges * 3 * dim * 4) // MEMBER_BUFFER_LIMIT_BYTES))
-    if (n_chunks == 1 and _user_reduced_wanted(dim, order) and n_edges > 0 and getattr(layout, 'user_sorted', False)
+    if (n_chunks == 1 and USER_REDUCED_BACKWARD and n_edges > 0 and getattr(layout, 'user_sorted', False)
             and lib.ihg_interact_bwd_user_reduced_supported(dim, order, _ld(h)) and h.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
             and _ld(w) % 4 == 0 and _ld(grad_out) % 4 == 0 and grad_out.data_ptr() % 16 == 0):
         # hyperedges are numbered by user: the kernel sums the user slot on chip and writes dh[users] itself; only the query and item

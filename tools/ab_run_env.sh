@@ -1,0 +1,15 @@
+#!/bin/bash
+# like ab_run.sh with extra environment for the kbench process: tools/ab_run_env.sh "VAR=val ..." KERNEL_SUBSTRING NAME...
+envs=$1; pat=$2; shift 2
+export TMPDIR=/tmp
+for name in "$@"; do
+  out=/tmp/abe_$name; rm -rf $out
+  (cd /tmp && env $envs IHGNN_HIP_LIBRARY=/root/repo/build_ab/lib_$name.so rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 /root/repo/tools/kbench.py --config C3 --rounds 4 --ops interact > /dev/null 2>&1)
+  python3 - "$out" "$name" "$pat" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True)
+for r in csv.DictReader(open(f[0])) if f else []:
+    if sys.argv[3] in r['Name']:
+        print(f"{sys.argv[2]:12s} {r['Name'][28:84]:56s} {int(r['Calls']):3d} avg {float(r['AverageNs'])/1e3:9.1f} us")
+PY
+done
