@@ -253,12 +253,13 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             if (k < n_my) load_members(k, hm_cur);
             if (k + 2 < n_my) load_dout(k + 2, fill);
             if (k + 3 < n_my && st < 3 * TE) id_carry = fetch_id(k + 3);
-            if (k >= 1 && k - 1 < n_my) epilogue(k, hm_prev);
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
-            if (UR && k >= 2) scan_and_emit(k - 2);
-            // delivery of this phase's requests before the barrier (a whole matrix phase after they were issued)
+            // delivery of this phase's requests, THEN everything that stores: the memory counter is in order, a wait behind a store sits out
+            // the store's round trip to memory
             asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2]), "+v"(fill[3]));
             asm volatile("" : "+v"(hm_cur[0][0]), "+v"(hm_cur[0][1]), "+v"(hm_cur[0][2]), "+v"(hm_cur[1][0]), "+v"(hm_cur[1][1]), "+v"(hm_cur[1][2]));
+            if (k >= 1 && k - 1 < n_my) epilogue(k, hm_prev);
+            if (UR && k >= 2) scan_and_emit(k - 2);
             __syncthreads();
         };
         for (int k = 0; k < n_phases; k += 2) {
@@ -331,15 +332,17 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
 }
 
 // ------------------------------------------------------------------------------------------------
-// Forward: out[e][j] = sum_b sum_c z_b[e][c] W_b[j][c] + (P[u] + P[q]) + P[i].  The products z_b are formed per hyperedge and would
-// have to be split by every wave that contracts them, so the contraction index is what the waves divide: a workgroup owns HALF of
-// the output columns (its weight planes: 192 KB = 96 registers per wave), wave (b, ch) owns block b's columns 64 ch .. 64 ch + 63
-// of the contraction index - it reads those 64 values of the member rows it needs from the LDS tile (filled by LDS-DMA, 16-byte
-// chunk c of row r at c ^ (r & 15)), forms its own z_b, splits it in registers and runs 48 MFMAs per tile of 16 hyperedges (issued
-// as W x z^T: a lane ends up with 4 consecutive output columns of one hyperedge).  The eight partial sums of a tile meet in an LDS
-// image and are added in wave order - together with the first-order rows, requested a tile earlier - inside the NEXT tile's
-// phase.  Tile, image and id ring are double-buffered: one barrier per tile.
-// wsp[half][wave][jt][kb][plane][lane][8]: element i = plane of W[64 half + 16 jt + (lane & 15)][(3 + b) d + 64 ch + 32 kb + 8 (lane >> 4) + i]
+// Forward: out[e][j] = sum_b sum_c z_b[e][c] W_b[j][c] + (P[u] + P[q]) + P[i].  A workgroup owns HALF of the output columns (its weight
+// planes: 192 KB), so both halves form and split every product: the forward carries twice the split work of the gradient kernels.
+// Matrix wave b (waves 0-3, one per SIMD) contracts product block b - 128 values of the contraction index, weight planes for the half's
+// 64 output columns in 192 registers, 96 MFMAs per 16-hyperedge tile, issued as W x z^T so that a lane holds 4 consecutive output columns
+// of one hyperedge - from bf16 images of z that the service waves 4-7 lay down a tile ahead: each of their 256 threads gathers 8 columns of
+// one hyperedge's three member rows straight into registers (two tiles ahead), forms the 32 products, splits them and writes 8-byte
+// pieces (chunk c of row r at c ^ r, rows of 1 KB: conflict-free ds_read_b128 for the fragments).  The four partial sums of a tile meet
+// in an LDS image; the service waves add them in block order with the first-order rows (requested a tile earlier) and store, a phase
+// later.  Images, partial-sum image and id ring are double-buffered: one barrier per tile.  (Every wave doing both jobs, members staged
+// by LDS-DMA: 2,215 us against 2,020 on the same box; alone, the matrix waves would take 1,350 us and the service waves 1,380.)
+// wsp[half][2 b + (kb >> 1)][jt][kb & 1][plane][lane][8]: element i = plane of W[64 half + 16 jt + (lane & 15)][(3 + b) d + 32 kb + 8 (lane >> 4) + i]
 // ------------------------------------------------------------------------------------------------
 constexpr int kFwdTE = 16;
 
@@ -355,17 +358,13 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_fwd_kernel(const fl
     for (int p = 0; p < 3; ++p) wsp[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
 }
 
-__device__ __forceinline__ void split_lds_dma16(const float* src, float* lds_piece) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
-}
-
-__global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p,
-                                                                           const int32_t* __restrict__ i3, const v4u* __restrict__ wsp, float* __restrict__ out,
-                                                                           int64_t ld_out, int64_t n_edges) {
-    constexpr int TE = kFwdTE, D = 128, HC = 64, PS = HC + 4;
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    __shared__ __attribute__((aligned(16))) float mt[2][3][TE][D];
-    __shared__ __attribute__((aligned(16))) float part[2][8][TE][PS];
+__global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p,
+                                                                              const int32_t* __restrict__ i3, const v4u* __restrict__ wsp, float* __restrict__ out,
+                                                                              int64_t ld_out, int64_t n_edges) {
+    constexpr int TE = kFwdTE, D = 128, HC = 64, PS = HC + 4, ZRB = 2 * 4 * D;     // bytes of one hyperedge's row of a z image (4 blocks x 128 columns)
+    constexpr int ZPL = TE * ZRB;
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
+    __shared__ __attribute__((aligned(16))) float part[2][4][TE][PS];
     __shared__ int ids[8][3 * TE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -375,108 +374,130 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kernel(const
     const int n_my = range < n_tiles ? static_cast<int>((n_tiles - range + kSplitRanges - 1) / kSplitRanges) : 0;   // tiles range, range + 128, ...
     if (n_my == 0) return;
     auto tile_of = [&](int k) { return static_cast<int64_t>(range) + static_cast<int64_t>(k) * kSplitRanges; };
-    const int blk = wave >> 1, ch = wave & 1;
 
-    v8s wreg[4][2][3];
-    {
-        const v4u* wf = wsp + static_cast<int64_t>((half * 8 + wave) * 24) * kWave + lane;
+    if (wave >= 4) {
+        // ---------------- service waves: thread -> hyperedge row, member columns 4 o .. and 64 + 4 o ..; epilogue: output columns 4 o .. of the half
+        const int st = tid - 256, row = st >> 4, o = st & 15;
+        const int64_t last_pos = n_edges * 3 - 1;
+        auto fetch_id = [&](int k) { return i3[std::min<int64_t>(tile_of(k) * (3 * TE) + st, last_pos)]; };           // (st < 48)
+        auto load_members = [&](int k, v4f (&hm)[2][3]) {
+            const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+            for (int m = 0; m < 3; ++m) {
+                const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + 4 * o;
+                hm[0][m] = *reinterpret_cast<const v4f*>(hp);
+                hm[1][m] = *reinterpret_cast<const v4f*>(hp + 64);
+            }
+        };
+        auto load_first_order = [&](int k, v4f (&pr)[3]) {
+            const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int m = 0; m < 3; ++m) pr[m] = *reinterpret_cast<const v4f*>(p + static_cast<int64_t>(idk[m]) * ld_p + HC * half + 4 * o);
+        };
+        auto split_tile = [&](const v4f (&hm)[2][3], int buf) {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wreg[jt][kb][pl] = __builtin_bit_cast(v8s, wf[((jt * 2 + kb) * 3 + pl) * kWave]);
-    }
-
-    const int64_t last_pos = n_edges * 3 - 1;
-    auto fetch_id = [&](int k) { return i3[std::min<int64_t>(tile_of(k) * (3 * TE) + tid, last_pos)]; };          // (threads < 48)
-    // member rows of tile k -> LDS: wave w moves rows 2 w and 2 w + 1 of each of the three members (lane: row + (lane >> 5), chunk lane & 31)
-    const uint32_t h_row_bytes = static_cast<uint32_t>(ld_h) * 4u;
-    auto issue_dma = [&](int k) {
-        const int r = 2 * wave + (lane >> 5), chunk = lane & 31;
-        const int* idk = ids[k & 7] + r * 3;
-        const char* hb = reinterpret_cast<const char*>(h) + ((chunk ^ (r & 15)) << 4);
+            for (int x = 0; x < 2; ++x) {
+                const v4f u = hm[x][0], q = hm[x][1], it = hm[x][2];
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
-            split_lds_dma16(reinterpret_cast<const float*>(hb + static_cast<uint64_t>(static_cast<uint32_t>(idk[m])) * h_row_bytes), &mt[k & 1][m][2 * wave][0]);
-    };
-    const int erow = tid >> 5, ec = 2 * (tid & 31);                        // epilogue role: hyperedge row, 2 output columns of the half
-    auto load_first_order = [&](int k, v2f (&pr)[3]) {
-        const int* idk = ids[k & 7] + erow * 3;
+                for (int b = 0; b < 4; ++b) {
+                    const v4f z = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
+                    unsigned w0[3], w1[3];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) pr[m] = *reinterpret_cast<const v2f*>(p + static_cast<int64_t>(idk[m]) * ld_p + HC * half + ec);
-    };
-
-    if (tid < 3 * TE) {
-        ids[0][tid] = fetch_id(0);
-        if (n_my > 1) ids[1][tid] = fetch_id(1);
-        if (n_my > 2) ids[2][tid] = fetch_id(2);
-    }
-    __syncthreads();
-    issue_dma(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int arow = lane & 15, kq = lane >> 4;
-    const int m0 = blk == 2 ? 2 : (blk == 1 ? 1 : 0), m1 = blk == 2 ? 0 : (blk == 1 ? 2 : 1);   // uq, qi, iu, (uq) i
-    int id_carry = 0;
-    v2f pr0[3], pr1[3];                                                    // first-order rows of tile m live in pr<m & 1>
-    // Phase k: matrix work of tile k; sums, first-order rows and store of tile k - 1; requests the member rows of tile k + 1 (DMA), the
-    // first-order rows of tile k and the ids of tile k + 3.
-    auto phase = [&](auto parity, int k, v2f (&pr_cur)[3], v2f (&pr_prev)[3]) {
-        constexpr int BUF = decltype(parity)::value;
-        if (k >= 1 && k + 2 < n_my && tid < 3 * TE) ids[(k + 2) & 7][tid] = id_carry;    // requested in the previous phase
-        if (k + 1 < n_my) issue_dma(k + 1);                                 // that buffer's last reader was tile k - 1's matrix phase
-        if (k < n_my) load_first_order(k, pr_cur);
-        if (k + 3 < n_my && tid < 3 * TE) id_carry = fetch_id(k + 3);
-        // tile k - 1: the eight partial sums in wave order, the first-order rows, the store
-        if (k >= 1) {
-            const float (*pp)[TE][PS] = part[BUF ^ 1];
-            v2f s[8];
+                    for (int hp2 = 0; hp2 < 2; ++hp2) {
+                        const float xa = z[2 * hp2], xb = z[2 * hp2 + 1];
+                        const float ra = xa - top16(xa), rb = xb - top16(xb);
+                        const float la = ra - top16(ra), lb = rb - top16(rb);
+                        (hp2 == 0 ? w0 : w1)[0] = pack_hi(xa, xb);
+                        (hp2 == 0 ? w0 : w1)[1] = pack_hi(ra, rb);
+                        (hp2 == 0 ? w0 : w1)[2] = pack_hi(la, lb);
+                    }
+                    // columns b * 128 + 64 x + 4 o ..: chunk 16 b + 8 x + (o >> 1), half o & 1
+                    const int off = row * ZRB + (((16 * b + 8 * x + (o >> 1)) ^ row) << 4) + 8 * (o & 1);
 #pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) s[w8] = *reinterpret_cast<const v2f*>(&pp[w8][erow][ec]);
-            const v2f sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-            const v2f first = (pr_prev[0] + pr_prev[1]) + pr_prev[2];
-            const int64_t e = tile_of(k - 1) * TE + erow;
-            if (e < n_edges) __builtin_nontemporal_store(sum + first, reinterpret_cast<v2f*>(out + e * ld_out + HC * half + ec));
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + pl * ZPL + off) = v2u{w0[pl], w1[pl]};
+                }
+            }
+        };
+        auto epilogue = [&](int k, const v4f (&pr)[3]) {                 // tile k - 1
+            const float (*pp)[TE][PS] = part[(k - 1) & 1];
+            const v4f s0 = *reinterpret_cast<const v4f*>(&pp[0][row][4 * o]), s1 = *reinterpret_cast<const v4f*>(&pp[1][row][4 * o]);
+            const v4f s2 = *reinterpret_cast<const v4f*>(&pp[2][row][4 * o]), s3 = *reinterpret_cast<const v4f*>(&pp[3][row][4 * o]);
+            const v4f sum = (s0 + s1) + (s2 + s3);
+            const v4f first = (pr[0] + pr[1]) + pr[2];
+            const int64_t e = tile_of(k - 1) * TE + row;
+            if (e < n_edges) store_stream4(out + e * ld_out + HC * half + 4 * o, sum + first);
+        };
+        if (st < 3 * TE) {
+            ids[0][st] = fetch_id(0);
+            if (n_my > 1) ids[1][st] = fetch_id(1);
+            if (n_my > 2) ids[2][st] = fetch_id(2);
+            if (n_my > 3) ids[3][st] = fetch_id(3);
         }
+        __syncthreads();
+        v4f hm0[2][3], hm1[2][3], pr0[3], pr1[3];                        // member values of tile m in hm<m & 1>, first-order rows in pr<m & 1>
+        load_members(0, hm0);
+        if (n_my > 1) load_members(1, hm1);
+        split_tile(hm0, 0);
+        __syncthreads();
+        int id_carry = 0;
+        // phase k: products of tile k + 1 (`use`) into the images; sums, first-order rows and store of tile k - 1; requests: member values of
+        // tile k + 2 (`fill`), first-order rows of tile k, ids of tile k + 4 (they reach the ring in the next phase and are first read in the one after)
+        auto phase = [&](int k, v4f (&use)[2][3], v4f (&fill)[2][3], v4f (&pr_cur)[3], v4f (&pr_prev)[3]) {
+            if (k >= 1 && k + 3 < n_my && st < 3 * TE) ids[(k + 3) & 7][st] = id_carry;
+            if (k + 2 < n_my) load_members(k + 2, fill);
+            if (k < n_my) load_first_order(k, pr_cur);
+            if (k + 4 < n_my && st < 3 * TE) id_carry = fetch_id(k + 4);
+            if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
+            // delivery of this phase's requests, THEN the store: the memory counter is in order, a wait behind the store would sit out its
+            // round trip to memory in every phase (measured: 2.07 ms instead of 0.9 for this kernel)
+            asm volatile("" : "+v"(fill[0][0]), "+v"(fill[0][1]), "+v"(fill[0][2]), "+v"(fill[1][0]), "+v"(fill[1][1]), "+v"(fill[1][2]));
+            asm volatile("" : "+v"(pr_cur[0]), "+v"(pr_cur[1]), "+v"(pr_cur[2]));
+            if (k >= 1) epilogue(k, pr_prev);
+            __syncthreads();
+        };
+        for (int k = 0; k <= n_my; k += 2) {
+            phase(k, hm1, hm0, pr0, pr1);
+            if (k + 1 <= n_my) phase(k + 1, hm0, hm1, pr1, pr0);
+        }
+        return;
+    }
+
+    // ---------------- matrix waves: wave = product block; weight planes of the half's 64 output columns x the block's 128 contraction values
+    const int blk = wave;
+    v8s wreg[4][4][3];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)      // the packing is [half][2 b + (kb >> 1)][jt][kb & 1][plane] (see pack_planes_fwd_kernel)
+                wreg[jt][kb][pl] = __builtin_bit_cast(v8s, wsp[(static_cast<int64_t>((half * 8 + 2 * blk + (kb >> 1)) * 24) + (jt * 2 + (kb & 1)) * 3 + pl) * kWave + lane]);
+    __syncthreads();
+    __syncthreads();
+    const int arow = lane & 15, kq = lane >> 4;
+    for (int k = 0; k <= n_my; ++k) {
         if (k < n_my) {
             v4f acc[4];
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) acc[jt] = v4f{0.f, 0.f, 0.f, 0.f};
-            const float* t0p = &mt[BUF][m0][arow][0];
-            const float* t1p = &mt[BUF][m1][arow][0];
-            const float* t2p = &mt[BUF][2][arow][0];
+            const unsigned char* zp = &zplanes[k & 1][0][0][0] + arow * ZRB;
+            v8s zf[4][3];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const int c4 = 16 * ch + 8 * kb + 2 * kq;                  // first of the two 16-byte chunks of this lane's 8 values
-                const int s0 = ((c4 ^ arow) << 2), s1 = (((c4 + 1) ^ arow) << 2);
-                const v4f x0 = *reinterpret_cast<const v4f*>(t0p + s0), x1 = *reinterpret_cast<const v4f*>(t0p + s1);
-                const v4f y0 = *reinterpret_cast<const v4f*>(t1p + s0), y1 = *reinterpret_cast<const v4f*>(t1p + s1);
-                v4f z0 = x0 * y0, z1 = x1 * y1;
-                if (blk == 3) {
-                    z0 *= *reinterpret_cast<const v4f*>(t2p + s0);
-                    z1 *= *reinterpret_cast<const v4f*>(t2p + s1);
-                }
-                const Planes zp = split8(z0, z1);
-                v8s zf[3];
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) zf[pl] = __builtin_bit_cast(v8s, zp.p[pl]);
+                for (int pl = 0; pl < 3; ++pl) zf[kb][pl] = *reinterpret_cast<const v8s*>(zp + pl * ZPL + (((16 * blk + 4 * kb + kq) ^ arow) << 4));
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt)
-                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[jt][kb][kTermB[term]], zf[kTermA[term]], acc[jt], 0, 0, 0);
-            }
+                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[jt][kb][kTermB[term]], zf[kb][kTermA[term]], acc[jt], 0, 0, 0);
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<v4f*>(&part[BUF][wave][arow][16 * jt + 4 * kq]) = acc[jt];
+            for (int jt = 0; jt < 4; ++jt) *reinterpret_cast<v4f*>(&part[k & 1][blk][arow][16 * jt + 4 * kq]) = acc[jt];
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the DMA of tile k + 1 (requested a whole phase ago) has landed
         __syncthreads();
-    };
-    for (int k = 0; k <= n_my; k += 2) {
-        phase(std::integral_constant<int, 0>{}, k, pr0, pr1);
-        if (k + 1 <= n_my) phase(std::integral_constant<int, 1>{}, k + 1, pr1, pr0);
     }
 }
 
@@ -1056,15 +1077,14 @@ int launch_weight_split(const float* h, int64_t ld_h, const int32_t* i3, const f
 }
 
 bool split_fwd_ok(int dim, int order, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h) {
-    return split_arith_enabled() && dim == 128 && order == 3 && p != nullptr && ld_p % 2 == 0 && ld_out % 2 == 0 && (reinterpret_cast<uintptr_t>(p) & 7u) == 0 &&
-           (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && ld_h % 4 == 0 && ld_h < (int64_t{1} << 30);
+    return split_arith_enabled() && dim == 128 && order == 3 && p != nullptr && ld_p % 4 == 0 && ld_out % 4 == 0 && aligned16(p) && aligned16(out) && ld_h % 4 == 0;
 }
 
 void launch_fwd_split(const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes, float* out,
                       int64_t ld_out, int64_t n_edges, hipStream_t s) {
     v4u* wsp = static_cast<v4u*>(planes);
     hipLaunchKernelGGL(pack_planes_fwd_kernel, dim3(2 * 8 * 4 * 2 * kWave / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, wsp);
-    hipLaunchKernelGGL(interact_fwd_split_kernel, dim3(2 * kSplitRanges), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
+    hipLaunchKernelGGL(interact_fwd_split_ws_kernel, dim3(2 * kSplitRanges), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
 }
 
 bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x) {
