@@ -11,10 +11,10 @@
 // floats of workspace the weight planes of one direction take (three bf16 per weight)
 IHG_INTERNAL int64_t split_plane_floats(int dim, int order);
 IHG_INTERNAL bool split_arith_enabled();                       // IHG_INTERACT_ARITH != "f32"
-IHG_INTERNAL bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout);
+IHG_INTERNAL bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout, bool user_reduced);
 
 // member gradients; dh_user == nullptr: g is [E, 3, d], else the user-reduced form (g is [E, 2, d], boundary table as in interact.hip)
-IHG_INTERNAL void launch_members_split(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
+IHG_INTERNAL void launch_members_split(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
                                        int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
                                        int* n_boundary_entries, hipStream_t s);
 
@@ -25,7 +25,7 @@ IHG_INTERNAL void launch_fwd_split(const float* h, int64_t ld_h, const float* p,
 
 // weight gradients into slabs [range][j][b d + c] (interact.hip's slab layout); returns the number of slabs written
 IHG_INTERNAL bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout);
-IHG_INTERNAL int launch_weight_split(const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s);
+IHG_INTERNAL int launch_weight_split(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s);
 
 // node-level row GEMM (d = 128, 256): out = in W_t^T (transpose == 0) or in W_t (transpose == 1), rows grouped by node type
 IHG_INTERNAL int64_t split_dense_plane_floats(int dim);

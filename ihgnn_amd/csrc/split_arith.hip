@@ -61,13 +61,14 @@ __device__ constexpr int kTermA[6] = {0, 2, 1, 0, 1, 0};
 __device__ constexpr int kTermB[6] = {2, 0, 1, 1, 0, 0};
 
 // planes of the member-gradient contraction dz_b[e][c] = sum_j dout[e][j] W[j][(3+b)d + c]   (k runs along j):
-// wsp[qtr][b][kb][ct][plane][lane][8], element i = plane of W[32 kb + 8 (lane>>4) + i][(3+b) d + 32 qtr + 16 ct + (lane&15)]
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(const float* __restrict__ w, int64_t ld_w, v4u* __restrict__ wsp) {
-    constexpr int D = 128, NBLK = 4;
+// wsp[g][b][kb][ct][plane][lane][8] (g = 32-column group, d / 32 of them; kb < d / 32; ct < 2): element i = plane of
+// W[32 kb + 8 (lane>>4) + i][(3+b) d + 32 g + 16 ct + (lane&15)]
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(const float* __restrict__ w, int64_t ld_w, int d, v4u* __restrict__ wsp) {
+    const int kbs = d / 32, groups = d / 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 4 * NBLK * 4 * 2 * kWave) return;
-    const int lane = idx & 63, ct = (idx >> 6) & 1, kb = (idx >> 7) & 3, b = (idx >> 9) & 3, qtr = idx >> 11;
-    const float* src = w + static_cast<int64_t>(32 * kb + 8 * (lane >> 4)) * ld_w + (3 + b) * D + 32 * qtr + 16 * ct + (lane & 15);
+    if (idx >= groups * 4 * kbs * 2 * kWave) return;
+    const int lane = idx & 63, ct = (idx >> 6) & 1, kb = (idx >> 7) % kbs, b = ((idx >> 7) / kbs) & 3, g = (idx >> 7) / (kbs * 4);
+    const float* src = w + static_cast<int64_t>(32 * kb + 8 * (lane >> 4)) * ld_w + (3 + b) * d + 32 * g + 16 * ct + (lane & 15);
     v4f x0, x1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -99,22 +100,27 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
 // finished runs (their sums fetched four at a time) to dh[user].  (user, destination, running sums) are carried from tile to tile, which
 // is why a workgroup takes a CONTIGUOUS tile range; the first and the last run of a range may continue in the neighbours and go to the
 // boundary table that interact.hip's user_boundary_fixup_kernel adds up (indexed by tile range here, shared by the two halves).
-template <bool UR>
+// D = 128: two column halves of 64 per tile range.  D = 256: eight parts of 32 columns (the weight planes are 1.5 MB), the dout tile is 32 KB
+// and every part splits it again; no user reduction there.
+template <int D, bool UR>
 __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
                                                                                       const v4u* __restrict__ wsp, const float* __restrict__ dout, int64_t ld_dout,
                                                                                       float* __restrict__ g_out, int64_t n_edges, float* __restrict__ dh_user,
                                                                                       int64_t ld_dh, float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user) {
-    constexpr int TE = kSplitTE, D = 128, HC = 64, DZ = HC + 4, UT = TE + 4, GS = UR ? 2 : 3;
-    __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][256];
+    static_assert(D == 128 || (D == 256 && !UR), "shapes");
+    constexpr int TE = kSplitTE, PARTS = D == 128 ? 2 : 8, RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, KB = D / 32, RB = 2 * D;
+    constexpr int DOCT = D / 64, EX = HC / 32;                          // per service thread: dout octets, 4-column groups of the product rule
+    constexpr int DZ = HC + 4, UT = TE + 4, GS = UR ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][RB];
     __shared__ __attribute__((aligned(16))) float dzimg[2][4][TE][DZ];
     __shared__ __attribute__((aligned(16))) float utile[UR ? 2 : 1][UR ? HC : 1][UT];     // transposed: [column][row]
     __shared__ int ids[8][3 * TE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x;
-    const int half = (bid >> 3) & 1, range = (bid & 7) + 8 * (bid >> 4);
+    const int half = (bid >> 3) & (PARTS - 1), range = (bid & 7) + 8 * (bid / (8 * PARTS));      // `half`: this workgroup's column part
     const int64_t n_tiles = (n_edges + TE - 1) / TE;
-    const int64_t per = (n_tiles + kSplitRanges - 1) / kSplitRanges;
+    const int64_t per = (n_tiles + RANGES - 1) / RANGES;
     const int64_t t0 = range * per;
     const int n_my = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(per, n_tiles - t0)));
     if (n_my == 0) {
@@ -128,37 +134,38 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         const int st = tid - 256, row = st >> 3, o = st & 7;
         const int64_t last_pos = n_edges * 3 - 1;
         auto fetch_id = [&](int k) { return i3[std::min<int64_t>((t0 + k) * (3 * TE) + st, last_pos)]; };     // (st < 96)
-        auto load_dout = [&](int k, v4f (&dr)[4]) {
+        auto load_dout = [&](int k, v4f (&dr)[2 * DOCT]) {
             const float* src = dout + std::min<int64_t>((t0 + k) * TE + row, n_edges - 1) * ld_dout + 8 * o;
-            dr[0] = *reinterpret_cast<const v4f*>(src);
-            dr[1] = *reinterpret_cast<const v4f*>(src + 4);
-            dr[2] = *reinterpret_cast<const v4f*>(src + 64);
-            dr[3] = *reinterpret_cast<const v4f*>(src + 68);
+#pragma unroll
+            for (int x = 0; x < DOCT; ++x) {
+                dr[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
+                dr[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
+            }
         };
-        auto load_members = [&](int k, v4f (&hm)[2][3]) {
+        auto load_members = [&](int k, v4f (&hm)[EX][3]) {
             const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + HC * half + 4 * o;
-                hm[0][m] = *reinterpret_cast<const v4f*>(hp);
-                hm[1][m] = *reinterpret_cast<const v4f*>(hp + 32);
+#pragma unroll
+                for (int x = 0; x < EX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + 32 * x);
             }
         };
         const int swz = row & 15;
-        auto split_tile = [&](const v4f (&dr)[4], int buf) {
+        auto split_tile = [&](const v4f (&dr)[2 * DOCT], int buf) {
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
+            for (int x = 0; x < DOCT; ++x) {
                 const Planes pl = split8(dr[2 * x], dr[2 * x + 1]);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[buf][p][row][((o + 8 * x) ^ swz) << 4]) = pl.p[p];
             }
         };
         // product rule of tile k - 1 (its contractions in dzimg[(k - 1) & 1], its member values in hm) and the stores
-        auto epilogue = [&](int k, const v4f (&hm)[2][3]) {
+        auto epilogue = [&](int k, const v4f (&hm)[EX][3]) {
             const float (*dz)[TE][DZ] = dzimg[(k - 1) & 1];
             const int64_t e = (t0 + k - 1) * TE + row;
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
+            for (int x = 0; x < EX; ++x) {
                 const int c = 4 * o + 32 * x;
                 const v4f z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][c]), z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][c]);
                 const v4f z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][c]), z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][c]);
@@ -242,13 +249,13 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             if (n_my > 2) ids[2][st] = fetch_id(2);
         }
         __syncthreads();
-        v4f dr0[4], dr1[4], hm0[2][3], hm1[2][3];                        // dout values of tile m in dr<m & 1>, member values in hm<m & 1>
+        v4f dr0[2 * DOCT], dr1[2 * DOCT], hm0[EX][3], hm1[EX][3];                        // dout values of tile m in dr<m & 1>, member values in hm<m & 1>
         load_dout(0, dr0);
         if (n_my > 1) load_dout(1, dr1);
         split_tile(dr0, 0);
         __syncthreads();
         int id_carry = 0;
-        auto phase = [&](int k, v4f (&use)[4], v4f (&fill)[4], v4f (&hm_cur)[2][3], v4f (&hm_prev)[2][3]) {
+        auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3]) {
             if (k >= 1 && k + 2 < n_my && st < 3 * TE) ids[(k + 2) & 7][st] = id_carry;     // requested in the previous phase
             if (k < n_my) load_members(k, hm_cur);
             if (k + 2 < n_my) load_dout(k + 2, fill);
@@ -256,8 +263,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
             // delivery of this phase's requests, THEN everything that stores: the memory counter is in order, a wait behind a store sits out
             // the store's round trip to memory
-            asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2]), "+v"(fill[3]));
-            asm volatile("" : "+v"(hm_cur[0][0]), "+v"(hm_cur[0][1]), "+v"(hm_cur[0][2]), "+v"(hm_cur[1][0]), "+v"(hm_cur[1][1]), "+v"(hm_cur[1][2]));
+            asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * DOCT - 2]), "+v"(fill[2 * DOCT - 1]));     // (in order: the last delivered = all delivered)
+            asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));
             if (k >= 1 && k - 1 < n_my) epilogue(k, hm_prev);
             if (UR && k >= 2) scan_and_emit(k - 2);
             __syncthreads();
@@ -283,41 +290,41 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
 
     // ---------------- matrix waves: wave = product block, the half's four 16-column tiles, both row tiles
     const int blk = wave;
-    v8s wreg[4][4][3];
+    v8s wreg[KB][CT][3];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                wreg[kb][ct][p] = __builtin_bit_cast(v8s, wsp[(static_cast<int64_t>(((2 * half + (ct >> 1)) * 4 + blk) * 24) + (kb * 2 + (ct & 1)) * 3 + p) * kWave + lane]);
+            for (int p = 0; p < 3; ++p)      // 32-column group of column tile ct: (HC / 32) half + (ct >> 1)
+                wreg[kb][ct][p] = __builtin_bit_cast(v8s, wsp[(static_cast<int64_t>((((HC / 32) * half + (ct >> 1)) * 4 + blk) * (KB * 2) + kb * 2 + (ct & 1)) * 3 + p) * kWave + lane]);
     __syncthreads();
     __syncthreads();
     const int arow = lane & 15, kq = lane >> 4;
     for (int k = 0; k < n_phases; ++k) {
         if (k < n_my) {
-            v4f acc[2][4];
+            v4f acc[2][CT];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
             const unsigned char* pbase = &planes[k & 1][0][0][0];
             auto fragment = [&](int step, v8s (&a)[3]) {
                 const int kb = step >> 1, rt = step & 1;
-                const unsigned char* src = pbase + (16 * rt + arow) * 256 + (((4 * kb + kq) ^ arow) << 4);
+                const unsigned char* src = pbase + (16 * rt + arow) * RB + (((4 * kb + kq) ^ arow) << 4);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * 256));
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * RB));
             };
             v8s a[3], an[3];
             fragment(0, a);
 #pragma unroll
-            for (int step = 0; step < 8; ++step) {
+            for (int step = 0; step < 2 * KB; ++step) {
                 const int kb = step >> 1, rt = step & 1;
-                if (step + 1 < 8) fragment(step + 1, an);
+                if (step + 1 < 2 * KB) fragment(step + 1, an);
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
+                    for (int ct = 0; ct < CT; ++ct)
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][ct][kTermB[term]], a[kTermA[term]], acc[rt][ct], 0, 0, 0);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) a[p] = an[p];
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<v4f*>(&dzimg[k & 1][blk][16 * rt + arow][16 * ct + 4 * kq]) = acc[rt][ct];
+                for (int ct = 0; ct < CT; ++ct) *reinterpret_cast<v4f*>(&dzimg[k & 1][blk][16 * rt + arow][16 * ct + 4 * kq]) = acc[rt][ct];
         }
         __syncthreads();
     }
@@ -527,20 +534,23 @@ __device__ __forceinline__ v8s read_tr_fragment(const unsigned char* lo, const u
 // 1,710 on the same box); apart, the matrix waves run at the one-wave-per-SIMD rate (tools/split_probe.hip: 17.6 instead of 21
 // cycles per MFMA) and part of the split waves' vector instructions falls into the issue cycles the MFMAs leave.  Alone, the matrix
 // waves would take 1,350 us and the split waves 1,035.
+// D = 128: two column halves of 64 per tile range; D = 256: eight parts of 32 columns (the dout tile is split by every part).
+template <int D>
 __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
                                                                                      const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ slabs,
                                                                                      int64_t n_edges) {
-    constexpr int TE = kSplitTE, D = 128, HC = 64, NBLK = 4;
-    constexpr int DPL = TE * 256, ZPL = TE * 512;
-    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][256];
-    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][512];
+    constexpr int TE = kSplitTE, NBLK = 4, PARTS = D == 128 ? 2 : 8, RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, JT = D / 16, DRB = 2 * D, ZRB = 8 * HC;
+    constexpr int DOCT = D / 64, ZX = HC / 32;                          // per service thread: dout octets, 4-column groups of products
+    constexpr int DPL = TE * DRB, ZPL = TE * ZRB;
+    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][DRB];
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
     __shared__ int ids[8][3 * TE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x;
-    const int half = (bid >> 3) & 1, range = (bid & 7) + 8 * (bid >> 4);
+    const int half = (bid >> 3) & (PARTS - 1), range = (bid & 7) + 8 * (bid / (8 * PARTS));      // `half`: this workgroup's column part
     const int64_t n_tiles = (n_edges + TE - 1) / TE;
-    const int64_t per = (n_tiles + kSplitRanges - 1) / kSplitRanges;
+    const int64_t per = (n_tiles + RANGES - 1) / RANGES;
     const int64_t t0 = range * per;
     const int n_my = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(per, n_tiles - t0)));
 
@@ -550,22 +560,26 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
         const int64_t last_pos = n_edges * 3 - 1;
         auto fetch_id = [&](int k) { return i3[std::min<int64_t>((t0 + k) * (3 * TE) + st, last_pos)]; };     // (st < 96)
         struct Rows {
-            v4f d[4], m[2][3];
+            v4f d[2 * DOCT], m[ZX][3];
         };
         auto load_rows = [&](int k, Rows& r) {
             const int64_t e = (t0 + k) * TE + row;
             const float* src = dout + std::min<int64_t>(e, n_edges - 1) * ld_dout + 8 * o;
-            r.d[0] = *reinterpret_cast<const v4f*>(src);
-            r.d[1] = *reinterpret_cast<const v4f*>(src + 4);
-            r.d[2] = *reinterpret_cast<const v4f*>(src + 64);
-            r.d[3] = *reinterpret_cast<const v4f*>(src + 68);
-            if (e >= n_edges) r.d[0] = r.d[1] = r.d[2] = r.d[3] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int x = 0; x < DOCT; ++x) {
+                r.d[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
+                r.d[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
+            }
+            if (e >= n_edges) {                                          // hyperedges past the end contribute nothing
+#pragma unroll
+                for (int x = 0; x < 2 * DOCT; ++x) r.d[x] = v4f{0.f, 0.f, 0.f, 0.f};
+            }
             const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + HC * half + 4 * o;
-                r.m[0][m] = *reinterpret_cast<const v4f*>(hp);
-                r.m[1][m] = *reinterpret_cast<const v4f*>(hp + 32);
+#pragma unroll
+                for (int x = 0; x < ZX; ++x) r.m[x][m] = *reinterpret_cast<const v4f*>(hp + 32 * x);
             }
         };
         const int swz = tr_swizzle(row);
@@ -578,7 +592,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
                 out[2] = pack_hi(la, lb);
             };
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {                                // dout octets o + 8 x
+            for (int x = 0; x < DOCT; ++x) {                             // dout octets o + 8 x (256-byte segments swizzled separately)
                 v4u sp[3];
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
@@ -588,10 +602,11 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
                     for (int p = 0; p < 3; ++p) sp[p][pr] = w[p];
                 }
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + row * 256 + (((o + 8 * x) ^ swz) << 4)) = sp[p];
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + row * DRB + 256 * ((o + 8 * x) >> 4) + ((((o + 8 * x) & 15) ^ swz) << 4)) = sp[p];
             }
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {                                // member column groups 4 (o + 8 x) ..
+            for (int x = 0; x < ZX; ++x) {                               // member column groups 4 (o + 8 x) ..
                 const int og = o + 8 * x;
                 const v4f u = r.m[x][0], q = r.m[x][1], it = r.m[x][2];
 #pragma unroll
@@ -601,7 +616,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
                     unsigned w0[3], w1[3];
                     pair(z[0], z[1], w0);
                     pair(z[2], z[3], w1);
-                    const int off = row * 512 + 256 * (b >> 1) + (((8 * (b & 1) + (og >> 1)) ^ swz) << 4) + 8 * (og & 1);
+                    const int byte = 2 * (b * HC + 4 * og);               // columns b HC + 4 og .. of the product image's row
+                    const int off = row * ZRB + 256 * (byte >> 8) + ((((byte >> 4) & 15) ^ swz) << 4) + (byte & 8);
 #pragma unroll
                     for (int p = 0; p < 3; ++p) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + p * ZPL + off) = v2u{w0[p], w1[p]};
                 }
@@ -639,23 +655,26 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
 
     // ---------------- matrix waves: wave = product block, 8 x 4 accumulator tiles (all 128 dout columns x the block's 64 columns of the half)
     const int blk = wave;
-    v4f acc[8][4];
+    v4f acc[JT][CT];
 #pragma unroll
-    for (int jt = 0; jt < 8; ++jt)
+    for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[jt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < CT; ++ct) acc[jt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
     if (n_my > 0) {
         __syncthreads();
         __syncthreads();
         const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
         const int rlo = 8 * g + q, rhi = rlo + 4;
-        auto a_addr = [&](int r, int jt) { return r * 256 + ((((2 * jt + (pp >> 1))) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
-        auto b_addr = [&](int r, int ct) { return r * 512 + 256 * (blk >> 1) + (((8 * (blk & 1) + 2 * ct + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
+        auto a_addr = [&](int r, int jt) { return r * DRB + 256 * (jt >> 3) + (((2 * (jt & 7) + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
+        auto b_addr = [&](int r, int ct) {
+            const int byte = 2 * (blk * HC + 16 * ct);                   // first column of the tile in the product image's row
+            return r * ZRB + 256 * (byte >> 8) + (((((byte >> 4) & 15) + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1);
+        };
         for (int k = 0; k < n_my; ++k) {
             const unsigned char* dp = &dplanes[k & 1][0][0][0];
             const unsigned char* zp = &zplanes[k & 1][0][0][0];
 #pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {
+            for (int jh = 0; jh < JT / 4; ++jh) {
                 v8s a[4][3];
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt)
@@ -665,8 +684,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
 #pragma unroll
                 for (int p = 0; p < 3; ++p) b[p] = read_tr_fragment(zp + p * ZPL + b_addr(rlo, 0), zp + p * ZPL + b_addr(rhi, 0));
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    if (ct + 1 < 4) {
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (ct + 1 < CT) {
 #pragma unroll
                         for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(zp + p * ZPL + b_addr(rlo, ct + 1), zp + p * ZPL + b_addr(rhi, ct + 1));
                     }
@@ -685,9 +704,9 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
     float* slab = slabs + static_cast<int64_t>(range) * D * NBLK * D;
     const int c = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int jt = 0; jt < 8; ++jt)
+    for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) slab[static_cast<int64_t>(16 * jt + 4 * kq + r) * NBLK * D + blk * D + HC * half + 16 * ct + c] = acc[jt][ct][r];
 }
@@ -1008,28 +1027,33 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 
 }  // namespace
 
-int64_t split_plane_floats(int dim, int order) { return dim == 128 && order == 3 ? (3LL * 4 * dim * dim) / 2 : 0; }
+int64_t split_plane_floats(int dim, int order) { return (dim == 128 || dim == 256) && order == 3 ? (3LL * 4 * dim * dim) / 2 : 0; }
 
 bool split_arith_enabled() {                                             // read at every call: tests and the bench switch it in-process
     const char* v = std::getenv("IHG_INTERACT_ARITH");
     return v == nullptr || std::strcmp(v, "f32") != 0;
 }
 
-bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout) {
-    return split_arith_enabled() && dim == 128 && order == 3 && aligned16(g) && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
+// dim 128: either form of g; dim 256: the [E, 3, d] form only
+bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout, bool user_reduced) {
+    return split_arith_enabled() && (dim == 128 || (dim == 256 && !user_reduced)) && order == 3 && aligned16(g) && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
 }
 
-void launch_members_split(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
+void launch_members_split(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
                           int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
                           int* n_boundary_entries, hipStream_t s) {
     v4u* wsp = static_cast<v4u*>(planes);
-    hipLaunchKernelGGL(pack_planes_members_kernel, dim3(4 * 4 * 4 * 2 * kWave / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, wsp);
-    const int grid = 2 * kSplitRanges;
-    if (dh_user != nullptr)
-        hipLaunchKernelGGL(interact_bwd_members_split_ws_kernel<true>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user,
+    const int items = (dim / 32) * 4 * (dim / 32) * 2 * kWave;
+    hipLaunchKernelGGL(pack_planes_members_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, wsp);
+    const int grid = 256;                                                // tile ranges x column parts
+    if (dim == 256)
+        hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<256, false>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
+                           static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
+    else if (dh_user != nullptr)
+        hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<128, true>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user,
                            ld_dh, bnd_val, bnd_user);
     else
-        hipLaunchKernelGGL(interact_bwd_members_split_ws_kernel<false>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
+        hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<128, false>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
                            static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
     if (n_boundary_entries != nullptr) *n_boundary_entries = 2 * kSplitRanges;
 }
@@ -1068,11 +1092,15 @@ void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float*
 }
 
 bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout) {
-    return split_arith_enabled() && dim == 128 && order == 3 && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
+    return split_arith_enabled() && (dim == 128 || dim == 256) && order == 3 && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
 }
 
-int launch_weight_split(const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s) {
-    hipLaunchKernelGGL(interact_bwd_weight_split_ws_kernel, dim3(2 * kSplitRanges), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
+int launch_weight_split(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s) {
+    if (dim == 256) {
+        hipLaunchKernelGGL(interact_bwd_weight_split_ws_kernel<256>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
+        return 32;
+    }
+    hipLaunchKernelGGL(interact_bwd_weight_split_ws_kernel<128>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
     return kSplitRanges;                                                 // slabs written (every range writes one, empty ranges zeros)
 }
 
