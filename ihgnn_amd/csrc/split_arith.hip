@@ -101,14 +101,15 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
 // is why a workgroup takes a CONTIGUOUS tile range; the first and the last run of a range may continue in the neighbours and go to the
 // boundary table that interact.hip's user_boundary_fixup_kernel adds up (indexed by tile range here, shared by the two halves).
 // D = 128: two column halves of 64 per tile range.  D = 256: eight parts of 32 columns (the weight planes are 1.5 MB), the dout tile is 32 KB
-// and every part splits it again; no user reduction there.
+// and every part splits it again.  D = 64: one workgroup holds all of it.  No user reduction at 64 / 256.
 template <int D, bool UR>
 __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
                                                                                       const v4u* __restrict__ wsp, const float* __restrict__ dout, int64_t ld_dout,
                                                                                       float* __restrict__ g_out, int64_t n_edges, float* __restrict__ dh_user,
                                                                                       int64_t ld_dh, float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user) {
-    static_assert(D == 128 || (D == 256 && !UR), "shapes");
-    constexpr int TE = kSplitTE, PARTS = D == 128 ? 2 : 8, RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, KB = D / 32, RB = 2 * D;
+    static_assert(D == 128 || ((D == 256 || D == 64) && !UR), "shapes");
+    constexpr int TE = kSplitTE, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, KB = D / 32, RB = 2 * D;
+    constexpr int SWZ = RB / 16 - 1 < 15 ? RB / 16 - 1 : 15;            // the row swizzle stays inside a row (D = 64: rows of 8 chunks)
     constexpr int DOCT = D / 64, EX = HC / 32;                          // per service thread: dout octets, 4-column groups of the product rule
     constexpr int DZ = HC + 4, UT = TE + 4, GS = UR ? 2 : 3;
     __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][RB];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 for (int x = 0; x < EX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + 32 * x);
             }
         };
-        const int swz = row & 15;
+        const int swz = row & SWZ;
         auto split_tile = [&](const v4f (&dr)[2 * DOCT], int buf) {
 #pragma unroll
             for (int x = 0; x < DOCT; ++x) {
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             const unsigned char* pbase = &planes[k & 1][0][0][0];
             auto fragment = [&](int step, v8s (&a)[3]) {
                 const int kb = step >> 1, rt = step & 1;
-                const unsigned char* src = pbase + (16 * rt + arow) * RB + (((4 * kb + kq) ^ arow) << 4);
+                const unsigned char* src = pbase + (16 * rt + arow) * RB + (((4 * kb + kq) ^ (arow & SWZ)) << 4);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * RB));
             };
@@ -534,12 +535,13 @@ __device__ __forceinline__ v8s read_tr_fragment(const unsigned char* lo, const u
 // 1,710 on the same box); apart, the matrix waves run at the one-wave-per-SIMD rate (tools/split_probe.hip: 17.6 instead of 21
 // cycles per MFMA) and part of the split waves' vector instructions falls into the issue cycles the MFMAs leave.  Alone, the matrix
 // waves would take 1,350 us and the split waves 1,035.
-// D = 128: two column halves of 64 per tile range; D = 256: eight parts of 32 columns (the dout tile is split by every part).
+// D = 128: two column halves of 64 per tile range; D = 256: eight parts of 32 columns (the dout tile is split by every part); D = 64: one workgroup.
 template <int D>
 __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
                                                                                      const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ slabs,
                                                                                      int64_t n_edges) {
-    constexpr int TE = kSplitTE, NBLK = 4, PARTS = D == 128 ? 2 : 8, RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, JT = D / 16, DRB = 2 * D, ZRB = 8 * HC;
+    constexpr int TE = kSplitTE, NBLK = 4, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, JT = D / 16;
+    constexpr int DRB = 2 * D < 256 ? 256 : 2 * D, ZRB = 8 * HC;         // image rows are whole 256-byte segments (the transposed-read swizzle moves chunks inside one)
     constexpr int DOCT = D / 64, ZX = HC / 32;                          // per service thread: dout octets, 4-column groups of products
     constexpr int DPL = TE * DRB, ZPL = TE * ZRB;
     __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][DRB];
@@ -1027,16 +1029,16 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 
 }  // namespace
 
-int64_t split_plane_floats(int dim, int order) { return (dim == 128 || dim == 256) && order == 3 ? (3LL * 4 * dim * dim) / 2 : 0; }
+int64_t split_plane_floats(int dim, int order) { return (dim == 64 || dim == 128 || dim == 256) && order == 3 ? (3LL * 4 * dim * dim) / 2 : 0; }
 
 bool split_arith_enabled() {                                             // read at every call: tests and the bench switch it in-process
     const char* v = std::getenv("IHG_INTERACT_ARITH");
     return v == nullptr || std::strcmp(v, "f32") != 0;
 }
 
-// dim 128: either form of g; dim 256: the [E, 3, d] form only
+// dim 128: either form of g; dim 64, 256: the [E, 3, d] form only
 bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout, bool user_reduced) {
-    return split_arith_enabled() && (dim == 128 || (dim == 256 && !user_reduced)) && order == 3 && aligned16(g) && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
+    return split_arith_enabled() && (dim == 128 || ((dim == 256 || dim == 64) && !user_reduced)) && order == 3 && aligned16(g) && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
 }
 
 void launch_members_split(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
@@ -1048,6 +1050,9 @@ void launch_members_split(int dim, const float* h, int64_t ld_h, const int32_t* 
     const int grid = 256;                                                // tile ranges x column parts
     if (dim == 256)
         hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<256, false>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
+                           static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
+    else if (dim == 64)
+        hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<64, false>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
                            static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
     else if (dh_user != nullptr)
         hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<128, true>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user,
@@ -1092,13 +1097,17 @@ void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float*
 }
 
 bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout) {
-    return split_arith_enabled() && (dim == 128 || dim == 256) && order == 3 && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
+    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && order == 3 && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
 }
 
 int launch_weight_split(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s) {
     if (dim == 256) {
         hipLaunchKernelGGL(interact_bwd_weight_split_ws_kernel<256>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
         return 32;
+    }
+    if (dim == 64) {
+        hipLaunchKernelGGL(interact_bwd_weight_split_ws_kernel<64>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
+        return 256;
     }
     hipLaunchKernelGGL(interact_bwd_weight_split_ws_kernel<128>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
     return kSplitRanges;                                                 // slabs written (every range writes one, empty ranges zeros)
