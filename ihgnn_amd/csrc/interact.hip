@@ -2055,7 +2055,7 @@ int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p,
         float* wp = static_cast<float*>(workspace);
         const int nblk = order == 3 ? 4 : 3;
         if (split_fwd_ok(dim, order, p, ld_p, out, ld_out, ld_h)) {       // bf16-split contraction; its planes sit behind the fp32-packed weights
-            launch_fwd_split(h, ld_h, p, ld_p, i3, w, ld_w, wp + packed_weight_floats(dim, order), out, ld_out, n_edges, s);
+            launch_fwd_split(dim, h, ld_h, p, ld_p, i3, w, ld_w, wp + packed_weight_floats(dim, order), out, ld_out, n_edges, s);
             return check_launch("ihg_interact_fwd");
         }
         const int pack_items = (dim / 32) * nblk * (dim / 8) * kWave;

@@ -20,7 +20,7 @@ IHG_INTERNAL void launch_members_split(int dim, const float* h, int64_t ld_h, co
 
 // forward (first-order rows p required); planes: split_plane_floats(dim, order) floats of workspace
 IHG_INTERNAL bool split_fwd_ok(int dim, int order, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h);
-IHG_INTERNAL void launch_fwd_split(const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes, float* out,
+IHG_INTERNAL void launch_fwd_split(int dim, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes, float* out,
                                    int64_t ld_out, int64_t n_edges, hipStream_t s);
 
 // weight gradients into slabs [range][j][b d + c] (interact.hip's slab layout); returns the number of slabs written

@@ -350,26 +350,28 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
 // in an LDS image; the service waves add them in block order with the first-order rows (requested a tile earlier) and store, a phase
 // later.  Images, partial-sum image and id ring are double-buffered: one barrier per tile.  (Every wave doing both jobs, members staged
 // by LDS-DMA: 2,215 us against 2,020 on the same box; alone, the matrix waves would take 1,350 us and the service waves 1,380.)
-// wsp[half][2 b + (kb >> 1)][jt][kb & 1][plane][lane][8]: element i = plane of W[64 half + 16 jt + (lane & 15)][(3 + b) d + 32 kb + 8 (lane >> 4) + i]
 // ------------------------------------------------------------------------------------------------
 constexpr int kFwdTE = 16;
 
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_fwd_kernel(const float* __restrict__ w, int64_t ld_w, v4u* __restrict__ wsp) {
-    constexpr int D = 128;
+// wsp[half][b][jt][kb][plane][lane][8] (half < d / 64, kb < d / 32): element i = plane of W[64 half + 16 jt + (lane & 15)][(3 + b) d + 32 kb + 8 (lane >> 4) + i]
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_fwd_kernel(const float* __restrict__ w, int64_t ld_w, int d, v4u* __restrict__ wsp) {
+    const int kbs = d / 32, halves = d / 64;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * 8 * 4 * 2 * kWave) return;
-    const int lane = idx & 63, kb = (idx >> 6) & 1, jt = (idx >> 7) & 3, wave = (idx >> 9) & 7, half = idx >> 12;
-    const int b = wave >> 1, ch = wave & 1;
-    const float* src = w + static_cast<int64_t>(64 * half + 16 * jt + (lane & 15)) * ld_w + (3 + b) * D + 64 * ch + 32 * kb + 8 * (lane >> 4);
+    if (idx >= halves * 4 * 4 * kbs * kWave) return;
+    const int lane = idx & 63, kb = (idx >> 6) % kbs, jt = ((idx >> 6) / kbs) & 3, b = ((idx >> 6) / (kbs * 4)) & 3, half = (idx >> 6) / (kbs * 16);
+    const float* src = w + static_cast<int64_t>(64 * half + 16 * jt + (lane & 15)) * ld_w + (3 + b) * d + 32 * kb + 8 * (lane >> 4);
     const Planes pl = split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]});
 #pragma unroll
     for (int p = 0; p < 3; ++p) wsp[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
 }
 
+// D = 128: two output-column halves per tile sequence (both form and split every product).  D = 64: one workgroup, no duplicated work.
+template <int D>
 __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p,
                                                                               const int32_t* __restrict__ i3, const v4u* __restrict__ wsp, float* __restrict__ out,
                                                                               int64_t ld_out, int64_t n_edges) {
-    constexpr int TE = kFwdTE, D = 128, HC = 64, PS = HC + 4, ZRB = 2 * 4 * D;     // bytes of one hyperedge's row of a z image (4 blocks x 128 columns)
+    constexpr int TE = kFwdTE, PARTS = D / 64, RANGES = 256 / PARTS, HC = 64, PS = HC + 4, KB = D / 32, ZX = D / 64;
+    constexpr int ZRB = 2 * 4 * D;                                       // bytes of one hyperedge's row of a z image (4 blocks x D columns)
     constexpr int ZPL = TE * ZRB;
     __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
     __shared__ __attribute__((aligned(16))) float part[2][4][TE][PS];
@@ -377,24 +379,24 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x;
-    const int half = (bid >> 3) & 1, range = (bid & 7) + 8 * (bid >> 4);
+    const int half = (bid >> 3) & (PARTS - 1), range = (bid & 7) + 8 * (bid / (8 * PARTS));
     const int64_t n_tiles = (n_edges + TE - 1) / TE;
-    const int n_my = range < n_tiles ? static_cast<int>((n_tiles - range + kSplitRanges - 1) / kSplitRanges) : 0;   // tiles range, range + 128, ...
+    const int n_my = range < n_tiles ? static_cast<int>((n_tiles - range + RANGES - 1) / RANGES) : 0;   // tiles range, range + RANGES, ...
     if (n_my == 0) return;
-    auto tile_of = [&](int k) { return static_cast<int64_t>(range) + static_cast<int64_t>(k) * kSplitRanges; };
+    auto tile_of = [&](int k) { return static_cast<int64_t>(range) + static_cast<int64_t>(k) * RANGES; };
 
     if (wave >= 4) {
         // ---------------- service waves: thread -> hyperedge row, member columns 4 o .. and 64 + 4 o ..; epilogue: output columns 4 o .. of the half
         const int st = tid - 256, row = st >> 4, o = st & 15;
         const int64_t last_pos = n_edges * 3 - 1;
         auto fetch_id = [&](int k) { return i3[std::min<int64_t>(tile_of(k) * (3 * TE) + st, last_pos)]; };           // (st < 48)
-        auto load_members = [&](int k, v4f (&hm)[2][3]) {
+        auto load_members = [&](int k, v4f (&hm)[ZX][3]) {
             const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + 4 * o;
-                hm[0][m] = *reinterpret_cast<const v4f*>(hp);
-                hm[1][m] = *reinterpret_cast<const v4f*>(hp + 64);
+#pragma unroll
+                for (int x = 0; x < ZX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + 64 * x);
             }
         };
         auto load_first_order = [&](int k, v4f (&pr)[3]) {
@@ -402,10 +404,10 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
 #pragma unroll
             for (int m = 0; m < 3; ++m) pr[m] = *reinterpret_cast<const v4f*>(p + static_cast<int64_t>(idk[m]) * ld_p + HC * half + 4 * o);
         };
-        auto split_tile = [&](const v4f (&hm)[2][3], int buf) {
+        auto split_tile = [&](const v4f (&hm)[ZX][3], int buf) {
             typedef unsigned v2u __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
+            for (int x = 0; x < ZX; ++x) {
                 const v4f u = hm[x][0], q = hm[x][1], it = hm[x][2];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -420,8 +422,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
                         (hp2 == 0 ? w0 : w1)[1] = pack_hi(ra, rb);
                         (hp2 == 0 ? w0 : w1)[2] = pack_hi(la, lb);
                     }
-                    // columns b * 128 + 64 x + 4 o ..: chunk 16 b + 8 x + (o >> 1), half o & 1
-                    const int off = row * ZRB + (((16 * b + 8 * x + (o >> 1)) ^ row) << 4) + 8 * (o & 1);
+                    // columns b D + 64 x + 4 o ..: chunk b D / 8 + 8 x + (o >> 1), half o & 1
+                    const int off = row * ZRB + ((((D / 8) * b + 8 * x + (o >> 1)) ^ row) << 4) + 8 * (o & 1);
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + pl * ZPL + off) = v2u{w0[pl], w1[pl]};
                 }
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
             if (n_my > 3) ids[3][st] = fetch_id(3);
         }
         __syncthreads();
-        v4f hm0[2][3], hm1[2][3], pr0[3], pr1[3];                        // member values of tile m in hm<m & 1>, first-order rows in pr<m & 1>
+        v4f hm0[ZX][3], hm1[ZX][3], pr0[3], pr1[3];                        // member values of tile m in hm<m & 1>, first-order rows in pr<m & 1>
         load_members(0, hm0);
         if (n_my > 1) load_members(1, hm1);
         split_tile(hm0, 0);
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
         int id_carry = 0;
         // phase k: products of tile k + 1 (`use`) into the images; sums, first-order rows and store of tile k - 1; requests: member values of
         // tile k + 2 (`fill`), first-order rows of tile k, ids of tile k + 4 (they reach the ring in the next phase and are first read in the one after)
-        auto phase = [&](int k, v4f (&use)[2][3], v4f (&fill)[2][3], v4f (&pr_cur)[3], v4f (&pr_prev)[3]) {
+        auto phase = [&](int k, v4f (&use)[ZX][3], v4f (&fill)[ZX][3], v4f (&pr_cur)[3], v4f (&pr_prev)[3]) {
             if (k >= 1 && k + 3 < n_my && st < 3 * TE) ids[(k + 3) & 7][st] = id_carry;
             if (k + 2 < n_my) load_members(k + 2, fill);
             if (k < n_my) load_first_order(k, pr_cur);
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
             // delivery of this phase's requests, THEN the store: the memory counter is in order, a wait behind the store would sit out its
             // round trip to memory in every phase (measured: 2.07 ms instead of 0.9 for this kernel)
-            asm volatile("" : "+v"(fill[0][0]), "+v"(fill[0][1]), "+v"(fill[0][2]), "+v"(fill[1][0]), "+v"(fill[1][1]), "+v"(fill[1][2]));
+            asm volatile("" : "+v"(fill[ZX - 1][0]), "+v"(fill[ZX - 1][1]), "+v"(fill[ZX - 1][2]));      // (in order: the last delivered = all delivered)
             asm volatile("" : "+v"(pr_cur[0]), "+v"(pr_cur[1]), "+v"(pr_cur[2]));
             if (k >= 1) epilogue(k, pr_prev);
             __syncthreads();
@@ -473,14 +475,14 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
 
     // ---------------- matrix waves: wave = product block; weight planes of the half's 64 output columns x the block's 128 contraction values
     const int blk = wave;
-    v8s wreg[4][4][3];
+    v8s wreg[4][KB][3];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)      // the packing is [half][2 b + (kb >> 1)][jt][kb & 1][plane] (see pack_planes_fwd_kernel)
-                wreg[jt][kb][pl] = __builtin_bit_cast(v8s, wsp[(static_cast<int64_t>((half * 8 + 2 * blk + (kb >> 1)) * 24) + (jt * 2 + (kb & 1)) * 3 + pl) * kWave + lane]);
+            for (int pl = 0; pl < 3; ++pl)
+                wreg[jt][kb][pl] = __builtin_bit_cast(v8s, wsp[(static_cast<int64_t>(((half * 4 + blk) * 4 + jt) * KB + kb) * 3 + pl) * kWave + lane]);
     __syncthreads();
     __syncthreads();
     const int arow = lane & 15, kq = lane >> 4;
@@ -490,13 +492,13 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) acc[jt] = v4f{0.f, 0.f, 0.f, 0.f};
             const unsigned char* zp = &zplanes[k & 1][0][0][0] + arow * ZRB;
-            v8s zf[4][3];
+            v8s zf[KB][3];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) zf[kb][pl] = *reinterpret_cast<const v8s*>(zp + pl * ZPL + (((16 * blk + 4 * kb + kq) ^ arow) << 4));
+                for (int pl = 0; pl < 3; ++pl) zf[kb][pl] = *reinterpret_cast<const v8s*>(zp + pl * ZPL + ((((D / 8) * blk + 4 * kb + kq) ^ arow) << 4));
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
 #pragma unroll
@@ -1114,14 +1116,17 @@ int launch_weight_split(int dim, const float* h, int64_t ld_h, const int32_t* i3
 }
 
 bool split_fwd_ok(int dim, int order, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h) {
-    return split_arith_enabled() && dim == 128 && order == 3 && p != nullptr && ld_p % 4 == 0 && ld_out % 4 == 0 && aligned16(p) && aligned16(out) && ld_h % 4 == 0;
+    return split_arith_enabled() && (dim == 64 || dim == 128) && order == 3 && p != nullptr && ld_p % 4 == 0 && ld_out % 4 == 0 && aligned16(p) && aligned16(out) &&
+           ld_h % 4 == 0;
 }
 
-void launch_fwd_split(const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes, float* out,
+void launch_fwd_split(int dim, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes, float* out,
                       int64_t ld_out, int64_t n_edges, hipStream_t s) {
     v4u* wsp = static_cast<v4u*>(planes);
-    hipLaunchKernelGGL(pack_planes_fwd_kernel, dim3(2 * 8 * 4 * 2 * kWave / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, wsp);
-    hipLaunchKernelGGL(interact_fwd_split_ws_kernel, dim3(2 * kSplitRanges), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
+    const int items = (dim / 64) * 4 * 4 * (dim / 32) * kWave;
+    hipLaunchKernelGGL(pack_planes_fwd_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, wsp);
+    if (dim == 64) hipLaunchKernelGGL(interact_fwd_split_ws_kernel<64>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
+    else hipLaunchKernelGGL(interact_fwd_split_ws_kernel<128>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
 }
 
 bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x) {
