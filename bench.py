@@ -53,9 +53,13 @@ MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md); the split arithmetic spends six bf16 products per fp32 multiply
 
 
-def split_arithmetic(dim, order):
-    """True when the library runs this shape's contractions through three exact bf16 terms per operand (csrc/split_arith.hip)."""
-    return dim == 128 and order == 3 and os.environ.get('IHG_INTERACT_ARITH') != 'f32'
+def split_arithmetic(dim, order, direction='any'):
+    """True when the library runs this shape's contractions through three exact bf16 terms per operand (csrc/split_arith.hip):
+    order 3; forward at d = 64 / 128, member and weight gradients at d = 64 / 128 / 256."""
+    if order != 3 or os.environ.get('IHG_INTERACT_ARITH') == 'f32':
+        return False
+    dims = {'forward': (64, 128), 'backward': (64, 128, 256), 'any': (64, 128, 256)}[direction]
+    return dim in dims
 
 
 def parse():
@@ -419,20 +423,20 @@ def main():
         flops_fwd = 2.0 * m_blocks * dim * dim * E
         f, bw = table['interact_fwd'], table['interact_bwd']
         bwd_us = bw['avg_us'] * bw['launches'] / table_steps        # the backward may run in several hyperedge chunks
-        split = split_arithmetic(dim, args.order)
-        peak = MFMA_BF16_PEAK_TF / 6 if split else MFMA_F32_PEAK_TF
-        mfma_roof = dict(bound='mfma', kernel='interact_fwd + interact_bwd (order-%d product blocks of layer 0)' % args.order,
-                         peak=round(peak, 1), unit='TFLOP/s',
-                         dtype=('f32 operands taken apart exactly into three bf16 terms, six v_mfma_f32_16x16x32_bf16 products per multiply, f32 accumulate: '
-                                'peak = dense bf16 MFMA peak / 6, flops counted as fp32 multiply-adds') if split else
-                               'f32 in / f32 accumulate (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)',
-                         f32_mfma_peak=MFMA_F32_PEAK_TF,
-                         forward=dict(achieved=round(flops_fwd / (f['avg_us'] * 1e-6) / 1e12, 1), frac=round(flops_fwd / (f['avg_us'] * 1e-6) / (peak * 1e12), 4),
-                                      vs_f32_mfma_peak=round(flops_fwd / (f['avg_us'] * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 3),
-                                      flops_per_launch=flops_fwd, avg_us=round(f['avg_us'], 2)),
-                         backward=dict(achieved=round(2 * flops_fwd / (bwd_us * 1e-6) / 1e12, 1), frac=round(2 * flops_fwd / (bwd_us * 1e-6) / (peak * 1e12), 4),
-                                       vs_f32_mfma_peak=round(2 * flops_fwd / (bwd_us * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 3),
-                                       flops_per_step=2 * flops_fwd, us_per_step=round(bwd_us, 2)),
+        split_dtype = ('f32 operands taken apart exactly into three bf16 terms, six v_mfma_f32_16x16x32_bf16 products per multiply, f32 accumulate: '
+                       'peak = dense bf16 MFMA peak / 6, flops counted as fp32 multiply-adds')
+        f32_dtype = 'f32 in / f32 accumulate (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)'
+
+        def direction(name, flops, us, extra):
+            split = split_arithmetic(dim, args.order, name)
+            peak = MFMA_BF16_PEAK_TF / 6 if split else MFMA_F32_PEAK_TF
+            return dict(achieved=round(flops / (us * 1e-6) / 1e12, 1), peak=round(peak, 1), frac=round(flops / (us * 1e-6) / (peak * 1e12), 4),
+                        dtype=split_dtype if split else f32_dtype, vs_f32_mfma_peak=round(flops / (us * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 3), **extra)
+
+        mfma_roof = dict(bound='mfma', kernel='interact_fwd + interact_bwd (order-%d product blocks of layer 0)' % args.order, unit='TFLOP/s',
+                         f32_mfma_peak=MFMA_F32_PEAK_TF, split_peak=round(MFMA_BF16_PEAK_TF / 6, 1),
+                         forward=direction('forward', flops_fwd, f['avg_us'], dict(flops_per_launch=flops_fwd, avg_us=round(f['avg_us'], 2))),
+                         backward=direction('backward', 2 * flops_fwd, bwd_us, dict(flops_per_step=2 * flops_fwd, us_per_step=round(bwd_us, 2))),
                          share_of_step=round((f['avg_us'] + bwd_us) * 1e-3 / (1e3 * elapsed / args.steps), 3),
                          measured='instrumented pass after the timed region (every launch bracketed)')
     out = {
@@ -445,9 +449,10 @@ def main():
                    'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd + Adam' +
                            (f' + RCCL gradient exchange ({args.sync})' if world > 1 else ''),
                    'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
-                   'arithmetic': ('f32 results; the d = 128 / order 3 contractions and node-level row GEMMs multiply through three exact bf16 terms per '
-                                  'operand (six bf16 MFMA products, f32 accumulation; error <= the fp32-MFMA kernels\' - tests/test_gpu_parity.py); '
-                                  'IHG_INTERACT_ARITH=f32 selects the fp32-MFMA kernels') if split_arithmetic(dim, args.order) else 'f32 (fp32 MFMA / VALU)'},
+                   'arithmetic': ('f32 results; the order-3 contractions (forward at d = 64 / 128, member and weight gradients at d = 64 / 128 / 256) and the '
+                                  'node-level linear maps at d = 128 / 256 multiply through three exact bf16 terms per operand (six bf16 MFMA products, f32 '
+                                  'accumulation; error <= the fp32-MFMA kernels\' - tests/test_gpu_parity.py); IHG_INTERACT_ARITH=f32 selects the fp32-MFMA kernels')
+                                 if split_arithmetic(dim, args.order) else 'f32 (fp32 MFMA / VALU)'},
         'final_loss': round(final_loss, 6),
         'roofline': roofline,
         'roofline_hyperedge_to_node': k7_roles(table, E, N, dim, layout, table_steps) or None,

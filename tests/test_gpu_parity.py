@@ -374,24 +374,28 @@ def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, monkey
 
 @pytest.mark.parametrize('which', ['forward_backward', 'persistent', 'user_slot'])
 def test_interact_fp32_mfma_kernels_stay_covered(which, monkeypatch):
-    """d = 128, order 3 runs on the bf16-split kernels by default; IHG_INTERACT_ARITH=f32 (read by the library at every call) selects
-    the fp32-MFMA strip kernels, which must keep passing the same cases."""
+    """Order 3 at d = 64 / 128 / 256 runs on the bf16-split kernels by default; IHG_INTERACT_ARITH=f32 (read by the library at every call)
+    selects the fp32-MFMA kernels, which must keep passing the same cases."""
     monkeypatch.setenv('IHG_INTERACT_ARITH', 'f32')
     if which == 'forward_backward':
-        test_interact_forward_backward(128, 3)
+        for dim in (64, 128, 256):
+            test_interact_forward_backward(dim, 3)
     elif which == 'persistent':
         test_interact_persistent_tiles_and_strided_rows(128, 3, 1100 * 64 + 37)
+        test_interact_persistent_tiles_and_strided_rows(64, 3, 3 * 256 * 64 + 37)
+        test_interact_persistent_tiles_and_strided_rows(256, 3, 1100 * 64 + 37)
     else:
         test_interact_backward_user_slot_reduced_on_chip(3, 700 * 32 + 5, 301, monkeypatch)
 
 
-def test_split_arithmetic_is_as_accurate_as_fp32_mfma(monkeypatch):
-    """The d = 128 / order 3 contractions through three exact bf16 terms per operand (six bf16 MFMA products, fp32 accumulation) against
-    the same op in float64: the error must not exceed the fp32-MFMA kernels' own (both are far inside the 1e-5 bar).  Also the
-    node-level row GEMM, which takes the same arithmetic."""
+@pytest.mark.parametrize('dim', [64, 128, 256])
+def test_split_arithmetic_is_as_accurate_as_fp32_mfma(dim, monkeypatch):
+    """The order-3 contractions through three exact bf16 terms per operand (six bf16 MFMA products, fp32 accumulation; forward at d = 64 / 128,
+    member and weight gradients at d = 64 / 128 / 256) against the same op in float64: the error must not exceed the fp32-MFMA kernels' own
+    (both are far inside the 1e-5 bar).  Also the node-level linear map, which takes the same arithmetic at d = 128 / 256."""
     from ihgnn_amd import ops
     from oracle import ihgnn_ref as ref
-    dim, order, U, Q, I, E = 128, 3, 301, 17, 211, 9000
+    order, U, Q, I, E = 3, 301, 17, 211, 9000
     w_, lay = make_layout(U, Q, I, E, seed=5, edge_order='user')
     gen = torch.Generator().manual_seed(11)
     h = torch.randn(lay.node_count, dim, generator=gen)
