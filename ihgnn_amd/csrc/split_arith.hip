@@ -1,5 +1,5 @@
-// split_arith.hip - contractions of the d = 128 path (interactive step, order 3; node-level linear maps) on the bf16 matrix pipe at
-// fp32 accuracy.
+// split_arith.hip - contractions of the order-3 interactive step (d = 64, 128, 256) and of the node-level linear maps (d = 128, 256) on
+// the bf16 matrix pipe at fp32 accuracy.
 //
 // Every fp32 operand x is taken apart EXACTLY into three bf16 terms, x = hi + mid + lo (hi = the top 16 bits of x, mid = the top
 // 16 bits of x - hi, lo = the rest: 8 + 8 + 8 significand bits, both subtractions exact), and a product a b is accumulated in fp32
@@ -9,9 +9,11 @@
 // the same 1e-5 bar, tools/split_probe.hip has the standalone rate measurement): v_mfma_f32_16x16x32_bf16 runs 16 x the rate of
 // v_mfma_f32_16x16x4_f32, six of them replace eight -> the same contraction in ~ 0.4 of the matrix-pipe time.
 //
-// Three bf16 planes of the weights are 1.5 x their fp32 size: 384 KB, more than one workgroup's registers can keep beside the
-// accumulators.  So a workgroup owns HALF of one index (output columns, or the contraction index); the two halves of one tile range
-// sit on one XCD (workgroups are dealt to XCDs round-robin by their linear id), so the second read of a streamed row hits that L2.
+// Three bf16 planes of the weights are 1.5 x their fp32 size: 384 KB at d = 128, more than one workgroup's registers can keep beside
+// the accumulators.  So a workgroup owns a PART of the columns (a half at d = 128, an eighth at d = 256, all of them at d = 64); the
+// parts of one tile range sit on one XCD (workgroups are dealt to XCDs round-robin by their linear id), so the later reads of a
+// streamed row hit that L2.  The waves of a workgroup have two jobs, one of each per SIMD: matrix waves 0-3 only read fragments and
+// issue MFMAs, service waves 4-7 request, split, apply the element-wise part and store.
 // What bounds these kernels is not the matrix pipe but the vector instructions of the split (5.5 per element) and of forming the
 // products: the pipe is 0.4-0.5 busy (DESIGN.md section 4 has the ladder, the probes and the counters).
 #include <cstdlib>
@@ -26,7 +28,7 @@ typedef short v8s __attribute__((ext_vector_type(8)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int kSplitTE = 32;            // hyperedges per tile
-constexpr int kSplitRanges = 128;       // contiguous tile ranges (x 2 column halves = 256 workgroups, one per CU)
+constexpr int kSplitRanges = 128;       // contiguous tile ranges at d = 128 (x 2 column halves = 256 workgroups, one per CU)
 constexpr int kSplitThreads = 512;
 
 __device__ __forceinline__ unsigned pack_hi(float a, float b) {          // {top half of b, top half of a}
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             }
         };
         // UR: service wave w scans columns 16 w .. 16 w + 15 of the half (lane & 15; the other lanes repeat them) of the tile whose product
-        // rule ran a phase ago, carrying (user, destination, running sums) from tile to tile; see the kernel above for the scheme
+        // rule ran a phase ago, carrying (user, destination, running sums) from tile to tile (scheme: the comment at the head of this kernel)
         int cur_user = -1, first_user = -1;
         float run_sum = 0.f, carry_prev = 0.f;
         float* const first_slot = UR ? bnd_val + static_cast<int64_t>(2 * range) * D : nullptr;
