@@ -372,6 +372,31 @@ def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, monkey
     assert bool((grads[True][0][:users][isolated.to(dev())] == 0).all())
 
 
+@pytest.mark.parametrize('dim', [64, 128, 256])
+@pytest.mark.parametrize('edges', [1, 15, 33])
+def test_interact_split_kernels_on_tiny_hypergraphs(dim, edges):
+    """Fewer hyperedges than one tile / one tile and a bit: most workgroups of the split kernels have no tile at all, the first has a
+    partial one (rows past the end must contribute nothing to the weight gradient and must not be stored)."""
+    from ihgnn_amd import ops
+    from oracle import ihgnn_ref as ref
+    U, Q, I = 7, 3, 5
+    w_, lay = make_layout(U, Q, I, edges, seed=dim + edges, edge_order='user')
+    gen = torch.Generator().manual_seed(dim + edges)
+    h = torch.randn(lay.node_count, dim, generator=gen)
+    w = torch.randn(dim, 7 * dim, generator=gen) / np.sqrt(7 * dim)
+    b = torch.randn(dim, generator=gen)
+    cot = torch.randn(lay.edge_count, dim, generator=gen)
+    hc, wc = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    want = ref.feature_interactor(hc, torch.from_numpy(lay.i3_host.astype(np.int64)), wc, b, 3)
+    want.backward(cot)
+    hg, wg = h.clone().to(dev()).requires_grad_(True), w.clone().to(dev()).requires_grad_(True)
+    first = torch.cat([torch.nn.functional.linear(hg[:U], wg[:, :dim], b.to(dev())), torch.nn.functional.linear(hg[U:U + Q], wg[:, dim:2 * dim]),
+                       torch.nn.functional.linear(hg[U + Q:], wg[:, 2 * dim:3 * dim])])
+    got = ops.interact(hg, first, wg, lay, 3)
+    got.backward(cot.to(dev()))
+    assert rel(got, want) <= RTOL and rel(hg.grad, hc.grad) <= RTOL and rel(wg.grad, wc.grad) <= RTOL
+
+
 @pytest.mark.parametrize('which', ['forward_backward', 'persistent', 'user_slot'])
 def test_interact_fp32_mfma_kernels_stay_covered(which, monkeypatch):
     """Order 3 at d = 64 / 128 / 256 runs on the bf16-split kernels by default; IHG_INTERACT_ARITH=f32 (read by the library at every call)
