@@ -514,6 +514,213 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward at d = 256 (the kernel is written for d = 128 as well, where the resident-weights form above is faster), without eightfold product work: the contraction index is walked in CHUNKS of 128 (one product block, or
+// half of one at d = 256), one chunk per phase.  The matrix waves own the OUTPUT - wave m: 32 columns x the tile's 32 hyperedges,
+// accumulators kept across the chunks - and do not keep the weights: the 24 weight fragments of the next chunk (24 KB per wave, the planes
+// are L2-resident: 0.4 / 1.5 MB) are requested while the current chunk's 96 MFMAs run.  The service waves keep one hyperedge's member values
+// (16 columns x 3 per thread, the next set requested a set ahead) and lay down each chunk's products as bf16 images a phase ahead; every
+// product is formed and split exactly once per 128 output columns (d = 128: once; d = 256: once per column half).  The finished tile
+// goes through an LDS image at the start of the next tile; the service waves add the first-order rows and store it during the following
+// three phases.  One barrier per phase.
+// wck[half][m][c][jt][kb][plane][lane][8]: element i = plane of W[128 half + 32 m + 16 jt + (lane & 15)][(3 + b) D + 128 cp + 32 kb + 8 (lane >> 4) + i],
+// chunk c = 4 cp + b (the four blocks of one column part are consecutive: they share the member values)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_fwd_chunk_kernel(const float* __restrict__ w, int64_t ld_w, int d, v4u* __restrict__ wck) {
+    const int jh = d / 128, nch = 4 * jh;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= jh * 4 * nch * 2 * 4 * kWave) return;
+    const int lane = idx & 63, kb = (idx >> 6) & 3, jt = (idx >> 8) & 1, c = (idx >> 9) % nch, m = ((idx >> 9) / nch) & 3, half = (idx >> 9) / (nch * 4);
+    const int b = c & 3, cp = c >> 2;
+    const float* src = w + static_cast<int64_t>(128 * half + 32 * m + 16 * jt + (lane & 15)) * ld_w + (3 + b) * d + 128 * cp + 32 * kb + 8 * (lane >> 4);
+    const Planes pl = split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]});
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wck[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
+}
+
+template <int D>
+__global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_chunk_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p,
+                                                                                 const int32_t* __restrict__ i3, const v4u* __restrict__ wck, float* __restrict__ out,
+                                                                                 int64_t ld_out, int64_t n_edges) {
+    constexpr int TE = kSplitTE, JH = D / 128, NCH = 4 * JH, NSEQ = 256 / JH, OS = 128 + 4, ZPL = TE * 256;
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][256];
+    __shared__ __attribute__((aligned(16))) float oimg[TE][OS];
+    __shared__ int ids[4][3 * TE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int half = (bid >> 3) & (JH - 1), seq = (bid & 7) + 8 * (bid / (8 * JH));
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int n_my = seq < n_tiles ? static_cast<int>((n_tiles - seq + NSEQ - 1) / NSEQ) : 0;   // tiles seq, seq + NSEQ, ...
+    if (n_my == 0) return;
+    auto tile_of = [&](int k) { return static_cast<int64_t>(seq) + static_cast<int64_t>(k) * NSEQ; };
+    const int n_phases = (n_my + 1) * NCH;                               // the last tile leaves during one more (empty) tile's worth of phases
+
+    if (wave >= 4) {
+        // ---------------- service waves: thread -> hyperedge row, 16 columns of a 128-column part
+        const int st = tid - 256, row = st >> 3, cq = st & 7;
+        const int64_t last_pos = n_edges * 3 - 1;
+        auto fetch_id = [&](int k) { return i3[std::min<int64_t>(tile_of(k) * (3 * TE) + st, last_pos)]; };           // (st < 96)
+        auto load_members = [&](int k, int cp, v4f (&hm)[3][4]) {        // member values of tile k, column part cp
+            const int* idk = ids[k & 3] + row * 3;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + 128 * cp + 16 * cq;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) hm[m][x] = *reinterpret_cast<const v4f*>(hp + 4 * x);
+            }
+        };
+        auto load_first_order = [&](int k, v4f (&pr)[3][4]) {
+            const int* idk = ids[k & 3] + row * 3;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float* pp = p + static_cast<int64_t>(idk[m]) * ld_p + 128 * half + 16 * cq;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) pr[m][x] = *reinterpret_cast<const v4f*>(pp + 4 * x);
+            }
+        };
+        // products of block b from a member set -> the 16 columns' three planes into image `buf` (two 16-byte chunks per plane)
+        auto split_chunk = [&](const v4f (&hm)[3][4], int b, int buf) {
+            unsigned char* zrow = &zplanes[buf][0][row][0];
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2) {
+                v4f z[2];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    const v4f u = hm[0][2 * x2 + y], q = hm[1][2 * x2 + y], it = hm[2][2 * x2 + y];
+                    z[y] = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
+                }
+                const Planes pl = split8(z[0], z[1]);
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<v4u*>(zrow + pp * ZPL + (((2 * cq + x2) ^ (row & 15)) << 4)) = pl.p[pp];
+            }
+        };
+        if (st < 3 * TE) {
+            ids[0][st] = fetch_id(0);
+            if (n_my > 1) ids[1][st] = fetch_id(1);
+            if (n_my > 2) ids[2][st] = fetch_id(2);
+        }
+        __syncthreads();
+        v4f ms0[3][4], ms1[3][4], pr[3][4];                              // member sets: set s = k JH + cp lives in ms<s & 1>; first-order rows of the leaving tile
+        load_members(0, 0, ms0);
+        split_chunk(ms0, 0, 0);
+        __syncthreads();
+        int id_carry = 0;
+        // phase g = k NCH + c: image of chunk g + 1; requests at the first phase of a set: the next set; at the first phase of a tile: the
+        // first-order rows of the tile that just finished and the ids two tiles ahead; parts of that tile's store in phases 1 .. 3
+        auto phase = [&](int g, v4f (&cur)[3][4], v4f (&nxt)[3][4], bool first_of_set) {
+            const int k = g / NCH, c = g % NCH;
+            if (c == 0) {
+                if (k >= 1 && k + 2 < n_my && st < 3 * TE) ids[(k + 2) & 3][st] = id_carry;
+                if (k + 3 < n_my && st < 3 * TE) id_carry = fetch_id(k + 3);
+                if (k >= 1) load_first_order(k - 1, pr);
+            }
+            if (first_of_set) {                                          // the set after this one: tile / column part of chunk g + 4
+                const int g4 = g + 4;
+                if (g4 / NCH < n_my) load_members(g4 / NCH, (g4 % NCH) >> 2, nxt);
+            }
+            {                                                            // chunk g + 1 belongs to set (g + 1) / 4: `cur`, or `nxt` at the set's last phase
+                const int g1 = g + 1;
+                if (g1 / NCH < n_my) {
+                    if ((g1 & 3) == 0) split_chunk(nxt, 0, g1 & 1);
+                    else split_chunk(cur, g1 & 3, g1 & 1);
+                }
+            }
+            if (first_of_set) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) asm volatile("" : "+v"(nxt[m][0]), "+v"(nxt[m][1]), "+v"(nxt[m][2]), "+v"(nxt[m][3]));
+            }
+            if (c == 0 && k >= 1) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) asm volatile("" : "+v"(pr[m][0]), "+v"(pr[m][1]), "+v"(pr[m][2]), "+v"(pr[m][3]));
+            }
+            if (k >= 1 && c >= 1 && c <= 3) {                            // store of tile k - 1: its 16 columns in parts of 8, 4, 4
+                const int64_t e = tile_of(k - 1) * TE + row;
+                const int x0 = c == 1 ? 0 : c, x1 = c == 1 ? 2 : c + 1;
+                if (e < n_edges) {
+                    for (int x = x0; x < x1; ++x) {
+                        const v4f sum = *reinterpret_cast<const v4f*>(&oimg[row][16 * cq + 4 * x]);
+                        const v4f first = (pr[0][x] + pr[1][x]) + pr[2][x];
+                        store_stream4(out + e * ld_out + 128 * half + 16 * cq + 4 * x, sum + first);
+                    }
+                }
+            }
+            __syncthreads();
+        };
+        // a set spans four phases; sets alternate between ms0 and ms1
+        for (int g = 0; g < n_phases; g += 8) {
+#pragma unroll
+            for (int u8 = 0; u8 < 8; ++u8) {
+                if (g + u8 >= n_phases) break;
+                if (u8 < 4) phase(g + u8, ms0, ms1, u8 == 0);
+                else phase(g + u8, ms1, ms0, u8 == 4);
+            }
+        }
+        return;
+    }
+
+    // ---------------- matrix waves: wave m = output columns 32 m .. 32 m + 31 of the half, both 16-row tiles
+    const v4u* wbase = wck + static_cast<int64_t>((half * 4 + wave) * NCH) * 24 * kWave + lane;
+    auto load_w = [&](int c, v8s (&wr)[2][4][3]) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wr[jt][kb][pl] = __builtin_bit_cast(v8s, wbase[(static_cast<int64_t>(c) * 24 + (jt * 4 + kb) * 3 + pl) * kWave]);
+    };
+    v8s w0[2][4][3], w1[2][4][3];                                        // weight fragments of chunk g live in w<g & 1>
+    load_w(0, w0);
+    __syncthreads();
+    __syncthreads();
+    const int arow = lane & 15, kq = lane >> 4;
+    v4f acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
+    auto mphase = [&](int g, v8s (&wc)[2][4][3], v8s (&wn)[2][4][3]) {
+        const int k = g / NCH, c = g % NCH;
+        if (c == 0 && k >= 1) {                                          // the finished tile leaves through the image
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    *reinterpret_cast<v4f*>(&oimg[16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
+                    acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        if (k < n_my) {
+            if (g + 1 < n_my * NCH) load_w((g + 1) % NCH, wn);
+            const unsigned char* zp = &zplanes[g & 1][0][0][0];
+            auto fragment = [&](int step, v8s (&zf)[3]) {                // step = (kb, rt)
+                const int kb = step >> 1, rt = step & 1;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) zf[pl] = *reinterpret_cast<const v8s*>(zp + pl * ZPL + (16 * rt + arow) * 256 + (((4 * kb + kq) ^ arow) << 4));
+            };
+            v8s zf[3], zn[3];
+            fragment(0, zf);
+#pragma unroll
+            for (int step = 0; step < 8; ++step) {
+                const int kb = step >> 1, rt = step & 1;
+                if (step + 1 < 8) fragment(step + 1, zn);
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int jt = 0; jt < 2; ++jt)
+                        acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[jt][kb][kTermB[term]], zf[kTermA[term]], acc[rt][jt], 0, 0, 0);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) zf[pl] = zn[pl];
+            }
+        }
+        __syncthreads();
+    };
+    for (int g = 0; g < n_phases; g += 2) {
+        mphase(g, w0, w1);
+        if (g + 1 < n_phases) mphase(g + 1, w1, w0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Weight gradients dW_b[j][c] = sum_e dout[e][j] z_b[e][c].  The contraction runs over the hyperedges, both operands are streams:
 // per tile of 32 hyperedges (one MFMA k-block) the dout values and the products z_b of a column HALF (the two halves of a tile range
 // are two workgroups on one XCD) are split and laid down as bf16 images, ROW-major
@@ -1118,17 +1325,26 @@ int launch_weight_split(int dim, const float* h, int64_t ld_h, const int32_t* i3
 }
 
 bool split_fwd_ok(int dim, int order, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h) {
-    return split_arith_enabled() && (dim == 64 || dim == 128) && order == 3 && p != nullptr && ld_p % 4 == 0 && ld_out % 4 == 0 && aligned16(p) && aligned16(out) &&
-           ld_h % 4 == 0;
+    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && order == 3 && p != nullptr && ld_p % 4 == 0 && ld_out % 4 == 0 && aligned16(p) &&
+           aligned16(out) && ld_h % 4 == 0;
 }
 
 void launch_fwd_split(int dim, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes, float* out,
                       int64_t ld_out, int64_t n_edges, hipStream_t s) {
     v4u* wsp = static_cast<v4u*>(planes);
-    const int items = (dim / 64) * 4 * 4 * (dim / 32) * kWave;
-    hipLaunchKernelGGL(pack_planes_fwd_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, wsp);
-    if (dim == 64) hipLaunchKernelGGL(interact_fwd_split_ws_kernel<64>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
-    else hipLaunchKernelGGL(interact_fwd_split_ws_kernel<128>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
+    // d = 256: chunked (the eight-part column split of the other form would repeat the product work eight times); d = 64 / 128: weights
+    // resident.  At d = 128 the chunked form measured 2,430 us against 2,000: with 32-hyperedge tiles its weight stream (393 KB per tile)
+    // alone fills the CU's L2 port for 0.8 ms.
+    if (dim != 256) {
+        const int items = (dim / 64) * 4 * 4 * (dim / 32) * kWave;
+        hipLaunchKernelGGL(pack_planes_fwd_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, wsp);
+        if (dim == 64) hipLaunchKernelGGL(interact_fwd_split_ws_kernel<64>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
+        else hipLaunchKernelGGL(interact_fwd_split_ws_kernel<128>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
+        return;
+    }
+    const int items = (dim / 128) * 4 * (4 * dim / 128) * 2 * 4 * kWave;
+    hipLaunchKernelGGL(pack_planes_fwd_chunk_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, wsp);
+    hipLaunchKernelGGL(interact_fwd_split_chunk_kernel<256>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
 }
 
 bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x) {
