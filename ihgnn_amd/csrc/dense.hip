@@ -712,8 +712,11 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     // weights of type t are the column block t of w exactly as for dw: w_type_stride == dw_type_stride
     int n_slabs = kDenseSlabs;
     if (split_dense_weight_ok(dim, dout, ld_dout, x, ld_x)) {             // bf16-split contraction (d = 128, 256); the input gradient stays a row-GEMM launch
-        if (dx != nullptr) launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace), s);
-        n_slabs = launch_dense_weight_split(dim, dout, ld_dout, x, ld_x, type_begin, n_types, slabs, bias_slabs, s);
+        const bool fused_dx = dx != nullptr && dim == 128 && aligned16(dx) && ld_dx % 4 == 0;
+        if (dx != nullptr && !fused_dx) launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace), s);
+        void* planes = static_cast<float*>(workspace) + 3LL * dim * dim + 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
+        n_slabs = launch_dense_weight_split(dim, dout, ld_dout, x, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, fused_dx ? dx : nullptr, ld_dx,
+                                            planes, s);
     } else if (dim == 64 && dx != nullptr) {
         hipLaunchKernelGGL((dense_weight_grad_kernel<64, true>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
                            n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, w, ld_w, dw_type_stride, dx, ld_dx, dx_accumulate);

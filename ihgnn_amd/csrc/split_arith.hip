@@ -1077,10 +1077,15 @@ __global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(c
 // (wave = 2 x 4 accumulator tiles); D = 256: a workgroup owns a column half (wave = 4 x 4 tiles), both halves of a tile sequence on
 // one XCD.  The column sums of dout ride along in the staging threads' registers.  grid = (sequences x halves, 1, node types).
 // ------------------------------------------------------------------------------------------------
-template <int D>
+// DX (d = 128): the input gradient dx = dout W_t of the same rows is formed here too - the dout images are in LDS anyway (the transposed-read
+// layout also serves row reads), wave w takes output columns 16 w .. with the type's weight planes in 48 registers - and the separate row-GEMM
+// pass over dout goes away.
+template <int D, bool DX>
 __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(const float* __restrict__ dout, int64_t ld_dout, const float* __restrict__ x,
                                                                                 int64_t ld_x, RowTiles plan, int single_weight, float* __restrict__ slabs,
-                                                                                float* __restrict__ bias_slabs) {
+                                                                                float* __restrict__ bias_slabs, const v4u* __restrict__ pk, int64_t pk_type_stride,
+                                                                                float* __restrict__ dx, int64_t ld_dx) {
+    static_assert(!DX || D == 128, "the fused input gradient holds a whole weight matrix per workgroup");
     constexpr int TE = 32, HALVES = D / 128, DOCT = D / 128, IT = D / 64, DRB = 2 * D;     // dout image rows: 2 D bytes, x image rows: 256 bytes (128 columns)
     constexpr int DPL = TE * DRB, XPL = TE * 256;
     __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][DRB];
@@ -1163,6 +1168,14 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 
         const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
         const int rlo = 8 * g + q, rhi = rlo + 4;
+        v8s wdx[DX ? 4 : 1][3];                                          // DX: planes of W_t[32 kb + 8 (lane >> 4) + i][16 wave + (lane & 15)]
+        if (DX) {
+            const v4u* wf = pk + (single_weight ? 0 : type) * pk_type_stride + static_cast<int64_t>(wave) * 12 * kWave + lane;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wdx[kb][p] = __builtin_bit_cast(v8s, wf[(kb * 3 + p) * kWave]);
+        }
         // dout columns (output rows i): tile IT iq + it -> byte 32 (IT iq + it) + 8 pp of a DRB-byte row, 256-byte segments swizzled separately
         auto a_addr = [&](int r, int it) {
             const int tile = IT * iq + it, seg = tile >> 3, ch = 2 * (tile & 7) + (pp >> 1);
@@ -1203,8 +1216,35 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 #pragma unroll
                 for (int p = 0; p < 3; ++p) b[p] = bn[p];
             }
+            v4f gx[2];
+            if (DX) {                                                    // row reads of the same dout images: chunk 4 kb + (lane >> 4) of row 16 rt + (lane & 15)
+                const int arow = lane & 15, kq = lane >> 4;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    gx[rt] = v4f{0.f, 0.f, 0.f, 0.f};
+                    const int r = 16 * rt + arow;
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        v8s d3[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) d3[p] = *reinterpret_cast<const v8s*>(dp + p * DPL + r * DRB + (((4 * kb + kq) ^ tr_swizzle(r)) << 4));
+#pragma unroll
+                        for (int term = 0; term < 6; ++term)
+                            gx[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdx[kb][kTermB[term]], d3[kTermA[term]], gx[rt], 0, 0, 0);
+                    }
+                }
+            }
             if (DOCT == 1) asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
             else asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.d[2 * DOCT - 2]), "+v"(fill.d[2 * DOCT - 1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
+            if (DX) {                                                    // (after the delivery of the requested rows: the counter is in order)
+                const int arow = lane & 15, kq = lane >> 4;
+                const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int64_t v = r_base + 16 * rt + arow;
+                    if (v < r_end) *reinterpret_cast<v4f*>(dx + v * ld_dx + 16 * wave + 4 * kq) = gx[rt];
+                }
+            }
             __syncthreads();
         };
         for (int k = 0; k < n_my; k += 2) {
@@ -1352,18 +1392,27 @@ bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const fl
 }
 
 int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs,
-                              float* bias_slabs, hipStream_t s) {
+                              float* bias_slabs, const float* w, int64_t ld_w, int64_t w_type_stride, float* dx, int64_t ld_dx, void* planes, hipStream_t s) {
     RowTiles plan;
     for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
     for (int t = 0; t < 4; ++t) plan.tile_prefix[t] = 0;                 // (the kernel takes its tiles from the row ranges)
     if (dim == 128) {
         const int n_seq = 256;
-        hipLaunchKernelGGL(dense_weight_grad_split_kernel<128>, dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0,
-                           slabs, bias_slabs);
+        if (dx != nullptr) {                                             // fused input gradient: planes of W for out = in W
+            v4u* pk = static_cast<v4u*>(planes);
+            const int items = n_types * 8 * 4 * kWave;
+            hipLaunchKernelGGL(pack_planes_dense_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types,
+                               dim, 1, pk);
+            hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, true>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+                               n_types == 1 ? 1 : 0, slabs, bias_slabs, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 3 * kWave}, dx, ld_dx);
+        } else {
+            hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, false>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+                               n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), int64_t{0});
+        }
         return n_seq;
     }
     const int n_seq = 128;
-    hipLaunchKernelGGL(dense_weight_grad_split_kernel<256>, dim3(2 * n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0,
-                       slabs, bias_slabs);
+    hipLaunchKernelGGL((dense_weight_grad_split_kernel<256, false>), dim3(2 * n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+                       n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), int64_t{0});
     return n_seq;
 }
