@@ -413,8 +413,8 @@ def test_interact_fp32_mfma_kernels_stay_covered(which, monkeypatch):
         test_interact_backward_user_slot_reduced_on_chip(3, 700 * 32 + 5, 301, monkeypatch)
 
 
-@pytest.mark.parametrize('dim', [64, 128, 256])
-def test_split_arithmetic_is_as_accurate_as_fp32_mfma(dim, monkeypatch):
+@pytest.mark.parametrize('dim,scale', [(64, 1.0), (128, 1.0), (256, 1.0), (128, 3.0e3), (128, 2.0e-4)])
+def test_split_arithmetic_is_as_accurate_as_fp32_mfma(dim, scale, monkeypatch):
     """The order-3 contractions through three exact bf16 terms per operand (six bf16 MFMA products, fp32 accumulation; forward at d = 64 / 128,
     member and weight gradients at d = 64 / 128 / 256) against the same op in float64: the error must not exceed the fp32-MFMA kernels' own
     (both are far inside the 1e-5 bar).  Also the node-level linear map, which takes the same arithmetic at d = 128 / 256."""
@@ -423,10 +423,10 @@ def test_split_arithmetic_is_as_accurate_as_fp32_mfma(dim, monkeypatch):
     order, U, Q, I, E = 3, 301, 17, 211, 9000
     w_, lay = make_layout(U, Q, I, E, seed=5, edge_order='user')
     gen = torch.Generator().manual_seed(11)
-    h = torch.randn(lay.node_count, dim, generator=gen)
-    w = torch.randn(dim, 7 * dim, generator=gen) / np.sqrt(7 * dim)
+    h = torch.randn(lay.node_count, dim, generator=gen) * scale          # other magnitudes: the three terms must follow the exponent
+    w = torch.randn(dim, 7 * dim, generator=gen) / np.sqrt(7 * dim) / scale
     b = torch.randn(dim, generator=gen)
-    cot = torch.randn(lay.edge_count, dim, generator=gen) / 8
+    cot = torch.randn(lay.edge_count, dim, generator=gen) / 8 * scale
     h64, w64 = h.double().requires_grad_(True), w.double().requires_grad_(True)
     want = ref.feature_interactor(h64, torch.from_numpy(lay.i3_host.astype(np.int64)), w64, b.double(), order)
     want.backward(cot.double())
