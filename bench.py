@@ -55,10 +55,10 @@ MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md); the
 
 def split_arithmetic(dim, order, direction='any'):
     """True when the library runs this shape's contractions through three exact bf16 terms per operand (csrc/split_arith.hip):
-    order 3 at d = 64 / 128 / 256."""
-    if order != 3 or os.environ.get('IHG_INTERACT_ARITH') == 'f32':
+    orders 2 and 3 at d = 64 / 128 / 256 (the d = 256 forward: order 3 only)."""
+    if order not in (2, 3) or os.environ.get('IHG_INTERACT_ARITH') == 'f32' or dim not in (64, 128, 256):
         return False
-    return dim in (64, 128, 256)
+    return not (direction == 'forward' and dim == 256 and order == 2)
 
 
 def parse():
@@ -448,7 +448,7 @@ def main():
                    'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd + Adam' +
                            (f' + RCCL gradient exchange ({args.sync})' if world > 1 else ''),
                    'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
-                   'arithmetic': ('f32 results; the order-3 contractions (d = 64 / 128 / 256) and the '
+                   'arithmetic': ('f32 results; the order-2/3 contractions (d = 64 / 128 / 256) and the '
                                   'node-level linear maps at d = 128 / 256 multiply through three exact bf16 terms per operand (six bf16 MFMA products, f32 '
                                   'accumulation; error <= the fp32-MFMA kernels\' - tests/test_gpu_parity.py); IHG_INTERACT_ARITH=f32 selects the fp32-MFMA kernels')
                                  if split_arithmetic(dim, args.order) else 'f32 (fp32 MFMA / VALU)'},

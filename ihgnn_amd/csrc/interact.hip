@@ -1980,7 +1980,7 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     const bool vector_io = aligned16(g) && ld_h < (int64_t{1} << 30);     // the pipelined form stores g as 16-byte vectors
     if (planes != nullptr && split_members_ok(dim, NBLK == 4 ? 3 : 2, g, ld_h, ld_dout, dout, dh_user != nullptr)) {   // bf16-split contraction
         int entries = 0;
-        launch_members_split(dim, h, ld_h, i3, w_raw, ld_w, planes, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, &entries, s);
+        launch_members_split(dim, NBLK == 4 ? 3 : 2, h, ld_h, i3, w_raw, ld_w, planes, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, &entries, s);
         if (dh_user != nullptr) hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(entries), dim3(128), 0, s, bnd_val, bnd_user, entries, dim, dh_user, ld_dh);
     } else if (strip_bwd_ok(dim, g, ld_h) && dim == 256) {               // wq is strip-packed
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStrip256TE - 1) / kStrip256TE, kStrip256Grid));
@@ -2013,7 +2013,7 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     const int subs_ws = (dim / 64) * (dim / 64);
     int n_slabs = static_cast<int>(std::min<int64_t>(dim >= 64 ? std::max(kPipeGrid / subs_ws, 8) : weight_slabs(dim), (n_edges + 63) / 64));
     if (split_weight_ok(dim, NBLK == 4 ? 3 : 2, ld_h, ld_dout, dout)) {      // bf16-split contraction
-        n_slabs = launch_weight_split(dim, h, ld_h, i3, dout, ld_dout, slabs, n_edges, s);
+        n_slabs = launch_weight_split(dim, NBLK == 4 ? 3 : 2, h, ld_h, i3, dout, ld_dout, slabs, n_edges, s);
     } else if (dim == 128 && ld_h < (int64_t{1} << 30)) {
         n_slabs = static_cast<int>(std::min<int64_t>((n_edges + kStripTE - 1) / kStripTE, kPipeGridSlabs));
         hipLaunchKernelGGL((interact_bwd_weight_strip_kernel<128, NBLK>), dim3(n_slabs), dim3(kWsThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
@@ -2055,7 +2055,7 @@ int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p,
         float* wp = static_cast<float*>(workspace);
         const int nblk = order == 3 ? 4 : 3;
         if (split_fwd_ok(dim, order, p, ld_p, out, ld_out, ld_h)) {       // bf16-split contraction; its planes sit behind the fp32-packed weights
-            launch_fwd_split(dim, h, ld_h, p, ld_p, i3, w, ld_w, wp + packed_weight_floats(dim, order), out, ld_out, n_edges, s);
+            launch_fwd_split(dim, order, h, ld_h, p, ld_p, i3, w, ld_w, wp + packed_weight_floats(dim, order), out, ld_out, n_edges, s);
             return check_launch("ihg_interact_fwd");
         }
         const int pack_items = (dim / 32) * nblk * (dim / 8) * kWave;
@@ -2110,7 +2110,7 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
     hipLaunchKernelGGL(pack_weights_strip_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk,
                        static_cast<float*>(nullptr), wq);
     if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes);
-    else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user);
+    else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes);
     return check_launch("ihg_interact_bwd_user_reduced");
 }
 
@@ -2142,7 +2142,7 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const floa
         void* planes = split_plane_floats(dim, order) == 0 ? nullptr :
                        static_cast<void*>(slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order) + (dim == 128 ? 2LL * kPipeGrid * dim + 2LL * kPipeGrid : 0));
         if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s, nullptr, 0, nullptr, nullptr, w, ld_w, planes);
-        else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s);
+        else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s, nullptr, 0, nullptr, nullptr, w, ld_w, planes);
         return check_launch("ihg_interact_bwd");
     }
     if (n_edges > 0) {

@@ -14,18 +14,18 @@ IHG_INTERNAL bool split_arith_enabled();                       // IHG_INTERACT_A
 IHG_INTERNAL bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout, bool user_reduced);
 
 // member gradients; dh_user == nullptr: g is [E, 3, d], else the user-reduced form (g is [E, 2, d], boundary table as in interact.hip)
-IHG_INTERNAL void launch_members_split(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
+IHG_INTERNAL void launch_members_split(int dim, int order, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
                                        int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
                                        int* n_boundary_entries, hipStream_t s);
 
 // forward (first-order rows p required); planes: split_plane_floats(dim, order) floats of workspace
 IHG_INTERNAL bool split_fwd_ok(int dim, int order, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h);
-IHG_INTERNAL void launch_fwd_split(int dim, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes, float* out,
+IHG_INTERNAL void launch_fwd_split(int dim, int order, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes, float* out,
                                    int64_t ld_out, int64_t n_edges, hipStream_t s);
 
 // weight gradients into slabs [range][j][b d + c] (interact.hip's slab layout); returns the number of slabs written
 IHG_INTERNAL bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout);
-IHG_INTERNAL int launch_weight_split(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s);
+IHG_INTERNAL int launch_weight_split(int dim, int order, const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s);
 
 // node-level row GEMM (d = 128, 256): out = in W_t^T (transpose == 0) or in W_t (transpose == 1), rows grouped by node type
 IHG_INTERNAL int64_t split_dense_plane_floats(int dim);

@@ -65,17 +65,19 @@ __device__ constexpr int kTermB[6] = {2, 0, 1, 1, 0, 0};
 // planes of the member-gradient contraction dz_b[e][c] = sum_j dout[e][j] W[j][(3+b)d + c]   (k runs along j):
 // wsp[g][b][kb][ct][plane][lane][8] (g = 32-column group, d / 32 of them; kb < d / 32; ct < 2): element i = plane of
 // W[32 kb + 8 (lane>>4) + i][(3+b) d + 32 g + 16 ct + (lane&15)]
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(const float* __restrict__ w, int64_t ld_w, int d, v4u* __restrict__ wsp) {
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(const float* __restrict__ w, int64_t ld_w, int d, int nblk, v4u* __restrict__ wsp) {
     const int kbs = d / 32, groups = d / 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= groups * 4 * kbs * 2 * kWave) return;
     const int lane = idx & 63, ct = (idx >> 6) & 1, kb = (idx >> 7) % kbs, b = ((idx >> 7) / kbs) & 3, g = (idx >> 7) / (kbs * 4);
     const float* src = w + static_cast<int64_t>(32 * kb + 8 * (lane >> 4)) * ld_w + (3 + b) * d + 32 * g + 16 * ct + (lane & 15);
-    v4f x0, x1;
+    v4f x0 = v4f{0.f, 0.f, 0.f, 0.f}, x1 = x0;                            // (order 2 has three blocks: the fourth slot stays zero and is never read)
+    if (b < nblk) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        x0[i] = src[i * ld_w];
-        x1[i] = src[(4 + i) * ld_w];
+        for (int i = 0; i < 4; ++i) {
+            x0[i] = src[i * ld_w];
+            x1[i] = src[(4 + i) * ld_w];
+        }
     }
     const Planes pl = split8(x0, x1);
 #pragma unroll
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
 // boundary table that interact.hip's user_boundary_fixup_kernel adds up (indexed by tile range here, shared by the two halves).
 // D = 128: two column halves of 64 per tile range.  D = 256: eight parts of 32 columns (the weight planes are 1.5 MB), the dout tile is 32 KB
 // and every part splits it again.  D = 64: one workgroup holds all of it.  No user reduction at 64 / 256.
-template <int D, bool UR>
+// NBLK = 3 (order 2): matrix wave 3 has no block and only keeps the barriers.
+template <int D, bool UR, int NBLK>
 __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
                                                                                       const v4u* __restrict__ wsp, const float* __restrict__ dout, int64_t ld_dout,
                                                                                       float* __restrict__ g_out, int64_t n_edges, float* __restrict__ dh_user,
@@ -171,11 +174,15 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             for (int x = 0; x < EX; ++x) {
                 const int c = 4 * o + 32 * x;
                 const v4f z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][c]), z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][c]);
-                const v4f z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][c]), z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][c]);
+                const v4f z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][c]);
                 const v4f hu = hm[x][0], hq = hm[x][1], hi = hm[x][2];
-                const v4f g_u = z_uq * hq + z_iu * hi + z_uqi * (hq * hi);
-                const v4f g_q = z_uq * hu + z_qi * hi + z_uqi * (hu * hi);
-                const v4f g_i = z_qi * hq + z_iu * hu + z_uqi * (hu * hq);
+                v4f g_u = z_uq * hq + z_iu * hi, g_q = z_uq * hu + z_qi * hi, g_i = z_qi * hq + z_iu * hu;
+                if (NBLK == 4) {
+                    const v4f z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][c]);
+                    g_u += z_uqi * (hq * hi);
+                    g_q += z_uqi * (hu * hi);
+                    g_i += z_uqi * (hu * hq);
+                }
                 const bool live = e < n_edges;
                 if (UR) {                                                // rows past the end hold zeros for the scan
 #pragma unroll
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     __syncthreads();
     const int arow = lane & 15, kq = lane >> 4;
     for (int k = 0; k < n_phases; ++k) {
-        if (k < n_my) {
+        if (k < n_my && blk < NBLK) {
             v4f acc[2][CT];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -356,19 +363,21 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
 constexpr int kFwdTE = 16;
 
 // wsp[half][b][jt][kb][plane][lane][8] (half < d / 64, kb < d / 32): element i = plane of W[64 half + 16 jt + (lane & 15)][(3 + b) d + 32 kb + 8 (lane >> 4) + i]
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_fwd_kernel(const float* __restrict__ w, int64_t ld_w, int d, v4u* __restrict__ wsp) {
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_fwd_kernel(const float* __restrict__ w, int64_t ld_w, int d, int nblk, v4u* __restrict__ wsp) {
     const int kbs = d / 32, halves = d / 64;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= halves * 4 * 4 * kbs * kWave) return;
     const int lane = idx & 63, kb = (idx >> 6) % kbs, jt = ((idx >> 6) / kbs) & 3, b = ((idx >> 6) / (kbs * 4)) & 3, half = (idx >> 6) / (kbs * 16);
     const float* src = w + static_cast<int64_t>(64 * half + 16 * jt + (lane & 15)) * ld_w + (3 + b) * d + 32 * kb + 8 * (lane >> 4);
-    const Planes pl = split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]});
+    const Planes pl = b < nblk ? split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]})
+                               : split8(v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
     for (int p = 0; p < 3; ++p) wsp[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
 }
 
 // D = 128: two output-column halves per tile sequence (both form and split every product).  D = 64: one workgroup, no duplicated work.
-template <int D>
+// NBLK = 3 (order 2): matrix wave 3 has no block and only keeps the barriers.
+template <int D, int NBLK>
 __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p,
                                                                               const int32_t* __restrict__ i3, const v4u* __restrict__ wsp, float* __restrict__ out,
                                                                               int64_t ld_out, int64_t n_edges) {
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
             for (int x = 0; x < ZX; ++x) {
                 const v4f u = hm[x][0], q = hm[x][1], it = hm[x][2];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < NBLK; ++b) {
                     const v4f z = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
                     unsigned w0[3], w1[3];
 #pragma unroll
@@ -434,8 +443,9 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
         auto epilogue = [&](int k, const v4f (&pr)[3]) {                 // tile k - 1
             const float (*pp)[TE][PS] = part[(k - 1) & 1];
             const v4f s0 = *reinterpret_cast<const v4f*>(&pp[0][row][4 * o]), s1 = *reinterpret_cast<const v4f*>(&pp[1][row][4 * o]);
-            const v4f s2 = *reinterpret_cast<const v4f*>(&pp[2][row][4 * o]), s3 = *reinterpret_cast<const v4f*>(&pp[3][row][4 * o]);
-            const v4f sum = (s0 + s1) + (s2 + s3);
+            const v4f s2 = *reinterpret_cast<const v4f*>(&pp[2][row][4 * o]);
+            v4f sum = (s0 + s1) + s2;
+            if (NBLK == 4) sum = (s0 + s1) + (s2 + *reinterpret_cast<const v4f*>(&pp[3][row][4 * o]));
             const v4f first = (pr[0] + pr[1]) + pr[2];
             const int64_t e = tile_of(k - 1) * TE + row;
             if (e < n_edges) store_stream4(out + e * ld_out + HC * half + 4 * o, sum + first);
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
     __syncthreads();
     const int arow = lane & 15, kq = lane >> 4;
     for (int k = 0; k <= n_my; ++k) {
-        if (k < n_my) {
+        if (k < n_my && blk < NBLK) {
             v4f acc[4];
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) acc[jt] = v4f{0.f, 0.f, 0.f, 0.f};
@@ -747,11 +757,12 @@ __device__ __forceinline__ v8s read_tr_fragment(const unsigned char* lo, const u
 // cycles per MFMA) and part of the split waves' vector instructions falls into the issue cycles the MFMAs leave.  Alone, the matrix
 // waves would take 1,350 us and the split waves 1,035.
 // D = 128: two column halves of 64 per tile range; D = 256: eight parts of 32 columns (the dout tile is split by every part); D = 64: one workgroup.
-template <int D>
+// NBLK = 3 (order 2): three product blocks, matrix wave 3 only keeps the barriers.
+template <int D, int NBLK>
 __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
                                                                                      const float* __restrict__ dout, int64_t ld_dout, float* __restrict__ slabs,
                                                                                      int64_t n_edges) {
-    constexpr int TE = kSplitTE, NBLK = 4, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, JT = D / 16;
+    constexpr int TE = kSplitTE, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, JT = D / 16;
     constexpr int DRB = 2 * D < 256 ? 256 : 2 * D, ZRB = 8 * HC;         // image rows are whole 256-byte segments (the transposed-read swizzle moves chunks inside one)
     constexpr int DOCT = D / 64, ZX = HC / 32;                          // per service thread: dout octets, 4-column groups of products
     constexpr int DPL = TE * DRB, ZPL = TE * ZRB;
@@ -823,7 +834,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
                 const int og = o + 8 * x;
                 const v4f u = r.m[x][0], q = r.m[x][1], it = r.m[x][2];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < NBLK; ++b) {
                     const v4f z = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
                     typedef unsigned v2u __attribute__((ext_vector_type(2)));
                     unsigned w0[3], w1[3];
@@ -886,6 +897,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
         for (int k = 0; k < n_my; ++k) {
             const unsigned char* dp = &dplanes[k & 1][0][0][0];
             const unsigned char* zp = &zplanes[k & 1][0][0][0];
+            if (blk < NBLK)
 #pragma unroll
             for (int jh = 0; jh < JT / 4; ++jh) {
                 v8s a[4][3];
@@ -914,6 +926,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
             __syncthreads();
         }
     }
+    if (blk >= NBLK) return;
     float* slab = slabs + static_cast<int64_t>(range) * D * NBLK * D;
     const int c = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -1280,7 +1293,8 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 
 }  // namespace
 
-int64_t split_plane_floats(int dim, int order) { return (dim == 64 || dim == 128 || dim == 256) && order == 3 ? (3LL * 4 * dim * dim) / 2 : 0; }
+// floats of workspace for the weight planes of one direction: laid out for four blocks at either order
+int64_t split_plane_floats(int dim, int order) { return (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) ? (3LL * 4 * dim * dim) / 2 : 0; }
 
 bool split_arith_enabled() {                                             // read at every call: tests and the bench switch it in-process
     const char* v = std::getenv("IHG_INTERACT_ARITH");
@@ -1289,28 +1303,40 @@ bool split_arith_enabled() {                                             // read
 
 // dim 128: either form of g; dim 64, 256: the [E, 3, d] form only
 bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout, bool user_reduced) {
-    return split_arith_enabled() && (dim == 128 || ((dim == 256 || dim == 64) && !user_reduced)) && order == 3 && aligned16(g) && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
+    return split_arith_enabled() && (dim == 128 || ((dim == 256 || dim == 64) && !user_reduced)) && (order == 2 || order == 3) && aligned16(g) && aligned16(dout) &&
+           ld_h % 4 == 0 && ld_dout % 4 == 0;
 }
 
-void launch_members_split(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
+namespace {
+template <int D, int NBLK>
+void launch_members_split_t(const float* h, int64_t ld_h, const int32_t* i3, const v4u* wsp, const float* dout, int64_t ld_dout, float* g, int64_t n_edges,
+                            float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user, hipStream_t s) {
+    if constexpr (D == 128) {
+        if (dh_user != nullptr) {
+            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<128, true, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
+                               dh_user, ld_dh, bnd_val, bnd_user);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, false, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
+                       static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
+}
+}  // namespace
+
+void launch_members_split(int dim, int order, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
                           int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
                           int* n_boundary_entries, hipStream_t s) {
     v4u* wsp = static_cast<v4u*>(planes);
+    const int nblk = order == 3 ? 4 : 3;
     const int items = (dim / 32) * 4 * (dim / 32) * 2 * kWave;
-    hipLaunchKernelGGL(pack_planes_members_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, wsp);
-    const int grid = 256;                                                // tile ranges x column parts
-    if (dim == 256)
-        hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<256, false>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
-                           static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
-    else if (dim == 64)
-        hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<64, false>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
-                           static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
-    else if (dh_user != nullptr)
-        hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<128, true>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user,
-                           ld_dh, bnd_val, bnd_user);
-    else
-        hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<128, false>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
-                           static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
+    hipLaunchKernelGGL(pack_planes_members_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wsp);
+#define IHG_MEMBERS(D)                                                                                                                       \
+    {                                                                                                                                        \
+        if (nblk == 4) launch_members_split_t<D, 4>(h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, s);    \
+        else launch_members_split_t<D, 3>(h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, s);              \
+    }
+    if (dim == 256) IHG_MEMBERS(256) else if (dim == 64) IHG_MEMBERS(64) else IHG_MEMBERS(128)
+#undef IHG_MEMBERS
     if (n_boundary_entries != nullptr) *n_boundary_entries = 2 * kSplitRanges;
 }
 
@@ -1348,38 +1374,51 @@ void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float*
 }
 
 bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout) {
-    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && order == 3 && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
+    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
 }
 
-int launch_weight_split(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges, hipStream_t s) {
+int launch_weight_split(int dim, int order, const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges,
+                        hipStream_t s) {
+#define IHG_WEIGHT(D)                                                                                                                                   \
+    {                                                                                                                                                   \
+        if (order == 3) hipLaunchKernelGGL((interact_bwd_weight_split_ws_kernel<D, 4>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges); \
+        else hipLaunchKernelGGL((interact_bwd_weight_split_ws_kernel<D, 3>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);           \
+    }
     if (dim == 256) {
-        hipLaunchKernelGGL(interact_bwd_weight_split_ws_kernel<256>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
+        IHG_WEIGHT(256)
         return 32;
     }
     if (dim == 64) {
-        hipLaunchKernelGGL(interact_bwd_weight_split_ws_kernel<64>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
+        IHG_WEIGHT(64)
         return 256;
     }
-    hipLaunchKernelGGL(interact_bwd_weight_split_ws_kernel<128>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, dout, ld_dout, slabs, n_edges);
+    IHG_WEIGHT(128)
+#undef IHG_WEIGHT
     return kSplitRanges;                                                 // slabs written (every range writes one, empty ranges zeros)
 }
 
+// order 3 at d = 64 / 128 / 256, order 2 at d = 64 / 128 (the chunked d = 256 form is written for four blocks)
 bool split_fwd_ok(int dim, int order, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h) {
-    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && order == 3 && p != nullptr && ld_p % 4 == 0 && ld_out % 4 == 0 && aligned16(p) &&
-           aligned16(out) && ld_h % 4 == 0;
+    return split_arith_enabled() && ((order == 3 && (dim == 64 || dim == 128 || dim == 256)) || (order == 2 && (dim == 64 || dim == 128))) && p != nullptr &&
+           ld_p % 4 == 0 && ld_out % 4 == 0 && aligned16(p) && aligned16(out) && ld_h % 4 == 0;
 }
 
-void launch_fwd_split(int dim, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes, float* out,
-                      int64_t ld_out, int64_t n_edges, hipStream_t s) {
+void launch_fwd_split(int dim, int order, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes,
+                      float* out, int64_t ld_out, int64_t n_edges, hipStream_t s) {
     v4u* wsp = static_cast<v4u*>(planes);
     // d = 256: chunked (the eight-part column split of the other form would repeat the product work eight times); d = 64 / 128: weights
     // resident.  At d = 128 the chunked form measured 2,430 us against 2,000: with 32-hyperedge tiles its weight stream (393 KB per tile)
     // alone fills the CU's L2 port for 0.8 ms.
     if (dim != 256) {
         const int items = (dim / 64) * 4 * 4 * (dim / 32) * kWave;
-        hipLaunchKernelGGL(pack_planes_fwd_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, wsp);
-        if (dim == 64) hipLaunchKernelGGL(interact_fwd_split_ws_kernel<64>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
-        else hipLaunchKernelGGL(interact_fwd_split_ws_kernel<128>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
+        hipLaunchKernelGGL(pack_planes_fwd_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, order == 3 ? 4 : 3, wsp);
+#define IHG_FWD(D)                                                                                                                                              \
+    {                                                                                                                                                           \
+        if (order == 3) hipLaunchKernelGGL((interact_fwd_split_ws_kernel<D, 4>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges); \
+        else hipLaunchKernelGGL((interact_fwd_split_ws_kernel<D, 3>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);           \
+    }
+        if (dim == 64) IHG_FWD(64) else IHG_FWD(128)
+#undef IHG_FWD
         return;
     }
     const int items = (dim / 128) * 4 * (4 * dim / 128) * 2 * 4 * kWave;

@@ -194,7 +194,7 @@ int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr
  *   bytes: the product blocks of w re-packed into MFMA fragment order (+ the dW slabs for bwd).  For dim in
  *   {32, 64, 128, 256} with 16-byte aligned rows the contraction runs on the matrix cores in exact fp32
  *   (v_mfma_f32_32x32x2_f32 / 16x16x4_f32); every other shape takes a scalar kernel with the same results.
- *   Order 3 at dim 64 / 128 / 256 and the dim-128 / 256 node-level maps of ihg_node_linear_* multiply through three exact bf16
+ *   Orders 2 and 3 at dim 64 / 128 / 256 (order 2 forward: 64 / 128) and the dim-128 / 256 node-level maps of ihg_node_linear_* multiply through three exact bf16
  *   terms per fp32 operand instead - six v_mfma_f32_16x16x32_bf16 products per multiply, fp32 accumulation, an error at or
  *   below the fp32-MFMA kernels' (csrc/split_arith.hip).  The environment variable IHG_INTERACT_ARITH=f32, read at every
  *   call, keeps those shapes on the fp32-MFMA kernels.

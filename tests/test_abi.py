@@ -38,9 +38,9 @@ def test_bad_arguments_return_codes_and_messages():
     assert lib.ihg_interact_fwd(None, 4, None, 4, None, None, 28, 1, None, 4, None, 0, 3, 4, None) == _lib.ERR_INVALID
     assert 'order' in _lib.last_error()
     assert lib.ihg_interact_fwd(None, 4, None, 4, None, None, 8, 3, None, 4, None, 0, 3, 4, None) == _lib.ERR_INVALID   # ld_w < 7*dim
-    # fp32-packed product blocks; order 3 at d = 64 / 128 / 256 adds their three bf16 planes (1.5 x)
-    assert lib.ihg_interact_fwd_workspace_bytes(1000, 64, 2) == 3 * 64 * 64 * 4 and lib.ihg_interact_fwd_workspace_bytes(1000, 12, 3) == 0
-    assert lib.ihg_interact_fwd_workspace_bytes(1000, 64, 3) == (4 * 64 * 64 + 6 * 64 * 64) * 4
+    # fp32-packed product blocks (3 or 4 of them) + at d = 64 / 128 / 256 the three bf16 planes of four block slots (1.5 x 4 d^2)
+    assert lib.ihg_interact_fwd_workspace_bytes(1000, 64, 2) == (3 * 64 * 64 + 6 * 64 * 64) * 4 and lib.ihg_interact_fwd_workspace_bytes(1000, 12, 3) == 0
+    assert lib.ihg_interact_fwd_workspace_bytes(1000, 64, 3) == (4 * 64 * 64 + 6 * 64 * 64) * 4 and lib.ihg_interact_fwd_workspace_bytes(1000, 32, 3) == 4 * 32 * 32 * 4
     assert lib.ihg_interact_bwd_workspace_bytes(1000, 64, 3) > lib.ihg_interact_fwd_workspace_bytes(1000, 64, 3)
     # empty problems are fine and launch nothing
     assert lib.ihg_edge_gather_sum(None, 4, None, None, None, 1.0, None, 4, 0, 4, None) == _lib.OK
