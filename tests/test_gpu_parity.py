@@ -399,12 +399,13 @@ def test_interact_split_kernels_on_tiny_hypergraphs(dim, edges):
 
 @pytest.mark.parametrize('which', ['forward_backward', 'persistent', 'user_slot'])
 def test_interact_fp32_mfma_kernels_stay_covered(which, monkeypatch):
-    """Order 3 at d = 64 / 128 / 256 runs on the bf16-split kernels by default; IHG_INTERACT_ARITH=f32 (read by the library at every call)
+    """Orders 2 and 3 at d = 64 / 128 / 256 run on the bf16-split kernels by default; IHG_INTERACT_ARITH=f32 (read by the library at every call)
     selects the fp32-MFMA kernels, which must keep passing the same cases."""
     monkeypatch.setenv('IHG_INTERACT_ARITH', 'f32')
     if which == 'forward_backward':
         for dim in (64, 128, 256):
             test_interact_forward_backward(dim, 3)
+            test_interact_forward_backward(dim, 2)
     elif which == 'persistent':
         test_interact_persistent_tiles_and_strided_rows(128, 3, 1100 * 64 + 37)
         test_interact_persistent_tiles_and_strided_rows(64, 3, 3 * 256 * 64 + 37)
