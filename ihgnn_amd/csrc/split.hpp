@@ -1,6 +1,7 @@
-// split.hpp - internal interface of split_arith.hip: the interactive step's contractions for d = 128, order 3, with every fp32
-// operand taken apart EXACTLY into three bf16 terms (x = hi + mid + lo) and the products accumulated in fp32 on the bf16 matrix
-// pipe.  Not part of the C ABI: interact.hip chooses between these and its fp32-MFMA kernels.
+// split.hpp - internal interface of split_arith.hip: the interactive step's contractions (orders 2 and 3; d = 64, 128, 256) and the
+// node-level linear maps (d = 128, 256) with every fp32 operand taken apart EXACTLY into three bf16 terms (x = hi + mid + lo) and the
+// products accumulated in fp32 on the bf16 matrix pipe.  Not part of the C ABI: interact.hip and dense.hip choose between these and
+// their fp32-MFMA kernels through the *_ok() predicates.
 #pragma once
 #include <hip/hip_runtime.h>
 

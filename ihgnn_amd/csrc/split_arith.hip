@@ -34,6 +34,11 @@ constexpr int kSplitThreads = 512;
 __device__ __forceinline__ unsigned pack_hi(float a, float b) {          // {top half of b, top half of a}
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
 }
+// row r of a table whose rows are ld floats apart (ld < 2^31: the *_ok() predicates): ONE v_mad_u64_u32 where the 64 x 64-bit product of
+// an int64 leading dimension costs three quarter-rate multiplies per row - service-wave cycles the matrix pipe waits for
+__device__ __forceinline__ const float* row_at(const float* base, int32_t r, uint32_t ld) {
+    return base + static_cast<uint64_t>(static_cast<uint32_t>(r)) * static_cast<uint64_t>(ld);
+}
 __device__ __forceinline__ float top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 
 // eight consecutive k of one row / column -> the three bf16 planes of that MFMA fragment
@@ -139,9 +144,17 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         // ---------------- service waves: 256 threads, thread -> hyperedge row, dout octets o and o + 8, member / gradient columns 4 o .. and 32 + 4 o ..
         const int st = tid - 256, row = st >> 3, o = st & 7;
         const int64_t last_pos = n_edges * 3 - 1;
-        auto fetch_id = [&](int k) { return i3[std::min<int64_t>((t0 + k) * (3 * TE) + st, last_pos)]; };     // (st < 96)
-        auto load_dout = [&](int k, v4f (&dr)[2 * DOCT]) {
-            const float* src = dout + std::min<int64_t>((t0 + k) * TE + row, n_edges - 1) * ld_dout + 8 * o;
+        const uint32_t ldh = static_cast<uint32_t>(ld_h), ldd = static_cast<uint32_t>(ld_dout);
+        // tile bases and the clamps at the end of the hyperedge list are scalar (the tile number is uniform); per lane: one min, one multiply
+        auto fetch_id = [&](int k) {                                     // (st < 96; the tile exists)
+            const int64_t first = (t0 + k) * (3 * TE);
+            const int lim = static_cast<int>(std::min<int64_t>(last_pos - first, 3 * TE - 1));
+            return (i3 + first)[std::min(st, lim)];
+        };
+        auto load_dout = [&](int k, v4f (&dr)[2 * DOCT]) {               // (tiles past the end: the last row, dropped)
+            const int64_t first = std::min<int64_t>((t0 + k) * TE, n_edges - 1);
+            const int lim = static_cast<int>(std::min<int64_t>(n_edges - 1 - first, TE - 1));
+            const float* src = row_at(dout + first * ld_dout, std::min(row, lim), ldd) + 8 * o;
 #pragma unroll
             for (int x = 0; x < DOCT; ++x) {
                 dr[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + HC * half + 4 * o;
+                const float* hp = row_at(h, idk[m], ldh) + HC * half + 4 * o;
 #pragma unroll
                 for (int x = 0; x < EX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + 32 * x);
             }
@@ -255,8 +268,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         };
         if (st < 3 * TE) {
             ids[0][st] = fetch_id(0);
-            if (n_my > 1) ids[1][st] = fetch_id(1);
-            if (n_my > 2) ids[2][st] = fetch_id(2);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) ids[k][st] = k < 3 && k < n_my ? fetch_id(k) : 0;       // (slots of tiles past the end: row 0, requested and dropped)
         }
         __syncthreads();
         v4f dr0[2 * DOCT], dr1[2 * DOCT], hm0[EX][3], hm1[EX][3];                        // dout values of tile m in dr<m & 1>, member values in hm<m & 1>
@@ -267,8 +280,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         int id_carry = 0;
         auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3]) {
             if (k >= 1 && k + 2 < n_my && st < 3 * TE) ids[(k + 2) & 7][st] = id_carry;     // requested in the previous phase
-            if (k < n_my) load_members(k, hm_cur);
-            if (k + 2 < n_my) load_dout(k + 2, fill);
+            load_members(k, hm_cur);                                     // unconditional: a branch around requests costs whole-set register copies
+            load_dout(k + 2, fill);
             if (k + 3 < n_my && st < 3 * TE) id_carry = fetch_id(k + 3);
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
             // delivery of this phase's requests, THEN everything that stores: the memory counter is in order, a wait behind a store sits out
@@ -279,10 +292,13 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             if (UR && k >= 2) scan_and_emit(k - 2);
             __syncthreads();
         };
-        for (int k = 0; k < n_phases; k += 2) {
+        int k = 0;
+#pragma clang loop unroll(disable)
+        for (; k + 1 < n_phases; k += 2) {                                // exactly two phases per trip: the register sets come back in place
             phase(k, dr1, dr0, hm0, hm1);
-            if (k + 1 < n_phases) phase(k + 1, dr0, dr1, hm1, hm0);
+            phase(k + 1, dr0, dr1, hm1, hm0);
         }
+        if (k < n_phases) phase(k, dr1, dr0, hm0, hm1);
         if (UR) {
             // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
             const bool one_run = run_dst == first_slot;
@@ -400,12 +416,17 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
         // ---------------- service waves: thread -> hyperedge row, member columns 4 o .. and 64 + 4 o ..; epilogue: output columns 4 o .. of the half
         const int st = tid - 256, row = st >> 4, o = st & 15;
         const int64_t last_pos = n_edges * 3 - 1;
-        auto fetch_id = [&](int k) { return i3[std::min<int64_t>(tile_of(k) * (3 * TE) + st, last_pos)]; };           // (st < 48)
+        const uint32_t ldh = static_cast<uint32_t>(ld_h), ldp = static_cast<uint32_t>(ld_p);
+        auto fetch_id = [&](int k) {                                     // (st < 48; the tile exists) - scalar tile base, one vector min
+            const int64_t first = tile_of(k) * (3 * TE);
+            const int lim = static_cast<int>(std::min<int64_t>(last_pos - first, 3 * TE - 1));
+            return (i3 + first)[std::min(st, lim)];
+        };
         auto load_members = [&](int k, v4f (&hm)[ZX][3]) {
             const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + 4 * o;
+                const float* hp = row_at(h, idk[m], ldh) + 4 * o;
 #pragma unroll
                 for (int x = 0; x < ZX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + 64 * x);
             }
@@ -413,7 +434,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
         auto load_first_order = [&](int k, v4f (&pr)[3]) {
             const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
-            for (int m = 0; m < 3; ++m) pr[m] = *reinterpret_cast<const v4f*>(p + static_cast<int64_t>(idk[m]) * ld_p + HC * half + 4 * o);
+            for (int m = 0; m < 3; ++m) pr[m] = *reinterpret_cast<const v4f*>(row_at(p, idk[m], ldp) + HC * half + 4 * o);
         };
         auto split_tile = [&](const v4f (&hm)[ZX][3], int buf) {
             typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -452,9 +473,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
         };
         if (st < 3 * TE) {
             ids[0][st] = fetch_id(0);
-            if (n_my > 1) ids[1][st] = fetch_id(1);
-            if (n_my > 2) ids[2][st] = fetch_id(2);
-            if (n_my > 3) ids[3][st] = fetch_id(3);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) ids[k][st] = k < 4 && k < n_my ? fetch_id(k) : 0;       // (slots of tiles past the end: row 0, requested and dropped)
         }
         __syncthreads();
         v4f hm0[ZX][3], hm1[ZX][3], pr0[3], pr1[3];                        // member values of tile m in hm<m & 1>, first-order rows in pr<m & 1>
@@ -467,8 +487,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
         // tile k + 2 (`fill`), first-order rows of tile k, ids of tile k + 4 (they reach the ring in the next phase and are first read in the one after)
         auto phase = [&](int k, v4f (&use)[ZX][3], v4f (&fill)[ZX][3], v4f (&pr_cur)[3], v4f (&pr_prev)[3]) {
             if (k >= 1 && k + 3 < n_my && st < 3 * TE) ids[(k + 3) & 7][st] = id_carry;
-            if (k + 2 < n_my) load_members(k + 2, fill);
-            if (k < n_my) load_first_order(k, pr_cur);
+            load_members(k + 2, fill);                                   // unconditional (past the end: whatever rows the ring slot names, dropped)
+            load_first_order(k, pr_cur);
             if (k + 4 < n_my && st < 3 * TE) id_carry = fetch_id(k + 4);
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
             // delivery of this phase's requests, THEN the store: the memory counter is in order, a wait behind the store would sit out its
@@ -478,10 +498,13 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
             if (k >= 1) epilogue(k, pr_prev);
             __syncthreads();
         };
-        for (int k = 0; k <= n_my; k += 2) {
+        int k = 0;
+#pragma clang loop unroll(disable)
+        for (; k + 1 <= n_my; k += 2) {                                   // exactly two phases per trip: the register sets come back in place
             phase(k, hm1, hm0, pr0, pr1);
-            if (k + 1 <= n_my) phase(k + 1, hm0, hm1, pr1, pr0);
+            phase(k + 1, hm0, hm1, pr1, pr0);
         }
+        if (k <= n_my) phase(k, hm1, hm0, pr0, pr1);
         return;
     }
 
@@ -569,12 +592,17 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_chunk_kernel
         // ---------------- service waves: thread -> hyperedge row, 16 columns of a 128-column part
         const int st = tid - 256, row = st >> 3, cq = st & 7;
         const int64_t last_pos = n_edges * 3 - 1;
-        auto fetch_id = [&](int k) { return i3[std::min<int64_t>(tile_of(k) * (3 * TE) + st, last_pos)]; };           // (st < 96)
+        const uint32_t ldh = static_cast<uint32_t>(ld_h), ldp = static_cast<uint32_t>(ld_p);
+        auto fetch_id = [&](int k) {                                     // (st < 96; the tile exists) - scalar tile base, one vector min
+            const int64_t first = tile_of(k) * (3 * TE);
+            const int lim = static_cast<int>(std::min<int64_t>(last_pos - first, 3 * TE - 1));
+            return (i3 + first)[std::min(st, lim)];
+        };
         auto load_members = [&](int k, int cp, v4f (&hm)[3][4]) {        // member values of tile k, column part cp
             const int* idk = ids[k & 3] + row * 3;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + 128 * cp + 16 * cq;
+                const float* hp = row_at(h, idk[m], ldh) + 128 * cp + 16 * cq;
 #pragma unroll
                 for (int x = 0; x < 4; ++x) hm[m][x] = *reinterpret_cast<const v4f*>(hp + 4 * x);
             }
@@ -583,7 +611,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_chunk_kernel
             const int* idk = ids[k & 3] + row * 3;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                const float* pp = p + static_cast<int64_t>(idk[m]) * ld_p + 128 * half + 16 * cq;
+                const float* pp = row_at(p, idk[m], ldp) + 128 * half + 16 * cq;
 #pragma unroll
                 for (int x = 0; x < 4; ++x) pr[m][x] = *reinterpret_cast<const v4f*>(pp + 4 * x);
             }
@@ -782,26 +810,32 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
         // ---------------- split waves: 256 threads, thread -> hyperedge row, dout octets o and o + 8, member columns 4 o .. and 32 + 4 o ..
         const int st = tid - 256, row = st >> 3, o = st & 7;
         const int64_t last_pos = n_edges * 3 - 1;
-        auto fetch_id = [&](int k) { return i3[std::min<int64_t>((t0 + k) * (3 * TE) + st, last_pos)]; };     // (st < 96)
+        const uint32_t ldh = static_cast<uint32_t>(ld_h), ldd = static_cast<uint32_t>(ld_dout);
+        auto fetch_id = [&](int k) {                                     // (st < 96; the tile exists) - scalar tile base, one vector min
+            const int64_t first = (t0 + k) * (3 * TE);
+            const int lim = static_cast<int>(std::min<int64_t>(last_pos - first, 3 * TE - 1));
+            return (i3 + first)[std::min(st, lim)];
+        };
         struct Rows {
             v4f d[2 * DOCT], m[ZX][3];
         };
         auto load_rows = [&](int k, Rows& r) {
-            const int64_t e = (t0 + k) * TE + row;
-            const float* src = dout + std::min<int64_t>(e, n_edges - 1) * ld_dout + 8 * o;
+            const int64_t first = std::min<int64_t>((t0 + k) * TE, n_edges - 1);                    // scalar; tiles past the end: the last row
+            const int rows = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(n_edges - (t0 + k) * TE, TE)));
+            const float* src = row_at(dout + first * ld_dout, std::min(row, std::max(rows - 1, 0)), ldd) + 8 * o;
 #pragma unroll
             for (int x = 0; x < DOCT; ++x) {
                 r.d[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
                 r.d[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
             }
-            if (e >= n_edges) {                                          // hyperedges past the end contribute nothing
+            if (row >= rows) {                                           // hyperedges past the end contribute nothing
 #pragma unroll
                 for (int x = 0; x < 2 * DOCT; ++x) r.d[x] = v4f{0.f, 0.f, 0.f, 0.f};
             }
             const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                const float* hp = h + static_cast<int64_t>(idk[m]) * ld_h + HC * half + 4 * o;
+                const float* hp = row_at(h, idk[m], ldh) + HC * half + 4 * o;
 #pragma unroll
                 for (int x = 0; x < ZX; ++x) r.m[x][m] = *reinterpret_cast<const v4f*>(hp + 32 * x);
             }
@@ -850,9 +884,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
         if (n_my > 0) {
             if (st < 3 * TE) {
                 ids[0][st] = fetch_id(0);
-                if (n_my > 1) ids[1][st] = fetch_id(1);
-                if (n_my > 2) ids[2][st] = fetch_id(2);
-                if (n_my > 3) ids[3][st] = fetch_id(3);
+#pragma unroll
+                for (int k = 1; k < 8; ++k) ids[k][st] = k < 4 && k < n_my ? fetch_id(k) : 0;   // (slots of tiles past the end: row 0, requested and dropped)
             }
             // (only the split waves read the id ring: a barrier among themselves would do; the workgroup barrier keeps the counts equal)
             __syncthreads();
@@ -864,15 +897,18 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
             int id_carry = 0;
             auto phase = [&](int k, Rows& use, Rows& fill) {
                 if (k >= 1 && k + 3 < n_my && st < 3 * TE) ids[(k + 3) & 7][st] = id_carry;
-                if (k + 2 < n_my) load_rows(k + 2, fill);
+                load_rows(k + 2, fill);                                  // unconditional: a branch around requests costs whole-set register copies
                 if (k + 4 < n_my && st < 3 * TE) id_carry = fetch_id(k + 4);
                 if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
                 __syncthreads();
             };
-            for (int k = 0; k < n_my; k += 2) {
+            int k = 0;
+#pragma clang loop unroll(disable)
+            for (; k + 1 < n_my; k += 2) {                                // exactly two phases per trip: the register sets come back in place
                 phase(k, r1, r0);
-                if (k + 1 < n_my) phase(k + 1, r0, r1);
+                phase(k + 1, r0, r1);
             }
+            if (k < n_my) phase(k, r1, r0);
         }
         return;
     }
@@ -1301,10 +1337,15 @@ bool split_arith_enabled() {                                             // read
     return v == nullptr || std::strcmp(v, "f32") != 0;
 }
 
+namespace {
+// leading dimensions the kernels' 32-bit row arithmetic takes (row_at): 16-byte rows, below 2^31 floats
+inline bool ld_ok(int64_t ld) { return ld > 0 && ld % 4 == 0 && ld < (int64_t{1} << 31); }
+}  // namespace
+
 // dim 128: either form of g; dim 64, 256: the [E, 3, d] form only
 bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout, bool user_reduced) {
     return split_arith_enabled() && (dim == 128 || ((dim == 256 || dim == 64) && !user_reduced)) && (order == 2 || order == 3) && aligned16(g) && aligned16(dout) &&
-           ld_h % 4 == 0 && ld_dout % 4 == 0;
+           ld_ok(ld_h) && ld_ok(ld_dout);
 }
 
 namespace {
@@ -1374,7 +1415,7 @@ void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float*
 }
 
 bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout) {
-    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) && aligned16(dout) && ld_h % 4 == 0 && ld_dout % 4 == 0;
+    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) && aligned16(dout) && ld_ok(ld_h) && ld_ok(ld_dout);
 }
 
 int launch_weight_split(int dim, int order, const float* h, int64_t ld_h, const int32_t* i3, const float* dout, int64_t ld_dout, float* slabs, int64_t n_edges,
@@ -1400,7 +1441,7 @@ int launch_weight_split(int dim, int order, const float* h, int64_t ld_h, const 
 // order 3 at d = 64 / 128 / 256, order 2 at d = 64 / 128 (the chunked d = 256 form is written for four blocks)
 bool split_fwd_ok(int dim, int order, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h) {
     return split_arith_enabled() && ((order == 3 && (dim == 64 || dim == 128 || dim == 256)) || (order == 2 && (dim == 64 || dim == 128))) && p != nullptr &&
-           ld_p % 4 == 0 && ld_out % 4 == 0 && aligned16(p) && aligned16(out) && ld_h % 4 == 0;
+           ld_ok(ld_p) && ld_out % 4 == 0 && aligned16(p) && aligned16(out) && ld_ok(ld_h);
 }
 
 void launch_fwd_split(int dim, int order, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes,
