@@ -41,6 +41,18 @@ __device__ __forceinline__ const float* row_at(const float* base, int32_t r, uin
 }
 __device__ __forceinline__ float top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 
+// Two fp32 values -> one dword of each of the three bf16 planes (low half: xa's term, high half: xb's): mask, subtract, mask, subtract, and
+// three v_perm_b32 that pack the top halves - 11 vector instructions per pair.  (Tried: the remainder x - top16(x) as ONE
+// v_dot2c_f32_bf16 of the packed plane with the selector {-1, 0} accumulated onto x, 7 instructions per pair and bit-identical planes
+// - tools/dot2_probe.hip - but the dot instruction is not a full-rate one: forward +2 %, weight gradients +8 %.)
+__device__ __forceinline__ void split_pair(float xa, float xb, unsigned (&w)[3]) {
+    const float ra = xa - top16(xa), rb = xb - top16(xb);
+    const float la = ra - top16(ra), lb = rb - top16(rb);
+    w[0] = pack_hi(xa, xb);
+    w[1] = pack_hi(ra, rb);
+    w[2] = pack_hi(la, lb);
+}
+
 // eight consecutive k of one row / column -> the three bf16 planes of that MFMA fragment
 struct Planes {
     v4u p[3];
@@ -52,12 +64,10 @@ __device__ __forceinline__ Planes split8(v4f x0, v4f x1) {
         const v4f x = half == 0 ? x0 : x1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float a = x[2 * i], b = x[2 * i + 1];
-            const float ra = a - top16(a), rb = b - top16(b);
-            const float la = ra - top16(ra), lb = rb - top16(rb);
-            out.p[0][2 * half + i] = pack_hi(a, b);
-            out.p[1][2 * half + i] = pack_hi(ra, rb);
-            out.p[2][2 * half + i] = pack_hi(la, lb);
+            unsigned w[3];
+            split_pair(x[2 * i], x[2 * i + 1], w);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) out.p[p][2 * half + i] = w[p];
         }
     }
     return out;
@@ -446,14 +456,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
                     const v4f z = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
                     unsigned w0[3], w1[3];
 #pragma unroll
-                    for (int hp2 = 0; hp2 < 2; ++hp2) {
-                        const float xa = z[2 * hp2], xb = z[2 * hp2 + 1];
-                        const float ra = xa - top16(xa), rb = xb - top16(xb);
-                        const float la = ra - top16(ra), lb = rb - top16(rb);
-                        (hp2 == 0 ? w0 : w1)[0] = pack_hi(xa, xb);
-                        (hp2 == 0 ? w0 : w1)[1] = pack_hi(ra, rb);
-                        (hp2 == 0 ? w0 : w1)[2] = pack_hi(la, lb);
-                    }
+                    for (int hp2 = 0; hp2 < 2; ++hp2) split_pair(z[2 * hp2], z[2 * hp2 + 1], hp2 == 0 ? w0 : w1);
                     // columns b D + 64 x + 4 o ..: chunk b D / 8 + 8 x + (o >> 1), half o & 1
                     const int off = row * ZRB + ((((D / 8) * b + 8 * x + (o >> 1)) ^ row) << 4) + 8 * (o & 1);
 #pragma unroll
@@ -842,13 +845,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
         };
         const int swz = tr_swizzle(row);
         auto split_tile = [&](const Rows& r, int buf) {
-            auto pair = [&](float xa, float xb, unsigned (&out)[3]) {
-                const float ra = xa - top16(xa), rb = xb - top16(xb);
-                const float la = ra - top16(ra), lb = rb - top16(rb);
-                out[0] = pack_hi(xa, xb);
-                out[1] = pack_hi(ra, rb);
-                out[2] = pack_hi(la, lb);
-            };
+            auto pair = [&](float xa, float xb, unsigned (&out)[3]) { split_pair(xa, xb, out); };
 #pragma unroll
             for (int x = 0; x < DOCT; ++x) {                             // dout octets o + 8 x (256-byte segments swizzled separately)
                 v4u sp[3];
@@ -1085,11 +1082,10 @@ __global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(c
             if (step < 4 * OCT) {   // two values of the next tile's row piece -> one dword of each plane
                 const int x = step >> 2, pr = step & 3;
                 const float xa = use[2 * x + (pr >> 1)][2 * (pr & 1)], xb = use[2 * x + (pr >> 1)][2 * (pr & 1) + 1];
-                const float ra = xa - top16(xa), rb = xb - top16(xb);
-                const float la = ra - top16(ra), lb = rb - top16(rb);
-                sp[x][0][pr] = pack_hi(xa, xb);
-                sp[x][1][pr] = pack_hi(ra, rb);
-                sp[x][2][pr] = pack_hi(la, lb);
+                unsigned w[3];
+                split_pair(xa, xb, w);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) sp[x][p][pr] = w[p];
             }
 #pragma unroll
             for (int term = 0; term < 6; ++term)
@@ -1191,11 +1187,10 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
         const int s = is_x ? slice - 4 * DOCT : slice, oct = s >> 2, pr = s & 3;
         const v4f v = is_x ? r.x[pr >> 1] : r.d[2 * oct + (pr >> 1)];
         const float xa = v[2 * (pr & 1)], xb = v[2 * (pr & 1) + 1];
-        const float ra = xa - top16(xa), rb = xb - top16(xb);
-        const float la = ra - top16(ra), lb = rb - top16(rb);
-        sp[0][pr] = pack_hi(xa, xb);
-        sp[1][pr] = pack_hi(ra, rb);
-        sp[2][pr] = pack_hi(la, lb);
+        unsigned w[3];
+        split_pair(xa, xb, w);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) sp[p][pr] = w[p];
         if (!is_x && (pr & 1) == 1 && counted) bsum[2 * oct + (pr >> 1)] += v;
         if (pr == 3) {
 #pragma unroll
