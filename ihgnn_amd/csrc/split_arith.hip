@@ -113,12 +113,14 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
 // An in-order wave that does both jobs stalls its MFMA stream on every wait of the service work (that form: 1,520 us, this one 1,370,
 // same box, kbench scale).  Images, contraction image and id ring are double-buffered: one barrier per tile.  The two halves of a tile
 // range sit on one XCD, so the second read of a dout row hits that L2.
-// UR (hyperedges numbered by user; g is [E, 2, d]): the user-slot gradient is not stored per hyperedge.  The product rule leaves it in a
-// transposed LDS image [column][row]; a phase later service wave w scans columns 16 w .. 16 w + 15 row by row (inclusive sums of the runs: a
-// run start, known from one ballot over the tile's user ids, resets the running sum through a scalar factor), then stores the few
-// finished runs (their sums fetched four at a time) to dh[user].  (user, destination, running sums) are carried from tile to tile, which
-// is why a workgroup takes a CONTIGUOUS tile range; the first and the last run of a range may continue in the neighbours and go to the
-// boundary table that interact.hip's user_boundary_fixup_kernel adds up (indexed by tile range here, shared by the two halves).
+// UR (hyperedges numbered by user; g is [E, 2, d]): the user-slot gradient is not stored per hyperedge.  The product rule leaves it in an
+// LDS image [row][column]; a phase later service wave w adds up the image's rows 8 w .. 8 w + 7 (lane = column; a run = the rows of one
+// user, its starts from one ballot over the tile's user ids) and stores the runs inside its window to dh[user] as 256-byte row pieces; a
+// phase after that every wave closes the run that ends in its window from the carried sum and the windows' end pieces.  (user and -
+// through LDS - the open run's sum) are carried from tile to tile, which is why a workgroup takes a CONTIGUOUS tile range; the first and the last run of a
+// range may continue in the neighbours and go to the boundary table that interact.hip's user_boundary_fixup_kernel adds up (indexed by
+// tile range here, shared by the two halves).  (First form: every wave scanned 16 columns of all 32 rows with a scalar reset factor and
+// wrote the inclusive sums back for an emit loop - four times the additions on a quarter of the lanes, three LDS round trips in series.)
 // D = 128: two column halves of 64 per tile range.  D = 256: eight parts of 32 columns (the weight planes are 1.5 MB), the dout tile is 32 KB
 // and every part splits it again.  D = 64: one workgroup holds all of it.  No user reduction at 64 / 256.
 // NBLK = 3 (order 2): matrix wave 3 has no block and only keeps the barriers.
@@ -131,10 +133,12 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     constexpr int TE = kSplitTE, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, KB = D / 32, RB = 2 * D;
     constexpr int SWZ = RB / 16 - 1 < 15 ? RB / 16 - 1 : 15;            // the row swizzle stays inside a row (D = 64: rows of 8 chunks)
     constexpr int DOCT = D / 64, EX = HC / 32;                          // per service thread: dout octets, 4-column groups of the product rule
-    constexpr int DZ = HC + 4, UT = TE + 4, GS = UR ? 2 : 3;
+    constexpr int DZ = HC + 4, UTS = HC + 4, GS = UR ? 2 : 3;
     __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][RB];
     __shared__ __attribute__((aligned(16))) float dzimg[2][4][TE][DZ];
-    __shared__ __attribute__((aligned(16))) float utile[UR ? 2 : 1][UR ? HC : 1][UT];     // transposed: [column][row]
+    __shared__ __attribute__((aligned(16))) float utile[UR ? 2 : 1][UR ? TE : 1][UTS];    // user-slot gradients of a tile, [row][column of the half]
+    __shared__ float ucarry[2][UR ? HC : 1];                              // sum so far of the run that is open when tile t begins: [t & 1]
+    __shared__ float uhead[2][4][UR ? HC : 1], utail[2][4][UR ? HC : 1];  // per 8-row window of a tile: sum before its first run start / after its last
     __shared__ int ids[8][3 * TE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         if (UR && half == 0 && tid == 0) bnd_user[2 * range] = bnd_user[2 * range + 1] = -1;
         return;
     }
-    const int n_phases = n_my + (UR ? 2 : 1);
+    const int n_phases = n_my + (UR ? 3 : 1);
 
     if (wave >= 4) {
         // ---------------- service waves: 256 threads, thread -> hyperedge row, dout octets o and o + 8, member / gradient columns 4 o .. and 32 + 4 o ..
@@ -207,10 +211,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                     g_i += z_uqi * (hu * hq);
                 }
                 const bool live = e < n_edges;
-                if (UR) {                                                // rows past the end hold zeros for the scan
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) utile[(k - 1) & 1][c + i][row] = live ? g_u[i] : 0.f;
-                }
+                if (UR) *reinterpret_cast<v4f*>(&utile[(k - 1) & 1][row][c]) = live ? g_u : v4f{0.f, 0.f, 0.f, 0.f};     // (rows past the end: zeros for the sums)
                 if (live) {
                     float* dst = g_out + e * (GS * D) + HC * half + c;
                     if (!UR) {
@@ -222,60 +223,93 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 }
             }
         };
-        // UR: service wave w scans columns 16 w .. 16 w + 15 of the half (lane & 15; the other lanes repeat them) of the tile whose product
-        // rule ran a phase ago, carrying (user, destination, running sums) from tile to tile (scheme: the comment at the head of this kernel)
+        // UR, lane = column of the half (64 lanes, 256-byte stores); a run = the rows of one user, its starts come from one ballot over the
+        // tile's user ids.  A wave issues at most one instruction every four cycles whatever its kind, so what counts here is the number of
+        // instructions - scalar ones included - on the service waves' path through a phase:
+        //   tile t, phase t + 2: service wave w forms the running sums of rows 8 w .. 8 w + 7 (read at the START of the phase; a run start
+        //     resets the sum through a scalar factor: two instructions per row, no branch), leaves the sum before the window's first run
+        //     start and the one after its last in LDS and stores the runs that lie inside the window (a loop over the window's run starts);
+        //   phase t + 3: wave w closes the run that ends at ITS window's first run start: carried sum (when no run started earlier in the
+        //     tile) + the end sums of the windows since + its own start sum, added in that order; wave 3 leaves the new carried sum.
+        // Every wave keeps the open run's user and whether it still is the range's first run.
         int cur_user = -1, first_user = -1;
-        float run_sum = 0.f, carry_prev = 0.f;
+        bool first_run_open = true;                                      // no run has ended yet in this range
         float* const first_slot = UR ? bnd_val + static_cast<int64_t>(2 * range) * D : nullptr;
-        float* run_dst = first_slot;
-        const int ucol = 16 * (wave - 4) + (lane & 15), colg = HC * half + ucol;
-        auto scan_and_emit = [&](int k) {                                // tile k, 0 <= k < n_my
-            const int* idk = ids[k & 7];
-            const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + k) * TE));
+        const int colg = HC * half + lane, win = wave - 4;
+        uint64_t heads_prev = 0;                                         // run starts / user ids / rows of the tile whose windows were summed a phase ago
+        int uid_prev = 0, rows_prev = 0;
+        auto run_target = [&](int t, int r, int uid) {                   // destination of the run that starts at row r of tile t
+            return (t == 0 && r == 0) ? first_slot : dh_user + static_cast<int64_t>(__builtin_amdgcn_readlane(uid, r)) * ld_dh;
+        };
+        auto load_window = [&](int t, float (&v)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = utile[t & 1][8 * win + i][lane];
+        };
+        auto sum_window = [&](int t, const float (&v)[8]) {              // tile t, 0 <= t < n_my
+            const int* idk = ids[t & 7];
+            const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + t) * TE));
             const int r = lane < rows ? lane : rows - 1;
             const int uid = idk[r * 3];
             const int prev_uid = r == 0 ? cur_user : idk[(r - 1) * 3];
-            const uint64_t mask = __ballot(lane < rows && uid != prev_uid);
-            carry_prev = run_sum;
-            float* col = utile[k & 1][ucol];
+            const uint64_t m = __ballot(lane < rows && uid != prev_uid);
+            heads_prev = m;
+            uid_prev = uid;
+            rows_prev = rows;
+            const unsigned mw = static_cast<unsigned>(m >> (8 * win)) & 0xffu;
+            float pre[8], sum = 0.f;                                     // (rows past the end hold zeros and start no run)
 #pragma unroll
-            for (int x0 = 0; x0 < TE; x0 += 4) {
-                v4f v = *reinterpret_cast<const v4f*>(col + x0);
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const float keep = (mask >> (x0 + x)) & 1 ? 0.f : 1.f;
-                    run_sum = run_sum * keep + v[x];
-                    v[x] = run_sum;
-                }
-                *reinterpret_cast<v4f*>(col + x0) = v;
+            for (int i = 0; i < 8; ++i) {
+                sum = sum * ((mw >> i) & 1 ? 0.f : 1.f) + v[i];
+                pre[i] = sum;
             }
-            uint64_t m = mask;
-            while (m != 0) {                                             // the finished runs, four run starts at a time
-                int x[4];
-                bool have[4];
+            utail[t & 1][win][lane] = sum;
+            if (mw != 0) {                                               // (0.85 run starts per window on C3)
+                auto before = [&](int i) {                               // running sum in front of window row i
+                    float x = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    have[i] = m != 0;
-                    x[i] = have[i] ? __builtin_ctzll(m) : 1;
-                    m = have[i] ? m & (m - 1) : 0;
-                }
-                float done[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) done[i] = col[x[i] == 0 ? 0 : x[i] - 1];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (!have[i]) continue;
-                    const int user = __builtin_amdgcn_readlane(uid, x[i]);
-                    if (cur_user >= 0) {
-                        if (lane < 16) run_dst[colg] = x[i] == 0 ? carry_prev : done[i];
-                        run_dst = dh_user + static_cast<int64_t>(user) * ld_dh;
-                    } else {
-                        first_user = user;
-                    }
-                    cur_user = user;
+                    for (int j = 0; j < 7; ++j) x = i == j + 1 ? pre[j] : x;
+                    return x;
+                };
+                unsigned left = mw;
+                int start = __builtin_ctz(left);
+                uhead[t & 1][win][lane] = before(start);
+                for (left &= left - 1; left != 0; left &= left - 1) {
+                    const int next = __builtin_ctz(left);
+                    run_target(t, 8 * win + start, uid)[colg] = before(next);
+                    start = next;
                 }
             }
         };
+        struct Chain {
+            float tail[4], head, carry;
+        };
+        auto load_chain = [&](int t, Chain& c) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) c.tail[w] = utail[t & 1][w][lane];
+            c.head = uhead[t & 1][win][lane];
+            c.carry = ucarry[t & 1][lane];
+        };
+        auto chain_windows = [&](int t, const Chain& c) {                // tile t, a phase after sum_window(t)
+            const unsigned m = static_cast<unsigned>(heads_prev);
+            const unsigned before_me = m & ((1u << (8 * win)) - 1u);     // run starts in earlier windows of the tile
+            const int p = before_me != 0 ? (31 - __builtin_clz(before_me)) >> 3 : -1;            // the last earlier window that has one
+            if (((m >> (8 * win)) & 0xffu) != 0 || win == 3) {
+                float sum = p < 0 ? c.carry : 0.f;
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    if (w < win && w >= p) sum += c.tail[w];
+                if (((m >> (8 * win)) & 0xffu) != 0) {                   // the open run ends at this window's first run start
+                    if (p >= 0) run_target(t, 31 - __builtin_clz(before_me), uid_prev)[colg] = sum + c.head;
+                    else if (cur_user >= 0) (first_run_open ? first_slot : dh_user + static_cast<int64_t>(cur_user) * ld_dh)[colg] = sum + c.head;
+                    sum = 0.f;
+                }
+                if (win == 3) ucarry[(t + 1) & 1][lane] = sum + c.tail[3];
+            }
+            if (t == 0) first_user = __builtin_amdgcn_readlane(uid_prev, 0);
+            if (m != 0) first_run_open = t == 0 && m == 1u;
+            cur_user = __builtin_amdgcn_readlane(uid_prev, rows_prev - 1);
+        };
+        if (UR && st < HC) ucarry[0][st] = 0.f;
         if (st < 3 * TE) {
             ids[0][st] = fetch_id(0);
 #pragma unroll
@@ -289,6 +323,12 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         __syncthreads();
         int id_carry = 0;
         auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3]) {
+            float wrows[8];
+            Chain chain;
+            if (UR) {                                                    // LDS reads of this phase's run sums, used at its end
+                if (k >= 2 && k - 2 < n_my) load_window(k - 2, wrows);
+                if (k >= 3) load_chain(k - 3, chain);
+            }
             if (k >= 1 && k + 2 < n_my && st < 3 * TE) ids[(k + 2) & 7][st] = id_carry;     // requested in the previous phase
             load_members(k, hm_cur);                                     // unconditional: a branch around requests costs whole-set register copies
             load_dout(k + 2, fill);
@@ -299,7 +339,10 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * DOCT - 2]), "+v"(fill[2 * DOCT - 1]));     // (in order: the last delivered = all delivered)
             asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));
             if (k >= 1 && k - 1 < n_my) epilogue(k, hm_prev);
-            if (UR && k >= 2) scan_and_emit(k - 2);
+            if (UR) {
+                if (k >= 3) chain_windows(k - 3, chain);                 // (before the next tile's ballot: it compares with the open run's user)
+                if (k >= 2 && k - 2 < n_my) sum_window(k - 2, wrows);
+            }
             __syncthreads();
         };
         int k = 0;
@@ -311,9 +354,10 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         if (k < n_phases) phase(k, dr1, dr0, hm0, hm1);
         if (UR) {
             // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
-            const bool one_run = run_dst == first_slot;
-            if (cur_user >= 0 && lane < 16) {
-                if (one_run) run_dst[colg] = run_sum;
+            const bool one_run = first_run_open;
+            if (cur_user >= 0 && wave == 4) {
+                const float run_sum = ucarry[n_my & 1][lane];            // (written before the last barrier)
+                if (one_run) first_slot[colg] = run_sum;
                 else bnd_val[static_cast<int64_t>(2 * range + 1) * D + colg] = run_sum;
             }
             if (half == 0 && st == 0) {
