@@ -17,12 +17,14 @@ also the per-GPU replica shape of C4).  --config C2 / C1 / C5 select the others 
 touches the GPU and forwards rank 0's JSON line; under `python -m torch.distributed.run` it uses the ranks it was given.
 
 One JSON line is printed by rank 0.  It carries
-  roofline                    K5 (node->hyperedge gather-sum) against the HBM roofline: `achieved` = COMPULSORY HBM bytes per launch
-                              (every touched node row once + the [E,d] store + the ids) / the kernel's average duration measured with
-                              HIP events on the launch stream inside the timed region; `algorithmic_gbs` = the SURVEY §8 d3 byte model
-                              (16 d + 12 B per hyperedge, row re-reads counted - they are served by L2 / Infinity Cache, so this rate
-                              may exceed the HBM peak and is NOT used for `frac`); `traffic` = PMC-measured HBM bytes per launch
-                              (profiles/r2/pmc_traffic_<config>.json) when committed for this exact workload;
+  roofline                    the aggregation kernel the step is dominated by, against the HBM roofline: K5 (node->hyperedge gather-sum)
+                              where the step launches it, else - the layer-0 backward forms the hyperedges' cotangents inside the
+                              member-gradient kernel - K7's hyperedge->node launch.  `achieved` = COMPULSORY HBM bytes per launch (every
+                              source row once + stores + ids) / the kernel's average duration measured with HIP events on the launch
+                              stream inside the timed region; `algorithmic_gbs` = the SURVEY §8 d3 byte model (every gathered row counted;
+                              NOT used for `frac`); `traffic` = PMC-measured bytes per launch (profiles/r2/pmc_traffic_<config>.json)
+                              when committed for this exact workload;
+  roofline_node_to_hyperedge  K5 at this workload, launched on its own after the timed region (same fields);
   roofline_hyperedge_to_node  one object per K7 launch role (edge features -> nodes, member gradients -> nodes, two-hop ...), each with
                               its own byte counts;
   roofline_interaction        the order-2/3 contraction - the kernels that own most of a C3 / C5 step - against the matrix-core peak of the
@@ -297,10 +299,10 @@ def main():
 
     for k in range(args.warmup):
         step(k)
-    # Inside the timed region only the roofline kernel (K5) is bracketed by HIP events: a pair of timing events costs a few
+    # Inside the timed region only the roofline kernel (K5 where the step launches it, else K7's hyperedge -> node launch) is bracketed by HIP events: a pair of timing events costs a few
     # microseconds of stream time, and bracketing all launches of a step would inflate it.
     if not args.no_kernel_events:
-        profiler.start(only={'edge_gather_sum'})
+        profiler.start(only={'edge_gather_sum', 'k7.edges_to_nodes'})
     fence()
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
@@ -311,7 +313,8 @@ def main():
     kernels = profiler.summary() if not args.no_kernel_events else {}
     final_loss = float(last.item())
 
-    table, table_steps, restricted_elapsed, fwd_elapsed, stress, eval_stats, f32_elapsed = {}, min(args.steps, 5), None, None, None, None, None
+    table, table_steps, restricted_elapsed, fwd_elapsed, stress, eval_stats, f32_elapsed, k5_alone = {}, min(args.steps, 5), None, None, None, None, None, None
+    N_nodes = w.node_count
     if not args.no_extras:
         # per-kernel table (K7 roles, MFMA kernels): a second, untimed pass over the same batches with every launch bracketed
         if not args.no_kernel_events:
@@ -357,6 +360,19 @@ def main():
             torch.cuda.synchronize()
             fwd_elapsed = (time.perf_counter() - t1) / n_f
         stress = gather_stress(dev) if rank == 0 else None
+        # K5 at this workload, launched on its own (it is not part of a step whose layer-0 backward forms the hyperedges' cotangents in the
+        # member-gradient kernel): the node -> hyperedge gather-sum of a [N, d] table with the layer's Dv^-1 scaling
+        if rank == 0 and not args.no_kernel_events:
+            from ihgnn_amd import ops
+            xk = torch.randn(N_nodes, dim, device=dev)
+            for _ in range(2):
+                ops.edge_gather_sum_raw(xk, layout.i3, layout.inv_deg)
+            profiler.start(only={'edge_gather_sum'})
+            for _ in range(6):
+                ops.edge_gather_sum_raw(xk, layout.i3, layout.inv_deg)
+            profiler.stop()
+            k5_alone = profiler.summary().get('edge_gather_sum')
+            del xk
         # evaluation: cached propagation + fused scoring / running top-10 of 4,096 (user, query) pairs against every item
         eval_stats = None
         if rank == 0:
@@ -389,31 +405,47 @@ def main():
     touched = int((layout.degree > 0.5).sum().item())
     k5_compulsory = touched * row + E * row + 12 * E          # every touched node row once + the [E,d] store + the ids
     k5_algorithmic = E * (16 * dim + 12)                       # 3 ids + 3 row reads + 1 row write per hyperedge
-    roofline = None
-    traffic = traffic_source = None                            # HBM bytes per K5 launch from the committed PMC passes (profiles/)
+    pmc = None                                                 # HBM bytes per launch from the committed PMC passes (profiles/)
     for pmc_file in (os.path.join(REPO, 'profiles', 'r2', f'pmc_traffic_{args.config}.json'), os.path.join(REPO, 'profiles', 'r1', 'pmc_traffic.json')):
         if os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file))
-            if (pmc.get('workload'), pmc.get('dim'), pmc.get('edges')) == (args.config, dim, E) and 'edge_gather_sum' in pmc:
-                traffic = pmc['edge_gather_sum']['hbm_bytes_per_launch']
-                traffic_source = f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled (gfx950) ({os.path.relpath(pmc_file, REPO)})'
+            cand = json.load(open(pmc_file))
+            if (cand.get('workload'), cand.get('dim'), cand.get('edges')) == (args.config, dim, E):
+                pmc, pmc_name = cand, os.path.relpath(pmc_file, REPO)
                 break
-    if 'edge_gather_sum' in kernels:
-        k5 = kernels['edge_gather_sum']
-        t = k5['avg_us'] * 1e-6
-        achieved = k5_compulsory / t / 1e9
-        roofline = dict(bound='hbm', kernel='edge_gather_sum (K5 node->hyperedge gather-sum; first-order hyperedge features and the backward of K7)',
-                        achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
-                        bytes='compulsory HBM bytes per launch: touched node rows once + [E,d] store + ids', bytes_per_launch=k5_compulsory,
-                        algorithmic_bytes_per_launch=k5_algorithmic, algorithmic_gbs=round(k5_algorithmic / t / 1e9, 1),
-                        algorithmic_note='16 d + 12 B per hyperedge (SURVEY §8 d3) counts three row gathers per hyperedge; repeats are served by L2 / '
-                                         'Infinity Cache, so this rate is not an HBM rate and may exceed the peak',
-                        traffic=traffic, traffic_gbs=round(traffic / t / 1e9, 1) if traffic else None,
-                        traffic_frac=round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if traffic else None, traffic_source=traffic_source,
-                        traffic_note='FETCH_SIZE / WRITE_SIZE count at the L2 <-> fabric boundary: L2-miss bytes, Infinity-Cache hits included - an upper '
-                                     'bound of the HBM bytes; traffic above the compulsory bytes = rows re-fetched after leaving L2' if traffic else None,
-                        avg_us=round(k5['avg_us'], 2), launches=k5['launches'], hyperedges_per_s=round(E / t, 1),
-                        measured='HIP events on the launch stream, inside the timed region')
+
+    def hbm_roofline(kernel, what, rec, compulsory, algorithmic, bytes_note, algorithmic_note, pmc_key, measured):
+        t = rec['avg_us'] * 1e-6
+        achieved = compulsory / t / 1e9
+        traffic = pmc[pmc_key]['hbm_bytes_per_launch'] if pmc is not None and pmc_key in pmc else None
+        return dict(bound='hbm', kernel=f'{kernel} ({what})', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
+                    bytes=bytes_note, bytes_per_launch=compulsory, algorithmic_bytes_per_launch=algorithmic, algorithmic_gbs=round(algorithmic / t / 1e9, 1),
+                    algorithmic_note=algorithmic_note, traffic=traffic, traffic_gbs=round(traffic / t / 1e9, 1) if traffic else None,
+                    traffic_frac=round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    traffic_source=f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled (gfx950) ({pmc_name}: {pmc[pmc_key].get("source", "in-situ pass")})' if traffic else None,
+                    traffic_note='FETCH_SIZE / WRITE_SIZE count at the L2 <-> fabric boundary: L2-miss bytes, Infinity-Cache hits included - an upper '
+                                 'bound of the HBM bytes; traffic above the compulsory bytes = rows re-fetched after leaving L2' if traffic else None,
+                    avg_us=round(rec['avg_us'], 2), launches=rec['launches'], hyperedges_per_s=round(E / t, 1), measured=measured)
+
+    k5_args = ('edge_gather_sum', 'K5 node->hyperedge gather-sum; first-order hyperedge features and the backward of K7', None, k5_compulsory, k5_algorithmic,
+               'compulsory HBM bytes per launch: touched node rows once + [E,d] store + ids',
+               '16 d + 12 B per hyperedge (SURVEY §8 d3) counts three row gathers per hyperedge; repeats are served by L2 / Infinity Cache, so this rate '
+               'is not an HBM rate and may exceed the peak', 'edge_gather_sum')
+    roofline = k5_outside = None
+    if 'edge_gather_sum' in kernels:                           # the step launches K5: it is the bracketed kernel
+        roofline = hbm_roofline(*k5_args[:2], kernels['edge_gather_sum'], *k5_args[3:], 'HIP events on the launch stream, inside the timed region')
+    elif 'k7.edges_to_nodes' in kernels:
+        # no K5 launch in this step (the layer-0 backward forms the hyperedges' cotangents inside the member-gradient kernel): the bracketed
+        # kernel is the hyperedge -> node launch of the interactive layer, the largest of the seven K7 launches that own 40 % of the step
+        k7_compulsory = E * row + 12 * E + N * (row + 8)       # every hyperedge row once + the member lists + the [N,d] store and its row pointers
+        k7_algorithmic = 3 * E * row + 12 * E + N * (row + 8)  # every (node, hyperedge) incidence reads its row
+        roofline = hbm_roofline('node_segment_sum, role k7.edges_to_nodes', 'K7 hyperedge->node: [E,d] hyperedge features -> [N,d] x Dv^-1, the forward of the interactive layer',
+                                kernels['k7.edges_to_nodes'], k7_compulsory, k7_algorithmic,
+                                'compulsory HBM bytes per launch: every hyperedge row once + member lists + [N,d] store',
+                                '12 d + 12 B per hyperedge + (4 d + 8) B per node (SURVEY §8 d3): every incidence reads its 4 d-byte row; a row is read by its three '
+                                'members at unrelated times out of a table (E x 4 d B) far larger than L2 + Infinity Cache, so most of these ARE fabric reads',
+                                'k7.edges_to_nodes', 'HIP events on the launch stream, inside the timed region')
+    if k5_alone is not None:
+        k5_outside = hbm_roofline(*k5_args[:2], k5_alone, *k5_args[3:], 'HIP events on the launch stream; six launches of their own after the timed region (no step launches K5)')
     mfma_roof = None
     if args.layer == 'ihgnn' and args.order in (2, 3) and 'interact_fwd' in table and 'interact_bwd' in table:
         # the order-2/3 contraction of layer 0 is the only MFMA-bound piece: 2 m d^2 flop per hyperedge forward
@@ -468,13 +500,15 @@ def main():
     if fwd_elapsed is not None:
         out['fwd_only_hyperedges_per_s'] = round(E * layers / fwd_elapsed, 1)
         out['fwd_only_ms'] = round(1e3 * fwd_elapsed, 4)
+    if k5_outside is not None:
+        out['roofline_node_to_hyperedge'] = k5_outside
     if stress is not None:
         out['roofline_gather_stress'] = stress
     if eval_stats is not None:
         out['evaluation_top10'] = eval_stats
     if table:
         out['kernels_us'] = {name: {'avg_us': round(v['avg_us'], 2), 'launches_per_step': v['launches'] / table_steps} for name, v in table.items()}
-        out['kernels_us_note'] = f'HIP events around every launch, {table_steps} untimed steps after the timed region; the timed region brackets K5 only'
+        out['kernels_us_note'] = f'HIP events around every launch, {table_steps} untimed steps after the timed region; the timed region brackets the `roofline` kernel only'
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.config, args.layer, layers, args.order, dim, args.cpu_scale)
     print(json.dumps(out), flush=True)

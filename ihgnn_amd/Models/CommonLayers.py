@@ -8,6 +8,8 @@ order 1 / 2 / 3; column blocks u, q, i, uq, qi, iu, uqi) but never builds the ``
   instead of ``E*3*d*d`` - and the hyperedge value is the gather-sum ``P[u] + P[q] + P[i]`` (HIP kernel K5);
 * the product blocks (orders 2, 3) are contracted inside the fused HIP kernel ``ihg_interact_fwd``.
 """
+from typing import Optional
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -39,6 +41,14 @@ class FeatureInteractor(nn.Module):
         return torch.cat([F.linear(node_features[:u_end], w[:, :d], b),
                           F.linear(node_features[u_end:q_end], w[:, d:2 * d]),
                           F.linear(node_features[q_end:], w[:, 2 * d:3 * d])])
+
+    def to_nodes(self, node_features: Tensor, out_scale: Optional[Tensor] = None, rows: Optional[Tensor] = None) -> Tensor:
+        """``out_scale * H forward(node_features)``: the hyperedge features taken on to the nodes (``GnnLayers.py:229-236``).  Orders 2 / 3
+        on the hoisted path run as one autograd node whose backward forms the hyperedges' cotangents inside the member-gradient kernel."""
+        layout = self.dataset.hypergraph.layout
+        if self.max_order > 1 and not ops.interact_from_nodes_supported(node_features, self.aggregation.weight):
+            return ops.interact_to_nodes(node_features, self.first_order(node_features), self.aggregation.weight, layout, self.max_order, out_scale, rows)
+        return ops.node_segment_sum(self(node_features), layout, out_scale=out_scale, rows=rows)
 
     def forward(self, node_features: Tensor) -> Tensor:
         layout = self.dataset.hypergraph.layout

@@ -82,8 +82,7 @@ class IHGNNLayer(nn.Module):
             # first-order layer: hoisted node-level blocks, then node -> hyperedge -> node fused into one two-hop pass
             return ops.node_two_hop(self._first_order_of_input(input_features), self.layout, out_scale=self.layout.inv_deg, rows=output_rows)
         h = _transform(self.feature_transform, input_features, self.layout)
-        edge_features = self.feature_interactor(h)
-        return ops.node_segment_sum(edge_features, self.layout, out_scale=self.layout.inv_deg, rows=output_rows)
+        return self.feature_interactor.to_nodes(h, out_scale=self.layout.inv_deg, rows=output_rows)
 
     def _first_order_of_input(self, x: Tensor) -> Tensor:
         """``first_order(feature_transform(x))``.  With no non-linearity between them (``GnnLayers.py:224-227`` +

@@ -1963,7 +1963,10 @@ template <int NBLK>
 void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32_t* i3, const float* wq, const float* dout, int64_t ld_dout,
                               float* g, float* slabs, float* dw, int64_t ld_dw, int64_t n_edges, hipStream_t s,
                               float* dh_user = nullptr, int64_t ld_dh = 0, float* bnd_val = nullptr, int32_t* bnd_user = nullptr,
-                              const float* w_raw = nullptr, int64_t ld_w = 0, void* planes = nullptr) {
+                              const float* w_raw = nullptr, int64_t ld_w = 0, void* planes = nullptr,
+                              const float* dy_scale = nullptr, float* dout_store = nullptr, int64_t ld_store = 0) {
+    // dout_store != nullptr (the caller has checked the split kernels take the shape): `dout` is the node-level cotangent, the member-gradient
+    // kernel forms the hyperedges' cotangents from it and leaves them in dout_store for everything after it
 #define IHG_MEM(D)                                                                                                          \
     {                                                                                                                       \
         constexpr int TE = D == 32 ? 128 : 64;                                                                              \
@@ -1980,8 +1983,13 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     const bool vector_io = aligned16(g) && ld_h < (int64_t{1} << 30);     // the pipelined form stores g as 16-byte vectors
     if (planes != nullptr && split_members_ok(dim, NBLK == 4 ? 3 : 2, g, ld_h, ld_dout, dout, dh_user != nullptr)) {   // bf16-split contraction
         int entries = 0;
-        launch_members_split(dim, NBLK == 4 ? 3 : 2, h, ld_h, i3, w_raw, ld_w, planes, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, &entries, s);
+        launch_members_split(dim, NBLK == 4 ? 3 : 2, h, ld_h, i3, w_raw, ld_w, planes, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, &entries, s,
+                             dy_scale, dout_store, ld_store);
         if (dh_user != nullptr) hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(entries), dim3(128), 0, s, bnd_val, bnd_user, entries, dim, dh_user, ld_dh);
+        if (dout_store != nullptr) {
+            dout = dout_store;
+            ld_dout = ld_store;
+        }
     } else if (strip_bwd_ok(dim, g, ld_h) && dim == 256) {               // wq is strip-packed
         const int grid = static_cast<int>(std::min<int64_t>((n_edges + kStrip256TE - 1) / kStrip256TE, kStrip256Grid));
         hipLaunchKernelGGL((interact_bwd_members_strip256_kernel<NBLK>), dim3(grid, 4), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges);
@@ -2112,6 +2120,37 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
     if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes);
     else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes);
     return check_launch("ihg_interact_bwd_user_reduced");
+}
+
+int32_t ihg_interact_bwd_gathered_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_dy) {
+    return ihg_interact_bwd_user_reduced_supported(dim, order, ld_h) && split_arith_enabled() && ld_dy >= dim && ld_dy % 4 == 0 && ld_dy < (int64_t{1} << 30) ? 1 : 0;
+}
+
+int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
+                              const float* dy, int64_t ld_dy, const float* dy_scale, float* dout, int64_t ld_dout, float* g2, float* dh, int64_t ld_dh,
+                              float* dw, int64_t ld_dw, void* workspace, int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream) {
+    if (!ihg_interact_bwd_gathered_supported(dim, order, ld_h, ld_dy))
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: shape or arithmetic mode not supported (ask ihg_interact_bwd_gathered_supported)");
+    const int k = order == 3 ? 7 : 6;
+    if (n_edges <= 0 || ld_h < dim || ld_dout < dim || ld_dh < dim || ld_w < static_cast<int64_t>(k) * dim || ld_dw < static_cast<int64_t>(k) * dim)
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: bad size");
+    if (h == nullptr || i3 == nullptr || w == nullptr || dy == nullptr || dout == nullptr || g2 == nullptr || dh == nullptr || dw == nullptr || workspace == nullptr)
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: null pointer");
+    if (ld_w % 4 || ld_dout % 4 || !aligned16(h) || !aligned16(w) || !aligned16(dy) || !aligned16(dout) || !aligned16(g2) || !aligned16(workspace))
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: rows must be 16-byte aligned");
+    if (workspace_bytes < ihg_interact_bwd_workspace_bytes(n_edges, dim, order)) return fail(IHG_ERR_WORKSPACE, "ihg_interact_bwd_gathered: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblk = order == 3 ? 4 : 3;
+    float* wq = static_cast<float*>(workspace);                          // (the fp32 fragment image of w is not needed by the split kernels)
+    float* slabs = wq + packed_weight_floats(dim, order);
+    float* bnd_val = slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order);
+    int32_t* bnd_user = reinterpret_cast<int32_t*>(bnd_val + 2LL * kPipeGrid * dim);
+    void* planes = bnd_user + 2LL * kPipeGrid;
+    if (!split_members_ok(dim, order, g2, ld_h, ld_dy, dy, true) || !split_weight_ok(dim, order, ld_h, ld_dout, dout))
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: the split kernels do not take these strides / alignments");
+    if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dy, ld_dy, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes, dy_scale, dout, ld_dout);
+    else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dy, ld_dy, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes, dy_scale, dout, ld_dout);
+    return check_launch("ihg_interact_bwd_gathered");
 }
 
 int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,

@@ -124,12 +124,21 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
 // D = 128: two column halves of 64 per tile range.  D = 256: eight parts of 32 columns (the weight planes are 1.5 MB), the dout tile is 32 KB
 // and every part splits it again.  D = 64: one workgroup holds all of it.  No user reduction at 64 / 256.
 // NBLK = 3 (order 2): matrix wave 3 has no block and only keeps the barriers.
-template <int D, bool UR, int NBLK>
+// GATHER (D = 128, UR): there is no dout tensor yet - the cotangent of a hyperedge is the scaled sum of its three members' rows of a
+// node-level cotangent dy ([N, d]; dout[e] = sum_m dy_scale[m] dy[m], the transpose of the hyperedge -> node pass that follows the
+// interactive step in an IHGNN layer).  The service waves gather the three rows instead of streaming one, form the sum in the order of
+// the node -> hyperedge kernel (K5) and store it to dout_store (each column half its 64 columns) for the weight-gradient kernel and the
+// first-order scatter: K5's launch - memory-bound, on a chip whose issue slots it leaves idle - disappears into a kernel that is
+// issue-bound and leaves the memory pipes idle.
+template <int D, bool UR, int NBLK, bool GATHER = false>
 __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
                                                                                       const v4u* __restrict__ wsp, const float* __restrict__ dout, int64_t ld_dout,
                                                                                       float* __restrict__ g_out, int64_t n_edges, float* __restrict__ dh_user,
-                                                                                      int64_t ld_dh, float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user) {
+                                                                                      int64_t ld_dh, float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user,
+                                                                                      const float* __restrict__ dy_scale = nullptr,
+                                                                                      float* __restrict__ dout_store = nullptr, int64_t ld_store = 0) {
     static_assert(D == 128 || ((D == 256 || D == 64) && !UR), "shapes");
+    static_assert(!GATHER || (D == 128 && UR), "the gathering form exists where the layer's backward uses it");
     constexpr int TE = kSplitTE, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, KB = D / 32, RB = 2 * D;
     constexpr int SWZ = RB / 16 - 1 < 15 ? RB / 16 - 1 : 15;            // the row swizzle stays inside a row (D = 64: rows of 8 chunks)
     constexpr int DOCT = D / 64, EX = HC / 32;                          // per service thread: dout octets, 4-column groups of the product rule
@@ -173,6 +182,40 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             for (int x = 0; x < DOCT; ++x) {
                 dr[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
                 dr[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
+            }
+        };
+        // GATHER: `dout` is the node-level cotangent dy; rows of the three members of hyperedge `row` of tile k, and their scales
+        struct Raw {
+            v4f r[3][2 * DOCT];
+            float s[3];
+        };
+        auto load_gather = [&](int k, Raw& raw) {
+            const int* idk = ids[k & 7] + row * 3;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int id = idk[m];
+                const float* src = row_at(dout, id, ldd) + 8 * o;
+#pragma unroll
+                for (int x = 0; x < DOCT; ++x) {
+                    raw.r[m][2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
+                    raw.r[m][2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
+                }
+                raw.s[m] = dy_scale != nullptr ? dy_scale[id] : 1.f;
+            }
+        };
+        auto combine = [&](int k, const Raw& raw, v4f (&dr)[2 * DOCT]) {   // K5's order: ((0 + s_u u) + s_q q) + s_i i; the half's columns go to dout_store
+#pragma unroll
+            for (int j = 0; j < 2 * DOCT; ++j) {
+                v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 3; ++m) acc += raw.s[m] * raw.r[m][j];
+                dr[j] = acc;
+            }
+            const int64_t e0 = (t0 + k) * TE;
+            if (k < n_my && e0 + row < n_edges) {
+                float* dst = dout_store + (e0 + row) * ld_store + 64 * half + 8 * o;
+                store_stream4(dst, dr[2 * half]);
+                store_stream4(dst + 4, dr[2 * half + 1]);
             }
         };
         auto load_members = [&](int k, v4f (&hm)[EX][3]) {
@@ -313,13 +356,22 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         if (st < 3 * TE) {
             ids[0][st] = fetch_id(0);
 #pragma unroll
-            for (int k = 1; k < 8; ++k) ids[k][st] = k < 3 && k < n_my ? fetch_id(k) : 0;       // (slots of tiles past the end: row 0, requested and dropped)
+            for (int k = 1; k < 8; ++k) ids[k][st] = k < 4 && k < n_my ? fetch_id(k) : 0;       // (slots of tiles past the end: row 0, requested and dropped)
         }
         __syncthreads();
         v4f dr0[2 * DOCT], dr1[2 * DOCT], hm0[EX][3], hm1[EX][3];                        // dout values of tile m in dr<m & 1>, member values in hm<m & 1>
-        load_dout(0, dr0);
-        if (n_my > 1) load_dout(1, dr1);
-        split_tile(dr0, 0);
+        Raw raw;                                                         // (GATHER) the rows behind the dout values being requested
+        if (GATHER) {                                                    // one set of dout values: a tile's sum is formed after the previous one was split
+            load_gather(0, raw);
+            combine(0, raw, dr0);
+            split_tile(dr0, 0);
+            load_gather(1, raw);
+            combine(1, raw, dr0);
+        } else {
+            load_dout(0, dr0);
+            if (n_my > 1) load_dout(1, dr1);
+            split_tile(dr0, 0);
+        }
         __syncthreads();
         int id_carry = 0;
         auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3]) {
@@ -329,15 +381,23 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 if (k >= 2 && k - 2 < n_my) load_window(k - 2, wrows);
                 if (k >= 3) load_chain(k - 3, chain);
             }
-            if (k >= 1 && k + 2 < n_my && st < 3 * TE) ids[(k + 2) & 7][st] = id_carry;     // requested in the previous phase
+            // ids of tile k + 3 (requested in the previous phase) into the ring: a phase ahead of their first readers (the gathered rows of
+            // tile k + 3 in the next phase)
+            if (k >= 1 && k + 3 < n_my && st < 3 * TE) ids[(k + 3) & 7][st] = id_carry;
             load_members(k, hm_cur);                                     // unconditional: a branch around requests costs whole-set register copies
-            load_dout(k + 2, fill);
-            if (k + 3 < n_my && st < 3 * TE) id_carry = fetch_id(k + 3);
+            if (GATHER) load_gather(k + 2, raw);
+            else load_dout(k + 2, fill);
+            if (k + 4 < n_my && st < 3 * TE) id_carry = fetch_id(k + 4);
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
             // delivery of this phase's requests, THEN everything that stores: the memory counter is in order, a wait behind a store sits out
             // the store's round trip to memory
-            asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * DOCT - 2]), "+v"(fill[2 * DOCT - 1]));     // (in order: the last delivered = all delivered)
+            if (GATHER) {
+                asm volatile("" : "+v"(raw.r[2][2 * DOCT - 2]), "+v"(raw.r[2][2 * DOCT - 1]), "+v"(raw.s[2]));
+            } else {
+                asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * DOCT - 2]), "+v"(fill[2 * DOCT - 1]));     // (in order: the last delivered = all delivered)
+            }
             asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));
+            if (GATHER) combine(k + 2, raw, fill);
             if (k >= 1 && k - 1 < n_my) epilogue(k, hm_prev);
             if (UR) {
                 if (k >= 3) chain_windows(k - 3, chain);                 // (before the next tile's ballot: it compares with the open run's user)
@@ -348,10 +408,10 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         int k = 0;
 #pragma clang loop unroll(disable)
         for (; k + 1 < n_phases; k += 2) {                                // exactly two phases per trip: the register sets come back in place
-            phase(k, dr1, dr0, hm0, hm1);
-            phase(k + 1, dr0, dr1, hm1, hm0);
+            phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1);
+            phase(k + 1, dr0, GATHER ? dr0 : dr1, hm1, hm0);
         }
-        if (k < n_phases) phase(k, dr1, dr0, hm0, hm1);
+        if (k < n_phases) phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1);
         if (UR) {
             // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
             const bool one_run = first_run_open;
@@ -1390,8 +1450,14 @@ bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t 
 namespace {
 template <int D, int NBLK>
 void launch_members_split_t(const float* h, int64_t ld_h, const int32_t* i3, const v4u* wsp, const float* dout, int64_t ld_dout, float* g, int64_t n_edges,
-                            float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user, hipStream_t s) {
+                            float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user, const float* dy_scale, float* dout_store, int64_t ld_store,
+                            hipStream_t s) {
     if constexpr (D == 128) {
+        if (dh_user != nullptr && dout_store != nullptr) {              // `dout` is the node-level cotangent: gathered, summed, stored
+            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<128, true, NBLK, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g,
+                               n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store);
+            return;
+        }
         if (dh_user != nullptr) {
             hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<128, true, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
                                dh_user, ld_dh, bnd_val, bnd_user);
@@ -1405,15 +1471,15 @@ void launch_members_split_t(const float* h, int64_t ld_h, const int32_t* i3, con
 
 void launch_members_split(int dim, int order, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
                           int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
-                          int* n_boundary_entries, hipStream_t s) {
+                          int* n_boundary_entries, hipStream_t s, const float* dy_scale, float* dout_store, int64_t ld_store) {
     v4u* wsp = static_cast<v4u*>(planes);
     const int nblk = order == 3 ? 4 : 3;
     const int items = (dim / 32) * 4 * (dim / 32) * 2 * kWave;
     hipLaunchKernelGGL(pack_planes_members_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wsp);
 #define IHG_MEMBERS(D)                                                                                                                       \
     {                                                                                                                                        \
-        if (nblk == 4) launch_members_split_t<D, 4>(h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, s);    \
-        else launch_members_split_t<D, 3>(h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, s);              \
+        if (nblk == 4) launch_members_split_t<D, 4>(h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store, s); \
+        else launch_members_split_t<D, 3>(h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store, s);           \
     }
     if (dim == 256) IHG_MEMBERS(256) else if (dim == 64) IHG_MEMBERS(64) else IHG_MEMBERS(128)
 #undef IHG_MEMBERS

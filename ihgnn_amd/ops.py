@@ -534,6 +534,74 @@ class _Interact(torch.autograd.Function):
         return dh, dp, dw, None, None
 
 
+def _gathered_backward_ok(h: Tensor, w: Tensor, dy: Tensor, layout: IncidenceLayout, order: int) -> bool:
+    lib = _lib.load()
+    n_edges, dim = layout.edge_count, int(h.shape[1])
+    return (USER_REDUCED_BACKWARD and n_edges > 0 and getattr(layout, 'user_sorted', False)
+            and n_edges * 3 * dim * 4 <= MEMBER_BUFFER_LIMIT_BYTES
+            and bool(lib.ihg_interact_bwd_gathered_supported(dim, order, _ld(h), _ld(dy)))
+            and h.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and _ld(w) % 4 == 0)
+
+
+class _InteractToNodes(torch.autograd.Function):
+    """Interactive node -> hyperedge step and the hyperedge -> node pass behind it (``GnnLayers.py:229-236``) as ONE autograd node:
+    ``y = out_scale * H interact(h, p, w)``.  Forward: the two kernels of the separate ops.  Backward: the hyperedge cotangent
+    ``sum_m out_scale[m] dy[m]`` is not produced by a node -> hyperedge launch (K5) - the member-gradient kernel gathers the three
+    ``dy`` rows of a hyperedge itself and leaves their sum for the weight gradients and the first-order scatter
+    (``ihg_interact_bwd_gathered``); where that kernel does not apply, the separate ops' sequence."""
+
+    @staticmethod
+    def forward(ctx, h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: int, out_scale: Optional[Tensor], rows: Optional[Tensor]) -> Tensor:
+        lib = _lib.load()
+        h, p, w = _rows(h, 'h'), _rows(p, 'p'), _rows(w, 'w')
+        dim = int(h.shape[1])
+        edge = torch.empty(layout.edge_count, dim, dtype=torch.float32, device=h.device)
+        ws = _workspace(int(lib.ihg_interact_fwd_workspace_bytes(layout.edge_count, dim, order)), h.device)
+        with profiler.kernel('interact_fwd', layout.edge_count, dim):
+            _lib.check(lib.ihg_interact_fwd(_ptr(h), _ld(h), _ptr(p), _ld(p), _ptr(layout.i3), _ptr(w), _ld(w), order,
+                                            _ptr(edge), _ld(edge), _ptr(ws), ws.numel() * 4, layout.edge_count, dim, _stream()),
+                       'ihg_interact_fwd')
+        mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
+        y = node_segment_sum_raw(edge, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes')
+        ctx.save_for_backward(h, w)
+        ctx.layout, ctx.order, ctx.out_scale = layout, order, out_scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        lib = _lib.load()
+        h, w = ctx.saved_tensors
+        layout, order, out_scale = ctx.layout, ctx.order, ctx.out_scale
+        dy = _rows(dy, 'dy')
+        n_edges, dim = layout.edge_count, int(h.shape[1])
+        dw = torch.zeros_like(w)
+        if _gathered_backward_ok(h, w, dy, layout, order):
+            csr_qi, qi_rows = layout.member_csr_qi()
+            dout = torch.empty(n_edges, dim, dtype=torch.float32, device=h.device)
+            g2 = torch.empty(n_edges, 2 * dim, dtype=torch.float32, device=h.device)
+            dh = torch.empty(layout.node_count, dim, dtype=torch.float32, device=h.device)
+            dh[:layout.user_count].zero_()                         # users without hyperedges are not written by the kernel
+            ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
+            with profiler.kernel('interact_bwd', n_edges, dim):
+                _lib.check(lib.ihg_interact_bwd_gathered(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(dy), _ld(dy), _ptr(out_scale),
+                                                         _ptr(dout), dim, _ptr(g2), _ptr(dh), dim, _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4,
+                                                         n_edges, dim, _stream()), 'ihg_interact_bwd_gathered')
+            node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients')
+        else:
+            dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
+            dh = _interact_backward(h, w, dout, layout, order, dw)
+        dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
+        return dh, dp, dw, None, None, None, None
+
+
+def interact_to_nodes(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: int, out_scale: Optional[Tensor] = None,
+                      rows: Optional[Tensor] = None) -> Tensor:
+    """``node_segment_sum(interact(h, p, w, layout, order), layout, out_scale, rows)`` with a backward that has no node -> hyperedge launch."""
+    if order not in (2, 3):
+        raise ValueError('interact_to_nodes handles interaction orders 2 and 3')
+    return _InteractToNodes.apply(h, p, w, layout, int(order), out_scale, rows)
+
+
 class _InteractFromNodes(torch.autograd.Function):
     """First-order blocks (typed row-GEMM) + product blocks (MFMA interact kernel) of ``FeatureInteractor`` as ONE autograd
     node, so that in the backward the first-order path's contribution to ``d h`` is accumulated by the kernel into the member

@@ -227,6 +227,19 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
                                   const float* dout, int64_t ld_dout, float* g2, float* dh, int64_t ld_dh, float* dw, int64_t ld_dw,
                                   void* workspace, int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream);
 
+/* The user-reduced backward fused with the transpose of the hyperedge -> node pass that follows the interactive step in an IHGNN layer
+ * (Models/GnnLayers.py:229-236: Y = Dv^-1 H Ef): the caller has the NODE-level cotangent dy [n_nodes, dim], and the hyperedge
+ * cotangent dout[e] = sum over the three members m of dy_scale[m] * dy[m] (dy_scale NULL: 1) - what ihg_edge_gather_sum would
+ * have produced - is formed inside the member-gradient kernel from three gathered rows; it is left in `dout` [n_edges, dim]
+ * (written, not read) for the weight gradients here and for the caller's first-order scatter.  Everything else as
+ * ihg_interact_bwd_user_reduced.  Available where ihg_interact_bwd_gathered_supported says so (dim 128, split arithmetic on).
+ */
+int32_t ihg_interact_bwd_gathered_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_dy);
+int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
+                              const float* dy, int64_t ld_dy, const float* dy_scale, float* dout, int64_t ld_dout,
+                              float* g2, float* dh, int64_t ld_dh, float* dw, int64_t ld_dw,
+                              void* workspace, int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * DEVICE: node-level dense transforms (K4 and the hoisted first-order blocks of K6).
  * Replaces nn.Linear(d, d) `feature_transform` (Models/GnnLayers.py:145, 224) and the u / q / i column blocks of

@@ -372,6 +372,57 @@ def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, monkey
     assert bool((grads[True][0][:users][isolated.to(dev())] == 0).all())
 
 
+@pytest.mark.parametrize('order,edges,users,dim,restricted', [(3, 700 * 32 + 5, 301, 128, False), (2, 300 * 32, 7, 128, False), (3, 40, 3, 128, True),
+                                                             (3, 9000, 5000, 128, True), (3, 33, 7, 128, False), (3, 700, 31, 64, False), (2, 300, 11, 12, False)])
+def test_interact_to_nodes_backward_forms_the_hyperedge_cotangents_itself(order, edges, users, dim, restricted, monkeypatch):
+    """``interact_to_nodes`` = interact + hyperedge -> node pass as one autograd node.  At d = 128 (hyperedges numbered by user) its backward
+    has no node -> hyperedge launch: the member-gradient kernel gathers the three ``dy`` rows of a hyperedge (ring of ids a phase earlier,
+    tiles past the end, partial last tile, 33 hyperedges = one tile and a row) and leaves their scaled sum for the weight gradients and
+    the first-order scatter.  Against the separate ops (whose K5 launch it replaces), with and without a row restriction of the forward,
+    and at widths where it falls back to their sequence; the fp32-MFMA mode must take the fallback too."""
+    from ihgnn_amd import ops, profiler
+    Q, I = 17, 211
+    w_, lay = make_layout(users, Q, I, edges, seed=order + edges + dim, edge_order='user')
+    gen = torch.Generator().manual_seed(edges + dim)
+    h = torch.randn(lay.node_count, dim, generator=gen)
+    k = 6 if order == 2 else 7
+    w = torch.randn(dim, k * dim, generator=gen) / np.sqrt(k * dim)
+    p = torch.randn(lay.node_count, dim, generator=gen)
+    cot = torch.randn(lay.node_count, dim, generator=gen) / 8
+    rows = None
+    if restricted:                                                       # the training step's last layer: only these rows are read, the cotangent is zero elsewhere
+        rows = torch.unique(torch.randint(0, lay.node_count, (64,), generator=gen)).to(torch.int32).to(dev())
+        mask = torch.zeros(lay.node_count, 1)
+        mask[rows.cpu().long()] = 1
+        cot = cot * mask
+    scale = lay.inv_deg
+
+    def run(fused):
+        hg, pg, wg = (t.clone().to(dev()).requires_grad_(True) for t in (h, p, w))
+        if fused:
+            y = ops.interact_to_nodes(hg, pg, wg, lay, order, scale, rows)
+        else:
+            y = ops.node_segment_sum(ops.interact(hg, pg, wg, lay, order), lay, out_scale=scale, rows=rows)
+        if rows is not None:
+            y = y * mask.to(dev())                                       # rows outside the list are unwritten
+        y.backward(cot.to(dev()))
+        return y.detach(), hg.grad, pg.grad, wg.grad
+
+    profiler.start()
+    fused = run(True)
+    launched = profiler.summary()
+    profiler.stop()
+    assert ('edge_gather_sum' not in launched) == (dim == 128), sorted(launched)
+    separate = run(False)
+    assert torch.equal(fused[0], separate[0])
+    for got, want in zip(fused[1:], separate[1:]):
+        assert rel(got, want) <= RTOL_SUM
+    if dim == 128:
+        monkeypatch.setenv('IHG_INTERACT_ARITH', 'f32')                 # no gathering kernel in this mode: the separate ops' sequence
+        for got, want in zip(run(True)[1:], separate[1:]):
+            assert rel(got, want) <= RTOL
+
+
 @pytest.mark.parametrize('dim', [64, 128, 256])
 @pytest.mark.parametrize('edges', [1, 15, 33])
 def test_interact_split_kernels_on_tiny_hypergraphs(dim, edges):

@@ -36,6 +36,18 @@ def main():
         for key, v in table.items():
             if key.startswith('edge_gather_sum_kernel'):
                 out['edge_gather_sum'] = dict(hbm_bytes_per_launch=v['hbm_bytes_per_launch'], avg_us_under_pmc=v['avg_us_under_pmc'])
+        # K5 and K7's hyperedge -> node launch on their own (kbench): the step may not launch K5 at all, and K7's launch roles share a name
+        f57, w57 = os.path.join(src, 'pmc_k57_FETCH_SIZE'), os.path.join(src, 'pmc_k57_WRITE_SIZE')
+        if os.path.isdir(f57) and os.path.isdir(w57):
+            alone = json.loads(subprocess.run([sys.executable, os.path.join(here, 'pmc_summary.py'), f57, w57, '--skip', '2'], capture_output=True, text=True, check=True).stdout)
+            source = f'tools/kbench.py --config {config} --rounds 4 --ops k5,k7 (the kernel launched on its own, same shapes)'
+            for key, v in alone.items():
+                entry = dict(hbm_bytes_per_launch=v['hbm_bytes_per_launch'], avg_us_under_pmc=v['avg_us_under_pmc'], source=source)
+                if key.startswith('edge_gather_sum_kernel') and 'edge_gather_sum' not in out:
+                    out['edge_gather_sum'] = entry
+                if key.startswith('node_segment_sum_kernel'):
+                    out['k7.edges_to_nodes'] = entry
+            out['kernels_alone'] = alone
         json.dump(out, open(os.path.join(dst, f'pmc_traffic_{config}.json'), 'w'), indent=1)
         for d, c in ((fetch, 'fetch_size'), (write, 'write_size')):
             f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
@@ -49,7 +61,7 @@ def main():
             if 'interact' in name:
                 agg[name][r['Counter_Name']].append((float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
         out = dict(command='rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 tools/kbench.py --config '
-                           f'{config} --rounds 3 --ops interact', notes='GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs', kernels={})
+                           f'{config} --rounds 3 --ops layer0', notes='GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs', kernels={})
         for name, c in agg.items():
             busy = sum(v for v, _ in c['SQ_VALU_MFMA_BUSY_CYCLES']) / len(c['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024
             gui = sum(v for v, _ in c['GRBM_GUI_ACTIVE']) / len(c['GRBM_GUI_ACTIVE']) / 8

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the individual HIP ops at a bench.py workload shape (interleaved rounds, HIP-event timing).
 
-    python tools/kbench.py [--config C2] [--rounds 10] [--ops k5,k7,interact,linear]
+    python tools/kbench.py [--config C2] [--rounds 10] [--ops k5,k7,interact,layer0,linear]
 """
 import argparse
 import os
@@ -50,6 +50,10 @@ def main():
             y = ops.node_linear(xr, wt, b, lay)
             y2 = ops.node_linear(y, wa, b, lay, typed=True, bias_mask=1)
             y2.backward(x)
+        if 'layer0' in want:                                              # interactive step + hyperedge -> node pass as one autograd node (the gathering backward at d = 128)
+            hr = x.detach().requires_grad_(True)
+            pr = x.detach().requires_grad_(True)
+            ops.interact_to_nodes(hr, pr, wa, lay, args.order, lay.inv_deg).backward(x)
         if 'interact' in want:
             hr = x.detach().requires_grad_(True)
             pr = x.detach().requires_grad_(True)

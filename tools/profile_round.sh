@@ -2,7 +2,7 @@
 # Collect the profile artefacts of a round on the GPU box (run through gpurun from the repo root):
 #   tools/profile_round.sh <tag>            -> gpurun_out/<tag>/...
 # 1. rocprofv3 --kernel-trace --stats of the default bench (10 steps)      2. the default bench line, unprofiled
-# 3. PMC passes (separate runs): FETCH_SIZE, WRITE_SIZE over 3 bench steps; SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE over the interact kernels
+# 3. PMC passes (separate runs): FETCH_SIZE, WRITE_SIZE over 3 bench steps and over K5 / K7 launched alone (tools/kbench.py); SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE over the interact kernels
 set -u
 TAG=${1:-prof}
 OUT=gpurun_out/$TAG
@@ -13,6 +13,9 @@ python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-kernel-events > $OUT/pmc_$c.json 2> $OUT/pmc_$c.log
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -- python3 tools/kbench.py --config C3 --rounds 3 --ops interact > $OUT/pmc_mfma.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do     # K5 and K7's hyperedge -> node launch on their own (K7's seven in-situ launches per step share one kernel name and grid)
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_k57_$c -- python3 tools/kbench.py --config C3 --rounds 4 --ops k5,k7 > $OUT/pmc_k57_$c.log 2>&1
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -- python3 tools/kbench.py --config C3 --rounds 3 --ops layer0 > $OUT/pmc_mfma.log 2>&1
 find $OUT -name '*kernel_trace.csv' -delete        # large, and the stats / counter files carry what is quoted
 ls -R $OUT | head -40
