@@ -1,18 +1,55 @@
-"""tools/step_trace.py DIR: the kernels of ONE steady-state training step in launch order, from a `rocprofv3 --kernel-trace --output-format csv`
-run of bench.py (DIR = its -d directory): name, duration, gap to the previous kernel's end.  The step is cut at the Adam launches."""
-import csv
-import glob
+#!/usr/bin/env python3
+"""torch.profiler view of one training step at a bench.py workload: which ATen ops (and which of our ops) own the device time.
+
+    python tools/step_trace.py [--config C2] [--steps 5]
+"""
+import argparse
+import os
 import sys
 
-f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
-rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
-a, b = adam[len(adam) // 2], adam[len(adam) // 2 + 1]
-prev_end, total, busy = int(rows[a]['End_Timestamp']), 0, 0
-for r in rows[a + 1:b + 1]:
-    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    name = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').replace('at::native::', '')[:70]
-    print(f'{(e - s) / 1e3:9.1f} us  gap {(s - prev_end) / 1e3:7.1f}  {name}')
-    busy += e - s
-    prev_end = e
-print(f'step {(int(rows[b]["End_Timestamp"]) - int(rows[a]["End_Timestamp"])) / 1e6:.3f} ms, kernels {busy / 1e6:.3f} ms, {b - a} launches')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+import bench
+from ihgnn_amd import synth
+from ihgnn_amd.Dataset import GraphDataset
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default='C2')
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--layer', default='ihgnn')
+    ap.add_argument('--order', type=int, default=3)
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    cfg = synth.CONFIGS[args.config]
+    w = synth.draw_config(args.config)
+    ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets, w.triples, device=dev)
+    model = bench.build_model(ds, dev, args.layer, cfg['layers'], args.order, cfg['dim'])
+    from ihgnn_amd.optim import Adam
+    opt = Adam(model.parameters(), 1e-3, weight_decay=0)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    batches = list(ds.sample_batches(100, args.steps + 3, seed=1000))
+
+    def step(k):
+        u, q, i, y = batches[k]
+        loss = model.bce_loss(u, q, i, y) if model.supports_fused_loss(lossf) else lossf(model(u, q, i), y)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+
+    for k in range(3):
+        step(k)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for k in range(3, 3 + args.steps):
+            step(k)
+        torch.cuda.synchronize()
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by='self_cuda_time_total', row_limit=45, max_name_column_width=60,
+                                                             max_shapes_column_width=70))
+
+
+if __name__ == '__main__':
+    main()
