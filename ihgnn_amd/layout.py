@@ -188,6 +188,7 @@ class IncidenceLayout:
         # member buffer is [E, 2, d] (query, item) and only query / item nodes have lists: row of (node v, hyperedge e) = 2 e + type(v) - 1
         self.user_sorted = bool(e == 0 or (np.diff(i3[:e, 0]) >= 0).all())
         self._member_qi = None
+        self._isolated_users = None
         self._rowptr_host, self._edge_ids_host, self._slot_of_entry = rowptr, edge_ids[:3 * e], slot_of_entry
         # hop2_csr: node v -> the OTHER two members of each of its hyperedges (2 ids per incidence); together with
         # self_weight = deg(v) for the node's own row it is the two-hop operator H H^T, read straight from the node table.
@@ -199,6 +200,14 @@ class IncidenceLayout:
         self.hop2_csr = Csr((rowptr.astype(np.int64) * 2).astype(np.int32), others, device, heavy_threshold)
         self.self_weight = torch.where(isolated, torch.zeros_like(deg), deg).to(device)
 
+
+    def users_without_hyperedges(self):
+        """int64 device indices of the user rows with an empty incidence list (the user-reduced backward writes ``dh`` only for users that have
+        hyperedges: these rows are zeroed by the caller - a handful of rows instead of a fill of the whole user block)."""
+        if self._isolated_users is None:
+            deg = np.diff(self._rowptr_host.astype(np.int64))[:self.user_count]
+            self._isolated_users = torch.from_numpy(np.nonzero(deg == 0)[0].astype(np.int64)).to(self.device)
+        return self._isolated_users
 
     def member_csr_qi(self):
         """``(Csr, rows)``: the member lists of the query and item nodes over an ``[E, 2, d]`` buffer (user rows are empty) and the
