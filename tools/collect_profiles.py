@@ -20,7 +20,7 @@ def main():
     stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f'{prefix}_kernel_stats.csv'))
-    for name in ('bench_under_rocprof.json', 'bench_default.json'):
+    for name in ('bench_under_rocprof.json', 'bench_default.json', 'k7_by_role.json'):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f'{prefix}_{name}'))
     fetch, write = os.path.join(src, 'pmc_FETCH_SIZE'), os.path.join(src, 'pmc_WRITE_SIZE')
