@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
 // ================================================================================================
 // K7  hyperedge -> node segment-sum (also: EmbeddingBag mean forward/backward, scatter-add backward)
 //   G lanes own one output row and walk its id list in chunks of G ids: one coalesced id load per chunk,
-//   shuffles broadcast each id inside the group, UNR row gathers in flight per lane, adds in list order.
+//   shuffles broadcast each id inside the group, UNR (8 or 16) row gathers in flight per lane, adds in list order.
 //   The chunk loop is made wave-uniform with a cross-group max so the shuffles always run converged.
 // ================================================================================================
 template <int VEC, int G>
@@ -102,7 +102,7 @@ __device__ __forceinline__ Frag<VEC> accumulate_list(const float* __restrict__ s
                                                      const int32_t* __restrict__ ids, const float* __restrict__ src_scale,
                                                      const float* __restrict__ entry_scale, const uint8_t* __restrict__ src_mask,
                                                      int begin, int len, int wave_max_len, int lane, int col) {
-    constexpr int UNR = G < 8 ? G : 8;
+    constexpr int UNR = G < 8 ? G : (G >= 32 ? 16 : 8);      // row gathers in flight per lane (G = 32, d = 128: 16 - 2-3 % on C3's launches over 8)
     const int lig = lane & (G - 1);
     const int group_base = lane & ~(G - 1);
     Frag<VEC> acc = Frag<VEC>::zero();
