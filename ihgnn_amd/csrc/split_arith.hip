@@ -1,5 +1,5 @@
-// split_arith.hip - contractions of the order-3 interactive step (d = 64, 128, 256) and of the node-level linear maps (d = 128, 256) on
-// the bf16 matrix pipe at fp32 accuracy.
+// split_arith.hip - contractions of the order-2 / order-3 interactive step (d = 64, 128, 256) and of the node-level linear maps
+// (d = 128, 256) on the bf16 matrix pipe at fp32 accuracy.
 //
 // Every fp32 operand x is taken apart EXACTLY into three bf16 terms, x = hi + mid + lo (hi = the top 16 bits of x, mid = the top
 // 16 bits of x - hi, lo = the rest: 8 + 8 + 8 significand bits, both subtractions exact), and a product a b is accumulated in fp32
@@ -14,8 +14,9 @@
 // parts of one tile range sit on one XCD (workgroups are dealt to XCDs round-robin by their linear id), so the later reads of a
 // streamed row hit that L2.  The waves of a workgroup have two jobs, one of each per SIMD: matrix waves 0-3 only read fragments and
 // issue MFMAs, service waves 4-7 request, split, apply the element-wise part and store.
-// What bounds these kernels is not the matrix pipe but the vector instructions of the split (5.5 per element) and of forming the
-// products: the pipe is 0.4-0.5 busy (DESIGN.md section 4 has the ladder, the probes and the counters).
+// What bounds these kernels is instruction issue: a SIMD spends ~ 16 cycles per MFMA and ~ 4 per every other instruction of its matrix
+// and its service wave, one after the other - so the count of instructions beside the MFMAs (the split: 5.5 per element; addresses;
+// scalar bookkeeping) is what to cut; the pipe is 0.45-0.64 busy (DESIGN.md section 4 has the ladder, the probes and the counters).
 #include <cstdlib>
 #include <type_traits>
 
