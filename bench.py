@@ -185,6 +185,8 @@ def k7_roles(table, E, N, dim, layout, table_steps):
                                                           'was summed on chip by the member-gradient kernel); every row read exactly once'),
         'k7.two_hop': (N, 6 * E + N, 24 * E, 'first-order layer forward: node table -> node table over hop2_csr (no [E,d] intermediate)'),
         'k7.two_hop_bwd': (N, 6 * E + N, 24 * E, 'first-order layer backward (same operator, scalings swapped)'),
+        'k7.two_hop_bwd_masked': (N, 6 * E + N, 24 * E, 'backward of the LAST first-order layer: its cotangent is zero outside the 3B batch rows (the output feeds the batch '
+                                                          'tail only), the pull skips the gathers of the zero rows - same gradient; bytes as for the dense pull (an upper bound)'),
         'k7.edges_to_nodes_bwd_of_k5': (E, 3 * E, 12 * E, 'backward of a K5 launch'),
     }
     out = {}
@@ -314,6 +316,7 @@ def main():
     final_loss = float(last.item())
 
     table, table_steps, restricted_elapsed, fwd_elapsed, stress, eval_stats, f32_elapsed, k5_alone = {}, min(args.steps, 5), None, None, None, None, None, None
+    dense_cot_elapsed = None
     N_nodes = w.node_count
     if not args.no_extras:
         # per-kernel table (K7 roles, MFMA kernels): a second, untimed pass over the same batches with every launch bracketed
@@ -337,6 +340,20 @@ def main():
             fence()
             f32_elapsed = max_over_ranks((time.perf_counter() - t3) / n_3)
             del os.environ['IHG_INTERACT_ARITH']
+        # the same step with the last layer's backward pulling every row of its (zero outside the batch rows) cotangent
+        from ihgnn_amd import ops as _ops
+        if _ops.SPARSE_LAST_COTANGENT:
+            _ops.SPARSE_LAST_COTANGENT = False
+            for k in range(2):
+                step(k)
+            fence()
+            t4 = time.perf_counter()
+            n_4 = min(args.steps, 10)
+            for k in range(args.warmup, args.warmup + n_4):
+                step(k)
+            fence()
+            dense_cot_elapsed = max_over_ranks((time.perf_counter() - t4) / n_4)
+            _ops.SPARSE_LAST_COTANGENT = True
         # the same step with the last layer's hyperedge -> node pass evaluated only at the rows the loss reads (split rows + the 3B
         # batch rows): identical loss and gradients, what the training loop runs by default; reported beside the headline
         model.batch_rows_only_last_layer = True
@@ -477,7 +494,7 @@ def main():
         'config': {'workload': WORKLOAD_NOTES.get(args.config, args.config) + (f' SCALED x{args.scale:g};' if args.scale != 1.0 else '') +
                                f' U={w.user_count} Q={w.query_count} I={w.item_count} E={E}, {cfg["distribution"]} members, '
                                f'dim={dim}, {layers}x{args.layer} layers, interaction order {args.order}, batch 100 pos + 1000 neg',
-                   'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd + Adam' +
+                   'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd (the last layer\'s backward pulls the 3B non-zero rows of its cotangent) + Adam' +
                            (f' + RCCL gradient exchange ({args.sync})' if world > 1 else ''),
                    'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
                    'arithmetic': ('f32 results; the order-2/3 contractions (d = 64 / 128 / 256) and the '
@@ -494,6 +511,10 @@ def main():
         out['batch_rows_last_layer_value'] = round(world * E * layers / restricted_elapsed, 1)
         out['batch_rows_last_layer_note'] = ('same step with the last layer\'s hyperedge->node pass evaluated only at the rows the loss reads '
                                              '(identical loss and gradients; the training loop\'s default); NOT the headline')
+    if dense_cot_elapsed is not None:
+        out['dense_last_cotangent_ms_per_step'] = round(1e3 * dense_cot_elapsed, 4)
+        out['dense_last_cotangent_note'] = ('same full step with the last layer\'s backward pulling all N rows of its cotangent (zero outside the 3B batch rows: '
+                                            'the layer\'s output feeds the batch tail only) instead of the 3B rows; identical loss and gradients (IHG_SPARSE_LAST_COTANGENT=0); NOT the headline')
     if f32_elapsed is not None:
         out['fp32_mfma_kernels_ms_per_step'] = round(1e3 * f32_elapsed, 4)
         out['fp32_mfma_kernels_note'] = 'same full step with IHG_INTERACT_ARITH=f32 (fp32-MFMA contractions instead of the bf16-split ones); NOT the headline'

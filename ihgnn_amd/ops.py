@@ -160,8 +160,8 @@ class _TwoHop(torch.autograd.Function):
     def backward(ctx, grad_out: Tensor):
         lay = ctx.layout
         mode = _lib.SCALE_NONE if ctx.in_scale is None else _lib.SCALE_MULTIPLY
-        mask = None
-        if ctx.rows is not None:
+        mask = _nonzero_row_mask(grad_out, lay.node_count)      # the last layer's cotangent: zero outside the batch rows (the tap says so)
+        if mask is None and ctx.rows is not None:
             # only `rows` of the output were read, so grad_out is zero elsewhere: the pull skips the gathers of those zero rows
             # (two thirds of them - every neighbour that is not a query - and the ones that would miss the cache)
             mask = torch.zeros(lay.node_count, dtype=torch.uint8, device=grad_out.device)
@@ -452,6 +452,7 @@ def node_linear(x: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceL
 # the [E, 3, d] member-gradient buffer of the interactive backward is produced in hyperedge chunks beyond this many bytes
 MEMBER_BUFFER_LIMIT_BYTES = 48 << 30
 import os as _os
+import weakref
 # use ihg_interact_bwd_user_reduced (user slot summed on chip, [E, 2, d] member buffer) where the library offers it; IHG_USER_REDUCED=0
 # keeps the [E, 3, d] form (C3: the same step time with the bf16-split kernels - the scan costs their service waves what K7 saves - and
 # 1.1 GB less written and read per step; -0.05 ms with the fp32-MFMA kernels).  Tests compare the two forms.
@@ -732,6 +733,25 @@ def _hem_backward(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float,
     return dbias, tuple(dense[l] for l in range(n_layers))
 
 
+SPARSE_LAST_COTANGENT = _os.environ.get('IHG_SPARSE_LAST_COTANGENT', '1') != '0'
+_SPARSE_ROWS = {}                   # address of a cotangent known to be zero outside some rows -> (those rows, weak reference to the tensor): set by the last tap's backward
+
+
+def _nonzero_row_mask(grad: Tensor, n_rows: int) -> Optional[Tensor]:
+    """uint8 ``[n_rows]`` mask of the rows of ``grad`` that may be non-zero, when the tap that built it said so; consumed once.  The entry
+    counts only while the tensor the tap built is alive (an address can be reused once it is gone)."""
+    entry = _SPARSE_ROWS.pop(grad.data_ptr(), None)
+    if entry is None:
+        return None
+    rows, alive = entry
+    built = alive()
+    if built is None or built.data_ptr() != grad.data_ptr() or tuple(built.shape) != tuple(grad.shape):
+        return None
+    mask = torch.zeros(n_rows, dtype=torch.uint8, device=grad.device)
+    mask.index_fill_(0, rows.long(), 1)
+    return mask
+
+
 class TailGradients:
     """Side channel from the batch tail's backward to the taps on the layer outputs (one per training step).
 
@@ -775,7 +795,12 @@ class _Tap(torch.autograd.Function):
                 return (g_next if g_next is not None else g_tail), None, None
             return g_next + g_tail, None, None
         if g_next is None:
+            # the last layer's output feeds the batch tail only: its cotangent is zero outside the batch rows.  The layer's backward is
+            # told (by the tensor's address) and skips the gathers of the zero rows - same gradient, a pull over 3B rows instead of N
             g = torch.zeros(n, dim, dtype=torch.float32, device=ctx.device)
+            if SPARSE_LAST_COTANGENT:
+                _SPARSE_ROWS.clear()
+                _SPARSE_ROWS[g.data_ptr()] = (holder.rows, weakref.ref(g))
         else:
             g = g_next if (g_next.is_contiguous() and g_next.dtype == torch.float32) else g_next.contiguous().float()
         holder.add_into(g, ctx.index * dim, dim)

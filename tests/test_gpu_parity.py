@@ -1244,6 +1244,42 @@ def test_fused_bce_tail_equals_unfused_path():
     assert abs(lo.item() - lb.item()) <= 1e-5 * abs(lo.item())
 
 
+def test_last_layer_backward_skips_the_zero_rows_of_its_cotangent(monkeypatch):
+    """The last layer's output feeds the batch tail only, so its cotangent is zero outside the 3B batch rows: the tap says so and the
+    layer's two-hop backward pulls only those rows (`k7.two_hop_bwd_masked`) - every layer still evaluated over all rows in the forward.
+    Same loss, bitwise the same gradients as the dense backward; an address registered by a tap whose tensor is gone must not mask."""
+    from ihgnn_amd import ops, profiler, synth
+    from ihgnn_amd.Dataset import GraphDataset
+    w = synth.draw(90, 12, 140, 20, 1500, seed=8)
+    ds = GraphDataset.from_arrays(90, 12, 140, 20, w.bag_words, w.bag_offsets, w.triples, device=dev())
+    torch.manual_seed(5)
+    m = build_model(ds, 'ihgnn', 3, 3, 32)
+    m.batch_rows_only_last_layer = False
+    u, q, i, y = next(ds.sample_batches(100, 1, seed=3))
+    grads = {}
+    for sparse in (True, False):
+        monkeypatch.setattr(ops, 'SPARSE_LAST_COTANGENT', sparse)
+        m.zero_grad()
+        profiler.start()
+        loss = m.bce_loss(u, q, i, y)
+        loss.backward()
+        launched = profiler.summary()
+        profiler.stop()
+        assert ('k7.two_hop_bwd_masked' in launched) == sparse, sorted(launched)
+        grads[sparse] = (loss.item(), {n: p.grad.clone() for n, p in m.named_parameters()})
+    assert grads[True][0] == grads[False][0]
+    for n in grads[True][1]:
+        assert torch.equal(grads[True][1][n], grads[False][1][n]), n
+    # a stale registration: the tensor the tap built is gone, another one may sit at its address
+    g = torch.zeros(8, 4, device=dev())
+    ops._SPARSE_ROWS[g.data_ptr()] = (torch.zeros(1, dtype=torch.int64, device=dev()), __import__('weakref').ref(g))
+    ptr = g.data_ptr()
+    del g
+    other = torch.ones(8, 4, device=dev())
+    ops._SPARSE_ROWS[other.data_ptr()] = ops._SPARSE_ROWS.pop(ptr, (None, lambda: None)) if other.data_ptr() != ptr else ops._SPARSE_ROWS[ptr]
+    assert ops._nonzero_row_mask(other, 8) is None
+
+
 # ---------------------------------------------------------------------------------------------
 # multi-rank path on one GPU (SURVEY §8 e1): the HIP model, N ranks == 1 rank on the union batch; bench.py launches itself
 # ---------------------------------------------------------------------------------------------

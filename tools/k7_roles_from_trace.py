@@ -3,14 +3,14 @@
 directory).  All of K7's launches share one kernel name (`node_segment_sum_kernel<4, 32>`) and, at one workload, one grid, so rocprofv3's
 --stats line averages unlike jobs; this cuts the trace into training steps at the Adam launches and averages the large K7 launches of the
 split-arithmetic steps by their POSITION in the step, which is fixed (bench.py --config C3, ihgnn, order 3):
-forward: hyperedge features -> nodes, two-hop (layer 1), two-hop (layer 2); backward: two-hop (layer 2), two-hop (layer 1), member
+forward: hyperedge features -> nodes, two-hop (layer 1), two-hop (layer 2); backward: two-hop (layer 2, masked), two-hop (layer 1), member
 gradients -> nodes, first-order cotangent -> nodes.  Prints one JSON object."""
 import csv
 import glob
 import json
 import sys
 
-ROLES = ['k7.edges_to_nodes', 'k7.two_hop (layer 1)', 'k7.two_hop (layer 2)', 'k7.two_hop_bwd (layer 2)', 'k7.two_hop_bwd (layer 1)',
+ROLES = ['k7.edges_to_nodes', 'k7.two_hop (layer 1)', 'k7.two_hop (layer 2)', 'k7.two_hop_bwd_masked (layer 2: only the batch rows of its cotangent are non-zero)', 'k7.two_hop_bwd (layer 1)',
          'k7.member_gradients_rows', 'k7.first_order_gradient']
 
 
