@@ -10,8 +10,8 @@ A step is one FULL training step of RawGnn (full-graph propagation forward over 
 (graph layout, weights, pre-drawn batches) are resident in HBM before the clock starts.  With N > 1 every rank holds a
 full replica and its own batches (weak scaling) and the value is the aggregate over ranks.
 
-Workload: the largest BASELINE config that fits one GPU's step budget, C3 (CIKM-Cup-2016 stand-in: d = 128, 3 layers; it is
-also the per-GPU replica shape of C4).  --config C2 / C1 / C5 select the others (C5 on one GPU takes ~1.1 s per step).
+Workload: the largest BASELINE config that fits one GPU's step budget, C3 (CIKM-Cup-2016 stand-in: d = 128, 3 layers; C4
+(Amazon full catalog stand-in, same model shape, E = 3.3 M) is the per-GPU replica of the 8-GPU config).  --config C1 / C2 / C4 / C5 select the others (C5 on one GPU takes ~1.1 s per step).
 
 `--gpus N` without a torchrun environment launches itself: the parent starts N child processes (one per GPU) BEFORE it
 touches the GPU and forwards rank 0's JSON line; under `python -m torch.distributed.run` it uses the ranks it was given.
@@ -47,7 +47,9 @@ WORKLOAD_NOTES = {
     'C1': 'C1 = BASELINE configs[0]: synthetic 1k-user / 1k-item / 500-query hypergraph (the reference\'s CPU-runnable case);',
     'C2': 'C2: size-matched synthetic stand-in for BASELINE configs[1] (Amazon-Electronics subset; the corpus is not in the image);',
     'C3': 'C3: size-matched synthetic stand-in for BASELINE configs[2] (CIKM-Cup-2016 Track 2, dim 128, 3 layers; the corpus is not in the image; '
-          'also the per-GPU replica shape of configs[3]);',
+          'the same model shape as configs[3], whose own stand-in is --config C4);',
+    'C4': 'C4: size-matched synthetic stand-in for BASELINE configs[3] (Amazon full catalog = the five Amazon 5-core corpora of the reference\'s Main.py:35-39 '
+          'as one graph: 317,713 users / 148,456 items / 3.15 M reviews -> 3.3 M training hyperedges; dim 128, 3 layers; one replica per GPU; the corpus is not in the image);',
     'C5': 'C5 = BASELINE configs[4]: synthetic power-law 10M-node / 50M-hyperedge hypergraph;',
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a float4 streaming copy reaches ~6290
@@ -68,7 +70,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', default='C3', help='synth.CONFIGS key (C1 | C2 | C3 | C5)')
+    ap.add_argument('--config', default='C3', help='synth.CONFIGS key (C1 | C2 | C3 | C4 | C5)')
     ap.add_argument('--order', type=int, default=3)
     ap.add_argument('--layer', default='ihgnn', choices=['ihgnn', 'hgcn'])
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -292,11 +292,18 @@ class GraphDataset(Dataset):
         gen.manual_seed(seed * 1_000_003 + epoch)
         order = torch.randperm(len(self), device=dev, generator=gen)[rank::world_size]
         n_batches = -(-(-(-len(self) // world_size)) // batch_size)
-        base, extra = divmod(int(order.shape[0]), n_batches)
+        mine = int(order.shape[0])
+        if mine < n_batches:
+            raise ValueError(f'rank {rank} holds {mine} positives for {n_batches} batches: batch_size {batch_size} is too small for {world_size} ranks '
+                             '(an empty batch on one rank would leave the others waiting in the gradient exchange)')
+        base, extra = divmod(mine, n_batches)
         lo = 0
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for b in range(n_batches):
-            hi = lo + base + (1 if b < extra else 0)
+            if world_size == 1:                                          # DataLoader's batching: full batches and a shorter last one
+                hi = min(lo + batch_size, mine)
+            else:                                                        # equal batch counts on every rank, sizes within one row of each other
+                hi = lo + base + (1 if b < extra else 0)
             pos = self._pos_device[order[lo:hi]]
             lo = hi
             n = int(pos.shape[0])

@@ -36,16 +36,12 @@ def _evaluate_batched(model, logs, item_count: int, device: torch.device, indice
     ``[C, I]`` matrix), one D2H copy per chunk (the reference scores one log at a time and syncs on every one,
     ``TrainTestHelper.py:58-67``, ``Metrics.py:60-61``)."""
     out: List[Tuple[int, Metrics]] = []
-    fused = hasattr(model, 'top_items')
-    chunk = 8192 if fused else max(1, min(2048, (1 << 28) // max(item_count, 1)))
+    chunk = 8192
     k = min(10, item_count)
     for lo in range(0, len(indices), chunk):
         part = indices[lo:lo + chunk]
         uq = torch.tensor([(logs[i][0], logs[i][1]) for i in part], dtype=torch.long, device=device)
-        if fused:                                           # HIP kernel: fp32-MFMA scores reduced to a running top-10 on chip
-            top = model.top_items(uq[:, 0], uq[:, 1], k)[0].tolist()
-        else:
-            top = model.score_all_items(uq[:, 0], uq[:, 1]).topk(k, dim=1, largest=True, sorted=True).indices.tolist()
+        top = model.top_items(uq[:, 0], uq[:, 1], k)[0].tolist()          # HIP kernel: fp32-MFMA scores reduced to a running top-10 on chip
         for i, row in zip(part, top):
             _, _, items, flags, all_1 = logs[i]
             out.append((i, Metrics.from_top_indices(row, items, flags, all_1)))
@@ -71,7 +67,7 @@ def test_and_get_avg_metrics(model, dataset_train: GraphDataset, dataloader: Tes
     with torch.no_grad():
         model.save_features_for_test()
         try:
-            if hasattr(model, 'score_all_items') and not Gs.Prediction.use_cosine_similarity:
+            if hasattr(model, 'top_items') and not Gs.Prediction.use_cosine_similarity:
                 scored = _evaluate_batched(model, logs, dataset_train.item_count, device, mine)
             else:
                 scored = []

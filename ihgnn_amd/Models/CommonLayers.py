@@ -12,7 +12,6 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch import Tensor
 
 from .. import ops
@@ -32,23 +31,17 @@ class FeatureInteractor(nn.Module):
 
     def first_order(self, node_features: Tensor) -> Tensor:
         """Node-level image of the u / q / i blocks (+ bias, carried by the user rows: one user per hyperedge)."""
-        d = self.node_feature_dimension
         w, b = self.aggregation.weight, self.aggregation.bias
-        if ops.node_linear_supported(node_features, w):
-            return ops.node_linear(node_features, w, b, self.dataset.hypergraph.layout, typed=True, bias_mask=0b001)
-        u_end = self.dataset.query_start_index_in_graph
-        q_end = self.dataset.item_start_index_in_graph
-        return torch.cat([F.linear(node_features[:u_end], w[:, :d], b),
-                          F.linear(node_features[u_end:q_end], w[:, d:2 * d]),
-                          F.linear(node_features[q_end:], w[:, 2 * d:3 * d])])
+        return ops.node_linear(node_features, w, b, self.dataset.hypergraph.layout, typed=True, bias_mask=0b001)      # any width; no torch path
 
-    def to_nodes(self, node_features: Tensor, out_scale: Optional[Tensor] = None, rows: Optional[Tensor] = None) -> Tensor:
+    def to_nodes(self, node_features: Tensor, out_scale: Optional[Tensor] = None, rows: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
         """``out_scale * H forward(node_features)``: the hyperedge features taken on to the nodes (``GnnLayers.py:229-236``).  Orders 2 / 3
-        on the hoisted path run as one autograd node whose backward forms the hyperedges' cotangents inside the member-gradient kernel."""
+        run as ONE autograd node (``ops.interact_layer``): the backward forms the hyperedges' cotangents inside the member-gradient kernel where it
+        can and adds the first-order path's input gradient onto the member gradients inside the node-level kernel."""
         layout = self.dataset.hypergraph.layout
-        if self.max_order > 1 and not ops.interact_from_nodes_supported(node_features, self.aggregation.weight):
-            return ops.interact_to_nodes(node_features, self.first_order(node_features), self.aggregation.weight, layout, self.max_order, out_scale, rows)
-        return ops.node_segment_sum(self(node_features), layout, out_scale=out_scale, rows=rows)
+        if self.max_order > 1:
+            return ops.interact_layer(node_features, self.aggregation.weight, self.aggregation.bias, layout, self.max_order, out_scale, rows, out)
+        return ops.node_segment_sum(self(node_features), layout, out_scale=out_scale, rows=rows, out=out)
 
     def forward(self, node_features: Tensor) -> Tensor:
         layout = self.dataset.hypergraph.layout

@@ -35,12 +35,10 @@ class EmbeddingLayer(nn.Module):
                 item_indices: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
         return self.embed_user(user_indices), self.embed_query(query_indices), self.embed_item(item_indices)
 
-    def all_nodes(self) -> Tensor:
-        """``torch.cat(self(None, None, None))`` as one op (``RawGnn.py:112-113``): ``[U+Q+I, d]``."""
-        w = self.embedding_bag_vocabulary.weight
-        if w.is_cuda and Gs.Query.transform == Gsv.mean:
-            return ops.embed_all_nodes(self.embedding_user.weight, self.embedding_item.weight, w, self.dataset.bag_layout)
-        return torch.cat(self(None, None, None))
+    def all_nodes(self, out: Optional[Tensor] = None) -> Tensor:
+        """``torch.cat(self(None, None, None))`` as one op (``RawGnn.py:112-113``): ``[U+Q+I, d]``.  ``out`` (inference only): write into
+        this ``[N, d]`` destination (a column slice of the feature matrix)."""
+        return ops.embed_all_nodes(self.embedding_user.weight, self.embedding_item.weight, self.embedding_bag_vocabulary.weight, self.dataset.bag_layout, out)
 
     def embed_user(self, user_indices: Optional[Tensor] = None) -> Tensor:
         w = self.embedding_user.weight

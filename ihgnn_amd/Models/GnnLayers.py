@@ -17,11 +17,13 @@ from .CommonLayers import FeatureInteractor
 
 
 def _transform(linear: nn.Linear, x: Tensor, layout) -> Tensor:
-    """``nn.Linear`` (square) on every node row through the HIP node-level kernels (MFMA row-GEMM for d in {32,64,128,256},
-    the any-width kernel otherwise); only a rectangular transform - which RawGnn never builds - is left to torch."""
-    if linear.in_features == linear.out_features and ops.node_linear_supported(x, linear.weight):
-        return ops.node_linear(x, linear.weight, linear.bias, layout)
-    return linear(x)
+    """``nn.Linear`` (square) on every node row through the HIP node-level kernels (bf16-split / MFMA row-GEMM for d in {32,64,128,256},
+    the any-width kernels otherwise).  There is no torch path: a rectangular transform - which RawGnn never builds
+    (``RawGnn.py:59-91``: input and output dimension are both the embedding size) - is refused."""
+    if linear.in_features != linear.out_features:
+        raise NotImplementedError(f'feature_transform {linear.in_features} -> {linear.out_features}: the MI355X path has square node-level transforms only '
+                                  '(RawGnn builds every layer with input_dimension == output_dimension)')
+    return ops.node_linear(x, linear.weight, linear.bias, layout)
 
 
 class HGCNLayer(nn.Module):
@@ -40,19 +42,21 @@ class HGCNLayer(nn.Module):
             self.out_scale = self.layout.inv_sqrt_deg * self.edge_scale
         self.feature_transform = nn.Linear(input_dimension, output_dimension)
 
-    def forward(self, input_features: Tensor, output_rows: Optional[Tensor] = None) -> Tensor:
-        """``output_rows`` (int32 node rows, not in the reference signature): the caller reads only these rows of the result
-        (last layer of a training step); other rows may be left unwritten."""
+    def forward(self, input_features: Tensor, output_rows: Optional[Tensor] = None, cotangent_rows: Optional[Tensor] = None,
+                out: Optional[Tensor] = None) -> Tensor:
+        """``out`` (inference only): the ``[N, d]`` destination, e.g. a column slice of the ``[N, d (L + 1)]`` feature matrix.
+        ``output_rows`` (int32 node rows, not in the reference signature): the caller reads only these rows of the result
+        (last layer of a training step); other rows may be left unwritten.  ``cotangent_rows``: every row is computed, but the caller
+        promises that the gradient of the result is zero outside these rows (``ops.node_two_hop``)."""
         lay = self.layout
         if self.general:
             # general incidence: node -> hyperedge (x Dv^-1/2 in, De^-1 out), hyperedge -> node (x Dv^-1/2 out): two K7 launches
-            h = self.feature_transform(input_features) if not ops.node_linear_supported(input_features, self.feature_transform.weight) \
-                else ops.node_linear(input_features, self.feature_transform.weight, self.feature_transform.bias, lay)
+            h = _transform(self.feature_transform, input_features, lay)
             edge_features = ops.hyper_node_to_edge(h, lay, src_scale=lay.inv_sqrt_deg, out_scale=lay.inv_edge_degree)
-            return ops.hyper_edge_to_node(edge_features, lay, out_scale=lay.inv_sqrt_deg)
+            return ops.hyper_edge_to_node(edge_features, lay, out_scale=lay.inv_sqrt_deg, out=out)
         h = _transform(self.feature_transform, input_features, lay)
         # node -> hyperedge -> node in one two-hop pass over the node table: Dv^-1/2 on the way in, Dv^-1/2 De^-1 on the way out
-        return ops.node_two_hop(h, lay, in_scale=lay.inv_sqrt_deg, out_scale=self.out_scale, rows=output_rows)
+        return ops.node_two_hop(h, lay, in_scale=lay.inv_sqrt_deg, out_scale=self.out_scale, rows=output_rows, cotangent_rows=cotangent_rows, out=out)
 
 
 class IHGNNLayer(nn.Module):
@@ -76,13 +80,15 @@ class IHGNNLayer(nn.Module):
                                                     output_dimension=input_dimension)
         self.feature_transform = nn.Linear(input_dimension, output_dimension)
 
-    def forward(self, input_features: Tensor, output_rows: Optional[Tensor] = None) -> Tensor:
-        """``output_rows``: as in ``HGCNLayer.forward``."""
+    def forward(self, input_features: Tensor, output_rows: Optional[Tensor] = None, cotangent_rows: Optional[Tensor] = None,
+                out: Optional[Tensor] = None) -> Tensor:
+        """``output_rows`` / ``cotangent_rows`` / ``out``: as in ``HGCNLayer.forward``."""
         if self.feature_interaction_order == 1:
             # first-order layer: hoisted node-level blocks, then node -> hyperedge -> node fused into one two-hop pass
-            return ops.node_two_hop(self._first_order_of_input(input_features), self.layout, out_scale=self.layout.inv_deg, rows=output_rows)
+            return ops.node_two_hop(self._first_order_of_input(input_features), self.layout, out_scale=self.layout.inv_deg, rows=output_rows,
+                                    cotangent_rows=cotangent_rows, out=out)
         h = _transform(self.feature_transform, input_features, self.layout)
-        return self.feature_interactor.to_nodes(h, out_scale=self.layout.inv_deg, rows=output_rows)
+        return self.feature_interactor.to_nodes(h, out_scale=self.layout.inv_deg, rows=output_rows, out=out)
 
     def _first_order_of_input(self, x: Tensor) -> Tensor:
         """``first_order(feature_transform(x))``.  With no non-linearity between them (``GnnLayers.py:224-227`` +
@@ -91,9 +97,7 @@ class IHGNNLayer(nn.Module):
         each backward direction); the ``[d, d]`` products are formed per call by a tiny kernel (``ihg_compose_first_order_fwd``).  Same reassociation class as the hoisting itself:
         <= 5e-7 relative against the reference's order of operations."""
         lin, agg = self.feature_transform, self.feature_interactor.aggregation
-        d = lin.in_features
-        if not (lin.in_features == lin.out_features and agg.out_features == d and agg.weight.shape[1] == 3 * d and lin.bias is not None
-                and ops.node_linear_supported(x, lin.weight)):
+        if lin.bias is None:
             return self.feature_interactor.first_order(_transform(lin, x, self.layout))
         weight, bias = ops.compose_first_order(agg.weight, agg.bias, lin.weight, lin.bias)      # [d, 3 d]: A_t W side by side; [3, d]
         return ops.node_linear(x, weight, bias, self.layout, typed=True, bias_mask=0b111)
@@ -102,8 +106,8 @@ class IHGNNLayer(nn.Module):
 class GCNLayer(nn.Module):
     """``Y = D^-1/2 A D^-1/2 (X W^T + b)`` over the pairwise graph (``GnnLayers.py:9-45``).
 
-    The reference orders transform and propagation by which side is narrower (``GnnLayers.py:33-43``); both orders are
-    kept.  Propagation is the weighted-CSR form of the K7 kernel with both ``D^-1/2`` scalings fused in."""
+    The reference orders transform and propagation by which side is narrower (``GnnLayers.py:33-43``); RawGnn builds square layers
+    (transform first).  Propagation is the weighted-CSR form of the K7 kernel with both ``D^-1/2`` scalings fused in."""
 
     def __init__(self, device: torch.device, dataset, input_dimension: int, output_dimension: int):
         super().__init__()
@@ -114,10 +118,9 @@ class GCNLayer(nn.Module):
         self.graph = dataset.graph2d.layout
         self.feature_transform = nn.Linear(input_dimension, output_dimension)
 
-    def forward(self, input_features: Tensor) -> Tensor:
-        if self.input_dimension >= self.output_dimension:
-            return ops.pair_spmm(_transform(self.feature_transform, input_features, self.graph), self.graph)
-        return self.feature_transform(ops.pair_spmm(input_features, self.graph))
+    def forward(self, input_features: Tensor, out: Optional[Tensor] = None) -> Tensor:
+        # the reference transforms first when the output is not wider (GnnLayers.py:33-43); RawGnn's layers are square, so that is the only order here
+        return ops.pair_spmm(_transform(self.feature_transform, input_features, self.graph), self.graph, out=out)
 
 
 class GATLayer(nn.Module):

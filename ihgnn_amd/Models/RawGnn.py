@@ -59,12 +59,13 @@ class RawGnn(nn.Module):
     # bce_loss: evaluate the last layer's hyperedge -> node pass only at the rows the loss reads (same loss, same gradients)
     batch_rows_only_last_layer = True
 
-    def propagate_layers(self, tail_gradients=None, batch_rows=None):
+    def propagate_layers(self, tail_gradients=None, batch_rows=None, restrict_last_layer=True):
         """Full-graph propagation: the list ``[X0, X1, ..., XL]`` of ``[N, d]`` node features (input embeddings and every
         layer's output).  With ``tail_gradients`` (an ``ops.TailGradients``) every output is tapped: the returned tensors
         are the batch tail's halves, whose gradients travel through the holder instead of dense ``[N, d]`` tensors.
-        ``batch_rows`` (int64 node rows): nobody reads ``XL`` outside these rows (a training step scores the batch only), so
-        the last hypergraph layer computes just them (plus the split rows of its plan) and leaves the rest unwritten."""
+        ``batch_rows`` (int64 node rows): nobody reads ``XL`` outside these rows (a training step scores the batch only).  With
+        ``restrict_last_layer`` the last hypergraph layer computes just them (plus the split rows of its plan) and leaves the rest
+        unwritten; without it every row is computed and the layer is only told that its cotangent is zero outside them."""
         x = self.embeddings.all_nodes()
         outputs = []
         last = len(self.gnns)
@@ -72,7 +73,8 @@ class RawGnn(nn.Module):
             if depth > 0:
                 layer = self.gnns[depth - 1]
                 if depth == last and batch_rows is not None and isinstance(layer, (IHGNNLayer, HGCNLayer)):
-                    x = layer(x, output_rows=batch_rows.to(torch.int32))
+                    rows = batch_rows.to(torch.int32)
+                    x = layer(x, output_rows=rows) if restrict_last_layer else layer(x, cotangent_rows=rows)
                 else:
                     x = layer(x)
             if tail_gradients is not None:
@@ -84,8 +86,19 @@ class RawGnn(nn.Module):
         return outputs
 
     def propagate(self) -> Tensor:
-        """``[N, d*(L+1)]``: all layer outputs side by side (``RawGnn.py:122``)."""
-        return torch.cat(self.propagate_layers(), 1)
+        """``[N, d*(L+1)]``: all layer outputs side by side (``RawGnn.py:122``).  Outside autograd (the evaluation cache,
+        ``save_features_for_test``) the matrix is allocated once and every layer WRITES ITS COLUMN SLICE of it - the kernels take row
+        strides, layer l reads columns ``(l-1) d ..`` and writes columns ``l d ..`` of the same buffer - so there is no concatenation
+        pass over ``[N, D]``.  Under autograd the outputs are separate tensors and are concatenated."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return torch.cat(self.propagate_layers(), 1)
+        d = self.embedding_size
+        w = self.embeddings.embedding_bag_vocabulary.weight
+        features = torch.empty(self.dataset.node_count, self.output_feature_size, dtype=torch.float32, device=w.device)
+        x = self.embeddings.all_nodes(out=features[:, :d])
+        for depth, layer in enumerate(self.gnns, 1):
+            x = layer(x, out=features[:, depth * d:(depth + 1) * d])
+        return features
 
     def forward(self, user_indices: Tensor, query_indices: Tensor, item_indices: Optional[Tensor] = None) -> Tensor:
         """Indices are 0-based per type.  ``item_indices=None`` scores the given (user, query) against every item."""
@@ -123,7 +136,7 @@ class RawGnn(nn.Module):
         ds, head = self.dataset, self.prediction_layer
         rows = torch.cat([user_indices, query_indices + ds.query_start_index_in_graph, item_indices + ds.item_start_index_in_graph])
         holder = ops.TailGradients() if torch.is_grad_enabled() else None
-        return ops.hem_bce_loss(self.propagate_layers(holder, rows if self.batch_rows_only_last_layer else None), rows, item_indices, labels,
+        return ops.hem_bce_loss(self.propagate_layers(holder, rows, self.batch_rows_only_last_layer), rows, item_indices, labels,
                                 head.items_bias, head.lambda_muq,
                                 ds.item_start_index_in_graph, holder)
 
@@ -133,7 +146,8 @@ class RawGnn(nn.Module):
                 and len(self.gnns) + 1 <= 8 and next(self.parameters()).is_cuda)
 
     def score_all_items(self, user_indices: Tensor, query_indices: Tensor) -> Tensor:
-        """Scores of ``C`` (user, query) pairs against every item in one GEMM: ``[C] x [C] -> [C, I]``.
+        """Scores of ``C`` (user, query) pairs against every item as a dense ``[C, I]`` matrix (torch; a checker for tests and
+        notebooks - the evaluation loop uses ``top_items``, which never builds that matrix).
 
         Same arithmetic as ``forward(u * ones(I), q * ones(I), None)`` per pair (``RawGnn.py:124-137`` +
         ``PredictionLayers.py:35-43``), batched: ``(lam*F[q] + (1-lam)*F[u]) @ F_items^T + bias``."""
@@ -147,15 +161,14 @@ class RawGnn(nn.Module):
     def top_items(self, user_indices: Tensor, query_indices: Tensor, k: int = 10):
         """``(items [C, k] int32, scores [C, k])``: the ``k`` best items of each (user, query) pair over the whole catalogue, best
         first - what ``Metrics.calculate_on_all_items`` keeps of ``forward(u, q, None)`` (``Metrics.py:60-61``) - from the fused
-        HIP scoring + running top-k kernel; the ``[C, I]`` scores are never stored.  Ties: ascending item id."""
+        HIP scoring + running top-k kernel; the ``[C, I]`` scores are never stored.  Ties: ascending item id.  No torch path: the feature width
+        ``d (L + 1)`` must be a multiple of 4 (``ops.score_topk`` raises otherwise)."""
         from .. import ops
         features = self._saved_output_feature if self._saved_output_feature is not None else self.propagate()
         ds, head = self.dataset, self.prediction_layer
         k = min(k, ds.item_count)
-        if not ops.score_topk_supported(features) or k > 10:
-            scores = self.score_all_items(user_indices, query_indices)          # odd widths (d % 4 != 0): rocBLAS + a stable sort
-            order = torch.sort(scores, dim=1, descending=True, stable=True).indices[:, :k]
-            return order.to(torch.int32), torch.gather(scores, 1, order)
+        if k > 10:
+            raise NotImplementedError('RawGnn.top_items keeps at most ten items per pair (the reference reports HR / NDCG / MAP @10, Metrics.py:60-88)')
         return ops.score_topk(features, user_indices, query_indices, ds.query_start_index_in_graph, ds.item_start_index_in_graph,
                               head.items_bias, head.lambda_muq, k)
 

@@ -590,33 +590,72 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_generic_kernel(const f
     }
 }
 
-// dW_t[c][j] = sum_{v in t} dout[v][c] x[v][j]; the bias part as dense_slab_reduce_kernel writes it
+// dW_t[c][j] = sum_{v in t} dout[v][c] x[v][j] and the bias gradient for ANY width: grid = (row slabs, 16 x 16 output tiles, weight
+// types); a workgroup walks its slab of the type's rows in chunks of 32 staged in LDS, thread (c, j) of the tile keeps one sum (rows in
+// index order); per-slab partials in dense_weight_grad_kernel's slab layout ([type][slab][d][d], bias part [type][slab][d]), added up in
+// slab order by dense_generic_reduce_kernel - deterministic, and N / slabs serial steps per thread instead of N.
+constexpr int kGenericSlabs = 64;
+constexpr int kGenericChunk = 32;
+
 __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_generic_kernel(const float* __restrict__ dout, int64_t ld_dout, const float* __restrict__ x,
-                                                                                  int64_t ld_x, TypePlan plan, int n_types, int d, float* __restrict__ dw,
-                                                                                  int64_t ld_dw, int64_t dw_type_stride, float* __restrict__ dbias,
-                                                                                  int bias_mask, int64_t dbias_type_stride) {
+                                                                                  int64_t ld_x, TypePlan plan, int single_weight, int d,
+                                                                                  float* __restrict__ slabs, float* __restrict__ bias_slabs) {
+    __shared__ float dt[kGenericChunk][17], xt[kGenericChunk][17];
+    const int tiles = (d + 15) / 16;
+    const int tc = blockIdx.y / tiles, tj = blockIdx.y % tiles, type = blockIdx.z;
+    const int n_slabs = gridDim.x;
+    const int64_t r_begin = single_weight ? plan.begin[0] : plan.begin[type], r_end = single_weight ? plan.begin[3] : plan.begin[type + 1];
+    const int64_t per = (r_end - r_begin + n_slabs - 1) / n_slabs;
+    const int64_t v0 = r_begin + blockIdx.x * per, v1 = v0 + per < r_end ? v0 + per : r_end;
+    const int tid = threadIdx.x, c = tid >> 4, j = tid & 15;
+    float acc = 0.f, colsum = 0.f;
+    for (int64_t base = v0; base < v1; base += kGenericChunk) {
+        for (int idx = tid; idx < kGenericChunk * 16; idx += kBlockThreads) {
+            const int r = idx >> 4, k = idx & 15;
+            const int64_t v = base + r;
+            const bool live = v < v1;
+            dt[r][k] = live && 16 * tc + k < d ? dout[v * ld_dout + 16 * tc + k] : 0.f;
+            xt[r][k] = live && 16 * tj + k < d ? x[v * ld_x + 16 * tj + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < kGenericChunk; ++r) acc += dt[r][c] * xt[r][j];
+        if (tj == 0 && j == 0) {
+#pragma unroll 8
+            for (int r = 0; r < kGenericChunk; ++r) colsum += dt[r][c];
+        }
+        __syncthreads();
+    }
+    const int64_t slab = static_cast<int64_t>(type) * n_slabs + blockIdx.x;
+    if (16 * tc + c < d && 16 * tj + j < d) slabs[(slab * d + 16 * tc + c) * d + 16 * tj + j] = acc;
+    if (tj == 0 && j == 0 && 16 * tc + c < d) bias_slabs[slab * d + 16 * tc + c] = colsum;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void dense_generic_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias_slabs, int n_slabs,
+                                                                             int n_types, int d, float* __restrict__ dw, int64_t ld_dw, int64_t dw_type_stride,
+                                                                             float* __restrict__ dbias, int bias_mask, int64_t dbias_type_stride) {
     const int64_t per_type = static_cast<int64_t>(d) * d;
     const int64_t total = per_type * n_types + d;
     for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         if (idx < per_type * n_types) {
             const int type = static_cast<int>(idx / per_type);
-            const int c = static_cast<int>((idx % per_type) / d), j = static_cast<int>(idx % d);
-            const int64_t v0 = n_types == 1 ? plan.begin[0] : plan.begin[type], v1 = n_types == 1 ? plan.begin[3] : plan.begin[type + 1];
+            const int64_t rem = idx % per_type;
+            const float* src = slabs + static_cast<int64_t>(type) * n_slabs * per_type + rem;
             float acc = 0.f;
-            for (int64_t v = v0; v < v1; ++v) acc += dout[v * ld_dout + c] * x[v * ld_x + j];
-            dw[static_cast<int64_t>(c) * ld_dw + type * dw_type_stride + j] = acc;
+            for (int sl = 0; sl < n_slabs; ++sl) acc += src[sl * per_type];
+            dw[(rem / d) * ld_dw + type * dw_type_stride + rem % d] = acc;
         } else if (dbias != nullptr) {
             const int c = static_cast<int>(idx - per_type * n_types);
             float all = 0.f;
-            for (int type = 0; type < 3; ++type) {
+            for (int type = 0; type < n_types; ++type) {
                 const bool use = n_types == 1 || ((bias_mask >> type) & 1);
                 float part = 0.f;
                 if (use)
-                    for (int64_t v = plan.begin[type]; v < plan.begin[type + 1]; ++v) part += dout[v * ld_dout + c];
+                    for (int sl = 0; sl < n_slabs; ++sl) part += bias_slabs[(static_cast<int64_t>(type) * n_slabs + sl) * d + c];
                 all += part;
-                if (n_types != 1 && dbias_type_stride != 0) dbias[type * dbias_type_stride + c] = part;
+                if (dbias_type_stride != 0) dbias[type * dbias_type_stride + c] = part;
             }
-            if (n_types == 1 || dbias_type_stride == 0) dbias[c] = all;
+            if (dbias_type_stride == 0) dbias[c] = all;
         }
     }
 }
@@ -641,7 +680,7 @@ extern "C" {
 
 int64_t ihg_node_linear_workspace_bytes(int32_t dim) {
     if (dim <= 0) return -1;
-    if (!mfma_dim(dim)) return 0;                           // any-width kernels: no packed weights, no slabs
+    if (!mfma_dim(dim)) return 3LL * kGenericSlabs * (static_cast<int64_t>(dim) * dim + dim) * static_cast<int64_t>(sizeof(float));      // any-width kernels: row-slab partials only
     const int64_t packed = 3LL * dim * dim;
     const int64_t slabs = 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
     return (packed + slabs + split_dense_plane_floats(dim)) * static_cast<int64_t>(sizeof(float));
@@ -688,6 +727,12 @@ int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w
     return check_launch("ihg_node_linear_bwd_input");
 }
 
+int32_t ihg_node_linear_bwd_accumulates(int32_t dim, int64_t ld_dout, int64_t ld_x, int64_t ld_dx) {
+    // the weight-gradient kernels that form dx in the same pass and can add it onto what dx already holds: d = 64 (fp32 MFMA), d = 128 (bf16-split)
+    if (ld_dout % 4 || ld_x % 4 || ld_dx % 4) return 0;
+    return dim == 64 || (dim == 128 && split_arith_enabled()) ? 1 : 0;
+}
+
 int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin,
                                float* dw, int64_t ld_dw, int64_t dw_type_stride, float* dbias, int32_t bias_type_mask, int64_t dbias_type_stride,
                                const float* w, int64_t ld_w, float* dx, int64_t ld_dx, int32_t dx_accumulate,
@@ -695,15 +740,24 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     if (int rc = node_linear_common_check("ihg_node_linear_bwd_weight", dim, ld_dout, ld_x, ld_dw, type_begin, workspace, workspace_bytes)) return rc;
     if (dout == nullptr || x == nullptr || dw == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: null pointer");
     if (dx != nullptr && (w == nullptr || ld_w < dim || ld_dx < dim)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx needs w and row strides >= dim");
-    if (dx_accumulate && (dx == nullptr || dim != 64)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate needs dx and dim 64 (the fused kernel)");
+    if (dx_accumulate && (dx == nullptr || !ihg_node_linear_bwd_accumulates(dim, ld_dout, ld_x, ld_dx)))
+        return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate needs dx and a fused input-gradient kernel (ihg_node_linear_bwd_accumulates)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_types = dw_type_stride == 0 ? 1 : 3;
     if (!tiled_node_linear(dim, ld_dout, ld_x, dout, workspace) || !aligned16(x) || (dx != nullptr && ld_dx % 4)) {
         if (dx != nullptr) launch_row_gemm_generic(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, s);
+        // row-slab partials at the front of the workspace (every width's workspace holds at least kGenericSlabs of them), then a fixed-order sum
+        const int64_t need = 3LL * kGenericSlabs * (static_cast<int64_t>(dim) * dim + dim) * static_cast<int64_t>(sizeof(float));
+        if (workspace == nullptr || workspace_bytes < need) return fail(IHG_ERR_WORKSPACE, "ihg_node_linear_bwd_weight: workspace too small (any-width path)");
+        float* gslabs = static_cast<float*>(workspace);
+        float* gbias = gslabs + 3LL * kGenericSlabs * dim * dim;
+        const int tiles = (dim + 15) / 16;
+        hipLaunchKernelGGL(dense_weight_grad_generic_kernel, dim3(kGenericSlabs, tiles * tiles, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x,
+                           make_plan(type_begin, 64), n_types == 1 ? 1 : 0, dim, gslabs, gbias);
         const int64_t total = static_cast<int64_t>(dim) * dim * n_types + dim;
-        hipLaunchKernelGGL(dense_weight_grad_generic_kernel, dim3(static_cast<int>(std::min<int64_t>((total + kBlockThreads - 1) / kBlockThreads, kMaxBlocks))),
-                           dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, make_plan(type_begin, 64), n_types, dim, dw, ld_dw, dw_type_stride, dbias,
-                           bias_type_mask, n_types == 1 ? int64_t{0} : dbias_type_stride);
+        hipLaunchKernelGGL(dense_generic_reduce_kernel, dim3(static_cast<int>(std::min<int64_t>((total + kBlockThreads - 1) / kBlockThreads, kMaxBlocks))),
+                           dim3(kBlockThreads), 0, s, gslabs, gbias, kGenericSlabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask,
+                           n_types == 1 ? int64_t{0} : dbias_type_stride);
         return check_launch("ihg_node_linear_bwd_weight");
     }
     float* slabs = static_cast<float*>(workspace) + 3LL * dim * dim;
@@ -715,8 +769,9 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
         const bool fused_dx = dx != nullptr && dim == 128 && aligned16(dx) && ld_dx % 4 == 0;
         if (dx != nullptr && !fused_dx) launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace), s);
         void* planes = static_cast<float*>(workspace) + 3LL * dim * dim + 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
+        if (dx_accumulate && !fused_dx) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate needs 16-byte aligned dx rows at dim 128");
         n_slabs = launch_dense_weight_split(dim, dout, ld_dout, x, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, fused_dx ? dx : nullptr, ld_dx,
-                                            planes, s);
+                                            planes, s, dx_accumulate);
     } else if (dim == 64 && dx != nullptr) {
         hipLaunchKernelGGL((dense_weight_grad_kernel<64, true>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
                            n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, w, ld_w, dw_type_stride, dx, ld_dx, dx_accumulate);

@@ -217,11 +217,13 @@ int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query
     const int64_t n_lists = static_cast<int64_t>(slices) * kEvalWaves * 2;
     float* part_val = static_cast<float*>(workspace);
     int32_t* part_idx = reinterpret_cast<int32_t*>(part_val + n_pairs * n_lists * kTopMax);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                           // per device ordinal: the opt-in to > 64 KB of LDS belongs to the device's code object
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) (void)hipGetLastError();
+    if (device < 0 || device >= 64 || !attr_set[device]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
-        attr_set = true;
+        if (device >= 0 && device < 64) attr_set[device] = true;
     }
     const int64_t blocks = (n_pairs + kPairsPerBlock - 1) / kPairsPerBlock;
     hipLaunchKernelGGL(score_topk_kernel, dim3(static_cast<unsigned>(blocks), slices), dim3(kBlockThreads), lds, s, features, ld, dim, item_row0, n_items,

@@ -40,4 +40,4 @@ IHG_INTERNAL void launch_row_gemm_split(int dim, const float* in, int64_t ld_in,
 IHG_INTERNAL bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x);
 IHG_INTERNAL int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin, int n_types,
                                            float* slabs, float* bias_slabs, const float* w, int64_t ld_w, int64_t w_type_stride, float* dx, int64_t ld_dx,
-                                           void* planes, hipStream_t s);        // dx != nullptr (dim 128, 16-byte aligned rows): dx = dout W_t of the same rows, fused
+                                           void* planes, hipStream_t s, int dx_accumulate = 0);   // dx != nullptr (dim 128, 16-byte aligned rows): dx (+)= dout W_t of the same rows, fused

@@ -1234,7 +1234,7 @@ template <int D, bool DX>
 __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(const float* __restrict__ dout, int64_t ld_dout, const float* __restrict__ x,
                                                                                 int64_t ld_x, RowTiles plan, int single_weight, float* __restrict__ slabs,
                                                                                 float* __restrict__ bias_slabs, const v4u* __restrict__ pk, int64_t pk_type_stride,
-                                                                                float* __restrict__ dx, int64_t ld_dx) {
+                                                                                float* __restrict__ dx, int64_t ld_dx, int dx_accumulate) {
     static_assert(!DX || D == 128, "the fused input gradient holds a whole weight matrix per workgroup");
     constexpr int TE = 32, HALVES = D / 128, DOCT = D / 128, IT = D / 64, DRB = 2 * D;     // dout image rows: 2 D bytes, x image rows: 256 bytes (128 columns)
     constexpr int DPL = TE * DRB, XPL = TE * 256;
@@ -1335,6 +1335,17 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
         auto phase = [&](auto parity, int k, Rows& use, Rows& fill) {
             constexpr int BUF = decltype(parity)::value;
             if (k + 2 < n_my) load_rows(k + 2, fill);
+            // dx_accumulate: dx already holds another contribution to the same gradient (the member gradients of the interactive step); its rows
+            // of this tile are requested now and seed the accumulators of the dx product at the end of the phase
+            v4f gold[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+            if (DX && dx_accumulate) {
+                const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int64_t v = r_base + 16 * rt + (lane & 15);
+                    if (v < r_end) gold[rt] = *reinterpret_cast<const v4f*>(dx + v * ld_dx + 16 * wave + 4 * (lane >> 4));
+                }
+            }
             const unsigned char* dp = &dplanes[BUF][0][0][0];
             const unsigned char* xp = &xplanes[BUF][0][0][0];
             v8s a[IT][3];
@@ -1370,7 +1381,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                 const int arow = lane & 15, kq = lane >> 4;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    gx[rt] = v4f{0.f, 0.f, 0.f, 0.f};
+                    gx[rt] = gold[rt];
                     const int r = 16 * rt + arow;
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) {
@@ -1578,7 +1589,8 @@ bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const fl
 }
 
 int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs,
-                              float* bias_slabs, const float* w, int64_t ld_w, int64_t w_type_stride, float* dx, int64_t ld_dx, void* planes, hipStream_t s) {
+                              float* bias_slabs, const float* w, int64_t ld_w, int64_t w_type_stride, float* dx, int64_t ld_dx, void* planes, hipStream_t s,
+                              int dx_accumulate) {
     RowTiles plan;
     for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
     for (int t = 0; t < 4; ++t) plan.tile_prefix[t] = 0;                 // (the kernel takes its tiles from the row ranges)
@@ -1590,15 +1602,15 @@ int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, const
             hipLaunchKernelGGL(pack_planes_dense_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types,
                                dim, 1, pk);
             hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, true>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                               n_types == 1 ? 1 : 0, slabs, bias_slabs, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 3 * kWave}, dx, ld_dx);
+                               n_types == 1 ? 1 : 0, slabs, bias_slabs, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 3 * kWave}, dx, ld_dx, dx_accumulate);
         } else {
             hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, false>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                               n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), int64_t{0});
+                               n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), int64_t{0}, 0);
         }
         return n_seq;
     }
     const int n_seq = 128;
     hipLaunchKernelGGL((dense_weight_grad_split_kernel<256, false>), dim3(2 * n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                       n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), int64_t{0});
+                       n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), int64_t{0}, 0);
     return n_seq;
 }

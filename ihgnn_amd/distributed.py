@@ -160,7 +160,12 @@ class BucketedGradientSync(GradientSync):
 
     def _on_grad(self, p) -> None:
         index = self._bucket_of[p]
-        view_ok = p.grad is not None and self.flat.data_ptr() <= p.grad.data_ptr() < self.flat.data_ptr() + self.flat.numel() * 4
+        if self._launched[index]:
+            # a second backward before average_gradients() (gradient accumulation, two losses): the bucket's exchange is already in flight,
+            # the new contribution would land on top of the averaged values and never be reduced - the ranks would drift apart silently
+            raise RuntimeError('BucketedGradientSync: a gradient arrived for a bucket whose all-reduce was already launched; call '
+                               'average_gradients() after every backward, or use the flat exchange for gradient accumulation')
+        view_ok = p.grad is not None and self.flat.data_ptr() <= p.grad.data_ptr() < self.flat.data_ptr() + self.flat.numel() * self.flat.element_size()
         if not view_ok:                                      # someone detached the view (set_to_none): exchange everything at the end
             self._pending[index] = -1
             return
@@ -204,10 +209,49 @@ class _ShardOptimizer:
         self.sync.zero_grad()
 
     def state_dict(self):
-        return self.inner.state_dict()
+        """Adam state of ALL parameters: every rank's shard of ``exp_avg`` / ``exp_avg_sq`` gathered into full-length flat vectors
+        (the same on every rank, so rank 0's checkpoint is complete and can be resumed at another world size)."""
+        sync = self.sync
+        state = self.inner.state_dict()
+        entry = next(iter(state['state'].values()), None)
+        full = {}
+        if entry is not None:
+            for key in ('exp_avg', 'exp_avg_sq'):
+                gathered = torch.empty(sync.padded, dtype=sync.param_shard.dtype, device=sync.param_shard.device)
+                if sync.world_size > 1:
+                    dist.all_gather_into_tensor(gathered, entry[key].reshape(-1).contiguous(), group=sync.group)
+                else:
+                    gathered.copy_(entry[key].reshape(-1))
+                full[key] = gathered[:sync.flat.numel()].clone()
+            full['step'] = entry['step']
+        return {'sharded_adam': full, 'param_groups': state['param_groups'], 'numel': sync.flat.numel()}
 
     def load_state_dict(self, state):
-        self.inner.load_state_dict(state)
+        sync = self.sync
+        if 'sharded_adam' not in state:
+            raise ValueError('not a sharded-Adam checkpoint (expected the dict written by _ShardOptimizer.state_dict)')
+        if state['numel'] != sync.flat.numel():
+            raise ValueError(f"checkpoint holds Adam state for {state['numel']} parameters, the model has {sync.flat.numel()}")
+        full = state['sharded_adam']
+        if not full:
+            return
+        lo, hi = sync.shard_range
+        inner = self.inner.state_dict()
+        if not inner['state']:                               # no step taken yet: let the inner optimizer create its buffers
+            self.shard.grad = torch.zeros_like(self.shard)
+            saved = self.shard.detach().clone()
+            self.inner.step()
+            with torch.no_grad():
+                self.shard.copy_(saved)
+            inner = self.inner.state_dict()
+        entry = next(iter(inner['state'].values()))
+        for key in ('exp_avg', 'exp_avg_sq'):
+            padded = torch.zeros(sync.padded, dtype=sync.param_shard.dtype, device=sync.param_shard.device)
+            padded[:sync.flat.numel()].copy_(full[key].to(padded.device))
+            entry[key] = padded[lo:hi].clone().view_as(entry[key])
+        entry['step'] = full['step']
+        inner['param_groups'] = state['param_groups']
+        self.inner.load_state_dict(inner)
 
 
 class ShardedGradientSync(GradientSync):
@@ -324,6 +368,9 @@ class ShardedBatchSampler:
             for lo in range(0, len(mine), self.batch_size):
                 yield mine[lo:lo + self.batch_size]
             return
+        if len(mine) < self.n_batches:
+            raise ValueError(f'rank {self.rank} holds {len(mine)} rows for {self.n_batches} batches: batch_size {self.batch_size} is too small for '
+                             f'{self.world_size} ranks (an empty batch on one rank would leave the others waiting in the gradient exchange)')
         base, extra = divmod(len(mine), self.n_batches)
         lo = 0
         for b in range(self.n_batches):

@@ -100,6 +100,14 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
     return out
 
 
+def _check_out(out: Optional[Tensor], *inputs: Tensor) -> Optional[Tensor]:
+    """``out=``: a caller-owned ``[rows, d]`` destination (any row stride - a column slice of the ``[N, d (L + 1)]`` feature matrix,
+    ``RawGnn.propagate``).  Only outside autograd: a recorded op must own its output."""
+    if out is not None and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in inputs):
+        raise ValueError('out= is for inference (torch.no_grad()): a differentiable op allocates its own output')
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # K5 / K7 as a transposed pair
 # ---------------------------------------------------------------------------------------------
@@ -121,14 +129,14 @@ class _EdgeGatherSum(torch.autograd.Function):
 
 class _NodeSegmentSum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor], rows: Optional[Tensor]) -> Tensor:
+    def forward(ctx, src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor], rows: Optional[Tensor], out: Optional[Tensor]) -> Tensor:
         ctx.layout, ctx.out_scale = layout, out_scale
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(src, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes')
+        return node_segment_sum_raw(src, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=_check_out(out, src))
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
-        return edge_gather_sum_raw(grad_out, ctx.layout.i3, ctx.out_scale, None, 1.0), None, None, None
+        return edge_gather_sum_raw(grad_out, ctx.layout.i3, ctx.out_scale, None, 1.0), None, None, None, None
 
 
 def edge_gather_sum(src: Tensor, layout: IncidenceLayout, node_scale: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
@@ -136,13 +144,14 @@ def edge_gather_sum(src: Tensor, layout: IncidenceLayout, node_scale: Optional[T
     return _EdgeGatherSum.apply(src, layout, node_scale, float(alpha))
 
 
-def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor] = None, rows: Optional[Tensor] = None) -> Tensor:
+def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor] = None, rows: Optional[Tensor] = None,
+                     out: Optional[Tensor] = None) -> Tensor:
     """hyperedge -> node: ``out[v] = out_scale[v] * sum_{e containing v} src[e]``  (``[E,d] -> [N,d]``).
 
     ``rows`` (int32): the caller reads only these rows of the result (the batch rows of the last layer's output in a training
     step); rows outside the list and outside the split-row plan are left UNWRITTEN.  The gradient must then be zero outside
     ``rows`` too - which it is when only those rows were read."""
-    return _NodeSegmentSum.apply(src, layout, out_scale, rows)
+    return _NodeSegmentSum.apply(src, layout, out_scale, rows, out)
 
 
 class _TwoHop(torch.autograd.Function):
@@ -151,46 +160,56 @@ class _TwoHop(torch.autograd.Function):
     ``H H^T`` is symmetric, so the backward is the same launch with the two diagonal scalings swapped."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor], out_scale: Optional[Tensor], rows: Optional[Tensor]) -> Tensor:
-        ctx.layout, ctx.in_scale, ctx.out_scale, ctx.rows = layout, in_scale, out_scale, rows
+    def forward(ctx, x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor], out_scale: Optional[Tensor], rows: Optional[Tensor],
+                cotangent_rows: Optional[Tensor], out: Optional[Tensor]) -> Tensor:
+        ctx.layout, ctx.in_scale, ctx.out_scale = layout, in_scale, out_scale
+        # rows outside which the cotangent is zero: the rows that were computed at all, or the caller's explicit promise
+        ctx.cot_rows = rows if rows is not None else (cotangent_rows if SPARSE_LAST_COTANGENT else None)
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(x, layout.hop2_csr, in_scale, out_scale, mode, self_weight=layout.self_weight, rows=rows, role='k7.two_hop')
+        return node_segment_sum_raw(x, layout.hop2_csr, in_scale, out_scale, mode, self_weight=layout.self_weight, rows=rows, role='k7.two_hop',
+                                    out=_check_out(out, x))
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         lay = ctx.layout
         mode = _lib.SCALE_NONE if ctx.in_scale is None else _lib.SCALE_MULTIPLY
-        mask = _nonzero_row_mask(grad_out, lay.node_count)      # the last layer's cotangent: zero outside the batch rows (the tap says so)
-        if mask is None and ctx.rows is not None:
-            # only `rows` of the output were read, so grad_out is zero elsewhere: the pull skips the gathers of those zero rows
-            # (two thirds of them - every neighbour that is not a query - and the ones that would miss the cache)
+        mask = None
+        if ctx.cot_rows is not None:
+            # grad_out is zero outside these rows: the pull skips the gathers of the zero rows (two thirds of them - every neighbour that
+            # is not a query - and the ones that would miss the cache); same gradient as the dense pull
             mask = torch.zeros(lay.node_count, dtype=torch.uint8, device=grad_out.device)
-            mask.index_fill_(0, ctx.rows.long(), 1)
+            mask.index_fill_(0, ctx.cot_rows.long(), 1)
+            if CHECK_SPARSE_COTANGENT and bool((grad_out[mask == 0] != 0).any()):
+                raise RuntimeError('node_two_hop: the cotangent is not zero outside cotangent_rows / rows - the output has a consumer the caller did not declare')
         return (node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight, src_mask=mask,
                                      role='k7.two_hop_bwd' if mask is None else 'k7.two_hop_bwd_masked'),
-                None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def node_two_hop(x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None,
-                 rows: Optional[Tensor] = None) -> Tensor:
+                 rows: Optional[Tensor] = None, cotangent_rows: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """``out[v] = out_scale[v] * sum_{e containing v} sum_{w in e} in_scale[w] * x[w]`` - the first-order
     node -> hyperedge -> node step (K5 followed by K7) without materialising the hyperedge features.  ``rows``: as in
-    ``node_segment_sum``."""
-    return _TwoHop.apply(x, layout, in_scale, out_scale, rows)
+    ``node_segment_sum``.  ``cotangent_rows`` (int32 / int64 node rows): the caller's PROMISE that the gradient with respect to the
+    output is zero outside these rows - true of the last layer of a training step, whose output is read at the batch rows only - so
+    the backward pulls just them.  The promise is carried by the op itself (not looked up by address); ``IHG_CHECK_SPARSE_COTANGENT=1``
+    verifies it at every backward.  ``IHG_SPARSE_LAST_COTANGENT=0`` ignores it (dense pull, same gradient)."""
+    return _TwoHop.apply(x, layout, in_scale, out_scale, rows, cotangent_rows, out)
 
 
 class _PairSpmm(torch.autograd.Function):
     """``out = Ds (A (Ds x))`` for a symmetric weighted adjacency: its own transpose, so backward is the same launch."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, graph) -> Tensor:
+    def forward(ctx, x: Tensor, graph, out: Optional[Tensor]) -> Tensor:
         ctx.graph = graph
-        return node_segment_sum_raw(x, graph.csr, graph.inv_sqrt_deg, graph.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=graph.values, role='k7.pair_graph')
+        return node_segment_sum_raw(x, graph.csr, graph.inv_sqrt_deg, graph.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=graph.values, role='k7.pair_graph',
+                                    out=_check_out(out, x))
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         g = ctx.graph
-        return node_segment_sum_raw(grad_out, g.csr, g.inv_sqrt_deg, g.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=g.values, role='k7.pair_graph'), None
+        return node_segment_sum_raw(grad_out, g.csr, g.inv_sqrt_deg, g.inv_sqrt_deg, _lib.SCALE_MULTIPLY, entry_scale=g.values, role='k7.pair_graph'), None, None
 
 
 class _CsrSpmm(torch.autograd.Function):
@@ -198,33 +217,33 @@ class _CsrSpmm(torch.autograd.Function):
     is the same launch over the transpose with the two scalings swapped."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, csr, csr_t, values, values_t, src_scale, out_scale, role: str) -> Tensor:
+    def forward(ctx, x: Tensor, csr, csr_t, values, values_t, src_scale, out_scale, role: str, out: Optional[Tensor]) -> Tensor:
         ctx.args = (csr, csr_t, values, values_t, src_scale, out_scale, role)
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(x, csr, src_scale, out_scale, mode, entry_scale=values, role=role)
+        return node_segment_sum_raw(x, csr, src_scale, out_scale, mode, entry_scale=values, role=role, out=_check_out(out, x))
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         csr, csr_t, values, values_t, src_scale, out_scale, role = ctx.args
         mode = _lib.SCALE_NONE if src_scale is None else _lib.SCALE_MULTIPLY
-        return (node_segment_sum_raw(grad_out, csr_t, out_scale, src_scale, mode, entry_scale=values_t, role=role + '_bwd'),) + (None,) * 7
+        return (node_segment_sum_raw(grad_out, csr_t, out_scale, src_scale, mode, entry_scale=values_t, role=role + '_bwd'),) + (None,) * 8
 
 
 def hyper_node_to_edge(x: Tensor, layout, src_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None) -> Tensor:
     """node -> hyperedge over a general (variable-arity) incidence: ``out[e] = out_scale[e] * sum_{v in e} val(v,e) src_scale[v] x[v]``
     (``thsp.matmul(incidence_t, .)``, ``GnnLayers.py:148``) - ``layout`` is a :class:`ihgnn_amd.layout.LogHyperLayout`."""
-    return _CsrSpmm.apply(x, layout.edge_csr, layout.node_csr, layout.edge_values, layout.node_values, src_scale, out_scale, 'k7.hyper_node_to_edge')
+    return _CsrSpmm.apply(x, layout.edge_csr, layout.node_csr, layout.edge_values, layout.node_values, src_scale, out_scale, 'k7.hyper_node_to_edge', None)
 
 
-def hyper_edge_to_node(x: Tensor, layout, src_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None) -> Tensor:
+def hyper_edge_to_node(x: Tensor, layout, src_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """hyperedge -> node over a general incidence: ``out[v] = out_scale[v] * sum_{e containing v} val(v,e) src_scale[e] x[e]``
     (``thsp.matmul(incidence, .)``, ``GnnLayers.py:151``)."""
-    return _CsrSpmm.apply(x, layout.node_csr, layout.edge_csr, layout.node_values, layout.edge_values, src_scale, out_scale, 'k7.hyper_edge_to_node')
+    return _CsrSpmm.apply(x, layout.node_csr, layout.edge_csr, layout.node_values, layout.edge_values, src_scale, out_scale, 'k7.hyper_edge_to_node', out)
 
 
-def pair_spmm(x: Tensor, graph) -> Tensor:
+def pair_spmm(x: Tensor, graph, out: Optional[Tensor] = None) -> Tensor:
     """GCN propagation ``D^-1/2 A D^-1/2 x`` over a :class:`ihgnn_amd.layout.PairLayout` (``GnnLayers.py:35-38``)."""
-    return _PairSpmm.apply(x, graph)
+    return _PairSpmm.apply(x, graph, out)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -286,19 +305,21 @@ class _EmbedAllNodes(torch.autograd.Function):
     kernel writes its rows in place), with a backward that hands each table its gradient without a full-size zero fill."""
 
     @staticmethod
-    def forward(ctx, user_table: Tensor, item_table: Tensor, word_table: Tensor, bag: BagLayout) -> Tensor:
+    def forward(ctx, user_table: Tensor, item_table: Tensor, word_table: Tensor, bag: BagLayout, out: Optional[Tensor]) -> Tensor:
         lib = _lib.load()
         word_table = _rows(word_table, 'word table')
         u, q, i = int(user_table.shape[0]) - 1, bag.n_bags, int(item_table.shape[0]) - 1
         dim = int(word_table.shape[1])
-        x = torch.empty(u + q + i, dim, dtype=torch.float32, device=word_table.device)
+        x = _check_out(out, user_table, item_table, word_table)
+        if x is None:
+            x = torch.empty(u + q + i, dim, dtype=torch.float32, device=word_table.device)
         x[:u].copy_(user_table[1:])
         x[u + q:].copy_(item_table[1:])
         rows = x[u:u + q]
         if q > 0:
             with profiler.kernel('bag_mean_fwd', q, dim):
                 _lib.check(lib.ihg_bag_mean_fwd(_ptr(word_table), _ld(word_table), _ptr(bag.bags.ptr), _ptr(bag.bags.ids), _ptr(bag.bag_len),
-                                                _ptr(rows), dim, q, dim, _stream()), 'ihg_bag_mean_fwd')
+                                                _ptr(rows), _ld(x), q, dim, _stream()), 'ihg_bag_mean_fwd')
         ctx.bag, ctx.counts = bag, (u, q, i)
         return x
 
@@ -319,13 +340,13 @@ class _EmbedAllNodes(torch.autograd.Function):
         with profiler.kernel('bag_mean_bwd', bag.table_rows, dim):
             _lib.check(lib.ihg_bag_mean_bwd(_ptr(g_q), _ld(grad), _ptr(bag.words_of.ptr), _ptr(bag.words_of.ids),
                                             _ptr(bag.inv_len), _ptr(d_word), dim, bag.table_rows, dim, _stream()), 'ihg_bag_mean_bwd')
-        return d_user, d_item, d_word, None
+        return d_user, d_item, d_word, None, None
 
 
-def embed_all_nodes(user_table: Tensor, item_table: Tensor, word_table: Tensor, bag: BagLayout) -> Tensor:
+def embed_all_nodes(user_table: Tensor, item_table: Tensor, word_table: Tensor, bag: BagLayout, out: Optional[Tensor] = None) -> Tensor:
     """The full-graph input features ``EmbeddingLayer(None, None, None)`` concatenated (``RawGnn.py:112-113``): ``[U+Q+I, d]``
     from the ``[U+1, d]`` / ``[I+1, d]`` tables (row 0 = padding) and the ``[V+1, d]`` word table."""
-    return _EmbedAllNodes.apply(user_table, item_table, word_table, bag)
+    return _EmbedAllNodes.apply(user_table, item_table, word_table, bag, out)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -452,11 +473,13 @@ def node_linear(x: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceL
 # the [E, 3, d] member-gradient buffer of the interactive backward is produced in hyperedge chunks beyond this many bytes
 MEMBER_BUFFER_LIMIT_BYTES = 48 << 30
 import os as _os
-import weakref
 # use ihg_interact_bwd_user_reduced (user slot summed on chip, [E, 2, d] member buffer) where the library offers it; IHG_USER_REDUCED=0
 # keeps the [E, 3, d] form (C3: the same step time with the bf16-split kernels - the scan costs their service waves what K7 saves - and
 # 1.1 GB less written and read per step; -0.05 ms with the fp32-MFMA kernels).  Tests compare the two forms.
 USER_REDUCED_BACKWARD = _os.environ.get('IHG_USER_REDUCED', '1') != '0'
+# the last layer of a training step is told which rows of its output are read (node_two_hop's cotangent_rows): its backward pulls only those
+SPARSE_LAST_COTANGENT = _os.environ.get('IHG_SPARSE_LAST_COTANGENT', '1') != '0'
+CHECK_SPARSE_COTANGENT = _os.environ.get('IHG_CHECK_SPARSE_COTANGENT', '0') == '1'
 
 
 def _zero_isolated_users(dh: Tensor, layout: IncidenceLayout) -> None:
@@ -560,10 +583,12 @@ class _InteractToNodes(torch.autograd.Function):
     (``ihg_interact_bwd_gathered``); where that kernel does not apply, the separate ops' sequence."""
 
     @staticmethod
-    def forward(ctx, h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: int, out_scale: Optional[Tensor], rows: Optional[Tensor]) -> Tensor:
+    def forward(ctx, h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: int, out_scale: Optional[Tensor], rows: Optional[Tensor],
+                out: Optional[Tensor]) -> Tensor:
         lib = _lib.load()
         h, p, w = _rows(h, 'h'), _rows(p, 'p'), _rows(w, 'w')
         dim = int(h.shape[1])
+        _check_out(out, h, p, w)
         edge = torch.empty(layout.edge_count, dim, dtype=torch.float32, device=h.device)
         ws = _workspace(int(lib.ihg_interact_fwd_workspace_bytes(layout.edge_count, dim, order)), h.device)
         with profiler.kernel('interact_fwd', layout.edge_count, dim):
@@ -571,7 +596,7 @@ class _InteractToNodes(torch.autograd.Function):
                                             _ptr(edge), _ld(edge), _ptr(ws), ws.numel() * 4, layout.edge_count, dim, _stream()),
                        'ihg_interact_fwd')
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        y = node_segment_sum_raw(edge, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes')
+        y = node_segment_sum_raw(edge, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=out)
         ctx.save_for_backward(h, w)
         ctx.layout, ctx.order, ctx.out_scale = layout, order, out_scale
         return y
@@ -600,15 +625,97 @@ class _InteractToNodes(torch.autograd.Function):
             dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
             dh = _interact_backward(h, w, dout, layout, order, dw)
         dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
-        return dh, dp, dw, None, None, None, None
+        return dh, dp, dw, None, None, None, None, None
 
 
 def interact_to_nodes(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: int, out_scale: Optional[Tensor] = None,
-                      rows: Optional[Tensor] = None) -> Tensor:
+                      rows: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """``node_segment_sum(interact(h, p, w, layout, order), layout, out_scale, rows)`` with a backward that has no node -> hyperedge launch."""
     if order not in (2, 3):
         raise ValueError('interact_to_nodes handles interaction orders 2 and 3')
-    return _InteractToNodes.apply(h, p, w, layout, int(order), out_scale, rows)
+    return _InteractToNodes.apply(h, p, w, layout, int(order), out_scale, rows, out)
+
+
+class _InteractLayer(torch.autograd.Function):
+    """The whole interactive layer behind ``feature_transform`` as ONE autograd node (``CommonLayers.py:70-85`` + ``GnnLayers.py:229-236``):
+    hoisted first-order blocks (typed row GEMM) -> product blocks (``ihg_interact_fwd``) -> hyperedge -> node pass.  Backward: the member-
+    gradient kernel forms the hyperedges' cotangents itself where it can (``ihg_interact_bwd_gathered``, else a K5 launch), the first-order
+    path's contribution to ``d h`` is ADDED by the node-level weight-gradient kernel onto the member gradients' scatter result
+    (``dx_accumulate``: no separate ``[N, d]`` add, no second ``[N, d]`` buffer), and both halves of ``d aggregation.weight`` land in one tensor."""
+
+    @staticmethod
+    def forward(ctx, h: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, order: int, out_scale: Optional[Tensor], rows: Optional[Tensor],
+                out: Optional[Tensor]) -> Tensor:
+        lib = _lib.load()
+        h, w = _rows(h, 'h'), _rows(w, 'w')
+        dim = int(h.shape[1])
+        _check_out(out, h, w, bias)
+        p = torch.empty(h.shape[0], dim, dtype=torch.float32, device=h.device)
+        ws = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)
+        with profiler.kernel('node_linear_fwd', h.shape[0], dim):
+            _lib.check(lib.ihg_node_linear_fwd(_ptr(h), _ld(h), _ptr(w), int(w.stride(0)), dim, _ptr(bias), 0b001, 0, _type_begin(layout),
+                                               _ptr(p), _ld(p), _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_fwd')
+        edge = torch.empty(layout.edge_count, dim, dtype=torch.float32, device=h.device)
+        ws2 = _workspace(int(lib.ihg_interact_fwd_workspace_bytes(layout.edge_count, dim, order)), h.device)
+        with profiler.kernel('interact_fwd', layout.edge_count, dim):
+            _lib.check(lib.ihg_interact_fwd(_ptr(h), _ld(h), _ptr(p), _ld(p), _ptr(layout.i3), _ptr(w), _ld(w), order,
+                                            _ptr(edge), _ld(edge), _ptr(ws2), ws2.numel() * 4, layout.edge_count, dim, _stream()),
+                       'ihg_interact_fwd')
+        mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
+        y = node_segment_sum_raw(edge, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=out)
+        ctx.save_for_backward(h, w)
+        ctx.layout, ctx.order, ctx.out_scale, ctx.has_bias = layout, order, out_scale, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        lib = _lib.load()
+        h, w = ctx.saved_tensors
+        layout, order, out_scale = ctx.layout, ctx.order, ctx.out_scale
+        dy = _rows(dy, 'dy')
+        n_edges, dim = layout.edge_count, int(h.shape[1])
+        dw = torch.empty_like(w)                               # product blocks from the interact kernels, first-order blocks from the row-GEMM pass
+        if _gathered_backward_ok(h, w, dy, layout, order):
+            csr_qi, qi_rows = layout.member_csr_qi()
+            dout = torch.empty(n_edges, dim, dtype=torch.float32, device=h.device)
+            g2 = torch.empty(n_edges, 2 * dim, dtype=torch.float32, device=h.device)
+            dh = torch.empty(layout.node_count, dim, dtype=torch.float32, device=h.device)
+            _zero_isolated_users(dh, layout)
+            ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
+            with profiler.kernel('interact_bwd', n_edges, dim):
+                _lib.check(lib.ihg_interact_bwd_gathered(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(dy), _ld(dy), _ptr(out_scale),
+                                                         _ptr(dout), dim, _ptr(g2), _ptr(dh), dim, _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4,
+                                                         n_edges, dim, _stream()), 'ihg_interact_bwd_gathered')
+            node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients')
+            del g2
+            dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
+        else:
+            dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
+            # the scatter of dout goes first: K5 has just written it, so most of its rows are still in the Infinity Cache for these random
+            # reads; the interact kernels read it as a stream and do not care
+            dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
+            dh = _interact_backward(h, w, dout, layout, order, dw)
+        del dout
+        dbias = torch.empty(dim, dtype=torch.float32, device=h.device) if ctx.has_bias else None
+        ws2 = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)
+        accumulate = bool(lib.ihg_node_linear_bwd_accumulates(dim, _ld(dp), _ld(h), _ld(dh))) and h.data_ptr() % 16 == 0 and dh.data_ptr() % 16 == 0
+        dx = dh if accumulate else torch.empty_like(dh)
+        with profiler.kernel('node_linear_bwd', h.shape[0], dim):
+            _lib.check(lib.ihg_node_linear_bwd_weight(_ptr(dp), _ld(dp), _ptr(h), _ld(h), _type_begin(layout), _ptr(dw), int(dw.stride(0)), dim,
+                                                      _ptr(dbias), 0b001, 0, _ptr(w), int(w.stride(0)), _ptr(dx), _ld(dx), 1 if accumulate else 0,
+                                                      _ptr(ws2), ws2.numel() * 4, dim, _stream()), 'ihg_node_linear_bwd_weight')
+        if not accumulate:
+            dh.add_(dx)
+        return dh, dw, dbias, None, None, None, None, None
+
+
+def interact_layer(h: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, order: int, out_scale: Optional[Tensor] = None,
+                   rows: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """``out_scale * H FeatureInteractor(h)`` for interaction orders 2 / 3 with ``w = [A_u | A_q | A_i | W_uq | W_qi | W_iu (| W_uqi)]`` and
+    ``bias`` = the aggregation's bias: ``node_segment_sum(interact(h, first_order(h), w), out_scale, rows)`` as one differentiable op."""
+    if order not in (2, 3):
+        raise ValueError('interact_layer handles interaction orders 2 and 3')
+    return _InteractLayer.apply(h, w, bias, layout, int(order), out_scale, rows, out)
 
 
 class _InteractFromNodes(torch.autograd.Function):
@@ -733,25 +840,6 @@ def _hem_backward(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float,
     return dbias, tuple(dense[l] for l in range(n_layers))
 
 
-SPARSE_LAST_COTANGENT = _os.environ.get('IHG_SPARSE_LAST_COTANGENT', '1') != '0'
-_SPARSE_ROWS = {}                   # address of a cotangent known to be zero outside some rows -> (those rows, weak reference to the tensor): set by the last tap's backward
-
-
-def _nonzero_row_mask(grad: Tensor, n_rows: int) -> Optional[Tensor]:
-    """uint8 ``[n_rows]`` mask of the rows of ``grad`` that may be non-zero, when the tap that built it said so; consumed once.  The entry
-    counts only while the tensor the tap built is alive (an address can be reused once it is gone)."""
-    entry = _SPARSE_ROWS.pop(grad.data_ptr(), None)
-    if entry is None:
-        return None
-    rows, alive = entry
-    built = alive()
-    if built is None or built.data_ptr() != grad.data_ptr() or tuple(built.shape) != tuple(grad.shape):
-        return None
-    mask = torch.zeros(n_rows, dtype=torch.uint8, device=grad.device)
-    mask.index_fill_(0, rows.long(), 1)
-    return mask
-
-
 class TailGradients:
     """Side channel from the batch tail's backward to the taps on the layer outputs (one per training step).
 
@@ -795,12 +883,8 @@ class _Tap(torch.autograd.Function):
                 return (g_next if g_next is not None else g_tail), None, None
             return g_next + g_tail, None, None
         if g_next is None:
-            # the last layer's output feeds the batch tail only: its cotangent is zero outside the batch rows.  The layer's backward is
-            # told (by the tensor's address) and skips the gathers of the zero rows - same gradient, a pull over 3B rows instead of N
+            # the last layer's output feeds the batch tail only: its cotangent is zero outside the batch rows (RawGnn tells that layer so)
             g = torch.zeros(n, dim, dtype=torch.float32, device=ctx.device)
-            if SPARSE_LAST_COTANGENT:
-                _SPARSE_ROWS.clear()
-                _SPARSE_ROWS[g.data_ptr()] = (holder.rows, weakref.ref(g))
         else:
             g = g_next if (g_next.is_contiguous() and g_next.dtype == torch.float32) else g_next.contiguous().float()
         holder.add_into(g, ctx.index * dim, dim)

@@ -159,6 +159,13 @@ CONFIGS = {
                seed=2, distribution='powerlaw', exponent=0.8, dim=64, layers=2),
     'C3': dict(user_count=230_000, query_count=26_000, item_count=120_000, vocab_size=30_000, edge_count=2_200_000,
                seed=3, distribution='powerlaw', exponent=0.8, dim=128, layers=3),
+    # "Amazon full catalog" (BASELINE configs[3]): the union of the five Amazon 5-core corpora the reference's driver lists
+    # (Main.py:35-39: OfficeProducts, CellPhones, KindleStore, VideoGames, Electronics).  Their published 5-core counts add up
+    # to 317,713 users / 148,456 items / 3,151,284 reviews; Step1-Amazon.py:126-134 writes one log per (review, category-path
+    # query) - about 1.3 per review - and the train split keeps ~80 %: E = 3.3 M.  Queries = distinct category paths (~5 k).
+    # One replica of this graph per GPU (data-parallel batches); the 8-GPU run is `bench.py --config C4 --gpus 8`.
+    'C4': dict(user_count=317_713, query_count=5_000, item_count=148_456, vocab_size=6_000, edge_count=3_300_000,
+               seed=4, distribution='powerlaw', exponent=0.8, dim=128, layers=3),
     'C5': dict(user_count=4_000_000, query_count=1_000_000, item_count=5_000_000, vocab_size=200_000,
                edge_count=50_000_000, seed=5, distribution='powerlaw', exponent=1.2, dim=256, layers=2),
 }

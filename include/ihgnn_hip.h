@@ -255,12 +255,16 @@ int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, c
  *              dbias[c] = sum over rows of the masked types of dout[v,c]     (dbias may be NULL); with dbias_type_stride != 0
  *              (typed weights only) every type gets its own sum at dbias + t * dbias_type_stride, 0 for unmasked types.
  *              With dx != NULL the call also produces bwd_input's result (w typed exactly like dw: block t at column
- *              t * dw_type_stride); at dim 64 both come from one pass over dout, otherwise it runs the bwd_input launch itself.
- *              dx_accumulate != 0 (dim 64 only): dx += instead of dx = (a second contribution to the same gradient)
- * dim must be 32, 64, 128 or 256 with 16-byte aligned rows (ihg_node_linear_workspace_bytes returns -1 otherwise;
- * callers then keep their own GEMM).  `workspace`: ihg_node_linear_workspace_bytes(dim) bytes, 16-byte aligned.
+ *              t * dw_type_stride); at dim 64 / 128 both come from one pass over dout, otherwise it runs the bwd_input launch itself.
+ *              dx_accumulate != 0: dx += instead of dx = (a second contribution to the same gradient: the member gradients of
+ *              the interactive step land in dx first, Models/CommonLayers.py:70-85) - where ihg_node_linear_bwd_accumulates
+ *              says so (dim 64; dim 128 on the bf16-split kernels)
+ * Any dim > 0: 32, 64, 128, 256 with 16-byte aligned rows run on the matrix cores, every other shape on the any-width
+ * kernels (row-slab partials + a fixed-order sum for the weight gradient).  `workspace`: ihg_node_linear_workspace_bytes(dim)
+ * bytes, 16-byte aligned.
  */
 int64_t ihg_node_linear_workspace_bytes(int32_t dim);
+int32_t ihg_node_linear_bwd_accumulates(int32_t dim, int64_t ld_dout, int64_t ld_x, int64_t ld_dx);
 int ihg_node_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, int64_t w_type_stride,
                         const float* bias, int32_t bias_type_mask, int64_t bias_type_stride, const int64_t* type_begin,
                         float* out, int64_t ld_out, void* workspace, int64_t workspace_bytes,

@@ -216,6 +216,35 @@ def test_node_linear_forward_backward(dim, typed):
         assert (wg.grad[:, 3 * dim:] == 0).all()
 
 
+def test_any_width_node_linear_is_not_serial_over_the_rows():
+    """Widths outside {32, 64, 128, 256} run on the any-width kernels.  Their weight gradient used to walk ALL rows in one thread per
+    matrix element (N serial steps); it is row-slab partials + a fixed-order sum now.  At a realistic N (300 k rows, d = 100) the whole
+    forward + backward must take milliseconds, and match torch."""
+    import time
+    from ihgnn_amd import ops
+    _, lay = make_layout(200_000, 20_000, 80_000, 1000, seed=1)
+    d = 100
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(lay.node_count, d, generator=gen).to(dev()).requires_grad_(True)
+    w = (torch.randn(d, 3 * d, generator=gen) / 10).to(dev()).requires_grad_(True)
+    b = torch.randn(3, d, generator=gen).to(dev()).requires_grad_(True)
+    cot = torch.randn(lay.node_count, d, generator=gen).to(dev())
+    for timed in (False, True):
+        x.grad = w.grad = b.grad = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        y = ops.node_linear(x, w, b, lay, typed=True, bias_mask=0b111)
+        y.backward(cot)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    assert elapsed < 0.25, elapsed
+    u, uq = lay.user_count, lay.user_count + lay.query_count
+    xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    parts = [torch.nn.functional.linear(xr[lo:hi], wr[:, t * d:(t + 1) * d], br[t]) for t, (lo, hi) in enumerate([(0, u), (u, uq), (uq, lay.node_count)])]
+    torch.cat(parts).backward(cot)
+    assert rel(y, torch.cat(parts)) <= RTOL and rel(x.grad, xr.grad) <= RTOL and rel(w.grad, wr.grad) <= 3e-5 and rel(b.grad, br.grad) <= 3e-5   # 2e5-term fp32 sums in other orders
+
+
 def test_row_subset_outputs_equal_full_outputs():
     """hyperedge -> node and two-hop passes restricted to a row list (the last layer of a training step): the listed rows and
     the split rows are bitwise what the full pass writes."""
@@ -502,6 +531,56 @@ def test_split_arithmetic_is_as_accurate_as_fp32_mfma(dim, scale, monkeypatch):
         assert es <= RTOL / 5 and es <= max(2 * ef, 5e-7), (err_split, err_f32)
 
 
+@pytest.mark.parametrize('dim', [64, 128, 256])
+def test_split_arithmetic_worst_case_operands(dim):
+    """The split truncates toward zero, so the three products it leaves out (mid*lo, lo*mid, lo*lo) all carry the sign of the product
+    they belong to.  Worst case: every operand has the low 16 bits of its significand set (x = (1 + (2^16 - 1) 2^-23) 2^k: mid ~ 2^-7 x,
+    lo ~ 2^-15 x, so mid*lo + lo*mid ~ 2^-21 |ab|) and every product of a dot product has the same sign - the omitted terms then add
+    up instead of averaging out.  Users and items carry powers of two, queries and the weights the adversarial significand, so the
+    products uq, qi and uqi inherit it exactly.  Error against float64, forward and both gradients, and the node-level linear map:
+    must stay below 1e-6 (2^-21 = 4.8e-7 plus fp32 accumulation), a tenth of the 1e-5 contract."""
+    from ihgnn_amd import ops
+    from oracle import ihgnn_ref as ref
+    order, U, Q, I, E = 3, 301, 17, 211, 9000
+    w_, lay = make_layout(U, Q, I, E, seed=6, edge_order='user')
+    gen = torch.Generator().manual_seed(13)
+
+    def adversarial(*shape):
+        k = torch.randint(-3, 3, shape, generator=gen).float()
+        return (1.0 + (2.0 ** 16 - 1) * 2.0 ** -23) * torch.exp2(k)
+
+    def power_of_two(*shape):
+        return torch.exp2(torch.randint(-2, 2, shape, generator=gen).float())
+
+    h = torch.cat([power_of_two(U, dim), adversarial(Q, dim), power_of_two(I, dim)])
+    w = adversarial(dim, 7 * dim) / 64
+    cot = adversarial(lay.edge_count, dim) / 8
+    bits = h[U:U + Q].view(torch.int32) & 0xFFFF
+    assert bool((bits == 0xFFFF).all())
+    h64, w64 = h.double().requires_grad_(True), w.double().requires_grad_(True)
+    want = ref.feature_interactor(h64, torch.from_numpy(lay.i3_host.astype(np.int64)), w64, torch.zeros(dim).double(), order)
+    want.backward(cot.double())
+    hg, wg = h.clone().to(dev()).requires_grad_(True), w.clone().to(dev()).requires_grad_(True)
+    first = torch.cat([torch.nn.functional.linear(hg[:U], wg[:, :dim]), torch.nn.functional.linear(hg[U:U + Q], wg[:, dim:2 * dim]),
+                       torch.nn.functional.linear(hg[U + Q:], wg[:, 2 * dim:3 * dim])])
+    got = ops.interact(hg, first.detach(), wg, lay, order)
+    got.backward(cot.to(dev()))
+    first64 = torch.cat([h64[:U] @ w64[:, :dim].T, h64[U:U + Q] @ w64[:, dim:2 * dim].T, h64[U + Q:] @ w64[:, 2 * dim:3 * dim].T]).detach()
+    i3 = torch.from_numpy(lay.i3_host.astype(np.int64))
+    prod64 = want.detach() - ((first64[i3[:, 0]] + first64[i3[:, 1]]) + first64[i3[:, 2]])          # the product blocks' part in float64
+    prod = got.detach().cpu().double() - ((first.detach().cpu().double()[i3[:, 0]] + first.detach().cpu().double()[i3[:, 1]]) + first.detach().cpu().double()[i3[:, 2]])
+    wl = adversarial(dim, dim) / 16
+    x = adversarial(lay.node_count, dim)
+    lin = ops.node_linear(x.to(dev()), wl.to(dev()), None, lay)
+    # d h: the first-order blocks enter `want` too; take them out (exact in float64)
+    dfirst = torch.zeros(lay.node_count, dim, dtype=torch.float64).index_add_(0, i3.reshape(-1), cot.double().repeat_interleave(3, 0))
+    dh_first = torch.cat([dfirst[:U] @ w64.detach()[:, :dim], dfirst[U:U + Q] @ w64.detach()[:, dim:2 * dim], dfirst[U + Q:] @ w64.detach()[:, 2 * dim:3 * dim]])
+    errors = dict(forward=rel(prod, prod64), member_gradients=rel(hg.grad.double().cpu(), h64.grad - dh_first),
+                  weight_gradients=rel(wg.grad[:, 3 * dim:].double(), w64.grad[:, 3 * dim:]), node_linear=rel(lin.double(), x.double() @ wl.double().T))
+    print('split arithmetic, worst-case operands, d =', dim, errors)
+    assert max(errors.values()) <= 1e-6, errors
+
+
 @pytest.mark.parametrize('dim', [12, 64, 128, 256])
 def test_interact_backward_in_hyperedge_chunks(dim, monkeypatch):
     """The [E, 3, d] member-gradient buffer produced in three hyperedge chunks (what config C5 needs on one GPU): gradients
@@ -597,11 +676,11 @@ def test_f3_model_matches_reference(tag, kind):
     loss.backward()
     assert rel(scores, z[f'{tag}.scores']) <= RTOL
     assert abs(loss.item() - float(z[f'{tag}.loss'])) <= 1e-6
-    for name, p in m.named_parameters():
-        assert rel(p.grad, z[f'{tag}.grad.{name}']) <= 2e-5, name
+    errors = {name: rel(p.grad, z[f'{tag}.grad.{name}']) for name, p in m.named_parameters()}
+    assert max(errors.values()) <= RTOL, {k: v for k, v in errors.items() if v > RTOL}
     opt.step()
-    for name, p in m.state_dict().items():
-        assert rel(p, z[f'{tag}.after.{name}']) <= 2e-5, name
+    errors = {name: rel(p, z[f'{tag}.after.{name}']) for name, p in m.state_dict().items()}
+    assert max(errors.values()) <= RTOL, {k: v for k, v in errors.items() if v > RTOL}
     # evaluation path on the original weights
     m.load_state_dict(sd)
     with torch.no_grad():
@@ -639,8 +718,8 @@ def test_f8_wide_models_match_reference(tag, path):
         loss = m.bce_loss(u, q, i, flags)
     loss.backward()
     assert abs(loss.item() - float(z[f'{tag}.loss'])) <= 2e-6
-    for name, p in m.named_parameters():
-        assert f8_gradient_error(z, tag, name, p.grad.cpu().numpy()) <= 2e-5, name
+    errors = {name: f8_gradient_error(z, tag, name, p.grad.cpu().numpy()) for name, p in m.named_parameters()}
+    assert max(errors.values()) <= RTOL, {k: v for k, v in errors.items() if v > RTOL}
     with torch.no_grad():
         assert rel(m.propagate(), z[f'{tag}.features']) <= RTOL
 
@@ -727,7 +806,7 @@ def test_full_size_properties_c2_shape():
     assert torch.equal(ops.edge_gather_sum_raw(torch.ones(lay.node_count, 4, device=dev()), lay.i3), torch.full((lay.edge_count, 4), 3.0, device=dev()))
 
 
-@pytest.mark.parametrize('config,scale,order', [('C2', 1.0, 3), ('C3', 1.0, 3), ('C3', 1.0, 2), ('C5', 0.05, 3)])
+@pytest.mark.parametrize('config,scale,order', [('C2', 1.0, 3), ('C3', 1.0, 3), ('C3', 1.0, 2), ('C4', 1.0, 3), ('C5', 0.05, 3)])
 def test_full_size_properties_bench_workload(config, scale, order):
     """The bench.py workloads themselves - C2 stand-in (E = 1.35 M, d = 64), C3 stand-in (E = 2.2 M, d = 128, = the per-GPU
     replica of C4) and C5 x 0.05 (E = 2.5 M, N = 500 k, d = 256, power-law) - where the oracle over the whole graph would need
@@ -798,6 +877,167 @@ def test_full_size_properties_bench_workload(config, scale, order):
     out2.backward(cot)
     twice = 2 * ((out2.detach() - first).double() * cot.double()).sum()
     assert abs((h2.grad.double() * h2.detach().double()).sum() - twice) / abs(twice) <= 1e-4
+
+
+def _oracle_on_sampled_nodes(lay, nodes, h_dev, wz, order, edge_cotangent):
+    """The oracle's d h on ``nodes`` = its gradient over exactly their incident hyperedges (``edge_cotangent(edges) -> [len, d]`` on
+    the CPU).  Only the member rows of those hyperedges leave the GPU (the full table is 10 GB at C5)."""
+    from oracle import ihgnn_ref as ref
+    ptr = lay.node_csr.ptr_host.astype(np.int64)
+    edges = np.unique(np.concatenate([lay.node_csr.ids_host[ptr[v]:ptr[v + 1]] for v in nodes]).astype(np.int64))
+    i3e = lay.i3_host[edges].astype(np.int64)
+    members, local = np.unique(i3e, return_inverse=True)
+    hs = h_dev.detach()[torch.from_numpy(members).to(h_dev.device)].cpu().requires_grad_(True)
+    d = hs.shape[1]
+    ref.feature_interactor(hs, torch.from_numpy(local.reshape(-1, 3)), wz, torch.zeros(d), order).backward(edge_cotangent(edges))
+    return hs.grad[np.searchsorted(members, nodes)]
+
+
+def _sample_nodes(lay, rng, per_type=40, max_degree=64):
+    deg = np.diff(lay.node_csr.ptr_host.astype(np.int64))
+    cand = np.nonzero((deg > 0) & (deg <= max_degree))[0]
+    u, uq = lay.user_count, lay.user_count + lay.query_count
+    queries = np.nonzero(deg > 0)[0]
+    queries = queries[(queries >= u) & (queries < uq)][:8]
+    nodes = np.concatenate([rng.choice(cand[cand < u], per_type), rng.choice(cand[cand >= uq], per_type), queries])
+    return np.unique(nodes[deg[nodes] <= 20_000])
+
+
+@pytest.mark.parametrize('config,order', [('C3', 3), ('C3', 2), ('C4', 3)])
+def test_full_size_layer0_path_of_the_headline_step(config, order):
+    """The kernels the bench headline times, at the headline's size: ``ops.interact_to_nodes`` at d = 128 over the full C3 / C4
+    hypergraph - forward = interact + the hyperedge -> node pass, backward = the GATHERING member-gradient kernel
+    (``interact_bwd_members_split_ws_kernel<128, true, NBLK, true>``: user slot reduced on chip across hundreds of tiles per
+    workgroup, hyperedge cotangents formed from ``dy`` inside the kernel, no node -> hyperedge launch), weight gradients, first-order
+    scatter.  Against the ORACLE on sampled node rows (forward and d h, each over exactly the incident hyperedges of the node), the
+    Euler identity for d W, and the separately launched ops over the whole tensors."""
+    from ihgnn_amd import ops, profiler, synth
+    from ihgnn_amd.layout import IncidenceLayout
+    from oracle import ihgnn_ref as ref
+    w_ = synth.draw_config(config)
+    lay = IncidenceLayout(w_.triples, w_.user_count, w_.query_count, w_.item_count, dev())
+    assert lay.user_sorted
+    d = synth.CONFIGS[config]['dim']
+    k = 7 if order == 3 else 6
+    gen = torch.Generator(device=dev()).manual_seed(17)
+    h = (torch.randn(lay.node_count, d, device=dev(), generator=gen) / 4).requires_grad_(True)
+    p = torch.randn(lay.node_count, d, device=dev(), generator=gen).requires_grad_(True)
+    wgt = (torch.randn(d, k * d, device=dev(), generator=gen) / (3 * np.sqrt(k * d / 7))).requires_grad_(True)
+    dy = torch.randn(lay.node_count, d, device=dev(), generator=gen) / 8
+    scale = lay.inv_deg
+
+    profiler.start()
+    y = ops.interact_to_nodes(h, p, wgt, lay, order, scale)
+    y.backward(dy)
+    launched = profiler.summary()
+    profiler.stop()
+    assert 'edge_gather_sum' not in launched and launched['interact_bwd']['launches'] == 1, sorted(launched)      # the gathering kernel ran
+    assert 'k7.member_gradients_rows' in launched, sorted(launched)                                                # user slot reduced on chip
+
+    # the separately launched ops (interact is oracle-checked on sampled hyperedges in the test above), whole tensors
+    h2, p2, w2 = (t.detach().clone().requires_grad_(True) for t in (h, p, wgt))
+    ef = ops.interact(h2, p2, w2, lay, order)
+    y2 = ops.node_segment_sum(ef, lay, out_scale=scale)
+    y2.backward(dy)
+    assert torch.equal(y.detach(), y2.detach())
+    assert rel(h.grad, h2.grad) <= RTOL_SUM and rel(p.grad, p2.grad) <= RTOL_SUM and rel(wgt.grad, w2.grad) <= RTOL_SUM
+    assert bool((wgt.grad[:, :3 * d] == 0).all())
+    # Euler: the product part is linear in its weights, <dW, W> = <product part of Ef, dEf> with dEf[e] = sum_m scale[m] dy[m]
+    d_ef = ops.edge_gather_sum_raw(dy, lay.i3, scale)
+    first = ops.edge_gather_sum_raw(p.detach(), lay.i3)
+    lhs = (wgt.grad[:, 3 * d:].double() * wgt.detach()[:, 3 * d:].double()).sum()
+    rhs = ((ef.detach() - first).double() * d_ef.double()).sum()
+    assert abs(lhs - rhs) / abs(rhs) <= 1e-4
+    assert rel(p.grad, ops.node_segment_sum_raw(d_ef, lay.node_csr)) <= RTOL_SUM
+    del ef, y2, first, h2, p2, w2
+
+    # oracle on sampled nodes: y[v] = scale[v] sum_{e in v} Ef[e] and d h[v], over exactly the incident hyperedges of v
+    rng = np.random.default_rng(5)
+    nodes = _sample_nodes(lay, rng)
+    wc = wgt.detach().cpu()
+    wz = torch.cat([torch.zeros(d, 3 * d), wc[:, 3 * d:]], 1)
+    ptr = lay.node_csr.ptr_host.astype(np.int64)
+    scale_c = scale.cpu()
+    for v in nodes[:24]:
+        edges = lay.node_csr.ids_host[ptr[v]:ptr[v + 1]].astype(np.int64)
+        i3e = torch.from_numpy(lay.i3_host[edges].astype(np.int64))
+        members, local = torch.unique(i3e, return_inverse=True)
+        hm, pm = h.detach()[members.to(dev())].cpu(), p.detach()[members.to(dev())].cpu()
+        ef_v = ref.feature_interactor(hm, local, wz, torch.zeros(d), order) + (pm[local[:, 0]] + pm[local[:, 1]]) + pm[local[:, 2]]
+        want = scale_c[v] * ef_v.double().sum(0)
+        assert rel(y.detach()[int(v)], want) <= RTOL, int(v)
+
+    def edge_cotangent(edges):
+        i3e = torch.from_numpy(lay.i3_host[edges].astype(np.int64)).to(dev())
+        sd = scale[:, None] * dy
+        return ((sd[i3e[:, 0]] + sd[i3e[:, 1]]) + sd[i3e[:, 2]]).cpu()
+
+    want_dh = _oracle_on_sampled_nodes(lay, nodes, h, wz, order, edge_cotangent)
+    assert rel(h.grad[torch.from_numpy(nodes).to(dev())], want_dh) <= RTOL
+
+
+def test_full_size_c5_interact_in_three_chunks():
+    """BASELINE configs[4] at FULL size on one GPU: N = 10 M, E = 50 M, d = 256.  The interactive step forward (chunk kernel) and its
+    backward with the 154 GB member-gradient buffer produced in three hyperedge chunks, each scattered through its own member lists
+    (150 M entries in all).  Oracle on sampled hyperedges (forward) and sampled nodes (d h); Euler identity for d W over all 50 M
+    hyperedges; first-order gradient = K7 of the cotangent.  Needs ~210 GB of HBM: skipped on a smaller device."""
+    free, total = torch.cuda.mem_get_info()
+    if free < 215 * (1 << 30):
+        pytest.skip(f'needs 215 GiB of free HBM, this device has {free / (1 << 30):.0f}')
+    from ihgnn_amd import ops, profiler, synth
+    from ihgnn_amd.layout import IncidenceLayout
+    from oracle import ihgnn_ref as ref
+    w_ = synth.draw_config('C5')
+    lay = IncidenceLayout(w_.triples, w_.user_count, w_.query_count, w_.item_count, dev())
+    del w_
+    d, order, k = 256, 3, 7
+    E = lay.edge_count
+    assert E == 50_000_000 and lay.node_count == 10_000_000
+    gen = torch.Generator(device=dev()).manual_seed(23)
+    h = (torch.randn(lay.node_count, d, device=dev(), generator=gen) / 4).requires_grad_(True)
+    p = torch.randn(lay.node_count, d, device=dev(), generator=gen).requires_grad_(True)
+    wgt = (torch.randn(d, k * d, device=dev(), generator=gen) / (3 * np.sqrt(k * d / 7))).requires_grad_(True)
+    cot = torch.empty(E, d, device=dev())
+    for lo in range(0, E, 10_000_000):                                   # filled in slices: randn's own temporaries stay small
+        cot[lo:lo + 10_000_000].normal_(generator=gen).div_(8)
+    out = ops.interact(h, p, wgt, lay, order)
+    n_chunks = -(-(E * 3 * d * 4) // ops.MEMBER_BUFFER_LIMIT_BYTES)
+    assert n_chunks == 3
+    profiler.start()
+    out.backward(cot)
+    launched = profiler.summary()
+    profiler.stop()
+    assert launched['interact_bwd']['launches'] == 3 and launched['k7.member_gradients']['launches'] == 3, sorted(launched)
+
+    # forward against the oracle on sampled hyperedges (first tile, last partial tile, chunk seams, random)
+    step = lay.member_csr_chunks(3)[0][1]
+    pick = torch.cat([torch.arange(0, 64), torch.arange(E - 70, E), torch.arange(step - 40, step + 40), torch.arange(2 * step - 40, 2 * step + 40),
+                      torch.randint(0, E, (4096,))]).unique()
+    i3s = torch.from_numpy(lay.i3_host[pick.numpy()].astype(np.int64))
+    members, local = torch.unique(i3s, return_inverse=True)
+    hm, pm = h.detach()[members.to(dev())].cpu(), p.detach()[members.to(dev())].cpu()
+    wc = wgt.detach().cpu()
+    wz = torch.cat([torch.zeros(d, 3 * d), wc[:, 3 * d:]], 1)
+    want = ref.feature_interactor(hm, local, wz, torch.zeros(d), order) + (pm[local[:, 0]] + pm[local[:, 1]]) + pm[local[:, 2]]
+    assert rel(out.detach()[pick.to(dev())], want) <= RTOL
+
+    # d W: Euler identity over all hyperedges, slice by slice (the product part of `out` is linear in the product weights)
+    rhs = torch.zeros((), dtype=torch.float64, device=dev())
+    for lo in range(0, E, 5_000_000):
+        hi = min(lo + 5_000_000, E)
+        first = ops.edge_gather_sum_raw(p.detach(), lay.i3[lo:hi])
+        rhs += ((out.detach()[lo:hi] - first).double() * cot[lo:hi].double()).sum()
+        del first
+    lhs = (wgt.grad[:, 3 * d:].double() * wgt.detach()[:, 3 * d:].double()).sum()
+    assert abs(lhs - rhs) / abs(rhs) <= 1e-4
+    assert bool((wgt.grad[:, :3 * d] == 0).all())
+    del out
+    assert rel(p.grad, ops.node_segment_sum_raw(cot, lay.node_csr)) <= RTOL_SUM
+
+    # d h against the oracle on sampled nodes (users, items, a few queries with long lists that cross the chunk seams)
+    nodes = _sample_nodes(lay, np.random.default_rng(7))
+    want_dh = _oracle_on_sampled_nodes(lay, nodes, h, wz, order, lambda edges: cot[torch.from_numpy(edges).to(dev())].cpu())
+    assert rel(h.grad[torch.from_numpy(nodes).to(dev())], want_dh) <= RTOL
 
 
 def test_integration_md_binding_stub_runs():
@@ -1245,9 +1485,10 @@ def test_fused_bce_tail_equals_unfused_path():
 
 
 def test_last_layer_backward_skips_the_zero_rows_of_its_cotangent(monkeypatch):
-    """The last layer's output feeds the batch tail only, so its cotangent is zero outside the 3B batch rows: the tap says so and the
+    """The last layer's output feeds the batch tail only, so its cotangent is zero outside the 3B batch rows: RawGnn tells the layer so and the
     layer's two-hop backward pulls only those rows (`k7.two_hop_bwd_masked`) - every layer still evaluated over all rows in the forward.
-    Same loss, bitwise the same gradients as the dense backward; an address registered by a tap whose tensor is gone must not mask."""
+    Same loss, bitwise the same gradients as the dense backward.  The sparsity is an explicit argument of the last layer's op (``cotangent_rows``),
+    verified against the actual cotangent under IHG_CHECK_SPARSE_COTANGENT=1."""
     from ihgnn_amd import ops, profiler, synth
     from ihgnn_amd.Dataset import GraphDataset
     w = synth.draw(90, 12, 140, 20, 1500, seed=8)
@@ -1270,14 +1511,22 @@ def test_last_layer_backward_skips_the_zero_rows_of_its_cotangent(monkeypatch):
     assert grads[True][0] == grads[False][0]
     for n in grads[True][1]:
         assert torch.equal(grads[True][1][n], grads[False][1][n]), n
-    # a stale registration: the tensor the tap built is gone, another one may sit at its address
-    g = torch.zeros(8, 4, device=dev())
-    ops._SPARSE_ROWS[g.data_ptr()] = (torch.zeros(1, dtype=torch.int64, device=dev()), __import__('weakref').ref(g))
-    ptr = g.data_ptr()
-    del g
-    other = torch.ones(8, 4, device=dev())
-    ops._SPARSE_ROWS[other.data_ptr()] = ops._SPARSE_ROWS.pop(ptr, (None, lambda: None)) if other.data_ptr() != ptr else ops._SPARSE_ROWS[ptr]
-    assert ops._nonzero_row_mask(other, 8) is None
+    # the promise is checked on request: a second consumer of the last layer's output makes the cotangent dense, and the op says so
+    monkeypatch.setattr(ops, 'SPARSE_LAST_COTANGENT', True)
+    monkeypatch.setattr(ops, 'CHECK_SPARSE_COTANGENT', True)
+    lay = ds.hypergraph.layout
+    x = torch.randn(lay.node_count, 32, device=dev(), requires_grad=True)
+    rows = torch.arange(0, 40, dtype=torch.int32, device=dev())
+    out = ops.node_two_hop(x, lay, out_scale=lay.inv_deg, cotangent_rows=rows)
+    with pytest.raises(RuntimeError, match='cotangent is not zero'):
+        out.sum().backward()
+    x.grad = None
+    out = ops.node_two_hop(x, lay, out_scale=lay.inv_deg, cotangent_rows=rows)
+    out[rows.long()].sum().backward()                                    # an honest caller
+    dense = torch.zeros_like(out)
+    dense[rows.long()] = 1.0
+    want = ops.node_segment_sum_raw(dense, lay.hop2_csr, lay.inv_deg, None, 0, self_weight=lay.self_weight)
+    assert torch.equal(x.grad, want)
 
 
 # ---------------------------------------------------------------------------------------------
