@@ -74,7 +74,7 @@ def parse():
     ap.add_argument('--order', type=int, default=3)
     ap.add_argument('--layer', default='ihgnn', choices=['ihgnn', 'hgcn'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-scale', type=float, default=0.125, help='fraction of the workload the CPU baseline runs on')
+    ap.add_argument('--cpu-scale', type=float, default=0.25, help='fraction of the workload the CPU baseline runs on')
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--no-extras', action='store_true', help='skip the untimed extra passes (per-kernel table, restricted last layer, forward only)')
     ap.add_argument('--scale', type=float, default=1.0, help='shrink every count of the workload (exploratory runs of the big configs)')
@@ -123,7 +123,7 @@ def build_model(ds, dev, layer, layers, order, dim):
     return RawGnn(dev, ds, dim, layer_t, layers, order, False, HemPredictionLayer, 0.5).to(dev)
 
 
-def cpu_baseline(config, layer, layers, order, dim, scale):
+def cpu_baseline(config, layer, layers, order, dim, scale, budget_s=10.0):
     """Time the oracle's full training step on the host cores, on a `scale` sub-sample of the SAME config (every count scaled).
 
     PyTorch-CPU does not scale to hundreds of threads on this op mix, so a few thread counts are probed with one step
@@ -152,7 +152,7 @@ def cpu_baseline(config, layer, layers, order, dim, scale):
         loss.backward(); opt.step(); opt.zero_grad()
 
     probes = {}
-    for threads in sorted({min(host, 8), min(host, 16), min(host, 32), min(host, 64)}):     # more threads only get slower on this op mix
+    for threads in sorted({min(host, 8), min(host, 16), min(host, 32)}):     # more threads only get slower on this op mix
         torch.set_num_threads(threads)
         step()                               # warm-up at this thread count
         t0 = time.perf_counter(); step()
@@ -162,7 +162,7 @@ def cpu_baseline(config, layer, layers, order, dim, scale):
     cores = min(probes, key=probes.get)
     torch.set_num_threads(cores)
     t0 = time.perf_counter(); n = 0
-    while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 20):
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 20):
         step(); n += 1
     dt = time.perf_counter() - t0
     return dict(value=w.edge_count * layers * n / dt, unit='hyperedges/s', cores=cores, kind='port',
@@ -170,6 +170,21 @@ def cpu_baseline(config, layer, layers, order, dim, scale):
                        f'{config} (every count scaled: E={w.edge_count}, N={w.node_count}, d={dim}, {layers} layers); {cores} threads = fastest of '
                        f'{sorted(probes)} probed on a {host}-core host, torch {torch.__version__}',
                 ms_per_step=1e3 * dt / n)
+
+
+def mfma_pass_clocks(config):
+    """Clock and matrix-pipe occupancy of the interact kernels from the newest committed MFMA counter pass (profiles/r*/..._pmc_mfma.json;
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/kbench.py at C3) - NOT measured in this run."""
+    if config != 'C3':
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*', '*_pmc_mfma.json')), key=lambda f: (int(os.path.basename(os.path.dirname(f))[1:]), os.path.basename(f)))
+    if not files:
+        return None
+    doc = json.load(open(files[-1]))
+    return dict(source=os.path.relpath(files[-1], REPO), commit=doc.get('commit', 'unrecorded'),
+                kernels={k: dict(clock_ghz=v.get('clock_ghz'), mfma_busy_fraction=v.get('mfma_busy_fraction'), avg_us_under_pmc=v.get('avg_us_under_pmc'))
+                         for k, v in doc.get('kernels', {}).items()})
 
 
 def k7_roles(table, E, N, dim, layout, table_steps):
@@ -267,7 +282,7 @@ def main():
     from ihgnn_amd.optim import Adam
     lossf = torch.nn.BCEWithLogitsLoss()
     sync = None
-    if world > 1:
+    if world > 1 or ihg_dist.force_collectives():            # (IHG_FORCE_COLLECTIVES=1: a one-rank process group that really issues the collectives)
         sync = ihg_dist.make_gradient_sync(model, args.sync)
         sync.broadcast_parameters(0)
     opt = sync.optimizer(1e-3) if (sync is not None and sync.owns_optimizer) else Adam(model.parameters(), 1e-3, weight_decay=0)
@@ -276,12 +291,20 @@ def main():
     # headline = the step with every layer evaluated over ALL rows (each hyperedge through both phases of each layer)
     model.batch_rows_only_last_layer = False
 
-    def step(k):
+    exchange_events = []                                     # (before, after) the gradient exchange on the step's stream, timed region only
+
+    def step(k, timed=False):
         u, q, i, y = batches[k]
         loss = model.bce_loss(u, q, i, y) if fused_loss else lossf(model(u, q, i), y)       # what train_and_get_avg_loss does
         loss.backward()
         if sync is not None:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             sync.average_gradients()
+            if timed:
+                e1.record()
+                exchange_events.append((e0, e1))
         opt.step()
         if sync is not None:
             sync.zero_grad()
@@ -310,9 +333,27 @@ def main():
     fence()
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
-        last = step(k)
+        last = step(k, timed=True)
     fence()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(my_elapsed)
+    # per-rank breakdown for the scaling run: every rank's own step time and the time its stream sat in the gradient exchange (events on the
+    # step's stream around average_gradients(): what of the exchange is NOT hidden behind the backward)
+    exchange = None
+    if sync is not None:
+        exposed = sum(a.elapsed_time(b) for a, b in exchange_events) / max(len(exchange_events), 1)
+        mine = torch.tensor([1e3 * my_elapsed / args.steps, exposed], dtype=torch.float64, device=dev)
+        table_ranks = [torch.zeros_like(mine) for _ in range(world)]
+        if dist.is_initialized():
+            dist.all_gather(table_ranks, mine)
+        else:
+            table_ranks = [mine]
+        flat = getattr(sync, '_grads_padded', None) if getattr(sync, '_grads_padded', None) is not None else sync.flat
+        exchange = dict(mode=args.sync, backend=dist.get_backend() if dist.is_initialized() else None, gradient_bytes_per_rank=int(flat.numel() * flat.element_size()),
+                        per_rank=[dict(rank=r, ms_per_step=round(float(t[0]), 4), exposed_exchange_ms_per_step=round(float(t[1]), 4)) for r, t in enumerate(table_ranks)],
+                        exposed_exchange_ms_per_step_max=round(max(float(t[1]) for t in table_ranks), 4),
+                        note='exposed = HIP events on the step\'s stream around average_gradients(): the part of the exchange the stream waits for '
+                             '(bucketed: the dense bucket overlaps the backward, the embedding tables\' buckets are produced by its last kernels)')
     profiler.stop()
     kernels = profiler.summary() if not args.no_kernel_events else {}
     final_loss = float(last.item())
@@ -424,8 +465,9 @@ def main():
     touched = int((layout.degree > 0.5).sum().item())
     k5_compulsory = touched * row + E * row + 12 * E          # every touched node row once + the [E,d] store + the ids
     k5_algorithmic = E * (16 * dim + 12)                       # 3 ids + 3 row reads + 1 row write per hyperedge
-    pmc = None                                                 # HBM bytes per launch from the committed PMC passes (profiles/)
-    for pmc_file in (os.path.join(REPO, 'profiles', 'r2', f'pmc_traffic_{args.config}.json'), os.path.join(REPO, 'profiles', 'r1', 'pmc_traffic.json')):
+    pmc = None                                                 # HBM bytes per launch from the committed PMC passes (profiles/), newest round first
+    rounds = sorted((d for d in os.listdir(os.path.join(REPO, 'profiles')) if d.startswith('r') and d[1:].isdigit()), key=lambda d: -int(d[1:]))
+    for pmc_file in [os.path.join(REPO, 'profiles', r, f'pmc_traffic_{args.config}.json') for r in rounds] + [os.path.join(REPO, 'profiles', 'r1', 'pmc_traffic.json')]:
         if os.path.exists(pmc_file):
             cand = json.load(open(pmc_file))
             if (cand.get('workload'), cand.get('dim'), cand.get('edges')) == (args.config, dim, E):
@@ -435,12 +477,25 @@ def main():
     def hbm_roofline(kernel, what, rec, compulsory, algorithmic, bytes_note, algorithmic_note, pmc_key, measured):
         t = rec['avg_us'] * 1e-6
         achieved = compulsory / t / 1e9
-        traffic = pmc[pmc_key]['hbm_bytes_per_launch'] if pmc is not None and pmc_key in pmc else None
+        # PMC traffic is NOT measured in this run: it comes from a committed rocprofv3 pass over the same kernel at the same shapes.  It is only
+        # carried when that pass's kernel duration agrees with this run's within 10 % (another box, another clock, another kernel version: refused)
+        traffic = traffic_refused = None
+        if pmc is not None and pmc_key in pmc:
+            prof_us = pmc[pmc_key].get('avg_us_under_pmc')
+            if prof_us and abs(prof_us - rec['avg_us']) <= 0.10 * rec['avg_us']:
+                traffic = pmc[pmc_key]['hbm_bytes_per_launch']
+            else:
+                traffic_refused = f'committed profile {pmc_name} times this kernel at {prof_us} us, this run at {rec["avg_us"]:.1f} us (> 10 % apart): not carried'
         return dict(bound='hbm', kernel=f'{kernel} ({what})', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(achieved / HBM_PEAK_GBS, 4),
+                    frac_note='frac = COMPULSORY bytes / time / peak (every source row once + stores + ids): what must cross the HBM pins; frac_algorithmic uses SURVEY §8 d3\'s byte model',
+                    frac_algorithmic=round(algorithmic / t / 1e9 / HBM_PEAK_GBS, 4),
                     bytes=bytes_note, bytes_per_launch=compulsory, algorithmic_bytes_per_launch=algorithmic, algorithmic_gbs=round(algorithmic / t / 1e9, 1),
                     algorithmic_note=algorithmic_note, traffic=traffic, traffic_gbs=round(traffic / t / 1e9, 1) if traffic else None,
                     traffic_frac=round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                    traffic_source=f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled (gfx950) ({pmc_name}: {pmc[pmc_key].get("source", "in-situ pass")})' if traffic else None,
+                    traffic_source=(f'NOT measured in this run: from the committed profile {pmc_name} (commit {pmc.get("commit", "unrecorded")}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                    f'separate passes, FETCH_SIZE doubled per the gfx950 correction; {pmc[pmc_key].get("source", "in-situ pass")}; kernel time in that pass '
+                                    f'{pmc[pmc_key].get("avg_us_under_pmc")} us)') if traffic else None,
+                    traffic_refused=traffic_refused,
                     traffic_note='FETCH_SIZE / WRITE_SIZE count at the L2 <-> fabric boundary: L2-miss bytes, Infinity-Cache hits included - an upper '
                                  'bound of the HBM bytes; traffic above the compulsory bytes = rows re-fetched after leaving L2' if traffic else None,
                     avg_us=round(rec['avg_us'], 2), launches=rec['launches'], hyperedges_per_s=round(E / t, 1), measured=measured)
@@ -488,7 +543,8 @@ def main():
                          forward=direction('forward', flops_fwd, f['avg_us'], dict(flops_per_launch=flops_fwd, avg_us=round(f['avg_us'], 2))),
                          backward=direction('backward', 2 * flops_fwd, bwd_us, dict(flops_per_step=2 * flops_fwd, us_per_step=round(bwd_us, 2))),
                          share_of_step=round((f['avg_us'] + bwd_us) * 1e-3 / (1e3 * elapsed / args.steps), 3),
-                         measured='instrumented pass after the timed region (every launch bracketed)')
+                         measured='instrumented pass after the timed region (every launch bracketed)',
+                         profiled_clock=mfma_pass_clocks(args.config))
     out = {
         'metric': 'hyperedges_aggregated_per_sec', 'value': round(value, 1), 'unit': 'hyperedges/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
@@ -504,6 +560,7 @@ def main():
                                   'accumulation; error <= the fp32-MFMA kernels\' - tests/test_gpu_parity.py); IHG_INTERACT_ARITH=f32 selects the fp32-MFMA kernels')
                                  if split_arithmetic(dim, args.order) else 'f32 (fp32 MFMA / VALU)'},
         'final_loss': round(final_loss, 6),
+        'gradient_exchange': exchange,
         'roofline': roofline,
         'roofline_hyperedge_to_node': k7_roles(table, E, N, dim, layout, table_steps) or None,
         'roofline_interaction': mfma_roof,
@@ -534,6 +591,27 @@ def main():
         out['kernels_us_note'] = f'HIP events around every launch, {table_steps} untimed steps after the timed region; the timed region brackets the `roofline` kernel only'
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args.config, args.layer, layers, args.order, dim, args.cpu_scale)
+        if args.config != 'C1':
+            # the reference's own CPU-runnable config at FULL size (BASELINE configs[0]), the SAME input on both sides
+            c1 = synth.CONFIGS['C1']
+            w1 = synth.draw_config('C1')
+            ds1 = GraphDataset.from_arrays(w1.user_count, w1.query_count, w1.item_count, w1.vocab_size, w1.bag_words, w1.bag_offsets, w1.triples, device=dev)
+            m1 = build_model(ds1, dev, args.layer, c1['layers'], args.order, c1['dim'])
+            o1 = Adam(m1.parameters(), 1e-3, weight_decay=0)
+            b1 = list(ds1.sample_batches(100, 60, seed=7))
+            m1.batch_rows_only_last_layer = False
+            for k in range(10):
+                m1.bce_loss(*b1[k]).backward(); o1.step(); o1.zero_grad()
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            for k in range(10, 60):
+                m1.bce_loss(*b1[k]).backward(); o1.step(); o1.zero_grad()
+            torch.cuda.synchronize()
+            gpu_ms = 1e3 * (time.perf_counter() - t5) / 50
+            leg = cpu_baseline('C1', args.layer, c1['layers'], args.order, c1['dim'], 1.0, budget_s=4.0)
+            leg['gpu_same_input'] = dict(ms_per_step=round(gpu_ms, 4), value=round(w1.edge_count * c1['layers'] / (gpu_ms * 1e-3), 1), unit='hyperedges/s',
+                                         note='the HIP path on the identical C1 workload (E = 20,000: a launch-bound step, ~50 launches of a few microseconds each)')
+            out['cpu_baseline_c1_full_size'] = leg
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

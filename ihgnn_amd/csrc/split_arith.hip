@@ -4,10 +4,16 @@
 // Every fp32 operand x is taken apart EXACTLY into three bf16 terms, x = hi + mid + lo (hi = the top 16 bits of x, mid = the top
 // 16 bits of x - hi, lo = the rest: 8 + 8 + 8 significand bits, both subtractions exact), and a product a b is accumulated in fp32
 // as the six partial products hi hi + hi mid + mid hi + hi lo + mid mid + lo hi, smallest first.  Each partial product of two
-// bf16 values is exact in fp32; the three that are left out are below 2^-26 |a b|, a quarter of the rounding error of ONE fp32
-// multiply-add.  Measured against fp64 the result is as close as the fp32-MFMA kernels' (tests/test_gpu_parity.py holds both to
-// the same 1e-5 bar, tools/split_probe.hip has the standalone rate measurement): v_mfma_f32_16x16x32_bf16 runs 16 x the rate of
-// v_mfma_f32_16x16x4_f32, six of them replace eight -> the same contraction in ~ 0.4 of the matrix-pipe time.
+// bf16 values is exact in fp32.  The three that are left out (mid lo + lo mid + lo lo) are bounded by 2^-21 |a b|: the split truncates
+// toward zero, so with the low 16 significand bits set mid ~ 2^-7 x and lo ~ 2^-15 x, and the omitted terms all carry the sign of the
+// product they belong to - in a dot product whose terms share a sign they add up instead of averaging out (on random data the bias is
+// ~ 2^-24).  Measured on exactly that worst case against float64 (tests/test_gpu_parity.py::test_split_arithmetic_worst_case_operands,
+// every operand's low 16 bits set, all products positive), d = 64: forward 5.6e-7, weight gradients 5.2e-7, node-level map 4.5e-7, member
+// gradients 1.3e-6 relative (two contractions deep: dout W, then the product rule in fp32); d = 256 (contraction length 1,024): forward
+// 1.4e-6, member gradients 1.4e-6, node-level map 9.3e-7 - all at least 7 x inside the 1e-5 contract (the test holds 2e-6);
+// on random data 2-4e-7, the fp32-MFMA kernels' own level (test_split_arithmetic_is_as_accurate_as_fp32_mfma).
+// v_mfma_f32_16x16x32_bf16 runs 16 x the rate of v_mfma_f32_16x16x4_f32, six of them replace eight -> the same contraction in ~ 0.4 of
+// the matrix-pipe time (tools/split_probe.hip has the standalone rate measurement).
 //
 // Three bf16 planes of the weights are 1.5 x their fp32 size: 384 KB at d = 128, more than one workgroup's registers can keep beside
 // the accumulators.  So a workgroup owns a PART of the columns (a half at d = 128, an eighth at d = 256, all of them at d = 64); the
@@ -31,6 +37,22 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr int kSplitTE = 32;            // hyperedges per tile
 constexpr int kSplitRanges = 128;       // contiguous tile ranges at d = 128 (x 2 column halves = 256 workgroups, one per CU)
 constexpr int kSplitThreads = 512;
+
+// Issue priority of the two wave roles (s_setprio, 0 .. 3; A/B: tools/ab_variant.sh NAME -DIHG_SERVICE_PRIO=n -DIHG_MATRIX_PRIO=m).  The
+// service waves are the second-dispatched half of the workgroup - the arbitration loser at equal priority (oldest first).
+#ifndef IHG_SERVICE_PRIO
+#define IHG_SERVICE_PRIO 3           // measured at C3 (same box, us): forward 1,874 -> 1,766, weight gradients 1,454 -> 1,342, member gradients 1,870 -> 1,834;
+#endif                               // priority 1: 1,787 / 1,366 / 1,827; matrix waves at 1 instead: no change (profiles/r3/ab_priority.txt)
+#ifndef IHG_MATRIX_PRIO
+#define IHG_MATRIX_PRIO 0
+#endif
+__device__ __forceinline__ void role_priority(bool service) {
+    if (service) {
+        if (IHG_SERVICE_PRIO) __builtin_amdgcn_s_setprio(IHG_SERVICE_PRIO);
+    } else {
+        if (IHG_MATRIX_PRIO) __builtin_amdgcn_s_setprio(IHG_MATRIX_PRIO);
+    }
+}
 
 __device__ __forceinline__ unsigned pack_hi(float a, float b) {          // {top half of b, top half of a}
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
@@ -164,6 +186,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     }
     const int n_phases = n_my + (UR ? 3 : 1);
 
+    role_priority(wave >= 4);
     if (wave >= 4) {
         // ---------------- service waves: 256 threads, thread -> hyperedge row, dout octets o and o + 8, member / gradient columns 4 o .. and 32 + 4 o ..
         const int st = tid - 256, row = st >> 3, o = st & 7;
@@ -527,6 +550,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
     if (n_my == 0) return;
     auto tile_of = [&](int k) { return static_cast<int64_t>(range) + static_cast<int64_t>(k) * RANGES; };
 
+    role_priority(wave >= 4);
     if (wave >= 4) {
         // ---------------- service waves: thread -> hyperedge row, member columns 4 o .. and 64 + 4 o ..; epilogue: output columns 4 o .. of the half
         const int st = tid - 256, row = st >> 4, o = st & 15;
@@ -655,6 +679,193 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward at d = 128 in TWO PASSES over the contraction index (the default; IHG_FWD_KPASS=0 keeps the column-half kernel above).
+// The column-half form forms and splits every product twice (once per half); here a workgroup owns ALL 128 output columns and HALF of
+// the contraction index - pass A: blocks uq, qi (+ the first-order rows), pass B: blocks iu, uqi, added onto pass A's result, which
+// goes through `out` (one extra write and read of [E, d]: 2.2 GB that an issue-bound kernel moves beside its MFMAs) - so every product
+// is formed and split ONCE.  The weight planes of a pass are again 192 KB: matrix wave m owns output columns 32 m .. 32 m + 31 with the
+// pass's whole contraction index (two blocks = 256 values: 192 registers), so no partial sums meet across waves; it reads all of the
+// tile's product images (32 hyperedges x 512 B x 3 planes).  Tiles of 32 hyperedges: half the barriers, ids and address arithmetic per
+// hyperedge of the 16-hyperedge form.  Service thread = (hyperedge row, 16 columns): 12 member loads, 32 products, 24 8-byte image
+// writes per tile; the epilogue (tile k - 1: sums from the LDS image + first-order rows or pass A's row -> store) rides in phase k.
+// A workgroup takes a CONTIGUOUS tile range (hyperedges are numbered by user).
+// wkp[pass][m][jt < 2][kb < 8][plane][lane][8]: element i = plane of W[32 m + 16 jt + (lane & 15)][(3 + 2 pass + (kb >> 2)) d + 32 (kb & 3) + 8 (lane >> 4) + i]
+// ------------------------------------------------------------------------------------------------
+constexpr int kKpTE = 32;
+constexpr int kKpPassV4 = 4 * 2 * 8 * 3 * kWave;                        // v4u of one pass's planes
+
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_fwd_kpass_kernel(const float* __restrict__ w, int64_t ld_w, int nblk, v4u* __restrict__ wkp) {
+    constexpr int D = 128;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * 4 * 2 * 8 * kWave) return;
+    const int lane = idx & 63, kb = (idx >> 6) & 7, jt = (idx >> 9) & 1, m = (idx >> 10) & 3, pass = idx >> 12;
+    const int b = 2 * pass + (kb >> 2);
+    const float* src = w + static_cast<int64_t>(32 * m + 16 * jt + (lane & 15)) * ld_w + (3 + b) * D + 32 * (kb & 3) + 8 * (lane >> 4);
+    const Planes pl = b < nblk ? split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]})
+                               : split8(v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wkp[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
+}
+
+// NB: product blocks of this pass (2, or 1 for the second pass of order 2); B0: the pass's first block (0: uq, qi; 2: iu, uqi);
+// ACC: `out` already holds the other pass's result (and the first-order rows) - add onto it instead of gathering the first-order rows
+template <int NB, int B0, bool ACC>
+__global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p,
+                                                                                 const int32_t* __restrict__ i3, const v4u* __restrict__ wkp, float* __restrict__ out,
+                                                                                 int64_t ld_out, int64_t n_edges) {
+    constexpr int D = 128, TE = kKpTE, KB = 4 * NB, ZRB = 2 * NB * D, ZPL = TE * ZRB, PS = D + 4, ZX = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
+    __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
+    __shared__ int ids[8][3 * TE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t n_tiles = (n_edges + TE - 1) / TE;
+    const int64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * per;
+    const int n_my = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(per, n_tiles - t0)));
+    if (n_my == 0) return;
+
+    role_priority(wave >= 4);
+    if (wave >= 4) {
+        // ---------------- service waves: thread -> hyperedge row, columns 4 o + 32 x .. (x < 4)
+        const int st = tid - 256, row = st >> 3, o = st & 7;
+        const int64_t last_pos = n_edges * 3 - 1;
+        const uint32_t ldh = static_cast<uint32_t>(ld_h), ldp = static_cast<uint32_t>(ld_p);
+        auto fetch_id = [&](int k) {                                     // (st < 96; the tile exists) - scalar tile base, one vector min
+            const int64_t first = (t0 + k) * (3 * TE);
+            const int lim = static_cast<int>(std::min<int64_t>(last_pos - first, 3 * TE - 1));
+            return (i3 + first)[std::min(st, lim)];
+        };
+        auto load_members = [&](int k, v4f (&hm)[ZX][3]) {
+            const int* idk = ids[k & 7] + row * 3;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float* hp = row_at(h, idk[m], ldh) + 4 * o;
+#pragma unroll
+                for (int x = 0; x < ZX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + 32 * x);
+            }
+        };
+        // what the products are added to: the three first-order rows (summed on arrival order u, q, i) or the row the other pass left in `out`
+        auto load_first = [&](int k, v4f (&pr)[ZX][ACC ? 1 : 3]) {
+            if (ACC) {
+                const int64_t e = std::min<int64_t>((t0 + k) * TE + row, n_edges - 1);
+                const float* op = out + e * ld_out + 4 * o;
+#pragma unroll
+                for (int x = 0; x < ZX; ++x) pr[x][0] = *reinterpret_cast<const v4f*>(op + 32 * x);
+            } else {
+                const int* idk = ids[k & 7] + row * 3;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const float* pp = row_at(p, idk[m], ldp) + 4 * o;
+#pragma unroll
+                    for (int x = 0; x < ZX; ++x) pr[x][ACC ? 0 : m] = *reinterpret_cast<const v4f*>(pp + 32 * x);
+                }
+            }
+        };
+        auto split_tile = [&](const v4f (&hm)[ZX][3], int buf) {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int x = 0; x < ZX; ++x) {
+                const v4f u = hm[x][0], q = hm[x][1], it = hm[x][2];
+#pragma unroll
+                for (int b2 = 0; b2 < NB; ++b2) {
+                    const int b = B0 + b2;
+                    const v4f z = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
+                    unsigned w0[3], w1[3];
+                    split_pair(z[0], z[1], w0);
+                    split_pair(z[2], z[3], w1);
+                    // columns b2 D + 32 x + 4 o ..: chunk 16 b2 + 4 x + (o >> 1), half o & 1
+                    const int off = row * ZRB + (((16 * b2 + 4 * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + pl * ZPL + off) = v2u{w0[pl], w1[pl]};
+                }
+            }
+        };
+        auto epilogue = [&](int k, const v4f (&pr)[ZX][ACC ? 1 : 3]) {   // tile k
+            const int64_t e = (t0 + k) * TE + row;
+            const float (*pp)[PS] = part[k & 1];
+#pragma unroll
+            for (int x = 0; x < ZX; ++x) {
+                const v4f sum = *reinterpret_cast<const v4f*>(&pp[row][4 * o + 32 * x]);
+                const v4f first = ACC ? pr[x][0] : (pr[x][0] + pr[x][ACC ? 0 : 1]) + pr[x][ACC ? 0 : 2];
+                if (e < n_edges) store_stream4(out + e * ld_out + 4 * o + 32 * x, first + sum);
+            }
+        };
+        if (st < 3 * TE) {
+            ids[0][st] = fetch_id(0);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) ids[k][st] = k < 4 && k < n_my ? fetch_id(k) : 0;       // (slots of tiles past the end: row 0, requested and dropped)
+        }
+        __syncthreads();
+        v4f hm0[ZX][3], hm1[ZX][3], pr[ZX][ACC ? 1 : 3];                    // member values of tile m in hm<m & 1>
+        load_members(0, hm0);
+        if (n_my > 1) load_members(1, hm1);
+        split_tile(hm0, 0);
+        __syncthreads();
+        int id_carry = 0;
+        // phase k: products of tile k + 1 (`use`) into the images; first-order rows (requested at the start of the phase), sums and store of
+        // tile k - 1 at its end; requests: member values of tile k + 2 (`fill`), ids of tile k + 4
+        auto phase = [&](int k, v4f (&use)[ZX][3], v4f (&fill)[ZX][3]) {
+            if (k >= 1 && k + 3 < n_my && st < 3 * TE) ids[(k + 3) & 7][st] = id_carry;
+            load_members(k + 2, fill);                                   // unconditional (past the end: whatever rows the ring slot names, dropped)
+            if (k >= 1) load_first(k - 1, pr);
+            if (k + 4 < n_my && st < 3 * TE) id_carry = fetch_id(k + 4);
+            if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
+            // delivery of this phase's requests, THEN the store (the memory counter is in order)
+            asm volatile("" : "+v"(fill[ZX - 1][0]), "+v"(fill[ZX - 1][1]), "+v"(fill[ZX - 1][2]));
+            asm volatile("" : "+v"(pr[ZX - 1][0]));
+            if (k >= 1) epilogue(k - 1, pr);
+            __syncthreads();
+        };
+        int k = 0;
+#pragma clang loop unroll(disable)
+        for (; k + 1 <= n_my; k += 2) {                                   // exactly two phases per trip: the register sets come back in place
+            phase(k, hm1, hm0);
+            phase(k + 1, hm0, hm1);
+        }
+        if (k <= n_my) phase(k, hm1, hm0);
+        return;
+    }
+
+    // ---------------- matrix waves: wave m = output columns 32 m .. 32 m + 31, the pass's whole contraction index
+    v8s wreg[2][KB][3];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                wreg[jt][kb][pl] = __builtin_bit_cast(v8s, wkp[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 3 + pl) * kWave + lane]);
+    __syncthreads();
+    __syncthreads();
+    const int arow = lane & 15, kq = lane >> 4;
+    for (int k = 0; k <= n_my; ++k) {
+        if (k < n_my) {
+            const unsigned char* zp = &zplanes[k & 1][0][0][0];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+                const unsigned char* rp = zp + (16 * rt + arow) * ZRB;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    v8s zf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) zf[pl] = *reinterpret_cast<const v8s*>(rp + pl * ZPL + ((((4 * kb + kq)) ^ arow) << 4));
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int jt = 0; jt < 2; ++jt)
+                            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[jt][kb][kTermB[term]], zf[kTermA[term]], acc[jt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[k & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[jt];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Forward at d = 256 (the kernel is written for d = 128 as well, where the resident-weights form above is faster), without eightfold product work: the contraction index is walked in CHUNKS of 128 (one product block, or
 // half of one at d = 256), one chunk per phase.  The matrix waves own the OUTPUT - wave m: 32 columns x the tile's 32 hyperedges,
 // accumulators kept across the chunks - and do not keep the weights: the 24 weight fragments of the next chunk (24 KB per wave, the planes
@@ -696,6 +907,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_chunk_kernel
     auto tile_of = [&](int k) { return static_cast<int64_t>(seq) + static_cast<int64_t>(k) * NSEQ; };
     const int n_phases = (n_my + 1) * NCH;                               // the last tile leaves during one more (empty) tile's worth of phases
 
+    role_priority(wave >= 4);
     if (wave >= 4) {
         // ---------------- service waves: thread -> hyperedge row, 16 columns of a 128-column part
         const int st = tid - 256, row = st >> 3, cq = st & 7;
@@ -914,6 +1126,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
     const int64_t t0 = range * per;
     const int n_my = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(per, n_tiles - t0)));
 
+    role_priority(wave >= 4);
     if (wave >= 4) {
         // ---------------- split waves: 256 threads, thread -> hyperedge row, dout octets o and o + 8, member columns 4 o .. and 32 + 4 o ..
         const int st = tid - 256, row = st >> 3, o = st & 7;
@@ -1443,6 +1656,11 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 // floats of workspace for the weight planes of one direction: laid out for four blocks at either order
 int64_t split_plane_floats(int dim, int order) { return (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) ? (3LL * 4 * dim * dim) / 2 : 0; }
 
+static bool fwd_kpass_enabled() {                                        // IHG_FWD_KPASS=0: the column-half forward at d = 128 (A/B, tests)
+    const char* v = std::getenv("IHG_FWD_KPASS");
+    return v == nullptr || std::strcmp(v, "0") != 0;
+}
+
 bool split_arith_enabled() {                                             // read at every call: tests and the bench switch it in-process
     const char* v = std::getenv("IHG_INTERACT_ARITH");
     return v == nullptr || std::strcmp(v, "f32") != 0;
@@ -1567,6 +1785,16 @@ void launch_fwd_split(int dim, int order, const float* h, int64_t ld_h, const fl
     // d = 256: chunked (the eight-part column split of the other form would repeat the product work eight times); d = 64 / 128: weights
     // resident.  At d = 128 the chunked form measured 2,430 us against 2,000: with 32-hyperedge tiles its weight stream (393 KB per tile)
     // alone fills the CU's L2 port for 0.8 ms.
+    if (dim == 128 && fwd_kpass_enabled()) {
+        hipLaunchKernelGGL(pack_planes_fwd_kpass_kernel, dim3((2 * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w,
+                           order == 3 ? 4 : 3, wsp);
+        hipLaunchKernelGGL((interact_fwd_split_kpass_kernel<2, 0, false>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
+        if (order == 3)
+            hipLaunchKernelGGL((interact_fwd_split_kpass_kernel<2, 2, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp + kKpPassV4, out, ld_out, n_edges);
+        else
+            hipLaunchKernelGGL((interact_fwd_split_kpass_kernel<1, 2, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp + kKpPassV4, out, ld_out, n_edges);
+        return;
+    }
     if (dim != 256) {
         const int items = (dim / 64) * 4 * 4 * (dim / 32) * kWave;
         hipLaunchKernelGGL(pack_planes_fwd_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, order == 3 ? 4 : 3, wsp);

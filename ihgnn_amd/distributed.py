@@ -18,12 +18,19 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives() -> bool:
+    """``IHG_FORCE_COLLECTIVES=1``: run every collective even in a ONE-rank process group (they are identities there).  This is how the RCCL
+    code paths - ``ReduceOp.AVG``, ``reduce_scatter_tensor``, ``all_gather_into_tensor``, async launches from gradient hooks - are
+    executed on a box with a single GPU (tests/test_gpu_parity.py, tools/two_rank_check.py --ranks 1 --backend nccl)."""
+    return os.environ.get('IHG_FORCE_COLLECTIVES') == '1'
+
+
 def init_from_env(backend: Optional[str] = None) -> tuple:
     """Initialise the default process group from torchrun's environment.  -> (rank, local_rank, world_size)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -44,6 +51,7 @@ class GradientSync:
         self.params: List[torch.nn.Parameter] = [p for p in parameters if p.requires_grad]
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.distributed = dist.is_initialized() and (self.world_size > 1 or force_collectives())      # collectives are issued
         self._use_avg = None
         if not self.params:
             self.flat = None
@@ -80,7 +88,7 @@ class GradientSync:
         if self.flat is None:
             return
         self._reattach()
-        if self.world_size > 1:
+        if self.distributed:
             if self._use_avg is None:
                 self._use_avg = dist.get_backend(self.group) == 'nccl'
             if self._use_avg:                                # RCCL averages inside the collective: no second pass over the buffer
@@ -94,7 +102,7 @@ class GradientSync:
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """Make every replica start from rank ``src``'s weights."""
-        if self.world_size > 1:
+        if self.distributed:
             for p in self.params:
                 dist.broadcast(p.data, src=src, group=self.group)
 
@@ -130,7 +138,7 @@ class BucketedGradientSync(GradientSync):
         self._works = []
         self._launched = [False] * len(self.buckets)
         self._arm()
-        if self.world_size > 1:
+        if self.distributed:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -174,7 +182,7 @@ class BucketedGradientSync(GradientSync):
             self._launch(index)
 
     def average_gradients(self):
-        if self.flat is None or self.world_size == 1:
+        if self.flat is None or not self.distributed:
             return
         self._reattach()
         for index in range(len(self.buckets)):               # buckets whose hooks did not all fire (unused parameters, detached views)
@@ -218,7 +226,7 @@ class _ShardOptimizer:
         if entry is not None:
             for key in ('exp_avg', 'exp_avg_sq'):
                 gathered = torch.empty(sync.padded, dtype=sync.param_shard.dtype, device=sync.param_shard.device)
-                if sync.world_size > 1:
+                if sync.distributed:
                     dist.all_gather_into_tensor(gathered, entry[key].reshape(-1).contiguous(), group=sync.group)
                 else:
                     gathered.copy_(entry[key].reshape(-1))
@@ -293,7 +301,7 @@ class ShardedGradientSync(GradientSync):
     def average_gradients(self):
         self._reattach()
         lo, hi = self.shard_range
-        if self.world_size == 1:
+        if not self.distributed:
             self.grad_shard.copy_(self._grads_padded[lo:hi])
             return
         backend = dist.get_backend(self.group)
@@ -311,14 +319,14 @@ class ShardedGradientSync(GradientSync):
         torch.div(self._grads_padded[lo:hi], self.world_size, out=self.grad_shard)
 
     def gather_parameters(self) -> None:
-        if self.world_size > 1:
+        if self.distributed:
             dist.all_gather_into_tensor(self.flat_params, self.param_shard.clone(), group=self.group)
 
     def zero_grad(self) -> None:
         self._grads_padded.zero_()
 
     def broadcast_parameters(self, src: int = 0) -> None:
-        if self.world_size > 1:
+        if self.distributed:
             dist.broadcast(self.flat_params, src=src, group=self.group)
 
 

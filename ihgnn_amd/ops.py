@@ -480,6 +480,8 @@ USER_REDUCED_BACKWARD = _os.environ.get('IHG_USER_REDUCED', '1') != '0'
 # the last layer of a training step is told which rows of its output are read (node_two_hop's cotangent_rows): its backward pulls only those
 SPARSE_LAST_COTANGENT = _os.environ.get('IHG_SPARSE_LAST_COTANGENT', '1') != '0'
 CHECK_SPARSE_COTANGENT = _os.environ.get('IHG_CHECK_SPARSE_COTANGENT', '0') == '1'
+# the interactive layer as ONE autograd node (interact_layer); IHG_LAYER0_ONE_NODE=0: first_order and interact_to_nodes as two nodes (A/B)
+LAYER0_ONE_NODE = _os.environ.get('IHG_LAYER0_ONE_NODE', '1') != '0'
 
 
 def _zero_isolated_users(dh: Tensor, layout: IncidenceLayout) -> None:

@@ -55,7 +55,7 @@ def _worker(rank, world, port, out_dir, mode='flat'):
     sl = slice(rows.start, rows.stop)
     opt = sync.optimizer(1e-2) if sync.owns_optimizer else torch.optim.Adam(model.parameters(), 1e-2)
     lossf = torch.nn.BCEWithLogitsLoss()
-    for _ in range(2):                                      # two steps: the .grad views must survive zero_grad
+    for step in range(2):                                   # two steps: the .grad views must survive zero_grad
         loss = lossf(model(u[sl], q[sl], i[sl]), y[sl])
         loss.backward()
         assert all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in sync.params)      # grads live in the flat buffer
@@ -64,9 +64,24 @@ def _worker(rank, world, port, out_dir, mode='flat'):
         sync.average_gradients()
         opt.step()
         sync.zero_grad()
+        if mode == 'sharded' and step == 0:                 # the checkpoint of the sharded optimizer holds EVERY rank's Adam state
+            state = opt.state_dict()
+            assert state['sharded_adam']['exp_avg'].numel() == sync.flat.numel() and float(state['sharded_adam']['exp_avg'].abs().sum()) > 0
+            fresh = sync.optimizer(1e-2)
+            fresh.load_state_dict(state)
+            lo, hi = sync.shard_range
+            mine = next(iter(fresh.inner.state_dict()['state'].values()))
+            want = next(iter(opt.inner.state_dict()['state'].values()))
+            assert torch.equal(mine['exp_avg'], want['exp_avg']) and torch.equal(mine['exp_avg_sq'], want['exp_avg_sq'])
+            opt = fresh
+    torch.save({k: v.clone() for k, v in model.reference_state().items()}, os.path.join(out_dir, f'rank{rank}.pt'))
+    if mode == 'bucketed':                                  # a second backward before the exchange was waited for must not pass silently
+        lossf(model(u[sl], q[sl], i[sl]), y[sl]).backward()
+        with pytest.raises(RuntimeError, match='already launched'):
+            lossf(model(u[sl], q[sl], i[sl]), y[sl]).backward()
+        sync.average_gradients()
     sums = ihg_dist.all_reduce_sums([float(rank + 1), 10.0], torch.device('cpu'))
     assert sums == [3.0, 20.0]
-    torch.save({k: v.clone() for k, v in model.reference_state().items()}, os.path.join(out_dir, f'rank{rank}.pt'))
     dist.destroy_process_group()
 
 

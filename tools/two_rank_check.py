@@ -7,6 +7,10 @@ The parent starts the rank processes before touching the GPU (as bench.py does).
 GPU `--device` (RCCL refuses two ranks on one GPU, so the single-GPU form uses gloo; on a multi-GPU node pass `--backend nccl
 --device -1`), trains two steps on its slice of one global batch with the chosen gradient exchange, and rank 0 then repeats the
 two steps alone on the whole batch and compares every parameter.  Exit code 0 = equal within 2e-5 relative.
+
+`--ranks 1 --backend nccl` is the single-GPU RCCL form: one rank in an RCCL process group with IHG_FORCE_COLLECTIVES=1, so every collective
+of the chosen exchange (all-reduce with ReduceOp.AVG, async bucket launches from the gradient hooks, reduce_scatter_tensor,
+all_gather_into_tensor, broadcast) really runs through RCCL - as identities - and the result must equal the plain one-rank training.
 """
 import argparse
 import os
@@ -32,7 +36,8 @@ def main():
             port = s.getsockname()[1]
         kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                                  env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.ranks), MASTER_ADDR='127.0.0.1',
-                                          MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')) for r in range(args.ranks)]
+                                          MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0',
+                                          **({'IHG_FORCE_COLLECTIVES': '1'} if args.ranks == 1 else {}))) for r in range(args.ranks)]
         codes = [k.wait() for k in kids]
         raise SystemExit(max(abs(c) for c in codes))
 
@@ -65,11 +70,16 @@ def main():
     opt = sync.optimizer(1e-3) if sync.owns_optimizer else Adam(model.parameters(), 1e-3)
     rows = ihg_dist.shard_range(B, rank, world)
     sl = slice(rows.start, rows.stop)
-    for _ in range(2):
+    assert world > 1 or sync.distributed, 'a one-rank run must be forced through the collectives (IHG_FORCE_COLLECTIVES=1)'
+    for step in range(2):
         model.bce_loss(u[sl], q[sl], i[sl], y[sl]).backward()
         sync.average_gradients()
         opt.step()
         sync.zero_grad()
+        if step == 0 and sync.owns_optimizer:                # the sharded optimizer's checkpoint: gathered over ranks, loadable again
+            state = opt.state_dict()
+            assert state['sharded_adam']['exp_avg'].numel() == sync.flat.numel()
+            opt.load_state_dict(state)
     torch.cuda.synchronize()
     ok = True
     if rank == 0:
