@@ -106,8 +106,10 @@ def test_and_get_avg_metrics(model, dataset_train: GraphDataset, dataloader: Tes
 
 def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.Module, dataset_train: GraphDataset,
                            dataloader_train, pc: ProcessController, device: torch.device,
-                           grad_sync=None) -> Tuple[float, float]:
-    """One epoch over ``dataloader_train`` -> (average loss, seconds)."""
+                           grad_sync=None, record_step: bool = False) -> Tuple[float, float]:
+    """One epoch over ``dataloader_train`` -> (average loss, seconds).  ``record_step`` (single process, fused loss, the HIP Adam): batches
+    of the common size run as replays of ONE recorded step (``ihgnn_amd.captured_step``: worth it where the step is bound by the host's
+    launch rate, i.e. on small graphs); other batch sizes - the epoch's last batch - run eagerly."""
     started = time.time()
     loss_sum = torch.zeros((), dtype=torch.float32, device=device)
     batches = positives = 0
@@ -118,7 +120,19 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
         positives += len(p_u)
         users, queries, items = torch.cat([p_u, n_u]), torch.cat([p_q, n_q]), torch.cat([p_i, n_i])
         flags = torch.cat([p_f, n_f]).float()
-        if getattr(model, 'supports_fused_loss', None) and model.supports_fused_loss(loss_function):
+        fused = getattr(model, 'supports_fused_loss', None) and model.supports_fused_loss(loss_function)
+        if record_step and fused and grad_sync is None:
+            recorded = getattr(model, '_recorded_step', None)
+            if recorded is None or recorded.optimizer is not optimizer:
+                from ..captured_step import CapturedTrainingStep
+                recorded = model._recorded_step = CapturedTrainingStep(model, optimizer, int(users.shape[0]), warmup_batch=(users, queries, items, flags))
+            if recorded.batch_rows == int(users.shape[0]):
+                loss_sum += recorded.step(users, queries, items, flags)
+                batches += 1
+                continue
+        if getattr(model, '_recorded_step', None) is not None:
+            optimizer.zero_grad(set_to_none=True)           # the last replay's gradients (in the recording's pool) must not be accumulated onto
+        if fused:
             loss = model.bce_loss(users, queries, items, flags)
         else:
             loss = loss_function(model(users, queries, items), flags)

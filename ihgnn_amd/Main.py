@@ -139,7 +139,7 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
     history = MetricsCollection(Gs.use_valid_dataset)
     for _ in pc:
         avg_loss, train_seconds = train_and_get_avg_loss(model, optimizer, loss_function, dataset_train, dataloader_train,
-                                                         pc, device, grad_sync=grad_sync)
+                                                         pc, device, grad_sync=grad_sync, record_step=bool(getattr(args, 'record_step', False)) and world == 1)
         pc.AddTrainTime(train_seconds)
         if chief and pc.ShouldStore():
             fn = os.path.join(result_dir, time.strftime(f'checkpoint_%y%m%d-%H%M%S_epoch{pc.CurrentEpoch}', time.localtime()))

@@ -1,0 +1,84 @@
+"""One training step of ``RawGnn`` recorded as a hipGraph and replayed (``torch.cuda.graph``).
+
+A step of the hot path is ~85 kernel launches issued from Python through ctypes.  At the BASELINE workloads from C2 up the GPU is
+the bound (the kernels of a C3 step add up to the step's wall time: profiles/r3), so recording buys nothing there; on small graphs
+(config C1: 20,000 hyperedges, every kernel a few microseconds) the step is bound by the host's launch rate, and a replay removes
+that.  What is recorded: forward (``RawGnn.bce_loss``), backward, and the Adam update with its two step-dependent scalars read from
+device memory (``ihg_adam_step_device_scalars``).  Per replay the host copies the batch into the static input buffers, refreshes the two
+Adam scalars and launches the graph.  Single process only (a recorded RCCL exchange is not attempted).
+"""
+from __future__ import annotations
+
+import torch
+
+from .optim import Adam
+
+
+class CapturedTrainingStep:
+    """``step(users, queries, items, labels) -> loss`` (a device scalar, valid until the next call), same result as::
+
+        loss = model.bce_loss(users, queries, items, labels); loss.backward(); optimizer.step(); optimizer.zero_grad()
+
+    for batches of ``batch_rows`` rows.  The learning rate may change between calls (it enters through the device scalars)."""
+
+    def __init__(self, model, optimizer: Adam, batch_rows: int, warmup_batch=None):
+        if not isinstance(optimizer, Adam):
+            raise TypeError('CapturedTrainingStep records ihgnn_amd.optim.Adam')
+        self.model, self.optimizer, self.batch_rows = model, optimizer, int(batch_rows)
+        dev = next(model.parameters()).device
+        self.users = torch.zeros(batch_rows, dtype=torch.int64, device=dev)
+        self.queries = torch.zeros(batch_rows, dtype=torch.int64, device=dev)
+        self.items = torch.zeros(batch_rows, dtype=torch.int64, device=dev)
+        self.labels = torch.zeros(batch_rows, dtype=torch.float32, device=dev)
+        self.scalars = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._table, self._table_first, self._table_lr = None, 0, None   # Adam scalars of the coming steps, on the device
+        if warmup_batch is not None:
+            for dst, src in zip((self.users, self.queries, self.items, self.labels), warmup_batch):
+                dst.copy_(src)
+        optimizer.ensure_state()                             # exp_avg / exp_avg_sq exist before the recording (not in the graph's pool)
+        # torch's recipe for whole-step capture: a few eager iterations on a side stream (allocator warm-up), gradients released, then the
+        # recording; the gradients the recording allocates live in the graph's pool and are rewritten by every replay.  The warm-up runs
+        # forward and backward only: no parameter changes.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                optimizer.zero_grad(set_to_none=True)
+                model.bce_loss(self.users, self.queries, self.items, self.labels).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = model.bce_loss(self.users, self.queries, self.items, self.labels)
+            self.loss.backward()
+            optimizer.launch_with_device_scalars(self.scalars)
+
+    TABLE_STEPS = 2048
+
+    def _refresh_scalars(self) -> None:
+        """``scalars <- (lr / (1 - beta1^t), sqrt(1 - beta2^t))`` of the coming step by a device-to-device copy out of a table that holds the
+        next ``TABLE_STEPS`` steps (rebuilt when it runs out or the learning rate changes): no host buffer is read by an in-flight copy."""
+        opt = self.optimizer
+        group = opt.param_groups[0]
+        t = opt.next_step()
+        if self._table is None or self._table_lr != group['lr'] or not (self._table_first <= t < self._table_first + self.TABLE_STEPS):
+            import numpy as np
+            # exactly ihg_adam_step's arithmetic: lr and the betas arrive there as fp32, the bias corrections are formed in double
+            lr, beta1, beta2 = (float(np.float32(x)) for x in (group['lr'], group['betas'][0], group['betas'][1]))
+            steps = np.arange(t, t + self.TABLE_STEPS, dtype=np.float64)
+            table = torch.from_numpy(np.stack([lr / (1.0 - np.power(beta1, steps)), np.sqrt(1.0 - np.power(beta2, steps))], 1).astype(np.float32))
+            self._table, self._table_first, self._table_lr = table.to(self.scalars.device), t, group['lr']
+        self.scalars.copy_(self._table[t - self._table_first], non_blocking=True)
+
+    def step(self, users, queries, items, labels):
+        if users.shape[0] != self.batch_rows:
+            raise ValueError(f'this step was recorded for batches of {self.batch_rows} rows, got {users.shape[0]}')
+        self.users.copy_(users, non_blocking=True)
+        self.queries.copy_(queries, non_blocking=True)
+        self.items.copy_(items, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+        self._refresh_scalars()
+        self.graph.replay()
+        self.optimizer.advance()
+        return self.loss

@@ -46,6 +46,15 @@ constexpr int kSplitThreads = 512;
 #ifndef IHG_MATRIX_PRIO
 #define IHG_MATRIX_PRIO 0
 #endif
+// Left to the scheduler, an LDS fragment read that the source issues a step ahead is sunk to just in front of its first MFMA (the weight
+// planes hold 192 registers, and shortening live ranges wins): every step then sits out the LDS latency.  A scheduling barrier on both sides
+// of a step's MFMA group keeps the reads of step s + 1 in front of the MFMAs of step s.  -DIHG_NO_PIN: the scheduler's order (A/B).
+#ifdef IHG_NO_PIN
+#define IHG_PIN_ORDER()
+#else
+#define IHG_PIN_ORDER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 __device__ __forceinline__ void role_priority(bool service) {
     if (service) {
         if (IHG_SERVICE_PRIO) __builtin_amdgcn_s_setprio(IHG_SERVICE_PRIO);
@@ -467,36 +476,39 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     const int arow = lane & 15, kq = lane >> 4;
     for (int k = 0; k < n_phases; ++k) {
         if (k < n_my && blk < NBLK) {
-            v4f acc[2][CT];
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
             const unsigned char* pbase = &planes[k & 1][0][0][0];
+            // row tile after row tile (one set of CT accumulator tiles live), the fragments of step s + 1 requested in front of the MFMAs of step s
             auto fragment = [&](int step, v8s (&a)[3]) {
-                const int kb = step >> 1, rt = step & 1;
+                const int rt = step / KB, kb = step % KB;
                 const unsigned char* src = pbase + (16 * rt + arow) * RB + (((4 * kb + kq) ^ (arow & SWZ)) << 4);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * RB));
             };
             v8s a[3], an[3];
+            v4f acc[CT];
             fragment(0, a);
 #pragma unroll
             for (int step = 0; step < 2 * KB; ++step) {
-                const int kb = step >> 1, rt = step & 1;
+                const int rt = step / KB, kb = step % KB;
+                if (kb == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[ct] = v4f{0.f, 0.f, 0.f, 0.f};
+                }
                 if (step + 1 < 2 * KB) fragment(step + 1, an);
+                IHG_PIN_ORDER();                                         // keep the next step's reads IN FRONT of this step's MFMAs
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][ct][kTermB[term]], a[kTermA[term]], acc[rt][ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][ct][kTermB[term]], a[kTermA[term]], acc[ct], 0, 0, 0);
+                IHG_PIN_ORDER();
 #pragma unroll
                 for (int p = 0; p < 3; ++p) a[p] = an[p];
+                if (kb == KB - 1) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) *reinterpret_cast<v4f*>(&dzimg[k & 1][blk][16 * rt + arow][16 * ct + 4 * kq]) = acc[ct];
+                }
             }
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) *reinterpret_cast<v4f*>(&dzimg[k & 1][blk][16 * rt + arow][16 * ct + 4 * kq]) = acc[rt][ct];
         }
         __syncthreads();
     }
@@ -744,9 +756,22 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
 #pragma unroll
                 for (int x = 0; x < ZX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + 32 * x);
             }
+#ifdef IHG_ABL_NO_MEMBER_LOADS
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int x = 0; x < ZX; ++x) hm[x][m] = v4f{1.f * k, 2.f, 3.f, 4.f};
+#endif
         };
         // what the products are added to: the three first-order rows (summed on arrival order u, q, i) or the row the other pass left in `out`
         auto load_first = [&](int k, v4f (&pr)[ZX][ACC ? 1 : 3]) {
+#ifdef IHG_ABL_NO_FIRST_LOADS
+#pragma unroll
+            for (int x = 0; x < ZX; ++x)
+#pragma unroll
+                for (int m = 0; m < (ACC ? 1 : 3); ++m) pr[x][m] = v4f{1.f * k, 2.f, 3.f, 4.f};
+            return;
+#endif
             if (ACC) {
                 const int64_t e = std::min<int64_t>((t0 + k) * TE + row, n_edges - 1);
                 const float* op = out + e * ld_out + 4 * o;
@@ -772,12 +797,21 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
                     const int b = B0 + b2;
                     const v4f z = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
                     unsigned w0[3], w1[3];
+#ifdef IHG_ABL_NO_SPLIT
+                    w0[0] = w0[1] = w0[2] = __float_as_uint(z[0] + z[1]);
+                    w1[0] = w1[1] = w1[2] = __float_as_uint(z[2] + z[3]);
+#else
                     split_pair(z[0], z[1], w0);
                     split_pair(z[2], z[3], w1);
+#endif
                     // columns b2 D + 32 x + 4 o ..: chunk 16 b2 + 4 x + (o >> 1), half o & 1
                     const int off = row * ZRB + (((16 * b2 + 4 * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
+#ifdef IHG_ABL_NO_IMAGE_WRITES
+                    asm volatile("" ::"v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(off));
+#else
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + pl * ZPL + off) = v2u{w0[pl], w1[pl]};
+#endif
                 }
             }
         };
@@ -788,7 +822,11 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
             for (int x = 0; x < ZX; ++x) {
                 const v4f sum = *reinterpret_cast<const v4f*>(&pp[row][4 * o + 32 * x]);
                 const v4f first = ACC ? pr[x][0] : (pr[x][0] + pr[x][ACC ? 0 : 1]) + pr[x][ACC ? 0 : 2];
+#ifdef IHG_ABL_NO_STORES
+                asm volatile("" ::"v"(first + sum));
+#else
                 if (e < n_edges) store_stream4(out + e * ld_out + 4 * o + 32 * x, first + sum);
+#endif
             }
         };
         if (st < 3 * TE) {
@@ -810,7 +848,9 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
             load_members(k + 2, fill);                                   // unconditional (past the end: whatever rows the ring slot names, dropped)
             if (k >= 1) load_first(k - 1, pr);
             if (k + 4 < n_my && st < 3 * TE) id_carry = fetch_id(k + 4);
+#ifndef IHG_ABL_NO_SERVICE_SPLIT
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
+#endif
             // delivery of this phase's requests, THEN the store (the memory counter is in order)
             asm volatile("" : "+v"(fill[ZX - 1][0]), "+v"(fill[ZX - 1][1]), "+v"(fill[ZX - 1][2]));
             asm volatile("" : "+v"(pr[ZX - 1][0]));
@@ -842,24 +882,43 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
     for (int k = 0; k <= n_my; ++k) {
         if (k < n_my) {
             const unsigned char* zp = &zplanes[k & 1][0][0][0];
+            // the fragments of step s + 1 are requested before the MFMAs of step s (left to the compiler, with the weights holding 192
+            // registers, every read is issued right in front of its first use and its LDS latency is exposed sixteen times per tile)
+            auto fragment = [&](int step, v8s (&a)[3]) {
+                const int rt = step / KB, kb = step % KB;
+                const unsigned char* src = zp + (16 * rt + arow) * ZRB + (((4 * kb + kq) ^ arow) << 4);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
-                const unsigned char* rp = zp + (16 * rt + arow) * ZRB;
+                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const v8s*>(src + pl * ZPL);
+            };
+            v4f acc[2][2];
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    v8s zf[3];
+            for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) zf[pl] = *reinterpret_cast<const v8s*>(rp + pl * ZPL + ((((4 * kb + kq)) ^ arow) << 4));
+                for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
+            v8s a[3], an[3];
+            fragment(0, a);
 #pragma unroll
-                    for (int term = 0; term < 6; ++term)
+            for (int step = 0; step < 2 * KB; ++step) {
+                const int rt = step / KB, kb = step % KB;
+                if (step + 1 < 2 * KB) fragment(step + 1, an);
+                IHG_PIN_ORDER();                                         // (the scheduler would sink the reads to their first use)
+#ifdef IHG_ABL_NO_MFMA
+                acc[rt][0] += __builtin_bit_cast(v4f, a[0]) + __builtin_bit_cast(v4f, a[1]) + __builtin_bit_cast(v4f, a[2]);
+#else
 #pragma unroll
-                        for (int jt = 0; jt < 2; ++jt)
-                            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[jt][kb][kTermB[term]], zf[kTermA[term]], acc[jt], 0, 0, 0);
-                }
+                for (int term = 0; term < 6; ++term)
 #pragma unroll
-                for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[k & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[jt];
+                    for (int jt = 0; jt < 2; ++jt)
+                        acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[jt][kb][kTermB[term]], a[kTermA[term]], acc[rt][jt], 0, 0, 0);
+#endif
+                IHG_PIN_ORDER();
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = an[pl];
             }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[k & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
         }
         __syncthreads();
     }

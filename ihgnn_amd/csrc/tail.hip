@@ -217,8 +217,13 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
     p = p - step_size * (m / denom);
 }
 
+// `scalars` != nullptr: {step_size, bias2_sqrt} are read from device memory at launch time (a captured launch replays with the step's own values)
 __global__ __launch_bounds__(kBlockThreads) void adam_kernel(AdamTable tab, float beta1, float beta2, float eps, float weight_decay, float step_size,
-                                                             float bias2_sqrt) {
+                                                             float bias2_sqrt, const float* __restrict__ scalars) {
+    if (scalars != nullptr) {
+        step_size = scalars[0];
+        bias2_sqrt = scalars[1];
+    }
     const int64_t total_chunks = tab.chunk_begin[tab.n_tensors];
     for (int64_t chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
         int t = 0;
@@ -386,13 +391,8 @@ int ihg_batch_rows_add(const float* src, int64_t ld_src, int32_t width, const in
     return check_launch("ihg_batch_rows_add");
 }
 
-int ihg_adam_step(const ihg_adam_tensor* tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
-                  int64_t step, ihg_stream_t stream) {
-    if (n_tensors < 0 || (n_tensors > 0 && tensors == nullptr) || step < 1) return fail(IHG_ERR_INVALID, "ihg_adam_step: bad argument");
-    const double bias1 = 1.0 - std::pow(static_cast<double>(beta1), static_cast<double>(step));
-    const double bias2 = 1.0 - std::pow(static_cast<double>(beta2), static_cast<double>(step));
-    const float step_size = static_cast<float>(static_cast<double>(lr) / bias1);
-    const float bias2_sqrt = static_cast<float>(std::sqrt(bias2));
+static int adam_launch(const char* what, const ihg_adam_tensor* tensors, int32_t n_tensors, float beta1, float beta2, float eps, float weight_decay, float step_size,
+                       float bias2_sqrt, const float* scalars, ihg_stream_t stream) {
     for (int t = 0; t < n_tensors;) {                        // one launch per kAdamMaxTensors NON-EMPTY tensors; t is the only cursor
         AdamTable tab{};
         int64_t chunks = 0;
@@ -400,7 +400,7 @@ int ihg_adam_step(const ihg_adam_tensor* tensors, int32_t n_tensors, float lr, f
         for (; t < n_tensors && used < kAdamMaxTensors; ++t) {
             const ihg_adam_tensor& a = tensors[t];
             if (a.count < 0 || (a.count > 0 && (a.param == nullptr || a.grad == nullptr || a.exp_avg == nullptr || a.exp_avg_sq == nullptr)))
-                return fail(IHG_ERR_INVALID, "ihg_adam_step: tensor %d has a null pointer or a negative count", t);
+                return fail(IHG_ERR_INVALID, "%s: tensor %d has a null pointer or a negative count", what, t);
             if (a.count == 0) continue;
             tab.param[used] = a.param; tab.grad[used] = a.grad; tab.exp_avg[used] = a.exp_avg; tab.exp_avg_sq[used] = a.exp_avg_sq;
             tab.count[used] = a.count;
@@ -413,8 +413,23 @@ int ihg_adam_step(const ihg_adam_tensor* tensors, int32_t n_tensors, float lr, f
         if (used == 0) continue;
         const int grid = static_cast<int>(std::min<int64_t>(chunks, 256 * 16));
         hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), tab, beta1, beta2, eps, weight_decay,
-                           step_size, bias2_sqrt);
+                           step_size, bias2_sqrt, scalars);
     }
-    return check_launch("ihg_adam_step");
+    return check_launch(what);
+}
+
+int ihg_adam_step(const ihg_adam_tensor* tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t step, ihg_stream_t stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && tensors == nullptr) || step < 1) return fail(IHG_ERR_INVALID, "ihg_adam_step: bad argument");
+    const double bias1 = 1.0 - std::pow(static_cast<double>(beta1), static_cast<double>(step));
+    const double bias2 = 1.0 - std::pow(static_cast<double>(beta2), static_cast<double>(step));
+    return adam_launch("ihg_adam_step", tensors, n_tensors, beta1, beta2, eps, weight_decay, static_cast<float>(static_cast<double>(lr) / bias1),
+                       static_cast<float>(std::sqrt(bias2)), nullptr, stream);
+}
+
+int ihg_adam_step_device_scalars(const ihg_adam_tensor* tensors, int32_t n_tensors, float beta1, float beta2, float eps, float weight_decay,
+                                 const float* step_scalars, ihg_stream_t stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && tensors == nullptr) || step_scalars == nullptr) return fail(IHG_ERR_INVALID, "ihg_adam_step_device_scalars: bad argument");
+    return adam_launch("ihg_adam_step_device_scalars", tensors, n_tensors, beta1, beta2, eps, weight_decay, 0.f, 1.f, step_scalars, stream);
 }
 }  // extern "C"

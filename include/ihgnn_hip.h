@@ -352,6 +352,11 @@ typedef struct ihg_adam_tensor {
 } ihg_adam_tensor;
 int ihg_adam_step(const ihg_adam_tensor* tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, ihg_stream_t stream);
+/* The same update with the two step-dependent scalars read from DEVICE memory when the kernel runs: step_scalars[0] = lr / (1 - beta1^t),
+ * step_scalars[1] = sqrt(1 - beta2^t).  For a launch recorded in a hipGraph (ihgnn_amd/captured_step.py): the host refreshes the two floats
+ * before every replay, the recorded launch stays the same. */
+int ihg_adam_step_device_scalars(const ihg_adam_tensor* tensors, int32_t n_tensors, float beta1, float beta2, float eps, float weight_decay,
+                                 const float* step_scalars, ihg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DEVICE: negative sampling of a training batch.  Replaces `random.sample(range(item_count), k)` per positive in

@@ -1240,6 +1240,14 @@ def test_driver_end_to_end(tmp_path, monkeypatch):
     resumed = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '1', '--est', '1',
                            '--cp', 'latest'])
     assert [e for e, _ in resumed.iter_epoch_test()] == [4]            # resumes at epoch_count + 1 (Main.py:207-208)
+    # the same run with the training step replayed from a recording (full batches: replays; the epoch's short last batch: eager)
+    import random
+    random.seed(11); torch.manual_seed(11)
+    eager = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '2', '--est', '2', '--etf', '1'])
+    random.seed(11); torch.manual_seed(11)
+    recorded = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '2', '--est', '2', '--etf', '1', '--record_step'])
+    (_, m_e), (_, m_r) = list(eager.iter_epoch_test())[-1], list(recorded.iter_epoch_test())[-1]
+    assert abs(m_e.NDCG_at10 - m_r.NDCG_at10) <= 2e-3 and abs(m_e.HitRatio_at10 - m_r.HitRatio_at10) <= 2e-3
 
 
 @pytest.mark.parametrize('tag,d,mode', [('tiny_uqi', 8, 'uqi'), ('small_uqi', 64, 'uqi'), ('small_ui', 32, 'ui'), ('tiny_qi', 8, 'qi')])
@@ -1565,6 +1573,43 @@ def test_last_layer_backward_skips_the_zero_rows_of_its_cotangent(monkeypatch):
     dense[rows.long()] = 1.0
     want = ops.node_segment_sum_raw(dense, lay.hop2_csr, lay.inv_deg, None, 0, self_weight=lay.self_weight)
     assert torch.equal(x.grad, want)
+
+
+def test_recorded_training_step_equals_the_eager_step():
+    """``CapturedTrainingStep`` (forward + backward + Adam recorded as one hipGraph, the Adam scalars read from device memory) replayed four
+    times - with a learning-rate change in between - against the same four eager steps: same losses, same parameters, same Adam state."""
+    from ihgnn_amd import synth
+    from ihgnn_amd.Dataset import GraphDataset
+    from ihgnn_amd.captured_step import CapturedTrainingStep
+    from ihgnn_amd.optim import Adam
+    w = synth.draw(300, 40, 200, 50, 4000, seed=21)
+    ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets, w.triples, device=dev())
+    batches = list(ds.sample_batches(100, 4, seed=5))
+
+    def run(recorded):
+        torch.manual_seed(7)
+        m = build_model(ds, 'ihgnn', 2, 3, 64)
+        m.batch_rows_only_last_layer = False
+        opt = Adam(m.parameters(), 1e-3, weight_decay=0)
+        step = CapturedTrainingStep(m, opt, batches[0][0].shape[0], warmup_batch=batches[0]) if recorded else None
+        losses = []
+        for k, (u, q, i, y) in enumerate(batches):
+            if k == 2:
+                opt.param_groups[0]['lr'] = 5e-4
+            if recorded:
+                losses.append(step.step(u, q, i, y).item())
+            else:
+                loss = m.bce_loss(u, q, i, y)
+                loss.backward(); opt.step(); opt.zero_grad()
+                losses.append(loss.item())
+        return losses, {k: v.clone() for k, v in m.state_dict().items()}, opt
+
+    l0, p0, o0 = run(False)
+    l1, p1, o1 = run(True)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    for k in p0:
+        assert rel(p1[k], p0[k]) <= 1e-6, k
+    assert o1.next_step() == o0.next_step() == 5
 
 
 # ---------------------------------------------------------------------------------------------
