@@ -691,7 +691,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Forward at d = 128 in TWO PASSES over the contraction index (the default; IHG_FWD_KPASS=0 keeps the column-half kernel above).
+// Forward at d = 128 (and, further down, d = 256) in PASSES over the contraction index (the default; IHG_FWD_KPASS=0 keeps the column-half kernel
+// above / the chunked kernel below).
 // The column-half form forms and splits every product twice (once per half); here a workgroup owns ALL 128 output columns and HALF of
 // the contraction index - pass A: blocks uq, qi (+ the first-order rows), pass B: blocks iu, uqi, added onto pass A's result, which
 // goes through `out` (one extra write and read of [E, d]: 2.2 GB that an issue-bound kernel moves beside its MFMAs) - so every product
@@ -703,47 +704,60 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
 // A workgroup takes a CONTIGUOUS tile range (hyperedges are numbered by user).
 // wkp[pass][m][jt < 2][kb < 8][plane][lane][8]: element i = plane of W[32 m + 16 jt + (lane & 15)][(3 + 2 pass + (kb >> 2)) d + 32 (kb & 3) + 8 (lane >> 4) + i]
 // ------------------------------------------------------------------------------------------------
-constexpr int kKpTE = 32;
-constexpr int kKpPassV4 = 4 * 2 * 8 * 3 * kWave;                        // v4u of one pass's planes
+// d = 256 (same kernel, template D): a workgroup owns a column HALF (128 output columns, so both halves of a tile range - adjacent
+// workgroups on one XCD - form the pass's products) and a pass is ONE product block (256 values of the contraction index: the same
+// 192 weight registers per matrix wave, the same 512-byte image rows); tiles of 16 hyperedges (a service thread = one hyperedge row x 16
+// of its 256 member columns); four passes at order 3.  Unlike the chunked kernel below nothing streams the weight planes from L2
+// (there: 768 KB per 32-hyperedge tile and workgroup, as much time on the CU's vector-memory path as the tile's MFMAs take).
+// wkp, d = 256: [pass = block][half][m][jt < 2][kb < 8][plane][lane][8]: element i = plane of W[128 half + 32 m + 16 jt + (lane & 15)][(3 + pass) d + 32 kb + 8 (lane >> 4) + i]
+constexpr int kKpPassV4 = 4 * 2 * 8 * 3 * kWave;                        // v4u of one (pass, column half)'s planes
 
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_fwd_kpass_kernel(const float* __restrict__ w, int64_t ld_w, int nblk, v4u* __restrict__ wkp) {
-    constexpr int D = 128;
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_fwd_kpass_kernel(const float* __restrict__ w, int64_t ld_w, int d, int nblk, v4u* __restrict__ wkp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * 4 * 2 * 8 * kWave) return;
-    const int lane = idx & 63, kb = (idx >> 6) & 7, jt = (idx >> 9) & 1, m = (idx >> 10) & 3, pass = idx >> 12;
-    const int b = 2 * pass + (kb >> 2);
-    const float* src = w + static_cast<int64_t>(32 * m + 16 * jt + (lane & 15)) * ld_w + (3 + b) * D + 32 * (kb & 3) + 8 * (lane >> 4);
+    const int halves = d / 128, passes = d == 128 ? 2 : 4;
+    if (idx >= passes * halves * 4 * 2 * 8 * kWave) return;
+    const int lane = idx & 63, kb = (idx >> 6) & 7, jt = (idx >> 9) & 1, m = (idx >> 10) & 3, half = (idx >> 12) & (halves - 1), pass = idx >> (d == 128 ? 12 : 13);
+    const int b = d == 128 ? 2 * pass + (kb >> 2) : pass;
+    const int k0 = d == 128 ? 32 * (kb & 3) : 32 * kb;
+    const float* src = w + static_cast<int64_t>(128 * half + 32 * m + 16 * jt + (lane & 15)) * ld_w + (3 + b) * d + k0 + 8 * (lane >> 4);
     const Planes pl = b < nblk ? split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]})
                                : split8(v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
     for (int p = 0; p < 3; ++p) wkp[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
 }
 
-// NB: product blocks of this pass (2, or 1 for the second pass of order 2); B0: the pass's first block (0: uq, qi; 2: iu, uqi);
-// ACC: `out` already holds the other pass's result (and the first-order rows) - add onto it instead of gathering the first-order rows
-template <int NB, int B0, bool ACC>
+// D: feature width (128: all columns in one workgroup, tiles of 32; 256: column halves, tiles of 16);
+// NB: product blocks of this pass (d = 128: 2, or 1 for the second pass of order 2; d = 256: 1); B0: the pass's first block;
+// ACC: `out` already holds the earlier passes' result (and the first-order rows) - add onto it instead of gathering the first-order rows
+template <int D, int NB, int B0, bool ACC>
 __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p,
                                                                                  const int32_t* __restrict__ i3, const v4u* __restrict__ wkp, float* __restrict__ out,
                                                                                  int64_t ld_out, int64_t n_edges) {
-    constexpr int D = 128, TE = kKpTE, KB = 4 * NB, ZRB = 2 * NB * D, ZPL = TE * ZRB, PS = D + 4, ZX = 4;
+    static_assert((D == 128 && (NB == 1 || NB == 2)) || (D == 256 && NB == 1), "shapes");
+    constexpr int HALVES = D / 128, TE = D == 128 ? 32 : 16, RT = TE / 16, TPR = 256 / TE, CSTR = 4 * TPR;      // threads per hyperedge row; stride of a thread's 4-column groups
+    constexpr int KB = NB * D / 32, ZRB = 2 * NB * D, ZPL = TE * ZRB, PS = 128 + 4, ZX = D / (4 * TPR), OX = 128 / CSTR;
     __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
     __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
     __shared__ int ids[8][3 * TE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int half = HALVES == 1 ? 0 : (bid >> 3) & 1;
+    const int range = HALVES == 1 ? bid : (bid & 7) + 8 * (bid >> 4), n_ranges = gridDim.x / HALVES;
     const int64_t n_tiles = (n_edges + TE - 1) / TE;
-    const int64_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * per;
+    const int64_t per = (n_tiles + n_ranges - 1) / n_ranges;
+    const int64_t t0 = static_cast<int64_t>(range) * per;
     const int n_my = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(per, n_tiles - t0)));
     if (n_my == 0) return;
+    const int hoff = 128 * half;                                         // first output column of this workgroup
 
     role_priority(wave >= 4);
     if (wave >= 4) {
-        // ---------------- service waves: thread -> hyperedge row, columns 4 o + 32 x .. (x < 4)
-        const int st = tid - 256, row = st >> 3, o = st & 7;
+        // ---------------- service waves: thread -> hyperedge row, member columns 4 o + CSTR x .. (x < ZX), output columns hoff + 4 o + CSTR x .. (x < OX)
+        const int st = tid - 256, row = st / TPR, o = st % TPR;
         const int64_t last_pos = n_edges * 3 - 1;
         const uint32_t ldh = static_cast<uint32_t>(ld_h), ldp = static_cast<uint32_t>(ld_p);
-        auto fetch_id = [&](int k) {                                     // (st < 96; the tile exists) - scalar tile base, one vector min
+        auto fetch_id = [&](int k) {                                     // (st < 3 TE; the tile exists) - scalar tile base, one vector min
             const int64_t first = (t0 + k) * (3 * TE);
             const int lim = static_cast<int>(std::min<int64_t>(last_pos - first, 3 * TE - 1));
             return (i3 + first)[std::min(st, lim)];
@@ -754,7 +768,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
             for (int m = 0; m < 3; ++m) {
                 const float* hp = row_at(h, idk[m], ldh) + 4 * o;
 #pragma unroll
-                for (int x = 0; x < ZX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + 32 * x);
+                for (int x = 0; x < ZX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + CSTR * x);
             }
 #ifdef IHG_ABL_NO_MEMBER_LOADS
 #pragma unroll
@@ -763,27 +777,27 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
                 for (int x = 0; x < ZX; ++x) hm[x][m] = v4f{1.f * k, 2.f, 3.f, 4.f};
 #endif
         };
-        // what the products are added to: the three first-order rows (summed on arrival order u, q, i) or the row the other pass left in `out`
-        auto load_first = [&](int k, v4f (&pr)[ZX][ACC ? 1 : 3]) {
+        // what the products are added to: the three first-order rows (summed in the order u, q, i) or the row the earlier passes left in `out`
+        auto load_first = [&](int k, v4f (&pr)[OX][ACC ? 1 : 3]) {
 #ifdef IHG_ABL_NO_FIRST_LOADS
 #pragma unroll
-            for (int x = 0; x < ZX; ++x)
+            for (int x = 0; x < OX; ++x)
 #pragma unroll
                 for (int m = 0; m < (ACC ? 1 : 3); ++m) pr[x][m] = v4f{1.f * k, 2.f, 3.f, 4.f};
             return;
 #endif
             if (ACC) {
                 const int64_t e = std::min<int64_t>((t0 + k) * TE + row, n_edges - 1);
-                const float* op = out + e * ld_out + 4 * o;
+                const float* op = out + e * ld_out + hoff + 4 * o;
 #pragma unroll
-                for (int x = 0; x < ZX; ++x) pr[x][0] = *reinterpret_cast<const v4f*>(op + 32 * x);
+                for (int x = 0; x < OX; ++x) pr[x][0] = *reinterpret_cast<const v4f*>(op + CSTR * x);
             } else {
                 const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    const float* pp = row_at(p, idk[m], ldp) + 4 * o;
+                    const float* pp = row_at(p, idk[m], ldp) + hoff + 4 * o;
 #pragma unroll
-                    for (int x = 0; x < ZX; ++x) pr[x][ACC ? 0 : m] = *reinterpret_cast<const v4f*>(pp + 32 * x);
+                    for (int x = 0; x < OX; ++x) pr[x][ACC ? 0 : m] = *reinterpret_cast<const v4f*>(pp + CSTR * x);
                 }
             }
         };
@@ -804,8 +818,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
                     split_pair(z[0], z[1], w0);
                     split_pair(z[2], z[3], w1);
 #endif
-                    // columns b2 D + 32 x + 4 o ..: chunk 16 b2 + 4 x + (o >> 1), half o & 1
-                    const int off = row * ZRB + (((16 * b2 + 4 * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
+                    // columns b2 D + CSTR x + 4 o ..: chunk b2 D / 8 + (CSTR / 8) x + (o >> 1), half o & 1
+                    const int off = row * ZRB + ((((D / 8) * b2 + (CSTR / 8) * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
 #ifdef IHG_ABL_NO_IMAGE_WRITES
                     asm volatile("" ::"v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(off));
 #else
@@ -815,17 +829,17 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
                 }
             }
         };
-        auto epilogue = [&](int k, const v4f (&pr)[ZX][ACC ? 1 : 3]) {   // tile k
+        auto epilogue = [&](int k, const v4f (&pr)[OX][ACC ? 1 : 3]) {   // tile k
             const int64_t e = (t0 + k) * TE + row;
             const float (*pp)[PS] = part[k & 1];
 #pragma unroll
-            for (int x = 0; x < ZX; ++x) {
-                const v4f sum = *reinterpret_cast<const v4f*>(&pp[row][4 * o + 32 * x]);
+            for (int x = 0; x < OX; ++x) {
+                const v4f sum = *reinterpret_cast<const v4f*>(&pp[row][4 * o + CSTR * x]);
                 const v4f first = ACC ? pr[x][0] : (pr[x][0] + pr[x][ACC ? 0 : 1]) + pr[x][ACC ? 0 : 2];
 #ifdef IHG_ABL_NO_STORES
                 asm volatile("" ::"v"(first + sum));
 #else
-                if (e < n_edges) store_stream4(out + e * ld_out + 4 * o + 32 * x, first + sum);
+                if (e < n_edges) store_stream4(out + e * ld_out + hoff + 4 * o + CSTR * x, first + sum);
 #endif
             }
         };
@@ -835,7 +849,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
             for (int k = 1; k < 8; ++k) ids[k][st] = k < 4 && k < n_my ? fetch_id(k) : 0;       // (slots of tiles past the end: row 0, requested and dropped)
         }
         __syncthreads();
-        v4f hm0[ZX][3], hm1[ZX][3], pr[ZX][ACC ? 1 : 3];                    // member values of tile m in hm<m & 1>
+        v4f hm0[ZX][3], hm1[ZX][3], pr[OX][ACC ? 1 : 3];                    // member values of tile m in hm<m & 1>
         load_members(0, hm0);
         if (n_my > 1) load_members(1, hm1);
         split_tile(hm0, 0);
@@ -853,7 +867,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
 #endif
             // delivery of this phase's requests, THEN the store (the memory counter is in order)
             asm volatile("" : "+v"(fill[ZX - 1][0]), "+v"(fill[ZX - 1][1]), "+v"(fill[ZX - 1][2]));
-            asm volatile("" : "+v"(pr[ZX - 1][0]));
+            asm volatile("" : "+v"(pr[OX - 1][0]));
             if (k >= 1) epilogue(k - 1, pr);
             __syncthreads();
         };
@@ -867,7 +881,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
         return;
     }
 
-    // ---------------- matrix waves: wave m = output columns 32 m .. 32 m + 31, the pass's whole contraction index
+    // ---------------- matrix waves: wave m = output columns hoff + 32 m .. + 31, the pass's whole contraction index
     v8s wreg[2][KB][3];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
@@ -875,32 +889,31 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                wreg[jt][kb][pl] = __builtin_bit_cast(v8s, wkp[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 3 + pl) * kWave + lane]);
+                wreg[jt][kb][pl] = __builtin_bit_cast(v8s, wkp[(static_cast<int64_t>(((half * 4 + wave) * 2 + jt) * 8 + kb) * 3 + pl) * kWave + lane]);
     __syncthreads();
     __syncthreads();
     const int arow = lane & 15, kq = lane >> 4;
     for (int k = 0; k <= n_my; ++k) {
         if (k < n_my) {
             const unsigned char* zp = &zplanes[k & 1][0][0][0];
-            // the fragments of step s + 1 are requested before the MFMAs of step s (left to the compiler, with the weights holding 192
-            // registers, every read is issued right in front of its first use and its LDS latency is exposed sixteen times per tile)
+            // the fragments of step s + 1 are requested before the MFMAs of step s (IHG_PIN_ORDER)
             auto fragment = [&](int step, v8s (&a)[3]) {
                 const int rt = step / KB, kb = step % KB;
                 const unsigned char* src = zp + (16 * rt + arow) * ZRB + (((4 * kb + kq) ^ arow) << 4);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const v8s*>(src + pl * ZPL);
             };
-            v4f acc[2][2];
+            v4f acc[RT][2];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
             v8s a[3], an[3];
             fragment(0, a);
 #pragma unroll
-            for (int step = 0; step < 2 * KB; ++step) {
+            for (int step = 0; step < RT * KB; ++step) {
                 const int rt = step / KB, kb = step % KB;
-                if (step + 1 < 2 * KB) fragment(step + 1, an);
+                if (step + 1 < RT * KB) fragment(step + 1, an);
                 IHG_PIN_ORDER();                                         // (the scheduler would sink the reads to their first use)
 #ifdef IHG_ABL_NO_MFMA
                 acc[rt][0] += __builtin_bit_cast(v4f, a[0]) + __builtin_bit_cast(v4f, a[1]) + __builtin_bit_cast(v4f, a[2]);
@@ -916,7 +929,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
                 for (int pl = 0; pl < 3; ++pl) a[pl] = an[pl];
             }
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[k & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
         }
@@ -1715,7 +1728,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 // floats of workspace for the weight planes of one direction: laid out for four blocks at either order
 int64_t split_plane_floats(int dim, int order) { return (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) ? (3LL * 4 * dim * dim) / 2 : 0; }
 
-static bool fwd_kpass_enabled() {                                        // IHG_FWD_KPASS=0: the column-half forward at d = 128 (A/B, tests)
+static bool fwd_kpass_enabled() {                                        // IHG_FWD_KPASS=0: the column-half forward at d = 128, the chunked one at d = 256 (A/B, tests)
     const char* v = std::getenv("IHG_FWD_KPASS");
     return v == nullptr || std::strcmp(v, "0") != 0;
 }
@@ -1844,14 +1857,23 @@ void launch_fwd_split(int dim, int order, const float* h, int64_t ld_h, const fl
     // d = 256: chunked (the eight-part column split of the other form would repeat the product work eight times); d = 64 / 128: weights
     // resident.  At d = 128 the chunked form measured 2,430 us against 2,000: with 32-hyperedge tiles its weight stream (393 KB per tile)
     // alone fills the CU's L2 port for 0.8 ms.
-    if (dim == 128 && fwd_kpass_enabled()) {
-        hipLaunchKernelGGL(pack_planes_fwd_kpass_kernel, dim3((2 * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w,
-                           order == 3 ? 4 : 3, wsp);
-        hipLaunchKernelGGL((interact_fwd_split_kpass_kernel<2, 0, false>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
-        if (order == 3)
-            hipLaunchKernelGGL((interact_fwd_split_kpass_kernel<2, 2, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp + kKpPassV4, out, ld_out, n_edges);
-        else
-            hipLaunchKernelGGL((interact_fwd_split_kpass_kernel<1, 2, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp + kKpPassV4, out, ld_out, n_edges);
+    if ((dim == 128 || (dim == 256 && order == 3)) && fwd_kpass_enabled()) {
+        const int passes = dim == 128 ? 2 : 4, halves = dim / 128;
+        hipLaunchKernelGGL(pack_planes_fwd_kpass_kernel, dim3((passes * halves * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w,
+                           dim, order == 3 ? 4 : 3, wsp);
+#define IHG_KPASS(D, NB, B0, ACC, PASS) \
+    hipLaunchKernelGGL((interact_fwd_split_kpass_kernel<D, NB, B0, ACC>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp + (PASS) * halves * kKpPassV4, out, ld_out, n_edges)
+        if (dim == 128) {
+            IHG_KPASS(128, 2, 0, false, 0);
+            if (order == 3) IHG_KPASS(128, 2, 2, true, 1);
+            else IHG_KPASS(128, 1, 2, true, 1);
+        } else {
+            IHG_KPASS(256, 1, 0, false, 0);
+            IHG_KPASS(256, 1, 1, true, 1);
+            IHG_KPASS(256, 1, 2, true, 2);
+            IHG_KPASS(256, 1, 3, true, 3);
+        }
+#undef IHG_KPASS
         return;
     }
     if (dim != 256) {

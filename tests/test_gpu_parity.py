@@ -494,15 +494,16 @@ def test_interact_fp32_mfma_kernels_stay_covered(which, monkeypatch):
         test_interact_backward_user_slot_reduced_on_chip(3, 700 * 32 + 5, 301, monkeypatch)
 
 
-@pytest.mark.parametrize('order', [3, 2])
-def test_forward_in_two_passes_equals_the_column_half_kernel(order, monkeypatch):
+@pytest.mark.parametrize('dim,order', [(128, 3), (128, 2), (256, 3)])
+def test_forward_in_two_passes_equals_the_column_half_kernel(dim, order, monkeypatch):
     """d = 128: the default forward runs in two passes over the contraction index (blocks uq, qi + first-order rows, then iu (, uqi) added onto
-    `out`; every product formed once); IHG_FWD_KPASS=0 selects the column-half kernel.  Both against the oracle - more tiles than workgroups
-    with a partial last tile, fewer tiles than workgroups, one hyperedge, a strided `out` - and against each other (same products, the four
-    block sums associated differently)."""
+    `out`; every product formed once); d = 256, order 3: four passes of one block, column halves, 16-hyperedge tiles.  IHG_FWD_KPASS=0 selects
+    the column-half kernel (d = 128) / the chunked kernel (d = 256).  Both against the oracle - more tiles than workgroups with a partial
+    last tile, fewer tiles than workgroups, one hyperedge, a strided `out` - and against each other (same products, the block sums
+    associated differently)."""
     from ihgnn_amd import _lib, ops
     from oracle import ihgnn_ref as ref
-    dim, k = 128, 6 if order == 2 else 7
+    k = 6 if order == 2 else 7
     for edges in (1, 33, 300 * 32 + 5, 70437):
         w_, lay = make_layout(301, 17, 211, edges, seed=edges + order, edge_order='user')
         gen = torch.Generator().manual_seed(edges)
