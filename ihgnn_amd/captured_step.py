@@ -36,22 +36,49 @@ class CapturedTrainingStep:
             for dst, src in zip((self.users, self.queries, self.items, self.labels), warmup_batch):
                 dst.copy_(src)
         optimizer.ensure_state()                             # exp_avg / exp_avg_sq exist before the recording (not in the graph's pool)
-        # torch's recipe for whole-step capture: a few eager iterations on a side stream (allocator warm-up), gradients released, then the
-        # recording; the gradients the recording allocates live in the graph's pool and are rewritten by every replay.  The warm-up runs
-        # forward and backward only: no parameter changes.
+        params = [p for group in optimizer.param_groups for p in group['params'] if p.requires_grad]
+        slots = []                                           # (module, attribute name, parameter) of every trainable parameter of the model
+        wanted = {id(p) for p in params}
+        for module in model.modules():
+            for name, p in list(module._parameters.items()):
+                if p is not None and id(p) in wanted:
+                    slots.append((module, name, p))
+        if {id(p) for _, _, p in slots} != wanted:
+            raise ValueError('CapturedTrainingStep: the optimizer holds parameters that are not parameters of the model')
+
+        def forward_backward():
+            # The forward runs on fresh LEAF ALIASES of the parameters (same storage, new autograd identity) and the gradients come from
+            # torch.autograd.grad.  A parameter's AccumulateGrad node belongs to the stream that first used it and stays alive as long as the
+            # caller holds ANY earlier loss; autograd then routes the parameter's gradient through that (default) stream - inside a
+            # recording on another stream that is a cross-stream dependency the capture cannot hold (it ends in a crash at capture end).
+            # Aliases made here have no history: their gradient edges are created on the recording's stream.
+            aliases = {id(p): p.detach().requires_grad_(True) for p in params}
+            try:
+                for module, name, p in slots:
+                    module._parameters[name] = aliases[id(p)]
+                loss = model.bce_loss(self.users, self.queries, self.items, self.labels)
+            finally:
+                for module, name, p in slots:
+                    module._parameters[name] = p
+            grads = torch.autograd.grad(loss, [aliases[id(p)] for p in params], allow_unused=True)
+            return loss, grads
+
+        # torch's recipe for whole-step capture: a few eager iterations on a side stream (allocator warm-up), then the recording; the
+        # gradients the recording allocates live in the graph's pool and are rewritten by every replay.  The warm-up runs forward and
+        # backward only: no parameter changes.
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                optimizer.zero_grad(set_to_none=True)
-                model.bce_loss(self.users, self.queries, self.items, self.labels).backward()
+                forward_backward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = model.bce_loss(self.users, self.queries, self.items, self.labels)
-            self.loss.backward()
+            self.loss, grads = forward_backward()
+            for p, g in zip(params, grads):
+                p.grad = g if g is not None else torch.zeros_like(p)
             optimizer.launch_with_device_scalars(self.scalars)
 
     TABLE_STEPS = 2048

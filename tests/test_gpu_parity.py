@@ -1592,6 +1592,11 @@ def test_recorded_training_step_equals_the_eager_step():
         m = build_model(ds, 'ihgnn', 2, 3, 64)
         m.batch_rows_only_last_layer = False
         opt = Adam(m.parameters(), 1e-3, weight_decay=0)
+        held = None
+        if recorded:                                        # a caller that still holds an earlier loss (its graph keeps the parameters' AccumulateGrad nodes alive)
+            held = m.bce_loss(*batches[0])
+            held.backward()
+            opt.zero_grad(set_to_none=True)
         step = CapturedTrainingStep(m, opt, batches[0][0].shape[0], warmup_batch=batches[0]) if recorded else None
         losses = []
         for k, (u, q, i, y) in enumerate(batches):

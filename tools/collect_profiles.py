@@ -13,6 +13,17 @@ import subprocess
 import sys
 
 
+def head_commit():
+    """Short hash of the commit the profiled tree belongs to (the collection runs in the repository, right after the GPU call)."""
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        rev = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=here, capture_output=True, text=True, check=True).stdout.strip()
+        dirty = subprocess.run(['git', 'status', '--porcelain', '--', 'ihgnn_amd', 'bench.py', 'tools/kbench.py'], cwd=here, capture_output=True, text=True).stdout.strip()
+        return rev + ('+uncommitted' if dirty else '')
+    except Exception:
+        return 'unrecorded'
+
+
 def main():
     src, dst, prefix = sys.argv[1:4]
     config = sys.argv[sys.argv.index('--config') + 1] if '--config' in sys.argv else 'C3'
@@ -32,7 +43,7 @@ def main():
                            '--no-extras --no-kernel-events   (one pass per counter, in situ: every kernel of the training step)',
                    notes='KiB counters; FETCH_SIZE doubled (gfx950 counts 128-B requests of wide reads as 64 B); both counters sit at the L2 <-> fabric '
                          'boundary, so Infinity-Cache hits are included: hbm_bytes_per_launch is L2-miss traffic, an upper bound of the HBM bytes',
-                   workload=config, dim=bench['config']['dim'], edges=bench['config']['edges'], kernels=table)
+                   workload=config, dim=bench['config']['dim'], edges=bench['config']['edges'], commit=head_commit(), kernels=table)
         for key, v in table.items():
             if key.startswith('edge_gather_sum_kernel'):
                 out['edge_gather_sum'] = dict(hbm_bytes_per_launch=v['hbm_bytes_per_launch'], avg_us_under_pmc=v['avg_us_under_pmc'])
@@ -61,7 +72,7 @@ def main():
             if 'interact' in name:
                 agg[name][r['Counter_Name']].append((float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
         out = dict(command='rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 tools/kbench.py --config '
-                           f'{config} --rounds 3 --ops layer0', notes='GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs', kernels={})
+                           f'{config} --rounds 3 --ops layer0', notes='GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs', commit=head_commit(), kernels={})
         for name, c in agg.items():
             busy = sum(v for v, _ in c['SQ_VALU_MFMA_BUSY_CYCLES']) / len(c['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024
             gui = sum(v for v, _ in c['GRBM_GUI_ACTIVE']) / len(c['GRBM_GUI_ACTIVE']) / 8

@@ -54,6 +54,9 @@ def main():
             hr = x.detach().requires_grad_(True)
             pr = x.detach().requires_grad_(True)
             ops.interact_to_nodes(hr, pr, wa, lay, args.order, lay.inv_deg).backward(x)
+        if 'layer' in want:                                               # the whole interactive layer as one autograd node (what IHGNNLayer runs)
+            hr = x.detach().requires_grad_(True)
+            ops.interact_layer(hr, wa, b, lay, args.order, lay.inv_deg).backward(x)
         if 'ifwd' in want:                                                # the interactive step's forward alone
             with torch.no_grad():
                 ops.interact(x, x, wa, lay, args.order)
