@@ -59,6 +59,25 @@ def main():
                 if key.startswith('node_segment_sum_kernel'):
                     out['k7.edges_to_nodes'] = entry
             out['kernels_alone'] = alone
+        # K7's launches IN SITU by role: the seven long launches of a training step come in a fixed order (tools/k7_roles_from_trace.py); the
+        # counter passes are cut into steps at the Adam launches and the first long K7 launch of a step is the hyperedge -> node pass of the
+        # interactive layer - the kernel bench.py's `roofline` brackets inside the timed region
+        def k7_in_situ(directory, counter):
+            path = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)[0]
+            rows = sorted((r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter), key=lambda r: int(r['Start_Timestamp']))
+            adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+            picked = []
+            for a, b in zip(adam, adam[1:]):
+                k7 = [r for r in rows[a + 1:b + 1] if 'node_segment_sum_kernel' in r['Kernel_Name'] and int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 100_000]
+                if len(k7) == 7:
+                    picked.append((float(k7[0]['Counter_Value']), (int(k7[0]['End_Timestamp']) - int(k7[0]['Start_Timestamp'])) / 1e3))
+            return picked
+        f_rows, w_rows = k7_in_situ(fetch, 'FETCH_SIZE'), k7_in_situ(write, 'WRITE_SIZE')
+        if f_rows and w_rows:
+            fk, wk = sum(v for v, _ in f_rows) / len(f_rows), sum(v for v, _ in w_rows) / len(w_rows)
+            us = sum(t for _, t in f_rows + w_rows) / len(f_rows + w_rows)
+            out['k7.edges_to_nodes'] = dict(hbm_bytes_per_launch=int(2 * fk * 1024 + wk * 1024), avg_us_under_pmc=round(us, 1), launches=len(f_rows),
+                                            source='in situ: the first long K7 launch of each training step of the counter passes over bench.py (FETCH_SIZE doubled + WRITE_SIZE)')
         json.dump(out, open(os.path.join(dst, f'pmc_traffic_{config}.json'), 'w'), indent=1)
         for d, c in ((fetch, 'fetch_size'), (write, 'write_size')):
             f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
