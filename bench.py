@@ -59,10 +59,10 @@ MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md); the
 
 def split_arithmetic(dim, order, direction='any'):
     """True when the library runs this shape's contractions through three exact bf16 terms per operand (csrc/split_arith.hip):
-    orders 2 and 3 at d = 64 / 128 / 256 (the d = 256 forward: order 3 only)."""
+    orders 2 and 3 at d = 64 / 128 / 256 (the d = 256 order-2 forward: on the pass kernel only, i.e. not under IHG_FWD_KPASS=0)."""
     if order not in (2, 3) or os.environ.get('IHG_INTERACT_ARITH') == 'f32' or dim not in (64, 128, 256):
         return False
-    return not (direction == 'forward' and dim == 256 and order == 2)
+    return not (direction == 'forward' and dim == 256 and order == 2 and os.environ.get('IHG_FWD_KPASS') == '0')
 
 
 def parse():

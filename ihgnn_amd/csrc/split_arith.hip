@@ -1845,9 +1845,9 @@ int launch_weight_split(int dim, int order, const float* h, int64_t ld_h, const 
     return kSplitRanges;                                                 // slabs written (every range writes one, empty ranges zeros)
 }
 
-// order 3 at d = 64 / 128 / 256, order 2 at d = 64 / 128 (the chunked d = 256 form is written for four blocks)
+// orders 2 and 3 at d = 64 / 128 / 256 (d = 256, order 2: the pass kernel only - the chunked form is written for four blocks)
 bool split_fwd_ok(int dim, int order, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h) {
-    return split_arith_enabled() && ((order == 3 && (dim == 64 || dim == 128 || dim == 256)) || (order == 2 && (dim == 64 || dim == 128))) && p != nullptr &&
+    return split_arith_enabled() && ((order == 3 && (dim == 64 || dim == 128 || dim == 256)) || (order == 2 && (dim == 64 || dim == 128 || (dim == 256 && fwd_kpass_enabled())))) && p != nullptr &&
            ld_ok(ld_p) && ld_out % 4 == 0 && aligned16(p) && aligned16(out) && ld_ok(ld_h);
 }
 
@@ -1857,7 +1857,7 @@ void launch_fwd_split(int dim, int order, const float* h, int64_t ld_h, const fl
     // d = 256: chunked (the eight-part column split of the other form would repeat the product work eight times); d = 64 / 128: weights
     // resident.  At d = 128 the chunked form measured 2,430 us against 2,000: with 32-hyperedge tiles its weight stream (393 KB per tile)
     // alone fills the CU's L2 port for 0.8 ms.
-    if ((dim == 128 || (dim == 256 && order == 3)) && fwd_kpass_enabled()) {
+    if ((dim == 128 || dim == 256) && fwd_kpass_enabled()) {
         const int passes = dim == 128 ? 2 : 4, halves = dim / 128;
         hipLaunchKernelGGL(pack_planes_fwd_kpass_kernel, dim3((passes * halves * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w,
                            dim, order == 3 ? 4 : 3, wsp);

@@ -494,11 +494,11 @@ def test_interact_fp32_mfma_kernels_stay_covered(which, monkeypatch):
         test_interact_backward_user_slot_reduced_on_chip(3, 700 * 32 + 5, 301, monkeypatch)
 
 
-@pytest.mark.parametrize('dim,order', [(128, 3), (128, 2), (256, 3)])
+@pytest.mark.parametrize('dim,order', [(128, 3), (128, 2), (256, 3), (256, 2)])
 def test_forward_in_two_passes_equals_the_column_half_kernel(dim, order, monkeypatch):
     """d = 128: the default forward runs in two passes over the contraction index (blocks uq, qi + first-order rows, then iu (, uqi) added onto
-    `out`; every product formed once); d = 256, order 3: four passes of one block, column halves, 16-hyperedge tiles.  IHG_FWD_KPASS=0 selects
-    the column-half kernel (d = 128) / the chunked kernel (d = 256).  Both against the oracle - more tiles than workgroups with a partial
+    `out`; every product formed once); d = 256: one pass per block (four at order 3, three at order 2), column halves, 16-hyperedge tiles.
+    IHG_FWD_KPASS=0 selects the column-half kernel (d = 128) / the chunked kernel (d = 256, order 3) / the fp32 strip kernel (d = 256, order 2).  Both against the oracle - more tiles than workgroups with a partial
     last tile, fewer tiles than workgroups, one hyperedge, a strided `out` - and against each other (same products, the block sums
     associated differently)."""
     from ihgnn_amd import _lib, ops
