@@ -520,6 +520,12 @@ def test_forward_in_two_passes_equals_the_column_half_kernel(dim, order, monkeyp
                 got[mode] = ops.interact(h.to(dev()), p.to(dev()), w.to(dev()), lay, order)
             assert rel(got[mode], want) <= RTOL, (mode, edges)
         assert rel(got['1'], got['0']) <= RTOL_SUM
+        if edges > 8192:                                                  # the passes chunk by chunk of the hyperedge list (IHG_FWD_CHUNK): the same numbers
+            monkeypatch.setenv('IHG_FWD_KPASS', '1')
+            monkeypatch.setenv('IHG_FWD_CHUNK', '8192')
+            with torch.no_grad():
+                assert torch.equal(ops.interact(h.to(dev()), p.to(dev()), w.to(dev()), lay, order), got['1'])
+            monkeypatch.delenv('IHG_FWD_CHUNK')
         # a column slice as destination (row stride 2 d): the raw entry point with ld_out = 2 d
         monkeypatch.setenv('IHG_FWD_KPASS', '1')
         lib = _lib.load()
