@@ -23,6 +23,7 @@ import os
 
 HEAVY_THRESHOLD = int(os.environ.get('IHG_HEAVY_THRESHOLD', 256))   # rows longer than this are split ...
 HEAVY_CHUNK = int(os.environ.get('IHG_HEAVY_CHUNK', 128))           # ... into segments of this many ids (bounds every lane group's serial chain)
+HEAVY_MAX_SEGMENTS = int(os.environ.get('IHG_HEAVY_MAX_SEGMENTS', 4096))   # ... but never more than this many per row (longer segments instead; C5 step, ms: uncapped 683, 4096: 661, 1024: 667, 256: 691)
 
 
 def _as_ptr(a: np.ndarray, ctype):
@@ -56,14 +57,17 @@ class Csr:
             self.n_segments = 0
             self.heavy_rows = self.heavy_segptr = self.seg_begin = self.seg_end = None
             return
-        seg_counts = (lens[heavy] + chunk - 1) // chunk
+        # a row is cut into at most HEAVY_MAX_SEGMENTS pieces: the few extreme rows of a power-law graph (config C5: one query with millions of
+        # hyperedges) get longer segments instead of tens of thousands of partial sums that ONE workgroup of the finish kernel adds up serially
+        row_chunk = np.maximum(chunk, -(-lens[heavy] // HEAVY_MAX_SEGMENTS))
+        seg_counts = (lens[heavy] + row_chunk - 1) // row_chunk
         segptr = np.zeros(self.n_heavy + 1, np.int64)
         np.cumsum(seg_counts, out=segptr[1:])
         self.n_segments = int(segptr[-1])
         owner = np.repeat(np.arange(self.n_heavy), seg_counts)
         within = np.arange(self.n_segments) - segptr[owner]
-        begin = self.ptr_host[heavy][owner].astype(np.int64) + within * chunk
-        end = np.minimum(begin + chunk, self.ptr_host[heavy + 1][owner].astype(np.int64))
+        begin = self.ptr_host[heavy][owner].astype(np.int64) + within * row_chunk[owner]
+        end = np.minimum(begin + row_chunk[owner], self.ptr_host[heavy + 1][owner].astype(np.int64))
         dev = self.device
         self.heavy_rows = torch.from_numpy(heavy.astype(np.int32)).to(dev)
         self.heavy_segptr = torch.from_numpy(segptr.astype(np.int32)).to(dev)
