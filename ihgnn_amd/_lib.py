@@ -20,10 +20,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # IHGNN_HIP_LIBRARY points at another build of the same ABI (A/B timing of kernel variants); default: the in-tree library
 LIB_PATH = os.environ.get('IHGNN_HIP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
+SCALE_ACCUMULATE = 0x100                                 # OR-ed into the mode of ihg_node_segment_sum: out += instead of out =
 
 _i64p, _i32p, _f32p = POINTER(c_int64), POINTER(c_int32), POINTER(c_float)
 

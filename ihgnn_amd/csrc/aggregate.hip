@@ -147,6 +147,7 @@ __device__ __forceinline__ int wave_max_over_groups(int v) {
 
 template <int VEC>
 __device__ __forceinline__ void apply_out_scale(Frag<VEC>& acc, const float* out_scale, int mode, int64_t row) {
+    mode &= 0xff;                                           // (IHG_SCALE_ACCUMULATE rides in the mode word)
     if (mode == IHG_SCALE_MULTIPLY) {
         acc.mul(out_scale[row]);
     } else if (mode == IHG_SCALE_DIVIDE) {
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
                         acc.add_scaled(Frag<VEC>::load(src + scale_row * ld_src + col * VEC),
                                        self_weight[scale_row] * (src_scale != nullptr ? src_scale[scale_row] : 1.f));
                     apply_out_scale<VEC>(acc, out_scale, mode, scale_row);
+                    if (mode & IHG_SCALE_ACCUMULATE) acc.add(Frag<VEC>::load(dst + col * VEC));     // out += (hyperedge chunks of one scatter)
                 }
                 acc.store(dst + col * VEC);
             }
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
                 if (self_weight != nullptr)
                     total.add_scaled(Frag<VEC>::load(src + row * ld_src + c * VEC), self_weight[row] * (src_scale != nullptr ? src_scale[row] : 1.f));
                 apply_out_scale<VEC>(total, out_scale, mode, row);
+                if (mode & IHG_SCALE_ACCUMULATE) total.add(Frag<VEC>::load(out + row * ld_out + c * VEC));
                 total.store(out + row * ld_out + c * VEC);
             }
             __syncthreads();
@@ -332,6 +335,8 @@ int launch_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, 
 }
 
 inline bool scale_mode_ok(int mode, const float* scale) {
+    if (mode & ~(0xff | IHG_SCALE_ACCUMULATE)) return false;
+    mode &= 0xff;
     if (mode == IHG_SCALE_NONE) return true;
     return (mode == IHG_SCALE_MULTIPLY || mode == IHG_SCALE_DIVIDE) && scale != nullptr;
 }

@@ -76,14 +76,18 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
                          out_scale: Optional[Tensor] = None, mode: int = _lib.SCALE_NONE,
                          out: Optional[Tensor] = None, entry_scale: Optional[Tensor] = None,
                          self_weight: Optional[Tensor] = None, rows: Optional[Tensor] = None, src_mask: Optional[Tensor] = None,
-                         role: Optional[str] = None) -> Tensor:
+                         role: Optional[str] = None, accumulate: bool = False) -> Tensor:
     """``role`` names the launch for the profiler (one kernel, several jobs with different byte counts: ``bench.py`` reports each).
     ``rows`` (int32, device): only these output rows are needed.  The split rows of the plan are always computed; of the
     others only the listed ones are, and the rest of ``out`` is left unwritten.  ``src_mask`` (uint8 per source row): rows with a 0
-    are all-zero and are not fetched."""
+    are all-zero and are not fetched.  ``accumulate``: ``out +=`` instead of ``out =`` (``out`` required; the hyperedge chunks of one scatter)."""
     lib = _lib.load()
     src = _rows(src, 'src')
     dim = int(src.shape[1])
+    if accumulate:
+        if out is None or rows is not None:
+            raise ValueError('accumulate needs an existing `out` and all rows')
+        mode = mode | _lib.SCALE_ACCUMULATE
     if out is None:
         out = torch.empty(csr.n_rows, dim, dtype=torch.float32, device=src.device)
     heavy = csr.n_heavy > 0
@@ -532,9 +536,9 @@ def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: Incidence
                        'ihg_interact_bwd')
         if index > 0:
             dw[:, 3 * dim:].add_(dw_part[:, 3 * dim:])
-        part = node_segment_sum_raw(g.view(3 * n, dim), csr, role='k7.member_gradients')       # (node v, hyperedge e) reads row 3 (e - e0) + type(v)
+        # (node v, hyperedge e) reads row 3 (e - e0) + type(v); the chunks after the first ADD onto dh inside the kernel (no [N, d] add pass)
+        dh = node_segment_sum_raw(g.view(3 * n, dim), csr, role='k7.member_gradients', out=dh, accumulate=dh is not None)
         del g
-        dh = part if dh is None else dh.add_(part)
     return dh
 
 
