@@ -768,7 +768,13 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
             for (int m = 0; m < 3; ++m) {
                 const float* hp = row_at(h, idk[m], ldh) + 4 * o;
 #pragma unroll
-                for (int x = 0; x < ZX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + CSTR * x);
+                for (int x = 0; x < ZX; ++x) {
+#ifdef IHG_NT_USER_ROWS
+                    if (m == 0) hm[x][m] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(hp + CSTR * x));
+                    else
+#endif
+                    hm[x][m] = *reinterpret_cast<const v4f*>(hp + CSTR * x);
+                }
             }
 #ifdef IHG_ABL_NO_MEMBER_LOADS
 #pragma unroll
@@ -790,7 +796,13 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
                 const int64_t e = std::min<int64_t>((t0 + k) * TE + row, n_edges - 1);
                 const float* op = out + e * ld_out + hoff + 4 * o;
 #pragma unroll
-                for (int x = 0; x < OX; ++x) pr[x][0] = *reinterpret_cast<const v4f*>(op + CSTR * x);
+                for (int x = 0; x < OX; ++x) {
+#ifndef IHG_PLAIN_OUT_READ
+                    pr[x][0] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(op + CSTR * x));     // read once, never again (pass B at C3: 861 -> 847 us;
+#else                                                                                                     //  the user rows read the same way: 878, they are re-read by the next hyperedges)
+                    pr[x][0] = *reinterpret_cast<const v4f*>(op + CSTR * x);
+#endif
+                }
             } else {
                 const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
