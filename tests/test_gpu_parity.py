@@ -1020,6 +1020,19 @@ def test_full_size_layer0_path_of_the_headline_step(config, order):
     want_dh = _oracle_on_sampled_nodes(lay, nodes, h, wz, order, edge_cotangent)
     assert rel(h.grad[torch.from_numpy(nodes).to(dev())], want_dh) <= RTOL
 
+    # the form the model runs (IHGNNLayer -> FeatureInteractor.to_nodes -> ops.interact_layer): the first-order blocks inside the same autograd
+    # node, their input gradient ADDED onto the member gradients by the node-level weight-gradient kernel (dx_accumulate) - against the
+    # composition of the two ops checked above, whole tensors
+    bias = torch.randn(d, device=dev(), generator=gen).requires_grad_(True)
+    h3, w3 = (t.detach().clone().requires_grad_(True) for t in (h, wgt))
+    y3 = ops.interact_layer(h3, w3, bias, lay, order, scale)
+    y3.backward(dy)
+    h4, w4, b4 = (t.detach().clone().requires_grad_(True) for t in (h, wgt, bias))
+    y4 = ops.interact_to_nodes(h4, ops.node_linear(h4, w4, b4, lay, typed=True, bias_mask=0b001), w4, lay, order, scale)
+    y4.backward(dy)
+    assert torch.equal(y3.detach(), y4.detach())
+    assert rel(h3.grad, h4.grad) <= 4 * RTOL_SUM and rel(w3.grad, w4.grad) <= 4 * RTOL_SUM and rel(bias.grad, b4.grad) <= 4 * RTOL_SUM
+
 
 def test_full_size_c5_interact_in_three_chunks():
     """BASELINE configs[4] at FULL size on one GPU: N = 10 M, E = 50 M, d = 256.  The interactive step forward (chunk kernel) and its
