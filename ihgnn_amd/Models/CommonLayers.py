@@ -10,7 +10,6 @@ order 1 / 2 / 3; column blocks u, q, i, uq, qi, iu, uqi) but never builds the ``
 """
 from typing import Optional
 
-import torch
 import torch.nn as nn
 from torch import Tensor
 

@@ -11,7 +11,6 @@ padding row, xavier-uniform initialised), but the full-graph lookup that every t
 """
 from typing import Optional, Tuple
 
-import torch
 import torch.nn as nn
 import torch.nn.init as init
 from torch import Tensor
