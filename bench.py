@@ -19,18 +19,23 @@ touches the GPU and forwards rank 0's JSON line; under `python -m torch.distribu
 One JSON line is printed by rank 0.  It carries
   roofline                    the aggregation kernel the step is dominated by, against the HBM roofline: K5 (node->hyperedge gather-sum)
                               where the step launches it, else - the layer-0 backward forms the hyperedges' cotangents inside the
-                              member-gradient kernel - K7's hyperedge->node launch.  `achieved` = COMPULSORY HBM bytes per launch (every
+                              member-gradient kernel - K7's hyperedge->node launch.  `achieved` / `frac` = COMPULSORY HBM bytes per launch (every
                               source row once + stores + ids) / the kernel's average duration measured with HIP events on the launch
-                              stream inside the timed region; `algorithmic_gbs` = the SURVEY §8 d3 byte model (every gathered row counted;
-                              NOT used for `frac`); `traffic` = PMC-measured bytes per launch (profiles/r2/pmc_traffic_<config>.json)
-                              when committed for this exact workload;
+                              stream inside the timed region; `frac_algorithmic` / `algorithmic_gbs` = the SURVEY §8 d3 byte model (every gathered
+                              row counted); `traffic` = PMC-measured bytes per launch from the newest committed profile of this exact workload
+                              (profiles/r*/pmc_traffic_<config>.json; NOT measured in this run: the object names the file and its commit and
+                              carries the number only when that profile's kernel time is within 10 % of this run's, `traffic_refused` otherwise);
   roofline_node_to_hyperedge  K5 at this workload, launched on its own after the timed region (same fields);
   roofline_hyperedge_to_node  one object per K7 launch role (edge features -> nodes, member gradients -> nodes, two-hop ...), each with
                               its own byte counts;
-  roofline_interaction        the order-2/3 contraction - the kernels that own most of a C3 / C5 step - against the matrix-core peak of the
-                              arithmetic it runs in (fp32 MFMA, or for d = 128 / order 3 the bf16 peak / 6: six bf16 products per multiply);
+  roofline_interaction        the order-2/3 contraction against the matrix-core peak of the arithmetic it runs in (fp32 MFMA, or for
+                              d = 64 / 128 / 256 the bf16 peak / 6: six bf16 products per multiply), with the clocks and matrix-pipe occupancy of
+                              the newest committed counter pass (`profiled_clock`);
+  gradient_exchange           (N > 1) mode, backend, gradient bytes per rank, every rank's ms per step and the time its stream spent in the exchange;
+  recorded_step_ms_per_step   the same step replayed from one recorded hipGraph (ihgnn_amd/captured_step.py); NOT the headline;
   cpu_baseline                the CPU oracle (= the reference's PyTorch-CPU op sequence) timed on this box's host cores on a stated
-                              sub-sample of the same config.
+                              sub-sample of the same config; cpu_baseline_c1_full_size: the oracle on BASELINE configs[0] at FULL size, with the
+                              HIP path timed on the identical input.
 """
 import argparse
 import json
