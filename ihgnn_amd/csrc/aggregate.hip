@@ -230,7 +230,17 @@ __global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
             const int c = c0 + lig;
             Frag<VEC> acc = Frag<VEC>::zero();
             if (c < dim_vec) {
+                // the longest row's chain of dependent round trips IS this kernel's duration (one workgroup per row): sixteen partials in flight per
+                // lane group, added in index order
+                constexpr int FLY = 16;
                 int sgm = s_begin + grp;
+                for (; sgm + (FLY - 1) * GROUPS < s_end; sgm += FLY * GROUPS) {
+                    Frag<VEC> a[FLY];
+#pragma unroll
+                    for (int k = 0; k < FLY; ++k) a[k] = Frag<VEC>::load(partials + static_cast<int64_t>(sgm + k * GROUPS) * dim + c * VEC);
+#pragma unroll
+                    for (int k = 0; k < FLY; ++k) acc.add(a[k]);
+                }
                 for (; sgm + 3 * GROUPS < s_end; sgm += 4 * GROUPS) {
                     const Frag<VEC> a0 = Frag<VEC>::load(partials + static_cast<int64_t>(sgm) * dim + c * VEC);
                     const Frag<VEC> a1 = Frag<VEC>::load(partials + static_cast<int64_t>(sgm + GROUPS) * dim + c * VEC);
