@@ -97,6 +97,28 @@ def test_member_lists_cut_by_hyperedge_range_partition_the_full_lists():
             assert ((piece // 3 >= e0) & (piece // 3 < e1)).all()
 
 
+def test_split_row_plan_covers_every_long_row_once_and_caps_its_segments(monkeypatch):
+    """Rows longer than the threshold are cut into segments of `heavy_chunk` ids - but never more than HEAVY_MAX_SEGMENTS per row (the extreme
+    rows of a power-law graph get longer segments instead): the segments of a row tile its id range exactly, in order."""
+    from ihgnn_amd import layout
+    rng = np.random.default_rng(0)
+    lens = np.concatenate([rng.integers(0, 40, 200), [257, 1000, 130_000, 5]])
+    ptr = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    ids = rng.integers(0, 1000, int(ptr[-1])).astype(np.int32)
+    monkeypatch.setattr(layout, 'HEAVY_MAX_SEGMENTS', 64)
+    csr = layout.Csr(ptr.astype(np.int32), ids, CPU, heavy_threshold=256, heavy_chunk=128)
+    heavy = csr.heavy_rows.numpy()
+    assert list(heavy) == [200, 201, 202]
+    segptr, begin, end = csr.heavy_segptr.numpy(), csr.seg_begin.numpy(), csr.seg_end.numpy()
+    for k, row in enumerate(heavy):
+        b, e = begin[segptr[k]:segptr[k + 1]], end[segptr[k]:segptr[k + 1]]
+        assert b[0] == ptr[row] and e[-1] == ptr[row + 1] and (b[1:] == e[:-1]).all() and (e > b).all()
+        assert len(b) <= 64
+    assert segptr[1] - segptr[0] == 3 and segptr[2] - segptr[1] == 8            # 257 and 1,000 ids in pieces of 128
+    assert segptr[3] - segptr[2] == 64 and (end - begin).max() == -(-130_000 // 64)  # the long row: 64 longer pieces
+
+
 def test_build_csr_rejects_bad_ids():
     from ihgnn_amd._lib import IhgnnHipError
     with pytest.raises(IhgnnHipError, match='out of range'):
