@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # IHGNN_HIP_LIBRARY points at another build of the same ABI (A/B timing of kernel variants); default: the in-tree library
 LIB_PATH = os.environ.get('IHGNN_HIP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
@@ -63,6 +63,16 @@ SIGNATURES = {
     'ihg_interact_bwd_gathered_supported': (c_int32, [c_int32, c_int32, c_int64, c_int64]),
     'ihg_interact_bwd_gathered': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                                  c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    'ihg_node_pair_sums': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
+                                          c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    'ihg_node_interact_fwd_supported': (c_int32, [c_int32, c_int32, c_int64, c_int64, c_int64]),
+    'ihg_node_interact_fwd_workspace_bytes': (c_int64, [c_int32]),
+    'ihg_node_interact_fwd': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, _i64p,
+                                             c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p]),
+    'ihg_node_interact_bwd_weight_supported': (c_int32, [c_int32, c_int32, c_int64, c_int64, c_int64]),
+    'ihg_node_interact_bwd_weight_workspace_bytes': (c_int64, [c_int32, c_int32]),
+    'ihg_node_interact_bwd_weight': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, _i64p,
+                                                    c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p]),
     'ihg_node_linear_workspace_bytes': (c_int64, [c_int32]),
     'ihg_node_linear_bwd_accumulates': (c_int32, [c_int32, c_int64, c_int64, c_int64]),
     'ihg_node_linear_fwd': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_int64, _i64p,

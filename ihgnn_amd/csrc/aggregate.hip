@@ -212,6 +212,82 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
     }
 }
 
+// ================================================================================================
+// Pair sums: the gather half of the interactive layer in its NODE-LEVEL form ("the layer without hyperedge rows").
+//   For node v, over its incident hyperedges e with their other two members (a_e, b_e) - the id pairs of the two-hop list -
+//       S_a[v] = sum_e h[a_e]      S_b[v] = sum_e h[b_e]      S_ab[v] = sum_e h[a_e] * h[b_e]   (elementwise product)
+//   written side by side as one row of 3 d floats.  Every product of member features that the interactive layer contracts has, for a fixed
+//   node, that node's own feature as a constant factor: the sums of the hyperedge features over the node's hyperedges are linear maps of
+//   (h[v], S_a, S_b, S_ab), so no [E, d] row is ever formed (ihg_node_interact_fwd applies the maps).  Same work list, lane layout and
+//   split-row plan as K7; a segment of a split row must hold whole pairs (the layout keeps segment lengths even).
+// ================================================================================================
+template <int G>
+__global__ __launch_bounds__(kBlockThreads) void node_pair_sums_kernel(
+    const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ids,
+    const int32_t* __restrict__ row_order, float* __restrict__ out, int64_t ld_out, int64_t n_rows, int dim, int dim_vec,
+    int heavy_threshold, const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments,
+    float* __restrict__ partials) {
+    constexpr int GPW = kWave / G;
+    constexpr int UNR = G < 8 ? G : (G >= 32 ? 16 : 8);      // ids in flight per lane: UNR / 2 pairs
+    const int lane = threadIdx.x & (kWave - 1);
+    const int lig = lane & (G - 1);
+    const int grp = lane / G;
+    const int group_base = lane & ~(G - 1);
+    const int64_t n_units = n_segments + n_rows;
+    for (int64_t u0 = global_wave_id() * GPW; u0 < n_units; u0 += global_wave_count() * GPW) {
+        const int64_t u = u0 + grp;
+        int begin = 0, len = 0;
+        float* dst = nullptr;
+        if (u < n_segments) {
+            begin = seg_begin[u];
+            len = seg_end[u] - begin;
+            dst = partials + u * 3 * dim;
+        } else if (u < n_units) {
+            int64_t r = u - n_segments;
+            if (row_order != nullptr) r = row_order[r];
+            begin = rowptr[r];
+            len = rowptr[r + 1] - begin;
+            if (heavy_threshold > 0 && len > heavy_threshold) len = 0;      // finished from the partials
+            else dst = out + r * ld_out;
+        }
+        const int wave_len = wave_max_over_groups<G>(len);
+        const int col_iters = (dim_vec + G - 1) / G;
+        for (int ci = 0; ci < col_iters; ++ci) {
+            const int c = ci * G + lig;
+            const bool col_ok = c < dim_vec;
+            Frag<4> sa = Frag<4>::zero(), sb = Frag<4>::zero(), sab = Frag<4>::zero();
+            for (int base = 0; base < wave_len; base += G) {
+                const int my_id = base + lig < len ? ids[begin + base + lig] : -1;
+#pragma unroll 1
+                for (int j = 0; j < G; j += UNR) {
+                    if (base + j >= wave_len) break;          // wave-uniform
+                    int id[UNR];
+                    Frag<4> row[UNR];
+#pragma unroll
+                    for (int k = 0; k < UNR; ++k) id[k] = __shfl(my_id, group_base + j + k);
+#pragma unroll
+                    for (int k = 0; k < UNR; ++k)
+                        row[k] = (id[k] >= 0 && col_ok) ? Frag<4>::load(h + static_cast<int64_t>(id[k]) * ld_h + c * 4) : Frag<4>::zero();
+#pragma unroll
+                    for (int k = 0; k < UNR; k += 2) {
+                        sa.add(row[k]);
+                        sb.add(row[k + 1]);
+                        sab.v.x += row[k].v.x * row[k + 1].v.x;
+                        sab.v.y += row[k].v.y * row[k + 1].v.y;
+                        sab.v.z += row[k].v.z * row[k + 1].v.z;
+                        sab.v.w += row[k].v.w * row[k + 1].v.w;
+                    }
+                }
+            }
+            if (dst != nullptr && col_ok) {
+                sa.store(dst + c * 4);
+                sb.store(dst + dim + c * 4);
+                sab.store(dst + 2 * dim + c * 4);
+            }
+        }
+    }
+}
+
 // One workgroup per heavy row: its 256/G lane groups take the row's partials round-robin (4 loads in flight each), the
 // per-group sums are combined through LDS in group order - a fixed summation tree, so the result is bitwise reproducible.
 template <int VEC, int G>
@@ -386,6 +462,45 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
     const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out) && (n_heavy == 0 || aligned16(partials));
     return wide ? launch_segment_sum<4>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, self_weight, s)
                 : launch_segment_sum<1>(src, ld_src, rowptr, ids, row_order, src_scale, entry_scale, out_scale, out_scale_mode, out, ld_out, n_rows, dim, heavy_threshold, hp, self_weight, s);
+}
+
+int ihg_node_pair_sums(const float* h, int64_t ld_h, const int32_t* pair_ptr, const int32_t* pair_ids, const int32_t* row_order, float* out,
+                       int64_t ld_out, int64_t n_rows, int32_t dim, int32_t heavy_threshold, const int32_t* seg_begin, const int32_t* seg_end,
+                       int64_t n_segments, const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy, float* partials,
+                       ihg_stream_t stream) {
+    if (n_rows < 0 || dim <= 0 || dim % 4 != 0 || ld_h < dim || ld_h % 4 != 0 || ld_out < 3 * static_cast<int64_t>(dim) || ld_out % 4 != 0 || n_segments < 0 || n_heavy < 0)
+        return fail(IHG_ERR_INVALID, "ihg_node_pair_sums: bad size (rows=%lld dim=%d ld_h=%lld ld_out=%lld)", (long long)n_rows, dim, (long long)ld_h, (long long)ld_out);
+    if (n_rows == 0) return IHG_OK;
+    if (h == nullptr || pair_ptr == nullptr || pair_ids == nullptr || out == nullptr || !aligned16(h) || !aligned16(out))
+        return fail(IHG_ERR_INVALID, "ihg_node_pair_sums: null or unaligned pointer");
+    if (n_heavy > 0 && (heavy_threshold <= 0 || seg_begin == nullptr || seg_end == nullptr || heavy_rows == nullptr || heavy_segptr == nullptr || partials == nullptr || !aligned16(partials)))
+        return fail(IHG_ERR_INVALID, "ihg_node_pair_sums: incomplete split-row plan");
+    if (n_heavy == 0) {
+        n_segments = 0;
+        heavy_threshold = 0;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int dim_vec = dim / 4;
+#define IHG_PAIRS(G)                                                                                                                        \
+    {                                                                                                                                       \
+        constexpr int GPW = kWave / G;                                                                                                      \
+        const int grid = grid_for_waves((n_rows + n_segments + GPW - 1) / GPW);                                                             \
+        hipLaunchKernelGGL((node_pair_sums_kernel<G>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, pair_ptr, pair_ids, row_order, out,  \
+                           ld_out, n_rows, dim, dim_vec, heavy_threshold, seg_begin, seg_end, n_segments, partials);                        \
+        if (n_heavy > 0)                                                                                                                    \
+            hipLaunchKernelGGL((heavy_finish_kernel<4, G>), dim3(static_cast<int>(std::min<int64_t>(n_heavy, kMaxBlocks * 4))),             \
+                               dim3(kBlockThreads), 0, s, partials, heavy_rows, heavy_segptr, n_heavy, nullptr, IHG_SCALE_NONE, out, ld_out, \
+                               3 * dim, 3 * dim_vec, nullptr, 0, nullptr, nullptr);                                                         \
+    }
+    switch (group_lanes(dim_vec)) {
+        case 4: IHG_PAIRS(4) break;
+        case 8: IHG_PAIRS(8) break;
+        case 16: IHG_PAIRS(16) break;
+        case 32: IHG_PAIRS(32) break;
+        default: IHG_PAIRS(64) break;
+    }
+#undef IHG_PAIRS
+    return check_launch("ihg_node_pair_sums");
 }
 
 int ihg_bag_mean_fwd(const float* table, int64_t ld_table, const int32_t* bag_ptr, const int32_t* words, const float* bag_len,

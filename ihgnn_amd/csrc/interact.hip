@@ -2018,6 +2018,7 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
     }
 #undef IHG_MEM
 #undef IHG_MEM_PIPE
+    if (dw == nullptr) return;                               // member gradients only (the caller takes d w from the node-level kernel)
     const int subs_ws = (dim / 64) * (dim / 64);
     int n_slabs = static_cast<int>(std::min<int64_t>(dim >= 64 ? std::max(kPipeGrid / subs_ws, 8) : weight_slabs(dim), (n_edges + 63) / 64));
     if (split_weight_ok(dim, NBLK == 4 ? 3 : 2, ld_h, ld_dout, dout)) {      // bf16-split contraction
@@ -2083,6 +2084,54 @@ int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p,
     return check_launch("ihg_interact_fwd");
 }
 
+int32_t ihg_node_interact_fwd_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_sums, int64_t ld_out) {
+    static float aligned_probe __attribute__((aligned(16)));
+    return split_node_fwd_ok(dim, order, ld_h, ld_sums, &aligned_probe, ld_out, nullptr) && ld_h >= dim && ld_sums >= 3LL * dim && ld_out >= dim ? 1 : 0;
+}
+
+int64_t ihg_node_interact_fwd_workspace_bytes(int32_t dim) { return split_node_fwd_plane_floats(dim) * static_cast<int64_t>(sizeof(float)); }
+
+int ihg_node_interact_fwd(const float* h, int64_t ld_h, const float* sums, int64_t ld_sums, const float* degree, const float* out_scale, const float* bias,
+                          const float* w, int64_t ld_w, int32_t order, const int64_t* type_begin, float* out, int64_t ld_out, void* workspace,
+                          int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
+    if (order != 2 && order != 3) return fail(IHG_ERR_INVALID, "ihg_node_interact_fwd: order must be 2 or 3, got %d", order);
+    if (type_begin == nullptr || type_begin[0] != 0 || type_begin[1] < type_begin[0] || type_begin[2] < type_begin[1] || type_begin[3] < type_begin[2])
+        return fail(IHG_ERR_INVALID, "ihg_node_interact_fwd: bad type_begin");
+    if (dim <= 0 || ld_h < dim || ld_out < dim || ld_sums < 3LL * dim || ld_w < static_cast<int64_t>(order == 3 ? 7 : 6) * dim)
+        return fail(IHG_ERR_INVALID, "ihg_node_interact_fwd: bad size");
+    if (type_begin[3] == 0) return IHG_OK;
+    if (h == nullptr || sums == nullptr || degree == nullptr || w == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_interact_fwd: null pointer");
+    if (!split_node_fwd_ok(dim, order, ld_h, ld_sums, out, ld_out, bias) || !aligned16(h) || !aligned16(sums))
+        return fail(IHG_ERR_INVALID, "ihg_node_interact_fwd: dim %d / order %d / alignment not supported (ihg_node_interact_fwd_supported)", dim, order);
+    if (workspace == nullptr || !aligned16(workspace) || workspace_bytes < ihg_node_interact_fwd_workspace_bytes(dim))
+        return fail(IHG_ERR_WORKSPACE, "ihg_node_interact_fwd: workspace too small");
+    launch_node_fwd_split(order, h, ld_h, sums, ld_sums, degree, out_scale, bias, w, ld_w, type_begin, out, ld_out, workspace, static_cast<hipStream_t>(stream));
+    return check_launch("ihg_node_interact_fwd");
+}
+
+int32_t ihg_node_interact_bwd_weight_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_sums, int64_t ld_dy) {
+    static float aligned_probe __attribute__((aligned(16)));
+    return split_node_weight_ok(dim, order, ld_h, ld_sums, ld_dy, &aligned_probe) && ld_h >= dim && ld_sums >= 3LL * dim && ld_dy >= dim ? 1 : 0;
+}
+
+int64_t ihg_node_interact_bwd_weight_workspace_bytes(int32_t dim, int32_t order) { return split_node_weight_slab_floats(dim, order) * static_cast<int64_t>(sizeof(float)); }
+
+int ihg_node_interact_bwd_weight(const float* h, int64_t ld_h, const float* sums, int64_t ld_sums, const float* dy, int64_t ld_dy, const float* dy_scale, int32_t order,
+                                 const int64_t* type_begin, float* dw, int64_t ld_dw, void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
+    if (order != 2 && order != 3) return fail(IHG_ERR_INVALID, "ihg_node_interact_bwd_weight: order must be 2 or 3, got %d", order);
+    if (type_begin == nullptr || type_begin[0] != 0 || type_begin[1] < type_begin[0] || type_begin[2] < type_begin[1] || type_begin[3] < type_begin[2])
+        return fail(IHG_ERR_INVALID, "ihg_node_interact_bwd_weight: bad type_begin");
+    if (dim <= 0 || ld_h < dim || ld_dy < dim || ld_sums < 3LL * dim || ld_dw < static_cast<int64_t>(order == 3 ? 7 : 6) * dim)
+        return fail(IHG_ERR_INVALID, "ihg_node_interact_bwd_weight: bad size");
+    if (h == nullptr || sums == nullptr || dy == nullptr || dw == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_interact_bwd_weight: null pointer");
+    if (!split_node_weight_ok(dim, order, ld_h, ld_sums, ld_dy, dy) || !aligned16(h) || !aligned16(sums))
+        return fail(IHG_ERR_INVALID, "ihg_node_interact_bwd_weight: dim %d / order %d / alignment not supported (ihg_node_interact_bwd_weight_supported)", dim, order);
+    if (workspace == nullptr || !aligned16(workspace) || workspace_bytes < ihg_node_interact_bwd_weight_workspace_bytes(dim, order))
+        return fail(IHG_ERR_WORKSPACE, "ihg_node_interact_bwd_weight: workspace too small");
+    launch_node_weight_split(order, h, ld_h, sums, ld_sums, dy, ld_dy, dy_scale, type_begin, static_cast<float*>(workspace), dw, ld_dw, static_cast<hipStream_t>(stream));
+    return check_launch("ihg_node_interact_bwd_weight");
+}
+
 int64_t ihg_interact_bwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order) {
     (void)n_edges;
     if (!mfma_dim(dim) || (order != 2 && order != 3)) return 0;
@@ -2132,9 +2181,9 @@ int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, c
     if (!ihg_interact_bwd_gathered_supported(dim, order, ld_h, ld_dy))
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: shape or arithmetic mode not supported (ask ihg_interact_bwd_gathered_supported)");
     const int k = order == 3 ? 7 : 6;
-    if (n_edges <= 0 || ld_h < dim || ld_dout < dim || ld_dh < dim || ld_w < static_cast<int64_t>(k) * dim || ld_dw < static_cast<int64_t>(k) * dim)
+    if (n_edges <= 0 || ld_h < dim || ld_dout < dim || ld_dh < dim || ld_w < static_cast<int64_t>(k) * dim || (dw != nullptr && ld_dw < static_cast<int64_t>(k) * dim))
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: bad size");
-    if (h == nullptr || i3 == nullptr || w == nullptr || dy == nullptr || dout == nullptr || g2 == nullptr || dh == nullptr || dw == nullptr || workspace == nullptr)
+    if (h == nullptr || i3 == nullptr || w == nullptr || dy == nullptr || dout == nullptr || g2 == nullptr || dh == nullptr || workspace == nullptr)
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: null pointer");
     if (ld_w % 4 || ld_dout % 4 || !aligned16(h) || !aligned16(w) || !aligned16(dy) || !aligned16(dout) || !aligned16(g2) || !aligned16(workspace))
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: rows must be 16-byte aligned");

@@ -950,6 +950,219 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
 }
 
 // ------------------------------------------------------------------------------------------------
+// The interactive layer WITHOUT hyperedge rows (d = 128): node-level form of  out = scale * H FeatureInteractor(h).
+// For a node v of type t with incident hyperedges e and their other two members (a_e, b_e), every term of the hyperedge feature is linear
+// in the member features once v's own feature is held fixed, so the sum over v's hyperedges is a linear map of
+//     deg(v) h[v],   S_a = sum h[a_e],   S_b = sum h[b_e],   S_ab = sum h[a_e] h[b_e]     (ihg_node_pair_sums; products elementwise)
+// and of their products with h[v]:
+//     sum_e F(e) = deg (A_t h + c) + L_a S_a + P_a (h S_a) + L_b S_b + P_b (h S_b) + L_ab S_ab + W_uqi (h S_ab)
+// with the blocks of w = [A_u | A_q | A_i | W_uq | W_qi | W_iu | W_uqi] assigned by node type (kNodeBlocks).  That is a row GEMM over the
+// N nodes with a contraction index of 7 d - E / N times fewer multiply-adds than the hyperedge form, no [E, d] tensor, no hyperedge -> node
+// pass - run in PASSES like the forward above: a pass contracts one source block and its product with h (256 values: the 192 weight
+// registers per matrix wave), adds onto what the earlier passes left in `out`; the last pass applies the output scale.  Matrix waves reload
+// their weight registers where a workgroup's tile range crosses a node type.
+// wnp[type][pass][m][jt < 2][kb < 8][plane][lane][8]: element i = plane of W[32 m + 16 jt + (lane & 15)][block(type, pass, kb >> 2) d + 32 (kb & 3) + 8 (lane >> 4) + i]
+// passes: 0 = {deg h}, 1 = {S_a, h S_a}, 2 = {S_b, h S_b}, 3 = {S_ab, h S_ab}
+// ------------------------------------------------------------------------------------------------
+// rows grouped by node type in tiles of 32 that do not cross a type: begin[t] = first row of type t, tile_prefix[t] = tiles before type t
+struct RowTiles {
+    int64_t begin[4];
+    int tile_prefix[4];
+};
+
+__device__ __forceinline__ int node_block(int type, int pass, int second) {
+    // user: a = query, b = item; query: a = user, b = item; item: a = user, b = query     (-1: no such block)
+    constexpr signed char kNodeBlocks[3][4][2] = {{{0, -1}, {1, 3}, {2, 5}, {4, 6}}, {{1, -1}, {0, 3}, {2, 4}, {5, 6}}, {{2, -1}, {0, 5}, {1, 4}, {3, 6}}};
+    return kNodeBlocks[type][pass][second];
+}
+
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd_kernel(const float* __restrict__ w, int64_t ld_w, int order, v4u* __restrict__ wnp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * 4 * 4 * 2 * 8 * kWave) return;
+    const int lane = idx & 63, kb = (idx >> 6) & 7, jt = (idx >> 9) & 1, m = (idx >> 10) & 3, pass = (idx >> 12) & 3, type = idx >> 14;
+    int b = node_block(type, pass, kb >> 2);
+    if (b == 6 && order != 3) b = -1;
+    Planes pl;
+    if (b >= 0) {
+        const float* src = w + static_cast<int64_t>(32 * m + 16 * jt + (lane & 15)) * ld_w + b * 128 + 32 * (kb & 3) + 8 * (lane >> 4);
+        pl = split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]});
+    } else {
+        pl = split8(v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f});
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wnp[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
+}
+
+constexpr int kNodePassV4 = 4 * 2 * 8 * 3 * kWave;                      // v4u of one (type, pass)'s planes
+
+// KIND 0: blocks {S, h S} of the source block `sums`; 1: {S} (the S_ab pass at order 2); 2: {deg h} (the first pass: `out` = deg c + ...)
+// ACC: add onto `out`; FINAL: multiply the row by scale[v] (nullptr: 1) before the store
+template <int KIND, bool ACC, bool FINAL>
+__global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
+                                                                          const float* __restrict__ deg, const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                          const v4u* __restrict__ wnp, RowTiles plan, float* __restrict__ out, int64_t ld_out) {
+    constexpr int NB = KIND == 0 ? 2 : 1, TE = 32, RT = 2, CSTR = 32, KB = NB * 4, ZRB = 2 * NB * 128, ZPL = TE * ZRB, PS = 128 + 4, X = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
+    __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total_tiles = plan.tile_prefix[3];
+    const int per = (total_tiles + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+    const int t0 = static_cast<int>(blockIdx.x) * per;
+    const int n_my = std::max(0, std::min(per, total_tiles - t0));
+    if (n_my == 0) return;
+    // tile k of this workgroup (tiles past its range: the last tile of the graph, read and dropped): node type, first row, end of the type's rows
+    auto tile_rows = [&](int k, int64_t& r_base, int64_t& r_end) {
+        const int tile_id = std::min(t0 + k, total_tiles - 1);
+        const int type = tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0);
+        r_base = plan.begin[type] + static_cast<int64_t>(tile_id - plan.tile_prefix[type]) * TE;
+        r_end = plan.begin[type + 1];
+        return type;
+    };
+
+    role_priority(wave >= 4);
+    if (wave >= 4) {
+        // ---------------- service waves: thread -> node row of the tile, columns 4 o + 32 x .. (x < 4)
+        const int st = tid - 256, row = st >> 3, o = st & 7;
+        struct Piece { v4f hv[X], sv[X]; float d; };
+        auto load_piece = [&](int k, Piece& pc) {
+            int64_t r_base, r_end;
+            tile_rows(k, r_base, r_end);
+            const int64_t v = std::min(r_base + row, r_end - 1);        // rows past the type's end re-read its last row (never stored)
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+                if (KIND != 1) pc.hv[x] = *reinterpret_cast<const v4f*>(h + v * ld_h + 4 * o + CSTR * x);
+                if (KIND != 2) pc.sv[x] = *reinterpret_cast<const v4f*>(sums + v * ld_s + 4 * o + CSTR * x);
+            }
+            if (KIND == 2) pc.d = deg[v];
+        };
+        struct First { v4f old[X]; float d, sc; };
+        auto load_first = [&](int k, First& f) {
+            int64_t r_base, r_end;
+            tile_rows(k, r_base, r_end);
+            const int64_t v = std::min(r_base + row, r_end - 1);
+            if (ACC) {
+#pragma unroll
+                for (int x = 0; x < X; ++x) f.old[x] = *reinterpret_cast<const v4f*>(out + v * ld_out + 4 * o + CSTR * x);
+            } else {
+                f.d = deg[v];
+            }
+            if (FINAL) f.sc = scale != nullptr ? scale[v] : 1.f;
+        };
+        auto split_tile = [&](const Piece& pc, int buf) {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+#pragma unroll
+                for (int b2 = 0; b2 < NB; ++b2) {
+                    const v4f z = KIND == 2 ? pc.hv[x] * pc.d : (b2 == 0 ? pc.sv[x] : pc.hv[x] * pc.sv[x]);
+                    unsigned w0[3], w1[3];
+                    split_pair(z[0], z[1], w0);
+                    split_pair(z[2], z[3], w1);
+                    // columns 128 b2 + 32 x + 4 o ..: chunk 16 b2 + 4 x + (o >> 1), half o & 1
+                    const int off = row * ZRB + (((16 * b2 + 4 * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + pl * ZPL + off) = v2u{w0[pl], w1[pl]};
+                }
+            }
+        };
+        auto epilogue = [&](int k, const First& f) {                     // tile k
+            int64_t r_base, r_end;
+            tile_rows(k, r_base, r_end);
+            const int64_t v = r_base + row;
+            const float (*pp)[PS] = part[k & 1];
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+                v4f val = *reinterpret_cast<const v4f*>(&pp[row][4 * o + CSTR * x]);
+                if (ACC) val += f.old[x];
+                else if (bias != nullptr) val += *reinterpret_cast<const v4f*>(bias + 4 * o + CSTR * x) * f.d;
+                if (FINAL) val *= f.sc;
+                if (v < r_end) *reinterpret_cast<v4f*>(out + v * ld_out + 4 * o + CSTR * x) = val;
+            }
+        };
+        Piece pc0, pc1;                                                  // values of tile m in pc<m & 1>
+        First f;
+        load_piece(0, pc0);
+        load_piece(1, pc1);
+        split_tile(pc0, 0);
+        __syncthreads();
+        // phase k: images of tile k + 1 (`use`); what tile k - 1 is added to (requested at the start of the phase), its sums and store at the end;
+        // request: values of tile k + 2 (`fill`)
+        auto phase = [&](int k, const Piece& use, Piece& fill) {
+            load_piece(k + 2, fill);
+            if (k >= 1) load_first(k - 1, f);
+            if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
+            if (k >= 1) epilogue(k - 1, f);
+            __syncthreads();
+        };
+        int k = 0;
+#pragma clang loop unroll(disable)
+        for (; k + 1 <= n_my; k += 2) {
+            phase(k, pc1, pc0);
+            phase(k + 1, pc0, pc1);
+        }
+        if (k <= n_my) phase(k, pc1, pc0);
+        return;
+    }
+
+    // ---------------- matrix waves: wave m = output columns 32 m .. + 31, the pass's whole contraction index
+    v8s wreg[2][KB][3];
+    int cur_type = -1;
+    __syncthreads();
+    const int arow = lane & 15, kq = lane >> 4;
+    for (int k = 0; k <= n_my; ++k) {
+        if (k < n_my) {
+            int64_t r_base, r_end;
+            const int type = tile_rows(k, r_base, r_end);
+            if (type != cur_type) {
+                const v4u* wf = wnp + static_cast<int64_t>(type) * 4 * kNodePassV4;
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            wreg[jt][kb][pl] = __builtin_bit_cast(v8s, wf[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 3 + pl) * kWave + lane]);
+                cur_type = type;
+            }
+            const unsigned char* zp = &zplanes[k & 1][0][0][0];
+            auto fragment = [&](int step, v8s (&a)[3]) {
+                const int rt = step / KB, kb = step % KB;
+                const unsigned char* src = zp + (16 * rt + arow) * ZRB + (((4 * kb + kq) ^ arow) << 4);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const v8s*>(src + pl * ZPL);
+            };
+            v4f acc[RT][2];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
+            v8s a[3], an[3];
+            fragment(0, a);
+#pragma unroll
+            for (int step = 0; step < RT * KB; ++step) {
+                const int rt = step / KB, kb = step % KB;
+                if (step + 1 < RT * KB) fragment(step + 1, an);
+                IHG_PIN_ORDER();
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int jt = 0; jt < 2; ++jt)
+                        acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[jt][kb][kTermB[term]], a[kTermA[term]], acc[rt][jt], 0, 0, 0);
+                IHG_PIN_ORDER();
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = an[pl];
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[k & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Forward at d = 256 (the kernel is written for d = 128 as well, where the resident-weights form above is faster), without eightfold product work: the contraction index is walked in CHUNKS of 128 (one product block, or
 // half of one at d = 256), one chunk per phase.  The matrix waves own the OUTPUT - wave m: 32 columns x the tile's 32 hyperedges,
 // accumulators kept across the chunks - and do not keep the weights: the 24 weight fragments of the next chunk (24 KB per wave, the planes
@@ -1373,6 +1586,209 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradients of the interactive layer's product blocks at NODE level (d = 128).  The layer's output row is
+//     y[v] = scale[v] * ( ... + P_a (h S_a) + P_b (h S_b) + L_ab S_ab + W_uqi (h S_ab) )      (node_interact_fwd_kernel),
+// so d W_block = sum over the nodes of (scale dy)[v] x X_block[v]^T with X = [h S_a | h S_b | S_ab | h S_ab] - N rows instead of E hyperedges, no
+// member gathers.  The kernel is the hyperedge form's (interact_bwd_weight_split_ws_kernel: matrix wave b = block b with 8 x 4 accumulator
+// tiles, transposed reads of row-major bf16 images, one slab per tile range) behind another front end: node rows of one type, their
+// cotangent, feature and pair-sum rows as straight streams.  A tile range belongs to ONE node type (the assignment of X blocks to the
+// blocks of w depends on the type); node_weight_reduce_kernel adds the ranges of each type into the w blocks that type's X blocks stand for.
+// ------------------------------------------------------------------------------------------------
+struct NodeRanges {
+    int64_t begin[4];      // first row of every node type
+    int range_prefix[4];   // tile ranges before type t (range_prefix[3] = ranges in all)
+};
+
+template <int NBLK>
+__global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
+                                                                                   const float* __restrict__ dy, int64_t ld_dy, const float* __restrict__ dy_scale,
+                                                                                   NodeRanges plan, float* __restrict__ slabs) {
+    constexpr int D = 128, TE = kSplitTE, HC = 64, CT = HC / 16, JT = D / 16;
+    constexpr int DRB = 2 * D, ZRB = 8 * HC, DOCT = 2, ZX = 2, DPL = TE * DRB, ZPL = TE * ZRB;
+    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][DRB];
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int half = (bid >> 3) & 1, range = (bid & 7) + 8 * (bid >> 4);
+    const int type = range >= plan.range_prefix[2] ? 2 : (range >= plan.range_prefix[1] ? 1 : 0);
+    const int64_t r_begin = plan.begin[type], r_end = plan.begin[type + 1];
+    const int n_tiles = static_cast<int>((r_end - r_begin + TE - 1) / TE);
+    const int n_ranges = plan.range_prefix[type + 1] - plan.range_prefix[type];
+    const int per = n_ranges > 0 ? (n_tiles + n_ranges - 1) / n_ranges : 0;
+    const int t0 = (range - plan.range_prefix[type]) * per;
+    const int n_my = range < plan.range_prefix[3] ? std::max(0, std::min(per, n_tiles - t0)) : 0;
+
+    role_priority(wave >= 4);
+    if (wave >= 4) {
+        // ---------------- split waves: thread -> node row of the tile, cotangent octets o and o + 8, columns HC half + 4 o + 32 x .. of h and the pair sums
+        const int st = tid - 256, row = st >> 3, o = st & 7;
+        struct Rows {
+            v4f d[2 * DOCT], hv[ZX], sa[ZX], sb[ZX], sab[ZX];
+        };
+        auto load_rows = [&](int k, Rows& r) {
+            const int64_t first = r_begin + static_cast<int64_t>(std::min(t0 + k, n_tiles - 1)) * TE;   // tiles past the range: the type's last tile, dropped
+            const bool live = t0 + k < n_tiles && first + row < r_end;
+            const int64_t v = std::min(first + row, r_end - 1);
+            const float* src = dy + v * ld_dy + 8 * o;
+            const float sc = dy_scale != nullptr ? dy_scale[v] : 1.f;
+#pragma unroll
+            for (int x = 0; x < DOCT; ++x) {
+                r.d[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x) * sc;
+                r.d[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4) * sc;
+            }
+            if (!live) {                                                 // rows past the type's end contribute nothing
+#pragma unroll
+                for (int x = 0; x < 2 * DOCT; ++x) r.d[x] = v4f{0.f, 0.f, 0.f, 0.f};
+            }
+            const float* hp = h + v * ld_h + HC * half + 4 * o;
+            const float* sp = sums + v * ld_s + HC * half + 4 * o;
+#pragma unroll
+            for (int x = 0; x < ZX; ++x) {
+                r.hv[x] = *reinterpret_cast<const v4f*>(hp + 32 * x);
+                r.sa[x] = *reinterpret_cast<const v4f*>(sp + 32 * x);
+                r.sb[x] = *reinterpret_cast<const v4f*>(sp + D + 32 * x);
+                r.sab[x] = *reinterpret_cast<const v4f*>(sp + 2 * D + 32 * x);
+            }
+        };
+        const int swz = tr_swizzle(row);
+        auto split_tile = [&](const Rows& r, int buf) {
+#pragma unroll
+            for (int x = 0; x < DOCT; ++x) {
+                v4u sp[3];
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    unsigned w[3];
+                    split_pair(r.d[2 * x + (pr >> 1)][2 * (pr & 1)], r.d[2 * x + (pr >> 1)][2 * (pr & 1) + 1], w);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) sp[p][pr] = w[p];
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + row * DRB + 256 * ((o + 8 * x) >> 4) + ((((o + 8 * x) & 15) ^ swz) << 4)) = sp[p];
+            }
+#pragma unroll
+            for (int x = 0; x < ZX; ++x) {
+                const int og = o + 8 * x;
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) {
+                    const v4f z = b == 0 ? r.hv[x] * r.sa[x] : b == 1 ? r.hv[x] * r.sb[x] : b == 2 ? r.sab[x] : r.hv[x] * r.sab[x];
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    unsigned w0[3], w1[3];
+                    split_pair(z[0], z[1], w0);
+                    split_pair(z[2], z[3], w1);
+                    const int byte = 2 * (b * HC + 4 * og);
+                    const int off = row * ZRB + 256 * (byte >> 8) + ((((byte >> 4) & 15) ^ swz) << 4) + (byte & 8);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + p * ZPL + off) = v2u{w0[p], w1[p]};
+                }
+            }
+        };
+        if (n_my > 0) {
+            Rows r0, r1;
+            load_rows(0, r0);
+            load_rows(1, r1);
+            split_tile(r0, 0);
+            __syncthreads();
+            auto phase = [&](int k, Rows& use, Rows& fill) {
+                load_rows(k + 2, fill);
+                if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
+                __syncthreads();
+            };
+            int k = 0;
+#pragma clang loop unroll(disable)
+            for (; k + 1 < n_my; k += 2) {
+                phase(k, r1, r0);
+                phase(k + 1, r0, r1);
+            }
+            if (k < n_my) phase(k, r1, r0);
+        }
+        return;
+    }
+
+    // ---------------- matrix waves: wave = X block, 8 x 4 accumulator tiles (all 128 cotangent columns x the block's 64 columns of the half)
+    const int blk = wave;
+    v4f acc[JT][CT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[jt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
+    if (n_my > 0) {
+        __syncthreads();
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const int rlo = 8 * g + q, rhi = rlo + 4;
+        auto a_addr = [&](int r, int jt) { return r * DRB + 256 * (jt >> 3) + (((2 * (jt & 7) + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
+        auto b_addr = [&](int r, int ct) {
+            const int byte = 2 * (blk * HC + 16 * ct);
+            return r * ZRB + 256 * (byte >> 8) + (((((byte >> 4) & 15) + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1);
+        };
+        for (int k = 0; k < n_my; ++k) {
+            const unsigned char* dp = &dplanes[k & 1][0][0][0];
+            const unsigned char* zp = &zplanes[k & 1][0][0][0];
+            if (blk < NBLK)
+#pragma unroll
+            for (int jh = 0; jh < JT / 4; ++jh) {
+                v8s a[4][3];
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[jt][p] = read_tr_fragment(dp + p * DPL + a_addr(rlo, 4 * jh + jt), dp + p * DPL + a_addr(rhi, 4 * jh + jt));
+                v8s b[3], bn[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = read_tr_fragment(zp + p * ZPL + b_addr(rlo, 0), zp + p * ZPL + b_addr(rhi, 0));
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (ct + 1 < CT) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(zp + p * ZPL + b_addr(rlo, ct + 1), zp + p * ZPL + b_addr(rhi, ct + 1));
+                    }
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int jt = 0; jt < 4; ++jt)
+                            acc[4 * jh + jt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jt][kTermA[term]], b[kTermB[term]], acc[4 * jh + jt][ct], 0, 0, 0);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[p] = bn[p];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (blk >= NBLK) return;
+    float* slab = slabs + static_cast<int64_t>(range) * D * NBLK * D;
+    const int c = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[static_cast<int64_t>(16 * jt + 4 * kq + r) * NBLK * D + blk * D + HC * half + 16 * ct + c] = acc[jt][ct][r];
+}
+
+// dw[j][(3 + b) d + c] = sum over the node types of the sum over the type's slabs at the X block that stands for w block b there
+// (b: 0 = uq, 1 = qi, 2 = iu, 3 = uqi; fixed order: users, queries, items, slabs in range order - bitwise reproducible)
+__global__ __launch_bounds__(kBlockThreads) void node_weight_reduce_kernel(const float* __restrict__ slabs, NodeRanges plan, int nblk, float* __restrict__ dw, int64_t ld_dw) {
+    constexpr int d = 128;
+    constexpr signed char kPos[3][4] = {{0, 2, 1, 3}, {0, 1, 2, 3}, {2, 1, 0, 3}};      // [type][w block] -> X block
+    const int width = nblk * d;
+    const int64_t total = static_cast<int64_t>(d) * width;
+    for (int64_t base = static_cast<int64_t>(blockIdx.x) * kWave; base < total; base += static_cast<int64_t>(gridDim.x) * kWave) {
+        const int64_t idx = base + (threadIdx.x & 63);
+        const bool live = idx < total;
+        const int j = static_cast<int>((live ? idx : 0) / width), col = static_cast<int>((live ? idx : 0) - static_cast<int64_t>(j) * width);
+        const int b = col / d, c = col - b * d;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int n = plan.range_prefix[t + 1] - plan.range_prefix[t];
+            const int64_t at = static_cast<int64_t>(j) * width + kPos[t][b] * d + c;
+            sum += slab_sum(slabs + static_cast<int64_t>(plan.range_prefix[t]) * total, n, total, at, live);
+        }
+        if ((threadIdx.x >> 6) == 0 && live) dw[static_cast<int64_t>(j) * ld_dw + 3 * static_cast<int64_t>(d) + col] = sum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Row GEMM (node-level linear maps, d = 128): out[v] = in[v] W_t^T (+ bias_t), rows grouped by node type.  A stream over [N, d] - 1 KB
 // of traffic per row against 32 K multiply-adds - that the fp32 matrix pipe cannot feed at HBM speed and the bf16 pipe can.
 // Eight waves, wave w owns output columns 16 w .. with the whole contraction index (its weight planes: 48 registers per node type,
@@ -1383,11 +1799,6 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
 // pk[type][strip][kb][plane][lane][8]: element i = plane of Wt[k = 32 kb + 8 (lane >> 4) + i][c = 16 strip + (lane & 15)],
 //                                       Wt[k][c] = W_t[c][k] (transpose == 0, out = in W^T) or W_t[k][c] (transpose == 1, out = in W)
 // ------------------------------------------------------------------------------------------------
-struct RowTiles {
-    int64_t begin[4];
-    int tile_prefix[4];
-};
-
 __global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride, int n_types, int d,
                                                                           int transpose, v4u* __restrict__ pk) {
     const int kbs = d / 32, strips = d / 16;
@@ -1831,6 +2242,75 @@ void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float*
         hipLaunchKernelGGL(row_gemm_split_kernel<256>, dim3(2 * n_seq), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, bias, bias_mask, bias_type_stride, plan, out,
                            ld_out);
     }
+}
+
+// node-level forward of the interactive layer (d = 128): see node_interact_fwd_kernel
+int64_t split_node_fwd_plane_floats(int dim) { return dim == 128 ? 3LL * 4 * kNodePassV4 * 4 : 0; }
+
+bool split_node_fwd_ok(int dim, int order, int64_t ld_h, int64_t ld_s, const float* out, int64_t ld_out, const float* bias) {
+    return split_arith_enabled() && dim == 128 && (order == 2 || order == 3) && ld_ok(ld_h) && ld_ok(ld_s) && ld_ok(ld_out) && aligned16(out) && (bias == nullptr || aligned16(bias));
+}
+
+void launch_node_fwd_split(int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* deg, const float* scale, const float* bias, const float* w,
+                           int64_t ld_w, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s) {
+    v4u* wnp = static_cast<v4u*>(planes);
+    hipLaunchKernelGGL(pack_planes_node_fwd_kernel, dim3((3 * 4 * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, order, wnp);
+    RowTiles plan;
+    int acc = 0;
+    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
+    for (int t = 0; t < 3; ++t) {
+        plan.tile_prefix[t] = acc;
+        acc += static_cast<int>((type_begin[t + 1] - type_begin[t] + 31) / 32);
+    }
+    plan.tile_prefix[3] = acc;
+    if (acc == 0) return;
+    const int grid = std::min(acc, 256);
+#define IHG_NODE_PASS(KIND, ACC, FINAL, PASS, BLK)                                                                                                          \
+    hipLaunchKernelGGL((node_interact_fwd_kernel<KIND, ACC, FINAL>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums + (BLK) * 128, ld_s, deg, scale, bias, \
+                       wnp + (PASS) * kNodePassV4, plan, out, ld_out)
+    IHG_NODE_PASS(2, false, false, 0, 0);
+    IHG_NODE_PASS(0, true, false, 1, 0);
+    IHG_NODE_PASS(0, true, false, 2, 1);
+    if (order == 3) IHG_NODE_PASS(0, true, true, 3, 2);
+    else IHG_NODE_PASS(1, true, true, 3, 2);
+#undef IHG_NODE_PASS
+}
+
+// node-level weight gradients of the product blocks (d = 128): see node_interact_weight_split_kernel
+int64_t split_node_weight_slab_floats(int dim, int order) { return dim == 128 ? static_cast<int64_t>(kSplitRanges) * dim * (order == 3 ? 4 : 3) * dim : 0; }
+
+bool split_node_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_s, int64_t ld_dy, const float* dy) {
+    return split_arith_enabled() && dim == 128 && (order == 2 || order == 3) && ld_ok(ld_h) && ld_ok(ld_s) && ld_ok(ld_dy) && aligned16(dy);
+}
+
+void launch_node_weight_split(int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* dy, int64_t ld_dy, const float* dy_scale,
+                              const int64_t* type_begin, float* slabs, float* dw, int64_t ld_dw, hipStream_t s) {
+    NodeRanges plan;
+    int64_t tiles[3], total = 0;
+    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
+    for (int t = 0; t < 3; ++t) {
+        tiles[t] = (type_begin[t + 1] - type_begin[t] + kSplitTE - 1) / kSplitTE;
+        total += tiles[t];
+    }
+    // tile ranges by type in proportion to the tiles, every non-empty type at least one, kSplitRanges in all at most
+    int n[3], used = 0;
+    for (int t = 0; t < 3; ++t) {
+        n[t] = tiles[t] == 0 ? 0 : static_cast<int>(std::max<int64_t>(1, tiles[t] * (kSplitRanges - 2) / std::max<int64_t>(total, 1)));
+        n[t] = static_cast<int>(std::min<int64_t>(n[t], tiles[t]));
+        used += n[t];
+    }
+    int acc = 0;
+    for (int t = 0; t < 3; ++t) {
+        plan.range_prefix[t] = acc;
+        acc += n[t];
+    }
+    plan.range_prefix[3] = acc;
+    (void)used;
+    const int nblk = order == 3 ? 4 : 3;
+    if (order == 3) hipLaunchKernelGGL((node_interact_weight_split_kernel<4>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);
+    else hipLaunchKernelGGL((node_interact_weight_split_kernel<3>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);
+    const int total_w = 128 * nblk * 128;
+    hipLaunchKernelGGL(node_weight_reduce_kernel, dim3((total_w + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, plan, nblk, dw, ld_dw);
 }
 
 bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout) {

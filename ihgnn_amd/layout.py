@@ -60,6 +60,7 @@ class Csr:
         # a row is cut into at most HEAVY_MAX_SEGMENTS pieces: the few extreme rows of a power-law graph (config C5: one query with millions of
         # hyperedges) get longer segments instead of tens of thousands of partial sums that ONE workgroup of the finish kernel adds up serially
         row_chunk = np.maximum(chunk, -(-lens[heavy] // HEAVY_MAX_SEGMENTS))
+        row_chunk = row_chunk + (row_chunk & 1)                 # even: the two-hop list holds id PAIRS, a segment must hold whole pairs (ihg_node_pair_sums)
         seg_counts = (lens[heavy] + row_chunk - 1) // row_chunk
         segptr = np.zeros(self.n_heavy + 1, np.int64)
         np.cumsum(seg_counts, out=segptr[1:])

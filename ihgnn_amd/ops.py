@@ -104,6 +104,25 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
     return out
 
 
+def node_pair_sums_raw(h: Tensor, layout: IncidenceLayout, out: Optional[Tensor] = None) -> Tensor:
+    """``[N, 3 d]``: per node the sums over its incident hyperedges' OTHER two members ``(a, b)`` of ``h[a]``, ``h[b]`` and ``h[a] * h[b]``
+    (``ihg_node_pair_sums`` over ``layout.hop2_csr``) - the gather half of the interactive layer's node-level form."""
+    lib = _lib.load()
+    h = _rows(h, 'h')
+    dim = int(h.shape[1])
+    csr = layout.hop2_csr
+    if out is None:
+        out = torch.empty(layout.node_count, 3 * dim, dtype=torch.float32, device=h.device)
+    heavy = csr.n_heavy > 0
+    with profiler.kernel('node_pair_sums', layout.node_count, dim):
+        _lib.check(lib.ihg_node_pair_sums(
+            _ptr(h), _ld(h), _ptr(csr.ptr), _ptr(csr.ids), _ptr(csr.row_order), _ptr(out), _ld(out), csr.n_rows, dim,
+            csr.heavy_threshold if heavy else 0, _ptr(csr.seg_begin) if heavy else None, _ptr(csr.seg_end) if heavy else None,
+            csr.n_segments if heavy else 0, _ptr(csr.heavy_rows) if heavy else None, _ptr(csr.heavy_segptr) if heavy else None, csr.n_heavy,
+            _ptr(csr.partials(3 * dim)) if heavy else None, _stream()), 'ihg_node_pair_sums')
+    return out
+
+
 def _check_out(out: Optional[Tensor], *inputs: Tensor) -> Optional[Tensor]:
     """``out=``: a caller-owned ``[rows, d]`` destination (any row stride - a column slice of the ``[N, d (L + 1)]`` feature matrix,
     ``RawGnn.propagate``).  Only outside autograd: a recorded op must own its output."""
@@ -484,6 +503,20 @@ USER_REDUCED_BACKWARD = _os.environ.get('IHG_USER_REDUCED', '1') != '0'
 # the last layer of a training step is told which rows of its output are read (node_two_hop's cotangent_rows): its backward pulls only those
 SPARSE_LAST_COTANGENT = _os.environ.get('IHG_SPARSE_LAST_COTANGENT', '1') != '0'
 CHECK_SPARSE_COTANGENT = _os.environ.get('IHG_CHECK_SPARSE_COTANGENT', '0') == '1'
+# the forward of the interactive layer in its node-level form (no [E, d] rows: ihg_node_pair_sums + ihg_node_interact_fwd) where the library has it;
+# IHG_NODE_LEVEL_FORWARD=0: the hyperedge form (typed first-order GEMM -> ihg_interact_fwd -> K7) everywhere (A/B, tests)
+NODE_LEVEL_FORWARD = _os.environ.get('IHG_NODE_LEVEL_FORWARD', '1') != '0'
+# ... and the product blocks' weight gradients from node-level data (ihg_node_interact_bwd_weight) after such a forward; IHG_NODE_LEVEL_WEIGHT=0: the hyperedge kernel
+NODE_LEVEL_WEIGHT = _os.environ.get('IHG_NODE_LEVEL_WEIGHT', '1') != '0'
+
+
+def _node_level_forward_ok(h: Tensor, w: Tensor, bias: Optional[Tensor], out: Optional[Tensor], dim: int, order: int) -> bool:
+    lib = _lib.load()
+    ld_out = dim if out is None else _ld(out)
+    return (bool(lib.ihg_node_interact_fwd_supported(dim, order, _ld(h), 3 * dim, ld_out)) and h.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and _ld(w) % 4 == 0
+            and (bias is None or bias.data_ptr() % 16 == 0) and (out is None or out.data_ptr() % 16 == 0))
+
+
 # the interactive layer as ONE autograd node (interact_layer); IHG_LAYER0_ONE_NODE=0: first_order and interact_to_nodes as two nodes (A/B)
 LAYER0_ONE_NODE = _os.environ.get('IHG_LAYER0_ONE_NODE', '1') != '0'
 
@@ -656,6 +689,19 @@ class _InteractLayer(torch.autograd.Function):
         h, w = _rows(h, 'h'), _rows(w, 'w')
         dim = int(h.shape[1])
         _check_out(out, h, w, bias)
+        ctx.layout, ctx.order, ctx.out_scale, ctx.has_bias = layout, order, out_scale, bias is not None
+        if NODE_LEVEL_FORWARD and rows is None and _node_level_forward_ok(h, w, bias, out, dim, order):
+            # no hyperedge rows: sums over each node's other members, then a node-level contraction (ihg_node_interact_fwd)
+            sums = node_pair_sums_raw(h, layout)
+            ctx.save_for_backward(h, w, sums)                  # the pair sums: the backward's node-level weight gradients read them again
+            y = out if out is not None else torch.empty(layout.node_count, dim, dtype=torch.float32, device=h.device)
+            ws = _workspace(int(lib.ihg_node_interact_fwd_workspace_bytes(dim)), h.device)
+            with profiler.kernel('node_interact_fwd', layout.node_count, dim):
+                _lib.check(lib.ihg_node_interact_fwd(_ptr(h), _ld(h), _ptr(sums), _ld(sums), _ptr(layout.self_weight), _ptr(out_scale), _ptr(bias), _ptr(w), _ld(w),
+                                                     order, _type_begin(layout), _ptr(y), _ld(y), _ptr(ws), ws.numel() * 4, dim, _stream()),
+                           'ihg_node_interact_fwd')
+            return y
+        ctx.save_for_backward(h, w)
         p = torch.empty(h.shape[0], dim, dtype=torch.float32, device=h.device)
         ws = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)
         with profiler.kernel('node_linear_fwd', h.shape[0], dim):
@@ -668,20 +714,28 @@ class _InteractLayer(torch.autograd.Function):
                                             _ptr(edge), _ld(edge), _ptr(ws2), ws2.numel() * 4, layout.edge_count, dim, _stream()),
                        'ihg_interact_fwd')
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        y = node_segment_sum_raw(edge, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=out)
-        ctx.save_for_backward(h, w)
-        ctx.layout, ctx.order, ctx.out_scale, ctx.has_bias = layout, order, out_scale, bias is not None
-        return y
+        return node_segment_sum_raw(edge, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=out)
 
     @staticmethod
     def backward(ctx, dy: Tensor):
         lib = _lib.load()
-        h, w = ctx.saved_tensors
+        h, w = ctx.saved_tensors[:2]
+        sums = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None
         layout, order, out_scale = ctx.layout, ctx.order, ctx.out_scale
         dy = _rows(dy, 'dy')
         n_edges, dim = layout.edge_count, int(h.shape[1])
         dw = torch.empty_like(w)                               # product blocks from the interact kernels, first-order blocks from the row-GEMM pass
-        if _gathered_backward_ok(h, w, dy, layout, order):
+        gathered = _gathered_backward_ok(h, w, dy, layout, order)
+        # the product blocks' weight gradients from node-level data (N rows, no gathers) where the forward left the pair sums
+        node_weight = (gathered and sums is not None and NODE_LEVEL_WEIGHT and dy.data_ptr() % 16 == 0 and _ld(dw) % 4 == 0
+                       and bool(lib.ihg_node_interact_bwd_weight_supported(dim, order, _ld(h), _ld(sums), _ld(dy))))
+        if node_weight:
+            ws_w = _workspace(int(lib.ihg_node_interact_bwd_weight_workspace_bytes(dim, order)), h.device)
+            with profiler.kernel('node_interact_bwd_weight', layout.node_count, dim):
+                _lib.check(lib.ihg_node_interact_bwd_weight(_ptr(h), _ld(h), _ptr(sums), _ld(sums), _ptr(dy), _ld(dy), _ptr(out_scale), order, _type_begin(layout),
+                                                            _ptr(dw), _ld(dw), _ptr(ws_w), ws_w.numel() * 4, dim, _stream()), 'ihg_node_interact_bwd_weight')
+        del sums
+        if gathered:
             csr_qi, qi_rows = layout.member_csr_qi()
             dout = torch.empty(n_edges, dim, dtype=torch.float32, device=h.device)
             g2 = torch.empty(n_edges, 2 * dim, dtype=torch.float32, device=h.device)
@@ -690,7 +744,7 @@ class _InteractLayer(torch.autograd.Function):
             ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
             with profiler.kernel('interact_bwd', n_edges, dim):
                 _lib.check(lib.ihg_interact_bwd_gathered(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(dy), _ld(dy), _ptr(out_scale),
-                                                         _ptr(dout), dim, _ptr(g2), _ptr(dh), dim, _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4,
+                                                         _ptr(dout), dim, _ptr(g2), _ptr(dh), dim, None if node_weight else _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4,
                                                          n_edges, dim, _stream()), 'ihg_interact_bwd_gathered')
             node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients')
             del g2

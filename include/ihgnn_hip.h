@@ -234,12 +234,52 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
  * have produced - is formed inside the member-gradient kernel from three gathered rows; it is left in `dout` [n_edges, dim]
  * (written, not read) for the weight gradients here and for the caller's first-order scatter.  Everything else as
  * ihg_interact_bwd_user_reduced.  Available where ihg_interact_bwd_gathered_supported says so (dim 128, split arithmetic on).
+ * dw == NULL: member gradients and dout only (the weight gradients come from ihg_node_interact_bwd_weight).
  */
 int32_t ihg_interact_bwd_gathered_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_dy);
 int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
                               const float* dy, int64_t ld_dy, const float* dy_scale, float* dout, int64_t ld_dout,
                               float* g2, float* dh, int64_t ld_dh, float* dw, int64_t ld_dw,
                               void* workspace, int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The interactive layer in its NODE-LEVEL form: out = out_scale * H FeatureInteractor(h) without any [n_edges, dim] tensor.
+ * Replaces, for the layer as a whole, the reference's FeatureInteractor.forward + torch.sparse.mm(norm_factor * H, .)
+ * (CommonLayers.py:70-85, GnnLayers.py:229-236): for a fixed node every product term of a hyperedge feature has the node's own feature
+ * as a constant factor, so the sum over the node's hyperedges is a linear map of deg(v) h[v], three sums over the OTHER two members
+ * (a_e, b_e) of its hyperedges and their products with h[v].  Two calls:
+ *
+ * ihg_node_pair_sums: sums[v] = [ sum_e h[a_e] | sum_e h[b_e] | sum_e h[a_e] * h[b_e] ]  (3 dim floats per node; * elementwise).
+ *   pair_ptr / pair_ids: CSR over the nodes with 2 ids per incident hyperedge - (query, item) for a user, (user, item) for a query,
+ *   (user, query) for an item; the split-row plan is ihg_node_segment_sum's, with segments of even length.  Any dim % 4 == 0.
+ *
+ * ihg_node_interact_fwd: out[v] = out_scale[v] * ( degree[v] (A_t h[v] + bias) + the typed blocks of w applied to the sums and their
+ *   products with h[v] ), w = [A_u | A_q | A_i | W_uq | W_qi | W_iu (| W_uqi)] as in ihg_interact_fwd, rows grouped by type_begin[4]
+ *   (host array).  degree: the node's hyperedge count as float (0 for an isolated node); out_scale / bias may be NULL.  Available where
+ *   ihg_node_interact_fwd_supported says so (dim 128, bf16-split arithmetic on); the hyperedge form (ihg_interact_fwd +
+ *   ihg_node_segment_sum) is the path everywhere else and gives the same rows to the tolerance of DESIGN.md section 5.
+ */
+int ihg_node_pair_sums(const float* h, int64_t ld_h, const int32_t* pair_ptr, const int32_t* pair_ids, const int32_t* row_order, float* sums,
+                       int64_t ld_sums, int64_t n_rows, int32_t dim, int32_t heavy_threshold, const int32_t* seg_begin, const int32_t* seg_end,
+                       int64_t n_segments, const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy, float* partials,
+                       ihg_stream_t stream);
+int32_t ihg_node_interact_fwd_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_sums, int64_t ld_out);
+int64_t ihg_node_interact_fwd_workspace_bytes(int32_t dim);
+int ihg_node_interact_fwd(const float* h, int64_t ld_h, const float* sums, int64_t ld_sums, const float* degree, const float* out_scale, const float* bias,
+                          const float* w, int64_t ld_w, int32_t order, const int64_t* type_begin, float* out, int64_t ld_out, void* workspace,
+                          int64_t workspace_bytes, int32_t dim, ihg_stream_t stream);
+
+/* ihg_node_interact_bwd_weight: dw[:, 3 dim ..] (the product blocks W_uq, W_qi, W_iu (, W_uqi)) of the layer above from node-level data only:
+ *   d W_block = sum over the nodes of (dy_scale[v] dy[v]) x X_block[v]^T, X = h * sums_a | h * sums_b | sums_ab | h * sums_ab assigned to the blocks of w by
+ *   node type - N rows instead of n_edges hyperedges, no gathers.  dy: the layer output's cotangent [N, dim]; dy_scale (NULL: 1): the out_scale of the
+ *   forward.  The first-order blocks dw[:, :3 dim] are not written (ihg_node_linear_bwd_weight has them).  With this, ihg_interact_bwd_gathered is called
+ *   with dw == NULL (member gradients only).  Available where ihg_node_interact_bwd_weight_supported says so (dim 128, bf16-split arithmetic on).
+ */
+int32_t ihg_node_interact_bwd_weight_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_sums, int64_t ld_dy);
+int64_t ihg_node_interact_bwd_weight_workspace_bytes(int32_t dim, int32_t order);
+int ihg_node_interact_bwd_weight(const float* h, int64_t ld_h, const float* sums, int64_t ld_sums, const float* dy, int64_t ld_dy, const float* dy_scale, int32_t order,
+                                 const int64_t* type_begin, float* dw, int64_t ld_dw, void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * DEVICE: node-level dense transforms (K4 and the hoisted first-order blocks of K6).

@@ -537,6 +537,85 @@ def test_forward_in_two_passes_equals_the_column_half_kernel(dim, order, monkeyp
         assert torch.equal(wide[:, dim:], got['1']) and bool((wide[:, :dim] == 7.0).all())
 
 
+def _node_sums_f64(h, i3, n_nodes):
+    """float64: per node [sum h[a] | sum h[b] | sum h[a] h[b]] over its hyperedges' other two members (a = the lower slot)."""
+    h = h.double()
+    d = h.shape[1]
+    out = torch.zeros(n_nodes, 3 * d, dtype=torch.float64)
+    for slot, (a, b) in enumerate(((1, 2), (0, 2), (0, 1))):
+        ha, hb = h[i3[:, a]], h[i3[:, b]]
+        out.index_add_(0, i3[:, slot], torch.cat([ha, hb, ha * hb], 1))
+    return out
+
+
+@pytest.mark.parametrize('dim', [8, 64, 128, 256])
+def test_pair_sums_over_the_other_members_of_a_nodes_hyperedges(dim):
+    """ihg_node_pair_sums against explicit float64 sums: one hyperedge, a handful, a graph whose 17 queries are split rows (thousands of
+    hyperedges each: segments of whole id pairs + the finish kernel over 3 d-wide partials) and isolated nodes (zero rows)."""
+    from ihgnn_amd import ops
+    for edges, thr in ((1, 1024), (33, 1024), (9000, 64), (70437, 1024)):
+        w_, lay = make_layout(301, 17, 211, edges, seed=edges, heavy_threshold=thr, edge_order='user')
+        assert (np.diff(lay.hop2_csr.seg_begin.cpu().numpy()) % 2 == 0).all() if lay.hop2_csr.n_heavy else True
+        h = torch.randn(lay.node_count, dim, generator=torch.Generator().manual_seed(edges))
+        want = _node_sums_f64(h, torch.from_numpy(lay.i3_host.astype(np.int64)), lay.node_count)
+        got = ops.node_pair_sums_raw(h.to(dev()), lay)
+        assert rel(got, want) <= RTOL_SUM, (dim, edges)
+        wide = torch.full((lay.node_count, 3 * dim + 8), 7.0, device=dev())       # a strided destination
+        ops.node_pair_sums_raw(h.to(dev()), lay, out=wide[:, :3 * dim])
+        assert torch.equal(wide[:, :3 * dim], got) and bool((wide[:, 3 * dim:] == 7.0).all())
+
+
+@pytest.mark.parametrize('order', [3, 2])
+def test_interactive_layer_without_hyperedge_rows(order, monkeypatch):
+    """d = 128: the forward of the interactive layer in its node-level form (pair sums + a node-level contraction with the typed weight
+    blocks: no [E, d] tensor) against the oracle's FeatureInteractor + segment sum in float64 and against the hyperedge form
+    (IHG_NODE_LEVEL_FORWARD=0) - with and without bias / output scale, more row tiles than workgroups, fewer, split rows, isolated nodes of
+    every type, a strided destination; the gradients of h, w and the bias against float64 autograd of the oracle, with the product blocks' weight
+    gradients from the node-level kernel (ihg_node_interact_bwd_weight: the pair sums saved by the forward) and from the hyperedge kernel."""
+    from ihgnn_amd import ops
+    from oracle import ihgnn_ref as ref
+    dim, k = 128, (7 if order == 3 else 6)
+    for edges, (U, Q, I) in ((1, (5, 3, 4)), (33, (40, 7, 50)), (300 * 32 + 5, (301, 17, 211)), (70437, (9001, 170, 4103))):
+        w_, lay = make_layout(U, Q, I, edges, seed=edges + order, edge_order='user')
+        gen = torch.Generator().manual_seed(edges)
+        h = torch.randn(lay.node_count, dim, generator=gen)
+        w = torch.randn(dim, k * dim, generator=gen) / np.sqrt(k * dim)
+        b = torch.randn(dim, generator=gen)
+        i3 = torch.from_numpy(lay.i3_host.astype(np.int64))
+        for bias, scaled in ((b, True), (None, False)):
+            h64, w64 = h.double().requires_grad_(True), w.double().requires_grad_(True)
+            b64 = (bias if bias is not None else torch.zeros(dim)).double().requires_grad_(True)
+            feats = ref.feature_interactor(h64, i3, w64, b64, order)
+            want = torch.zeros(lay.node_count, dim, dtype=torch.float64)
+            for slot in range(3):
+                want = want.index_add(0, i3[:, slot], feats)
+            scale = lay.inv_deg if scaled else None
+            if scaled:
+                want = want * lay.inv_deg.cpu().double()[:, None]
+            cot = torch.randn(want.shape, generator=torch.Generator().manual_seed(3))
+            want.backward(cot.double())
+            want_grads = [h64.grad, w64.grad] + ([b64.grad] if bias is not None else [])
+            got = {}
+            for forward_flag, weight_flag in ((True, True), (True, False), (False, False)):
+                monkeypatch.setattr(ops, 'NODE_LEVEL_FORWARD', forward_flag)
+                monkeypatch.setattr(ops, 'NODE_LEVEL_WEIGHT', weight_flag)
+                hd, wd = h.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True)
+                bd = bias.to(dev()).requires_grad_(True) if bias is not None else None
+                y = ops.interact_layer(hd, wd, bd, lay, order, scale)
+                assert rel(y, want) <= RTOL, (forward_flag, edges, scaled)
+                y.backward(cot.to(dev()))
+                for a, c in zip([hd.grad, wd.grad] + ([bd.grad] if bd is not None else []), want_grads):
+                    assert rel(a, c) <= RTOL, (forward_flag, weight_flag, edges, scaled)
+                got[forward_flag] = y.detach()
+            assert rel(got[True], got[False]) <= RTOL
+            monkeypatch.setattr(ops, 'NODE_LEVEL_WEIGHT', True)
+            monkeypatch.setattr(ops, 'NODE_LEVEL_FORWARD', True)
+            wide = torch.full((lay.node_count, 2 * dim), 7.0, device=dev())
+            with torch.no_grad():
+                ops.interact_layer(h.to(dev()), w.to(dev()), bias.to(dev()) if bias is not None else None, lay, order, scale, out=wide[:, dim:])
+            assert torch.equal(wide[:, dim:], got[True]) and bool((wide[:, :dim] == 7.0).all())
+
+
 @pytest.mark.parametrize('dim,scale', [(64, 1.0), (128, 1.0), (256, 1.0), (128, 3.0e3), (128, 2.0e-4)])
 def test_split_arithmetic_is_as_accurate_as_fp32_mfma(dim, scale, monkeypatch):
     """The order-3 contractions through three exact bf16 terms per operand (six bf16 MFMA products, fp32 accumulation; forward at d = 64 / 128,
