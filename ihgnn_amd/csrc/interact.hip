@@ -2105,7 +2105,7 @@ int ihg_node_interact_fwd(const float* h, int64_t ld_h, const float* sums, int64
         return fail(IHG_ERR_INVALID, "ihg_node_interact_fwd: dim %d / order %d / alignment not supported (ihg_node_interact_fwd_supported)", dim, order);
     if (workspace == nullptr || !aligned16(workspace) || workspace_bytes < ihg_node_interact_fwd_workspace_bytes(dim))
         return fail(IHG_ERR_WORKSPACE, "ihg_node_interact_fwd: workspace too small");
-    launch_node_fwd_split(order, h, ld_h, sums, ld_sums, degree, out_scale, bias, w, ld_w, type_begin, out, ld_out, workspace, static_cast<hipStream_t>(stream));
+    launch_node_fwd_split(dim, order, h, ld_h, sums, ld_sums, degree, out_scale, bias, w, ld_w, type_begin, out, ld_out, workspace, static_cast<hipStream_t>(stream));
     return check_launch("ihg_node_interact_fwd");
 }
 
@@ -2128,7 +2128,7 @@ int ihg_node_interact_bwd_weight(const float* h, int64_t ld_h, const float* sums
         return fail(IHG_ERR_INVALID, "ihg_node_interact_bwd_weight: dim %d / order %d / alignment not supported (ihg_node_interact_bwd_weight_supported)", dim, order);
     if (workspace == nullptr || !aligned16(workspace) || workspace_bytes < ihg_node_interact_bwd_weight_workspace_bytes(dim, order))
         return fail(IHG_ERR_WORKSPACE, "ihg_node_interact_bwd_weight: workspace too small");
-    launch_node_weight_split(order, h, ld_h, sums, ld_sums, dy, ld_dy, dy_scale, type_begin, static_cast<float*>(workspace), dw, ld_dw, static_cast<hipStream_t>(stream));
+    launch_node_weight_split(dim, order, h, ld_h, sums, ld_sums, dy, ld_dy, dy_scale, type_begin, static_cast<float*>(workspace), dw, ld_dw, static_cast<hipStream_t>(stream));
     return check_launch("ihg_node_interact_bwd_weight");
 }
 
@@ -2149,9 +2149,9 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
                                   void* workspace, int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream) {
     if (!ihg_interact_bwd_user_reduced_supported(dim, order, ld_h)) return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced: shape not supported (ask ihg_interact_bwd_user_reduced_supported)");
     const int k = order == 3 ? 7 : 6;
-    if (n_edges <= 0 || ld_h < dim || ld_dout < dim || ld_dh < dim || ld_w < static_cast<int64_t>(k) * dim || ld_dw < static_cast<int64_t>(k) * dim)
+    if (n_edges <= 0 || ld_h < dim || ld_dout < dim || ld_dh < dim || ld_w < static_cast<int64_t>(k) * dim || (dw != nullptr && ld_dw < static_cast<int64_t>(k) * dim))
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced: bad size");
-    if (h == nullptr || i3 == nullptr || w == nullptr || dout == nullptr || g2 == nullptr || dh == nullptr || dw == nullptr || workspace == nullptr)
+    if (h == nullptr || i3 == nullptr || w == nullptr || dout == nullptr || g2 == nullptr || dh == nullptr || workspace == nullptr)
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced: null pointer");
     if (ld_w % 4 || ld_dout % 4 || !aligned16(h) || !aligned16(w) || !aligned16(dout) || !aligned16(g2) || !aligned16(workspace))
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced: rows must be 16-byte aligned");
@@ -2181,11 +2181,15 @@ int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, c
     if (!ihg_interact_bwd_gathered_supported(dim, order, ld_h, ld_dy))
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: shape or arithmetic mode not supported (ask ihg_interact_bwd_gathered_supported)");
     const int k = order == 3 ? 7 : 6;
-    if (n_edges <= 0 || ld_h < dim || ld_dout < dim || ld_dh < dim || ld_w < static_cast<int64_t>(k) * dim || (dw != nullptr && ld_dw < static_cast<int64_t>(k) * dim))
+    if (n_edges <= 0 || ld_h < dim || (dout != nullptr && ld_dout < dim) || ld_dh < dim || ld_w < static_cast<int64_t>(k) * dim || (dw != nullptr && ld_dw < static_cast<int64_t>(k) * dim))
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: bad size");
-    if (h == nullptr || i3 == nullptr || w == nullptr || dy == nullptr || dout == nullptr || g2 == nullptr || dh == nullptr || workspace == nullptr)
+    if (h == nullptr || i3 == nullptr || w == nullptr || dy == nullptr || (dout == nullptr && dw != nullptr) || g2 == nullptr || dh == nullptr || workspace == nullptr)
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: null pointer");
-    if (ld_w % 4 || ld_dout % 4 || !aligned16(h) || !aligned16(w) || !aligned16(dy) || !aligned16(dout) || !aligned16(g2) || !aligned16(workspace))
+    if (dout == nullptr) {                                               // the hyperedges' cotangents are formed and used on chip only
+        dout = g2;
+        ld_dout = -1;
+    }
+    if (ld_w % 4 || (ld_dout > 0 && ld_dout % 4) || !aligned16(h) || !aligned16(w) || !aligned16(dy) || !aligned16(dout) || !aligned16(g2) || !aligned16(workspace))
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: rows must be 16-byte aligned");
     if (workspace_bytes < ihg_interact_bwd_workspace_bytes(n_edges, dim, order)) return fail(IHG_ERR_WORKSPACE, "ihg_interact_bwd_gathered: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2195,7 +2199,7 @@ int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, c
     float* bnd_val = slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order);
     int32_t* bnd_user = reinterpret_cast<int32_t*>(bnd_val + 2LL * kPipeGrid * dim);
     void* planes = bnd_user + 2LL * kPipeGrid;
-    if (!split_members_ok(dim, order, g2, ld_h, ld_dy, dy, true) || !split_weight_ok(dim, order, ld_h, ld_dout, dout))
+    if (!split_members_ok(dim, order, g2, ld_h, ld_dy, dy, true) || (dw != nullptr && !split_weight_ok(dim, order, ld_h, ld_dout, dout)))
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: the split kernels do not take these strides / alignments");
     if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dy, ld_dy, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes, dy_scale, dout, ld_dout);
     else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dy, ld_dy, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes, dy_scale, dout, ld_dout);
@@ -2207,9 +2211,9 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const floa
                      int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream) {
     if (order != 2 && order != 3) return fail(IHG_ERR_INVALID, "ihg_interact_bwd: order must be 2 or 3, got %d", order);
     const int k = order == 3 ? 7 : 6;
-    if (n_edges < 0 || dim <= 0 || ld_h < dim || ld_dout < dim || ld_w < static_cast<int64_t>(k) * dim || ld_dw < static_cast<int64_t>(k) * dim)
+    if (n_edges < 0 || dim <= 0 || ld_h < dim || ld_dout < dim || ld_w < static_cast<int64_t>(k) * dim || (dw != nullptr && ld_dw < static_cast<int64_t>(k) * dim))
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd: bad size");
-    if (h == nullptr || i3 == nullptr || w == nullptr || dout == nullptr || g == nullptr || dw == nullptr)
+    if (h == nullptr || i3 == nullptr || w == nullptr || dout == nullptr || g == nullptr)
         return fail(IHG_ERR_INVALID, "ihg_interact_bwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool tiled = mfma_dim(dim) && n_edges > 0 && ld_h % 4 == 0 && ld_w % 4 == 0 && ld_dout % 4 == 0 && aligned16(h) && aligned16(w) &&
@@ -2238,6 +2242,7 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const floa
         const int grid = static_cast<int>(std::min<int64_t>((total + kBlockThreads - 1) / kBlockThreads, kMaxBlocks * 4));
         hipLaunchKernelGGL(interact_bwd_members_generic_kernel, dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, w, ld_w, order, dout, ld_dout, g, n_edges, dim);
     }
+    if (dw == nullptr) return check_launch("ihg_interact_bwd");
     const int64_t wtotal = static_cast<int64_t>(dim) * (order == 3 ? 4 : 3) * dim;
     const int wgrid = static_cast<int>(std::min<int64_t>((wtotal + kBlockThreads - 1) / kBlockThreads, kMaxBlocks * 4));
     hipLaunchKernelGGL(interact_bwd_weight_generic_kernel, dim3(wgrid), dim3(kBlockThreads), 0, s, h, ld_h, i3, order, dout, ld_dout, dw, ld_dw, n_edges, dim);

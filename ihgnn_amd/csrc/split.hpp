@@ -42,16 +42,16 @@ IHG_INTERNAL int launch_dense_weight_split(int dim, const float* dout, int64_t l
                                            float* slabs, float* bias_slabs, const float* w, int64_t ld_w, int64_t w_type_stride, float* dx, int64_t ld_dx,
                                            void* planes, hipStream_t s, int dx_accumulate = 0);   // dx != nullptr (dim 128, 16-byte aligned rows): dx (+)= dout W_t of the same rows, fused
 
-// node-level form of the interactive layer's forward (d = 128): out = scale * (sum over the node's hyperedges of their features) from h and the
+// node-level form of the interactive layer's forward (d = 64 / 128 / 256): out = scale * (sum over the node's hyperedges of their features) from h and the
 // pair sums of ihg_node_pair_sums; planes: split_node_fwd_plane_floats(dim) floats of workspace
 IHG_INTERNAL int64_t split_node_fwd_plane_floats(int dim);
 IHG_INTERNAL bool split_node_fwd_ok(int dim, int order, int64_t ld_h, int64_t ld_s, const float* out, int64_t ld_out, const float* bias);
-IHG_INTERNAL void launch_node_fwd_split(int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* deg, const float* scale, const float* bias,
+IHG_INTERNAL void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* deg, const float* scale, const float* bias,
                                         const float* w, int64_t ld_w, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s);
 
-// node-level weight gradients of the product blocks (d = 128): dw[:, 3 d ..] from h, the pair sums and the node-level cotangent; slabs:
+// node-level weight gradients of the product blocks (d = 64 / 128 / 256): dw[:, 3 d ..] from h, the pair sums and the node-level cotangent; slabs:
 // split_node_weight_slab_floats(dim, order) floats of workspace
 IHG_INTERNAL int64_t split_node_weight_slab_floats(int dim, int order);
 IHG_INTERNAL bool split_node_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_s, int64_t ld_dy, const float* dy);
-IHG_INTERNAL void launch_node_weight_split(int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* dy, int64_t ld_dy, const float* dy_scale,
+IHG_INTERNAL void launch_node_weight_split(int dim, int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* dy, int64_t ld_dy, const float* dy_scale,
                                            const int64_t* type_begin, float* slabs, float* dw, int64_t ld_dw, hipStream_t s);

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 dr[j] = acc;
             }
             const int64_t e0 = (t0 + k) * TE;
-            if (k < n_my && e0 + row < n_edges) {
+            if (ld_store > 0 && k < n_my && e0 + row < n_edges) {       // (ld_store <= 0: nobody reads the hyperedges' cotangents after this kernel)
                 float* dst = dout_store + (e0 + row) * ld_store + 64 * half + 8 * o;
                 store_stream4(dst, dr[2 * half]);
                 store_stream4(dst + 4, dr[2 * half + 1]);
@@ -1163,6 +1163,197 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same node-level forward for d = 64 / 128 / 256 in one geometry: a workgroup owns 64 output columns (`part`) and up to 512 values of the
+// contraction index per pass - matrix wave m: 16 columns x 512 values = the 192 weight registers - over tiles of 16 node rows.  The seven
+// source blocks X = [deg h | S_a | h S_a | S_b | h S_b | S_ab | h S_ab] come 512 / d to a pass: d = 64: ONE pass, d = 128: two (x 2 column parts),
+// d = 256: four (x 4 parts; the parts of a tile range are adjacent workgroups on one XCD and share the rows through its L2).  At d = 128 this
+// halves the passes of the kernel above, and is slower (C3: 592 against 543 us - one accumulator tile per matrix wave, twice the split work): d = 128 keeps
+// the four passes of 256 values unless IHG_NODE_FWD_Q=1.
+// wnq[type][pass][part][m][kb < 16][plane][lane][8]: element i = plane of W[64 part + 16 m + (lane & 15)][block(type, xb) d + c], where
+//   kk = 32 kb + 8 (lane >> 4) + i,  xb = pass (512 / d) + kk / d,  c = kk % d     (xb > 6, or the uqi block at order 2: zeros)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int node_xblock_weight(int type, int xb) {
+    constexpr signed char kBlock[3][7] = {{0, 1, 3, 2, 5, 4, 6}, {1, 0, 3, 2, 4, 5, 6}, {2, 0, 5, 1, 4, 3, 6}};
+    return kBlock[type][xb];
+}
+
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd_q_kernel(const float* __restrict__ w, int64_t ld_w, int d, int order, v4u* __restrict__ wnq) {
+    const int bpp = 512 / d, n_pass = (7 + bpp - 1) / bpp, parts = d / 64;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * n_pass * parts * 4 * 16 * kWave) return;
+    const int lane = idx & 63, kb = (idx >> 6) & 15, m = (idx >> 10) & 3;
+    int rest = idx >> 12;
+    const int part = rest % parts;
+    rest /= parts;
+    const int pass = rest % n_pass, type = rest / n_pass;
+    const int kk = 32 * kb + 8 * (lane >> 4), xb = pass * bpp + kk / d, c = kk % d;
+    int b = xb < 7 ? node_xblock_weight(type, xb) : -1;
+    if (b == 6 && order != 3) b = -1;
+    Planes pl;
+    if (b >= 0) {
+        const float* src = w + static_cast<int64_t>(64 * part + 16 * m + (lane & 15)) * ld_w + static_cast<int64_t>(b) * d + c;
+        pl = split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]});
+    } else {
+        pl = split8(v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f});
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wnq[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
+}
+
+template <int D, int PASS, bool ACC, bool FINAL>
+__global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
+                                                                            const float* __restrict__ deg, const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                            const v4u* __restrict__ wnq, RowTiles plan, float* __restrict__ out, int64_t ld_out) {
+    constexpr int BPP = 512 / D, XB0 = PASS * BPP, NB = (7 - XB0) < BPP ? (7 - XB0) : BPP, NPASS = (7 + BPP - 1) / BPP, PARTS = D / 64;
+    constexpr int TE = 16, KB = NB * D / 32, ZRB = (2 * NB * D + 255) / 256 * 256, ZPL = TE * ZRB, PS = 64 + 4, X = D / 64;
+    constexpr bool NEED_A = XB0 <= 2 && XB0 + NB > 1, NEED_B = XB0 <= 4 && XB0 + NB > 3, NEED_AB = XB0 + NB > 5, NEED_DEG = XB0 == 0;
+    static_assert(NB >= 1 && KB <= 16, "pass shape");
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
+    __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int cpart = PARTS == 1 ? 0 : (bid >> 3) & (PARTS - 1);
+    const int range = PARTS == 1 ? bid : (bid & 7) + 8 * (bid / (8 * PARTS)), n_ranges = static_cast<int>(gridDim.x) / PARTS;
+    const int total_tiles = plan.tile_prefix[3];
+    const int per = (total_tiles + n_ranges - 1) / n_ranges;
+    const int t0 = range * per;
+    const int n_my = std::max(0, std::min(per, total_tiles - t0));
+    if (n_my == 0) return;
+    const int coff = 64 * cpart;
+    auto tile_rows = [&](int k, int64_t& r_base, int64_t& r_end) {      // (tiles past the range: the graph's last tile, read and dropped)
+        const int tile_id = std::min(t0 + k, total_tiles - 1);
+        const int type = tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0);
+        r_base = plan.begin[type] + static_cast<int64_t>(tile_id - plan.tile_prefix[type]) * TE;
+        r_end = plan.begin[type + 1];
+        return type;
+    };
+
+    role_priority(wave >= 4);
+    if (wave >= 4) {
+        // ---------------- service waves: thread -> node row of the tile, source columns 4 o + 64 x .. (x < D / 64), output columns coff + 4 o ..
+        const int st = tid - 256, row = st >> 4, o = st & 15;
+        struct Piece { v4f hv[X], sa[X], sb[X], sab[X]; float d; };
+        auto load_piece = [&](int k, Piece& pc) {
+            int64_t r_base, r_end;
+            tile_rows(k, r_base, r_end);
+            const int64_t v = std::min(r_base + row, r_end - 1);
+            const float* hp = h + v * ld_h + 4 * o;
+            const float* sp = sums + v * ld_s + 4 * o;
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+                pc.hv[x] = *reinterpret_cast<const v4f*>(hp + 64 * x);
+                if (NEED_A) pc.sa[x] = *reinterpret_cast<const v4f*>(sp + 64 * x);
+                if (NEED_B) pc.sb[x] = *reinterpret_cast<const v4f*>(sp + D + 64 * x);
+                if (NEED_AB) pc.sab[x] = *reinterpret_cast<const v4f*>(sp + 2 * D + 64 * x);
+            }
+            if (NEED_DEG) pc.d = deg[v];
+        };
+        struct First { v4f old; float d, sc; };
+        auto load_first = [&](int k, First& f) {
+            int64_t r_base, r_end;
+            tile_rows(k, r_base, r_end);
+            const int64_t v = std::min(r_base + row, r_end - 1);
+            if (ACC) f.old = *reinterpret_cast<const v4f*>(out + v * ld_out + coff + 4 * o);
+            else f.d = deg[v];
+            if (FINAL) f.sc = scale != nullptr ? scale[v] : 1.f;
+        };
+        auto split_tile = [&](const Piece& pc, int buf) {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+#pragma unroll
+                for (int b2 = 0; b2 < NB; ++b2) {
+                    const int xb = XB0 + b2;
+                    const v4f z = xb == 0 ? pc.hv[x] * pc.d : xb == 1 ? pc.sa[x] : xb == 2 ? pc.hv[x] * pc.sa[x] : xb == 3 ? pc.sb[x] : xb == 4 ? pc.hv[x] * pc.sb[x]
+                                  : xb == 5 ? pc.sab[x] : pc.hv[x] * pc.sab[x];
+                    unsigned w0[3], w1[3];
+                    split_pair(z[0], z[1], w0);
+                    split_pair(z[2], z[3], w1);
+                    // columns D b2 + 64 x + 4 o ..: chunk (D / 8) b2 + 8 x + (o >> 1), half o & 1
+                    const int off = row * ZRB + ((((D / 8) * b2 + 8 * x + (o >> 1)) ^ row) << 4) + 8 * (o & 1);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + pl * ZPL + off) = v2u{w0[pl], w1[pl]};
+                }
+            }
+        };
+        auto epilogue = [&](int k, const First& f) {
+            int64_t r_base, r_end;
+            tile_rows(k, r_base, r_end);
+            const int64_t v = r_base + row;
+            v4f val = *reinterpret_cast<const v4f*>(&part[k & 1][row][4 * o]);
+            if (ACC) val += f.old;
+            else if (bias != nullptr) val += *reinterpret_cast<const v4f*>(bias + coff + 4 * o) * f.d;
+            if (FINAL) val *= f.sc;
+            if (v < r_end) *reinterpret_cast<v4f*>(out + v * ld_out + coff + 4 * o) = val;
+        };
+        Piece pc0, pc1;
+        First f;
+        load_piece(0, pc0);
+        load_piece(1, pc1);
+        split_tile(pc0, 0);
+        __syncthreads();
+        auto phase = [&](int k, const Piece& use, Piece& fill) {
+            load_piece(k + 2, fill);
+            if (k >= 1) load_first(k - 1, f);
+            if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
+            if (k >= 1) epilogue(k - 1, f);
+            __syncthreads();
+        };
+        int k = 0;
+#pragma clang loop unroll(disable)
+        for (; k + 1 <= n_my; k += 2) {
+            phase(k, pc1, pc0);
+            phase(k + 1, pc0, pc1);
+        }
+        if (k <= n_my) phase(k, pc1, pc0);
+        return;
+    }
+
+    // ---------------- matrix waves: wave m = output columns coff + 16 m .. + 15, the pass's whole contraction index
+    v8s wreg[KB][3];
+    int cur_type = -1;
+    __syncthreads();
+    const int arow = lane & 15, kq = lane >> 4;
+    for (int k = 0; k <= n_my; ++k) {
+        if (k < n_my) {
+            int64_t r_base, r_end;
+            const int type = tile_rows(k, r_base, r_end);
+            if (type != cur_type) {
+                const v4u* wf = wnq + (static_cast<int64_t>((type * NPASS + PASS) * PARTS + cpart) * 4 + wave) * (16 * 3 * kWave) + lane;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wreg[kb][pl] = __builtin_bit_cast(v8s, wf[(kb * 3 + pl) * kWave]);
+                cur_type = type;
+            }
+            const unsigned char* zp = &zplanes[k & 1][0][0][0] + arow * ZRB;
+            auto fragment = [&](int kb, v8s (&a)[3]) {
+                const unsigned char* src = zp + (((4 * kb + kq) ^ arow) << 4);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const v8s*>(src + pl * ZPL);
+            };
+            v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};       // one column tile per wave: two chains, alternate products
+            v8s a[3], an[3];
+            fragment(0, a);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                if (kb + 1 < KB) fragment(kb + 1, an);
+                IHG_PIN_ORDER();
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+                    acc[term & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][kTermB[term]], a[kTermA[term]], acc[term & 1], 0, 0, 0);
+                IHG_PIN_ORDER();
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[pl] = an[pl];
+            }
+            *reinterpret_cast<v4f*>(&part[k & 1][arow][16 * wave + 4 * kq]) = acc[0] + acc[1];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Forward at d = 256 (the kernel is written for d = 128 as well, where the resident-weights form above is faster), without eightfold product work: the contraction index is walked in CHUNKS of 128 (one product block, or
 // half of one at d = 256), one chunk per phase.  The matrix waves own the OUTPUT - wave m: 32 columns x the tile's 32 hyperedges,
 // accumulators kept across the chunks - and do not keep the weights: the 24 weight fragments of the next chunk (24 KB per wave, the planes
@@ -1586,7 +1777,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight gradients of the interactive layer's product blocks at NODE level (d = 128).  The layer's output row is
+// Weight gradients of the interactive layer's product blocks at NODE level (d = 64 / 128 / 256; column parts as in the hyperedge form).  The layer's output row is
 //     y[v] = scale[v] * ( ... + P_a (h S_a) + P_b (h S_b) + L_ab S_ab + W_uqi (h S_ab) )      (node_interact_fwd_kernel),
 // so d W_block = sum over the nodes of (scale dy)[v] x X_block[v]^T with X = [h S_a | h S_b | S_ab | h S_ab] - N rows instead of E hyperedges, no
 // member gathers.  The kernel is the hyperedge form's (interact_bwd_weight_split_ws_kernel: matrix wave b = block b with 8 x 4 accumulator
@@ -1599,18 +1790,18 @@ struct NodeRanges {
     int range_prefix[4];   // tile ranges before type t (range_prefix[3] = ranges in all)
 };
 
-template <int NBLK>
+template <int D, int NBLK>
 __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
                                                                                    const float* __restrict__ dy, int64_t ld_dy, const float* __restrict__ dy_scale,
                                                                                    NodeRanges plan, float* __restrict__ slabs) {
-    constexpr int D = 128, TE = kSplitTE, HC = 64, CT = HC / 16, JT = D / 16;
-    constexpr int DRB = 2 * D, ZRB = 8 * HC, DOCT = 2, ZX = 2, DPL = TE * DRB, ZPL = TE * ZRB;
+    constexpr int TE = kSplitTE, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), HC = D / PARTS, CT = HC / 16, JT = D / 16;
+    constexpr int DRB = 2 * D < 256 ? 256 : 2 * D, ZRB = 8 * HC, DOCT = D / 64, ZX = HC / 32, DPL = TE * DRB, ZPL = TE * ZRB;
     __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][DRB];
     __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x;
-    const int half = (bid >> 3) & 1, range = (bid & 7) + 8 * (bid >> 4);
+    const int half = (bid >> 3) & (PARTS - 1), range = (bid & 7) + 8 * (bid / (8 * PARTS));      // `half`: this workgroup's column part
     const int type = range >= plan.range_prefix[2] ? 2 : (range >= plan.range_prefix[1] ? 1 : 0);
     const int64_t r_begin = plan.begin[type], r_end = plan.begin[type + 1];
     const int n_tiles = static_cast<int>((r_end - r_begin + TE - 1) / TE);
@@ -1767,8 +1958,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
 
 // dw[j][(3 + b) d + c] = sum over the node types of the sum over the type's slabs at the X block that stands for w block b there
 // (b: 0 = uq, 1 = qi, 2 = iu, 3 = uqi; fixed order: users, queries, items, slabs in range order - bitwise reproducible)
-__global__ __launch_bounds__(kBlockThreads) void node_weight_reduce_kernel(const float* __restrict__ slabs, NodeRanges plan, int nblk, float* __restrict__ dw, int64_t ld_dw) {
-    constexpr int d = 128;
+__global__ __launch_bounds__(kBlockThreads) void node_weight_reduce_kernel(const float* __restrict__ slabs, NodeRanges plan, int d, int nblk, float* __restrict__ dw, int64_t ld_dw) {
     constexpr signed char kPos[3][4] = {{0, 2, 1, 3}, {0, 1, 2, 3}, {2, 1, 0, 3}};      // [type][w block] -> X block
     const int width = nblk * d;
     const int64_t total = static_cast<int64_t>(d) * width;
@@ -2244,46 +2434,92 @@ void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float*
     }
 }
 
-// node-level forward of the interactive layer (d = 128): see node_interact_fwd_kernel
-int64_t split_node_fwd_plane_floats(int dim) { return dim == 128 ? 3LL * 4 * kNodePassV4 * 4 : 0; }
-
-bool split_node_fwd_ok(int dim, int order, int64_t ld_h, int64_t ld_s, const float* out, int64_t ld_out, const float* bias) {
-    return split_arith_enabled() && dim == 128 && (order == 2 || order == 3) && ld_ok(ld_h) && ld_ok(ld_s) && ld_ok(ld_out) && aligned16(out) && (bias == nullptr || aligned16(bias));
+// node-level forward of the interactive layer: see node_interact_fwd_q_kernel (d = 64 / 128 / 256) and node_interact_fwd_kernel (d = 128, IHG_NODE_FWD_Q=0)
+static bool node_fwd_q_enabled() {                                       // d = 128 only: IHG_NODE_FWD_Q=1 selects the 64-column geometry there too (A/B, tests; C3: 592 against 543 us)
+    const char* v = std::getenv("IHG_NODE_FWD_Q");
+    return v != nullptr && std::strcmp(v, "1") == 0;
 }
 
-void launch_node_fwd_split(int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* deg, const float* scale, const float* bias, const float* w,
-                           int64_t ld_w, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s) {
-    v4u* wnp = static_cast<v4u*>(planes);
-    hipLaunchKernelGGL(pack_planes_node_fwd_kernel, dim3((3 * 4 * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, order, wnp);
+static int64_t node_fwd_q_v4(int dim) {                                  // v4u of the q kernel's planes
+    const int bpp = 512 / dim, n_pass = (7 + bpp - 1) / bpp, parts = dim / 64;
+    return 3LL * n_pass * parts * 4 * 16 * 3 * kWave;
+}
+
+int64_t split_node_fwd_plane_floats(int dim) {
+    if (dim != 64 && dim != 128 && dim != 256) return 0;
+    return std::max<int64_t>(node_fwd_q_v4(dim), dim == 128 ? 3LL * 4 * kNodePassV4 : 0) * 4;
+}
+
+bool split_node_fwd_ok(int dim, int order, int64_t ld_h, int64_t ld_s, const float* out, int64_t ld_out, const float* bias) {
+    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) && ld_ok(ld_h) && ld_ok(ld_s) && ld_ok(ld_out) && aligned16(out) &&
+           (bias == nullptr || aligned16(bias));
+}
+
+static RowTiles row_tiles(const int64_t* type_begin, int rows_per_tile) {
     RowTiles plan;
     int acc = 0;
     for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
     for (int t = 0; t < 3; ++t) {
         plan.tile_prefix[t] = acc;
-        acc += static_cast<int>((type_begin[t + 1] - type_begin[t] + 31) / 32);
+        acc += static_cast<int>((type_begin[t + 1] - type_begin[t] + rows_per_tile - 1) / rows_per_tile);
     }
     plan.tile_prefix[3] = acc;
-    if (acc == 0) return;
-    const int grid = std::min(acc, 256);
+    return plan;
+}
+
+void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* deg, const float* scale, const float* bias,
+                           const float* w, int64_t ld_w, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s) {
+    v4u* wnp = static_cast<v4u*>(planes);
+    if (dim == 128 && !node_fwd_q_enabled()) {
+        hipLaunchKernelGGL(pack_planes_node_fwd_kernel, dim3((3 * 4 * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, order, wnp);
+        const RowTiles plan = row_tiles(type_begin, 32);
+        if (plan.tile_prefix[3] == 0) return;
+        const int grid = std::min(plan.tile_prefix[3], 256);
 #define IHG_NODE_PASS(KIND, ACC, FINAL, PASS, BLK)                                                                                                          \
     hipLaunchKernelGGL((node_interact_fwd_kernel<KIND, ACC, FINAL>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums + (BLK) * 128, ld_s, deg, scale, bias, \
                        wnp + (PASS) * kNodePassV4, plan, out, ld_out)
-    IHG_NODE_PASS(2, false, false, 0, 0);
-    IHG_NODE_PASS(0, true, false, 1, 0);
-    IHG_NODE_PASS(0, true, false, 2, 1);
-    if (order == 3) IHG_NODE_PASS(0, true, true, 3, 2);
-    else IHG_NODE_PASS(1, true, true, 3, 2);
+        IHG_NODE_PASS(2, false, false, 0, 0);
+        IHG_NODE_PASS(0, true, false, 1, 0);
+        IHG_NODE_PASS(0, true, false, 2, 1);
+        if (order == 3) IHG_NODE_PASS(0, true, true, 3, 2);
+        else IHG_NODE_PASS(1, true, true, 3, 2);
 #undef IHG_NODE_PASS
+        return;
+    }
+    const int items = static_cast<int>(node_fwd_q_v4(dim) / 3);
+    hipLaunchKernelGGL(pack_planes_node_fwd_q_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, order, wnp);
+    const RowTiles plan = row_tiles(type_begin, 16);
+    if (plan.tile_prefix[3] == 0) return;
+    const int parts = dim / 64;
+    const int n_ranges = std::min((plan.tile_prefix[3] + 7) / 8 * 8, 256 / parts);      // a multiple of 8: the parts of a range land on one XCD
+#define IHG_NODE_Q(D, PASS, ACC, FINAL) \
+    hipLaunchKernelGGL((node_interact_fwd_q_kernel<D, PASS, ACC, FINAL>), dim3(n_ranges * parts), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, plan, out, ld_out)
+    if (dim == 64) {
+        IHG_NODE_Q(64, 0, false, true);
+    } else if (dim == 128) {
+        IHG_NODE_Q(128, 0, false, false);
+        IHG_NODE_Q(128, 1, true, true);
+    } else {
+        IHG_NODE_Q(256, 0, false, false);
+        IHG_NODE_Q(256, 1, true, false);
+        IHG_NODE_Q(256, 2, true, false);
+        IHG_NODE_Q(256, 3, true, true);
+    }
+#undef IHG_NODE_Q
 }
 
-// node-level weight gradients of the product blocks (d = 128): see node_interact_weight_split_kernel
-int64_t split_node_weight_slab_floats(int dim, int order) { return dim == 128 ? static_cast<int64_t>(kSplitRanges) * dim * (order == 3 ? 4 : 3) * dim : 0; }
+// node-level weight gradients of the product blocks (d = 64 / 128 / 256): see node_interact_weight_split_kernel
+static int node_weight_ranges(int dim) { return dim == 64 ? 256 : (dim == 128 ? 128 : 32); }
+
+int64_t split_node_weight_slab_floats(int dim, int order) {
+    return dim == 64 || dim == 128 || dim == 256 ? static_cast<int64_t>(node_weight_ranges(dim)) * dim * (order == 3 ? 4 : 3) * dim : 0;
+}
 
 bool split_node_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_s, int64_t ld_dy, const float* dy) {
-    return split_arith_enabled() && dim == 128 && (order == 2 || order == 3) && ld_ok(ld_h) && ld_ok(ld_s) && ld_ok(ld_dy) && aligned16(dy);
+    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) && ld_ok(ld_h) && ld_ok(ld_s) && ld_ok(ld_dy) && aligned16(dy);
 }
 
-void launch_node_weight_split(int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* dy, int64_t ld_dy, const float* dy_scale,
+void launch_node_weight_split(int dim, int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* dy, int64_t ld_dy, const float* dy_scale,
                               const int64_t* type_begin, float* slabs, float* dw, int64_t ld_dw, hipStream_t s) {
     NodeRanges plan;
     int64_t tiles[3], total = 0;
@@ -2292,25 +2528,28 @@ void launch_node_weight_split(int order, const float* h, int64_t ld_h, const flo
         tiles[t] = (type_begin[t + 1] - type_begin[t] + kSplitTE - 1) / kSplitTE;
         total += tiles[t];
     }
-    // tile ranges by type in proportion to the tiles, every non-empty type at least one, kSplitRanges in all at most
-    int n[3], used = 0;
-    for (int t = 0; t < 3; ++t) {
-        n[t] = tiles[t] == 0 ? 0 : static_cast<int>(std::max<int64_t>(1, tiles[t] * (kSplitRanges - 2) / std::max<int64_t>(total, 1)));
-        n[t] = static_cast<int>(std::min<int64_t>(n[t], tiles[t]));
-        used += n[t];
-    }
+    // tile ranges by type in proportion to the tiles, every non-empty type at least one, `ranges` in all at most
+    const int ranges = node_weight_ranges(dim);
     int acc = 0;
     for (int t = 0; t < 3; ++t) {
+        int n = tiles[t] == 0 ? 0 : static_cast<int>(std::max<int64_t>(1, tiles[t] * (ranges - 2) / std::max<int64_t>(total, 1)));
+        n = static_cast<int>(std::min<int64_t>(n, tiles[t]));
         plan.range_prefix[t] = acc;
-        acc += n[t];
+        acc += n;
     }
     plan.range_prefix[3] = acc;
-    (void)used;
     const int nblk = order == 3 ? 4 : 3;
-    if (order == 3) hipLaunchKernelGGL((node_interact_weight_split_kernel<4>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);
-    else hipLaunchKernelGGL((node_interact_weight_split_kernel<3>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);
-    const int total_w = 128 * nblk * 128;
-    hipLaunchKernelGGL(node_weight_reduce_kernel, dim3((total_w + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, plan, nblk, dw, ld_dw);
+#define IHG_NODE_WEIGHT(D)                                                                                                                                   \
+    {                                                                                                                                                        \
+        if (order == 3) hipLaunchKernelGGL((node_interact_weight_split_kernel<D, 4>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs); \
+        else hipLaunchKernelGGL((node_interact_weight_split_kernel<D, 3>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);           \
+    }
+    if (dim == 64) IHG_NODE_WEIGHT(64)
+    else if (dim == 128) IHG_NODE_WEIGHT(128)
+    else IHG_NODE_WEIGHT(256)
+#undef IHG_NODE_WEIGHT
+    const int total_w = dim * nblk * dim;
+    hipLaunchKernelGGL(node_weight_reduce_kernel, dim3((total_w + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, plan, dim, nblk, dw, ld_dw);
 }
 
 bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout) {

@@ -508,6 +508,8 @@ CHECK_SPARSE_COTANGENT = _os.environ.get('IHG_CHECK_SPARSE_COTANGENT', '0') == '
 NODE_LEVEL_FORWARD = _os.environ.get('IHG_NODE_LEVEL_FORWARD', '1') != '0'
 # ... and the product blocks' weight gradients from node-level data (ihg_node_interact_bwd_weight) after such a forward; IHG_NODE_LEVEL_WEIGHT=0: the hyperedge kernel
 NODE_LEVEL_WEIGHT = _os.environ.get('IHG_NODE_LEVEL_WEIGHT', '1') != '0'
+# ... and then the first-order gradient d P = H H^T (scale * dy) by the two-hop operator instead of a scatter of stored [E, d] cotangents (IHG_FIRST_ORDER_TWO_HOP=1; measured at C3: 8.81 against 8.74 ms per step for store + scatter, the default)
+FIRST_ORDER_TWO_HOP = _os.environ.get('IHG_FIRST_ORDER_TWO_HOP', '0') != '0'
 
 
 def _node_level_forward_ok(h: Tensor, w: Tensor, bias: Optional[Tensor], out: Optional[Tensor], dim: int, order: int) -> bool:
@@ -529,9 +531,9 @@ def _zero_isolated_users(dh: Tensor, layout: IncidenceLayout) -> None:
         dh.index_fill_(0, idx, 0.0)
 
 
-def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: IncidenceLayout, order: int, dw: Tensor) -> Tensor:
-    """Product-block weight gradient into ``dw`` (its columns from ``3 d`` on) and the member gradients scattered to nodes
-    (returned).  One pass when the ``[E, 3, d]`` buffer fits ``MEMBER_BUFFER_LIMIT_BYTES``, otherwise hyperedge chunks, each with
+def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: IncidenceLayout, order: int, dw: Optional[Tensor]) -> Tensor:
+    """Product-block weight gradient into ``dw`` (its columns from ``3 d`` on; ``None``: not wanted - the caller has it from the node-level
+    kernel) and the member gradients scattered to nodes (returned).  One pass when the ``[E, 3, d]`` buffer fits ``MEMBER_BUFFER_LIMIT_BYTES``, otherwise hyperedge chunks, each with
     its own member lists (``IncidenceLayout.member_csr_chunks``): same sums, associated chunk by chunk."""
     lib = _lib.load()
     n_edges, dim = layout.edge_count, int(h.shape[1])
@@ -548,7 +550,7 @@ def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: Incidence
         ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
         with profiler.kernel('interact_bwd', n_edges, dim):
             _lib.check(lib.ihg_interact_bwd_user_reduced(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(grad_out), _ld(grad_out), _ptr(g2),
-                                                         _ptr(dh), dim, _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4, n_edges, dim, _stream()),
+                                                         _ptr(dh), dim, _ptr(dw), _ld(dw) if dw is not None else 0, _ptr(ws), ws.numel() * 4, n_edges, dim, _stream()),
                        'ihg_interact_bwd_user_reduced')
         node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients')
         return dh
@@ -560,14 +562,14 @@ def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: Incidence
     for index, (e0, e1, csr) in enumerate(parts):
         n = e1 - e0
         g = torch.empty(n, 3 * dim, dtype=torch.float32, device=h.device)
-        dw_part = dw if index == 0 else torch.empty_like(dw)
+        dw_part = dw if index == 0 or dw is None else torch.empty_like(dw)
         ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n, dim, order)), h.device)
         go = grad_out[e0:e1]
         with profiler.kernel('interact_bwd', n, dim):
             _lib.check(lib.ihg_interact_bwd(_ptr(h), _ld(h), _ptr(layout.i3[e0:e1]), _ptr(w), _ld(w), order, _ptr(go), _ld(grad_out),
-                                            _ptr(g), _ptr(dw_part), _ld(dw_part), _ptr(ws), ws.numel() * 4, n, dim, _stream()),
+                                            _ptr(g), _ptr(dw_part), _ld(dw_part) if dw_part is not None else 0, _ptr(ws), ws.numel() * 4, n, dim, _stream()),
                        'ihg_interact_bwd')
-        if index > 0:
+        if index > 0 and dw is not None:
             dw[:, 3 * dim:].add_(dw_part[:, 3 * dim:])
         # (node v, hyperedge e) reads row 3 (e - e0) + type(v); the chunks after the first ADD onto dh inside the kernel (no [N, d] add pass)
         dh = node_segment_sum_raw(g.view(3 * n, dim), csr, role='k7.member_gradients', out=dh, accumulate=dh is not None)
@@ -727,7 +729,7 @@ class _InteractLayer(torch.autograd.Function):
         dw = torch.empty_like(w)                               # product blocks from the interact kernels, first-order blocks from the row-GEMM pass
         gathered = _gathered_backward_ok(h, w, dy, layout, order)
         # the product blocks' weight gradients from node-level data (N rows, no gathers) where the forward left the pair sums
-        node_weight = (gathered and sums is not None and NODE_LEVEL_WEIGHT and dy.data_ptr() % 16 == 0 and _ld(dw) % 4 == 0
+        node_weight = (sums is not None and NODE_LEVEL_WEIGHT and dy.data_ptr() % 16 == 0 and _ld(dw) % 4 == 0 and h.data_ptr() % 16 == 0
                        and bool(lib.ihg_node_interact_bwd_weight_supported(dim, order, _ld(h), _ld(sums), _ld(dy))))
         if node_weight:
             ws_w = _workspace(int(lib.ihg_node_interact_bwd_weight_workspace_bytes(dim, order)), h.device)
@@ -737,7 +739,10 @@ class _InteractLayer(torch.autograd.Function):
         del sums
         if gathered:
             csr_qi, qi_rows = layout.member_csr_qi()
-            dout = torch.empty(n_edges, dim, dtype=torch.float32, device=h.device)
+            # with the weight gradients taken at node level nobody but the first-order scatter would read the hyperedges' cotangents: that scatter is
+            # the two-hop operator applied to the node-level cotangent, and the [E, d] rows are not stored at all
+            keep_dout = not (node_weight and FIRST_ORDER_TWO_HOP)
+            dout = torch.empty(n_edges, dim, dtype=torch.float32, device=h.device) if keep_dout else None
             g2 = torch.empty(n_edges, 2 * dim, dtype=torch.float32, device=h.device)
             dh = torch.empty(layout.node_count, dim, dtype=torch.float32, device=h.device)
             _zero_isolated_users(dh, layout)
@@ -748,13 +753,16 @@ class _InteractLayer(torch.autograd.Function):
                                                          n_edges, dim, _stream()), 'ihg_interact_bwd_gathered')
             node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients')
             del g2
-            dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
+            if keep_dout:
+                dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
+            else:
+                dp = node_segment_sum_raw(dy, layout.hop2_csr, out_scale, None, _lib.SCALE_NONE, self_weight=layout.self_weight, role='k7.two_hop_first_order_gradient')
         else:
             dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
             # the scatter of dout goes first: K5 has just written it, so most of its rows are still in the Infinity Cache for these random
             # reads; the interact kernels read it as a stream and do not care
             dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
-            dh = _interact_backward(h, w, dout, layout, order, dw)
+            dh = _interact_backward(h, w, dout, layout, order, None if node_weight else dw)
         del dout
         dbias = torch.empty(dim, dtype=torch.float32, device=h.device) if ctx.has_bias else None
         ws2 = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)

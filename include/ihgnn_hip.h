@@ -199,6 +199,8 @@ int ihg_bag_mean_bwd(const float* dout, int64_t ld_dout, const int32_t* word_ptr
  *   terms per fp32 operand instead - six v_mfma_f32_16x16x32_bf16 products per multiply, fp32 accumulation, an error at or
  *   below the fp32-MFMA kernels' (csrc/split_arith.hip).  The environment variable IHG_INTERACT_ARITH=f32, read at every
  *   call, keeps those shapes on the fp32-MFMA kernels.
+ * dw == NULL (here and in ihg_interact_bwd_user_reduced): member gradients only - the caller takes the product blocks' weight gradients from
+ * ihg_node_interact_bwd_weight.
  */
 int64_t ihg_interact_fwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t order);
 
@@ -234,7 +236,8 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
  * have produced - is formed inside the member-gradient kernel from three gathered rows; it is left in `dout` [n_edges, dim]
  * (written, not read) for the weight gradients here and for the caller's first-order scatter.  Everything else as
  * ihg_interact_bwd_user_reduced.  Available where ihg_interact_bwd_gathered_supported says so (dim 128, split arithmetic on).
- * dw == NULL: member gradients and dout only (the weight gradients come from ihg_node_interact_bwd_weight).
+ * dw == NULL: member gradients and dout only (the weight gradients come from ihg_node_interact_bwd_weight); then dout == NULL as well: the
+ * hyperedges' cotangents are not stored at all (the caller takes the first-order gradient from dy by the two-hop operator).
  */
 int32_t ihg_interact_bwd_gathered_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_dy);
 int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,

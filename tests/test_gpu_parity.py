@@ -565,16 +565,17 @@ def test_pair_sums_over_the_other_members_of_a_nodes_hyperedges(dim):
         assert torch.equal(wide[:, :3 * dim], got) and bool((wide[:, 3 * dim:] == 7.0).all())
 
 
-@pytest.mark.parametrize('order', [3, 2])
-def test_interactive_layer_without_hyperedge_rows(order, monkeypatch):
-    """d = 128: the forward of the interactive layer in its node-level form (pair sums + a node-level contraction with the typed weight
+@pytest.mark.parametrize('order,dim,passes', [(3, 128, 'q'), (2, 128, 'q'), (3, 128, 'four'), (2, 128, 'four'), (3, 64, 'q'), (2, 64, 'q'), (3, 256, 'q'), (2, 256, 'q')])
+def test_interactive_layer_without_hyperedge_rows(order, dim, passes, monkeypatch):
+    """d = 64 / 128 / 256 (`passes`: the 64-column / 512-value pass geometry, or at d = 128 the four passes of 256 values - the default there, IHG_NODE_FWD_Q=1 selects the other): the forward of the interactive layer in its node-level form (pair sums + a node-level contraction with the typed weight
     blocks: no [E, d] tensor) against the oracle's FeatureInteractor + segment sum in float64 and against the hyperedge form
     (IHG_NODE_LEVEL_FORWARD=0) - with and without bias / output scale, more row tiles than workgroups, fewer, split rows, isolated nodes of
     every type, a strided destination; the gradients of h, w and the bias against float64 autograd of the oracle, with the product blocks' weight
     gradients from the node-level kernel (ihg_node_interact_bwd_weight: the pair sums saved by the forward) and from the hyperedge kernel."""
     from ihgnn_amd import ops
     from oracle import ihgnn_ref as ref
-    dim, k = 128, (7 if order == 3 else 6)
+    k = 7 if order == 3 else 6
+    monkeypatch.setenv('IHG_NODE_FWD_Q', '0' if passes == 'four' else '1')
     for edges, (U, Q, I) in ((1, (5, 3, 4)), (33, (40, 7, 50)), (300 * 32 + 5, (301, 17, 211)), (70437, (9001, 170, 4103))):
         w_, lay = make_layout(U, Q, I, edges, seed=edges + order, edge_order='user')
         gen = torch.Generator().manual_seed(edges)
