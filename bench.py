@@ -220,14 +220,17 @@ def k7_roles(table, E, N, dim, layout, table_steps):
         'k7.two_hop_bwd_masked': (N, 6 * E + N, 24 * E, 'backward of the LAST first-order layer: its cotangent is zero outside the 3B batch rows (the output feeds the batch '
                                                           'tail only), the pull skips the gathers of the zero rows - same gradient; bytes as for the dense pull (an upper bound)'),
         'k7.edges_to_nodes_bwd_of_k5': (E, 3 * E, 12 * E, 'backward of a K5 launch'),
+        'k7.two_hop_first_order_gradient': (N, 6 * E + N, 24 * E, 'backward of the interactive layer, first-order part: the two-hop operator on the node-level cotangent (IHG_FIRST_ORDER_TWO_HOP=1)'),
+        'node_pair_sums': (N, 6 * E, 24 * E, 'interactive layer forward, node-level form: node table -> [N,3d] pair sums over hop2_csr (the output row is 3 d wide)', 3),
     }
     out = {}
-    for name, (src_rows, gathers, id_bytes, what) in roles.items():
+    for name, (src_rows, gathers, id_bytes, what, *rest) in roles.items():
         if name not in table:
             continue
+        out_row = (rest[0] if rest else 1) * row
         t = table[name]['avg_us'] * 1e-6
-        algorithmic = gathers * row + id_bytes + N * (row + 8)
-        compulsory = src_rows * row + id_bytes + N * (row + 8)
+        algorithmic = gathers * row + id_bytes + N * (out_row + 8)
+        compulsory = src_rows * row + id_bytes + N * (out_row + 8)
         out[name] = dict(what=what, avg_us=round(table[name]['avg_us'], 2), launches_per_step=table[name]['launches'] / table_steps,
                          compulsory_bytes=compulsory, achieved=round(compulsory / t / 1e9, 1), frac=round(compulsory / t / 1e9 / HBM_PEAK_GBS, 4),
                          algorithmic_bytes=algorithmic, algorithmic_gbs=round(algorithmic / t / 1e9, 1))
@@ -341,10 +344,11 @@ def main():
 
     for k in range(args.warmup):
         step(k)
-    # Inside the timed region only the roofline kernel (K5 where the step launches it, else K7's hyperedge -> node launch) is bracketed by HIP events: a pair of timing events costs a few
+    # Inside the timed region only the roofline kernel (K5 where the step launches it, else the interactive layer's gather launch - the pair sums of its node-level
+    # form, or K7's hyperedge -> node launch of its hyperedge form) is bracketed by HIP events: a pair of timing events costs a few
     # microseconds of stream time, and bracketing all launches of a step would inflate it.
     if not args.no_kernel_events:
-        profiler.start(only={'edge_gather_sum', 'k7.edges_to_nodes'})
+        profiler.start(only={'edge_gather_sum', 'k7.edges_to_nodes', 'node_pair_sums'})
     fence()
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
@@ -555,16 +559,35 @@ def main():
                                 '12 d + 12 B per hyperedge + (4 d + 8) B per node (SURVEY §8 d3): every incidence reads its 4 d-byte row; a row is read by its three '
                                 'members at unrelated times out of a table (E x 4 d B) far larger than L2 + Infinity Cache, so most of these ARE fabric reads',
                                 'k7.edges_to_nodes', 'HIP events on the launch stream, inside the timed region')
+    elif 'node_pair_sums' in kernels:
+        # the interactive layer runs in its node-level form (no [E, d] tensor, no hyperedge -> node launch): its gather is the pair-sum launch - per node
+        # the sums of h[a], h[b], h[a] h[b] over the other two members of its hyperedges - the largest gather launch of the step
+        ps_compulsory = N * row + 24 * E + N * (3 * row + 8)  # every node row once + the pair lists + the [N, 3 d] store and its row pointers
+        ps_algorithmic = 6 * E * row + 24 * E + N * (3 * row + 8)   # every incidence reads its two other members' rows
+        roofline = hbm_roofline('node_pair_sums', 'pair sums of the interactive layer\'s node-level form: [N,d] node table -> [N,3d] (sum h[a] | sum h[b] | sum h[a] h[b] over each '
+                                'node\'s hyperedges) - the hyperedge aggregation of the layer\'s forward', kernels['node_pair_sums'], ps_compulsory, ps_algorithmic,
+                                'compulsory HBM bytes per launch: every node row once + pair lists (2 ids per incidence) + [N,3d] store',
+                                '2 x 4 d B per incidence (3 E incidences) + 24 B of ids per hyperedge + (12 d + 8) B per node: the two other members\' rows of every incidence; '
+                                'the node table (N x 4 d B) fits the Infinity Cache at C3, so most of these are cache reads - this rate is not an HBM rate and may exceed the peak',
+                                'node_pair_sums', 'HIP events on the launch stream, inside the timed region')
     if k5_alone is not None:
         k5_outside = hbm_roofline(*k5_args[:2], k5_alone, *k5_args[3:], 'HIP events on the launch stream; six launches of their own after the timed region (no step launches K5)')
     mfma_roof = None
-    if args.layer == 'ihgnn' and args.order in (2, 3) and 'interact_fwd' in table and 'interact_bwd' in table:
+    if args.layer == 'ihgnn' and args.order in (2, 3) and 'interact_bwd' in table and ('interact_fwd' in table or 'node_interact_fwd' in table):
         # the order-2/3 contraction of layer 0 is the only MFMA-bound piece: 2 m d^2 flop per hyperedge forward
         # (m product blocks after hoisting), twice that backward (member gradients + weight gradients), against fp32 MFMA
         m_blocks = 4 if args.order == 3 else 3
-        flops_fwd = 2.0 * m_blocks * dim * dim * E
-        f, bw = table['interact_fwd'], table['interact_bwd']
+        node_level = 'node_interact_fwd' in table
+        # node-level form: the forward contracts 3 + m blocks per NODE (first-order blocks included), the product blocks' weight gradients m blocks per node;
+        # the member gradients stay per hyperedge.  Hyperedge form: m blocks per hyperedge forward, 2 m backward (members + weights).
+        flops_fwd = 2.0 * (3 + m_blocks) * dim * dim * N if node_level else 2.0 * m_blocks * dim * dim * E
+        f, bw = table['node_interact_fwd' if node_level else 'interact_fwd'], table['interact_bwd']
         bwd_us = bw['avg_us'] * bw['launches'] / table_steps        # the backward may run in several hyperedge chunks
+        flops_bwd = 2 * 2.0 * m_blocks * dim * dim * E
+        if 'node_interact_bwd_weight' in table:
+            nw = table['node_interact_bwd_weight']
+            bwd_us += nw['avg_us'] * nw['launches'] / table_steps
+            flops_bwd = 2.0 * m_blocks * dim * dim * E + 2.0 * m_blocks * dim * dim * N
         split_dtype = ('f32 operands taken apart exactly into three bf16 terms, six v_mfma_f32_16x16x32_bf16 products per multiply, f32 accumulate: '
                        'peak = dense bf16 MFMA peak / 6, flops counted as fp32 multiply-adds')
         f32_dtype = 'f32 in / f32 accumulate (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)'
@@ -575,10 +598,13 @@ def main():
             return dict(achieved=round(flops / (us * 1e-6) / 1e12, 1), peak=round(peak, 1), frac=round(flops / (us * 1e-6) / (peak * 1e12), 4),
                         dtype=split_dtype if split else f32_dtype, vs_f32_mfma_peak=round(flops / (us * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 3), **extra)
 
-        mfma_roof = dict(bound='mfma', kernel='interact_fwd + interact_bwd (order-%d product blocks of layer 0)' % args.order, unit='TFLOP/s',
+        mfma_roof = dict(bound='mfma', kernel=('node_interact_fwd (node-level contraction, %d blocks per node) + interact_bwd (member gradients, per hyperedge) + node_interact_bwd_weight (per node)' % (3 + m_blocks)
+                                               if node_level else 'interact_fwd + interact_bwd (order-%d product blocks of layer 0)' % args.order), unit='TFLOP/s',
+                         note='flops are the multiply-adds the algorithm in use performs (the node-level form does E / N times fewer than the hyperedge form for the same result), '
+                              'not the hyperedge form\'s count' if node_level else None,
                          f32_mfma_peak=MFMA_F32_PEAK_TF, split_peak=round(MFMA_BF16_PEAK_TF / 6, 1),
                          forward=direction('forward', flops_fwd, f['avg_us'], dict(flops_per_launch=flops_fwd, avg_us=round(f['avg_us'], 2))),
-                         backward=direction('backward', 2 * flops_fwd, bwd_us, dict(flops_per_step=2 * flops_fwd, us_per_step=round(bwd_us, 2))),
+                         backward=direction('backward', flops_bwd, bwd_us, dict(flops_per_step=flops_bwd, us_per_step=round(bwd_us, 2))),
                          share_of_step=round((f['avg_us'] + bwd_us) * 1e-3 / (1e3 * elapsed / args.steps), 3),
                          measured='instrumented pass after the timed region (every launch bracketed)',
                          profiled_clock=mfma_pass_clocks(args.config))

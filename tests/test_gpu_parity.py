@@ -1100,18 +1100,31 @@ def test_full_size_layer0_path_of_the_headline_step(config, order):
     want_dh = _oracle_on_sampled_nodes(lay, nodes, h, wz, order, edge_cotangent)
     assert rel(h.grad[torch.from_numpy(nodes).to(dev())], want_dh) <= RTOL
 
-    # the form the model runs (IHGNNLayer -> FeatureInteractor.to_nodes -> ops.interact_layer): the first-order blocks inside the same autograd
-    # node, their input gradient ADDED onto the member gradients by the node-level weight-gradient kernel (dx_accumulate) - against the
-    # composition of the two ops checked above, whole tensors
+    # the form the model runs (IHGNNLayer -> FeatureInteractor.to_nodes -> ops.interact_layer): the layer in its NODE-LEVEL form (pair sums + a node-level
+    # contraction, no [E, d] tensor; the product blocks' weight gradients from node-level data, the first-order blocks' input gradient added onto the
+    # member gradients by the node-level weight-gradient kernel) - against the composition of the two hyperedge-form ops checked above, whole tensors
     bias = torch.randn(d, device=dev(), generator=gen).requires_grad_(True)
     h3, w3 = (t.detach().clone().requires_grad_(True) for t in (h, wgt))
+    profiler.start()
     y3 = ops.interact_layer(h3, w3, bias, lay, order, scale)
     y3.backward(dy)
+    launched = profiler.summary()
+    profiler.stop()
+    assert {'node_pair_sums', 'node_interact_fwd', 'node_interact_bwd_weight'} <= set(launched) and 'interact_fwd' not in launched, sorted(launched)
     h4, w4, b4 = (t.detach().clone().requires_grad_(True) for t in (h, wgt, bias))
     y4 = ops.interact_to_nodes(h4, ops.node_linear(h4, w4, b4, lay, typed=True, bias_mask=0b001), w4, lay, order, scale)
     y4.backward(dy)
-    assert torch.equal(y3.detach(), y4.detach())
-    assert rel(h3.grad, h4.grad) <= 4 * RTOL_SUM and rel(w3.grad, w4.grad) <= 4 * RTOL_SUM and rel(bias.grad, b4.grad) <= 4 * RTOL_SUM
+    assert rel(y3, y4) <= RTOL
+    assert rel(h3.grad, h4.grad) <= 4 * RTOL_SUM and rel(w3.grad, w4.grad) <= RTOL and rel(bias.grad, b4.grad) <= 4 * RTOL_SUM
+    # ... and the node-level rows against the oracle on the sampled nodes (first-order part included: p = h A_t^T + c on the users)
+    hc, bc = h.detach().cpu(), bias.detach().cpu()
+    u_, uq_ = lay.user_count, lay.user_count + lay.query_count
+    for v in np.concatenate([nodes[:8], nodes[(nodes >= u_) & (nodes < uq_)][:4], nodes[nodes >= uq_][:8]]):     # users, queries (split rows), items
+        edges = lay.node_csr.ids_host[ptr[v]:ptr[v + 1]].astype(np.int64)
+        i3e = torch.from_numpy(lay.i3_host[edges].astype(np.int64))
+        members, local = torch.unique(i3e, return_inverse=True)
+        ef_v = ref.feature_interactor(hc[members].double(), local, wc.double(), bc.double(), order)
+        assert rel(y3.detach()[int(v)], scale_c[v].double() * ef_v.sum(0)) <= RTOL, int(v)
 
 
 def test_full_size_c5_interact_in_three_chunks():

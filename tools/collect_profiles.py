@@ -47,6 +47,9 @@ def main():
         for key, v in table.items():
             if key.startswith('edge_gather_sum_kernel'):
                 out['edge_gather_sum'] = dict(hbm_bytes_per_launch=v['hbm_bytes_per_launch'], avg_us_under_pmc=v['avg_us_under_pmc'])
+            if key.startswith('node_pair_sums_kernel'):                   # one launch per step under its own name: in situ
+                out['node_pair_sums'] = dict(hbm_bytes_per_launch=v['hbm_bytes_per_launch'], avg_us_under_pmc=v['avg_us_under_pmc'],
+                                             source='in situ: the pair-sum launch of each training step of the counter passes over bench.py (FETCH_SIZE doubled + WRITE_SIZE)')
         # K5 and K7's hyperedge -> node launch on their own (kbench): the step may not launch K5 at all, and K7's launch roles share a name
         f57, w57 = os.path.join(src, 'pmc_k57_FETCH_SIZE'), os.path.join(src, 'pmc_k57_WRITE_SIZE')
         if os.path.isdir(f57) and os.path.isdir(w57):
@@ -69,7 +72,7 @@ def main():
             picked = []
             for a, b in zip(adam, adam[1:]):
                 k7 = [r for r in rows[a + 1:b + 1] if 'node_segment_sum_kernel' in r['Kernel_Name'] and int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 100_000]
-                if len(k7) == 7:
+                if len(k7) == 7:                                         # (the hyperedge form of the interactive layer: IHG_NODE_LEVEL_FORWARD=0)
                     picked.append((float(k7[0]['Counter_Value']), (int(k7[0]['End_Timestamp']) - int(k7[0]['Start_Timestamp'])) / 1e3))
             return picked
         f_rows, w_rows = k7_in_situ(fetch, 'FETCH_SIZE'), k7_in_situ(write, 'WRITE_SIZE')
@@ -91,7 +94,7 @@ def main():
             if 'interact' in name:
                 agg[name][r['Counter_Name']].append((float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
         out = dict(command='rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 tools/kbench.py --config '
-                           f'{config} --rounds 3 --ops layer0', notes='GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs', commit=head_commit(), kernels={})
+                           f'{config} --rounds 3 --ops layer', notes='GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs', commit=head_commit(), kernels={})
         for name, c in agg.items():
             busy = sum(v for v, _ in c['SQ_VALU_MFMA_BUSY_CYCLES']) / len(c['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024
             gui = sum(v for v, _ in c['GRBM_GUI_ACTIVE']) / len(c['GRBM_GUI_ACTIVE']) / 8

@@ -10,6 +10,7 @@ import glob
 import json
 import sys
 
+# (node-level form of the interactive layer - the default at d = 64 / 128 / 256: no hyperedge -> node launch, six long K7 launches per step; IHG_NODE_LEVEL_FORWARD=0: seven)
 ROLES = ['k7.edges_to_nodes', 'k7.two_hop (layer 1)', 'k7.two_hop (layer 2)', 'k7.two_hop_bwd_masked (layer 2: only the batch rows of its cotangent are non-zero)', 'k7.two_hop_bwd (layer 1)',
          'k7.member_gradients_rows', 'k7.first_order_gradient']
 
@@ -27,6 +28,8 @@ def main():
             continue                                                     # a step of the fp32-MFMA comparison pass, or not a training step
         k7 = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in step
               if 'node_segment_sum_kernel' in r['Kernel_Name'] and int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 100_000]
+        if len(k7) == len(ROLES) - 1:
+            k7 = [None] + k7                                             # node-level form: the first role does not exist
         if len(k7) != len(ROLES) or k7[2] < 0.8 * k7[1]:                 # (the steps with the last layer restricted to the batch rows have a short second two-hop)
             continue
         all_steps.append(k7)
@@ -36,7 +39,8 @@ def main():
     for k7 in headline:
         steps += 1
         for lst, us in zip(per_role, k7):
-            lst.append(us)
+            if us is not None:
+                lst.append(us)
     out = dict(command='rocprofv3 --kernel-trace --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline',
                kernel='node_segment_sum_kernel<4, 32>', steps=steps,
                note='launches longer than 100 us, by position in the training step, steps with every layer over all rows (the small launches of the same kernel are the bag means and the batch tail)',

@@ -16,7 +16,7 @@ done
 for c in FETCH_SIZE WRITE_SIZE; do     # K5 and K7's hyperedge -> node launch on their own (K7's seven in-situ launches per step share one kernel name and grid)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_k57_$c -- python3 tools/kbench.py --config C3 --rounds 4 --ops k5,k7 > $OUT/pmc_k57_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -- python3 tools/kbench.py --config C3 --rounds 3 --ops layer0 > $OUT/pmc_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -- python3 tools/kbench.py --config C3 --rounds 3 --ops layer > $OUT/pmc_mfma.log 2>&1
 python3 tools/k7_roles_from_trace.py $OUT/stats > $OUT/k7_by_role.json 2>> $OUT/stats.log     # K7's launches by role (one kernel name, one grid: --stats averages them)
 find $OUT -name '*kernel_trace.csv' -delete        # large, and the stats / counter files carry what is quoted
 ls -R $OUT | head -40
