@@ -2136,12 +2136,13 @@ int64_t ihg_interact_bwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t o
     (void)n_edges;
     if (!mfma_dim(dim) || (order != 2 && order != 3)) return 0;
     const int64_t w_floats = packed_weight_floats(dim, order);
-    const int64_t boundary = dim == 128 ? (2LL * kPipeGrid * dim + 2LL * kPipeGrid) : 0;      // user-reduced form: boundary runs + their users
+    const int64_t boundary = dim == 128 || dim == 64 ? (2LL * kPipeGrid * dim + 2LL * kPipeGrid) : 0;      // user-reduced form: boundary runs + their users
     return (w_floats + static_cast<int64_t>(weight_slabs(dim)) * w_floats + boundary + split_plane_floats(dim, order)) * static_cast<int64_t>(sizeof(float));
 }
 
 int32_t ihg_interact_bwd_user_reduced_supported(int32_t dim, int32_t order, int64_t ld_h) {
-    return dim == 128 && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_h < (int64_t{1} << 30) ? 1 : 0;
+    // d = 128: the split kernel or the fp32 strip kernel; d = 64: the split kernel only (its fp32-MFMA kernels have no user-reduced form)
+    return (dim == 128 || (dim == 64 && split_arith_enabled())) && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_h < (int64_t{1} << 30) ? 1 : 0;
 }
 
 int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
@@ -2232,7 +2233,7 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const floa
                                static_cast<float*>(nullptr), wq);
         // the bf16 planes of the split contraction sit behind the boundary table (only d = 128 has either)
         void* planes = split_plane_floats(dim, order) == 0 ? nullptr :
-                       static_cast<void*>(slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order) + (dim == 128 ? 2LL * kPipeGrid * dim + 2LL * kPipeGrid : 0));
+                       static_cast<void*>(slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order) + (dim == 128 || dim == 64 ? 2LL * kPipeGrid * dim + 2LL * kPipeGrid : 0));
         if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s, nullptr, 0, nullptr, nullptr, w, ld_w, planes);
         else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s, nullptr, 0, nullptr, nullptr, w, ld_w, planes);
         return check_launch("ihg_interact_bwd");

@@ -169,8 +169,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                                                                                       int64_t ld_dh, float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user,
                                                                                       const float* __restrict__ dy_scale = nullptr,
                                                                                       float* __restrict__ dout_store = nullptr, int64_t ld_store = 0) {
-    static_assert(D == 128 || ((D == 256 || D == 64) && !UR), "shapes");
-    static_assert(!GATHER || (D == 128 && UR), "the gathering form exists where the layer's backward uses it");
+    static_assert(D == 128 || D == 64 || (D == 256 && !UR), "shapes");     // the user-slot reduction is written for column parts of 64 (d = 128: two, d = 64: one)
+    static_assert(!GATHER || ((D == 128 || D == 64) && UR), "the gathering form exists where the layer's backward uses it");
     constexpr int TE = kSplitTE, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, KB = D / 32, RB = 2 * D;
     constexpr int SWZ = RB / 16 - 1 < 15 ? RB / 16 - 1 : 15;            // the row swizzle stays inside a row (D = 64: rows of 8 chunks)
     constexpr int DOCT = D / 64, EX = HC / 32;                          // per service thread: dout octets, 4-column groups of the product rule
@@ -2358,7 +2358,7 @@ inline bool ld_ok(int64_t ld) { return ld > 0 && ld % 4 == 0 && ld < (int64_t{1}
 
 // dim 128: either form of g; dim 64, 256: the [E, 3, d] form only
 bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout, bool user_reduced) {
-    return split_arith_enabled() && (dim == 128 || ((dim == 256 || dim == 64) && !user_reduced)) && (order == 2 || order == 3) && aligned16(g) && aligned16(dout) &&
+    return split_arith_enabled() && (dim == 128 || dim == 64 || (dim == 256 && !user_reduced)) && (order == 2 || order == 3) && aligned16(g) && aligned16(dout) &&
            ld_ok(ld_h) && ld_ok(ld_dout);
 }
 
@@ -2367,14 +2367,14 @@ template <int D, int NBLK>
 void launch_members_split_t(const float* h, int64_t ld_h, const int32_t* i3, const v4u* wsp, const float* dout, int64_t ld_dout, float* g, int64_t n_edges,
                             float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user, const float* dy_scale, float* dout_store, int64_t ld_store,
                             hipStream_t s) {
-    if constexpr (D == 128) {
+    if constexpr (D == 128 || D == 64) {
         if (dh_user != nullptr && dout_store != nullptr) {              // `dout` is the node-level cotangent: gathered, summed, stored
-            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<128, true, NBLK, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g,
+            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, true, NBLK, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g,
                                n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store);
             return;
         }
         if (dh_user != nullptr) {
-            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<128, true, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
+            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, true, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
                                dh_user, ld_dh, bnd_val, bnd_user);
             return;
         }
@@ -2398,7 +2398,7 @@ void launch_members_split(int dim, int order, const float* h, int64_t ld_h, cons
     }
     if (dim == 256) IHG_MEMBERS(256) else if (dim == 64) IHG_MEMBERS(64) else IHG_MEMBERS(128)
 #undef IHG_MEMBERS
-    if (n_boundary_entries != nullptr) *n_boundary_entries = 2 * kSplitRanges;
+    if (n_boundary_entries != nullptr) *n_boundary_entries = 2 * (dim == 64 ? 256 : kSplitRanges);     // two per tile range (d = 64: one workgroup per range, 256 ranges)
 }
 
 int64_t split_dense_plane_floats(int dim) { return dim == 128 || dim == 256 ? (3LL * 3 * dim * dim) / 2 : 0; }

@@ -370,14 +370,15 @@ def test_interact_persistent_tiles_and_strided_rows(dim, order, edges):
     assert rel(hg.grad, hc.grad) <= RTOL and rel(wg.grad, wc.grad) <= RTOL
 
 
+@pytest.mark.parametrize('dim', [128, 64])
 @pytest.mark.parametrize('order,edges,users', [(3, 700 * 32 + 5, 301), (2, 300 * 32, 7), (3, 40, 3), (3, 9000, 5000)])
-def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, monkeypatch):
-    """d = 128 with hyperedges numbered by user: the member-gradient kernel sums the user slot on chip (runs inside a tile, across
+def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, dim, monkeypatch):
+    """d = 128 (two column halves per tile range) and d = 64 (one workgroup per range) with hyperedges numbered by user: the member-gradient kernel sums the user slot on chip (runs inside a tile, across
     tiles, across workgroups - 7 users over 9,600 hyperedges put one user's run in several workgroups - users without hyperedges)
     and writes dh[users] itself, the [E, 2, d] buffer carries the other two slots.  Against the oracle and against the [E, 3, d] form."""
     from ihgnn_amd import ops
     from oracle import ihgnn_ref as ref
-    dim, Q, I = 128, 17, 211
+    Q, I = 17, 211
     w_, lay = make_layout(users, Q, I, edges, seed=order + edges, edge_order='user')
     assert lay.user_sorted
     gen = torch.Generator().manual_seed(edges)
@@ -402,9 +403,10 @@ def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, monkey
 
 
 @pytest.mark.parametrize('order,edges,users,dim,restricted', [(3, 700 * 32 + 5, 301, 128, False), (2, 300 * 32, 7, 128, False), (3, 40, 3, 128, True),
-                                                             (3, 9000, 5000, 128, True), (3, 33, 7, 128, False), (3, 700, 31, 64, False), (2, 300, 11, 12, False)])
+                                                             (3, 9000, 5000, 128, True), (3, 33, 7, 128, False), (3, 700, 31, 64, False), (2, 300 * 32 + 9, 7, 64, False),
+                                                             (3, 9000, 5000, 64, True), (3, 700, 31, 256, False), (2, 300, 11, 12, False)])
 def test_interact_to_nodes_backward_forms_the_hyperedge_cotangents_itself(order, edges, users, dim, restricted, monkeypatch):
-    """``interact_to_nodes`` = interact + hyperedge -> node pass as one autograd node.  At d = 128 (hyperedges numbered by user) its backward
+    """``interact_to_nodes`` = interact + hyperedge -> node pass as one autograd node.  At d = 128 and d = 64 (hyperedges numbered by user) its backward
     has no node -> hyperedge launch: the member-gradient kernel gathers the three ``dy`` rows of a hyperedge (ring of ids a phase earlier,
     tiles past the end, partial last tile, 33 hyperedges = one tile and a row) and leaves their scaled sum for the weight gradients and
     the first-order scatter.  Against the separate ops (whose K5 launch it replaces), with and without a row restriction of the forward,
@@ -441,12 +443,12 @@ def test_interact_to_nodes_backward_forms_the_hyperedge_cotangents_itself(order,
     fused = run(True)
     launched = profiler.summary()
     profiler.stop()
-    assert ('edge_gather_sum' not in launched) == (dim == 128), sorted(launched)
+    assert ('edge_gather_sum' not in launched) == (dim in (128, 64)), sorted(launched)
     separate = run(False)
     assert torch.equal(fused[0], separate[0])
     for got, want in zip(fused[1:], separate[1:]):
         assert rel(got, want) <= RTOL_SUM
-    if dim == 128:
+    if dim in (128, 64):
         monkeypatch.setenv('IHG_INTERACT_ARITH', 'f32')                 # no gathering kernel in this mode: the separate ops' sequence
         for got, want in zip(run(True)[1:], separate[1:]):
             assert rel(got, want) <= RTOL
@@ -491,7 +493,7 @@ def test_interact_fp32_mfma_kernels_stay_covered(which, monkeypatch):
         test_interact_persistent_tiles_and_strided_rows(64, 3, 3 * 256 * 64 + 37)
         test_interact_persistent_tiles_and_strided_rows(256, 3, 1100 * 64 + 37)
     else:
-        test_interact_backward_user_slot_reduced_on_chip(3, 700 * 32 + 5, 301, monkeypatch)
+        test_interact_backward_user_slot_reduced_on_chip(3, 700 * 32 + 5, 301, 128, monkeypatch)
 
 
 @pytest.mark.parametrize('dim,order', [(128, 3), (128, 2), (256, 3), (256, 2)])
