@@ -11,15 +11,16 @@ A step is one FULL training step of RawGnn (full-graph propagation forward over 
 full replica and its own batches (weak scaling) and the value is the aggregate over ranks.
 
 Workload: the largest BASELINE config that fits one GPU's step budget, C3 (CIKM-Cup-2016 stand-in: d = 128, 3 layers; C4
-(Amazon full catalog stand-in, same model shape, E = 3.3 M) is the per-GPU replica of the 8-GPU config).  --config C1 / C2 / C4 / C5 select the others (C5 on one GPU takes ~1.1 s per step).
+(Amazon full catalog stand-in, same model shape, E = 3.3 M) is the per-GPU replica of the 8-GPU config).  --config C1 / C2 / C4 / C5 select the others (C5 on one GPU: 0.46 s per step; give it --warmup 2, the allocator's pool still grows in the second step).
 
 `--gpus N` without a torchrun environment launches itself: the parent starts N child processes (one per GPU) BEFORE it
 touches the GPU and forwards rank 0's JSON line; under `python -m torch.distributed.run` it uses the ranks it was given.
 
 One JSON line is printed by rank 0.  It carries
   roofline                    the aggregation kernel the step is dominated by, against the HBM roofline: K5 (node->hyperedge gather-sum)
-                              where the step launches it, else - the layer-0 backward forms the hyperedges' cotangents inside the
-                              member-gradient kernel - K7's hyperedge->node launch.  `achieved` / `frac` = COMPULSORY HBM bytes per launch (every
+                              where the step launches it, else the interactive layer's gather launch - the pair sums of its node-level form
+                              (ihg_node_pair_sums: per node the sums over its hyperedges' other two members; the default at d = 64 / 128 / 256), or K7's
+                              hyperedge->node launch of its hyperedge form (IHG_NODE_LEVEL_FORWARD=0).  `achieved` / `frac` = COMPULSORY HBM bytes per launch (every
                               source row once + stores + ids) / the kernel's average duration measured with HIP events on the launch
                               stream inside the timed region; `frac_algorithmic` / `algorithmic_gbs` = the SURVEY §8 d3 byte model (every gathered
                               row counted); `traffic` = PMC-measured bytes per launch from the newest committed profile of this exact workload
@@ -28,8 +29,9 @@ One JSON line is printed by rank 0.  It carries
   roofline_node_to_hyperedge  K5 at this workload, launched on its own after the timed region (same fields);
   roofline_hyperedge_to_node  one object per K7 launch role (edge features -> nodes, member gradients -> nodes, two-hop ...), each with
                               its own byte counts;
-  roofline_interaction        the order-2/3 contraction against the matrix-core peak of the arithmetic it runs in (fp32 MFMA, or for
-                              d = 64 / 128 / 256 the bf16 peak / 6: six bf16 products per multiply), with the clocks and matrix-pipe occupancy of
+  roofline_interaction        the interactive layer's contractions (node-level form: contraction per node, member gradients per hyperedge, weight
+                              gradients per node; flops = the multiply-adds of the algorithm in use) against the matrix-core peak of the arithmetic
+                              they run in (fp32 MFMA, or for d = 64 / 128 / 256 the bf16 peak / 6: six bf16 products per multiply), with the clocks and matrix-pipe occupancy of
                               the newest committed counter pass (`profiled_clock`);
   gradient_exchange           (N > 1) mode, backend, gradient bytes per rank, every rank's ms per step and the time its stream spent in the exchange;
   recorded_step_ms_per_step   the same step replayed from one recorded hipGraph (ihgnn_amd/captured_step.py); NOT the headline;
