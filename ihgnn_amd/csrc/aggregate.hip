@@ -221,6 +221,9 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
 //   (h[v], S_a, S_b, S_ab), so no [E, d] row is ever formed (ihg_node_interact_fwd applies the maps).  Same work list, lane layout and
 //   split-row plan as K7; a segment of a split row must hold whole pairs (the layout keeps segment lengths even).
 // ================================================================================================
+#ifndef IHG_PAIR_UNR
+#define IHG_PAIR_UNR 16
+#endif
 template <int G>
 __global__ __launch_bounds__(kBlockThreads) void node_pair_sums_kernel(
     const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ids,
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(kBlockThreads) void node_pair_sums_kernel(
     int heavy_threshold, const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments,
     float* __restrict__ partials) {
     constexpr int GPW = kWave / G;
-    constexpr int UNR = G < 8 ? G : (G >= 32 ? 16 : 8);      // ids in flight per lane: UNR / 2 pairs
+    constexpr int UNR = G < 8 ? G : (G >= 32 ? IHG_PAIR_UNR : 8);      // ids in flight per lane: UNR / 2 pairs
     const int lane = threadIdx.x & (kWave - 1);
     const int lig = lane & (G - 1);
     const int grp = lane / G;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the individual HIP ops at a bench.py workload shape (interleaved rounds, HIP-event timing).
 
-    python tools/kbench.py [--config C2] [--rounds 10] [--ops k5,k7,interact,layer0,linear]
+    python tools/kbench.py [--config C2] [--rounds 10] [--ops k5,k7,pairs,twohop,interact,layer0,layer,ifwd,linear]
 """
 import argparse
 import os
@@ -45,6 +45,10 @@ def main():
             ops.edge_gather_sum_raw(x, lay.i3, lay.inv_deg)
         if 'k7' in want:
             ops.node_segment_sum_raw(ef, lay.node_csr, None, lay.inv_deg, 1)
+        if 'pairs' in want:                                               # pair sums of the interactive layer's node-level form
+            ops.node_pair_sums_raw(x, lay)
+        if 'twohop' in want:                                              # a first-order layer's two-hop launch
+            ops.node_segment_sum_raw(x, lay.hop2_csr, None, lay.inv_deg, 1, self_weight=lay.self_weight, role='k7.two_hop')
         if 'linear' in want:
             xr = x.detach().requires_grad_(True)
             y = ops.node_linear(xr, wt, b, lay)
