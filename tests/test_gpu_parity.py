@@ -1193,6 +1193,61 @@ def test_full_size_c5_interact_in_three_chunks():
     assert rel(h.grad[torch.from_numpy(nodes).to(dev())], want_dh) <= RTOL
 
 
+def test_full_size_c5_node_level_layer():
+    """BASELINE configs[4] at FULL size (N = 10 M, E = 50 M, d = 256): the interactive layer in its node-level form - pair sums over 300 M neighbour ids
+    (split rows of millions of pairs), the node-level contraction in four passes x four column parts, the node-level weight gradients over 10 M rows.
+    Output rows against the oracle on sampled users, items and queries; d W through the Euler identity (the layer is linear in its product blocks:
+    <d W_prod, W_prod> = <dy, y(product blocks only)>) and its first-order blocks / bias likewise.  Needs ~150 GB of HBM: skipped on a smaller device."""
+    free, total = torch.cuda.mem_get_info()
+    if free < 160 * (1 << 30):
+        pytest.skip(f'needs 160 GiB of free HBM, this device has {free / (1 << 30):.0f}')
+    from ihgnn_amd import ops, profiler, synth
+    from ihgnn_amd.layout import IncidenceLayout
+    from oracle import ihgnn_ref as ref
+    w_ = synth.draw_config('C5')
+    lay = IncidenceLayout(w_.triples, w_.user_count, w_.query_count, w_.item_count, dev())
+    del w_
+    d, order, k = 256, 3, 7
+    gen = torch.Generator(device=dev()).manual_seed(29)
+    h = (torch.randn(lay.node_count, d, device=dev(), generator=gen) / 4).requires_grad_(True)
+    wgt = (torch.randn(d, k * d, device=dev(), generator=gen) / (3 * np.sqrt(k * d / 7))).requires_grad_(True)
+    bias = torch.randn(d, device=dev(), generator=gen).requires_grad_(True)
+    scale = lay.inv_deg
+    with torch.no_grad():                                                # a cotangent that correlates with the output: the Euler sums below do not cancel
+        dy = ops.interact_layer(h.detach(), wgt.detach(), bias.detach(), lay, order, scale)
+        dy.mul_(torch.rand(lay.node_count, 1, device=dev(), generator=gen).add_(0.5).div_(8))
+    profiler.start()
+    y = ops.interact_layer(h, wgt, bias, lay, order, scale)
+    y.backward(dy)
+    launched = profiler.summary()
+    profiler.stop()
+    assert {'node_pair_sums', 'node_interact_fwd', 'node_interact_bwd_weight'} <= set(launched) and 'interact_fwd' not in launched, sorted(launched)
+    y = y.detach()
+
+    # rows against the oracle: users, items, the first queries with hyperedges (<= 20,000 of them: split rows)
+    nodes = _sample_nodes(lay, np.random.default_rng(11))
+    u_, uq_ = lay.user_count, lay.user_count + lay.query_count
+    ptr = lay.node_csr.ptr_host.astype(np.int64)
+    hc, wc, bc, scale_c = h.detach(), wgt.detach().cpu().double(), bias.detach().cpu().double(), scale.cpu().double()
+    for v in np.concatenate([nodes[:8], nodes[(nodes >= u_) & (nodes < uq_)][:4], nodes[nodes >= uq_][:8]]):
+        edges = lay.node_csr.ids_host[ptr[v]:ptr[v + 1]].astype(np.int64)
+        i3e = torch.from_numpy(lay.i3_host[edges].astype(np.int64))
+        members, local = torch.unique(i3e, return_inverse=True)
+        ef_v = ref.feature_interactor(hc[members.to(dev())].cpu().double(), local, wc, bc, order)
+        assert rel(y[int(v)], scale_c[v] * ef_v.sum(0)) <= RTOL, int(v)
+
+    # Euler: y is linear in (w, bias): <d w, w> + <d bias, bias> = <dy, y>; and block by block: the product blocks alone, the first-order blocks + bias alone
+    total = (dy.double() * y.double()).sum()
+    lhs = (wgt.grad.double() * wgt.detach().double()).sum() + (bias.grad.double() * bias.detach().double()).sum()
+    assert abs(lhs - total) / abs(total) <= 1e-4
+    with torch.no_grad():
+        w_prod = torch.cat([torch.zeros(d, 3 * d, device=dev()), wgt.detach()[:, 3 * d:]], 1)
+        y_prod = ops.interact_layer(h.detach(), w_prod, None, lay, order, scale)
+    lhs_prod = (wgt.grad[:, 3 * d:].double() * wgt.detach()[:, 3 * d:].double()).sum()
+    rhs_prod = (dy.double() * y_prod.double()).sum()
+    assert abs(lhs_prod - rhs_prod) / abs(rhs_prod) <= 1e-4
+
+
 def test_integration_md_binding_stub_runs():
     """The ctypes stub INTEGRATION.md shows a maintainer of the reference (section 2) is executed as written, against the
     built library: SpmmSum.apply == torch.sparse.mm(incidence, x) * Dv^-1, and its backward == the transposed product."""
