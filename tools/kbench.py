@@ -38,6 +38,10 @@ def main():
     wt = (torch.randn(d, d, device=dev) / d ** 0.5).requires_grad_(True)
     b = torch.randn(d, device=dev, requires_grad=True)
     want = set(args.ops.split(','))
+    listed = torch.randint(0, N, (3300,), device=dev)
+    mask = torch.zeros(N, dtype=torch.uint8, device=dev)
+    mask[listed] = 1
+    xm = x * mask[:, None].float()
 
     def run_once():
         if 'k5' in want:
@@ -47,6 +51,8 @@ def main():
             ops.node_segment_sum_raw(ef, lay.node_csr, None, lay.inv_deg, 1)
         if 'pairs' in want:                                               # pair sums of the interactive layer's node-level form
             ops.node_pair_sums_raw(x, lay)
+        if 'masked' in want:                                              # the last layer's backward: the two-hop pull with 3,300 listed source rows
+            ops.node_segment_sum_raw(xm, lay.hop2_csr, lay.inv_deg, None, 0, self_weight=lay.self_weight, src_mask=mask, role='k7.two_hop_bwd_masked')
         if 'twohop' in want:                                              # a first-order layer's two-hop launch
             ops.node_segment_sum_raw(x, lay.hop2_csr, None, lay.inv_deg, 1, self_weight=lay.self_weight, role='k7.two_hop')
         if 'linear' in want:
