@@ -97,7 +97,9 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
 //   shuffles broadcast each id inside the group, UNR (8 or 16) row gathers in flight per lane, adds in list order.
 //   The chunk loop is made wave-uniform with a cross-group max so the shuffles always run converged.
 // ================================================================================================
-template <int VEC, int G>
+// STREAM: every source row is read exactly once by the launch (the member-gradient scatter): non-temporal loads, the rows do not displace what other
+// kernels keep in the caches (C3: 488 -> 436 us; the same on rows that ARE re-read - the two-hop launches - costs 50 %: 740 -> 1,120 us)
+template <int VEC, int G, bool STREAM = false>
 __device__ __forceinline__ Frag<VEC> accumulate_list(const float* __restrict__ src, int64_t ld_src,
                                                      const int32_t* __restrict__ ids, const float* __restrict__ src_scale,
                                                      const float* __restrict__ entry_scale, const uint8_t* __restrict__ src_mask,
@@ -126,7 +128,8 @@ __device__ __forceinline__ Frag<VEC> accumulate_list(const float* __restrict__ s
             }
 #pragma unroll
             for (int k = 0; k < UNR; ++k)
-                row[k] = (id[k] >= 0 && col >= 0) ? Frag<VEC>::load(src + static_cast<int64_t>(id[k]) * ld_src + col * VEC)
+                row[k] = (id[k] >= 0 && col >= 0) ? (STREAM ? Frag<VEC>::load_stream(src + static_cast<int64_t>(id[k]) * ld_src + col * VEC)
+                                                            : Frag<VEC>::load(src + static_cast<int64_t>(id[k]) * ld_src + col * VEC))
                                                   : Frag<VEC>::zero();
 #pragma unroll
             for (int k = 0; k < UNR; ++k) acc.add_scaled(row[k], w[k]);
@@ -198,7 +201,7 @@ __device__ __forceinline__ void apply_out_scale(Frag<VEC>& acc, const float* out
 
 // Work list of one launch: first the fixed-length segments of the split (heavy) rows, then the light rows in `row_order`
 // (decreasing length).  Unit u < n_segments writes partials[u]; unit u >= n_segments writes its output row.
-template <int VEC, int G, bool MASKED = false>
+template <int VEC, int G, bool MASKED = false, bool STREAM = false>
 __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
     const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ids,
     const int32_t* __restrict__ row_order, const float* __restrict__ src_scale, const float* __restrict__ entry_scale,
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
             const int c = ci * G + lig;
             const int col = c < dim_vec ? c : -1;
             Frag<VEC> acc = MASKED ? accumulate_list_masked<VEC, G>(src, ld_src, ids, src_scale, entry_scale, src_mask, begin, len, wave_len, lane, col)
-                                   : accumulate_list<VEC, G>(src, ld_src, ids, src_scale, entry_scale, src_mask, begin, len, wave_len, lane, col);
+                                   : accumulate_list<VEC, G, STREAM>(src, ld_src, ids, src_scale, entry_scale, src_mask, begin, len, wave_len, lane, col);
             if (dst != nullptr && col >= 0) {
                 if (scale_row >= 0) {
                     if (self_weight != nullptr)             // square operators: the row's own source row, weighted
@@ -443,6 +446,10 @@ void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowpt
         hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G, true>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr, ids, row_order,
                            src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, dim_vec, heavy_threshold, hp.seg_begin, hp.seg_end,
                            hp.n_segments, hp.partials, self_weight, hp.src_mask);
+    else if (mode & IHG_SRC_READ_ONCE)
+        hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G, false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr, ids, row_order,
+                           src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, dim_vec, heavy_threshold, hp.seg_begin, hp.seg_end,
+                           hp.n_segments, hp.partials, self_weight, hp.src_mask);
     else
         hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr, ids, row_order,
                            src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, dim_vec, heavy_threshold, hp.seg_begin, hp.seg_end,
@@ -470,7 +477,7 @@ int launch_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, 
 }
 
 inline bool scale_mode_ok(int mode, const float* scale) {
-    if (mode & ~(0xff | IHG_SCALE_ACCUMULATE)) return false;
+    if (mode & ~(0xff | IHG_SCALE_ACCUMULATE | IHG_SRC_READ_ONCE)) return false;
     mode &= 0xff;
     if (mode == IHG_SCALE_NONE) return true;
     return (mode == IHG_SCALE_MULTIPLY || mode == IHG_SCALE_DIVIDE) && scale != nullptr;

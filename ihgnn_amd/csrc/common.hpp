@@ -50,6 +50,12 @@ template <> struct Frag<4> {
     float4 v;
     __device__ static Frag zero() { return {make_float4(0.f, 0.f, 0.f, 0.f)}; }
     __device__ static Frag load(const float* p) { return {*reinterpret_cast<const float4*>(p)}; }
+    // a row that is read once and not again soon: non-temporal
+    __device__ static Frag load_stream(const float* p) {
+        typedef float vec4 __attribute__((ext_vector_type(4)));
+        const vec4 t = __builtin_nontemporal_load(reinterpret_cast<const vec4*>(p));
+        return {make_float4(t[0], t[1], t[2], t[3])};
+    }
     __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
     // write-once output that nobody re-reads soon: non-temporal, so the stream does not push the gathered table out of the caches
     __device__ void store_stream(float* p) const {
@@ -65,6 +71,7 @@ template <> struct Frag<1> {
     float v;
     __device__ static Frag zero() { return {0.f}; }
     __device__ static Frag load(const float* p) { return {*p}; }
+    __device__ static Frag load_stream(const float* p) { return {__builtin_nontemporal_load(p)}; }
     __device__ void store(float* p) const { *p = v; }
     __device__ void store_stream(float* p) const { __builtin_nontemporal_store(v, p); }
     __device__ void add_scaled(const Frag& o, float s) { v += s * o.v; }

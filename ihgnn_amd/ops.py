@@ -76,11 +76,12 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
                          out_scale: Optional[Tensor] = None, mode: int = _lib.SCALE_NONE,
                          out: Optional[Tensor] = None, entry_scale: Optional[Tensor] = None,
                          self_weight: Optional[Tensor] = None, rows: Optional[Tensor] = None, src_mask: Optional[Tensor] = None,
-                         role: Optional[str] = None, accumulate: bool = False) -> Tensor:
+                         role: Optional[str] = None, accumulate: bool = False, read_once: bool = False) -> Tensor:
     """``role`` names the launch for the profiler (one kernel, several jobs with different byte counts: ``bench.py`` reports each).
     ``rows`` (int32, device): only these output rows are needed.  The split rows of the plan are always computed; of the
     others only the listed ones are, and the rest of ``out`` is left unwritten.  ``src_mask`` (uint8 per source row): rows with a 0
-    are all-zero and are not fetched.  ``accumulate``: ``out +=`` instead of ``out =`` (``out`` required; the hyperedge chunks of one scatter)."""
+    are all-zero and are not fetched.  ``accumulate``: ``out +=`` instead of ``out =`` (``out`` required; the hyperedge chunks of one scatter).
+    ``read_once``: every source row is read exactly once by this launch (non-temporal loads)."""
     lib = _lib.load()
     src = _rows(src, 'src')
     dim = int(src.shape[1])
@@ -88,6 +89,8 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
         if out is None or rows is not None:
             raise ValueError('accumulate needs an existing `out` and all rows')
         mode = mode | _lib.SCALE_ACCUMULATE
+    if read_once:
+        mode = mode | _lib.SRC_READ_ONCE
     if out is None:
         out = torch.empty(csr.n_rows, dim, dtype=torch.float32, device=src.device)
     heavy = csr.n_heavy > 0
@@ -552,7 +555,7 @@ def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: Incidence
             _lib.check(lib.ihg_interact_bwd_user_reduced(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(grad_out), _ld(grad_out), _ptr(g2),
                                                          _ptr(dh), dim, _ptr(dw), _ld(dw) if dw is not None else 0, _ptr(ws), ws.numel() * 4, n_edges, dim, _stream()),
                        'ihg_interact_bwd_user_reduced')
-        node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients')
+        node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients', read_once=True)
         return dh
     if n_chunks == 1:
         parts = [(0, n_edges, layout.member_csr)]
@@ -572,7 +575,7 @@ def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: Incidence
         if index > 0 and dw is not None:
             dw[:, 3 * dim:].add_(dw_part[:, 3 * dim:])
         # (node v, hyperedge e) reads row 3 (e - e0) + type(v); the chunks after the first ADD onto dh inside the kernel (no [N, d] add pass)
-        dh = node_segment_sum_raw(g.view(3 * n, dim), csr, role='k7.member_gradients', out=dh, accumulate=dh is not None)
+        dh = node_segment_sum_raw(g.view(3 * n, dim), csr, role='k7.member_gradients', out=dh, accumulate=dh is not None, read_once=True)
         del g
     return dh
 
@@ -661,7 +664,7 @@ class _InteractToNodes(torch.autograd.Function):
                 _lib.check(lib.ihg_interact_bwd_gathered(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(dy), _ld(dy), _ptr(out_scale),
                                                          _ptr(dout), dim, _ptr(g2), _ptr(dh), dim, _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4,
                                                          n_edges, dim, _stream()), 'ihg_interact_bwd_gathered')
-            node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients')
+            node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients', read_once=True)
         else:
             dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
             dh = _interact_backward(h, w, dout, layout, order, dw)
@@ -751,7 +754,7 @@ class _InteractLayer(torch.autograd.Function):
                 _lib.check(lib.ihg_interact_bwd_gathered(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(dy), _ld(dy), _ptr(out_scale),
                                                          _ptr(dout), dim, _ptr(g2), _ptr(dh), dim, None if node_weight else _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4,
                                                          n_edges, dim, _stream()), 'ihg_interact_bwd_gathered')
-            node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients')
+            node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients', read_once=True)
             del g2
             if keep_dout:
                 dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')

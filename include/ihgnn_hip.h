@@ -33,6 +33,7 @@ extern "C" {
 #define IHG_SCALE_NONE        0
 #define IHG_SCALE_MULTIPLY    1   /* out[r] = scale[r] * sum   (Dv^-1, Dv^-1/2) */
 #define IHG_SCALE_DIVIDE      2   /* out[r] = sum / scale[r]   (EmbeddingBag 'mean': scale = bag length) */
+#define IHG_SRC_READ_ONCE     0x400 /* OR-ed into out_scale_mode of ihg_node_segment_sum: every source row is read exactly once by this launch (a scatter of per-member rows) - non-temporal loads */
 #define IHG_SCALE_ACCUMULATE  0x100 /* OR-ed into out_scale_mode of ihg_node_segment_sum: out[r] += (scaled) sum - the hyperedge chunks of one scatter add up in `out` */
 
 typedef void* ihg_stream_t;       /* hipStream_t */
