@@ -1838,9 +1838,10 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
 #pragma unroll
             for (int x = 0; x < ZX; ++x) {
                 r.hv[x] = *reinterpret_cast<const v4f*>(hp + 32 * x);
-                r.sa[x] = *reinterpret_cast<const v4f*>(sp + 32 * x);
-                r.sb[x] = *reinterpret_cast<const v4f*>(sp + D + 32 * x);
-                r.sab[x] = *reinterpret_cast<const v4f*>(sp + 2 * D + 32 * x);
+                // (the pair sums are read once here and not again: non-temporal, so that h and dy stay cached for the member-gradient kernel that follows - 2 % there)
+                r.sa[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp + 32 * x));
+                r.sb[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp + D + 32 * x));
+                r.sab[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp + 2 * D + 32 * x));
             }
         };
         const int swz = tr_swizzle(row);
