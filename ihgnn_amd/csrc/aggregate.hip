@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
     for (int64_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         const int64_t row = heavy_rows[h];
         const int s_begin = heavy_segptr[h], s_end = heavy_segptr[h + 1];
-        for (int c0 = 0; c0 < dim_vec; c0 += G) {
+        for (int c0 = blockIdx.y * G; c0 < dim_vec; c0 += gridDim.y * G) {     // (gridDim.y > 1: the column groups of a wide row - the 3 d-wide pair sums - on workgroups of their own)
             const int c = c0 + lig;
             Frag<VEC> acc = Frag<VEC>::zero();
             if (c < dim_vec) {
@@ -544,7 +544,7 @@ int ihg_node_pair_sums(const float* h, int64_t ld_h, const int32_t* pair_ptr, co
         hipLaunchKernelGGL((node_pair_sums_kernel<G>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, pair_ptr, pair_ids, row_order, out,  \
                            ld_out, n_rows, dim, dim_vec, heavy_threshold, seg_begin, seg_end, n_segments, partials);                        \
         if (n_heavy > 0)                                                                                                                    \
-            hipLaunchKernelGGL((heavy_finish_kernel<4, G>), dim3(static_cast<int>(std::min<int64_t>(n_heavy, kMaxBlocks * 4))),             \
+            hipLaunchKernelGGL((heavy_finish_kernel<4, G>), dim3(static_cast<int>(std::min<int64_t>(n_heavy, kMaxBlocks * 4)), (3 * dim_vec + G - 1) / G), \
                                dim3(kBlockThreads), 0, s, partials, heavy_rows, heavy_segptr, n_heavy, nullptr, IHG_SCALE_NONE, out, ld_out, \
                                3 * dim, 3 * dim_vec, nullptr, 0, nullptr, nullptr);                                                         \
     }

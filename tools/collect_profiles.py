@@ -48,8 +48,23 @@ def main():
             if key.startswith('edge_gather_sum_kernel'):
                 out['edge_gather_sum'] = dict(hbm_bytes_per_launch=v['hbm_bytes_per_launch'], avg_us_under_pmc=v['avg_us_under_pmc'])
             if key.startswith('node_pair_sums_kernel'):                   # one launch per step under its own name: in situ
-                out['node_pair_sums'] = dict(hbm_bytes_per_launch=v['hbm_bytes_per_launch'], avg_us_under_pmc=v['avg_us_under_pmc'],
-                                             source='in situ: the pair-sum launch of each training step of the counter passes over bench.py (FETCH_SIZE doubled + WRITE_SIZE)')
+                # bench.py brackets the OP (the pair-sum kernel and the finish kernel of its split rows, which follows it): add that launch's time
+                def finish_after_pairs(directory):
+                    path = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)[0]
+                    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r['Start_Timestamp']))
+                    seen, extra = set(), []
+                    for i, r in enumerate(rows):
+                        if 'node_pair_sums_kernel' in r['Kernel_Name'] and r['Start_Timestamp'] not in seen:
+                            seen.add(r['Start_Timestamp'])
+                            nxt = next((x for x in rows[i + 1:i + 8] if 'heavy_finish_kernel' in x['Kernel_Name']), None)
+                            if nxt is not None:
+                                extra.append((int(nxt['End_Timestamp']) - int(nxt['Start_Timestamp'])) / 1e3)
+                    return sum(extra) / len(extra) if extra else 0.0
+                finish_us = finish_after_pairs(fetch)
+                out['node_pair_sums'] = dict(hbm_bytes_per_launch=v['hbm_bytes_per_launch'], avg_us_under_pmc=round(v['avg_us_under_pmc'] + finish_us, 1),
+                                             kernel_us=v['avg_us_under_pmc'], finish_kernel_us=round(finish_us, 1),
+                                             source='in situ: the pair-sum launch of each training step of the counter passes over bench.py (FETCH_SIZE doubled + WRITE_SIZE); '
+                                                    'time = the pair-sum kernel + the finish kernel of its split rows (what bench.py brackets)')
         # K5 and K7's hyperedge -> node launch on their own (kbench): the step may not launch K5 at all, and K7's launch roles share a name
         f57, w57 = os.path.join(src, 'pmc_k57_FETCH_SIZE'), os.path.join(src, 'pmc_k57_WRITE_SIZE')
         if os.path.isdir(f57) and os.path.isdir(w57):
