@@ -1134,6 +1134,9 @@ def test_full_size_c5_interact_in_three_chunks():
     backward with the 154 GB member-gradient buffer produced in three hyperedge chunks, each scattered through its own member lists
     (150 M entries in all).  Oracle on sampled hyperedges (forward) and sampled nodes (d h); Euler identity for d W over all 50 M
     hyperedges; first-order gradient = K7 of the cotangent.  Needs ~210 GB of HBM: skipped on a smaller device."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                                              # (the allocator's cache of the tests before this one is not free memory to mem_get_info)
     free, total = torch.cuda.mem_get_info()
     if free < 215 * (1 << 30):
         pytest.skip(f'needs 215 GiB of free HBM, this device has {free / (1 << 30):.0f}')
@@ -1198,6 +1201,9 @@ def test_full_size_c5_node_level_layer():
     (split rows of millions of pairs), the node-level contraction in four passes x four column parts, the node-level weight gradients over 10 M rows.
     Output rows against the oracle on sampled users, items and queries; d W through the Euler identity (the layer is linear in its product blocks:
     <d W_prod, W_prod> = <dy, y(product blocks only)>) and its first-order blocks / bias likewise.  Needs ~150 GB of HBM: skipped on a smaller device."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                                              # (the allocator's cache of the tests before this one is not free memory to mem_get_info)
     free, total = torch.cuda.mem_get_info()
     if free < 160 * (1 << 30):
         pytest.skip(f'needs 160 GiB of free HBM, this device has {free / (1 << 30):.0f}')
