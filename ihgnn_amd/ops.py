@@ -513,6 +513,7 @@ NODE_LEVEL_FORWARD = _os.environ.get('IHG_NODE_LEVEL_FORWARD', '1') != '0'
 NODE_LEVEL_WEIGHT = _os.environ.get('IHG_NODE_LEVEL_WEIGHT', '1') != '0'
 # ... and then the first-order gradient d P = H H^T (scale * dy) by the two-hop operator instead of a scatter of stored [E, d] cotangents (IHG_FIRST_ORDER_TWO_HOP=1; measured at C3: 8.81 against 8.74 ms per step for store + scatter, the default)
 FIRST_ORDER_TWO_HOP = _os.environ.get('IHG_FIRST_ORDER_TWO_HOP', '0') != '0'
+FIRST_ORDER_TWO_HOP_BYTES = int(_os.environ.get('IHG_FIRST_ORDER_TWO_HOP_BYTES', 8 << 30))     # where the member-gradient kernel does not form the hyperedges' cotangents itself: [E, d] tables larger than this take the two-hop form
 
 
 def _node_level_forward_ok(h: Tensor, w: Tensor, bias: Optional[Tensor], out: Optional[Tensor], dim: int, order: int) -> bool:
@@ -762,9 +763,14 @@ class _InteractLayer(torch.autograd.Function):
                 dp = node_segment_sum_raw(dy, layout.hop2_csr, out_scale, None, _lib.SCALE_NONE, self_weight=layout.self_weight, role='k7.two_hop_first_order_gradient')
         else:
             dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
-            # the scatter of dout goes first: K5 has just written it, so most of its rows are still in the Infinity Cache for these random
-            # reads; the interact kernels read it as a stream and do not care
-            dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
+            if n_edges * dim * 4 > FIRST_ORDER_TWO_HOP_BYTES:
+                # a [E, d] table far beyond the caches (config C5: 51 GB): its scatter reads HBM at random, the two-hop operator on the node-level
+                # cotangent (10 GB) gathers twice the rows and is still the shorter launch (22 against 32 ms)
+                dp = node_segment_sum_raw(dy, layout.hop2_csr, out_scale, None, _lib.SCALE_NONE, self_weight=layout.self_weight, role='k7.two_hop_first_order_gradient')
+            else:
+                # the scatter of dout goes first: K5 has just written it, so most of its rows are still in the Infinity Cache for these random
+                # reads; the interact kernels read it as a stream and do not care
+                dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
             dh = _interact_backward(h, w, dout, layout, order, None if node_weight else dw)
         del dout
         dbias = torch.empty(dim, dtype=torch.float32, device=h.device) if ctx.has_bias else None
