@@ -350,7 +350,7 @@ def main():
     # form, or K7's hyperedge -> node launch of its hyperedge form) is bracketed by HIP events: a pair of timing events costs a few
     # microseconds of stream time, and bracketing all launches of a step would inflate it.
     if not args.no_kernel_events:
-        profiler.start(only={'edge_gather_sum', 'k7.edges_to_nodes', 'node_pair_sums'})
+        profiler.start(only={'edge_gather_sum', 'k7.edges_to_nodes', 'node_pair_sums'} | ({'k7.two_hop'} if args.layer == 'hgcn' else set()))
     fence()
     t0 = time.perf_counter()
     for k in range(args.warmup, args.warmup + args.steps):
@@ -572,6 +572,17 @@ def main():
                                 '2 x 4 d B per incidence (3 E incidences) + 24 B of ids per hyperedge + (12 d + 8) B per node: the two other members\' rows of every incidence; '
                                 'the node table (N x 4 d B) fits the Infinity Cache at C3, so most of these are cache reads - this rate is not an HBM rate and may exceed the peak',
                                 'node_pair_sums', 'HIP events on the launch stream, inside the timed region')
+    if args.layer == 'hgcn' and 'k7.two_hop' in kernels:
+        # HGCNLayer (GnnLayers.py:142-153) is the pure aggregation layer: Dv^-1/2 H De^-1 H^T Dv^-1/2 (X W + b) - node -> hyperedge scatter-reduce and hyperedge -> node
+        # reduce with no per-hyperedge dense work.  The build applies H De^-1 H^T in ONE launch over the two-hop list (no [E, d] round trip), so that launch IS the
+        # layer's node -> hyperedge + hyperedge -> node aggregation and it is the bracketed kernel
+        th_compulsory = N * row + 24 * E + N * (row + 8)      # every node row once + the two-hop lists (2 ids per incidence) + the [N, d] store and its row pointers
+        th_algorithmic = E * (16 * dim + 12) + E * (12 * dim + 12) + N * (row + 8)    # K5 (16 d + 12) + K7 (12 d + 12 + (N / E)(4 d + 8)) per hyperedge
+        roofline = hbm_roofline('node_segment_sum, role k7.two_hop', 'HGCN layer: node -> hyperedge -> node aggregation H De^-1 H^T in one pass over the two-hop list', kernels['k7.two_hop'],
+                                th_compulsory, th_algorithmic, 'compulsory HBM bytes per launch: every node row once + two-hop lists (2 ids per incidence) + [N,d] store',
+                                'SURVEY §8 d3 for the two phases it replaces: K5 16 d + 12 B and K7 12 d + 12 B per hyperedge + (4 d + 8) B per node; the launch gathers 6 E + N rows '
+                                'of a node table that fits the Infinity Cache at C2-C4, so this rate is not an HBM rate there and may exceed the peak', 'k7.two_hop',
+                                'HIP events on the launch stream, inside the timed region')
     if k5_alone is not None:
         k5_outside = hbm_roofline(*k5_args[:2], k5_alone, *k5_args[3:], 'HIP events on the launch stream; six launches of their own after the timed region (no step launches K5)')
     mfma_roof = None

@@ -23,6 +23,7 @@ _FLAGS = (
     ('embedding_size', ('--embedding_size', '--emb'), int, 0, 'embedding width (0 = Gs.embedding_size)'),
     # not in the reference: batches (positive permutation + negative sampling) produced on the GPU instead of by DataLoader + random.sample
     ('device_sampling', ('--device_sampling',), 'flag', False, 'draw training batches on the device (same distribution, different random stream)'),
+    ('grad_sync', ('--grad_sync',), str, 'flat', 'gradient exchange under torchrun: flat | bucketed | sharded (ihgnn_amd.distributed)'),
     ('record_step', ('--record_step',), 'flag', False, 'replay the training step as one recorded hipGraph (single process; pays on small graphs, where the step is launch-bound)'),
 )
 

@@ -123,7 +123,7 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
         fused = getattr(model, 'supports_fused_loss', None) and model.supports_fused_loss(loss_function)
         if record_step and fused and grad_sync is None:
             recorded = getattr(model, '_recorded_step', None)
-            if recorded is None or recorded.optimizer is not optimizer:
+            if recorded is None or recorded.optimizer is not optimizer or recorded.stale():     # (stale: a hyper-parameter or path switch baked into the recording changed)
                 from ..captured_step import CapturedTrainingStep
                 recorded = model._recorded_step = CapturedTrainingStep(model, optimizer, int(users.shape[0]), warmup_batch=(users, queries, items, flags))
             if recorded.batch_rows == int(users.shape[0]):

@@ -106,7 +106,16 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
                    feature_interaction_order=order, phase2_attention=False).to(device)
     loss_function = nn.BCEWithLogitsLoss().to(device)
     from .optim import Adam
-    optimizer = Adam(model.parameters(), Gs.learning_rate, weight_decay=Gs.weight_decay)      # torch.optim.Adam's rule (Main.py:192), one launch
+    grad_sync = None
+    if world > 1:
+        # one exchange step per training step: flat all-reduce | per-bucket all-reduces overlapped with the backward |
+        # reduce-scatter + Adam on this rank's shard + all-gather.  Built BEFORE the optimizer: the sharded exchange owns it.
+        grad_sync = ihg_dist.make_gradient_sync(model, args.grad_sync)
+        grad_sync.broadcast_parameters(0)
+    if grad_sync is not None and grad_sync.owns_optimizer:
+        optimizer = grad_sync.optimizer(Gs.learning_rate, Gs.weight_decay)
+    else:
+        optimizer = Adam(model.parameters(), Gs.learning_rate, weight_decay=Gs.weight_decay)      # torch.optim.Adam's rule (Main.py:192), one launch
 
     epoch_start = 1
     if args.checkpoint:
@@ -123,10 +132,8 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
         epoch_start = int(state['epoch_count']) + 1
         say(f'resumed from {name} ({epoch_start - 1} epochs done)')
 
-    grad_sync = None
-    if world > 1:
-        grad_sync = ihg_dist.GradientSync(model.parameters())
-        grad_sync.broadcast_parameters(0)
+    if grad_sync is not None and args.checkpoint:
+        grad_sync.broadcast_parameters(0)                    # (the loaded weights, identical on every rank anyway)
 
     store_from, store_every = (epoch_count, 1000000) if args.storecheckpoint else (None, None)
     if chief:
@@ -141,10 +148,14 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
         avg_loss, train_seconds = train_and_get_avg_loss(model, optimizer, loss_function, dataset_train, dataloader_train,
                                                          pc, device, grad_sync=grad_sync, record_step=bool(getattr(args, 'record_step', False)) and world == 1)
         pc.AddTrainTime(train_seconds)
-        if chief and pc.ShouldStore():
-            fn = os.path.join(result_dir, time.strftime(f'checkpoint_%y%m%d-%H%M%S_epoch{pc.CurrentEpoch}', time.localtime()))
-            say(f'\ncheckpoint -> {fn}')
-            torch.save({'epoch_count': pc.CurrentEpoch, 'model': model.state_dict(), 'optimizer': optimizer.state_dict()}, fn)
+        if pc.ShouldStore():
+            # every rank builds the state (a sharded optimizer gathers its Adam shards with a collective), the chief writes it
+            state = ihg_dist.checkpoint_state(pc.CurrentEpoch, model, optimizer)
+            if chief:
+                fn = os.path.join(result_dir, time.strftime(f'checkpoint_%y%m%d-%H%M%S_epoch{pc.CurrentEpoch}', time.localtime()))
+                say(f'\ncheckpoint -> {fn}')
+                torch.save(state, fn)
+            del state
         if pc.ShouldTest():
             say('\nevaluating on the TEST set ...')
             per_user, m_test, t_test = test_and_get_avg_metrics(model, dataset_train, dataloader_test, bool(Gs.long_tail_stat_fn))

@@ -32,6 +32,11 @@ class RawGnn(nn.Module):
         self.phase2_attention = phase2_attention
         self.prediction_layer_type = predictions
         self.output_feature_size = embedding_size * (1 + gnn_layer_count)
+        if self.output_feature_size > self.MAX_SCORED_WIDTH:
+            # refused HERE, not at the first evaluation after an epoch of training: the scoring kernel (ihg_score_topk) keeps the mixed rows of 32
+            # (user, query) pairs in LDS for its whole run, which bounds the feature width d (L + 1)
+            raise NotImplementedError(f'RawGnn: feature width embedding_size * (layers + 1) = {self.output_feature_size} exceeds {self.MAX_SCORED_WIDTH}, the widest '
+                                      'matrix the MI355X evaluation kernel scores (32 mixed rows in 160 KB of LDS); use a smaller embedding or fewer layers')
 
         self.embeddings = EmbeddingLayer(dataset=dataset, embedding_size=embedding_size)
 
@@ -58,6 +63,7 @@ class RawGnn(nn.Module):
 
     # bce_loss: evaluate the last layer's hyperedge -> node pass only at the rows the loss reads (same loss, same gradients)
     batch_rows_only_last_layer = True
+    MAX_SCORED_WIDTH = 1272                                   # ops.score_topk: 32 x (width + 4) floats of LDS
 
     def propagate_layers(self, tail_gradients=None, batch_rows=None, restrict_last_layer=True):
         """Full-graph propagation: the list ``[X0, X1, ..., XL]`` of ``[N, d]`` node features (input embeddings and every
@@ -94,7 +100,15 @@ class RawGnn(nn.Module):
             return torch.cat(self.propagate_layers(), 1)
         d = self.embedding_size
         w = self.embeddings.embedding_bag_vocabulary.weight
-        features = torch.empty(self.dataset.node_count, self.output_feature_size, dtype=torch.float32, device=w.device)
+        width = self.output_feature_size
+        if width % 4:
+            # any embedding size works (the reference takes any; `--emb 50 --gnns 2` gives 150): rows are stored 16-byte aligned with ZERO pad columns, which the
+            # evaluation kernel reads as part of the dot product (they add exact zeros); callers see the [N, D] view
+            storage = torch.zeros(self.dataset.node_count, (width + 3) // 4 * 4, dtype=torch.float32, device=w.device)
+            storage._ihg_zero_padded = True                  # (ops.score_topk takes the padded buffer behind the view as it is)
+            features = storage[:, :width]
+        else:
+            features = torch.empty(self.dataset.node_count, width, dtype=torch.float32, device=w.device)
         x = self.embeddings.all_nodes(out=features[:, :d])
         for depth, layer in enumerate(self.gnns, 1):
             x = layer(x, out=features[:, depth * d:(depth + 1) * d])
@@ -161,8 +175,8 @@ class RawGnn(nn.Module):
     def top_items(self, user_indices: Tensor, query_indices: Tensor, k: int = 10):
         """``(items [C, k] int32, scores [C, k])``: the ``k`` best items of each (user, query) pair over the whole catalogue, best
         first - what ``Metrics.calculate_on_all_items`` keeps of ``forward(u, q, None)`` (``Metrics.py:60-61``) - from the fused
-        HIP scoring + running top-k kernel; the ``[C, I]`` scores are never stored.  Ties: ascending item id.  No torch path: the feature width
-        ``d (L + 1)`` must be a multiple of 4 (``ops.score_topk`` raises otherwise)."""
+        HIP scoring + running top-k kernel; the ``[C, I]`` scores are never stored.  Ties: ascending item id.  No torch path: any feature width
+        ``d (L + 1)`` up to ``MAX_SCORED_WIDTH`` (checked at construction) - widths that are not a multiple of 4 are scored on zero-padded rows."""
         from .. import ops
         features = self._saved_output_feature if self._saved_output_feature is not None else self.propagate()
         ds, head = self.dataset, self.prediction_layer

@@ -24,8 +24,8 @@ ABI_VERSION = 27
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
-SCALE_ACCUMULATE = 0x100
-SRC_READ_ONCE = 0x400         # every source row of this ihg_node_segment_sum launch is read exactly once: non-temporal loads                                 # OR-ed into the mode of ihg_node_segment_sum: out += instead of out =
+SCALE_ACCUMULATE = 0x100      # OR-ed into the mode of ihg_node_segment_sum: out += instead of out =
+SRC_READ_ONCE = 0x400         # OR-ed into the mode of ihg_node_segment_sum: every source row of this launch is read exactly once (non-temporal loads)
 
 _i64p, _i32p, _f32p = POINTER(c_int64), POINTER(c_int32), POINTER(c_float)
 

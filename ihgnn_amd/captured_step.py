@@ -45,6 +45,10 @@ class CapturedTrainingStep:
                     slots.append((module, name, p))
         if {id(p) for _, _, p in slots} != wanted:
             raise ValueError('CapturedTrainingStep: the optimizer holds parameters that are not parameters of the model')
+        first_slot = {}
+        for module, name, p in slots:
+            first_slot.setdefault(id(p), (module, name, p))
+        slots_by_param = [first_slot[id(p)] for p in params]
 
         def forward_backward():
             # The forward runs on fresh LEAF ALIASES of the parameters (same storage, new autograd identity) and the gradients come from
@@ -70,16 +74,40 @@ class CapturedTrainingStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                forward_backward()
+                _, warm_grads = forward_backward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        unused = [name for (module, name, p), g in zip(slots_by_param, warm_grads) if g is None]
+        del warm_grads
+        if unused:
+            # the eager Adam.step skips a parameter whose gradient is None (no decay, no step count); a recording cannot - it would have to
+            # step it with a zero gradient, which decays it under weight_decay > 0 and lets the step counts of the two paths drift apart
+            raise ValueError(f'CapturedTrainingStep: parameters without a gradient in this step ({", ".join(unused)}): freeze them (requires_grad = False) '
+                             'or train eagerly')
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss, grads = forward_backward()
             for p, g in zip(params, grads):
-                p.grad = g if g is not None else torch.zeros_like(p)
+                p.grad = g
             optimizer.launch_with_device_scalars(self.scalars)
+        self._baked = self._baked_settings()
+
+    def _baked_settings(self):
+        """Everything a replay cannot change any more: the recording holds the kernels these settings selected.  Only the learning rate is
+        refreshed per replay (it enters through the device scalars)."""
+        import os
+        group = self.optimizer.param_groups[0]
+        switches = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('IHG_')))
+        from . import ops
+        flags = tuple((name, getattr(ops, name)) for name in ('USER_REDUCED_BACKWARD', 'SPARSE_LAST_COTANGENT', 'NODE_LEVEL_FORWARD', 'NODE_LEVEL_WEIGHT',
+                                                              'FIRST_ORDER_TWO_HOP', 'LAYER0_ONE_NODE', 'MEMBER_BUFFER_LIMIT_BYTES') if hasattr(ops, name))
+        return (tuple(group['betas']), float(group['eps']), float(group['weight_decay']), bool(self.model.batch_rows_only_last_layer), switches, flags)
+
+    def stale(self) -> bool:
+        """True when a setting that is baked into the recording (Adam's betas / eps / weight decay, ``batch_rows_only_last_layer``, the ``IHG_*``
+        path switches) has changed since: the caller must record a new step (``TrainTestHelper`` does) - replaying would silently ignore the change."""
+        return self._baked != self._baked_settings()
 
     TABLE_STEPS = 2048
 
@@ -101,6 +129,9 @@ class CapturedTrainingStep:
     def step(self, users, queries, items, labels):
         if users.shape[0] != self.batch_rows:
             raise ValueError(f'this step was recorded for batches of {self.batch_rows} rows, got {users.shape[0]}')
+        if self.stale():
+            raise RuntimeError('CapturedTrainingStep: a setting baked into the recording changed (Adam betas / eps / weight_decay, batch_rows_only_last_layer or an '
+                               'IHG_* switch); record a new step')
         self.users.copy_(users, non_blocking=True)
         self.queries.copy_(queries, non_blocking=True)
         self.items.copy_(items, non_blocking=True)

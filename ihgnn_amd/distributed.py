@@ -218,7 +218,12 @@ class _ShardOptimizer:
 
     def state_dict(self):
         """Adam state of ALL parameters: every rank's shard of ``exp_avg`` / ``exp_avg_sq`` gathered into full-length flat vectors
-        (the same on every rank, so rank 0's checkpoint is complete and can be resumed at another world size)."""
+        (the same on every rank, so rank 0's checkpoint is complete and can be resumed at another world size).
+
+        COLLECTIVE: it issues ``all_gather_into_tensor`` - EVERY rank of the group must call it, at the same point of the program.  The
+        usual ``if chief: torch.save({... optimizer.state_dict()})`` would leave rank 0 waiting for peers that never come; call
+        :func:`checkpoint_state` on every rank and save its result on the chief (``Main.py`` does).  ``local_state_dict()`` is the
+        collective-free form (this rank's shard only)."""
         sync = self.sync
         state = self.inner.state_dict()
         entry = next(iter(state['state'].values()), None)
@@ -233,6 +238,10 @@ class _ShardOptimizer:
                 full[key] = gathered[:sync.flat.numel()].clone()
             full['step'] = entry['step']
         return {'sharded_adam': full, 'param_groups': state['param_groups'], 'numel': sync.flat.numel()}
+
+    def local_state_dict(self):
+        """This rank's shard of the Adam state, no collective (a per-rank checkpoint file; not loadable at another world size)."""
+        return {'adam_shard': self.inner.state_dict(), 'shard_range': tuple(self.sync.shard_range), 'numel': self.sync.flat.numel()}
 
     def load_state_dict(self, state):
         sync = self.sync
@@ -328,6 +337,13 @@ class ShardedGradientSync(GradientSync):
     def broadcast_parameters(self, src: int = 0) -> None:
         if self.distributed:
             dist.broadcast(self.flat_params, src=src, group=self.group)
+
+
+def checkpoint_state(epoch: int, model: torch.nn.Module, optimizer) -> dict:
+    """The dict a training checkpoint holds (``Main.py:144-147`` of the reference: epoch, model, optimizer).  Call it on EVERY rank: a sharded
+    optimizer's ``state_dict()`` gathers the ranks' Adam shards with a collective, and a chief-only call would deadlock.  Every rank gets the
+    same complete dict back; only the chief writes it."""
+    return {'epoch_count': int(epoch), 'model': model.state_dict(), 'optimizer': optimizer.state_dict()}
 
 
 def make_gradient_sync(model: torch.nn.Module, mode: str = 'bucketed', group=None) -> GradientSync:

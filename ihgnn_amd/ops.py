@@ -1069,6 +1069,21 @@ def score_topk(features: Tensor, users: Tensor, queries: Tensor, query_row0: int
     ``(top_items [C, k] int32, top_scores [C, k])``, best first, ties in ascending item order; the ``[C, I]`` score matrix is
     never materialised.  ``features`` = the cached ``[N, D]`` propagation output; items are its rows from ``item_row0`` on."""
     lib = _lib.load()
+    width = int(features.shape[1]) if features.dim() == 2 else 0
+    if features.is_cuda and features.dtype == torch.float32 and features.dim() == 2 and 0 < width <= 1272 and (
+            width % 4 or features.stride(1) != 1 or features.stride(0) % 4 or features.data_ptr() % 16):
+        # a width that is not a multiple of 4 (the reference accepts any embedding size) or unaligned rows: scored on 16-byte aligned rows with ZERO pad
+        # columns (exact zeros in every dot product).  RawGnn.propagate() already stores its matrix that way - the view [N, D] of a zero-padded
+        # [N, ceil4(D)] buffer is taken as it is; anything else is copied once into such a buffer
+        padded = (width + 3) // 4 * 4
+        base = features._base if features._base is not None else None
+        if (base is not None and base.dim() == 2 and tuple(base.shape) == (features.shape[0], padded) and base.is_contiguous() and features.data_ptr() == base.data_ptr()
+                and features.stride(0) == padded and base.data_ptr() % 16 == 0 and getattr(base, '_ihg_zero_padded', False)):
+            features = base
+        else:
+            wide = torch.zeros(features.shape[0], padded, dtype=torch.float32, device=features.device)
+            wide[:, :width].copy_(features)
+            features = wide
     if not score_topk_supported(features):
         raise _lib.IhgnnHipError(f'ihg_score_topk needs a float32 GPU feature matrix with 16-byte aligned rows and width % 4 == 0, got '
                                  f'{tuple(features.shape)} {features.dtype} on {features.device}')

@@ -74,6 +74,21 @@ def _worker(rank, world, port, out_dir, mode='flat'):
             want = next(iter(opt.inner.state_dict()['state'].values()))
             assert torch.equal(mine['exp_avg'], want['exp_avg']) and torch.equal(mine['exp_avg_sq'], want['exp_avg_sq'])
             opt = fresh
+        if mode == 'sharded' and step == 1:
+            # the driver's checkpoint pattern (Main.py): EVERY rank builds the state - state_dict() of the sharded optimizer is a collective, a
+            # chief-only call would wait for its peers forever - and only the chief writes it; the file is complete: the other rank finds its shard in it
+            state = ihg_dist.checkpoint_state(7, model, opt)
+            path = os.path.join(out_dir, 'checkpoint_chief.pt')
+            if rank == 0:
+                torch.save(state, path)
+            dist.barrier()
+            saved = torch.load(path)
+            assert saved['epoch_count'] == 7 and set(saved) == {'epoch_count', 'model', 'optimizer'}
+            lo, hi = sync.shard_range
+            mine = next(iter(opt.inner.state_dict()['state'].values()))
+            hi_real = min(hi, sync.flat.numel())
+            assert torch.equal(saved['optimizer']['sharded_adam']['exp_avg'][lo:hi_real], mine['exp_avg'].reshape(-1)[:hi_real - lo])
+            assert set(opt.local_state_dict()) == {'adam_shard', 'shard_range', 'numel'}           # the collective-free form
     torch.save({k: v.clone() for k, v in model.reference_state().items()}, os.path.join(out_dir, f'rank{rank}.pt'))
     if mode == 'bucketed':                                  # a second backward before the exchange was waited for must not pass silently
         lossf(model(u[sl], q[sl], i[sl]), y[sl]).backward()

@@ -1337,7 +1337,7 @@ def test_batched_evaluation_equals_per_log_scoring(tmp_path):
     np.testing.assert_allclose([avg.HitRatio_at10, avg.NDCG_at10, avg.MAP_at10], [want.HitRatio_at10, want.NDCG_at10, want.MAP_at10], atol=1e-9)
 
 
-@pytest.mark.parametrize('dim,n_items,n_pairs', [(64, 257, 5), (36, 31, 40), (192, 70001, 97), (512, 4100, 33), (128, 7, 3), (768, 1200, 64)])
+@pytest.mark.parametrize('dim,n_items,n_pairs', [(64, 257, 5), (36, 31, 40), (192, 70001, 97), (512, 4100, 33), (128, 7, 3), (768, 1200, 64), (150, 333, 21), (7, 90, 9)])
 def test_score_topk_matches_oracle(dim, n_items, n_pairs):
     """f1: the fused scoring + running top-10 kernel against the oracle's HEM scores of every item (PredictionLayers.py:35-43) sorted
     as Metrics.calculate_on_all_items does (Metrics.py:60-61) - widths with dim % 8 == 4, item counts off the 32-item tile, fewer
@@ -1362,6 +1362,31 @@ def test_score_topk_matches_oracle(dim, n_items, n_pairs):
         gap = (want[order][:-1] - want[order][1:]).abs().min().item() if k > 1 else 1.0
         if gap > 1e-4 * want.abs().max().item():                 # no near-tie among the top k: same items in the same order
             assert items[c].tolist() == order.tolist()
+
+
+def test_top_items_at_a_width_that_is_not_a_multiple_of_four():
+    """``--emb 50 --gnns 2`` (feature width 150; the reference accepts any embedding size): the cached propagation is stored on zero-padded 16-byte
+    aligned rows and ``top_items`` scores it on the HIP kernel - same items and scores as the dense ``score_all_items`` + a stable sort."""
+    from ihgnn_amd import profiler, synth
+    from ihgnn_amd.Dataset import GraphDataset
+    w = synth.draw(60, 20, 150, 30, 800, seed=31)
+    ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets, w.triples, device=dev())
+    torch.manual_seed(2)
+    m = build_model(ds, 'ihgnn', 2, 3, 50)
+    users = torch.arange(40, device=dev()) % w.user_count
+    queries = torch.arange(40, device=dev()) % w.query_count
+    with torch.no_grad():
+        m.save_features_for_test()
+        assert tuple(m._saved_output_feature.shape) == (w.node_count, 150) and m._saved_output_feature.stride(0) == 152
+        profiler.start()
+        items, scores = m.top_items(users, queries)
+        profiler.stop()
+        assert 'score_topk' in profiler.summary()
+        dense = m.score_all_items(users, queries)
+        m.clear_saved_feature()
+    order = torch.sort(dense, dim=1, descending=True, stable=True).indices[:, :10]
+    assert rel(scores, torch.gather(dense, 1, order)) <= RTOL
+    assert rel(torch.gather(dense, 1, items.long()), torch.gather(dense, 1, order)) <= RTOL
 
 
 def test_score_topk_ties_and_ranking_metrics():
@@ -1791,6 +1816,43 @@ def test_recorded_training_step_equals_the_eager_step():
     for k in p0:
         assert rel(p1[k], p0[k]) <= 1e-6, k
     assert o1.next_step() == o0.next_step() == 5
+
+
+def test_recorded_step_refuses_what_it_cannot_replay():
+    """What is baked into a recording is checked at every replay (Adam's eps / betas / weight decay, ``batch_rows_only_last_layer``, the path switches: only the
+    learning rate is refreshed), and a model with a parameter that gets no gradient is refused at recording time (the eager Adam skips such a parameter, a
+    recording would step and decay it)."""
+    from ihgnn_amd import synth
+    from ihgnn_amd.Dataset import GraphDataset
+    from ihgnn_amd.captured_step import CapturedTrainingStep
+    from ihgnn_amd.optim import Adam
+    w = synth.draw(120, 20, 90, 30, 1500, seed=22)
+    ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets, w.triples, device=dev())
+    batches = list(ds.sample_batches(50, 2, seed=5))
+    torch.manual_seed(3)
+    m = build_model(ds, 'ihgnn', 2, 3, 64)
+    opt = Adam(m.parameters(), 1e-3, weight_decay=0)
+    step = CapturedTrainingStep(m, opt, batches[0][0].shape[0], warmup_batch=batches[0])
+    step.step(*batches[0])
+    assert not step.stale()
+    opt.param_groups[0]['lr'] = 2e-3                          # the learning rate is NOT baked
+    step.step(*batches[1])
+    opt.param_groups[0]['weight_decay'] = 0.01
+    assert step.stale()
+    with pytest.raises(RuntimeError, match='baked into the recording'):
+        step.step(*batches[0])
+    opt.param_groups[0]['weight_decay'] = 0.0
+    m.batch_rows_only_last_layer = not m.batch_rows_only_last_layer
+    assert step.stale()
+    m.batch_rows_only_last_layer = not m.batch_rows_only_last_layer
+    assert not step.stale()
+    del step
+    opt.zero_grad(set_to_none=True)
+    extra = torch.nn.Parameter(torch.zeros(4, device=dev()))
+    m.register_parameter('never_used', extra)
+    opt2 = Adam(m.parameters(), 1e-3, weight_decay=0)
+    with pytest.raises(ValueError, match='without a gradient'):
+        CapturedTrainingStep(m, opt2, batches[0][0].shape[0], warmup_batch=batches[0])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -363,3 +363,11 @@ def test_log_hypergraph_matches_reference():
     # the entry point the reference's dataset calls
     g2 = PpsLogHyperGraph.from_search_logs(ds.search_logs, ds.node_count, ds.user_count, ds.query_count, CPU)
     np.testing.assert_array_equal(g2.Adjacency.indices().numpy(), z['adj_indices'])
+
+
+def test_model_refuses_a_feature_width_the_evaluation_kernel_cannot_score_at_construction():
+    """d (L + 1) beyond the scoring kernel's LDS pair block is refused when the model is BUILT - not at the first evaluation, an epoch of training later."""
+    import torch
+    from ihgnn_amd.Models import HemPredictionLayer, IHGNNLayer, RawGnn
+    with pytest.raises(NotImplementedError, match='1280 exceeds 1272'):
+        RawGnn(torch.device('cpu'), None, 256, IHGNNLayer, 4, 3, False, HemPredictionLayer, 0.5)
