@@ -663,7 +663,25 @@ def main():
         out['fwd_only_hyperedges_per_s'] = round(E * layers / fwd_elapsed, 1)
         out['fwd_only_ms'] = round(1e3 * fwd_elapsed, 4)
     if k5_outside is not None:
+        # north_star: ">= 40 % of the MI355X HBM roofline on the node -> hyperedge scatter-reduce at 1 GPU" - judged on the COMPULSORY bytes (frac); the SURVEY §8 d3
+        # byte model counts every gathered row, which at these node-table sizes is a cache rate and can exceed the HBM peak
+        k5_outside['target'] = 0.40
+        k5_outside['target_met'] = bool(k5_outside['frac'] >= 0.40)
         out['roofline_node_to_hyperedge'] = k5_outside
+    # SURVEY §8 d3's byte model against what the step really moves: the model prices the reference's two-phase formulation (K5 + K7 per layer, training ~ 3 x forward);
+    # the build's re-associations (two-hop fusion, node-level form of the interactive layer) move fewer bytes for the same result, so model / time can exceed the HBM peak
+    d3_fwd = (16 * dim + 12 + 12 * dim + 12) * E * layers + (4 * dim + 8) * N * layers
+    step_s = elapsed / args.steps
+    measured = measured_src = None
+    if pmc is not None and pmc.get('step_l2_miss_bytes'):
+        measured = int(pmc['step_l2_miss_bytes'])
+        measured_src = f'NOT measured in this run: every kernel of one training step of the committed in-situ counter pass {pmc_name} (commit {pmc.get("commit", "unrecorded")})'
+    out['step_bytes'] = dict(model_d3_forward=d3_fwd, model_d3_training=3 * d3_fwd, model_d3_gbs=round(3 * d3_fwd / step_s / 1e9, 1),
+                             model_d3_frac_of_hbm_peak=round(3 * d3_fwd / step_s / 1e9 / HBM_PEAK_GBS, 3), measured_l2_miss=measured,
+                             measured_l2_miss_gbs=round(measured / step_s / 1e9, 1) if measured else None, measured_source=measured_src, ms=round(1e3 * step_s, 4),
+                             note='model_d3 = SURVEY §8 d3 algorithmic bytes of the REFERENCE formulation ((16 d + 12) + (12 d + 12) per hyperedge-layer + (4 d + 8) per node-layer forward, '
+                                  'training = 3 x); a model rate above the HBM peak is not skipped work: the step computes the same function with fewer bytes (DESIGN.md section 4); '
+                                  'measured_l2_miss = FETCH_SIZE (doubled) + WRITE_SIZE at the L2 <-> fabric boundary, Infinity-Cache hits included')
     if stress is not None:
         out['roofline_gather_stress'] = stress
     if eval_stats is not None:

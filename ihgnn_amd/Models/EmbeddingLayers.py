@@ -39,6 +39,14 @@ class EmbeddingLayer(nn.Module):
         this ``[N, d]`` destination (a column slice of the feature matrix)."""
         return ops.embed_all_nodes(self.embedding_user.weight, self.embedding_item.weight, self.embedding_bag_vocabulary.weight, self.dataset.bag_layout, out)
 
+    def node_tables(self, holder):
+        """The same features WITHOUT assembling them (``ops.NodeTables``): the first layer's node-level transform reads the tables in place and its backward writes
+        their gradients in place; ``None`` where the library does not offer that (other widths, fp32-MFMA arithmetic)."""
+        tables = (self.embedding_user.weight, self.embedding_item.weight, self.embedding_bag_vocabulary.weight)
+        if not ops.NodeTables.supported(*tables):
+            return None
+        return ops.NodeTables(*tables, self.dataset.bag_layout, holder)
+
     def embed_user(self, user_indices: Optional[Tensor] = None) -> Tensor:
         w = self.embedding_user.weight
         return w[1:] if user_indices is None else w[user_indices + 1]

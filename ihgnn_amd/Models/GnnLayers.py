@@ -42,6 +42,10 @@ class HGCNLayer(nn.Module):
             self.out_scale = self.layout.inv_sqrt_deg * self.edge_scale
         self.feature_transform = nn.Linear(input_dimension, output_dimension)
 
+    def reads_cotangent_rows_only(self) -> bool:
+        """With ``output_rows`` / ``cotangent_rows`` the backward reads its cotangent at those rows only (``ops.node_two_hop``'s masked pull)."""
+        return not self.general
+
     def forward(self, input_features: Tensor, output_rows: Optional[Tensor] = None, cotangent_rows: Optional[Tensor] = None,
                 out: Optional[Tensor] = None) -> Tensor:
         """``out`` (inference only): the ``[N, d]`` destination, e.g. a column slice of the ``[N, d (L + 1)]`` feature matrix.
@@ -79,6 +83,10 @@ class IHGNNLayer(nn.Module):
                                                     node_feature_dimension=input_dimension,
                                                     output_dimension=input_dimension)
         self.feature_transform = nn.Linear(input_dimension, output_dimension)
+
+    def reads_cotangent_rows_only(self) -> bool:
+        """First-order layers run the two-hop operator, whose backward under ``output_rows`` / ``cotangent_rows`` is the masked pull."""
+        return self.feature_interaction_order == 1
 
     def forward(self, input_features: Tensor, output_rows: Optional[Tensor] = None, cotangent_rows: Optional[Tensor] = None,
                 out: Optional[Tensor] = None) -> Tensor:

@@ -72,20 +72,33 @@ class RawGnn(nn.Module):
         ``batch_rows`` (int64 node rows): nobody reads ``XL`` outside these rows (a training step scores the batch only).  With
         ``restrict_last_layer`` the last hypergraph layer computes just them (plus the split rows of its plan) and leaves the rest
         unwritten; without it every row is computed and the layer is only told that its cotangent is zero outside them."""
-        x = self.embeddings.all_nodes()
-        outputs = []
+        from .. import ops
         last = len(self.gnns)
+        x = None
+        if tail_gradients is not None and last >= 1 and ops.NODE_TABLES and (batch_rows is None or int(batch_rows.shape[0]) <= ops.SCATTER_CHUNK_ROWS):
+            # a training step through the fused batch tail: X0 is not assembled - the first layer's transform and the tail read the embedding tables in place
+            x = self.embeddings.node_tables(tail_gradients)
+        if x is None:
+            x = self.embeddings.all_nodes()
+        outputs = []
         for depth in range(last + 1):
+            sparse_top = None
             if depth > 0:
                 layer = self.gnns[depth - 1]
                 if depth == last and batch_rows is not None and isinstance(layer, (IHGNNLayer, HGCNLayer)):
                     rows = batch_rows.to(torch.int32)
                     x = layer(x, output_rows=rows) if restrict_last_layer else layer(x, cotangent_rows=rows)
+                    # the layer's backward pulls the listed rows of its cotangent only (the masked two-hop pull): the tap writes them and fills nothing
+                    if ((restrict_last_layer or ops.SPARSE_LAST_COTANGENT) and not ops.CHECK_SPARSE_COTANGENT and layer.reads_cotangent_rows_only()
+                            and int(batch_rows.shape[0]) <= ops.SCATTER_CHUNK_ROWS):
+                        sparse_top = layer.layout
                 else:
                     x = layer(x)
             if tail_gradients is not None:
-                from .. import ops
-                x, for_tail = ops.tap(x, tail_gradients, depth)
+                if isinstance(x, ops.NodeTables):
+                    outputs.append(x)                        # (no tap: the first layer's transform adds the tail's layer-0 gradients itself)
+                    continue
+                x, for_tail = ops.tap(x, tail_gradients, depth, sparse_top)
                 outputs.append(for_tail)
             else:
                 outputs.append(x)
@@ -148,7 +161,7 @@ class RawGnn(nn.Module):
         kernels (the training loops use it when the loss function is a plain ``BCEWithLogitsLoss``)."""
         from .. import ops
         ds, head = self.dataset, self.prediction_layer
-        rows = torch.cat([user_indices, query_indices + ds.query_start_index_in_graph, item_indices + ds.item_start_index_in_graph])
+        rows = ops.batch_node_rows(user_indices, query_indices, item_indices, ds.query_start_index_in_graph, ds.item_start_index_in_graph)
         holder = ops.TailGradients() if torch.is_grad_enabled() else None
         return ops.hem_bce_loss(self.propagate_layers(holder, rows, self.batch_rows_only_last_layer), rows, item_indices, labels,
                                 head.items_bias, head.lambda_muq,

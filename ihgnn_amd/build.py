@@ -11,7 +11,7 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(CSRC, 'libihgnn_hip.so')
 SOURCES = [os.path.join(CSRC, name) for name in ('host.hip', 'aggregate.hip', 'interact.hip', 'split_arith.hip', 'dense.hip', 'tail.hip', 'eval.hip')]
-HEADERS = [os.path.join(REPO, 'include', 'ihgnn_hip.h'), os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'split.hpp')]
+HEADERS = [os.path.join(REPO, 'include', 'ihgnn_hip.h'), os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'split.hpp'), os.path.join(CSRC, 'ablate.hpp')]
 ARCH = 'gfx950'
 
 

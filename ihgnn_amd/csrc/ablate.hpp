@@ -1,0 +1,56 @@
+// ablate.hpp - compile-time switches of the ABLATION builds (tools/ab_variant.sh NAME -DIHG_ABL_<SWITCH> ...; never the product build).
+// An ablation build removes one class of work from a kernel - its result is WRONG on purpose - so that the time that class costs inside the
+// kernel can be read off (profiles/r4/abl_members.txt).  The product build defines none of the macros: every switch below is a constexpr false and
+// the branches it guards fold away (tests/test_abi.py checks that the shipped library was not built with one).
+#pragma once
+
+namespace abl {
+
+#ifdef IHG_ABL_M_NO_G_STORES      // member gradients: no stores of the [E, 2|3, d] member buffer
+constexpr bool m_no_g_stores = true;
+#else
+constexpr bool m_no_g_stores = false;
+#endif
+#ifdef IHG_ABL_M_NO_DOUT_STORE    // member gradients, gathering form: the hyperedges' cotangents are not stored
+constexpr bool m_no_dout_store = true;
+#else
+constexpr bool m_no_dout_store = false;
+#endif
+#ifdef IHG_ABL_M_NO_MEMBER_LOADS  // member gradients: the three member rows of h are not loaded (values made up from the ids)
+constexpr bool m_no_member_loads = true;
+#else
+constexpr bool m_no_member_loads = false;
+#endif
+#ifdef IHG_ABL_M_NO_DY_LOADS      // member gradients: the cotangent rows (dout, or the three gathered dy rows) are not loaded
+constexpr bool m_no_dy_loads = true;
+#else
+constexpr bool m_no_dy_loads = false;
+#endif
+#ifdef IHG_ABL_M_NO_MFMA          // member gradients: the matrix waves only keep the barriers
+constexpr bool m_no_mfma = true;
+#else
+constexpr bool m_no_mfma = false;
+#endif
+#ifdef IHG_ABL_M_NO_SPLIT         // member gradients: the bf16 images are written from the raw bits (no split arithmetic)
+constexpr bool m_no_split = true;
+#else
+constexpr bool m_no_split = false;
+#endif
+#ifdef IHG_ABL_M_NO_USER_SUMS     // member gradients, user-reduced form: no run sums of the user slot
+constexpr bool m_no_user_sums = true;
+#else
+constexpr bool m_no_user_sums = false;
+#endif
+#ifdef IHG_ABL_M_NO_PRODUCT_RULE  // member gradients: no product rule (and so no member-buffer stores and no user image)
+constexpr bool m_no_product_rule = true;
+#else
+constexpr bool m_no_product_rule = false;
+#endif
+
+#ifdef IHG_VAR_LATE_DELIVERY        // A/B (not an ablation: results stay right): the node-level streaming kernels do not take delivery of a phase's row requests at its end
+constexpr bool late_delivery = true;
+#else
+constexpr bool late_delivery = false;
+#endif
+constexpr bool any = m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
+}  // namespace abl

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
                                    : accumulate_list<VEC, G, STREAM>(src, ld_src, ids, src_scale, entry_scale, src_mask, begin, len, wave_len, lane, col);
             if (dst != nullptr && col >= 0) {
                 if (scale_row >= 0) {
-                    if (self_weight != nullptr)             // square operators: the row's own source row, weighted
+                    if (self_weight != nullptr && (src_mask == nullptr || src_mask[scale_row] != 0))   // square operators: the row's own source row, weighted (a masked row is zero: not fetched)
                         acc.add_scaled(Frag<VEC>::load(src + scale_row * ld_src + col * VEC),
                                        self_weight[scale_row] * (src_scale != nullptr ? src_scale[scale_row] : 1.f));
                     apply_out_scale<VEC>(acc, out_scale, mode, scale_row);
@@ -341,7 +341,8 @@ template <int VEC, int G>
 __global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
     const float* __restrict__ partials, const int32_t* __restrict__ heavy_rows, const int32_t* __restrict__ heavy_segptr,
     int64_t n_heavy, const float* __restrict__ out_scale, int mode, float* __restrict__ out, int64_t ld_out, int dim, int dim_vec,
-    const float* __restrict__ src, int64_t ld_src, const float* __restrict__ src_scale, const float* __restrict__ self_weight) {
+    const float* __restrict__ src, int64_t ld_src, const float* __restrict__ src_scale, const float* __restrict__ self_weight,
+    const uint8_t* __restrict__ src_mask = nullptr) {
     constexpr int GROUPS = kBlockThreads / G;
     __shared__ __attribute__((aligned(16))) float red[GROUPS][G * VEC];
     const int lig = threadIdx.x & (G - 1);
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
                 Frag<VEC> total = Frag<VEC>::load(&red[0][lig * VEC]);
                 const int used = s_end - s_begin < GROUPS ? s_end - s_begin : GROUPS;
                 for (int g2 = 1; g2 < used; ++g2) total.add(Frag<VEC>::load(&red[g2][lig * VEC]));
-                if (self_weight != nullptr)
+                if (self_weight != nullptr && (src_mask == nullptr || src_mask[row] != 0))
                     total.add_scaled(Frag<VEC>::load(src + row * ld_src + c * VEC), self_weight[row] * (src_scale != nullptr ? src_scale[row] : 1.f));
                 apply_out_scale<VEC>(total, out_scale, mode, row);
                 if (mode & IHG_SCALE_ACCUMULATE) total.add(Frag<VEC>::load(out + row * ld_out + c * VEC));
@@ -457,7 +458,7 @@ void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowpt
     if (hp.n_heavy > 0)
         hipLaunchKernelGGL((heavy_finish_kernel<VEC, G>), dim3(static_cast<int>(std::min<int64_t>(hp.n_heavy, kMaxBlocks * 4))),
                            dim3(kBlockThreads), 0, stream, hp.partials, hp.heavy_rows, hp.heavy_segptr, hp.n_heavy, out_scale, mode, out,
-                           ld_out, dim, dim_vec, src, ld_src, src_scale, self_weight);
+                           ld_out, dim, dim_vec, src, ld_src, src_scale, self_weight, hp.src_mask);
 }
 
 template <int VEC>

@@ -121,6 +121,43 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ slabs, int n
 }
 
 
+}  // namespace
+
+// Rows of a node-level matrix that is not ONE contiguous [N, ld] block: the rows of every node type (users, queries, items) start at an address of
+// their own - the input features X0 are rows 1.. of the user table, the bag means of the queries and rows 1.. of the item table (Models/RawGnn.py:112,
+// Models/EmbeddingLayers.py:70-79), and assembling them costs four [N, d]-sized copies per training step.  p[t] + v * ld addresses GLOBAL node row v of
+// type t: p[t] = (first row of type t) - type_begin[t] * ld, a virtual base.  A contiguous matrix is three equal pointers.
+struct TypedRows {
+    const float* p[3];
+};
+struct TypedRowsOut {
+    float* p[3];
+};
+
+namespace {
+inline TypedRows typed_rows(const float* base) { return TypedRows{{base, base, base}}; }
+inline TypedRowsOut typed_rows_out(float* base) { return TypedRowsOut{{base, base, base}}; }
+inline TypedRows typed_rows(const float* const* first_rows, const int64_t* type_begin, int64_t ld) {
+    TypedRows t;
+    for (int k = 0; k < 3; ++k) t.p[k] = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(first_rows[k]) - static_cast<uintptr_t>(type_begin[k] * ld * 4));
+    return t;
+}
+inline TypedRowsOut typed_rows_out(float* const* first_rows, const int64_t* type_begin, int64_t ld) {
+    TypedRowsOut t;
+    for (int k = 0; k < 3; ++k) t.p[k] = reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(first_rows[k]) - static_cast<uintptr_t>(type_begin[k] * ld * 4));
+    return t;
+}
+
+// p[0 .. n) = 0 (small fills that would otherwise be torch launches inside a training step: padding rows of gradients, bias gradients, row masks)
+__global__ __launch_bounds__(kBlockThreads) void zero_floats_kernel(float* __restrict__ p, int64_t n) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * kBlockThreads) p[i] = 0.f;
+}
+inline void launch_zero_floats(float* p, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    const int grid = static_cast<int>(std::min<int64_t>((n + kBlockThreads - 1) / kBlockThreads, kMaxBlocks));
+    hipLaunchKernelGGL(zero_floats_kernel, dim3(grid), dim3(kBlockThreads), 0, s, p, n);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool mfma_dim(int dim) { return dim == 32 || dim == 64 || dim == 128 || dim == 256; }
 

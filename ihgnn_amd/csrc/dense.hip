@@ -446,15 +446,19 @@ __global__ __launch_bounds__(512, 4) void row_gemm_strip_kernel(const float* __r
 
 constexpr int kDenseSlabs = 256;
 
+// in_typed / out_typed: the rows of every node type start at an address of their own (TypedRows; `in` / `out` are then ignored) - on the bf16-split kernels only
 int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose,
                     const float* bias, int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, float* pk,
-                    hipStream_t s) {
+                    hipStream_t s, const TypedRows* in_typed = nullptr, const TypedRowsOut* out_typed = nullptr) {
     const int n_types = w_type_stride == 0 ? 1 : 3;
-    if (split_row_gemm_ok(dim, out, ld_out, bias, bias_type_stride)) {   // the bf16 planes sit behind the slabs (see ihg_node_linear_workspace_bytes)
+    const bool out_ok = out_typed != nullptr ? (aligned16(out_typed->p[0]) && aligned16(out_typed->p[1]) && aligned16(out_typed->p[2])) : aligned16(out);
+    if (out_ok && split_row_gemm_ok(dim, nullptr, ld_out, bias, bias_type_stride)) {   // the bf16 planes sit behind the slabs (see ihg_node_linear_workspace_bytes)
         void* planes = pk + 3LL * dim * dim + 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
-        launch_row_gemm_split(dim, in, ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin, out, ld_out, planes, s);
+        launch_row_gemm_split(dim, in_typed != nullptr ? *in_typed : typed_rows(in), ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin,
+                              out_typed != nullptr ? *out_typed : typed_rows_out(out), ld_out, planes, s);
         return IHG_OK;
     }
+    if (in_typed != nullptr || out_typed != nullptr) return fail(IHG_ERR_INVALID, "node-level linear map over typed rows: needs the bf16-split kernels (dim 128 / 256, aligned rows)");
     if (dim == 128 && aligned16(out) && ld_out % 4 == 0 && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0))) {
         const int items = n_types * (dim / 16) * (dim / 16) * kWave;
         hipLaunchKernelGGL(pack_dense_strip_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride,
@@ -770,7 +774,8 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
         if (dx != nullptr && !fused_dx) launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace), s);
         void* planes = static_cast<float*>(workspace) + 3LL * dim * dim + 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
         if (dx_accumulate && !fused_dx) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate needs 16-byte aligned dx rows at dim 128");
-        n_slabs = launch_dense_weight_split(dim, dout, ld_dout, x, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, fused_dx ? dx : nullptr, ld_dx,
+        const TypedRowsOut dx_rows = typed_rows_out(dx);
+        n_slabs = launch_dense_weight_split(dim, dout, ld_dout, typed_rows(x), ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, fused_dx ? &dx_rows : nullptr, ld_dx,
                                             planes, s, dx_accumulate);
     } else if (dim == 64 && dx != nullptr) {
         hipLaunchKernelGGL((dense_weight_grad_kernel<64, true>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
@@ -794,6 +799,66 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, bias_slabs,
                        n_slabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask, n_types == 1 ? int64_t{0} : dbias_type_stride);
     return check_launch("ihg_node_linear_bwd_weight");
+}
+
+int32_t ihg_node_linear_typed_supported(int32_t dim, int64_t ld_x, int64_t ld_out) {
+    return split_arith_enabled() && (dim == 128 || dim == 256) && ld_x >= dim && ld_out >= dim && ld_x % 4 == 0 && ld_out % 4 == 0 ? 1 : 0;
+}
+
+int ihg_node_linear_fwd_typed(const float* const* x_rows, int64_t ld_x, const float* w, int64_t ld_w, int64_t w_type_stride, const float* bias,
+                              int32_t bias_type_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, void* workspace,
+                              int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
+    if (int rc = node_linear_common_check("ihg_node_linear_fwd_typed", dim, ld_x, ld_out, ld_w, type_begin, workspace, workspace_bytes)) return rc;
+    if (type_begin[3] == type_begin[0]) return IHG_OK;
+    if (x_rows == nullptr || w == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_linear_fwd_typed: null pointer");
+    for (int t = 0; t < 3; ++t)
+        if (type_begin[t + 1] > type_begin[t] && (x_rows[t] == nullptr || !aligned16(x_rows[t]))) return fail(IHG_ERR_INVALID, "ihg_node_linear_fwd_typed: rows of type %d null or not 16-byte aligned", t);
+    if (!ihg_node_linear_typed_supported(dim, ld_x, ld_out) || workspace == nullptr || !aligned16(workspace))
+        return fail(IHG_ERR_INVALID, "ihg_node_linear_fwd_typed: not available for this shape (ihg_node_linear_typed_supported)");
+    const TypedRows in = typed_rows(x_rows, type_begin, ld_x);
+    if (int rc = launch_row_gemm(dim, nullptr, ld_x, w, ld_w, w_type_stride, 0, bias, bias_type_mask, bias_type_stride, type_begin, out, ld_out, static_cast<float*>(workspace),
+                                 static_cast<hipStream_t>(stream), &in, nullptr))
+        return rc;
+    return check_launch("ihg_node_linear_fwd_typed");
+}
+
+int ihg_node_linear_bwd_weight_typed(const float* dout, int64_t ld_dout, const float* const* x_rows, int64_t ld_x, const int64_t* type_begin,
+                                     float* dw, int64_t ld_dw, int64_t dw_type_stride, float* dbias, int32_t bias_type_mask, int64_t dbias_type_stride,
+                                     const float* w, int64_t ld_w, float* const* dx_rows, int64_t ld_dx, int32_t zero_row_before_mask,
+                                     void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
+    if (int rc = node_linear_common_check("ihg_node_linear_bwd_weight_typed", dim, ld_dout, ld_x, ld_dw, type_begin, workspace, workspace_bytes)) return rc;
+    if (dout == nullptr || x_rows == nullptr || dw == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight_typed: null pointer");
+    if (dx_rows != nullptr && (w == nullptr || ld_w < dim || ld_dx < dim)) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight_typed: dx needs w and row strides >= dim");
+    for (int t = 0; t < 3; ++t) {
+        if (type_begin[t + 1] == type_begin[t]) continue;
+        if (x_rows[t] == nullptr || !aligned16(x_rows[t]) || (dx_rows != nullptr && (dx_rows[t] == nullptr || !aligned16(dx_rows[t]))))
+            return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight_typed: rows of type %d null or not 16-byte aligned", t);
+    }
+    if (!ihg_node_linear_typed_supported(dim, ld_x, dx_rows != nullptr ? ld_dx : ld_x) || !split_dense_weight_ok(dim, dout, ld_dout, x_rows[0], ld_x) || workspace == nullptr ||
+        !aligned16(workspace))
+        return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight_typed: not available for this shape (ihg_node_linear_typed_supported)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int n_types = dw_type_stride == 0 ? 1 : 3;
+    float* slabs = static_cast<float*>(workspace) + 3LL * dim * dim;
+    float* bias_slabs = slabs + 3LL * kDenseSlabs * dim * dim;
+    void* planes = static_cast<float*>(workspace) + 3LL * dim * dim + 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
+    const TypedRows xin = typed_rows(x_rows, type_begin, ld_x);
+    TypedRowsOut dxo = typed_rows_out(nullptr);
+    if (dx_rows != nullptr) {
+        dxo = typed_rows_out(dx_rows, type_begin, ld_dx);
+        // gradient tables with a padding row in front of a type's rows (row 0 of the [U + 1, d] / [I + 1, d] embedding tables, Models/EmbeddingLayers.py:33-35): zeroed here
+        for (int t = 0; t < 3; ++t)
+            if ((zero_row_before_mask >> t) & 1) launch_zero_floats(dx_rows[t] - ld_dx, dim, s);
+    }
+    const bool fused_dx = dx_rows != nullptr && dim == 128;
+    if (dx_rows != nullptr && !fused_dx) {
+        if (int rc = launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, nullptr, ld_dx, static_cast<float*>(workspace), s, nullptr, &dxo)) return rc;
+    }
+    const int n_slabs = launch_dense_weight_split(dim, dout, ld_dout, xin, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, fused_dx ? &dxo : nullptr, ld_dx, planes, s, 0);
+    const int total = dim * dim * n_types + dim;
+    hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, bias_slabs,
+                       n_slabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask, n_types == 1 ? int64_t{0} : dbias_type_stride);
+    return check_launch("ihg_node_linear_bwd_weight_typed");
 }
 
 int ihg_compose_first_order_fwd(const float* a, int64_t ld_a, const float* c, const float* w, int64_t ld_w, const float* b, float* w_eff,

@@ -7,6 +7,8 @@
 
 #include <cstdint>
 
+#include "common.hpp"
+
 #define IHG_INTERNAL __attribute__((visibility("hidden")))
 
 // floats of workspace the weight planes of one direction take (three bf16 per weight)
@@ -33,13 +35,13 @@ IHG_INTERNAL int launch_weight_split(int dim, int order, const float* h, int64_t
 // node-level row GEMM (d = 128, 256): out = in W_t^T (transpose == 0) or in W_t (transpose == 1), rows grouped by node type
 IHG_INTERNAL int64_t split_dense_plane_floats(int dim);
 IHG_INTERNAL bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* bias, int64_t bias_type_stride);
-IHG_INTERNAL void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
-                                        int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s);
+IHG_INTERNAL void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
+                                        int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, void* planes, hipStream_t s);
 
 // weight / bias gradient of the node-level linear maps into dense.hip's slabs ([type][slab][d][d], [type][slab][d]); returns the slabs per type
 IHG_INTERNAL bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x);
-IHG_INTERNAL int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin, int n_types,
-                                           float* slabs, float* bias_slabs, const float* w, int64_t ld_w, int64_t w_type_stride, float* dx, int64_t ld_dx,
+IHG_INTERNAL int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, TypedRows x, int64_t ld_x, const int64_t* type_begin, int n_types,
+                                           float* slabs, float* bias_slabs, const float* w, int64_t ld_w, int64_t w_type_stride, const TypedRowsOut* dx, int64_t ld_dx,
                                            void* planes, hipStream_t s, int dx_accumulate = 0);   // dx != nullptr (dim 128, 16-byte aligned rows): dx (+)= dout W_t of the same rows, fused
 
 // node-level form of the interactive layer's forward (d = 64 / 128 / 256): out = scale * (sum over the node's hyperedges of their features) from h and the

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "ablate.hpp"
 #include "common.hpp"
 #include "split.hpp"
 
@@ -213,6 +214,10 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             const float* src = row_at(dout + first * ld_dout, std::min(row, lim), ldd) + 8 * o;
 #pragma unroll
             for (int x = 0; x < DOCT; ++x) {
+                if (abl::m_no_dy_loads) {
+                    dr[2 * x] = dr[2 * x + 1] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(lim + x);
+                    continue;
+                }
                 dr[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
                 dr[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
             }
@@ -230,10 +235,14 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 const float* src = row_at(dout, id, ldd) + 8 * o;
 #pragma unroll
                 for (int x = 0; x < DOCT; ++x) {
+                    if (abl::m_no_dy_loads) {
+                        raw.r[m][2 * x] = raw.r[m][2 * x + 1] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(id + x);
+                        continue;
+                    }
                     raw.r[m][2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
                     raw.r[m][2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
                 }
-                raw.s[m] = dy_scale != nullptr ? dy_scale[id] : 1.f;
+                raw.s[m] = abl::m_no_dy_loads ? 0.5f : (dy_scale != nullptr ? dy_scale[id] : 1.f);
             }
         };
         auto combine = [&](int k, const Raw& raw, v4f (&dr)[2 * DOCT]) {   // K5's order: ((0 + s_u u) + s_q q) + s_i i; the half's columns go to dout_store
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 dr[j] = acc;
             }
             const int64_t e0 = (t0 + k) * TE;
-            if (ld_store > 0 && k < n_my && e0 + row < n_edges) {       // (ld_store <= 0: nobody reads the hyperedges' cotangents after this kernel)
+            if (!abl::m_no_dout_store && ld_store > 0 && k < n_my && e0 + row < n_edges) {       // (ld_store <= 0: nobody reads the hyperedges' cotangents after this kernel)
                 float* dst = dout_store + (e0 + row) * ld_store + 64 * half + 8 * o;
                 store_stream4(dst, dr[2 * half]);
                 store_stream4(dst + 4, dr[2 * half + 1]);
@@ -257,14 +266,21 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             for (int m = 0; m < 3; ++m) {
                 const float* hp = row_at(h, idk[m], ldh) + HC * half + 4 * o;
 #pragma unroll
-                for (int x = 0; x < EX; ++x) hm[x][m] = *reinterpret_cast<const v4f*>(hp + 32 * x);
+                for (int x = 0; x < EX; ++x) hm[x][m] = abl::m_no_member_loads ? v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(idk[m] + x) : *reinterpret_cast<const v4f*>(hp + 32 * x);
             }
         };
         const int swz = row & SWZ;
         auto split_tile = [&](const v4f (&dr)[2 * DOCT], int buf) {
 #pragma unroll
             for (int x = 0; x < DOCT; ++x) {
-                const Planes pl = split8(dr[2 * x], dr[2 * x + 1]);
+                Planes pl;
+                if (abl::m_no_split) {
+                    pl.p[0] = __builtin_bit_cast(v4u, dr[2 * x]);
+                    pl.p[1] = __builtin_bit_cast(v4u, dr[2 * x + 1]);
+                    pl.p[2] = pl.p[0];
+                } else {
+                    pl = split8(dr[2 * x], dr[2 * x + 1]);
+                }
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[buf][p][row][((o + 8 * x) ^ swz) << 4]) = pl.p[p];
             }
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 }
                 const bool live = e < n_edges;
                 if (UR) *reinterpret_cast<v4f*>(&utile[(k - 1) & 1][row][c]) = live ? g_u : v4f{0.f, 0.f, 0.f, 0.f};     // (rows past the end: zeros for the sums)
-                if (live) {
+                if (live && !abl::m_no_g_stores) {
                     float* dst = g_out + e * (GS * D) + HC * half + c;
                     if (!UR) {
                         store_stream4(dst, g_u);
@@ -410,7 +426,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3]) {
             float wrows[8];
             Chain chain;
-            if (UR) {                                                    // LDS reads of this phase's run sums, used at its end
+            if (UR && !abl::m_no_user_sums) {                            // LDS reads of this phase's run sums, used at its end
                 if (k >= 2 && k - 2 < n_my) load_window(k - 2, wrows);
                 if (k >= 3) load_chain(k - 3, chain);
             }
@@ -431,8 +447,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             }
             asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));
             if (GATHER) combine(k + 2, raw, fill);
-            if (k >= 1 && k - 1 < n_my) epilogue(k, hm_prev);
-            if (UR) {
+            if (k >= 1 && k - 1 < n_my && !abl::m_no_product_rule) epilogue(k, hm_prev);
+            if (UR && !abl::m_no_user_sums) {
                 if (k >= 3) chain_windows(k - 3, chain);                 // (before the next tile's ballot: it compares with the open run's user)
                 if (k >= 2 && k - 2 < n_my) sum_window(k - 2, wrows);
             }
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     __syncthreads();
     const int arow = lane & 15, kq = lane >> 4;
     for (int k = 0; k < n_phases; ++k) {
-        if (k < n_my && blk < NBLK) {
+        if (k < n_my && blk < NBLK && !abl::m_no_mfma) {
             const unsigned char* pbase = &planes[k & 1][0][0][0];
             // row tile after row tile (one set of CT accumulator tiles live), the fragments of step s + 1 requested in front of the MFMAs of step s
             auto fragment = [&](int step, v8s (&a)[3]) {
@@ -2013,9 +2029,9 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_kernel(const 
 // D = 128: one workgroup covers all columns, two workgroups per CU.  D = 256: a workgroup covers a column HALF (96 weight registers per
 // wave), the two halves of a tile sequence are two workgroups on one XCD (the second read of a row hits that L2), one workgroup per CU.
 template <int D>
-__global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(const float* __restrict__ in, int64_t ld_in, const v4u* __restrict__ pk,
+__global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(TypedRows in, int64_t ld_in, const v4u* __restrict__ pk,
                                                                              int64_t pk_type_stride, const float* __restrict__ bias, int bias_mask,
-                                                                             int64_t bias_type_stride, RowTiles plan, float* __restrict__ out, int64_t ld_out) {
+                                                                             int64_t bias_type_stride, RowTiles plan, TypedRowsOut out, int64_t ld_out) {
     constexpr int TE = 32, KB = D / 32, OCT = D / 128, HALVES = D / 128, RB = 2 * D, STEPS = 2 * KB;
     __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][RB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2039,9 +2055,9 @@ __global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(c
     const int chunk = (o ^ (row & 15)) << 4;
     auto load_rows = [&](int k, v4f (&dr)[2 * OCT]) {
         int64_t r_base, r_end;
-        tile_rows(k, r_base, r_end);
+        const int type = tile_rows(k, r_base, r_end);
         const int64_t v = std::min(r_base + row, r_end - 1);             // rows past the type's end re-read its last row (never stored)
-        const float* src = in + v * ld_in + 8 * o;
+        const float* src = in.p[type] + v * ld_in + 8 * o;
 #pragma unroll
         for (int x = 0; x < OCT; ++x) {
             dr[2 * x] = *reinterpret_cast<const v4f*>(src + 128 * x);
@@ -2101,15 +2117,17 @@ __global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(c
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk + 256 * x]) = sp[x][p];     // (past the last tile: nobody reads it)
         // delivery of the next-but-one tile's rows before the stores (see the member-gradient kernel)
-        if (OCT == 1) asm volatile("" : "+v"(fill[0]), "+v"(fill[1]));
-        else asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * OCT - 2]), "+v"(fill[2 * OCT - 1]));
+        if (!abl::late_delivery) {
+            if (OCT == 1) asm volatile("" : "+v"(fill[0]), "+v"(fill[1]));
+            else asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * OCT - 2]), "+v"(fill[2 * OCT - 1]));
+        }
         const int c4 = 128 * half + 16 * wave + 4 * kq;
         v4f bv = v4f{0.f, 0.f, 0.f, 0.f};
         if (bias != nullptr && ((bias_mask >> type) & 1)) bv = *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + c4);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int64_t v = r_base + 16 * rt + arow;
-            if (v < r_end) *reinterpret_cast<v4f*>(out + v * ld_out + c4) = acc[rt] + bv;
+            if (v < r_end) *reinterpret_cast<v4f*>(out.p[type] + v * ld_out + c4) = acc[rt] + bv;
         }
         __syncthreads();
     };
@@ -2131,10 +2149,10 @@ __global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(c
 // layout also serves row reads), wave w takes output columns 16 w .. with the type's weight planes in 48 registers - and the separate row-GEMM
 // pass over dout goes away.
 template <int D, bool DX>
-__global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(const float* __restrict__ dout, int64_t ld_dout, const float* __restrict__ x,
+__global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(const float* __restrict__ dout, int64_t ld_dout, TypedRows x,
                                                                                 int64_t ld_x, RowTiles plan, int single_weight, float* __restrict__ slabs,
                                                                                 float* __restrict__ bias_slabs, const v4u* __restrict__ pk, int64_t pk_type_stride,
-                                                                                float* __restrict__ dx, int64_t ld_dx, int dx_accumulate) {
+                                                                                TypedRowsOut dx, int64_t ld_dx, int dx_accumulate) {
     static_assert(!DX || D == 128, "the fused input gradient holds a whole weight matrix per workgroup");
     constexpr int TE = 32, HALVES = D / 128, DOCT = D / 128, IT = D / 64, DRB = 2 * D;     // dout image rows: 2 D bytes, x image rows: 256 bytes (128 columns)
     constexpr int DPL = TE * DRB, XPL = TE * 256;
@@ -2151,6 +2169,8 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
     const int64_t n_tiles = (r_end - r_begin + TE - 1) / TE;
     const int n_my = seq < n_tiles ? static_cast<int>((n_tiles - seq + n_seq - 1) / n_seq) : 0;
     const int iq = wave & 3, jh = wave >> 2;
+    // x and dx may be typed rows (TypedRows): with one weight for every node (single_weight) a tile sequence crosses the node types
+    auto row_type = [&](int64_t v) { return single_weight ? (v >= plan.begin[2] ? 2 : (v >= plan.begin[1] ? 1 : 0)) : type; };
 
     v4f acc[IT][4];
 #pragma unroll
@@ -2170,7 +2190,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
         const bool live = v < r_end;
         const int64_t vc = live ? v : r_end - 1;
         const float* ds = dout + vc * ld_dout + 8 * o;
-        const float* xs = x + vc * ld_x + 128 * half + 8 * o;
+        const float* xs = x.p[row_type(vc)] + vc * ld_x + 128 * half + 8 * o;
 #pragma unroll
         for (int i = 0; i < DOCT; ++i) {
             r.d[2 * i] = *reinterpret_cast<const v4f*>(ds + 128 * i);
@@ -2243,7 +2263,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     const int64_t v = r_base + 16 * rt + (lane & 15);
-                    if (v < r_end) gold[rt] = *reinterpret_cast<const v4f*>(dx + v * ld_dx + 16 * wave + 4 * (lane >> 4));
+                    if (v < r_end) gold[rt] = *reinterpret_cast<const v4f*>(dx.p[row_type(v)] + v * ld_dx + 16 * wave + 4 * (lane >> 4));
                 }
             }
             const unsigned char* dp = &dplanes[BUF][0][0][0];
@@ -2294,15 +2314,17 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                     }
                 }
             }
-            if (DOCT == 1) asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
-            else asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.d[2 * DOCT - 2]), "+v"(fill.d[2 * DOCT - 1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
+            if (!abl::late_delivery) {
+                if (DOCT == 1) asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
+                else asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.d[2 * DOCT - 2]), "+v"(fill.d[2 * DOCT - 1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
+            }
             if (DX) {                                                    // (after the delivery of the requested rows: the counter is in order)
                 const int arow = lane & 15, kq = lane >> 4;
                 const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     const int64_t v = r_base + 16 * rt + arow;
-                    if (v < r_end) *reinterpret_cast<v4f*>(dx + v * ld_dx + 16 * wave + 4 * kq) = gx[rt];
+                    if (v < r_end) *reinterpret_cast<v4f*>(dx.p[row_type(v)] + v * ld_dx + 16 * wave + 4 * kq) = gx[rt];
                 }
             }
             __syncthreads();
@@ -2409,8 +2431,8 @@ bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* b
     return split_arith_enabled() && (dim == 128 || dim == 256) && aligned16(out) && ld_out % 4 == 0 && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0));
 }
 
-void launch_row_gemm_split(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
-                           int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s) {
+void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
+                           int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, void* planes, hipStream_t s) {
     const int n_types = w_type_stride == 0 ? 1 : 3;
     v4u* pk = static_cast<v4u*>(planes);
     const int items = n_types * (dim / 16) * (dim / 32) * kWave;
@@ -2640,15 +2662,17 @@ bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const fl
     return split_arith_enabled() && (dim == 128 || dim == 256) && aligned16(dout) && aligned16(x) && ld_dout % 4 == 0 && ld_x % 4 == 0;
 }
 
-int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs,
-                              float* bias_slabs, const float* w, int64_t ld_w, int64_t w_type_stride, float* dx, int64_t ld_dx, void* planes, hipStream_t s,
+int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, TypedRows x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs,
+                              float* bias_slabs, const float* w, int64_t ld_w, int64_t w_type_stride, const TypedRowsOut* dx_rows, int64_t ld_dx, void* planes, hipStream_t s,
                               int dx_accumulate) {
+    const bool has_dx = dx_rows != nullptr;
+    const TypedRowsOut dx = has_dx ? *dx_rows : typed_rows_out(nullptr);
     RowTiles plan;
     for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
     for (int t = 0; t < 4; ++t) plan.tile_prefix[t] = 0;                 // (the kernel takes its tiles from the row ranges)
     if (dim == 128) {
         const int n_seq = 256;
-        if (dx != nullptr) {                                             // fused input gradient: planes of W for out = in W
+        if (has_dx) {                                                    // fused input gradient: planes of W for out = in W
             v4u* pk = static_cast<v4u*>(planes);
             const int items = n_types * 8 * 4 * kWave;
             hipLaunchKernelGGL(pack_planes_dense_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types,
@@ -2657,12 +2681,12 @@ int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, const
                                n_types == 1 ? 1 : 0, slabs, bias_slabs, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 3 * kWave}, dx, ld_dx, dx_accumulate);
         } else {
             hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, false>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                               n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), int64_t{0}, 0);
+                               n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, typed_rows_out(nullptr), int64_t{0}, 0);
         }
         return n_seq;
     }
     const int n_seq = 128;
     hipLaunchKernelGGL((dense_weight_grad_split_kernel<256, false>), dim3(2 * n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                       n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), int64_t{0}, 0);
+                       n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, typed_rows_out(nullptr), int64_t{0}, 0);
     return n_seq;
 }

@@ -12,11 +12,15 @@ namespace {
 //        rowgrad[2B + r] = ds (lam X[query_r] + (1 - lam) X[user_r])   (item row); [3B, L1*d] dense and conflict-free -
 //        the caller adds duplicate rows with one deterministic scatter.
 // ================================================================================================
+// per layer: the matrix (virtual base, common.hpp TypedRows) its user / query / item rows are read from - three equal pointers for an ordinary [N, d] layer
+// output; layer 0 may be the embedding tables themselves (rows 1.. of the user table, the queries' bag means, rows 1.. of the item table): a batch's user,
+// query and item rows are typed by construction, so the head needs no type lookup
 struct LayerPtrs {
-    const float* x[8];
+    const float* x[8][3];
+    int64_t ld[8];
 };
 
-__global__ __launch_bounds__(kBlockThreads) void hem_score_fwd_kernel(LayerPtrs layers, int n_layers, int64_t ld, int dim,
+__global__ __launch_bounds__(kBlockThreads) void hem_score_fwd_kernel(LayerPtrs layers, int n_layers, int dim,
                                                                       const int64_t* __restrict__ rows, const int64_t* __restrict__ items,
                                                                       const float* __restrict__ bias, float lam, float* __restrict__ scores,
                                                                       int64_t batch) {
@@ -25,10 +29,12 @@ __global__ __launch_bounds__(kBlockThreads) void hem_score_fwd_kernel(LayerPtrs 
         const int64_t u = rows[r], q = rows[batch + r], it = rows[2 * batch + r];
         float acc = 0.f;
         for (int l = 0; l < n_layers; ++l) {
-            const float* x = layers.x[l];
+            const float* xu = layers.x[l][0] + u * layers.ld[l];
+            const float* xq = layers.x[l][1] + q * layers.ld[l];
+            const float* xi = layers.x[l][2] + it * layers.ld[l];
             for (int c = lane; c < dim; c += kWave) {
-                const float m = lam * x[q * ld + c] + (1.f - lam) * x[u * ld + c];
-                acc += x[it * ld + c] * m;
+                const float m = lam * xq[c] + (1.f - lam) * xu[c];
+                acc += xi[c] * m;
             }
         }
 #pragma unroll
@@ -37,7 +43,7 @@ __global__ __launch_bounds__(kBlockThreads) void hem_score_fwd_kernel(LayerPtrs 
     }
 }
 
-__global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs layers, int n_layers, int64_t ld, int dim,
+__global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs layers, int n_layers, int dim,
                                                                       const int64_t* __restrict__ rows, const float* __restrict__ dscores,
                                                                       float grad_scale, float lam, float* __restrict__ rowgrad, int64_t width,
                                                                       int64_t batch) {
@@ -52,9 +58,11 @@ __global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs 
             rowgrad[(2 * batch + r) * width + col] = ds;
         }
         for (int l = 0; l < n_layers; ++l) {
-            const float* x = layers.x[l];
+            const float* pu = layers.x[l][0] + u * layers.ld[l];
+            const float* pq = layers.x[l][1] + q * layers.ld[l];
+            const float* pi = layers.x[l][2] + it * layers.ld[l];
             for (int c = lane; c < dim; c += kWave) {
-                const float xu = x[u * ld + c], xq = x[q * ld + c], xi = x[it * ld + c];
+                const float xu = pu[c], xq = pq[c], xi = pi[c];
                 const int64_t col = static_cast<int64_t>(l) * dim + c;
                 rowgrad[r * width + col] = ds * (1.f - lam) * xi;
                 rowgrad[(batch + r) * width + col] = ds * lam * xi;
@@ -175,9 +183,11 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(float* __r
 
 // dense[rows[k], 0:width] += src[k, 0:width] for the leader rows of a combined batch (no two leaders share a destination);
 // with `tail`, the single column src[k, 0] goes to tail[rows[k] - tail_row_offset] instead.
+// dense: virtual bases per node type (TypedRowsOut; a plain matrix: three equal pointers), begin1 / begin2 = first query / item row; ASSIGN: = instead of +=
+template <bool ASSIGN>
 __global__ __launch_bounds__(kBlockThreads) void batch_rows_add_kernel(const float* __restrict__ src, int64_t ld_src, int width,
                                                                        const int64_t* __restrict__ rows, const int32_t* __restrict__ leader, int n,
-                                                                       float* __restrict__ dense, int64_t ld_dense, float* __restrict__ tail,
+                                                                       TypedRowsOut dense, int64_t begin1, int64_t begin2, int64_t ld_dense, float* __restrict__ tail,
                                                                        int64_t tail_row_offset, int64_t tail_rows) {
     const int lane = threadIdx.x & 63;
     for (int64_t k = global_wave_id(); k < n; k += global_wave_count()) {
@@ -188,8 +198,23 @@ __global__ __launch_bounds__(kBlockThreads) void batch_rows_add_kernel(const flo
             if (lane == 0 && tr >= 0 && tr < tail_rows) tail[tr] += src[k * ld_src];
             continue;
         }
-        for (int c = lane; c < width; c += kWave) dense[row * ld_dense + c] += src[k * ld_src + c];
+        float* dst = dense.p[row >= begin2 ? 2 : (row >= begin1 ? 1 : 0)] + row * ld_dense;
+        for (int c = lane; c < width; c += kWave) dst[c] = ASSIGN ? src[k * ld_src + c] : dst[c] + src[k * ld_src + c];
     }
+}
+
+// mask[rows[k]] = value for the k < n listed rows (the row mask of the last layer's sparse cotangent: set before its pull, cleared after)
+__global__ __launch_bounds__(kBlockThreads) void mark_rows_kernel(const int64_t* __restrict__ rows64, const int32_t* __restrict__ rows32, int64_t n, uint8_t* __restrict__ mask,
+                                                                  uint8_t value) {
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; k < n; k += static_cast<int64_t>(gridDim.x) * kBlockThreads)
+        mask[rows64 != nullptr ? rows64[k] : static_cast<int64_t>(rows32[k])] = value;
+}
+
+// rows[0 .. 3 b) = users | queries + query_row0 | items + item_row0 (the global node rows of a batch, Models/RawGnn.py:128-131: torch.cat of three index vectors + two adds)
+__global__ __launch_bounds__(kBlockThreads) void batch_node_rows_kernel(const int64_t* __restrict__ users, const int64_t* __restrict__ queries, const int64_t* __restrict__ items,
+                                                                        int64_t b, int64_t query_row0, int64_t item_row0, int64_t* __restrict__ rows) {
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; k < 3 * b; k += static_cast<int64_t>(gridDim.x) * kBlockThreads)
+        rows[k] = k < b ? users[k] : (k < 2 * b ? queries[k - b] + query_row0 : items[k - 2 * b] + item_row0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -310,6 +335,21 @@ int ihg_sample_negatives(uint64_t seed, uint64_t counter, int64_t n_rows, int64_
 }
 
 
+// layers[l] for l >= 1 (and for l == 0 without layer0_rows) are plain [N, ld] matrices; with layer0_rows the three node types of layer 0 start at their own addresses
+static LayerPtrs layer_ptrs(const float* const* layers, int32_t n_layers, int64_t ld, const float* const* layer0_rows, int64_t ld0, const int64_t* type_begin) {
+    LayerPtrs lp{};
+    for (int l = 0; l < n_layers; ++l) {
+        for (int t = 0; t < 3; ++t) lp.x[l][t] = layers[l];
+        lp.ld[l] = ld;
+    }
+    if (layer0_rows != nullptr) {
+        const TypedRows t0 = typed_rows(layer0_rows, type_begin, ld0);
+        for (int t = 0; t < 3; ++t) lp.x[0][t] = t0.p[t];
+        lp.ld[0] = ld0;
+    }
+    return lp;
+}
+
 static int hem_common_check(const char* what, const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const int64_t* rows, int64_t batch) {
     if (n_layers < 1 || n_layers > 8) return fail(IHG_ERR_INVALID, "%s: 1..8 layer outputs supported, got %d", what, n_layers);
     if (layers == nullptr || rows == nullptr || dim <= 0 || ld < dim || batch < 0) return fail(IHG_ERR_INVALID, "%s: bad argument", what);
@@ -323,9 +363,8 @@ int ihg_hem_score_fwd(const float* const* layers, int32_t n_layers, int64_t ld, 
     if (int rc = hem_common_check("ihg_hem_score_fwd", layers, n_layers, ld, dim, rows, batch)) return rc;
     if (batch == 0) return IHG_OK;
     if (items == nullptr || bias == nullptr || scores == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd: null pointer");
-    LayerPtrs lp{};
-    for (int l = 0; l < n_layers; ++l) lp.x[l] = layers[l];
-    hipLaunchKernelGGL(hem_score_fwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers, ld,
+    const LayerPtrs lp = layer_ptrs(layers, n_layers, ld, nullptr, 0, nullptr);
+    hipLaunchKernelGGL(hem_score_fwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers,
                        dim, rows, items, bias, lambda_muq, scores, batch);
     return check_launch("ihg_hem_score_fwd");
 }
@@ -335,11 +374,37 @@ int ihg_hem_score_bwd(const float* const* layers, int32_t n_layers, int64_t ld, 
     if (int rc = hem_common_check("ihg_hem_score_bwd", layers, n_layers, ld, dim, rows, batch)) return rc;
     if (batch == 0) return IHG_OK;
     if (dscores == nullptr || rowgrad == nullptr || ld_rowgrad < static_cast<int64_t>(n_layers) * dim) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd: null pointer or short row stride");
-    LayerPtrs lp{};
-    for (int l = 0; l < n_layers; ++l) lp.x[l] = layers[l];
-    hipLaunchKernelGGL(hem_score_bwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers, ld,
+    const LayerPtrs lp = layer_ptrs(layers, n_layers, ld, nullptr, 0, nullptr);
+    hipLaunchKernelGGL(hem_score_bwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers,
                        dim, rows, dscores, grad_scale, lambda_muq, rowgrad, ld_rowgrad, batch);
     return check_launch("ihg_hem_score_bwd");
+}
+
+int ihg_hem_score_fwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
+                             const int64_t* type_begin, const int64_t* rows, const int64_t* items, const float* bias, float lambda_muq, float* scores,
+                             int64_t batch, ihg_stream_t stream) {
+    if (layer0_rows == nullptr || type_begin == nullptr || ld0 < dim) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd_typed0: layer 0 rows / type ranges missing");
+    if (n_layers < 1 || n_layers > 8 || ld < dim || dim <= 0 || batch < 0 || layers == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd_typed0: bad size");
+    if (batch == 0) return IHG_OK;
+    if (rows == nullptr || items == nullptr || bias == nullptr || scores == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd_typed0: null pointer");
+    const LayerPtrs lp = layer_ptrs(layers, n_layers, ld, layer0_rows, ld0, type_begin);
+    hipLaunchKernelGGL(hem_score_fwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers,
+                       dim, rows, items, bias, lambda_muq, scores, batch);
+    return check_launch("ihg_hem_score_fwd_typed0");
+}
+
+int ihg_hem_score_bwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
+                             const int64_t* type_begin, const int64_t* rows, const float* dscores, float grad_scale, float lambda_muq, float* rowgrad,
+                             int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream) {
+    if (layer0_rows == nullptr || type_begin == nullptr || ld0 < dim) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd_typed0: layer 0 rows / type ranges missing");
+    if (n_layers < 1 || n_layers > 8 || ld < dim || dim <= 0 || batch < 0 || layers == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd_typed0: bad size");
+    if (batch == 0) return IHG_OK;
+    if (rows == nullptr || dscores == nullptr || rowgrad == nullptr || ld_rowgrad < static_cast<int64_t>(n_layers) * dim)
+        return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd_typed0: null pointer or short row stride");
+    const LayerPtrs lp = layer_ptrs(layers, n_layers, ld, layer0_rows, ld0, type_begin);
+    hipLaunchKernelGGL(hem_score_bwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers,
+                       dim, rows, dscores, grad_scale, lambda_muq, rowgrad, ld_rowgrad, batch);
+    return check_launch("ihg_hem_score_bwd_typed0");
 }
 
 int ihg_bce_with_logits(const float* scores, const float* labels, int64_t n, float* loss, float* dscores, ihg_stream_t stream) {
@@ -386,9 +451,47 @@ int ihg_batch_rows_add(const float* src, int64_t ld_src, int32_t width, const in
     if (n_rows == 0) return IHG_OK;
     if (src == nullptr || rows == nullptr || leader == nullptr || (dense == nullptr && tail == nullptr) || (dense != nullptr && ld_dense < width))
         return fail(IHG_ERR_INVALID, "ihg_batch_rows_add: null pointer or short row stride");
-    hipLaunchKernelGGL(batch_rows_add_kernel, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), src, ld_src, width,
-                       rows, leader, static_cast<int>(n_rows), dense, ld_dense, tail, tail_row_offset, tail_rows);
+    hipLaunchKernelGGL(batch_rows_add_kernel<false>, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), src, ld_src, width,
+                       rows, leader, static_cast<int>(n_rows), typed_rows_out(dense), int64_t{0}, int64_t{0}, ld_dense, tail, tail_row_offset, tail_rows);
     return check_launch("ihg_batch_rows_add");
+}
+
+int ihg_batch_rows_put(const float* src, int64_t ld_src, int32_t width, const int64_t* rows, const int32_t* leader, int64_t n_rows, float* const* dense_rows,
+                       int64_t ld_dense, const int64_t* type_begin, int32_t assign, ihg_stream_t stream) {
+    if (n_rows < 0 || width <= 0 || ld_src < width || ld_dense < width) return fail(IHG_ERR_INVALID, "ihg_batch_rows_put: bad size");
+    if (n_rows == 0) return IHG_OK;
+    if (src == nullptr || rows == nullptr || leader == nullptr || dense_rows == nullptr || type_begin == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_rows_put: null pointer");
+    const TypedRowsOut dense = typed_rows_out(dense_rows, type_begin, ld_dense);
+    if (assign)
+        hipLaunchKernelGGL(batch_rows_add_kernel<true>, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), src, ld_src, width, rows, leader,
+                           static_cast<int>(n_rows), dense, type_begin[1], type_begin[2], ld_dense, static_cast<float*>(nullptr), int64_t{0}, int64_t{0});
+    else
+        hipLaunchKernelGGL(batch_rows_add_kernel<false>, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), src, ld_src, width, rows, leader,
+                           static_cast<int>(n_rows), dense, type_begin[1], type_begin[2], ld_dense, static_cast<float*>(nullptr), int64_t{0}, int64_t{0});
+    return check_launch("ihg_batch_rows_put");
+}
+
+int ihg_zero_floats(float* p, int64_t n, ihg_stream_t stream) {
+    if (n < 0 || (n > 0 && p == nullptr)) return fail(IHG_ERR_INVALID, "ihg_zero_floats: bad argument");
+    launch_zero_floats(p, n, static_cast<hipStream_t>(stream));
+    return check_launch("ihg_zero_floats");
+}
+
+int ihg_mark_rows(const int64_t* rows64, const int32_t* rows32, int64_t n, uint8_t* mask, int32_t value, ihg_stream_t stream) {
+    if (n < 0 || (n > 0 && (mask == nullptr || (rows64 == nullptr) == (rows32 == nullptr)))) return fail(IHG_ERR_INVALID, "ihg_mark_rows: one of rows64 / rows32 and a mask");
+    if (n == 0) return IHG_OK;
+    const int grid = static_cast<int>(std::min<int64_t>((n + kBlockThreads - 1) / kBlockThreads, kMaxBlocks));
+    hipLaunchKernelGGL(mark_rows_kernel, dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rows64, rows32, n, mask, static_cast<uint8_t>(value));
+    return check_launch("ihg_mark_rows");
+}
+
+int ihg_batch_node_rows(const int64_t* users, const int64_t* queries, const int64_t* items, int64_t batch, int64_t query_row0, int64_t item_row0, int64_t* rows,
+                        ihg_stream_t stream) {
+    if (batch < 0 || (batch > 0 && (users == nullptr || queries == nullptr || items == nullptr || rows == nullptr))) return fail(IHG_ERR_INVALID, "ihg_batch_node_rows: bad argument");
+    if (batch == 0) return IHG_OK;
+    const int grid = static_cast<int>(std::min<int64_t>((3 * batch + kBlockThreads - 1) / kBlockThreads, kMaxBlocks));
+    hipLaunchKernelGGL(batch_node_rows_kernel, dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), users, queries, items, batch, query_row0, item_row0, rows);
+    return check_launch("ihg_batch_node_rows");
 }
 
 static int adam_launch(const char* what, const ihg_adam_tensor* tensors, int32_t n_tensors, float beta1, float beta2, float eps, float weight_decay, float step_size,

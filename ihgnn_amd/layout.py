@@ -206,6 +206,13 @@ class IncidenceLayout:
         self.self_weight = torch.where(isolated, torch.zeros_like(deg), deg).to(device)
 
 
+    def row_mask(self) -> torch.Tensor:
+        """A byte per node row, all zero between uses (``ops._TwoHop.backward`` sets the rows of a sparse cotangent before its pull and clears them after)."""
+        mask = self.__dict__.get('_row_mask')
+        if mask is None:
+            mask = self.__dict__['_row_mask'] = torch.zeros(self.node_count, dtype=torch.uint8, device=self.device)
+        return mask
+
     def users_without_hyperedges(self):
         """int64 device indices of the user rows with an empty incidence list (the user-reduced backward writes ``dh`` only for users that have
         hyperedges: these rows are zeroed by the caller - a handful of rows instead of a fill of the whole user block)."""

@@ -202,14 +202,21 @@ class _TwoHop(torch.autograd.Function):
         mask = None
         if ctx.cot_rows is not None:
             # grad_out is zero outside these rows: the pull skips the gathers of the zero rows (two thirds of them - every neighbour that
-            # is not a query - and the ones that would miss the cache); same gradient as the dense pull
-            mask = torch.zeros(lay.node_count, dtype=torch.uint8, device=grad_out.device)
-            mask.index_fill_(0, ctx.cot_rows.long(), 1)
+            # is not a query - and the ones that would miss the cache); same gradient as the dense pull.  The byte-per-row mask is the layout's, all zero
+            # between uses: the listed rows are set here and cleared after the pull (two launches over 3 B ids instead of a fill of N bytes + an index fill)
+            lib = _lib.load()
+            mask = lay.row_mask()
+            rows = ctx.cot_rows
+            r64, r32 = (_ptr(rows), None) if rows.dtype == torch.int64 else (None, _ptr(rows))
+            _lib.check(lib.ihg_mark_rows(r64, r32, int(rows.shape[0]), _ptr(mask), 1, _stream()), 'ihg_mark_rows')
             if CHECK_SPARSE_COTANGENT and bool((grad_out[mask == 0] != 0).any()):
+                _lib.check(lib.ihg_mark_rows(r64, r32, int(rows.shape[0]), _ptr(mask), 0, _stream()), 'ihg_mark_rows')
                 raise RuntimeError('node_two_hop: the cotangent is not zero outside cotangent_rows / rows - the output has a consumer the caller did not declare')
-        return (node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight, src_mask=mask,
-                                     role='k7.two_hop_bwd' if mask is None else 'k7.two_hop_bwd_masked'),
-                None, None, None, None, None, None)
+        out = node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight, src_mask=mask,
+                                   role='k7.two_hop_bwd' if mask is None else 'k7.two_hop_bwd_masked')
+        if mask is not None:
+            _lib.check(lib.ihg_mark_rows(r64, r32, int(rows.shape[0]), _ptr(mask), 0, _stream()), 'ihg_mark_rows')
+        return out, None, None, None, None, None, None
 
 
 def node_two_hop(x: Tensor, layout: IncidenceLayout, in_scale: Optional[Tensor] = None, out_scale: Optional[Tensor] = None,
@@ -486,10 +493,109 @@ def compose_first_order(a: Tensor, c: Optional[Tensor], w: Tensor, b: Tensor):
     return _ComposeFirstOrder.apply(a, c, w, b)
 
 
-def node_linear(x: Tensor, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, typed: bool = False, bias_mask: int = 0b111) -> Tensor:
+class NodeTables:
+    """The input features ``X0 = [user_table[1:] ; bag means of the queries ; item_table[1:]]`` (``RawGnn.py:112-113``) WITHOUT assembling them: the
+    first node-level transform of the model reads the three row blocks where they are (``ihg_node_linear_fwd_typed``), its backward writes the tables'
+    gradients in place (no ``[N, d]`` gradient that autograd then cuts apart), and the batch tail reads / scatters its layer-0 rows the same way.
+    Stands in for the ``[N, d]`` tensor between ``EmbeddingLayer.node_tables()`` and the first layer; ``node_linear`` resolves it (bag means, autograd token)."""
+
+    def __init__(self, user_table: Tensor, item_table: Tensor, word_table: Tensor, bag: 'BagLayout', holder: 'TailGradients'):
+        self.user_table, self.item_table, self.word_table, self.bag, self.holder = user_table, item_table, word_table, bag, holder
+        self.query_rows: Optional[Tensor] = None        # [Q, d] bag means, set by the first node_linear
+        self.token: Optional[Tensor] = None             # carries the autograd edge from the batch tail to that op
+        self.dim = int(user_table.shape[1])
+        self.shape = (int(user_table.shape[0]) - 1 + bag.n_bags + int(item_table.shape[0]) - 1, self.dim)
+        self.device = user_table.device
+
+    def row_pointers(self):
+        """HOST array of three device pointers: the first row of the users, the queries, the items (row 0 of either table is its padding row)."""
+        step = self.dim * 4
+        return (ctypes.c_void_p * 3)(self.user_table.data_ptr() + step, self.query_rows.data_ptr(), self.item_table.data_ptr() + step)
+
+    @staticmethod
+    def supported(user_table: Tensor, item_table: Tensor, word_table: Tensor) -> bool:
+        lib = _lib.load()
+        d = int(user_table.shape[1])
+        return (user_table.is_cuda and all(t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (user_table, item_table, word_table))
+                and d % 4 == 0 and bool(lib.ihg_node_linear_typed_supported(d, d, d)))
+
+
+class _LinearFromTables(torch.autograd.Function):
+    """``node_linear(X0)`` with X0 given by its tables (``NodeTables``): bag means of the queries + the typed-rows row GEMM forward; backward: weight / bias gradient
+    and the input gradient written straight into the tables' gradients (padding rows zeroed by the library), the batch tail's layer-0 row gradients added
+    there (this op is also the tap of layer 0), then the bag-mean backward."""
+
+    @staticmethod
+    def forward(ctx, user_table: Tensor, item_table: Tensor, word_table: Tensor, w: Tensor, bias: Optional[Tensor], nodes: NodeTables, layout: IncidenceLayout,
+                typed: bool, bias_mask: int):
+        lib = _lib.load()
+        bag, dim = nodes.bag, nodes.dim
+        n = nodes.shape[0]
+        query_rows = torch.empty(bag.n_bags, dim, dtype=torch.float32, device=word_table.device)
+        if bag.n_bags > 0:
+            with profiler.kernel('bag_mean_fwd', bag.n_bags, dim):
+                _lib.check(lib.ihg_bag_mean_fwd(_ptr(word_table), dim, _ptr(bag.bags.ptr), _ptr(bag.bags.ids), _ptr(bag.bag_len), _ptr(query_rows), dim, bag.n_bags, dim,
+                                                _stream()), 'ihg_bag_mean_fwd')
+        nodes.query_rows, nodes.layout = query_rows, layout
+        nodes.token = torch.empty(1, dtype=torch.float32, device=word_table.device)
+        out = torch.empty(n, dim, dtype=torch.float32, device=word_table.device)
+        ws = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), word_table.device)
+        per_type_bias = bias is not None and bias.dim() == 2
+        if per_type_bias:
+            if not typed or tuple(bias.shape) != (3, dim):
+                raise ValueError(f'a per-type bias is [3, {dim}] and needs typed weights, got {tuple(bias.shape)}')
+            bias = bias.contiguous()
+        with profiler.kernel('node_linear_fwd', n, dim):
+            _lib.check(lib.ihg_node_linear_fwd_typed(nodes.row_pointers(), dim, _ptr(w), int(w.stride(0)), dim if typed else 0, _ptr(bias), bias_mask, dim if per_type_bias else 0,
+                                                     _type_begin(layout), _ptr(out), dim, _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_fwd_typed')
+        ctx.save_for_backward(user_table, item_table, w, query_rows)
+        ctx.nodes, ctx.layout, ctx.typed, ctx.bias_mask, ctx.has_bias, ctx.per_type_bias = nodes, layout, typed, bias_mask, bias is not None, per_type_bias
+        ctx.mark_non_differentiable(query_rows)
+        return out, nodes.token, query_rows
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor, _grad_token, _grad_rows):
+        lib = _lib.load()
+        user_table, item_table, w, query_rows = ctx.saved_tensors
+        nodes, layout = ctx.nodes, ctx.layout
+        bag, dim = nodes.bag, nodes.dim
+        g = _rows(grad_out, 'grad_out')
+        if g.stride(0) % 4 or g.data_ptr() % 16:
+            g = g.contiguous()
+        dev = g.device
+        d_user, d_item = torch.empty_like(user_table), torch.empty_like(item_table)
+        d_query = torch.empty_like(query_rows)
+        dw = torch.zeros_like(w) if w.shape[1] != dim * (3 if ctx.typed else 1) else torch.empty_like(w)
+        dbias = None
+        if ctx.has_bias:
+            dbias = torch.empty((3, dim) if ctx.per_type_bias else (dim,), dtype=torch.float32, device=dev)
+        step = dim * 4
+        x_rows = (ctypes.c_void_p * 3)(user_table.data_ptr() + step, query_rows.data_ptr(), item_table.data_ptr() + step)
+        dx_rows = (ctypes.c_void_p * 3)(d_user.data_ptr() + step, d_query.data_ptr(), d_item.data_ptr() + step)
+        ws = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), dev)
+        with profiler.kernel('node_linear_bwd', nodes.shape[0], dim):
+            _lib.check(lib.ihg_node_linear_bwd_weight_typed(_ptr(g), _ld(g), x_rows, dim, _type_begin(layout), _ptr(dw), int(dw.stride(0)), dim if ctx.typed else 0,
+                                                            _ptr(dbias), ctx.bias_mask, dim if ctx.per_type_bias else 0, _ptr(w), int(w.stride(0)), dx_rows, dim, 0b101,
+                                                            _ptr(ws), ws.numel() * 4, dim, _stream()), 'ihg_node_linear_bwd_weight_typed')
+        holder = nodes.holder
+        if holder is not None and holder.rowgrad is not None:              # the batch tail's gradient of the layer-0 rows: this op is their tap
+            holder.put_into_typed(dx_rows, dim, layout, 0, dim)
+        d_word = torch.empty(bag.table_rows, dim, dtype=torch.float32, device=dev)
+        with profiler.kernel('bag_mean_bwd', bag.table_rows, dim):
+            _lib.check(lib.ihg_bag_mean_bwd(_ptr(d_query), dim, _ptr(bag.words_of.ptr), _ptr(bag.words_of.ids), _ptr(bag.inv_len), _ptr(d_word), dim, bag.table_rows, dim,
+                                            _stream()), 'ihg_bag_mean_bwd')
+        return d_user, d_item, d_word, dw, dbias, None, None, None, None
+
+
+def node_linear(x, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, typed: bool = False, bias_mask: int = 0b111) -> Tensor:
     """``out[v] = x[v] @ W_type(v).T (+ bias)``.  ``typed=False``: one ``[d,d]`` weight for every node; ``typed=True``:
     ``w`` is ``[d, k*d]`` and node type t uses its column block ``w[:, t*d:(t+1)*d]``; a ``[d]`` bias is added to the types in
-    ``bias_mask``, a ``[3, d]`` bias gives every (masked) type its own vector."""
+    ``bias_mask``, a ``[3, d]`` bias gives every (masked) type its own vector.  ``x`` may be a ``NodeTables`` (the input features given by their tables)."""
+    if isinstance(x, NodeTables):
+        if x.query_rows is not None:
+            raise RuntimeError('NodeTables: the input features were already consumed by a node-level transform (one per forward)')
+        out, _token, _rows_q = _LinearFromTables.apply(x.user_table, x.item_table, x.word_table, w, bias, x, layout, bool(typed), int(bias_mask))
+        return out
     return _NodeLinear.apply(x, w, bias, layout, bool(typed), int(bias_mask))
 
 
@@ -521,6 +627,10 @@ def _node_level_forward_ok(h: Tensor, w: Tensor, bias: Optional[Tensor], out: Op
     ld_out = dim if out is None else _ld(out)
     return (bool(lib.ihg_node_interact_fwd_supported(dim, order, _ld(h), 3 * dim, ld_out)) and h.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and _ld(w) % 4 == 0
             and (bias is None or bias.data_ptr() % 16 == 0) and (out is None or out.data_ptr() % 16 == 0))
+
+
+# the input features read from the embedding tables in place (NodeTables) in a training step through the fused batch tail; IHG_NODE_TABLES=0: X0 assembled by copies (A/B, tests)
+NODE_TABLES = _os.environ.get('IHG_NODE_TABLES', '1') != '0'
 
 
 # the interactive layer as ONE autograd node (interact_layer); IHG_LAYER0_ONE_NODE=0: first_order and interact_to_nodes as two nodes (A/B)
@@ -864,16 +974,24 @@ def interact(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: in
 # ---------------------------------------------------------------------------------------------
 # Batch tail: HEM scores of a training batch straight from the layer outputs
 # ---------------------------------------------------------------------------------------------
-def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float):
-    """Per-batch-row gradients of the tail: ``[3B, (L+1) d + 4]``, layer l in columns ``l d .. (l+1) d``, d bias in column ``(L+1) d``."""
+def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float, tables=None):
+    """Per-batch-row gradients of the tail: ``[3B, (L+1) d + 4]``, layer l in columns ``l d .. (l+1) d``, d bias in column ``(L+1) d``.  ``tables`` (a resolved
+    ``NodeTables``): layer 0 is read from the embedding tables in place and ``layers`` are the outputs of the layers above it."""
     lib = _lib.load()
-    batch, dim, n_layers = int(items.shape[0]), int(layers[0].shape[1]), len(layers)
+    batch = int(items.shape[0])
+    dim = int(layers[0].shape[1]) if layers else tables.dim
+    n_layers = len(layers) + (1 if tables is not None else 0)
     width = n_layers * dim
-    ptrs = (ctypes.c_void_p * n_layers)(*[x.data_ptr() for x in layers])
     rowgrad = torch.empty(3 * batch, width + 4, dtype=torch.float32, device=bias.device)
     with profiler.kernel('hem_score_bwd', batch, dim):
-        _lib.check(lib.ihg_hem_score_bwd(ptrs, n_layers, _ld(layers[0]), dim, _ptr(rows), _ptr(dscores), float(grad_scale), float(lam),
-                                         _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd')
+        if tables is None:
+            ptrs = (ctypes.c_void_p * n_layers)(*[x.data_ptr() for x in layers])
+            _lib.check(lib.ihg_hem_score_bwd(ptrs, n_layers, _ld(layers[0]), dim, _ptr(rows), _ptr(dscores), float(grad_scale), float(lam),
+                                             _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd')
+        else:
+            ptrs = (ctypes.c_void_p * n_layers)(tables.query_rows.data_ptr(), *[x.data_ptr() for x in layers])
+            _lib.check(lib.ihg_hem_score_bwd_typed0(ptrs, n_layers, _ld(layers[0]) if layers else dim, dim, tables.row_pointers(), dim, _type_begin(tables.layout), _ptr(rows),
+                                                    _ptr(dscores), float(grad_scale), float(lam), _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd_typed0')
     return rowgrad
 
 
@@ -930,6 +1048,18 @@ class TailGradients:
         self.rowgrad: Optional[Tensor] = None      # [3B, .], rows of equal destination already summed into their first occurrence
         self.leader: Optional[Tensor] = None       # int32 [3B]: 1 on those first occurrences (None: rowgrad is not combined)
 
+    def put_into_typed(self, dense_rows, ld_dense: int, layout, col0: int, width: int) -> None:
+        """``add_into`` for a destination whose node types start at their own addresses (``dense_rows``: host array of three device pointers)."""
+        _put_rows(self, dense_rows, ld_dense, layout, col0, width, False)
+
+    def assign_into(self, dense: Tensor, layout, col0: int, width: int) -> None:
+        """``dense[rows[k]] = rowgrad[k, col0 : col0 + width]`` on the (combined) batch rows, nothing else written: a gradient that is zero outside the batch rows
+        and READ at those rows only (the last layer's cotangent under the sparse pull) needs no ``[N, d]`` zero fill."""
+        base = dense.data_ptr()
+        tb = _type_begin(layout)
+        step = _ld(dense) * 4
+        _put_rows(self, (ctypes.c_void_p * 3)(base + tb[0] * step, base + tb[1] * step, base + tb[2] * step), _ld(dense), layout, col0, width, True)
+
     def add_into(self, dense: Optional[Tensor], col0: int, width: int, tail: Optional[Tensor] = None, tail_offset: int = 0) -> None:
         """``dense[rows[k]] += rowgrad[k, col0 : col0 + width]`` (or ``tail[rows[k] - tail_offset] += rowgrad[k, col0]``)."""
         if self.leader is None:
@@ -944,10 +1074,21 @@ class TailGradients:
                                               int(tail.shape[0]) if tail is not None else 0, _stream()), 'ihg_batch_rows_add')
 
 
+def _put_rows(holder: 'TailGradients', dense_rows, ld_dense: int, layout, col0: int, width: int, assign: bool) -> None:
+    lib = _lib.load()
+    if holder.leader is None:
+        raise _lib.IhgnnHipError('typed / assigning row scatter needs the combined row gradients (batches of at most 16,384 rows)')
+    n = int(holder.rows.shape[0])
+    src = holder.rowgrad[:, col0:]
+    with profiler.kernel('batch_rows_add', n, width):
+        _lib.check(lib.ihg_batch_rows_put(_ptr(src), int(holder.rowgrad.stride(0)), width, _ptr(holder.rows), _ptr(holder.leader), n, dense_rows, ld_dense,
+                                          _type_begin(layout), 1 if assign else 0, _stream()), 'ihg_batch_rows_put')
+
+
 class _Tap(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, holder: TailGradients, index: int):
-        ctx.holder, ctx.index = holder, int(index)
+    def forward(ctx, x: Tensor, holder: TailGradients, index: int, sparse_layout):
+        ctx.holder, ctx.index, ctx.sparse_layout = holder, int(index), sparse_layout
         ctx.shape, ctx.device = tuple(x.shape), x.device
         ctx.set_materialize_grads(False)
         return x.view_as(x), x.view_as(x)
@@ -957,20 +1098,28 @@ class _Tap(torch.autograd.Function):
         holder, (n, dim) = ctx.holder, ctx.shape
         if holder.rowgrad is None:                           # the tail did not run a backward through this holder
             if g_next is None or g_tail is None:
-                return (g_next if g_next is not None else g_tail), None, None
-            return g_next + g_tail, None, None
+                return (g_next if g_next is not None else g_tail), None, None, None
+            return g_next + g_tail, None, None, None
         if g_next is None:
             # the last layer's output feeds the batch tail only: its cotangent is zero outside the batch rows (RawGnn tells that layer so)
-            g = torch.zeros(n, dim, dtype=torch.float32, device=ctx.device)
+            if ctx.sparse_layout is not None and holder.leader is not None:
+                # ... and that layer's backward READS it at those rows only (the masked pull of node_two_hop): the rows are written, nothing is filled
+                g = torch.empty(n, dim, dtype=torch.float32, device=ctx.device)
+                holder.assign_into(g, ctx.sparse_layout, ctx.index * dim, dim)
+                return g, None, None, None
+            g = torch.empty(n, dim, dtype=torch.float32, device=ctx.device)
+            _lib.check(_lib.load().ihg_zero_floats(_ptr(g), n * dim, _stream()), 'ihg_zero_floats')
         else:
             g = g_next if (g_next.is_contiguous() and g_next.dtype == torch.float32) else g_next.contiguous().float()
         holder.add_into(g, ctx.index * dim, dim)
-        return g, None, None
+        return g, None, None, None
 
 
-def tap(x: Tensor, holder: TailGradients, index: int):
-    """``(x for the next layer, x for the batch tail)``: same values; see ``TailGradients``."""
-    return _Tap.apply(x, holder, int(index))
+def tap(x: Tensor, holder: TailGradients, index: int, sparse_layout=None):
+    """``(x for the next layer, x for the batch tail)``: same values; see ``TailGradients``.  ``sparse_layout`` (an ``IncidenceLayout``; only for an output that
+    feeds NOTHING but the tail): the caller's promise that the backward of the op that produced ``x`` reads its cotangent at the batch rows only (the last layer
+    under ``cotangent_rows`` / ``rows``) - the tap then writes those rows of an uninitialised ``[N, d]`` tensor instead of filling it with zeros first."""
+    return _Tap.apply(x, holder, int(index), sparse_layout)
 
 
 _ZERO_SCALARS = {}
@@ -1020,42 +1169,57 @@ class _HemBceLoss(torch.autograd.Function):
     returned here); without one they are returned dense."""
 
     @staticmethod
-    def forward(ctx, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int, holder, *layers: Tensor) -> Tensor:
+    def forward(ctx, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int, holder, tables, *layers: Tensor) -> Tensor:
+        # tables (a resolved NodeTables): layer 0 is the embedding tables in place; layers[0] is then its token (the autograd edge), not a matrix
         lib = _lib.load()
-        layers = _same_layout(layers)
-        batch, dim = int(items.shape[0]), int(layers[0].shape[1])
-        ptrs = (ctypes.c_void_p * len(layers))(*[x.data_ptr() for x in layers])
+        real = _same_layout(layers[1:] if tables is not None else layers)
+        batch, dim = int(items.shape[0]), int(real[0].shape[1]) if real else tables.dim
         scores = torch.empty(batch, dtype=torch.float32, device=bias.device)
         dscores = torch.empty(batch, dtype=torch.float32, device=bias.device)
         loss = torch.empty((), dtype=torch.float32, device=bias.device)
         labels = labels.to(torch.float32).contiguous()
         with profiler.kernel('hem_score_fwd', batch, dim):
-            _lib.check(lib.ihg_hem_score_fwd(ptrs, len(layers), _ld(layers[0]), dim, _ptr(rows), _ptr(items), _ptr(bias), float(lam), _ptr(scores),
-                                             batch, _stream()), 'ihg_hem_score_fwd')
+            if tables is None:
+                ptrs = (ctypes.c_void_p * len(real))(*[x.data_ptr() for x in real])
+                _lib.check(lib.ihg_hem_score_fwd(ptrs, len(real), _ld(real[0]), dim, _ptr(rows), _ptr(items), _ptr(bias), float(lam), _ptr(scores),
+                                                 batch, _stream()), 'ihg_hem_score_fwd')
+            else:
+                ptrs = (ctypes.c_void_p * (len(real) + 1))(tables.query_rows.data_ptr(), *[x.data_ptr() for x in real])     # (slot 0 is replaced by the typed rows)
+                _lib.check(lib.ihg_hem_score_fwd_typed0(ptrs, len(real) + 1, _ld(real[0]) if real else dim, dim, tables.row_pointers(), dim, _type_begin(tables.layout),
+                                                        _ptr(rows), _ptr(items), _ptr(bias), float(lam), _ptr(scores), batch, _stream()), 'ihg_hem_score_fwd_typed0')
             _lib.check(lib.ihg_bce_with_logits(_ptr(scores), _ptr(labels), batch, _ptr(loss), _ptr(dscores), _stream()), 'ihg_bce_with_logits')
-        ctx.save_for_backward(rows, items, bias, dscores, *layers)
-        ctx.lam, ctx.offset, ctx.holder = float(lam), int(item_row_offset), holder
+        ctx.save_for_backward(rows, items, bias, dscores, *real)
+        ctx.lam, ctx.offset, ctx.holder, ctx.tables = float(lam), int(item_row_offset), holder, tables
+        ctx.token_shape = tuple(layers[0].shape) if tables is not None else None
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss: Tensor):
         rows, items, bias, dscores, *layers = ctx.saved_tensors
+        tables = ctx.tables
         if ctx.holder is None:
+            if tables is not None:
+                raise _lib.IhgnnHipError('hem_bce_loss over NodeTables needs a TailGradients holder')
             dbias, grads = _hem_backward(layers, rows, items, bias, ctx.lam, dscores * grad_loss, 1.0, ctx.offset)
-            return (None, None, None, dbias, None, None, None) + grads
+            return (None, None, None, dbias, None, None, None, None) + grads
         holder = ctx.holder
-        rowgrad = _hem_row_gradients(layers, rows, items, bias, ctx.lam, dscores * grad_loss, 1.0)     # no host read of grad_loss: no sync
+        rowgrad = _hem_row_gradients(layers, rows, items, bias, ctx.lam, dscores * grad_loss, 1.0, tables)     # no host read of grad_loss: no sync
         holder.rows, holder.rowgrad, holder.leader = rows, rowgrad, None
         lib = _lib.load()
-        n, width = int(rows.shape[0]), len(layers) * int(layers[0].shape[1])
+        n_layers = len(layers) + (1 if tables is not None else 0)
+        n, width = int(rows.shape[0]), n_layers * (int(layers[0].shape[1]) if layers else tables.dim)
         if lib.ihg_batch_scatter_workspace_bytes(n) >= 0:    # one pass sums duplicate destinations; the taps then add plain rows
             holder.leader = torch.empty(n, dtype=torch.int32, device=rows.device)
             with profiler.kernel('batch_combine', n, width + 1):
                 _lib.check(lib.ihg_batch_combine(_ptr(rowgrad), int(rowgrad.stride(0)), width + 1, _ptr(rows), n, n // 3, _ptr(holder.leader), _stream()),
                            'ihg_batch_combine')
-        dbias = torch.zeros_like(bias)
+        dbias = torch.empty_like(bias)
+        _lib.check(lib.ihg_zero_floats(_ptr(dbias), dbias.numel(), _stream()), 'ihg_zero_floats')
         holder.add_into(None, width, 1, dbias, ctx.offset)
-        return (None, None, None, dbias, None, None, None) + tuple(_zero_like_expanded(x.shape, x.device) for x in layers)
+        placeholders = tuple(_zero_like_expanded(x.shape, x.device) for x in layers)
+        if tables is not None:
+            placeholders = (_zero_like_expanded(ctx.token_shape, bias.device),) + placeholders
+        return (None, None, None, dbias, None, None, None, None) + placeholders
 
 
 def score_topk_supported(features: Tensor) -> bool:
@@ -1102,6 +1266,18 @@ def score_topk(features: Tensor, users: Tensor, queries: Tensor, query_row0: int
     return top_items, top_scores
 
 
+def batch_node_rows(users: Tensor, queries: Tensor, items: Tensor, query_row0: int, item_row0: int) -> Tensor:
+    """``torch.cat([users, queries + query_row0, items + item_row0])`` (``RawGnn.py:128-131``): the global node rows of a batch, int64 ``[3 B]``, one launch."""
+    lib = _lib.load()
+    if not users.is_cuda:
+        return torch.cat([users, queries + query_row0, items + item_row0])
+    u, q, i = (t.to(torch.int64).contiguous() for t in (users, queries, items))
+    b = int(u.shape[0])
+    rows = torch.empty(3 * b, dtype=torch.int64, device=u.device)
+    _lib.check(lib.ihg_batch_node_rows(_ptr(u), _ptr(q), _ptr(i), b, int(query_row0), int(item_row0), _ptr(rows), _stream()), 'ihg_batch_node_rows')
+    return rows
+
+
 def hem_score(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, item_row_offset: int) -> Tensor:
     """HEM scores of a batch: ``rows`` = global node rows of users, queries, items (``[3B]`` int64), ``items`` = 0-based item
     ids (``[B]``), ``layers`` = the ``[N,d]`` outputs ``X_0..X_L`` whose concatenation the reference scores on."""
@@ -1111,5 +1287,13 @@ def hem_score(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, ite
 def hem_bce_loss(layers, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int,
                  holder: Optional[TailGradients] = None) -> Tensor:
     """``nn.BCEWithLogitsLoss()(hem_score(...), labels)`` as one differentiable op (scalar).  ``holder``: the layers are the
-    tail halves of ``tap`` outputs made with this holder, and their gradients travel through it (see ``TailGradients``)."""
-    return _HemBceLoss.apply(rows, items, labels, bias, float(lam), int(item_row_offset), holder, *layers)
+    tail halves of ``tap`` outputs made with this holder, and their gradients travel through it (see ``TailGradients``).  ``layers[0]`` may be a
+    ``NodeTables`` (resolved by the first layer's transform): the head reads its layer-0 rows from the embedding tables in place."""
+    tables = None
+    layers = list(layers)
+    if layers and isinstance(layers[0], NodeTables):
+        tables = layers[0]
+        if tables.query_rows is None or tables.token is None:
+            raise RuntimeError('hem_bce_loss: the NodeTables were not consumed by a node-level transform (a model without layers?)')
+        layers[0] = tables.token
+    return _HemBceLoss.apply(rows, items, labels, bias, float(lam), int(item_row_offset), holder, tables, *layers)

@@ -428,6 +428,48 @@ int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query
                    const float* item_bias, const int64_t* users, const int64_t* queries, float lambda_muq, int64_t n_pairs,
                    int32_t k, float* top_scores, int32_t* top_items, void* workspace, int64_t workspace_bytes, ihg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DEVICE: the input features X0 WITHOUT assembling them.  The reference concatenates rows 1.. of the user table, the queries' bag means and
+ * rows 1.. of the item table into one [N, d] matrix every step (Models/RawGnn.py:112-113, Models/EmbeddingLayers.py:70-79) and autograd cuts the
+ * gradient apart again: four [N, d]-sized copies per training step.  The *_typed entry points take, instead of one matrix, the address of the FIRST ROW
+ * of every node type (a HOST array of 3 device pointers: users, queries, items; common row stride) - the layer-0 transform, its weight / input gradient,
+ * the scoring head's layer-0 rows and the scatter of the batch rows' gradients read and write the tables in place.
+ *   ihg_node_linear_fwd_typed          ihg_node_linear_fwd with x given as typed rows
+ *   ihg_node_linear_bwd_weight_typed   ihg_node_linear_bwd_weight with x (and the optional input gradient dx) as typed rows; bit t of
+ *                                      zero_row_before_mask: the row in front of dx_rows[t] (the padding row 0 of an embedding table's gradient) is zeroed
+ *   ihg_hem_score_fwd_typed0 / ihg_hem_score_bwd_typed0   ihg_hem_score_fwd / _bwd with layer 0 given as typed rows (row stride ld0)
+ *   ihg_batch_rows_put                 ihg_batch_rows_add into typed rows; assign != 0: dense[rows[k]] = src[k] on the leader rows (a gradient that is
+ *                                      zero elsewhere and read at these rows only: no fill of the matrix)
+ * Available where ihg_node_linear_typed_supported says so (dim 128 / 256 on the bf16-split kernels, row strides % 4 == 0, 16-byte aligned rows).
+ */
+int32_t ihg_node_linear_typed_supported(int32_t dim, int64_t ld_x, int64_t ld_out);
+int ihg_node_linear_fwd_typed(const float* const* x_rows, int64_t ld_x, const float* w, int64_t ld_w, int64_t w_type_stride,
+                              const float* bias, int32_t bias_type_mask, int64_t bias_type_stride, const int64_t* type_begin,
+                              float* out, int64_t ld_out, void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream);
+int ihg_node_linear_bwd_weight_typed(const float* dout, int64_t ld_dout, const float* const* x_rows, int64_t ld_x, const int64_t* type_begin,
+                                     float* dw, int64_t ld_dw, int64_t dw_type_stride, float* dbias, int32_t bias_type_mask, int64_t dbias_type_stride,
+                                     const float* w, int64_t ld_w, float* const* dx_rows, int64_t ld_dx, int32_t zero_row_before_mask,
+                                     void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream);
+int ihg_hem_score_fwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
+                             const int64_t* type_begin, const int64_t* rows, const int64_t* items, const float* bias, float lambda_muq,
+                             float* scores, int64_t batch, ihg_stream_t stream);
+int ihg_hem_score_bwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
+                             const int64_t* type_begin, const int64_t* rows, const float* dscores, float grad_scale, float lambda_muq,
+                             float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream);
+int ihg_batch_rows_put(const float* src, int64_t ld_src, int32_t width, const int64_t* rows, const int32_t* leader, int64_t n_rows,
+                       float* const* dense_rows, int64_t ld_dense, const int64_t* type_begin, int32_t assign, ihg_stream_t stream);
+
+/* Small device-side helpers that keep a training step free of framework launches (torch fills / index ops of a few microseconds each):
+ *   ihg_zero_floats      p[0 .. n) = 0
+ *   ihg_mark_rows        mask[rows[k]] = value, k < n (rows as int64 OR int32: pass the other NULL) - the row mask of a sparse cotangent, set before
+ *                        the pull that reads it and cleared after (ihg_node_segment_sum's src_mask)
+ *   ihg_batch_node_rows  rows[0 .. 3 b) = users | queries + query_row0 | items + item_row0 (Models/RawGnn.py:128-131)
+ */
+int ihg_zero_floats(float* p, int64_t n, ihg_stream_t stream);
+int ihg_mark_rows(const int64_t* rows64, const int32_t* rows32, int64_t n, uint8_t* mask, int32_t value, ihg_stream_t stream);
+int ihg_batch_node_rows(const int64_t* users, const int64_t* queries, const int64_t* items, int64_t batch, int64_t query_row0, int64_t item_row0,
+                        int64_t* rows, ihg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

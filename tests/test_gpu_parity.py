@@ -1818,6 +1818,48 @@ def test_recorded_training_step_equals_the_eager_step():
     assert o1.next_step() == o0.next_step() == 5
 
 
+@pytest.mark.parametrize('kind,layers,order,dim', [('ihgnn', 3, 3, 128), ('ihgnn', 2, 1, 128), ('hgcn', 2, 3, 128), ('ihgnn', 2, 3, 256), ('ihgnn', 1, 3, 128)])
+@pytest.mark.parametrize('restrict', [False, True])
+def test_training_step_reads_the_embedding_tables_in_place(kind, layers, order, dim, restrict):
+    """The training step through the fused batch tail does not assemble X0 (``ops.NodeTables``: the first layer's transform, its backward, the scoring head and the
+    tail's layer-0 scatter work on the embedding tables in place) and writes the last layer's cotangent at the batch rows only: loss and EVERY parameter gradient equal
+    the assembled-X0 path's bit for bit (same kernels, same order of operations) - and both hold the oracle's gradients at 1e-5."""
+    from ihgnn_amd import ops, profiler, synth
+    from ihgnn_amd.Dataset import GraphDataset
+    from oracle import ihgnn_ref as ref
+    w = synth.draw(150, 30, 110, 40, 2500, seed=33, distribution='powerlaw')
+    ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets, w.triples, device=dev())
+    u, q, i, y = next(iter(ds.sample_batches(60, 1, seed=9)))
+    torch.manual_seed(11)
+    m = build_model(ds, kind, layers, order, dim)
+    m.batch_rows_only_last_layer = restrict
+    results = []
+    for tables in (True, False):
+        ops.NODE_TABLES = tables
+        try:
+            m.zero_grad(set_to_none=True)
+            profiler.start()
+            loss = m.bce_loss(u, q, i, y)
+            loss.backward()
+            profiler.stop()
+        finally:
+            ops.NODE_TABLES = True
+        results.append((loss.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}, profiler.summary()))
+    (l1, g1, s1), (l0, g0, _) = results
+    assert 'bag_mean_fwd' in s1 and 'node_linear_bwd' in s1
+    assert torch.equal(l1, l0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
+    assert float(g1['embeddings.embedding_user.weight'][0].abs().max()) == 0.0 and float(g1['embeddings.embedding_item.weight'][0].abs().max()) == 0.0      # padding rows
+    g = ref.HyperGraph(w.triples, w.user_count, w.query_count, w.item_count)
+    oracle = ref.OracleRawGnn(g, torch.from_numpy(w.bag_words + 1), torch.from_numpy(w.bag_offsets), w.vocab_size, dim, kind, layers, order)
+    oracle.load_reference_state({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()})
+    torch.nn.BCEWithLogitsLoss()(oracle(u.cpu(), q.cpu(), i.cpu()), y.cpu().float()).backward()
+    want = oracle.reference_grads()
+    for k in g1:
+        assert rel(g1[k], want[k]) <= RTOL, k
+
+
 def test_recorded_step_refuses_what_it_cannot_replay():
     """What is baked into a recording is checked at every replay (Adam's eps / betas / weight decay, ``batch_rows_only_last_layer``, the path switches: only the
     learning rate is refreshed), and a model with a parameter that gets no gradient is refused at recording time (the eager Adam skips such a parameter, a

@@ -96,6 +96,18 @@ def main():
             us = sum(t for _, t in f_rows + w_rows) / len(f_rows + w_rows)
             out['k7.edges_to_nodes'] = dict(hbm_bytes_per_launch=int(2 * fk * 1024 + wk * 1024), avg_us_under_pmc=round(us, 1), launches=len(f_rows),
                                             source='in situ: the first long K7 launch of each training step of the counter passes over bench.py (FETCH_SIZE doubled + WRITE_SIZE)')
+        # the whole training step: the counter passes cut into steps at the Adam launches, every kernel between two of them summed
+        def step_total(directory, counter):
+            path = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)[0]
+            rows = sorted((r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter), key=lambda r: int(r['Start_Timestamp']))
+            adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+            sums = [sum(float(r['Counter_Value']) for r in rows[a + 1:b + 1]) for a, b in zip(adam, adam[1:])]
+            return (sum(sums[1:]) / len(sums[1:]) if len(sums) > 1 else (sums[0] if sums else None)), len(sums)     # (the first full step may still be a warm-up one)
+        f_step, n_steps = step_total(fetch, 'FETCH_SIZE')
+        w_step, _ = step_total(write, 'WRITE_SIZE')
+        if f_step is not None and w_step is not None:
+            out['step_l2_miss_bytes'] = int(2 * f_step * 1024 + w_step * 1024)
+            out['step_l2_miss_note'] = f'FETCH_SIZE (doubled) + WRITE_SIZE summed over every kernel between two Adam launches, averaged over the last {max(n_steps - 1, 1)} steps of the pass'
         json.dump(out, open(os.path.join(dst, f'pmc_traffic_{config}.json'), 'w'), indent=1)
         for d, c in ((fetch, 'fetch_size'), (write, 'write_size')):
             f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
