@@ -283,7 +283,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ihgnn_amd import distributed as ihg_dist, profiler, synth
+    from ihgnn_amd import distributed as ihg_dist, ops as ihg_ops, profiler, synth
     from ihgnn_amd.Dataset import GraphDataset
 
     rank, local_rank, world = ihg_dist.init_from_env(args.backend if args.gpus > 1 else None)
@@ -316,7 +316,7 @@ def main():
     def step(k, timed=False):
         u, q, i, y = batches[k]
         loss = model.bce_loss(u, q, i, y) if fused_loss else lossf(model(u, q, i), y)       # what train_and_get_avg_loss does
-        loss.backward()
+        ihg_ops.backward(loss)                               # loss.backward() with a cached root gradient
         if sync is not None:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

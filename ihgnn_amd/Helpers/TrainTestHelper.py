@@ -137,7 +137,11 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
         else:
             loss = loss_function(model(users, queries, items), flags)
         loss_sum += loss.detach()
-        loss.backward()
+        if loss.is_cuda:
+            from .. import ops
+            ops.backward(loss)                               # loss.backward() with a cached root gradient (no fill launch per step)
+        else:
+            loss.backward()
         if grad_sync is not None:
             grad_sync.average_gradients()
         optimizer.step()

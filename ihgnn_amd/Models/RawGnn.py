@@ -86,7 +86,9 @@ class RawGnn(nn.Module):
             if depth > 0:
                 layer = self.gnns[depth - 1]
                 if depth == last and batch_rows is not None and isinstance(layer, (IHGNNLayer, HGCNLayer)):
-                    rows = batch_rows.to(torch.int32)
+                    rows = getattr(batch_rows, 'as_int32', None)
+                    if rows is None:
+                        rows = batch_rows.to(torch.int32)
                     x = layer(x, output_rows=rows) if restrict_last_layer else layer(x, cotangent_rows=rows)
                     # the layer's backward pulls the listed rows of its cotangent only (the masked two-hop pull): the tap writes them and fills nothing
                     if ((restrict_last_layer or ops.SPARSE_LAST_COTANGENT) and not ops.CHECK_SPARSE_COTANGENT and layer.reads_cotangent_rows_only()

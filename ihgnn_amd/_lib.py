@@ -111,12 +111,13 @@ SIGNATURES = {
                                                         c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
     'ihg_hem_score_fwd_typed0': (ctypes.c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64, _i64p, c_void_p, c_void_p, c_void_p, c_float,
                                                 c_void_p, c_int64, c_void_p]),
-    'ihg_hem_score_bwd_typed0': (ctypes.c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64, _i64p, c_void_p, c_void_p, c_float, c_float,
+    'ihg_hem_score_bwd_typed0': (ctypes.c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64, _i64p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                                 c_void_p, c_int64, c_int64, c_void_p]),
     'ihg_batch_rows_put': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int64, _i64p, c_int32, c_void_p]),
     'ihg_zero_floats': (ctypes.c_int, [c_void_p, c_int64, c_void_p]),
     'ihg_mark_rows': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
-    'ihg_batch_node_rows': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    'ihg_batch_node_rows': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    'ihg_zero_rows': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

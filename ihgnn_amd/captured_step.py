@@ -31,6 +31,7 @@ class CapturedTrainingStep:
         self.items = torch.zeros(batch_rows, dtype=torch.int64, device=dev)
         self.labels = torch.zeros(batch_rows, dtype=torch.float32, device=dev)
         self.scalars = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._unit = torch.ones((), dtype=torch.float32, device=dev)         # root gradient of every replay (autograd would fill a fresh one inside the recording)
         self._table, self._table_first, self._table_lr = None, 0, None   # Adam scalars of the coming steps, on the device
         if warmup_batch is not None:
             for dst, src in zip((self.users, self.queries, self.items, self.labels), warmup_batch):
@@ -64,7 +65,7 @@ class CapturedTrainingStep:
             finally:
                 for module, name, p in slots:
                     module._parameters[name] = p
-            grads = torch.autograd.grad(loss, [aliases[id(p)] for p in params], allow_unused=True)
+            grads = torch.autograd.grad(loss, [aliases[id(p)] for p in params], grad_outputs=self._unit, allow_unused=True)
             return loss, grads
 
         # torch's recipe for whole-step capture: a few eager iterations on a side stream (allocator warm-up), then the recording; the

@@ -46,8 +46,9 @@ __global__ __launch_bounds__(kBlockThreads) void hem_score_fwd_kernel(LayerPtrs 
 __global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs layers, int n_layers, int dim,
                                                                       const int64_t* __restrict__ rows, const float* __restrict__ dscores,
                                                                       float grad_scale, float lam, float* __restrict__ rowgrad, int64_t width,
-                                                                      int64_t batch) {
+                                                                      int64_t batch, const float* __restrict__ grad_scale_device = nullptr) {
     const int lane = threadIdx.x & 63;
+    if (grad_scale_device != nullptr) grad_scale *= *grad_scale_device;      // the upstream gradient of the loss, still on the device (no host read, no extra launch)
     for (int64_t r = global_wave_id(); r < batch; r += global_wave_count()) {
         const int64_t u = rows[r], q = rows[batch + r], it = rows[2 * batch + r];
         const float ds = dscores[r] * grad_scale;
@@ -212,9 +213,19 @@ __global__ __launch_bounds__(kBlockThreads) void mark_rows_kernel(const int64_t*
 
 // rows[0 .. 3 b) = users | queries + query_row0 | items + item_row0 (the global node rows of a batch, Models/RawGnn.py:128-131: torch.cat of three index vectors + two adds)
 __global__ __launch_bounds__(kBlockThreads) void batch_node_rows_kernel(const int64_t* __restrict__ users, const int64_t* __restrict__ queries, const int64_t* __restrict__ items,
-                                                                        int64_t b, int64_t query_row0, int64_t item_row0, int64_t* __restrict__ rows) {
-    for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; k < 3 * b; k += static_cast<int64_t>(gridDim.x) * kBlockThreads)
-        rows[k] = k < b ? users[k] : (k < 2 * b ? queries[k - b] + query_row0 : items[k - 2 * b] + item_row0);
+                                                                        int64_t b, int64_t query_row0, int64_t item_row0, int64_t* __restrict__ rows, int32_t* __restrict__ rows32) {
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * kBlockThreads + threadIdx.x; k < 3 * b; k += static_cast<int64_t>(gridDim.x) * kBlockThreads) {
+        const int64_t r = k < b ? users[k] : (k < 2 * b ? queries[k - b] + query_row0 : items[k - 2 * b] + item_row0);
+        rows[k] = r;
+        if (rows32 != nullptr) rows32[k] = static_cast<int32_t>(r);
+    }
+}
+
+// base[rows[k], 0 .. dim) = 0 for the k < n listed rows (one wave per row)
+__global__ __launch_bounds__(kBlockThreads) void zero_rows_kernel(float* __restrict__ base, int64_t ld, int dim, const int64_t* __restrict__ rows, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t k = global_wave_id(); k < n; k += global_wave_count())
+        for (int c = lane; c < dim; c += kWave) base[rows[k] * ld + c] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -383,7 +394,7 @@ int ihg_hem_score_bwd(const float* const* layers, int32_t n_layers, int64_t ld, 
 int ihg_hem_score_fwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
                              const int64_t* type_begin, const int64_t* rows, const int64_t* items, const float* bias, float lambda_muq, float* scores,
                              int64_t batch, ihg_stream_t stream) {
-    if (layer0_rows == nullptr || type_begin == nullptr || ld0 < dim) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd_typed0: layer 0 rows / type ranges missing");
+    if (layer0_rows != nullptr && (type_begin == nullptr || ld0 < dim)) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd_typed0: type ranges / row stride of layer 0 missing");
     if (n_layers < 1 || n_layers > 8 || ld < dim || dim <= 0 || batch < 0 || layers == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd_typed0: bad size");
     if (batch == 0) return IHG_OK;
     if (rows == nullptr || items == nullptr || bias == nullptr || scores == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd_typed0: null pointer");
@@ -394,16 +405,16 @@ int ihg_hem_score_fwd_typed0(const float* const* layers, int32_t n_layers, int64
 }
 
 int ihg_hem_score_bwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
-                             const int64_t* type_begin, const int64_t* rows, const float* dscores, float grad_scale, float lambda_muq, float* rowgrad,
-                             int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream) {
-    if (layer0_rows == nullptr || type_begin == nullptr || ld0 < dim) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd_typed0: layer 0 rows / type ranges missing");
+                             const int64_t* type_begin, const int64_t* rows, const float* dscores, const float* grad_scale_device, float grad_scale,
+                             float lambda_muq, float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream) {
+    if (layer0_rows != nullptr && (type_begin == nullptr || ld0 < dim)) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd_typed0: type ranges / row stride of layer 0 missing");
     if (n_layers < 1 || n_layers > 8 || ld < dim || dim <= 0 || batch < 0 || layers == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd_typed0: bad size");
     if (batch == 0) return IHG_OK;
     if (rows == nullptr || dscores == nullptr || rowgrad == nullptr || ld_rowgrad < static_cast<int64_t>(n_layers) * dim)
         return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd_typed0: null pointer or short row stride");
     const LayerPtrs lp = layer_ptrs(layers, n_layers, ld, layer0_rows, ld0, type_begin);
     hipLaunchKernelGGL(hem_score_bwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers,
-                       dim, rows, dscores, grad_scale, lambda_muq, rowgrad, ld_rowgrad, batch);
+                       dim, rows, dscores, grad_scale, lambda_muq, rowgrad, ld_rowgrad, batch, grad_scale_device);
     return check_launch("ihg_hem_score_bwd_typed0");
 }
 
@@ -485,12 +496,19 @@ int ihg_mark_rows(const int64_t* rows64, const int32_t* rows32, int64_t n, uint8
     return check_launch("ihg_mark_rows");
 }
 
+int ihg_zero_rows(float* base, int64_t ld, int32_t dim, const int64_t* rows, int64_t n, ihg_stream_t stream) {
+    if (n < 0 || dim <= 0 || ld < dim || (n > 0 && (base == nullptr || rows == nullptr))) return fail(IHG_ERR_INVALID, "ihg_zero_rows: bad argument");
+    if (n == 0) return IHG_OK;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for_waves(n)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), base, ld, dim, rows, n);
+    return check_launch("ihg_zero_rows");
+}
+
 int ihg_batch_node_rows(const int64_t* users, const int64_t* queries, const int64_t* items, int64_t batch, int64_t query_row0, int64_t item_row0, int64_t* rows,
-                        ihg_stream_t stream) {
+                        int32_t* rows32, ihg_stream_t stream) {
     if (batch < 0 || (batch > 0 && (users == nullptr || queries == nullptr || items == nullptr || rows == nullptr))) return fail(IHG_ERR_INVALID, "ihg_batch_node_rows: bad argument");
     if (batch == 0) return IHG_OK;
     const int grid = static_cast<int>(std::min<int64_t>((3 * batch + kBlockThreads - 1) / kBlockThreads, kMaxBlocks));
-    hipLaunchKernelGGL(batch_node_rows_kernel, dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), users, queries, items, batch, query_row0, item_row0, rows);
+    hipLaunchKernelGGL(batch_node_rows_kernel, dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), users, queries, items, batch, query_row0, item_row0, rows, rows32);
     return check_launch("ihg_batch_node_rows");
 }
 

@@ -551,6 +551,7 @@ class _LinearFromTables(torch.autograd.Function):
         ctx.save_for_backward(user_table, item_table, w, query_rows)
         ctx.nodes, ctx.layout, ctx.typed, ctx.bias_mask, ctx.has_bias, ctx.per_type_bias = nodes, layout, typed, bias_mask, bias is not None, per_type_bias
         ctx.mark_non_differentiable(query_rows)
+        ctx.set_materialize_grads(False)                     # (the token's and the bag means' gradients are never read: no zero tensors made for them)
         return out, nodes.token, query_rows
 
     @staticmethod
@@ -559,6 +560,8 @@ class _LinearFromTables(torch.autograd.Function):
         user_table, item_table, w, query_rows = ctx.saved_tensors
         nodes, layout = ctx.nodes, ctx.layout
         bag, dim = nodes.bag, nodes.dim
+        if grad_out is None:
+            raise RuntimeError('the output of the first node-level transform received no gradient')
         g = _rows(grad_out, 'grad_out')
         if g.stride(0) % 4 or g.data_ptr() % 16:
             g = g.contiguous()
@@ -642,7 +645,7 @@ def _zero_isolated_users(dh: Tensor, layout: IncidenceLayout) -> None:
     rows; a fill of the whole user block is 118 MB at C3)."""
     idx = layout.users_without_hyperedges()
     if idx.numel():
-        dh.index_fill_(0, idx, 0.0)
+        _lib.check(_lib.load().ihg_zero_rows(_ptr(dh), _ld(dh), int(dh.shape[1]), _ptr(idx), int(idx.numel()), _stream()), 'ihg_zero_rows')
 
 
 def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: IncidenceLayout, order: int, dw: Optional[Tensor]) -> Tensor:
@@ -974,7 +977,7 @@ def interact(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: in
 # ---------------------------------------------------------------------------------------------
 # Batch tail: HEM scores of a training batch straight from the layer outputs
 # ---------------------------------------------------------------------------------------------
-def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float, tables=None):
+def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float, tables=None, grad_scale_device=None):
     """Per-batch-row gradients of the tail: ``[3B, (L+1) d + 4]``, layer l in columns ``l d .. (l+1) d``, d bias in column ``(L+1) d``.  ``tables`` (a resolved
     ``NodeTables``): layer 0 is read from the embedding tables in place and ``layers`` are the outputs of the layers above it."""
     lib = _lib.load()
@@ -983,15 +986,18 @@ def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: f
     n_layers = len(layers) + (1 if tables is not None else 0)
     width = n_layers * dim
     rowgrad = torch.empty(3 * batch, width + 4, dtype=torch.float32, device=bias.device)
+    if grad_scale_device is not None and (grad_scale_device.dtype != torch.float32 or grad_scale_device.numel() != 1):
+        raise TypeError('grad_scale_device is a float32 device scalar')
     with profiler.kernel('hem_score_bwd', batch, dim):
         if tables is None:
             ptrs = (ctypes.c_void_p * n_layers)(*[x.data_ptr() for x in layers])
-            _lib.check(lib.ihg_hem_score_bwd(ptrs, n_layers, _ld(layers[0]), dim, _ptr(rows), _ptr(dscores), float(grad_scale), float(lam),
-                                             _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd')
+            _lib.check(lib.ihg_hem_score_bwd_typed0(ptrs, n_layers, _ld(layers[0]), dim, None, 0, None, _ptr(rows), _ptr(dscores), _ptr(grad_scale_device), float(grad_scale),
+                                                    float(lam), _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd_typed0')
         else:
             ptrs = (ctypes.c_void_p * n_layers)(tables.query_rows.data_ptr(), *[x.data_ptr() for x in layers])
             _lib.check(lib.ihg_hem_score_bwd_typed0(ptrs, n_layers, _ld(layers[0]) if layers else dim, dim, tables.row_pointers(), dim, _type_begin(tables.layout), _ptr(rows),
-                                                    _ptr(dscores), float(grad_scale), float(lam), _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd_typed0')
+                                                    _ptr(dscores), _ptr(grad_scale_device), float(grad_scale), float(lam), _ptr(rowgrad), width + 4, batch, _stream()),
+                       'ihg_hem_score_bwd_typed0')
     return rowgrad
 
 
@@ -1203,7 +1209,7 @@ class _HemBceLoss(torch.autograd.Function):
             dbias, grads = _hem_backward(layers, rows, items, bias, ctx.lam, dscores * grad_loss, 1.0, ctx.offset)
             return (None, None, None, dbias, None, None, None, None) + grads
         holder = ctx.holder
-        rowgrad = _hem_row_gradients(layers, rows, items, bias, ctx.lam, dscores * grad_loss, 1.0, tables)     # no host read of grad_loss: no sync
+        rowgrad = _hem_row_gradients(layers, rows, items, bias, ctx.lam, dscores, 1.0, tables, grad_loss.contiguous())     # d loss stays on the device: no host read, no multiply launch
         holder.rows, holder.rowgrad, holder.leader = rows, rowgrad, None
         lib = _lib.load()
         n_layers = len(layers) + (1 if tables is not None else 0)
@@ -1274,8 +1280,21 @@ def batch_node_rows(users: Tensor, queries: Tensor, items: Tensor, query_row0: i
     u, q, i = (t.to(torch.int64).contiguous() for t in (users, queries, items))
     b = int(u.shape[0])
     rows = torch.empty(3 * b, dtype=torch.int64, device=u.device)
-    _lib.check(lib.ihg_batch_node_rows(_ptr(u), _ptr(q), _ptr(i), b, int(query_row0), int(item_row0), _ptr(rows), _stream()), 'ihg_batch_node_rows')
+    rows32 = torch.empty(3 * b, dtype=torch.int32, device=u.device)
+    _lib.check(lib.ihg_batch_node_rows(_ptr(u), _ptr(q), _ptr(i), b, int(query_row0), int(item_row0), _ptr(rows), _ptr(rows32), _stream()), 'ihg_batch_node_rows')
+    rows.as_int32 = rows32                                   # the layers' row lists are int32: written by the same launch instead of a cast
     return rows
+
+
+_UNIT = {}
+
+
+def backward(loss: Tensor) -> None:
+    """``loss.backward()`` with the root gradient taken from a cached ones scalar (autograd otherwise fills a fresh one every step: a framework launch)."""
+    one = _UNIT.get(loss.device)
+    if one is None:
+        one = _UNIT[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    loss.backward(one)
 
 
 def hem_score(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, item_row_offset: int) -> Tensor:

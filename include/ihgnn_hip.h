@@ -437,7 +437,9 @@ int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query
  *   ihg_node_linear_fwd_typed          ihg_node_linear_fwd with x given as typed rows
  *   ihg_node_linear_bwd_weight_typed   ihg_node_linear_bwd_weight with x (and the optional input gradient dx) as typed rows; bit t of
  *                                      zero_row_before_mask: the row in front of dx_rows[t] (the padding row 0 of an embedding table's gradient) is zeroed
- *   ihg_hem_score_fwd_typed0 / ihg_hem_score_bwd_typed0   ihg_hem_score_fwd / _bwd with layer 0 given as typed rows (row stride ld0)
+ *   ihg_hem_score_fwd_typed0 / ihg_hem_score_bwd_typed0   ihg_hem_score_fwd / _bwd with layer 0 given as typed rows (row stride ld0; layer0_rows NULL: every layer a
+ *                                      plain matrix); _bwd multiplies the upstream gradient by *grad_scale_device (a DEVICE scalar, NULL: 1) as well - d loss of a
+ *                                      backward pass, without a host read or a separate multiply launch
  *   ihg_batch_rows_put                 ihg_batch_rows_add into typed rows; assign != 0: dense[rows[k]] = src[k] on the leader rows (a gradient that is
  *                                      zero elsewhere and read at these rows only: no fill of the matrix)
  * Available where ihg_node_linear_typed_supported says so (dim 128 / 256 on the bf16-split kernels, row strides % 4 == 0, 16-byte aligned rows).
@@ -454,8 +456,8 @@ int ihg_hem_score_fwd_typed0(const float* const* layers, int32_t n_layers, int64
                              const int64_t* type_begin, const int64_t* rows, const int64_t* items, const float* bias, float lambda_muq,
                              float* scores, int64_t batch, ihg_stream_t stream);
 int ihg_hem_score_bwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
-                             const int64_t* type_begin, const int64_t* rows, const float* dscores, float grad_scale, float lambda_muq,
-                             float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream);
+                             const int64_t* type_begin, const int64_t* rows, const float* dscores, const float* grad_scale_device, float grad_scale,
+                             float lambda_muq, float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream);
 int ihg_batch_rows_put(const float* src, int64_t ld_src, int32_t width, const int64_t* rows, const int32_t* leader, int64_t n_rows,
                        float* const* dense_rows, int64_t ld_dense, const int64_t* type_begin, int32_t assign, ihg_stream_t stream);
 
@@ -463,12 +465,14 @@ int ihg_batch_rows_put(const float* src, int64_t ld_src, int32_t width, const in
  *   ihg_zero_floats      p[0 .. n) = 0
  *   ihg_mark_rows        mask[rows[k]] = value, k < n (rows as int64 OR int32: pass the other NULL) - the row mask of a sparse cotangent, set before
  *                        the pull that reads it and cleared after (ihg_node_segment_sum's src_mask)
- *   ihg_batch_node_rows  rows[0 .. 3 b) = users | queries + query_row0 | items + item_row0 (Models/RawGnn.py:128-131)
+ *   ihg_batch_node_rows  rows[0 .. 3 b) = users | queries + query_row0 | items + item_row0 (Models/RawGnn.py:128-131); rows32 (may be NULL): the same as int32
+ *   ihg_zero_rows        base[rows[k], 0 .. dim) = 0, k < n
  */
 int ihg_zero_floats(float* p, int64_t n, ihg_stream_t stream);
 int ihg_mark_rows(const int64_t* rows64, const int32_t* rows32, int64_t n, uint8_t* mask, int32_t value, ihg_stream_t stream);
 int ihg_batch_node_rows(const int64_t* users, const int64_t* queries, const int64_t* items, int64_t batch, int64_t query_row0, int64_t item_row0,
-                        int64_t* rows, ihg_stream_t stream);
+                        int64_t* rows, int32_t* rows32, ihg_stream_t stream);
+int ihg_zero_rows(float* base, int64_t ld, int32_t dim, const int64_t* rows, int64_t n, ihg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1860,6 +1860,34 @@ def test_training_step_reads_the_embedding_tables_in_place(kind, layers, order, 
         assert rel(g1[k], want[k]) <= RTOL, k
 
 
+def test_training_step_launches_no_framework_kernels(tmp_path):
+    """One full training step (d = 128, 3 layers, interaction order 3; eager) under a kernel trace: between two Adam launches every kernel is one of the library's -
+    no ``at::native::*`` fill / copy / index kernel, no ``__amd_rocclr_*`` buffer copy (the assembled-X0 step had four [N, d] copies and ~20 small framework launches)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import sys
+    profiler_exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(profiler_exe):
+        pytest.skip('rocprofv3 not available')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'trace')
+    r = subprocess.run([profiler_exe, '--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(repo, 'tools', 'step_launches.py')],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=600, env=dict(os.environ, TMPDIR=str(tmp_path)))
+    assert r.returncode == 0 and 'steps done' in r.stdout, r.stderr[-2000:]
+    files = glob.glob(os.path.join(out, '**', '*kernel_trace.csv'), recursive=True)
+    assert files, 'no kernel trace written'
+    rows = sorted(csv.DictReader(open(files[0])), key=lambda x: int(x['Start_Timestamp']))
+    adam = [k for k, x in enumerate(rows) if 'adam_kernel' in x['Kernel_Name']]
+    assert len(adam) >= 6
+    step = [x['Kernel_Name'] for x in rows[adam[-3] + 1:adam[-2] + 1]]         # a steady-state step: everything after one Adam launch up to the next
+    assert 40 <= len(step) <= 120, len(step)
+    foreign = [n for n in step if 'at::native' in n or '__amd_rocclr' in n or 'elementwise_kernel' in n]
+    assert not foreign, foreign
+    assert any('row_gemm_split_kernel' in n and 'TypedRows' in n for n in step)
+
+
 def test_recorded_step_refuses_what_it_cannot_replay():
     """What is baked into a recording is checked at every replay (Adam's eps / betas / weight decay, ``batch_rows_only_last_layer``, the path switches: only the
     learning rate is refreshed), and a model with a parameter that gets no gradient is refused at recording time (the eager Adam skips such a parameter, a
