@@ -106,6 +106,39 @@ __device__ __forceinline__ Planes split8(v4f x0, v4f x1) {
     return out;
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 through TWO fp16 terms (node-level contraction, d = 128).  An fp32 value, first multiplied by a power of two that brings its row's (or its weight column's)
+// largest magnitude to [2^13, 2^14), is hi + lo with hi = fp16(x) (11 significand bits, round to nearest even) and lo = fp16(x - hi) (the difference is exact in fp32;
+// lo carries the next 11 bits wherever |x| >= 2^-3, i.e. within 2^-17 of the row's largest entry - below that it is an fp16 subnormal with an ABSOLUTE error of 2^-25,
+// 2^-38 of the row's largest entry).  A product a b is then three partial products - hi lo + lo hi + hi hi, each exact in fp32, accumulated by
+// v_mfma_f32_16x16x32_f16 - instead of six: half the matrix-pipe time, and the split costs 4 vector instructions per element instead of 5.5.  What is left out
+// (lo lo, and the rounding of lo) is bounded by 3 x 2^-22 |a b|; rounding to nearest, not truncation, so there is no one-sided bias (numpy emulation of both
+// schemes against float64 on normal, wide-range (2e-4 .. 3e3), one-huge-many-tiny and low-16-bits-set operands: 0.8 - 1.8e-7 per-row against 1.0 - 2.6e-7 for the
+// three-bf16 scheme).  The scales are powers of two: applying and removing them is exact.  fp16's narrow exponent is what the scaling is for: scaled magnitudes
+// stay below 2^14, partial products below 2^28, sums over 1,024 of them below 2^38.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+
+// 2^(13 - floor(log2 m)) and its inverse for a magnitude m >= 0 (zero, denormals and magnitudes beyond 2^100 either way: exponent clamped - such rows are all-zero
+// or all-huge relative to anything they meet)
+__device__ __forceinline__ float scale_up_for(float m, float& inverse) {
+    int e = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);         // biased exponent of the largest magnitude
+    e = e < 27 ? 27 : (e > 227 ? 227 : e);
+    inverse = __uint_as_float(static_cast<unsigned>(e - 13) << 23);       // 2^(e - 127 - 13)
+    return __uint_as_float(static_cast<unsigned>(267 - e) << 23);         // 2^(13 - (e - 127))
+}
+// two scaled fp32 values -> one dword of each plane (low half: xa's term)
+__device__ __forceinline__ void split_pair_h2(float xa, float xb, unsigned& hi, unsigned& lo) {
+    const v2h h = v2h{static_cast<_Float16>(xa), static_cast<_Float16>(xb)};
+    const v2h l = v2h{static_cast<_Float16>(xa - static_cast<float>(h[0])), static_cast<_Float16>(xb - static_cast<float>(h[1]))};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// partial products in accumulation order (A plane, B plane): smallest first; planes: 0 = hi, 1 = lo
+__device__ constexpr int kTermA2[3] = {0, 1, 0};
+__device__ constexpr int kTermB2[3] = {1, 0, 0};
+
 // partial products in accumulation order (A plane, B plane): smallest first
 __device__ constexpr int kTermA[6] = {0, 2, 1, 0, 1, 0};
 __device__ constexpr int kTermB[6] = {2, 0, 1, 1, 0, 0};
@@ -992,36 +1025,76 @@ __device__ __forceinline__ int node_block(int type, int pass, int second) {
     return kNodeBlocks[type][pass][second];
 }
 
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd_kernel(const float* __restrict__ w, int64_t ld_w, int order, v4u* __restrict__ wnp) {
+// scale of every weight ROW of every node type (= output column j of that type's contraction): wsc[type][j] = scale_up_for(max_k |W_t[j][k]|) over the type's seven blocks,
+// winv[type][j] its inverse.  One wave per (type, j).
+__global__ __launch_bounds__(kBlockThreads) void node_fwd_weight_scales_kernel(const float* __restrict__ w, int64_t ld_w, int order, float* __restrict__ wsc, float* __restrict__ winv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = global_wave_id();
+    if (unit >= 3 * 128) return;
+    const int type = static_cast<int>(unit) / 128, j = static_cast<int>(unit) % 128;
+    float m = 0.f;
+    for (int pass = 0; pass < 4; ++pass)
+        for (int second = 0; second < 2; ++second) {
+            int b = node_block(type, pass, second);
+            if (b == 6 && order != 3) b = -1;
+            if (b < 0) continue;
+            const float* src = w + static_cast<int64_t>(j) * ld_w + b * 128;
+            m = fmaxf(m, fmaxf(fabsf(src[lane]), fabsf(src[64 + lane])));
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float inv;
+    const float sc = scale_up_for(m, inv);
+    if (lane == 0) {
+        wsc[unit] = sc;
+        winv[unit] = inv;
+    }
+}
+
+// wnp[type][pass][m][jt < 2][kb < 8][plane < 2][lane][8 x fp16]: element i = plane of wsc[type][j] W[j][block(type, pass, kb >> 2) d + 32 (kb & 3) + 8 (lane >> 4) + i],
+// j = 32 m + 16 jt + (lane & 15)
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd_kernel(const float* __restrict__ w, int64_t ld_w, int order, const float* __restrict__ wsc,
+                                                                             v4u* __restrict__ wnp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 3 * 4 * 4 * 2 * 8 * kWave) return;
     const int lane = idx & 63, kb = (idx >> 6) & 7, jt = (idx >> 9) & 1, m = (idx >> 10) & 3, pass = (idx >> 12) & 3, type = idx >> 14;
     int b = node_block(type, pass, kb >> 2);
     if (b == 6 && order != 3) b = -1;
-    Planes pl;
+    v4u hi = v4u{0, 0, 0, 0}, lo = v4u{0, 0, 0, 0};
     if (b >= 0) {
-        const float* src = w + static_cast<int64_t>(32 * m + 16 * jt + (lane & 15)) * ld_w + b * 128 + 32 * (kb & 3) + 8 * (lane >> 4);
-        pl = split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]});
-    } else {
-        pl = split8(v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f});
-    }
+        const int j = 32 * m + 16 * jt + (lane & 15);
+        const float sc = wsc[type * 128 + j];
+        const float* src = w + static_cast<int64_t>(j) * ld_w + b * 128 + 32 * (kb & 3) + 8 * (lane >> 4);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) wnp[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
+        for (int i = 0; i < 4; ++i) {
+            unsigned hh, ll;
+            split_pair_h2(src[2 * i] * sc, src[2 * i + 1] * sc, hh, ll);
+            hi[i] = hh;
+            lo[i] = ll;
+        }
+    }
+    wnp[(static_cast<int64_t>(idx >> 6) * 2 + 0) * kWave + lane] = hi;
+    wnp[(static_cast<int64_t>(idx >> 6) * 2 + 1) * kWave + lane] = lo;
 }
 
-constexpr int kNodePassV4 = 4 * 2 * 8 * 3 * kWave;                      // v4u of one (type, pass)'s planes
+constexpr int kNodePassV4 = 4 * 2 * 8 * 2 * kWave;                      // v4u of one (type, pass)'s planes
 
 // KIND 0: blocks {S, h S} of the source block `sums`; 1: {S} (the S_ab pass at order 2); 2: {deg h} (the first pass: `out` = deg c + ...)
 // ACC: add onto `out`; FINAL: multiply the row by scale[v] (nullptr: 1) before the store
+// Arithmetic: two fp16 terms per operand (above): a tile row's contraction values of a pass are scaled by ONE power of two (the 8 threads of a row agree on its largest
+// magnitude with three shuffles), the weights by one per output column (winv, all types); the epilogue removes both.
 template <int KIND, bool ACC, bool FINAL>
 __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
                                                                           const float* __restrict__ deg, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                                          const v4u* __restrict__ wnp, RowTiles plan, float* __restrict__ out, int64_t ld_out) {
+                                                                          const v4u* __restrict__ wnp, const float* __restrict__ winv, RowTiles plan, float* __restrict__ out,
+                                                                          int64_t ld_out) {
     constexpr int NB = KIND == 0 ? 2 : 1, TE = 32, RT = 2, CSTR = 32, KB = NB * 4, ZRB = 2 * NB * 128, ZPL = TE * ZRB, PS = 128 + 4, X = 4;
-    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][2][TE][ZRB];
     __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
+    __shared__ __attribute__((aligned(16))) float swinv[3][128];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 3 * 128) (&swinv[0][0])[tid] = winv[tid];
     const int total_tiles = plan.tile_prefix[3];
     const int per = (total_tiles + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
     const int t0 = static_cast<int>(blockIdx.x) * per;
@@ -1060,56 +1133,76 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_kernel(const 
             const int64_t v = std::min(r_base + row, r_end - 1);
             if (ACC) {
 #pragma unroll
-                for (int x = 0; x < X; ++x) f.old[x] = *reinterpret_cast<const v4f*>(out + v * ld_out + 4 * o + CSTR * x);
+                for (int x = 0; x < X; ++x) f.old[x] = abl::n_no_first ? v4f{1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const v4f*>(out + v * ld_out + 4 * o + CSTR * x);
             } else {
                 f.d = deg[v];
             }
             if (FINAL) f.sc = scale != nullptr ? scale[v] : 1.f;
         };
+        // the tile's contraction values of this thread's row piece -> scaled, two fp16 planes; returns the inverse of the row's scale
         auto split_tile = [&](const Piece& pc, int buf) {
             typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            if (abl::n_no_split) return 1.f;
+            v4f z[X][NB];
+            float m = 0.f;
 #pragma unroll
-            for (int x = 0; x < X; ++x) {
+            for (int x = 0; x < X; ++x)
 #pragma unroll
                 for (int b2 = 0; b2 < NB; ++b2) {
-                    const v4f z = KIND == 2 ? pc.hv[x] * pc.d : (b2 == 0 ? pc.sv[x] : pc.hv[x] * pc.sv[x]);
-                    unsigned w0[3], w1[3];
-                    split_pair(z[0], z[1], w0);
-                    split_pair(z[2], z[3], w1);
+                    z[x][b2] = KIND == 2 ? pc.hv[x] * pc.d : (b2 == 0 ? pc.sv[x] : pc.hv[x] * pc.sv[x]);
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(z[x][b2][0]), fabsf(z[x][b2][1]))), fmaxf(fabsf(z[x][b2][2]), fabsf(z[x][b2][3])));
+                }
+            if (!abl::n_no_shuffle) {
+                m = fmaxf(m, __shfl_xor(m, 1));                         // the row's eight threads are eight consecutive lanes
+                m = fmaxf(m, __shfl_xor(m, 2));
+                m = fmaxf(m, __shfl_xor(m, 4));
+            }
+            float inv;
+            const float sc = scale_up_for(m, inv);
+#pragma unroll
+            for (int x = 0; x < X; ++x)
+#pragma unroll
+                for (int b2 = 0; b2 < NB; ++b2) {
+                    unsigned h0, l0, h1, l1;
+                    split_pair_h2(z[x][b2][0] * sc, z[x][b2][1] * sc, h0, l0);
+                    split_pair_h2(z[x][b2][2] * sc, z[x][b2][3] * sc, h1, l1);
                     // columns 128 b2 + 32 x + 4 o ..: chunk 16 b2 + 4 x + (o >> 1), half o & 1
                     const int off = row * ZRB + (((16 * b2 + 4 * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + pl * ZPL + off) = v2u{w0[pl], w1[pl]};
+                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + off) = v2u{h0, h1};
+                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + ZPL + off) = v2u{l0, l1};
                 }
-            }
+            return inv;
         };
-        auto epilogue = [&](int k, const First& f) {                     // tile k
+        auto epilogue = [&](int k, const First& f, float xinv) {         // tile k
             int64_t r_base, r_end;
-            tile_rows(k, r_base, r_end);
+            const int type = tile_rows(k, r_base, r_end);
             const int64_t v = r_base + row;
             const float (*pp)[PS] = part[k & 1];
 #pragma unroll
             for (int x = 0; x < X; ++x) {
-                v4f val = *reinterpret_cast<const v4f*>(&pp[row][4 * o + CSTR * x]);
+                v4f val = *reinterpret_cast<const v4f*>(&pp[row][4 * o + CSTR * x]) * (*reinterpret_cast<const v4f*>(&swinv[type][4 * o + CSTR * x]) * xinv);
                 if (ACC) val += f.old[x];
                 else if (bias != nullptr) val += *reinterpret_cast<const v4f*>(bias + 4 * o + CSTR * x) * f.d;
                 if (FINAL) val *= f.sc;
-                if (v < r_end) *reinterpret_cast<v4f*>(out + v * ld_out + 4 * o + CSTR * x) = val;
+                if (abl::n_no_first) *reinterpret_cast<v4f*>(&swinv[0][4 * o]) = val;      // (kept alive, never read back meaningfully)
+                else if (v < r_end) *reinterpret_cast<v4f*>(out + v * ld_out + 4 * o + CSTR * x) = val;
             }
         };
         Piece pc0, pc1;                                                  // values of tile m in pc<m & 1>
         First f;
         load_piece(0, pc0);
         load_piece(1, pc1);
-        split_tile(pc0, 0);
+        float inv_prev = 1.f, inv_cur = split_tile(pc0, 0), inv_next = 1.f;   // inverse row scales of tiles k - 1, k, k + 1
         __syncthreads();
         // phase k: images of tile k + 1 (`use`); what tile k - 1 is added to (requested at the start of the phase), its sums and store at the end;
         // request: values of tile k + 2 (`fill`)
         auto phase = [&](int k, const Piece& use, Piece& fill) {
             load_piece(k + 2, fill);
             if (k >= 1) load_first(k - 1, f);
-            if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
-            if (k >= 1) epilogue(k - 1, f);
+            if (k + 1 < n_my) inv_next = split_tile(use, (k + 1) & 1);
+            if (k >= 1) epilogue(k - 1, f, inv_prev);
+            inv_prev = inv_cur;
+            inv_cur = inv_next;
             __syncthreads();
         };
         int k = 0;
@@ -1123,7 +1216,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_kernel(const 
     }
 
     // ---------------- matrix waves: wave m = output columns 32 m .. + 31, the pass's whole contraction index
-    v8s wreg[2][KB][3];
+    v8h wreg[2][KB][2];
     int cur_type = -1;
     __syncthreads();
     const int arow = lane & 15, kq = lane >> 4;
@@ -1138,42 +1231,301 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_kernel(const 
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
-                            wreg[jt][kb][pl] = __builtin_bit_cast(v8s, wf[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 3 + pl) * kWave + lane]);
+                        for (int pl = 0; pl < 2; ++pl)
+                            wreg[jt][kb][pl] = __builtin_bit_cast(v8h, wf[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 2 + pl) * kWave + lane]);
                 cur_type = type;
             }
             const unsigned char* zp = &zplanes[k & 1][0][0][0];
-            auto fragment = [&](int step, v8s (&a)[3]) {
+            auto fragment = [&](int step, v8h (&a)[2]) {
                 const int rt = step / KB, kb = step % KB;
                 const unsigned char* src = zp + (16 * rt + arow) * ZRB + (((4 * kb + kq) ^ arow) << 4);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const v8s*>(src + pl * ZPL);
+                for (int pl = 0; pl < 2; ++pl) a[pl] = *reinterpret_cast<const v8h*>(src + pl * ZPL);
             };
             v4f acc[RT][2];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
-            v8s a[3], an[3];
+            v8h a[2], an[2];
             fragment(0, a);
 #pragma unroll
             for (int step = 0; step < RT * KB; ++step) {
                 const int rt = step / KB, kb = step % KB;
                 if (step + 1 < RT * KB) fragment(step + 1, an);
                 IHG_PIN_ORDER();
+                if (!abl::n_no_mfma) {
 #pragma unroll
-                for (int term = 0; term < 6; ++term)
+                    for (int term = 0; term < 3; ++term)
 #pragma unroll
-                    for (int jt = 0; jt < 2; ++jt)
-                        acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[jt][kb][kTermB[term]], a[kTermA[term]], acc[rt][jt], 0, 0, 0);
+                        for (int jt = 0; jt < 2; ++jt)
+                            acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[jt][kb][kTermB2[term]], a[kTermA2[term]], acc[rt][jt], 0, 0, 0);
+                }
                 IHG_PIN_ORDER();
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = an[pl];
+                for (int pl = 0; pl < 2; ++pl) a[pl] = an[pl];
             }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[k & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The four passes above as ONE launch that touches `out` once (d = 128; the default).  The passes stay - a matrix wave's weight registers hold the planes of 256
+// values of the contraction index - but they run GROUP by group of G = 8 row tiles: for each pass the matrix waves load that pass's planes once per group and contract
+// the group's tiles, and the partial sums of the group's rows live in the SERVICE waves' registers between the passes (thread = one row x 16 columns of every tile:
+// 16 G = 128 registers), not in `out`.  h and the pair sums are read once from memory (h four times out of L2: a group's rows are 128 KB), `out` is written once:
+// 0.96 GB at C3 instead of the 2.8 GB of four launches that each read-modify-write `out` - the four launches are streams at 5.1 TB/s, this one is bound by its matrix
+// waves.  No global load is issued and consumed inside one phase (the memory counter is in order: waiting for such a load also waits for the row requests in front of it,
+// and the phase becomes as long as a memory round trip - what bounded each of the four launches' phases at ~3 us).
+// Measured at C3 (us): four launches, three bf16 terms 560; this kernel with three bf16 terms 650 (matrix waves: 6 MFMAs per product); two fp16 terms: four launches 541,
+// this kernel: see DESIGN.md section 4.
+// ------------------------------------------------------------------------------------------------
+constexpr int kNodeGroupTiles = 8;
+
+struct NodeGroups {
+    RowTiles tiles;                                                      // tiles of 32 rows that do not cross a node type
+    int group_prefix[4];                                                 // groups of kNodeGroupTiles consecutive tiles of ONE type: groups before type t
+};
+
+template <int ORDER>
+__global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
+                                                                                  const float* __restrict__ deg, const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                                  const v4u* __restrict__ wnp, const float* __restrict__ winv, NodeGroups plan,
+                                                                                  float* __restrict__ out, int64_t ld_out) {
+    constexpr int G = kNodeGroupTiles, TE = 32, RT = 2, CSTR = 32, ZRB = 512, ZPL = TE * ZRB, PS = 128 + 4, X = 4, PASSES = 4, KB = 8;
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][2][TE][ZRB];
+    __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
+    __shared__ __attribute__((aligned(16))) float swinv[3][128];
+    __shared__ __attribute__((aligned(16))) float sbias[128];            // the aggregation's bias (zeros without one)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 3 * 128) (&swinv[0][0])[tid] = winv[tid];
+    if (tid < 128) sbias[tid] = bias != nullptr ? bias[tid] : 0.f;
+    const int total_groups = plan.group_prefix[3];
+    const int per = (total_groups + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+    const int g_begin = static_cast<int>(blockIdx.x) * per;
+    const int g_end = std::min(g_begin + per, total_groups);
+    if (g_begin >= g_end) return;
+
+    // cursor over this workgroup's phases: (group, pass, tile of the group), all wave-uniform
+    struct Cur {
+        int gi, p, t, n, type;
+        int64_t row0, r_end;                                             // first row of the group, end of the type's rows
+    };
+    auto open_group = [&](Cur& c) {                                     // (c.gi < g_end)
+        const int type = c.gi >= plan.group_prefix[2] ? 2 : (c.gi >= plan.group_prefix[1] ? 1 : 0);
+        const int first_tile = (c.gi - plan.group_prefix[type]) * G;     // within the type
+        const int type_tiles = plan.tiles.tile_prefix[type + 1] - plan.tiles.tile_prefix[type];
+        c.type = type;
+        c.n = std::min(G, type_tiles - first_tile);
+        c.row0 = plan.tiles.begin[type] + static_cast<int64_t>(first_tile) * TE;
+        c.r_end = plan.tiles.begin[type + 1];
+        c.p = 0;
+        c.t = 0;
+    };
+    auto advance = [&](Cur& c) {                                        // past the last phase the cursor repeats the last tile (read and dropped)
+        if (c.t + 1 < c.n) {
+            ++c.t;
+        } else if (c.p + 1 < PASSES) {
+            ++c.p;
+            c.t = 0;
+        } else if (c.gi + 1 < g_end) {
+            ++c.gi;
+            open_group(c);
+        }
+    };
+    int n_phases = 0;
+    {
+        Cur c;
+        for (int gi = g_begin; gi < g_end; ++gi) {
+            c.gi = gi;
+            open_group(c);
+            n_phases += PASSES * c.n;
+        }
+    }
+    // pass p contracts: 0 {deg h}; 1 {S_a, h S_a}; 2 {S_b, h S_b}; 3 {S_ab, h S_ab} (order 2: {S_ab})
+    auto blocks_of = [&](int p) { return (p == 0 || (ORDER == 2 && p == 3)) ? 1 : 2; };
+
+    role_priority(wave >= 4);
+    if (wave >= 4) {
+        // ---------------- service waves: thread -> node row of the tile, columns 4 o + 32 x .. (x < 4)
+        const int st = tid - 256, row = st >> 3, o = st & 7;
+        struct Piece { v4f hv[X], sv[X]; float d; };
+        auto load_piece = [&](const Cur& c, Piece& pc) {
+            const int64_t v = std::min(c.row0 + static_cast<int64_t>(c.t) * TE + row, c.r_end - 1);      // rows past the type's end re-read its last row (never stored)
+            const float* sp = sums + v * ld_s + (c.p > 0 ? (c.p - 1) * 128 : 0) + 4 * o;
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+                pc.hv[x] = *reinterpret_cast<const v4f*>(h + v * ld_h + 4 * o + CSTR * x);
+                // (a block of the pair sums is read by exactly one pass: non-temporal, h keeps the caches)
+                pc.sv[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp + CSTR * x));
+            }
+            pc.d = deg[v];
+        };
+        // the phase's contraction values of this thread's row piece -> scaled by the row's power of two, two fp16 planes; returns the inverse of the scale
+        auto split_tile = [&](const Cur& c, const Piece& pc, int buf) {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            const int nb = blocks_of(c.p);
+            v4f z[X][2];
+            float m = 0.f;
+#pragma unroll
+            for (int x = 0; x < X; ++x)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    z[x][b2] = c.p == 0 ? pc.hv[x] * pc.d : (b2 == 0 ? pc.sv[x] : pc.hv[x] * pc.sv[x]);
+                    if (b2 < nb) m = fmaxf(fmaxf(m, fmaxf(fabsf(z[x][b2][0]), fabsf(z[x][b2][1]))), fmaxf(fabsf(z[x][b2][2]), fabsf(z[x][b2][3])));
+                }
+            m = fmaxf(m, __shfl_xor(m, 1));                             // the row's eight threads are eight consecutive lanes
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fmaxf(m, __shfl_xor(m, 4));
+            float inv;
+            const float sc = scale_up_for(m, inv);
+#pragma unroll
+            for (int x = 0; x < X; ++x)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    if (b2 >= nb) continue;
+                    unsigned h0, l0, h1, l1;
+                    split_pair_h2(z[x][b2][0] * sc, z[x][b2][1] * sc, h0, l0);
+                    split_pair_h2(z[x][b2][2] * sc, z[x][b2][3] * sc, h1, l1);
+                    const int off = row * ZRB + (((16 * b2 + 4 * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
+                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + off) = v2u{h0, h1};
+                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + ZPL + off) = v2u{l0, l1};
+                }
+            return inv;
+        };
+        v4f acc[G][X];                                                   // partial sums of this thread's row piece of every tile of the open group
+        // the partial sums of the phase before: unscaled and added to the tile's accumulators; after the last pass the row is finished and stored (no global loads in here)
+        auto finish = [&](const Cur& c, int buf, float xinv, float d, float sc) {
+            const float (*pp)[PS] = part[buf];
+            const int64_t v = c.row0 + static_cast<int64_t>(c.t) * TE + row;
+            v4f val[X];
+#pragma unroll
+            for (int x = 0; x < X; ++x) val[x] = *reinterpret_cast<const v4f*>(&pp[row][4 * o + CSTR * x]) * (*reinterpret_cast<const v4f*>(&swinv[c.type][4 * o + CSTR * x]) * xinv);
+            if (c.p == 0) {
+#pragma unroll
+                for (int x = 0; x < X; ++x) val[x] += *reinterpret_cast<const v4f*>(&sbias[4 * o + CSTR * x]) * d;
+            }
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                if (c.t != t) continue;
+#pragma unroll
+                for (int x = 0; x < X; ++x) {
+                    if (c.p != 0) val[x] += acc[t][x];
+                    acc[t][x] = val[x];
+                }
+            }
+            if (c.p == PASSES - 1 && v < c.r_end) {
+#pragma unroll
+                for (int x = 0; x < X; ++x) *reinterpret_cast<v4f*>(out + v * ld_out + 4 * o + CSTR * x) = val[x] * sc;
+            }
+        };
+        Cur cprev, cnext, cnext2;                                        // phases s - 1, s + 1, s + 2
+        cprev.gi = g_begin;
+        open_group(cprev);
+        cnext = cprev;
+        advance(cnext);
+        cnext2 = cnext;
+        advance(cnext2);
+        Piece pc0, pc1;                                                  // values of phase m in pc<m & 1>
+        load_piece(cprev, pc0);
+        load_piece(cnext, pc1);
+        float inv_prev = 1.f, inv_cur = split_tile(cprev, pc0, 0), inv_next = 1.f;     // inverse row scales of phases s - 1, s, s + 1
+        __syncthreads();
+        const float* const sc_src = scale != nullptr ? scale : deg;
+        // phase s: images of phase s + 1 (`use`); partial sums of phase s - 1 into the accumulators (its row finished after the last pass); request: values of phase s + 2 (`fill`)
+        auto phase = [&](int s, const Piece& use, Piece& fill) {
+            // the finished phase's degree and output scale: requested FIRST and unconditionally (older than this phase's row requests: the wait for them in finish() leaves the
+            // row requests in flight), consumed after the split
+            const int64_t vp = std::min(cprev.row0 + static_cast<int64_t>(cprev.t) * TE + row, cprev.r_end - 1);
+            const float d = deg[vp];
+            float sc = sc_src[vp];
+            load_piece(cnext2, fill);
+            if (s + 1 < n_phases) inv_next = split_tile(cnext, use, (s + 1) & 1);
+            if (scale == nullptr) sc = 1.f;
+            if (s >= 1) {
+                finish(cprev, (s - 1) & 1, inv_prev, d, sc);
+                advance(cprev);
+            }
+            inv_prev = inv_cur;
+            inv_cur = inv_next;
+            cnext = cnext2;
+            advance(cnext2);
+            __syncthreads();
+        };
+        int s = 0;
+#pragma clang loop unroll(disable)
+        for (; s + 1 <= n_phases; s += 2) {
+            phase(s, pc1, pc0);
+            phase(s + 1, pc0, pc1);
+        }
+        if (s <= n_phases) phase(s, pc1, pc0);
+        return;
+    }
+
+    // ---------------- matrix waves: wave m = output columns 32 m .. + 31, the pass's whole contraction index
+    v8h wreg[2][KB][2];
+    int cur_type = -1, cur_pass = -1;
+    Cur c;
+    c.gi = g_begin;
+    open_group(c);
+    __syncthreads();
+    const int arow = lane & 15, kq = lane >> 4;
+    for (int s = 0; s <= n_phases; ++s) {
+        if (s < n_phases) {
+            if (c.type != cur_type || c.p != cur_pass) {
+                const v4u* wf = wnp + static_cast<int64_t>(c.type * 4 + c.p) * kNodePassV4;
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+                            wreg[jt][kb][pl] = __builtin_bit_cast(v8h, wf[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 2 + pl) * kWave + lane]);
+                cur_type = c.type;
+                cur_pass = c.p;
+            }
+            const unsigned char* zp = &zplanes[s & 1][0][0][0];
+            const int kb_live = 4 * blocks_of(c.p);                      // a one-block pass skips the steps of its empty second block (uniform branches; one MFMA body)
+            auto fragment = [&](int step, v8h (&a)[2]) {
+                const int rt = step / KB, kb = step % KB;
+                const unsigned char* src = zp + (16 * rt + arow) * ZRB + (((4 * kb + kq) ^ arow) << 4);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[pl] = *reinterpret_cast<const v8h*>(src + pl * ZPL);
+            };
+            v4f acc[RT][2];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
+            v8h a[2], an[2];
+            fragment(0, a);
+#pragma unroll
+            for (int step = 0; step < RT * KB; ++step) {
+                const int rt = step / KB, kb = step % KB;
+                if (step + 1 < RT * KB) fragment(step + 1, an);          // (the fragment of a skipped step is read and dropped)
+                IHG_PIN_ORDER();
+                if (kb < kb_live) {
+#pragma unroll
+                    for (int term = 0; term < 3; ++term)
+#pragma unroll
+                        for (int jt = 0; jt < 2; ++jt)
+                            acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[jt][kb][kTermB2[term]], a[kTermA2[term]], acc[rt][jt], 0, 0, 0);
+                }
+                IHG_PIN_ORDER();
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) a[pl] = an[pl];
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[s & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
+            advance(c);
         }
         __syncthreads();
     }
@@ -2464,6 +2816,11 @@ static bool node_fwd_q_enabled() {                                       // d = 
     return v != nullptr && std::strcmp(v, "1") == 0;
 }
 
+static bool node_fwd_grouped_enabled() {                                 // d = 128: IHG_NODE_FWD_GROUPED=0 keeps the four launches that read-modify-write `out` (A/B, tests)
+    const char* v = std::getenv("IHG_NODE_FWD_GROUPED");
+    return v == nullptr || std::strcmp(v, "0") != 0;
+}
+
 static int64_t node_fwd_q_v4(int dim) {                                  // v4u of the q kernel's planes
     const int bpp = 512 / dim, n_pass = (7 + bpp - 1) / bpp, parts = dim / 64;
     return 3LL * n_pass * parts * 4 * 16 * 3 * kWave;
@@ -2471,7 +2828,7 @@ static int64_t node_fwd_q_v4(int dim) {                                  // v4u 
 
 int64_t split_node_fwd_plane_floats(int dim) {
     if (dim != 64 && dim != 128 && dim != 256) return 0;
-    return std::max<int64_t>(node_fwd_q_v4(dim), dim == 128 ? 3LL * 4 * kNodePassV4 : 0) * 4;
+    return std::max<int64_t>(node_fwd_q_v4(dim), dim == 128 ? 3LL * 4 * kNodePassV4 + 2 * 3 * 128 / 4 : 0) * 4;     // (d = 128: two fp16 planes + the weight rows' scales and inverses)
 }
 
 bool split_node_fwd_ok(int dim, int order, int64_t ld_h, int64_t ld_s, const float* out, int64_t ld_out, const float* bias) {
@@ -2495,13 +2852,31 @@ void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, con
                            const float* w, int64_t ld_w, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s) {
     v4u* wnp = static_cast<v4u*>(planes);
     if (dim == 128 && !node_fwd_q_enabled()) {
-        hipLaunchKernelGGL(pack_planes_node_fwd_kernel, dim3((3 * 4 * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, order, wnp);
+        // the planes (2 fp16 per weight) are followed by the weight rows' scales and their inverses ([3][128] floats each)
+        float* wsc = reinterpret_cast<float*>(wnp + 3LL * 4 * kNodePassV4);
+        float* winv = wsc + 3 * 128;
+        hipLaunchKernelGGL(node_fwd_weight_scales_kernel, dim3(grid_for_waves(3 * 128)), dim3(kBlockThreads), 0, s, w, ld_w, order, wsc, winv);
+        hipLaunchKernelGGL(pack_planes_node_fwd_kernel, dim3((3 * 4 * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, order, wsc, wnp);
         const RowTiles plan = row_tiles(type_begin, 32);
         if (plan.tile_prefix[3] == 0) return;
+        if (node_fwd_grouped_enabled()) {                                // one launch, `out` written once (IHG_NODE_FWD_GROUPED=0: the four launches, A/B and tests)
+            NodeGroups groups;
+            groups.tiles = plan;
+            int acc = 0;
+            for (int t = 0; t < 3; ++t) {
+                groups.group_prefix[t] = acc;
+                acc += (plan.tile_prefix[t + 1] - plan.tile_prefix[t] + kNodeGroupTiles - 1) / kNodeGroupTiles;
+            }
+            groups.group_prefix[3] = acc;
+            const int grid = std::min(acc, 256);
+            if (order == 3) hipLaunchKernelGGL(node_interact_fwd_grouped_kernel<3>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, groups, out, ld_out);
+            else hipLaunchKernelGGL(node_interact_fwd_grouped_kernel<2>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, groups, out, ld_out);
+            return;
+        }
         const int grid = std::min(plan.tile_prefix[3], 256);
 #define IHG_NODE_PASS(KIND, ACC, FINAL, PASS, BLK)                                                                                                          \
     hipLaunchKernelGGL((node_interact_fwd_kernel<KIND, ACC, FINAL>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums + (BLK) * 128, ld_s, deg, scale, bias, \
-                       wnp + (PASS) * kNodePassV4, plan, out, ld_out)
+                       wnp + (PASS) * kNodePassV4, winv, plan, out, ld_out)
         IHG_NODE_PASS(2, false, false, 0, 0);
         IHG_NODE_PASS(0, true, false, 1, 0);
         IHG_NODE_PASS(0, true, false, 2, 1);
