@@ -493,7 +493,9 @@ def main():
             flops = 2.0 * 4096 * dim * (layers + 1) * w.item_count
             eval_stats = dict(pairs=4096, items=w.item_count, width=dim * (layers + 1), ms=round(1e3 * dt, 3), logs_per_s=round(4096 / dt, 1),
                               tflops=round(flops / dt / 1e12, 1), frac_of_f32_mfma_peak=round(flops / dt / 1e12 / MFMA_F32_PEAK_TF, 4),
-                              kernel='ihg_score_topk: fp32-MFMA HEM scores of every (pair, item) + running top-10 per pair, no [pairs, items] matrix')
+                              peak=round(MFMA_BF16_PEAK_TF / 3, 1), frac=round(flops / dt / 1e12 / (MFMA_BF16_PEAK_TF / 3), 4),
+                              kernel='ihg_score_topk: HEM scores of every (pair, item) through two fp16 terms per operand (three v_mfma_f32_32x32x16_f16 products per multiply, '
+                                     'fp32 accumulation; peak = dense fp16 MFMA peak / 3, flops counted as fp32 multiply-adds) + running top-10 per pair, no [pairs, items] matrix')
 
     if rank != 0:
         if world > 1:

@@ -63,7 +63,7 @@ class RawGnn(nn.Module):
 
     # bce_loss: evaluate the last layer's hyperedge -> node pass only at the rows the loss reads (same loss, same gradients)
     batch_rows_only_last_layer = True
-    MAX_SCORED_WIDTH = 1272                                   # ops.score_topk: 32 x (width + 4) floats of LDS
+    MAX_SCORED_WIDTH = 1272                                   # ops.score_topk: 32 mixed rows as two fp16 planes in 160 KB of LDS
 
     def propagate_layers(self, tail_gradients=None, batch_rows=None, restrict_last_layer=True):
         """Full-graph propagation: the list ``[X0, X1, ..., XL]`` of ``[N, d]`` node features (input embeddings and every
@@ -115,15 +115,7 @@ class RawGnn(nn.Module):
             return torch.cat(self.propagate_layers(), 1)
         d = self.embedding_size
         w = self.embeddings.embedding_bag_vocabulary.weight
-        width = self.output_feature_size
-        if width % 4:
-            # any embedding size works (the reference takes any; `--emb 50 --gnns 2` gives 150): rows are stored 16-byte aligned with ZERO pad columns, which the
-            # evaluation kernel reads as part of the dot product (they add exact zeros); callers see the [N, D] view
-            storage = torch.zeros(self.dataset.node_count, (width + 3) // 4 * 4, dtype=torch.float32, device=w.device)
-            storage._ihg_zero_padded = True                  # (ops.score_topk takes the padded buffer behind the view as it is)
-            features = storage[:, :width]
-        else:
-            features = torch.empty(self.dataset.node_count, width, dtype=torch.float32, device=w.device)
+        features = torch.empty(self.dataset.node_count, self.output_feature_size, dtype=torch.float32, device=w.device)
         x = self.embeddings.all_nodes(out=features[:, :d])
         for depth, layer in enumerate(self.gnns, 1):
             x = layer(x, out=features[:, depth * d:(depth + 1) * d])
@@ -191,7 +183,7 @@ class RawGnn(nn.Module):
         """``(items [C, k] int32, scores [C, k])``: the ``k`` best items of each (user, query) pair over the whole catalogue, best
         first - what ``Metrics.calculate_on_all_items`` keeps of ``forward(u, q, None)`` (``Metrics.py:60-61``) - from the fused
         HIP scoring + running top-k kernel; the ``[C, I]`` scores are never stored.  Ties: ascending item id.  No torch path: any feature width
-        ``d (L + 1)`` up to ``MAX_SCORED_WIDTH`` (checked at construction) - widths that are not a multiple of 4 are scored on zero-padded rows."""
+        ``d (L + 1)`` up to ``MAX_SCORED_WIDTH`` (checked at construction)."""
         from .. import ops
         features = self._saved_output_feature if self._saved_output_feature is not None else self.propagate()
         ds, head = self.dataset, self.prediction_layer

@@ -98,7 +98,7 @@ SIGNATURES = {
     'ihg_adam_step_device_scalars': (ctypes.c_int, [c_void_p, c_int32, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     'ihg_batch_combine': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     'ihg_sample_negatives': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
-    'ihg_score_topk_workspace_bytes': (c_int64, [c_int64, c_int64]),
+    'ihg_score_topk_workspace_bytes': (c_int64, [c_int64, c_int64, c_int32]),
     'ihg_score_topk': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_int64,
                                       c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'ihg_batch_rows_add': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,

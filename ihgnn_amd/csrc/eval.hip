@@ -18,8 +18,6 @@
 namespace {
 
 constexpr int kTopMax = 10;                 // list length kept per lane (Metrics.py:60: top 10)
-constexpr int kPairsPerBlock = 32;
-constexpr int kEvalWaves = 4;
 
 __device__ __forceinline__ bool ranks_before(float s, int i, float v, int j) { return s > v || (s == v && i < j); }
 
@@ -50,90 +48,186 @@ struct TopList {
     }
 };
 
-// grid (pair blocks, item slices); 256 threads.  partial[(pair * n_lists + list) * kTopMax + p]
-__global__ __launch_bounds__(kBlockThreads, 2) void score_topk_kernel(
-    const float* __restrict__ feat, int64_t ld, int dim, int64_t item_row0, int64_t n_items, const float* __restrict__ bias,
+// ------------------------------------------------------------------------------------------------
+// Arithmetic: fp32 through TWO fp16 terms (split_arith.hip has the scheme and its error analysis): every item row and every mixed row is multiplied by the power of
+// two that brings its largest magnitude to [2^13, 2^14), x = hi + lo with hi = fp16(x), lo = fp16(x - hi), and a product is hi lo + lo hi + hi hi on
+// v_mfma_f32_32x32x16_f16, fp32 accumulation; the score is the accumulator times the two inverse scales (exact: powers of two) plus the bias.  Unlike the training
+// kernels nothing is split inside the hot loop: the item rows are split ONCE per call into MFMA-fragment order (score_prepare_kernel: 1 KB per (tile, k-step, plane), a
+// fully coalesced wave load), the mixed rows of a pair block once into LDS - the loop is loads, LDS reads and MFMAs.  A workgroup owns PB x 32 pairs (PB = 2 where their
+// planes fit LDS: widths up to 636) and its eight waves stream disjoint runs of item tiles: every item row is fetched once per 32 PB pairs.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+constexpr int kEvalThreads = 512;
+
+__device__ __forceinline__ float eval_scale_up_for(float m, float& inverse) {      // 2^(13 - floor(log2 m)) and its inverse (exponent clamped; split_arith.hip scale_up_for)
+    int e = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);
+    e = e < 27 ? 27 : (e > 227 ? 227 : e);
+    inverse = __uint_as_float(static_cast<unsigned>(e - 13) << 23);
+    return __uint_as_float(static_cast<unsigned>(267 - e) << 23);
+}
+__device__ __forceinline__ void eval_split8(const float (&x)[8], v4u& hi, v4u& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const v2h h = v2h{static_cast<_Float16>(x[2 * i]), static_cast<_Float16>(x[2 * i + 1])};
+        const v2h l = v2h{static_cast<_Float16>(x[2 * i] - static_cast<float>(h[0])), static_cast<_Float16>(x[2 * i + 1] - static_cast<float>(h[1]))};
+        hi[i] = __builtin_bit_cast(unsigned, h);
+        lo[i] = __builtin_bit_cast(unsigned, l);
+    }
+}
+
+// Item rows -> frag[tile][ks][plane][lane][8 x fp16] (tile = 32 items, ks = 16 columns; lane = 32 (column half of the k-step) + item % 32: the A fragment of
+// v_mfma_f32_32x32x16_f16), aux[item] = {inverse scale, bias}.  One wave per item row; columns past `dim` are zero.
+__global__ __launch_bounds__(kBlockThreads) void score_prepare_kernel(const float* __restrict__ feat, int64_t ld, int dim, int ksteps, int64_t item_row0, int64_t n_items,
+                                                                      const float* __restrict__ bias, v4u* __restrict__ frag, float2* __restrict__ aux) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t item = global_wave_id(); item < n_items; item += global_wave_count()) {
+        const float* row = feat + (item_row0 + item) * ld;
+        float m = 0.f;
+        for (int c = lane; c < dim; c += kWave) m = fmaxf(m, fabsf(row[c]));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        float inv;
+        const float sc = eval_scale_up_for(m, inv);
+        if (lane == 0) aux[item] = make_float2(inv, bias[item]);
+        const int64_t tile = item >> 5;
+        for (int chunk = lane; chunk < 2 * ksteps; chunk += kWave) {      // eight consecutive columns
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = 8 * chunk + i < dim ? row[8 * chunk + i] * sc : 0.f;
+            v4u hi, lo;
+            eval_split8(x, hi, lo);
+            const int64_t base = ((tile * ksteps + (chunk >> 1)) * 2) * kWave + 32 * (chunk & 1) + (item & 31);
+            frag[base] = hi;
+            frag[base + kWave] = lo;
+        }
+    }
+}
+
+// grid (pair blocks of 32 PB pairs, item slices); 512 threads.  partial[(pair * n_lists + list) * kTopMax + p]
+template <int PB>
+__global__ __launch_bounds__(kEvalThreads) void score_topk_kernel(
+    const float* __restrict__ feat, int64_t ld, int dim, int ksteps, const v4u* __restrict__ frag, const float2* __restrict__ aux, int64_t n_items,
     const int64_t* __restrict__ users, const int64_t* __restrict__ queries, int64_t query_row0, float lam, int64_t n_pairs,
     float* __restrict__ part_val, int32_t* __restrict__ part_idx) {
-    extern __shared__ __attribute__((aligned(16))) float mixed[];           // [32][dim8 + kRowPad]
-    const int dim8 = (dim + 7) & ~7;
-    const int stride = dim8 + kRowPad;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];    // mixed planes: [32 PB][hi: 2 dp bytes | lo: 2 dp bytes | 16 bytes of padding], then pinv[32 PB]
+    const int dp = 16 * ksteps;
+    const int row_bytes = 4 * dp + 16;                                      // (the padding spreads the pairs' equal chunks over the banks)
+    float* pinv = reinterpret_cast<float*>(smem + static_cast<size_t>(32 * PB) * row_bytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t pair0 = static_cast<int64_t>(blockIdx.x) * kPairsPerBlock;
-    // mixed rows of this block's pairs (PredictionLayers.py:35), zero-padded to a multiple of 8 columns; pairs past the end repeat the last one
-    for (int idx = tid; idx < kPairsPerBlock * (dim8 / 4); idx += kBlockThreads) {
-        const int r = idx / (dim8 / 4), c4 = idx % (dim8 / 4);
+    const int64_t pair0 = static_cast<int64_t>(blockIdx.x) * (32 * PB);
+    // mixed rows m = lam F[q] + (1 - lam) F[u] (PredictionLayers.py:35) of this block's pairs, one wave per row: largest magnitude, scale, two fp16 planes;
+    // pairs past the end repeat the last one
+    for (int r = wave; r < 32 * PB; r += kEvalThreads / kWave) {
         int64_t pr = pair0 + r;
         pr = pr < n_pairs ? pr : n_pairs - 1;
-        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c4 * 4 < dim) {
-            const float4 q = *reinterpret_cast<const float4*>(feat + (queries[pr] + query_row0) * ld + c4 * 4);
-            const float4 u = *reinterpret_cast<const float4*>(feat + users[pr] * ld + c4 * 4);
-            m = make_float4(lam * q.x + (1 - lam) * u.x, lam * q.y + (1 - lam) * u.y, lam * q.z + (1 - lam) * u.z, lam * q.w + (1 - lam) * u.w);
+        const float* qrow = feat + (queries[pr] + query_row0) * ld;
+        const float* urow = feat + users[pr] * ld;
+        float m = 0.f;
+        for (int c = lane; c < dim; c += kWave) m = fmaxf(m, fabsf(lam * qrow[c] + (1.f - lam) * urow[c]));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        float inv;
+        const float sc = eval_scale_up_for(m, inv);
+        if (lane == 0) pinv[r] = inv;
+        for (int chunk = lane; chunk < 2 * ksteps; chunk += kWave) {
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = 8 * chunk + i;
+                x[i] = c < dim ? (lam * qrow[c] + (1.f - lam) * urow[c]) * sc : 0.f;
+            }
+            v4u hi, lo;
+            eval_split8(x, hi, lo);
+            *reinterpret_cast<v4u*>(smem + static_cast<size_t>(r) * row_bytes + 16 * chunk) = hi;
+            *reinterpret_cast<v4u*>(smem + static_cast<size_t>(r) * row_bytes + 2 * dp + 16 * chunk) = lo;
         }
-        *reinterpret_cast<float4*>(&mixed[r * stride + c4 * 4]) = m;
     }
     __syncthreads();
 
     // this wave's run of 32-item tiles inside this block's item slice
+    constexpr int WAVES = kEvalThreads / kWave;
     const int64_t n_tiles = (n_items + 31) / 32;
-    const int64_t n_runs = static_cast<int64_t>(gridDim.y) * kEvalWaves;
-    const int64_t run = static_cast<int64_t>(blockIdx.y) * kEvalWaves + wave;
+    const int64_t n_runs = static_cast<int64_t>(gridDim.y) * WAVES;
+    const int64_t run = static_cast<int64_t>(blockIdx.y) * WAVES + wave;
     const int64_t tile_begin = n_tiles * run / n_runs, tile_end = n_tiles * (run + 1) / n_runs;
-    const int r31 = lane & 31, half = lane >> 5;
-    const float* mrow = mixed + r31 * stride + 4 * half;
-    const int t_steps = dim8 / 8;
-    TopList top;
-    top.init();
+    const int n31 = lane & 31, half = lane >> 5;
+    float my_pinv[PB];
+    const unsigned char* brow[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        my_pinv[pb] = pinv[32 * pb + n31];
+        brow[pb] = smem + static_cast<size_t>(32 * pb + n31) * row_bytes + 16 * half;
+    }
+    TopList top[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) top[pb].init();
 
+    constexpr int PF = 4;                                                   // k-steps of item fragments in flight
     for (int64_t tile = tile_begin; tile < tile_end; ++tile) {
-        int64_t item = tile * 32 + r31;
-        item = item < n_items ? item : n_items - 1;                          // rows past the end re-read the last item; masked below
-        const float* arow = feat + (item_row0 + item) * ld + 4 * half;
-        v16f acc;
+        const v4u* af = frag + (tile * ksteps * 2) * kWave + lane;
+        v16f acc[PB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // item rows straight from L2 / Infinity Cache into registers, four k-groups ahead of the MFMAs that use them
-        constexpr int PF = 4;
-        v4f a[PF];
+        for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-        for (int x = 0; x < PF; ++x) a[x] = 8 * x + 4 * half < dim ? *reinterpret_cast<const v4f*>(arow + 8 * x) : v4f{0.f, 0.f, 0.f, 0.f};
-        for (int t0 = 0; t0 < t_steps; t0 += PF) {
+            for (int r = 0; r < 16; ++r) acc[pb][r] = 0.f;
+        v4u a[PF][2];
+#pragma unroll
+        for (int x = 0; x < PF; ++x) {
+            const int ks = x < ksteps ? x : ksteps - 1;
+            a[x][0] = af[(2 * ks) * kWave];
+            a[x][1] = af[(2 * ks + 1) * kWave];
+        }
+        for (int k0 = 0; k0 < ksteps; k0 += PF) {
 #pragma unroll
             for (int x = 0; x < PF; ++x) {
-                const int t = t0 + x;
-                if (t < t_steps) {
-                    const v4f av = a[x];
-                    if (8 * (t + PF) + 4 * half < dim) a[x] = *reinterpret_cast<const v4f*>(arow + 8 * (t + PF));      // dim % 8 == 4: no read past the row
-                    const v4f bv = *reinterpret_cast<const v4f*>(mrow + 8 * t);
+                const int ks = k0 + x;
+                if (ks < ksteps) {
+                    const v8h ahi = __builtin_bit_cast(v8h, a[x][0]), alo = __builtin_bit_cast(v8h, a[x][1]);
+                    const int nk = ks + PF < ksteps ? ks + PF : ksteps - 1;     // (past the end: the last k-step again, read and dropped)
+                    a[x][0] = af[(2 * nk) * kWave];
+                    a[x][1] = af[(2 * nk + 1) * kWave];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+                    for (int pb = 0; pb < PB; ++pb) {
+                        const v8h bhi = *reinterpret_cast<const v8h*>(brow[pb] + 32 * ks), blo = *reinterpret_cast<const v8h*>(brow[pb] + 2 * dp + 32 * ks);
+                        acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[pb], 0, 0, 0);
+                        acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[pb], 0, 0, 0);
+                        acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[pb], 0, 0, 0);
+                    }
                 }
             }
         }
-        // this lane: pair r31, items tile * 32 + acc_row(r, lane)
+        // this lane: pairs 32 pb + n31, items tile * 32 + acc_row(r, lane)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const int64_t i0 = tile * 32 + 8 * r4 + 4 * half;
-            float bv[4];
+            float2 ax[4];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) bv[x] = i0 + x < n_items ? bias[i0 + x] : 0.f;
+            for (int x = 0; x < 4; ++x) ax[x] = i0 + x < n_items ? aux[i0 + x] : make_float2(0.f, 0.f);
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                const float s = acc[4 * r4 + x] + bv[x];
                 const int i = static_cast<int>(i0 + x);
-                if (i0 + x < n_items && ranks_before(s, i, top.val[kTopMax - 1], top.idx[kTopMax - 1])) top.insert(s, i);
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) {
+                    const float s = acc[pb][4 * r4 + x] * (ax[x].x * my_pinv[pb]) + ax[x].y;
+                    if (i0 + x < n_items && ranks_before(s, i, top[pb].val[kTopMax - 1], top[pb].idx[kTopMax - 1])) top[pb].insert(s, i);
+                }
             }
         }
     }
-    const int64_t pair = pair0 + r31;
-    if (pair < n_pairs) {
-        const int64_t n_lists = n_runs * 2;
-        const int64_t base = (pair * n_lists + run * 2 + half) * kTopMax;
+    const int64_t n_lists = n_runs * 2;
 #pragma unroll
-        for (int p = 0; p < kTopMax; ++p) {
-            part_val[base + p] = top.val[p];
-            part_idx[base + p] = top.idx[p];
+    for (int pb = 0; pb < PB; ++pb) {
+        const int64_t pair = pair0 + 32 * pb + n31;
+        if (pair < n_pairs) {
+            const int64_t base = (pair * n_lists + run * 2 + half) * kTopMax;
+#pragma unroll
+            for (int p = 0; p < kTopMax; ++p) {
+                part_val[base + p] = top[pb].val[p];
+                part_idx[base + p] = top[pb].idx[p];
+            }
         }
     }
 }
@@ -179,23 +273,32 @@ __global__ __launch_bounds__(kBlockThreads) void merge_topk_kernel(const float* 
     }
 }
 
-inline int eval_slices(int64_t n_pairs, int64_t n_items) {
-    const int64_t blocks = (n_pairs + kPairsPerBlock - 1) / kPairsPerBlock;
+constexpr int kEvalWavesPerBlock = kEvalThreads / kWave;
+
+inline int eval_ksteps(int dim) { return (dim + 15) / 16; }
+inline size_t eval_lds_bytes(int dim, int pb) { return static_cast<size_t>(32 * pb) * (4 * 16 * eval_ksteps(dim) + 16) + static_cast<size_t>(32 * pb) * sizeof(float); }
+inline int eval_pair_tiles(int dim) { return eval_lds_bytes(dim, 2) <= 160 * 1024 ? 2 : 1; }      // pair tiles of 32 per workgroup
+
+inline int eval_slices(int64_t n_pairs, int64_t n_items, int dim) {
+    const int64_t blocks = (n_pairs + 32 * eval_pair_tiles(dim) - 1) / (32 * eval_pair_tiles(dim));
     const int64_t tiles = (n_items + 31) / 32;
-    int64_t slices = (1024 + blocks - 1) / blocks;                          // ~4 workgroups per CU in all
-    const int64_t most = std::max<int64_t>(1, tiles / (kEvalWaves * 4));    // at least 4 tiles per wave
+    int64_t slices = (512 + blocks - 1) / blocks;                           // ~2 workgroups per CU in all (one resident per CU: LDS)
+    const int64_t most = std::max<int64_t>(1, tiles / (kEvalWavesPerBlock * 4));    // at least 4 tiles per wave
     slices = std::max<int64_t>(1, std::min<int64_t>({slices, most, 64}));
     return static_cast<int>(slices);
 }
+
+inline int64_t eval_frag_bytes(int64_t n_items, int dim) { return ((n_items + 31) / 32) * eval_ksteps(dim) * 2 * kWave * 16; }
+inline int64_t eval_aux_bytes(int64_t n_items) { return ((n_items + 31) / 32) * 32 * 8; }
 
 }  // namespace
 
 extern "C" {
 
-int64_t ihg_score_topk_workspace_bytes(int64_t n_pairs, int64_t n_items) {
-    if (n_pairs <= 0 || n_items <= 0) return 0;
-    const int64_t n_lists = static_cast<int64_t>(eval_slices(n_pairs, n_items)) * kEvalWaves * 2;
-    return n_pairs * n_lists * kTopMax * 8;
+int64_t ihg_score_topk_workspace_bytes(int64_t n_pairs, int64_t n_items, int32_t dim) {
+    if (n_pairs <= 0 || n_items <= 0 || dim <= 0) return 0;
+    const int64_t n_lists = static_cast<int64_t>(eval_slices(n_pairs, n_items, dim)) * kEvalWavesPerBlock * 2;
+    return eval_frag_bytes(n_items, dim) + eval_aux_bytes(n_items) + n_pairs * n_lists * kTopMax * 8;
 }
 
 int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query_row0, int64_t item_row0, int64_t n_items, const float* item_bias,
@@ -205,29 +308,35 @@ int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query
     if (n_pairs == 0) return IHG_OK;
     if (features == nullptr || item_bias == nullptr || users == nullptr || queries == nullptr || top_scores == nullptr || top_items == nullptr)
         return fail(IHG_ERR_INVALID, "ihg_score_topk: null pointer");
-    if (dim % 4 != 0 || ld % 4 != 0 || !aligned16(features)) return fail(IHG_ERR_INVALID, "ihg_score_topk: rows must be 16-byte aligned with dim %% 4 == 0");
     if (n_items > INT_MAX - 64) return fail(IHG_ERR_INVALID, "ihg_score_topk: item ids are int32");
-    const int dim8 = (dim + 7) & ~7;
-    const size_t lds = static_cast<size_t>(kPairsPerBlock) * (dim8 + kRowPad) * sizeof(float);
-    if (lds > 160 * 1024) return fail(IHG_ERR_INVALID, "ihg_score_topk: feature width %d does not fit the LDS pair block", dim);
-    if (workspace == nullptr || !aligned16(workspace) || workspace_bytes < ihg_score_topk_workspace_bytes(n_pairs, n_items))
+    if (eval_lds_bytes(dim, 1) > 160 * 1024) return fail(IHG_ERR_INVALID, "ihg_score_topk: feature width %d does not fit the LDS pair block", dim);
+    if (workspace == nullptr || !aligned16(workspace) || workspace_bytes < ihg_score_topk_workspace_bytes(n_pairs, n_items, dim))
         return fail(IHG_ERR_WORKSPACE, "ihg_score_topk: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int slices = eval_slices(n_pairs, n_items);
-    const int64_t n_lists = static_cast<int64_t>(slices) * kEvalWaves * 2;
-    float* part_val = static_cast<float*>(workspace);
+    const int ksteps = eval_ksteps(dim), pb = eval_pair_tiles(dim);
+    const int slices = eval_slices(n_pairs, n_items, dim);
+    const int64_t n_lists = static_cast<int64_t>(slices) * kEvalWavesPerBlock * 2;
+    v4u* frag = static_cast<v4u*>(workspace);
+    float2* aux = reinterpret_cast<float2*>(static_cast<unsigned char*>(workspace) + eval_frag_bytes(n_items, dim));
+    float* part_val = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(aux) + eval_aux_bytes(n_items));
     int32_t* part_idx = reinterpret_cast<int32_t*>(part_val + n_pairs * n_lists * kTopMax);
+    hipLaunchKernelGGL(score_prepare_kernel, dim3(grid_for_waves(n_items)), dim3(kBlockThreads), 0, s, features, ld, dim, ksteps, item_row0, n_items, item_bias, frag, aux);
     static bool attr_set[64] = {};                           // per device ordinal: the opt-in to > 64 KB of LDS belongs to the device's code object
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) (void)hipGetLastError();
     if (device < 0 || device >= 64 || !attr_set[device]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
         if (device >= 0 && device < 64) attr_set[device] = true;
     }
-    const int64_t blocks = (n_pairs + kPairsPerBlock - 1) / kPairsPerBlock;
-    hipLaunchKernelGGL(score_topk_kernel, dim3(static_cast<unsigned>(blocks), slices), dim3(kBlockThreads), lds, s, features, ld, dim, item_row0, n_items,
-                       item_bias, users, queries, query_row0, lambda_muq, n_pairs, part_val, part_idx);
+    const int64_t blocks = (n_pairs + 32 * pb - 1) / (32 * pb);
+    const size_t lds = eval_lds_bytes(dim, pb);
+    if (pb == 2)
+        hipLaunchKernelGGL(score_topk_kernel<2>, dim3(static_cast<unsigned>(blocks), slices), dim3(kEvalThreads), lds, s, features, ld, dim, ksteps, frag, aux, n_items, users, queries,
+                           query_row0, lambda_muq, n_pairs, part_val, part_idx);
+    else
+        hipLaunchKernelGGL(score_topk_kernel<1>, dim3(static_cast<unsigned>(blocks), slices), dim3(kEvalThreads), lds, s, features, ld, dim, ksteps, frag, aux, n_items, users, queries,
+                           query_row0, lambda_muq, n_pairs, part_val, part_idx);
     hipLaunchKernelGGL(merge_topk_kernel, dim3(grid_for_waves(n_pairs)), dim3(kBlockThreads), 0, s, part_val, part_idx, n_pairs,
                        static_cast<int>(n_lists * kTopMax), k, top_scores, top_items);
     return check_launch("ihg_score_topk");

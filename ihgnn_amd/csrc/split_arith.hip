@@ -1361,6 +1361,10 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
             const float* sp = sums + v * ld_s + (c.p > 0 ? (c.p - 1) * 128 : 0) + 4 * o;
 #pragma unroll
             for (int x = 0; x < X; ++x) {
+                if (abl::n_no_first) {                                   // (ablation: no row loads)
+                    pc.hv[x] = pc.sv[x] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(v + x);
+                    continue;
+                }
                 pc.hv[x] = *reinterpret_cast<const v4f*>(h + v * ld_h + 4 * o + CSTR * x);
                 // (a block of the pair sums is read by exactly one pass: non-temporal, h keeps the caches)
                 pc.sv[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp + CSTR * x));
@@ -1371,6 +1375,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
         auto split_tile = [&](const Cur& c, const Piece& pc, int buf) {
             typedef unsigned v2u __attribute__((ext_vector_type(2)));
             const int nb = blocks_of(c.p);
+            if (abl::n_no_split) return 1.f;
             v4f z[X][2];
             float m = 0.f;
 #pragma unroll
@@ -1378,11 +1383,21 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
 #pragma unroll
                 for (int b2 = 0; b2 < 2; ++b2) {
                     z[x][b2] = c.p == 0 ? pc.hv[x] * pc.d : (b2 == 0 ? pc.sv[x] : pc.hv[x] * pc.sv[x]);
-                    if (b2 < nb) m = fmaxf(fmaxf(m, fmaxf(fabsf(z[x][b2][0]), fabsf(z[x][b2][1]))), fmaxf(fabsf(z[x][b2][2]), fabsf(z[x][b2][3])));
                 }
-            m = fmaxf(m, __shfl_xor(m, 1));                             // the row's eight threads are eight consecutive lanes
-            m = fmaxf(m, __shfl_xor(m, 2));
-            m = fmaxf(m, __shfl_xor(m, 4));
+            {
+                float mx[X];                                             // (a tree, not a chain of dependent maxima)
+#pragma unroll
+                for (int x = 0; x < X; ++x) {
+                    mx[x] = fmaxf(fmaxf(fabsf(z[x][0][0]), fabsf(z[x][0][1])), fmaxf(fabsf(z[x][0][2]), fabsf(z[x][0][3])));
+                    if (nb == 2) mx[x] = fmaxf(mx[x], fmaxf(fmaxf(fabsf(z[x][1][0]), fabsf(z[x][1][1])), fmaxf(fabsf(z[x][1][2]), fabsf(z[x][1][3]))));
+                }
+                m = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+            }
+            if (!abl::n_no_shuffle) {
+                m = fmaxf(m, __shfl_xor(m, 1));                         // the row's eight threads are eight consecutive lanes
+                m = fmaxf(m, __shfl_xor(m, 2));
+                m = fmaxf(m, __shfl_xor(m, 4));
+            }
             float inv;
             const float sc = scale_up_for(m, inv);
 #pragma unroll
@@ -1476,20 +1491,24 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
     open_group(c);
     __syncthreads();
     const int arow = lane & 15, kq = lane >> 4;
+    // the planes of (type, pass): requested as soon as the last MFMA of the pass before has been issued - in front of that phase's barrier, so that the round trip to L2
+    // runs beside the barrier and the service waves' tail instead of in front of the next pass's first MFMA
+    auto load_weights = [&](const Cur& cw) {
+        if (cw.type == cur_type && cw.p == cur_pass) return;
+        const v4u* wf = wnp + static_cast<int64_t>(cw.type * 4 + cw.p) * kNodePassV4;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    wreg[jt][kb][pl] = __builtin_bit_cast(v8h, wf[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 2 + pl) * kWave + lane]);
+        cur_type = cw.type;
+        cur_pass = cw.p;
+    };
+    load_weights(c);
     for (int s = 0; s <= n_phases; ++s) {
         if (s < n_phases) {
-            if (c.type != cur_type || c.p != cur_pass) {
-                const v4u* wf = wnp + static_cast<int64_t>(c.type * 4 + c.p) * kNodePassV4;
-#pragma unroll
-                for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                        for (int pl = 0; pl < 2; ++pl)
-                            wreg[jt][kb][pl] = __builtin_bit_cast(v8h, wf[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 2 + pl) * kWave + lane]);
-                cur_type = c.type;
-                cur_pass = c.p;
-            }
             const unsigned char* zp = &zplanes[s & 1][0][0][0];
             const int kb_live = 4 * blocks_of(c.p);                      // a one-block pass skips the steps of its empty second block (uniform branches; one MFMA body)
             auto fragment = [&](int step, v8h (&a)[2]) {
@@ -1510,7 +1529,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
                 const int rt = step / KB, kb = step % KB;
                 if (step + 1 < RT * KB) fragment(step + 1, an);          // (the fragment of a skipped step is read and dropped)
                 IHG_PIN_ORDER();
-                if (kb < kb_live) {
+                if (kb < kb_live && !abl::n_no_mfma) {
 #pragma unroll
                     for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -1526,6 +1545,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[s & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
             advance(c);
+            if (s + 1 < n_phases) load_weights(c);
         }
         __syncthreads();
     }

@@ -1229,44 +1229,29 @@ class _HemBceLoss(torch.autograd.Function):
 
 
 def score_topk_supported(features: Tensor) -> bool:
-    """True when ``ihg_score_topk`` takes this feature matrix (16-byte aligned rows, width a multiple of 4 and at most 1272)."""
-    return (features.is_cuda and features.dtype == torch.float32 and features.dim() == 2 and features.stride(1) == 1 and features.shape[1] % 4 == 0
-            and features.stride(0) % 4 == 0 and features.data_ptr() % 16 == 0 and features.shape[1] <= 1272)
+    """True when ``ihg_score_topk`` takes this feature matrix: float32 GPU rows of any width up to 1272 (any row stride)."""
+    return (features.is_cuda and features.dtype == torch.float32 and features.dim() == 2 and features.stride(1) == 1 and 0 < features.shape[1] <= 1272
+            and (features.shape[0] <= 1 or features.stride(0) >= features.shape[1]))
 
 
 def score_topk(features: Tensor, users: Tensor, queries: Tensor, query_row0: int, item_row0: int, item_bias: Tensor, lam: float, k: int = 10):
     """Evaluation scoring: for every (user, query) pair the ``k`` best items over ALL items and their HEM scores,
     ``(top_items [C, k] int32, top_scores [C, k])``, best first, ties in ascending item order; the ``[C, I]`` score matrix is
-    never materialised.  ``features`` = the cached ``[N, D]`` propagation output; items are its rows from ``item_row0`` on."""
+    never materialised.  ``features`` = the cached ``[N, D]`` propagation output (any width up to 1272); items are its rows from ``item_row0`` on."""
     lib = _lib.load()
-    width = int(features.shape[1]) if features.dim() == 2 else 0
-    if features.is_cuda and features.dtype == torch.float32 and features.dim() == 2 and 0 < width <= 1272 and (
-            width % 4 or features.stride(1) != 1 or features.stride(0) % 4 or features.data_ptr() % 16):
-        # a width that is not a multiple of 4 (the reference accepts any embedding size) or unaligned rows: scored on 16-byte aligned rows with ZERO pad
-        # columns (exact zeros in every dot product).  RawGnn.propagate() already stores its matrix that way - the view [N, D] of a zero-padded
-        # [N, ceil4(D)] buffer is taken as it is; anything else is copied once into such a buffer
-        padded = (width + 3) // 4 * 4
-        base = features._base if features._base is not None else None
-        if (base is not None and base.dim() == 2 and tuple(base.shape) == (features.shape[0], padded) and base.is_contiguous() and features.data_ptr() == base.data_ptr()
-                and features.stride(0) == padded and base.data_ptr() % 16 == 0 and getattr(base, '_ihg_zero_padded', False)):
-            features = base
-        else:
-            wide = torch.zeros(features.shape[0], padded, dtype=torch.float32, device=features.device)
-            wide[:, :width].copy_(features)
-            features = wide
     if not score_topk_supported(features):
-        raise _lib.IhgnnHipError(f'ihg_score_topk needs a float32 GPU feature matrix with 16-byte aligned rows and width % 4 == 0, got '
-                                 f'{tuple(features.shape)} {features.dtype} on {features.device}')
+        raise _lib.IhgnnHipError(f'ihg_score_topk needs a float32 GPU feature matrix of width <= 1272, got {tuple(features.shape)} {features.dtype} on {features.device}')
     n_pairs = int(users.shape[0])
     n_items = int(features.shape[0]) - int(item_row0)
+    dim = int(features.shape[1])
     users = users.to(device=features.device, dtype=torch.int64).contiguous()
     queries = queries.to(device=features.device, dtype=torch.int64).contiguous()
     bias = item_bias.detach().to(torch.float32).contiguous()
     top_scores = torch.empty(n_pairs, k, dtype=torch.float32, device=features.device)
     top_items = torch.empty(n_pairs, k, dtype=torch.int32, device=features.device)
-    ws = _workspace(int(lib.ihg_score_topk_workspace_bytes(n_pairs, n_items)), features.device)
-    with profiler.kernel('score_topk', n_pairs, int(features.shape[1])):
-        _lib.check(lib.ihg_score_topk(_ptr(features), _ld(features), int(features.shape[1]), int(query_row0), int(item_row0), n_items, _ptr(bias),
+    ws = _workspace(int(lib.ihg_score_topk_workspace_bytes(n_pairs, n_items, dim)), features.device)
+    with profiler.kernel('score_topk', n_pairs, dim):
+        _lib.check(lib.ihg_score_topk(_ptr(features), _ld(features), dim, int(query_row0), int(item_row0), n_items, _ptr(bias),
                                       _ptr(users), _ptr(queries), float(lam), n_pairs, int(k), _ptr(top_scores), _ptr(top_items), _ptr(ws),
                                       ws.numel() * 4, _stream()), 'ihg_score_topk')
     return top_items, top_scores

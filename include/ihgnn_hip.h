@@ -419,11 +419,14 @@ int ihg_sample_negatives(uint64_t seed, uint64_t counter, int64_t n_rows, int64_
  *                 + item_bias[i]
  *   top_items[c][0..k) = the k items of highest score, best first; equal scores in ascending item order (a stable descending
  *   sort; the reference's sort is unstable on ties); top_scores[c][0..k) their scores.  With fewer than k items the tail is -1.
- * `features` is the cached [N, dim] propagation output (rows 16-byte aligned, dim % 4 == 0, dim <= 1272); k <= 10.
- * The [n_pairs, n_items] score matrix is never stored: fp32 MFMA tiles are reduced to per-lane top-k lists in registers.
- * Workspace: ihg_score_topk_workspace_bytes(n_pairs, n_items) bytes (partial lists).
+ * `features` is the cached [N, dim] propagation output (any row stride >= dim, dim <= 1272); k <= 10.
+ * The [n_pairs, n_items] score matrix is never stored: 32 x 32 matrix-core tiles are reduced to per-lane top-k lists in registers.  Arithmetic: every row is
+ * multiplied by a power of two and taken apart into two fp16 terms (hi + lo, 22 significand bits); a product is three v_mfma_f32_32x32x16_f16 partial products
+ * accumulated in fp32 (relative error <= 3 x 2^-22 per product, as accurate as the fp32 matrix instructions on these sums - tests/test_gpu_parity.py); the item rows are
+ * split once per call into the workspace.
+ * Workspace: ihg_score_topk_workspace_bytes(n_pairs, n_items, dim) bytes (the split item rows + partial lists).
  */
-int64_t ihg_score_topk_workspace_bytes(int64_t n_pairs, int64_t n_items);
+int64_t ihg_score_topk_workspace_bytes(int64_t n_pairs, int64_t n_items, int32_t dim);
 int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query_row0, int64_t item_row0, int64_t n_items,
                    const float* item_bias, const int64_t* users, const int64_t* queries, float lambda_muq, int64_t n_pairs,
                    int32_t k, float* top_scores, int32_t* top_items, void* workspace, int64_t workspace_bytes, ihg_stream_t stream);

@@ -1451,8 +1451,8 @@ def test_score_topk_matches_oracle(dim, n_items, n_pairs):
 
 
 def test_top_items_at_a_width_that_is_not_a_multiple_of_four():
-    """``--emb 50 --gnns 2`` (feature width 150; the reference accepts any embedding size): the cached propagation is stored on zero-padded 16-byte
-    aligned rows and ``top_items`` scores it on the HIP kernel - same items and scores as the dense ``score_all_items`` + a stable sort."""
+    """``--emb 50 --gnns 2`` (feature width 150; the reference accepts any embedding size): ``top_items`` scores the cached propagation on the HIP kernel (rows of
+    any width and alignment) - same items and scores as the dense ``score_all_items`` + a stable sort."""
     from ihgnn_amd import profiler, synth
     from ihgnn_amd.Dataset import GraphDataset
     w = synth.draw(60, 20, 150, 30, 800, seed=31)
@@ -1463,7 +1463,7 @@ def test_top_items_at_a_width_that_is_not_a_multiple_of_four():
     queries = torch.arange(40, device=dev()) % w.query_count
     with torch.no_grad():
         m.save_features_for_test()
-        assert tuple(m._saved_output_feature.shape) == (w.node_count, 150) and m._saved_output_feature.stride(0) == 152
+        assert tuple(m._saved_output_feature.shape) == (w.node_count, 150)
         profiler.start()
         items, scores = m.top_items(users, queries)
         profiler.stop()
