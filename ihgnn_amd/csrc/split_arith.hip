@@ -2398,14 +2398,65 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_kernel(const 
     for (int p = 0; p < 3; ++p) pk[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
 }
 
-// D = 128: one workgroup covers all columns, two workgroups per CU.  D = 256: a workgroup covers a column HALF (96 weight registers per
+// scale of every output column of the node-level linear maps (= weight row c, or column c with transpose): wsc[type][c] = scale_up_for(max_k |w(c, k)|), winv its inverse.
+// One wave per (type, c).
+__global__ __launch_bounds__(kBlockThreads) void dense_weight_scales_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride, int n_types, int d, int transpose,
+                                                                            float* __restrict__ wsc, float* __restrict__ winv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = global_wave_id();
+    if (unit >= static_cast<int64_t>(n_types) * d) return;
+    const int type = static_cast<int>(unit) / d, c = static_cast<int>(unit) % d;
+    const float* wt = w + type * type_stride;
+    float m = 0.f;
+    for (int k = lane; k < d; k += kWave) m = fmaxf(m, fabsf(transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k] : wt[static_cast<int64_t>(k) * ld_w + c]));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float inv;
+    const float sc = scale_up_for(m, inv);
+    if (lane == 0) {
+        wsc[unit] = sc;
+        winv[unit] = inv;
+    }
+}
+
+// pk[type][strip][kb][plane < 2][lane][8 x fp16]: element i = plane of wsc[type][c] w(c, 32 kb + 8 (lane >> 4) + i), c = 16 strip + (lane & 15)
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_h2_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride, int n_types, int d,
+                                                                             int transpose, const float* __restrict__ wsc, v4u* __restrict__ pk) {
+    const int kbs = d / 32, strips = d / 16;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_types * strips * kbs * kWave) return;
+    const int lane = idx & 63, kb = (idx >> 6) % kbs, strip = ((idx >> 6) / kbs) % strips, type = (idx >> 6) / (kbs * strips);
+    const int c = 16 * strip + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
+    const float* wt = w + type * type_stride;
+    const float sc = wsc[type * d + c];
+    v4u hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float xa = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k0 + 2 * i] : wt[static_cast<int64_t>(k0 + 2 * i) * ld_w + c];
+        const float xb = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k0 + 2 * i + 1] : wt[static_cast<int64_t>(k0 + 2 * i + 1) * ld_w + c];
+        unsigned hh, ll;
+        split_pair_h2(xa * sc, xb * sc, hh, ll);
+        hi[i] = hh;
+        lo[i] = ll;
+    }
+    pk[(static_cast<int64_t>(idx >> 6) * 2 + 0) * kWave + lane] = hi;
+    pk[(static_cast<int64_t>(idx >> 6) * 2 + 1) * kWave + lane] = lo;
+}
+
+// D = 128: one workgroup covers all columns, two workgroups per CU.  D = 256: a workgroup covers a column HALF (64 weight registers per
 // wave), the two halves of a tile sequence are two workgroups on one XCD (the second read of a row hits that L2), one workgroup per CU.
+// Arithmetic: two fp16 terms per operand (node-level contraction above): a row is scaled by ONE power of two (its 16 staging threads agree on its largest magnitude with
+// four shuffles), the weights by one per output column; the accumulators leave through the two inverse scales.  Half the MFMAs and two thirds of the weight / image
+// registers of the three-bf16 form - the registers pay for a THIRD set of row pieces: a tile's rows are requested three tiles ahead and taken delivery of a whole phase
+// after the request (two tiles of 16 KB in flight per workgroup instead of one: the kernel is a stream whose rate is bytes in flight over the memory round trip).
 template <int D>
-__global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(TypedRows in, int64_t ld_in, const v4u* __restrict__ pk,
-                                                                             int64_t pk_type_stride, const float* __restrict__ bias, int bias_mask,
+__global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, int64_t ld_in, const v4u* __restrict__ pk,
+                                                                             int64_t pk_type_stride, const float* __restrict__ winv, const float* __restrict__ bias, int bias_mask,
                                                                              int64_t bias_type_stride, RowTiles plan, TypedRowsOut out, int64_t ld_out) {
     constexpr int TE = 32, KB = D / 32, OCT = D / 128, HALVES = D / 128, RB = 2 * D, STEPS = 2 * KB;
-    __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][RB];
+    constexpr int NBUF = D == 128 ? 6 : 3;                               // sets of row pieces: a tile's rows are requested NBUF tiles ahead, NBUF - 2 tiles (16 KB each) in flight
+    __shared__ __attribute__((aligned(16))) unsigned char planes[2][2][TE][RB];
+    __shared__ float sinv[2][TE];                                        // inverse row scales of the tile whose images are in planes[.]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int total_tiles = plan.tile_prefix[3];
@@ -2416,8 +2467,8 @@ __global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(T
     const int n_my = seq < total_tiles ? (total_tiles - seq + n_seq - 1) / n_seq : 0;
     if (n_my == 0) return;
     auto tile_type = [&](int tile_id) { return tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0); };
-    auto tile_rows = [&](int k, int64_t& r_base, int64_t& r_end) {
-        const int tile_id = seq + k * n_seq;
+    auto tile_rows = [&](int k, int64_t& r_base, int64_t& r_end) {      // (tiles past this workgroup's last: the last one again, read and dropped)
+        const int tile_id = seq + std::min(k, n_my - 1) * n_seq;
         const int type = tile_type(tile_id);
         r_base = plan.begin[type] + static_cast<int64_t>(tile_id - plan.tile_prefix[type]) * TE;
         r_end = plan.begin[type + 1];
@@ -2425,7 +2476,7 @@ __global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(T
     };
     const int row = tid >> 4, o = tid & 15;                              // staging role: row, octets o (and o + 16) of it
     const int chunk = (o ^ (row & 15)) << 4;
-    auto load_rows = [&](int k, v4f (&dr)[2 * OCT]) {
+    auto load_rows = [&](int k, v4f (&dr)[2 * OCT]) {                    // unconditional: a branch around requests makes the compiler wait for all of them
         int64_t r_base, r_end;
         const int type = tile_rows(k, r_base, r_end);
         const int64_t v = std::min(r_base + row, r_end - 1);             // rows past the type's end re-read its last row (never stored)
@@ -2436,77 +2487,110 @@ __global__ __launch_bounds__(512, D == 128 ? 4 : 2) void row_gemm_split_kernel(T
             dr[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 128 * x + 4);
         }
     };
-    v4f dr0[2 * OCT], dr1[2 * OCT];
-    load_rows(0, dr0);
-    if (n_my > 1) load_rows(1, dr1);
+    // the row's power-of-two scale from this thread's piece and its 15 neighbours' (the row's staging threads are 16 consecutive lanes)
+    auto row_scale = [&](const v4f (&dr)[2 * OCT], float& inv) {
+        float m = 0.f;
 #pragma unroll
-    for (int x = 0; x < OCT; ++x) {
-        const Planes p0 = split8(dr0[2 * x], dr0[2 * x + 1]);
+        for (int j = 0; j < 2 * OCT; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(dr[j][0]), fabsf(dr[j][1])), fmaxf(fabsf(dr[j][2]), fabsf(dr[j][3]))));
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        m = fmaxf(m, __shfl_xor(m, 4));
+        m = fmaxf(m, __shfl_xor(m, 8));
+        return scale_up_for(m, inv);
+    };
+    v4f dbuf[NBUF][2 * OCT];                                             // row pieces of tile m in dbuf[m % NBUF] (indices are compile-time: the phases are unrolled NBUF at a time)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[0][p][row][chunk + 256 * x]) = p0.p[p];
+    for (int j = 0; j < NBUF; ++j) load_rows(j, dbuf[j]);
+    {
+        v4f (&d0)[2 * OCT] = dbuf[0];
+        float inv;
+        const float sc = row_scale(d0, inv);
+#pragma unroll
+        for (int x = 0; x < OCT; ++x) {
+            v4u hi, lo;
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                unsigned hh, ll;
+                split_pair_h2(d0[2 * x + (pr >> 1)][2 * (pr & 1)] * sc, d0[2 * x + (pr >> 1)][2 * (pr & 1) + 1] * sc, hh, ll);
+                hi[pr] = hh;
+                lo[pr] = ll;
+            }
+            *reinterpret_cast<v4u*>(&planes[0][0][row][chunk + 256 * x]) = hi;
+            *reinterpret_cast<v4u*>(&planes[0][1][row][chunk + 256 * x]) = lo;
+        }
+        if (o == 0) sinv[0][row] = inv;
     }
     __syncthreads();
 
-    v8s wreg[KB][3];
-    int cur_type = -1;
+    v8h wreg[KB][2];
+    v4f wiv = v4f{1.f, 1.f, 1.f, 1.f};                                    // inverse scales of this lane's four output columns
+    v4f bv = v4f{0.f, 0.f, 0.f, 0.f};                                     // ... and their bias (per node type: loaded with the weights - a load issued and consumed inside a phase
+    int cur_type = -1;                                                    //     would make the phase wait for every row request in front of it: the memory counter is in order)
     const int arow = lane & 15, kq = lane >> 4;
-    auto phase = [&](int k, v4f (&use)[2 * OCT], v4f (&fill)[2 * OCT]) {
+    const int c4 = 128 * half + 16 * wave + 4 * kq;
+    // phase k: contraction of tile k; images of tile k + 1 (`use`); delivery of tile k + 2 (`arrive`, requested NBUF - 2 phases ago); request of tile k + NBUF (`fill`)
+    auto phase = [&](int k, v4f (&use)[2 * OCT], v4f (&arrive)[2 * OCT], v4f (&fill)[2 * OCT]) {
         int64_t r_base, r_end;
         const int type = tile_rows(k, r_base, r_end);
         if (type != cur_type) {
-            const v4u* wf = pk + type * pk_type_stride + static_cast<int64_t>(8 * half + wave) * (KB * 3) * kWave + lane;
+            const v4u* wf = pk + type * pk_type_stride + static_cast<int64_t>(8 * half + wave) * (KB * 2) * kWave + lane;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wreg[kb][p] = __builtin_bit_cast(v8s, wf[(kb * 3 + p) * kWave]);
+                for (int p = 0; p < 2; ++p) wreg[kb][p] = __builtin_bit_cast(v8h, wf[(kb * 2 + p) * kWave]);
+            wiv = *reinterpret_cast<const v4f*>(winv + type * (pk_type_stride == 0 ? 0 : D) + c4);
+            bv = v4f{0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr && ((bias_mask >> type) & 1)) bv = *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + c4);
             cur_type = type;
         }
-        if (k + 2 < n_my) load_rows(k + 2, fill);
+        load_rows(k + NBUF, fill);
+        float inv_next;
+        const float sc_next = row_scale(use, inv_next);
         v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
         const unsigned char* pbase = &planes[k & 1][0][0][0];
-        v4u sp[OCT][3];
+        v4u sp[OCT][2];
 #pragma unroll
         for (int step = 0; step < STEPS; ++step) {
             const int kb = step >> 1, rt = step & 1;
-            v8s a[3];
+            v8h a[2];
             const unsigned char* src = pbase + (16 * rt + arow) * RB + (((4 * kb + kq) ^ arow) << 4);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * RB));
+            for (int p = 0; p < 2; ++p) a[p] = *reinterpret_cast<const v8h*>(src + p * (TE * RB));
             if (step < 4 * OCT) {   // two values of the next tile's row piece -> one dword of each plane
                 const int x = step >> 2, pr = step & 3;
-                const float xa = use[2 * x + (pr >> 1)][2 * (pr & 1)], xb = use[2 * x + (pr >> 1)][2 * (pr & 1) + 1];
-                unsigned w[3];
-                split_pair(xa, xb, w);
-#pragma unroll
-                for (int p = 0; p < 3; ++p) sp[x][p][pr] = w[p];
+                unsigned hh, ll;
+                split_pair_h2(use[2 * x + (pr >> 1)][2 * (pr & 1)] * sc_next, use[2 * x + (pr >> 1)][2 * (pr & 1) + 1] * sc_next, hh, ll);
+                sp[x][0][pr] = hh;
+                sp[x][1][pr] = ll;
             }
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][kTermB[term]], a[kTermA[term]], acc[rt], 0, 0, 0);
+            for (int term = 0; term < 3; ++term)
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[kb][kTermB2[term]], a[kTermA2[term]], acc[rt], 0, 0, 0);
         }
+        const float iv0 = sinv[k & 1][arow], iv1 = sinv[k & 1][16 + arow];
 #pragma unroll
         for (int x = 0; x < OCT; ++x)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk + 256 * x]) = sp[x][p];     // (past the last tile: nobody reads it)
-        // delivery of the next-but-one tile's rows before the stores (see the member-gradient kernel)
-        if (!abl::late_delivery) {
-            if (OCT == 1) asm volatile("" : "+v"(fill[0]), "+v"(fill[1]));
-            else asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * OCT - 2]), "+v"(fill[2 * OCT - 1]));
-        }
-        const int c4 = 128 * half + 16 * wave + 4 * kq;
-        v4f bv = v4f{0.f, 0.f, 0.f, 0.f};
-        if (bias != nullptr && ((bias_mask >> type) & 1)) bv = *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + c4);
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk + 256 * x]) = sp[x][p];     // (past the last tile: nobody reads it)
+        if (o == 0) sinv[(k + 1) & 1][row] = inv_next;
+        // delivery of the rows requested a phase ago, before the stores (the memory counter is in order: a wait behind a store sits out the store's round trip)
+        if (OCT == 1) asm volatile("" : "+v"(arrive[0]), "+v"(arrive[1]));
+        else asm volatile("" : "+v"(arrive[0]), "+v"(arrive[1]), "+v"(arrive[2 * OCT - 2]), "+v"(arrive[2 * OCT - 1]));
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int64_t v = r_base + 16 * rt + arow;
-            if (v < r_end) *reinterpret_cast<v4f*>(out.p[type] + v * ld_out + c4) = acc[rt] + bv;
+            if (v < r_end) *reinterpret_cast<v4f*>(out.p[type] + v * ld_out + c4) = acc[rt] * (wiv * (rt == 0 ? iv0 : iv1)) + bv;
         }
         __syncthreads();
     };
-    for (int k = 0; k < n_my; k += 2) {
-        phase(k, dr1, dr0);
-        if (k + 1 < n_my) phase(k + 1, dr0, dr1);
+    int k = 0;
+    for (; k + NBUF <= n_my; k += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) phase(k + j, dbuf[(j + 1) % NBUF], dbuf[(j + 2) % NBUF], dbuf[j]);
     }
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j)
+        if (k + j < n_my) phase(k + j, dbuf[(j + 1) % NBUF], dbuf[(j + 2) % NBUF], dbuf[j]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2808,8 +2892,13 @@ void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w,
     const int n_types = w_type_stride == 0 ? 1 : 3;
     v4u* pk = static_cast<v4u*>(planes);
     const int items = n_types * (dim / 16) * (dim / 32) * kWave;
-    hipLaunchKernelGGL(pack_planes_dense_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types, dim,
-                       transpose, pk);
+    // two fp16 planes of the scaled weights, followed by the output columns' scales and their inverses ([n_types][dim] floats each)
+    float* wsc = reinterpret_cast<float*>(pk + static_cast<int64_t>(items) * 2);
+    float* winv = wsc + 3 * dim;
+    hipLaunchKernelGGL(dense_weight_scales_kernel, dim3(grid_for_waves(static_cast<int64_t>(n_types) * dim)), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types, dim, transpose,
+                       wsc, winv);
+    hipLaunchKernelGGL(pack_planes_dense_h2_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types, dim,
+                       transpose, wsc, pk);
     RowTiles plan;
     int acc = 0;
     for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
@@ -2819,13 +2908,13 @@ void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w,
     }
     plan.tile_prefix[3] = acc;
     if (acc == 0) return;
-    const int64_t pk_type_stride = n_types == 1 ? int64_t{0} : static_cast<int64_t>(dim / 16) * (dim / 32) * 3 * kWave;
+    const int64_t pk_type_stride = n_types == 1 ? int64_t{0} : static_cast<int64_t>(dim / 16) * (dim / 32) * 2 * kWave;
     if (dim == 128) {
-        hipLaunchKernelGGL(row_gemm_split_kernel<128>, dim3(std::min(acc, 512)), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, bias, bias_mask, bias_type_stride, plan,
+        hipLaunchKernelGGL(row_gemm_split_kernel<128>, dim3(std::min(acc, 256)), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, winv, bias, bias_mask, bias_type_stride, plan,
                            out, ld_out);
     } else {
         const int n_seq = std::min((acc + 7) / 8 * 8, 256);              // tile sequences: a multiple of 8, so that both halves of one land on one XCD
-        hipLaunchKernelGGL(row_gemm_split_kernel<256>, dim3(2 * n_seq), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, bias, bias_mask, bias_type_stride, plan, out,
+        hipLaunchKernelGGL(row_gemm_split_kernel<256>, dim3(2 * n_seq), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, winv, bias, bias_mask, bias_type_stride, plan, out,
                            ld_out);
     }
 }
