@@ -135,6 +135,10 @@ struct TypedRowsOut {
 };
 
 namespace {
+// p[t] by compares, not by indexing: a per-lane index into a by-value kernel argument makes the compiler fetch the pointer from the argument segment with a vector load
+// (and wait for every outstanding request in front of it)
+__device__ __forceinline__ const float* typed_base(const TypedRows& r, int t) { return t == 0 ? r.p[0] : (t == 1 ? r.p[1] : r.p[2]); }
+__device__ __forceinline__ float* typed_base(const TypedRowsOut& r, int t) { return t == 0 ? r.p[0] : (t == 1 ? r.p[1] : r.p[2]); }
 inline TypedRows typed_rows(const float* base) { return TypedRows{{base, base, base}}; }
 inline TypedRowsOut typed_rows_out(float* base) { return TypedRowsOut{{base, base, base}}; }
 inline TypedRows typed_rows(const float* const* first_rows, const int64_t* type_begin, int64_t ld) {

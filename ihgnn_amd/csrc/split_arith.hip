@@ -2480,7 +2480,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
         int64_t r_base, r_end;
         const int type = tile_rows(k, r_base, r_end);
         const int64_t v = std::min(r_base + row, r_end - 1);             // rows past the type's end re-read its last row (never stored)
-        const float* src = in.p[type] + v * ld_in + 8 * o;
+        const float* src = typed_base(in, type) + v * ld_in + 8 * o;
 #pragma unroll
         for (int x = 0; x < OCT; ++x) {
             dr[2 * x] = *reinterpret_cast<const v4f*>(src + 128 * x);
@@ -2579,7 +2579,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int64_t v = r_base + 16 * rt + arow;
-            if (v < r_end) *reinterpret_cast<v4f*>(out.p[type] + v * ld_out + c4) = acc[rt] * (wiv * (rt == 0 ? iv0 : iv1)) + bv;
+            if (v < r_end) *reinterpret_cast<v4f*>(typed_base(out, type) + v * ld_out + c4) = acc[rt] * (wiv * (rt == 0 ? iv0 : iv1)) + bv;
         }
         __syncthreads();
     };
@@ -2646,7 +2646,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
         const bool live = v < r_end;
         const int64_t vc = live ? v : r_end - 1;
         const float* ds = dout + vc * ld_dout + 8 * o;
-        const float* xs = x.p[row_type(vc)] + vc * ld_x + 128 * half + 8 * o;
+        const float* xs = typed_base(x, row_type(vc)) + vc * ld_x + 128 * half + 8 * o;
 #pragma unroll
         for (int i = 0; i < DOCT; ++i) {
             r.d[2 * i] = *reinterpret_cast<const v4f*>(ds + 128 * i);
@@ -2710,18 +2710,20 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 
         auto phase = [&](auto parity, int k, Rows& use, Rows& fill) {
             constexpr int BUF = decltype(parity)::value;
-            if (k + 2 < n_my) load_rows(k + 2, fill);
             // dx_accumulate: dx already holds another contribution to the same gradient (the member gradients of the interactive step); its rows
-            // of this tile are requested now and seed the accumulators of the dx product at the end of the phase
+            // of this tile seed the accumulators of the dx product at the end of the phase.  Requested BEFORE the next-but-one tile's rows: the memory
+            // counter is in order, so the wait for these at the end of the phase leaves the younger row requests in flight (issued behind them, that wait
+            // took delivery of the whole tile as well: 253 against 190 us per launch at C3)
             v4f gold[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
             if (DX && dx_accumulate) {
                 const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const int64_t v = r_base + 16 * rt + (lane & 15);
-                    if (v < r_end) gold[rt] = *reinterpret_cast<const v4f*>(dx.p[row_type(v)] + v * ld_dx + 16 * wave + 4 * (lane >> 4));
+                    const int64_t v = std::min(r_base + 16 * rt + (lane & 15), r_end - 1);          // (rows past the end: the last row, read and dropped)
+                    gold[rt] = *reinterpret_cast<const v4f*>(typed_base(dx, row_type(v)) + v * ld_dx + 16 * wave + 4 * (lane >> 4));
                 }
             }
+            load_rows(std::min(k + 2, n_my - 1), fill);                  // (unconditional: a branch around requests makes the compiler wait for all of them)
             const unsigned char* dp = &dplanes[BUF][0][0][0];
             const unsigned char* xp = &xplanes[BUF][0][0][0];
             v8s a[IT][3];
@@ -2780,7 +2782,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     const int64_t v = r_base + 16 * rt + arow;
-                    if (v < r_end) *reinterpret_cast<v4f*>(dx.p[row_type(v)] + v * ld_dx + 16 * wave + 4 * kq) = gx[rt];
+                    if (v < r_end) *reinterpret_cast<v4f*>(typed_base(dx, row_type(v)) + v * ld_dx + 16 * wave + 4 * kq) = gx[rt];
                 }
             }
             __syncthreads();

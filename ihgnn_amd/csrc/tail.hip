@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_rows_add_kernel(const flo
             if (lane == 0 && tr >= 0 && tr < tail_rows) tail[tr] += src[k * ld_src];
             continue;
         }
-        float* dst = dense.p[row >= begin2 ? 2 : (row >= begin1 ? 1 : 0)] + row * ld_dense;
+        float* dst = typed_base(dense, row >= begin2 ? 2 : (row >= begin1 ? 1 : 0)) + row * ld_dense;
         for (int c = lane; c < width; c += kWave) dst[c] = ASSIGN ? src[k * ld_src + c] : dst[c] + src[k * ld_src + c];
     }
 }
