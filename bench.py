@@ -11,7 +11,7 @@ A step is one FULL training step of RawGnn (full-graph propagation forward over 
 full replica and its own batches (weak scaling) and the value is the aggregate over ranks.
 
 Workload: the largest BASELINE config that fits one GPU's step budget, C3 (CIKM-Cup-2016 stand-in: d = 128, 3 layers; C4
-(Amazon full catalog stand-in, same model shape, E = 3.3 M) is the per-GPU replica of the 8-GPU config).  --config C1 / C2 / C4 / C5 select the others (C5 on one GPU: 0.46 s per step; give it --warmup 2, the allocator's pool still grows in the second step).
+(Amazon full catalog stand-in, same model shape, E = 3.3 M) is the per-GPU replica of the 8-GPU config).  --config C1 / C2 / C4 / C5 select the others (C5 on one GPU: 0.43 s per step; one warm-up step is enough - Adam's state is created before it).
 
 `--gpus N` without a torchrun environment launches itself: the parent starts N child processes (one per GPU) BEFORE it
 touches the GPU and forwards rank 0's JSON line; under `python -m torch.distributed.run` it uses the ranks it was given.
@@ -306,6 +306,10 @@ def main():
         sync = ihg_dist.make_gradient_sync(model, args.sync)
         sync.broadcast_parameters(0)
     opt = sync.optimizer(1e-3) if (sync is not None and sync.owns_optimizer) else Adam(model.parameters(), 1e-3, weight_decay=0)
+    if hasattr(opt, 'ensure_state'):
+        # Adam's moment buffers exist BEFORE the first step: otherwise they are created at the end of step 1, step 2 meets a different memory pattern and the caching
+        # allocator grows its pool again (C5: two more device allocations, 47 GB, and a second step of 1.6 s instead of 0.43 s) - with them in place ONE warm-up step is enough
+        opt.ensure_state()
     batches = list(ds.sample_batches(100, args.steps + args.warmup, seed=1000 + rank))
     fused_loss = model.supports_fused_loss(lossf)
     # headline = the step with every layer evaluated over ALL rows (each hyperedge through both phases of each layer)

@@ -449,15 +449,16 @@ constexpr int kDenseSlabs = 256;
 // in_typed / out_typed: the rows of every node type start at an address of their own (TypedRows; `in` / `out` are then ignored) - on the bf16-split kernels only
 int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose,
                     const float* bias, int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, float* out, int64_t ld_out, float* pk,
-                    hipStream_t s, const TypedRows* in_typed = nullptr, const TypedRowsOut* out_typed = nullptr) {
+                    hipStream_t s, const TypedRows* in_typed = nullptr, const TypedRowsOut* out_typed = nullptr, int accumulate = 0) {
     const int n_types = w_type_stride == 0 ? 1 : 3;
     const bool out_ok = out_typed != nullptr ? (aligned16(out_typed->p[0]) && aligned16(out_typed->p[1]) && aligned16(out_typed->p[2])) : aligned16(out);
     if (out_ok && split_row_gemm_ok(dim, nullptr, ld_out, bias, bias_type_stride)) {   // the bf16 planes sit behind the slabs (see ihg_node_linear_workspace_bytes)
         void* planes = pk + 3LL * dim * dim + 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
         launch_row_gemm_split(dim, in_typed != nullptr ? *in_typed : typed_rows(in), ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin,
-                              out_typed != nullptr ? *out_typed : typed_rows_out(out), ld_out, planes, s);
+                              out_typed != nullptr ? *out_typed : typed_rows_out(out), ld_out, planes, s, accumulate);
         return IHG_OK;
     }
+    if (accumulate) return fail(IHG_ERR_INVALID, "node-level linear map accumulating into its output: needs the bf16-split kernels (dim 128 / 256, aligned rows)");
     if (in_typed != nullptr || out_typed != nullptr) return fail(IHG_ERR_INVALID, "node-level linear map over typed rows: needs the bf16-split kernels (dim 128 / 256, aligned rows)");
     if (dim == 128 && aligned16(out) && ld_out % 4 == 0 && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0))) {
         const int items = n_types * (dim / 16) * (dim / 16) * kWave;
@@ -734,7 +735,7 @@ int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w
 int32_t ihg_node_linear_bwd_accumulates(int32_t dim, int64_t ld_dout, int64_t ld_x, int64_t ld_dx) {
     // the weight-gradient kernels that form dx in the same pass and can add it onto what dx already holds: d = 64 (fp32 MFMA), d = 128 (bf16-split)
     if (ld_dout % 4 || ld_x % 4 || ld_dx % 4) return 0;
-    return dim == 64 || (dim == 128 && split_arith_enabled()) ? 1 : 0;
+    return dim == 64 || ((dim == 128 || dim == 256) && split_arith_enabled()) ? 1 : 0;       // (d = 256: the input gradient is a row-GEMM launch of its own, which adds onto dx)
 }
 
 int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin,
@@ -771,12 +772,15 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     int n_slabs = kDenseSlabs;
     if (split_dense_weight_ok(dim, dout, ld_dout, x, ld_x)) {             // bf16-split contraction (d = 128, 256); the input gradient stays a row-GEMM launch
         const bool fused_dx = dx != nullptr && dim == 128 && aligned16(dx) && ld_dx % 4 == 0;
-        if (dx != nullptr && !fused_dx) launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace), s);
+        if (dx_accumulate && !fused_dx && !(dim == 256 && aligned16(dx) && ld_dx % 4 == 0))
+            return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate needs 16-byte aligned dx rows");
+        if (dx != nullptr && !fused_dx) {
+            if (int rc = launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, static_cast<float*>(workspace), s, nullptr, nullptr, dx_accumulate)) return rc;
+        }
         void* planes = static_cast<float*>(workspace) + 3LL * dim * dim + 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
-        if (dx_accumulate && !fused_dx) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate needs 16-byte aligned dx rows at dim 128");
         const TypedRowsOut dx_rows = typed_rows_out(dx);
         n_slabs = launch_dense_weight_split(dim, dout, ld_dout, typed_rows(x), ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, fused_dx ? &dx_rows : nullptr, ld_dx,
-                                            planes, s, dx_accumulate);
+                                            planes, s, fused_dx ? dx_accumulate : 0);
     } else if (dim == 64 && dx != nullptr) {
         hipLaunchKernelGGL((dense_weight_grad_kernel<64, true>), dim3(kDenseSlabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan,
                            n_types == 1 ? 1 : 0, slabs, bias_slabs, dim, w, ld_w, dw_type_stride, dx, ld_dx, dx_accumulate);

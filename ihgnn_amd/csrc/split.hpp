@@ -36,7 +36,8 @@ IHG_INTERNAL int launch_weight_split(int dim, int order, const float* h, int64_t
 IHG_INTERNAL int64_t split_dense_plane_floats(int dim);
 IHG_INTERNAL bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* bias, int64_t bias_type_stride);
 IHG_INTERNAL void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
-                                        int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, void* planes, hipStream_t s);
+                                        int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, void* planes, hipStream_t s,
+                                        int accumulate = 0);      // accumulate: out += (out holds another contribution to the same rows)
 
 // weight / bias gradient of the node-level linear maps into dense.hip's slabs ([type][slab][d][d], [type][slab][d]); returns the slabs per type
 IHG_INTERNAL bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x);

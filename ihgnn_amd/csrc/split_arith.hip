@@ -2452,7 +2452,7 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_h2_kernel(con
 template <int D>
 __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, int64_t ld_in, const v4u* __restrict__ pk,
                                                                              int64_t pk_type_stride, const float* __restrict__ winv, const float* __restrict__ bias, int bias_mask,
-                                                                             int64_t bias_type_stride, RowTiles plan, TypedRowsOut out, int64_t ld_out) {
+                                                                             int64_t bias_type_stride, RowTiles plan, TypedRowsOut out, int64_t ld_out, int accumulate) {
     constexpr int TE = 32, KB = D / 32, OCT = D / 128, HALVES = D / 128, RB = 2 * D, STEPS = 2 * KB;
     constexpr int NBUF = D == 128 ? 6 : 3;                               // sets of row pieces: a tile's rows are requested NBUF tiles ahead, NBUF - 2 tiles (16 KB each) in flight
     __shared__ __attribute__((aligned(16))) unsigned char planes[2][2][TE][RB];
@@ -2543,6 +2543,16 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
             if (bias != nullptr && ((bias_mask >> type) & 1)) bv = *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + c4);
             cur_type = type;
         }
+        // accumulate: `out` already holds another contribution to the same rows (out += ...): its rows of this tile are requested FIRST - older than the row requests
+        // below, so the wait for them at the end of the phase leaves those in flight
+        v4f gold[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+        if (accumulate) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int64_t v = std::min(r_base + 16 * rt + arow, r_end - 1);
+                gold[rt] = *reinterpret_cast<const v4f*>(typed_base(out, type) + v * ld_out + c4);
+            }
+        }
         load_rows(k + NBUF, fill);
         float inv_next;
         const float sc_next = row_scale(use, inv_next);
@@ -2579,7 +2589,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int64_t v = r_base + 16 * rt + arow;
-            if (v < r_end) *reinterpret_cast<v4f*>(typed_base(out, type) + v * ld_out + c4) = acc[rt] * (wiv * (rt == 0 ? iv0 : iv1)) + bv;
+            if (v < r_end) *reinterpret_cast<v4f*>(typed_base(out, type) + v * ld_out + c4) = acc[rt] * (wiv * (rt == 0 ? iv0 : iv1)) + bv + gold[rt];
         }
         __syncthreads();
     };
@@ -2890,7 +2900,7 @@ bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* b
 }
 
 void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
-                           int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, void* planes, hipStream_t s) {
+                           int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, void* planes, hipStream_t s, int accumulate) {
     const int n_types = w_type_stride == 0 ? 1 : 3;
     v4u* pk = static_cast<v4u*>(planes);
     const int items = n_types * (dim / 16) * (dim / 32) * kWave;
@@ -2913,11 +2923,11 @@ void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w,
     const int64_t pk_type_stride = n_types == 1 ? int64_t{0} : static_cast<int64_t>(dim / 16) * (dim / 32) * 2 * kWave;
     if (dim == 128) {
         hipLaunchKernelGGL(row_gemm_split_kernel<128>, dim3(std::min(acc, 256)), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, winv, bias, bias_mask, bias_type_stride, plan,
-                           out, ld_out);
+                           out, ld_out, accumulate);
     } else {
         const int n_seq = std::min((acc + 7) / 8 * 8, 256);              // tile sequences: a multiple of 8, so that both halves of one land on one XCD
         hipLaunchKernelGGL(row_gemm_split_kernel<256>, dim3(2 * n_seq), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, winv, bias, bias_mask, bias_type_stride, plan, out,
-                           ld_out);
+                           ld_out, accumulate);
     }
 }
 
