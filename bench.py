@@ -65,11 +65,9 @@ MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md); the
 
 
 def split_arithmetic(dim, order, direction='any'):
-    """True when the library runs this shape's contractions through three exact bf16 terms per operand (csrc/split_arith.hip):
-    orders 2 and 3 at d = 64 / 128 / 256 (the d = 256 order-2 forward: on the pass kernel only, i.e. not under IHG_FWD_KPASS=0)."""
-    if order not in (2, 3) or os.environ.get('IHG_INTERACT_ARITH') == 'f32' or dim not in (64, 128, 256):
-        return False
-    return not (direction == 'forward' and dim == 256 and order == 2 and os.environ.get('IHG_FWD_KPASS') == '0')
+    """True when the library runs this shape's contractions through exactly split fp32 operands on the 16-bit matrix pipe (csrc/split_arith.hip): orders 2 and 3 at
+    d = 64 / 128 / 256."""
+    return order in (2, 3) and os.environ.get('IHG_INTERACT_ARITH') != 'f32' and dim in (64, 128, 256)
 
 
 def parse():
@@ -79,6 +77,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='C3', help='synth.CONFIGS key (C1 | C2 | C3 | C4 | C5)')
     ap.add_argument('--order', type=int, default=3)
+    ap.add_argument('--dim', type=int, default=0, help='embedding width instead of the config\'s (the reference\'s default is --emb 32, Helpers/GlobalSettings.py:30)')
     ap.add_argument('--layer', default='ihgnn', choices=['ihgnn', 'hgcn'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-scale', type=float, default=0.25, help='fraction of the workload the CPU baseline runs on')
@@ -222,7 +221,7 @@ def k7_roles(table, E, N, dim, layout, table_steps):
         'k7.two_hop_bwd_masked': (N, 6 * E + N, 24 * E, 'backward of the LAST first-order layer: its cotangent is zero outside the 3B batch rows (the output feeds the batch '
                                                           'tail only), the pull skips the gathers of the zero rows - same gradient; bytes as for the dense pull (an upper bound)'),
         'k7.edges_to_nodes_bwd_of_k5': (E, 3 * E, 12 * E, 'backward of a K5 launch'),
-        'k7.two_hop_first_order_gradient': (N, 6 * E + N, 24 * E, 'backward of the interactive layer, first-order part: the two-hop operator on the node-level cotangent (IHG_FIRST_ORDER_TWO_HOP=1)'),
+        'k7.two_hop_first_order_gradient': (N, 6 * E + N, 24 * E, 'backward of the interactive layer, first-order part: the two-hop operator on the node-level cotangent ([E, d] tables beyond ops.FIRST_ORDER_TWO_HOP_BYTES: config C5)'),
         'node_pair_sums': (N, 6 * E, 24 * E, 'interactive layer forward, node-level form: node table -> [N,3d] pair sums over hop2_csr (the output row is 3 d wide)', 3),
     }
     out = {}
@@ -293,7 +292,7 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = synth.CONFIGS[args.config]
-    dim, layers = cfg['dim'], cfg['layers']
+    dim, layers = args.dim or cfg['dim'], cfg['layers']
     w = synth.draw_config(args.config, scale=args.scale)
     ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets,
                                   w.triples, device=dev)
@@ -632,6 +631,7 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': WORKLOAD_NOTES.get(args.config, args.config) + (f' SCALED x{args.scale:g};' if args.scale != 1.0 else '') +
+                               (f' WIDTH OVERRIDE --dim {dim};' if args.dim else '') +
                                f' U={w.user_count} Q={w.query_count} I={w.item_count} E={E}, {cfg["distribution"]} members, '
                                f'dim={dim}, {layers}x{args.layer} layers, interaction order {args.order}, batch 100 pos + 1000 neg',
                    'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd (the last layer\'s backward pulls the 3B non-zero rows of its cotangent) + Adam' +

@@ -39,8 +39,6 @@ class FeatureInteractor(nn.Module):
         can and adds the first-order path's input gradient onto the member gradients inside the node-level kernel."""
         layout = self.dataset.hypergraph.layout
         if self.max_order > 1:
-            if not ops.LAYER0_ONE_NODE:
-                return ops.interact_to_nodes(node_features, self.first_order(node_features), self.aggregation.weight, layout, self.max_order, out_scale, rows, out)
             return ops.interact_layer(node_features, self.aggregation.weight, self.aggregation.bias, layout, self.max_order, out_scale, rows, out)
         return ops.node_segment_sum(self(node_features), layout, out_scale=out_scale, rows=rows, out=out)
 

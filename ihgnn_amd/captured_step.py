@@ -101,8 +101,8 @@ class CapturedTrainingStep:
         group = self.optimizer.param_groups[0]
         switches = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('IHG_')))
         from . import ops
-        flags = tuple((name, getattr(ops, name)) for name in ('USER_REDUCED_BACKWARD', 'SPARSE_LAST_COTANGENT', 'NODE_LEVEL_FORWARD', 'NODE_LEVEL_WEIGHT',
-                                                              'FIRST_ORDER_TWO_HOP', 'LAYER0_ONE_NODE', 'MEMBER_BUFFER_LIMIT_BYTES') if hasattr(ops, name))
+        flags = tuple((name, getattr(ops, name)) for name in ('USER_REDUCED_BACKWARD', 'SPARSE_LAST_COTANGENT', 'NODE_LEVEL_FORWARD', 'NODE_LEVEL_WEIGHT', 'NODE_TABLES',
+                                                              'FIRST_ORDER_TWO_HOP_BYTES', 'MEMBER_BUFFER_LIMIT_BYTES') if hasattr(ops, name))
         return (tuple(group['betas']), float(group['eps']), float(group['weight_decay']), bool(self.model.batch_rows_only_last_layer), switches, flags)
 
     def stale(self) -> bool:

@@ -57,7 +57,7 @@ constexpr bool n_no_split = true;
 #else
 constexpr bool n_no_split = false;
 #endif
-#ifdef IHG_ABL_N_NO_FIRST          // node-level contraction: `out` is neither re-read nor stored (the epilogue's sums go to LDS only)
+#ifdef IHG_ABL_N_NO_FIRST          // node-level contraction: no row loads in the service waves (values made up from the row number)
 constexpr bool n_no_first = true;
 #else
 constexpr bool n_no_first = false;
@@ -66,11 +66,6 @@ constexpr bool n_no_first = false;
 constexpr bool n_no_shuffle = true;
 #else
 constexpr bool n_no_shuffle = false;
-#endif
-#ifdef IHG_VAR_LATE_DELIVERY        // A/B (not an ablation: results stay right): the node-level streaming kernels do not take delivery of a phase's row requests at its end
-constexpr bool late_delivery = true;
-#else
-constexpr bool late_delivery = false;
 #endif
 constexpr bool any = n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
 }  // namespace abl

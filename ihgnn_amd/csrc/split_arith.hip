@@ -740,9 +740,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_ws_kernel(co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Forward at d = 128 (and, further down, d = 256) in PASSES over the contraction index (the default; IHG_FWD_KPASS=0 keeps the column-half kernel
-// above / the chunked kernel below).
-// The column-half form forms and splits every product twice (once per half); here a workgroup owns ALL 128 output columns and HALF of
+// Forward at d = 128 and d = 256 in PASSES over the contraction index (the hyperedge form: `rows=` subsets, IHG_NODE_LEVEL_FORWARD=0).
+// The column-half form (kept for d = 64, where one workgroup holds the whole weight block) forms and splits every product twice (once per half); here a workgroup owns ALL 128 output columns and HALF of
 // the contraction index - pass A: blocks uq, qi (+ the first-order rows), pass B: blocks iu, uqi, added onto pass A's result, which
 // goes through `out` (one extra write and read of [E, d]: 2.2 GB that an issue-bound kernel moves beside its MFMAs) - so every product
 // is formed and split ONCE.  The weight planes of a pass are again 192 KB: matrix wave m owns output columns 32 m .. 32 m + 31 with the
@@ -818,40 +817,19 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
                 const float* hp = row_at(h, idk[m], ldh) + 4 * o;
 #pragma unroll
                 for (int x = 0; x < ZX; ++x) {
-#ifdef IHG_NT_USER_ROWS
-                    if (m == 0) hm[x][m] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(hp + CSTR * x));
-                    else
-#endif
                     hm[x][m] = *reinterpret_cast<const v4f*>(hp + CSTR * x);
                 }
             }
-#ifdef IHG_ABL_NO_MEMBER_LOADS
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                for (int x = 0; x < ZX; ++x) hm[x][m] = v4f{1.f * k, 2.f, 3.f, 4.f};
-#endif
         };
         // what the products are added to: the three first-order rows (summed in the order u, q, i) or the row the earlier passes left in `out`
         auto load_first = [&](int k, v4f (&pr)[OX][ACC ? 1 : 3]) {
-#ifdef IHG_ABL_NO_FIRST_LOADS
-#pragma unroll
-            for (int x = 0; x < OX; ++x)
-#pragma unroll
-                for (int m = 0; m < (ACC ? 1 : 3); ++m) pr[x][m] = v4f{1.f * k, 2.f, 3.f, 4.f};
-            return;
-#endif
             if (ACC) {
                 const int64_t e = std::min<int64_t>((t0 + k) * TE + row, n_edges - 1);
                 const float* op = out + e * ld_out + hoff + 4 * o;
 #pragma unroll
                 for (int x = 0; x < OX; ++x) {
-#ifndef IHG_PLAIN_OUT_READ
                     pr[x][0] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(op + CSTR * x));     // read once, never again (pass B at C3: 861 -> 847 us;
-#else                                                                                                     //  the user rows read the same way: 878, they are re-read by the next hyperedges)
-                    pr[x][0] = *reinterpret_cast<const v4f*>(op + CSTR * x);
-#endif
-                }
+                }                                                                                         //  the user rows read the same way: 878, they are re-read by the next hyperedges)
             } else {
                 const int* idk = ids[k & 7] + row * 3;
 #pragma unroll
@@ -872,21 +850,12 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
                     const int b = B0 + b2;
                     const v4f z = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
                     unsigned w0[3], w1[3];
-#ifdef IHG_ABL_NO_SPLIT
-                    w0[0] = w0[1] = w0[2] = __float_as_uint(z[0] + z[1]);
-                    w1[0] = w1[1] = w1[2] = __float_as_uint(z[2] + z[3]);
-#else
                     split_pair(z[0], z[1], w0);
                     split_pair(z[2], z[3], w1);
-#endif
                     // columns b2 D + CSTR x + 4 o ..: chunk b2 D / 8 + (CSTR / 8) x + (o >> 1), half o & 1
                     const int off = row * ZRB + ((((D / 8) * b2 + (CSTR / 8) * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
-#ifdef IHG_ABL_NO_IMAGE_WRITES
-                    asm volatile("" ::"v"(w0[0]), "v"(w0[1]), "v"(w0[2]), "v"(w1[0]), "v"(w1[1]), "v"(w1[2]), "v"(off));
-#else
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + pl * ZPL + off) = v2u{w0[pl], w1[pl]};
-#endif
                 }
             }
         };
@@ -897,11 +866,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
             for (int x = 0; x < OX; ++x) {
                 const v4f sum = *reinterpret_cast<const v4f*>(&pp[row][4 * o + CSTR * x]);
                 const v4f first = ACC ? pr[x][0] : (pr[x][0] + pr[x][ACC ? 0 : 1]) + pr[x][ACC ? 0 : 2];
-#ifdef IHG_ABL_NO_STORES
-                asm volatile("" ::"v"(first + sum));
-#else
                 if (e < n_edges) store_stream4(out + e * ld_out + hoff + 4 * o + CSTR * x, first + sum);
-#endif
             }
         };
         if (st < 3 * TE) {
@@ -923,9 +888,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
             load_members(k + 2, fill);                                   // unconditional (past the end: whatever rows the ring slot names, dropped)
             if (k >= 1) load_first(k - 1, pr);
             if (k + 4 < n_my && st < 3 * TE) id_carry = fetch_id(k + 4);
-#ifndef IHG_ABL_NO_SERVICE_SPLIT
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
-#endif
             // delivery of this phase's requests, THEN the store (the memory counter is in order)
             asm volatile("" : "+v"(fill[ZX - 1][0]), "+v"(fill[ZX - 1][1]), "+v"(fill[ZX - 1][2]));
             asm volatile("" : "+v"(pr[OX - 1][0]));
@@ -976,15 +939,11 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
                 const int rt = step / KB, kb = step % KB;
                 if (step + 1 < RT * KB) fragment(step + 1, an);
                 IHG_PIN_ORDER();                                         // (the scheduler would sink the reads to their first use)
-#ifdef IHG_ABL_NO_MFMA
-                acc[rt][0] += __builtin_bit_cast(v4f, a[0]) + __builtin_bit_cast(v4f, a[1]) + __builtin_bit_cast(v4f, a[2]);
-#else
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
 #pragma unroll
                     for (int jt = 0; jt < 2; ++jt)
                         acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[jt][kb][kTermB[term]], a[kTermA[term]], acc[rt][jt], 0, 0, 0);
-#endif
                 IHG_PIN_ORDER();
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) a[pl] = an[pl];
@@ -1079,203 +1038,9 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd_kernel(con
 
 constexpr int kNodePassV4 = 4 * 2 * 8 * 2 * kWave;                      // v4u of one (type, pass)'s planes
 
-// KIND 0: blocks {S, h S} of the source block `sums`; 1: {S} (the S_ab pass at order 2); 2: {deg h} (the first pass: `out` = deg c + ...)
-// ACC: add onto `out`; FINAL: multiply the row by scale[v] (nullptr: 1) before the store
-// Arithmetic: two fp16 terms per operand (above): a tile row's contraction values of a pass are scaled by ONE power of two (the 8 threads of a row agree on its largest
-// magnitude with three shuffles), the weights by one per output column (winv, all types); the epilogue removes both.
-template <int KIND, bool ACC, bool FINAL>
-__global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
-                                                                          const float* __restrict__ deg, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                                          const v4u* __restrict__ wnp, const float* __restrict__ winv, RowTiles plan, float* __restrict__ out,
-                                                                          int64_t ld_out) {
-    constexpr int NB = KIND == 0 ? 2 : 1, TE = 32, RT = 2, CSTR = 32, KB = NB * 4, ZRB = 2 * NB * 128, ZPL = TE * ZRB, PS = 128 + 4, X = 4;
-    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][2][TE][ZRB];
-    __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
-    __shared__ __attribute__((aligned(16))) float swinv[3][128];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 3 * 128) (&swinv[0][0])[tid] = winv[tid];
-    const int total_tiles = plan.tile_prefix[3];
-    const int per = (total_tiles + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
-    const int t0 = static_cast<int>(blockIdx.x) * per;
-    const int n_my = std::max(0, std::min(per, total_tiles - t0));
-    if (n_my == 0) return;
-    // tile k of this workgroup (tiles past its range: the last tile of the graph, read and dropped): node type, first row, end of the type's rows
-    auto tile_rows = [&](int k, int64_t& r_base, int64_t& r_end) {
-        const int tile_id = std::min(t0 + k, total_tiles - 1);
-        const int type = tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0);
-        r_base = plan.begin[type] + static_cast<int64_t>(tile_id - plan.tile_prefix[type]) * TE;
-        r_end = plan.begin[type + 1];
-        return type;
-    };
-
-    role_priority(wave >= 4);
-    if (wave >= 4) {
-        // ---------------- service waves: thread -> node row of the tile, columns 4 o + 32 x .. (x < 4)
-        const int st = tid - 256, row = st >> 3, o = st & 7;
-        struct Piece { v4f hv[X], sv[X]; float d; };
-        auto load_piece = [&](int k, Piece& pc) {
-            int64_t r_base, r_end;
-            tile_rows(k, r_base, r_end);
-            const int64_t v = std::min(r_base + row, r_end - 1);        // rows past the type's end re-read its last row (never stored)
-#pragma unroll
-            for (int x = 0; x < X; ++x) {
-                if (KIND != 1) pc.hv[x] = *reinterpret_cast<const v4f*>(h + v * ld_h + 4 * o + CSTR * x);
-                // (a block of the pair sums is read by exactly one pass: non-temporal, `out` and h keep the caches; 2-3 %)
-                if (KIND != 2) pc.sv[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sums + v * ld_s + 4 * o + CSTR * x));
-            }
-            if (KIND == 2) pc.d = deg[v];
-        };
-        struct First { v4f old[X]; float d, sc; };
-        auto load_first = [&](int k, First& f) {
-            int64_t r_base, r_end;
-            tile_rows(k, r_base, r_end);
-            const int64_t v = std::min(r_base + row, r_end - 1);
-            if (ACC) {
-#pragma unroll
-                for (int x = 0; x < X; ++x) f.old[x] = abl::n_no_first ? v4f{1.f, 2.f, 3.f, 4.f} : *reinterpret_cast<const v4f*>(out + v * ld_out + 4 * o + CSTR * x);
-            } else {
-                f.d = deg[v];
-            }
-            if (FINAL) f.sc = scale != nullptr ? scale[v] : 1.f;
-        };
-        // the tile's contraction values of this thread's row piece -> scaled, two fp16 planes; returns the inverse of the row's scale
-        auto split_tile = [&](const Piece& pc, int buf) {
-            typedef unsigned v2u __attribute__((ext_vector_type(2)));
-            if (abl::n_no_split) return 1.f;
-            v4f z[X][NB];
-            float m = 0.f;
-#pragma unroll
-            for (int x = 0; x < X; ++x)
-#pragma unroll
-                for (int b2 = 0; b2 < NB; ++b2) {
-                    z[x][b2] = KIND == 2 ? pc.hv[x] * pc.d : (b2 == 0 ? pc.sv[x] : pc.hv[x] * pc.sv[x]);
-                    m = fmaxf(fmaxf(m, fmaxf(fabsf(z[x][b2][0]), fabsf(z[x][b2][1]))), fmaxf(fabsf(z[x][b2][2]), fabsf(z[x][b2][3])));
-                }
-            if (!abl::n_no_shuffle) {
-                m = fmaxf(m, __shfl_xor(m, 1));                         // the row's eight threads are eight consecutive lanes
-                m = fmaxf(m, __shfl_xor(m, 2));
-                m = fmaxf(m, __shfl_xor(m, 4));
-            }
-            float inv;
-            const float sc = scale_up_for(m, inv);
-#pragma unroll
-            for (int x = 0; x < X; ++x)
-#pragma unroll
-                for (int b2 = 0; b2 < NB; ++b2) {
-                    unsigned h0, l0, h1, l1;
-                    split_pair_h2(z[x][b2][0] * sc, z[x][b2][1] * sc, h0, l0);
-                    split_pair_h2(z[x][b2][2] * sc, z[x][b2][3] * sc, h1, l1);
-                    // columns 128 b2 + 32 x + 4 o ..: chunk 16 b2 + 4 x + (o >> 1), half o & 1
-                    const int off = row * ZRB + (((16 * b2 + 4 * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
-                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + off) = v2u{h0, h1};
-                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + ZPL + off) = v2u{l0, l1};
-                }
-            return inv;
-        };
-        auto epilogue = [&](int k, const First& f, float xinv) {         // tile k
-            int64_t r_base, r_end;
-            const int type = tile_rows(k, r_base, r_end);
-            const int64_t v = r_base + row;
-            const float (*pp)[PS] = part[k & 1];
-#pragma unroll
-            for (int x = 0; x < X; ++x) {
-                v4f val = *reinterpret_cast<const v4f*>(&pp[row][4 * o + CSTR * x]) * (*reinterpret_cast<const v4f*>(&swinv[type][4 * o + CSTR * x]) * xinv);
-                if (ACC) val += f.old[x];
-                else if (bias != nullptr) val += *reinterpret_cast<const v4f*>(bias + 4 * o + CSTR * x) * f.d;
-                if (FINAL) val *= f.sc;
-                if (abl::n_no_first) *reinterpret_cast<v4f*>(&swinv[0][4 * o]) = val;      // (kept alive, never read back meaningfully)
-                else if (v < r_end) *reinterpret_cast<v4f*>(out + v * ld_out + 4 * o + CSTR * x) = val;
-            }
-        };
-        Piece pc0, pc1;                                                  // values of tile m in pc<m & 1>
-        First f;
-        load_piece(0, pc0);
-        load_piece(1, pc1);
-        float inv_prev = 1.f, inv_cur = split_tile(pc0, 0), inv_next = 1.f;   // inverse row scales of tiles k - 1, k, k + 1
-        __syncthreads();
-        // phase k: images of tile k + 1 (`use`); what tile k - 1 is added to (requested at the start of the phase), its sums and store at the end;
-        // request: values of tile k + 2 (`fill`)
-        auto phase = [&](int k, const Piece& use, Piece& fill) {
-            load_piece(k + 2, fill);
-            if (k >= 1) load_first(k - 1, f);
-            if (k + 1 < n_my) inv_next = split_tile(use, (k + 1) & 1);
-            if (k >= 1) epilogue(k - 1, f, inv_prev);
-            inv_prev = inv_cur;
-            inv_cur = inv_next;
-            __syncthreads();
-        };
-        int k = 0;
-#pragma clang loop unroll(disable)
-        for (; k + 1 <= n_my; k += 2) {
-            phase(k, pc1, pc0);
-            phase(k + 1, pc0, pc1);
-        }
-        if (k <= n_my) phase(k, pc1, pc0);
-        return;
-    }
-
-    // ---------------- matrix waves: wave m = output columns 32 m .. + 31, the pass's whole contraction index
-    v8h wreg[2][KB][2];
-    int cur_type = -1;
-    __syncthreads();
-    const int arow = lane & 15, kq = lane >> 4;
-    for (int k = 0; k <= n_my; ++k) {
-        if (k < n_my) {
-            int64_t r_base, r_end;
-            const int type = tile_rows(k, r_base, r_end);
-            if (type != cur_type) {
-                const v4u* wf = wnp + static_cast<int64_t>(type) * 4 * kNodePassV4;
-#pragma unroll
-                for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                        for (int pl = 0; pl < 2; ++pl)
-                            wreg[jt][kb][pl] = __builtin_bit_cast(v8h, wf[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 2 + pl) * kWave + lane]);
-                cur_type = type;
-            }
-            const unsigned char* zp = &zplanes[k & 1][0][0][0];
-            auto fragment = [&](int step, v8h (&a)[2]) {
-                const int rt = step / KB, kb = step % KB;
-                const unsigned char* src = zp + (16 * rt + arow) * ZRB + (((4 * kb + kq) ^ arow) << 4);
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[pl] = *reinterpret_cast<const v8h*>(src + pl * ZPL);
-            };
-            v4f acc[RT][2];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
-            v8h a[2], an[2];
-            fragment(0, a);
-#pragma unroll
-            for (int step = 0; step < RT * KB; ++step) {
-                const int rt = step / KB, kb = step % KB;
-                if (step + 1 < RT * KB) fragment(step + 1, an);
-                IHG_PIN_ORDER();
-                if (!abl::n_no_mfma) {
-#pragma unroll
-                    for (int term = 0; term < 3; ++term)
-#pragma unroll
-                        for (int jt = 0; jt < 2; ++jt)
-                            acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[jt][kb][kTermB2[term]], a[kTermA2[term]], acc[rt][jt], 0, 0, 0);
-                }
-                IHG_PIN_ORDER();
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[pl] = an[pl];
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[k & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// The four passes above as ONE launch that touches `out` once (d = 128; the default).  The passes stay - a matrix wave's weight registers hold the planes of 256
+// The node-level contraction at d = 128: FOUR passes over the contraction index ({deg h}, {S_a, h S_a}, {S_b, h S_b}, {S_ab, h S_ab}) as ONE launch that touches
+// `out` once.  A matrix wave's weight registers hold the planes of 256
 // values of the contraction index - but they run GROUP by group of G = 8 row tiles: for each pass the matrix waves load that pass's planes once per group and contract
 // the group's tiles, and the partial sums of the group's rows live in the SERVICE waves' registers between the passes (thread = one row x 16 columns of every tile:
 // 16 G = 128 registers), not in `out`.  h and the pair sums are read once from memory (h four times out of L2: a group's rows are 128 KB), `out` is written once:
@@ -1552,12 +1317,11 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same node-level forward for d = 64 / 128 / 256 in one geometry: a workgroup owns 64 output columns (`part`) and up to 512 values of the
+// The node-level forward for d = 64 / 256 (three bf16 terms per operand): a workgroup owns 64 output columns (`part`) and up to 512 values of the
 // contraction index per pass - matrix wave m: 16 columns x 512 values = the 192 weight registers - over tiles of 16 node rows.  The seven
 // source blocks X = [deg h | S_a | h S_a | S_b | h S_b | S_ab | h S_ab] come 512 / d to a pass: d = 64: ONE pass, d = 128: two (x 2 column parts),
-// d = 256: four (x 4 parts; the parts of a tile range are adjacent workgroups on one XCD and share the rows through its L2).  At d = 128 this
-// halves the passes of the kernel above, and is slower (C3: 592 against 543 us - one accumulator tile per matrix wave, twice the split work): d = 128 keeps
-// the four passes of 256 values unless IHG_NODE_FWD_Q=1.
+// d = 256: four (x 4 parts; the parts of a tile range are adjacent workgroups on one XCD and share the rows through its L2).  (At d = 128 this geometry
+// measured 592 us against 543 for four passes of 256 values - one accumulator tile per matrix wave, twice the split work; d = 128 runs the grouped kernel above.)
 // wnq[type][pass][part][m][kb < 16][plane][lane][8]: element i = plane of W[64 part + 16 m + (lane & 15)][block(type, xb) d + c], where
 //   kk = 32 kb + 8 (lane >> 4) + i,  xb = pass (512 / d) + kk / d,  c = kk % d     (xb > 6, or the uqi block at order 2: zeros)
 // ------------------------------------------------------------------------------------------------
@@ -1742,218 +1506,6 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(cons
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Forward at d = 256 (the kernel is written for d = 128 as well, where the resident-weights form above is faster), without eightfold product work: the contraction index is walked in CHUNKS of 128 (one product block, or
-// half of one at d = 256), one chunk per phase.  The matrix waves own the OUTPUT - wave m: 32 columns x the tile's 32 hyperedges,
-// accumulators kept across the chunks - and do not keep the weights: the 24 weight fragments of the next chunk (24 KB per wave, the planes
-// are L2-resident: 0.4 / 1.5 MB) are requested while the current chunk's 96 MFMAs run.  The service waves keep one hyperedge's member values
-// (16 columns x 3 per thread, the next set requested a set ahead) and lay down each chunk's products as bf16 images a phase ahead; every
-// product is formed and split exactly once per 128 output columns (d = 128: once; d = 256: once per column half).  The finished tile
-// goes through an LDS image at the start of the next tile; the service waves add the first-order rows and store it during the following
-// three phases.  One barrier per phase.
-// wck[half][m][c][jt][kb][plane][lane][8]: element i = plane of W[128 half + 32 m + 16 jt + (lane & 15)][(3 + b) D + 128 cp + 32 kb + 8 (lane >> 4) + i],
-// chunk c = 4 cp + b (the four blocks of one column part are consecutive: they share the member values)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_fwd_chunk_kernel(const float* __restrict__ w, int64_t ld_w, int d, v4u* __restrict__ wck) {
-    const int jh = d / 128, nch = 4 * jh;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= jh * 4 * nch * 2 * 4 * kWave) return;
-    const int lane = idx & 63, kb = (idx >> 6) & 3, jt = (idx >> 8) & 1, c = (idx >> 9) % nch, m = ((idx >> 9) / nch) & 3, half = (idx >> 9) / (nch * 4);
-    const int b = c & 3, cp = c >> 2;
-    const float* src = w + static_cast<int64_t>(128 * half + 32 * m + 16 * jt + (lane & 15)) * ld_w + (3 + b) * d + 128 * cp + 32 * kb + 8 * (lane >> 4);
-    const Planes pl = split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]});
-#pragma unroll
-    for (int p = 0; p < 3; ++p) wck[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
-}
-
-template <int D>
-__global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_chunk_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ p, int64_t ld_p,
-                                                                                 const int32_t* __restrict__ i3, const v4u* __restrict__ wck, float* __restrict__ out,
-                                                                                 int64_t ld_out, int64_t n_edges) {
-    constexpr int TE = kSplitTE, JH = D / 128, NCH = 4 * JH, NSEQ = 256 / JH, OS = 128 + 4, ZPL = TE * 256;
-    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][256];
-    __shared__ __attribute__((aligned(16))) float oimg[TE][OS];
-    __shared__ int ids[4][3 * TE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x;
-    const int half = (bid >> 3) & (JH - 1), seq = (bid & 7) + 8 * (bid / (8 * JH));
-    const int64_t n_tiles = (n_edges + TE - 1) / TE;
-    const int n_my = seq < n_tiles ? static_cast<int>((n_tiles - seq + NSEQ - 1) / NSEQ) : 0;   // tiles seq, seq + NSEQ, ...
-    if (n_my == 0) return;
-    auto tile_of = [&](int k) { return static_cast<int64_t>(seq) + static_cast<int64_t>(k) * NSEQ; };
-    const int n_phases = (n_my + 1) * NCH;                               // the last tile leaves during one more (empty) tile's worth of phases
-
-    role_priority(wave >= 4);
-    if (wave >= 4) {
-        // ---------------- service waves: thread -> hyperedge row, 16 columns of a 128-column part
-        const int st = tid - 256, row = st >> 3, cq = st & 7;
-        const int64_t last_pos = n_edges * 3 - 1;
-        const uint32_t ldh = static_cast<uint32_t>(ld_h), ldp = static_cast<uint32_t>(ld_p);
-        auto fetch_id = [&](int k) {                                     // (st < 96; the tile exists) - scalar tile base, one vector min
-            const int64_t first = tile_of(k) * (3 * TE);
-            const int lim = static_cast<int>(std::min<int64_t>(last_pos - first, 3 * TE - 1));
-            return (i3 + first)[std::min(st, lim)];
-        };
-        auto load_members = [&](int k, int cp, v4f (&hm)[3][4]) {        // member values of tile k, column part cp
-            const int* idk = ids[k & 3] + row * 3;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const float* hp = row_at(h, idk[m], ldh) + 128 * cp + 16 * cq;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) hm[m][x] = *reinterpret_cast<const v4f*>(hp + 4 * x);
-            }
-        };
-        auto load_first_order = [&](int k, v4f (&pr)[3][4]) {
-            const int* idk = ids[k & 3] + row * 3;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const float* pp = row_at(p, idk[m], ldp) + 128 * half + 16 * cq;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) pr[m][x] = *reinterpret_cast<const v4f*>(pp + 4 * x);
-            }
-        };
-        // products of block b from a member set -> the 16 columns' three planes into image `buf` (two 16-byte chunks per plane)
-        auto split_chunk = [&](const v4f (&hm)[3][4], int b, int buf) {
-            unsigned char* zrow = &zplanes[buf][0][row][0];
-#pragma unroll
-            for (int x2 = 0; x2 < 2; ++x2) {
-                v4f z[2];
-#pragma unroll
-                for (int y = 0; y < 2; ++y) {
-                    const v4f u = hm[0][2 * x2 + y], q = hm[1][2 * x2 + y], it = hm[2][2 * x2 + y];
-                    z[y] = b == 0 ? u * q : b == 1 ? q * it : b == 2 ? it * u : (u * q) * it;
-                }
-                const Planes pl = split8(z[0], z[1]);
-#pragma unroll
-                for (int pp = 0; pp < 3; ++pp) *reinterpret_cast<v4u*>(zrow + pp * ZPL + (((2 * cq + x2) ^ (row & 15)) << 4)) = pl.p[pp];
-            }
-        };
-        if (st < 3 * TE) {
-            ids[0][st] = fetch_id(0);
-            if (n_my > 1) ids[1][st] = fetch_id(1);
-            if (n_my > 2) ids[2][st] = fetch_id(2);
-        }
-        __syncthreads();
-        v4f ms0[3][4], ms1[3][4], pr[3][4];                              // member sets: set s = k JH + cp lives in ms<s & 1>; first-order rows of the leaving tile
-        load_members(0, 0, ms0);
-        split_chunk(ms0, 0, 0);
-        __syncthreads();
-        int id_carry = 0;
-        // phase g = k NCH + c: image of chunk g + 1; requests at the first phase of a set: the next set; at the first phase of a tile: the
-        // first-order rows of the tile that just finished and the ids two tiles ahead; parts of that tile's store in phases 1 .. 3
-        auto phase = [&](int g, v4f (&cur)[3][4], v4f (&nxt)[3][4], bool first_of_set) {
-            const int k = g / NCH, c = g % NCH;
-            if (c == 0) {
-                if (k >= 1 && k + 2 < n_my && st < 3 * TE) ids[(k + 2) & 3][st] = id_carry;
-                if (k + 3 < n_my && st < 3 * TE) id_carry = fetch_id(k + 3);
-                if (k >= 1) load_first_order(k - 1, pr);
-            }
-            if (first_of_set) {                                          // the set after this one: tile / column part of chunk g + 4
-                const int g4 = g + 4;
-                if (g4 / NCH < n_my) load_members(g4 / NCH, (g4 % NCH) >> 2, nxt);
-            }
-            {                                                            // chunk g + 1 belongs to set (g + 1) / 4: `cur`, or `nxt` at the set's last phase
-                const int g1 = g + 1;
-                if (g1 / NCH < n_my) {
-                    if ((g1 & 3) == 0) split_chunk(nxt, 0, g1 & 1);
-                    else split_chunk(cur, g1 & 3, g1 & 1);
-                }
-            }
-            if (first_of_set) {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) asm volatile("" : "+v"(nxt[m][0]), "+v"(nxt[m][1]), "+v"(nxt[m][2]), "+v"(nxt[m][3]));
-            }
-            if (c == 0 && k >= 1) {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) asm volatile("" : "+v"(pr[m][0]), "+v"(pr[m][1]), "+v"(pr[m][2]), "+v"(pr[m][3]));
-            }
-            if (k >= 1 && c >= 1 && c <= 3) {                            // store of tile k - 1: its 16 columns in parts of 8, 4, 4
-                const int64_t e = tile_of(k - 1) * TE + row;
-                const int x0 = c == 1 ? 0 : c, x1 = c == 1 ? 2 : c + 1;
-                if (e < n_edges) {
-                    for (int x = x0; x < x1; ++x) {
-                        const v4f sum = *reinterpret_cast<const v4f*>(&oimg[row][16 * cq + 4 * x]);
-                        const v4f first = (pr[0][x] + pr[1][x]) + pr[2][x];
-                        store_stream4(out + e * ld_out + 128 * half + 16 * cq + 4 * x, sum + first);
-                    }
-                }
-            }
-            __syncthreads();
-        };
-        // a set spans four phases; sets alternate between ms0 and ms1
-        for (int g = 0; g < n_phases; g += 8) {
-#pragma unroll
-            for (int u8 = 0; u8 < 8; ++u8) {
-                if (g + u8 >= n_phases) break;
-                if (u8 < 4) phase(g + u8, ms0, ms1, u8 == 0);
-                else phase(g + u8, ms1, ms0, u8 == 4);
-            }
-        }
-        return;
-    }
-
-    // ---------------- matrix waves: wave m = output columns 32 m .. 32 m + 31 of the half, both 16-row tiles
-    const v4u* wbase = wck + static_cast<int64_t>((half * 4 + wave) * NCH) * 24 * kWave + lane;
-    auto load_w = [&](int c, v8s (&wr)[2][4][3]) {
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wr[jt][kb][pl] = __builtin_bit_cast(v8s, wbase[(static_cast<int64_t>(c) * 24 + (jt * 4 + kb) * 3 + pl) * kWave]);
-    };
-    v8s w0[2][4][3], w1[2][4][3];                                        // weight fragments of chunk g live in w<g & 1>
-    load_w(0, w0);
-    __syncthreads();
-    __syncthreads();
-    const int arow = lane & 15, kq = lane >> 4;
-    v4f acc[2][2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
-    auto mphase = [&](int g, v8s (&wc)[2][4][3], v8s (&wn)[2][4][3]) {
-        const int k = g / NCH, c = g % NCH;
-        if (c == 0 && k >= 1) {                                          // the finished tile leaves through the image
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int jt = 0; jt < 2; ++jt) {
-                    *reinterpret_cast<v4f*>(&oimg[16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
-                    acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
-                }
-        }
-        if (k < n_my) {
-            if (g + 1 < n_my * NCH) load_w((g + 1) % NCH, wn);
-            const unsigned char* zp = &zplanes[g & 1][0][0][0];
-            auto fragment = [&](int step, v8s (&zf)[3]) {                // step = (kb, rt)
-                const int kb = step >> 1, rt = step & 1;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) zf[pl] = *reinterpret_cast<const v8s*>(zp + pl * ZPL + (16 * rt + arow) * 256 + (((4 * kb + kq) ^ arow) << 4));
-            };
-            v8s zf[3], zn[3];
-            fragment(0, zf);
-#pragma unroll
-            for (int step = 0; step < 8; ++step) {
-                const int kb = step >> 1, rt = step & 1;
-                if (step + 1 < 8) fragment(step + 1, zn);
-#pragma unroll
-                for (int term = 0; term < 6; ++term)
-#pragma unroll
-                    for (int jt = 0; jt < 2; ++jt)
-                        acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[jt][kb][kTermB[term]], zf[kTermA[term]], acc[rt][jt], 0, 0, 0);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) zf[pl] = zn[pl];
-            }
-        }
-        __syncthreads();
-    };
-    for (int g = 0; g < n_phases; g += 2) {
-        mphase(g, w0, w1);
-        if (g + 1 < n_phases) mphase(g + 1, w1, w0);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradients dW_b[j][c] = sum_e dout[e][j] z_b[e][c].  The contraction runs over the hyperedges, both operands are streams:
@@ -2782,10 +2334,8 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                     }
                 }
             }
-            if (!abl::late_delivery) {
-                if (DOCT == 1) asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
-                else asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.d[2 * DOCT - 2]), "+v"(fill.d[2 * DOCT - 1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
-            }
+            if (DOCT == 1) asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
+            else asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.d[2 * DOCT - 2]), "+v"(fill.d[2 * DOCT - 1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
             if (DX) {                                                    // (after the delivery of the requested rows: the counter is in order)
                 const int arow = lane & 15, kq = lane >> 4;
                 const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
@@ -2833,10 +2383,6 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 // floats of workspace for the weight planes of one direction: laid out for four blocks at either order
 int64_t split_plane_floats(int dim, int order) { return (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) ? (3LL * 4 * dim * dim) / 2 : 0; }
 
-static bool fwd_kpass_enabled() {                                        // IHG_FWD_KPASS=0: the column-half forward at d = 128, the chunked one at d = 256 (A/B, tests)
-    const char* v = std::getenv("IHG_FWD_KPASS");
-    return v == nullptr || std::strcmp(v, "0") != 0;
-}
 
 bool split_arith_enabled() {                                             // read at every call: tests and the bench switch it in-process
     const char* v = std::getenv("IHG_INTERACT_ARITH");
@@ -2931,17 +2477,7 @@ void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w,
     }
 }
 
-// node-level forward of the interactive layer: see node_interact_fwd_q_kernel (d = 64 / 128 / 256) and node_interact_fwd_kernel (d = 128, IHG_NODE_FWD_Q=0)
-static bool node_fwd_q_enabled() {                                       // d = 128 only: IHG_NODE_FWD_Q=1 selects the 64-column geometry there too (A/B, tests; C3: 592 against 543 us)
-    const char* v = std::getenv("IHG_NODE_FWD_Q");
-    return v != nullptr && std::strcmp(v, "1") == 0;
-}
-
-static bool node_fwd_grouped_enabled() {                                 // d = 128: IHG_NODE_FWD_GROUPED=0 keeps the four launches that read-modify-write `out` (A/B, tests)
-    const char* v = std::getenv("IHG_NODE_FWD_GROUPED");
-    return v == nullptr || std::strcmp(v, "0") != 0;
-}
-
+// node-level forward of the interactive layer: node_interact_fwd_grouped_kernel (d = 128), node_interact_fwd_q_kernel (d = 64 / 256)
 static int64_t node_fwd_q_v4(int dim) {                                  // v4u of the q kernel's planes
     const int bpp = 512 / dim, n_pass = (7 + bpp - 1) / bpp, parts = dim / 64;
     return 3LL * n_pass * parts * 4 * 16 * 3 * kWave;
@@ -2972,7 +2508,7 @@ static RowTiles row_tiles(const int64_t* type_begin, int rows_per_tile) {
 void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* deg, const float* scale, const float* bias,
                            const float* w, int64_t ld_w, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s) {
     v4u* wnp = static_cast<v4u*>(planes);
-    if (dim == 128 && !node_fwd_q_enabled()) {
+    if (dim == 128) {
         // the planes (2 fp16 per weight) are followed by the weight rows' scales and their inverses ([3][128] floats each)
         float* wsc = reinterpret_cast<float*>(wnp + 3LL * 4 * kNodePassV4);
         float* winv = wsc + 3 * 128;
@@ -2980,7 +2516,7 @@ void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, con
         hipLaunchKernelGGL(pack_planes_node_fwd_kernel, dim3((3 * 4 * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, order, wsc, wnp);
         const RowTiles plan = row_tiles(type_begin, 32);
         if (plan.tile_prefix[3] == 0) return;
-        if (node_fwd_grouped_enabled()) {                                // one launch, `out` written once (IHG_NODE_FWD_GROUPED=0: the four launches, A/B and tests)
+        {
             NodeGroups groups;
             groups.tiles = plan;
             int acc = 0;
@@ -2994,17 +2530,6 @@ void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, con
             else hipLaunchKernelGGL(node_interact_fwd_grouped_kernel<2>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, groups, out, ld_out);
             return;
         }
-        const int grid = std::min(plan.tile_prefix[3], 256);
-#define IHG_NODE_PASS(KIND, ACC, FINAL, PASS, BLK)                                                                                                          \
-    hipLaunchKernelGGL((node_interact_fwd_kernel<KIND, ACC, FINAL>), dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums + (BLK) * 128, ld_s, deg, scale, bias, \
-                       wnp + (PASS) * kNodePassV4, winv, plan, out, ld_out)
-        IHG_NODE_PASS(2, false, false, 0, 0);
-        IHG_NODE_PASS(0, true, false, 1, 0);
-        IHG_NODE_PASS(0, true, false, 2, 1);
-        if (order == 3) IHG_NODE_PASS(0, true, true, 3, 2);
-        else IHG_NODE_PASS(1, true, true, 3, 2);
-#undef IHG_NODE_PASS
-        return;
     }
     const int items = static_cast<int>(node_fwd_q_v4(dim) / 3);
     hipLaunchKernelGGL(pack_planes_node_fwd_q_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, order, wnp);
@@ -3016,9 +2541,6 @@ void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, con
     hipLaunchKernelGGL((node_interact_fwd_q_kernel<D, PASS, ACC, FINAL>), dim3(n_ranges * parts), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, plan, out, ld_out)
     if (dim == 64) {
         IHG_NODE_Q(64, 0, false, true);
-    } else if (dim == 128) {
-        IHG_NODE_Q(128, 0, false, false);
-        IHG_NODE_Q(128, 1, true, true);
     } else {
         IHG_NODE_Q(256, 0, false, false);
         IHG_NODE_Q(256, 1, true, false);
@@ -3096,29 +2618,22 @@ int launch_weight_split(int dim, int order, const float* h, int64_t ld_h, const 
     return kSplitRanges;                                                 // slabs written (every range writes one, empty ranges zeros)
 }
 
-// orders 2 and 3 at d = 64 / 128 / 256 (d = 256, order 2: the pass kernel only - the chunked form is written for four blocks)
+// orders 2 and 3 at d = 64 / 128 / 256
 bool split_fwd_ok(int dim, int order, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h) {
-    return split_arith_enabled() && ((order == 3 && (dim == 64 || dim == 128 || dim == 256)) || (order == 2 && (dim == 64 || dim == 128 || (dim == 256 && fwd_kpass_enabled())))) && p != nullptr &&
+    return split_arith_enabled() && ((order == 3 && (dim == 64 || dim == 128 || dim == 256)) || (order == 2 && (dim == 64 || dim == 128 || dim == 256))) && p != nullptr &&
            ld_ok(ld_p) && ld_out % 4 == 0 && aligned16(p) && aligned16(out) && ld_ok(ld_h);
 }
 
 void launch_fwd_split(int dim, int order, const float* h, int64_t ld_h, const float* p, int64_t ld_p, const int32_t* i3, const float* w, int64_t ld_w, void* planes,
                       float* out, int64_t ld_out, int64_t n_edges, hipStream_t s) {
     v4u* wsp = static_cast<v4u*>(planes);
-    // d = 256: chunked (the eight-part column split of the other form would repeat the product work eight times); d = 64 / 128: weights
-    // resident.  At d = 128 the chunked form measured 2,430 us against 2,000: with 32-hyperedge tiles its weight stream (393 KB per tile)
-    // alone fills the CU's L2 port for 0.8 ms.
-    if ((dim == 128 || dim == 256) && fwd_kpass_enabled()) {
+    // d = 128 / 256: passes over the contraction index, every product formed once (the column-half kernel formed them twice; a chunked form that streamed the
+    // weight planes at d = 256 filled the CU's L2 port: both removed); d = 64: one workgroup holds the whole weight block
+    if (dim == 128 || dim == 256) {
         const int passes = dim == 128 ? 2 : 4, halves = dim / 128;
         hipLaunchKernelGGL(pack_planes_fwd_kpass_kernel, dim3((passes * halves * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w,
                            dim, order == 3 ? 4 : 3, wsp);
-        // IHG_FWD_CHUNK = hyperedges per chunk (default 0: the whole list): the passes can run chunk by chunk, so that a pass reads what the
-        // previous one wrote (and gathers the same member rows again) while it is still in the Infinity Cache.  Measured at C3 (us, both passes):
-        // one chunk 1,839; 786 k hyperedges 1,836; 393 k 1,861; 197 k 1,954; 98 k 2,046 - no gain, the short launches cost more than the cache gives.
-        int64_t chunk = 0;
-        if (const char* v = std::getenv("IHG_FWD_CHUNK")) chunk = std::atoll(v);
-        if (chunk <= 0) chunk = n_edges;
-        chunk = (chunk + 8191) / 8192 * 8192;                            // whole tiles for every workgroup
+        const int64_t chunk = n_edges;
 #define IHG_KPASS(D, NB, B0, ACC, PASS) \
     hipLaunchKernelGGL((interact_fwd_split_kpass_kernel<D, NB, B0, ACC>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3 + 3 * e0, wsp + (PASS) * halves * kKpPassV4, \
                        out + e0 * ld_out, ld_out, std::min<int64_t>(chunk, n_edges - e0))
@@ -3137,7 +2652,7 @@ void launch_fwd_split(int dim, int order, const float* h, int64_t ld_h, const fl
 #undef IHG_KPASS
         return;
     }
-    if (dim != 256) {
+    {
         const int items = (dim / 64) * 4 * 4 * (dim / 32) * kWave;
         hipLaunchKernelGGL(pack_planes_fwd_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, order == 3 ? 4 : 3, wsp);
 #define IHG_FWD(D)                                                                                                                                              \
@@ -3145,13 +2660,9 @@ void launch_fwd_split(int dim, int order, const float* h, int64_t ld_h, const fl
         if (order == 3) hipLaunchKernelGGL((interact_fwd_split_ws_kernel<D, 4>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges); \
         else hipLaunchKernelGGL((interact_fwd_split_ws_kernel<D, 3>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);           \
     }
-        if (dim == 64) IHG_FWD(64) else IHG_FWD(128)
+        IHG_FWD(64)
 #undef IHG_FWD
-        return;
     }
-    const int items = (dim / 128) * 4 * (4 * dim / 128) * 2 * 4 * kWave;
-    hipLaunchKernelGGL(pack_planes_fwd_chunk_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, wsp);
-    hipLaunchKernelGGL(interact_fwd_split_chunk_kernel<256>, dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, p, ld_p, i3, wsp, out, ld_out, n_edges);
 }
 
 bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x) {

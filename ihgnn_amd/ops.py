@@ -608,10 +608,9 @@ def node_linear(x, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, t
 # the [E, 3, d] member-gradient buffer of the interactive backward is produced in hyperedge chunks beyond this many bytes
 MEMBER_BUFFER_LIMIT_BYTES = 48 << 30
 import os as _os
-# use ihg_interact_bwd_user_reduced (user slot summed on chip, [E, 2, d] member buffer) where the library offers it; IHG_USER_REDUCED=0
-# keeps the [E, 3, d] form (C3: the same step time with the bf16-split kernels - the scan costs their service waves what K7 saves - and
-# 1.1 GB less written and read per step; -0.05 ms with the fp32-MFMA kernels).  Tests compare the two forms.
-USER_REDUCED_BACKWARD = _os.environ.get('IHG_USER_REDUCED', '1') != '0'
+# use ihg_interact_bwd_user_reduced (user slot summed on chip, [E, 2, d] member buffer) where the library offers it (tests set this attribute to compare with the
+# [E, 3, d] form, which every shape without such a kernel runs anyway)
+USER_REDUCED_BACKWARD = True
 # the last layer of a training step is told which rows of its output are read (node_two_hop's cotangent_rows): its backward pulls only those
 SPARSE_LAST_COTANGENT = _os.environ.get('IHG_SPARSE_LAST_COTANGENT', '1') != '0'
 CHECK_SPARSE_COTANGENT = _os.environ.get('IHG_CHECK_SPARSE_COTANGENT', '0') == '1'
@@ -620,8 +619,8 @@ CHECK_SPARSE_COTANGENT = _os.environ.get('IHG_CHECK_SPARSE_COTANGENT', '0') == '
 NODE_LEVEL_FORWARD = _os.environ.get('IHG_NODE_LEVEL_FORWARD', '1') != '0'
 # ... and the product blocks' weight gradients from node-level data (ihg_node_interact_bwd_weight) after such a forward; IHG_NODE_LEVEL_WEIGHT=0: the hyperedge kernel
 NODE_LEVEL_WEIGHT = _os.environ.get('IHG_NODE_LEVEL_WEIGHT', '1') != '0'
-# ... and then the first-order gradient d P = H H^T (scale * dy) by the two-hop operator instead of a scatter of stored [E, d] cotangents (IHG_FIRST_ORDER_TWO_HOP=1; measured at C3: 8.81 against 8.74 ms per step for store + scatter, the default)
-FIRST_ORDER_TWO_HOP = _os.environ.get('IHG_FIRST_ORDER_TWO_HOP', '0') != '0'
+# the first-order gradient d P = H H^T (scale * dy): a scatter of the stored [E, d] cotangents - or, for tables beyond this many bytes, the two-hop operator on dy
+# (at C3 the scatter wins, 8.74 against 8.81 ms per step; at C5 the 51 GB table's scatter reads HBM at random and the two-hop form wins, 22 against 32 ms)
 FIRST_ORDER_TWO_HOP_BYTES = int(_os.environ.get('IHG_FIRST_ORDER_TWO_HOP_BYTES', 8 << 30))     # where the member-gradient kernel does not form the hyperedges' cotangents itself: [E, d] tables larger than this take the two-hop form
 
 
@@ -636,8 +635,6 @@ def _node_level_forward_ok(h: Tensor, w: Tensor, bias: Optional[Tensor], out: Op
 NODE_TABLES = _os.environ.get('IHG_NODE_TABLES', '1') != '0'
 
 
-# the interactive layer as ONE autograd node (interact_layer); IHG_LAYER0_ONE_NODE=0: first_order and interact_to_nodes as two nodes (A/B)
-LAYER0_ONE_NODE = _os.environ.get('IHG_LAYER0_ONE_NODE', '1') != '0'
 
 
 def _zero_isolated_users(dh: Tensor, layout: IncidenceLayout) -> None:
@@ -858,8 +855,8 @@ class _InteractLayer(torch.autograd.Function):
             csr_qi, qi_rows = layout.member_csr_qi()
             # with the weight gradients taken at node level nobody but the first-order scatter would read the hyperedges' cotangents: that scatter is
             # the two-hop operator applied to the node-level cotangent, and the [E, d] rows are not stored at all
-            keep_dout = not (node_weight and FIRST_ORDER_TWO_HOP)
-            dout = torch.empty(n_edges, dim, dtype=torch.float32, device=h.device) if keep_dout else None
+            keep_dout = True
+            dout = torch.empty(n_edges, dim, dtype=torch.float32, device=h.device)
             g2 = torch.empty(n_edges, 2 * dim, dtype=torch.float32, device=h.device)
             dh = torch.empty(layout.node_count, dim, dtype=torch.float32, device=h.device)
             _zero_isolated_users(dh, layout)

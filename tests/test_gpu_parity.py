@@ -513,12 +513,10 @@ def test_interact_fp32_mfma_kernels_stay_covered(which, monkeypatch):
 
 
 @pytest.mark.parametrize('dim,order', [(128, 3), (128, 2), (256, 3), (256, 2)])
-def test_forward_in_two_passes_equals_the_column_half_kernel(dim, order, monkeypatch):
-    """d = 128: the default forward runs in two passes over the contraction index (blocks uq, qi + first-order rows, then iu (, uqi) added onto
-    `out`; every product formed once); d = 256: one pass per block (four at order 3, three at order 2), column halves, 16-hyperedge tiles.
-    IHG_FWD_KPASS=0 selects the column-half kernel (d = 128) / the chunked kernel (d = 256, order 3) / the fp32 strip kernel (d = 256, order 2).  Both against the oracle - more tiles than workgroups with a partial
-    last tile, fewer tiles than workgroups, one hyperedge, a strided `out` - and against each other (same products, the block sums
-    associated differently)."""
+def test_hyperedge_forward_in_passes_over_the_contraction_index(dim, order, monkeypatch):
+    """The hyperedge-form forward (what `rows=` subsets and IHG_NODE_LEVEL_FORWARD=0 run) - d = 128: two passes over the contraction index (blocks uq, qi + first-order
+    rows, then iu (, uqi) added onto `out`; every product formed once); d = 256: one pass per block (four at order 3, three at order 2), column halves, 16-hyperedge tiles -
+    against the oracle: more tiles than workgroups with a partial last tile, fewer tiles than workgroups, one hyperedge, a strided `out`."""
     from ihgnn_amd import _lib, ops
     from oracle import ihgnn_ref as ref
     k = 6 if order == 2 else 7
@@ -531,21 +529,10 @@ def test_forward_in_two_passes_equals_the_column_half_kernel(dim, order, monkeyp
         wz = torch.cat([torch.zeros(dim, 3 * dim), w[:, 3 * dim:]], 1)
         i3 = torch.from_numpy(lay.i3_host.astype(np.int64))
         want = ref.feature_interactor(h, i3, wz, torch.zeros(dim), order) + (p[i3[:, 0]] + p[i3[:, 1]]) + p[i3[:, 2]]
-        got = {}
-        for mode in ('1', '0'):
-            monkeypatch.setenv('IHG_FWD_KPASS', mode)
-            with torch.no_grad():
-                got[mode] = ops.interact(h.to(dev()), p.to(dev()), w.to(dev()), lay, order)
-            assert rel(got[mode], want) <= RTOL, (mode, edges)
-        assert rel(got['1'], got['0']) <= RTOL_SUM
-        if edges > 8192:                                                  # the passes chunk by chunk of the hyperedge list (IHG_FWD_CHUNK): the same numbers
-            monkeypatch.setenv('IHG_FWD_KPASS', '1')
-            monkeypatch.setenv('IHG_FWD_CHUNK', '8192')
-            with torch.no_grad():
-                assert torch.equal(ops.interact(h.to(dev()), p.to(dev()), w.to(dev()), lay, order), got['1'])
-            monkeypatch.delenv('IHG_FWD_CHUNK')
+        with torch.no_grad():
+            got = {'1': ops.interact(h.to(dev()), p.to(dev()), w.to(dev()), lay, order)}
+        assert rel(got['1'], want) <= RTOL, edges
         # a column slice as destination (row stride 2 d): the raw entry point with ld_out = 2 d
-        monkeypatch.setenv('IHG_FWD_KPASS', '1')
         lib = _lib.load()
         wide = torch.full((lay.edge_count, 2 * dim), 7.0, device=dev())
         hd, pd, wd = h.to(dev()), p.to(dev()), w.to(dev())
@@ -583,9 +570,9 @@ def test_pair_sums_over_the_other_members_of_a_nodes_hyperedges(dim):
         assert torch.equal(wide[:, :3 * dim], got) and bool((wide[:, 3 * dim:] == 7.0).all())
 
 
-@pytest.mark.parametrize('order,dim,passes', [(3, 128, 'q'), (2, 128, 'q'), (3, 128, 'four'), (2, 128, 'four'), (3, 64, 'q'), (2, 64, 'q'), (3, 256, 'q'), (2, 256, 'q')])
-def test_interactive_layer_without_hyperedge_rows(order, dim, passes, monkeypatch):
-    """d = 64 / 128 / 256 (`passes`: the 64-column / 512-value pass geometry, or at d = 128 the four passes of 256 values - the default there, IHG_NODE_FWD_Q=1 selects the other): the forward of the interactive layer in its node-level form (pair sums + a node-level contraction with the typed weight
+@pytest.mark.parametrize('order,dim', [(3, 128), (2, 128), (3, 64), (2, 64), (3, 256), (2, 256)])
+def test_interactive_layer_without_hyperedge_rows(order, dim, monkeypatch):
+    """d = 64 / 128 / 256 (d = 128: four passes over the contraction index in one launch, two fp16 terms per operand; d = 64 / 256: the 64-column / 512-value pass geometry): the forward of the interactive layer in its node-level form (pair sums + a node-level contraction with the typed weight
     blocks: no [E, d] tensor) against the oracle's FeatureInteractor + segment sum in float64 and against the hyperedge form
     (IHG_NODE_LEVEL_FORWARD=0) - with and without bias / output scale, more row tiles than workgroups, fewer, split rows, isolated nodes of
     every type, a strided destination; the gradients of h, w and the bias against float64 autograd of the oracle, with the product blocks' weight
@@ -593,7 +580,6 @@ def test_interactive_layer_without_hyperedge_rows(order, dim, passes, monkeypatc
     from ihgnn_amd import ops
     from oracle import ihgnn_ref as ref
     k = 7 if order == 3 else 6
-    monkeypatch.setenv('IHG_NODE_FWD_Q', '0' if passes == 'four' else '1')
     for edges, (U, Q, I) in ((1, (5, 3, 4)), (33, (40, 7, 50)), (300 * 32 + 5, (301, 17, 211)), (70437, (9001, 170, 4103))):
         w_, lay = make_layout(U, Q, I, edges, seed=edges + order, edge_order='user')
         gen = torch.Generator().manual_seed(edges)
