@@ -143,26 +143,31 @@ __device__ constexpr int kTermB2[3] = {1, 0, 0};
 __device__ constexpr int kTermA[6] = {0, 2, 1, 0, 1, 0};
 __device__ constexpr int kTermB[6] = {2, 0, 1, 1, 0, 0};
 
-// planes of the member-gradient contraction dz_b[e][c] = sum_j dout[e][j] W[j][(3+b)d + c]   (k runs along j):
-// wsp[g][b][kb][ct][plane][lane][8] (g = 32-column group, d / 32 of them; kb < d / 32; ct < 2): element i = plane of
-// W[32 kb + 8 (lane>>4) + i][(3+b) d + 32 g + 16 ct + (lane&15)]
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(const float* __restrict__ w, int64_t ld_w, int d, int nblk, v4u* __restrict__ wsp) {
+// planes of the member-gradient contraction dz_b[e][c] = sum_j dout[e][j] W[j][(3+b)d + c]   (k runs along j), two fp16 terms per weight:
+// wsp[g][b][kb][ct][plane < 2][lane][8 x fp16] (g = 32-column group, d / 32 of them; kb < d / 32; ct < 2): element i = plane of
+// wsc[b][c] W[32 kb + 8 (lane>>4) + i][(3+b) d + c],  c = 32 g + 16 ct + (lane&15);  wsc[b][c] = scale_up_for(max_j |W[j][(3+b)d + c]|)
+// (dense_weight_scales_kernel over the four blocks as "types", transpose = 1)
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(const float* __restrict__ w, int64_t ld_w, int d, int nblk, const float* __restrict__ wsc,
+                                                                            v4u* __restrict__ wsp) {
     const int kbs = d / 32, groups = d / 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= groups * 4 * kbs * 2 * kWave) return;
     const int lane = idx & 63, ct = (idx >> 6) & 1, kb = (idx >> 7) % kbs, b = ((idx >> 7) / kbs) & 3, g = (idx >> 7) / (kbs * 4);
-    const float* src = w + static_cast<int64_t>(32 * kb + 8 * (lane >> 4)) * ld_w + (3 + b) * d + 32 * g + 16 * ct + (lane & 15);
-    v4f x0 = v4f{0.f, 0.f, 0.f, 0.f}, x1 = x0;                            // (order 2 has three blocks: the fourth slot stays zero and is never read)
+    const int c = 32 * g + 16 * ct + (lane & 15);
+    const float* src = w + static_cast<int64_t>(32 * kb + 8 * (lane >> 4)) * ld_w + (3 + b) * d + c;
+    v4u hi = v4u{0u, 0u, 0u, 0u}, lo = hi;                               // (order 2 has three blocks: the fourth slot stays zero and is never read)
     if (b < nblk) {
+        const float sc = wsc[b * d + c];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            x0[i] = src[i * ld_w];
-            x1[i] = src[(4 + i) * ld_w];
+            unsigned hh, ll;
+            split_pair_h2(src[(2 * i) * ld_w] * sc, src[(2 * i + 1) * ld_w] * sc, hh, ll);
+            hi[i] = hh;
+            lo[i] = ll;
         }
     }
-    const Planes pl = split8(x0, x1);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) wsp[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
+    wsp[(static_cast<int64_t>(idx >> 6) * 2 + 0) * kWave + lane] = hi;
+    wsp[(static_cast<int64_t>(idx >> 6) * 2 + 1) * kWave + lane] = lo;
 }
 
 // Member gradients dz_b = dout W_b, then the product rule.  A workgroup owns HALF of the columns (its weight planes: 192 KB) and its eight
@@ -198,7 +203,8 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
 // issue-bound and leaves the memory pipes idle.
 template <int D, bool UR, int NBLK, bool GATHER = false>
 __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
-                                                                                      const v4u* __restrict__ wsp, const float* __restrict__ dout, int64_t ld_dout,
+                                                                                      const v4u* __restrict__ wsp, const float* __restrict__ winv,
+                                                                                      const float* __restrict__ dout, int64_t ld_dout,
                                                                                       float* __restrict__ g_out, int64_t n_edges, float* __restrict__ dh_user,
                                                                                       int64_t ld_dh, float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user,
                                                                                       const float* __restrict__ dy_scale = nullptr,
@@ -209,7 +215,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     constexpr int SWZ = RB / 16 - 1 < 15 ? RB / 16 - 1 : 15;            // the row swizzle stays inside a row (D = 64: rows of 8 chunks)
     constexpr int DOCT = D / 64, EX = HC / 32;                          // per service thread: dout octets, 4-column groups of the product rule
     constexpr int DZ = HC + 4, UTS = HC + 4, GS = UR ? 2 : 3;
-    __shared__ __attribute__((aligned(16))) unsigned char planes[2][3][TE][RB];
+    __shared__ __attribute__((aligned(16))) unsigned char planes[2][2][TE][RB];
+    __shared__ float sinv[2][TE];                                        // inverse scales of the rows whose images are in planes[.]
     __shared__ __attribute__((aligned(16))) float dzimg[2][4][TE][DZ];
     __shared__ __attribute__((aligned(16))) float utile[UR ? 2 : 1][UR ? TE : 1][UTS];    // user-slot gradients of a tile, [row][column of the half]
     __shared__ float ucarry[2][UR ? HC : 1];                              // sum so far of the run that is open when tile t begins: [t & 1]
@@ -303,20 +310,35 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             }
         };
         const int swz = row & SWZ;
+        // a row's cotangent goes in scaled by ONE power of two: its eight staging threads (consecutive lanes) agree on its largest magnitude with three shuffles
         auto split_tile = [&](const v4f (&dr)[2 * DOCT], int buf) {
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2 * DOCT; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(dr[j][0]), fabsf(dr[j][1])), fmaxf(fabsf(dr[j][2]), fabsf(dr[j][3]))));
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fmaxf(m, __shfl_xor(m, 4));
+            float inv;
+            const float sc = abl::m_no_split ? 1.f : scale_up_for(m, inv);
 #pragma unroll
             for (int x = 0; x < DOCT; ++x) {
-                Planes pl;
+                v4u hi, lo;
                 if (abl::m_no_split) {
-                    pl.p[0] = __builtin_bit_cast(v4u, dr[2 * x]);
-                    pl.p[1] = __builtin_bit_cast(v4u, dr[2 * x + 1]);
-                    pl.p[2] = pl.p[0];
+                    hi = __builtin_bit_cast(v4u, dr[2 * x]);
+                    lo = __builtin_bit_cast(v4u, dr[2 * x + 1]);
                 } else {
-                    pl = split8(dr[2 * x], dr[2 * x + 1]);
-                }
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<v4u*>(&planes[buf][p][row][((o + 8 * x) ^ swz) << 4]) = pl.p[p];
+                    for (int pr = 0; pr < 4; ++pr) {
+                        unsigned hh, ll;
+                        split_pair_h2(dr[2 * x + (pr >> 1)][2 * (pr & 1)] * sc, dr[2 * x + (pr >> 1)][2 * (pr & 1) + 1] * sc, hh, ll);
+                        hi[pr] = hh;
+                        lo[pr] = ll;
+                    }
+                }
+                *reinterpret_cast<v4u*>(&planes[buf][0][row][((o + 8 * x) ^ swz) << 4]) = hi;
+                *reinterpret_cast<v4u*>(&planes[buf][1][row][((o + 8 * x) ^ swz) << 4]) = lo;
             }
+            if (o == 0) sinv[buf][row] = abl::m_no_split ? 1.f : inv;
         };
         // product rule of tile k - 1 (its contractions in dzimg[(k - 1) & 1], its member values in hm) and the stores
         auto epilogue = [&](int k, const v4f (&hm)[EX][3]) {
@@ -348,92 +370,6 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 }
             }
         };
-        // UR, lane = column of the half (64 lanes, 256-byte stores); a run = the rows of one user, its starts come from one ballot over the
-        // tile's user ids.  A wave issues at most one instruction every four cycles whatever its kind, so what counts here is the number of
-        // instructions - scalar ones included - on the service waves' path through a phase:
-        //   tile t, phase t + 2: service wave w forms the running sums of rows 8 w .. 8 w + 7 (read at the START of the phase; a run start
-        //     resets the sum through a scalar factor: two instructions per row, no branch), leaves the sum before the window's first run
-        //     start and the one after its last in LDS and stores the runs that lie inside the window (a loop over the window's run starts);
-        //   phase t + 3: wave w closes the run that ends at ITS window's first run start: carried sum (when no run started earlier in the
-        //     tile) + the end sums of the windows since + its own start sum, added in that order; wave 3 leaves the new carried sum.
-        // Every wave keeps the open run's user and whether it still is the range's first run.
-        int cur_user = -1, first_user = -1;
-        bool first_run_open = true;                                      // no run has ended yet in this range
-        float* const first_slot = UR ? bnd_val + static_cast<int64_t>(2 * range) * D : nullptr;
-        const int colg = HC * half + lane, win = wave - 4;
-        uint64_t heads_prev = 0;                                         // run starts / user ids / rows of the tile whose windows were summed a phase ago
-        int uid_prev = 0, rows_prev = 0;
-        auto run_target = [&](int t, int r, int uid) {                   // destination of the run that starts at row r of tile t
-            return (t == 0 && r == 0) ? first_slot : dh_user + static_cast<int64_t>(__builtin_amdgcn_readlane(uid, r)) * ld_dh;
-        };
-        auto load_window = [&](int t, float (&v)[8]) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = utile[t & 1][8 * win + i][lane];
-        };
-        auto sum_window = [&](int t, const float (&v)[8]) {              // tile t, 0 <= t < n_my
-            const int* idk = ids[t & 7];
-            const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + t) * TE));
-            const int r = lane < rows ? lane : rows - 1;
-            const int uid = idk[r * 3];
-            const int prev_uid = r == 0 ? cur_user : idk[(r - 1) * 3];
-            const uint64_t m = __ballot(lane < rows && uid != prev_uid);
-            heads_prev = m;
-            uid_prev = uid;
-            rows_prev = rows;
-            const unsigned mw = static_cast<unsigned>(m >> (8 * win)) & 0xffu;
-            float pre[8], sum = 0.f;                                     // (rows past the end hold zeros and start no run)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                sum = sum * ((mw >> i) & 1 ? 0.f : 1.f) + v[i];
-                pre[i] = sum;
-            }
-            utail[t & 1][win][lane] = sum;
-            if (mw != 0) {                                               // (0.85 run starts per window on C3)
-                auto before = [&](int i) {                               // running sum in front of window row i
-                    float x = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) x = i == j + 1 ? pre[j] : x;
-                    return x;
-                };
-                unsigned left = mw;
-                int start = __builtin_ctz(left);
-                uhead[t & 1][win][lane] = before(start);
-                for (left &= left - 1; left != 0; left &= left - 1) {
-                    const int next = __builtin_ctz(left);
-                    run_target(t, 8 * win + start, uid)[colg] = before(next);
-                    start = next;
-                }
-            }
-        };
-        struct Chain {
-            float tail[4], head, carry;
-        };
-        auto load_chain = [&](int t, Chain& c) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) c.tail[w] = utail[t & 1][w][lane];
-            c.head = uhead[t & 1][win][lane];
-            c.carry = ucarry[t & 1][lane];
-        };
-        auto chain_windows = [&](int t, const Chain& c) {                // tile t, a phase after sum_window(t)
-            const unsigned m = static_cast<unsigned>(heads_prev);
-            const unsigned before_me = m & ((1u << (8 * win)) - 1u);     // run starts in earlier windows of the tile
-            const int p = before_me != 0 ? (31 - __builtin_clz(before_me)) >> 3 : -1;            // the last earlier window that has one
-            if (((m >> (8 * win)) & 0xffu) != 0 || win == 3) {
-                float sum = p < 0 ? c.carry : 0.f;
-#pragma unroll
-                for (int w = 0; w < 3; ++w)
-                    if (w < win && w >= p) sum += c.tail[w];
-                if (((m >> (8 * win)) & 0xffu) != 0) {                   // the open run ends at this window's first run start
-                    if (p >= 0) run_target(t, 31 - __builtin_clz(before_me), uid_prev)[colg] = sum + c.head;
-                    else if (cur_user >= 0) (first_run_open ? first_slot : dh_user + static_cast<int64_t>(cur_user) * ld_dh)[colg] = sum + c.head;
-                    sum = 0.f;
-                }
-                if (win == 3) ucarry[(t + 1) & 1][lane] = sum + c.tail[3];
-            }
-            if (t == 0) first_user = __builtin_amdgcn_readlane(uid_prev, 0);
-            if (m != 0) first_run_open = t == 0 && m == 1u;
-            cur_user = __builtin_amdgcn_readlane(uid_prev, rows_prev - 1);
-        };
         if (UR && st < HC) ucarry[0][st] = 0.f;
         if (st < 3 * TE) {
             ids[0][st] = fetch_id(0);
@@ -457,12 +393,6 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         __syncthreads();
         int id_carry = 0;
         auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3]) {
-            float wrows[8];
-            Chain chain;
-            if (UR && !abl::m_no_user_sums) {                            // LDS reads of this phase's run sums, used at its end
-                if (k >= 2 && k - 2 < n_my) load_window(k - 2, wrows);
-                if (k >= 3) load_chain(k - 3, chain);
-            }
             // ids of tile k + 3 (requested in the previous phase) into the ring: a phase ahead of their first readers (the gathered rows of
             // tile k + 3 in the next phase)
             if (k >= 1 && k + 3 < n_my && st < 3 * TE) ids[(k + 3) & 7][st] = id_carry;
@@ -481,10 +411,6 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));
             if (GATHER) combine(k + 2, raw, fill);
             if (k >= 1 && k - 1 < n_my && !abl::m_no_product_rule) epilogue(k, hm_prev);
-            if (UR && !abl::m_no_user_sums) {
-                if (k >= 3) chain_windows(k - 3, chain);                 // (before the next tile's ballot: it compares with the open run's user)
-                if (k >= 2 && k - 2 < n_my) sum_window(k - 2, wrows);
-            }
             __syncthreads();
         };
         int k = 0;
@@ -494,47 +420,131 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             phase(k + 1, dr0, GATHER ? dr0 : dr1, hm1, hm0);
         }
         if (k < n_phases) phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1);
-        if (UR) {
-            // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
-            const bool one_run = first_run_open;
-            if (cur_user >= 0 && wave == 4) {
-                const float run_sum = ucarry[n_my & 1][lane];            // (written before the last barrier)
-                if (one_run) first_slot[colg] = run_sum;
-                else bnd_val[static_cast<int64_t>(2 * range + 1) * D + colg] = run_sum;
-            }
-            if (half == 0 && st == 0) {
-                bnd_user[2 * range] = first_user;
-                bnd_user[2 * range + 1] = (cur_user >= 0 && !one_run) ? cur_user : -1;
-            }
-        }
         return;
     }
 
     // ---------------- matrix waves: wave = product block, the half's four 16-column tiles, both row tiles
     const int blk = wave;
-    v8s wreg[KB][CT][3];
+    const int arow = lane & 15, kq = lane >> 4;
+    v8h wreg[KB][CT][2];
+    v4f wiv[CT];                                                         // inverse scales of this lane's output columns 16 ct + 4 kq ..
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)      // 32-column group of column tile ct: (HC / 32) half + (ct >> 1)
-                wreg[kb][ct][p] = __builtin_bit_cast(v8s, wsp[(static_cast<int64_t>((((HC / 32) * half + (ct >> 1)) * 4 + blk) * (KB * 2) + kb * 2 + (ct & 1)) * 3 + p) * kWave + lane]);
+            for (int p = 0; p < 2; ++p)      // 32-column group of column tile ct: (HC / 32) half + (ct >> 1)
+                wreg[kb][ct][p] = __builtin_bit_cast(v8h, wsp[(static_cast<int64_t>((((HC / 32) * half + (ct >> 1)) * 4 + blk) * (KB * 2) + kb * 2 + (ct & 1)) * 2 + p) * kWave + lane]);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) wiv[ct] = blk < NBLK ? *reinterpret_cast<const v4f*>(winv + blk * D + HC * half + 16 * ct + 4 * kq) : v4f{0.f, 0.f, 0.f, 0.f};
+    // UR, lane = column of the half (64 lanes, 256-byte stores); a run = the rows of one user, its starts come from one ballot over the
+    // tile's user ids.  The sums ride on the MATRIX waves: with two fp16 terms a tile's contraction keeps the matrix pipe busy for a quarter of
+    // a phase, the service waves are the ones on the kernel's critical path (without the sums: - 320 us of 1,900, profiles/r4/01_abl_member_gradients.txt),
+    // and this work is wave-shaped anyway (four 8-row windows, lane = column):
+    //   tile t, phase t + 2: matrix wave w forms the running sums of rows 8 w .. 8 w + 7 (read at the START of the phase; a run start
+    //     resets the sum through a scalar factor: two instructions per row, no branch), leaves the sum before the window's first run
+    //     start and the one after its last in LDS and stores the runs that lie inside the window (a loop over the window's run starts);
+    //   phase t + 3: wave w closes the run that ends at ITS window's first run start: carried sum (when no run started earlier in the
+    //     tile) + the end sums of the windows since + its own start sum, added in that order; wave 3 leaves the new carried sum.
+    // Every wave keeps the open run's user and whether it still is the range's first run.
+    int cur_user = -1, first_user = -1;
+    bool first_run_open = true;                                      // no run has ended yet in this range
+    float* const first_slot = UR ? bnd_val + static_cast<int64_t>(2 * range) * D : nullptr;
+    const int colg = HC * half + lane, win = wave;
+    uint64_t heads_prev = 0;                                         // run starts / user ids / rows of the tile whose windows were summed a phase ago
+    int uid_prev = 0, rows_prev = 0;
+    auto run_target = [&](int t, int r, int uid) {                   // destination of the run that starts at row r of tile t
+        return (t == 0 && r == 0) ? first_slot : dh_user + static_cast<int64_t>(__builtin_amdgcn_readlane(uid, r)) * ld_dh;
+    };
+    auto load_window = [&](int t, float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = utile[t & 1][8 * win + i][lane];
+    };
+    auto sum_window = [&](int t, const float (&v)[8]) {              // tile t, 0 <= t < n_my
+        const int* idk = ids[t & 7];
+        const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + t) * TE));
+        const int r = lane < rows ? lane : rows - 1;
+        const int uid = idk[r * 3];
+        const int prev_uid = r == 0 ? cur_user : idk[(r - 1) * 3];
+        const uint64_t m = __ballot(lane < rows && uid != prev_uid);
+        heads_prev = m;
+        uid_prev = uid;
+        rows_prev = rows;
+        const unsigned mw = static_cast<unsigned>(m >> (8 * win)) & 0xffu;
+        float pre[8], sum = 0.f;                                     // (rows past the end hold zeros and start no run)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sum = sum * ((mw >> i) & 1 ? 0.f : 1.f) + v[i];
+            pre[i] = sum;
+        }
+        utail[t & 1][win][lane] = sum;
+        if (mw != 0) {                                               // (0.85 run starts per window on C3)
+            auto before = [&](int i) {                               // running sum in front of window row i
+                float x = 0.f;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) x = i == j + 1 ? pre[j] : x;
+                return x;
+            };
+            unsigned left = mw;
+            int start = __builtin_ctz(left);
+            uhead[t & 1][win][lane] = before(start);
+            for (left &= left - 1; left != 0; left &= left - 1) {
+                const int next = __builtin_ctz(left);
+                run_target(t, 8 * win + start, uid)[colg] = before(next);
+                start = next;
+            }
+        }
+    };
+    struct Chain {
+        float tail[4], head, carry;
+    };
+    auto load_chain = [&](int t, Chain& c) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) c.tail[w] = utail[t & 1][w][lane];
+        c.head = uhead[t & 1][win][lane];
+        c.carry = ucarry[t & 1][lane];
+    };
+    auto chain_windows = [&](int t, const Chain& c) {                // tile t, a phase after sum_window(t)
+        const unsigned m = static_cast<unsigned>(heads_prev);
+        const unsigned before_me = m & ((1u << (8 * win)) - 1u);     // run starts in earlier windows of the tile
+        const int p = before_me != 0 ? (31 - __builtin_clz(before_me)) >> 3 : -1;            // the last earlier window that has one
+        if (((m >> (8 * win)) & 0xffu) != 0 || win == 3) {
+            float sum = p < 0 ? c.carry : 0.f;
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+                if (w < win && w >= p) sum += c.tail[w];
+            if (((m >> (8 * win)) & 0xffu) != 0) {                   // the open run ends at this window's first run start
+                if (p >= 0) run_target(t, 31 - __builtin_clz(before_me), uid_prev)[colg] = sum + c.head;
+                else if (cur_user >= 0) (first_run_open ? first_slot : dh_user + static_cast<int64_t>(cur_user) * ld_dh)[colg] = sum + c.head;
+                sum = 0.f;
+            }
+            if (win == 3) ucarry[(t + 1) & 1][lane] = sum + c.tail[3];
+        }
+        if (t == 0) first_user = __builtin_amdgcn_readlane(uid_prev, 0);
+        if (m != 0) first_run_open = t == 0 && m == 1u;
+        cur_user = __builtin_amdgcn_readlane(uid_prev, rows_prev - 1);
+    };
     __syncthreads();
     __syncthreads();
-    const int arow = lane & 15, kq = lane >> 4;
     for (int k = 0; k < n_phases; ++k) {
+        float wrows[8];
+        Chain chain;
+        if (UR && !abl::m_no_user_sums) {                                // LDS reads of this phase's run sums, used at its end
+            if (k >= 2 && k - 2 < n_my) load_window(k - 2, wrows);
+            if (k >= 3) load_chain(k - 3, chain);
+        }
         if (k < n_my && blk < NBLK && !abl::m_no_mfma) {
             const unsigned char* pbase = &planes[k & 1][0][0][0];
             // row tile after row tile (one set of CT accumulator tiles live), the fragments of step s + 1 requested in front of the MFMAs of step s
-            auto fragment = [&](int step, v8s (&a)[3]) {
+            auto fragment = [&](int step, v8h (&a)[2]) {
                 const int rt = step / KB, kb = step % KB;
                 const unsigned char* src = pbase + (16 * rt + arow) * RB + (((4 * kb + kq) ^ (arow & SWZ)) << 4);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const v8s*>(src + p * (TE * RB));
+                for (int p = 0; p < 2; ++p) a[p] = *reinterpret_cast<const v8h*>(src + p * (TE * RB));
             };
-            v8s a[3], an[3];
+            v8h a[2], an[2];
             v4f acc[CT];
+            const float iv[2] = {sinv[k & 1][arow], sinv[k & 1][16 + arow]};
             fragment(0, a);
 #pragma unroll
             for (int step = 0; step < 2 * KB; ++step) {
@@ -546,20 +556,37 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 if (step + 1 < 2 * KB) fragment(step + 1, an);
                 IHG_PIN_ORDER();                                         // keep the next step's reads IN FRONT of this step's MFMAs
 #pragma unroll
-                for (int term = 0; term < 6; ++term)
+                for (int term = 0; term < 3; ++term)
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][ct][kTermB[term]], a[kTermA[term]], acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[kb][ct][kTermB2[term]], a[kTermA2[term]], acc[ct], 0, 0, 0);
                 IHG_PIN_ORDER();
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[p] = an[p];
+                for (int p = 0; p < 2; ++p) a[p] = an[p];
                 if (kb == KB - 1) {
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) *reinterpret_cast<v4f*>(&dzimg[k & 1][blk][16 * rt + arow][16 * ct + 4 * kq]) = acc[ct];
+                    for (int ct = 0; ct < CT; ++ct) *reinterpret_cast<v4f*>(&dzimg[k & 1][blk][16 * rt + arow][16 * ct + 4 * kq]) = acc[ct] * (wiv[ct] * iv[rt]);
                 }
             }
         }
+        if (UR && !abl::m_no_user_sums) {
+            if (k >= 3) chain_windows(k - 3, chain);                     // (before the next tile's ballot: it compares with the open run's user)
+            if (k >= 2 && k - 2 < n_my) sum_window(k - 2, wrows);
+        }
         __syncthreads();
+    }
+    if (UR) {
+        // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
+        const bool one_run = first_run_open;
+        if (cur_user >= 0 && wave == 0) {
+            const float run_sum = ucarry[n_my & 1][lane];            // (written before the last barrier)
+            if (one_run) first_slot[colg] = run_sum;
+            else bnd_val[static_cast<int64_t>(2 * range + 1) * D + colg] = run_sum;
+        }
+        if (half == 0 && tid == 0) {
+            bnd_user[2 * range] = first_user;
+            bnd_user[2 * range + 1] = (cur_user >= 0 && !one_run) ? cur_user : -1;
+        }
     }
 }
 
@@ -2402,22 +2429,22 @@ bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t 
 
 namespace {
 template <int D, int NBLK>
-void launch_members_split_t(const float* h, int64_t ld_h, const int32_t* i3, const v4u* wsp, const float* dout, int64_t ld_dout, float* g, int64_t n_edges,
+void launch_members_split_t(const float* h, int64_t ld_h, const int32_t* i3, const v4u* wsp, const float* winv, const float* dout, int64_t ld_dout, float* g, int64_t n_edges,
                             float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user, const float* dy_scale, float* dout_store, int64_t ld_store,
                             hipStream_t s) {
     if constexpr (D == 128 || D == 64) {
         if (dh_user != nullptr && dout_store != nullptr) {              // `dout` is the node-level cotangent: gathered, summed, stored
-            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, true, NBLK, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g,
+            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, true, NBLK, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, winv, dout, ld_dout, g,
                                n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store);
             return;
         }
         if (dh_user != nullptr) {
-            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, true, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
+            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, true, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges,
                                dh_user, ld_dh, bnd_val, bnd_user);
             return;
         }
     }
-    hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, false, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, dout, ld_dout, g, n_edges,
+    hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, false, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges,
                        static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
 }
 }  // namespace
@@ -2428,11 +2455,16 @@ void launch_members_split(int dim, int order, const float* h, int64_t ld_h, cons
     v4u* wsp = static_cast<v4u*>(planes);
     const int nblk = order == 3 ? 4 : 3;
     const int items = (dim / 32) * 4 * (dim / 32) * 2 * kWave;
-    hipLaunchKernelGGL(pack_planes_members_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wsp);
+    // the planes (2 fp16 per weight: 4 d^2 dwords) are followed by the weight columns' scales and their inverses ([4][d] floats each)
+    float* wsc = reinterpret_cast<float*>(wsp) + 4LL * dim * dim;
+    float* winv = wsc + 4 * dim;
+    hipLaunchKernelGGL(dense_weight_scales_kernel, dim3(grid_for_waves(static_cast<int64_t>(nblk) * dim)), dim3(kBlockThreads), 0, s, w + 3 * dim, ld_w, int64_t{dim}, nblk, dim, 1,
+                       wsc, winv);
+    hipLaunchKernelGGL(pack_planes_members_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wsc, wsp);
 #define IHG_MEMBERS(D)                                                                                                                       \
     {                                                                                                                                        \
-        if (nblk == 4) launch_members_split_t<D, 4>(h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store, s); \
-        else launch_members_split_t<D, 3>(h, ld_h, i3, wsp, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store, s);           \
+        if (nblk == 4) launch_members_split_t<D, 4>(h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store, s); \
+        else launch_members_split_t<D, 3>(h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store, s);           \
     }
     if (dim == 256) IHG_MEMBERS(256) else if (dim == 64) IHG_MEMBERS(64) else IHG_MEMBERS(128)
 #undef IHG_MEMBERS

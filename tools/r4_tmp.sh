@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r4
-timeout 1500 python -m pytest tests/test_gpu_parity.py -q -x -k "without_hyperedge_rows or f8_ or full_size_c5 or linear or heaviest" 2>&1 | tail -3
-python bench.py --config C5 --steps 4 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r4/bench_C5_now.json 2>/dev/null; python -c "
-import json; p=json.load(open('gpurun_out/r4/bench_C5_now.json')); print('C5', p['ms_per_step'])"
+timeout 1500 python -m pytest tests/test_gpu_parity.py -q -x -k "member or backward or gradient or training_step or heaviest or split" 2>&1 | tail -5
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r4/bench_C3_members_h2.json 2>gpurun_out/r4/bench_C3_members_h2.err; python -c "
+import json; p=json.load(open('gpurun_out/r4/bench_C3_members_h2.json')); print('C3', p['ms_per_step'], p['roofline'])"
