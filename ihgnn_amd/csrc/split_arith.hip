@@ -1013,19 +1013,20 @@ __device__ __forceinline__ int node_block(int type, int pass, int second) {
 
 // scale of every weight ROW of every node type (= output column j of that type's contraction): wsc[type][j] = scale_up_for(max_k |W_t[j][k]|) over the type's seven blocks,
 // winv[type][j] its inverse.  One wave per (type, j).
-__global__ __launch_bounds__(kBlockThreads) void node_fwd_weight_scales_kernel(const float* __restrict__ w, int64_t ld_w, int order, float* __restrict__ wsc, float* __restrict__ winv) {
+__global__ __launch_bounds__(kBlockThreads) void node_fwd_weight_scales_kernel(const float* __restrict__ w, int64_t ld_w, int d, int order, float* __restrict__ wsc,
+                                                                               float* __restrict__ winv) {
     const int lane = threadIdx.x & 63;
     const int64_t unit = global_wave_id();
-    if (unit >= 3 * 128) return;
-    const int type = static_cast<int>(unit) / 128, j = static_cast<int>(unit) % 128;
+    if (unit >= 3 * d) return;
+    const int type = static_cast<int>(unit) / d, j = static_cast<int>(unit) % d;
     float m = 0.f;
     for (int pass = 0; pass < 4; ++pass)
         for (int second = 0; second < 2; ++second) {
             int b = node_block(type, pass, second);
             if (b == 6 && order != 3) b = -1;
             if (b < 0) continue;
-            const float* src = w + static_cast<int64_t>(j) * ld_w + b * 128;
-            m = fmaxf(m, fmaxf(fabsf(src[lane]), fabsf(src[64 + lane])));
+            const float* src = w + static_cast<int64_t>(j) * ld_w + b * d;
+            for (int c = lane; c < d; c += kWave) m = fmaxf(m, fabsf(src[c]));
         }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -1344,12 +1345,14 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
 }
 
 // ------------------------------------------------------------------------------------------------
-// The node-level forward for d = 64 / 256 (three bf16 terms per operand): a workgroup owns 64 output columns (`part`) and up to 512 values of the
-// contraction index per pass - matrix wave m: 16 columns x 512 values = the 192 weight registers - over tiles of 16 node rows.  The seven
-// source blocks X = [deg h | S_a | h S_a | S_b | h S_b | S_ab | h S_ab] come 512 / d to a pass: d = 64: ONE pass, d = 128: two (x 2 column parts),
-// d = 256: four (x 4 parts; the parts of a tile range are adjacent workgroups on one XCD and share the rows through its L2).  (At d = 128 this geometry
+// The node-level forward for d = 64 / 256 (two fp16 terms per operand, like the grouped kernel): a workgroup owns 64 output columns (`part`) and up to 512 values of
+// the contraction index per pass - matrix wave m: 16 columns x 512 values = 128 weight registers - over tiles of 16 node rows.  The seven
+// source blocks X = [deg h | S_a | h S_a | S_b | h S_b | S_ab | h S_ab] come 512 / d to a pass: d = 64: ONE pass, d = 256: four launches (x 4 parts; the parts of a
+// tile range are adjacent workgroups on one XCD and share the rows through its L2).  (At d = 128 this geometry
 // measured 592 us against 543 for four passes of 256 values - one accumulator tile per matrix wave, twice the split work; d = 128 runs the grouped kernel above.)
-// wnq[type][pass][part][m][kb < 16][plane][lane][8]: element i = plane of W[64 part + 16 m + (lane & 15)][block(type, xb) d + c], where
+// A row's values of a pass go in scaled by ONE power of two (its 16 service threads agree on the largest magnitude with four shuffles), a weight row by one over the
+// type's seven blocks (node_fwd_weight_scales_kernel); the partial sums leave through the two inverses in the service threads' epilogue.
+// wnq[type][pass][part][m][kb < 16][plane < 2][lane][8 x fp16]: element i = plane of wsc[type][j] W[j][block(type, xb) d + c], j = 64 part + 16 m + (lane & 15), where
 //   kk = 32 kb + 8 (lane >> 4) + i,  xb = pass (512 / d) + kk / d,  c = kk % d     (xb > 6, or the uqi block at order 2: zeros)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int node_xblock_weight(int type, int xb) {
@@ -1357,7 +1360,8 @@ __device__ __forceinline__ int node_xblock_weight(int type, int xb) {
     return kBlock[type][xb];
 }
 
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd_q_kernel(const float* __restrict__ w, int64_t ld_w, int d, int order, v4u* __restrict__ wnq) {
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd_q_kernel(const float* __restrict__ w, int64_t ld_w, int d, int order, const float* __restrict__ wsc,
+                                                                               v4u* __restrict__ wnq) {
     const int bpp = 512 / d, n_pass = (7 + bpp - 1) / bpp, parts = d / 64;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 3 * n_pass * parts * 4 * 16 * kWave) return;
@@ -1369,27 +1373,35 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd_q_kernel(c
     const int kk = 32 * kb + 8 * (lane >> 4), xb = pass * bpp + kk / d, c = kk % d;
     int b = xb < 7 ? node_xblock_weight(type, xb) : -1;
     if (b == 6 && order != 3) b = -1;
-    Planes pl;
+    v4u hi = v4u{0u, 0u, 0u, 0u}, lo = hi;
     if (b >= 0) {
-        const float* src = w + static_cast<int64_t>(64 * part + 16 * m + (lane & 15)) * ld_w + static_cast<int64_t>(b) * d + c;
-        pl = split8(v4f{src[0], src[1], src[2], src[3]}, v4f{src[4], src[5], src[6], src[7]});
-    } else {
-        pl = split8(v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f});
-    }
+        const int j = 64 * part + 16 * m + (lane & 15);
+        const float sc = wsc[type * d + j];
+        const float* src = w + static_cast<int64_t>(j) * ld_w + static_cast<int64_t>(b) * d + c;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) wnq[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
+        for (int i = 0; i < 4; ++i) {
+            unsigned hh, ll;
+            split_pair_h2(src[2 * i] * sc, src[2 * i + 1] * sc, hh, ll);
+            hi[i] = hh;
+            lo[i] = ll;
+        }
+    }
+    wnq[(static_cast<int64_t>(idx >> 6) * 2 + 0) * kWave + lane] = hi;
+    wnq[(static_cast<int64_t>(idx >> 6) * 2 + 1) * kWave + lane] = lo;
 }
 
 template <int D, int PASS, bool ACC, bool FINAL>
 __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
                                                                             const float* __restrict__ deg, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                                            const v4u* __restrict__ wnq, RowTiles plan, float* __restrict__ out, int64_t ld_out) {
+                                                                            const v4u* __restrict__ wnq, const float* __restrict__ winv, RowTiles plan,
+                                                                            float* __restrict__ out, int64_t ld_out) {
     constexpr int BPP = 512 / D, XB0 = PASS * BPP, NB = (7 - XB0) < BPP ? (7 - XB0) : BPP, NPASS = (7 + BPP - 1) / BPP, PARTS = D / 64;
     constexpr int TE = 16, KB = NB * D / 32, ZRB = (2 * NB * D + 255) / 256 * 256, ZPL = TE * ZRB, PS = 64 + 4, X = D / 64;
     constexpr bool NEED_A = XB0 <= 2 && XB0 + NB > 1, NEED_B = XB0 <= 4 && XB0 + NB > 3, NEED_AB = XB0 + NB > 5, NEED_DEG = XB0 == 0;
     static_assert(NB >= 1 && KB <= 16, "pass shape");
-    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][2][TE][ZRB];
     __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
+    __shared__ __attribute__((aligned(16))) float swinv[3][64];          // inverse scales of this part's 64 weight rows, per node type
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x;
@@ -1413,6 +1425,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(cons
     if (wave >= 4) {
         // ---------------- service waves: thread -> node row of the tile, source columns 4 o + 64 x .. (x < D / 64), output columns coff + 4 o ..
         const int st = tid - 256, row = st >> 4, o = st & 15;
+        if (st < 3 * 64) swinv[st >> 6][st & 63] = winv[(st >> 6) * D + coff + (st & 63)];
         struct Piece { v4f hv[X], sa[X], sb[X], sab[X]; float d; };
         auto load_piece = [&](int k, Piece& pc) {
             int64_t r_base, r_end;
@@ -1420,6 +1433,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(cons
             const int64_t v = std::min(r_base + row, r_end - 1);
             const float* hp = h + v * ld_h + 4 * o;
             const float* sp = sums + v * ld_s + 4 * o;
+            if (NEED_DEG) pc.d = deg[v];
 #pragma unroll
             for (int x = 0; x < X; ++x) {
                 pc.hv[x] = *reinterpret_cast<const v4f*>(hp + 64 * x);
@@ -1427,8 +1441,9 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(cons
                 if (NEED_B) pc.sb[x] = *reinterpret_cast<const v4f*>(sp + D + 64 * x);
                 if (NEED_AB) pc.sab[x] = *reinterpret_cast<const v4f*>(sp + 2 * D + 64 * x);
             }
-            if (NEED_DEG) pc.d = deg[v];
         };
+        // what the epilogue of a tile adds or multiplies: requested a phase BEFORE its use, in front of that phase's row requests - the memory counter is in order,
+        // a request issued and consumed inside one phase would make the phase wait for every row request in front of it
         struct First { v4f old; float d, sc; };
         auto load_first = [&](int k, First& f) {
             int64_t r_base, r_end;
@@ -1438,60 +1453,78 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(cons
             else f.d = deg[v];
             if (FINAL) f.sc = scale != nullptr ? scale[v] : 1.f;
         };
-        auto split_tile = [&](const Piece& pc, int buf) {
+        const v4f bias4 = (!ACC && bias != nullptr) ? *reinterpret_cast<const v4f*>(bias + coff + 4 * o) : v4f{0.f, 0.f, 0.f, 0.f};
+        auto split_tile = [&](const Piece& pc, int buf, float& inv) {
             typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            v4f z[X][NB];
+            float m = 0.f;
 #pragma unroll
             for (int x = 0; x < X; ++x) {
 #pragma unroll
                 for (int b2 = 0; b2 < NB; ++b2) {
                     const int xb = XB0 + b2;
-                    const v4f z = xb == 0 ? pc.hv[x] * pc.d : xb == 1 ? pc.sa[x] : xb == 2 ? pc.hv[x] * pc.sa[x] : xb == 3 ? pc.sb[x] : xb == 4 ? pc.hv[x] * pc.sb[x]
-                                  : xb == 5 ? pc.sab[x] : pc.hv[x] * pc.sab[x];
-                    unsigned w0[3], w1[3];
-                    split_pair(z[0], z[1], w0);
-                    split_pair(z[2], z[3], w1);
+                    z[x][b2] = xb == 0 ? pc.hv[x] * pc.d : xb == 1 ? pc.sa[x] : xb == 2 ? pc.hv[x] * pc.sa[x] : xb == 3 ? pc.sb[x] : xb == 4 ? pc.hv[x] * pc.sb[x]
+                               : xb == 5 ? pc.sab[x] : pc.hv[x] * pc.sab[x];
+                    m = fmaxf(m, fmaxf(fmaxf(fabsf(z[x][b2][0]), fabsf(z[x][b2][1])), fmaxf(fabsf(z[x][b2][2]), fabsf(z[x][b2][3]))));
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 1));
+            m = fmaxf(m, __shfl_xor(m, 2));
+            m = fmaxf(m, __shfl_xor(m, 4));
+            m = fmaxf(m, __shfl_xor(m, 8));
+            const float sc = scale_up_for(m, inv);
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+#pragma unroll
+                for (int b2 = 0; b2 < NB; ++b2) {
+                    unsigned h0, l0, h1, l1;
+                    split_pair_h2(z[x][b2][0] * sc, z[x][b2][1] * sc, h0, l0);
+                    split_pair_h2(z[x][b2][2] * sc, z[x][b2][3] * sc, h1, l1);
                     // columns D b2 + 64 x + 4 o ..: chunk (D / 8) b2 + 8 x + (o >> 1), half o & 1
                     const int off = row * ZRB + ((((D / 8) * b2 + 8 * x + (o >> 1)) ^ row) << 4) + 8 * (o & 1);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + pl * ZPL + off) = v2u{w0[pl], w1[pl]};
+                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + off) = v2u{h0, h1};
+                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + ZPL + off) = v2u{l0, l1};
                 }
             }
         };
-        auto epilogue = [&](int k, const First& f) {
+        auto epilogue = [&](int k, const First& f, float inv) {
             int64_t r_base, r_end;
-            tile_rows(k, r_base, r_end);
+            const int type = tile_rows(k, r_base, r_end);
             const int64_t v = r_base + row;
-            v4f val = *reinterpret_cast<const v4f*>(&part[k & 1][row][4 * o]);
+            v4f val = *reinterpret_cast<const v4f*>(&part[k & 1][row][4 * o]) * (*reinterpret_cast<const v4f*>(&swinv[type][4 * o]) * inv);
             if (ACC) val += f.old;
-            else if (bias != nullptr) val += *reinterpret_cast<const v4f*>(bias + coff + 4 * o) * f.d;
+            else val += bias4 * f.d;
             if (FINAL) val *= f.sc;
             if (v < r_end) *reinterpret_cast<v4f*>(out + v * ld_out + coff + 4 * o) = val;
         };
         Piece pc0, pc1;
-        First f;
+        First f0, f1;                                                    // of tile m in f<m & 1>
+        float inv0 = 1.f, inv1 = 1.f;                                    // inverse row scale of tile m in inv<m & 1>
+        load_first(0, f0);
         load_piece(0, pc0);
         load_piece(1, pc1);
-        split_tile(pc0, 0);
+        split_tile(pc0, 0, inv0);
         __syncthreads();
-        auto phase = [&](int k, const Piece& use, Piece& fill) {
+        // phase k: request of tile k + 2's rows and tile k's epilogue operands; epilogue of tile k - 1 (its scale's slot is then free); images of tile k + 1
+        auto phase = [&](int k, const Piece& use, Piece& fill, First& f_req, const First& f_use, float& inv_slot) {
+            if (k >= 1) load_first(k, f_req);
             load_piece(k + 2, fill);
-            if (k >= 1) load_first(k - 1, f);
-            if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
-            if (k >= 1) epilogue(k - 1, f);
+            if (k >= 1) epilogue(k - 1, f_use, inv_slot);
+            if (k + 1 < n_my) split_tile(use, (k + 1) & 1, inv_slot);
             __syncthreads();
         };
         int k = 0;
 #pragma clang loop unroll(disable)
         for (; k + 1 <= n_my; k += 2) {
-            phase(k, pc1, pc0);
-            phase(k + 1, pc0, pc1);
+            phase(k, pc1, pc0, f0, f1, inv1);
+            phase(k + 1, pc0, pc1, f1, f0, inv0);
         }
-        if (k <= n_my) phase(k, pc1, pc0);
+        if (k <= n_my) phase(k, pc1, pc0, f0, f1, inv1);
         return;
     }
 
     // ---------------- matrix waves: wave m = output columns coff + 16 m .. + 15, the pass's whole contraction index
-    v8s wreg[KB][3];
+    v8h wreg[KB][2];
     int cur_type = -1;
     __syncthreads();
     const int arow = lane & 15, kq = lane >> 4;
@@ -1500,32 +1533,32 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(cons
             int64_t r_base, r_end;
             const int type = tile_rows(k, r_base, r_end);
             if (type != cur_type) {
-                const v4u* wf = wnq + (static_cast<int64_t>((type * NPASS + PASS) * PARTS + cpart) * 4 + wave) * (16 * 3 * kWave) + lane;
+                const v4u* wf = wnq + (static_cast<int64_t>((type * NPASS + PASS) * PARTS + cpart) * 4 + wave) * (16 * 2 * kWave) + lane;
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) wreg[kb][pl] = __builtin_bit_cast(v8s, wf[(kb * 3 + pl) * kWave]);
+                    for (int pl = 0; pl < 2; ++pl) wreg[kb][pl] = __builtin_bit_cast(v8h, wf[(kb * 2 + pl) * kWave]);
                 cur_type = type;
             }
             const unsigned char* zp = &zplanes[k & 1][0][0][0] + arow * ZRB;
-            auto fragment = [&](int kb, v8s (&a)[3]) {
+            auto fragment = [&](int kb, v8h (&a)[2]) {
                 const unsigned char* src = zp + (((4 * kb + kq) ^ arow) << 4);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const v8s*>(src + pl * ZPL);
+                for (int pl = 0; pl < 2; ++pl) a[pl] = *reinterpret_cast<const v8h*>(src + pl * ZPL);
             };
             v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};       // one column tile per wave: two chains, alternate products
-            v8s a[3], an[3];
+            v8h a[2], an[2];
             fragment(0, a);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 if (kb + 1 < KB) fragment(kb + 1, an);
                 IHG_PIN_ORDER();
 #pragma unroll
-                for (int term = 0; term < 6; ++term)
-                    acc[term & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[kb][kTermB[term]], a[kTermA[term]], acc[term & 1], 0, 0, 0);
+                for (int term = 0; term < 3; ++term)
+                    acc[(kb + term) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[kb][kTermB2[term]], a[kTermA2[term]], acc[(kb + term) & 1], 0, 0, 0);
                 IHG_PIN_ORDER();
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[pl] = an[pl];
+                for (int pl = 0; pl < 2; ++pl) a[pl] = an[pl];
             }
             *reinterpret_cast<v4f*>(&part[k & 1][arow][16 * wave + 4 * kq]) = acc[0] + acc[1];
         }
@@ -2512,12 +2545,12 @@ void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w,
 // node-level forward of the interactive layer: node_interact_fwd_grouped_kernel (d = 128), node_interact_fwd_q_kernel (d = 64 / 256)
 static int64_t node_fwd_q_v4(int dim) {                                  // v4u of the q kernel's planes
     const int bpp = 512 / dim, n_pass = (7 + bpp - 1) / bpp, parts = dim / 64;
-    return 3LL * n_pass * parts * 4 * 16 * 3 * kWave;
+    return 3LL * n_pass * parts * 4 * 16 * 2 * kWave;
 }
 
 int64_t split_node_fwd_plane_floats(int dim) {
     if (dim != 64 && dim != 128 && dim != 256) return 0;
-    return std::max<int64_t>(node_fwd_q_v4(dim), dim == 128 ? 3LL * 4 * kNodePassV4 + 2 * 3 * 128 / 4 : 0) * 4;     // (d = 128: two fp16 planes + the weight rows' scales and inverses)
+    return (dim == 128 ? 3LL * 4 * kNodePassV4 : node_fwd_q_v4(dim)) * 4 + 2 * 3 * dim;     // two fp16 planes per weight + the weight rows' scales and inverses
 }
 
 bool split_node_fwd_ok(int dim, int order, int64_t ld_h, int64_t ld_s, const float* out, int64_t ld_out, const float* bias) {
@@ -2544,7 +2577,7 @@ void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, con
         // the planes (2 fp16 per weight) are followed by the weight rows' scales and their inverses ([3][128] floats each)
         float* wsc = reinterpret_cast<float*>(wnp + 3LL * 4 * kNodePassV4);
         float* winv = wsc + 3 * 128;
-        hipLaunchKernelGGL(node_fwd_weight_scales_kernel, dim3(grid_for_waves(3 * 128)), dim3(kBlockThreads), 0, s, w, ld_w, order, wsc, winv);
+        hipLaunchKernelGGL(node_fwd_weight_scales_kernel, dim3(grid_for_waves(3 * 128)), dim3(kBlockThreads), 0, s, w, ld_w, 128, order, wsc, winv);
         hipLaunchKernelGGL(pack_planes_node_fwd_kernel, dim3((3 * 4 * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, order, wsc, wnp);
         const RowTiles plan = row_tiles(type_begin, 32);
         if (plan.tile_prefix[3] == 0) return;
@@ -2563,14 +2596,17 @@ void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, con
             return;
         }
     }
-    const int items = static_cast<int>(node_fwd_q_v4(dim) / 3);
-    hipLaunchKernelGGL(pack_planes_node_fwd_q_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, order, wnp);
+    const int items = static_cast<int>(node_fwd_q_v4(dim) / 2);
+    float* wsc = reinterpret_cast<float*>(wnp + node_fwd_q_v4(dim));
+    float* winv = wsc + 3 * dim;
+    hipLaunchKernelGGL(node_fwd_weight_scales_kernel, dim3(grid_for_waves(3 * dim)), dim3(kBlockThreads), 0, s, w, ld_w, dim, order, wsc, winv);
+    hipLaunchKernelGGL(pack_planes_node_fwd_q_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, order, wsc, wnp);
     const RowTiles plan = row_tiles(type_begin, 16);
     if (plan.tile_prefix[3] == 0) return;
     const int parts = dim / 64;
     const int n_ranges = std::min((plan.tile_prefix[3] + 7) / 8 * 8, 256 / parts);      // a multiple of 8: the parts of a range land on one XCD
 #define IHG_NODE_Q(D, PASS, ACC, FINAL) \
-    hipLaunchKernelGGL((node_interact_fwd_q_kernel<D, PASS, ACC, FINAL>), dim3(n_ranges * parts), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, plan, out, ld_out)
+    hipLaunchKernelGGL((node_interact_fwd_q_kernel<D, PASS, ACC, FINAL>), dim3(n_ranges * parts), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, plan, out, ld_out)
     if (dim == 64) {
         IHG_NODE_Q(64, 0, false, true);
     } else {

@@ -1,5 +1,8 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r4
-timeout 1500 python -m pytest tests/test_gpu_parity.py -q -x -k "member or backward or gradient or training_step or heaviest or split" 2>&1 | tail -5
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r4/bench_C3_members_h2.json 2>gpurun_out/r4/bench_C3_members_h2.err; python -c "
-import json; p=json.load(open('gpurun_out/r4/bench_C3_members_h2.json')); print('C3', p['ms_per_step'], p['roofline'])"
+O=gpurun_out/r4
+mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py -q -x -k "without_hyperedge_rows or node_level or interactive or training_step or heaviest or full_size" 2>&1 | tail -5
+for c in C2 C5; do
+python bench.py --config $c --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_${c}_q_h2.json 2>/dev/null; python -c "
+import json; p=json.load(open('$O/bench_${c}_q_h2.json')); print('$c', p['ms_per_step'])"
+done
