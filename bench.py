@@ -31,7 +31,8 @@ One JSON line is printed by rank 0.  It carries
                               its own byte counts;
   roofline_interaction        the interactive layer's contractions (node-level form: contraction per node, member gradients per hyperedge, weight
                               gradients per node; flops = the multiply-adds of the algorithm in use) against the matrix-core peak of the arithmetic
-                              they run in (fp32 MFMA, or for d = 64 / 128 / 256 the bf16 peak / 6: six bf16 products per multiply), with the clocks and matrix-pipe occupancy of
+                              they run in (fp32 MFMA, or for d = 64 / 128 / 256 the 16-bit peak / 3 - two fp16 terms per operand: node-level contraction, member gradients - or / 6 -
+                              three bf16 terms: weight gradients), with the clocks and matrix-pipe occupancy of
                               the newest committed counter pass (`profiled_clock`);
   gradient_exchange           (N > 1) mode, backend, gradient bytes per rank, every rank's ms per step and the time its stream spent in the exchange;
   recorded_step_ms_per_step   the same step replayed from one recorded hipGraph (ihgnn_amd/captured_step.py); NOT the headline;
@@ -61,7 +62,7 @@ WORKLOAD_NOTES = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); a float4 streaming copy reaches ~6290
 MFMA_F32_PEAK_TF = 157.3       # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
-MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md); the split arithmetic spends six bf16 products per fp32 multiply
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md); the split arithmetic spends three fp16 or six bf16 products per fp32 multiply
 
 
 def split_arithmetic(dim, order, direction='any'):
@@ -606,23 +607,42 @@ def main():
             nw = table['node_interact_bwd_weight']
             bwd_us += nw['avg_us'] * nw['launches'] / table_steps
             flops_bwd = 2.0 * m_blocks * dim * dim * E + 2.0 * m_blocks * dim * dim * N
-        split_dtype = ('f32 operands taken apart exactly into three bf16 terms, six v_mfma_f32_16x16x32_bf16 products per multiply, f32 accumulate: '
-                       'peak = dense bf16 MFMA peak / 6, flops counted as fp32 multiply-adds')
-        f32_dtype = 'f32 in / f32 accumulate (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)'
+        dtype_by_products = {
+            3: ('f32 operands scaled by a power of two and taken apart into two fp16 terms (22 significand bits), three v_mfma_f32_16x16x32_f16 products per multiply '
+                '(hi lo + lo hi + hi hi), f32 accumulate: peak = dense 16-bit MFMA peak / 3, flops counted as fp32 multiply-adds'),
+            6: ('f32 operands taken apart exactly into three bf16 terms, six v_mfma_f32_16x16x32_bf16 products per multiply, f32 accumulate: '
+                'peak = dense bf16 MFMA peak / 6, flops counted as fp32 multiply-adds'),
+            4.5: 'member gradients through two fp16 terms (3 products), weight gradients through three bf16 terms (6 products), equal flops: peak = dense 16-bit MFMA peak / 4.5',
+            0: 'f32 in / f32 accumulate (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)'}
 
-        def direction(name, flops, us, extra):
+        def direction(name, pieces, extra):
+            """pieces: (kernel, flops, us, MFMA products per multiply in the split arithmetic); the direction's peak is the flop-weighted harmonic mean of its kernels' peaks."""
             split = split_arithmetic(dim, args.order, name)
-            peak = MFMA_BF16_PEAK_TF / 6 if split else MFMA_F32_PEAK_TF
-            return dict(achieved=round(flops / (us * 1e-6) / 1e12, 1), peak=round(peak, 1), frac=round(flops / (us * 1e-6) / (peak * 1e12), 4),
-                        dtype=split_dtype if split else f32_dtype, vs_f32_mfma_peak=round(flops / (us * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 3), **extra)
+            rows, flops_all, us_all, floor_s = [], 0.0, 0.0, 0.0
+            for kernel, flops, us, products in pieces:
+                products = products if split else 0
+                peak = MFMA_BF16_PEAK_TF / products if products else MFMA_F32_PEAK_TF
+                rows.append(dict(kernel=kernel, achieved=round(flops / (us * 1e-6) / 1e12, 1), peak=round(peak, 1), frac=round(flops / (us * 1e-6) / (peak * 1e12), 4),
+                                 us=round(us, 2), flops=flops, dtype=dtype_by_products[products]))
+                flops_all, us_all, floor_s = flops_all + flops, us_all + us, floor_s + flops / (peak * 1e12)
+            peak = flops_all / floor_s / 1e12
+            return dict(achieved=round(flops_all / (us_all * 1e-6) / 1e12, 1), peak=round(peak, 1), frac=round(flops_all / (us_all * 1e-6) / (peak * 1e12), 4),
+                        dtype=rows[0]['dtype'] if len(rows) == 1 else 'per kernel: see `kernels`', kernels=rows,
+                        vs_f32_mfma_peak=round(flops_all / (us_all * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 3), **extra)
 
+        fwd_pieces = [('node_interact_fwd' if node_level else 'interact_fwd', flops_fwd, f['avg_us'], 3 if node_level else 6)]
+        bwd_pieces = [('interact_bwd (member gradients)', 2.0 * m_blocks * dim * dim * E, bw['avg_us'] * bw['launches'] / table_steps, 3)]
+        if 'node_interact_bwd_weight' in table:
+            bwd_pieces.append(('node_interact_bwd_weight', 2.0 * m_blocks * dim * dim * N, nw['avg_us'] * nw['launches'] / table_steps, 6))
+        else:
+            bwd_pieces[0] = ('interact_bwd (member + weight gradients, hyperedge form)', flops_bwd, bwd_us, 4.5)
         mfma_roof = dict(bound='mfma', kernel=('node_interact_fwd (node-level contraction, %d blocks per node) + interact_bwd (member gradients, per hyperedge) + node_interact_bwd_weight (per node)' % (3 + m_blocks)
                                                if node_level else 'interact_fwd + interact_bwd (order-%d product blocks of layer 0)' % args.order), unit='TFLOP/s',
                          note='flops are the multiply-adds the algorithm in use performs (the node-level form does E / N times fewer than the hyperedge form for the same result), '
                               'not the hyperedge form\'s count' if node_level else None,
-                         f32_mfma_peak=MFMA_F32_PEAK_TF, split_peak=round(MFMA_BF16_PEAK_TF / 6, 1),
-                         forward=direction('forward', flops_fwd, f['avg_us'], dict(flops_per_launch=flops_fwd, avg_us=round(f['avg_us'], 2))),
-                         backward=direction('backward', flops_bwd, bwd_us, dict(flops_per_step=flops_bwd, us_per_step=round(bwd_us, 2))),
+                         f32_mfma_peak=MFMA_F32_PEAK_TF, two_fp16_terms_peak=round(MFMA_BF16_PEAK_TF / 3, 1), three_bf16_terms_peak=round(MFMA_BF16_PEAK_TF / 6, 1),
+                         forward=direction('forward', fwd_pieces, dict(flops_per_launch=flops_fwd, avg_us=round(f['avg_us'], 2))),
+                         backward=direction('backward', bwd_pieces, dict(flops_per_step=flops_bwd, us_per_step=round(bwd_us, 2))),
                          share_of_step=round((f['avg_us'] + bwd_us) * 1e-3 / (1e3 * elapsed / args.steps), 3),
                          measured='instrumented pass after the timed region (every launch bracketed)',
                          profiled_clock=mfma_pass_clocks(args.config))
@@ -637,9 +657,10 @@ def main():
                    'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd (the last layer\'s backward pulls the 3B non-zero rows of its cotangent) + Adam' +
                            (f' + RCCL gradient exchange ({args.sync})' if world > 1 else ''),
                    'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
-                   'arithmetic': ('f32 results; the order-2/3 contractions (d = 64 / 128 / 256) and the '
-                                  'node-level linear maps at d = 128 / 256 multiply through three exact bf16 terms per operand (six bf16 MFMA products, f32 '
-                                  'accumulation; error <= the fp32-MFMA kernels\' - tests/test_gpu_parity.py); IHG_INTERACT_ARITH=f32 selects the fp32-MFMA kernels')
+                   'arithmetic': ('f32 results; f32 accumulation everywhere.  Row contractions (node-level contraction and member gradients at d = 64 / 128 / 256, node-level linear '
+                                  'maps and their input gradients at d = 128 / 256): operands scaled by a power of two and taken apart into two fp16 terms, three fp16 MFMA products '
+                                  'per multiply (error <= 3 x 2^-22 per product); weight gradients (contraction over the rows): three exact bf16 terms, six bf16 MFMA products; '
+                                  'both within the fp32-MFMA kernels\' error against float64 (tests/test_gpu_parity.py); IHG_INTERACT_ARITH=f32 selects the fp32-MFMA kernels')
                                  if split_arithmetic(dim, args.order) else 'f32 (fp32 MFMA / VALU)'},
         'final_loss': round(final_loss, 6),
         'gradient_exchange': exchange,

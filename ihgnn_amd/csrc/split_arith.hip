@@ -170,31 +170,34 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
     wsp[(static_cast<int64_t>(idx >> 6) * 2 + 1) * kWave + lane] = lo;
 }
 
-// Member gradients dz_b = dout W_b, then the product rule.  A workgroup owns HALF of the columns (its weight planes: 192 KB) and its eight
+// Member gradients dz_b = dout W_b, then the product rule.  A workgroup owns HALF of the columns (its weight planes: 128 KB) and its eight
 // waves have two jobs, one of each per SIMD:
-//   - waves 0-3, the matrix waves: wave = product block b, the half's 64 columns x the tile's 32 hyperedges, 192 MFMAs per tile, weight
-//     planes resident (192 registers).  They read the dout fragments from three bf16 images (16-byte chunk o of row r at o ^ (r & 15):
-//     conflict-free ds_read_b128) and issue the MFMA as W^T x dout^T, so that a lane holds 4 consecutive COLUMNS of one hyperedge and the
-//     four blocks' contractions go to an LDS image in 16-byte pieces.
+//   - waves 0-3, the matrix waves: wave = product block b, the half's 64 columns x the tile's 32 hyperedges, 96 MFMAs per tile (two fp16 terms per
+//     operand, three products), weight planes resident (128 registers).  They read the dout fragments from two fp16 images (16-byte chunk o of row r
+//     at o ^ (r & 15): conflict-free ds_read_b128) and issue the MFMA as W^T x dout^T, so that a lane holds 4 consecutive COLUMNS of one hyperedge;
+//     the accumulators leave through the inverse scales (its columns' and the hyperedge's) into an LDS image in 16-byte pieces.
 //   - waves 4-7, the service waves (256 threads): request rows two tiles ahead (dout: 16 values per thread; member values: 4 columns x 2 of
-//     one hyperedge), split the next tile's dout values into the images, apply the product rule to the previous tile (contractions from
-//     the image, member values from registers) and store.  Requested rows are taken delivery of (an opaque asm use) at the END of the phase
+//     one hyperedge), scale (one power of two per hyperedge row: its eight threads agree on the largest magnitude) and split the next tile's dout
+//     values into the images, apply the product rule to the previous tile (contractions from the image, member values from registers) and store.
+//     Requested rows are taken delivery of (an opaque asm use) at the END of the phase
 //     that requested them, before the barrier: the memory counter is in order, and left to the compiler the waits land in the next
 //     phase's stream behind that phase's own requests and stores.
 // An in-order wave that does both jobs stalls its MFMA stream on every wait of the service work (that form: 1,520 us, this one 1,370,
 // same box, kbench scale).  Images, contraction image and id ring are double-buffered: one barrier per tile.  The two halves of a tile
 // range sit on one XCD, so the second read of a dout row hits that L2.
+// (Three bf16 terms per operand, six products, the user-slot sums on the service waves: 1,727 us at C3; two fp16 terms: 1,621; the sums moved
+// to the matrix waves: 1,489.  Ablation ladder of this form: profiles/r4/09_abl_member_gradients_fp16.txt.)
 // UR (hyperedges numbered by user; g is [E, 2, d]): the user-slot gradient is not stored per hyperedge.  The product rule leaves it in an
-// LDS image [row][column]; a phase later service wave w adds up the image's rows 8 w .. 8 w + 7 (lane = column; a run = the rows of one
+// LDS image [row][column]; a phase later MATRIX wave w adds up the image's rows 8 w .. 8 w + 7 (lane = column; a run = the rows of one
 // user, its starts from one ballot over the tile's user ids) and stores the runs inside its window to dh[user] as 256-byte row pieces; a
 // phase after that every wave closes the run that ends in its window from the carried sum and the windows' end pieces.  (user and -
 // through LDS - the open run's sum) are carried from tile to tile, which is why a workgroup takes a CONTIGUOUS tile range; the first and the last run of a
 // range may continue in the neighbours and go to the boundary table that interact.hip's user_boundary_fixup_kernel adds up (indexed by
 // tile range here, shared by the two halves).  (First form: every wave scanned 16 columns of all 32 rows with a scalar reset factor and
 // wrote the inclusive sums back for an emit loop - four times the additions on a quarter of the lanes, three LDS round trips in series.)
-// D = 128: two column halves of 64 per tile range.  D = 256: eight parts of 32 columns (the weight planes are 1.5 MB), the dout tile is 32 KB
-// and every part splits it again.  D = 64: one workgroup holds all of it.  No user reduction at 64 / 256.
-// NBLK = 3 (order 2): matrix wave 3 has no block and only keeps the barriers.
+// D = 128: two column halves of 64 per tile range.  D = 256: eight parts of 32 columns (the weight planes are 1 MB), the dout tile is 32 KB
+// and every part splits it again.  D = 64: one workgroup holds all of it.  No user reduction at 256.
+// NBLK = 3 (order 2): matrix wave 3 has no block; it keeps the barriers and its window of the user sums.
 // GATHER (D = 128, UR): there is no dout tensor yet - the cotangent of a hyperedge is the scaled sum of its three members' rows of a
 // node-level cotangent dy ([N, d]; dout[e] = sum_m dy_scale[m] dy[m], the transpose of the hyperedge -> node pass that follows the
 // interactive step in an IHGNN layer).  The service waves gather the three rows instead of streaming one, form the sum in the order of
