@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # IHGNN_HIP_LIBRARY points at another build of the same ABI (A/B timing of kernel variants); default: the in-tree library
 LIB_PATH = os.environ.get('IHGNN_HIP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
@@ -33,6 +33,7 @@ _i64p, _i32p, _f32p = POINTER(c_int64), POINTER(c_int32), POINTER(c_float)
 # c_void_p (tensor.data_ptr()); host-side builders take real typed pointers.
 SIGNATURES = {
     'ihg_abi_version': (c_int32, []),
+    'ihg_ablation_build': (c_int32, []),
     'ihg_last_error_string': (c_char_p, []),
     'ihg_build_csr': (ctypes.c_int, [_i64p, c_int64, c_int64, c_int64, c_int64, _i32p, _i32p, _i32p, _f32p]),
     'ihg_parse_search_logs': (ctypes.c_int, [c_char_p, _i64p, _i64p, _i64p, _i64p, c_int64, _i64p, c_int64, _i64p]),
@@ -146,6 +147,9 @@ def load() -> ctypes.CDLL:
     got = lib.ihg_abi_version()
     if got != ABI_VERSION:
         raise IhgnnHipError(f'{LIB_PATH} has ABI version {got}, this package needs {ABI_VERSION}: rebuild it')
+    if lib.ihg_ablation_build() and os.environ.get('IHG_ALLOW_ABLATION_BUILD') != '1':
+        raise IhgnnHipError(f'{LIB_PATH} is an ablation build (csrc/ablate.hpp: a kernel with part of its work removed, wrong results on purpose); '
+                            'only the timing tools load one (IHG_ALLOW_ABLATION_BUILD=1)')
     _lib = lib
     return lib
 

@@ -1,7 +1,7 @@
 // ablate.hpp - compile-time switches of the ABLATION builds (tools/ab_variant.sh NAME -DIHG_ABL_<SWITCH> ...; never the product build).
 // An ablation build removes one class of work from a kernel - its result is WRONG on purpose - so that the time that class costs inside the
 // kernel can be read off (profiles/r4/abl_members.txt).  The product build defines none of the macros: every switch below is a constexpr false and
-// the branches it guards fold away (tests/test_abi.py checks that the shipped library was not built with one).
+// the branches it guards fold away; ihg_ablation_build() reports abl::any and the binding refuses such a library (tests/test_abi.py).
 #pragma once
 
 namespace abl {

@@ -320,11 +320,7 @@ __device__ __forceinline__ void lds_dma16(const float* src, float* lds_piece) {
 }
 
 __device__ __forceinline__ void edge_row_store(float* p, v4f v) {
-#ifdef IHG_PLAIN_EDGE_OUT
-    *reinterpret_cast<v4f*>(p) = v;
-#else
     store_stream4(p, v);
-#endif
 }
 
 template <int D, int NBLK>
@@ -860,13 +856,8 @@ __global__ __launch_bounds__(kWsThreads) void interact_fwd_strip_kernel(
         const v4f s1 = *reinterpret_cast<const v4f*>(&pimg[erow][64 + ecol]) + first_prev[1];
         if (e < n_edges) {
             float* dst = out + e * ld_out + ecol;
-#ifdef IHG_PLAIN_EDGE_OUT
-            *reinterpret_cast<v4f*>(dst) = s0;
-            *reinterpret_cast<v4f*>(dst + 64) = s1;
-#else
             store_stream4(dst, s0);
             store_stream4(dst + 64, s1);
-#endif
         }
     };
 

@@ -2447,6 +2447,9 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 int64_t split_plane_floats(int dim, int order) { return (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) ? (3LL * 4 * dim * dim) / 2 : 0; }
 
 
+// the translation unit the ablation macros reach (tools/ab_variant.sh): include/ihgnn_hip.h
+extern "C" int32_t ihg_ablation_build(void) { return abl::any ? 1 : 0; }
+
 bool split_arith_enabled() {                                             // read at every call: tests and the bench switch it in-process
     const char* v = std::getenv("IHG_INTERACT_ARITH");
     return v == nullptr || std::strcmp(v, "f32") != 0;

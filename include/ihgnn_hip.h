@@ -41,6 +41,10 @@ typedef void* ihg_stream_t;       /* hipStream_t */
 /* Version of this ABI; bumped on any signature change. */
 int32_t ihg_abi_version(void);
 
+/* 1 when the library was built with an ablation switch of csrc/ablate.hpp (tools/ab_variant.sh ... -DIHG_ABL_*: a kernel with one class of its work removed, wrong
+ * results on purpose, for timing only); the product build returns 0 and the binding refuses anything else unless IHG_ALLOW_ABLATION_BUILD=1. */
+int32_t ihg_ablation_build(void);
+
 /* Text of the last error raised on this thread ("" if none). */
 const char* ihg_last_error_string(void);
 

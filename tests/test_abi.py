@@ -26,6 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f'{name} declared in include/ihgnn_hip.h but not exported'
     assert _lib.load().ihg_abi_version() == _lib.ABI_VERSION
+    assert lib.ihg_ablation_build() == 0, 'the shipped library was built with an ablation switch (csrc/ablate.hpp)'
 
 
 def test_bad_arguments_return_codes_and_messages():

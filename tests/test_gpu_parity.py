@@ -615,6 +615,16 @@ def test_interactive_layer_without_hyperedge_rows(order, dim, monkeypatch):
             assert rel(got[True], got[False]) <= RTOL
             monkeypatch.setattr(ops, 'NODE_LEVEL_WEIGHT', True)
             monkeypatch.setattr(ops, 'NODE_LEVEL_FORWARD', True)
+            if dim == 256 and edges > 1:
+                # the first-order gradient by the two-hop operator on the node-level cotangent instead of the scatter of the [E, d] cotangents
+                # (IHG_FIRST_ORDER_TWO_HOP_BYTES: what C5's 51 GB table takes by default)
+                monkeypatch.setattr(ops, 'FIRST_ORDER_TWO_HOP_BYTES', 0)
+                hd, wd = h.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True)
+                bd = bias.to(dev()).requires_grad_(True) if bias is not None else None
+                ops.interact_layer(hd, wd, bd, lay, order, scale).backward(cot.to(dev()))
+                for a, c in zip([hd.grad, wd.grad] + ([bd.grad] if bd is not None else []), want_grads):
+                    assert rel(a, c) <= RTOL, ('two-hop first-order gradient', edges, scaled)
+                monkeypatch.undo()
             wide = torch.full((lay.node_count, 2 * dim), 7.0, device=dev())
             with torch.no_grad():
                 ops.interact_layer(h.to(dev()), w.to(dev()), bias.to(dev()) if bias is not None else None, lay, order, scale, out=wide[:, dim:])

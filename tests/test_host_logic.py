@@ -371,3 +371,20 @@ def test_model_refuses_a_feature_width_the_evaluation_kernel_cannot_score_at_con
     from ihgnn_amd.Models import HemPredictionLayer, IHGNNLayer, RawGnn
     with pytest.raises(NotImplementedError, match='1280 exceeds 1272'):
         RawGnn(torch.device('cpu'), None, 256, IHGNNLayer, 4, 3, False, HemPredictionLayer, 0.5)
+
+
+def test_readme_lists_every_switch_the_code_reads():
+    """Every IHG_* / IHGNN_* environment variable the package or the library reads is a row of README.md's switch table (a switch whose A/B is settled leaves
+    the code and the table together)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    readme = open(os.path.join(root, 'README.md')).read()
+    read = set()
+    for path in glob.glob(os.path.join(root, 'ihgnn_amd', '**', '*.py'), recursive=True) + glob.glob(os.path.join(root, 'ihgnn_amd', 'csrc', '*.h*')):
+        text = open(path).read()
+        read.update(re.findall(r"environ(?:\.get)?\(\s*'(IHG[A-Z_]*_[A-Z0-9_]+)'", text))
+        read.update(re.findall(r'getenv\(\s*"(IHG[A-Z_]*_[A-Z0-9_]+)"', text))
+    assert 'IHG_INTERACT_ARITH' in read and 'IHG_NODE_TABLES' in read, read
+    missing = sorted(name for name in read if name not in readme)
+    assert not missing, f'not in README.md\'s switch table: {missing}'
