@@ -1281,67 +1281,74 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
 
     // ---------------- matrix waves: wave m = output columns 32 m .. + 31, the pass's whole contraction index
     v8h wreg[2][KB][2];
-    int cur_type = -1, cur_pass = -1;
     Cur c;
     c.gi = g_begin;
     open_group(c);
     __syncthreads();
     const int arow = lane & 15, kq = lane >> 4;
-    // the planes of (type, pass): requested as soon as the last MFMA of the pass before has been issued - in front of that phase's barrier, so that the round trip to L2
-    // runs beside the barrier and the service waves' tail instead of in front of the next pass's first MFMA
-    auto load_weights = [&](const Cur& cw) {
-        if (cw.type == cur_type && cw.p == cur_pass) return;
-        const v4u* wf = wnp + static_cast<int64_t>(cw.type * 4 + cw.p) * kNodePassV4;
+    auto plane_ptr = [&](const Cur& cw) { return wnp + static_cast<int64_t>(cw.type * 4 + cw.p) * kNodePassV4 + lane; };
+    auto load_kb = [&](const v4u* wf, int kb) {                          // the planes of k-block kb of this wave's two column tiles
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    wreg[jt][kb][pl] = __builtin_bit_cast(v8h, wf[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 2 + pl) * kWave + lane]);
-        cur_type = cw.type;
-        cur_pass = cw.p;
+            for (int pl = 0; pl < 2; ++pl) wreg[jt][kb][pl] = __builtin_bit_cast(v8h, wf[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 2 + pl) * kWave]);
     };
-    load_weights(c);
+    {
+        const v4u* wf = plane_ptr(c);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) load_kb(wf, kb);
+    }
+    // One tile: step = (k-block, row tile), six MFMAs on two accumulators, the fragment of the next step requested in front of them; the two row tiles alternate, so an
+    // accumulator's next product is a step away.
+    // RELOAD - the last tile of a (type, pass): the planes of the NEXT pass are requested k-block by k-block, each right behind the last MFMAs that read its registers,
+    // so that their round trips to L2 run beside the rest of this tile and the barrier instead of in front of the next pass's first MFMA (one request for all of them after
+    // the tile: 92 exposed round trips per workgroup at C3; 455 -> 441 us, same box)
+    auto tile = [&](bool reload, int s, const v4u* wf_next) {
+        const unsigned char* zp = &zplanes[s & 1][0][0][0];
+        const int kb_live = 4 * blocks_of(c.p);                          // a one-block pass skips the steps of its empty second block (uniform branches; one MFMA body)
+        int ar = arow, kqq = kq;                                         // opaque copies: the sixteen fragment offsets are re-derived per tile (hoisted out of the phase loop
+        asm volatile("" : "+v"(ar), "+v"(kqq));                          // they cost sixteen registers beside 128 of weights, and the weights spill)
+        auto fragment = [&](int step, v8h (&f)[2]) {
+            const int kb = step >> 1, rt = step & 1;
+            const unsigned char* src = zp + (16 * rt + ar) * ZRB + (((4 * kb + kqq) ^ ar) << 4);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) f[pl] = *reinterpret_cast<const v8h*>(src + pl * ZPL);
+        };
+        v4f acc[RT][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
+        v8h a[2], an[2];                                                 // (fragments two steps ahead instead of one: 438 - 448 us against 441 - 447, no gain)
+        fragment(0, a);
+#pragma unroll
+        for (int step = 0; step < RT * KB; ++step) {
+            const int kb = step >> 1, rt = step & 1;
+            if (step + 1 < RT * KB) fragment(step + 1, an);              // (the fragment of a skipped step is read and dropped)
+            IHG_PIN_ORDER();
+            if (kb < kb_live && !abl::n_no_mfma) {
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int jt = 0; jt < 2; ++jt)
+                        acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[jt][kb][kTermB2[term]], a[kTermA2[term]], acc[rt][jt], 0, 0, 0);
+            }
+            IHG_PIN_ORDER();
+            if (rt == RT - 1 && reload) load_kb(wf_next, kb);             // (a uniform branch around four requests: one code path, so that old and new planes share their registers)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) a[pl] = an[pl];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[s & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
+    };
     for (int s = 0; s <= n_phases; ++s) {
         if (s < n_phases) {
-            const unsigned char* zp = &zplanes[s & 1][0][0][0];
-            const int kb_live = 4 * blocks_of(c.p);                      // a one-block pass skips the steps of its empty second block (uniform branches; one MFMA body)
-            auto fragment = [&](int step, v8h (&a)[2]) {
-                const int rt = step / KB, kb = step % KB;
-                const unsigned char* src = zp + (16 * rt + arow) * ZRB + (((4 * kb + kq) ^ arow) << 4);
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[pl] = *reinterpret_cast<const v8h*>(src + pl * ZPL);
-            };
-            v4f acc[RT][2];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
-            v8h a[2], an[2];
-            fragment(0, a);
-#pragma unroll
-            for (int step = 0; step < RT * KB; ++step) {
-                const int rt = step / KB, kb = step % KB;
-                if (step + 1 < RT * KB) fragment(step + 1, an);          // (the fragment of a skipped step is read and dropped)
-                IHG_PIN_ORDER();
-                if (kb < kb_live && !abl::n_no_mfma) {
-#pragma unroll
-                    for (int term = 0; term < 3; ++term)
-#pragma unroll
-                        for (int jt = 0; jt < 2; ++jt)
-                            acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[jt][kb][kTermB2[term]], a[kTermA2[term]], acc[rt][jt], 0, 0, 0);
-                }
-                IHG_PIN_ORDER();
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[pl] = an[pl];
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[s & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
-            advance(c);
-            if (s + 1 < n_phases) load_weights(c);
+            Cur cn = c;
+            advance(cn);
+            tile(s + 1 < n_phases && (cn.type != c.type || cn.p != c.p), s, plane_ptr(cn));
+            c = cn;
         }
         __syncthreads();
     }
