@@ -192,13 +192,13 @@ def cpu_baseline(config, layer, layers, order, dim, scale, budget_s=10.0):
 def mfma_pass_clocks(config):
     """Clock and matrix-pipe occupancy of the interact kernels from the newest committed MFMA counter pass (profiles/r*/..._pmc_mfma.json;
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/kbench.py at C3) - NOT measured in this run."""
-    if config != 'C3':
-        return None
     import glob
     files = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*', '*_pmc_mfma.json')), key=lambda f: (int(os.path.basename(os.path.dirname(f))[1:]), os.path.basename(f)))
-    if not files:
+    docs = [(f, json.load(open(f))) for f in files]
+    docs = [(f, d) for f, d in docs if f'--config {config} ' in d.get('command', '') + ' ']      # the pass over THIS workload
+    if not docs:
         return None
-    doc = json.load(open(files[-1]))
+    files, doc = [docs[-1][0]], docs[-1][1]
     return dict(source=os.path.relpath(files[-1], REPO), commit=doc.get('commit', 'unrecorded'),
                 kernels={k: dict(clock_ghz=v.get('clock_ghz'), mfma_busy_fraction=v.get('mfma_busy_fraction'), avg_us_under_pmc=v.get('avg_us_under_pmc'))
                          for k, v in doc.get('kernels', {}).items()})

@@ -120,8 +120,8 @@ def main():
             name = (name[5:] if name.startswith('void ') else name).split('(')[0]
             if 'interact' in name:
                 agg[name][r['Counter_Name']].append((float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
-        out = dict(command='rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 tools/kbench.py --config '
-                           f'{config} --rounds 3 --ops layer', notes='GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs', commit=head_commit(), kernels={})
+        program = f'tools/kbench.py --config {config} --rounds 3 --ops layer' if config == 'C3' else f'bench.py --config {config} --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-events'
+        out = dict(command=f'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -- python3 {program}', notes='GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs', commit=head_commit(), kernels={})
         for name, c in agg.items():
             busy = sum(v for v, _ in c['SQ_VALU_MFMA_BUSY_CYCLES']) / len(c['SQ_VALU_MFMA_BUSY_CYCLES']) / 1024
             gui = sum(v for v, _ in c['GRBM_GUI_ACTIVE']) / len(c['GRBM_GUI_ACTIVE']) / 8
