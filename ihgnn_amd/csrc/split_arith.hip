@@ -1,5 +1,6 @@
-// split_arith.hip - contractions of the order-2 / order-3 interactive step (d = 64, 128, 256) and of the node-level linear maps
-// (d = 128, 256) on the bf16 matrix pipe at fp32 accuracy.
+// split_arith.hip - contractions of the order-2 / order-3 interactive step PER HYPEREDGE (d = 64, 128, 256: member gradients, the hyperedge form's forward and
+// weight gradients) on the 16-bit matrix pipe at fp32 accuracy.  The node-level contractions and linear maps are split_node.hip's; the helpers both share
+// (operand splits, wave roles) split_common.hpp's.
 //
 // Every fp32 operand x is taken apart EXACTLY into three bf16 terms, x = hi + mid + lo (hi = the top 16 bits of x, mid = the top
 // 16 bits of x - hi, lo = the rest: 8 + 8 + 8 significand bits, both subtractions exact), and a product a b is accumulated in fp32
@@ -23,125 +24,9 @@
 // What bounds these kernels is instruction issue: a SIMD spends ~ 16 cycles per MFMA and ~ 4 per every other instruction of its matrix
 // and its service wave, one after the other - so the count of instructions beside the MFMAs (the split: 5.5 per element; addresses;
 // scalar bookkeeping) is what to cut; the pipe is 0.45-0.64 busy (DESIGN.md section 4 has the ladder, the probes and the counters).
-#include <cstdlib>
-#include <type_traits>
-
-#include "ablate.hpp"
-#include "common.hpp"
-#include "split.hpp"
+#include "split_common.hpp"
 
 namespace {
-
-typedef short v8s __attribute__((ext_vector_type(8)));
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-
-constexpr int kSplitTE = 32;            // hyperedges per tile
-constexpr int kSplitRanges = 128;       // contiguous tile ranges at d = 128 (x 2 column halves = 256 workgroups, one per CU)
-constexpr int kSplitThreads = 512;
-
-// Issue priority of the two wave roles (s_setprio, 0 .. 3; A/B: tools/ab_variant.sh NAME -DIHG_SERVICE_PRIO=n -DIHG_MATRIX_PRIO=m).  The
-// service waves are the second-dispatched half of the workgroup - the arbitration loser at equal priority (oldest first).
-#ifndef IHG_SERVICE_PRIO
-#define IHG_SERVICE_PRIO 3           // measured at C3 (same box, us): forward 1,874 -> 1,766, weight gradients 1,454 -> 1,342, member gradients 1,870 -> 1,834;
-#endif                               // priority 1: 1,787 / 1,366 / 1,827; matrix waves at 1 instead: no change (profiles/r3/ab_priority.txt)
-#ifndef IHG_MATRIX_PRIO
-#define IHG_MATRIX_PRIO 0
-#endif
-// Left to the scheduler, an LDS fragment read that the source issues a step ahead is sunk to just in front of its first MFMA (the weight
-// planes hold 192 registers, and shortening live ranges wins): every step then sits out the LDS latency.  A scheduling barrier on both sides
-// of a step's MFMA group keeps the reads of step s + 1 in front of the MFMAs of step s.  -DIHG_NO_PIN: the scheduler's order (A/B).
-#ifdef IHG_NO_PIN
-#define IHG_PIN_ORDER()
-#else
-#define IHG_PIN_ORDER() __builtin_amdgcn_sched_barrier(0)
-#endif
-
-__device__ __forceinline__ void role_priority(bool service) {
-    if (service) {
-        if (IHG_SERVICE_PRIO) __builtin_amdgcn_s_setprio(IHG_SERVICE_PRIO);
-    } else {
-        if (IHG_MATRIX_PRIO) __builtin_amdgcn_s_setprio(IHG_MATRIX_PRIO);
-    }
-}
-
-__device__ __forceinline__ unsigned pack_hi(float a, float b) {          // {top half of b, top half of a}
-    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
-}
-// row r of a table whose rows are ld floats apart (ld < 2^31: the *_ok() predicates): ONE v_mad_u64_u32 where the 64 x 64-bit product of
-// an int64 leading dimension costs three quarter-rate multiplies per row - service-wave cycles the matrix pipe waits for
-__device__ __forceinline__ const float* row_at(const float* base, int32_t r, uint32_t ld) {
-    return base + static_cast<uint64_t>(static_cast<uint32_t>(r)) * static_cast<uint64_t>(ld);
-}
-__device__ __forceinline__ float top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
-
-// Two fp32 values -> one dword of each of the three bf16 planes (low half: xa's term, high half: xb's): mask, subtract, mask, subtract, and
-// three v_perm_b32 that pack the top halves - 11 vector instructions per pair.  (Tried: the remainder x - top16(x) as ONE
-// v_dot2c_f32_bf16 of the packed plane with the selector {-1, 0} accumulated onto x, 7 instructions per pair and bit-identical planes
-// - tools/dot2_probe.hip - but the dot instruction is not a full-rate one: forward +2 %, weight gradients +8 %.)
-__device__ __forceinline__ void split_pair(float xa, float xb, unsigned (&w)[3]) {
-    const float ra = xa - top16(xa), rb = xb - top16(xb);
-    const float la = ra - top16(ra), lb = rb - top16(rb);
-    w[0] = pack_hi(xa, xb);
-    w[1] = pack_hi(ra, rb);
-    w[2] = pack_hi(la, lb);
-}
-
-// eight consecutive k of one row / column -> the three bf16 planes of that MFMA fragment
-struct Planes {
-    v4u p[3];
-};
-__device__ __forceinline__ Planes split8(v4f x0, v4f x1) {
-    Planes out;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const v4f x = half == 0 ? x0 : x1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            unsigned w[3];
-            split_pair(x[2 * i], x[2 * i + 1], w);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) out.p[p][2 * half + i] = w[p];
-        }
-    }
-    return out;
-}
-
-// ------------------------------------------------------------------------------------------------
-// fp32 through TWO fp16 terms (node-level contraction, d = 128).  An fp32 value, first multiplied by a power of two that brings its row's (or its weight column's)
-// largest magnitude to [2^13, 2^14), is hi + lo with hi = fp16(x) (11 significand bits, round to nearest even) and lo = fp16(x - hi) (the difference is exact in fp32;
-// lo carries the next 11 bits wherever |x| >= 2^-3, i.e. within 2^-17 of the row's largest entry - below that it is an fp16 subnormal with an ABSOLUTE error of 2^-25,
-// 2^-38 of the row's largest entry).  A product a b is then three partial products - hi lo + lo hi + hi hi, each exact in fp32, accumulated by
-// v_mfma_f32_16x16x32_f16 - instead of six: half the matrix-pipe time, and the split costs 4 vector instructions per element instead of 5.5.  What is left out
-// (lo lo, and the rounding of lo) is bounded by 3 x 2^-22 |a b|; rounding to nearest, not truncation, so there is no one-sided bias (numpy emulation of both
-// schemes against float64 on normal, wide-range (2e-4 .. 3e3), one-huge-many-tiny and low-16-bits-set operands: 0.8 - 1.8e-7 per-row against 1.0 - 2.6e-7 for the
-// three-bf16 scheme).  The scales are powers of two: applying and removing them is exact.  fp16's narrow exponent is what the scaling is for: scaled magnitudes
-// stay below 2^14, partial products below 2^28, sums over 1,024 of them below 2^38.
-// ------------------------------------------------------------------------------------------------
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-typedef _Float16 v2h __attribute__((ext_vector_type(2)));
-
-// 2^(13 - floor(log2 m)) and its inverse for a magnitude m >= 0 (zero, denormals and magnitudes beyond 2^100 either way: exponent clamped - such rows are all-zero
-// or all-huge relative to anything they meet)
-__device__ __forceinline__ float scale_up_for(float m, float& inverse) {
-    int e = static_cast<int>((__float_as_uint(m) >> 23) & 0xffu);         // biased exponent of the largest magnitude
-    e = e < 27 ? 27 : (e > 227 ? 227 : e);
-    inverse = __uint_as_float(static_cast<unsigned>(e - 13) << 23);       // 2^(e - 127 - 13)
-    return __uint_as_float(static_cast<unsigned>(267 - e) << 23);         // 2^(13 - (e - 127))
-}
-// two scaled fp32 values -> one dword of each plane (low half: xa's term)
-__device__ __forceinline__ void split_pair_h2(float xa, float xb, unsigned& hi, unsigned& lo) {
-    const v2h h = v2h{static_cast<_Float16>(xa), static_cast<_Float16>(xb)};
-    const v2h l = v2h{static_cast<_Float16>(xa - static_cast<float>(h[0])), static_cast<_Float16>(xb - static_cast<float>(h[1]))};
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
-// partial products in accumulation order (A plane, B plane): smallest first; planes: 0 = hi, 1 = lo
-__device__ constexpr int kTermA2[3] = {0, 1, 0};
-__device__ constexpr int kTermB2[3] = {1, 0, 0};
-
-// partial products in accumulation order (A plane, B plane): smallest first
-__device__ constexpr int kTermA[6] = {0, 2, 1, 0, 1, 0};
-__device__ constexpr int kTermB[6] = {2, 0, 1, 1, 0, 0};
 
 // planes of the member-gradient contraction dz_b[e][c] = sum_j dout[e][j] W[j][(3+b)d + c]   (k runs along j), two fp16 terms per weight:
 // wsp[g][b][kb][ct][plane < 2][lane][8 x fp16] (g = 32-column group, d / 32 of them; kb < d / 32; ct < 2): element i = plane of
@@ -988,596 +873,6 @@ __global__ __launch_bounds__(kSplitThreads) void interact_fwd_split_kpass_kernel
 }
 
 // ------------------------------------------------------------------------------------------------
-// The interactive layer WITHOUT hyperedge rows (d = 128): node-level form of  out = scale * H FeatureInteractor(h).
-// For a node v of type t with incident hyperedges e and their other two members (a_e, b_e), every term of the hyperedge feature is linear
-// in the member features once v's own feature is held fixed, so the sum over v's hyperedges is a linear map of
-//     deg(v) h[v],   S_a = sum h[a_e],   S_b = sum h[b_e],   S_ab = sum h[a_e] h[b_e]     (ihg_node_pair_sums; products elementwise)
-// and of their products with h[v]:
-//     sum_e F(e) = deg (A_t h + c) + L_a S_a + P_a (h S_a) + L_b S_b + P_b (h S_b) + L_ab S_ab + W_uqi (h S_ab)
-// with the blocks of w = [A_u | A_q | A_i | W_uq | W_qi | W_iu | W_uqi] assigned by node type (kNodeBlocks).  That is a row GEMM over the
-// N nodes with a contraction index of 7 d - E / N times fewer multiply-adds than the hyperedge form, no [E, d] tensor, no hyperedge -> node
-// pass - run in PASSES like the forward above: a pass contracts one source block and its product with h (256 values: the 192 weight
-// registers per matrix wave), adds onto what the earlier passes left in `out`; the last pass applies the output scale.  Matrix waves reload
-// their weight registers where a workgroup's tile range crosses a node type.
-// wnp[type][pass][m][jt < 2][kb < 8][plane][lane][8]: element i = plane of W[32 m + 16 jt + (lane & 15)][block(type, pass, kb >> 2) d + 32 (kb & 3) + 8 (lane >> 4) + i]
-// passes: 0 = {deg h}, 1 = {S_a, h S_a}, 2 = {S_b, h S_b}, 3 = {S_ab, h S_ab}
-// ------------------------------------------------------------------------------------------------
-// rows grouped by node type in tiles of 32 that do not cross a type: begin[t] = first row of type t, tile_prefix[t] = tiles before type t
-struct RowTiles {
-    int64_t begin[4];
-    int tile_prefix[4];
-};
-
-__device__ __forceinline__ int node_block(int type, int pass, int second) {
-    // user: a = query, b = item; query: a = user, b = item; item: a = user, b = query     (-1: no such block)
-    constexpr signed char kNodeBlocks[3][4][2] = {{{0, -1}, {1, 3}, {2, 5}, {4, 6}}, {{1, -1}, {0, 3}, {2, 4}, {5, 6}}, {{2, -1}, {0, 5}, {1, 4}, {3, 6}}};
-    return kNodeBlocks[type][pass][second];
-}
-
-// scale of every weight ROW of every node type (= output column j of that type's contraction): wsc[type][j] = scale_up_for(max_k |W_t[j][k]|) over the type's seven blocks,
-// winv[type][j] its inverse.  One wave per (type, j).
-__global__ __launch_bounds__(kBlockThreads) void node_fwd_weight_scales_kernel(const float* __restrict__ w, int64_t ld_w, int d, int order, float* __restrict__ wsc,
-                                                                               float* __restrict__ winv) {
-    const int lane = threadIdx.x & 63;
-    const int64_t unit = global_wave_id();
-    if (unit >= 3 * d) return;
-    const int type = static_cast<int>(unit) / d, j = static_cast<int>(unit) % d;
-    float m = 0.f;
-    for (int pass = 0; pass < 4; ++pass)
-        for (int second = 0; second < 2; ++second) {
-            int b = node_block(type, pass, second);
-            if (b == 6 && order != 3) b = -1;
-            if (b < 0) continue;
-            const float* src = w + static_cast<int64_t>(j) * ld_w + b * d;
-            for (int c = lane; c < d; c += kWave) m = fmaxf(m, fabsf(src[c]));
-        }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    float inv;
-    const float sc = scale_up_for(m, inv);
-    if (lane == 0) {
-        wsc[unit] = sc;
-        winv[unit] = inv;
-    }
-}
-
-// wnp[type][pass][m][jt < 2][kb < 8][plane < 2][lane][8 x fp16]: element i = plane of wsc[type][j] W[j][block(type, pass, kb >> 2) d + 32 (kb & 3) + 8 (lane >> 4) + i],
-// j = 32 m + 16 jt + (lane & 15)
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd_kernel(const float* __restrict__ w, int64_t ld_w, int order, const float* __restrict__ wsc,
-                                                                             v4u* __restrict__ wnp) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 3 * 4 * 4 * 2 * 8 * kWave) return;
-    const int lane = idx & 63, kb = (idx >> 6) & 7, jt = (idx >> 9) & 1, m = (idx >> 10) & 3, pass = (idx >> 12) & 3, type = idx >> 14;
-    int b = node_block(type, pass, kb >> 2);
-    if (b == 6 && order != 3) b = -1;
-    v4u hi = v4u{0, 0, 0, 0}, lo = v4u{0, 0, 0, 0};
-    if (b >= 0) {
-        const int j = 32 * m + 16 * jt + (lane & 15);
-        const float sc = wsc[type * 128 + j];
-        const float* src = w + static_cast<int64_t>(j) * ld_w + b * 128 + 32 * (kb & 3) + 8 * (lane >> 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned hh, ll;
-            split_pair_h2(src[2 * i] * sc, src[2 * i + 1] * sc, hh, ll);
-            hi[i] = hh;
-            lo[i] = ll;
-        }
-    }
-    wnp[(static_cast<int64_t>(idx >> 6) * 2 + 0) * kWave + lane] = hi;
-    wnp[(static_cast<int64_t>(idx >> 6) * 2 + 1) * kWave + lane] = lo;
-}
-
-constexpr int kNodePassV4 = 4 * 2 * 8 * 2 * kWave;                      // v4u of one (type, pass)'s planes
-
-// ------------------------------------------------------------------------------------------------
-// The node-level contraction at d = 128: FOUR passes over the contraction index ({deg h}, {S_a, h S_a}, {S_b, h S_b}, {S_ab, h S_ab}) as ONE launch that touches
-// `out` once.  A matrix wave's weight registers hold the planes of 256
-// values of the contraction index - but they run GROUP by group of G = 8 row tiles: for each pass the matrix waves load that pass's planes once per group and contract
-// the group's tiles, and the partial sums of the group's rows live in the SERVICE waves' registers between the passes (thread = one row x 16 columns of every tile:
-// 16 G = 128 registers), not in `out`.  h and the pair sums are read once from memory (h four times out of L2: a group's rows are 128 KB), `out` is written once:
-// 0.96 GB at C3 instead of the 2.8 GB of four launches that each read-modify-write `out` - the four launches are streams at 5.1 TB/s, this one is bound by its matrix
-// waves.  No global load is issued and consumed inside one phase (the memory counter is in order: waiting for such a load also waits for the row requests in front of it,
-// and the phase becomes as long as a memory round trip - what bounded each of the four launches' phases at ~3 us).
-// Measured at C3 (us): four launches, three bf16 terms 560; this kernel with three bf16 terms 650 (matrix waves: 6 MFMAs per product); two fp16 terms: four launches 541,
-// this kernel: see DESIGN.md section 4.
-// ------------------------------------------------------------------------------------------------
-constexpr int kNodeGroupTiles = 8;
-
-struct NodeGroups {
-    RowTiles tiles;                                                      // tiles of 32 rows that do not cross a node type
-    int group_prefix[4];                                                 // groups of kNodeGroupTiles consecutive tiles of ONE type: groups before type t
-};
-
-template <int ORDER>
-__global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
-                                                                                  const float* __restrict__ deg, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                                                  const v4u* __restrict__ wnp, const float* __restrict__ winv, NodeGroups plan,
-                                                                                  float* __restrict__ out, int64_t ld_out) {
-    constexpr int G = kNodeGroupTiles, TE = 32, RT = 2, CSTR = 32, ZRB = 512, ZPL = TE * ZRB, PS = 128 + 4, X = 4, PASSES = 4, KB = 8;
-    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][2][TE][ZRB];
-    __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
-    __shared__ __attribute__((aligned(16))) float swinv[3][128];
-    __shared__ __attribute__((aligned(16))) float sbias[128];            // the aggregation's bias (zeros without one)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (tid < 3 * 128) (&swinv[0][0])[tid] = winv[tid];
-    if (tid < 128) sbias[tid] = bias != nullptr ? bias[tid] : 0.f;
-    const int total_groups = plan.group_prefix[3];
-    const int per = (total_groups + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
-    const int g_begin = static_cast<int>(blockIdx.x) * per;
-    const int g_end = std::min(g_begin + per, total_groups);
-    if (g_begin >= g_end) return;
-
-    // cursor over this workgroup's phases: (group, pass, tile of the group), all wave-uniform
-    struct Cur {
-        int gi, p, t, n, type;
-        int64_t row0, r_end;                                             // first row of the group, end of the type's rows
-    };
-    auto open_group = [&](Cur& c) {                                     // (c.gi < g_end)
-        const int type = c.gi >= plan.group_prefix[2] ? 2 : (c.gi >= plan.group_prefix[1] ? 1 : 0);
-        const int first_tile = (c.gi - plan.group_prefix[type]) * G;     // within the type
-        const int type_tiles = plan.tiles.tile_prefix[type + 1] - plan.tiles.tile_prefix[type];
-        c.type = type;
-        c.n = std::min(G, type_tiles - first_tile);
-        c.row0 = plan.tiles.begin[type] + static_cast<int64_t>(first_tile) * TE;
-        c.r_end = plan.tiles.begin[type + 1];
-        c.p = 0;
-        c.t = 0;
-    };
-    auto advance = [&](Cur& c) {                                        // past the last phase the cursor repeats the last tile (read and dropped)
-        if (c.t + 1 < c.n) {
-            ++c.t;
-        } else if (c.p + 1 < PASSES) {
-            ++c.p;
-            c.t = 0;
-        } else if (c.gi + 1 < g_end) {
-            ++c.gi;
-            open_group(c);
-        }
-    };
-    int n_phases = 0;
-    {
-        Cur c;
-        for (int gi = g_begin; gi < g_end; ++gi) {
-            c.gi = gi;
-            open_group(c);
-            n_phases += PASSES * c.n;
-        }
-    }
-    // pass p contracts: 0 {deg h}; 1 {S_a, h S_a}; 2 {S_b, h S_b}; 3 {S_ab, h S_ab} (order 2: {S_ab})
-    auto blocks_of = [&](int p) { return (p == 0 || (ORDER == 2 && p == 3)) ? 1 : 2; };
-
-    role_priority(wave >= 4);
-    if (wave >= 4) {
-        // ---------------- service waves: thread -> node row of the tile, columns 4 o + 32 x .. (x < 4)
-        const int st = tid - 256, row = st >> 3, o = st & 7;
-        struct Piece { v4f hv[X], sv[X]; float d; };
-        auto load_piece = [&](const Cur& c, Piece& pc) {
-            const int64_t v = std::min(c.row0 + static_cast<int64_t>(c.t) * TE + row, c.r_end - 1);      // rows past the type's end re-read its last row (never stored)
-            const float* sp = sums + v * ld_s + (c.p > 0 ? (c.p - 1) * 128 : 0) + 4 * o;
-#pragma unroll
-            for (int x = 0; x < X; ++x) {
-                if (abl::n_no_first) {                                   // (ablation: no row loads)
-                    pc.hv[x] = pc.sv[x] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(v + x);
-                    continue;
-                }
-                pc.hv[x] = *reinterpret_cast<const v4f*>(h + v * ld_h + 4 * o + CSTR * x);
-                // (a block of the pair sums is read by exactly one pass: non-temporal, h keeps the caches)
-                pc.sv[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp + CSTR * x));
-            }
-            pc.d = deg[v];
-        };
-        // the phase's contraction values of this thread's row piece -> scaled by the row's power of two, two fp16 planes; returns the inverse of the scale
-        auto split_tile = [&](const Cur& c, const Piece& pc, int buf) {
-            typedef unsigned v2u __attribute__((ext_vector_type(2)));
-            const int nb = blocks_of(c.p);
-            if (abl::n_no_split) return 1.f;
-            v4f z[X][2];
-            float m = 0.f;
-#pragma unroll
-            for (int x = 0; x < X; ++x)
-#pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) {
-                    z[x][b2] = c.p == 0 ? pc.hv[x] * pc.d : (b2 == 0 ? pc.sv[x] : pc.hv[x] * pc.sv[x]);
-                }
-            {
-                float mx[X];                                             // (a tree, not a chain of dependent maxima)
-#pragma unroll
-                for (int x = 0; x < X; ++x) {
-                    mx[x] = fmaxf(fmaxf(fabsf(z[x][0][0]), fabsf(z[x][0][1])), fmaxf(fabsf(z[x][0][2]), fabsf(z[x][0][3])));
-                    if (nb == 2) mx[x] = fmaxf(mx[x], fmaxf(fmaxf(fabsf(z[x][1][0]), fabsf(z[x][1][1])), fmaxf(fabsf(z[x][1][2]), fabsf(z[x][1][3]))));
-                }
-                m = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
-            }
-            if (!abl::n_no_shuffle) {
-                m = fmaxf(m, __shfl_xor(m, 1));                         // the row's eight threads are eight consecutive lanes
-                m = fmaxf(m, __shfl_xor(m, 2));
-                m = fmaxf(m, __shfl_xor(m, 4));
-            }
-            float inv;
-            const float sc = scale_up_for(m, inv);
-#pragma unroll
-            for (int x = 0; x < X; ++x)
-#pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) {
-                    if (b2 >= nb) continue;
-                    unsigned h0, l0, h1, l1;
-                    split_pair_h2(z[x][b2][0] * sc, z[x][b2][1] * sc, h0, l0);
-                    split_pair_h2(z[x][b2][2] * sc, z[x][b2][3] * sc, h1, l1);
-                    const int off = row * ZRB + (((16 * b2 + 4 * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
-                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + off) = v2u{h0, h1};
-                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + ZPL + off) = v2u{l0, l1};
-                }
-            return inv;
-        };
-        v4f acc[G][X];                                                   // partial sums of this thread's row piece of every tile of the open group
-        // the partial sums of the phase before: unscaled and added to the tile's accumulators; after the last pass the row is finished and stored (no global loads in here)
-        auto finish = [&](const Cur& c, int buf, float xinv, float d, float sc) {
-            const float (*pp)[PS] = part[buf];
-            const int64_t v = c.row0 + static_cast<int64_t>(c.t) * TE + row;
-            v4f val[X];
-#pragma unroll
-            for (int x = 0; x < X; ++x) val[x] = *reinterpret_cast<const v4f*>(&pp[row][4 * o + CSTR * x]) * (*reinterpret_cast<const v4f*>(&swinv[c.type][4 * o + CSTR * x]) * xinv);
-            if (c.p == 0) {
-#pragma unroll
-                for (int x = 0; x < X; ++x) val[x] += *reinterpret_cast<const v4f*>(&sbias[4 * o + CSTR * x]) * d;
-            }
-#pragma unroll
-            for (int t = 0; t < G; ++t) {
-                if (c.t != t) continue;
-#pragma unroll
-                for (int x = 0; x < X; ++x) {
-                    if (c.p != 0) val[x] += acc[t][x];
-                    acc[t][x] = val[x];
-                }
-            }
-            if (c.p == PASSES - 1 && v < c.r_end) {
-#pragma unroll
-                for (int x = 0; x < X; ++x) *reinterpret_cast<v4f*>(out + v * ld_out + 4 * o + CSTR * x) = val[x] * sc;
-            }
-        };
-        Cur cprev, cnext, cnext2;                                        // phases s - 1, s + 1, s + 2
-        cprev.gi = g_begin;
-        open_group(cprev);
-        cnext = cprev;
-        advance(cnext);
-        cnext2 = cnext;
-        advance(cnext2);
-        Piece pc0, pc1;                                                  // values of phase m in pc<m & 1>
-        load_piece(cprev, pc0);
-        load_piece(cnext, pc1);
-        float inv_prev = 1.f, inv_cur = split_tile(cprev, pc0, 0), inv_next = 1.f;     // inverse row scales of phases s - 1, s, s + 1
-        __syncthreads();
-        const float* const sc_src = scale != nullptr ? scale : deg;
-        // phase s: images of phase s + 1 (`use`); partial sums of phase s - 1 into the accumulators (its row finished after the last pass); request: values of phase s + 2 (`fill`)
-        auto phase = [&](int s, const Piece& use, Piece& fill) {
-            // the finished phase's degree and output scale: requested FIRST and unconditionally (older than this phase's row requests: the wait for them in finish() leaves the
-            // row requests in flight), consumed after the split
-            const int64_t vp = std::min(cprev.row0 + static_cast<int64_t>(cprev.t) * TE + row, cprev.r_end - 1);
-            const float d = deg[vp];
-            float sc = sc_src[vp];
-            load_piece(cnext2, fill);
-            if (s + 1 < n_phases) inv_next = split_tile(cnext, use, (s + 1) & 1);
-            if (scale == nullptr) sc = 1.f;
-            if (s >= 1) {
-                finish(cprev, (s - 1) & 1, inv_prev, d, sc);
-                advance(cprev);
-            }
-            inv_prev = inv_cur;
-            inv_cur = inv_next;
-            cnext = cnext2;
-            advance(cnext2);
-            __syncthreads();
-        };
-        int s = 0;
-#pragma clang loop unroll(disable)
-        for (; s + 1 <= n_phases; s += 2) {
-            phase(s, pc1, pc0);
-            phase(s + 1, pc0, pc1);
-        }
-        if (s <= n_phases) phase(s, pc1, pc0);
-        return;
-    }
-
-    // ---------------- matrix waves: wave m = output columns 32 m .. + 31, the pass's whole contraction index
-    v8h wreg[2][KB][2];
-    Cur c;
-    c.gi = g_begin;
-    open_group(c);
-    __syncthreads();
-    const int arow = lane & 15, kq = lane >> 4;
-    auto plane_ptr = [&](const Cur& cw) { return wnp + static_cast<int64_t>(cw.type * 4 + cw.p) * kNodePassV4 + lane; };
-    auto load_kb = [&](const v4u* wf, int kb) {                          // the planes of k-block kb of this wave's two column tiles
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) wreg[jt][kb][pl] = __builtin_bit_cast(v8h, wf[(static_cast<int64_t>((wave * 2 + jt) * 8 + kb) * 2 + pl) * kWave]);
-    };
-    {
-        const v4u* wf = plane_ptr(c);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) load_kb(wf, kb);
-    }
-    // One tile: step = (k-block, row tile), six MFMAs on two accumulators, the fragment of the next step requested in front of them; the two row tiles alternate, so an
-    // accumulator's next product is a step away.
-    // RELOAD - the last tile of a (type, pass): the planes of the NEXT pass are requested k-block by k-block, each right behind the last MFMAs that read its registers,
-    // so that their round trips to L2 run beside the rest of this tile and the barrier instead of in front of the next pass's first MFMA (one request for all of them after
-    // the tile: 92 exposed round trips per workgroup at C3; 455 -> 441 us, same box)
-    auto tile = [&](bool reload, int s, const v4u* wf_next) {
-        const unsigned char* zp = &zplanes[s & 1][0][0][0];
-        const int kb_live = 4 * blocks_of(c.p);                          // a one-block pass skips the steps of its empty second block (uniform branches; one MFMA body)
-        int ar = arow, kqq = kq;                                         // opaque copies: the sixteen fragment offsets are re-derived per tile (hoisted out of the phase loop
-        asm volatile("" : "+v"(ar), "+v"(kqq));                          // they cost sixteen registers beside 128 of weights, and the weights spill)
-        auto fragment = [&](int step, v8h (&f)[2]) {
-            const int kb = step >> 1, rt = step & 1;
-            const unsigned char* src = zp + (16 * rt + ar) * ZRB + (((4 * kb + kqq) ^ ar) << 4);
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) f[pl] = *reinterpret_cast<const v8h*>(src + pl * ZPL);
-        };
-        v4f acc[RT][2];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
-        v8h a[2], an[2];                                                 // (fragments two steps ahead instead of one: 438 - 448 us against 441 - 447, no gain)
-        fragment(0, a);
-#pragma unroll
-        for (int step = 0; step < RT * KB; ++step) {
-            const int kb = step >> 1, rt = step & 1;
-            if (step + 1 < RT * KB) fragment(step + 1, an);              // (the fragment of a skipped step is read and dropped)
-            IHG_PIN_ORDER();
-            if (kb < kb_live && !abl::n_no_mfma) {
-#pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int jt = 0; jt < 2; ++jt)
-                        acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[jt][kb][kTermB2[term]], a[kTermA2[term]], acc[rt][jt], 0, 0, 0);
-            }
-            IHG_PIN_ORDER();
-            if (rt == RT - 1 && reload) load_kb(wf_next, kb);             // (a uniform branch around four requests: one code path, so that old and new planes share their registers)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) a[pl] = an[pl];
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) *reinterpret_cast<v4f*>(&part[s & 1][16 * rt + arow][32 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
-    };
-    for (int s = 0; s <= n_phases; ++s) {
-        if (s < n_phases) {
-            Cur cn = c;
-            advance(cn);
-            tile(s + 1 < n_phases && (cn.type != c.type || cn.p != c.p), s, plane_ptr(cn));
-            c = cn;
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The node-level forward for d = 64 / 256 (two fp16 terms per operand, like the grouped kernel): a workgroup owns 64 output columns (`part`) and up to 512 values of
-// the contraction index per pass - matrix wave m: 16 columns x 512 values = 128 weight registers - over tiles of 16 node rows.  The seven
-// source blocks X = [deg h | S_a | h S_a | S_b | h S_b | S_ab | h S_ab] come 512 / d to a pass: d = 64: ONE pass, d = 256: four launches (x 4 parts; the parts of a
-// tile range are adjacent workgroups on one XCD and share the rows through its L2).  (At d = 128 this geometry
-// measured 592 us against 543 for four passes of 256 values - one accumulator tile per matrix wave, twice the split work; d = 128 runs the grouped kernel above.)
-// A row's values of a pass go in scaled by ONE power of two (its 16 service threads agree on the largest magnitude with four shuffles), a weight row by one over the
-// type's seven blocks (node_fwd_weight_scales_kernel); the partial sums leave through the two inverses in the service threads' epilogue.
-// wnq[type][pass][part][m][kb < 16][plane < 2][lane][8 x fp16]: element i = plane of wsc[type][j] W[j][block(type, xb) d + c], j = 64 part + 16 m + (lane & 15), where
-//   kk = 32 kb + 8 (lane >> 4) + i,  xb = pass (512 / d) + kk / d,  c = kk % d     (xb > 6, or the uqi block at order 2: zeros)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int node_xblock_weight(int type, int xb) {
-    constexpr signed char kBlock[3][7] = {{0, 1, 3, 2, 5, 4, 6}, {1, 0, 3, 2, 4, 5, 6}, {2, 0, 5, 1, 4, 3, 6}};
-    return kBlock[type][xb];
-}
-
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd_q_kernel(const float* __restrict__ w, int64_t ld_w, int d, int order, const float* __restrict__ wsc,
-                                                                               v4u* __restrict__ wnq) {
-    const int bpp = 512 / d, n_pass = (7 + bpp - 1) / bpp, parts = d / 64;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 3 * n_pass * parts * 4 * 16 * kWave) return;
-    const int lane = idx & 63, kb = (idx >> 6) & 15, m = (idx >> 10) & 3;
-    int rest = idx >> 12;
-    const int part = rest % parts;
-    rest /= parts;
-    const int pass = rest % n_pass, type = rest / n_pass;
-    const int kk = 32 * kb + 8 * (lane >> 4), xb = pass * bpp + kk / d, c = kk % d;
-    int b = xb < 7 ? node_xblock_weight(type, xb) : -1;
-    if (b == 6 && order != 3) b = -1;
-    v4u hi = v4u{0u, 0u, 0u, 0u}, lo = hi;
-    if (b >= 0) {
-        const int j = 64 * part + 16 * m + (lane & 15);
-        const float sc = wsc[type * d + j];
-        const float* src = w + static_cast<int64_t>(j) * ld_w + static_cast<int64_t>(b) * d + c;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned hh, ll;
-            split_pair_h2(src[2 * i] * sc, src[2 * i + 1] * sc, hh, ll);
-            hi[i] = hh;
-            lo[i] = ll;
-        }
-    }
-    wnq[(static_cast<int64_t>(idx >> 6) * 2 + 0) * kWave + lane] = hi;
-    wnq[(static_cast<int64_t>(idx >> 6) * 2 + 1) * kWave + lane] = lo;
-}
-
-template <int D, int PASS, bool ACC, bool FINAL>
-__global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
-                                                                            const float* __restrict__ deg, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                                            const v4u* __restrict__ wnq, const float* __restrict__ winv, RowTiles plan,
-                                                                            float* __restrict__ out, int64_t ld_out) {
-    constexpr int BPP = 512 / D, XB0 = PASS * BPP, NB = (7 - XB0) < BPP ? (7 - XB0) : BPP, NPASS = (7 + BPP - 1) / BPP, PARTS = D / 64;
-    constexpr int TE = 16, KB = NB * D / 32, ZRB = (2 * NB * D + 255) / 256 * 256, ZPL = TE * ZRB, PS = 64 + 4, X = D / 64;
-    constexpr bool NEED_A = XB0 <= 2 && XB0 + NB > 1, NEED_B = XB0 <= 4 && XB0 + NB > 3, NEED_AB = XB0 + NB > 5, NEED_DEG = XB0 == 0;
-    static_assert(NB >= 1 && KB <= 16, "pass shape");
-    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][2][TE][ZRB];
-    __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
-    __shared__ __attribute__((aligned(16))) float swinv[3][64];          // inverse scales of this part's 64 weight rows, per node type
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x;
-    const int cpart = PARTS == 1 ? 0 : (bid >> 3) & (PARTS - 1);
-    const int range = PARTS == 1 ? bid : (bid & 7) + 8 * (bid / (8 * PARTS)), n_ranges = static_cast<int>(gridDim.x) / PARTS;
-    const int total_tiles = plan.tile_prefix[3];
-    const int per = (total_tiles + n_ranges - 1) / n_ranges;
-    const int t0 = range * per;
-    const int n_my = std::max(0, std::min(per, total_tiles - t0));
-    if (n_my == 0) return;
-    const int coff = 64 * cpart;
-    auto tile_rows = [&](int k, int64_t& r_base, int64_t& r_end) {      // (tiles past the range: the graph's last tile, read and dropped)
-        const int tile_id = std::min(t0 + k, total_tiles - 1);
-        const int type = tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0);
-        r_base = plan.begin[type] + static_cast<int64_t>(tile_id - plan.tile_prefix[type]) * TE;
-        r_end = plan.begin[type + 1];
-        return type;
-    };
-
-    role_priority(wave >= 4);
-    if (wave >= 4) {
-        // ---------------- service waves: thread -> node row of the tile, source columns 4 o + 64 x .. (x < D / 64), output columns coff + 4 o ..
-        const int st = tid - 256, row = st >> 4, o = st & 15;
-        if (st < 3 * 64) swinv[st >> 6][st & 63] = winv[(st >> 6) * D + coff + (st & 63)];
-        struct Piece { v4f hv[X], sa[X], sb[X], sab[X]; float d; };
-        auto load_piece = [&](int k, Piece& pc) {
-            int64_t r_base, r_end;
-            tile_rows(k, r_base, r_end);
-            const int64_t v = std::min(r_base + row, r_end - 1);
-            const float* hp = h + v * ld_h + 4 * o;
-            const float* sp = sums + v * ld_s + 4 * o;
-            if (NEED_DEG) pc.d = deg[v];
-#pragma unroll
-            for (int x = 0; x < X; ++x) {
-                pc.hv[x] = *reinterpret_cast<const v4f*>(hp + 64 * x);
-                if (NEED_A) pc.sa[x] = *reinterpret_cast<const v4f*>(sp + 64 * x);
-                if (NEED_B) pc.sb[x] = *reinterpret_cast<const v4f*>(sp + D + 64 * x);
-                if (NEED_AB) pc.sab[x] = *reinterpret_cast<const v4f*>(sp + 2 * D + 64 * x);
-            }
-        };
-        // what the epilogue of a tile adds or multiplies: requested a phase BEFORE its use, in front of that phase's row requests - the memory counter is in order,
-        // a request issued and consumed inside one phase would make the phase wait for every row request in front of it
-        struct First { v4f old; float d, sc; };
-        auto load_first = [&](int k, First& f) {
-            int64_t r_base, r_end;
-            tile_rows(k, r_base, r_end);
-            const int64_t v = std::min(r_base + row, r_end - 1);
-            if (ACC) f.old = *reinterpret_cast<const v4f*>(out + v * ld_out + coff + 4 * o);
-            else f.d = deg[v];
-            if (FINAL) f.sc = scale != nullptr ? scale[v] : 1.f;
-        };
-        const v4f bias4 = (!ACC && bias != nullptr) ? *reinterpret_cast<const v4f*>(bias + coff + 4 * o) : v4f{0.f, 0.f, 0.f, 0.f};
-        auto split_tile = [&](const Piece& pc, int buf, float& inv) {
-            typedef unsigned v2u __attribute__((ext_vector_type(2)));
-            v4f z[X][NB];
-            float m = 0.f;
-#pragma unroll
-            for (int x = 0; x < X; ++x) {
-#pragma unroll
-                for (int b2 = 0; b2 < NB; ++b2) {
-                    const int xb = XB0 + b2;
-                    z[x][b2] = xb == 0 ? pc.hv[x] * pc.d : xb == 1 ? pc.sa[x] : xb == 2 ? pc.hv[x] * pc.sa[x] : xb == 3 ? pc.sb[x] : xb == 4 ? pc.hv[x] * pc.sb[x]
-                               : xb == 5 ? pc.sab[x] : pc.hv[x] * pc.sab[x];
-                    m = fmaxf(m, fmaxf(fmaxf(fabsf(z[x][b2][0]), fabsf(z[x][b2][1])), fmaxf(fabsf(z[x][b2][2]), fabsf(z[x][b2][3]))));
-                }
-            }
-            m = fmaxf(m, __shfl_xor(m, 1));
-            m = fmaxf(m, __shfl_xor(m, 2));
-            m = fmaxf(m, __shfl_xor(m, 4));
-            m = fmaxf(m, __shfl_xor(m, 8));
-            const float sc = scale_up_for(m, inv);
-#pragma unroll
-            for (int x = 0; x < X; ++x) {
-#pragma unroll
-                for (int b2 = 0; b2 < NB; ++b2) {
-                    unsigned h0, l0, h1, l1;
-                    split_pair_h2(z[x][b2][0] * sc, z[x][b2][1] * sc, h0, l0);
-                    split_pair_h2(z[x][b2][2] * sc, z[x][b2][3] * sc, h1, l1);
-                    // columns D b2 + 64 x + 4 o ..: chunk (D / 8) b2 + 8 x + (o >> 1), half o & 1
-                    const int off = row * ZRB + ((((D / 8) * b2 + 8 * x + (o >> 1)) ^ row) << 4) + 8 * (o & 1);
-                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + off) = v2u{h0, h1};
-                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + ZPL + off) = v2u{l0, l1};
-                }
-            }
-        };
-        auto epilogue = [&](int k, const First& f, float inv) {
-            int64_t r_base, r_end;
-            const int type = tile_rows(k, r_base, r_end);
-            const int64_t v = r_base + row;
-            v4f val = *reinterpret_cast<const v4f*>(&part[k & 1][row][4 * o]) * (*reinterpret_cast<const v4f*>(&swinv[type][4 * o]) * inv);
-            if (ACC) val += f.old;
-            else val += bias4 * f.d;
-            if (FINAL) val *= f.sc;
-            if (v < r_end) *reinterpret_cast<v4f*>(out + v * ld_out + coff + 4 * o) = val;
-        };
-        Piece pc0, pc1;
-        First f0, f1;                                                    // of tile m in f<m & 1>
-        float inv0 = 1.f, inv1 = 1.f;                                    // inverse row scale of tile m in inv<m & 1>
-        load_first(0, f0);
-        load_piece(0, pc0);
-        load_piece(1, pc1);
-        split_tile(pc0, 0, inv0);
-        __syncthreads();
-        // phase k: request of tile k + 2's rows and tile k's epilogue operands; epilogue of tile k - 1 (its scale's slot is then free); images of tile k + 1
-        auto phase = [&](int k, const Piece& use, Piece& fill, First& f_req, const First& f_use, float& inv_slot) {
-            if (k >= 1) load_first(k, f_req);
-            load_piece(k + 2, fill);
-            if (k >= 1) epilogue(k - 1, f_use, inv_slot);
-            if (k + 1 < n_my) split_tile(use, (k + 1) & 1, inv_slot);
-            __syncthreads();
-        };
-        int k = 0;
-#pragma clang loop unroll(disable)
-        for (; k + 1 <= n_my; k += 2) {
-            phase(k, pc1, pc0, f0, f1, inv1);
-            phase(k + 1, pc0, pc1, f1, f0, inv0);
-        }
-        if (k <= n_my) phase(k, pc1, pc0, f0, f1, inv1);
-        return;
-    }
-
-    // ---------------- matrix waves: wave m = output columns coff + 16 m .. + 15, the pass's whole contraction index
-    v8h wreg[KB][2];
-    int cur_type = -1;
-    __syncthreads();
-    const int arow = lane & 15, kq = lane >> 4;
-    for (int k = 0; k <= n_my; ++k) {
-        if (k < n_my) {
-            int64_t r_base, r_end;
-            const int type = tile_rows(k, r_base, r_end);
-            if (type != cur_type) {
-                const v4u* wf = wnq + (static_cast<int64_t>((type * NPASS + PASS) * PARTS + cpart) * 4 + wave) * (16 * 2 * kWave) + lane;
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) wreg[kb][pl] = __builtin_bit_cast(v8h, wf[(kb * 2 + pl) * kWave]);
-                cur_type = type;
-            }
-            const unsigned char* zp = &zplanes[k & 1][0][0][0] + arow * ZRB;
-            auto fragment = [&](int kb, v8h (&a)[2]) {
-                const unsigned char* src = zp + (((4 * kb + kq) ^ arow) << 4);
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[pl] = *reinterpret_cast<const v8h*>(src + pl * ZPL);
-            };
-            v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};       // one column tile per wave: two chains, alternate products
-            v8h a[2], an[2];
-            fragment(0, a);
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                if (kb + 1 < KB) fragment(kb + 1, an);
-                IHG_PIN_ORDER();
-#pragma unroll
-                for (int term = 0; term < 3; ++term)
-                    acc[(kb + term) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[kb][kTermB2[term]], a[kTermA2[term]], acc[(kb + term) & 1], 0, 0, 0);
-                IHG_PIN_ORDER();
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) a[pl] = an[pl];
-            }
-            *reinterpret_cast<v4f*>(&part[k & 1][arow][16 * wave + 4 * kq]) = acc[0] + acc[1];
-        }
-        __syncthreads();
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // Weight gradients dW_b[j][c] = sum_e dout[e][j] z_b[e][c].  The contraction runs over the hyperedges, both operands are streams:
 // per tile of 32 hyperedges (one MFMA k-block) the dout values and the products z_b of a column HALF (the two halves of a tile range
 // are two workgroups on one XCD) are split and laid down as bf16 images, ROW-major
@@ -1588,14 +883,6 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(cons
 // accumulators for the whole kernel; nothing leaves the CU until the end (one slab per tile range, summed by interact.hip's
 // slab_reduce_kernel in a fixed order).  One barrier per tile, images double-buffered, rows requested two tiles ahead.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int tr_swizzle(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-
-__device__ __forceinline__ v8s read_tr_fragment(const unsigned char* lo, const unsigned char* hi) {
-    typedef short v4s __attribute__((ext_vector_type(4)));
-    const v4s a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)lo);
-    const v4s b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)hi);
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
 
 // The two jobs sit on different waves: waves 0-3 (one per SIMD) only read fragments and issue MFMAs - 192 per tile, block b = wave, all
 // eight 16-row tiles of dout columns - and waves 4-7 (their SIMD partners) only request, multiply, split and lay down the next tile.
@@ -1787,667 +1074,6 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_weight_split_ws_ke
             for (int r = 0; r < 4; ++r) slab[static_cast<int64_t>(16 * jt + 4 * kq + r) * NBLK * D + blk * D + HC * half + 16 * ct + c] = acc[jt][ct][r];
 }
 
-// ------------------------------------------------------------------------------------------------
-// Weight gradients of the interactive layer's product blocks at NODE level (d = 64 / 128 / 256; column parts as in the hyperedge form).  The layer's output row is
-//     y[v] = scale[v] * ( ... + P_a (h S_a) + P_b (h S_b) + L_ab S_ab + W_uqi (h S_ab) )      (node_interact_fwd_kernel),
-// so d W_block = sum over the nodes of (scale dy)[v] x X_block[v]^T with X = [h S_a | h S_b | S_ab | h S_ab] - N rows instead of E hyperedges, no
-// member gathers.  The kernel is the hyperedge form's (interact_bwd_weight_split_ws_kernel: matrix wave b = block b with 8 x 4 accumulator
-// tiles, transposed reads of row-major bf16 images, one slab per tile range) behind another front end: node rows of one type, their
-// cotangent, feature and pair-sum rows as straight streams.  A tile range belongs to ONE node type (the assignment of X blocks to the
-// blocks of w depends on the type); node_weight_reduce_kernel adds the ranges of each type into the w blocks that type's X blocks stand for.
-// ------------------------------------------------------------------------------------------------
-struct NodeRanges {
-    int64_t begin[4];      // first row of every node type
-    int range_prefix[4];   // tile ranges before type t (range_prefix[3] = ranges in all)
-};
-
-template <int D, int NBLK>
-__global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
-                                                                                   const float* __restrict__ dy, int64_t ld_dy, const float* __restrict__ dy_scale,
-                                                                                   NodeRanges plan, float* __restrict__ slabs) {
-    constexpr int TE = kSplitTE, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), HC = D / PARTS, CT = HC / 16, JT = D / 16;
-    constexpr int DRB = 2 * D < 256 ? 256 : 2 * D, ZRB = 8 * HC, DOCT = D / 64, ZX = HC / 32, DPL = TE * DRB, ZPL = TE * ZRB;
-    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][DRB];
-    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x;
-    const int half = (bid >> 3) & (PARTS - 1), range = (bid & 7) + 8 * (bid / (8 * PARTS));      // `half`: this workgroup's column part
-    const int type = range >= plan.range_prefix[2] ? 2 : (range >= plan.range_prefix[1] ? 1 : 0);
-    const int64_t r_begin = plan.begin[type], r_end = plan.begin[type + 1];
-    const int n_tiles = static_cast<int>((r_end - r_begin + TE - 1) / TE);
-    const int n_ranges = plan.range_prefix[type + 1] - plan.range_prefix[type];
-    const int per = n_ranges > 0 ? (n_tiles + n_ranges - 1) / n_ranges : 0;
-    const int t0 = (range - plan.range_prefix[type]) * per;
-    const int n_my = range < plan.range_prefix[3] ? std::max(0, std::min(per, n_tiles - t0)) : 0;
-
-    role_priority(wave >= 4);
-    if (wave >= 4) {
-        // ---------------- split waves: thread -> node row of the tile, cotangent octets o and o + 8, columns HC half + 4 o + 32 x .. of h and the pair sums
-        const int st = tid - 256, row = st >> 3, o = st & 7;
-        struct Rows {
-            v4f d[2 * DOCT], hv[ZX], sa[ZX], sb[ZX], sab[ZX];
-        };
-        auto load_rows = [&](int k, Rows& r) {
-            const int64_t first = r_begin + static_cast<int64_t>(std::min(t0 + k, n_tiles - 1)) * TE;   // tiles past the range: the type's last tile, dropped
-            const bool live = t0 + k < n_tiles && first + row < r_end;
-            const int64_t v = std::min(first + row, r_end - 1);
-            const float* src = dy + v * ld_dy + 8 * o;
-            const float sc = dy_scale != nullptr ? dy_scale[v] : 1.f;
-#pragma unroll
-            for (int x = 0; x < DOCT; ++x) {
-                r.d[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x) * sc;
-                r.d[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4) * sc;
-            }
-            if (!live) {                                                 // rows past the type's end contribute nothing
-#pragma unroll
-                for (int x = 0; x < 2 * DOCT; ++x) r.d[x] = v4f{0.f, 0.f, 0.f, 0.f};
-            }
-            const float* hp = h + v * ld_h + HC * half + 4 * o;
-            const float* sp = sums + v * ld_s + HC * half + 4 * o;
-#pragma unroll
-            for (int x = 0; x < ZX; ++x) {
-                r.hv[x] = *reinterpret_cast<const v4f*>(hp + 32 * x);
-                // (the pair sums are read once here and not again: non-temporal, so that h and dy stay cached for the member-gradient kernel that follows - 2 % there)
-                r.sa[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp + 32 * x));
-                r.sb[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp + D + 32 * x));
-                r.sab[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp + 2 * D + 32 * x));
-            }
-        };
-        const int swz = tr_swizzle(row);
-        auto split_tile = [&](const Rows& r, int buf) {
-#pragma unroll
-            for (int x = 0; x < DOCT; ++x) {
-                v4u sp[3];
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) {
-                    unsigned w[3];
-                    split_pair(r.d[2 * x + (pr >> 1)][2 * (pr & 1)], r.d[2 * x + (pr >> 1)][2 * (pr & 1) + 1], w);
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) sp[p][pr] = w[p];
-                }
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + row * DRB + 256 * ((o + 8 * x) >> 4) + ((((o + 8 * x) & 15) ^ swz) << 4)) = sp[p];
-            }
-#pragma unroll
-            for (int x = 0; x < ZX; ++x) {
-                const int og = o + 8 * x;
-#pragma unroll
-                for (int b = 0; b < NBLK; ++b) {
-                    const v4f z = b == 0 ? r.hv[x] * r.sa[x] : b == 1 ? r.hv[x] * r.sb[x] : b == 2 ? r.sab[x] : r.hv[x] * r.sab[x];
-                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                    unsigned w0[3], w1[3];
-                    split_pair(z[0], z[1], w0);
-                    split_pair(z[2], z[3], w1);
-                    const int byte = 2 * (b * HC + 4 * og);
-                    const int off = row * ZRB + 256 * (byte >> 8) + ((((byte >> 4) & 15) ^ swz) << 4) + (byte & 8);
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + p * ZPL + off) = v2u{w0[p], w1[p]};
-                }
-            }
-        };
-        if (n_my > 0) {
-            Rows r0, r1;
-            load_rows(0, r0);
-            load_rows(1, r1);
-            split_tile(r0, 0);
-            __syncthreads();
-            auto phase = [&](int k, Rows& use, Rows& fill) {
-                load_rows(k + 2, fill);
-                if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
-                __syncthreads();
-            };
-            int k = 0;
-#pragma clang loop unroll(disable)
-            for (; k + 1 < n_my; k += 2) {
-                phase(k, r1, r0);
-                phase(k + 1, r0, r1);
-            }
-            if (k < n_my) phase(k, r1, r0);
-        }
-        return;
-    }
-
-    // ---------------- matrix waves: wave = X block, 8 x 4 accumulator tiles (all 128 cotangent columns x the block's 64 columns of the half)
-    const int blk = wave;
-    v4f acc[JT][CT];
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[jt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
-    if (n_my > 0) {
-        __syncthreads();
-        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-        const int rlo = 8 * g + q, rhi = rlo + 4;
-        auto a_addr = [&](int r, int jt) { return r * DRB + 256 * (jt >> 3) + (((2 * (jt & 7) + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
-        auto b_addr = [&](int r, int ct) {
-            const int byte = 2 * (blk * HC + 16 * ct);
-            return r * ZRB + 256 * (byte >> 8) + (((((byte >> 4) & 15) + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1);
-        };
-        for (int k = 0; k < n_my; ++k) {
-            const unsigned char* dp = &dplanes[k & 1][0][0][0];
-            const unsigned char* zp = &zplanes[k & 1][0][0][0];
-            if (blk < NBLK)
-#pragma unroll
-            for (int jh = 0; jh < JT / 4; ++jh) {
-                v8s a[4][3];
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) a[jt][p] = read_tr_fragment(dp + p * DPL + a_addr(rlo, 4 * jh + jt), dp + p * DPL + a_addr(rhi, 4 * jh + jt));
-                v8s b[3], bn[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = read_tr_fragment(zp + p * ZPL + b_addr(rlo, 0), zp + p * ZPL + b_addr(rhi, 0));
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    if (ct + 1 < CT) {
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(zp + p * ZPL + b_addr(rlo, ct + 1), zp + p * ZPL + b_addr(rhi, ct + 1));
-                    }
-#pragma unroll
-                    for (int term = 0; term < 6; ++term)
-#pragma unroll
-                        for (int jt = 0; jt < 4; ++jt)
-                            acc[4 * jh + jt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jt][kTermA[term]], b[kTermB[term]], acc[4 * jh + jt][ct], 0, 0, 0);
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) b[p] = bn[p];
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (blk >= NBLK) return;
-    float* slab = slabs + static_cast<int64_t>(range) * D * NBLK * D;
-    const int c = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) slab[static_cast<int64_t>(16 * jt + 4 * kq + r) * NBLK * D + blk * D + HC * half + 16 * ct + c] = acc[jt][ct][r];
-}
-
-// dw[j][(3 + b) d + c] = sum over the node types of the sum over the type's slabs at the X block that stands for w block b there
-// (b: 0 = uq, 1 = qi, 2 = iu, 3 = uqi; fixed order: users, queries, items, slabs in range order - bitwise reproducible)
-__global__ __launch_bounds__(kBlockThreads) void node_weight_reduce_kernel(const float* __restrict__ slabs, NodeRanges plan, int d, int nblk, float* __restrict__ dw, int64_t ld_dw) {
-    constexpr signed char kPos[3][4] = {{0, 2, 1, 3}, {0, 1, 2, 3}, {2, 1, 0, 3}};      // [type][w block] -> X block
-    const int width = nblk * d;
-    const int64_t total = static_cast<int64_t>(d) * width;
-    for (int64_t base = static_cast<int64_t>(blockIdx.x) * kWave; base < total; base += static_cast<int64_t>(gridDim.x) * kWave) {
-        const int64_t idx = base + (threadIdx.x & 63);
-        const bool live = idx < total;
-        const int j = static_cast<int>((live ? idx : 0) / width), col = static_cast<int>((live ? idx : 0) - static_cast<int64_t>(j) * width);
-        const int b = col / d, c = col - b * d;
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int n = plan.range_prefix[t + 1] - plan.range_prefix[t];
-            const int64_t at = static_cast<int64_t>(j) * width + kPos[t][b] * d + c;
-            sum += slab_sum(slabs + static_cast<int64_t>(plan.range_prefix[t]) * total, n, total, at, live);
-        }
-        if ((threadIdx.x >> 6) == 0 && live) dw[static_cast<int64_t>(j) * ld_dw + 3 * static_cast<int64_t>(d) + col] = sum;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Row GEMM (node-level linear maps, d = 128): out[v] = in[v] W_t^T (+ bias_t), rows grouped by node type.  A stream over [N, d] - 1 KB
-// of traffic per row against 32 K multiply-adds - that the fp32 matrix pipe cannot feed at HBM speed and the bf16 pipe can.
-// Eight waves, wave w owns output columns 16 w .. with the whole contraction index (its weight planes: 48 registers per node type,
-// reloaded at the at most two type changes of a workgroup's tile sequence); tiles of 32 rows come in through registers two tiles
-// ahead (each thread 8 values), are split inside the previous tile's matrix phase and laid down as three bf16 images like the
-// member-gradient kernel's; the MFMA is issued as W x in^T, so a lane ends up with 4 consecutive columns of one row and stores
-// them straight from the accumulator.  One barrier per tile, two workgroups per CU.
-// pk[type][strip][kb][plane][lane][8]: element i = plane of Wt[k = 32 kb + 8 (lane >> 4) + i][c = 16 strip + (lane & 15)],
-//                                       Wt[k][c] = W_t[c][k] (transpose == 0, out = in W^T) or W_t[k][c] (transpose == 1, out = in W)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride, int n_types, int d,
-                                                                          int transpose, v4u* __restrict__ pk) {
-    const int kbs = d / 32, strips = d / 16;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_types * strips * kbs * kWave) return;
-    const int lane = idx & 63, kb = (idx >> 6) % kbs, strip = ((idx >> 6) / kbs) % strips, type = (idx >> 6) / (kbs * strips);
-    const int c = 16 * strip + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
-    const float* wt = w + type * type_stride;
-    v4f x0, x1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        x0[i] = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k0 + i] : wt[static_cast<int64_t>(k0 + i) * ld_w + c];
-        x1[i] = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k0 + 4 + i] : wt[static_cast<int64_t>(k0 + 4 + i) * ld_w + c];
-    }
-    const Planes pl = split8(x0, x1);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) pk[(static_cast<int64_t>(idx >> 6) * 3 + p) * kWave + lane] = pl.p[p];
-}
-
-// scale of every output column of the node-level linear maps (= weight row c, or column c with transpose): wsc[type][c] = scale_up_for(max_k |w(c, k)|), winv its inverse.
-// One wave per (type, c).
-__global__ __launch_bounds__(kBlockThreads) void dense_weight_scales_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride, int n_types, int d, int transpose,
-                                                                            float* __restrict__ wsc, float* __restrict__ winv) {
-    const int lane = threadIdx.x & 63;
-    const int64_t unit = global_wave_id();
-    if (unit >= static_cast<int64_t>(n_types) * d) return;
-    const int type = static_cast<int>(unit) / d, c = static_cast<int>(unit) % d;
-    const float* wt = w + type * type_stride;
-    float m = 0.f;
-    for (int k = lane; k < d; k += kWave) m = fmaxf(m, fabsf(transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k] : wt[static_cast<int64_t>(k) * ld_w + c]));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    float inv;
-    const float sc = scale_up_for(m, inv);
-    if (lane == 0) {
-        wsc[unit] = sc;
-        winv[unit] = inv;
-    }
-}
-
-// pk[type][strip][kb][plane < 2][lane][8 x fp16]: element i = plane of wsc[type][c] w(c, 32 kb + 8 (lane >> 4) + i), c = 16 strip + (lane & 15)
-__global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_h2_kernel(const float* __restrict__ w, int64_t ld_w, int64_t type_stride, int n_types, int d,
-                                                                             int transpose, const float* __restrict__ wsc, v4u* __restrict__ pk) {
-    const int kbs = d / 32, strips = d / 16;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_types * strips * kbs * kWave) return;
-    const int lane = idx & 63, kb = (idx >> 6) % kbs, strip = ((idx >> 6) / kbs) % strips, type = (idx >> 6) / (kbs * strips);
-    const int c = 16 * strip + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
-    const float* wt = w + type * type_stride;
-    const float sc = wsc[type * d + c];
-    v4u hi, lo;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float xa = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k0 + 2 * i] : wt[static_cast<int64_t>(k0 + 2 * i) * ld_w + c];
-        const float xb = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k0 + 2 * i + 1] : wt[static_cast<int64_t>(k0 + 2 * i + 1) * ld_w + c];
-        unsigned hh, ll;
-        split_pair_h2(xa * sc, xb * sc, hh, ll);
-        hi[i] = hh;
-        lo[i] = ll;
-    }
-    pk[(static_cast<int64_t>(idx >> 6) * 2 + 0) * kWave + lane] = hi;
-    pk[(static_cast<int64_t>(idx >> 6) * 2 + 1) * kWave + lane] = lo;
-}
-
-// D = 128: one workgroup covers all columns, two workgroups per CU.  D = 256: a workgroup covers a column HALF (64 weight registers per
-// wave), the two halves of a tile sequence are two workgroups on one XCD (the second read of a row hits that L2), one workgroup per CU.
-// Arithmetic: two fp16 terms per operand (node-level contraction above): a row is scaled by ONE power of two (its 16 staging threads agree on its largest magnitude with
-// four shuffles), the weights by one per output column; the accumulators leave through the two inverse scales.  Half the MFMAs and two thirds of the weight / image
-// registers of the three-bf16 form - the registers pay for a THIRD set of row pieces: a tile's rows are requested three tiles ahead and taken delivery of a whole phase
-// after the request (two tiles of 16 KB in flight per workgroup instead of one: the kernel is a stream whose rate is bytes in flight over the memory round trip).
-template <int D>
-__global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, int64_t ld_in, const v4u* __restrict__ pk,
-                                                                             int64_t pk_type_stride, const float* __restrict__ winv, const float* __restrict__ bias, int bias_mask,
-                                                                             int64_t bias_type_stride, RowTiles plan, TypedRowsOut out, int64_t ld_out, int accumulate) {
-    constexpr int TE = 32, KB = D / 32, OCT = D / 128, HALVES = D / 128, RB = 2 * D, STEPS = 2 * KB;
-    constexpr int NBUF = D == 128 ? 6 : 3;                               // sets of row pieces: a tile's rows are requested NBUF tiles ahead, NBUF - 2 tiles (16 KB each) in flight
-    __shared__ __attribute__((aligned(16))) unsigned char planes[2][2][TE][RB];
-    __shared__ float sinv[2][TE];                                        // inverse row scales of the tile whose images are in planes[.]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int total_tiles = plan.tile_prefix[3];
-    const int bid = blockIdx.x;
-    const int half = HALVES == 1 ? 0 : (bid >> 3) & 1;
-    const int seq = HALVES == 1 ? bid : (bid & 7) + 8 * (bid >> 4);
-    const int n_seq = gridDim.x / HALVES;
-    const int n_my = seq < total_tiles ? (total_tiles - seq + n_seq - 1) / n_seq : 0;
-    if (n_my == 0) return;
-    auto tile_type = [&](int tile_id) { return tile_id >= plan.tile_prefix[2] ? 2 : (tile_id >= plan.tile_prefix[1] ? 1 : 0); };
-    auto tile_rows = [&](int k, int64_t& r_base, int64_t& r_end) {      // (tiles past this workgroup's last: the last one again, read and dropped)
-        const int tile_id = seq + std::min(k, n_my - 1) * n_seq;
-        const int type = tile_type(tile_id);
-        r_base = plan.begin[type] + static_cast<int64_t>(tile_id - plan.tile_prefix[type]) * TE;
-        r_end = plan.begin[type + 1];
-        return type;
-    };
-    const int row = tid >> 4, o = tid & 15;                              // staging role: row, octets o (and o + 16) of it
-    const int chunk = (o ^ (row & 15)) << 4;
-    auto load_rows = [&](int k, v4f (&dr)[2 * OCT]) {                    // unconditional: a branch around requests makes the compiler wait for all of them
-        int64_t r_base, r_end;
-        const int type = tile_rows(k, r_base, r_end);
-        const int64_t v = std::min(r_base + row, r_end - 1);             // rows past the type's end re-read its last row (never stored)
-        const float* src = typed_base(in, type) + v * ld_in + 8 * o;
-#pragma unroll
-        for (int x = 0; x < OCT; ++x) {
-            dr[2 * x] = *reinterpret_cast<const v4f*>(src + 128 * x);
-            dr[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 128 * x + 4);
-        }
-    };
-    // the row's power-of-two scale from this thread's piece and its 15 neighbours' (the row's staging threads are 16 consecutive lanes)
-    auto row_scale = [&](const v4f (&dr)[2 * OCT], float& inv) {
-        float m = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2 * OCT; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(dr[j][0]), fabsf(dr[j][1])), fmaxf(fabsf(dr[j][2]), fabsf(dr[j][3]))));
-        m = fmaxf(m, __shfl_xor(m, 1));
-        m = fmaxf(m, __shfl_xor(m, 2));
-        m = fmaxf(m, __shfl_xor(m, 4));
-        m = fmaxf(m, __shfl_xor(m, 8));
-        return scale_up_for(m, inv);
-    };
-    v4f dbuf[NBUF][2 * OCT];                                             // row pieces of tile m in dbuf[m % NBUF] (indices are compile-time: the phases are unrolled NBUF at a time)
-#pragma unroll
-    for (int j = 0; j < NBUF; ++j) load_rows(j, dbuf[j]);
-    {
-        v4f (&d0)[2 * OCT] = dbuf[0];
-        float inv;
-        const float sc = row_scale(d0, inv);
-#pragma unroll
-        for (int x = 0; x < OCT; ++x) {
-            v4u hi, lo;
-#pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {
-                unsigned hh, ll;
-                split_pair_h2(d0[2 * x + (pr >> 1)][2 * (pr & 1)] * sc, d0[2 * x + (pr >> 1)][2 * (pr & 1) + 1] * sc, hh, ll);
-                hi[pr] = hh;
-                lo[pr] = ll;
-            }
-            *reinterpret_cast<v4u*>(&planes[0][0][row][chunk + 256 * x]) = hi;
-            *reinterpret_cast<v4u*>(&planes[0][1][row][chunk + 256 * x]) = lo;
-        }
-        if (o == 0) sinv[0][row] = inv;
-    }
-    __syncthreads();
-
-    v8h wreg[KB][2];
-    v4f wiv = v4f{1.f, 1.f, 1.f, 1.f};                                    // inverse scales of this lane's four output columns
-    v4f bv = v4f{0.f, 0.f, 0.f, 0.f};                                     // ... and their bias (per node type: loaded with the weights - a load issued and consumed inside a phase
-    int cur_type = -1;                                                    //     would make the phase wait for every row request in front of it: the memory counter is in order)
-    const int arow = lane & 15, kq = lane >> 4;
-    const int c4 = 128 * half + 16 * wave + 4 * kq;
-    // phase k: contraction of tile k; images of tile k + 1 (`use`); delivery of tile k + 2 (`arrive`, requested NBUF - 2 phases ago); request of tile k + NBUF (`fill`)
-    auto phase = [&](int k, v4f (&use)[2 * OCT], v4f (&arrive)[2 * OCT], v4f (&fill)[2 * OCT]) {
-        int64_t r_base, r_end;
-        const int type = tile_rows(k, r_base, r_end);
-        if (type != cur_type) {
-            const v4u* wf = pk + type * pk_type_stride + static_cast<int64_t>(8 * half + wave) * (KB * 2) * kWave + lane;
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) wreg[kb][p] = __builtin_bit_cast(v8h, wf[(kb * 2 + p) * kWave]);
-            wiv = *reinterpret_cast<const v4f*>(winv + type * (pk_type_stride == 0 ? 0 : D) + c4);
-            bv = v4f{0.f, 0.f, 0.f, 0.f};
-            if (bias != nullptr && ((bias_mask >> type) & 1)) bv = *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + c4);
-            cur_type = type;
-        }
-        // accumulate: `out` already holds another contribution to the same rows (out += ...): its rows of this tile are requested FIRST - older than the row requests
-        // below, so the wait for them at the end of the phase leaves those in flight
-        v4f gold[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
-        if (accumulate) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                const int64_t v = std::min(r_base + 16 * rt + arow, r_end - 1);
-                gold[rt] = *reinterpret_cast<const v4f*>(typed_base(out, type) + v * ld_out + c4);
-            }
-        }
-        load_rows(k + NBUF, fill);
-        float inv_next;
-        const float sc_next = row_scale(use, inv_next);
-        v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
-        const unsigned char* pbase = &planes[k & 1][0][0][0];
-        v4u sp[OCT][2];
-#pragma unroll
-        for (int step = 0; step < STEPS; ++step) {
-            const int kb = step >> 1, rt = step & 1;
-            v8h a[2];
-            const unsigned char* src = pbase + (16 * rt + arow) * RB + (((4 * kb + kq) ^ arow) << 4);
-#pragma unroll
-            for (int p = 0; p < 2; ++p) a[p] = *reinterpret_cast<const v8h*>(src + p * (TE * RB));
-            if (step < 4 * OCT) {   // two values of the next tile's row piece -> one dword of each plane
-                const int x = step >> 2, pr = step & 3;
-                unsigned hh, ll;
-                split_pair_h2(use[2 * x + (pr >> 1)][2 * (pr & 1)] * sc_next, use[2 * x + (pr >> 1)][2 * (pr & 1) + 1] * sc_next, hh, ll);
-                sp[x][0][pr] = hh;
-                sp[x][1][pr] = ll;
-            }
-#pragma unroll
-            for (int term = 0; term < 3; ++term)
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[kb][kTermB2[term]], a[kTermA2[term]], acc[rt], 0, 0, 0);
-        }
-        const float iv0 = sinv[k & 1][arow], iv1 = sinv[k & 1][16 + arow];
-#pragma unroll
-        for (int x = 0; x < OCT; ++x)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk + 256 * x]) = sp[x][p];     // (past the last tile: nobody reads it)
-        if (o == 0) sinv[(k + 1) & 1][row] = inv_next;
-        // delivery of the rows requested a phase ago, before the stores (the memory counter is in order: a wait behind a store sits out the store's round trip)
-        if (OCT == 1) asm volatile("" : "+v"(arrive[0]), "+v"(arrive[1]));
-        else asm volatile("" : "+v"(arrive[0]), "+v"(arrive[1]), "+v"(arrive[2 * OCT - 2]), "+v"(arrive[2 * OCT - 1]));
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const int64_t v = r_base + 16 * rt + arow;
-            if (v < r_end) *reinterpret_cast<v4f*>(typed_base(out, type) + v * ld_out + c4) = acc[rt] * (wiv * (rt == 0 ? iv0 : iv1)) + bv + gold[rt];
-        }
-        __syncthreads();
-    };
-    int k = 0;
-    for (; k + NBUF <= n_my; k += NBUF) {
-#pragma unroll
-        for (int j = 0; j < NBUF; ++j) phase(k + j, dbuf[(j + 1) % NBUF], dbuf[(j + 2) % NBUF], dbuf[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < NBUF - 1; ++j)
-        if (k + j < n_my) phase(k + j, dbuf[(j + 1) % NBUF], dbuf[(j + 2) % NBUF], dbuf[j]);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Weight gradient of the node-level linear maps: dW_t[i][j] = sum_{v of type t} dout[v][i] x[v][j], dbias_t[i] = sum_v dout[v][i].
-// Same shape of problem as the interactive weight gradient (both operands are streams, the contraction runs over the rows), same
-// machinery: row-major bf16 images with the transposed-read swizzle, ds_read_b64_tr_b16 fragments, accumulators resident for the
-// whole sweep, one slab per tile sequence (dense.hip's layout and reduction).  D = 128: a workgroup owns the whole 128 x 128 gradient
-// (wave = 2 x 4 accumulator tiles); D = 256: a workgroup owns a column half (wave = 4 x 4 tiles), both halves of a tile sequence on
-// one XCD.  The column sums of dout ride along in the staging threads' registers.  grid = (sequences x halves, 1, node types).
-// ------------------------------------------------------------------------------------------------
-// DX (d = 128): the input gradient dx = dout W_t of the same rows is formed here too - the dout images are in LDS anyway (the transposed-read
-// layout also serves row reads), wave w takes output columns 16 w .. with the type's weight planes in 48 registers - and the separate row-GEMM
-// pass over dout goes away.
-template <int D, bool DX>
-__global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(const float* __restrict__ dout, int64_t ld_dout, TypedRows x,
-                                                                                int64_t ld_x, RowTiles plan, int single_weight, float* __restrict__ slabs,
-                                                                                float* __restrict__ bias_slabs, const v4u* __restrict__ pk, int64_t pk_type_stride,
-                                                                                TypedRowsOut dx, int64_t ld_dx, int dx_accumulate) {
-    static_assert(!DX || D == 128, "the fused input gradient holds a whole weight matrix per workgroup");
-    constexpr int TE = 32, HALVES = D / 128, DOCT = D / 128, IT = D / 64, DRB = 2 * D;     // dout image rows: 2 D bytes, x image rows: 256 bytes (128 columns)
-    constexpr int DPL = TE * DRB, XPL = TE * 256;
-    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][DRB];
-    __shared__ __attribute__((aligned(16))) unsigned char xplanes[2][3][TE][256];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x, type = blockIdx.z;
-    const int half = HALVES == 1 ? 0 : (bid >> 3) & 1;
-    const int seq = HALVES == 1 ? bid : (bid & 7) + 8 * (bid >> 4);
-    const int n_seq = gridDim.x / HALVES;
-    const int64_t r_begin = single_weight ? plan.begin[0] : plan.begin[type];
-    const int64_t r_end = single_weight ? plan.begin[3] : plan.begin[type + 1];
-    const int64_t n_tiles = (r_end - r_begin + TE - 1) / TE;
-    const int n_my = seq < n_tiles ? static_cast<int>((n_tiles - seq + n_seq - 1) / n_seq) : 0;
-    const int iq = wave & 3, jh = wave >> 2;
-    // x and dx may be typed rows (TypedRows): with one weight for every node (single_weight) a tile sequence crosses the node types
-    auto row_type = [&](int64_t v) { return single_weight ? (v >= plan.begin[2] ? 2 : (v >= plan.begin[1] ? 1 : 0)) : type; };
-
-    v4f acc[IT][4];
-#pragma unroll
-    for (int it = 0; it < IT; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) acc[it][jt] = v4f{0.f, 0.f, 0.f, 0.f};
-    v4f bsum[2 * DOCT];
-#pragma unroll
-    for (int i = 0; i < 2 * DOCT; ++i) bsum[i] = v4f{0.f, 0.f, 0.f, 0.f};
-
-    const int row = tid >> 4, o = tid & 15;                              // staging role: row; dout columns 8 o .. (and 128 + 8 o ..), x columns 128 half + 8 o ..
-    struct Rows {
-        v4f d[2 * DOCT], x[2];
-    };
-    auto load_rows = [&](int k, Rows& r) {
-        const int64_t v = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE + row;
-        const bool live = v < r_end;
-        const int64_t vc = live ? v : r_end - 1;
-        const float* ds = dout + vc * ld_dout + 8 * o;
-        const float* xs = typed_base(x, row_type(vc)) + vc * ld_x + 128 * half + 8 * o;
-#pragma unroll
-        for (int i = 0; i < DOCT; ++i) {
-            r.d[2 * i] = *reinterpret_cast<const v4f*>(ds + 128 * i);
-            r.d[2 * i + 1] = *reinterpret_cast<const v4f*>(ds + 128 * i + 4);
-        }
-        r.x[0] = *reinterpret_cast<const v4f*>(xs);
-        r.x[1] = *reinterpret_cast<const v4f*>(xs + 4);
-        if (!live) {                                                     // rows past the type's end contribute nothing
-#pragma unroll
-            for (int i = 0; i < 2 * DOCT; ++i) r.d[i] = v4f{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    const int swz = tr_swizzle(row);
-    const int st_off = row * 256 + ((o ^ swz) << 4);                     // 16 bytes of a 256-byte segment of this thread's row
-    // a staged tile -> images `buf`, one pair of values per slice: slices 0 .. 4 DOCT - 1 dout (the column sums ride along), then 4 of x
-    v4u sp[3];
-    auto split_slice = [&](int slice, const Rows& r, int buf, bool counted) {
-        const bool is_x = slice >= 4 * DOCT;
-        const int s = is_x ? slice - 4 * DOCT : slice, oct = s >> 2, pr = s & 3;
-        const v4f v = is_x ? r.x[pr >> 1] : r.d[2 * oct + (pr >> 1)];
-        const float xa = v[2 * (pr & 1)], xb = v[2 * (pr & 1) + 1];
-        unsigned w[3];
-        split_pair(xa, xb, w);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) sp[p][pr] = w[p];
-        if (!is_x && (pr & 1) == 1 && counted) bsum[2 * oct + (pr >> 1)] += v;
-        if (pr == 3) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                if (is_x) *reinterpret_cast<v4u*>(&xplanes[buf][0][0][0] + p * XPL + st_off) = sp[p];
-                else *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + row * (DRB - 256) + 256 * oct + st_off) = sp[p];
-            }
-        }
-    };
-    constexpr int SLICES = 4 * DOCT + 4, STEPS = IT * 4;
-
-    if (n_my > 0) {
-        Rows r0, r1;
-        load_rows(0, r0);
-        if (n_my > 1) load_rows(1, r1);
-#pragma unroll
-        for (int s2 = 0; s2 < SLICES; ++s2) split_slice(s2, r0, 0, true);
-        __syncthreads();
-
-        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-        const int rlo = 8 * g + q, rhi = rlo + 4;
-        v8s wdx[DX ? 4 : 1][3];                                          // DX: planes of W_t[32 kb + 8 (lane >> 4) + i][16 wave + (lane & 15)]
-        if (DX) {
-            const v4u* wf = pk + (single_weight ? 0 : type) * pk_type_stride + static_cast<int64_t>(wave) * 12 * kWave + lane;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) wdx[kb][p] = __builtin_bit_cast(v8s, wf[(kb * 3 + p) * kWave]);
-        }
-        // dout columns (output rows i): tile IT iq + it -> byte 32 (IT iq + it) + 8 pp of a DRB-byte row, 256-byte segments swizzled separately
-        auto a_addr = [&](int r, int it) {
-            const int tile = IT * iq + it, seg = tile >> 3, ch = 2 * (tile & 7) + (pp >> 1);
-            return r * DRB + 256 * seg + ((ch ^ tr_swizzle(r)) << 4) + 8 * (pp & 1);
-        };
-        auto b_addr = [&](int r, int jt) { return r * 256 + (((8 * jh + 2 * jt + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
-
-        auto phase = [&](auto parity, int k, Rows& use, Rows& fill) {
-            constexpr int BUF = decltype(parity)::value;
-            // dx_accumulate: dx already holds another contribution to the same gradient (the member gradients of the interactive step); its rows
-            // of this tile seed the accumulators of the dx product at the end of the phase.  Requested BEFORE the next-but-one tile's rows: the memory
-            // counter is in order, so the wait for these at the end of the phase leaves the younger row requests in flight (issued behind them, that wait
-            // took delivery of the whole tile as well: 253 against 190 us per launch at C3)
-            v4f gold[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
-            if (DX && dx_accumulate) {
-                const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    const int64_t v = std::min(r_base + 16 * rt + (lane & 15), r_end - 1);          // (rows past the end: the last row, read and dropped)
-                    gold[rt] = *reinterpret_cast<const v4f*>(typed_base(dx, row_type(v)) + v * ld_dx + 16 * wave + 4 * (lane >> 4));
-                }
-            }
-            load_rows(std::min(k + 2, n_my - 1), fill);                  // (unconditional: a branch around requests makes the compiler wait for all of them)
-            const unsigned char* dp = &dplanes[BUF][0][0][0];
-            const unsigned char* xp = &xplanes[BUF][0][0][0];
-            v8s a[IT][3];
-#pragma unroll
-            for (int it = 0; it < IT; ++it)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) a[it][p] = read_tr_fragment(dp + p * DPL + a_addr(rlo, it), dp + p * DPL + a_addr(rhi, it));
-            v8s b[3], bn[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) b[p] = read_tr_fragment(xp + p * XPL + b_addr(rlo, 0), xp + p * XPL + b_addr(rhi, 0));
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                if (jt + 1 < 4) {
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(xp + p * XPL + b_addr(rlo, jt + 1), xp + p * XPL + b_addr(rhi, jt + 1));
-                }
-#pragma unroll
-                for (int it = 0; it < IT; ++it) {
-                    const int step = jt * IT + it;                       // the next tile's split, spread over this tile's MFMA groups
-#pragma unroll
-                    for (int s2 = step * SLICES / STEPS; s2 < (step + 1) * SLICES / STEPS; ++s2) split_slice(s2, use, BUF ^ 1, k + 1 < n_my);   // (past the last tile: stale rows, nobody reads those images)
-                }
-#pragma unroll
-                for (int term = 0; term < 6; ++term)
-#pragma unroll
-                    for (int it = 0; it < IT; ++it)
-                        acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it][kTermA[term]], b[kTermB[term]], acc[it][jt], 0, 0, 0);
-#pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = bn[p];
-            }
-            v4f gx[2];
-            if (DX) {                                                    // row reads of the same dout images: chunk 4 kb + (lane >> 4) of row 16 rt + (lane & 15)
-                const int arow = lane & 15, kq = lane >> 4;
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    gx[rt] = gold[rt];
-                    const int r = 16 * rt + arow;
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) {
-                        v8s d3[3];
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) d3[p] = *reinterpret_cast<const v8s*>(dp + p * DPL + r * DRB + (((4 * kb + kq) ^ tr_swizzle(r)) << 4));
-#pragma unroll
-                        for (int term = 0; term < 6; ++term)
-                            gx[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdx[kb][kTermB[term]], d3[kTermA[term]], gx[rt], 0, 0, 0);
-                    }
-                }
-            }
-            if (DOCT == 1) asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
-            else asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.d[2 * DOCT - 2]), "+v"(fill.d[2 * DOCT - 1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
-            if (DX) {                                                    // (after the delivery of the requested rows: the counter is in order)
-                const int arow = lane & 15, kq = lane >> 4;
-                const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    const int64_t v = r_base + 16 * rt + arow;
-                    if (v < r_end) *reinterpret_cast<v4f*>(typed_base(dx, row_type(v)) + v * ld_dx + 16 * wave + 4 * kq) = gx[rt];
-                }
-            }
-            __syncthreads();
-        };
-        for (int k = 0; k < n_my; k += 2) {
-            phase(std::integral_constant<int, 0>{}, k, r1, r0);
-            if (k + 1 < n_my) phase(std::integral_constant<int, 1>{}, k + 1, r0, r1);
-        }
-    }
-    // slab [type][sequence][i][j]; accumulator tile (it, jt): row i = 16 (IT iq + it) + 4 (lane >> 4) + r, column j = 128 half + 64 jh + 16 jt + (lane & 15)
-    float* slab = slabs + (static_cast<int64_t>(type) * n_seq + seq) * D * D;
-    const int c = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int it = 0; it < IT; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) slab[static_cast<int64_t>(16 * (IT * iq + it) + 4 * kq + r) * D + 128 * half + 64 * jh + 16 * jt + c] = acc[it][jt][r];
-    // column sums of dout: the 32 staging rows of a column meet in LDS (the images are free now) and are added in row order
-    float* red = reinterpret_cast<float*>(&dplanes[0][0][0][0]);        // [32][D] floats = 4 KB .. 32 KB
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < DOCT; ++i) {
-        *reinterpret_cast<v4f*>(red + row * D + 128 * i + 8 * o) = bsum[2 * i];
-        *reinterpret_cast<v4f*>(red + row * D + 128 * i + 8 * o + 4) = bsum[2 * i + 1];
-    }
-    __syncthreads();
-    if (half == 0 && tid < D) {
-        float sum = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < TE; ++r) sum += red[r * D + tid];
-        bias_slabs[(static_cast<int64_t>(type) * n_seq + seq) * D + tid] = sum;
-    }
-}
-
 }  // namespace
 
 // floats of workspace for the weight planes of one direction: laid out for four blocks at either order
@@ -2461,11 +1087,6 @@ bool split_arith_enabled() {                                             // read
     const char* v = std::getenv("IHG_INTERACT_ARITH");
     return v == nullptr || std::strcmp(v, "f32") != 0;
 }
-
-namespace {
-// leading dimensions the kernels' 32-bit row arithmetic takes (row_at): 16-byte rows, below 2^31 floats
-inline bool ld_ok(int64_t ld) { return ld > 0 && ld % 4 == 0 && ld < (int64_t{1} << 31); }
-}  // namespace
 
 // dim 128: either form of g; dim 64, 256: the [E, 3, d] form only
 bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout, bool user_reduced) {
@@ -2515,164 +1136,6 @@ void launch_members_split(int dim, int order, const float* h, int64_t ld_h, cons
     if (dim == 256) IHG_MEMBERS(256) else if (dim == 64) IHG_MEMBERS(64) else IHG_MEMBERS(128)
 #undef IHG_MEMBERS
     if (n_boundary_entries != nullptr) *n_boundary_entries = 2 * (dim == 64 ? 256 : kSplitRanges);     // two per tile range (d = 64: one workgroup per range, 256 ranges)
-}
-
-int64_t split_dense_plane_floats(int dim) { return dim == 128 || dim == 256 ? (3LL * 3 * dim * dim) / 2 : 0; }
-
-bool split_row_gemm_ok(int dim, const float* out, int64_t ld_out, const float* bias, int64_t bias_type_stride) {
-    return split_arith_enabled() && (dim == 128 || dim == 256) && aligned16(out) && ld_out % 4 == 0 && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0));
-}
-
-void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias,
-                           int bias_mask, int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, void* planes, hipStream_t s, int accumulate) {
-    const int n_types = w_type_stride == 0 ? 1 : 3;
-    v4u* pk = static_cast<v4u*>(planes);
-    const int items = n_types * (dim / 16) * (dim / 32) * kWave;
-    // two fp16 planes of the scaled weights, followed by the output columns' scales and their inverses ([n_types][dim] floats each)
-    float* wsc = reinterpret_cast<float*>(pk + static_cast<int64_t>(items) * 2);
-    float* winv = wsc + 3 * dim;
-    hipLaunchKernelGGL(dense_weight_scales_kernel, dim3(grid_for_waves(static_cast<int64_t>(n_types) * dim)), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types, dim, transpose,
-                       wsc, winv);
-    hipLaunchKernelGGL(pack_planes_dense_h2_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types, dim,
-                       transpose, wsc, pk);
-    RowTiles plan;
-    int acc = 0;
-    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
-    for (int t = 0; t < 3; ++t) {
-        plan.tile_prefix[t] = acc;
-        acc += static_cast<int>((type_begin[t + 1] - type_begin[t] + 31) / 32);
-    }
-    plan.tile_prefix[3] = acc;
-    if (acc == 0) return;
-    const int64_t pk_type_stride = n_types == 1 ? int64_t{0} : static_cast<int64_t>(dim / 16) * (dim / 32) * 2 * kWave;
-    if (dim == 128) {
-        hipLaunchKernelGGL(row_gemm_split_kernel<128>, dim3(std::min(acc, 256)), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, winv, bias, bias_mask, bias_type_stride, plan,
-                           out, ld_out, accumulate);
-    } else {
-        const int n_seq = std::min((acc + 7) / 8 * 8, 256);              // tile sequences: a multiple of 8, so that both halves of one land on one XCD
-        hipLaunchKernelGGL(row_gemm_split_kernel<256>, dim3(2 * n_seq), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, winv, bias, bias_mask, bias_type_stride, plan, out,
-                           ld_out, accumulate);
-    }
-}
-
-// node-level forward of the interactive layer: node_interact_fwd_grouped_kernel (d = 128), node_interact_fwd_q_kernel (d = 64 / 256)
-static int64_t node_fwd_q_v4(int dim) {                                  // v4u of the q kernel's planes
-    const int bpp = 512 / dim, n_pass = (7 + bpp - 1) / bpp, parts = dim / 64;
-    return 3LL * n_pass * parts * 4 * 16 * 2 * kWave;
-}
-
-int64_t split_node_fwd_plane_floats(int dim) {
-    if (dim != 64 && dim != 128 && dim != 256) return 0;
-    return (dim == 128 ? 3LL * 4 * kNodePassV4 : node_fwd_q_v4(dim)) * 4 + 2 * 3 * dim;     // two fp16 planes per weight + the weight rows' scales and inverses
-}
-
-bool split_node_fwd_ok(int dim, int order, int64_t ld_h, int64_t ld_s, const float* out, int64_t ld_out, const float* bias) {
-    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) && ld_ok(ld_h) && ld_ok(ld_s) && ld_ok(ld_out) && aligned16(out) &&
-           (bias == nullptr || aligned16(bias));
-}
-
-static RowTiles row_tiles(const int64_t* type_begin, int rows_per_tile) {
-    RowTiles plan;
-    int acc = 0;
-    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
-    for (int t = 0; t < 3; ++t) {
-        plan.tile_prefix[t] = acc;
-        acc += static_cast<int>((type_begin[t + 1] - type_begin[t] + rows_per_tile - 1) / rows_per_tile);
-    }
-    plan.tile_prefix[3] = acc;
-    return plan;
-}
-
-void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* deg, const float* scale, const float* bias,
-                           const float* w, int64_t ld_w, const int64_t* type_begin, float* out, int64_t ld_out, void* planes, hipStream_t s) {
-    v4u* wnp = static_cast<v4u*>(planes);
-    if (dim == 128) {
-        // the planes (2 fp16 per weight) are followed by the weight rows' scales and their inverses ([3][128] floats each)
-        float* wsc = reinterpret_cast<float*>(wnp + 3LL * 4 * kNodePassV4);
-        float* winv = wsc + 3 * 128;
-        hipLaunchKernelGGL(node_fwd_weight_scales_kernel, dim3(grid_for_waves(3 * 128)), dim3(kBlockThreads), 0, s, w, ld_w, 128, order, wsc, winv);
-        hipLaunchKernelGGL(pack_planes_node_fwd_kernel, dim3((3 * 4 * 4 * 2 * 8 * kWave + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, order, wsc, wnp);
-        const RowTiles plan = row_tiles(type_begin, 32);
-        if (plan.tile_prefix[3] == 0) return;
-        {
-            NodeGroups groups;
-            groups.tiles = plan;
-            int acc = 0;
-            for (int t = 0; t < 3; ++t) {
-                groups.group_prefix[t] = acc;
-                acc += (plan.tile_prefix[t + 1] - plan.tile_prefix[t] + kNodeGroupTiles - 1) / kNodeGroupTiles;
-            }
-            groups.group_prefix[3] = acc;
-            const int grid = std::min(acc, 256);
-            if (order == 3) hipLaunchKernelGGL(node_interact_fwd_grouped_kernel<3>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, groups, out, ld_out);
-            else hipLaunchKernelGGL(node_interact_fwd_grouped_kernel<2>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, groups, out, ld_out);
-            return;
-        }
-    }
-    const int items = static_cast<int>(node_fwd_q_v4(dim) / 2);
-    float* wsc = reinterpret_cast<float*>(wnp + node_fwd_q_v4(dim));
-    float* winv = wsc + 3 * dim;
-    hipLaunchKernelGGL(node_fwd_weight_scales_kernel, dim3(grid_for_waves(3 * dim)), dim3(kBlockThreads), 0, s, w, ld_w, dim, order, wsc, winv);
-    hipLaunchKernelGGL(pack_planes_node_fwd_q_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, order, wsc, wnp);
-    const RowTiles plan = row_tiles(type_begin, 16);
-    if (plan.tile_prefix[3] == 0) return;
-    const int parts = dim / 64;
-    const int n_ranges = std::min((plan.tile_prefix[3] + 7) / 8 * 8, 256 / parts);      // a multiple of 8: the parts of a range land on one XCD
-#define IHG_NODE_Q(D, PASS, ACC, FINAL) \
-    hipLaunchKernelGGL((node_interact_fwd_q_kernel<D, PASS, ACC, FINAL>), dim3(n_ranges * parts), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, plan, out, ld_out)
-    if (dim == 64) {
-        IHG_NODE_Q(64, 0, false, true);
-    } else {
-        IHG_NODE_Q(256, 0, false, false);
-        IHG_NODE_Q(256, 1, true, false);
-        IHG_NODE_Q(256, 2, true, false);
-        IHG_NODE_Q(256, 3, true, true);
-    }
-#undef IHG_NODE_Q
-}
-
-// node-level weight gradients of the product blocks (d = 64 / 128 / 256): see node_interact_weight_split_kernel
-static int node_weight_ranges(int dim) { return dim == 64 ? 256 : (dim == 128 ? 128 : 32); }
-
-int64_t split_node_weight_slab_floats(int dim, int order) {
-    return dim == 64 || dim == 128 || dim == 256 ? static_cast<int64_t>(node_weight_ranges(dim)) * dim * (order == 3 ? 4 : 3) * dim : 0;
-}
-
-bool split_node_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_s, int64_t ld_dy, const float* dy) {
-    return split_arith_enabled() && (dim == 64 || dim == 128 || dim == 256) && (order == 2 || order == 3) && ld_ok(ld_h) && ld_ok(ld_s) && ld_ok(ld_dy) && aligned16(dy);
-}
-
-void launch_node_weight_split(int dim, int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* dy, int64_t ld_dy, const float* dy_scale,
-                              const int64_t* type_begin, float* slabs, float* dw, int64_t ld_dw, hipStream_t s) {
-    NodeRanges plan;
-    int64_t tiles[3], total = 0;
-    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
-    for (int t = 0; t < 3; ++t) {
-        tiles[t] = (type_begin[t + 1] - type_begin[t] + kSplitTE - 1) / kSplitTE;
-        total += tiles[t];
-    }
-    // tile ranges by type in proportion to the tiles, every non-empty type at least one, `ranges` in all at most
-    const int ranges = node_weight_ranges(dim);
-    int acc = 0;
-    for (int t = 0; t < 3; ++t) {
-        int n = tiles[t] == 0 ? 0 : static_cast<int>(std::max<int64_t>(1, tiles[t] * (ranges - 2) / std::max<int64_t>(total, 1)));
-        n = static_cast<int>(std::min<int64_t>(n, tiles[t]));
-        plan.range_prefix[t] = acc;
-        acc += n;
-    }
-    plan.range_prefix[3] = acc;
-    const int nblk = order == 3 ? 4 : 3;
-#define IHG_NODE_WEIGHT(D)                                                                                                                                   \
-    {                                                                                                                                                        \
-        if (order == 3) hipLaunchKernelGGL((node_interact_weight_split_kernel<D, 4>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs); \
-        else hipLaunchKernelGGL((node_interact_weight_split_kernel<D, 3>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);           \
-    }
-    if (dim == 64) IHG_NODE_WEIGHT(64)
-    else if (dim == 128) IHG_NODE_WEIGHT(128)
-    else IHG_NODE_WEIGHT(256)
-#undef IHG_NODE_WEIGHT
-    const int total_w = dim * nblk * dim;
-    hipLaunchKernelGGL(node_weight_reduce_kernel, dim3((total_w + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, plan, dim, nblk, dw, ld_dw);
 }
 
 bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout) {
@@ -2746,35 +1209,3 @@ void launch_fwd_split(int dim, int order, const float* h, int64_t ld_h, const fl
     }
 }
 
-bool split_dense_weight_ok(int dim, const float* dout, int64_t ld_dout, const float* x, int64_t ld_x) {
-    return split_arith_enabled() && (dim == 128 || dim == 256) && aligned16(dout) && aligned16(x) && ld_dout % 4 == 0 && ld_x % 4 == 0;
-}
-
-int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, TypedRows x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs,
-                              float* bias_slabs, const float* w, int64_t ld_w, int64_t w_type_stride, const TypedRowsOut* dx_rows, int64_t ld_dx, void* planes, hipStream_t s,
-                              int dx_accumulate) {
-    const bool has_dx = dx_rows != nullptr;
-    const TypedRowsOut dx = has_dx ? *dx_rows : typed_rows_out(nullptr);
-    RowTiles plan;
-    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
-    for (int t = 0; t < 4; ++t) plan.tile_prefix[t] = 0;                 // (the kernel takes its tiles from the row ranges)
-    if (dim == 128) {
-        const int n_seq = 256;
-        if (has_dx) {                                                    // fused input gradient: planes of W for out = in W
-            v4u* pk = static_cast<v4u*>(planes);
-            const int items = n_types * 8 * 4 * kWave;
-            hipLaunchKernelGGL(pack_planes_dense_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types,
-                               dim, 1, pk);
-            hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, true>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                               n_types == 1 ? 1 : 0, slabs, bias_slabs, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 3 * kWave}, dx, ld_dx, dx_accumulate);
-        } else {
-            hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, false>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                               n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, typed_rows_out(nullptr), int64_t{0}, 0);
-        }
-        return n_seq;
-    }
-    const int n_seq = 128;
-    hipLaunchKernelGGL((dense_weight_grad_split_kernel<256, false>), dim3(2 * n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                       n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, typed_rows_out(nullptr), int64_t{0}, 0);
-    return n_seq;
-}

@@ -10,5 +10,5 @@ if [ ! -f build_ab/obj/split_base.o ] || [ -n "$(find include/ihgnn_hip.h ihgnn_
   bash tools/ab_variant.sh base > /dev/null
 fi
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wno-unused-function -I include -I ihgnn_amd/csrc "$@" -o build_ab/obj/aggregate_$name.o ihgnn_amd/csrc/aggregate.hip
-hipcc --offload-arch=gfx950 -shared -fPIC -o build_ab/lib_$name.so build_ab/obj/host.o build_ab/obj/aggregate_$name.o build_ab/obj/interact.o build_ab/obj/dense.o build_ab/obj/tail.o build_ab/obj/eval.o build_ab/obj/split_base.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o build_ab/lib_$name.so build_ab/obj/host.o build_ab/obj/aggregate_$name.o build_ab/obj/interact.o build_ab/obj/dense.o build_ab/obj/tail.o build_ab/obj/eval.o build_ab/obj/split_base.o build_ab/obj/splitnode_base.o
 echo build_ab/lib_$name.so

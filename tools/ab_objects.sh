@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_objects.sh: compile every translation unit but split_arith.hip into build_ab/obj/*.o (what tools/ab_variant.sh links its variants against)
+# tools/ab_objects.sh: compile every translation unit but split_arith.hip / split_node.hip into build_ab/obj/*.o (what tools/ab_variant.sh links its variants against)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_ab/obj

@@ -1,5 +1,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/r4
 mkdir -p $O
-OPS=layer ROUNDS=10 bash tools/ab_run.sh node_interact_fwd_grouped base wkb wkb2 base wkb wkb2 > $O/ab_wkb2.txt 2>&1
-cat $O/ab_wkb2.txt
+( time timeout 2400 python -m pytest tests -m gpu -q --durations=5 ) > $O/t_full.log 2>&1
+tail -12 $O/t_full.log
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_C3_now.json 2>/dev/null; python -c "
+import json; p=json.load(open('$O/bench_C3_now.json')); print('C3', p['ms_per_step'], p['step_bytes'])"
