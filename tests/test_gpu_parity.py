@@ -956,6 +956,39 @@ def test_full_size_properties_c2_shape():
     assert torch.equal(ops.edge_gather_sum_raw(torch.ones(lay.node_count, 4, device=dev()), lay.i3), torch.full((lay.edge_count, 4), 3.0, device=dev()))
 
 
+def test_c5_scaled_weight_gradients_whole_matrix_against_the_oracle():
+    """C5 x 0.05 (N = 500 k, E = 2.5 M, d = 256, power-law members): the interactive layer in its node-level form - pair sums, the four-launch contraction at d = 256, the
+    node-level weight-gradient kernel, the first-order blocks' gradient - with EVERY entry of d w and d bias against the CPU oracle in float64: the oracle's
+    FeatureInteractor run chunk by chunk over all 2.5 M hyperedges (autograd adds the chunks' weight gradients up), the hyperedges' cotangents formed from the
+    node-level cotangent in float64.  (The full-size C5 tests check d w through the Euler identity only.)"""
+    from ihgnn_amd import ops, synth
+    from ihgnn_amd.layout import IncidenceLayout
+    from oracle import ihgnn_ref as ref
+    order, d, k = 3, synth.CONFIGS['C5']['dim'], 7
+    w_ = synth.draw_config('C5', scale=0.05)
+    lay = IncidenceLayout(w_.triples, w_.user_count, w_.query_count, w_.item_count, dev())
+    gen = torch.Generator().manual_seed(29)
+    h = torch.randn(lay.node_count, d, generator=gen) / 4
+    w = torch.randn(d, k * d, generator=gen) / np.sqrt(k * d)
+    b = torch.randn(d, generator=gen)
+    cot = torch.randn(lay.node_count, d, generator=gen)
+    hd, wd, bd = h.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+    ops.interact_layer(hd, wd, bd, lay, order, lay.inv_deg).backward(cot.to(dev()))
+    # oracle: Y[v] = Dv^-1[v] sum_{e in v} F(e), so dF[e] = sum over e's members of Dv^-1[m] dY[m]
+    i3 = torch.from_numpy(lay.i3_host.astype(np.int64))
+    sdy = cot.double() * lay.inv_deg.cpu().double()[:, None]
+    h64, w64, b64 = h.double(), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    step = 100_000
+    for e0 in range(0, lay.edge_count, step):
+        idx = i3[e0:e0 + step]
+        dF = sdy[idx[:, 0]] + sdy[idx[:, 1]] + sdy[idx[:, 2]]
+        (ref.feature_interactor(h64, idx, w64, b64, order) * dF).sum().backward()
+    assert rel(wd.grad, w64.grad) <= RTOL and row_rel(wd.grad, w64.grad) <= ROW_RTOL
+    for blk in range(k):                                                  # every block on its own: a small block must not hide behind a large one
+        assert rel(wd.grad[:, blk * d:(blk + 1) * d], w64.grad[:, blk * d:(blk + 1) * d]) <= RTOL, blk
+    assert rel(bd.grad, b64.grad) <= RTOL
+
+
 @pytest.mark.parametrize('config,scale,order', [('C2', 1.0, 3), ('C3', 1.0, 3), ('C3', 1.0, 2), ('C4', 1.0, 3), ('C5', 0.05, 3)])
 def test_full_size_properties_bench_workload(config, scale, order):
     """The bench.py workloads themselves - C2 stand-in (E = 1.35 M, d = 64), C3 stand-in (E = 2.2 M, d = 128, = the per-GPU
