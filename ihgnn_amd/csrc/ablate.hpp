@@ -67,5 +67,20 @@ constexpr bool n_no_shuffle = true;
 #else
 constexpr bool n_no_shuffle = false;
 #endif
-constexpr bool any = n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
+#ifdef IHG_ABL_N_NO_SERVICE        // node-level contraction: the service waves only keep the barriers (the matrix waves' time on their own)
+constexpr bool n_no_service = true;
+#else
+constexpr bool n_no_service = false;
+#endif
+#ifdef IHG_ABL_N_NO_FRAGMENTS      // node-level contraction: the matrix waves read no fragments from LDS (one set, read once)
+constexpr bool n_no_fragments = true;
+#else
+constexpr bool n_no_fragments = false;
+#endif
+#ifdef IHG_ABL_N_NO_RELOAD         // node-level contraction: the weight planes are loaded once per workgroup
+constexpr bool n_no_reload = true;
+#else
+constexpr bool n_no_reload = false;
+#endif
+constexpr bool any = n_no_service || n_no_fragments || n_no_reload || n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
 }  // namespace abl

@@ -202,10 +202,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         auto split_tile = [&](const v4f (&dr)[2 * DOCT], int buf) {
             float m = 0.f;
 #pragma unroll
-            for (int j = 0; j < 2 * DOCT; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(dr[j][0]), fabsf(dr[j][1])), fmaxf(fabsf(dr[j][2]), fabsf(dr[j][3]))));
-            m = fmaxf(m, __shfl_xor(m, 1));
-            m = fmaxf(m, __shfl_xor(m, 2));
-            m = fmaxf(m, __shfl_xor(m, 4));
+            for (int j = 0; j < 2 * DOCT; ++j) m = abs_max3(dr[j][2], dr[j][3], abs_max3(dr[j][0], dr[j][1], m));
+            m = row_lanes_max<8>(m);
             float inv;
             const float sc = abl::m_no_split ? 1.f : scale_up_for(m, inv);
 #pragma unroll

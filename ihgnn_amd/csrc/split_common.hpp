@@ -115,6 +115,32 @@ __device__ __forceinline__ void split_pair_h2(float xa, float xb, unsigned& hi, 
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }
+// The largest magnitude of a row piece and of the row, for scale_up_for().  fmaxf() costs a canonicalising v_max per operand under IEEE mode (a third of the
+// instructions of the maximum); v_max3_f32 with |.| modifiers takes two values per instruction.  m >= 0 throughout, so across lanes the maximum is taken on the bit
+// patterns (unsigned order = float order) with DPP moves inside the row's lanes - no LDS round trip (ds_bpermute, three or four in series, each waited for in order).
+__device__ __forceinline__ float abs_max3(float a, float b, float m) {
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+    return r;
+}
+__device__ __forceinline__ float abs_max_of(v4f a, v4f b, float m) { return abs_max3(b[2], b[3], abs_max3(b[0], b[1], abs_max3(a[2], a[3], abs_max3(a[0], a[1], m)))); }
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned u) {
+    const unsigned other = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), CTRL, 0xf, 0xf, true));
+    return u > other ? u : other;
+}
+// maximum over the 8 (16) consecutive lanes that hold one row: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror (, row_mirror)
+template <int LANES>
+__device__ __forceinline__ float row_lanes_max(float m) {
+    static_assert(LANES == 8 || LANES == 16, "a row's threads are 8 or 16 consecutive lanes");
+    unsigned u = __float_as_uint(m);
+    u = dpp_max_u32<0xB1>(u);
+    u = dpp_max_u32<0x4E>(u);
+    u = dpp_max_u32<0x141>(u);
+    if (LANES == 16) u = dpp_max_u32<0x140>(u);
+    return __uint_as_float(u);
+}
+
 // partial products in accumulation order (A plane, B plane): smallest first; planes: 0 = hi, 1 = lo
 __device__ constexpr int kTermA2[3] = {0, 1, 0};
 __device__ constexpr int kTermB2[3] = {1, 0, 0};

@@ -193,25 +193,30 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
             if (abl::n_no_split) return 1.f;
             v4f z[X][2];
             float m = 0.f;
-#pragma unroll
-            for (int x = 0; x < X; ++x)
-#pragma unroll
-                for (int b2 = 0; b2 < 2; ++b2) {
-                    z[x][b2] = c.p == 0 ? pc.hv[x] * pc.d : (b2 == 0 ? pc.sv[x] : pc.hv[x] * pc.sv[x]);
-                }
-            {
-                float mx[X];                                             // (a tree, not a chain of dependent maxima)
+            // the pass kind is wave-uniform: a real branch per kind (the empty asm keeps the compiler from flattening it into 58 selects + the products of both kinds)
+            if (c.p == 0) {
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int x = 0; x < X; ++x) {
-                    mx[x] = fmaxf(fmaxf(fabsf(z[x][0][0]), fabsf(z[x][0][1])), fmaxf(fabsf(z[x][0][2]), fabsf(z[x][0][3])));
-                    if (nb == 2) mx[x] = fmaxf(mx[x], fmaxf(fmaxf(fabsf(z[x][1][0]), fabsf(z[x][1][1])), fmaxf(fabsf(z[x][1][2]), fabsf(z[x][1][3]))));
+                    z[x][0] = pc.hv[x] * pc.d;
+                    z[x][1] = v4f{0.f, 0.f, 0.f, 0.f};
                 }
+            } else {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int x = 0; x < X; ++x) {
+                    z[x][0] = pc.sv[x];
+                    z[x][1] = pc.hv[x] * pc.sv[x];
+                }
+            }
+            {
+                float mx[X];                                             // (four chains, not one of sixteen dependent maxima; the second block of a one-block pass is zeros)
+#pragma unroll
+                for (int x = 0; x < X; ++x) mx[x] = abs_max_of(z[x][0], z[x][1], 0.f);
                 m = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
             }
             if (!abl::n_no_shuffle) {
-                m = fmaxf(m, __shfl_xor(m, 1));                         // the row's eight threads are eight consecutive lanes
-                m = fmaxf(m, __shfl_xor(m, 2));
-                m = fmaxf(m, __shfl_xor(m, 4));
+                m = row_lanes_max<8>(m);                                 // the row's eight threads are eight consecutive lanes
             }
             float inv;
             const float sc = scale_up_for(m, inv);
@@ -241,13 +246,17 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
 #pragma unroll
                 for (int x = 0; x < X; ++x) val[x] += *reinterpret_cast<const v4f*>(&sbias[4 * o + CSTR * x]) * d;
             }
+            // the open group's tile c.t (wave-uniform): a real branch per tile - flattened into selects (which the compiler does to bodies this small) the update costs
+            // 2 x 16 x G v_cndmask per phase and thread, two thirds of the service waves' vector instructions; the empty asm keeps the bodies from being if-converted
 #pragma unroll
             for (int t = 0; t < G; ++t) {
-                if (c.t != t) continue;
+                if (c.t == t) {
+                    asm volatile("" ::: "memory");
 #pragma unroll
-                for (int x = 0; x < X; ++x) {
-                    if (c.p != 0) val[x] += acc[t][x];
-                    acc[t][x] = val[x];
+                    for (int x = 0; x < X; ++x) {
+                        if (c.p != 0) val[x] += acc[t][x];
+                        acc[t][x] = val[x];
+                    }
                 }
             }
             if (c.p == PASSES - 1 && v < c.r_end) {
@@ -270,6 +279,12 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
         const float* const sc_src = scale != nullptr ? scale : deg;
         // phase s: images of phase s + 1 (`use`); partial sums of phase s - 1 into the accumulators (its row finished after the last pass); request: values of phase s + 2 (`fill`)
         auto phase = [&](int s, const Piece& use, Piece& fill) {
+            if (abl::n_no_service) {                                     // (one word of the partial sums read and - never - stored: the matrix waves' work stays observable)
+                const float probe = part[s & 1][row][4 * o];
+                if (probe == 1.2345e30f) out[0] = probe;
+                __syncthreads();
+                return;
+            }
             // the finished phase's degree and output scale: requested FIRST and unconditionally (older than this phase's row requests: the wait for them in finish() leaves the
             // row requests in flight), consumed after the split
             const int64_t vp = std::min(cprev.row0 + static_cast<int64_t>(cprev.t) * TE + row, cprev.r_end - 1);
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
 #pragma unroll
         for (int step = 0; step < RT * KB; ++step) {
             const int kb = step >> 1, rt = step & 1;
-            if (step + 1 < RT * KB) fragment(step + 1, an);              // (the fragment of a skipped step is read and dropped)
+            if (step + 1 < RT * KB && !abl::n_no_fragments) fragment(step + 1, an);      // (the fragment of a skipped step is read and dropped)
             IHG_PIN_ORDER();
             if (kb < kb_live && !abl::n_no_mfma) {
 #pragma unroll
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
         if (s < n_phases) {
             Cur cn = c;
             advance(cn);
-            tile(s + 1 < n_phases && (cn.type != c.type || cn.p != c.p), s, plane_ptr(cn));
+            tile(!abl::n_no_reload && s + 1 < n_phases && (cn.type != c.type || cn.p != c.p), s, plane_ptr(cn));
             c = cn;
         }
         __syncthreads();
@@ -494,13 +509,10 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(cons
                     const int xb = XB0 + b2;
                     z[x][b2] = xb == 0 ? pc.hv[x] * pc.d : xb == 1 ? pc.sa[x] : xb == 2 ? pc.hv[x] * pc.sa[x] : xb == 3 ? pc.sb[x] : xb == 4 ? pc.hv[x] * pc.sb[x]
                                : xb == 5 ? pc.sab[x] : pc.hv[x] * pc.sab[x];
-                    m = fmaxf(m, fmaxf(fmaxf(fabsf(z[x][b2][0]), fabsf(z[x][b2][1])), fmaxf(fabsf(z[x][b2][2]), fabsf(z[x][b2][3]))));
+                    m = abs_max3(z[x][b2][2], z[x][b2][3], abs_max3(z[x][b2][0], z[x][b2][1], m));
                 }
             }
-            m = fmaxf(m, __shfl_xor(m, 1));
-            m = fmaxf(m, __shfl_xor(m, 2));
-            m = fmaxf(m, __shfl_xor(m, 4));
-            m = fmaxf(m, __shfl_xor(m, 8));
+            m = row_lanes_max<16>(m);
             const float sc = scale_up_for(m, inv);
 #pragma unroll
             for (int x = 0; x < X; ++x) {
@@ -901,11 +913,8 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
     auto row_scale = [&](const v4f (&dr)[2 * OCT], float& inv) {
         float m = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2 * OCT; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(dr[j][0]), fabsf(dr[j][1])), fmaxf(fabsf(dr[j][2]), fabsf(dr[j][3]))));
-        m = fmaxf(m, __shfl_xor(m, 1));
-        m = fmaxf(m, __shfl_xor(m, 2));
-        m = fmaxf(m, __shfl_xor(m, 4));
-        m = fmaxf(m, __shfl_xor(m, 8));
+        for (int j = 0; j < 2 * OCT; ++j) m = abs_max3(dr[j][2], dr[j][3], abs_max3(dr[j][0], dr[j][1], m));
+        m = row_lanes_max<16>(m);
         return scale_up_for(m, inv);
     };
     v4f dbuf[NBUF][2 * OCT];                                             // row pieces of tile m in dbuf[m % NBUF] (indices are compile-time: the phases are unrolled NBUF at a time)

@@ -1,3 +1,7 @@
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r4
-( time timeout 1500 python -m pytest tests/test_gpu_parity.py -q -x -k "c5_scaled_weight_gradients" ) 2>&1 | tail -15
+O=gpurun_out/r4
+mkdir -p $O
+( time timeout 2400 python -m pytest tests -m gpu -q -x --durations=3 ) > $O/t_full.log 2>&1
+tail -8 $O/t_full.log
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_C3_now.json 2>/dev/null; python -c "
+import json; p=json.load(open('$O/bench_C3_now.json')); print('C3', p['ms_per_step'], {n:v['avg_us'] for n,v in p['kernels_us'].items() if v['avg_us']>80})"
