@@ -389,12 +389,333 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
 }
 
 // ------------------------------------------------------------------------------------------------
-// The node-level forward for d = 64 / 256 (two fp16 terms per operand, like the grouped kernel): a workgroup owns 64 output columns (`part`) and up to 512 values of
-// the contraction index per pass - matrix wave m: 16 columns x 512 values = 128 weight registers - over tiles of 16 node rows.  The seven
-// source blocks X = [deg h | S_a | h S_a | S_b | h S_b | S_ab | h S_ab] come 512 / d to a pass: d = 64: ONE pass, d = 256: four launches (x 4 parts; the parts of a
-// tile range are adjacent workgroups on one XCD and share the rows through its L2).  (At d = 128 this geometry
-// measured 592 us against 543 for four passes of 256 values - one accumulator tile per matrix wave, twice the split work; d = 128 runs the grouped kernel above.)
-// A row's values of a pass go in scaled by ONE power of two (its 16 service threads agree on the largest magnitude with four shuffles), a weight row by one over the
+// The same one-launch scheme at d = 256.  A matrix wave's 128 weight registers hold the planes of 128 values of the contraction index for 64 output columns, so a pass
+// is HALF a source block: 14 passes (order 2: 12) - {deg h} x 2 halves, then for each of the three pair sums S: {S half 0}, {h S half 0}, {S half 1}, {h S half 1} (the two
+// passes that read one half of S are neighbours: its second read comes out of L2) - over groups of FOUR 32-row tiles: a service thread keeps one row x 32 output columns of
+// every tile of the group (128 registers) and forms / splits 16 contraction values per phase.  Every value is split ONCE per row (the four-launch kernel below splits it in
+// each of its four column parts) and `out` is written once (four launches: read-modify-written four times).
+// wnx[type][pass][m][jt < 4][kb < 4][plane < 2][lane][8 x fp16]: element i = plane of wsc[type][j] W[j][block(type, xb) d + 128 half + 32 kb + 8 (lane >> 4) + i],
+// j = 64 m + 16 jt + (lane & 15), (xb, half) = node_pass256(pass)
+// ------------------------------------------------------------------------------------------------
+constexpr int kNodeGroupTiles256 = 4;
+
+__device__ __forceinline__ int node_xblock_weight(int type, int xb);
+
+// pass -> source block xb of X = [deg h | S_a | h S_a | S_b | h S_b | S_ab | h S_ab] and half of its 256 columns (order 3: 14 passes; order 2 has no h S_ab: its passes
+// 10, 11 are the two halves of S_ab - handled by the callers)
+__device__ __forceinline__ void node_pass256(int p, int& xb, int& half) {
+    if (p < 2) {
+        xb = 0;
+        half = p;
+    } else {
+        const int q = p - 2, sb = q >> 2, r = q & 3;
+        xb = 1 + 2 * sb + (r & 1);
+        half = r >> 1;
+    }
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(kBlockThreads) void pack_planes_node_fwd256_kernel(const float* __restrict__ w, int64_t ld_w, const float* __restrict__ wsc, v4u* __restrict__ wnx) {
+    constexpr int PASSES = ORDER == 3 ? 14 : 12;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * PASSES * 4 * 4 * 4 * kWave) return;
+    const int lane = idx & 63, kb = (idx >> 6) & 3, jt = (idx >> 8) & 3, m = (idx >> 10) & 3, pass = (idx >> 12) % PASSES, type = (idx >> 12) / PASSES;
+    int xb, half;
+    if (ORDER == 3) {
+        node_pass256(pass, xb, half);
+    } else if (pass < 10) {
+        node_pass256(pass, xb, half);
+    } else {                                                             // order 2: S_ab half 0, half 1
+        xb = 5;
+        half = pass - 10;
+    }
+    const int b = node_xblock_weight(type, xb);
+    const int j = 64 * m + 16 * jt + (lane & 15);
+    const float sc = wsc[type * 256 + j];
+    const float* src = w + static_cast<int64_t>(j) * ld_w + b * 256 + 128 * half + 32 * kb + 8 * (lane >> 4);
+    v4u hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned hh, ll;
+        split_pair_h2(src[2 * i] * sc, src[2 * i + 1] * sc, hh, ll);
+        hi[i] = hh;
+        lo[i] = ll;
+    }
+    wnx[(static_cast<int64_t>(idx >> 6) * 2 + 0) * kWave + lane] = hi;
+    wnx[(static_cast<int64_t>(idx >> 6) * 2 + 1) * kWave + lane] = lo;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped256_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
+                                                                                     const float* __restrict__ deg, const float* __restrict__ scale,
+                                                                                     const float* __restrict__ bias, const v4u* __restrict__ wnx,
+                                                                                     const float* __restrict__ winv, NodeGroups plan, float* __restrict__ out, int64_t ld_out) {
+    constexpr int D = 256, G = kNodeGroupTiles256, TE = 32, RT = 2, JT = 4, KB = 4, CSTR = 32, ZRB = 256, ZPL = TE * ZRB, PS = D + 4, X = 4, XO = 8;
+    constexpr int PASSES = ORDER == 3 ? 14 : 12, PASS_V4 = 4 * JT * KB * 2 * kWave;
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][2][TE][ZRB];
+    __shared__ __attribute__((aligned(16))) float part[2][TE][PS];
+    __shared__ __attribute__((aligned(16))) float swinv[3][D];
+    __shared__ __attribute__((aligned(16))) float sbias[D];              // the aggregation's bias (zeros without one)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 3 * D; i += kSplitThreads) (&swinv[0][0])[i] = winv[i];
+    if (tid < D) sbias[tid] = bias != nullptr ? bias[tid] : 0.f;
+    const int total_groups = plan.group_prefix[3];
+    const int per = (total_groups + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+    const int g_begin = static_cast<int>(blockIdx.x) * per;
+    const int g_end = std::min(g_begin + per, total_groups);
+    if (g_begin >= g_end) return;
+
+    // cursor over this workgroup's phases: (group, pass, tile of the group), all wave-uniform; xb / half: the pass's source block and column half
+    struct Cur {
+        int gi, p, t, n, type, xb, half;
+        int64_t row0, r_end;                                             // first row of the group, end of the type's rows
+    };
+    auto set_pass = [&](Cur& c) {
+        if (ORDER == 2 && c.p >= 10) {
+            c.xb = 5;
+            c.half = c.p - 10;
+        } else {
+            node_pass256(c.p, c.xb, c.half);
+        }
+    };
+    auto open_group = [&](Cur& c) {                                     // (c.gi < g_end)
+        const int type = c.gi >= plan.group_prefix[2] ? 2 : (c.gi >= plan.group_prefix[1] ? 1 : 0);
+        const int first_tile = (c.gi - plan.group_prefix[type]) * G;     // within the type
+        const int type_tiles = plan.tiles.tile_prefix[type + 1] - plan.tiles.tile_prefix[type];
+        c.type = type;
+        c.n = std::min(G, type_tiles - first_tile);
+        c.row0 = plan.tiles.begin[type] + static_cast<int64_t>(first_tile) * TE;
+        c.r_end = plan.tiles.begin[type + 1];
+        c.p = 0;
+        c.t = 0;
+        set_pass(c);
+    };
+    auto advance = [&](Cur& c) {                                        // past the last phase the cursor repeats the last tile (read and dropped)
+        if (c.t + 1 < c.n) {
+            ++c.t;
+        } else if (c.p + 1 < PASSES) {
+            ++c.p;
+            c.t = 0;
+            set_pass(c);
+        } else if (c.gi + 1 < g_end) {
+            ++c.gi;
+            open_group(c);
+        }
+    };
+    int n_phases = 0;
+    {
+        Cur c;
+        for (int gi = g_begin; gi < g_end; ++gi) {
+            c.gi = gi;
+            open_group(c);
+            n_phases += PASSES * c.n;
+        }
+    }
+
+    role_priority(wave >= 4);
+    if (wave >= 4) {
+        // ---------------- service waves: thread -> node row of the tile; contraction values at columns 128 half + 4 o + 32 x (x < 4), output columns 4 o + 32 x (x < 8)
+        const int st = tid - 256, row = st >> 3, o = st & 7;
+        struct Piece { v4f hv[X], sv[X]; float d; };
+        // both operands are requested in every pass (a branch around requests makes the compiler wait for all of them): a pass that does not use one reads bytes its
+        // neighbours use anyway
+        auto load_piece = [&](const Cur& c, Piece& pc) {
+            const int64_t v = std::min(c.row0 + static_cast<int64_t>(c.t) * TE + row, c.r_end - 1);      // rows past the type's end re-read its last row (never stored)
+            const int sb = c.xb > 0 ? (c.xb - 1) >> 1 : 0;
+            const float* hp = h + v * ld_h + 128 * c.half + 4 * o;
+            const float* sp = sums + v * ld_s + sb * D + 128 * c.half + 4 * o;
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+                pc.hv[x] = *reinterpret_cast<const v4f*>(hp + CSTR * x);
+                pc.sv[x] = *reinterpret_cast<const v4f*>(sp + CSTR * x);
+            }
+            pc.d = deg[v];
+        };
+        // the phase's contraction values of this thread's row piece -> scaled by the row's power of two, two fp16 planes; returns the inverse of the scale
+        auto split_tile = [&](const Cur& c, const Piece& pc, int buf) {
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            v4f z[X];
+            // the pass kind is wave-uniform: a real branch per kind (the empty asm keeps the compiler from flattening it into selects + the products of every kind)
+            if (c.xb == 0) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int x = 0; x < X; ++x) z[x] = pc.hv[x] * pc.d;
+            } else if (c.xb & 1) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int x = 0; x < X; ++x) z[x] = pc.sv[x];
+            } else {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int x = 0; x < X; ++x) z[x] = pc.hv[x] * pc.sv[x];
+            }
+            float m = fmaxf(abs_max_of(z[0], z[1], 0.f), abs_max_of(z[2], z[3], 0.f));
+            m = row_lanes_max<8>(m);                                     // the row's eight threads are eight consecutive lanes
+            float inv;
+            const float sc = scale_up_for(m, inv);
+#pragma unroll
+            for (int x = 0; x < X; ++x) {
+                unsigned h0, l0, h1, l1;
+                split_pair_h2(z[x][0] * sc, z[x][1] * sc, h0, l0);
+                split_pair_h2(z[x][2] * sc, z[x][3] * sc, h1, l1);
+                const int off = row * ZRB + (((4 * x + (o >> 1)) ^ (row & 15)) << 4) + 8 * (o & 1);
+                *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + off) = v2u{h0, h1};
+                *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + ZPL + off) = v2u{l0, l1};
+            }
+            return inv;
+        };
+        v4f acc[G][XO];                                                  // partial sums of this thread's row piece of every tile of the open group
+        // the partial sums of the phase before: unscaled and added to the tile's accumulators; after the last pass the row is finished and stored (no global loads in here).
+        // In two halves of four 16-byte pieces: one set of temporaries live at a time.
+        auto finish = [&](const Cur& c, int buf, float xinv, float d, float sc) {
+            const float (*pp)[PS] = part[buf];
+            const int64_t v = c.row0 + static_cast<int64_t>(c.t) * TE + row;
+#pragma unroll
+            for (int hx = 0; hx < XO; hx += 4) {
+                v4f val[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    val[x] = *reinterpret_cast<const v4f*>(&pp[row][4 * o + CSTR * (hx + x)]) * (*reinterpret_cast<const v4f*>(&swinv[c.type][4 * o + CSTR * (hx + x)]) * xinv);
+                if (c.p == 0) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) val[x] += *reinterpret_cast<const v4f*>(&sbias[4 * o + CSTR * (hx + x)]) * d;
+                }
+#pragma unroll
+                for (int t = 0; t < G; ++t) {
+                    if (c.t == t) {
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            if (c.p != 0) val[x] += acc[t][hx + x];
+                            acc[t][hx + x] = val[x];
+                        }
+                    }
+                }
+                if (c.p == PASSES - 1 && v < c.r_end) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) *reinterpret_cast<v4f*>(out + v * ld_out + 4 * o + CSTR * (hx + x)) = val[x] * sc;
+                }
+            }
+        };
+        Cur cprev, cnext, cnext2;                                        // phases s - 1, s + 1, s + 2
+        cprev.gi = g_begin;
+        open_group(cprev);
+        cnext = cprev;
+        advance(cnext);
+        cnext2 = cnext;
+        advance(cnext2);
+        Piece pc0, pc1;                                                  // values of phase m in pc<m & 1>
+        load_piece(cprev, pc0);
+        load_piece(cnext, pc1);
+        float inv_prev = 1.f, inv_cur = split_tile(cprev, pc0, 0), inv_next = 1.f;     // inverse row scales of phases s - 1, s, s + 1
+        __syncthreads();
+        const float* const sc_src = scale != nullptr ? scale : deg;
+        // phase s: images of phase s + 1 (`use`); partial sums of phase s - 1 into the accumulators (its row finished after the last pass); request: values of phase s + 2 (`fill`)
+        auto phase = [&](int s, const Piece& use, Piece& fill) {
+            // the finished phase's degree and output scale: requested FIRST and unconditionally (older than this phase's row requests: the wait for them in finish() leaves the
+            // row requests in flight), consumed after the split
+            const int64_t vp = std::min(cprev.row0 + static_cast<int64_t>(cprev.t) * TE + row, cprev.r_end - 1);
+            const float d = deg[vp];
+            float sc = sc_src[vp];
+            load_piece(cnext2, fill);
+            if (s + 1 < n_phases) inv_next = split_tile(cnext, use, (s + 1) & 1);
+            if (scale == nullptr) sc = 1.f;
+            if (s >= 1) {
+                finish(cprev, (s - 1) & 1, inv_prev, d, sc);
+                advance(cprev);
+            }
+            inv_prev = inv_cur;
+            inv_cur = inv_next;
+            cnext = cnext2;
+            advance(cnext2);
+            __syncthreads();
+        };
+        int s = 0;
+#pragma clang loop unroll(disable)
+        for (; s + 1 <= n_phases; s += 2) {
+            phase(s, pc1, pc0);
+            phase(s + 1, pc0, pc1);
+        }
+        if (s <= n_phases) phase(s, pc1, pc0);
+        return;
+    }
+
+    // ---------------- matrix waves: wave m = output columns 64 m .. + 63, the pass's 128 contraction values
+    v8h wreg[JT][KB][2];
+    Cur c;
+    c.gi = g_begin;
+    open_group(c);
+    __syncthreads();
+    const int arow = lane & 15, kq = lane >> 4;
+    auto plane_ptr = [&](const Cur& cw) { return wnx + static_cast<int64_t>(cw.type * PASSES + cw.p) * PASS_V4 + lane; };
+    auto load_kb = [&](const v4u* wf, int kb) {                          // the planes of k-block kb of this wave's four column tiles
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wreg[jt][kb][pl] = __builtin_bit_cast(v8h, wf[(static_cast<int64_t>((wave * JT + jt) * KB + kb) * 2 + pl) * kWave]);
+    };
+    {
+        const v4u* wf = plane_ptr(c);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) load_kb(wf, kb);
+    }
+    // one tile: step = (k-block, row tile), twelve MFMAs on four accumulators, the fragment of the next step requested in front of them; `reload`: the last tile of a
+    // (type, pass) - the next pass's planes requested k-block by k-block, each right behind the last MFMAs that read its registers
+    auto tile = [&](bool reload, int s, const v4u* wf_next) {
+        const unsigned char* zp = &zplanes[s & 1][0][0][0];
+        int ar = arow, kqq = kq;                                         // opaque copies: the fragment offsets are re-derived per tile, not kept in registers across the loop
+        asm volatile("" : "+v"(ar), "+v"(kqq));
+        auto fragment = [&](int step, v8h (&f)[2]) {
+            const int kb = step >> 1, rt = step & 1;
+            const unsigned char* src = zp + (16 * rt + ar) * ZRB + (((4 * kb + kqq) ^ ar) << 4);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) f[pl] = *reinterpret_cast<const v8h*>(src + pl * ZPL);
+        };
+        v4f acc[RT][JT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) acc[rt][jt] = v4f{0.f, 0.f, 0.f, 0.f};
+        v8h a[2], an[2];
+        fragment(0, a);
+#pragma unroll
+        for (int step = 0; step < RT * KB; ++step) {
+            const int kb = step >> 1, rt = step & 1;
+            if (step + 1 < RT * KB) fragment(step + 1, an);
+            IHG_PIN_ORDER();
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    acc[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[jt][kb][kTermB2[term]], a[kTermA2[term]], acc[rt][jt], 0, 0, 0);
+            IHG_PIN_ORDER();
+            if (rt == RT - 1 && reload) load_kb(wf_next, kb);             // (a uniform branch around the requests: one code path, so that old and new planes share their registers)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) a[pl] = an[pl];
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) *reinterpret_cast<v4f*>(&part[s & 1][16 * rt + arow][64 * wave + 16 * jt + 4 * kq]) = acc[rt][jt];
+    };
+    for (int s = 0; s <= n_phases; ++s) {
+        if (s < n_phases) {
+            Cur cn = c;
+            advance(cn);
+            tile(s + 1 < n_phases && (cn.type != c.type || cn.p != c.p), s, plane_ptr(cn));
+            c = cn;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The node-level forward for d = 64 (two fp16 terms per operand, like the grouped kernels): a workgroup owns the 64 output columns and all 448 values of the
+// contraction index in ONE pass - matrix wave m: 16 columns x 448 values = 112 weight registers - over tiles of 16 node rows.  (The template still carries the pass /
+// column-part geometry it served d = 128 and d = 256 with - d = 128: 592 us against 543 for four passes of 256 values, then the grouped kernel; d = 256: four launches x four
+// column parts, every value split in each part and `out` read-modify-written four times: 60 ms at C5 against 38 for the grouped kernel above - only <64, 0> is instantiated.)
+// A row's values go in scaled by ONE power of two (its 16 service threads agree on the largest magnitude), a weight row by one over the
 // type's seven blocks (node_fwd_weight_scales_kernel); the partial sums leave through the two inverses in the service threads' epilogue.
 // wnq[type][pass][part][m][kb < 16][plane < 2][lane][8 x fp16]: element i = plane of wsc[type][j] W[j][block(type, xb) d + c], j = 64 part + 16 m + (lane & 15), where
 //   kk = 32 kb + 8 (lane >> 4) + i,  xb = pass (512 / d) + kk / d,  c = kk % d     (xb > 6, or the uqi block at order 2: zeros)
@@ -1285,7 +1606,7 @@ void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w,
     }
 }
 
-// node-level forward of the interactive layer: node_interact_fwd_grouped_kernel (d = 128), node_interact_fwd_q_kernel (d = 64 / 256)
+// node-level forward of the interactive layer: node_interact_fwd_grouped_kernel (d = 128), node_interact_fwd_grouped256_kernel (d = 256), node_interact_fwd_q_kernel (d = 64)
 static int64_t node_fwd_q_v4(int dim) {                                  // v4u of the q kernel's planes
     const int bpp = 512 / dim, n_pass = (7 + bpp - 1) / bpp, parts = dim / 64;
     return 3LL * n_pass * parts * 4 * 16 * 2 * kWave;
@@ -1343,22 +1664,32 @@ void launch_node_fwd_split(int dim, int order, const float* h, int64_t ld_h, con
     float* wsc = reinterpret_cast<float*>(wnp + node_fwd_q_v4(dim));
     float* winv = wsc + 3 * dim;
     hipLaunchKernelGGL(node_fwd_weight_scales_kernel, dim3(grid_for_waves(3 * dim)), dim3(kBlockThreads), 0, s, w, ld_w, dim, order, wsc, winv);
+    if (dim == 256) {
+        // one launch: fourteen (order 2: twelve) passes of 128 contraction values over groups of four 32-row tiles
+        const int passes = order == 3 ? 14 : 12;
+        const int pack_items = 3 * passes * 4 * 4 * 4 * kWave;
+        if (order == 3) hipLaunchKernelGGL(pack_planes_node_fwd256_kernel<3>, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, wsc, wnp);
+        else hipLaunchKernelGGL(pack_planes_node_fwd256_kernel<2>, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, wsc, wnp);
+        const RowTiles tiles = row_tiles(type_begin, 32);
+        if (tiles.tile_prefix[3] == 0) return;
+        NodeGroups groups;
+        groups.tiles = tiles;
+        int acc = 0;
+        for (int t = 0; t < 3; ++t) {
+            groups.group_prefix[t] = acc;
+            acc += (tiles.tile_prefix[t + 1] - tiles.tile_prefix[t] + kNodeGroupTiles256 - 1) / kNodeGroupTiles256;
+        }
+        groups.group_prefix[3] = acc;
+        const int grid = std::min(acc, 256);
+        if (order == 3) hipLaunchKernelGGL(node_interact_fwd_grouped256_kernel<3>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, groups, out, ld_out);
+        else hipLaunchKernelGGL(node_interact_fwd_grouped256_kernel<2>, dim3(grid), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, groups, out, ld_out);
+        return;
+    }
     hipLaunchKernelGGL(pack_planes_node_fwd_q_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, order, wsc, wnp);
     const RowTiles plan = row_tiles(type_begin, 16);
     if (plan.tile_prefix[3] == 0) return;
-    const int parts = dim / 64;
-    const int n_ranges = std::min((plan.tile_prefix[3] + 7) / 8 * 8, 256 / parts);      // a multiple of 8: the parts of a range land on one XCD
-#define IHG_NODE_Q(D, PASS, ACC, FINAL) \
-    hipLaunchKernelGGL((node_interact_fwd_q_kernel<D, PASS, ACC, FINAL>), dim3(n_ranges * parts), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, plan, out, ld_out)
-    if (dim == 64) {
-        IHG_NODE_Q(64, 0, false, true);
-    } else {
-        IHG_NODE_Q(256, 0, false, false);
-        IHG_NODE_Q(256, 1, true, false);
-        IHG_NODE_Q(256, 2, true, false);
-        IHG_NODE_Q(256, 3, true, true);
-    }
-#undef IHG_NODE_Q
+    const int n_ranges = std::min((plan.tile_prefix[3] + 7) / 8 * 8, 256);              // (d = 64: one column part, one pass)
+    hipLaunchKernelGGL((node_interact_fwd_q_kernel<64, 0, false, true>), dim3(n_ranges), dim3(kSplitThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, wnp, winv, plan, out, ld_out);
 }
 
 // node-level weight gradients of the product blocks (d = 64 / 128 / 256): see node_interact_weight_split_kernel

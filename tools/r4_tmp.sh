@@ -1,7 +1,9 @@
 export TMPDIR=/tmp
 O=gpurun_out/r4
 mkdir -p $O
-( time timeout 2400 python -m pytest tests -m gpu -q -x --durations=3 ) > $O/t_full.log 2>&1
-tail -8 $O/t_full.log
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_C3_now.json 2>/dev/null; python -c "
-import json; p=json.load(open('$O/bench_C3_now.json')); print('C3', p['ms_per_step'], {n:v['avg_us'] for n,v in p['kernels_us'].items() if v['avg_us']>80})"
+timeout 1500 python -m pytest tests/test_gpu_parity.py -q -x -k "without_hyperedge_rows or full_size_c5_node_level or c5_scaled or heaviest or f8" 2>&1 | tail -4
+for v in new q; do
+  if [ $v = q ]; then export IHG_NODE_FWD_Q256=1; fi
+  python bench.py --config C5 --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_C5_grouped_$v.json 2>/dev/null; python -c "
+import json; p=json.load(open('$O/bench_C5_grouped_$v.json')); print('C5 $v', p['ms_per_step'])"
+done
