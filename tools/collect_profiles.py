@@ -30,7 +30,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)
     if stats:
-        shutil.copy(stats[0], os.path.join(dst, f'{prefix}_kernel_stats.csv'))
+        shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f'{prefix}_kernel_stats.csv'))
     for name in ('bench_under_rocprof.json', 'bench_default.json', 'k7_by_role.json'):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f'{prefix}_{name}'))
@@ -50,7 +50,7 @@ def main():
             if key.startswith('node_pair_sums_kernel'):                   # one launch per step under its own name: in situ
                 # bench.py brackets the OP (the pair-sum kernel and the finish kernel of its split rows, which follows it): add that launch's time
                 def finish_after_pairs(directory):
-                    path = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)[0]
+                    path = max(glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)
                     rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r['Start_Timestamp']))
                     seen, extra = set(), []
                     for i, r in enumerate(rows):
@@ -81,7 +81,7 @@ def main():
         # counter passes are cut into steps at the Adam launches and the first long K7 launch of a step is the hyperedge -> node pass of the
         # interactive layer - the kernel bench.py's `roofline` brackets inside the timed region
         def k7_in_situ(directory, counter):
-            path = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)[0]
+            path = max(glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)
             rows = sorted((r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter), key=lambda r: int(r['Start_Timestamp']))
             adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
             picked = []
@@ -98,7 +98,7 @@ def main():
                                             source='in situ: the first long K7 launch of each training step of the counter passes over bench.py (FETCH_SIZE doubled + WRITE_SIZE)')
         # the whole training step: the counter passes cut into steps at the Adam launches, every kernel between two of them summed
         def step_total(directory, counter):
-            path = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)[0]
+            path = max(glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)
             rows = sorted((r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter), key=lambda r: int(r['Start_Timestamp']))
             adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
             sums = [sum(float(r['Counter_Value']) for r in rows[a + 1:b + 1]) for a, b in zip(adam, adam[1:])]
@@ -110,10 +110,11 @@ def main():
             out['step_l2_miss_note'] = f'FETCH_SIZE (doubled) + WRITE_SIZE summed over every kernel between two Adam launches, averaged over the last {max(n_steps - 1, 1)} steps of the pass'
         json.dump(out, open(os.path.join(dst, f'pmc_traffic_{config}.json'), 'w'), indent=1)
         for d, c in ((fetch, 'fetch_size'), (write, 'write_size')):
-            f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
+            f = max(glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)
             shutil.copy(f, os.path.join(dst, f'{prefix}_pmc_{c}.csv'))
     mf = glob.glob(os.path.join(src, 'pmc_mfma', '**', '*counter_collection.csv'), recursive=True)
     if mf:
+        mf = [max(mf, key=os.path.getmtime)]      # (gpurun merges into gpurun_out/: an earlier run's files may still be there)
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(mf[0])):
             name = r['Kernel_Name'].replace('(anonymous namespace)::', '')

@@ -16,7 +16,7 @@ import sys
 
 
 def load(directory, counter):
-    path = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)[0]
+    path = max(glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)
     groups = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
