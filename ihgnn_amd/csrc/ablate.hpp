@@ -82,5 +82,30 @@ constexpr bool n_no_reload = true;
 #else
 constexpr bool n_no_reload = false;
 #endif
-constexpr bool any = n_no_service || n_no_fragments || n_no_reload || n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
+#ifdef IHG_ABL_D_NO_DW             // node-level backward: no weight-gradient MFMAs
+constexpr bool d_no_dw = true;
+#else
+constexpr bool d_no_dw = false;
+#endif
+#ifdef IHG_ABL_D_NO_DX             // node-level backward: no input-gradient MFMAs
+constexpr bool d_no_dx = true;
+#else
+constexpr bool d_no_dx = false;
+#endif
+#ifdef IHG_ABL_D_NO_SPLIT          // node-level backward: the images are not rewritten (no split of the next tile)
+constexpr bool d_no_split = true;
+#else
+constexpr bool d_no_split = false;
+#endif
+#ifdef IHG_ABL_D_NO_LOADS          // node-level backward: no row loads (values made up)
+constexpr bool d_no_loads = true;
+#else
+constexpr bool d_no_loads = false;
+#endif
+#ifdef IHG_ABL_D_NO_STORES         // node-level backward: dx is not stored
+constexpr bool d_no_stores = true;
+#else
+constexpr bool d_no_stores = false;
+#endif
+constexpr bool any = d_no_dw || d_no_dx || d_no_split || d_no_loads || d_no_stores || n_no_service || n_no_fragments || n_no_reload || n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
 }  // namespace abl

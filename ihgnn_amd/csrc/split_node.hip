@@ -1397,6 +1397,12 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
         const int64_t vc = live ? v : r_end - 1;
         const float* ds = dout + vc * ld_dout + 8 * o;
         const float* xs = typed_base(x, row_type(vc)) + vc * ld_x + 128 * half + 8 * o;
+        if (abl::d_no_loads) {
+#pragma unroll
+            for (int i = 0; i < 2 * DOCT; ++i) r.d[i] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(vc + i);
+            r.x[0] = r.x[1] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(vc);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < DOCT; ++i) {
             r.d[2 * i] = *reinterpret_cast<const v4f*>(ds + 128 * i);
@@ -1494,13 +1500,14 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                 for (int it = 0; it < IT; ++it) {
                     const int step = jt * IT + it;                       // the next tile's split, spread over this tile's MFMA groups
 #pragma unroll
-                    for (int s2 = step * SLICES / STEPS; s2 < (step + 1) * SLICES / STEPS; ++s2) split_slice(s2, use, BUF ^ 1, k + 1 < n_my);   // (past the last tile: stale rows, nobody reads those images)
+                    for (int s2 = step * SLICES / STEPS; s2 < (step + 1) * SLICES / STEPS; ++s2)
+                        if (!abl::d_no_split) split_slice(s2, use, BUF ^ 1, k + 1 < n_my);   // (past the last tile: stale rows, nobody reads those images)
                 }
 #pragma unroll
                 for (int term = 0; term < 6; ++term)
 #pragma unroll
                     for (int it = 0; it < IT; ++it)
-                        acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it][kTermA[term]], b[kTermB[term]], acc[it][jt], 0, 0, 0);
+                        if (!abl::d_no_dw) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it][kTermA[term]], b[kTermB[term]], acc[it][jt], 0, 0, 0);
 #pragma unroll
                 for (int p = 0; p < 3; ++p) b[p] = bn[p];
             }
@@ -1518,7 +1525,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                         for (int p = 0; p < 3; ++p) d3[p] = *reinterpret_cast<const v8s*>(dp + p * DPL + r * DRB + (((4 * kb + kq) ^ tr_swizzle(r)) << 4));
 #pragma unroll
                         for (int term = 0; term < 6; ++term)
-                            gx[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdx[kb][kTermB[term]], d3[kTermA[term]], gx[rt], 0, 0, 0);
+                            if (!abl::d_no_dx) gx[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdx[kb][kTermB[term]], d3[kTermA[term]], gx[rt], 0, 0, 0);
                     }
                 }
             }
@@ -1530,7 +1537,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     const int64_t v = r_base + 16 * rt + arow;
-                    if (v < r_end) *reinterpret_cast<v4f*>(typed_base(dx, row_type(v)) + v * ld_dx + 16 * wave + 4 * kq) = gx[rt];
+                    if (v < r_end && (!abl::d_no_stores || gx[rt][0] == 1.2345e30f)) *reinterpret_cast<v4f*>(typed_base(dx, row_type(v)) + v * ld_dx + 16 * wave + 4 * kq) = gx[rt];
                 }
             }
             __syncthreads();
