@@ -633,7 +633,7 @@ def main():
         fwd_pieces = [('node_interact_fwd' if node_level else 'interact_fwd', flops_fwd, f['avg_us'], 3 if node_level else 6)]
         bwd_pieces = [('interact_bwd (member gradients)', 2.0 * m_blocks * dim * dim * E, bw['avg_us'] * bw['launches'] / table_steps, 3)]
         if 'node_interact_bwd_weight' in table:
-            bwd_pieces.append(('node_interact_bwd_weight', 2.0 * m_blocks * dim * dim * N, nw['avg_us'] * nw['launches'] / table_steps, 6))
+            bwd_pieces.append(('node_interact_bwd_weight', 2.0 * m_blocks * dim * dim * N, nw['avg_us'] * nw['launches'] / table_steps, 3))
         else:
             bwd_pieces[0] = ('interact_bwd (member + weight gradients, hyperedge form)', flops_bwd, bwd_us, 4.5)
         mfma_roof = dict(bound='mfma', kernel=('node_interact_fwd (node-level contraction, %d blocks per node) + interact_bwd (member gradients, per hyperedge) + node_interact_bwd_weight (per node)' % (3 + m_blocks)
@@ -659,7 +659,8 @@ def main():
                    'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
                    'arithmetic': ('f32 results; f32 accumulation everywhere.  Row contractions (node-level contraction and member gradients at d = 64 / 128 / 256, node-level linear '
                                   'maps and their input gradients at d = 128 / 256): operands scaled by a power of two and taken apart into two fp16 terms, three fp16 MFMA products '
-                                  'per multiply (error <= 3 x 2^-22 per product); weight gradients (contraction over the rows): three exact bf16 terms, six bf16 MFMA products; '
+                                  'per multiply (error <= 3 x 2^-22 per product) - also the node-level weight gradients of the product blocks (a row\'s two operands scaled against each other); '
+                                  'weight gradients of the node-level linear maps: three exact bf16 terms, six bf16 MFMA products; '
                                   'both within the fp32-MFMA kernels\' error against float64 (tests/test_gpu_parity.py); IHG_INTERACT_ARITH=f32 selects the fp32-MFMA kernels')
                                  if split_arithmetic(dim, args.order) else 'f32 (fp32 MFMA / VALU)'},
         'final_loss': round(final_loss, 6),

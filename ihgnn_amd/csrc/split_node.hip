@@ -937,6 +937,14 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_q_kernel(cons
 // tiles, transposed reads of row-major bf16 images, one slab per tile range) behind another front end: node rows of one type, their
 // cotangent, feature and pair-sum rows as straight streams.  A tile range belongs to ONE node type (the assignment of X blocks to the
 // blocks of w depends on the type); node_weight_reduce_kernel adds the ranges of each type into the w blocks that type's X blocks stand for.
+// Arithmetic: TWO fp16 terms per operand, three MFMA products (the hyperedge form's kernel: three bf16 terms, six).  The contraction runs over the ROWS, so a row
+// scale does not factor out of a column of the result - but d W = sum_v a_v x b_v^T is unchanged by a_v 2^s, b_v 2^-s for ANY per-row s: each row's two operands are
+// scaled against each other (their largest magnitudes meet at 2^m, both inside fp16's range with 22 bits kept) under ONE power of two per workgroup that follows the
+// largest la + lb of the rows seen so far; when a tile raises it, the resident accumulators are brought to the new scale first (a multiplication by a power of two:
+// exact; it happens a few times per workgroup).  A row far below the largest loses low bits - but BOTH its operands are small, so its products are small squared: what
+// it can add to any entry's error is bounded by 2^-25 of the largest row's product however many such rows there are (a single scale per operand without the balancing
+// is not: 2^18 small rows x 2^-31 each).  A tile's exponents are published (tile_l) a phase before its split - from rows requested a phase before that: three sets of
+// rows - so that every thread of both roles derives the same running scale without a second barrier per tile.  291 -> 225 us at C3 (same box).
 // ------------------------------------------------------------------------------------------------
 struct NodeRanges {
     int64_t begin[4];      // first row of every node type
@@ -949,8 +957,10 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
                                                                                    NodeRanges plan, float* __restrict__ slabs) {
     constexpr int TE = kSplitTE, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), HC = D / PARTS, CT = HC / 16, JT = D / 16;
     constexpr int DRB = 2 * D < 256 ? 256 : 2 * D, ZRB = 8 * HC, DOCT = D / 64, ZX = HC / 32, DPL = TE * DRB, ZPL = TE * ZRB;
-    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][DRB];
-    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][3][TE][ZRB];
+    constexpr int kTarget = 24;                                          // twice the exponent the largest balanced row is scaled to (2^12: headroom for the odd half-step)
+    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][2][TE][DRB];
+    __shared__ __attribute__((aligned(16))) unsigned char zplanes[2][2][TE][ZRB];
+    __shared__ __attribute__((aligned(16))) int tile_l[4][4];            // per tile (mod 4) and service wave: the largest la + lb (biased exponents) of the wave's eight rows, -1: none
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x;
@@ -962,6 +972,11 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
     const int per = n_ranges > 0 ? (n_tiles + n_ranges - 1) / n_ranges : 0;
     const int t0 = (range - plan.range_prefix[type]) * per;
     const int n_my = range < plan.range_prefix[3] ? std::max(0, std::min(per, n_tiles - t0)) : 0;
+    // the running scale: l_max = the largest la + lb over the rows of the tiles so far (-1: none yet); both roles derive it from tile_l in the same way
+    auto tile_max = [&](int k) {
+        const int* t = tile_l[k & 3];
+        return std::max(std::max(t[0], t[1]), std::max(t[2], t[3]));
+    };
 
     role_priority(wave >= 4);
     if (wave >= 4) {
@@ -969,6 +984,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
         const int st = tid - 256, row = st >> 3, o = st & 7;
         struct Rows {
             v4f d[2 * DOCT], hv[ZX], sa[ZX], sb[ZX], sab[ZX];
+            int ea, eb;                                                  // the row's exponents (publish), used again by the split
         };
         auto load_rows = [&](int k, Rows& r) {
             const int64_t first = r_begin + static_cast<int64_t>(std::min(t0 + k, n_tiles - 1)) * TE;   // tiles past the range: the type's last tile, dropped
@@ -996,57 +1012,107 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
                 r.sab[x] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(sp + 2 * D + 32 * x));
             }
         };
+        auto product = [&](const Rows& r, int x, int b) { return b == 0 ? r.hv[x] * r.sa[x] : b == 1 ? r.hv[x] * r.sb[x] : b == 2 ? r.sab[x] : r.hv[x] * r.sab[x]; };
+        // biased exponents of the row's largest cotangent magnitude (ea) and largest product magnitude (eb); -1 where the row is all zero on that side
+        auto row_exponents = [&](const Rows& r, int& ea, int& eb) {
+            float ma = 0.f, mb = 0.f;
+#pragma unroll
+            for (int x = 0; x < DOCT; ++x) ma = abs_max_of(r.d[2 * x], r.d[2 * x + 1], ma);
+#pragma unroll
+            for (int x = 0; x < ZX; ++x)
+#pragma unroll
+                for (int b = 0; b < NBLK; ++b) {
+                    const v4f z = product(r, x, b);
+                    mb = abs_max3(z[2], z[3], abs_max3(z[0], z[1], mb));
+                }
+            ma = row_lanes_max<8>(ma);
+            mb = row_lanes_max<8>(mb);
+            // (bit tests, not comparisons: a NaN or an infinity counts as the largest exponent and stays what it is through the scaling - it reaches the gradient)
+            ea = (__float_as_uint(ma) & 0x7fffffffu) != 0u ? static_cast<int>((__float_as_uint(ma) >> 23) & 0xffu) : -1;
+            eb = (__float_as_uint(mb) & 0x7fffffffu) != 0u ? static_cast<int>((__float_as_uint(mb) >> 23) & 0xffu) : -1;
+        };
+        // the wave's largest ea + eb (eight rows) -> tile_l[k & 3][wave]
+        auto publish = [&](int k, Rows& r) {
+            row_exponents(r, r.ea, r.eb);
+            const int ea = r.ea, eb = r.eb;
+            int l = (ea >= 0 && eb >= 0) ? ea + eb : -1;
+            l = std::max(l, __shfl_xor(l, 8));
+            l = std::max(l, __shfl_xor(l, 16));
+            l = std::max(l, __shfl_xor(l, 32));
+            if (lane == 0) tile_l[k & 3][wave - 4] = l;
+        };
         const int swz = tr_swizzle(row);
-        auto split_tile = [&](const Rows& r, int buf) {
+        int l_max = -1;
+        // A row's two operands are scaled AGAINST each other by powers of two (a 2^sa, z 2^sz with sa + sz the same for every row of the workgroup: the products, and
+        // so the gradient, carry one known factor) so that their largest magnitudes meet at 2^m, m = (la + lb - l_max + kTarget) / 2 <= 12: both fit fp16's range and keep
+        // two fp16 terms = 22 bits; a row far below the largest loses low bits, but BOTH its operands are small - its products are small squared.
+        auto split_tile = [&](int k, const Rows& r, int buf) {
+            l_max = std::max(l_max, tile_max(k));
+            const int ea = r.ea, eb = r.eb;
+            int sa = -400, sz = -400;                                     // a row with an all-zero side contributes nothing: BOTH sides go in as zeros (an unscaled side could
+            if (ea >= 0 && eb >= 0) {                                    // exceed fp16's range, and 0 x inf is a NaN in every gradient entry)
+                const int m = (ea + eb - l_max + kTarget) >> 1;          // (unbiased exponent the row's maxima are brought to; ea + eb <= l_max)
+                sa = m - (ea - 127);
+                sz = (254 + kTarget - l_max) - sa;                       // sa + sz = 254 + kTarget - l_max for every row scaled under this l_max
+            }
 #pragma unroll
             for (int x = 0; x < DOCT; ++x) {
-                v4u sp[3];
+                v4u hi, lo;
 #pragma unroll
                 for (int pr = 0; pr < 4; ++pr) {
-                    unsigned w[3];
-                    split_pair(r.d[2 * x + (pr >> 1)][2 * (pr & 1)], r.d[2 * x + (pr >> 1)][2 * (pr & 1) + 1], w);
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) sp[p][pr] = w[p];
+                    unsigned hh, ll;
+                    split_pair_h2(__builtin_ldexpf(r.d[2 * x + (pr >> 1)][2 * (pr & 1)], sa), __builtin_ldexpf(r.d[2 * x + (pr >> 1)][2 * (pr & 1) + 1], sa), hh, ll);
+                    hi[pr] = hh;
+                    lo[pr] = ll;
                 }
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + row * DRB + 256 * ((o + 8 * x) >> 4) + ((((o + 8 * x) & 15) ^ swz) << 4)) = sp[p];
+                const int off = row * DRB + 256 * ((o + 8 * x) >> 4) + ((((o + 8 * x) & 15) ^ swz) << 4);
+                *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + off) = hi;
+                *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + DPL + off) = lo;
             }
 #pragma unroll
             for (int x = 0; x < ZX; ++x) {
                 const int og = o + 8 * x;
 #pragma unroll
                 for (int b = 0; b < NBLK; ++b) {
-                    const v4f z = b == 0 ? r.hv[x] * r.sa[x] : b == 1 ? r.hv[x] * r.sb[x] : b == 2 ? r.sab[x] : r.hv[x] * r.sab[x];
+                    const v4f z = product(r, x, b);
                     typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                    unsigned w0[3], w1[3];
-                    split_pair(z[0], z[1], w0);
-                    split_pair(z[2], z[3], w1);
+                    unsigned h0, l0, h1, l1;
+                    split_pair_h2(__builtin_ldexpf(z[0], sz), __builtin_ldexpf(z[1], sz), h0, l0);
+                    split_pair_h2(__builtin_ldexpf(z[2], sz), __builtin_ldexpf(z[3], sz), h1, l1);
                     const int byte = 2 * (b * HC + 4 * og);
                     const int off = row * ZRB + 256 * (byte >> 8) + ((((byte >> 4) & 15) ^ swz) << 4) + (byte & 8);
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + p * ZPL + off) = v2u{w0[p], w1[p]};
+                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + off) = v2u{h0, h1};
+                    *reinterpret_cast<v2u*>(&zplanes[buf][0][0][0] + ZPL + off) = v2u{l0, l1};
                 }
             }
         };
         if (n_my > 0) {
-            Rows r0, r1;
+            Rows r0, r1, r2;                                             // rows of tile m in r<m % 3>
             load_rows(0, r0);
             load_rows(1, r1);
-            split_tile(r0, 0);
+            load_rows(2, r2);
+            publish(0, r0);
+            publish(1, r1);
             __syncthreads();
-            auto phase = [&](int k, Rows& use, Rows& fill) {
-                load_rows(k + 2, fill);
-                if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
+            split_tile(0, r0, 0);
+            __syncthreads();
+            // phase k: images of tile k + 1 (`use`, whose exponents were published a phase ago); exponents of tile k + 2 (`arrive`, requested a phase ago: THREE sets of rows -
+            // publishing what the phase itself requested would make every phase wait out a memory round trip); request of tile k + 3 (`fill`)
+            auto phase = [&](int k, Rows& use, Rows& arrive, Rows& fill) {
+                load_rows(k + 3, fill);
+                if (k + 1 < n_my) split_tile(k + 1, use, (k + 1) & 1);
+                publish(k + 2, arrive);
                 __syncthreads();
             };
             int k = 0;
 #pragma clang loop unroll(disable)
-            for (; k + 1 < n_my; k += 2) {
-                phase(k, r1, r0);
-                phase(k + 1, r0, r1);
+            for (; k + 2 < n_my; k += 3) {
+                phase(k, r1, r2, r0);
+                phase(k + 1, r2, r0, r1);
+                phase(k + 2, r0, r1, r2);
             }
-            if (k < n_my) phase(k, r1, r0);
+            if (k < n_my) phase(k, r1, r2, r0);
+            if (k + 1 < n_my) phase(k + 1, r2, r0, r1);
         }
         return;
     }
@@ -1058,7 +1124,9 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
     for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[jt][ct] = v4f{0.f, 0.f, 0.f, 0.f};
+    int l_max = -1;
     if (n_my > 0) {
+        __syncthreads();
         __syncthreads();
         const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
         const int rlo = 8 * g + q, rhi = rlo + 4;
@@ -1067,39 +1135,55 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
             const int byte = 2 * (blk * HC + 16 * ct);
             return r * ZRB + 256 * (byte >> 8) + (((((byte >> 4) & 15) + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1);
         };
+        auto fragment = [&](const unsigned char* lo, const unsigned char* hi) { return __builtin_bit_cast(v8h, read_tr_fragment(lo, hi)); };
         for (int k = 0; k < n_my; ++k) {
+            // tile k was scaled under the running maximum INCLUDING its own rows: what the accumulators hold from the tiles before is brought to that scale first (exact:
+            // a power of two; rare - the maximum grows a few times per workgroup)
+            const int l_new = std::max(l_max, tile_max(k));
+            if (l_new != l_max && l_max >= 0 && blk < NBLK) {
+                const int shift = l_max - l_new;                         // (< 0)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[jt][ct][r] = __builtin_ldexpf(acc[jt][ct][r], shift);
+            }
+            l_max = l_new;
             const unsigned char* dp = &dplanes[k & 1][0][0][0];
             const unsigned char* zp = &zplanes[k & 1][0][0][0];
             if (blk < NBLK)
 #pragma unroll
             for (int jh = 0; jh < JT / 4; ++jh) {
-                v8s a[4][3];
+                v8h a[4][2];
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) a[jt][p] = read_tr_fragment(dp + p * DPL + a_addr(rlo, 4 * jh + jt), dp + p * DPL + a_addr(rhi, 4 * jh + jt));
-                v8s b[3], bn[3];
+                    for (int p = 0; p < 2; ++p) a[jt][p] = fragment(dp + p * DPL + a_addr(rlo, 4 * jh + jt), dp + p * DPL + a_addr(rhi, 4 * jh + jt));
+                v8h b[2], bn[2];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = read_tr_fragment(zp + p * ZPL + b_addr(rlo, 0), zp + p * ZPL + b_addr(rhi, 0));
+                for (int p = 0; p < 2; ++p) b[p] = fragment(zp + p * ZPL + b_addr(rlo, 0), zp + p * ZPL + b_addr(rhi, 0));
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     if (ct + 1 < CT) {
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(zp + p * ZPL + b_addr(rlo, ct + 1), zp + p * ZPL + b_addr(rhi, ct + 1));
+                        for (int p = 0; p < 2; ++p) bn[p] = fragment(zp + p * ZPL + b_addr(rlo, ct + 1), zp + p * ZPL + b_addr(rhi, ct + 1));
                     }
 #pragma unroll
-                    for (int term = 0; term < 6; ++term)
+                    for (int term = 0; term < 3; ++term)
 #pragma unroll
                         for (int jt = 0; jt < 4; ++jt)
-                            acc[4 * jh + jt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[jt][kTermA[term]], b[kTermB[term]], acc[4 * jh + jt][ct], 0, 0, 0);
+                            acc[4 * jh + jt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[jt][kTermA2[term]], b[kTermB2[term]], acc[4 * jh + jt][ct], 0, 0, 0);
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) b[p] = bn[p];
+                    for (int p = 0; p < 2; ++p) b[p] = bn[p];
                 }
             }
             __syncthreads();
         }
     }
     if (blk >= NBLK) return;
+    // the accumulators hold 2^(254 + kTarget - l_max) times the gradient (l_max < 0: no row of the range had a non-zero cotangent and product - they hold zeros)
+    const int unscale = l_max >= 0 ? l_max - 254 - kTarget : 0;
     float* slab = slabs + static_cast<int64_t>(range) * D * NBLK * D;
     const int c = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -1107,7 +1191,8 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) slab[static_cast<int64_t>(16 * jt + 4 * kq + r) * NBLK * D + blk * D + HC * half + 16 * ct + c] = acc[jt][ct][r];
+            for (int r = 0; r < 4; ++r)
+                slab[static_cast<int64_t>(16 * jt + 4 * kq + r) * NBLK * D + blk * D + HC * half + 16 * ct + c] = __builtin_ldexpf(acc[jt][ct][r], unscale);
 }
 
 // dw[j][(3 + b) d + c] = sum over the node types of the sum over the type's slabs at the X block that stands for w block b there
