@@ -660,7 +660,7 @@ def main():
                    'arithmetic': ('f32 results; f32 accumulation everywhere.  Row contractions (node-level contraction and member gradients at d = 64 / 128 / 256, node-level linear '
                                   'maps and their input gradients at d = 128 / 256): operands scaled by a power of two and taken apart into two fp16 terms, three fp16 MFMA products '
                                   'per multiply (error <= 3 x 2^-22 per product) - also the node-level weight gradients of the product blocks (a row\'s two operands scaled against each other); '
-                                  'weight gradients of the node-level linear maps: three exact bf16 terms, six bf16 MFMA products; '
+                                  'and of the node-level linear maps; the hyperedge form\'s weight gradients (IHG_NODE_LEVEL_WEIGHT=0): three exact bf16 terms, six bf16 MFMA products; '
                                   'both within the fp32-MFMA kernels\' error against float64 (tests/test_gpu_parity.py); IHG_INTERACT_ARITH=f32 selects the fp32-MFMA kernels')
                                  if split_arithmetic(dim, args.order) else 'f32 (fp32 MFMA / VALU)'},
         'final_loss': round(final_loss, 6),

@@ -1431,24 +1431,30 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
 // ------------------------------------------------------------------------------------------------
 // Weight gradient of the node-level linear maps: dW_t[i][j] = sum_{v of type t} dout[v][i] x[v][j], dbias_t[i] = sum_v dout[v][i].
 // Same shape of problem as the interactive weight gradient (both operands are streams, the contraction runs over the rows), same
-// machinery: row-major bf16 images with the transposed-read swizzle, ds_read_b64_tr_b16 fragments, accumulators resident for the
+// machinery: row-major 16-bit images with the transposed-read swizzle, ds_read_b64_tr_b16 fragments, accumulators resident for the
 // whole sweep, one slab per tile sequence (dense.hip's layout and reduction).  D = 128: a workgroup owns the whole 128 x 128 gradient
 // (wave = 2 x 4 accumulator tiles); D = 256: a workgroup owns a column half (wave = 4 x 4 tiles), both halves of a tile sequence on
 // one XCD.  The column sums of dout ride along in the staging threads' registers.  grid = (sequences x halves, 1, node types).
+// Arithmetic: two fp16 terms per operand with a row's two operands scaled against each other under one running scale per workgroup - node_interact_weight_split_kernel's
+// scheme (its comment has the argument); every wave is both roles here, so every thread keeps the two running maxima itself: l_split (all tiles up to the one being
+// split) and l_acc (the scale the accumulators are at: a tile behind).
 // ------------------------------------------------------------------------------------------------
-// DX (d = 128): the input gradient dx = dout W_t of the same rows is formed here too - the dout images are in LDS anyway (the transposed-read
-// layout also serves row reads), wave w takes output columns 16 w .. with the type's weight planes in 48 registers - and the separate row-GEMM
-// pass over dout goes away.
+// DX (d = 128): the input gradient dx = dout W_t of the same rows is formed here too - a ROW contraction, whose rows need their full relative accuracy each: it reads a
+// second image of dout, every row scaled to 2^13 by itself (the balanced image of a small row is deliberately coarse), against weight planes scaled per output column
+// (pack_planes_dense_h2_kernel); wave w takes output columns 16 w .. with the type's planes in 32 registers - and the separate row-GEMM pass over dout goes away.
 template <int D, bool DX>
 __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(const float* __restrict__ dout, int64_t ld_dout, TypedRows x,
                                                                                 int64_t ld_x, RowTiles plan, int single_weight, float* __restrict__ slabs,
                                                                                 float* __restrict__ bias_slabs, const v4u* __restrict__ pk, int64_t pk_type_stride,
-                                                                                TypedRowsOut dx, int64_t ld_dx, int dx_accumulate) {
+                                                                                const float* __restrict__ winv, TypedRowsOut dx, int64_t ld_dx, int dx_accumulate) {
     static_assert(!DX || D == 128, "the fused input gradient holds a whole weight matrix per workgroup");
     constexpr int TE = 32, HALVES = D / 128, DOCT = D / 128, IT = D / 64, DRB = 2 * D;     // dout image rows: 2 D bytes, x image rows: 256 bytes (128 columns)
-    constexpr int DPL = TE * DRB, XPL = TE * 256;
-    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][3][TE][DRB];
-    __shared__ __attribute__((aligned(16))) unsigned char xplanes[2][3][TE][256];
+    constexpr int DPL = TE * DRB, XPL = TE * 256, kTarget = 24;
+    __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][2][TE][DRB];          // dout, balanced against x (dW)
+    __shared__ __attribute__((aligned(16))) unsigned char xplanes[2][2][TE][256];
+    __shared__ __attribute__((aligned(16))) unsigned char nplanes[DX ? 2 : 1][2][DX ? TE : 1][DX ? DRB : 16];      // dout, every row scaled by itself (dx)
+    __shared__ float rown[2][TE];                                        // ... and the inverse of that scale
+    __shared__ __attribute__((aligned(16))) int tile_l[4][8];            // per tile (mod 4) and wave: the largest ea + eb (biased exponents) of the wave's four rows, -1: none
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x, type = blockIdx.z;
@@ -1462,6 +1468,10 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
     const int iq = wave & 3, jh = wave >> 2;
     // x and dx may be typed rows (TypedRows): with one weight for every node (single_weight) a tile sequence crosses the node types
     auto row_type = [&](int64_t v) { return single_weight ? (v >= plan.begin[2] ? 2 : (v >= plan.begin[1] ? 1 : 0)) : type; };
+    auto tile_max = [&](int k) {
+        const int* t = tile_l[k & 3];
+        return std::max(std::max(std::max(t[0], t[1]), std::max(t[2], t[3])), std::max(std::max(t[4], t[5]), std::max(t[6], t[7])));
+    };
 
     v4f acc[IT][4];
 #pragma unroll
@@ -1471,10 +1481,12 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
     v4f bsum[2 * DOCT];
 #pragma unroll
     for (int i = 0; i < 2 * DOCT; ++i) bsum[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    int l_acc = -1, l_split = -1;                                        // running maxima of ea + eb: what the accumulators are scaled under / what the tile being split is
 
     const int row = tid >> 4, o = tid & 15;                              // staging role: row; dout columns 8 o .. (and 128 + 8 o ..), x columns 128 half + 8 o ..
     struct Rows {
         v4f d[2 * DOCT], x[2];
+        int ea, eb;                                                      // biased exponents of the row's largest |dout| and |x| (-1: all zero), set by publish()
     };
     auto load_rows = [&](int k, Rows& r) {
         const int64_t v = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE + row;
@@ -1500,47 +1512,88 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
             for (int i = 0; i < 2 * DOCT; ++i) r.d[i] = v4f{0.f, 0.f, 0.f, 0.f};
         }
     };
+    // the row's exponents (its sixteen staging threads are sixteen consecutive lanes) and the wave's largest ea + eb (four rows) -> tile_l[k & 3][wave]
+    auto publish = [&](int k, Rows& r) {
+        float ma = 0.f;
+#pragma unroll
+        for (int i = 0; i < DOCT; ++i) ma = abs_max_of(r.d[2 * i], r.d[2 * i + 1], ma);
+        float mb = abs_max_of(r.x[0], r.x[1], 0.f);
+        ma = row_lanes_max<16>(ma);
+        mb = row_lanes_max<16>(mb);
+        // (bit tests, not comparisons: a NaN or an infinity counts as the largest exponent and stays what it is through the scaling)
+        r.ea = (__float_as_uint(ma) & 0x7fffffffu) != 0u ? static_cast<int>((__float_as_uint(ma) >> 23) & 0xffu) : -1;
+        r.eb = (__float_as_uint(mb) & 0x7fffffffu) != 0u ? static_cast<int>((__float_as_uint(mb) >> 23) & 0xffu) : -1;
+        int l = (r.ea >= 0 && r.eb >= 0) ? r.ea + r.eb : -1;
+        l = std::max(l, __shfl_xor(l, 16));
+        l = std::max(l, __shfl_xor(l, 32));
+        if (lane == 0) tile_l[k & 3][wave] = l;
+    };
     const int swz = tr_swizzle(row);
     const int st_off = row * 256 + ((o ^ swz) << 4);                     // 16 bytes of a 256-byte segment of this thread's row
-    // a staged tile -> images `buf`, one pair of values per slice: slices 0 .. 4 DOCT - 1 dout (the column sums ride along), then 4 of x
-    v4u sp[3];
+    // a staged tile -> images `buf`, one pair of values per slice: slices 0 .. 4 DOCT - 1 dout balanced (the column sums ride along), then 4 of x, then (DX) 4 DOCT of
+    // dout scaled by its own row.  sa / sx / sn: this row's three exponents of two (set per tile by row_scales)
+    v4u sph, spl;
+    int sa = 0, sx = 0, sn = 0;
+    auto row_scales = [&](const Rows& r) {
+        sa = sx = -400;                                                  // a row with an all-zero side goes in as zeros on BOTH sides (an unscaled side could exceed fp16's range)
+        if (r.ea >= 0 && r.eb >= 0) {
+            const int m = (r.ea + r.eb - l_split + kTarget) >> 1;        // the row's two maxima are brought to 2^m, m <= 12
+            sa = m - (r.ea - 127);
+            sx = (254 + kTarget - l_split) - sa;                         // sa + sx is the same for every row split under this l_split
+        }
+        sn = r.ea >= 0 ? 13 - (r.ea - 127) : 0;
+    };
+    constexpr int SLICES = 4 * DOCT + 4 + (DX ? 4 * DOCT : 0), STEPS = IT * 4;
     auto split_slice = [&](int slice, const Rows& r, int buf, bool counted) {
-        const bool is_x = slice >= 4 * DOCT;
-        const int s = is_x ? slice - 4 * DOCT : slice, oct = s >> 2, pr = s & 3;
-        const v4f v = is_x ? r.x[pr >> 1] : r.d[2 * oct + (pr >> 1)];
-        const float xa = v[2 * (pr & 1)], xb = v[2 * (pr & 1) + 1];
-        unsigned w[3];
-        split_pair(xa, xb, w);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) sp[p][pr] = w[p];
-        if (!is_x && (pr & 1) == 1 && counted) bsum[2 * oct + (pr >> 1)] += v;
+        const int kind = slice < 4 * DOCT ? 0 : (slice < 4 * DOCT + 4 ? 1 : 2);
+        const int s = kind == 0 ? slice : (kind == 1 ? slice - 4 * DOCT : slice - 4 * DOCT - 4), oct = s >> 2, pr = s & 3;
+        const v4f v = kind == 1 ? r.x[pr >> 1] : r.d[2 * oct + (pr >> 1)];
+        const int e = kind == 0 ? sa : (kind == 1 ? sx : sn);
+        unsigned hh, ll;
+        split_pair_h2(__builtin_ldexpf(v[2 * (pr & 1)], e), __builtin_ldexpf(v[2 * (pr & 1) + 1], e), hh, ll);
+        sph[pr] = hh;
+        spl[pr] = ll;
+        if (kind == 0 && (pr & 1) == 1 && counted) bsum[2 * oct + (pr >> 1)] += v;
         if (pr == 3) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                if (is_x) *reinterpret_cast<v4u*>(&xplanes[buf][0][0][0] + p * XPL + st_off) = sp[p];
-                else *reinterpret_cast<v4u*>(&dplanes[buf][0][0][0] + p * DPL + row * (DRB - 256) + 256 * oct + st_off) = sp[p];
+            if (kind == 1) {
+                *reinterpret_cast<v4u*>(&xplanes[buf][0][0][0] + st_off) = sph;
+                *reinterpret_cast<v4u*>(&xplanes[buf][0][0][0] + XPL + st_off) = spl;
+            } else {
+                unsigned char* base = kind == 0 ? &dplanes[buf][0][0][0] : &nplanes[DX ? buf : 0][0][0][0];
+                *reinterpret_cast<v4u*>(base + row * (DRB - 256) + 256 * oct + st_off) = sph;
+                *reinterpret_cast<v4u*>(base + DPL + row * (DRB - 256) + 256 * oct + st_off) = spl;
             }
         }
     };
-    constexpr int SLICES = 4 * DOCT + 4, STEPS = IT * 4;
+    auto note_row_scale = [&](int buf) {                                 // (DX) the inverse of the row's own scale, for the epilogue of its dx row
+        if (DX && o == 0) rown[buf][row] = __builtin_ldexpf(1.f, -sn);
+    };
 
     if (n_my > 0) {
-        Rows r0, r1;
-        load_rows(0, r0);
-        if (n_my > 1) load_rows(1, r1);
+        Rows r0, r1;                                                     // rows of tile m in r<m & 1>: requested two tiles ahead, taken delivery of at the END of the requesting
+        load_rows(0, r0);                                                // phase (this kernel is not sensitive to that wait: 15_ab_node_level_backward_three_row_sets.txt) - where their
+        load_rows(std::min(1, n_my - 1), r1);                            // exponents are published, a phase before the split (a third set of rows spills here)
+        publish(0, r0);
+        publish(1, r1);
+        __syncthreads();
+        l_split = tile_max(0);
+        row_scales(r0);
+        note_row_scale(0);
 #pragma unroll
         for (int s2 = 0; s2 < SLICES; ++s2) split_slice(s2, r0, 0, true);
         __syncthreads();
 
         const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
         const int rlo = 8 * g + q, rhi = rlo + 4;
-        v8s wdx[DX ? 4 : 1][3];                                          // DX: planes of W_t[32 kb + 8 (lane >> 4) + i][16 wave + (lane & 15)]
+        v8h wdx[DX ? 4 : 1][2];                                          // DX: planes of wsc[c] W_t[32 kb + 8 (lane >> 4) + i][c], c = 16 wave + (lane & 15)
+        v4f wiv = v4f{1.f, 1.f, 1.f, 1.f};                                // ... and the inverse scales of this lane's four output columns
         if (DX) {
-            const v4u* wf = pk + (single_weight ? 0 : type) * pk_type_stride + static_cast<int64_t>(wave) * 12 * kWave + lane;
+            const v4u* wf = pk + (single_weight ? 0 : type) * pk_type_stride + static_cast<int64_t>(wave) * 8 * kWave + lane;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wdx[kb][p] = __builtin_bit_cast(v8s, wf[(kb * 3 + p) * kWave]);
+                for (int p = 0; p < 2; ++p) wdx[kb][p] = __builtin_bit_cast(v8h, wf[(kb * 2 + p) * kWave]);
+            wiv = *reinterpret_cast<const v4f*>(winv + (single_weight ? 0 : type) * D + 16 * wave + 4 * (lane >> 4));
         }
         // dout columns (output rows i): tile IT iq + it -> byte 32 (IT iq + it) + 8 pp of a DRB-byte row, 256-byte segments swizzled separately
         auto a_addr = [&](int r, int it) {
@@ -1548,13 +1601,30 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
             return r * DRB + 256 * seg + ((ch ^ tr_swizzle(r)) << 4) + 8 * (pp & 1);
         };
         auto b_addr = [&](int r, int jt) { return r * 256 + (((8 * jh + 2 * jt + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
+        auto fragment = [&](const unsigned char* lo, const unsigned char* hi) { return __builtin_bit_cast(v8h, read_tr_fragment(lo, hi)); };
 
-        auto phase = [&](auto parity, int k, Rows& use, Rows& fill) {
-            constexpr int BUF = decltype(parity)::value;
+        // phase k: contraction of tile k (images k & 1); images of tile k + 1 from `use`; request of tile k + 2 (`fill`), delivered and its exponents published at the end
+        auto phase = [&](int k, Rows& use, Rows& fill) {
+            const int BUF = k & 1;
+            // the accumulators to the scale tile k was split under (it includes tile k's own rows); then the running maximum moves on to tile k + 1 for the split
+            if (l_split != l_acc) {
+                if (l_acc >= 0) {
+                    const int shift = l_acc - l_split;
+#pragma unroll
+                    for (int it = 0; it < IT; ++it)
+#pragma unroll
+                        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[it][jt][r] = __builtin_ldexpf(acc[it][jt][r], shift);
+                }
+                l_acc = l_split;
+            }
+            if (k + 1 < n_my) l_split = std::max(l_split, tile_max(k + 1));
+            row_scales(use);
+            if (k + 1 < n_my) note_row_scale(BUF ^ 1);
             // dx_accumulate: dx already holds another contribution to the same gradient (the member gradients of the interactive step); its rows
-            // of this tile seed the accumulators of the dx product at the end of the phase.  Requested BEFORE the next-but-one tile's rows: the memory
-            // counter is in order, so the wait for these at the end of the phase leaves the younger row requests in flight (issued behind them, that wait
-            // took delivery of the whole tile as well: 253 against 190 us per launch at C3)
+            // of this tile seed the accumulators of the dx product at the end of the phase.  Requested BEFORE the row requests: the memory
+            // counter is in order, so the wait for these leaves the younger row requests in flight
             v4f gold[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
             if (DX && dx_accumulate) {
                 const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
@@ -1565,21 +1635,21 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                 }
             }
             load_rows(std::min(k + 2, n_my - 1), fill);                  // (unconditional: a branch around requests makes the compiler wait for all of them)
-            const unsigned char* dp = &dplanes[BUF][0][0][0];
-            const unsigned char* xp = &xplanes[BUF][0][0][0];
-            v8s a[IT][3];
+            const unsigned char* dp = &dplanes[0][0][0][0] + BUF * (2 * DPL);
+            const unsigned char* xp = &xplanes[0][0][0][0] + BUF * (2 * XPL);
+            v8h a[IT][2];
 #pragma unroll
             for (int it = 0; it < IT; ++it)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[it][p] = read_tr_fragment(dp + p * DPL + a_addr(rlo, it), dp + p * DPL + a_addr(rhi, it));
-            v8s b[3], bn[3];
+                for (int p = 0; p < 2; ++p) a[it][p] = fragment(dp + p * DPL + a_addr(rlo, it), dp + p * DPL + a_addr(rhi, it));
+            v8h b[2], bn[2];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) b[p] = read_tr_fragment(xp + p * XPL + b_addr(rlo, 0), xp + p * XPL + b_addr(rhi, 0));
+            for (int p = 0; p < 2; ++p) b[p] = fragment(xp + p * XPL + b_addr(rlo, 0), xp + p * XPL + b_addr(rhi, 0));
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
                 if (jt + 1 < 4) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bn[p] = read_tr_fragment(xp + p * XPL + b_addr(rlo, jt + 1), xp + p * XPL + b_addr(rhi, jt + 1));
+                    for (int p = 0; p < 2; ++p) bn[p] = fragment(xp + p * XPL + b_addr(rlo, jt + 1), xp + p * XPL + b_addr(rhi, jt + 1));
                 }
 #pragma unroll
                 for (int it = 0; it < IT; ++it) {
@@ -1589,34 +1659,35 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                         if (!abl::d_no_split) split_slice(s2, use, BUF ^ 1, k + 1 < n_my);   // (past the last tile: stale rows, nobody reads those images)
                 }
 #pragma unroll
-                for (int term = 0; term < 6; ++term)
+                for (int term = 0; term < 3; ++term)
 #pragma unroll
                     for (int it = 0; it < IT; ++it)
-                        if (!abl::d_no_dw) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it][kTermA[term]], b[kTermB[term]], acc[it][jt], 0, 0, 0);
+                        if (!abl::d_no_dw) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[it][kTermA2[term]], b[kTermB2[term]], acc[it][jt], 0, 0, 0);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = bn[p];
+                for (int p = 0; p < 2; ++p) b[p] = bn[p];
             }
             v4f gx[2];
-            if (DX) {                                                    // row reads of the same dout images: chunk 4 kb + (lane >> 4) of row 16 rt + (lane & 15)
+            if (DX) {                                                    // row reads of the row-scaled dout images: chunk 4 kb + (lane >> 4) of row 16 rt + (lane & 15)
+                const unsigned char* np = &nplanes[0][0][0][0] + BUF * (2 * DPL);
                 const int arow = lane & 15, kq = lane >> 4;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    gx[rt] = gold[rt];
+                    gx[rt] = v4f{0.f, 0.f, 0.f, 0.f};
                     const int r = 16 * rt + arow;
 #pragma unroll
                     for (int kb = 0; kb < 4; ++kb) {
-                        v8s d3[3];
+                        v8h d2[2];
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) d3[p] = *reinterpret_cast<const v8s*>(dp + p * DPL + r * DRB + (((4 * kb + kq) ^ tr_swizzle(r)) << 4));
+                        for (int p = 0; p < 2; ++p) d2[p] = *reinterpret_cast<const v8h*>(np + p * DPL + r * DRB + (((4 * kb + kq) ^ tr_swizzle(r)) << 4));
 #pragma unroll
-                        for (int term = 0; term < 6; ++term)
-                            if (!abl::d_no_dx) gx[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdx[kb][kTermB[term]], d3[kTermA[term]], gx[rt], 0, 0, 0);
+                        for (int term = 0; term < 3; ++term)
+                            if (!abl::d_no_dx) gx[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wdx[kb][kTermB2[term]], d2[kTermA2[term]], gx[rt], 0, 0, 0);
                     }
+                    gx[rt] = gx[rt] * (wiv * rown[BUF][r]) + gold[rt];
                 }
             }
-            if (DOCT == 1) asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
-            else asm volatile("" : "+v"(fill.d[0]), "+v"(fill.d[1]), "+v"(fill.d[2 * DOCT - 2]), "+v"(fill.d[2 * DOCT - 1]), "+v"(fill.x[0]), "+v"(fill.x[1]));
-            if (DX) {                                                    // (after the delivery of the requested rows: the counter is in order)
+            publish(k + 2, fill);                                        // (takes delivery of the requested rows)
+            if (DX) {                                                    // (after the delivery: the counter is in order)
                 const int arow = lane & 15, kq = lane >> 4;
                 const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
 #pragma unroll
@@ -1627,12 +1698,15 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
             }
             __syncthreads();
         };
-        for (int k = 0; k < n_my; k += 2) {
-            phase(std::integral_constant<int, 0>{}, k, r1, r0);
-            if (k + 1 < n_my) phase(std::integral_constant<int, 1>{}, k + 1, r0, r1);
+        int k = 0;
+        for (; k < n_my; k += 2) {
+            phase(k, r1, r0);
+            if (k + 1 < n_my) phase(k + 1, r0, r1);
         }
     }
-    // slab [type][sequence][i][j]; accumulator tile (it, jt): row i = 16 (IT iq + it) + 4 (lane >> 4) + r, column j = 128 half + 64 jh + 16 jt + (lane & 15)
+    // slab [type][sequence][i][j]; accumulator tile (it, jt): row i = 16 (IT iq + it) + 4 (lane >> 4) + r, column j = 128 half + 64 jh + 16 jt + (lane & 15).
+    // The accumulators hold 2^(254 + kTarget - l_acc) times the gradient (l_acc < 0: zeros)
+    const int unscale = l_acc >= 0 ? l_acc - 254 - kTarget : 0;
     float* slab = slabs + (static_cast<int64_t>(type) * n_seq + seq) * D * D;
     const int c = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -1640,9 +1714,10 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) slab[static_cast<int64_t>(16 * (IT * iq + it) + 4 * kq + r) * D + 128 * half + 64 * jh + 16 * jt + c] = acc[it][jt][r];
+            for (int r = 0; r < 4; ++r)
+                slab[static_cast<int64_t>(16 * (IT * iq + it) + 4 * kq + r) * D + 128 * half + 64 * jh + 16 * jt + c] = __builtin_ldexpf(acc[it][jt][r], unscale);
     // column sums of dout: the 32 staging rows of a column meet in LDS (the images are free now) and are added in row order
-    float* red = reinterpret_cast<float*>(&dplanes[0][0][0][0]);        // [32][D] floats = 4 KB .. 32 KB
+    float* red = reinterpret_cast<float*>(&dplanes[0][0][0][0]);        // [32][D] floats = 16 KB .. 32 KB of the 32 KB .. 64 KB of images
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < DOCT; ++i) {
@@ -1843,20 +1918,27 @@ int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, Typed
     if (dim == 128) {
         const int n_seq = 256;
         if (has_dx) {                                                    // fused input gradient: planes of W for out = in W
+            // two fp16 planes per weight, then the output columns' scales and their inverses ([types][128] floats each)
             v4u* pk = static_cast<v4u*>(planes);
+            float* wsc = reinterpret_cast<float*>(pk + static_cast<int64_t>(n_types) * 8 * 4 * 2 * kWave);
+            float* winv = wsc + n_types * dim;
             const int items = n_types * 8 * 4 * kWave;
-            hipLaunchKernelGGL(pack_planes_dense_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types,
-                               dim, 1, pk);
+            hipLaunchKernelGGL(dense_weight_scales_kernel, dim3(grid_for_waves(static_cast<int64_t>(n_types) * dim)), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types, dim, 1,
+                               wsc, winv);
+            hipLaunchKernelGGL(pack_planes_dense_h2_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types,
+                               dim, 1, wsc, pk);
             hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, true>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                               n_types == 1 ? 1 : 0, slabs, bias_slabs, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 3 * kWave}, dx, ld_dx, dx_accumulate);
+                               n_types == 1 ? 1 : 0, slabs, bias_slabs, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 2 * kWave}, winv, dx, ld_dx, dx_accumulate);
         } else {
             hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, false>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                               n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, typed_rows_out(nullptr), int64_t{0}, 0);
+                               n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<const float*>(nullptr),
+                               typed_rows_out(nullptr), int64_t{0}, 0);
         }
         return n_seq;
     }
     const int n_seq = 128;
     hipLaunchKernelGGL((dense_weight_grad_split_kernel<256, false>), dim3(2 * n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                       n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, typed_rows_out(nullptr), int64_t{0}, 0);
+                       n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<const float*>(nullptr), typed_rows_out(nullptr),
+                       int64_t{0}, 0);
     return n_seq;
 }
