@@ -32,7 +32,7 @@ One JSON line is printed by rank 0.  It carries
   roofline_interaction        the interactive layer's contractions (node-level form: contraction per node, member gradients per hyperedge, weight
                               gradients per node; flops = the multiply-adds of the algorithm in use) against the matrix-core peak of the arithmetic
                               they run in (fp32 MFMA, or for d = 64 / 128 / 256 the 16-bit peak / 3 - two fp16 terms per operand: node-level contraction, member gradients - or / 6 -
-                              three bf16 terms: weight gradients), with the clocks and matrix-pipe occupancy of
+                              three bf16 terms: the hyperedge form's kernels), with the clocks and matrix-pipe occupancy of
                               the newest committed counter pass (`profiled_clock`);
   gradient_exchange           (N > 1) mode, backend, gradient bytes per rank, every rank's ms per step and the time its stream spent in the exchange;
   recorded_step_ms_per_step   the same step replayed from one recorded hipGraph (ihgnn_amd/captured_step.py); NOT the headline;

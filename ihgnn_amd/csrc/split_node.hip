@@ -1,6 +1,6 @@
 // split_node.hip - the NODE-LEVEL kernels of the split arithmetic (d = 64 / 128 / 256): the interactive layer's contraction per node (one launch at d = 128, the 64-column
 // pass kernel at d = 64 / 256) and its weight gradients, the node-level linear maps (typed row GEMM) and their weight / bias / input gradients.  The arithmetic
-// (two fp16 terms where the contraction runs along a row, three bf16 terms for the weight gradients), the wave roles and the helpers are split_common.hpp's;
+// (two fp16 terms per operand: per-row scales where the contraction runs along a row, a row's two operands balanced against each other where it runs over the rows), the wave roles and the helpers are split_common.hpp's;
 // the contractions per hyperedge are in split_arith.hip.  DESIGN.md section 4.
 #include "split_common.hpp"
 
