@@ -1,9 +1,10 @@
 export TMPDIR=/tmp
 O=gpurun_out/r4
 mkdir -p $O
-OPS=linear ROUNDS=10 bash tools/ab_run.sh dense_weight_grad base dwgfp16 base dwgfp16 > $O/ab_dwgfp16.txt 2>&1
-cat $O/ab_dwgfp16.txt
-( time timeout 2400 python -m pytest tests -m gpu -q --durations=3 ) > $O/t_full.log 2>&1
-tail -7 $O/t_full.log
-python bench.py --config C5 --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_C5_now.json 2>/dev/null; python -c "
-import json; p=json.load(open('$O/bench_C5_now.json')); print('C5', p['ms_per_step'])"
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --device 0 --backend gloo --no-cpu-baseline --no-extras > $O/bench_torchrun2.json 2> $O/bench_torchrun2.err
+tail -c 1500 $O/bench_torchrun2.json; echo; tail -3 $O/bench_torchrun2.err
+python - <<'PY'
+import json
+p=json.load(open('gpurun_out/r4/bench_torchrun2.json'))
+print(p['n_gpus'], p['ms_per_step'], p['value'], json.dumps(p['gradient_exchange'])[:600])
+PY
