@@ -1,10 +1,10 @@
+#!/bin/bash
+# scratch of round 4: what one gpurun call runs while a change is being tried (this state: the GPU suite and the default bench line)
 export TMPDIR=/tmp
 O=gpurun_out/r4
 mkdir -p $O
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --device 0 --backend gloo --no-cpu-baseline --no-extras > $O/bench_torchrun2.json 2> $O/bench_torchrun2.err
-tail -c 1500 $O/bench_torchrun2.json; echo; tail -3 $O/bench_torchrun2.err
-python - <<'PY'
-import json
-p=json.load(open('gpurun_out/r4/bench_torchrun2.json'))
-print(p['n_gpus'], p['ms_per_step'], p['value'], json.dumps(p['gradient_exchange'])[:600])
-PY
+( time timeout 2400 python -m pytest tests -m gpu -q --durations=3 ) > $O/t_full.log 2>&1
+tail -7 $O/t_full.log
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_C3_now.json 2>/dev/null
+python -c "
+import json; p=json.load(open('$O/bench_C3_now.json')); print('C3', p['ms_per_step'], {n: v['avg_us'] for n, v in p['kernels_us'].items() if v['avg_us'] > 80})"
