@@ -71,7 +71,8 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
 // same box, kbench scale).  Images, contraction image and id ring are double-buffered: one barrier per tile.  The two halves of a tile
 // range sit on one XCD, so the second read of a dout row hits that L2.
 // (Three bf16 terms per operand, six products, the user-slot sums on the service waves: 1,727 us at C3; two fp16 terms: 1,621; the sums moved
-// to the matrix waves: 1,489.  Ablation ladder of this form: profiles/r4/09_abl_member_gradients_fp16.txt.)
+// to the matrix waves: 1,489; row maxima without canonicalisation and LDS shuffles: 1,404; the gathered rows requested a phase before the phase that sums them
+// (two sets): 1,283 - 1,340 by box.  Ablation ladder of the 1,489 form: profiles/r4/09_abl_member_gradients_fp16.txt.)
 // UR (hyperedges numbered by user; g is [E, 2, d]): the user-slot gradient is not stored per hyperedge.  The product rule leaves it in an
 // LDS image [row][column]; a phase later MATRIX wave w adds up the image's rows 8 w .. 8 w + 7 (lane = column; a run = the rows of one
 // user, its starts from one ballot over the tile's user ids) and stores the runs inside its window to dh[user] as 256-byte row pieces; a
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     if (wave >= 4) {
         // ---------------- service waves: 256 threads, thread -> hyperedge row, dout octets o and o + 8, member / gradient columns 4 o .. and 32 + 4 o ..
         const int st = tid - 256, row = st >> 3, o = st & 7;
+        constexpr int AHEAD = GATHER ? 1 : 0;                            // the gathering form requests its rows a tile further ahead: its ids travel a phase earlier
         const int64_t last_pos = n_edges * 3 - 1;
         const uint32_t ldh = static_cast<uint32_t>(ld_h), ldd = static_cast<uint32_t>(ld_dout);
         // tile bases and the clamps at the end of the hyperedge list are scalar (the tile number is uniform); per lane: one min, one multiply
@@ -260,17 +262,20 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         if (st < 3 * TE) {
             ids[0][st] = fetch_id(0);
 #pragma unroll
-            for (int k = 1; k < 8; ++k) ids[k][st] = k < 4 && k < n_my ? fetch_id(k) : 0;       // (slots of tiles past the end: row 0, requested and dropped)
+            for (int k = 1; k < 8; ++k) ids[k][st] = k < 4 + AHEAD && k < n_my ? fetch_id(k) : 0;       // (slots of tiles past the end: row 0, requested and dropped)
         }
         __syncthreads();
         v4f dr0[2 * DOCT], dr1[2 * DOCT], hm0[EX][3], hm1[EX][3];                        // dout values of tile m in dr<m & 1>, member values in hm<m & 1>
-        Raw raw;                                                         // (GATHER) the rows behind the dout values being requested
+        // (GATHER) the rows behind the dout values: TWO sets - the rows of tile k + 3 are requested in phase k and summed at the end of phase k + 1 (one set, requested and
+        // summed inside one phase, made every phase wait out a loaded memory round trip)
+        Raw raw0, raw1;
         if (GATHER) {                                                    // one set of dout values: a tile's sum is formed after the previous one was split
-            load_gather(0, raw);
-            combine(0, raw, dr0);
+            load_gather(0, raw0);
+            combine(0, raw0, dr0);
             split_tile(dr0, 0);
-            load_gather(1, raw);
-            combine(1, raw, dr0);
+            load_gather(1, raw0);
+            load_gather(2, raw1);
+            combine(1, raw0, dr0);
         } else {
             load_dout(0, dr0);
             if (n_my > 1) load_dout(1, dr1);
@@ -278,34 +283,34 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         }
         __syncthreads();
         int id_carry = 0;
-        auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3]) {
-            // ids of tile k + 3 (requested in the previous phase) into the ring: a phase ahead of their first readers (the gathered rows of
-            // tile k + 3 in the next phase)
-            if (k >= 1 && k + 3 < n_my && st < 3 * TE) ids[(k + 3) & 7][st] = id_carry;
+        auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3], Raw& raw_use, Raw& raw_req) {
+            // ids of tile k + 3 + AHEAD (requested in the previous phase) into the ring: a phase ahead of their first readers (the gathered rows of
+            // that tile in the next phase)
+            if (k >= 1 && k + 3 + AHEAD < n_my && st < 3 * TE) ids[(k + 3 + AHEAD) & 7][st] = id_carry;
             load_members(k, hm_cur);                                     // unconditional: a branch around requests costs whole-set register copies
-            if (GATHER) load_gather(k + 2, raw);
+            if (GATHER) load_gather(k + 3, raw_req);
             else load_dout(k + 2, fill);
-            if (k + 4 < n_my && st < 3 * TE) id_carry = fetch_id(k + 4);
+            if (k + 4 + AHEAD < n_my && st < 3 * TE) id_carry = fetch_id(k + 4 + AHEAD);
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
             // delivery of this phase's requests, THEN everything that stores: the memory counter is in order, a wait behind a store sits out
             // the store's round trip to memory
-            if (GATHER) {
-                asm volatile("" : "+v"(raw.r[2][2 * DOCT - 2]), "+v"(raw.r[2][2 * DOCT - 1]), "+v"(raw.s[2]));
+            if (GATHER) {                                                // (the rows requested a phase ago: this phase's requests stay in flight)
+                asm volatile("" : "+v"(raw_use.r[2][2 * DOCT - 2]), "+v"(raw_use.r[2][2 * DOCT - 1]), "+v"(raw_use.s[2]));
             } else {
                 asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * DOCT - 2]), "+v"(fill[2 * DOCT - 1]));     // (in order: the last delivered = all delivered)
             }
-            asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));
-            if (GATHER) combine(k + 2, raw, fill);
+            asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));       // (left to where the next phase reads them: no gain)
+            if (GATHER) combine(k + 2, raw_use, fill);
             if (k >= 1 && k - 1 < n_my && !abl::m_no_product_rule) epilogue(k, hm_prev);
             __syncthreads();
         };
         int k = 0;
 #pragma clang loop unroll(disable)
         for (; k + 1 < n_phases; k += 2) {                                // exactly two phases per trip: the register sets come back in place
-            phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1);
-            phase(k + 1, dr0, GATHER ? dr0 : dr1, hm1, hm0);
+            phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1, raw1, raw0);
+            phase(k + 1, dr0, GATHER ? dr0 : dr1, hm1, hm0, raw0, raw1);
         }
-        if (k < n_phases) phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1);
+        if (k < n_phases) phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1, raw1, raw0);
         return;
     }
 
