@@ -525,10 +525,15 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped256_ke
             const int sb = c.xb > 0 ? (c.xb - 1) >> 1 : 0;
             const float* hp = h + v * ld_h + 128 * c.half + 4 * o;
             const float* sp = sums + v * ld_s + sb * D + 128 * c.half + 4 * o;
+            // ... but the operand a pass does not use is requested at the OTHER operand's address (the same cache lines a second time: no traffic): 3 of a half's 7 passes
+            // do not use h, the {deg h} pass no pair sum - 40 of 149 GB at C5 were rows nobody looked at
+            const bool need_h = (c.xb & 1) == 0, need_s = c.xb > 0;
+            const float* hq = need_h ? hp : sp;
+            const float* sq = need_s ? sp : hp;
 #pragma unroll
             for (int x = 0; x < X; ++x) {
-                pc.hv[x] = *reinterpret_cast<const v4f*>(hp + CSTR * x);
-                pc.sv[x] = *reinterpret_cast<const v4f*>(sp + CSTR * x);
+                pc.hv[x] = *reinterpret_cast<const v4f*>(hq + CSTR * x);
+                pc.sv[x] = *reinterpret_cast<const v4f*>(sq + CSTR * x);
             }
             pc.d = deg[v];
         };
