@@ -173,7 +173,8 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_fwd_grouped_kerne
         struct Piece { v4f hv[X], sv[X]; float d; };
         auto load_piece = [&](const Cur& c, Piece& pc) {
             const int64_t v = std::min(c.row0 + static_cast<int64_t>(c.t) * TE + row, c.r_end - 1);      // rows past the type's end re-read its last row (never stored)
-            const float* sp = sums + v * ld_s + (c.p > 0 ? (c.p - 1) * 128 : 0) + 4 * o;
+            // (the {deg h} pass uses no pair sum: its request goes to h's address - the same cache lines a second time - instead of fetching a block nobody looks at)
+            const float* sp = c.p > 0 ? sums + v * ld_s + (c.p - 1) * 128 + 4 * o : h + v * ld_h + 4 * o;
 #pragma unroll
             for (int x = 0; x < X; ++x) {
                 if (abl::n_no_first) {                                   // (ablation: no row loads)
