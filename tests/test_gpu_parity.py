@@ -720,6 +720,55 @@ def test_split_arithmetic_worst_case_operands(dim):
     assert max(errors.values()) <= RTOL / 5, errors
 
 
+@pytest.mark.parametrize('dim', [128, 256])
+def test_weight_gradients_over_rows_of_very_different_magnitude(dim):
+    """The weight gradients contract over the ROWS, and their two-fp16-term arithmetic scales a row's two operands against each other under one running scale per
+    workgroup (csrc/split_node.hip).  What that has to survive: rows whose magnitudes differ by many orders (here 2^-30 .. 2^10 per row, cotangent and input
+    independently, a few all-zero rows, the largest rows late in a workgroup's sweep so that the resident accumulators are rescaled) - every entry of d W and d bias of the
+    node-level linear map, its input gradient row by row (each row at ITS OWN relative accuracy), and the node-level weight gradients of the interactive layer's product
+    blocks, all against float64."""
+    from ihgnn_amd import ops
+    from oracle import ihgnn_ref as ref
+    U, Q, I, E = 6001, 170, 4103, 40000
+    w_, lay = make_layout(U, Q, I, E, seed=dim, edge_order='user')
+    N = lay.node_count
+    gen = torch.Generator().manual_seed(dim + 1)
+    row_scale = torch.exp2(torch.randint(-30, 11, (N, 1), generator=gen).float())
+    row_scale[torch.randperm(N, generator=gen)[:40]] = 0.0                      # rows with nothing on one side
+    big = torch.randperm(N, generator=gen)[:6]
+    col_scale = torch.exp2(torch.randint(-30, 11, (N, 1), generator=gen).float())
+    # node-level linear map: y = x W^T + b per node type
+    x = torch.randn(N, dim, generator=gen) * col_scale
+    wl = torch.randn(dim, dim, generator=gen) / np.sqrt(dim)
+    bl = torch.randn(dim, generator=gen)
+    cot = torch.randn(N, dim, generator=gen) * row_scale
+    cot[big] *= 2.0 ** 14                                                         # late, huge rows (node numbering puts some of them at the end of a sweep)
+    xd, wd, bd = x.to(dev()).requires_grad_(True), wl.to(dev()).requires_grad_(True), bl.to(dev()).requires_grad_(True)
+    ops.node_linear(xd, wd, bd, lay).backward(cot.to(dev()))
+    x64, w64, b64 = x.double().requires_grad_(True), wl.double().requires_grad_(True), bl.double().requires_grad_(True)
+    (x64 @ w64.T + b64).backward(cot.double())
+    assert rel(wd.grad, w64.grad) <= RTOL and row_rel(wd.grad, w64.grad) <= ROW_RTOL
+    assert rel(bd.grad, b64.grad) <= RTOL
+    got, want = xd.grad.cpu().double(), x64.grad
+    live = want.abs().amax(1) > 0
+    per_row = ((got - want).abs().amax(1)[live] / want.abs().amax(1)[live]).max().item()
+    assert per_row <= RTOL, per_row                                              # every input-gradient row to ITS OWN magnitude
+    assert bool((got[~live] == 0).all())
+    # interactive layer, node-level form: d w of the product blocks from h, the pair sums and the node-level cotangent
+    h = torch.randn(N, dim, generator=gen) * torch.exp2(torch.randint(-6, 7, (N, 1), generator=gen).float())
+    w = torch.randn(dim, 7 * dim, generator=gen) / np.sqrt(7 * dim)
+    dy = torch.randn(N, dim, generator=gen) * torch.exp2(torch.randint(-24, 9, (N, 1), generator=gen).float())
+    hd, wd2 = h.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True)
+    ops.interact_layer(hd, wd2, None, lay, 3, lay.inv_deg).backward(dy.to(dev()))
+    i3 = torch.from_numpy(lay.i3_host.astype(np.int64))
+    h64, w64b = h.double(), w.double().requires_grad_(True)
+    sdy = dy.double() * lay.inv_deg.cpu().double()[:, None]
+    dF = sdy[i3[:, 0]] + sdy[i3[:, 1]] + sdy[i3[:, 2]]
+    (ref.feature_interactor(h64, i3, w64b, torch.zeros(dim).double(), 3) * dF).sum().backward()
+    for blk in range(7):
+        assert rel(wd2.grad[:, blk * dim:(blk + 1) * dim], w64b.grad[:, blk * dim:(blk + 1) * dim]) <= RTOL, blk
+
+
 @pytest.mark.parametrize('dim', [12, 64, 128, 256])
 def test_interact_backward_in_hyperedge_chunks(dim, monkeypatch):
     """The [E, 3, d] member-gradient buffer produced in three hyperedge chunks (what config C5 needs on one GPU): gradients
