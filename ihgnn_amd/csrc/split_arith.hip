@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
 // range sit on one XCD, so the second read of a dout row hits that L2.
 // (Three bf16 terms per operand, six products, the user-slot sums on the service waves: 1,727 us at C3; two fp16 terms: 1,621; the sums moved
 // to the matrix waves: 1,489; row maxima without canonicalisation and LDS shuffles: 1,404; the gathered rows requested a phase before the phase that sums them
-// (two sets): 1,283 - 1,340 by box.  Ablation ladder of the 1,489 form: profiles/r4/09_abl_member_gradients_fp16.txt.)
+// (two sets): - 4 % (1,404 - 1,470 inside a step, by box).  Ablation ladder of the 1,489 form: profiles/r4/09_abl_member_gradients_fp16.txt.)
 // UR (hyperedges numbered by user; g is [E, 2, d]): the user-slot gradient is not stored per hyperedge.  The product rule leaves it in an
 // LDS image [row][column]; a phase later MATRIX wave w adds up the image's rows 8 w .. 8 w + 7 (lane = column; a run = the rows of one
 // user, its starts from one ballot over the tile's user ids) and stores the runs inside its window to dh[user] as 256-byte row pieces; a

@@ -32,6 +32,7 @@ def main():
     print(f'{args.config}: N={N} E={E} d={d} heavy_rows={lay.node_csr.n_heavy} segments={lay.node_csr.n_segments}')
     torch.manual_seed(0)
     x = torch.randn(N, d, device=dev)
+    dy_layer = torch.randn(N, d, device=dev)
     ef = torch.randn(E, d, device=dev)
     k = 7 if args.order == 3 else 6
     wa = (torch.randn(d, k * d, device=dev) / (k * d) ** 0.5).requires_grad_(True)
@@ -66,7 +67,8 @@ def main():
             ops.interact_to_nodes(hr, pr, wa, lay, args.order, lay.inv_deg).backward(x)
         if 'layer' in want:                                               # the whole interactive layer as one autograd node (what IHGNNLayer runs)
             hr = x.detach().requires_grad_(True)
-            ops.interact_layer(hr, wa, b, lay, args.order, lay.inv_deg).backward(x)
+            ops.interact_layer(hr, wa, b, lay, args.order, lay.inv_deg).backward(dy_layer)       # (a cotangent of its own: with `x` for both, the member-gradient
+                                                                                                 # kernel gathers h and dy rows out of ONE table - 8 % faster than in a step)
         if 'ifwd' in want:                                                # the interactive step's forward alone
             with torch.no_grad():
                 ops.interact(x, x, wa, lay, args.order)
