@@ -853,17 +853,19 @@ class _InteractLayer(torch.autograd.Function):
         del sums
         if gathered:
             csr_qi, qi_rows = layout.member_csr_qi()
-            # with the weight gradients taken at node level nobody but the first-order scatter would read the hyperedges' cotangents: that scatter is
-            # the two-hop operator applied to the node-level cotangent, and the [E, d] rows are not stored at all
-            keep_dout = True
-            dout = torch.empty(n_edges, dim, dtype=torch.float32, device=h.device)
+            # with the weight gradients taken at node level nobody but the first-order scatter would read the hyperedges' cotangents: then that gradient is
+            # the two-hop operator applied to the node-level cotangent and the [E, d] rows are not stored at all.  (Round 3 measured the opposite order - 8.81 against
+            # 8.74 ms per C3 step; since the member-gradient kernel became bound by its memory traffic the 1.1 GB it no longer writes are worth more than the two-hop
+            # launch costs over the scatter: C3 7.89 -> 7.78 ms, C2 1.92 -> 1.87, C4 10.59 -> 10.45; member kernel 1,426-1,467 -> 1,188 us, first-order gradient 672-681 -> 823-833)
+            keep_dout = not node_weight
+            dout = torch.empty(n_edges, dim, dtype=torch.float32, device=h.device) if keep_dout else None
             g2 = torch.empty(n_edges, 2 * dim, dtype=torch.float32, device=h.device)
             dh = torch.empty(layout.node_count, dim, dtype=torch.float32, device=h.device)
             _zero_isolated_users(dh, layout)
             ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
             with profiler.kernel('interact_bwd', n_edges, dim):
                 _lib.check(lib.ihg_interact_bwd_gathered(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(dy), _ld(dy), _ptr(out_scale),
-                                                         _ptr(dout), dim, _ptr(g2), _ptr(dh), dim, None if node_weight else _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4,
+                                                         _ptr(dout) if keep_dout else None, dim, _ptr(g2), _ptr(dh), dim, None if node_weight else _ptr(dw), _ld(dw), _ptr(ws), ws.numel() * 4,
                                                          n_edges, dim, _stream()), 'ihg_interact_bwd_gathered')
             node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients', read_once=True)
             del g2
