@@ -24,7 +24,8 @@ _FLAGS = (
     # not in the reference: batches (positive permutation + negative sampling) produced on the GPU instead of by DataLoader + random.sample
     ('device_sampling', ('--device_sampling',), 'flag', False, 'draw training batches on the device (same distribution, different random stream)'),
     ('grad_sync', ('--grad_sync',), str, 'flat', 'gradient exchange under torchrun: flat | bucketed | sharded (ihgnn_amd.distributed)'),
-    ('record_step', ('--record_step',), 'flag', False, 'replay the training step as one recorded hipGraph (single process; pays on small graphs, where the step is launch-bound)'),
+    ('record_step', ('--record_step',), 'optional', 'auto', 'replay the training step as one recorded hipGraph (single process): auto (default: when an eager step measures launch-bound, '
+                                                             '< 1.5 ms) | on (also a bare --record_step) | off'),
 )
 
 
@@ -40,6 +41,8 @@ def build_parser() -> argparse.ArgumentParser:
     for dest, flags, kind, default, text in _FLAGS:
         if kind == 'flag':
             parser.add_argument(*flags, dest=dest, action='store_true', default=default, help=text)
+        elif kind == 'optional':
+            parser.add_argument(*flags, dest=dest, nargs='?', const='on', default=default, choices=('auto', 'on', 'off'), help=text)
         else:
             parser.add_argument(*flags, dest=dest, type=kind, default=default, help=text)
     return parser

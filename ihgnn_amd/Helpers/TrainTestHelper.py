@@ -104,32 +104,69 @@ def test_and_get_avg_metrics(model, dataset_train: GraphDataset, dataloader: Tes
     return user_avgs, average, seconds
 
 
+# ``record_step='auto'``: an eager step faster than this is bound by the host's launch rate (config C1: 0.56 - 0.86 ms eager against 0.23 ms replayed; C2, 1.9 ms,
+# gains nothing) - such a model is trained from a recorded step without being asked to
+AUTO_RECORD_BELOW_MS = 1.5
+_AUTO_WARM_STEPS, _AUTO_TIMED_STEPS = 3, 4
+
+
+def _record_mode(record_step) -> str:
+    if record_step in (True, 'on', '1', 'yes'):
+        return 'on'
+    if record_step in (False, 'off', '0', 'no'):
+        return 'off'
+    if record_step in (None, 'auto', ''):
+        return 'auto'
+    raise ValueError(f'record_step: on | off | auto, got {record_step!r}')
+
+
 def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.Module, dataset_train: GraphDataset,
                            dataloader_train, pc: ProcessController, device: torch.device,
-                           grad_sync=None, record_step: bool = False) -> Tuple[float, float]:
-    """One epoch over ``dataloader_train`` -> (average loss, seconds).  ``record_step`` (single process, fused loss, the HIP Adam): batches
-    of the common size run as replays of ONE recorded step (``ihgnn_amd.captured_step``: worth it where the step is bound by the host's
-    launch rate, i.e. on small graphs); other batch sizes - the epoch's last batch - run eagerly."""
+                           grad_sync=None, record_step='auto') -> Tuple[float, float]:
+    """One epoch over ``dataloader_train`` -> (average loss, seconds) - the reference's loop (``Helpers/TrainTestHelper.py:123-143``).  ``record_step`` (single
+    process, fused loss, the HIP Adam): batches of the common size run as replays of ONE recorded step (``ihgnn_amd.captured_step``: worth it where the step is
+    bound by the host's launch rate, i.e. on small graphs); other batch sizes - the epoch's last batch - run eagerly.  ``'auto'`` (default): the first steps of the
+    first epoch run eagerly, steps 4 - 7 are timed, and the step is recorded when they took less than ``AUTO_RECORD_BELOW_MS`` each; ``'on'`` / ``'off'`` decide
+    without measuring.  A model the recording refuses (a parameter without gradient) trains eagerly, with one log line."""
     started = time.time()
     loss_sum = torch.zeros((), dtype=torch.float32, device=device)
     batches = positives = 0
     sampler = getattr(dataloader_train, 'batch_sampler', None)
     if hasattr(sampler, 'set_epoch'):
         sampler.set_epoch(pc.CurrentEpoch)                  # data parallel: a fresh shared permutation per epoch (ShardedBatchSampler)
+    mode = _record_mode(record_step)
+    from ..optim import Adam as _HipAdam
+    can_record = mode != 'off' and grad_sync is None and device.type == 'cuda' and isinstance(optimizer, _HipAdam)
+    decision = getattr(model, '_record_decision', None) if can_record else False       # None: undecided (auto, still measuring); True / False
+    if can_record and mode == 'on' and decision is None:
+        decision = True
+    if decision and getattr(model, '_recorded_step', None) is not None and model._recorded_step.stale(full=True):
+        model._recorded_step = None                          # an IHG_* switch or ops flag changed since the recording (checked once per epoch; the per-step check is the cheap one)
+    eager_seen, timed_from = getattr(model, '_auto_eager_steps', 0), None      # (persist across epochs: an epoch may be shorter than the measurement)
     for p_u, p_q, p_i, p_f, n_u, n_q, n_i, n_f in dataloader_train:
         positives += len(p_u)
         users, queries, items = torch.cat([p_u, n_u]), torch.cat([p_q, n_q]), torch.cat([p_i, n_i])
         flags = torch.cat([p_f, n_f]).float()
         fused = getattr(model, 'supports_fused_loss', None) and model.supports_fused_loss(loss_function)
-        if record_step and fused and grad_sync is None:
+        if decision and fused:
             recorded = getattr(model, '_recorded_step', None)
-            if recorded is None or recorded.optimizer is not optimizer or recorded.stale():     # (stale: a hyper-parameter or path switch baked into the recording changed)
+            if recorded is None or recorded.optimizer is not optimizer or recorded.stale():     # (stale: a hyper-parameter baked into the recording changed)
                 from ..captured_step import CapturedTrainingStep
-                recorded = model._recorded_step = CapturedTrainingStep(model, optimizer, int(users.shape[0]), warmup_batch=(users, queries, items, flags))
-            if recorded.batch_rows == int(users.shape[0]):
+                try:
+                    recorded = model._recorded_step = CapturedTrainingStep(model, optimizer, int(users.shape[0]), warmup_batch=(users, queries, items, flags))
+                except ValueError as refused:
+                    IOHelper.LogPrint(f'training step not recorded ({refused}); training eagerly')
+                    recorded, decision = None, False
+                    model._recorded_step, model._record_decision = None, False
+            if recorded is not None and recorded.batch_rows == int(users.shape[0]):
                 loss_sum += recorded.step(users, queries, items, flags)
                 batches += 1
                 continue
+        # auto: a few eager steps are timed (the step alone, device drained on both sides - not the loader's work between steps) once the allocator and the workspaces are warm
+        time_this = decision is None and fused and _AUTO_WARM_STEPS <= eager_seen < _AUTO_WARM_STEPS + _AUTO_TIMED_STEPS
+        if time_this:
+            torch.cuda.synchronize(device)
+            timed_from = time.perf_counter()
         if getattr(model, '_recorded_step', None) is not None:
             optimizer.zero_grad(set_to_none=True)           # the last replay's gradients (in the recording's pool) must not be accumulated onto
         if fused:
@@ -150,6 +187,18 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
         else:
             optimizer.zero_grad()
         batches += 1
+        if decision is None and fused:
+            if time_this:
+                torch.cuda.synchronize(device)
+                model._auto_timed_seconds = getattr(model, '_auto_timed_seconds', 0.0) + (time.perf_counter() - timed_from)
+            eager_seen += 1
+            model._auto_eager_steps = eager_seen
+            if eager_seen == _AUTO_WARM_STEPS + _AUTO_TIMED_STEPS:
+                step_ms = model._auto_timed_seconds * 1e3 / _AUTO_TIMED_STEPS
+                decision = model._record_decision = bool(step_ms < AUTO_RECORD_BELOW_MS)
+                model._auto_step_ms = step_ms
+                IOHelper.LogPrint(f'eager training step {step_ms:.2f} ms: ' + ('launch-bound - from here on ONE recorded step (hipGraph) is replayed' if decision
+                                                                              else 'GPU-bound - steps stay eager'))
     avg_loss = loss_sum.item() / max(batches, 1)
     if grad_sync is not None and grad_sync.world_size > 1:  # every rank reports (and schedules its learning rate on) the global average
         from .. import distributed as ihg_dist

@@ -146,7 +146,7 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
     history = MetricsCollection(Gs.use_valid_dataset)
     for _ in pc:
         avg_loss, train_seconds = train_and_get_avg_loss(model, optimizer, loss_function, dataset_train, dataloader_train,
-                                                         pc, device, grad_sync=grad_sync, record_step=bool(getattr(args, 'record_step', False)) and world == 1)
+                                                         pc, device, grad_sync=grad_sync, record_step=getattr(args, 'record_step', 'auto') if world == 1 else 'off')
         pc.AddTrainTime(train_seconds)
         if pc.ShouldStore():
             # every rank builds the state (a sharded optimizer gathers its Adam shards with a collective), the chief writes it
@@ -200,6 +200,9 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
                 if Gs.use_valid_dataset:
                     f.write(f'\n\nAll VALID metrics:\nEpoch {Metrics.title}\n')
                     f.writelines(f'{e} {m.to_string(no_title=True)}\n' for e, _, m in history.iter_epoch_test_valid())
+    # what the training loop decided about the step (TrainTestHelper.train_and_get_avg_loss, --record_step auto | on | off)
+    history.training_step_recorded = bool(getattr(model, '_record_decision', False))
+    history.eager_step_ms = getattr(model, '_auto_step_ms', None)
     if chief:
         IOHelper.EndLogging()
     return history

@@ -17,7 +17,7 @@ from .CommonLayers import FeatureInteractor
 
 
 def _transform(linear: nn.Linear, x: Tensor, layout) -> Tensor:
-    """``nn.Linear`` (square) on every node row through the HIP node-level kernels (bf16-split / MFMA row-GEMM for d in {32,64,128,256},
+    """``nn.Linear`` (square) on every node row through the HIP node-level kernels (split-arithmetic / MFMA row-GEMM for d in {32,64,128,256},
     the any-width kernels otherwise).  There is no torch path: a rectangular transform - which RawGnn never builds
     (``RawGnn.py:59-91``: input and output dimension are both the embedding size) - is refused."""
     if linear.in_features != linear.out_features:

@@ -63,7 +63,7 @@ class RawGnn(nn.Module):
 
     # bce_loss: evaluate the last layer's hyperedge -> node pass only at the rows the loss reads (same loss, same gradients)
     batch_rows_only_last_layer = True
-    MAX_SCORED_WIDTH = 1272                                   # ops.score_topk: 32 mixed rows as two fp16 planes in 160 KB of LDS
+    MAX_SCORED_WIDTH = 1264                                   # = ihg_score_topk_max_dim() (tests/test_abi.py): 32 mixed rows as two fp16 planes in 160 KB of LDS
 
     def propagate_layers(self, tail_gradients=None, batch_rows=None, restrict_last_layer=True):
         """Full-graph propagation: the list ``[X0, X1, ..., XL]`` of ``[N, d]`` node features (input embeddings and every

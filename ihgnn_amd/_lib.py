@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # IHGNN_HIP_LIBRARY points at another build of the same ABI (A/B timing of kernel variants); default: the in-tree library
 LIB_PATH = os.environ.get('IHGNN_HIP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
@@ -99,6 +99,7 @@ SIGNATURES = {
     'ihg_adam_step_device_scalars': (ctypes.c_int, [c_void_p, c_int32, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     'ihg_batch_combine': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     'ihg_sample_negatives': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
+    'ihg_score_topk_max_dim': (c_int32, []),
     'ihg_score_topk_workspace_bytes': (c_int64, [c_int64, c_int64, c_int32]),
     'ihg_score_topk': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_int64,
                                       c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

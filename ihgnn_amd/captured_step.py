@@ -94,21 +94,29 @@ class CapturedTrainingStep:
             optimizer.launch_with_device_scalars(self.scalars)
         self._baked = self._baked_settings()
 
+    def _baked_hyperparameters(self):
+        """The optimizer's hyper-parameters and the model attribute a replay cannot change any more (cheap: compared at every ``step()``)."""
+        group = self.optimizer.param_groups[0]
+        return (tuple(group['betas']), float(group['eps']), float(group['weight_decay']), bool(self.model.batch_rows_only_last_layer))
+
     def _baked_settings(self):
         """Everything a replay cannot change any more: the recording holds the kernels these settings selected.  Only the learning rate is
         refreshed per replay (it enters through the device scalars)."""
         import os
-        group = self.optimizer.param_groups[0]
         switches = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('IHG_')))
         from . import ops
         flags = tuple((name, getattr(ops, name)) for name in ('USER_REDUCED_BACKWARD', 'SPARSE_LAST_COTANGENT', 'NODE_LEVEL_FORWARD', 'NODE_LEVEL_WEIGHT', 'NODE_TABLES',
                                                               'FIRST_ORDER_TWO_HOP_BYTES', 'MEMBER_BUFFER_LIMIT_BYTES') if hasattr(ops, name))
-        return (tuple(group['betas']), float(group['eps']), float(group['weight_decay']), bool(self.model.batch_rows_only_last_layer), switches, flags)
+        return self._baked_hyperparameters() + (switches, flags)
 
-    def stale(self) -> bool:
-        """True when a setting that is baked into the recording (Adam's betas / eps / weight decay, ``batch_rows_only_last_layer``, the ``IHG_*``
-        path switches) has changed since: the caller must record a new step (``TrainTestHelper`` does) - replaying would silently ignore the change."""
-        return self._baked != self._baked_settings()
+    def stale(self, full: bool = False) -> bool:
+        """True when a setting that is baked into the recording has changed since: the caller must record a new step (``TrainTestHelper`` does) - replaying would
+        silently ignore the change.  The default compares Adam's betas / eps / weight decay and ``batch_rows_only_last_layer`` - four values, what every ``step()``
+        checks; ``full=True`` also the ``IHG_*`` environment and the path switches of ``ihgnn_amd.ops`` (a sort over the environment: for the caller to ask once per
+        epoch, not per replay on the launch-bound path the recording exists for)."""
+        if full:
+            return self._baked != self._baked_settings()
+        return self._baked[:4] != self._baked_hyperparameters()
 
     TABLE_STEPS = 2048
 

@@ -54,7 +54,7 @@ struct TopList {
 // v_mfma_f32_32x32x16_f16, fp32 accumulation; the score is the accumulator times the two inverse scales (exact: powers of two) plus the bias.  Unlike the training
 // kernels nothing is split inside the hot loop: the item rows are split ONCE per call into MFMA-fragment order (score_prepare_kernel: 1 KB per (tile, k-step, plane), a
 // fully coalesced wave load), the mixed rows of a pair block once into LDS - the loop is loads, LDS reads and MFMAs.  A workgroup owns PB x 32 pairs (PB = 2 where their
-// planes fit LDS: widths up to 636) and its eight waves stream disjoint runs of item tiles: every item row is fetched once per 32 PB pairs.
+// planes fit LDS: widths up to 624) and its eight waves stream disjoint runs of item tiles: every item row is fetched once per 32 PB pairs.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
@@ -295,6 +295,13 @@ inline int64_t eval_aux_bytes(int64_t n_items) { return ((n_items + 31) / 32) * 
 
 extern "C" {
 
+// the widest feature row whose 32-pair block (two fp16 planes + the row pad + the pair scales) fits the 160 KB of LDS: 1264 (79 k-steps of 16)
+int32_t ihg_score_topk_max_dim(void) {
+    int dim = 16;
+    while (eval_lds_bytes(dim + 16, 1) <= 160 * 1024) dim += 16;
+    return dim;
+}
+
 int64_t ihg_score_topk_workspace_bytes(int64_t n_pairs, int64_t n_items, int32_t dim) {
     if (n_pairs <= 0 || n_items <= 0 || dim <= 0) return 0;
     const int64_t n_lists = static_cast<int64_t>(eval_slices(n_pairs, n_items, dim)) * kEvalWavesPerBlock * 2;
@@ -309,7 +316,7 @@ int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query
     if (features == nullptr || item_bias == nullptr || users == nullptr || queries == nullptr || top_scores == nullptr || top_items == nullptr)
         return fail(IHG_ERR_INVALID, "ihg_score_topk: null pointer");
     if (n_items > INT_MAX - 64) return fail(IHG_ERR_INVALID, "ihg_score_topk: item ids are int32");
-    if (eval_lds_bytes(dim, 1) > 160 * 1024) return fail(IHG_ERR_INVALID, "ihg_score_topk: feature width %d does not fit the LDS pair block", dim);
+    if (eval_lds_bytes(dim, 1) > 160 * 1024) return fail(IHG_ERR_INVALID, "ihg_score_topk: feature width %d does not fit the LDS pair block (widest: %d)", dim, ihg_score_topk_max_dim());
     if (workspace == nullptr || !aligned16(workspace) || workspace_bytes < ihg_score_topk_workspace_bytes(n_pairs, n_items, dim))
         return fail(IHG_ERR_WORKSPACE, "ihg_score_topk: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -1,7 +1,10 @@
-// split.hpp - internal interface of split_arith.hip: the interactive step's contractions (orders 2 and 3; d = 64, 128, 256) and the
-// node-level linear maps (d = 128, 256) with every fp32 operand taken apart EXACTLY into three bf16 terms (x = hi + mid + lo) and the
-// products accumulated in fp32 on the bf16 matrix pipe.  Not part of the C ABI: interact.hip and dense.hip choose between these and
-// their fp32-MFMA kernels through the *_ok() predicates.
+// split.hpp - internal interface of split_arith.hip (contractions per hyperedge) and split_node.hip (node-level contractions and linear maps): the interactive
+// step's contractions (orders 2 and 3) and the node-level linear maps with every fp32 operand taken apart into 16-bit terms and the partial products accumulated
+// in fp32 on the 16-bit matrix pipe.  Two schemes (split_common.hpp): TWO fp16 terms under a per-row / per-column power of two, round to nearest, three
+// v_mfma_f32_16x16x32_f16 products per multiply (what is left out is <= 3 x 2^-22 of a product) - the default path: node-level contraction and its weight
+// gradients, member gradients, node-level linear maps; and THREE bf16 terms, an exact split by truncation (x = hi + mid + lo), six v_mfma_f32_16x16x32_bf16
+// products (<= 2^-21 left out) - the hyperedge form's forward and weight-gradient kernels.  Not part of the C ABI: interact.hip and dense.hip choose between
+// these and their fp32-MFMA kernels through the *_ok() predicates.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -11,7 +14,7 @@
 
 #define IHG_INTERNAL __attribute__((visibility("hidden")))
 
-// floats of workspace the weight planes of one direction take (three bf16 per weight)
+// floats of workspace the weight planes of one direction take (sized for three bf16 per weight; the two-fp16 kernels use two thirds of it)
 IHG_INTERNAL int64_t split_plane_floats(int dim, int order);
 IHG_INTERNAL bool split_arith_enabled();                       // IHG_INTERACT_ARITH != "f32"
 IHG_INTERNAL bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout, bool user_reduced);

@@ -213,6 +213,10 @@ class IncidenceLayout:
             mask = self.__dict__['_row_mask'] = torch.zeros(self.node_count, dtype=torch.uint8, device=self.device)
         return mask
 
+    def drop_row_mask(self) -> None:
+        """Forget the mask (the next ``row_mask()`` makes a fresh all-zero one): what a user that raised between its set and its clear calls."""
+        self.__dict__.pop('_row_mask', None)
+
     def users_without_hyperedges(self):
         """int64 device indices of the user rows with an empty incidence list (the user-reduced backward writes ``dh`` only for users that have
         hyperedges: these rows are zeroed by the caller - a handful of rows instead of a fill of the whole user block)."""

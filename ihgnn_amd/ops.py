@@ -212,10 +212,17 @@ class _TwoHop(torch.autograd.Function):
             if CHECK_SPARSE_COTANGENT and bool((grad_out[mask == 0] != 0).any()):
                 _lib.check(lib.ihg_mark_rows(r64, r32, int(rows.shape[0]), _ptr(mask), 0, _stream()), 'ihg_mark_rows')
                 raise RuntimeError('node_two_hop: the cotangent is not zero outside cotangent_rows / rows - the output has a consumer the caller did not declare')
-        out = node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight, src_mask=mask,
-                                   role='k7.two_hop_bwd' if mask is None else 'k7.two_hop_bwd_masked')
-        if mask is not None:
-            _lib.check(lib.ihg_mark_rows(r64, r32, int(rows.shape[0]), _ptr(mask), 0, _stream()), 'ihg_mark_rows')
+        try:
+            out = node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight, src_mask=mask,
+                                       role='k7.two_hop_bwd' if mask is None else 'k7.two_hop_bwd_masked')
+            if mask is not None:
+                _lib.check(lib.ihg_mark_rows(r64, r32, int(rows.shape[0]), _ptr(mask), 0, _stream()), 'ihg_mark_rows')
+        except BaseException:
+            # the mask belongs to the layout and must be all zero between uses: a pull that raised leaves it so (a stale bit would make the next
+            # masked pull gather rows of a cotangent buffer that only has its batch rows written)
+            if mask is not None:
+                lay.drop_row_mask()
+            raise
         return out, None, None, None, None, None, None
 
 
@@ -1227,19 +1234,24 @@ class _HemBceLoss(torch.autograd.Function):
         return (None, None, None, dbias, None, None, None, None) + placeholders
 
 
+def score_topk_max_width() -> int:
+    """The widest feature row ``ihg_score_topk`` scores (1264): asked of the library, the one place that knows its LDS budget."""
+    return int(_lib.load().ihg_score_topk_max_dim())
+
+
 def score_topk_supported(features: Tensor) -> bool:
-    """True when ``ihg_score_topk`` takes this feature matrix: float32 GPU rows of any width up to 1272 (any row stride)."""
-    return (features.is_cuda and features.dtype == torch.float32 and features.dim() == 2 and features.stride(1) == 1 and 0 < features.shape[1] <= 1272
+    """True when ``ihg_score_topk`` takes this feature matrix: float32 GPU rows of any width up to ``score_topk_max_width()`` (any row stride)."""
+    return (features.is_cuda and features.dtype == torch.float32 and features.dim() == 2 and features.stride(1) == 1 and 0 < features.shape[1] <= score_topk_max_width()
             and (features.shape[0] <= 1 or features.stride(0) >= features.shape[1]))
 
 
 def score_topk(features: Tensor, users: Tensor, queries: Tensor, query_row0: int, item_row0: int, item_bias: Tensor, lam: float, k: int = 10):
     """Evaluation scoring: for every (user, query) pair the ``k`` best items over ALL items and their HEM scores,
     ``(top_items [C, k] int32, top_scores [C, k])``, best first, ties in ascending item order; the ``[C, I]`` score matrix is
-    never materialised.  ``features`` = the cached ``[N, D]`` propagation output (any width up to 1272); items are its rows from ``item_row0`` on."""
+    never materialised.  ``features`` = the cached ``[N, D]`` propagation output (any width up to ``score_topk_max_width()``); items are its rows from ``item_row0`` on."""
     lib = _lib.load()
     if not score_topk_supported(features):
-        raise _lib.IhgnnHipError(f'ihg_score_topk needs a float32 GPU feature matrix of width <= 1272, got {tuple(features.shape)} {features.dtype} on {features.device}')
+        raise _lib.IhgnnHipError(f'ihg_score_topk needs a float32 GPU feature matrix of width <= {score_topk_max_width()}, got {tuple(features.shape)} {features.dtype} on {features.device}')
     n_pairs = int(users.shape[0])
     n_items = int(features.shape[0]) - int(item_row0)
     dim = int(features.shape[1])

@@ -264,7 +264,7 @@ int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, c
  * ihg_node_interact_fwd: out[v] = out_scale[v] * ( degree[v] (A_t h[v] + bias) + the typed blocks of w applied to the sums and their
  *   products with h[v] ), w = [A_u | A_q | A_i | W_uq | W_qi | W_iu (| W_uqi)] as in ihg_interact_fwd, rows grouped by type_begin[4]
  *   (host array).  degree: the node's hyperedge count as float (0 for an isolated node); out_scale / bias may be NULL.  Available where
- *   ihg_node_interact_fwd_supported says so (dim 128, bf16-split arithmetic on); the hyperedge form (ihg_interact_fwd +
+ *   ihg_node_interact_fwd_supported says so (dim 64 / 128 / 256, split arithmetic on: IHG_INTERACT_ARITH != f32); the hyperedge form (ihg_interact_fwd +
  *   ihg_node_segment_sum) is the path everywhere else and gives the same rows to the tolerance of DESIGN.md section 5.
  */
 int ihg_node_pair_sums(const float* h, int64_t ld_h, const int32_t* pair_ptr, const int32_t* pair_ids, const int32_t* row_order, float* sums,
@@ -281,7 +281,7 @@ int ihg_node_interact_fwd(const float* h, int64_t ld_h, const float* sums, int64
  *   d W_block = sum over the nodes of (dy_scale[v] dy[v]) x X_block[v]^T, X = h * sums_a | h * sums_b | sums_ab | h * sums_ab assigned to the blocks of w by
  *   node type - N rows instead of n_edges hyperedges, no gathers.  dy: the layer output's cotangent [N, dim]; dy_scale (NULL: 1): the out_scale of the
  *   forward.  The first-order blocks dw[:, :3 dim] are not written (ihg_node_linear_bwd_weight has them).  With this, ihg_interact_bwd_gathered is called
- *   with dw == NULL (member gradients only).  Available where ihg_node_interact_bwd_weight_supported says so (dim 128, bf16-split arithmetic on).
+ *   with dw == NULL (member gradients only).  Available where ihg_node_interact_bwd_weight_supported says so (dim 64 / 128 / 256, split arithmetic on: IHG_INTERACT_ARITH != f32).
  */
 int32_t ihg_node_interact_bwd_weight_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_sums, int64_t ld_dy);
 int64_t ihg_node_interact_bwd_weight_workspace_bytes(int32_t dim, int32_t order);
@@ -307,7 +307,7 @@ int ihg_node_interact_bwd_weight(const float* h, int64_t ld_h, const float* sums
  *              t * dw_type_stride); at dim 64 / 128 both come from one pass over dout, otherwise it runs the bwd_input launch itself.
  *              dx_accumulate != 0: dx += instead of dx = (a second contribution to the same gradient: the member gradients of
  *              the interactive step land in dx first, Models/CommonLayers.py:70-85) - where ihg_node_linear_bwd_accumulates
- *              says so (dim 64; dim 128 on the bf16-split kernels)
+ *              says so (dim 64; dim 128 on the split-arithmetic kernels)
  * Any dim > 0: 32, 64, 128, 256 with 16-byte aligned rows run on the matrix cores, every other shape on the any-width
  * kernels (row-slab partials + a fixed-order sum for the weight gradient).  `workspace`: ihg_node_linear_workspace_bytes(dim)
  * bytes, 16-byte aligned.
@@ -423,13 +423,15 @@ int ihg_sample_negatives(uint64_t seed, uint64_t counter, int64_t n_rows, int64_
  *                 + item_bias[i]
  *   top_items[c][0..k) = the k items of highest score, best first; equal scores in ascending item order (a stable descending
  *   sort; the reference's sort is unstable on ties); top_scores[c][0..k) their scores.  With fewer than k items the tail is -1.
- * `features` is the cached [N, dim] propagation output (any row stride >= dim, dim <= 1272); k <= 10.
+ * `features` is the cached [N, dim] propagation output (any row stride >= dim, dim <= ihg_score_topk_max_dim() = 1264: the mixed rows of 32 pairs
+ * stay in LDS); k <= 10.
  * The [n_pairs, n_items] score matrix is never stored: 32 x 32 matrix-core tiles are reduced to per-lane top-k lists in registers.  Arithmetic: every row is
  * multiplied by a power of two and taken apart into two fp16 terms (hi + lo, 22 significand bits); a product is three v_mfma_f32_32x32x16_f16 partial products
  * accumulated in fp32 (relative error <= 3 x 2^-22 per product, as accurate as the fp32 matrix instructions on these sums - tests/test_gpu_parity.py); the item rows are
  * split once per call into the workspace.
  * Workspace: ihg_score_topk_workspace_bytes(n_pairs, n_items, dim) bytes (the split item rows + partial lists).
  */
+int32_t ihg_score_topk_max_dim(void);
 int64_t ihg_score_topk_workspace_bytes(int64_t n_pairs, int64_t n_items, int32_t dim);
 int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query_row0, int64_t item_row0, int64_t n_items,
                    const float* item_bias, const int64_t* users, const int64_t* queries, float lambda_muq, int64_t n_pairs,
@@ -449,7 +451,7 @@ int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query
  *                                      backward pass, without a host read or a separate multiply launch
  *   ihg_batch_rows_put                 ihg_batch_rows_add into typed rows; assign != 0: dense[rows[k]] = src[k] on the leader rows (a gradient that is
  *                                      zero elsewhere and read at these rows only: no fill of the matrix)
- * Available where ihg_node_linear_typed_supported says so (dim 128 / 256 on the bf16-split kernels, row strides % 4 == 0, 16-byte aligned rows).
+ * Available where ihg_node_linear_typed_supported says so (dim 128 / 256 on the split-arithmetic kernels, row strides % 4 == 0, 16-byte aligned rows).
  */
 int32_t ihg_node_linear_typed_supported(int32_t dim, int64_t ld_x, int64_t ld_out);
 int ihg_node_linear_fwd_typed(const float* const* x_rows, int64_t ld_x, const float* w, int64_t ld_w, int64_t w_type_stride,

@@ -38,16 +38,30 @@ def golden():
     return load
 
 
-def f8_case(tag):
-    """Wide-model fixture F8 (``tests/golden/f8_wide_models.npz``): ``(cfg, state dict as numpy, fixture)`` with the weights
-    regenerated from the seed the generator used (``tests/golden/seeded_weights.py``)."""
+def f8_case(tag, fixture='f8_wide_models.npz'):
+    """Wide-model fixture F8 (``tests/golden/f8_wide_models.npz``; F10, the training curves at those widths, keeps its weights the same way):
+    ``(cfg, state dict as numpy, fixture)`` with the weights regenerated from the seed the generator used (``tests/golden/seeded_weights.py``)."""
     if GOLDEN not in sys.path:
         sys.path.insert(0, GOLDEN)
     from seeded_weights import seeded_state
-    z = np.load(os.path.join(GOLDEN, 'f8_wide_models.npz'))
+    z = np.load(os.path.join(GOLDEN, fixture))
     L, order, d, seed = (int(v) for v in z[f'{tag}.cfg'])
     shapes = [(str(k), tuple(int(x) for x in str(s).split(';'))) for k, s in zip(z[f'{tag}.keys'], z[f'{tag}.shapes'])]
     return (L, order, d), seeded_state(shapes, seed), z
+
+
+F10_TAGS = ('d128_l3_o3', 'd64_l2_o3', 'd32_l2_o3', 'd128_l3_o2')
+
+
+def f10_case(tag):
+    """Training-curve fixture F10 (``tests/golden/f10_training.npz`` + ``f10_workload.npz``): ``(cfg, initial state dict, fixture, workload)``."""
+    cfg, sd, z = f8_case(tag, 'f10_training.npz')
+    return cfg, sd, z, np.load(os.path.join(GOLDEN, 'f10_workload.npz'))
+
+
+def state_digest(tensors):
+    """[[sum, sum of squares]] per tensor in float64 - what F10 keeps of the trained weights."""
+    return np.array([[float(np.asarray(v, np.float64).sum()), float((np.asarray(v, np.float64) ** 2).sum())] for v in tensors], np.float64)
 
 
 def f8_gradient_error(z, tag, name, grad):

@@ -487,7 +487,99 @@ def make_f9():
     np.savez(os.path.join(HERE, 'f9_log_hypergraph.npz'), **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# F10: the F6 experiment at the widths the headline arithmetic runs on (two-fp16-term contractions, node-level
+# form, gathering member gradients): d = 128 x 3 layers x order 3 and d = 64 x 2 layers x order 3, plus the reference's
+# default width d = 32 x 2 layers.  The graph is big enough for several row tiles per node type, several
+# hyperedge tiles per workgroup range and split rows (power-law members: the top query sits in > 256 hyperedges).
+# Initial weights from seeded_weights.py; batches are the reference DataLoader's, kept as int16.
+# ---------------------------------------------------------------------------------------------
+F10_COUNTS = (900, 120, 700, 80, 6000)
+F10_CASES = (('d128_l3_o3', 3, 3, 128, 1001), ('d64_l2_o3', 2, 3, 64, 1002), ('d32_l2_o3', 2, 3, 32, 1003), ('d128_l3_o2', 3, 2, 128, 1004))
+F10_STEPS = 48
+
+
+def f10_workload():
+    U, Q, I, V, E = F10_COUNTS
+    w = synth.draw(U, Q, I, V, E, seed=10, distribution='powerlaw', exponent=1.1, eval_logs=0)
+    # held-out logs a trained model can rank: (user, query) pairs of the training graph with the items they met there
+    rng = np.random.default_rng(1010)
+    logs, seen = [], set()
+    for e in rng.permutation(E):
+        u, q, _ = (int(x) for x in w.triples[e])
+        if (u, q) in seen:
+            continue
+        seen.add((u, q))
+        items = sorted(set(int(x) for x in w.triples[(w.triples[:, 0] == u) & (w.triples[:, 1] == q), 2]))
+        logs.append((u, q, items))
+        if len(logs) == 96:
+            break
+    w.valid_logs, w.test_logs = logs[:48], logs[48:]
+    return w
+
+
+def make_f10():
+    from torch.utils.data import DataLoader
+    sys.path.insert(0, HERE)
+    from seeded_weights import seeded_state
+    w = f10_workload()
+    paths = synth.write_files(w, '/tmp/ihgnn_golden_f10')
+    np.savez_compressed(os.path.join(HERE, 'f10_workload.npz'), triples=w.triples.astype(np.int32), bag_words=w.bag_words, bag_offsets=w.bag_offsets,
+                        counts=np.array(F10_COUNTS[:4], np.int64),
+                        test_uq=np.array([(a, b) for a, b, _ in w.test_logs], np.int64),
+                        test_items_flat=np.array(sum([c for _, _, c in w.test_logs], []), np.int64),
+                        test_items_len=np.array([len(c) for _, _, c in w.test_logs], np.int64))
+    ds = load_dataset(paths)
+    out = {}
+    for tag, L, order, d, seed in F10_CASES:
+        seed_all(seed)
+        m = RawGnn(CPU, ds, d, IHGNNLayer, L, order, False, HemPredictionLayer, 0.5)
+        shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded_state(shapes, seed).items()})
+        loader = DataLoader(ds, 100, shuffle=True, collate_fn=GraphDataset.collate_fn)
+        opt = torch.optim.Adam(m.parameters(), 1e-3, weight_decay=0)
+        lossf = torch.nn.BCEWithLogitsLoss()
+        batches, losses = [], []
+        step = 0
+        while step < F10_STEPS:
+            for pu, pq, pi, pf, nu, nq, ni, nf in loader:
+                u, q, i = torch.cat([pu, nu]), torch.cat([pq, nq]), torch.cat([pi, ni])
+                fl = torch.cat([pf, nf]).float()
+                loss = lossf(m(u, q, i), fl)
+                loss.backward(); opt.step(); opt.zero_grad()
+                batches.append(torch.stack([u, q, i, fl.long()]).numpy().astype(np.int16))
+                losses.append(loss.item())
+                step += 1
+                if step >= F10_STEPS:
+                    break
+        out[f'{tag}.batches'] = np.stack(batches)
+        out[f'{tag}.losses'] = np.array(losses, np.float64)
+        test = TestSearchLogDataLoader(paths['fn_test_data'], ds, CPU)
+        total, n = Metrics(), 0
+        per_log = []
+        with torch.no_grad():
+            m.save_features_for_test()
+            for users, queries, items, _, all1 in test:
+                mm = Metrics.calculate_on_all_items(m(users, queries, None), items, None, all1)
+                total.add_to_self(mm); n += 1
+                per_log.append((mm.HitRatio_at10, mm.NDCG_at10, mm.MAP_at10))
+            m.clear_saved_feature()
+        avg = total.divide_and_get_new(n)
+        out[f'{tag}.metrics'] = np.array([avg.HitRatio_at10, avg.NDCG_at10, avg.MAP_at10], np.float64)
+        out[f'{tag}.metrics_per_log'] = np.array(per_log, np.float64)
+        out[f'{tag}.cfg'] = np.array([L, order, d, seed], np.int64)
+        out[f'{tag}.keys'] = np.array([k for k, _ in shapes])
+        out[f'{tag}.shapes'] = np.array([';'.join(map(str, s)) for _, s in shapes])
+        # the trained weights, digested: per-parameter float64 sum and sum of squares (a whole-run check beyond the loss curve)
+        out[f'{tag}.final_digest'] = np.array([[float(v.double().sum()), float((v.double() ** 2).sum())] for v in m.state_dict().values()], np.float64)
+        print(f'F10 {tag}: loss {losses[0]:.6f} -> {losses[-1]:.6f}; HR/NDCG/MAP@10 {out[tag + ".metrics"]} over {n} logs')
+    np.savez_compressed(os.path.join(HERE, 'f10_training.npz'), **out)
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['f10']:
+        make_f10()
+        sys.exit(0)
     if sys.argv[1:] == ['f9']:
         make_f9()
         sys.exit(0)
@@ -504,6 +596,7 @@ if __name__ == '__main__':
     make_f7()
     make_f8(ds_small)
     make_f9()
+    make_f10()
     for fn in sorted(os.listdir(HERE)):
         p = os.path.join(HERE, fn)
         if os.path.isfile(p):

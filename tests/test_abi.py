@@ -29,6 +29,18 @@ def test_library_exports_every_declared_symbol():
     assert lib.ihg_ablation_build() == 0, 'the shipped library was built with an ablation switch (csrc/ablate.hpp)'
 
 
+def test_widest_scored_row_is_one_number_everywhere():
+    """The evaluation kernel's width limit comes from the library's LDS budget; the model's constructor check and the header quote the same number."""
+    from ihgnn_amd.Models import RawGnn
+    lib = _lib.load()
+    assert lib.ihg_score_topk_max_dim() == RawGnn.MAX_SCORED_WIDTH
+    assert f'ihg_score_topk_max_dim() = {RawGnn.MAX_SCORED_WIDTH}' in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'ihgnn_hip.h')).read()
+    ws = ctypes.c_void_p(16)
+    # one past the limit is refused with a message that names the limit (argument checks come before any launch: runs without a GPU)
+    rc = lib.ihg_score_topk(ws, 2000, RawGnn.MAX_SCORED_WIDTH + 1, 0, 0, 10, ws, ws, ws, 0.5, 1, 10, ws, ws, ws, 1 << 40, None)
+    assert rc != 0 and str(RawGnn.MAX_SCORED_WIDTH) in _lib.last_error()
+
+
 def test_bad_arguments_return_codes_and_messages():
     lib = _lib.load()
     assert lib.ihg_edge_gather_sum(None, 4, None, None, None, 1.0, None, 4, 5, 4, None) == _lib.ERR_INVALID

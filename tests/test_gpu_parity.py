@@ -497,7 +497,7 @@ def test_interact_split_kernels_on_tiny_hypergraphs(dim, edges):
 
 @pytest.mark.parametrize('which', ['forward_backward', 'persistent', 'user_slot'])
 def test_interact_fp32_mfma_kernels_stay_covered(which, monkeypatch):
-    """Orders 2 and 3 at d = 64 / 128 / 256 run on the bf16-split kernels by default; IHG_INTERACT_ARITH=f32 (read by the library at every call)
+    """Orders 2 and 3 at d = 64 / 128 / 256 run on the split-arithmetic kernels (two fp16 / three bf16 terms per fp32 operand) by default; IHG_INTERACT_ARITH=f32 (read by the library at every call)
     selects the fp32-MFMA kernels, which must keep passing the same cases."""
     monkeypatch.setenv('IHG_INTERACT_ARITH', 'f32')
     if which == 'forward_backward':
@@ -633,9 +633,10 @@ def test_interactive_layer_without_hyperedge_rows(order, dim, monkeypatch):
 
 @pytest.mark.parametrize('dim,scale', [(64, 1.0), (128, 1.0), (256, 1.0), (128, 3.0e3), (128, 2.0e-4)])
 def test_split_arithmetic_is_as_accurate_as_fp32_mfma(dim, scale, monkeypatch):
-    """The order-3 contractions through three exact bf16 terms per operand (six bf16 MFMA products, fp32 accumulation; forward at d = 64 / 128,
-    member and weight gradients at d = 64 / 128 / 256) against the same op in float64: the error must not exceed the fp32-MFMA kernels' own
-    (both are far inside the 1e-5 bar).  Also the node-level linear map, which takes the same arithmetic at d = 128 / 256."""
+    """The order-3 contractions of the hyperedge form on the 16-bit matrix pipe (forward and weight gradients: three exact bf16 terms per operand, six
+    v_mfma_f32_16x16x32_bf16 products; member gradients: two fp16 terms under a per-row power of two, three v_mfma_f32_16x16x32_f16 products; fp32 accumulation)
+    against the same op in float64: the error must not exceed the fp32-MFMA kernels' own (both are far inside the 1e-5 bar).  Also the node-level linear
+    map (two fp16 terms at d = 128 / 256)."""
     from ihgnn_amd import ops
     from oracle import ihgnn_ref as ref
     order, U, Q, I, E = 3, 301, 17, 211, 9000
@@ -668,34 +669,44 @@ def test_split_arithmetic_is_as_accurate_as_fp32_mfma(dim, scale, monkeypatch):
         assert es <= RTOL / 5 and es <= max(2 * ef, 5e-7), (err_split, err_f32)
 
 
+def _adversarial_generators(scheme, gen):
+    """Operands at the worst case of one operand split (tests/split_emulation.py searches the significands; tests/test_host_logic.py holds the searches' results):
+    ``two_fp16``: 1 + 4093 * 2^-23 - hi = 1, lo = 4092 * 2^-23 (a tie, rounded to even), residual + 2^-23: every product of two such values omits + 2^-21 of itself;
+    ``three_bf16``: the low 16 bits of the significand set - truncation leaves mid ~ 2^-7 x, lo ~ 2^-15 x and the omitted mid lo + lo mid + lo lo ~ + 2^-21 of the product.
+    Each pattern is harmless under the OTHER split (two-fp16: the bf16 pattern splits exactly; three-bf16: the fp16 pattern has zero mid below bit 16), so a kernel's
+    worst case is the run with ITS scheme's pattern."""
+    import split_emulation as se
+    sig, loss = se.worst_two_fp16_significand() if scheme == 'two_fp16' else se.worst_three_bf16_significand()
+    assert loss >= 0.95 * 2.0 ** -21
+
+    def adversarial(*shape):
+        return np.float32(sig) * torch.exp2(torch.randint(-3, 3, shape, generator=gen).float())
+
+    def power_of_two(*shape):
+        return torch.exp2(torch.randint(-2, 2, shape, generator=gen).float())
+    return adversarial, power_of_two
+
+
 @pytest.mark.parametrize('dim', [64, 128, 256])
-def test_split_arithmetic_worst_case_operands(dim):
-    """The split truncates toward zero, so the three products it leaves out (mid*lo, lo*mid, lo*lo) all carry the sign of the product
-    they belong to.  Worst case: every operand has the low 16 bits of its significand set (x = (1 + (2^16 - 1) 2^-23) 2^k: mid ~ 2^-7 x,
-    lo ~ 2^-15 x, so mid*lo + lo*mid ~ 2^-21 |ab|) and every product of a dot product has the same sign - the omitted terms then add
-    up instead of averaging out.  Users and items carry powers of two, queries and the weights the adversarial significand, so the
-    products uq, qi and uqi inherit it exactly.  Error against float64, forward and both gradients, and the node-level linear map:
-    measured at d = 64: 4.5e-7 ... 5.6e-7 for the single contractions (2^-21 = 4.8e-7 plus fp32 accumulation) and 1.3e-6 for the member
-    gradients (a split contraction followed by the product rule); at d = 256 (contraction length 1,024): forward 1.4e-6, member gradients
-    1.4e-6, node-level map 9.3e-7.  The bound held here is 2e-6, a fifth of the 1e-5 contract."""
+@pytest.mark.parametrize('scheme', ['two_fp16', 'three_bf16'])
+def test_split_arithmetic_worst_case_operands(dim, scheme):
+    """Every contraction kernel of the interactive layer at the worst case of the operand split it runs on, all products of every dot product POSITIVE so that what a split
+    omits adds up instead of averaging out.  Round-to-nearest two-fp16 terms (member gradients, node-level contraction and weight gradients, node-level linear maps - the
+    default path): omitted lo lo + residuals = 2^-21 = 4.8e-7 per product at 1 + 4093 * 2^-23; truncating three-bf16 terms (the hyperedge form's forward and weight kernels):
+    2^-21 with the low 16 bits set.  Users and items carry powers of two, queries and the weights the adversarial significand, so the products uq, qi and uqi inherit it
+    exactly.  Against float64: hyperedge-form forward and both gradients, the node-level linear map forward and backward, and - on a graph whose users have ONE hyperedge
+    each, so that their pair sums ARE the adversarial rows - the layer in its node-level form (output, d h, d w).  The bound held is 2e-6, a fifth of the 1e-5 contract."""
     from ihgnn_amd import ops
+    from ihgnn_amd.layout import IncidenceLayout
     from oracle import ihgnn_ref as ref
     order, U, Q, I, E = 3, 301, 17, 211, 9000
     w_, lay = make_layout(U, Q, I, E, seed=6, edge_order='user')
     gen = torch.Generator().manual_seed(13)
-
-    def adversarial(*shape):
-        k = torch.randint(-3, 3, shape, generator=gen).float()
-        return (1.0 + (2.0 ** 16 - 1) * 2.0 ** -23) * torch.exp2(k)
-
-    def power_of_two(*shape):
-        return torch.exp2(torch.randint(-2, 2, shape, generator=gen).float())
+    adversarial, power_of_two = _adversarial_generators(scheme, gen)
 
     h = torch.cat([power_of_two(U, dim), adversarial(Q, dim), power_of_two(I, dim)])
     w = adversarial(dim, 7 * dim) / 64
     cot = adversarial(lay.edge_count, dim) / 8
-    bits = h[U:U + Q].view(torch.int32) & 0xFFFF
-    assert bool((bits == 0xFFFF).all())
     h64, w64 = h.double().requires_grad_(True), w.double().requires_grad_(True)
     want = ref.feature_interactor(h64, torch.from_numpy(lay.i3_host.astype(np.int64)), w64, torch.zeros(dim).double(), order)
     want.backward(cot.double())
@@ -708,16 +719,45 @@ def test_split_arithmetic_worst_case_operands(dim):
     i3 = torch.from_numpy(lay.i3_host.astype(np.int64))
     prod64 = want.detach() - ((first64[i3[:, 0]] + first64[i3[:, 1]]) + first64[i3[:, 2]])          # the product blocks' part in float64
     prod = got.detach().cpu().double() - ((first.detach().cpu().double()[i3[:, 0]] + first.detach().cpu().double()[i3[:, 1]]) + first.detach().cpu().double()[i3[:, 2]])
+    # node-level linear map, forward and backward (d x = cot W, d W = cot^T x: both operands adversarial)
     wl = adversarial(dim, dim) / 16
     x = adversarial(lay.node_count, dim)
-    lin = ops.node_linear(x.to(dev()), wl.to(dev()), None, lay)
+    cl = adversarial(lay.node_count, dim) / 4
+    xd, wld = x.to(dev()).requires_grad_(True), wl.to(dev()).requires_grad_(True)
+    lin = ops.node_linear(xd, wld, None, lay)
+    lin.backward(cl.to(dev()))
     # d h: the first-order blocks enter `want` too; take them out (exact in float64)
     dfirst = torch.zeros(lay.node_count, dim, dtype=torch.float64).index_add_(0, i3.reshape(-1), cot.double().repeat_interleave(3, 0))
     dh_first = torch.cat([dfirst[:U] @ w64.detach()[:, :dim], dfirst[U:U + Q] @ w64.detach()[:, dim:2 * dim], dfirst[U + Q:] @ w64.detach()[:, 2 * dim:3 * dim]])
     errors = dict(forward=rel(prod, prod64), member_gradients=rel(hg.grad.double().cpu(), h64.grad - dh_first),
-                  weight_gradients=rel(wg.grad[:, 3 * dim:].double(), w64.grad[:, 3 * dim:]), node_linear=rel(lin.double(), x.double() @ wl.double().T))
-    print('split arithmetic, worst-case operands, d =', dim, errors)
+                  weight_gradients=rel(wg.grad[:, 3 * dim:].double(), w64.grad[:, 3 * dim:]), node_linear=rel(lin.double(), x.double() @ wl.double().T),
+                  node_linear_dx=rel(xd.grad.double(), cl.double() @ wl.double()), node_linear_dw=rel(wld.grad.double(), cl.double().T @ x.double()))
+
+    # the layer in its node-level form where a user's pair sums are single adversarial rows: one hyperedge per user
+    E1, Q1, I1 = 4000, 9, 23
+    rng = np.random.default_rng(dim)
+    lay1 = IncidenceLayout(np.stack([np.arange(E1), rng.integers(0, Q1, E1), rng.integers(0, I1, E1)], 1), E1, Q1, I1, dev(), edge_order='user')
+    h1 = torch.cat([power_of_two(E1, dim), adversarial(Q1, dim), power_of_two(I1, dim)])
+    dy1 = adversarial(lay1.node_count, dim)
+    b1 = adversarial(dim)
+    i31 = torch.from_numpy(lay1.i3_host.astype(np.int64))
+    inv1 = lay1.inv_deg.cpu().double()
+    h164, w164, b164 = h1.double().requires_grad_(True), w.double().requires_grad_(True), b1.double().requires_grad_(True)
+    ef = ref.feature_interactor(h164, i31, w164, b164, order)
+    y64 = inv1[:, None] * torch.zeros(lay1.node_count, dim, dtype=torch.float64).index_add(0, i31.reshape(-1), ef.repeat_interleave(3, 0))
+    y64.backward(dy1.double())
+    h1d, w1d, b1d = h1.to(dev()).requires_grad_(True), w.clone().to(dev()).requires_grad_(True), b1.to(dev()).requires_grad_(True)
+    y1 = ops.interact_layer(h1d, w1d, b1d, lay1, order, lay1.inv_deg)
+    y1.backward(dy1.to(dev()))
+    users = slice(0, E1)
+    errors.update(node_level_user_rows=row_rel(y1[users], y64.detach()[users], floor=0.0), node_level_forward=rel(y1, y64.detach()),
+                  node_level_dh=rel(h1d.grad, h164.grad), node_level_dh_user_rows=row_rel(h1d.grad[users], h164.grad[users], floor=0.0),
+                  node_level_dw=rel(w1d.grad, w164.grad), node_level_dw_product_blocks=rel(w1d.grad[:, 3 * dim:], w164.grad[:, 3 * dim:]), node_level_dbias=rel(b1d.grad, b164.grad))
+    print('split arithmetic, worst-case operands,', scheme, 'd =', dim, {k: f'{v:.2e}' for k, v in errors.items()})
     assert max(errors.values()) <= RTOL / 5, errors
+    # the test is not vacuous: at least one kernel of the scheme shows the one-sided loss it was built for (> 2^-22; random operands sit at ~ 3e-8)
+    mine = ('member_gradients', 'node_linear', 'node_level_user_rows') if scheme == 'two_fp16' else ('forward', 'weight_gradients')
+    assert max(errors[k] for k in mine) >= 2.0 ** -22, errors
 
 
 @pytest.mark.parametrize('dim', [128, 256])
@@ -983,6 +1023,73 @@ def test_f6_training_curve_and_ranking_metrics(tag, path):
         m.clear_saved_feature()
     avg = acc.divide_and_get_new(len(w['test_uq']))
     np.testing.assert_allclose([avg.HitRatio_at10, avg.NDCG_at10, avg.MAP_at10], z[f'{tag}.metrics'], atol=2e-3)
+
+
+# what a training step of each F10 case must launch on the default switches (profiler names) - the arithmetic BENCH times - and what it must not
+F10_LAUNCHES = {
+    'd128_l3_o3': ({'node_pair_sums', 'node_interact_fwd', 'node_interact_bwd_weight', 'interact_bwd', 'k7.two_hop_first_order_gradient'}, {'interact_fwd', 'edge_gather_sum'}),
+    'd128_l3_o2': ({'node_pair_sums', 'node_interact_fwd', 'node_interact_bwd_weight', 'interact_bwd', 'k7.two_hop_first_order_gradient'}, {'interact_fwd', 'edge_gather_sum'}),
+    'd64_l2_o3': ({'node_pair_sums', 'node_interact_fwd', 'node_interact_bwd_weight', 'interact_bwd'}, {'interact_fwd'}),
+    'd32_l2_o3': ({'interact_bwd'}, set()),
+}
+
+
+@pytest.mark.parametrize('path', ['module_calls', 'fused_step'])
+@pytest.mark.parametrize('tag', ['d128_l3_o3', 'd64_l2_o3', 'd32_l2_o3', 'd128_l3_o2'])
+def test_f10_training_curve_and_ranking_metrics_on_the_headline_arithmetic(tag, path):
+    """The north_star's acceptance clause on the arithmetic the headline runs: 48 Adam steps of the REFERENCE (fixture F10: d = 128 x 3 layers orders 3 / 2,
+    d = 64 x 2 layers, d = 32 x 2 layers - its default width; power-law graph of 6,000 hyperedges with split rows, several row tiles per node type) replayed on
+    both call paths with the default switches: two-fp16-term contractions, the interactive layer in its node-level form, the gathering member-gradient kernel,
+    the two-hop first-order gradient.  Loss curve to 1e-4, HR@10 / NDCG@10 / MAP@10 within 0.002, trained weights' digests; the profiler says which kernels ran."""
+    from conftest import f10_case, state_digest
+    from ihgnn_amd import profiler
+    from ihgnn_amd.Helpers.Metrics import Metrics
+    (L, order, d), sd, z, w = f10_case(tag)
+    ds = dataset_from_npz(w)
+    assert ds.hypergraph.layout.node_csr.n_heavy > 0                    # split rows are on the path
+    m = build_model(ds, 'ihgnn', L, order, d)
+    assert set(sd) == set(m.state_dict())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    if path == 'fused_step':
+        from ihgnn_amd.optim import Adam
+        opt = Adam(m.parameters(), 1e-3, weight_decay=0)
+    else:
+        opt = torch.optim.Adam(m.parameters(), 1e-3, weight_decay=0)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    losses = []
+    profiler.start()
+    for b in z[f'{tag}.batches']:
+        u, q, i, fl = (torch.from_numpy(b[k].astype(np.int64)).to(dev()) for k in range(4))
+        loss = m.bce_loss(u, q, i, fl.float()) if path == 'fused_step' else lossf(m(u, q, i), fl.float())
+        loss.backward(); opt.step(); opt.zero_grad()
+        losses.append(loss.item())
+    launched = profiler.summary()
+    profiler.stop()
+    must, must_not = F10_LAUNCHES[tag]
+    assert must <= set(launched) and not (must_not & set(launched)), sorted(launched)
+    worst = float(np.abs(np.array(losses) / z[f'{tag}.losses'] - 1).max())
+    print(f'F10 {tag} {path}: worst loss deviation over {len(losses)} steps {worst:.2e}')
+    np.testing.assert_allclose(losses, z[f'{tag}.losses'], rtol=1e-4)
+    ends = np.cumsum(w['test_items_len'])
+    acc = Metrics()
+    per_log = []
+    with torch.no_grad():
+        m.save_features_for_test()
+        for k, (uu, qq) in enumerate(w['test_uq']):
+            items = w['test_items_flat'][ends[k] - w['test_items_len'][k]:ends[k]].tolist()
+            one = torch.tensor([int(uu)], device=dev()).expand(ds.item_count)
+            oneq = torch.tensor([int(qq)], device=dev()).expand(ds.item_count)
+            mm = Metrics.calculate_on_all_items(m(one, oneq, None), items, None, True)
+            acc.add_to_self(mm)
+            per_log.append((mm.HitRatio_at10, mm.NDCG_at10, mm.MAP_at10))
+        m.clear_saved_feature()
+    avg = acc.divide_and_get_new(len(w['test_uq']))
+    got = np.array([avg.HitRatio_at10, avg.NDCG_at10, avg.MAP_at10])
+    print(f'F10 {tag} {path}: HR/NDCG/MAP@10 {got} reference {z[f"{tag}.metrics"]}; logs whose metrics differ: {int((np.abs(np.array(per_log) - z[f"{tag}.metrics_per_log"]).max(1) > 1e-9).sum())} of {len(per_log)}')
+    np.testing.assert_allclose(got, z[f'{tag}.metrics'], atol=2e-3)
+    # the trained weights as a whole: per-parameter sum of squares against the reference's (sums of O(1e3) values of mixed sign are not compared relatively)
+    digest = state_digest([v.detach().cpu().numpy() for v in m.state_dict().values()])
+    np.testing.assert_allclose(digest[:, 1], z[f'{tag}.final_digest'][:, 1], rtol=2e-5)
 
 
 def test_full_size_properties_c2_shape():
@@ -1501,13 +1608,17 @@ def test_batched_evaluation_equals_per_log_scoring(tmp_path):
     np.testing.assert_allclose([avg.HitRatio_at10, avg.NDCG_at10, avg.MAP_at10], [want.HitRatio_at10, want.NDCG_at10, want.MAP_at10], atol=1e-9)
 
 
-@pytest.mark.parametrize('dim,n_items,n_pairs', [(64, 257, 5), (36, 31, 40), (192, 70001, 97), (512, 4100, 33), (128, 7, 3), (768, 1200, 64), (150, 333, 21), (7, 90, 9)])
+@pytest.mark.parametrize('dim,n_items,n_pairs', [(64, 257, 5), (36, 31, 40), (192, 70001, 97), (512, 4100, 33), (128, 7, 3), (768, 1200, 64), (150, 333, 21), (7, 90, 9),
+                                                (1264, 530, 37), (1263, 200, 33), (624, 300, 70), (625, 300, 70)])
 def test_score_topk_matches_oracle(dim, n_items, n_pairs):
     """f1: the fused scoring + running top-10 kernel against the oracle's HEM scores of every item (PredictionLayers.py:35-43) sorted
     as Metrics.calculate_on_all_items does (Metrics.py:60-61) - widths with dim % 8 == 4, item counts off the 32-item tile, fewer
-    than ten items, pair counts off the 32-pair block, enough items for several item slices per pair block."""
+    than ten items, pair counts off the 32-pair block, enough items for several item slices per pair block, the widest row the kernel takes
+    (``RawGnn.MAX_SCORED_WIDTH`` = ``ihg_score_topk_max_dim()`` = 1264: one pair tile per workgroup) and the widths either side of the two-tile limit (624 / 625)."""
     from ihgnn_amd import ops
+    from ihgnn_amd.Models import RawGnn
     from oracle import ihgnn_ref as ref
+    assert ops.score_topk_max_width() == RawGnn.MAX_SCORED_WIDTH == 1264
     U, Q = 50, 20
     gen = torch.Generator().manual_seed(dim + n_items)
     feats = torch.randn(U + Q + n_items, dim, generator=gen) / np.sqrt(dim)
@@ -1608,11 +1719,19 @@ def test_driver_end_to_end(tmp_path, monkeypatch):
     # the same run with the training step replayed from a recording (full batches: replays; the epoch's short last batch: eager)
     import random
     random.seed(11); torch.manual_seed(11)
-    eager = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '2', '--est', '2', '--etf', '1'])
+    eager = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '2', '--est', '2', '--etf', '1', '--record_step', 'off'])
     random.seed(11); torch.manual_seed(11)
     recorded = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '2', '--est', '2', '--etf', '1', '--record_step'])
     (_, m_e), (_, m_r) = list(eager.iter_epoch_test())[-1], list(recorded.iter_epoch_test())[-1]
     assert abs(m_e.NDCG_at10 - m_r.NDCG_at10) <= 2e-3 and abs(m_e.HitRatio_at10 - m_r.HitRatio_at10) <= 2e-3
+    assert eager.training_step_recorded is False and recorded.training_step_recorded is True
+    # the DEFAULT (auto): this model's eager step is launch-bound (a few hundred microseconds of kernels behind ~ 70 launches), so after seven eager steps - three to
+    # warm up, four timed - the loop records the step by itself; same metrics
+    random.seed(11); torch.manual_seed(11)
+    auto = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '3', '--est', '2', '--etf', '1'])
+    assert auto.training_step_recorded is True and auto.eager_step_ms < 1.5
+    m_a = dict(auto.iter_epoch_test())[2]
+    assert abs(m_e.NDCG_at10 - m_a.NDCG_at10) <= 2e-3 and abs(m_e.HitRatio_at10 - m_a.HitRatio_at10) <= 2e-3
 
 
 @pytest.mark.parametrize('tag,d,mode', [('tiny_uqi', 8, 'uqi'), ('small_uqi', 64, 'uqi'), ('small_ui', 32, 'ui'), ('tiny_qi', 8, 'qi')])
@@ -2052,7 +2171,7 @@ def test_training_step_launches_no_framework_kernels(tmp_path):
     assert any('row_gemm_split_kernel' in n and 'TypedRows' in n for n in step)
 
 
-def test_recorded_step_refuses_what_it_cannot_replay():
+def test_recorded_step_refuses_what_it_cannot_replay(monkeypatch):
     """What is baked into a recording is checked at every replay (Adam's eps / betas / weight decay, ``batch_rows_only_last_layer``, the path switches: only the
     learning rate is refreshed), and a model with a parameter that gets no gradient is refused at recording time (the eager Adam skips such a parameter, a
     recording would step and decay it)."""
@@ -2079,7 +2198,11 @@ def test_recorded_step_refuses_what_it_cannot_replay():
     m.batch_rows_only_last_layer = not m.batch_rows_only_last_layer
     assert step.stale()
     m.batch_rows_only_last_layer = not m.batch_rows_only_last_layer
-    assert not step.stale()
+    assert not step.stale() and not step.stale(full=True)
+    monkeypatch.setenv('IHG_SPARSE_LAST_COTANGENT', '0')      # a path switch: seen by the full check (once per epoch in the training loop), not by the per-step one
+    assert step.stale(full=True) and not step.stale()
+    monkeypatch.delenv('IHG_SPARSE_LAST_COTANGENT')
+    assert not step.stale(full=True)
     del step
     opt.zero_grad(set_to_none=True)
     extra = torch.nn.Parameter(torch.zeros(4, device=dev()))
@@ -2087,6 +2210,16 @@ def test_recorded_step_refuses_what_it_cannot_replay():
     opt2 = Adam(m.parameters(), 1e-3, weight_decay=0)
     with pytest.raises(ValueError, match='without a gradient'):
         CapturedTrainingStep(m, opt2, batches[0][0].shape[0], warmup_batch=batches[0])
+    # ... and the training loop, asked to record such a model, says so once and trains it eagerly
+    from ihgnn_amd.Helpers.ProcessController import ProcessController
+    from ihgnn_amd.Helpers.TrainTestHelper import train_and_get_avg_loss
+    loader = [(b[0][:50], b[1][:50], b[2][:50], b[3][:50].long(), b[0][50:], b[1][50:], b[2][50:], b[3][50:].long()) for b in batches]
+    pc = ProcessController(1, 1, 1, 1, None, None)
+    next(iter(pc))
+    before = m.state_dict()['gnn_0.feature_transform.weight'].clone()
+    loss, _ = train_and_get_avg_loss(m, opt2, torch.nn.BCEWithLogitsLoss(), ds, loader, pc, dev(), record_step='on')
+    assert np.isfinite(loss) and m._record_decision is False and getattr(m, '_recorded_step', None) is None
+    assert not torch.equal(before, m.state_dict()['gnn_0.feature_transform.weight'])
 
 
 # ---------------------------------------------------------------------------------------------

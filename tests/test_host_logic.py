@@ -369,7 +369,7 @@ def test_model_refuses_a_feature_width_the_evaluation_kernel_cannot_score_at_con
     """d (L + 1) beyond the scoring kernel's LDS pair block is refused when the model is BUILT - not at the first evaluation, an epoch of training later."""
     import torch
     from ihgnn_amd.Models import HemPredictionLayer, IHGNNLayer, RawGnn
-    with pytest.raises(NotImplementedError, match='1280 exceeds 1272'):
+    with pytest.raises(NotImplementedError, match='1280 exceeds 1264'):
         RawGnn(torch.device('cpu'), None, 256, IHGNNLayer, 4, 3, False, HemPredictionLayer, 0.5)
 
 
@@ -388,3 +388,55 @@ def test_readme_lists_every_switch_the_code_reads():
     assert 'IHG_INTERACT_ARITH' in read and 'IHG_NODE_TABLES' in read, read
     missing = sorted(name for name in read if name not in readme)
     assert not missing, f'not in README.md\'s switch table: {missing}'
+
+
+# ---------------------------------------------------------------------------------------------
+# the operand splits of the contraction kernels, emulated (tests/split_emulation.py; csrc/split_common.hpp)
+# ---------------------------------------------------------------------------------------------
+def test_two_fp16_split_worst_case_significand_and_bound():
+    """Search of all 2^23 significands: the value whose products lose most under the two-fp16 round-to-nearest split with every omitted term of one sign is
+    1 + 4093 * 2^-23 (hi = 1, lo = 4092 * 2^-23 by a tie to even, residual 2^-23): 2^-21 per product, one-sided.  The pattern the three-bf16 test used (low 16 bits
+    set) has NO error at all under this split - which is why the GPU test takes its operands from this search now."""
+    import split_emulation as se
+    x, loss = se.worst_two_fp16_significand()
+    assert x == np.float32(1.0 + 4093 * 2.0 ** -23)
+    assert 0.99 * 2.0 ** -21 <= loss <= 2.0 ** -21
+    old = np.array([(1.0 + (2.0 ** 16 - 1) * 2.0 ** -23) * 8192.0], np.float32)
+    hi, lo = se.split_two_fp16(old)
+    assert float(old[0]) - hi[0] - lo[0] == 0.0 and abs(lo[0] / hi[0]) < 2.0 ** -22          # exact, and lo*lo is 2^-45 of the product
+    # a dot product of such values (all products positive): the loss adds up, it does not average out
+    rng = np.random.default_rng(0)
+    a = np.float32(x) * np.exp2(rng.integers(-2, 3, (4, 1024))).astype(np.float32)
+    b = np.float32(x) * np.exp2(rng.integers(-2, 3, (3, 1024))).astype(np.float32)
+    exact = a.astype(np.float64) @ b.astype(np.float64).T
+    err = np.abs(se.dot_two_fp16(a, b) / exact - 1)
+    assert 0.9 * 2.0 ** -21 <= err.min() and err.max() <= 3 * 2.0 ** -22                    # the bound split_common.hpp states
+    assert np.abs(se.dot_three_bf16(a, b) / exact - 1).max() < 1e-8                          # harmless for the other scheme ...
+    y, loss3 = se.worst_three_bf16_significand()
+    assert y == np.float32(1.0 + (2.0 ** 16 - 1) * 2.0 ** -23) and 0.95 * 2.0 ** -21 <= loss3 <= 2.0 ** -21     # ... whose own worst case is the old pattern
+
+
+def test_two_fp16_split_bound_on_random_and_wide_range_rows():
+    """|error| <= 3 * 2^-22 * sum |a_k b_k| for rows whose entries lie within 2^-17 of the row's largest (lo is a normal fp16 there); on random data both schemes sit at
+    ~ 2e-8.  Below 2^-17 of the row's largest entry lo is a subnormal: ABSOLUTE error 2^-25 scaled, i.e. 2^-38 of the row's largest entry per element - the scheme's
+    bound is norm-wise there (|error| <= 2^-37 |a|_inf |b|_1 + ...), not component-wise; the one-huge-many-tiny case below states what that means."""
+    import split_emulation as se
+    rng = np.random.default_rng(1)
+    for spread in (0, 8, 16):
+        a = (rng.standard_normal((32, 512)) * np.exp2(rng.integers(-spread, 1, (32, 512)))).astype(np.float32)
+        b = (rng.standard_normal((32, 512)) * np.exp2(rng.integers(-spread, 1, (32, 512)))).astype(np.float32)
+        exact = a.astype(np.float64) @ b.astype(np.float64).T
+        den = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64).T
+        assert (np.abs(se.dot_two_fp16(a, b) - exact) / den).max() <= 3 * 2.0 ** -22, spread
+        assert (np.abs(se.dot_three_bf16(a, b) - exact) / den).max() <= 2.0 ** -21, spread
+    # one entry 2^24 above the rest, and the weight it meets is zero: the result is carried by entries whose lo term is subnormal
+    a = rng.standard_normal((8, 256)).astype(np.float32)
+    a[:, 0] = 2.0 ** 24
+    b = rng.standard_normal((8, 256)).astype(np.float32)
+    b[:, 0] = 0.0
+    exact = a.astype(np.float64) @ b.astype(np.float64).T
+    got = se.dot_two_fp16(a, b)
+    norm_wise = np.abs(a).max(1)[:, None] * np.abs(b).sum(1)[None, :]
+    assert (np.abs(got - exact) / norm_wise).max() <= 2.0 ** -36                             # tiny against |a|_inf |b|_1 ...
+    component_wise = np.abs(got - exact) / (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64).T)
+    assert component_wise.max() > 1e-5                                                       # ... and NOT against sum |a_k b_k|: the stated limit of a per-row scale

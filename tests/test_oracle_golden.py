@@ -253,6 +253,37 @@ def test_f6_training_curve_and_metrics(tag):
     np.testing.assert_allclose(acc / len(w['test_uq']), z[f'{tag}.metrics'], atol=2e-3)
 
 
+@pytest.mark.parametrize('tag', ['d128_l3_o3', 'd64_l2_o3', 'd32_l2_o3', 'd128_l3_o2'])
+def test_f10_training_curve_and_metrics_at_the_headline_widths(tag):
+    """F10: the reference's 48-step curve and ranking metrics at d = 128 x 3 layers (orders 3, 2), d = 64 x 2 and d = 32 x 2 (the reference's default
+    width) on a power-law graph with split rows - the oracle replays it."""
+    from conftest import f10_case, state_digest
+    (L, order, d), sd, z, w = f10_case(tag)
+    U, Q, I, V = (int(x) for x in w['counts'])
+    g = ref.HyperGraph(w['triples'].astype(np.int64), U, Q, I)
+    m = ref.OracleRawGnn(g, torch.from_numpy(w['bag_words'] + 1), torch.from_numpy(w['bag_offsets']), V, d, 'ihgnn', L, order)
+    m.load_reference_state(sd)
+    opt = torch.optim.Adam(m.parameters(), 1e-3, weight_decay=0)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    losses = []
+    for b in z[f'{tag}.batches']:
+        u, q, i, fl = (torch.from_numpy(b[k].astype(np.int64)) for k in range(4))
+        loss = lossf(m(u, q, i), fl.float())
+        loss.backward(); opt.step(); opt.zero_grad()
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, z[f'{tag}.losses'], rtol=2e-5, atol=0)
+    ends = np.cumsum(w['test_items_len'])
+    acc = np.zeros(3)
+    with torch.no_grad():
+        m.save_features_for_test()
+        ones = torch.ones(I, dtype=torch.long)
+        for k, (uu, qq) in enumerate(w['test_uq']):
+            items = w['test_items_flat'][ends[k] - w['test_items_len'][k]:ends[k]].tolist()
+            acc += ref.ranking_metrics(m(int(uu) * ones, int(qq) * ones, None), items)
+    np.testing.assert_allclose(acc / len(w['test_uq']), z[f'{tag}.metrics'], atol=2e-3)
+    assert z[f'{tag}.metrics'][0] > 0.05                       # a trained model: the metrics are not the all-zero kind that any scores match
+
+
 F7_CASES = [('tiny_uqi', 8, 'uqi'), ('small_uqi', 64, 'uqi'), ('small_ui', 32, 'ui'), ('tiny_qi', 8, 'qi')]
 
 

@@ -39,7 +39,8 @@ def main():
         here = os.path.dirname(os.path.abspath(__file__))
         table = json.loads(subprocess.run([sys.executable, os.path.join(here, 'pmc_summary.py'), fetch, write, '--skip', '2'], capture_output=True, text=True, check=True).stdout)
         bench = json.load(open(os.path.join(src, 'pmc_FETCH_SIZE.json')))
-        out = dict(command='rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline '
+        steps = '--steps 2 --warmup 1' if config == 'C5' else '--steps 3 --warmup 2'       # what tools/profile_round.sh runs for this config
+        out = dict(command=f'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --config {config} {steps} --no-cpu-baseline '
                            '--no-extras --no-kernel-events   (one pass per counter, in situ: every kernel of the training step)',
                    notes='KiB counters; FETCH_SIZE doubled (gfx950 counts 128-B requests of wide reads as 64 B); both counters sit at the L2 <-> fabric '
                          'boundary, so Infinity-Cache hits are included: hbm_bytes_per_launch is L2-miss traffic, an upper bound of the HBM bytes',
