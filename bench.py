@@ -686,7 +686,7 @@ def main():
         out['recorded_step_error'] = recorded_elapsed
     if f32_elapsed is not None:
         out['fp32_mfma_kernels_ms_per_step'] = round(1e3 * f32_elapsed, 4)
-        out['fp32_mfma_kernels_note'] = 'same full step with IHG_INTERACT_ARITH=f32 (fp32-MFMA contractions instead of the split-arithmetic ones: two fp16 terms on the default path, three bf16 terms in the hyperedge form's forward / weight kernels); NOT the headline'
+        out['fp32_mfma_kernels_note'] = 'same full step with IHG_INTERACT_ARITH=f32 (fp32-MFMA contractions instead of the split-arithmetic ones: two fp16 terms on the default path, three bf16 terms in the forward / weight kernels of the hyperedge form); NOT the headline'
     if fwd_elapsed is not None:
         out['fwd_only_hyperedges_per_s'] = round(E * layers / fwd_elapsed, 1)
         out['fwd_only_ms'] = round(1e3 * fwd_elapsed, 4)

@@ -139,7 +139,7 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
     can_record = mode != 'off' and grad_sync is None and device.type == 'cuda' and isinstance(optimizer, _HipAdam)
     decision = getattr(model, '_record_decision', None) if can_record else False       # None: undecided (auto, still measuring); True / False
     if can_record and mode == 'on' and decision is None:
-        decision = True
+        decision = model._record_decision = True
     if decision and getattr(model, '_recorded_step', None) is not None and model._recorded_step.stale(full=True):
         model._recorded_step = None                          # an IHG_* switch or ops flag changed since the recording (checked once per epoch; the per-step check is the cheap one)
     eager_seen, timed_from = getattr(model, '_auto_eager_steps', 0), None      # (persist across epochs: an epoch may be shorter than the measurement)
