@@ -210,6 +210,11 @@ def k7_roles(table, E, N, dim, layout, table_steps):
          compulsory   = every source row once + the ids + the output rows (what must cross the HBM pins at least once)."""
     row = 4 * dim
     n_src_edges = E * row
+    from ihgnn_amd import ops as _ops
+    # the first-order layers' launches walk the MERGED two-hop list (layout.two_hop_merged: one weighted entry per distinct (destination, source) pair,
+    # 4 B id + 4 B multiplicity) unless IHG_TWO_HOP_MERGED=0: fewer gathers than the 6 E of the plain list
+    hop = layout.two_hop_merged()[0].nnz if _ops.TWO_HOP_MERGED else 6 * E
+    hop_ids = 8 * hop if _ops.TWO_HOP_MERGED else 24 * E
     roles = {
         # name: (source rows, gathers, id bytes, what)
         'k7.edges_to_nodes': (E, 3 * E, 12 * E, 'forward of the interactive layer: [E,d] hyperedge features -> [N,d] (x Dv^-1)'),
@@ -217,12 +222,12 @@ def k7_roles(table, E, N, dim, layout, table_steps):
         'k7.member_gradients': (3 * E, 3 * E, 12 * E, 'backward: [E,3,d] member gradients -> d H [N,d] (every row read exactly once)'),
         'k7.member_gradients_rows': (2 * E, 2 * E, 8 * E, 'backward: [E,2,d] query / item member gradients -> d H rows of queries and items (the user slot '
                                                           'was summed on chip by the member-gradient kernel); every row read exactly once'),
-        'k7.two_hop': (N, 6 * E + N, 24 * E, 'first-order layer forward: node table -> node table over hop2_csr (no [E,d] intermediate)'),
-        'k7.two_hop_bwd': (N, 6 * E + N, 24 * E, 'first-order layer backward (same operator, scalings swapped)'),
-        'k7.two_hop_bwd_masked': (N, 6 * E + N, 24 * E, 'backward of the LAST first-order layer: its cotangent is zero outside the 3B batch rows (the output feeds the batch '
+        'k7.two_hop': (N, hop + N, hop_ids, 'first-order layer forward: node table -> node table over the (merged) two-hop list (no [E,d] intermediate)'),
+        'k7.two_hop_bwd': (N, hop + N, hop_ids, 'first-order layer backward (same operator, scalings swapped)'),
+        'k7.two_hop_bwd_masked': (N, hop + N, hop_ids, 'backward of the LAST first-order layer: its cotangent is zero outside the 3B batch rows (the output feeds the batch '
                                                           'tail only), the pull skips the gathers of the zero rows - same gradient; bytes as for the dense pull (an upper bound)'),
         'k7.edges_to_nodes_bwd_of_k5': (E, 3 * E, 12 * E, 'backward of a K5 launch'),
-        'k7.two_hop_first_order_gradient': (N, 6 * E + N, 24 * E, 'backward of the interactive layer, first-order part: the two-hop operator on the node-level cotangent ([E, d] tables beyond ops.FIRST_ORDER_TWO_HOP_BYTES: config C5)'),
+        'k7.two_hop_first_order_gradient': (N, hop + N, hop_ids, 'backward of the interactive layer, first-order part: the two-hop operator on the node-level cotangent ([E, d] tables beyond ops.FIRST_ORDER_TWO_HOP_BYTES: config C5)'),
         'node_pair_sums': (N, 6 * E, 24 * E, 'interactive layer forward, node-level form: node table -> [N,3d] pair sums over hop2_csr (the output row is 3 d wide)', 3),
     }
     out = {}
@@ -657,6 +662,8 @@ def main():
                    'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd (the last layer\'s backward pulls the 3B non-zero rows of its cotangent) + Adam' +
                            (f' + RCCL gradient exchange ({args.sync})' if world > 1 else ''),
                    'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
+                   # share of the two-hop list's 6 E entries that repeat a (destination, source) pair of their row: merged into weighted entries for the first-order launches
+                   'two_hop_duplicates': round(layout.two_hop_merged()[2], 4), 'two_hop_merged': bool(__import__('ihgnn_amd.ops', fromlist=['x']).TWO_HOP_MERGED),
                    'arithmetic': ('f32 results; f32 accumulation everywhere.  Row contractions (node-level contraction and member gradients at d = 64 / 128 / 256, node-level linear '
                                   'maps and their input gradients at d = 128 / 256): operands scaled by a power of two and taken apart into two fp16 terms, three fp16 MFMA products '
                                   'per multiply (error <= 3 x 2^-22 per product) - also the node-level weight gradients of the product blocks (a row\'s two operands scaled against each other); '

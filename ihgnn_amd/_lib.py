@@ -44,6 +44,7 @@ SIGNATURES = {
     'ihg_build_pair_csr': (ctypes.c_int, [_i64p, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32, _i32p, _i32p, _f32p, _f32p,
                                           c_int64, _i64p]),
     'ihg_transpose_csr': (ctypes.c_int, [_i32p, _i32p, c_int64, c_int64, _i32p, _i32p]),
+    'ihg_merge_id_lists': (ctypes.c_int, [_i32p, _i32p, c_int64, _i32p, _i32p, _f32p, _i64p]),
     'ihg_edge_gather_sum': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float,
                                            c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'ihg_node_segment_sum': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,

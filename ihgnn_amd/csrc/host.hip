@@ -2,6 +2,8 @@
 // layout builders, CSR transpose, search-log CSV ingestion.
 #include "common.hpp"
 
+#include <thread>
+
 thread_local char ihg_error_buffer[512] = "";
 
 namespace {
@@ -337,6 +339,55 @@ int ihg_transpose_csr(const int32_t* ptr, const int32_t* ids, int64_t n_rows, in
     std::vector<int32_t> cursor(t_ptr, t_ptr + n_cols);
     for (int64_t r = 0; r < n_rows; ++r)
         for (int32_t k = ptr[r]; k < ptr[r + 1]; ++k) t_rows[cursor[ids[k]]++] = static_cast<int32_t>(r);
+    return IHG_OK;
+}
+
+int ihg_merge_id_lists(const int32_t* ptr, const int32_t* ids, int64_t n_rows, int32_t* out_ptr, int32_t* out_ids, float* out_counts, int64_t* nnz_out) {
+    if (n_rows < 0 || ptr == nullptr || out_ptr == nullptr || nnz_out == nullptr) return fail(IHG_ERR_INVALID, "ihg_merge_id_lists: bad argument");
+    const int64_t nnz = n_rows > 0 ? ptr[n_rows] : 0;
+    if (nnz > 0 && (ids == nullptr || out_ids == nullptr || out_counts == nullptr)) return fail(IHG_ERR_INVALID, "ihg_merge_id_lists: null buffer");
+    // every row sorted on its own (rows are short; the few long ones of a power-law graph sort in place too), rows dealt to threads in contiguous ranges of about
+    // equal entry counts; then distinct ids are counted per row, the counts prefix-summed, and the (id, multiplicity) pairs written - ascending id inside a row
+    std::vector<int32_t> sorted(ids, ids + nnz);
+    const int n_threads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(std::thread::hardware_concurrency()), int64_t{32}, nnz / 200000 + 1})));
+    std::vector<int64_t> cut(static_cast<size_t>(n_threads) + 1, n_rows);
+    cut[0] = 0;
+    for (int t = 1; t < n_threads; ++t)
+        cut[t] = std::upper_bound(ptr, ptr + n_rows + 1, static_cast<int32_t>(nnz * t / n_threads)) - ptr - 1;
+    auto over_ranges = [&](auto&& body) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back([&, t] { body(cut[t], cut[t + 1]); });
+        body(cut[0], cut[1]);
+        for (auto& th : pool) th.join();
+    };
+    out_ptr[0] = 0;
+    over_ranges([&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+            int32_t* b = sorted.data() + ptr[r];
+            int32_t* e = sorted.data() + ptr[r + 1];
+            std::sort(b, e);
+            int32_t distinct = 0;
+            for (int32_t* p = b; p < e; ++p) distinct += (p == b || p[0] != p[-1]) ? 1 : 0;
+            out_ptr[r + 1] = distinct;
+        }
+    });
+    for (int64_t r = 0; r < n_rows; ++r) out_ptr[r + 1] += out_ptr[r];
+    over_ranges([&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+            const int32_t* b = sorted.data() + ptr[r];
+            const int32_t* e = sorted.data() + ptr[r + 1];
+            int64_t k = out_ptr[r];
+            for (const int32_t* p = b; p < e;) {
+                const int32_t* q = p;
+                while (q < e && *q == *p) ++q;
+                out_ids[k] = *p;
+                out_counts[k] = static_cast<float>(q - p);
+                ++k;
+                p = q;
+            }
+        }
+    });
+    *nnz_out = n_rows > 0 ? out_ptr[n_rows] : 0;
     return IHG_OK;
 }
 }  // extern "C"

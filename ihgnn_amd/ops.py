@@ -14,6 +14,7 @@ interact     (K5+K6)   ihg_interact_fwd            ihg_interact_bwd + 4x ihg_nod
 from __future__ import annotations
 
 import ctypes
+import os as _os
 from typing import Optional, Union
 
 import torch
@@ -180,6 +181,25 @@ def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[T
     return _NodeSegmentSum.apply(src, layout, out_scale, rows, out)
 
 
+# the first-order layers' gather launches over the two-hop list with repeated (destination, source) entries merged into one weighted entry (layout.two_hop_merged);
+# IHG_TWO_HOP_MERGED=0: the plain list, one gather per incidence and member (A/B, tests)
+TWO_HOP_MERGED = _os.environ.get('IHG_TWO_HOP_MERGED', '1') != '0'
+
+
+def _two_hop_list(layout: IncidenceLayout):
+    """``(csr, entry weights or None)`` of the two-hop operator's off-diagonal part ``H H^T - diag(deg)``."""
+    if TWO_HOP_MERGED:
+        csr, weights, _ = layout.two_hop_merged()
+        return csr, weights
+    return layout.hop2_csr, None
+
+
+def _two_hop_first_order_gradient(dy: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor]) -> Tensor:
+    """``d P = H H^T (out_scale * dy)``: the first-order blocks' gradient of the interactive layer by the two-hop operator on the node-level cotangent."""
+    csr, weights = _two_hop_list(layout)
+    return node_segment_sum_raw(dy, csr, out_scale, None, _lib.SCALE_NONE, entry_scale=weights, self_weight=layout.self_weight, role='k7.two_hop_first_order_gradient')
+
+
 class _TwoHop(torch.autograd.Function):
     """``out = Do * (H H^T) (Di * x)``: node -> hyperedge -> node in ONE pass over the node table (no ``[E,d]`` round trip).
 
@@ -192,7 +212,8 @@ class _TwoHop(torch.autograd.Function):
         # rows outside which the cotangent is zero: the rows that were computed at all, or the caller's explicit promise
         ctx.cot_rows = rows if rows is not None else (cotangent_rows if SPARSE_LAST_COTANGENT else None)
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(x, layout.hop2_csr, in_scale, out_scale, mode, self_weight=layout.self_weight, rows=rows, role='k7.two_hop',
+        csr, weights = _two_hop_list(layout)
+        return node_segment_sum_raw(x, csr, in_scale, out_scale, mode, entry_scale=weights, self_weight=layout.self_weight, rows=rows, role='k7.two_hop',
                                     out=_check_out(out, x))
 
     @staticmethod
@@ -213,7 +234,8 @@ class _TwoHop(torch.autograd.Function):
                 _lib.check(lib.ihg_mark_rows(r64, r32, int(rows.shape[0]), _ptr(mask), 0, _stream()), 'ihg_mark_rows')
                 raise RuntimeError('node_two_hop: the cotangent is not zero outside cotangent_rows / rows - the output has a consumer the caller did not declare')
         try:
-            out = node_segment_sum_raw(grad_out, lay.hop2_csr, ctx.out_scale, ctx.in_scale, mode, self_weight=lay.self_weight, src_mask=mask,
+            csr, weights = _two_hop_list(lay)
+            out = node_segment_sum_raw(grad_out, csr, ctx.out_scale, ctx.in_scale, mode, entry_scale=weights, self_weight=lay.self_weight, src_mask=mask,
                                        role='k7.two_hop_bwd' if mask is None else 'k7.two_hop_bwd_masked')
             if mask is not None:
                 _lib.check(lib.ihg_mark_rows(r64, r32, int(rows.shape[0]), _ptr(mask), 0, _stream()), 'ihg_mark_rows')
@@ -614,7 +636,6 @@ def node_linear(x, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, t
 # ---------------------------------------------------------------------------------------------
 # the [E, 3, d] member-gradient buffer of the interactive backward is produced in hyperedge chunks beyond this many bytes
 MEMBER_BUFFER_LIMIT_BYTES = 48 << 30
-import os as _os
 # use ihg_interact_bwd_user_reduced (user slot summed on chip, [E, 2, d] member buffer) where the library offers it (tests set this attribute to compare with the
 # [E, 3, d] form, which every shape without such a kernel runs anyway)
 USER_REDUCED_BACKWARD = True
@@ -879,13 +900,13 @@ class _InteractLayer(torch.autograd.Function):
             if keep_dout:
                 dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
             else:
-                dp = node_segment_sum_raw(dy, layout.hop2_csr, out_scale, None, _lib.SCALE_NONE, self_weight=layout.self_weight, role='k7.two_hop_first_order_gradient')
+                dp = _two_hop_first_order_gradient(dy, layout, out_scale)
         else:
             dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
             if n_edges * dim * 4 > FIRST_ORDER_TWO_HOP_BYTES:
                 # a [E, d] table far beyond the caches (config C5: 51 GB): its scatter reads HBM at random, the two-hop operator on the node-level
                 # cotangent (10 GB) gathers twice the rows and is still the shorter launch (22 against 32 ms)
-                dp = node_segment_sum_raw(dy, layout.hop2_csr, out_scale, None, _lib.SCALE_NONE, self_weight=layout.self_weight, role='k7.two_hop_first_order_gradient')
+                dp = _two_hop_first_order_gradient(dy, layout, out_scale)
             else:
                 # the scatter of dout goes first: K5 has just written it, so most of its rows are still in the Infinity Cache for these random
                 # reads; the interact kernels read it as a stream and do not care

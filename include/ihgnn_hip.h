@@ -110,6 +110,14 @@ int ihg_build_pair_csr(const int64_t* triples, int64_t n_edges, int64_t n_users,
                        int32_t completeness, int32_t self_loops,
                        int32_t* rowptr, int32_t* cols, float* vals, float* degree, int64_t capacity, int64_t* nnz_out);
 
+/* HOST: merge the repeated ids of every row of a CSR: row r of (out_ptr, out_ids, out_counts) holds the DISTINCT ids of row r of (ptr, ids) in ascending
+ * order with their multiplicities as floats (exact: a count).  Applied to the two-hop list of the hypergraph (node -> the other two members of each of
+ * its hyperedges, Helpers/Graph.py:107-118 composed with itself as Models/GnnLayers.py:233-234 does through two SpMMs) it gives H H^T - diag(deg) as a
+ * weighted CSR: a (user, query) pair that co-occurs in k hyperedges is ONE entry of weight k instead of k gathers (duplicate hyperedges stay distinct
+ * hyperedges: the multiplicities carry them).  out_ids / out_counts hold ptr[n_rows] entries; *nnz_out = entries used.
+ */
+int ihg_merge_id_lists(const int32_t* ptr, const int32_t* ids, int64_t n_rows, int32_t* out_ptr, int32_t* out_ids, float* out_counts, int64_t* nnz_out);
+
 /* HOST: invert any CSR (row -> sorted list of column ids) into its transpose.  Used for the
  * EmbeddingBag backward (word -> bags containing it).  Replaces the autograd-generated
  * _embedding_bag_dense_backward of Models/EmbeddingLayers.py:79.

@@ -183,6 +183,52 @@ def test_two_hop_equals_gather_then_segment_sum(dim):
         assert rel(yb, ya) <= RTOL_SUM * 2 and rel(xb.grad, xa.grad) <= RTOL_SUM * 2
 
 
+
+@pytest.mark.parametrize('dim', [8, 64, 128])
+def test_two_hop_over_the_merged_list(dim, monkeypatch):
+    """The first-order launches over the two-hop list with repeated (destination, source) entries merged into weighted entries (``layout.two_hop_merged``, the
+    default) against the plain list (``IHG_TWO_HOP_MERGED=0``: one gather per incidence and member) and against float64 sums over the plain list: forward, backward,
+    the masked pull of a sparse cotangent, and the interactive layer's first-order gradient.  A graph with few queries: a user meets the same query in many hyperedges,
+    duplicated hyperedges included (their multiplicities must be exact: ``Helpers/Graph.py:107-118`` keeps duplicates as distinct hyperedges)."""
+    from ihgnn_amd import ops
+    from ihgnn_amd.layout import IncidenceLayout
+    w_, _ = make_layout(300, 6, 500, 30000, seed=12, distribution='powerlaw')
+    triples = np.concatenate([w_.triples, w_.triples[:500]])
+    lay = IncidenceLayout(triples, 300, 6, 500, dev(), heavy_threshold=96)
+    csr, weights, dup = lay.two_hop_merged()
+    assert dup > 0.3 and csr.n_heavy > 3 and float(weights.max()) >= 3
+    gen = torch.Generator().manual_seed(dim)
+    x = torch.randn(lay.node_count, dim, generator=gen)
+    cot = torch.randn(lay.node_count, dim, generator=gen)
+    listed = torch.randperm(lay.node_count, generator=gen)[:90]
+    sparse_cot = torch.zeros_like(cot)
+    sparse_cot[listed] = cot[listed]
+    ptr, ids = lay.hop2_csr.ptr_host.astype(np.int64), lay.hop2_csr.ids_host.astype(np.int64)
+    rows = torch.from_numpy(np.repeat(np.arange(lay.node_count), np.diff(ptr)))
+    inv = lay.inv_deg.cpu().double()
+    deg = lay.self_weight.cpu().double()
+
+    def operator64(v):                                       # (H H^T) v in float64 over the PLAIN list
+        return torch.zeros(lay.node_count, dim, dtype=torch.float64).index_add_(0, rows, v.double()[torch.from_numpy(ids)]) + deg[:, None] * v.double()
+    results = {}
+    for merged in (True, False):
+        monkeypatch.setattr(ops, 'TWO_HOP_MERGED', merged)
+        xd = x.to(dev()).requires_grad_(True)
+        y = ops.node_two_hop(xd, lay, None, lay.inv_deg)
+        y.backward(cot.to(dev()))
+        xs = x.to(dev()).requires_grad_(True)
+        ys = ops.node_two_hop(xs, lay, None, lay.inv_deg, cotangent_rows=listed.to(dev()))
+        ys.backward(sparse_cot.to(dev()))
+        first = ops._two_hop_first_order_gradient(cot.to(dev()), lay, lay.inv_deg)
+        results[merged] = (y.detach(), xd.grad, xs.grad, first)
+    want = (inv[:, None] * operator64(x), operator64(inv[:, None] * cot.double()), operator64(inv[:, None] * sparse_cot.double()), operator64(inv[:, None] * cot.double()))
+    for got_m, got_p, w64 in zip(results[True], results[False], want):
+        assert rel(got_m, w64) <= RTOL_SUM and rel(got_p, w64) <= RTOL_SUM and rel(got_m, got_p) <= RTOL_SUM
+        assert row_rel(got_m, w64, floor=0.0) <= RTOL
+    again = ops._two_hop_first_order_gradient(cot.to(dev()), lay, lay.inv_deg)
+    assert torch.equal(again, results[False][3])             # (the plain list is the last one set: bitwise repeatable)
+
+
 def test_user_ordered_hyperedge_numbering_is_equivalent():
     """The layout's internal renumbering (hyperedges sorted by user) only permutes edge-feature rows."""
     from ihgnn_amd import ops

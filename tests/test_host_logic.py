@@ -390,6 +390,41 @@ def test_readme_lists_every_switch_the_code_reads():
     assert not missing, f'not in README.md\'s switch table: {missing}'
 
 
+
+def test_merged_two_hop_list_is_the_pairwise_graph_with_multiplicities():
+    """``ihg_merge_id_lists`` on the two-hop list: per node the distinct other members of its hyperedges, ascending, with exact multiplicities - against numpy, and
+    against the pairwise graph the reference builds for its GCN baseline (``Pps2DGraph``, completeness uqi: the same co-occurrence counts, ``Helpers/Graph.py:40-79``)."""
+    import ctypes
+    from ihgnn_amd import _lib
+    from ihgnn_amd.layout import _as_ptr
+    w = synth.draw(300, 12, 200, 10, 9000, seed=3, distribution='powerlaw', exponent=1.2)
+    triples = np.concatenate([w.triples, w.triples[:40]])               # duplicate hyperedges stay distinct: their members count twice
+    lay = IncidenceLayout(triples, 300, 12, 200, CPU)
+    csr, weights, dup = lay.two_hop_merged()
+    src = lay.hop2_csr
+    assert csr.n_rows == src.n_rows and 0.05 < dup < 0.9 and abs((1 - dup) * src.nnz - csr.nnz) < 1
+    sp, si = src.ptr_host.astype(np.int64), src.ids_host
+    mp, mi, mw = csr.ptr_host.astype(np.int64), csr.ids_host, weights.numpy()
+    for v in np.random.default_rng(0).integers(0, src.n_rows, 200).tolist() + [int(np.argmax(np.diff(sp)))]:
+        ids, counts = np.unique(si[sp[v]:sp[v + 1]], return_counts=True)
+        np.testing.assert_array_equal(mi[mp[v]:mp[v + 1]], ids)
+        np.testing.assert_array_equal(mw[mp[v]:mp[v + 1]], counts.astype(np.float32))
+    assert float(mw.sum()) == src.nnz
+    # the pairwise graph of the same interactions (no self loops): identical rows, columns and values
+    n = lay.node_count
+    rowptr, cols, vals, degree = np.empty(n + 1, np.int32), np.empty(6 * len(triples), np.int32), np.empty(6 * len(triples), np.float32), np.empty(n, np.float32)
+    nnz = ctypes.c_int64(0)
+    _lib.check(_lib.load().ihg_build_pair_csr(_as_ptr(np.ascontiguousarray(triples, np.int64), ctypes.c_int64), len(triples), 300, 12, 200, 0, 0, _as_ptr(rowptr, ctypes.c_int32),
+                                              _as_ptr(cols, ctypes.c_int32), _as_ptr(vals, ctypes.c_float), _as_ptr(degree, ctypes.c_float), 6 * len(triples), ctypes.byref(nnz)), 'pair')
+    assert nnz.value == csr.nnz
+    np.testing.assert_array_equal(rowptr, csr.ptr_host)
+    np.testing.assert_array_equal(cols[:nnz.value], mi)
+    np.testing.assert_array_equal(vals[:nnz.value], mw)
+    # an empty graph and a graph of one hyperedge
+    one = IncidenceLayout(np.array([[0, 0, 0]]), 2, 1, 1, CPU).two_hop_merged()
+    assert one[0].nnz == 6 and one[2] == 0.0 and bool((one[1] == 1).all())
+
+
 # ---------------------------------------------------------------------------------------------
 # the operand splits of the contraction kernels, emulated (tests/split_emulation.py; csrc/split_common.hpp)
 # ---------------------------------------------------------------------------------------------
