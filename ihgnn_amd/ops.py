@@ -181,9 +181,11 @@ def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[T
     return _NodeSegmentSum.apply(src, layout, out_scale, rows, out)
 
 
-# the first-order layers' gather launches over the two-hop list with repeated (destination, source) entries merged into one weighted entry (layout.two_hop_merged);
-# IHG_TWO_HOP_MERGED=0: the plain list, one gather per incidence and member (A/B, tests)
-TWO_HOP_MERGED = _os.environ.get('IHG_TWO_HOP_MERGED', '1') != '0'
+# IHG_TWO_HOP_MERGED=1: the first-order layers' gather launches walk the two-hop list with the repeated (destination, source) entries of a row merged into one weighted
+# entry (layout.two_hop_merged).  Off by default: measured in round 5 on the synthetic stand-ins it removes 8.6 % (C3) / 13.6 % (C4) / 17.9 % (C2) of the gathers and
+# NOT A MICROSECOND of the step (C3 7.74 against 7.71 ms, C2 1.888 / 1.871, C4 10.35 / 10.33: profiles/r5) - a repeated id of one row is re-read while its first copy is
+# still in the CU's L1 / the XCD's L2, the gathers that cost are the FIRST touches, and those stay.  Kept as a switch for corpora whose logs repeat (user, query) pairs far more.
+TWO_HOP_MERGED = _os.environ.get('IHG_TWO_HOP_MERGED', '0') == '1'
 
 
 def _two_hop_list(layout: IncidenceLayout):
