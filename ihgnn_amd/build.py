@@ -10,8 +10,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(CSRC, 'libihgnn_hip.so')
-SOURCES = [os.path.join(CSRC, name) for name in ('host.hip', 'aggregate.hip', 'interact.hip', 'split_arith.hip', 'split_node.hip', 'dense.hip', 'tail.hip', 'eval.hip')]
-HEADERS = [os.path.join(REPO, 'include', 'ihgnn_hip.h'), os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'split.hpp'), os.path.join(CSRC, 'split_common.hpp'), os.path.join(CSRC, 'ablate.hpp')]
+SOURCES = [os.path.join(CSRC, name) for name in ('host.hip', 'aggregate.hip', 'interact.hip', 'split_arith.hip', 'split_node.hip', 'narrow.hip', 'dense.hip', 'tail.hip', 'eval.hip')]
+HEADERS = [os.path.join(REPO, 'include', 'ihgnn_hip.h'), os.path.join(CSRC, 'common.hpp'), os.path.join(CSRC, 'split.hpp'), os.path.join(CSRC, 'split_common.hpp'), os.path.join(CSRC, 'ablate.hpp'), os.path.join(CSRC, 'narrow.hpp')]
 ARCH = 'gfx950'
 
 

@@ -1,6 +1,7 @@
 // interact.hip - the interactive (order 2 / 3) node -> hyperedge step and its backward on the matrix cores (exact fp32 MFMA),
 // plus the one-thread-per-output kernels that take every other shape.
 #include "common.hpp"
+#include "narrow.hpp"
 #include "split.hpp"
 
 namespace {
@@ -1888,6 +1889,8 @@ inline int weight_slabs(int dim) {
 }
 constexpr int kFwdGrid = 256 * 3;
 constexpr int kPipeGrid = 256;          // wave-specialised and strip kernels: one 512-thread workgroup per CU
+// tile ranges of the user-reduced member-gradient kernels (two boundary-table entries each): one per workgroup at d = 64 / 128, one per wave at d = 32 (narrow.hip)
+inline int64_t boundary_ranges(int dim) { return dim == 128 || dim == 64 ? kPipeGrid : (dim == kNarrowDim ? kNarrowMemberRanges : 0); }
 
 // Persistent grid of a plain (one role) tiling: as many workgroups as are resident at once - a larger grid runs in rounds, and
 // the workgroups of the last round start when the others have already walked their whole share of the tiles.
@@ -1972,7 +1975,18 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
         hipLaunchKernelGGL((interact_bwd_members_ws_kernel<D, NBLK>), dim3(grid), dim3(kWsThreads), 0, s, h, ld_h, i3, wq, dout, ld_dout, g, n_edges); \
     }
     const bool vector_io = aligned16(g) && ld_h < (int64_t{1} << 30);     // the pipelined form stores g as 16-byte vectors
-    if (planes != nullptr && split_members_ok(dim, NBLK == 4 ? 3 : 2, g, ld_h, ld_dout, dout, dh_user != nullptr)) {   // bf16-split contraction
+    if (dim == kNarrowDim && dh_user != nullptr && planes != nullptr && narrow_members_ok(dim, NBLK == 4 ? 3 : 2, g, ld_h, ld_dout, dout)) {
+        // d = 32, user-reduced (g is [E, 2, d]): one wave per 16-hyperedge tile on fp32 MFMA, gathering the node-level cotangent when dy_scale / dout_store say so
+        const bool gather = dout_store != nullptr || ld_store < 0;
+        int entries = 0;
+        launch_members_narrow(NBLK == 4 ? 3 : 2, gather ? 1 : 0, h, ld_h, i3, w_raw, ld_w, static_cast<float*>(planes), dout, ld_dout, dy_scale, ld_store > 0 ? dout_store : nullptr,
+                              ld_store, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, &entries, s);
+        hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(entries), dim3(128), 0, s, bnd_val, bnd_user, entries, dim, dh_user, ld_dh);
+        if (gather && ld_store > 0) {
+            dout = dout_store;
+            ld_dout = ld_store;
+        }
+    } else if (planes != nullptr && split_members_ok(dim, NBLK == 4 ? 3 : 2, g, ld_h, ld_dout, dout, dh_user != nullptr)) {   // bf16-split contraction
         int entries = 0;
         launch_members_split(dim, NBLK == 4 ? 3 : 2, h, ld_h, i3, w_raw, ld_w, planes, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, &entries, s,
                              dy_scale, dout_store, ld_store);
@@ -2077,10 +2091,13 @@ int ihg_interact_fwd(const float* h, int64_t ld_h, const float* p, int64_t ld_p,
 
 int32_t ihg_node_interact_fwd_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_sums, int64_t ld_out) {
     static float aligned_probe __attribute__((aligned(16)));
-    return split_node_fwd_ok(dim, order, ld_h, ld_sums, &aligned_probe, ld_out, nullptr) && ld_h >= dim && ld_sums >= 3LL * dim && ld_out >= dim ? 1 : 0;
+    return (narrow_node_fwd_ok(dim, order, ld_h, ld_sums, &aligned_probe, ld_out, nullptr) || split_node_fwd_ok(dim, order, ld_h, ld_sums, &aligned_probe, ld_out, nullptr)) &&
+           ld_h >= dim && ld_sums >= 3LL * dim && ld_out >= dim ? 1 : 0;
 }
 
-int64_t ihg_node_interact_fwd_workspace_bytes(int32_t dim) { return split_node_fwd_plane_floats(dim) * static_cast<int64_t>(sizeof(float)); }
+int64_t ihg_node_interact_fwd_workspace_bytes(int32_t dim) {
+    return (dim == kNarrowDim ? narrow_node_fwd_floats() : split_node_fwd_plane_floats(dim)) * static_cast<int64_t>(sizeof(float));
+}
 
 int ihg_node_interact_fwd(const float* h, int64_t ld_h, const float* sums, int64_t ld_sums, const float* degree, const float* out_scale, const float* bias,
                           const float* w, int64_t ld_w, int32_t order, const int64_t* type_begin, float* out, int64_t ld_out, void* workspace,
@@ -2092,20 +2109,28 @@ int ihg_node_interact_fwd(const float* h, int64_t ld_h, const float* sums, int64
         return fail(IHG_ERR_INVALID, "ihg_node_interact_fwd: bad size");
     if (type_begin[3] == 0) return IHG_OK;
     if (h == nullptr || sums == nullptr || degree == nullptr || w == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_interact_fwd: null pointer");
-    if (!split_node_fwd_ok(dim, order, ld_h, ld_sums, out, ld_out, bias) || !aligned16(h) || !aligned16(sums))
+    const bool narrow = narrow_node_fwd_ok(dim, order, ld_h, ld_sums, out, ld_out, bias);
+    if ((!narrow && !split_node_fwd_ok(dim, order, ld_h, ld_sums, out, ld_out, bias)) || !aligned16(h) || !aligned16(sums))
         return fail(IHG_ERR_INVALID, "ihg_node_interact_fwd: dim %d / order %d / alignment not supported (ihg_node_interact_fwd_supported)", dim, order);
     if (workspace == nullptr || !aligned16(workspace) || workspace_bytes < ihg_node_interact_fwd_workspace_bytes(dim))
         return fail(IHG_ERR_WORKSPACE, "ihg_node_interact_fwd: workspace too small");
+    if (narrow) {                                                        // d = 32: plain fp32 MFMA, one wave per 16-row tile (narrow.hip)
+        launch_node_fwd_narrow(order, h, ld_h, sums, ld_sums, degree, out_scale, bias, w, ld_w, type_begin, out, ld_out, static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
+        return check_launch("ihg_node_interact_fwd");
+    }
     launch_node_fwd_split(dim, order, h, ld_h, sums, ld_sums, degree, out_scale, bias, w, ld_w, type_begin, out, ld_out, workspace, static_cast<hipStream_t>(stream));
     return check_launch("ihg_node_interact_fwd");
 }
 
 int32_t ihg_node_interact_bwd_weight_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_sums, int64_t ld_dy) {
     static float aligned_probe __attribute__((aligned(16)));
-    return split_node_weight_ok(dim, order, ld_h, ld_sums, ld_dy, &aligned_probe) && ld_h >= dim && ld_sums >= 3LL * dim && ld_dy >= dim ? 1 : 0;
+    return (narrow_node_weight_ok(dim, order, ld_h, ld_sums, ld_dy, &aligned_probe) || split_node_weight_ok(dim, order, ld_h, ld_sums, ld_dy, &aligned_probe)) && ld_h >= dim &&
+           ld_sums >= 3LL * dim && ld_dy >= dim ? 1 : 0;
 }
 
-int64_t ihg_node_interact_bwd_weight_workspace_bytes(int32_t dim, int32_t order) { return split_node_weight_slab_floats(dim, order) * static_cast<int64_t>(sizeof(float)); }
+int64_t ihg_node_interact_bwd_weight_workspace_bytes(int32_t dim, int32_t order) {
+    return (dim == kNarrowDim ? narrow_node_weight_floats(order) : split_node_weight_slab_floats(dim, order)) * static_cast<int64_t>(sizeof(float));
+}
 
 int ihg_node_interact_bwd_weight(const float* h, int64_t ld_h, const float* sums, int64_t ld_sums, const float* dy, int64_t ld_dy, const float* dy_scale, int32_t order,
                                  const int64_t* type_begin, float* dw, int64_t ld_dw, void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream) {
@@ -2115,10 +2140,15 @@ int ihg_node_interact_bwd_weight(const float* h, int64_t ld_h, const float* sums
     if (dim <= 0 || ld_h < dim || ld_dy < dim || ld_sums < 3LL * dim || ld_dw < static_cast<int64_t>(order == 3 ? 7 : 6) * dim)
         return fail(IHG_ERR_INVALID, "ihg_node_interact_bwd_weight: bad size");
     if (h == nullptr || sums == nullptr || dy == nullptr || dw == nullptr) return fail(IHG_ERR_INVALID, "ihg_node_interact_bwd_weight: null pointer");
-    if (!split_node_weight_ok(dim, order, ld_h, ld_sums, ld_dy, dy) || !aligned16(h) || !aligned16(sums))
+    const bool narrow = narrow_node_weight_ok(dim, order, ld_h, ld_sums, ld_dy, dy);
+    if ((!narrow && !split_node_weight_ok(dim, order, ld_h, ld_sums, ld_dy, dy)) || !aligned16(h) || !aligned16(sums))
         return fail(IHG_ERR_INVALID, "ihg_node_interact_bwd_weight: dim %d / order %d / alignment not supported (ihg_node_interact_bwd_weight_supported)", dim, order);
     if (workspace == nullptr || !aligned16(workspace) || workspace_bytes < ihg_node_interact_bwd_weight_workspace_bytes(dim, order))
         return fail(IHG_ERR_WORKSPACE, "ihg_node_interact_bwd_weight: workspace too small");
+    if (narrow) {
+        launch_node_weight_narrow(order, h, ld_h, sums, ld_sums, dy, ld_dy, dy_scale, type_begin, static_cast<float*>(workspace), dw, ld_dw, static_cast<hipStream_t>(stream));
+        return check_launch("ihg_node_interact_bwd_weight");
+    }
     launch_node_weight_split(dim, order, h, ld_h, sums, ld_sums, dy, ld_dy, dy_scale, type_begin, static_cast<float*>(workspace), dw, ld_dw, static_cast<hipStream_t>(stream));
     return check_launch("ihg_node_interact_bwd_weight");
 }
@@ -2127,13 +2157,14 @@ int64_t ihg_interact_bwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t o
     (void)n_edges;
     if (!mfma_dim(dim) || (order != 2 && order != 3)) return 0;
     const int64_t w_floats = packed_weight_floats(dim, order);
-    const int64_t boundary = dim == 128 || dim == 64 ? (2LL * kPipeGrid * dim + 2LL * kPipeGrid) : 0;      // user-reduced form: boundary runs + their users
-    return (w_floats + static_cast<int64_t>(weight_slabs(dim)) * w_floats + boundary + split_plane_floats(dim, order)) * static_cast<int64_t>(sizeof(float));
+    const int64_t boundary = 2LL * boundary_ranges(dim) * dim + 2LL * boundary_ranges(dim);               // user-reduced form: boundary runs + their users
+    const int64_t planes = dim == kNarrowDim ? narrow_members_floats(order) : split_plane_floats(dim, order);
+    return (w_floats + static_cast<int64_t>(weight_slabs(dim)) * w_floats + boundary + planes) * static_cast<int64_t>(sizeof(float));
 }
 
 int32_t ihg_interact_bwd_user_reduced_supported(int32_t dim, int32_t order, int64_t ld_h) {
-    // d = 128: the split kernel or the fp32 strip kernel; d = 64: the split kernel only (its fp32-MFMA kernels have no user-reduced form)
-    return (dim == 128 || (dim == 64 && split_arith_enabled())) && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_h < (int64_t{1} << 30) ? 1 : 0;
+    // d = 128: the split kernel or the fp32 strip kernel; d = 64: the split kernel only (its fp32-MFMA kernels have no user-reduced form); d = 32: narrow.hip (fp32 MFMA)
+    return (dim == 128 || dim == kNarrowDim || (dim == 64 && split_arith_enabled())) && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_h < (int64_t{1} << 30) ? 1 : 0;
 }
 
 int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
@@ -2153,8 +2184,8 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
     float* wq = static_cast<float*>(workspace);
     float* slabs = wq + packed_weight_floats(dim, order);
     float* bnd_val = slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order);
-    int32_t* bnd_user = reinterpret_cast<int32_t*>(bnd_val + 2LL * kPipeGrid * dim);
-    void* planes = bnd_user + 2LL * kPipeGrid;
+    int32_t* bnd_user = reinterpret_cast<int32_t*>(bnd_val + 2LL * boundary_ranges(dim) * dim);
+    void* planes = bnd_user + 2LL * boundary_ranges(dim);
     const int pack_items = (dim / 16) * nblk * (dim / 16) * kWave;
     hipLaunchKernelGGL(pack_weights_strip_kernel, dim3((pack_items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk,
                        static_cast<float*>(nullptr), wq);
@@ -2164,7 +2195,7 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
 }
 
 int32_t ihg_interact_bwd_gathered_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_dy) {
-    return ihg_interact_bwd_user_reduced_supported(dim, order, ld_h) && split_arith_enabled() && ld_dy >= dim && ld_dy % 4 == 0 && ld_dy < (int64_t{1} << 30) ? 1 : 0;
+    return ihg_interact_bwd_user_reduced_supported(dim, order, ld_h) && (split_arith_enabled() || dim == kNarrowDim) && ld_dy >= dim && ld_dy % 4 == 0 && ld_dy < (int64_t{1} << 30) ? 1 : 0;
 }
 
 int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
@@ -2189,10 +2220,11 @@ int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, c
     float* wq = static_cast<float*>(workspace);                          // (the fp32 fragment image of w is not needed by the split kernels)
     float* slabs = wq + packed_weight_floats(dim, order);
     float* bnd_val = slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order);
-    int32_t* bnd_user = reinterpret_cast<int32_t*>(bnd_val + 2LL * kPipeGrid * dim);
-    void* planes = bnd_user + 2LL * kPipeGrid;
-    if (!split_members_ok(dim, order, g2, ld_h, ld_dy, dy, true) || (dw != nullptr && !split_weight_ok(dim, order, ld_h, ld_dout, dout)))
-        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: the split kernels do not take these strides / alignments");
+    int32_t* bnd_user = reinterpret_cast<int32_t*>(bnd_val + 2LL * boundary_ranges(dim) * dim);
+    void* planes = bnd_user + 2LL * boundary_ranges(dim);
+    if (dim == kNarrowDim ? (!narrow_members_ok(dim, order, g2, ld_h, ld_dy, dy) || (dw != nullptr && ld_dout <= 0))
+                          : (!split_members_ok(dim, order, g2, ld_h, ld_dy, dy, true) || (dw != nullptr && !split_weight_ok(dim, order, ld_h, ld_dout, dout))))
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_gathered: the kernels do not take these strides / alignments");
     if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dy, ld_dy, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes, dy_scale, dout, ld_dout);
     else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dy, ld_dy, g2, slabs, dw, ld_dw, n_edges, s, dh, ld_dh, bnd_val, bnd_user, w, ld_w, planes, dy_scale, dout, ld_dout);
     return check_launch("ihg_interact_bwd_gathered");
@@ -2224,7 +2256,7 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3, const floa
                                static_cast<float*>(nullptr), wq);
         // the bf16 planes of the split contraction sit behind the boundary table (only d = 128 has either)
         void* planes = split_plane_floats(dim, order) == 0 ? nullptr :
-                       static_cast<void*>(slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order) + (dim == 128 || dim == 64 ? 2LL * kPipeGrid * dim + 2LL * kPipeGrid : 0));
+                       static_cast<void*>(slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order) + 2LL * boundary_ranges(dim) * dim + 2LL * boundary_ranges(dim));
         if (nblk == 4) launch_interact_bwd_mfma<4>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s, nullptr, 0, nullptr, nullptr, w, ld_w, planes);
         else launch_interact_bwd_mfma<3>(dim, h, ld_h, i3, wq, dout, ld_dout, g, slabs, dw, ld_dw, n_edges, s, nullptr, 0, nullptr, nullptr, w, ld_w, planes);
         return check_launch("ihg_interact_bwd");

@@ -1,0 +1,544 @@
+// narrow.hip - the interactive layer at d = 32 (the reference's default width: Helpers/GlobalSettings.py:30, Main.py:23) in its node-level form, with the gathering /
+// user-reduced member gradients (narrow.hpp; DESIGN.md section 4, "Round 5: the reference's default width").  Replaces, at that width, the hyperedge-form kernels of
+// rounds 1 - 2 (interact_fwd_ws_kernel<32>, interact_bwd_members_ws_kernel<32>, interact_bwd_weight_mfma_kernel<32>: an [E, d] forward tensor, an [E, 3, d] member
+// buffer, a K5 launch) - Models/CommonLayers.py:58-87 and Models/GnnLayers.py:221-236 re-associated as in split_node.hip.
+//
+// One wave = one tile of 16 rows (nodes or hyperedges) at a time, a contiguous range of tiles per wave, no LDS, no barriers.  v_mfma_f32_16x16x4_f32 is issued as
+// W^T x rows^T: the B operand's lane (row = lane & 15, q = lane >> 4) supplies values of ITS row, the result's lane (row = lane & 15, q) receives four consecutive output
+// columns 4 q .. of that row per 16-column tile.  The contraction index is free to be enumerated in any order as long as both operands agree, so lane group q supplies the
+// columns { 4 q .. 4 q + 3 } and { 16 + 4 q .. 16 + 4 q + 3 } of a 32-wide row - exactly the two 16-byte pieces it loads: one load instruction moves the contiguous 64-byte
+// halves of 16 rows, and what a lane loads, multiplies element-wise (the product rule, the node-level products) and stores are the same eight columns.  Weights sit in
+// registers in A-fragment order (packed once per call).  Rows are requested one tile ahead (member ids two), unconditionally and with clamped indices - a branch around a
+// request makes the compiler wait for everything at the join.
+#include "narrow.hpp"
+
+namespace {
+
+constexpr int ND = kNarrowDim;
+constexpr int NT = 16;      // rows per tile
+
+// column of a 32-wide row that lane group q holds in register s < 8 (= contraction index of step s for lane group q)
+__host__ __device__ constexpr int ncol(int q, int s) { return 16 * (s >> 2) + 4 * q + (s & 3); }
+
+// X block xb of the node-level contraction ([deg h | S_a | h S_a | S_b | h S_b | S_ab | h S_ab]) -> block of w = [A_u | A_q | A_i | W_uq | W_qi | W_iu | W_uqi] it meets
+// at a node of `type` (the table of the node-level form; split_node.hip's node_xblock_weight)
+__device__ __forceinline__ int narrow_xblock_weight(int type, int xb) {
+    constexpr signed char kBlock[3][7] = {{0, 1, 3, 2, 5, 4, 6}, {1, 0, 3, 2, 4, 5, 6}, {2, 0, 5, 1, 4, 3, 6}};
+    return kBlock[type][xb];
+}
+
+struct NarrowTiles {
+    int64_t begin[4];      // first row of every node type
+    int tile_prefix[4];    // 16-row tiles before type t
+};
+struct NarrowRanges {
+    int64_t begin[4];
+    int range_prefix[4];   // row ranges (one per wave) before type t
+};
+
+// ------------------------------------------------------------------------------------------------
+// Node-level forward (ihg_node_interact_fwd at d = 32): out[v] = scale[v] (X[v] Wt_type(v) + deg[v] bias), X = the seven 32-wide blocks above formed in registers.
+// packed[type][xb][s][ct][lane] = w[16 ct + (lane & 15)][32 block(type, xb) + ncol(lane >> 4, s)]   (A fragment of the W^T tile ct at contraction step (xb, s))
+// 112 MFMAs per 16 rows beside 8 KB of rows in and 2 KB out: the matrix pipe needs ~ 25 us for C2's 256 k rows, the rows ~ 35 us at 5 TB/s.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads) void pack_node_fwd_narrow_kernel(const float* __restrict__ w, int64_t ld_w, int n_xb, float* __restrict__ packed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * n_xb * 8 * 2 * kWave) return;
+    const int lane = idx & 63, ct = (idx >> 6) & 1, s = (idx >> 7) & 7, rest = idx >> 10;
+    const int xb = rest % n_xb, type = rest / n_xb;
+    packed[idx] = w[static_cast<int64_t>(16 * ct + (lane & 15)) * ld_w + ND * narrow_xblock_weight(type, xb) + ncol(lane >> 4, s)];
+}
+
+struct FwdRows {
+    v4f h[2], a[2], b[2], ab[2];      // the lane's two pieces of h[v] and of the three pair sums of v
+    float d, sc;
+    int64_t v;
+    bool live;
+};
+
+template <int ORDER>
+__global__ __launch_bounds__(kBlockThreads, 2) void node_interact_fwd_narrow_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
+                                                                                     const float* __restrict__ deg, const float* __restrict__ scale,
+                                                                                     const float* __restrict__ bias, const float* __restrict__ packed, NarrowTiles plan,
+                                                                                     float* __restrict__ out, int64_t ld_out) {
+    constexpr int XB = ORDER == 3 ? 7 : 6;
+    const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
+    const int total = plan.tile_prefix[3];
+    const int64_t waves = global_wave_count();
+    const int per = static_cast<int>((total + waves - 1) / waves);
+    const int t0 = static_cast<int>(global_wave_id()) * per;
+    const int n_my = std::max(0, std::min(per, total - t0));
+    if (n_my == 0) return;
+    auto tile_type = [&](int k) {
+        const int tile = std::min(t0 + k, total - 1);
+        return tile >= plan.tile_prefix[2] ? 2 : (tile >= plan.tile_prefix[1] ? 1 : 0);
+    };
+    auto load = [&](int k, FwdRows& r) {
+        const int tile = std::min(t0 + k, total - 1);
+        const int type = tile_type(k);
+        const int64_t row = plan.begin[type] + static_cast<int64_t>(tile - plan.tile_prefix[type]) * NT + i;
+        r.live = row < plan.begin[type + 1];
+        r.v = std::min(row, plan.begin[type + 1] - 1);
+        const float* hp = h + r.v * ld_h + 4 * q;
+        const float* sp = sums + r.v * ld_s + 4 * q;
+        r.d = deg[r.v];
+        r.sc = scale != nullptr ? scale[r.v] : 1.f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            r.h[hf] = *reinterpret_cast<const v4f*>(hp + 16 * hf);
+            r.a[hf] = *reinterpret_cast<const v4f*>(sp + 16 * hf);
+            r.b[hf] = *reinterpret_cast<const v4f*>(sp + ND + 16 * hf);
+            r.ab[hf] = *reinterpret_cast<const v4f*>(sp + 2 * ND + 16 * hf);
+        }
+    };
+    v4f bias_c[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) bias_c[ct] = bias != nullptr ? *reinterpret_cast<const v4f*>(bias + 16 * ct + 4 * q) : v4f{0.f, 0.f, 0.f, 0.f};
+    float wreg[XB][8][2];
+    int cur_type = -1;
+    auto step = [&](int k, const FwdRows& use, FwdRows& fill) {
+        load(k + 1, fill);
+        const int type = tile_type(k);
+        if (type != cur_type) {                                            // wave-uniform: at most two changes in a wave's range
+            const float* wp = packed + static_cast<int64_t>(type) * XB * 8 * 2 * kWave + lane;
+#pragma unroll
+            for (int xb = 0; xb < XB; ++xb)
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) wreg[xb][s][ct] = wp[((xb * 8 + s) * 2 + ct) * kWave];
+            cur_type = type;
+        }
+        v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int xb = 0; xb < XB; ++xb) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float hv = use.h[s >> 2][s & 3];
+                const float z = xb == 0 ? hv * use.d : xb == 1 ? use.a[s >> 2][s & 3] : xb == 2 ? hv * use.a[s >> 2][s & 3] : xb == 3 ? use.b[s >> 2][s & 3]
+                                : xb == 4 ? hv * use.b[s >> 2][s & 3] : xb == 5 ? use.ab[s >> 2][s & 3] : hv * use.ab[s >> 2][s & 3];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[xb][s][ct], z, acc[ct], 0, 0, 0);
+            }
+        }
+        if (use.live) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) *reinterpret_cast<v4f*>(out + use.v * ld_out + 16 * ct + 4 * q) = (acc[ct] + bias_c[ct] * use.d) * use.sc;
+        }
+    };
+    FwdRows ra, rb;
+    load(0, ra);
+    int k = 0;
+#pragma clang loop unroll(disable)
+    for (; k + 1 < n_my; k += 2) {
+        step(k, ra, rb);
+        step(k + 1, rb, ra);
+    }
+    if (k < n_my) step(k, ra, rb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node-level weight gradients of the product blocks (ihg_node_interact_bwd_weight at d = 32): G_type[j][X col] = sum over the type's rows of (dy_scale dy)[v][j] X[v][col],
+// X = [h S_a | h S_b | S_ab | h S_ab].  The contraction index is the ROW: a step takes four rows (lane group rq = lane >> 4 -> row), lane ci = lane & 15 supplies columns
+// 2 ci and 2 ci + 1 of every operand row (8-byte loads, 16 lanes = one whole 128-byte row) - output index i of tile mt / nt stands for column 2 i + mt / nt.  A wave keeps
+// the whole [32 x NBLK 32] gradient of its row range in 8 NBLK accumulator tiles and writes ONE slab; narrow_weight_reduce_kernel adds the slabs of each type, in range
+// order, into the w blocks that type's X blocks stand for (split_node.hip's node_weight_reduce_kernel at this width).
+// ------------------------------------------------------------------------------------------------
+template <int NBLK>
+__global__ __launch_bounds__(kBlockThreads, 2) void node_interact_weight_narrow_kernel(const float* __restrict__ h, int64_t ld_h, const float* __restrict__ sums, int64_t ld_s,
+                                                                                        const float* __restrict__ dy, int64_t ld_dy, const float* __restrict__ dy_scale,
+                                                                                        NarrowRanges plan, float* __restrict__ slabs) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int range = static_cast<int>(global_wave_id());
+    if (range >= plan.range_prefix[3]) return;
+    const int lane = threadIdx.x & 63, ci = lane & 15, rq = lane >> 4;
+    const int type = range >= plan.range_prefix[2] ? 2 : (range >= plan.range_prefix[1] ? 1 : 0);
+    const int n_r = plan.range_prefix[type + 1] - plan.range_prefix[type];
+    const int64_t rows_t = plan.begin[type + 1] - plan.begin[type];
+    const int64_t per = ((rows_t + n_r - 1) / n_r + 15) / 16 * 16;
+    const int64_t r0 = plan.begin[type] + static_cast<int64_t>(range - plan.range_prefix[type]) * per;
+    const int64_t r1 = std::min(r0 + per, plan.begin[type + 1]);
+    v4f acc[2][NBLK * 2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < NBLK * 2; ++t) acc[mt][t] = v4f{0.f, 0.f, 0.f, 0.f};
+    struct Four { v2f dyv[4], hv[4], a[4], b[4], ab[4]; float sc[4]; };
+    auto load = [&](int64_t row, Four& f) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t v = row + 4 * u + rq;
+            const int64_t vc = std::max<int64_t>(std::min(v, r1 - 1), plan.begin[type]);
+            f.sc[u] = v < r1 ? (dy_scale != nullptr ? dy_scale[vc] : 1.f) : 0.f;       // rows past the range: zero cotangent
+            f.dyv[u] = *reinterpret_cast<const v2f*>(dy + vc * ld_dy + 2 * ci);
+            f.hv[u] = *reinterpret_cast<const v2f*>(h + vc * ld_h + 2 * ci);
+            f.a[u] = *reinterpret_cast<const v2f*>(sums + vc * ld_s + 2 * ci);
+            f.b[u] = *reinterpret_cast<const v2f*>(sums + vc * ld_s + ND + 2 * ci);
+            f.ab[u] = *reinterpret_cast<const v2f*>(sums + vc * ld_s + 2 * ND + 2 * ci);
+        }
+    };
+    auto contract = [&](const Four& f) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const v2f a = f.dyv[u] * f.sc[u];
+            const v2f z[4] = {f.hv[u] * f.a[u], f.hv[u] * f.b[u], f.ab[u], f.hv[u] * f.ab[u]};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int xb = 0; xb < NBLK; ++xb)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][2 * xb + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], z[xb][nt], acc[mt][2 * xb + nt], 0, 0, 0);
+        }
+    };
+    if (r0 < r1) {
+        Four fa, fb;
+        load(r0, fa);
+        int64_t row = r0;
+#pragma clang loop unroll(disable)
+        for (; row + 16 < r1; row += 32) {
+            load(row + 16, fb);
+            contract(fa);
+            load(row + 32, fa);
+            contract(fb);
+        }
+        if (row < r1) contract(fa);
+    }
+    float* slab = slabs + static_cast<int64_t>(range) * ND * NBLK * ND;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int xb = 0; xb < NBLK; ++xb)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(2 * (4 * rq + r) + mt) * (NBLK * ND) + xb * ND + 2 * ci + nt] = acc[mt][2 * xb + nt][r];
+}
+
+__global__ __launch_bounds__(kBlockThreads) void narrow_weight_reduce_kernel(const float* __restrict__ slabs, NarrowRanges plan, int nblk, float* __restrict__ dw, int64_t ld_dw) {
+    constexpr signed char kPos[3][4] = {{0, 2, 1, 3}, {0, 1, 2, 3}, {2, 1, 0, 3}};      // [type][w block uq / qi / iu / uqi] -> X block
+    const int width = nblk * ND;
+    const int64_t total = static_cast<int64_t>(ND) * width;
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * kWave + (threadIdx.x & 63);
+    const bool live = idx < total;
+    const int j = static_cast<int>((live ? idx : 0) / width), col = static_cast<int>((live ? idx : 0) - static_cast<int64_t>(j) * width);
+    const int b = col / ND, c = col - b * ND;
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int n = plan.range_prefix[t + 1] - plan.range_prefix[t];
+        sum += slab_sum(slabs + static_cast<int64_t>(plan.range_prefix[t]) * total, n, total, static_cast<int64_t>(j) * width + kPos[t][b] * ND + c, live);
+    }
+    if ((threadIdx.x >> 6) == 0 && live) dw[static_cast<int64_t>(j) * ld_dw + 3 * ND + col] = sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Member gradients (ihg_interact_bwd_user_reduced / ihg_interact_bwd_gathered at d = 32): dz_b = dout W_b, then the product rule; the user slot summed on chip.
+// packed[nt = 2 b + hf][s][lane] = w[ncol(lane >> 4, s)][(3 + b) 32 + 16 hf + (lane & 15)]: A fragment of the W_b^T tile (b, hf) at step s; 64 registers, 64 MFMAs per tile.
+// Lane (e = lane & 15, q = lane >> 4) of a tile of 16 CONSECUTIVE hyperedges: requests the member ids of e two tiles ahead and - GATHER - the three members' rows of the
+// node-level cotangent dy ([N, d]: dout[e] = sum over the members of dy_scale[m] dy[m], K5's order) or the row of dout, and the three members' rows of h, one tile ahead;
+// its eight values of dout are the B operand, its eight results per block the columns it holds of h - the product rule needs no data from another lane.
+// User slot: hyperedges are numbered by user, so the tile's 16 user-slot gradients are runs of equal user along e = the 16 lanes of a DPP row: a segmented inclusive scan
+// (row_shr 1 / 2 / 4 / 8, a lane adds what lies inside its run) leaves every run's sum in its last lane, which stores it to dh[user] - unless the run is the FIRST of
+// the wave's tile range (it may continue a run of the previous range) or the LAST (carried from tile to tile in lane 15's registers; at the end of the range it may continue
+// in the next): those go to the boundary table that interact.hip's user_boundary_fixup_kernel adds up in range order (two entries per range).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads) void pack_members_narrow_kernel(const float* __restrict__ w, int64_t ld_w, int nblk, float* __restrict__ packed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nblk * 2 * 8 * kWave) return;
+    const int lane = idx & 63, s = (idx >> 6) & 7, nt = idx >> 9;
+    packed[idx] = w[static_cast<int64_t>(ncol(lane >> 4, s)) * ld_w + (3 + (nt >> 1)) * ND + 16 * (nt & 1) + (lane & 15)];
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));      // lanes whose source lies outside the row read 0
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_row_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
+}
+
+struct MemberIds {
+    int u, q, i;
+};
+template <bool GATHER>
+struct MemberRows {
+    v4f hu[2], hq[2], hi[2];
+    v4f du[2], dq[GATHER ? 2 : 1], di[GATHER ? 2 : 1];      // GATHER: the three members' dy pieces; otherwise du = the dout pieces
+    float su, sq, si;
+    int user;                                                // user of the lane's hyperedge (-2: past the end of the list)
+    int64_t e;
+};
+
+template <int NBLK, bool GATHER>
+__global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
+                                                                           const float* __restrict__ packed, const float* __restrict__ dsrc, int64_t ld_d,
+                                                                           const float* __restrict__ dy_scale, float* __restrict__ dout_store, int64_t ld_store,
+                                                                           float* __restrict__ g2, int64_t n_edges, float* __restrict__ dh_user, int64_t ld_dh,
+                                                                           float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user, int n_ranges) {
+    const int range = static_cast<int>(global_wave_id());
+    if (range >= n_ranges) return;
+    const int lane = threadIdx.x & 63, q = lane >> 4, el = lane & 15;
+    const int64_t n_tiles = (n_edges + NT - 1) / NT;
+    const int64_t per = (n_tiles + n_ranges - 1) / n_ranges;
+    const int64_t t0 = static_cast<int64_t>(range) * per;
+    const int n_my = static_cast<int>(std::max<int64_t>(0, std::min<int64_t>(per, n_tiles - t0)));
+    if (n_my == 0) {
+        if (lane == 0) bnd_user[2 * range] = bnd_user[2 * range + 1] = -1;
+        return;
+    }
+    float wreg[NBLK * 2][8];
+#pragma unroll
+    for (int nt = 0; nt < NBLK * 2; ++nt)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wreg[nt][s] = packed[(nt * 8 + s) * kWave + lane];
+
+    auto edge_of = [&](int k) { return (t0 + std::min(k, n_my - 1)) * NT + el; };
+    auto load_ids = [&](int k, MemberIds& m) {
+        const int64_t ec = std::min(edge_of(k), n_edges - 1);
+        m.u = i3[3 * ec];
+        m.q = i3[3 * ec + 1];
+        m.i = i3[3 * ec + 2];
+    };
+    auto load_rows = [&](int k, const MemberIds& m, MemberRows<GATHER>& r) {
+        r.e = edge_of(k);
+        r.user = (r.e < n_edges && k < n_my) ? m.u : -2;
+        const int64_t ec = std::min(r.e, n_edges - 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            r.hu[hf] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(m.u) * ld_h + 16 * hf + 4 * q);
+            r.hq[hf] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(m.q) * ld_h + 16 * hf + 4 * q);
+            r.hi[hf] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(m.i) * ld_h + 16 * hf + 4 * q);
+            if (GATHER) {
+                r.du[hf] = *reinterpret_cast<const v4f*>(dsrc + static_cast<int64_t>(m.u) * ld_d + 16 * hf + 4 * q);
+                r.dq[GATHER ? hf : 0] = *reinterpret_cast<const v4f*>(dsrc + static_cast<int64_t>(m.q) * ld_d + 16 * hf + 4 * q);
+                r.di[GATHER ? hf : 0] = *reinterpret_cast<const v4f*>(dsrc + static_cast<int64_t>(m.i) * ld_d + 16 * hf + 4 * q);
+            } else {
+                r.du[hf] = *reinterpret_cast<const v4f*>(dsrc + ec * ld_d + 16 * hf + 4 * q);
+            }
+        }
+        if (GATHER) {
+            r.su = dy_scale != nullptr ? dy_scale[m.u] : 1.f;
+            r.sq = dy_scale != nullptr ? dy_scale[m.q] : 1.f;
+            r.si = dy_scale != nullptr ? dy_scale[m.i] : 1.f;
+        }
+    };
+
+    // the run that is open when a tile begins: its user (wave-uniform) and its sum so far (in the lanes el == 15); `first_run`: it is still the range's first run
+    int carry_user = -1;
+    float carry[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) carry[s] = 0.f;
+    bool first_run = true;
+    float* const slot0 = bnd_val + static_cast<int64_t>(2 * range) * ND;
+    auto put8 = [&](float* dst, const float (&v)[8]) {
+        *reinterpret_cast<v4f*>(dst + 4 * q) = v4f{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<v4f*>(dst + 16 + 4 * q) = v4f{v[4], v[5], v[6], v[7]};
+    };
+
+    auto step = [&](int k, const MemberRows<GATHER>& use, MemberRows<GATHER>& fill, const MemberIds& ids_next, MemberIds& ids_fill) {
+        load_rows(k + 1, ids_next, fill);
+        load_ids(k + 2, ids_fill);
+        const bool live = use.user >= 0;
+        // the hyperedge's cotangent at this lane's eight columns
+        float dout[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (GATHER) dout[s] = ((0.f + use.su * use.du[s >> 2][s & 3]) + use.sq * use.dq[GATHER ? s >> 2 : 0][s & 3]) + use.si * use.di[GATHER ? s >> 2 : 0][s & 3];
+            else dout[s] = use.du[s >> 2][s & 3];
+        }
+        if (GATHER && dout_store != nullptr && live) {
+            store_stream4(dout_store + use.e * ld_store + 4 * q, v4f{dout[0], dout[1], dout[2], dout[3]});
+            store_stream4(dout_store + use.e * ld_store + 16 + 4 * q, v4f{dout[4], dout[5], dout[6], dout[7]});
+        }
+        v4f acc[NBLK * 2];
+#pragma unroll
+        for (int nt = 0; nt < NBLK * 2; ++nt) acc[nt] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NBLK * 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][s], dout[s], acc[nt], 0, 0, 0);
+        // product rule at the lane's columns
+        float gu[8], gq[8], gi[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int hf = s >> 2, r = s & 3;
+            const float hu = use.hu[hf][r], hq = use.hq[hf][r], hi = use.hi[hf][r];
+            const float z_uq = acc[0 + hf][r], z_qi = acc[2 + hf][r], z_iu = acc[4 + hf][r];
+            const float z_uqi = NBLK == 4 ? acc[2 * (NBLK - 1) + hf][r] : 0.f;
+            gu[s] = live ? z_uq * hq + z_iu * hi + z_uqi * (hq * hi) : 0.f;
+            gq[s] = z_uq * hu + z_qi * hi + z_uqi * (hu * hi);
+            gi[s] = z_qi * hq + z_iu * hu + z_uqi * (hu * hq);
+        }
+        if (live) {
+            float* gp = g2 + use.e * (2 * ND);
+            store_stream4(gp + 4 * q, v4f{gq[0], gq[1], gq[2], gq[3]});
+            store_stream4(gp + 16 + 4 * q, v4f{gq[4], gq[5], gq[6], gq[7]});
+            store_stream4(gp + ND + 4 * q, v4f{gi[0], gi[1], gi[2], gi[3]});
+            store_stream4(gp + ND + 16 + 4 * q, v4f{gi[4], gi[5], gi[6], gi[7]});
+        }
+        // ---- user slot: the open run continues into this tile, or it has ended with the previous tile
+        const int user = use.user;
+        const int first_user = __builtin_amdgcn_readfirstlane(user);
+        const bool continuing = first_user == carry_user;
+        if (!continuing && carry_user >= 0) {
+            if (el == 15) put8(first_run ? slot0 : dh_user + static_cast<int64_t>(carry_user) * ld_dh, carry);
+            if (first_run && lane == 15) bnd_user[2 * range] = carry_user;
+        }
+        if (!continuing) first_run = first_run && carry_user < 0;           // (a range's first tile has no open run: its first run starts here)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float from15 = __shfl(carry[s], (lane & 48) | 15);
+            if (continuing && el == 0) gu[s] += from15;
+        }
+        const int prev_user = dpp_row_i<0x111>(user);                        // row_shr:1
+        const int next_user = dpp_row_i<0x101>(user);                        // row_shl:1
+        const bool head = el == 0 || prev_user != user;
+        int hp = head ? el : 0;                                              // position of the lane's run start inside the tile: a max-scan
+        hp = std::max(hp, dpp_row_i<0x111>(hp));
+        hp = std::max(hp, dpp_row_i<0x112>(hp));
+        hp = std::max(hp, dpp_row_i<0x114>(hp));
+        hp = std::max(hp, dpp_row_i<0x118>(hp));
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float v = gu[s];
+            float t = dpp_row_f<0x111>(v);
+            v += el - 1 >= hp ? t : 0.f;
+            t = dpp_row_f<0x112>(v);
+            v += el - 2 >= hp ? t : 0.f;
+            t = dpp_row_f<0x114>(v);
+            v += el - 4 >= hp ? t : 0.f;
+            t = dpp_row_f<0x118>(v);
+            v += el - 8 >= hp ? t : 0.f;
+            gu[s] = v;
+        }
+        const bool tail = el < 15 && user >= 0 && next_user != user;         // the run ends inside this tile
+        if (tail) {
+            const bool to_slot0 = first_run && hp == 0;
+            put8(to_slot0 ? slot0 : dh_user + static_cast<int64_t>(user) * ld_dh, gu);
+            if (to_slot0 && q == 0) bnd_user[2 * range] = user;
+        }
+        const bool any_head = __ballot(head && el > 0) != 0;
+        first_run = first_run && !any_head;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) carry[s] = gu[s];
+        carry_user = __builtin_amdgcn_readlane(user, 15);
+    };
+
+    MemberIds ia, ib;
+    MemberRows<GATHER> ra, rb;
+    load_ids(0, ia);
+    load_ids(1, ib);
+    load_rows(0, ia, ra);
+    int k = 0;
+#pragma clang loop unroll(disable)
+    for (; k + 1 < n_my; k += 2) {
+        step(k, ra, rb, ib, ia);
+        step(k + 1, rb, ra, ia, ib);
+    }
+    if (k < n_my) step(k, ra, rb, ib, ia);
+    // the run that is open at the end of the range
+    if (carry_user >= 0) {
+        if (el == 15) put8(first_run ? slot0 : slot0 + ND, carry);
+        if (lane == 15) {
+            if (first_run) bnd_user[2 * range] = carry_user;
+            bnd_user[2 * range + 1] = first_run ? -1 : carry_user;
+        }
+    } else if (lane == 15) {
+        bnd_user[2 * range + 1] = -1;
+    }
+}
+
+NarrowTiles narrow_tiles(const int64_t* type_begin) {
+    NarrowTiles plan;
+    int acc = 0;
+    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
+    for (int t = 0; t < 3; ++t) {
+        plan.tile_prefix[t] = acc;
+        acc += static_cast<int>((type_begin[t + 1] - type_begin[t] + NT - 1) / NT);
+    }
+    plan.tile_prefix[3] = acc;
+    return plan;
+}
+
+}  // namespace
+
+int64_t narrow_node_fwd_floats() { return 3LL * 7 * 8 * 2 * kWave; }
+
+bool narrow_node_fwd_ok(int dim, int order, int64_t ld_h, int64_t ld_s, const float* out, int64_t ld_out, const float* bias) {
+    return dim == ND && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_s % 4 == 0 && ld_out % 4 == 0 && aligned16(out) && (bias == nullptr || aligned16(bias));
+}
+
+void launch_node_fwd_narrow(int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* deg, const float* scale, const float* bias, const float* w,
+                            int64_t ld_w, const int64_t* type_begin, float* out, int64_t ld_out, float* packed, hipStream_t s) {
+    const int n_xb = order == 3 ? 7 : 6;
+    const int items = 3 * n_xb * 8 * 2 * kWave;
+    hipLaunchKernelGGL(pack_node_fwd_narrow_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, n_xb, packed);
+    const NarrowTiles plan = narrow_tiles(type_begin);
+    if (plan.tile_prefix[3] == 0) return;
+    const int grid = grid_for_waves(std::min(plan.tile_prefix[3], 2048));
+    if (order == 3) hipLaunchKernelGGL(node_interact_fwd_narrow_kernel<3>, dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, packed, plan, out, ld_out);
+    else hipLaunchKernelGGL(node_interact_fwd_narrow_kernel<2>, dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, packed, plan, out, ld_out);
+}
+
+int64_t narrow_node_weight_floats(int order) { return static_cast<int64_t>(kNarrowWeightRanges) * ND * (order == 3 ? 4 : 3) * ND; }
+
+bool narrow_node_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_s, int64_t ld_dy, const float* dy) {
+    return dim == ND && (order == 2 || order == 3) && ld_h % 2 == 0 && ld_s % 2 == 0 && ld_dy % 2 == 0 && (reinterpret_cast<uintptr_t>(dy) & 7u) == 0;
+}
+
+void launch_node_weight_narrow(int order, const float* h, int64_t ld_h, const float* sums, int64_t ld_s, const float* dy, int64_t ld_dy, const float* dy_scale,
+                               const int64_t* type_begin, float* slabs, float* dw, int64_t ld_dw, hipStream_t s) {
+    NarrowRanges plan;
+    int64_t rows[3], total = 0;
+    for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
+    for (int t = 0; t < 3; ++t) {
+        rows[t] = type_begin[t + 1] - type_begin[t];
+        total += rows[t];
+    }
+    // row ranges by type in proportion to the rows (at least 64 rows a range, every non-empty type at least one range, kNarrowWeightRanges in all at most)
+    int acc = 0;
+    for (int t = 0; t < 3; ++t) {
+        int64_t n = rows[t] == 0 ? 0 : std::max<int64_t>(1, rows[t] * (kNarrowWeightRanges - 2) / std::max<int64_t>(total, 1));
+        n = std::min<int64_t>(n, (rows[t] + 63) / 64);
+        plan.range_prefix[t] = acc;
+        acc += static_cast<int>(n);
+    }
+    plan.range_prefix[3] = acc;
+    const int nblk = order == 3 ? 4 : 3;
+    if (acc > 0) {
+        if (order == 3) hipLaunchKernelGGL(node_interact_weight_narrow_kernel<4>, dim3(grid_for_waves(acc)), dim3(kBlockThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);
+        else hipLaunchKernelGGL(node_interact_weight_narrow_kernel<3>, dim3(grid_for_waves(acc)), dim3(kBlockThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);
+    }
+    const int total_w = ND * nblk * ND;
+    hipLaunchKernelGGL(narrow_weight_reduce_kernel, dim3((total_w + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, plan, nblk, dw, ld_dw);
+}
+
+int64_t narrow_members_floats(int order) { return static_cast<int64_t>(order == 3 ? 4 : 3) * 2 * 8 * kWave; }
+
+bool narrow_members_ok(int dim, int order, const float* g2, int64_t ld_h, int64_t ld_d, const float* dsrc) {
+    return dim == ND && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_d % 4 == 0 && aligned16(g2) && aligned16(dsrc);
+}
+
+void launch_members_narrow(int order, int gather, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, float* packed, const float* dsrc, int64_t ld_d,
+                           const float* dy_scale, float* dout_store, int64_t ld_store, float* g2, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val,
+                           int32_t* bnd_user, int* n_boundary_entries, hipStream_t s) {
+    const int nblk = order == 3 ? 4 : 3;
+    const int items = nblk * 2 * 8 * kWave;
+    hipLaunchKernelGGL(pack_members_narrow_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, nblk, packed);
+    const int64_t n_tiles = (n_edges + NT - 1) / NT;
+    const int n_ranges = static_cast<int>(std::min<int64_t>(n_tiles, kNarrowMemberRanges));
+    *n_boundary_entries = 2 * n_ranges;
+    const int grid = grid_for_waves(n_ranges);
+#define IHG_NARROW_MEMBERS(NBLK, GATHER)                                                                                                                            \
+    hipLaunchKernelGGL((members_narrow_kernel<NBLK, GATHER>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, packed, dsrc, ld_d, dy_scale, dout_store, ld_store, g2, \
+                       n_edges, dh_user, ld_dh, bnd_val, bnd_user, n_ranges)
+    if (nblk == 4) {
+        if (gather) IHG_NARROW_MEMBERS(4, true);
+        else IHG_NARROW_MEMBERS(4, false);
+    } else {
+        if (gather) IHG_NARROW_MEMBERS(3, true);
+        else IHG_NARROW_MEMBERS(3, false);
+    }
+#undef IHG_NARROW_MEMBERS
+}

@@ -432,10 +432,11 @@ def test_interact_persistent_tiles_and_strided_rows(dim, order, edges):
     assert rel(hg.grad, hc.grad) <= RTOL and rel(wg.grad, wc.grad) <= RTOL
 
 
-@pytest.mark.parametrize('dim', [128, 64])
-@pytest.mark.parametrize('order,edges,users', [(3, 700 * 32 + 5, 301), (2, 300 * 32, 7), (3, 40, 3), (3, 9000, 5000)])
+@pytest.mark.parametrize('dim', [128, 64, 32])
+@pytest.mark.parametrize('order,edges,users', [(3, 700 * 32 + 5, 301), (2, 300 * 32, 7), (3, 40, 3), (3, 9000, 5000), (3, 2048 * 16 * 3 + 7, 1500)])
 def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, dim, monkeypatch):
-    """d = 128 (two column halves per tile range) and d = 64 (one workgroup per range) with hyperedges numbered by user: the member-gradient kernel sums the user slot on chip (runs inside a tile, across
+    """d = 128 (two column halves per tile range), d = 64 (one workgroup per range) and d = 32 (narrow.hip: one WAVE per range of 16-hyperedge tiles, the runs summed by a
+    segmented scan over the 16 lanes of a DPP row; 98,311 hyperedges = three tiles per range of the 2,048 and a partial last tile) with hyperedges numbered by user: the member-gradient kernel sums the user slot on chip (runs inside a tile, across
     tiles, across workgroups - 7 users over 9,600 hyperedges put one user's run in several workgroups - users without hyperedges)
     and writes dh[users] itself, the [E, 2, d] buffer carries the other two slots.  Against the oracle and against the [E, 3, d] form."""
     from ihgnn_amd import ops
@@ -466,7 +467,9 @@ def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, dim, m
 
 @pytest.mark.parametrize('order,edges,users,dim,restricted', [(3, 700 * 32 + 5, 301, 128, False), (2, 300 * 32, 7, 128, False), (3, 40, 3, 128, True),
                                                              (3, 9000, 5000, 128, True), (3, 33, 7, 128, False), (3, 700, 31, 64, False), (2, 300 * 32 + 9, 7, 64, False),
-                                                             (3, 9000, 5000, 64, True), (3, 700, 31, 256, False), (2, 300, 11, 12, False)])
+                                                             (3, 9000, 5000, 64, True), (3, 700, 31, 256, False), (2, 300, 11, 12, False),
+                                                             (3, 700, 31, 32, False), (2, 300 * 32 + 9, 7, 32, False), (3, 9000, 5000, 32, True), (3, 33, 7, 32, False),
+                                                             (3, 2048 * 16 * 2 + 3, 4000, 32, False)])
 def test_interact_to_nodes_backward_forms_the_hyperedge_cotangents_itself(order, edges, users, dim, restricted, monkeypatch):
     """``interact_to_nodes`` = interact + hyperedge -> node pass as one autograd node.  At d = 128 and d = 64 (hyperedges numbered by user) its backward
     has no node -> hyperedge launch: the member-gradient kernel gathers the three ``dy`` rows of a hyperedge (ring of ids a phase earlier,
@@ -505,13 +508,13 @@ def test_interact_to_nodes_backward_forms_the_hyperedge_cotangents_itself(order,
     fused = run(True)
     launched = profiler.summary()
     profiler.stop()
-    assert ('edge_gather_sum' not in launched) == (dim in (128, 64)), sorted(launched)
+    assert ('edge_gather_sum' not in launched) == (dim in (128, 64, 32)), sorted(launched)
     separate = run(False)
     assert torch.equal(fused[0], separate[0])
     for got, want in zip(fused[1:], separate[1:]):
         assert rel(got, want) <= RTOL_SUM
-    if dim in (128, 64):
-        monkeypatch.setenv('IHG_INTERACT_ARITH', 'f32')                 # no gathering kernel in this mode: the separate ops' sequence
+    if dim in (128, 64, 32):
+        monkeypatch.setenv('IHG_INTERACT_ARITH', 'f32')                 # no gathering kernel in this mode at d = 64 / 128: the separate ops' sequence (d = 32 gathers in fp32 either way)
         for got, want in zip(run(True)[1:], separate[1:]):
             assert rel(got, want) <= RTOL
 
@@ -616,9 +619,9 @@ def test_pair_sums_over_the_other_members_of_a_nodes_hyperedges(dim):
         assert torch.equal(wide[:, :3 * dim], got) and bool((wide[:, 3 * dim:] == 7.0).all())
 
 
-@pytest.mark.parametrize('order,dim', [(3, 128), (2, 128), (3, 64), (2, 64), (3, 256), (2, 256)])
+@pytest.mark.parametrize('order,dim', [(3, 128), (2, 128), (3, 64), (2, 64), (3, 256), (2, 256), (3, 32), (2, 32)])
 def test_interactive_layer_without_hyperedge_rows(order, dim, monkeypatch):
-    """d = 64 / 128 / 256 (d = 128: four passes over the contraction index in one launch, two fp16 terms per operand; d = 64 / 256: the 64-column / 512-value pass geometry): the forward of the interactive layer in its node-level form (pair sums + a node-level contraction with the typed weight
+    """d = 32 (the reference's default width: narrow.hip, fp32 MFMA, one wave per 16-row tile) and d = 64 / 128 / 256 (d = 128: four passes over the contraction index in one launch, two fp16 terms per operand; d = 64 / 256: the 64-column / 512-value pass geometry): the forward of the interactive layer in its node-level form (pair sums + a node-level contraction with the typed weight
     blocks: no [E, d] tensor) against the oracle's FeatureInteractor + segment sum in float64 and against the hyperedge form
     (IHG_NODE_LEVEL_FORWARD=0) - with and without bias / output scale, more row tiles than workgroups, fewer, split rows, isolated nodes of
     every type, a strided destination; the gradients of h, w and the bias against float64 autograd of the oracle, with the product blocks' weight
@@ -806,7 +809,7 @@ def test_split_arithmetic_worst_case_operands(dim, scheme):
     assert max(errors[k] for k in mine) >= 2.0 ** -22, errors
 
 
-@pytest.mark.parametrize('dim', [128, 256])
+@pytest.mark.parametrize('dim', [128, 256, 32])
 def test_weight_gradients_over_rows_of_very_different_magnitude(dim):
     """The weight gradients contract over the ROWS, and their two-fp16-term arithmetic scales a row's two operands against each other under one running scale per
     workgroup (csrc/split_node.hip).  What that has to survive: rows whose magnitudes differ by many orders (here 2^-30 .. 2^10 per row, cotangent and input
@@ -1076,7 +1079,7 @@ F10_LAUNCHES = {
     'd128_l3_o3': ({'node_pair_sums', 'node_interact_fwd', 'node_interact_bwd_weight', 'interact_bwd', 'k7.two_hop_first_order_gradient'}, {'interact_fwd', 'edge_gather_sum'}),
     'd128_l3_o2': ({'node_pair_sums', 'node_interact_fwd', 'node_interact_bwd_weight', 'interact_bwd', 'k7.two_hop_first_order_gradient'}, {'interact_fwd', 'edge_gather_sum'}),
     'd64_l2_o3': ({'node_pair_sums', 'node_interact_fwd', 'node_interact_bwd_weight', 'interact_bwd'}, {'interact_fwd'}),
-    'd32_l2_o3': ({'interact_bwd'}, set()),
+    'd32_l2_o3': ({'node_pair_sums', 'node_interact_fwd', 'node_interact_bwd_weight', 'interact_bwd', 'k7.two_hop_first_order_gradient'}, {'interact_fwd', 'edge_gather_sum'}),
 }
 
 
