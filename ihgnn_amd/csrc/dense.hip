@@ -1,6 +1,7 @@
 // dense.hip - node-level dense transforms (feature_transform and the hoisted first-order blocks): typed row GEMM, its input
 // gradient and its weight / bias gradient.
 #include "common.hpp"
+#include "narrow.hpp"
 #include "split.hpp"
 
 namespace {
@@ -452,6 +453,12 @@ int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int
                     hipStream_t s, const TypedRows* in_typed = nullptr, const TypedRowsOut* out_typed = nullptr, int accumulate = 0) {
     const int n_types = w_type_stride == 0 ? 1 : 3;
     const bool out_ok = out_typed != nullptr ? (aligned16(out_typed->p[0]) && aligned16(out_typed->p[1]) && aligned16(out_typed->p[2])) : aligned16(out);
+    const bool in_ok = in_typed != nullptr ? (aligned16(in_typed->p[0]) && aligned16(in_typed->p[1]) && aligned16(in_typed->p[2])) : aligned16(in);
+    if (narrow_linear_ok(dim, ld_in, ld_out) && in_ok && out_ok && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0))) {      // d = 32: narrow.hip (fp32 MFMA, any arithmetic mode)
+        launch_row_gemm_narrow(in_typed != nullptr ? *in_typed : typed_rows(in), ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin,
+                               out_typed != nullptr ? *out_typed : typed_rows_out(out), ld_out, accumulate, s);
+        return IHG_OK;
+    }
     if (out_ok && split_row_gemm_ok(dim, nullptr, ld_out, bias, bias_type_stride)) {   // the bf16 planes sit behind the slabs (see ihg_node_linear_workspace_bytes)
         void* planes = pk + 3LL * dim * dim + 3LL * kDenseSlabs * (static_cast<int64_t>(dim) * dim + dim);
         launch_row_gemm_split(dim, in_typed != nullptr ? *in_typed : typed_rows(in), ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin,
@@ -735,7 +742,7 @@ int ihg_node_linear_bwd_input(const float* dout, int64_t ld_dout, const float* w
 int32_t ihg_node_linear_bwd_accumulates(int32_t dim, int64_t ld_dout, int64_t ld_x, int64_t ld_dx) {
     // the weight-gradient kernels that form dx in the same pass and can add it onto what dx already holds: d = 64 (fp32 MFMA), d = 128 (bf16-split)
     if (ld_dout % 4 || ld_x % 4 || ld_dx % 4) return 0;
-    return dim == 64 || ((dim == 128 || dim == 256) && split_arith_enabled()) ? 1 : 0;       // (d = 256: the input gradient is a row-GEMM launch of its own, which adds onto dx)
+    return dim == 64 || dim == kNarrowDim || ((dim == 128 || dim == 256) && split_arith_enabled()) ? 1 : 0;       // (d = 256: the input gradient is a row-GEMM launch of its own, which adds onto dx)
 }
 
 int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* x, int64_t ld_x, const int64_t* type_begin,
@@ -770,7 +777,14 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     const TypePlan plan = make_plan(type_begin, 64);
     // weights of type t are the column block t of w exactly as for dw: w_type_stride == dw_type_stride
     int n_slabs = kDenseSlabs;
-    if (split_dense_weight_ok(dim, dout, ld_dout, x, ld_x)) {             // bf16-split contraction (d = 128, 256); the input gradient stays a row-GEMM launch
+    if (narrow_linear_ok(dim, ld_dout, ld_x) && aligned16(dout) && (dx == nullptr || (aligned16(dx) && aligned16(w) && ld_w % 4 == 0))) {
+        // d = 32: weight, bias and input gradient in one pass over (dout, x) (narrow.hip)
+        const TypedRowsOut dx_rows = typed_rows_out(dx);
+        n_slabs = launch_dense_weight_narrow(dout, ld_dout, typed_rows(x), ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, dx != nullptr ? &dx_rows : nullptr, ld_dx,
+                                             dx_accumulate, s);
+    } else if (dx_accumulate && dim == kNarrowDim) {
+        return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate at dim 32 needs 16-byte aligned rows");
+    } else if (split_dense_weight_ok(dim, dout, ld_dout, x, ld_x)) {             // bf16-split contraction (d = 128, 256); the input gradient stays a row-GEMM launch
         const bool fused_dx = dx != nullptr && dim == 128 && aligned16(dx) && ld_dx % 4 == 0;
         if (dx_accumulate && !fused_dx && !(dim == 256 && aligned16(dx) && ld_dx % 4 == 0))
             return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate needs 16-byte aligned dx rows");
@@ -806,7 +820,7 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
 }
 
 int32_t ihg_node_linear_typed_supported(int32_t dim, int64_t ld_x, int64_t ld_out) {
-    return split_arith_enabled() && (dim == 128 || dim == 256) && ld_x >= dim && ld_out >= dim && ld_x % 4 == 0 && ld_out % 4 == 0 ? 1 : 0;
+    return ((split_arith_enabled() && (dim == 128 || dim == 256)) || dim == kNarrowDim) && ld_x >= dim && ld_out >= dim && ld_x % 4 == 0 && ld_out % 4 == 0 ? 1 : 0;
 }
 
 int ihg_node_linear_fwd_typed(const float* const* x_rows, int64_t ld_x, const float* w, int64_t ld_w, int64_t w_type_stride, const float* bias,
@@ -838,7 +852,8 @@ int ihg_node_linear_bwd_weight_typed(const float* dout, int64_t ld_dout, const f
         if (x_rows[t] == nullptr || !aligned16(x_rows[t]) || (dx_rows != nullptr && (dx_rows[t] == nullptr || !aligned16(dx_rows[t]))))
             return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight_typed: rows of type %d null or not 16-byte aligned", t);
     }
-    if (!ihg_node_linear_typed_supported(dim, ld_x, dx_rows != nullptr ? ld_dx : ld_x) || !split_dense_weight_ok(dim, dout, ld_dout, x_rows[0], ld_x) || workspace == nullptr ||
+    const bool narrow = narrow_linear_ok(dim, ld_dout, ld_x) && aligned16(dout) && (dx_rows == nullptr || (aligned16(w) && ld_w % 4 == 0 && ld_dx % 4 == 0));
+    if (!ihg_node_linear_typed_supported(dim, ld_x, dx_rows != nullptr ? ld_dx : ld_x) || (!narrow && !split_dense_weight_ok(dim, dout, ld_dout, x_rows[0], ld_x)) || workspace == nullptr ||
         !aligned16(workspace))
         return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight_typed: not available for this shape (ihg_node_linear_typed_supported)");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -855,10 +870,15 @@ int ihg_node_linear_bwd_weight_typed(const float* dout, int64_t ld_dout, const f
             if ((zero_row_before_mask >> t) & 1) launch_zero_floats(dx_rows[t] - ld_dx, dim, s);
     }
     const bool fused_dx = dx_rows != nullptr && dim == 128;
-    if (dx_rows != nullptr && !fused_dx) {
-        if (int rc = launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, nullptr, ld_dx, static_cast<float*>(workspace), s, nullptr, &dxo)) return rc;
+    int n_slabs = 0;
+    if (narrow) {
+        n_slabs = launch_dense_weight_narrow(dout, ld_dout, xin, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, dx_rows != nullptr ? &dxo : nullptr, ld_dx, 0, s);
+    } else {
+        if (dx_rows != nullptr && !fused_dx) {
+            if (int rc = launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, nullptr, ld_dx, static_cast<float*>(workspace), s, nullptr, &dxo)) return rc;
+        }
+        n_slabs = launch_dense_weight_split(dim, dout, ld_dout, xin, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, fused_dx ? &dxo : nullptr, ld_dx, planes, s, 0);
     }
-    const int n_slabs = launch_dense_weight_split(dim, dout, ld_dout, xin, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, fused_dx ? &dxo : nullptr, ld_dx, planes, s, 0);
     const int total = dim * dim * n_types + dim;
     hipLaunchKernelGGL(dense_slab_reduce_kernel, dim3((total + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, bias_slabs,
                        n_slabs, n_types, dim, dw, ld_dw, dw_type_stride, dbias, bias_type_mask, n_types == 1 ? int64_t{0} : dbias_type_stride);

@@ -449,6 +449,216 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Node-level linear maps at d = 32 (ihg_node_linear_fwd / _bwd_input / _bwd_weight and their typed forms): streams over [N, 32] - 128 bytes in and out per row beside
+// 1 K multiply-adds.  Forward: out[v] = in[v] Wt_type(v) (+ bias of the type) (+ out[v]), Wt[k][c] = W_t[c][k] (transpose == 0) or W_t[k][c]; the W^T fragments of ALL three
+// node types sit in 48 registers.  Rows by typed base pointers (TypedRows: the embedding tables read in place).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRows in, int64_t ld_in, const float* __restrict__ w, int64_t ld_w, int64_t w_type_stride, int transpose,
+                                                                        const float* __restrict__ bias, int bias_mask, int64_t bias_type_stride, NarrowTiles plan, TypedRowsOut out,
+                                                                        int64_t ld_out, int accumulate) {
+    const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
+    const int total = plan.tile_prefix[3];
+    const int64_t waves = global_wave_count();
+    const int per = static_cast<int>((total + waves - 1) / waves);
+    const int t0 = static_cast<int>(global_wave_id()) * per;
+    const int n_my = std::max(0, std::min(per, total - t0));
+    if (n_my == 0) return;
+    float wreg[3][8][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const float* wt = w + (w_type_stride == 0 ? 0 : t) * w_type_stride;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+                wreg[t][s][ct] = transpose == 0 ? wt[static_cast<int64_t>(16 * ct + i) * ld_w + ncol(q, s)] : wt[static_cast<int64_t>(ncol(q, s)) * ld_w + 16 * ct + i];
+    }
+    struct Rows { v4f x[2], old[2]; int64_t v; int type; bool live; };
+    auto load = [&](int k, Rows& r) {
+        const int tile = std::min(t0 + k, total - 1);
+        r.type = tile >= plan.tile_prefix[2] ? 2 : (tile >= plan.tile_prefix[1] ? 1 : 0);
+        const int64_t row = plan.begin[r.type] + static_cast<int64_t>(tile - plan.tile_prefix[r.type]) * NT + i;
+        r.live = row < plan.begin[r.type + 1];
+        r.v = std::min(row, plan.begin[r.type + 1] - 1);
+        const float* ip = typed_base(in, r.type) + r.v * ld_in + 4 * q;
+        r.x[0] = *reinterpret_cast<const v4f*>(ip);
+        r.x[1] = *reinterpret_cast<const v4f*>(ip + 16);
+        if (accumulate) {
+            const float* op = typed_base(out, r.type) + r.v * ld_out + 4 * q;
+            r.old[0] = *reinterpret_cast<const v4f*>(op);
+            r.old[1] = *reinterpret_cast<const v4f*>(op + 16);
+        }
+    };
+    auto step = [&](int k, const Rows& use, Rows& fill) {
+        load(k + 1, fill);
+        v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float a0 = use.type == 0 ? wreg[0][s][0] : (use.type == 1 ? wreg[1][s][0] : wreg[2][s][0]);
+            const float a1 = use.type == 0 ? wreg[0][s][1] : (use.type == 1 ? wreg[1][s][1] : wreg[2][s][1]);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, use.x[s >> 2][s & 3], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, use.x[s >> 2][s & 3], acc[1], 0, 0, 0);
+        }
+        if (bias != nullptr && ((bias_mask >> use.type) & 1)) {
+            acc[0] += *reinterpret_cast<const v4f*>(bias + use.type * bias_type_stride + 4 * q);
+            acc[1] += *reinterpret_cast<const v4f*>(bias + use.type * bias_type_stride + 16 + 4 * q);
+        }
+        if (accumulate) {
+            acc[0] += use.old[0];
+            acc[1] += use.old[1];
+        }
+        if (use.live) {
+            float* op = typed_base(out, use.type) + use.v * ld_out + 4 * q;
+            *reinterpret_cast<v4f*>(op) = acc[0];
+            *reinterpret_cast<v4f*>(op + 16) = acc[1];
+        }
+    };
+    Rows ra, rb;
+    load(0, ra);
+    int k = 0;
+#pragma clang loop unroll(disable)
+    for (; k + 1 < n_my; k += 2) {
+        step(k, ra, rb);
+        step(k + 1, rb, ra);
+    }
+    if (k < n_my) step(k, ra, rb);
+}
+
+// Backward of the same maps in ONE pass over (dout, x): d W_t = dout^T x and the bias gradient over the rows of type t, and - DX - the input gradient dx = dout W_t
+// (+ dx) of the same rows.  grid = (slabs, 1, weight types); a workgroup's four waves take the 16-row tiles 4 sx + wave, + 4 slabs, ... of the type's rows.  The row
+// contraction reads its operands as in node_interact_weight_narrow_kernel (lane ci = columns 2 ci, 2 ci + 1; four rows a step), the input gradient as in the forward;
+// the second read of a row hits the CU's cache.  The waves' partial gradients meet in LDS in wave order; slab layout = dense.hip's ([type][slab][d][d], [type][slab][d]),
+// reduced by its dense_slab_reduce_kernel.
+template <bool DX>
+__global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_narrow_kernel(const float* __restrict__ dout, int64_t ld_dout, TypedRows x, int64_t ld_x, NarrowTiles plan,
+                                                                                 int single_weight, float* __restrict__ slabs, float* __restrict__ bias_slabs,
+                                                                                 const float* __restrict__ w, int64_t ld_w, int64_t w_type_stride, TypedRowsOut dx,
+                                                                                 int64_t ld_dx, int dx_accumulate) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    __shared__ float red[3][18][kWave];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
+    const int wtype = blockIdx.z;
+    const int64_t r_begin = single_weight ? plan.begin[0] : plan.begin[wtype];
+    const int64_t r_end = single_weight ? plan.begin[3] : plan.begin[wtype + 1];
+    const int64_t n_tiles = (r_end - r_begin + NT - 1) / NT;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
+    auto type_of = [&](int64_t v) { return v >= plan.begin[2] ? 2 : (v >= plan.begin[1] ? 1 : 0); };
+    float wreg[DX ? 8 : 1][2];
+    if (DX) {
+        const float* wt = w + wtype * w_type_stride;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) wreg[DX ? s : 0][ct] = wt[static_cast<int64_t>(ncol(q, s)) * ld_w + 16 * ct + i];
+    }
+    struct Rows { v4f d[2], old[2]; v2f dv[4], xv[4]; int64_t v; int type; bool live; };
+    auto load = [&](int64_t tile, Rows& r) {
+        const int64_t base = r_begin + std::min(tile, n_tiles - 1) * NT;
+        const bool tile_live = tile < n_tiles;
+        if (DX) {
+            const int64_t row = base + i;
+            r.live = tile_live && row < r_end;
+            r.v = std::min(row, r_end - 1);
+            r.type = type_of(r.v);
+            r.d[0] = *reinterpret_cast<const v4f*>(dout + r.v * ld_dout + 4 * q);
+            r.d[1] = *reinterpret_cast<const v4f*>(dout + r.v * ld_dout + 16 + 4 * q);
+            if (dx_accumulate) {
+                const float* op = typed_base(dx, r.type) + r.v * ld_dx + 4 * q;
+                r.old[0] = *reinterpret_cast<const v4f*>(op);
+                r.old[1] = *reinterpret_cast<const v4f*>(op + 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = base + 4 * u + q;
+            const int64_t vc = std::min(row, r_end - 1);
+            const bool live = tile_live && row < r_end;
+            const v2f dv = *reinterpret_cast<const v2f*>(dout + vc * ld_dout + 2 * i);
+            r.dv[u] = live ? dv : v2f{0.f, 0.f};
+            r.xv[u] = *reinterpret_cast<const v2f*>(typed_base(x, type_of(vc)) + vc * ld_x + 2 * i);
+        }
+    };
+    v4f acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
+    v2f colsum = v2f{0.f, 0.f};
+    auto work = [&](const Rows& r) {
+        if (DX) {
+            v4f g[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) g[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[DX ? s : 0][ct], r.d[s >> 2][s & 3], g[ct], 0, 0, 0);
+            if (dx_accumulate) {
+                g[0] += r.old[0];
+                g[1] += r.old[1];
+            }
+            if (r.live) {
+                float* op = typed_base(dx, r.type) + r.v * ld_dx + 4 * q;
+                *reinterpret_cast<v4f*>(op) = g[0];
+                *reinterpret_cast<v4f*>(op + 16) = g[1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            colsum += r.dv[u];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.dv[u][mt], r.xv[u][nt], acc[mt][nt], 0, 0, 0);
+        }
+    };
+    if (n_tiles > 0) {
+        Rows ra, rb;
+        int64_t tile = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave;
+        load(tile, ra);
+#pragma clang loop unroll(disable)
+        for (; tile < n_tiles; tile += 2 * stride) {
+            load(tile + stride, rb);
+            work(ra);
+            load(tile + 2 * stride, ra);
+            if (tile + stride < n_tiles) work(rb);
+        }
+    }
+    // the bias gradient's four row groups, then the four waves, in a fixed order
+    colsum[0] += __shfl_xor(colsum[0], 16);
+    colsum[1] += __shfl_xor(colsum[1], 16);
+    colsum[0] += __shfl_xor(colsum[0], 32);
+    colsum[1] += __shfl_xor(colsum[1], 32);
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave - 1][(2 * mt + nt) * 4 + r][lane] = acc[mt][nt][r];
+        red[wave - 1][16][lane] = colsum[0];
+        red[wave - 1][17][lane] = colsum[1];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int n_slabs = gridDim.x;
+        float* slab = slabs + (static_cast<int64_t>(wtype) * n_slabs + blockIdx.x) * ND * ND;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = (2 * mt + nt) * 4 + r;
+                    slab[(2 * (4 * q + r) + mt) * ND + 2 * i + nt] = ((acc[mt][nt][r] + red[0][slot][lane]) + red[1][slot][lane]) + red[2][slot][lane];
+                }
+        if (q == 0) {
+            float* bs = bias_slabs + (static_cast<int64_t>(wtype) * n_slabs + blockIdx.x) * ND;
+            bs[2 * i] = ((colsum[0] + red[0][16][lane]) + red[1][16][lane]) + red[2][16][lane];
+            bs[2 * i + 1] = ((colsum[1] + red[0][17][lane]) + red[1][17][lane]) + red[2][17][lane];
+        }
+    }
+}
+
 NarrowTiles narrow_tiles(const int64_t* type_begin) {
     NarrowTiles plan;
     int acc = 0;
@@ -541,4 +751,28 @@ void launch_members_narrow(int order, int gather, const float* h, int64_t ld_h, 
         else IHG_NARROW_MEMBERS(3, false);
     }
 #undef IHG_NARROW_MEMBERS
+}
+
+bool narrow_linear_ok(int dim, int64_t ld_a, int64_t ld_b) { return dim == ND && ld_a % 4 == 0 && ld_b % 4 == 0; }
+
+void launch_row_gemm_narrow(TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias, int bias_mask,
+                            int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, int accumulate, hipStream_t s) {
+    const NarrowTiles plan = narrow_tiles(type_begin);
+    if (plan.tile_prefix[3] == 0) return;
+    const int grid = grid_for_waves(std::min(plan.tile_prefix[3], 4096));
+    hipLaunchKernelGGL(row_gemm_narrow_kernel, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, plan, out, ld_out,
+                       accumulate);
+}
+
+int launch_dense_weight_narrow(const float* dout, int64_t ld_dout, TypedRows x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs, float* bias_slabs,
+                               const float* w, int64_t ld_w, int64_t w_type_stride, const TypedRowsOut* dx, int64_t ld_dx, int dx_accumulate, hipStream_t s) {
+    const NarrowTiles plan = narrow_tiles(type_begin);
+    const int n_slabs = 256;                                             // = dense.hip's kDenseSlabs: the workspace holds that many per type
+    if (dx != nullptr)
+        hipLaunchKernelGGL(dense_weight_grad_narrow_kernel<true>, dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0, slabs,
+                           bias_slabs, w, ld_w, w_type_stride, *dx, ld_dx, dx_accumulate);
+    else
+        hipLaunchKernelGGL(dense_weight_grad_narrow_kernel<false>, dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0, slabs,
+                           bias_slabs, static_cast<const float*>(nullptr), int64_t{0}, int64_t{0}, typed_rows_out(nullptr), int64_t{0}, 0);
+    return n_slabs;
 }
