@@ -456,7 +456,7 @@ int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int
     const bool in_ok = in_typed != nullptr ? (aligned16(in_typed->p[0]) && aligned16(in_typed->p[1]) && aligned16(in_typed->p[2])) : aligned16(in);
     if (narrow_linear_ok(dim, ld_in, ld_out) && in_ok && out_ok && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0))) {      // d = 32: narrow.hip (fp32 MFMA, any arithmetic mode)
         launch_row_gemm_narrow(in_typed != nullptr ? *in_typed : typed_rows(in), ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin,
-                               out_typed != nullptr ? *out_typed : typed_rows_out(out), ld_out, accumulate, s);
+                               out_typed != nullptr ? *out_typed : typed_rows_out(out), ld_out, accumulate, pk, s);
         return IHG_OK;
     }
     if (out_ok && split_row_gemm_ok(dim, nullptr, ld_out, bias, bias_type_stride)) {   // the bf16 planes sit behind the slabs (see ihg_node_linear_workspace_bytes)
@@ -781,7 +781,7 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
         // d = 32: weight, bias and input gradient in one pass over (dout, x) (narrow.hip)
         const TypedRowsOut dx_rows = typed_rows_out(dx);
         n_slabs = launch_dense_weight_narrow(dout, ld_dout, typed_rows(x), ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, dx != nullptr ? &dx_rows : nullptr, ld_dx,
-                                             dx_accumulate, s);
+                                             dx_accumulate, static_cast<float*>(workspace), s);
     } else if (dx_accumulate && dim == kNarrowDim) {
         return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate at dim 32 needs 16-byte aligned rows");
     } else if (split_dense_weight_ok(dim, dout, ld_dout, x, ld_x)) {             // bf16-split contraction (d = 128, 256); the input gradient stays a row-GEMM launch
@@ -872,7 +872,7 @@ int ihg_node_linear_bwd_weight_typed(const float* dout, int64_t ld_dout, const f
     const bool fused_dx = dx_rows != nullptr && dim == 128;
     int n_slabs = 0;
     if (narrow) {
-        n_slabs = launch_dense_weight_narrow(dout, ld_dout, xin, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, dx_rows != nullptr ? &dxo : nullptr, ld_dx, 0, s);
+        n_slabs = launch_dense_weight_narrow(dout, ld_dout, xin, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, dx_rows != nullptr ? &dxo : nullptr, ld_dx, 0, static_cast<float*>(workspace), s);
     } else {
         if (dx_rows != nullptr && !fused_dx) {
             if (int rc = launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, nullptr, ld_dx, static_cast<float*>(workspace), s, nullptr, &dxo)) return rc;

@@ -33,7 +33,7 @@ struct NarrowTiles {
 };
 struct NarrowRanges {
     int64_t begin[4];
-    int range_prefix[4];   // row ranges (one per wave) before type t
+    int range_prefix[4];   // row ranges (one per workgroup) before type t
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -149,15 +149,16 @@ __global__ __launch_bounds__(kBlockThreads, 2) void node_interact_weight_narrow_
                                                                                         const float* __restrict__ dy, int64_t ld_dy, const float* __restrict__ dy_scale,
                                                                                         NarrowRanges plan, float* __restrict__ slabs) {
     typedef float v2f __attribute__((ext_vector_type(2)));
-    const int range = static_cast<int>(global_wave_id());
-    if (range >= plan.range_prefix[3]) return;
-    const int lane = threadIdx.x & 63, ci = lane & 15, rq = lane >> 4;
+    __shared__ float red[3][NBLK * 16][kWave];                           // the partial gradients of waves 1 - 3, register by register (48 KB at order 3)
+    const int range = blockIdx.x;                                        // a row range = a workgroup = one slab; its four waves take a quarter of the rows each
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ci = lane & 15, rq = lane >> 4;
     const int type = range >= plan.range_prefix[2] ? 2 : (range >= plan.range_prefix[1] ? 1 : 0);
     const int n_r = plan.range_prefix[type + 1] - plan.range_prefix[type];
     const int64_t rows_t = plan.begin[type + 1] - plan.begin[type];
-    const int64_t per = ((rows_t + n_r - 1) / n_r + 15) / 16 * 16;
-    const int64_t r0 = plan.begin[type] + static_cast<int64_t>(range - plan.range_prefix[type]) * per;
-    const int64_t r1 = std::min(r0 + per, plan.begin[type + 1]);
+    const int64_t per = ((rows_t + n_r - 1) / n_r + 63) / 64 * 64;
+    const int64_t b0 = plan.begin[type] + static_cast<int64_t>(range - plan.range_prefix[type]) * per;
+    const int64_t r0 = std::min(b0 + wave * (per / 4), plan.begin[type + 1]);
+    const int64_t r1 = std::min(b0 + (wave + 1) * (per / 4), plan.begin[type + 1]);
     v4f acc[2][NBLK * 2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -203,6 +204,16 @@ __global__ __launch_bounds__(kBlockThreads, 2) void node_interact_weight_narrow_
         }
         if (row < r1) contract(fa);
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < NBLK * 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave - 1][(mt * NBLK * 2 + t) * 4 + r][lane] = acc[mt][t][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
     float* slab = slabs + static_cast<int64_t>(range) * ND * NBLK * ND;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -211,7 +222,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void node_interact_weight_narrow_
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) slab[(2 * (4 * rq + r) + mt) * (NBLK * ND) + xb * ND + 2 * ci + nt] = acc[mt][2 * xb + nt][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = (mt * NBLK * 2 + 2 * xb + nt) * 4 + r;
+                    slab[(2 * (4 * rq + r) + mt) * (NBLK * ND) + xb * ND + 2 * ci + nt] = ((acc[mt][2 * xb + nt][r] + red[0][slot][lane]) + red[1][slot][lane]) + red[2][slot][lane];
+                }
 }
 
 __global__ __launch_bounds__(kBlockThreads) void narrow_weight_reduce_kernel(const float* __restrict__ slabs, NarrowRanges plan, int nblk, float* __restrict__ dw, int64_t ld_dw) {
@@ -300,21 +314,26 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
         m.q = i3[3 * ec + 1];
         m.i = i3[3 * ec + 2];
     };
+    // row r of a table whose rows are ld floats apart (ld < 2^31, checked by narrow_members_ok): ONE v_mad_u64_u32 where the 64 x 64-bit product costs four instructions
+    const uint32_t ldh = static_cast<uint32_t>(ld_h), ldd = static_cast<uint32_t>(ld_d);
+    const float* const hq4 = h + 4 * q;
+    const float* const dq4 = dsrc + 4 * q;
+    auto row_of = [](const float* base, int id, uint32_t ld) { return base + static_cast<uint64_t>(static_cast<uint32_t>(id)) * static_cast<uint64_t>(ld); };
     auto load_rows = [&](int k, const MemberIds& m, MemberRows<GATHER>& r) {
         r.e = edge_of(k);
         r.user = (r.e < n_edges && k < n_my) ? m.u : -2;
         const int64_t ec = std::min(r.e, n_edges - 1);
+        const float *pu = row_of(hq4, m.u, ldh), *pq = row_of(hq4, m.q, ldh), *pi = row_of(hq4, m.i, ldh);
+        const float *du = GATHER ? row_of(dq4, m.u, ldd) : dq4 + ec * ld_d, *dq = row_of(dq4, m.q, ldd), *di = row_of(dq4, m.i, ldd);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            r.hu[hf] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(m.u) * ld_h + 16 * hf + 4 * q);
-            r.hq[hf] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(m.q) * ld_h + 16 * hf + 4 * q);
-            r.hi[hf] = *reinterpret_cast<const v4f*>(h + static_cast<int64_t>(m.i) * ld_h + 16 * hf + 4 * q);
+            r.hu[hf] = *reinterpret_cast<const v4f*>(pu + 16 * hf);
+            r.hq[hf] = *reinterpret_cast<const v4f*>(pq + 16 * hf);
+            r.hi[hf] = *reinterpret_cast<const v4f*>(pi + 16 * hf);
+            r.du[hf] = *reinterpret_cast<const v4f*>(du + 16 * hf);
             if (GATHER) {
-                r.du[hf] = *reinterpret_cast<const v4f*>(dsrc + static_cast<int64_t>(m.u) * ld_d + 16 * hf + 4 * q);
-                r.dq[GATHER ? hf : 0] = *reinterpret_cast<const v4f*>(dsrc + static_cast<int64_t>(m.q) * ld_d + 16 * hf + 4 * q);
-                r.di[GATHER ? hf : 0] = *reinterpret_cast<const v4f*>(dsrc + static_cast<int64_t>(m.i) * ld_d + 16 * hf + 4 * q);
-            } else {
-                r.du[hf] = *reinterpret_cast<const v4f*>(dsrc + ec * ld_d + 16 * hf + 4 * q);
+                r.dq[GATHER ? hf : 0] = *reinterpret_cast<const v4f*>(dq + 16 * hf);
+                r.di[GATHER ? hf : 0] = *reinterpret_cast<const v4f*>(di + 16 * hf);
             }
         }
         if (GATHER) {
@@ -351,13 +370,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
             store_stream4(dout_store + use.e * ld_store + 4 * q, v4f{dout[0], dout[1], dout[2], dout[3]});
             store_stream4(dout_store + use.e * ld_store + 16 + 4 * q, v4f{dout[4], dout[5], dout[6], dout[7]});
         }
-        v4f acc[NBLK * 2];
-#pragma unroll
-        for (int nt = 0; nt < NBLK * 2; ++nt) acc[nt] = v4f{0.f, 0.f, 0.f, 0.f};
+        v4f acc[NBLK * 2];                                                   // (the first product takes the constant 0 as its addend: no 32 zero moves per tile)
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int nt = 0; nt < NBLK * 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][s], dout[s], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NBLK * 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[nt][s], dout[s], s == 0 ? v4f{0.f, 0.f, 0.f, 0.f} : acc[nt], 0, 0, 0);
         // product rule at the lane's columns
         float gu[8], gq[8], gi[8];
 #pragma unroll
@@ -399,17 +416,16 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
         hp = std::max(hp, dpp_row_i<0x112>(hp));
         hp = std::max(hp, dpp_row_i<0x114>(hp));
         hp = std::max(hp, dpp_row_i<0x118>(hp));
+        // (a lane adds what lies inside its run: the shifted value times 1 or 0 - one fused multiply-add with a DPP operand per value and offset where a select and an
+        // add took three instructions; the values are finite, so 0 x anything is 0)
+        const float m1 = el - 1 >= hp ? 1.f : 0.f, m2 = el - 2 >= hp ? 1.f : 0.f, m4 = el - 4 >= hp ? 1.f : 0.f, m8 = el - 8 >= hp ? 1.f : 0.f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float v = gu[s];
-            float t = dpp_row_f<0x111>(v);
-            v += el - 1 >= hp ? t : 0.f;
-            t = dpp_row_f<0x112>(v);
-            v += el - 2 >= hp ? t : 0.f;
-            t = dpp_row_f<0x114>(v);
-            v += el - 4 >= hp ? t : 0.f;
-            t = dpp_row_f<0x118>(v);
-            v += el - 8 >= hp ? t : 0.f;
+            v = __builtin_fmaf(dpp_row_f<0x111>(v), m1, v);
+            v = __builtin_fmaf(dpp_row_f<0x112>(v), m2, v);
+            v = __builtin_fmaf(dpp_row_f<0x114>(v), m4, v);
+            v = __builtin_fmaf(dpp_row_f<0x118>(v), m8, v);
             gu[s] = v;
         }
         const bool tail = el < 15 && user >= 0 && next_user != user;         // the run ends inside this tile
@@ -454,7 +470,18 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
 // 1 K multiply-adds.  Forward: out[v] = in[v] Wt_type(v) (+ bias of the type) (+ out[v]), Wt[k][c] = W_t[c][k] (transpose == 0) or W_t[k][c]; the W^T fragments of ALL three
 // node types sit in 48 registers.  Rows by typed base pointers (TypedRows: the embedding tables read in place).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRows in, int64_t ld_in, const float* __restrict__ w, int64_t ld_w, int64_t w_type_stride, int transpose,
+// pk[t][s][ct][lane] = Wt_t[ncol(lane >> 4, s)][16 ct + (lane & 15)]: the A fragments of every node type's W^T
+__global__ __launch_bounds__(kBlockThreads) void pack_linear_narrow_kernel(const float* __restrict__ w, int64_t ld_w, int64_t w_type_stride, int n_types, int transpose,
+                                                                           float* __restrict__ pk) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_types * 8 * 2 * kWave) return;
+    const int lane = idx & 63, ct = (idx >> 6) & 1, s = (idx >> 7) & 7, t = idx >> 10;
+    const float* wt = w + t * w_type_stride;
+    const int c = 16 * ct + (lane & 15), k = ncol(lane >> 4, s);
+    pk[idx] = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k] : wt[static_cast<int64_t>(k) * ld_w + c];
+}
+
+__global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRows in, int64_t ld_in, const float* __restrict__ pk, int single_weight,
                                                                         const float* __restrict__ bias, int bias_mask, int64_t bias_type_stride, NarrowTiles plan, TypedRowsOut out,
                                                                         int64_t ld_out, int accumulate) {
     const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
@@ -464,16 +491,8 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRow
     const int t0 = static_cast<int>(global_wave_id()) * per;
     const int n_my = std::max(0, std::min(per, total - t0));
     if (n_my == 0) return;
-    float wreg[3][8][2];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const float* wt = w + (w_type_stride == 0 ? 0 : t) * w_type_stride;
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-                wreg[t][s][ct] = transpose == 0 ? wt[static_cast<int64_t>(16 * ct + i) * ld_w + ncol(q, s)] : wt[static_cast<int64_t>(ncol(q, s)) * ld_w + 16 * ct + i];
-    }
+    float wreg[8][2];
+    int cur_wtype = -1;
     struct Rows { v4f x[2], old[2]; int64_t v; int type; bool live; };
     auto load = [&](int k, Rows& r) {
         const int tile = std::min(t0 + k, total - 1);
@@ -492,13 +511,19 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRow
     };
     auto step = [&](int k, const Rows& use, Rows& fill) {
         load(k + 1, fill);
+        const int wtype = single_weight ? 0 : __builtin_amdgcn_readfirstlane(use.type);
+        if (wtype != cur_wtype) {                                          // wave-uniform: a tile belongs to one node type
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) wreg[s][ct] = pk[((wtype * 8 + s) * 2 + ct) * kWave + lane];
+            cur_wtype = wtype;
+        }
         v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const float a0 = use.type == 0 ? wreg[0][s][0] : (use.type == 1 ? wreg[1][s][0] : wreg[2][s][0]);
-            const float a1 = use.type == 0 ? wreg[0][s][1] : (use.type == 1 ? wreg[1][s][1] : wreg[2][s][1]);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, use.x[s >> 2][s & 3], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, use.x[s >> 2][s & 3], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][0], use.x[s >> 2][s & 3], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][1], use.x[s >> 2][s & 3], acc[1], 0, 0, 0);
         }
         if (bias != nullptr && ((bias_mask >> use.type) & 1)) {
             acc[0] += *reinterpret_cast<const v4f*>(bias + use.type * bias_type_stride + 4 * q);
@@ -533,8 +558,7 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRow
 template <bool DX>
 __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_narrow_kernel(const float* __restrict__ dout, int64_t ld_dout, TypedRows x, int64_t ld_x, NarrowTiles plan,
                                                                                  int single_weight, float* __restrict__ slabs, float* __restrict__ bias_slabs,
-                                                                                 const float* __restrict__ w, int64_t ld_w, int64_t w_type_stride, TypedRowsOut dx,
-                                                                                 int64_t ld_dx, int dx_accumulate) {
+                                                                                 const float* __restrict__ pk, TypedRowsOut dx, int64_t ld_dx, int dx_accumulate) {
     typedef float v2f __attribute__((ext_vector_type(2)));
     __shared__ float red[3][18][kWave];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
@@ -545,12 +569,11 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_narrow_kernel
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
     auto type_of = [&](int64_t v) { return v >= plan.begin[2] ? 2 : (v >= plan.begin[1] ? 1 : 0); };
     float wreg[DX ? 8 : 1][2];
-    if (DX) {
-        const float* wt = w + wtype * w_type_stride;
+    if (DX) {                                                            // dx = dout W_t: the fragments of pack_linear_narrow_kernel with transpose = 1
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) wreg[DX ? s : 0][ct] = wt[static_cast<int64_t>(ncol(q, s)) * ld_w + 16 * ct + i];
+            for (int ct = 0; ct < 2; ++ct) wreg[DX ? s : 0][ct] = pk[((wtype * 8 + s) * 2 + ct) * kWave + lane];
     }
     struct Rows { v4f d[2], old[2]; v2f dv[4], xv[4]; int64_t v; int type; bool live; };
     auto load = [&](int64_t tile, Rows& r) {
@@ -706,7 +729,7 @@ void launch_node_weight_narrow(int order, const float* h, int64_t ld_h, const fl
         rows[t] = type_begin[t + 1] - type_begin[t];
         total += rows[t];
     }
-    // row ranges by type in proportion to the rows (at least 64 rows a range, every non-empty type at least one range, kNarrowWeightRanges in all at most)
+    // row ranges (= workgroups = slabs) by type in proportion to the rows (at least 64 rows a range, every non-empty type at least one, kNarrowWeightRanges in all at most)
     int acc = 0;
     for (int t = 0; t < 3; ++t) {
         int64_t n = rows[t] == 0 ? 0 : std::max<int64_t>(1, rows[t] * (kNarrowWeightRanges - 2) / std::max<int64_t>(total, 1));
@@ -717,8 +740,8 @@ void launch_node_weight_narrow(int order, const float* h, int64_t ld_h, const fl
     plan.range_prefix[3] = acc;
     const int nblk = order == 3 ? 4 : 3;
     if (acc > 0) {
-        if (order == 3) hipLaunchKernelGGL(node_interact_weight_narrow_kernel<4>, dim3(grid_for_waves(acc)), dim3(kBlockThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);
-        else hipLaunchKernelGGL(node_interact_weight_narrow_kernel<3>, dim3(grid_for_waves(acc)), dim3(kBlockThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);
+        if (order == 3) hipLaunchKernelGGL(node_interact_weight_narrow_kernel<4>, dim3(acc), dim3(kBlockThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);
+        else hipLaunchKernelGGL(node_interact_weight_narrow_kernel<3>, dim3(acc), dim3(kBlockThreads), 0, s, h, ld_h, sums, ld_s, dy, ld_dy, dy_scale, plan, slabs);
     }
     const int total_w = ND * nblk * ND;
     hipLaunchKernelGGL(narrow_weight_reduce_kernel, dim3((total_w + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, plan, nblk, dw, ld_dw);
@@ -727,7 +750,7 @@ void launch_node_weight_narrow(int order, const float* h, int64_t ld_h, const fl
 int64_t narrow_members_floats(int order) { return static_cast<int64_t>(order == 3 ? 4 : 3) * 2 * 8 * kWave; }
 
 bool narrow_members_ok(int dim, int order, const float* g2, int64_t ld_h, int64_t ld_d, const float* dsrc) {
-    return dim == ND && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_d % 4 == 0 && aligned16(g2) && aligned16(dsrc);
+    return dim == ND && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_d % 4 == 0 && ld_h < (int64_t{1} << 31) && ld_d < (int64_t{1} << 31) && aligned16(g2) && aligned16(dsrc);
 }
 
 void launch_members_narrow(int order, int gather, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, float* packed, const float* dsrc, int64_t ld_d,
@@ -755,24 +778,33 @@ void launch_members_narrow(int order, int gather, const float* h, int64_t ld_h, 
 
 bool narrow_linear_ok(int dim, int64_t ld_a, int64_t ld_b) { return dim == ND && ld_a % 4 == 0 && ld_b % 4 == 0; }
 
+static void pack_linear_narrow(const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, float* pk, hipStream_t s) {
+    const int n_types = w_type_stride == 0 ? 1 : 3;
+    const int items = n_types * 8 * 2 * kWave;
+    hipLaunchKernelGGL(pack_linear_narrow_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types, transpose, pk);
+}
+
 void launch_row_gemm_narrow(TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias, int bias_mask,
-                            int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, int accumulate, hipStream_t s) {
+                            int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, int accumulate, float* pk, hipStream_t s) {
     const NarrowTiles plan = narrow_tiles(type_begin);
     if (plan.tile_prefix[3] == 0) return;
+    pack_linear_narrow(w, ld_w, w_type_stride, transpose, pk, s);
     const int grid = grid_for_waves(std::min(plan.tile_prefix[3], 4096));
-    hipLaunchKernelGGL(row_gemm_narrow_kernel, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, plan, out, ld_out,
+    hipLaunchKernelGGL(row_gemm_narrow_kernel, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, w_type_stride == 0 ? 1 : 0, bias, bias_mask, bias_type_stride, plan, out, ld_out,
                        accumulate);
 }
 
 int launch_dense_weight_narrow(const float* dout, int64_t ld_dout, TypedRows x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs, float* bias_slabs,
-                               const float* w, int64_t ld_w, int64_t w_type_stride, const TypedRowsOut* dx, int64_t ld_dx, int dx_accumulate, hipStream_t s) {
+                               const float* w, int64_t ld_w, int64_t w_type_stride, const TypedRowsOut* dx, int64_t ld_dx, int dx_accumulate, float* pk, hipStream_t s) {
     const NarrowTiles plan = narrow_tiles(type_begin);
     const int n_slabs = 256;                                             // = dense.hip's kDenseSlabs: the workspace holds that many per type
-    if (dx != nullptr)
+    if (dx != nullptr) {
+        pack_linear_narrow(w, ld_w, w_type_stride, 1, pk, s);
         hipLaunchKernelGGL(dense_weight_grad_narrow_kernel<true>, dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0, slabs,
-                           bias_slabs, w, ld_w, w_type_stride, *dx, ld_dx, dx_accumulate);
-    else
+                           bias_slabs, pk, *dx, ld_dx, dx_accumulate);
+    } else {
         hipLaunchKernelGGL(dense_weight_grad_narrow_kernel<false>, dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0, slabs,
-                           bias_slabs, static_cast<const float*>(nullptr), int64_t{0}, int64_t{0}, typed_rows_out(nullptr), int64_t{0}, 0);
+                           bias_slabs, static_cast<const float*>(nullptr), typed_rows_out(nullptr), int64_t{0}, 0);
+    }
     return n_slabs;
 }
