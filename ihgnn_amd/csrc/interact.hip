@@ -1981,7 +1981,6 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
         int entries = 0;
         launch_members_narrow(NBLK == 4 ? 3 : 2, gather ? 1 : 0, h, ld_h, i3, w_raw, ld_w, static_cast<float*>(planes), dout, ld_dout, dy_scale, ld_store > 0 ? dout_store : nullptr,
                               ld_store, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, &entries, s);
-        hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(entries), dim3(128), 0, s, bnd_val, bnd_user, entries, dim, dh_user, ld_dh);
         if (gather && ld_store > 0) {
             dout = dout_store;
             ld_dout = ld_store;

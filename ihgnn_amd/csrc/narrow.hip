@@ -16,6 +16,7 @@ namespace {
 
 constexpr int ND = kNarrowDim;
 constexpr int NT = 16;      // rows per tile
+constexpr int kNarrowDumpFloats = 64 * 4 + 64;      // a wave's dump region: 16 bytes per lane, and the + 16 / 32 / 48-float offsets of a row's further pieces stay inside it
 
 // column of a 32-wide row that lane group q holds in register s < 8 (= contraction index of step s for lane group q)
 __host__ __device__ constexpr int ncol(int q, int s) { return 16 * (s >> 2) + 4 * q + (s & 3); }
@@ -30,6 +31,7 @@ __device__ __forceinline__ int narrow_xblock_weight(int type, int xb) {
 struct NarrowTiles {
     int64_t begin[4];      // first row of every node type
     int tile_prefix[4];    // 16-row tiles before type t
+    int wave_prefix[4];    // waves before type t, where a launch gives every wave ONE type (narrow_tiles(type_begin, waves))
 };
 struct NarrowRanges {
     int64_t begin[4];
@@ -53,7 +55,6 @@ struct FwdRows {
     v4f h[2], a[2], b[2], ab[2];      // the lane's two pieces of h[v] and of the three pair sums of v
     float d, sc;
     int64_t v;
-    bool live;
 };
 
 template <int ORDER>
@@ -63,26 +64,27 @@ __global__ __launch_bounds__(kBlockThreads, 2) void node_interact_fwd_narrow_ker
                                                                                      float* __restrict__ out, int64_t ld_out) {
     constexpr int XB = ORDER == 3 ? 7 : 6;
     const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
-    const int total = plan.tile_prefix[3];
-    const int64_t waves = global_wave_count();
-    const int per = static_cast<int>((total + waves - 1) / waves);
-    const int t0 = static_cast<int>(global_wave_id()) * per;
-    const int n_my = std::max(0, std::min(per, total - t0));
+    // a wave works inside ONE node type (plan.wave_prefix: waves in proportion to the types' tiles): its weights are loaded once, in front of the loop - a reload under a
+    // branch inside the loop would turn the loop's waits into vmcnt(0)
+    const int wid = static_cast<int>(global_wave_id());
+    if (wid >= plan.wave_prefix[3]) return;
+    const int type = wid >= plan.wave_prefix[2] ? 2 : (wid >= plan.wave_prefix[1] ? 1 : 0);
+    const int n_w = plan.wave_prefix[type + 1] - plan.wave_prefix[type];
+    const int tiles_t = plan.tile_prefix[type + 1] - plan.tile_prefix[type];
+    const int per = (tiles_t + n_w - 1) / n_w;
+    const int t0 = (wid - plan.wave_prefix[type]) * per;                  // first tile, counted inside the type
+    const int n_my = std::max(0, std::min(per, tiles_t - t0));
     if (n_my == 0) return;
-    auto tile_type = [&](int k) {
-        const int tile = std::min(t0 + k, total - 1);
-        return tile >= plan.tile_prefix[2] ? 2 : (tile >= plan.tile_prefix[1] ? 1 : 0);
-    };
+    const float* const scale_src = scale != nullptr ? scale : deg;
     auto load = [&](int k, FwdRows& r) {
-        const int tile = std::min(t0 + k, total - 1);
-        const int type = tile_type(k);
-        const int64_t row = plan.begin[type] + static_cast<int64_t>(tile - plan.tile_prefix[type]) * NT + i;
-        r.live = row < plan.begin[type + 1];
-        r.v = std::min(row, plan.begin[type + 1] - 1);
+        const int tile = std::min(t0 + k, tiles_t - 1);
+        const int64_t row = plan.begin[type] + static_cast<int64_t>(tile) * NT + i;
+        r.v = std::min(row, plan.begin[type + 1] - 1);                   // (a lane past the type's last row: that row again, the same values stored to the same place)
         const float* hp = h + r.v * ld_h + 4 * q;
         const float* sp = sums + r.v * ld_s + 4 * q;
         r.d = deg[r.v];
-        r.sc = scale != nullptr ? scale[r.v] : 1.f;
+        r.sc = scale_src[r.v];                                             // (no scale: the degree is read again and replaced by 1 at use - a request under a branch is what costs,
+                                                                           //  and a select on the loaded value HERE would wait for it in front of the row requests)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             r.h[hf] = *reinterpret_cast<const v4f*>(hp + 16 * hf);
@@ -95,20 +97,18 @@ __global__ __launch_bounds__(kBlockThreads, 2) void node_interact_fwd_narrow_ker
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) bias_c[ct] = bias != nullptr ? *reinterpret_cast<const v4f*>(bias + 16 * ct + 4 * q) : v4f{0.f, 0.f, 0.f, 0.f};
     float wreg[XB][8][2];
-    int cur_type = -1;
+    {
+        const float* wp = packed + static_cast<int64_t>(type) * XB * 8 * 2 * kWave + lane;
+#pragma unroll
+        for (int xb = 0; xb < XB; ++xb)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) wreg[xb][s][ct] = wp[((xb * 8 + s) * 2 + ct) * kWave];
+    }
     auto step = [&](int k, const FwdRows& use, FwdRows& fill) {
         load(k + 1, fill);
-        const int type = tile_type(k);
-        if (type != cur_type) {                                            // wave-uniform: at most two changes in a wave's range
-            const float* wp = packed + static_cast<int64_t>(type) * XB * 8 * 2 * kWave + lane;
-#pragma unroll
-            for (int xb = 0; xb < XB; ++xb)
-#pragma unroll
-                for (int s = 0; s < 8; ++s)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) wreg[xb][s][ct] = wp[((xb * 8 + s) * 2 + ct) * kWave];
-            cur_type = type;
-        }
+        __builtin_amdgcn_sched_barrier(0);
         v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int xb = 0; xb < XB; ++xb) {
@@ -121,10 +121,9 @@ __global__ __launch_bounds__(kBlockThreads, 2) void node_interact_fwd_narrow_ker
                 for (int ct = 0; ct < 2; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[xb][s][ct], z, acc[ct], 0, 0, 0);
             }
         }
-        if (use.live) {
+        const float sc = scale != nullptr ? use.sc : 1.f;
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) *reinterpret_cast<v4f*>(out + use.v * ld_out + 16 * ct + 4 * q) = (acc[ct] + bias_c[ct] * use.d) * use.sc;
-        }
+        for (int ct = 0; ct < 2; ++ct) *reinterpret_cast<v4f*>(out + use.v * ld_out + 16 * ct + 4 * q) = (acc[ct] + bias_c[ct] * use.d) * sc;
     };
     FwdRows ra, rb;
     load(0, ra);
@@ -272,6 +271,12 @@ __device__ __forceinline__ int dpp_row_i(int x) {
     return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
 }
 
+// stores through pointers that are KNOWN to be global (a pointer rebuilt from an integer would be a flat one)
+typedef __attribute__((address_space(1))) float GlobalFloat;
+typedef __attribute__((address_space(1))) v4f GlobalV4;
+__device__ __forceinline__ void gstore4(GlobalFloat* p, v4f v) { *reinterpret_cast<GlobalV4*>(p) = v; }
+__device__ __forceinline__ void gstore_stream4(GlobalFloat* p, v4f v) { __builtin_nontemporal_store(v, reinterpret_cast<GlobalV4*>(p)); }
+
 struct MemberIds {
     int u, q, i;
 };
@@ -284,12 +289,18 @@ struct MemberRows {
     int64_t e;
 };
 
-template <int NBLK, bool GATHER>
+// EVERY vector-memory instruction of the loop is issued unconditionally.  The memory counter (vmcnt) is in order and the compiler waits by COUNT: "all but the N youngest
+// requests have returned".  A request inside a branch makes that count unknown, and the wait in front of the next use of ANY loaded value becomes vmcnt(0) - the first form
+// of this kernel (stores under `if (live)` / `if (tail)`, the scale loads under `dy_scale != nullptr`) drained the queue twice per tile, the tile's own stores included:
+// 249 us whatever was taken out of its instruction stream (- 34 % instructions: 249 us; no gathers AND no MFMAs: 150 us).  Here a lane that has nothing to store stores
+// to a dump row of its own (`dump`: 8 floats per lane and wave, never read: it stays in L2), absent scales are read from a vector of ones' stand-in and replaced by a
+// select, and the weights are loaded before the loop: every wait is an exact count and leaves the younger requests - the next tile's rows, this tile's stores - in flight.
+template <int NBLK, bool GATHER, bool STORE_DOUT>
 __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
                                                                            const float* __restrict__ packed, const float* __restrict__ dsrc, int64_t ld_d,
                                                                            const float* __restrict__ dy_scale, float* __restrict__ dout_store, int64_t ld_store,
                                                                            float* __restrict__ g2, int64_t n_edges, float* __restrict__ dh_user, int64_t ld_dh,
-                                                                           float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user, int n_ranges) {
+                                                                           float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user, int n_ranges, float* __restrict__ dump_base) {
     const int range = static_cast<int>(global_wave_id());
     if (range >= n_ranges) return;
     const int lane = threadIdx.x & 63, q = lane >> 4, el = lane & 15;
@@ -306,7 +317,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
     for (int nt = 0; nt < NBLK * 2; ++nt)
 #pragma unroll
         for (int s = 0; s < 8; ++s) wreg[nt][s] = packed[(nt * 8 + s) * kWave + lane];
+    float* const dump = dump_base + static_cast<int64_t>(range) * kNarrowDumpFloats + lane * 4;  // this lane's 16 bytes of nowhere (+ 16 / 32 / 48 floats: the pieces a row store adds; 12 floats below: the dout pieces)
+    const bool scaled = GATHER && dy_scale != nullptr;
+    const float* const scale_src = scaled ? dy_scale : reinterpret_cast<const float*>(i3);   // (unscaled: any readable word; the value is replaced by 1)
 
+    // row r of a table whose rows are ld floats apart (ld < 2^31, checked by narrow_members_ok): ONE v_mad_u64_u32 where the 64 x 64-bit product costs four instructions
+    const uint32_t ldh = static_cast<uint32_t>(ld_h), ldd = static_cast<uint32_t>(ld_d);
+    const float* const hq4 = h + 4 * q;
+    const float* const dq4 = dsrc + 4 * q;
+    auto row_of = [](const float* base, int id, uint32_t ld) { return base + static_cast<uint64_t>(static_cast<uint32_t>(id)) * static_cast<uint64_t>(ld); };
     auto edge_of = [&](int k) { return (t0 + std::min(k, n_my - 1)) * NT + el; };
     auto load_ids = [&](int k, MemberIds& m) {
         const int64_t ec = std::min(edge_of(k), n_edges - 1);
@@ -314,11 +333,6 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
         m.q = i3[3 * ec + 1];
         m.i = i3[3 * ec + 2];
     };
-    // row r of a table whose rows are ld floats apart (ld < 2^31, checked by narrow_members_ok): ONE v_mad_u64_u32 where the 64 x 64-bit product costs four instructions
-    const uint32_t ldh = static_cast<uint32_t>(ld_h), ldd = static_cast<uint32_t>(ld_d);
-    const float* const hq4 = h + 4 * q;
-    const float* const dq4 = dsrc + 4 * q;
-    auto row_of = [](const float* base, int id, uint32_t ld) { return base + static_cast<uint64_t>(static_cast<uint32_t>(id)) * static_cast<uint64_t>(ld); };
     auto load_rows = [&](int k, const MemberIds& m, MemberRows<GATHER>& r) {
         r.e = edge_of(k);
         r.user = (r.e < n_edges && k < n_my) ? m.u : -2;
@@ -337,38 +351,44 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
             }
         }
         if (GATHER) {
-            r.su = dy_scale != nullptr ? dy_scale[m.u] : 1.f;
-            r.sq = dy_scale != nullptr ? dy_scale[m.q] : 1.f;
-            r.si = dy_scale != nullptr ? dy_scale[m.i] : 1.f;
+            r.su = scale_src[scaled ? m.u : 0];                              // (replaced by 1 at use when there are no scales)
+            r.sq = scale_src[scaled ? m.q : 0];
+            r.si = scale_src[scaled ? m.i : 0];
         }
     };
 
-    // the run that is open when a tile begins: its user (wave-uniform) and its sum so far (in the lanes el == 15); `first_run`: it is still the range's first run
-    int carry_user = -1;
+    // the run that is open when a tile begins: whether it continues the previous tile's last run (wave-uniform) and that run's sum so far (in the lanes el == 15);
+    // `first_run`: the run that is open at the tile's start is still the range's first run
+    bool continuing = false, first_run = true, last_to_slot1 = false;
     float carry[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) carry[s] = 0.f;
-    bool first_run = true;
     float* const slot0 = bnd_val + static_cast<int64_t>(2 * range) * ND;
-    auto put8 = [&](float* dst, const float (&v)[8]) {
-        *reinterpret_cast<v4f*>(dst + 4 * q) = v4f{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<v4f*>(dst + 16 + 4 * q) = v4f{v[4], v[5], v[6], v[7]};
-    };
 
+    // (an address chosen between a real row and the dump row, made opaque: left visible, the choice is compiled into two stores under complementary branches -
+    // and kept in the GLOBAL address space: a pointer of unknown origin becomes a flat one, and flat stores drain the memory counter like a branch does)
+    auto pick = [](bool real, float* a, float* b) {
+        uint64_t p = real ? reinterpret_cast<uint64_t>(a) : reinterpret_cast<uint64_t>(b);
+        asm("" : "+v"(p));
+        return reinterpret_cast<GlobalFloat*>(p);
+    };
     auto step = [&](int k, const MemberRows<GATHER>& use, MemberRows<GATHER>& fill, const MemberIds& ids_next, MemberIds& ids_fill) {
-        load_rows(k + 1, ids_next, fill);
         load_ids(k + 2, ids_fill);
+        load_rows(k + 1, ids_next, fill);
+        __builtin_amdgcn_sched_barrier(0);                                   // the requests stay in front of the tile's work (the scheduler sinks them into the MFMA phase otherwise)
         const bool live = use.user >= 0;
         // the hyperedge's cotangent at this lane's eight columns
         float dout[8];
+        const float su = scaled ? use.su : 1.f, sq = scaled ? use.sq : 1.f, si = scaled ? use.si : 1.f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            if (GATHER) dout[s] = ((0.f + use.su * use.du[s >> 2][s & 3]) + use.sq * use.dq[GATHER ? s >> 2 : 0][s & 3]) + use.si * use.di[GATHER ? s >> 2 : 0][s & 3];
+            if (GATHER) dout[s] = ((0.f + su * use.du[s >> 2][s & 3]) + sq * use.dq[GATHER ? s >> 2 : 0][s & 3]) + si * use.di[GATHER ? s >> 2 : 0][s & 3];
             else dout[s] = use.du[s >> 2][s & 3];
         }
-        if (GATHER && dout_store != nullptr && live) {
-            store_stream4(dout_store + use.e * ld_store + 4 * q, v4f{dout[0], dout[1], dout[2], dout[3]});
-            store_stream4(dout_store + use.e * ld_store + 16 + 4 * q, v4f{dout[4], dout[5], dout[6], dout[7]});
+        if (STORE_DOUT) {
+            GlobalFloat* dp = pick(live, dout_store + use.e * ld_store + 4 * q, dump - 12);
+            gstore_stream4(dp, v4f{dout[0], dout[1], dout[2], dout[3]});
+            gstore_stream4(dp + 16, v4f{dout[4], dout[5], dout[6], dout[7]});
         }
         v4f acc[NBLK * 2];                                                   // (the first product takes the constant 0 as its addend: no 32 zero moves per tile)
 #pragma unroll
@@ -387,29 +407,25 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
             gq[s] = z_uq * hu + z_qi * hi + z_uqi * (hu * hi);
             gi[s] = z_qi * hq + z_iu * hu + z_uqi * (hu * hq);
         }
-        if (live) {
-            float* gp = g2 + use.e * (2 * ND);
-            store_stream4(gp + 4 * q, v4f{gq[0], gq[1], gq[2], gq[3]});
-            store_stream4(gp + 16 + 4 * q, v4f{gq[4], gq[5], gq[6], gq[7]});
-            store_stream4(gp + ND + 4 * q, v4f{gi[0], gi[1], gi[2], gi[3]});
-            store_stream4(gp + ND + 16 + 4 * q, v4f{gi[4], gi[5], gi[6], gi[7]});
+        {
+            GlobalFloat* gp = pick(live, g2 + use.e * (2 * ND) + 4 * q, dump);
+            gstore_stream4(gp, v4f{gq[0], gq[1], gq[2], gq[3]});
+            gstore_stream4(gp + 16, v4f{gq[4], gq[5], gq[6], gq[7]});
+            gstore_stream4(gp + ND, v4f{gi[0], gi[1], gi[2], gi[3]});
+            gstore_stream4(gp + ND + 16, v4f{gi[4], gi[5], gi[6], gi[7]});
         }
-        // ---- user slot: the open run continues into this tile, or it has ended with the previous tile
+        // ---- user slot.  The tile's first run continues the previous tile's last one: lane 0 takes the carried sum in
         const int user = use.user;
-        const int first_user = __builtin_amdgcn_readfirstlane(user);
-        const bool continuing = first_user == carry_user;
-        if (!continuing && carry_user >= 0) {
-            if (el == 15) put8(first_run ? slot0 : dh_user + static_cast<int64_t>(carry_user) * ld_dh, carry);
-            if (first_run && lane == 15) bnd_user[2 * range] = carry_user;
-        }
-        if (!continuing) first_run = first_run && carry_user < 0;           // (a range's first tile has no open run: its first run starts here)
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const float from15 = __shfl(carry[s], (lane & 48) | 15);
             if (continuing && el == 0) gu[s] += from15;
         }
         const int prev_user = dpp_row_i<0x111>(user);                        // row_shr:1
-        const int next_user = dpp_row_i<0x101>(user);                        // row_shl:1
+        const int next_in_tile = dpp_row_i<0x101>(user);                     // row_shl:1
+        // the user of the NEXT tile's first hyperedge (its ids came in a step ago) closes or continues lane 15's run; behind the range's last tile: nobody's
+        const int next_first = k + 1 < n_my ? __builtin_amdgcn_readfirstlane(ids_next.u) : -3;
+        const int next_user = el == 15 ? next_first : next_in_tile;
         const bool head = el == 0 || prev_user != user;
         int hp = head ? el : 0;                                              // position of the lane's run start inside the tile: a max-scan
         hp = std::max(hp, dpp_row_i<0x111>(hp));
@@ -428,24 +444,32 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
             v = __builtin_fmaf(dpp_row_f<0x118>(v), m8, v);
             gu[s] = v;
         }
-        const bool tail = el < 15 && user >= 0 && next_user != user;         // the run ends inside this tile
-        if (tail) {
-            const bool to_slot0 = first_run && hp == 0;
-            put8(to_slot0 ? slot0 : dh_user + static_cast<int64_t>(user) * ld_dh, gu);
-            if (to_slot0 && q == 0) bnd_user[2 * range] = user;
-        }
+        // a run ends in this lane: its sum goes to dh[user] - the range's first run (it may continue a run of the previous range) and its last (it may continue in the next)
+        // go to the boundary table instead; every other lane stores to its dump row
+        const bool tail = user >= 0 && next_user != user;
+        const bool to_slot0 = tail && first_run && hp == 0;
+        const bool to_slot1 = tail && !to_slot0 && el == 15 && k + 1 >= n_my;
+        GlobalFloat* dst = pick(tail, to_slot0 ? slot0 + 4 * q : (to_slot1 ? slot0 + ND + 4 * q : dh_user + static_cast<int64_t>(user) * ld_dh + 4 * q), dump);
+        gstore4(dst, v4f{gu[0], gu[1], gu[2], gu[3]});
+        gstore4(dst + 16, v4f{gu[4], gu[5], gu[6], gu[7]});
+        GlobalFloat* udst = pick((to_slot0 || to_slot1) && q == 0, reinterpret_cast<float*>(bnd_user + 2 * range + (to_slot1 ? 1 : 0)), dump);
+        *reinterpret_cast<__attribute__((address_space(1))) int*>(udst) = user;
+        last_to_slot1 = __ballot(to_slot1) != 0;
         const bool any_head = __ballot(head && el > 0) != 0;
-        first_run = first_run && !any_head;
+        const int user15 = __builtin_amdgcn_readlane(user, 15);
+        continuing = user15 >= 0 && next_first == user15;
+        first_run = first_run && !any_head && continuing;
 #pragma unroll
         for (int s = 0; s < 8; ++s) carry[s] = gu[s];
-        carry_user = __builtin_amdgcn_readlane(user, 15);
     };
 
     MemberIds ia, ib;
     MemberRows<GATHER> ra, rb;
     load_ids(0, ia);
     load_ids(1, ib);
+    __builtin_amdgcn_sched_barrier(0);                                     // (the order of the steady state: the ids of the tile after next are OLDER than the next tile's rows)
     load_rows(0, ia, ra);
+    __builtin_amdgcn_sched_barrier(0);
     int k = 0;
 #pragma clang loop unroll(disable)
     for (; k + 1 < n_my; k += 2) {
@@ -453,16 +477,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
         step(k + 1, rb, ra, ia, ib);
     }
     if (k < n_my) step(k, ra, rb, ib, ia);
-    // the run that is open at the end of the range
-    if (carry_user >= 0) {
-        if (el == 15) put8(first_run ? slot0 : slot0 + ND, carry);
-        if (lane == 15) {
-            if (first_run) bnd_user[2 * range] = carry_user;
-            bnd_user[2 * range + 1] = first_run ? -1 : carry_user;
-        }
-    } else if (lane == 15) {
-        bnd_user[2 * range + 1] = -1;
-    }
+    if (!last_to_slot1 && lane == 0) bnd_user[2 * range + 1] = -1;         // the range's last run was its first, or ended inside the range
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -481,9 +496,10 @@ __global__ __launch_bounds__(kBlockThreads) void pack_linear_narrow_kernel(const
     pk[idx] = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k] : wt[static_cast<int64_t>(k) * ld_w + c];
 }
 
+template <bool ACC>
 __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRows in, int64_t ld_in, const float* __restrict__ pk, int single_weight,
                                                                         const float* __restrict__ bias, int bias_mask, int64_t bias_type_stride, NarrowTiles plan, TypedRowsOut out,
-                                                                        int64_t ld_out, int accumulate) {
+                                                                        int64_t ld_out) {
     const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
     const int total = plan.tile_prefix[3];
     const int64_t waves = global_wave_count();
@@ -491,19 +507,30 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRow
     const int t0 = static_cast<int>(global_wave_id()) * per;
     const int n_my = std::max(0, std::min(per, total - t0));
     if (n_my == 0) return;
-    float wreg[8][2];
-    int cur_wtype = -1;
-    struct Rows { v4f x[2], old[2]; int64_t v; int type; bool live; };
+    float wreg[3][8][2];                                                 // every type's fragments, loaded once (48 registers): no request under a branch inside the loop
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) wreg[t][s][ct] = pk[(((single_weight ? 0 : t) * 8 + s) * 2 + ct) * kWave + lane];
+    struct Rows { v4f x[2], old[2], b[2]; float keep; int64_t v; int type; };
+    // (unconditional requests only: without a bias the input row is read again and multiplied by 0; accumulation is a template parameter)
+    const float bias_on = bias != nullptr ? 1.f : 0.f;
     auto load = [&](int k, Rows& r) {
         const int tile = std::min(t0 + k, total - 1);
         r.type = tile >= plan.tile_prefix[2] ? 2 : (tile >= plan.tile_prefix[1] ? 1 : 0);
         const int64_t row = plan.begin[r.type] + static_cast<int64_t>(tile - plan.tile_prefix[r.type]) * NT + i;
-        r.live = row < plan.begin[r.type + 1];
         r.v = std::min(row, plan.begin[r.type + 1] - 1);
         const float* ip = typed_base(in, r.type) + r.v * ld_in + 4 * q;
         r.x[0] = *reinterpret_cast<const v4f*>(ip);
         r.x[1] = *reinterpret_cast<const v4f*>(ip + 16);
-        if (accumulate) {
+        const bool with_bias = bias != nullptr && ((bias_mask >> r.type) & 1);
+        const float* bp = with_bias ? bias + r.type * bias_type_stride + 4 * q : ip;
+        r.keep = with_bias ? bias_on : 0.f;
+        r.b[0] = *reinterpret_cast<const v4f*>(bp);
+        r.b[1] = *reinterpret_cast<const v4f*>(bp + 16);
+        if (ACC) {
             const float* op = typed_base(out, r.type) + r.v * ld_out + 4 * q;
             r.old[0] = *reinterpret_cast<const v4f*>(op);
             r.old[1] = *reinterpret_cast<const v4f*>(op + 16);
@@ -511,33 +538,24 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRow
     };
     auto step = [&](int k, const Rows& use, Rows& fill) {
         load(k + 1, fill);
-        const int wtype = single_weight ? 0 : __builtin_amdgcn_readfirstlane(use.type);
-        if (wtype != cur_wtype) {                                          // wave-uniform: a tile belongs to one node type
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) wreg[s][ct] = pk[((wtype * 8 + s) * 2 + ct) * kWave + lane];
-            cur_wtype = wtype;
-        }
+        __builtin_amdgcn_sched_barrier(0);
         v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][0], use.x[s >> 2][s & 3], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][1], use.x[s >> 2][s & 3], acc[1], 0, 0, 0);
+            const float a0 = use.type == 0 ? wreg[0][s][0] : (use.type == 1 ? wreg[1][s][0] : wreg[2][s][0]);
+            const float a1 = use.type == 0 ? wreg[0][s][1] : (use.type == 1 ? wreg[1][s][1] : wreg[2][s][1]);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, use.x[s >> 2][s & 3], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, use.x[s >> 2][s & 3], acc[1], 0, 0, 0);
         }
-        if (bias != nullptr && ((bias_mask >> use.type) & 1)) {
-            acc[0] += *reinterpret_cast<const v4f*>(bias + use.type * bias_type_stride + 4 * q);
-            acc[1] += *reinterpret_cast<const v4f*>(bias + use.type * bias_type_stride + 16 + 4 * q);
-        }
-        if (accumulate) {
+        acc[0] += use.b[0] * use.keep;
+        acc[1] += use.b[1] * use.keep;
+        if (ACC) {
             acc[0] += use.old[0];
             acc[1] += use.old[1];
         }
-        if (use.live) {
-            float* op = typed_base(out, use.type) + use.v * ld_out + 4 * q;
-            *reinterpret_cast<v4f*>(op) = acc[0];
-            *reinterpret_cast<v4f*>(op + 16) = acc[1];
-        }
+        float* op = typed_base(out, use.type) + use.v * ld_out + 4 * q;       // (a lane past its type's last row: that row again, the same values)
+        *reinterpret_cast<v4f*>(op) = acc[0];
+        *reinterpret_cast<v4f*>(op + 16) = acc[1];
     };
     Rows ra, rb;
     load(0, ra);
@@ -555,10 +573,10 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRow
 // contraction reads its operands as in node_interact_weight_narrow_kernel (lane ci = columns 2 ci, 2 ci + 1; four rows a step), the input gradient as in the forward;
 // the second read of a row hits the CU's cache.  The waves' partial gradients meet in LDS in wave order; slab layout = dense.hip's ([type][slab][d][d], [type][slab][d]),
 // reduced by its dense_slab_reduce_kernel.
-template <bool DX>
+template <bool DX, bool ACC>
 __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_narrow_kernel(const float* __restrict__ dout, int64_t ld_dout, TypedRows x, int64_t ld_x, NarrowTiles plan,
                                                                                  int single_weight, float* __restrict__ slabs, float* __restrict__ bias_slabs,
-                                                                                 const float* __restrict__ pk, TypedRowsOut dx, int64_t ld_dx, int dx_accumulate) {
+                                                                                 const float* __restrict__ pk, TypedRowsOut dx, int64_t ld_dx) {
     typedef float v2f __attribute__((ext_vector_type(2)));
     __shared__ float red[3][18][kWave];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
@@ -586,7 +604,7 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_narrow_kernel
             r.type = type_of(r.v);
             r.d[0] = *reinterpret_cast<const v4f*>(dout + r.v * ld_dout + 4 * q);
             r.d[1] = *reinterpret_cast<const v4f*>(dout + r.v * ld_dout + 16 + 4 * q);
-            if (dx_accumulate) {
+            if (ACC) {
                 const float* op = typed_base(dx, r.type) + r.v * ld_dx + 4 * q;
                 r.old[0] = *reinterpret_cast<const v4f*>(op);
                 r.old[1] = *reinterpret_cast<const v4f*>(op + 16);
@@ -615,15 +633,13 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_narrow_kernel
             for (int s = 0; s < 8; ++s)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) g[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[DX ? s : 0][ct], r.d[s >> 2][s & 3], g[ct], 0, 0, 0);
-            if (dx_accumulate) {
+            if (ACC) {
                 g[0] += r.old[0];
                 g[1] += r.old[1];
             }
-            if (r.live) {
-                float* op = typed_base(dx, r.type) + r.v * ld_dx + 4 * q;
-                *reinterpret_cast<v4f*>(op) = g[0];
-                *reinterpret_cast<v4f*>(op + 16) = g[1];
-            }
+            float* op = typed_base(dx, r.type) + r.v * ld_dx + 4 * q;        // (a lane past the last row: that row again, the same values)
+            *reinterpret_cast<v4f*>(op) = g[0];
+            *reinterpret_cast<v4f*>(op + 16) = g[1];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -682,7 +698,31 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_narrow_kernel
     }
 }
 
-NarrowTiles narrow_tiles(const int64_t* type_begin) {
+// Adds up the boundary runs of members_narrow_kernel in range order and writes dh[user] (interact.hip's user_boundary_fixup_kernel at this width, eight table entries per
+// workgroup - 32 threads an entry - instead of one: 4,096 workgroups of a few instructions each took 17 us).  The entry that opens a user's run walks on while the following
+// entries carry the same user; every other entry's threads leave at once.  Same order of additions as a single walk over the table.
+__global__ __launch_bounds__(kBlockThreads) void narrow_boundary_fixup_kernel(const float* __restrict__ bnd_val, const int32_t* __restrict__ bnd_user, int n_entries,
+                                                                              float* __restrict__ dh_user, int64_t ld_dh) {
+    const int k0 = blockIdx.x * (kBlockThreads / ND) + threadIdx.x / ND, c = threadIdx.x % ND;
+    if (k0 >= n_entries) return;
+    const int user = bnd_user[k0];
+    if (user < 0) return;
+    for (int k = k0 - 1; k >= 0; --k) {
+        const int u = bnd_user[k];
+        if (u == user) return;                    // an earlier entry opens this run
+        if (u >= 0) break;
+    }
+    float acc = bnd_val[static_cast<int64_t>(k0) * ND + c];
+    for (int k = k0 + 1; k < n_entries; ++k) {
+        const int u = bnd_user[k];
+        if (u < 0) continue;
+        if (u != user) break;
+        acc += bnd_val[static_cast<int64_t>(k) * ND + c];
+    }
+    dh_user[static_cast<int64_t>(user) * ld_dh + c] = acc;
+}
+
+NarrowTiles narrow_tiles(const int64_t* type_begin, int waves = 0) {
     NarrowTiles plan;
     int acc = 0;
     for (int t = 0; t < 4; ++t) plan.begin[t] = type_begin[t];
@@ -691,6 +731,14 @@ NarrowTiles narrow_tiles(const int64_t* type_begin) {
         acc += static_cast<int>((type_begin[t + 1] - type_begin[t] + NT - 1) / NT);
     }
     plan.tile_prefix[3] = acc;
+    // `waves` dealt to the types in proportion to their tiles, every non-empty type at least one wave and none more waves than tiles
+    int wacc = 0;
+    for (int t = 0; t < 3; ++t) {
+        const int tiles = plan.tile_prefix[t + 1] - plan.tile_prefix[t];
+        plan.wave_prefix[t] = wacc;
+        if (tiles > 0 && waves > 0) wacc += std::min(tiles, std::max(1, static_cast<int>(static_cast<int64_t>(tiles) * waves / std::max(acc, 1))));
+    }
+    plan.wave_prefix[3] = wacc;
     return plan;
 }
 
@@ -707,9 +755,9 @@ void launch_node_fwd_narrow(int order, const float* h, int64_t ld_h, const float
     const int n_xb = order == 3 ? 7 : 6;
     const int items = 3 * n_xb * 8 * 2 * kWave;
     hipLaunchKernelGGL(pack_node_fwd_narrow_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, n_xb, packed);
-    const NarrowTiles plan = narrow_tiles(type_begin);
+    const NarrowTiles plan = narrow_tiles(type_begin, 2048);
     if (plan.tile_prefix[3] == 0) return;
-    const int grid = grid_for_waves(std::min(plan.tile_prefix[3], 2048));
+    const int grid = grid_for_waves(plan.wave_prefix[3]);
     if (order == 3) hipLaunchKernelGGL(node_interact_fwd_narrow_kernel<3>, dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, packed, plan, out, ld_out);
     else hipLaunchKernelGGL(node_interact_fwd_narrow_kernel<2>, dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, sums, ld_s, deg, scale, bias, packed, plan, out, ld_out);
 }
@@ -747,7 +795,8 @@ void launch_node_weight_narrow(int order, const float* h, int64_t ld_h, const fl
     hipLaunchKernelGGL(narrow_weight_reduce_kernel, dim3((total_w + kWave - 1) / kWave), dim3(kBlockThreads), 0, s, slabs, plan, nblk, dw, ld_dw);
 }
 
-int64_t narrow_members_floats(int order) { return static_cast<int64_t>(order == 3 ? 4 : 3) * 2 * 8 * kWave; }
+static int64_t narrow_members_packed(int order) { return static_cast<int64_t>(order == 3 ? 4 : 3) * 2 * 8 * kWave; }
+int64_t narrow_members_floats(int order) { return narrow_members_packed(order) + 16 + static_cast<int64_t>(kNarrowMemberRanges) * kNarrowDumpFloats; }      // the packed weights + a dump region per range
 
 bool narrow_members_ok(int dim, int order, const float* g2, int64_t ld_h, int64_t ld_d, const float* dsrc) {
     return dim == ND && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_d % 4 == 0 && ld_h < (int64_t{1} << 31) && ld_d < (int64_t{1} << 31) && aligned16(g2) && aligned16(dsrc);
@@ -763,17 +812,23 @@ void launch_members_narrow(int order, int gather, const float* h, int64_t ld_h, 
     const int n_ranges = static_cast<int>(std::min<int64_t>(n_tiles, kNarrowMemberRanges));
     *n_boundary_entries = 2 * n_ranges;
     const int grid = grid_for_waves(n_ranges);
-#define IHG_NARROW_MEMBERS(NBLK, GATHER)                                                                                                                            \
-    hipLaunchKernelGGL((members_narrow_kernel<NBLK, GATHER>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, packed, dsrc, ld_d, dy_scale, dout_store, ld_store, g2, \
-                       n_edges, dh_user, ld_dh, bnd_val, bnd_user, n_ranges)
+    float* dump = packed + narrow_members_packed(order) + 16;
+#define IHG_NARROW_MEMBERS(NBLK, GATHER, STORE)                                                                                                                            \
+    hipLaunchKernelGGL((members_narrow_kernel<NBLK, GATHER, STORE>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, i3, packed, dsrc, ld_d, dy_scale, dout_store, ld_store, g2, \
+                       n_edges, dh_user, ld_dh, bnd_val, bnd_user, n_ranges, dump)
+    const bool store = gather && dout_store != nullptr;
     if (nblk == 4) {
-        if (gather) IHG_NARROW_MEMBERS(4, true);
-        else IHG_NARROW_MEMBERS(4, false);
+        if (!gather) IHG_NARROW_MEMBERS(4, false, false);
+        else if (store) IHG_NARROW_MEMBERS(4, true, true);
+        else IHG_NARROW_MEMBERS(4, true, false);
     } else {
-        if (gather) IHG_NARROW_MEMBERS(3, true);
-        else IHG_NARROW_MEMBERS(3, false);
+        if (!gather) IHG_NARROW_MEMBERS(3, false, false);
+        else if (store) IHG_NARROW_MEMBERS(3, true, true);
+        else IHG_NARROW_MEMBERS(3, true, false);
     }
 #undef IHG_NARROW_MEMBERS
+    const int per_block = kBlockThreads / ND;
+    hipLaunchKernelGGL(narrow_boundary_fixup_kernel, dim3((2 * n_ranges + per_block - 1) / per_block), dim3(kBlockThreads), 0, s, bnd_val, bnd_user, 2 * n_ranges, dh_user, ld_dh);
 }
 
 bool narrow_linear_ok(int dim, int64_t ld_a, int64_t ld_b) { return dim == ND && ld_a % 4 == 0 && ld_b % 4 == 0; }
@@ -790,8 +845,8 @@ void launch_row_gemm_narrow(TypedRows in, int64_t ld_in, const float* w, int64_t
     if (plan.tile_prefix[3] == 0) return;
     pack_linear_narrow(w, ld_w, w_type_stride, transpose, pk, s);
     const int grid = grid_for_waves(std::min(plan.tile_prefix[3], 4096));
-    hipLaunchKernelGGL(row_gemm_narrow_kernel, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, w_type_stride == 0 ? 1 : 0, bias, bias_mask, bias_type_stride, plan, out, ld_out,
-                       accumulate);
+    if (accumulate) hipLaunchKernelGGL(row_gemm_narrow_kernel<true>, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, w_type_stride == 0 ? 1 : 0, bias, bias_mask, bias_type_stride, plan, out, ld_out);
+    else hipLaunchKernelGGL(row_gemm_narrow_kernel<false>, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, w_type_stride == 0 ? 1 : 0, bias, bias_mask, bias_type_stride, plan, out, ld_out);
 }
 
 int launch_dense_weight_narrow(const float* dout, int64_t ld_dout, TypedRows x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs, float* bias_slabs,
@@ -800,11 +855,13 @@ int launch_dense_weight_narrow(const float* dout, int64_t ld_dout, TypedRows x, 
     const int n_slabs = 256;                                             // = dense.hip's kDenseSlabs: the workspace holds that many per type
     if (dx != nullptr) {
         pack_linear_narrow(w, ld_w, w_type_stride, 1, pk, s);
-        hipLaunchKernelGGL(dense_weight_grad_narrow_kernel<true>, dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0, slabs,
-                           bias_slabs, pk, *dx, ld_dx, dx_accumulate);
+        if (dx_accumulate) hipLaunchKernelGGL((dense_weight_grad_narrow_kernel<true, true>), dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0,
+                                              slabs, bias_slabs, pk, *dx, ld_dx);
+        else hipLaunchKernelGGL((dense_weight_grad_narrow_kernel<true, false>), dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0, slabs,
+                                bias_slabs, pk, *dx, ld_dx);
     } else {
-        hipLaunchKernelGGL(dense_weight_grad_narrow_kernel<false>, dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0, slabs,
-                           bias_slabs, static_cast<const float*>(nullptr), typed_rows_out(nullptr), int64_t{0}, 0);
+        hipLaunchKernelGGL((dense_weight_grad_narrow_kernel<false, false>), dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0, slabs,
+                           bias_slabs, static_cast<const float*>(nullptr), typed_rows_out(nullptr), int64_t{0});
     }
     return n_slabs;
 }

@@ -33,7 +33,7 @@ IHG_INTERNAL void launch_node_weight_narrow(int order, const float* h, int64_t l
 
 // member gradients, user slot reduced on chip (g2 is [E, 2, d]; hyperedges numbered by user).  dy_scale / dout_store as in launch_members_split: with gather != 0 `dsrc` is
 // the node-level cotangent [N, d] and the kernel forms the hyperedges' cotangents itself (dout_store != nullptr: and leaves them there).  packed: narrow_members_floats(order)
-// floats of workspace; the boundary table holds 2 * kNarrowMemberRanges entries; *n_boundary_entries = entries written (for user_boundary_fixup_kernel).
+// floats of workspace; the boundary table holds 2 * kNarrowMemberRanges entries; *n_boundary_entries = entries written.  The boundary runs are added up by the launch itself.
 IHG_INTERNAL int64_t narrow_members_floats(int order);
 IHG_INTERNAL bool narrow_members_ok(int dim, int order, const float* g2, int64_t ld_h, int64_t ld_d, const float* dsrc);
 IHG_INTERNAL void launch_members_narrow(int order, int gather, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, float* packed, const float* dsrc,
