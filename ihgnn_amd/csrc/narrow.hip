@@ -501,37 +501,36 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRow
                                                                         const float* __restrict__ bias, int bias_mask, int64_t bias_type_stride, NarrowTiles plan, TypedRowsOut out,
                                                                         int64_t ld_out) {
     const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
-    const int total = plan.tile_prefix[3];
-    const int64_t waves = global_wave_count();
-    const int per = static_cast<int>((total + waves - 1) / waves);
-    const int t0 = static_cast<int>(global_wave_id()) * per;
-    const int n_my = std::max(0, std::min(per, total - t0));
+    // one node type per wave (plan.wave_prefix), its W^T fragments loaded once in front of the loop: 16 registers
+    const int wid = static_cast<int>(global_wave_id());
+    if (wid >= plan.wave_prefix[3]) return;
+    const int type = wid >= plan.wave_prefix[2] ? 2 : (wid >= plan.wave_prefix[1] ? 1 : 0);
+    const int n_w = plan.wave_prefix[type + 1] - plan.wave_prefix[type];
+    const int tiles_t = plan.tile_prefix[type + 1] - plan.tile_prefix[type];
+    const int per = (tiles_t + n_w - 1) / n_w;
+    const int t0 = (wid - plan.wave_prefix[type]) * per;
+    const int n_my = std::max(0, std::min(per, tiles_t - t0));
     if (n_my == 0) return;
-    float wreg[3][8][2];                                                 // every type's fragments, loaded once (48 registers): no request under a branch inside the loop
+    float wreg[8][2];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) wreg[t][s][ct] = pk[(((single_weight ? 0 : t) * 8 + s) * 2 + ct) * kWave + lane];
-    struct Rows { v4f x[2], old[2], b[2]; float keep; int64_t v; int type; };
-    // (unconditional requests only: without a bias the input row is read again and multiplied by 0; accumulation is a template parameter)
-    const float bias_on = bias != nullptr ? 1.f : 0.f;
+        for (int ct = 0; ct < 2; ++ct) wreg[s][ct] = pk[(((single_weight ? 0 : type) * 8 + s) * 2 + ct) * kWave + lane];
+    const float* const in_rows = typed_base(in, type);
+    float* const out_rows = typed_base(out, type);
+    const bool with_bias = bias != nullptr && ((bias_mask >> type) & 1);
+    const v4f bias0 = with_bias ? *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + 4 * q) : v4f{0.f, 0.f, 0.f, 0.f};
+    const v4f bias1 = with_bias ? *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + 16 + 4 * q) : v4f{0.f, 0.f, 0.f, 0.f};
+    struct Rows { v4f x[2], old[2]; int64_t v; };
     auto load = [&](int k, Rows& r) {
-        const int tile = std::min(t0 + k, total - 1);
-        r.type = tile >= plan.tile_prefix[2] ? 2 : (tile >= plan.tile_prefix[1] ? 1 : 0);
-        const int64_t row = plan.begin[r.type] + static_cast<int64_t>(tile - plan.tile_prefix[r.type]) * NT + i;
-        r.v = std::min(row, plan.begin[r.type + 1] - 1);
-        const float* ip = typed_base(in, r.type) + r.v * ld_in + 4 * q;
+        const int tile = std::min(t0 + k, tiles_t - 1);
+        const int64_t row = plan.begin[type] + static_cast<int64_t>(tile) * NT + i;
+        r.v = std::min(row, plan.begin[type + 1] - 1);                   // (a lane past the type's last row: that row again, the same values)
+        const float* ip = in_rows + r.v * ld_in + 4 * q;
         r.x[0] = *reinterpret_cast<const v4f*>(ip);
         r.x[1] = *reinterpret_cast<const v4f*>(ip + 16);
-        const bool with_bias = bias != nullptr && ((bias_mask >> r.type) & 1);
-        const float* bp = with_bias ? bias + r.type * bias_type_stride + 4 * q : ip;
-        r.keep = with_bias ? bias_on : 0.f;
-        r.b[0] = *reinterpret_cast<const v4f*>(bp);
-        r.b[1] = *reinterpret_cast<const v4f*>(bp + 16);
         if (ACC) {
-            const float* op = typed_base(out, r.type) + r.v * ld_out + 4 * q;
+            const float* op = out_rows + r.v * ld_out + 4 * q;
             r.old[0] = *reinterpret_cast<const v4f*>(op);
             r.old[1] = *reinterpret_cast<const v4f*>(op + 16);
         }
@@ -539,21 +538,17 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRow
     auto step = [&](int k, const Rows& use, Rows& fill) {
         load(k + 1, fill);
         __builtin_amdgcn_sched_barrier(0);
-        v4f acc[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+        v4f acc[2] = {bias0, bias1};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const float a0 = use.type == 0 ? wreg[0][s][0] : (use.type == 1 ? wreg[1][s][0] : wreg[2][s][0]);
-            const float a1 = use.type == 0 ? wreg[0][s][1] : (use.type == 1 ? wreg[1][s][1] : wreg[2][s][1]);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, use.x[s >> 2][s & 3], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, use.x[s >> 2][s & 3], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][0], use.x[s >> 2][s & 3], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][1], use.x[s >> 2][s & 3], acc[1], 0, 0, 0);
         }
-        acc[0] += use.b[0] * use.keep;
-        acc[1] += use.b[1] * use.keep;
         if (ACC) {
             acc[0] += use.old[0];
             acc[1] += use.old[1];
         }
-        float* op = typed_base(out, use.type) + use.v * ld_out + 4 * q;       // (a lane past its type's last row: that row again, the same values)
+        float* op = out_rows + use.v * ld_out + 4 * q;
         *reinterpret_cast<v4f*>(op) = acc[0];
         *reinterpret_cast<v4f*>(op + 16) = acc[1];
     };
@@ -841,10 +836,10 @@ static void pack_linear_narrow(const float* w, int64_t ld_w, int64_t w_type_stri
 
 void launch_row_gemm_narrow(TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias, int bias_mask,
                             int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, int accumulate, float* pk, hipStream_t s) {
-    const NarrowTiles plan = narrow_tiles(type_begin);
+    const NarrowTiles plan = narrow_tiles(type_begin, 4096);
     if (plan.tile_prefix[3] == 0) return;
     pack_linear_narrow(w, ld_w, w_type_stride, transpose, pk, s);
-    const int grid = grid_for_waves(std::min(plan.tile_prefix[3], 4096));
+    const int grid = grid_for_waves(plan.wave_prefix[3]);
     if (accumulate) hipLaunchKernelGGL(row_gemm_narrow_kernel<true>, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, w_type_stride == 0 ? 1 : 0, bias, bias_mask, bias_type_stride, plan, out, ld_out);
     else hipLaunchKernelGGL(row_gemm_narrow_kernel<false>, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, w_type_stride == 0 ? 1 : 0, bias, bias_mask, bias_type_stride, plan, out, ld_out);
 }
