@@ -454,8 +454,8 @@ int launch_row_gemm(int dim, const float* in, int64_t ld_in, const float* w, int
     const int n_types = w_type_stride == 0 ? 1 : 3;
     const bool out_ok = out_typed != nullptr ? (aligned16(out_typed->p[0]) && aligned16(out_typed->p[1]) && aligned16(out_typed->p[2])) : aligned16(out);
     const bool in_ok = in_typed != nullptr ? (aligned16(in_typed->p[0]) && aligned16(in_typed->p[1]) && aligned16(in_typed->p[2])) : aligned16(in);
-    if (narrow_linear_ok(dim, ld_in, ld_out) && in_ok && out_ok && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0))) {      // d = 32: narrow.hip (fp32 MFMA, any arithmetic mode)
-        launch_row_gemm_narrow(in_typed != nullptr ? *in_typed : typed_rows(in), ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin,
+    if (narrow_linear_ok(dim, ld_in, ld_out) && in_ok && out_ok && (bias == nullptr || (aligned16(bias) && bias_type_stride % 4 == 0))) {      // d = 32 / 64: narrow.hip (fp32 MFMA, any arithmetic mode)
+        launch_row_gemm_narrow(dim, in_typed != nullptr ? *in_typed : typed_rows(in), ld_in, w, ld_w, w_type_stride, transpose, bias, bias_mask, bias_type_stride, type_begin,
                                out_typed != nullptr ? *out_typed : typed_rows_out(out), ld_out, accumulate, pk, s);
         return IHG_OK;
     }
@@ -778,9 +778,9 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     // weights of type t are the column block t of w exactly as for dw: w_type_stride == dw_type_stride
     int n_slabs = kDenseSlabs;
     if (narrow_linear_ok(dim, ld_dout, ld_x) && aligned16(dout) && (dx == nullptr || (aligned16(dx) && aligned16(w) && ld_w % 4 == 0))) {
-        // d = 32: weight, bias and input gradient in one pass over (dout, x) (narrow.hip)
+        // d = 32 / 64: weight, bias and input gradient in one pass over (dout, x) (narrow.hip)
         const TypedRowsOut dx_rows = typed_rows_out(dx);
-        n_slabs = launch_dense_weight_narrow(dout, ld_dout, typed_rows(x), ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, dx != nullptr ? &dx_rows : nullptr, ld_dx,
+        n_slabs = launch_dense_weight_narrow(dim, dout, ld_dout, typed_rows(x), ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, dx != nullptr ? &dx_rows : nullptr, ld_dx,
                                              dx_accumulate, static_cast<float*>(workspace), s);
     } else if (dx_accumulate && dim == kNarrowDim) {
         return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate at dim 32 needs 16-byte aligned rows");
@@ -820,7 +820,7 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
 }
 
 int32_t ihg_node_linear_typed_supported(int32_t dim, int64_t ld_x, int64_t ld_out) {
-    return ((split_arith_enabled() && (dim == 128 || dim == 256)) || dim == kNarrowDim) && ld_x >= dim && ld_out >= dim && ld_x % 4 == 0 && ld_out % 4 == 0 ? 1 : 0;
+    return ((split_arith_enabled() && (dim == 128 || dim == 256)) || dim == kNarrowDim || dim == 64) && ld_x >= dim && ld_out >= dim && ld_x % 4 == 0 && ld_out % 4 == 0 ? 1 : 0;
 }
 
 int ihg_node_linear_fwd_typed(const float* const* x_rows, int64_t ld_x, const float* w, int64_t ld_w, int64_t w_type_stride, const float* bias,
@@ -872,7 +872,7 @@ int ihg_node_linear_bwd_weight_typed(const float* dout, int64_t ld_dout, const f
     const bool fused_dx = dx_rows != nullptr && dim == 128;
     int n_slabs = 0;
     if (narrow) {
-        n_slabs = launch_dense_weight_narrow(dout, ld_dout, xin, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, dx_rows != nullptr ? &dxo : nullptr, ld_dx, 0, static_cast<float*>(workspace), s);
+        n_slabs = launch_dense_weight_narrow(dim, dout, ld_dout, xin, ld_x, type_begin, n_types, slabs, bias_slabs, w, ld_w, dw_type_stride, dx_rows != nullptr ? &dxo : nullptr, ld_dx, 0, static_cast<float*>(workspace), s);
     } else {
         if (dx_rows != nullptr && !fused_dx) {
             if (int rc = launch_row_gemm(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, nullptr, ld_dx, static_cast<float*>(workspace), s, nullptr, &dxo)) return rc;

@@ -481,27 +481,33 @@ __global__ __launch_bounds__(kBlockThreads, 2) void members_narrow_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Node-level linear maps at d = 32 (ihg_node_linear_fwd / _bwd_input / _bwd_weight and their typed forms): streams over [N, 32] - 128 bytes in and out per row beside
-// 1 K multiply-adds.  Forward: out[v] = in[v] Wt_type(v) (+ bias of the type) (+ out[v]), Wt[k][c] = W_t[c][k] (transpose == 0) or W_t[k][c]; the W^T fragments of ALL three
-// node types sit in 48 registers.  Rows by typed base pointers (TypedRows: the embedding tables read in place).
+// Node-level linear maps at d = 32 and d = 64 (ihg_node_linear_fwd / _bwd_input / _bwd_weight and their typed forms; template <int D>): streams over [N, d] - 4 d bytes in
+// and out per row beside d^2 multiply-adds, which the fp32 matrix pipe keeps up with at these widths (d = 64: 28 us of MFMAs for C2's 256 k rows beside ~ 40 us of rows).
+// Forward: out[v] = in[v] Wt_type(v) (+ bias of the type) (+ out[v]), Wt[k][c] = W_t[c][k] (transpose == 0) or W_t[k][c].  One node type per wave (plan.wave_prefix), its W^T
+// fragments loaded once in front of the loop (d^2 / 64 registers).  Rows by typed base pointers (TypedRows: the embedding tables read in place).  A lane holds the d / 16
+// pieces 16 p + 4 q .. of its row.
 // ------------------------------------------------------------------------------------------------
-// pk[t][s][ct][lane] = Wt_t[ncol(lane >> 4, s)][16 ct + (lane & 15)]: the A fragments of every node type's W^T
-__global__ __launch_bounds__(kBlockThreads) void pack_linear_narrow_kernel(const float* __restrict__ w, int64_t ld_w, int64_t w_type_stride, int n_types, int transpose,
+template <int W>
+using vecf = float __attribute__((ext_vector_type(W)));
+
+// pk[t][s][ct][lane] = Wt_t[ncol(lane >> 4, s)][16 ct + (lane & 15)], s < d / 4, ct < d / 16: the A fragments of every node type's W^T
+__global__ __launch_bounds__(kBlockThreads) void pack_linear_narrow_kernel(const float* __restrict__ w, int64_t ld_w, int64_t w_type_stride, int n_types, int transpose, int d,
                                                                            float* __restrict__ pk) {
+    const int steps = d / 4, tiles = d / 16;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_types * 8 * 2 * kWave) return;
-    const int lane = idx & 63, ct = (idx >> 6) & 1, s = (idx >> 7) & 7, t = idx >> 10;
+    if (idx >= n_types * steps * tiles * kWave) return;
+    const int lane = idx & 63, ct = (idx >> 6) % tiles, s = ((idx >> 6) / tiles) % steps, t = (idx >> 6) / (tiles * steps);
     const float* wt = w + t * w_type_stride;
     const int c = 16 * ct + (lane & 15), k = ncol(lane >> 4, s);
     pk[idx] = transpose == 0 ? wt[static_cast<int64_t>(c) * ld_w + k] : wt[static_cast<int64_t>(k) * ld_w + c];
 }
 
-template <bool ACC>
+template <int D, bool ACC>
 __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRows in, int64_t ld_in, const float* __restrict__ pk, int single_weight,
                                                                         const float* __restrict__ bias, int bias_mask, int64_t bias_type_stride, NarrowTiles plan, TypedRowsOut out,
                                                                         int64_t ld_out) {
+    constexpr int P = D / 16, S = D / 4;
     const int lane = threadIdx.x & 63, q = lane >> 4, i = lane & 15;
-    // one node type per wave (plan.wave_prefix), its W^T fragments loaded once in front of the loop: 16 registers
     const int wid = static_cast<int>(global_wave_id());
     if (wid >= plan.wave_prefix[3]) return;
     const int type = wid >= plan.wave_prefix[2] ? 2 : (wid >= plan.wave_prefix[1] ? 1 : 0);
@@ -511,46 +517,44 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRow
     const int t0 = (wid - plan.wave_prefix[type]) * per;
     const int n_my = std::max(0, std::min(per, tiles_t - t0));
     if (n_my == 0) return;
-    float wreg[8][2];
+    float wreg[S][P];
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < S; ++s)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) wreg[s][ct] = pk[(((single_weight ? 0 : type) * 8 + s) * 2 + ct) * kWave + lane];
+        for (int ct = 0; ct < P; ++ct) wreg[s][ct] = pk[(((single_weight ? 0 : type) * S + s) * P + ct) * kWave + lane];
     const float* const in_rows = typed_base(in, type);
     float* const out_rows = typed_base(out, type);
     const bool with_bias = bias != nullptr && ((bias_mask >> type) & 1);
-    const v4f bias0 = with_bias ? *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + 4 * q) : v4f{0.f, 0.f, 0.f, 0.f};
-    const v4f bias1 = with_bias ? *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + 16 + 4 * q) : v4f{0.f, 0.f, 0.f, 0.f};
-    struct Rows { v4f x[2], old[2]; int64_t v; };
+    v4f bias_c[P];
+#pragma unroll
+    for (int ct = 0; ct < P; ++ct) bias_c[ct] = with_bias ? *reinterpret_cast<const v4f*>(bias + type * bias_type_stride + 16 * ct + 4 * q) : v4f{0.f, 0.f, 0.f, 0.f};
+    struct Rows { v4f x[P], old[P]; int64_t v; };
     auto load = [&](int k, Rows& r) {
         const int tile = std::min(t0 + k, tiles_t - 1);
         const int64_t row = plan.begin[type] + static_cast<int64_t>(tile) * NT + i;
         r.v = std::min(row, plan.begin[type + 1] - 1);                   // (a lane past the type's last row: that row again, the same values)
         const float* ip = in_rows + r.v * ld_in + 4 * q;
-        r.x[0] = *reinterpret_cast<const v4f*>(ip);
-        r.x[1] = *reinterpret_cast<const v4f*>(ip + 16);
+#pragma unroll
+        for (int p = 0; p < P; ++p) r.x[p] = *reinterpret_cast<const v4f*>(ip + 16 * p);
         if (ACC) {
             const float* op = out_rows + r.v * ld_out + 4 * q;
-            r.old[0] = *reinterpret_cast<const v4f*>(op);
-            r.old[1] = *reinterpret_cast<const v4f*>(op + 16);
+#pragma unroll
+            for (int p = 0; p < P; ++p) r.old[p] = *reinterpret_cast<const v4f*>(op + 16 * p);
         }
     };
     auto step = [&](int k, const Rows& use, Rows& fill) {
         load(k + 1, fill);
         __builtin_amdgcn_sched_barrier(0);
-        v4f acc[2] = {bias0, bias1};
+        v4f acc[P];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][0], use.x[s >> 2][s & 3], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][1], use.x[s >> 2][s & 3], acc[1], 0, 0, 0);
-        }
-        if (ACC) {
-            acc[0] += use.old[0];
-            acc[1] += use.old[1];
-        }
+        for (int ct = 0; ct < P; ++ct) acc[ct] = bias_c[ct];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int ct = 0; ct < P; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][ct], use.x[s >> 2][s & 3], acc[ct], 0, 0, 0);
         float* op = out_rows + use.v * ld_out + 4 * q;
-        *reinterpret_cast<v4f*>(op) = acc[0];
-        *reinterpret_cast<v4f*>(op + 16) = acc[1];
+#pragma unroll
+        for (int ct = 0; ct < P; ++ct) *reinterpret_cast<v4f*>(op + 16 * ct) = ACC ? acc[ct] + use.old[ct] : acc[ct];
     };
     Rows ra, rb;
     load(0, ra);
@@ -565,15 +569,17 @@ __global__ __launch_bounds__(kBlockThreads) void row_gemm_narrow_kernel(TypedRow
 
 // Backward of the same maps in ONE pass over (dout, x): d W_t = dout^T x and the bias gradient over the rows of type t, and - DX - the input gradient dx = dout W_t
 // (+ dx) of the same rows.  grid = (slabs, 1, weight types); a workgroup's four waves take the 16-row tiles 4 sx + wave, + 4 slabs, ... of the type's rows.  The row
-// contraction reads its operands as in node_interact_weight_narrow_kernel (lane ci = columns 2 ci, 2 ci + 1; four rows a step), the input gradient as in the forward;
-// the second read of a row hits the CU's cache.  The waves' partial gradients meet in LDS in wave order; slab layout = dense.hip's ([type][slab][d][d], [type][slab][d]),
-// reduced by its dense_slab_reduce_kernel.
-template <bool DX, bool ACC>
+// contraction reads its operands as in node_interact_weight_narrow_kernel (lane ci = the d / 16 consecutive columns (d / 16) ci ..; four rows a step), the input gradient
+// as in the forward; the second read of a row hits the CU's cache.  The waves' partial gradients meet in LDS in wave order; slab layout = dense.hip's
+// ([type][slab][d][d], [type][slab][d]), reduced by its dense_slab_reduce_kernel.
+template <int D, bool DX, bool ACC>
 __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_narrow_kernel(const float* __restrict__ dout, int64_t ld_dout, TypedRows x, int64_t ld_x, NarrowTiles plan,
                                                                                  int single_weight, float* __restrict__ slabs, float* __restrict__ bias_slabs,
                                                                                  const float* __restrict__ pk, TypedRowsOut dx, int64_t ld_dx) {
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    __shared__ float red[3][18][kWave];
+    constexpr int P = D / 16, S = D / 4, W = D / 16;
+    typedef vecf<W> vw;
+    constexpr int RED = W * W * 4 + W;
+    __shared__ float red[3][RED][kWave];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, i = lane & 15;
     const int wtype = blockIdx.z;
     const int64_t r_begin = single_weight ? plan.begin[0] : plan.begin[wtype];
@@ -581,68 +587,63 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_narrow_kernel
     const int64_t n_tiles = (r_end - r_begin + NT - 1) / NT;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
     auto type_of = [&](int64_t v) { return v >= plan.begin[2] ? 2 : (v >= plan.begin[1] ? 1 : 0); };
-    float wreg[DX ? 8 : 1][2];
+    float wreg[DX ? S : 1][P];
     if (DX) {                                                            // dx = dout W_t: the fragments of pack_linear_narrow_kernel with transpose = 1
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
+        for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) wreg[DX ? s : 0][ct] = pk[((wtype * 8 + s) * 2 + ct) * kWave + lane];
+            for (int ct = 0; ct < P; ++ct) wreg[DX ? s : 0][ct] = pk[((wtype * S + s) * P + ct) * kWave + lane];
     }
-    struct Rows { v4f d[2], old[2]; v2f dv[4], xv[4]; int64_t v; int type; bool live; };
+    struct Rows { v4f d[P], old[P]; vw dv[4], xv[4]; int64_t v; int type; };
     auto load = [&](int64_t tile, Rows& r) {
         const int64_t base = r_begin + std::min(tile, n_tiles - 1) * NT;
         const bool tile_live = tile < n_tiles;
         if (DX) {
-            const int64_t row = base + i;
-            r.live = tile_live && row < r_end;
-            r.v = std::min(row, r_end - 1);
+            r.v = std::min(base + i, r_end - 1);
             r.type = type_of(r.v);
-            r.d[0] = *reinterpret_cast<const v4f*>(dout + r.v * ld_dout + 4 * q);
-            r.d[1] = *reinterpret_cast<const v4f*>(dout + r.v * ld_dout + 16 + 4 * q);
+#pragma unroll
+            for (int p = 0; p < P; ++p) r.d[p] = *reinterpret_cast<const v4f*>(dout + r.v * ld_dout + 16 * p + 4 * q);
             if (ACC) {
                 const float* op = typed_base(dx, r.type) + r.v * ld_dx + 4 * q;
-                r.old[0] = *reinterpret_cast<const v4f*>(op);
-                r.old[1] = *reinterpret_cast<const v4f*>(op + 16);
+#pragma unroll
+                for (int p = 0; p < P; ++p) r.old[p] = *reinterpret_cast<const v4f*>(op + 16 * p);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t row = base + 4 * u + q;
             const int64_t vc = std::min(row, r_end - 1);
-            const bool live = tile_live && row < r_end;
-            const v2f dv = *reinterpret_cast<const v2f*>(dout + vc * ld_dout + 2 * i);
-            r.dv[u] = live ? dv : v2f{0.f, 0.f};
-            r.xv[u] = *reinterpret_cast<const v2f*>(typed_base(x, type_of(vc)) + vc * ld_x + 2 * i);
+            const float live = tile_live && row < r_end ? 1.f : 0.f;
+            r.dv[u] = *reinterpret_cast<const vw*>(dout + vc * ld_dout + W * i) * live;
+            r.xv[u] = *reinterpret_cast<const vw*>(typed_base(x, type_of(vc)) + vc * ld_x + W * i);
         }
     };
-    v4f acc[2][2];
+    v4f acc[W][W];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < W; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
-    v2f colsum = v2f{0.f, 0.f};
+        for (int nt = 0; nt < W; ++nt) acc[mt][nt] = v4f{0.f, 0.f, 0.f, 0.f};
+    vw colsum = vw(0.f);
     auto work = [&](const Rows& r) {
         if (DX) {
-            v4f g[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
+            v4f g[P];
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+            for (int ct = 0; ct < P; ++ct) g[ct] = ACC ? r.old[ct] : v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) g[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[DX ? s : 0][ct], r.d[s >> 2][s & 3], g[ct], 0, 0, 0);
-            if (ACC) {
-                g[0] += r.old[0];
-                g[1] += r.old[1];
-            }
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int ct = 0; ct < P; ++ct) g[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[DX ? s : 0][ct], r.d[s >> 2][s & 3], g[ct], 0, 0, 0);
             float* op = typed_base(dx, r.type) + r.v * ld_dx + 4 * q;        // (a lane past the last row: that row again, the same values)
-            *reinterpret_cast<v4f*>(op) = g[0];
-            *reinterpret_cast<v4f*>(op + 16) = g[1];
+#pragma unroll
+            for (int ct = 0; ct < P; ++ct) *reinterpret_cast<v4f*>(op + 16 * ct) = g[ct];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             colsum += r.dv[u];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < W; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.dv[u][mt], r.xv[u][nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < W; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.dv[u][mt], r.xv[u][nt], acc[mt][nt], 0, 0, 0);
         }
     };
     if (n_tiles > 0) {
@@ -658,37 +659,38 @@ __global__ __launch_bounds__(kBlockThreads) void dense_weight_grad_narrow_kernel
         }
     }
     // the bias gradient's four row groups, then the four waves, in a fixed order
-    colsum[0] += __shfl_xor(colsum[0], 16);
-    colsum[1] += __shfl_xor(colsum[1], 16);
-    colsum[0] += __shfl_xor(colsum[0], 32);
-    colsum[1] += __shfl_xor(colsum[1], 32);
+#pragma unroll
+    for (int t = 0; t < W; ++t) {
+        colsum[t] += __shfl_xor(colsum[t], 16);
+        colsum[t] += __shfl_xor(colsum[t], 32);
+    }
     if (wave > 0) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < W; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < W; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave - 1][(2 * mt + nt) * 4 + r][lane] = acc[mt][nt][r];
-        red[wave - 1][16][lane] = colsum[0];
-        red[wave - 1][17][lane] = colsum[1];
+                for (int r = 0; r < 4; ++r) red[wave - 1][(W * mt + nt) * 4 + r][lane] = acc[mt][nt][r];
+#pragma unroll
+        for (int t = 0; t < W; ++t) red[wave - 1][W * W * 4 + t][lane] = colsum[t];
     }
     __syncthreads();
     if (wave == 0) {
         const int n_slabs = gridDim.x;
-        float* slab = slabs + (static_cast<int64_t>(wtype) * n_slabs + blockIdx.x) * ND * ND;
+        float* slab = slabs + (static_cast<int64_t>(wtype) * n_slabs + blockIdx.x) * D * D;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < W; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < W; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int slot = (2 * mt + nt) * 4 + r;
-                    slab[(2 * (4 * q + r) + mt) * ND + 2 * i + nt] = ((acc[mt][nt][r] + red[0][slot][lane]) + red[1][slot][lane]) + red[2][slot][lane];
+                    const int slot = (W * mt + nt) * 4 + r;
+                    slab[(W * (4 * q + r) + mt) * D + W * i + nt] = ((acc[mt][nt][r] + red[0][slot][lane]) + red[1][slot][lane]) + red[2][slot][lane];
                 }
         if (q == 0) {
-            float* bs = bias_slabs + (static_cast<int64_t>(wtype) * n_slabs + blockIdx.x) * ND;
-            bs[2 * i] = ((colsum[0] + red[0][16][lane]) + red[1][16][lane]) + red[2][16][lane];
-            bs[2 * i + 1] = ((colsum[1] + red[0][17][lane]) + red[1][17][lane]) + red[2][17][lane];
+            float* bs = bias_slabs + (static_cast<int64_t>(wtype) * n_slabs + blockIdx.x) * D;
+#pragma unroll
+            for (int t = 0; t < W; ++t) bs[W * i + t] = ((colsum[t] + red[0][W * W * 4 + t][lane]) + red[1][W * W * 4 + t][lane]) + red[2][W * W * 4 + t][lane];
         }
     }
 }
@@ -826,37 +828,49 @@ void launch_members_narrow(int order, int gather, const float* h, int64_t ld_h, 
     hipLaunchKernelGGL(narrow_boundary_fixup_kernel, dim3((2 * n_ranges + per_block - 1) / per_block), dim3(kBlockThreads), 0, s, bnd_val, bnd_user, 2 * n_ranges, dh_user, ld_dh);
 }
 
-bool narrow_linear_ok(int dim, int64_t ld_a, int64_t ld_b) { return dim == ND && ld_a % 4 == 0 && ld_b % 4 == 0; }
+bool narrow_linear_ok(int dim, int64_t ld_a, int64_t ld_b) { return (dim == 32 || dim == 64) && ld_a % 4 == 0 && ld_b % 4 == 0; }
 
-static void pack_linear_narrow(const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, float* pk, hipStream_t s) {
+static void pack_linear_narrow(int dim, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, float* pk, hipStream_t s) {
     const int n_types = w_type_stride == 0 ? 1 : 3;
-    const int items = n_types * 8 * 2 * kWave;
-    hipLaunchKernelGGL(pack_linear_narrow_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types, transpose, pk);
+    const int items = n_types * (dim / 4) * (dim / 16) * kWave;
+    hipLaunchKernelGGL(pack_linear_narrow_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types, transpose, dim, pk);
 }
 
-void launch_row_gemm_narrow(TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias, int bias_mask,
+void launch_row_gemm_narrow(int dim, TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias, int bias_mask,
                             int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, int accumulate, float* pk, hipStream_t s) {
     const NarrowTiles plan = narrow_tiles(type_begin, 4096);
     if (plan.tile_prefix[3] == 0) return;
-    pack_linear_narrow(w, ld_w, w_type_stride, transpose, pk, s);
+    pack_linear_narrow(dim, w, ld_w, w_type_stride, transpose, pk, s);
     const int grid = grid_for_waves(plan.wave_prefix[3]);
-    if (accumulate) hipLaunchKernelGGL(row_gemm_narrow_kernel<true>, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, w_type_stride == 0 ? 1 : 0, bias, bias_mask, bias_type_stride, plan, out, ld_out);
-    else hipLaunchKernelGGL(row_gemm_narrow_kernel<false>, dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, w_type_stride == 0 ? 1 : 0, bias, bias_mask, bias_type_stride, plan, out, ld_out);
+    const int single = w_type_stride == 0 ? 1 : 0;
+#define IHG_NARROW_RG(D, ACC) hipLaunchKernelGGL((row_gemm_narrow_kernel<D, ACC>), dim3(grid), dim3(kBlockThreads), 0, s, in, ld_in, pk, single, bias, bias_mask, bias_type_stride, plan, out, ld_out)
+    if (dim == 32) {
+        if (accumulate) IHG_NARROW_RG(32, true);
+        else IHG_NARROW_RG(32, false);
+    } else {
+        if (accumulate) IHG_NARROW_RG(64, true);
+        else IHG_NARROW_RG(64, false);
+    }
+#undef IHG_NARROW_RG
 }
 
-int launch_dense_weight_narrow(const float* dout, int64_t ld_dout, TypedRows x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs, float* bias_slabs,
+int launch_dense_weight_narrow(int dim, const float* dout, int64_t ld_dout, TypedRows x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs, float* bias_slabs,
                                const float* w, int64_t ld_w, int64_t w_type_stride, const TypedRowsOut* dx, int64_t ld_dx, int dx_accumulate, float* pk, hipStream_t s) {
     const NarrowTiles plan = narrow_tiles(type_begin);
     const int n_slabs = 256;                                             // = dense.hip's kDenseSlabs: the workspace holds that many per type
-    if (dx != nullptr) {
-        pack_linear_narrow(w, ld_w, w_type_stride, 1, pk, s);
-        if (dx_accumulate) hipLaunchKernelGGL((dense_weight_grad_narrow_kernel<true, true>), dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0,
-                                              slabs, bias_slabs, pk, *dx, ld_dx);
-        else hipLaunchKernelGGL((dense_weight_grad_narrow_kernel<true, false>), dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0, slabs,
-                                bias_slabs, pk, *dx, ld_dx);
+    const int single = n_types == 1 ? 1 : 0;
+    const TypedRowsOut dxr = dx != nullptr ? *dx : typed_rows_out(nullptr);
+    if (dx != nullptr) pack_linear_narrow(dim, w, ld_w, w_type_stride, 1, pk, s);
+#define IHG_NARROW_DW(D, DXF, ACC) hipLaunchKernelGGL((dense_weight_grad_narrow_kernel<D, DXF, ACC>), dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, single, slabs, bias_slabs, pk, dxr, ld_dx)
+    if (dim == 32) {
+        if (dx == nullptr) IHG_NARROW_DW(32, false, false);
+        else if (dx_accumulate) IHG_NARROW_DW(32, true, true);
+        else IHG_NARROW_DW(32, true, false);
     } else {
-        hipLaunchKernelGGL((dense_weight_grad_narrow_kernel<false, false>), dim3(n_slabs, 1, n_types), dim3(kBlockThreads), 0, s, dout, ld_dout, x, ld_x, plan, n_types == 1 ? 1 : 0, slabs,
-                           bias_slabs, static_cast<const float*>(nullptr), typed_rows_out(nullptr), int64_t{0});
+        if (dx == nullptr) IHG_NARROW_DW(64, false, false);
+        else if (dx_accumulate) IHG_NARROW_DW(64, true, true);
+        else IHG_NARROW_DW(64, true, false);
     }
+#undef IHG_NARROW_DW
     return n_slabs;
 }

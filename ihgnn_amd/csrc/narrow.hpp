@@ -40,10 +40,10 @@ IHG_INTERNAL void launch_members_narrow(int order, int gather, const float* h, i
                                         int64_t ld_d, const float* dy_scale, float* dout_store, int64_t ld_store, float* g2, int64_t n_edges, float* dh_user, int64_t ld_dh,
                                         float* bnd_val, int32_t* bnd_user, int* n_boundary_entries, hipStream_t s);
 
-// node-level linear maps (ihg_node_linear_*): forward / input gradient as one stream over the rows; weight + bias gradient (and, dx != nullptr, the input gradient
-// of the same rows) in one pass, slabs in dense.hip's layout (returns the slabs per type); pk: 3 x 1024 floats of workspace for the packed weights
+// node-level linear maps (ihg_node_linear_*) at dim 32 and 64: forward / input gradient as one stream over the rows; weight + bias gradient (and, dx != nullptr, the input gradient
+// of the same rows) in one pass, slabs in dense.hip's layout (returns the slabs per type); pk: 3 dim^2 floats of workspace for the packed weights
 IHG_INTERNAL bool narrow_linear_ok(int dim, int64_t ld_a, int64_t ld_b);
-IHG_INTERNAL void launch_row_gemm_narrow(TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias, int bias_mask,
+IHG_INTERNAL void launch_row_gemm_narrow(int dim, TypedRows in, int64_t ld_in, const float* w, int64_t ld_w, int64_t w_type_stride, int transpose, const float* bias, int bias_mask,
                                          int64_t bias_type_stride, const int64_t* type_begin, TypedRowsOut out, int64_t ld_out, int accumulate, float* pk, hipStream_t s);
-IHG_INTERNAL int launch_dense_weight_narrow(const float* dout, int64_t ld_dout, TypedRows x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs, float* bias_slabs,
+IHG_INTERNAL int launch_dense_weight_narrow(int dim, const float* dout, int64_t ld_dout, TypedRows x, int64_t ld_x, const int64_t* type_begin, int n_types, float* slabs, float* bias_slabs,
                                             const float* w, int64_t ld_w, int64_t w_type_stride, const TypedRowsOut* dx, int64_t ld_dx, int dx_accumulate, float* pk, hipStream_t s);
