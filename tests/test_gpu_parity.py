@@ -40,7 +40,8 @@ def row_rel(a, b, floor=1e-3):
     return float((np.abs(a - b).max(1)[keep] / mag[keep]).max())
 
 
-ROW_RTOL = 5e-5      # per-row bar for the model-level feature matrices (rows above the noise floor; the tensor-level bar stays RTOL)
+ROW_RTOL = 1e-5      # per-row bar = the contract's (measured, round 5: model feature matrices F3 / F5 / F8 2.3e-7 ... 5.2e-7 per row, weight gradients over rows of very
+                     # different magnitude 1.9e-7 ... 2.7e-7, every entry of d w at C5 x 0.05 2.0e-6; rows above the noise floor)
 
 
 def make_layout(U, Q, I, E, seed, distribution='uniform', heavy_threshold=1024, edge_order='file'):
@@ -836,6 +837,7 @@ def test_weight_gradients_over_rows_of_very_different_magnitude(dim):
     ops.node_linear(xd, wd, bd, lay).backward(cot.to(dev()))
     x64, w64, b64 = x.double().requires_grad_(True), wl.double().requires_grad_(True), bl.double().requires_grad_(True)
     (x64 @ w64.T + b64).backward(cot.double())
+    print(f'node-level linear map, rows of very different magnitude, d = {dim}: dW rel {rel(wd.grad, w64.grad):.2e} row_rel {row_rel(wd.grad, w64.grad):.2e}')
     assert rel(wd.grad, w64.grad) <= RTOL and row_rel(wd.grad, w64.grad) <= ROW_RTOL
     assert rel(bd.grad, b64.grad) <= RTOL
     got, want = xd.grad.cpu().double(), x64.grad
@@ -1188,6 +1190,7 @@ def test_c5_scaled_weight_gradients_whole_matrix_against_the_oracle():
         idx = i3[e0:e0 + step]
         dF = sdy[idx[:, 0]] + sdy[idx[:, 1]] + sdy[idx[:, 2]]
         (ref.feature_interactor(h64, idx, w64, b64, order) * dF).sum().backward()
+    print(f'C5 x 0.05 weight gradients, whole matrix: rel {rel(wd.grad, w64.grad):.2e} row_rel {row_rel(wd.grad, w64.grad):.2e}')
     assert rel(wd.grad, w64.grad) <= RTOL and row_rel(wd.grad, w64.grad) <= ROW_RTOL
     for blk in range(k):                                                  # every block on its own: a small block must not hide behind a large one
         assert rel(wd.grad[:, blk * d:(blk + 1) * d], w64.grad[:, blk * d:(blk + 1) * d]) <= RTOL, blk
