@@ -216,40 +216,77 @@ class _ShardOptimizer:
     def zero_grad(self, set_to_none: bool = False):
         self.sync.zero_grad()
 
+    def _gather_full(self):
+        """``{exp_avg, exp_avg_sq: full-length flat vectors, step}`` gathered from every rank's shard (COLLECTIVE), or ``None`` before the first step."""
+        sync = self.sync
+        entry = next(iter(self.inner.state_dict()['state'].values()), None)
+        if entry is None:
+            return None
+        full = {}
+        for key in ('exp_avg', 'exp_avg_sq'):
+            gathered = torch.empty(sync.padded, dtype=sync.param_shard.dtype, device=sync.param_shard.device)
+            if sync.distributed:
+                dist.all_gather_into_tensor(gathered, entry[key].reshape(-1).contiguous(), group=sync.group)
+            else:
+                gathered.copy_(entry[key].reshape(-1))
+            full[key] = gathered[:sync.flat.numel()].clone()
+        full['step'] = entry['step']
+        return full
+
     def state_dict(self):
-        """Adam state of ALL parameters: every rank's shard of ``exp_avg`` / ``exp_avg_sq`` gathered into full-length flat vectors
-        (the same on every rank, so rank 0's checkpoint is complete and can be resumed at another world size).
+        """Adam state of ALL parameters in ``torch.optim.Adam``'s own layout - ``{'state': {i: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}``, parameter i = the i-th of
+        ``model.parameters()`` - what the reference writes (``Main.py:144-147``) and what the flat / bucketed modes' optimizers write and read: a checkpoint taken under one
+        ``--grad_sync`` mode (or world size, or by the reference) resumes under another.  Every rank's shard of ``exp_avg`` / ``exp_avg_sq`` is gathered, so rank 0's file is complete.
 
         COLLECTIVE: it issues ``all_gather_into_tensor`` - EVERY rank of the group must call it, at the same point of the program.  The
         usual ``if chief: torch.save({... optimizer.state_dict()})`` would leave rank 0 waiting for peers that never come; call
         :func:`checkpoint_state` on every rank and save its result on the chief (``Main.py`` does).  ``local_state_dict()`` is the
         collective-free form (this rank's shard only)."""
         sync = self.sync
-        state = self.inner.state_dict()
-        entry = next(iter(state['state'].values()), None)
-        full = {}
-        if entry is not None:
-            for key in ('exp_avg', 'exp_avg_sq'):
-                gathered = torch.empty(sync.padded, dtype=sync.param_shard.dtype, device=sync.param_shard.device)
-                if sync.distributed:
-                    dist.all_gather_into_tensor(gathered, entry[key].reshape(-1).contiguous(), group=sync.group)
-                else:
-                    gathered.copy_(entry[key].reshape(-1))
-                full[key] = gathered[:sync.flat.numel()].clone()
-            full['step'] = entry['step']
-        return {'sharded_adam': full, 'param_groups': state['param_groups'], 'numel': sync.flat.numel()}
+        full = self._gather_full()
+        groups = [dict(g) for g in self.inner.state_dict()['param_groups']]
+        for g in groups:
+            g['params'] = list(range(len(sync.params)))
+        state = {}
+        if full is not None:
+            offset = 0
+            for index, p in enumerate(sync.params):
+                n = p.numel()
+                state[index] = {'step': full['step'].clone() if torch.is_tensor(full['step']) else full['step'],
+                                'exp_avg': full['exp_avg'][offset:offset + n].view_as(p).clone(), 'exp_avg_sq': full['exp_avg_sq'][offset:offset + n].view_as(p).clone()}
+                offset += n
+        return {'state': state, 'param_groups': groups}
 
     def local_state_dict(self):
         """This rank's shard of the Adam state, no collective (a per-rank checkpoint file; not loadable at another world size)."""
         return {'adam_shard': self.inner.state_dict(), 'shard_range': tuple(self.sync.shard_range), 'numel': self.sync.flat.numel()}
 
     def load_state_dict(self, state):
+        """Takes ``torch.optim.Adam``'s layout (``state_dict()`` above; a checkpoint of the flat / bucketed modes or of the reference) and the flat form rounds 3 - 4 wrote
+        (``{'sharded_adam': ..., 'numel': ...}``)."""
         sync = self.sync
-        if 'sharded_adam' not in state:
-            raise ValueError('not a sharded-Adam checkpoint (expected the dict written by _ShardOptimizer.state_dict)')
-        if state['numel'] != sync.flat.numel():
-            raise ValueError(f"checkpoint holds Adam state for {state['numel']} parameters, the model has {sync.flat.numel()}")
-        full = state['sharded_adam']
+        if 'sharded_adam' in state:
+            if state['numel'] != sync.flat.numel():
+                raise ValueError(f"checkpoint holds Adam state for {state['numel']} parameters, the model has {sync.flat.numel()}")
+            full = state['sharded_adam']
+        elif 'state' in state and 'param_groups' in state:
+            entries = state['state']
+            if not entries:
+                full = {}
+            else:
+                if len(entries) != len(sync.params):
+                    raise ValueError(f'checkpoint holds Adam state for {len(entries)} parameters, the model has {len(sync.params)}')
+                ordered = [entries[k] for k in sorted(entries)]
+                for e, p in zip(ordered, sync.params):
+                    if tuple(e['exp_avg'].shape) != tuple(p.shape):
+                        raise ValueError(f"checkpoint Adam state of shape {tuple(e['exp_avg'].shape)} does not fit parameter of shape {tuple(p.shape)}")
+                steps = {float(e['step']) for e in ordered}
+                if len(steps) != 1:
+                    raise ValueError(f'the sharded optimizer keeps ONE step count; the checkpoint holds {sorted(steps)}')
+                full = {'exp_avg': torch.cat([e['exp_avg'].reshape(-1) for e in ordered]), 'exp_avg_sq': torch.cat([e['exp_avg_sq'].reshape(-1) for e in ordered]),
+                        'step': ordered[0]['step']}
+        else:
+            raise ValueError('not an Adam checkpoint (expected torch.optim.Adam\'s state_dict layout or the dict written by _ShardOptimizer.state_dict of rounds 3 - 4)')
         if not full:
             return
         lo, hi = sync.shard_range
@@ -266,8 +303,9 @@ class _ShardOptimizer:
             padded = torch.zeros(sync.padded, dtype=sync.param_shard.dtype, device=sync.param_shard.device)
             padded[:sync.flat.numel()].copy_(full[key].to(padded.device))
             entry[key] = padded[lo:hi].clone().view_as(entry[key])
-        entry['step'] = full['step']
-        inner['param_groups'] = state['param_groups']
+        entry['step'] = full['step'].clone() if torch.is_tensor(full['step']) else torch.tensor(float(full['step']))
+        for mine, theirs in zip(inner['param_groups'], state['param_groups']):
+            mine.update({k: v for k, v in theirs.items() if k != 'params'})
         self.inner.load_state_dict(inner)
 
 

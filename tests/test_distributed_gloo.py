@@ -66,9 +66,14 @@ def _worker(rank, world, port, out_dir, mode='flat'):
         sync.zero_grad()
         if mode == 'sharded' and step == 0:                 # the checkpoint of the sharded optimizer holds EVERY rank's Adam state
             state = opt.state_dict()
-            assert state['sharded_adam']['exp_avg'].numel() == sync.flat.numel() and float(state['sharded_adam']['exp_avg'].abs().sum()) > 0
+            # torch.optim.Adam's own layout (what the reference and the flat / bucketed modes write): a plain Adam over the same parameters loads it ...
+            assert set(state) == {'state', 'param_groups'} and len(state['state']) == len(sync.params)
+            assert sum(e['exp_avg'].numel() for e in state['state'].values()) == sync.flat.numel() and sum(float(e['exp_avg'].abs().sum()) for e in state['state'].values()) > 0
+            plain = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in sync.params], 1e-2)
+            plain.load_state_dict(state)
+            # ... and the sharded optimizer loads a plain Adam's checkpoint (a run resumed under another --grad_sync mode) as well as its own
             fresh = sync.optimizer(1e-2)
-            fresh.load_state_dict(state)
+            fresh.load_state_dict(plain.state_dict())
             lo, hi = sync.shard_range
             mine = next(iter(fresh.inner.state_dict()['state'].values()))
             want = next(iter(opt.inner.state_dict()['state'].values()))
@@ -87,7 +92,8 @@ def _worker(rank, world, port, out_dir, mode='flat'):
             lo, hi = sync.shard_range
             mine = next(iter(opt.inner.state_dict()['state'].values()))
             hi_real = min(hi, sync.flat.numel())
-            assert torch.equal(saved['optimizer']['sharded_adam']['exp_avg'][lo:hi_real], mine['exp_avg'].reshape(-1)[:hi_real - lo])
+            flat_saved = torch.cat([saved['optimizer']['state'][k]['exp_avg'].reshape(-1) for k in sorted(saved['optimizer']['state'])])
+            assert torch.equal(flat_saved[lo:hi_real], mine['exp_avg'].reshape(-1)[:hi_real - lo])
             assert set(opt.local_state_dict()) == {'adam_shard', 'shard_range', 'numel'}           # the collective-free form
     torch.save({k: v.clone() for k, v in model.reference_state().items()}, os.path.join(out_dir, f'rank{rank}.pt'))
     if mode == 'bucketed':                                  # a second backward before the exchange was waited for must not pass silently
