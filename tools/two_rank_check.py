@@ -78,7 +78,7 @@ def main():
         sync.zero_grad()
         if step == 0 and sync.owns_optimizer:                # the sharded optimizer's checkpoint: gathered over ranks, loadable again
             state = opt.state_dict()
-            assert state['sharded_adam']['exp_avg'].numel() == sync.flat.numel()
+            assert sum(e['exp_avg'].numel() for e in state['state'].values()) == sync.flat.numel()       # (torch.optim.Adam's layout)
             opt.load_state_dict(state)
     torch.cuda.synchronize()
     ok = True
