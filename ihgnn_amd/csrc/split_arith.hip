@@ -284,6 +284,9 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         __syncthreads();
         int id_carry = 0;
         auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3], Raw& raw_use, Raw& raw_req) {
+            // (Round 5 tried the streaming form - config C5's kernel - with this phase's requests first and then the work on what was requested a PHASE AGO behind one exact
+            // wait, every request unconditional: the loop's waits became vmcnt(11 .. 22) instead of two vmcnt(0) per trip, and the kernel went 29.7 -> 31.1 ms at C5: it does not
+            // wait for latency - 78 GB of L2-miss traffic and a matrix pipe half busy share its 30 ms.  Reverted.)
             // ids of tile k + 3 + AHEAD (requested in the previous phase) into the ring: a phase ahead of their first readers (the gathered rows of
             // that tile in the next phase)
             if (k >= 1 && k + 3 + AHEAD < n_my && st < 3 * TE) ids[(k + 3 + AHEAD) & 7][st] = id_carry;

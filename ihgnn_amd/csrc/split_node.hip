@@ -990,6 +990,7 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
         const int st = tid - 256, row = st >> 3, o = st & 7;
         struct Rows {
             v4f d[2 * DOCT], hv[ZX], sa[ZX], sb[ZX], sab[ZX];
+            float sc, keep;                                              // the cotangent row's factor as loaded (dy_scale[v], or a stand-in word) and 1 / 0 (past the end): applied by publish()
             int ea, eb;                                                  // the row's exponents (publish), used again by the split
         };
         auto load_rows = [&](int k, Rows& r) {
@@ -997,15 +998,14 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
             const bool live = t0 + k < n_tiles && first + row < r_end;
             const int64_t v = std::min(first + row, r_end - 1);
             const float* src = dy + v * ld_dy + 8 * o;
-            const float sc = dy_scale != nullptr ? dy_scale[v] : 1.f;
+            // (every request unconditional - round 5, narrow.hip's comment on the in-order memory counter: a load under `dy_scale != nullptr ?` made the compiler drain the
+            // queue in every phase.  Without scales the cotangent's first word is read in their place and replaced by 1; rows past the type's end take the factor 0.)
+            r.sc = (dy_scale != nullptr ? dy_scale + v : src)[0];
+            r.keep = live ? 1.f : 0.f;
 #pragma unroll
             for (int x = 0; x < DOCT; ++x) {
-                r.d[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x) * sc;
-                r.d[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4) * sc;
-            }
-            if (!live) {                                                 // rows past the type's end contribute nothing
-#pragma unroll
-                for (int x = 0; x < 2 * DOCT; ++x) r.d[x] = v4f{0.f, 0.f, 0.f, 0.f};
+                r.d[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
+                r.d[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
             }
             const float* hp = h + v * ld_h + HC * half + 4 * o;
             const float* sp = sums + v * ld_s + HC * half + 4 * o;
@@ -1039,6 +1039,8 @@ __global__ __launch_bounds__(kSplitThreads) void node_interact_weight_split_kern
         };
         // the wave's largest ea + eb (eight rows) -> tile_l[k & 3][wave]
         auto publish = [&](int k, Rows& r) {
+#pragma unroll
+            for (int x = 0; x < 2 * DOCT; ++x) r.d[x] *= (dy_scale != nullptr ? r.sc : 1.f) * r.keep;      // (here, a phase after the request - not where the rows are requested)
             row_exponents(r, r.ea, r.eb);
             const int ea = r.ea, eb = r.eb;
             int l = (ea >= 0 && eb >= 0) ? ea + eb : -1;
@@ -1448,12 +1450,16 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
 // DX (d = 128): the input gradient dx = dout W_t of the same rows is formed here too - a ROW contraction, whose rows need their full relative accuracy each: it reads a
 // second image of dout, every row scaled to 2^13 by itself (the balanced image of a small row is deliberately coarse), against weight planes scaled per output column
 // (pack_planes_dense_h2_kernel); wave w takes output columns 16 w .. with the type's planes in 32 registers - and the separate row-GEMM pass over dout goes away.
-template <int D, bool DX>
+// Round 5: every vector-memory request of the loop is unconditional (narrow.hip has the argument: the memory counter is in order and the compiler waits by count; a request
+// under a branch makes the next wait vmcnt(0)).  ACC (dx += instead of dx =) is a template parameter - its reads of dx were loads under a run-time flag -, and a lane whose dx
+// row lies past the type's end stores to a dump piece inside the workgroup's own slab (written for good only at the kernel's end) through a global-address-space pointer.
+template <int D, bool DX, bool ACC>
 __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(const float* __restrict__ dout, int64_t ld_dout, TypedRows x,
                                                                                 int64_t ld_x, RowTiles plan, int single_weight, float* __restrict__ slabs,
                                                                                 float* __restrict__ bias_slabs, const v4u* __restrict__ pk, int64_t pk_type_stride,
-                                                                                const float* __restrict__ winv, TypedRowsOut dx, int64_t ld_dx, int dx_accumulate) {
+                                                                                const float* __restrict__ winv, TypedRowsOut dx, int64_t ld_dx) {
     static_assert(!DX || D == 128, "the fused input gradient holds a whole weight matrix per workgroup");
+    static_assert(DX || !ACC, "accumulation is the fused input gradient's");
     constexpr int TE = 32, HALVES = D / 128, DOCT = D / 128, IT = D / 64, DRB = 2 * D;     // dout image rows: 2 D bytes, x image rows: 256 bytes (128 columns)
     constexpr int DPL = TE * DRB, XPL = TE * 256, kTarget = 24;
     __shared__ __attribute__((aligned(16))) unsigned char dplanes[2][2][TE][DRB];          // dout, balanced against x (dW)
@@ -1576,9 +1582,15 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
     };
 
     if (n_my > 0) {
-        Rows r0, r1;                                                     // rows of tile m in r<m & 1>: requested two tiles ahead, taken delivery of at the END of the requesting
-        load_rows(0, r0);                                                // phase (this kernel is not sensitive to that wait: 15_ab_node_level_backward_three_row_sets.txt) - where their
-        load_rows(std::min(1, n_my - 1), r1);                            // exponents are published, a phase before the split (a third set of rows spills here)
+        // rows of tile m in r<m % 3>: requested THREE tiles ahead and taken delivery of a phase later (round 5).  Two sets - delivery at the end of the requesting phase - made
+        // every phase sit out its own memory round trip behind a vmcnt(0); round 4 had measured three sets as no gain (15_ab_node_level_backward_three_row_sets.txt) while the
+        // loop still carried requests under branches (the dx reads under a run-time flag, the dx stores under `v < r_end`), which drain the counter whatever the row sets do.
+        // (THREE: where the registers allow it - d = 128 without accumulation; the accumulating instance and d = 256 spill with a third set and keep two)
+        constexpr bool THREE = D == 128 && !ACC;
+        Rows r0, r1, r2;
+        load_rows(0, r0);
+        load_rows(std::min(1, n_my - 1), r1);
+        if (THREE) load_rows(std::min(2, n_my - 1), r2);
         publish(0, r0);
         publish(1, r1);
         __syncthreads();
@@ -1609,8 +1621,9 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
         auto b_addr = [&](int r, int jt) { return r * 256 + (((8 * jh + 2 * jt + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
         auto fragment = [&](const unsigned char* lo, const unsigned char* hi) { return __builtin_bit_cast(v8h, read_tr_fragment(lo, hi)); };
 
-        // phase k: contraction of tile k (images k & 1); images of tile k + 1 from `use`; request of tile k + 2 (`fill`), delivered and its exponents published at the end
-        auto phase = [&](int k, Rows& use, Rows& fill) {
+        // phase k: contraction of tile k (images k & 1); images of tile k + 1 from `use`; request of tile k + 3 (`fill`); the rows of tile k + 2 (`arrive`, requested a phase
+        // ago) are delivered and their exponents published at the end
+        auto phase = [&](int k, Rows& use, Rows& arrive, Rows& fill) {
             const int BUF = k & 1;
             // the accumulators to the scale tile k was split under (it includes tile k's own rows); then the running maximum moves on to tile k + 1 for the split
             if (l_split != l_acc) {
@@ -1632,7 +1645,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
             // of this tile seed the accumulators of the dx product at the end of the phase.  Requested BEFORE the row requests: the memory
             // counter is in order, so the wait for these leaves the younger row requests in flight
             v4f gold[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
-            if (DX && dx_accumulate) {
+            if (DX && ACC) {
                 const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
@@ -1640,7 +1653,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                     gold[rt] = *reinterpret_cast<const v4f*>(typed_base(dx, row_type(v)) + v * ld_dx + 16 * wave + 4 * (lane >> 4));
                 }
             }
-            load_rows(std::min(k + 2, n_my - 1), fill);                  // (unconditional: a branch around requests makes the compiler wait for all of them)
+            load_rows(std::min(k + (THREE ? 3 : 2), n_my - 1), fill);    // (unconditional: a branch around requests makes the compiler wait for all of them)
             const unsigned char* dp = &dplanes[0][0][0][0] + BUF * (2 * DPL);
             const unsigned char* xp = &xplanes[0][0][0][0] + BUF * (2 * XPL);
             v8h a[IT][2];
@@ -1692,22 +1705,37 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                     gx[rt] = gx[rt] * (wiv * rown[BUF][r]) + gold[rt];
                 }
             }
-            publish(k + 2, fill);                                        // (takes delivery of the requested rows)
+            publish(k + 2, arrive);                                      // (takes delivery of the rows requested a phase ago: this phase's requests stay in flight)
             if (DX) {                                                    // (after the delivery: the counter is in order)
                 const int arow = lane & 15, kq = lane >> 4;
                 const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
                     const int64_t v = r_base + 16 * rt + arow;
-                    if (v < r_end && (!abl::d_no_stores || gx[rt][0] == 1.2345e30f)) *reinterpret_cast<v4f*>(typed_base(dx, row_type(v)) + v * ld_dx + 16 * wave + 4 * kq) = gx[rt];
+                    const int64_t vc = std::min(v, r_end - 1);
+                    uint64_t dst = v < r_end ? reinterpret_cast<uint64_t>(typed_base(dx, row_type(vc)) + vc * ld_dx + 16 * wave + 4 * kq)
+                                             : reinterpret_cast<uint64_t>(slabs + (static_cast<int64_t>(type) * n_seq + seq) * D * D + 4 * tid);
+                    asm("" : "+v"(dst));                                 // (opaque: left visible, the choice becomes two stores under complementary branches)
+                    if (!abl::d_no_stores || gx[rt][0] == 1.2345e30f) *reinterpret_cast<__attribute__((address_space(1))) v4f*>(dst) = gx[rt];
                 }
             }
             __syncthreads();
         };
         int k = 0;
-        for (; k < n_my; k += 2) {
-            phase(k, r1, r0);
-            if (k + 1 < n_my) phase(k + 1, r0, r1);
+        if (THREE) {
+#pragma clang loop unroll(disable)
+            for (; k + 2 < n_my; k += 3) {                                // exactly three phases per trip: the register sets come back in place
+                phase(k, r1, r2, r0);
+                phase(k + 1, r2, r0, r1);
+                phase(k + 2, r0, r1, r2);
+            }
+            if (k < n_my) phase(k, r1, r2, r0);
+            if (k + 1 < n_my) phase(k + 1, r2, r0, r1);
+        } else {                                                         // two sets: the rows a phase requests are delivered at its end
+            for (; k < n_my; k += 2) {
+                phase(k, r1, r0, r0);
+                if (k + 1 < n_my) phase(k + 1, r0, r1, r1);
+            }
         }
     }
     // slab [type][sequence][i][j]; accumulator tile (it, jt): row i = 16 (IT iq + it) + 4 (lane >> 4) + r, column j = 128 half + 64 jh + 16 jt + (lane & 15).
@@ -1933,18 +1961,22 @@ int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, Typed
                                wsc, winv);
             hipLaunchKernelGGL(pack_planes_dense_h2_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, w_type_stride, n_types,
                                dim, 1, wsc, pk);
-            hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, true>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
-                               n_types == 1 ? 1 : 0, slabs, bias_slabs, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 2 * kWave}, winv, dx, ld_dx, dx_accumulate);
+            if (dx_accumulate)
+                hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, true, true>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+                                   n_types == 1 ? 1 : 0, slabs, bias_slabs, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 2 * kWave}, winv, dx, ld_dx);
+            else
+                hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, true, false>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+                                   n_types == 1 ? 1 : 0, slabs, bias_slabs, pk, n_types == 1 ? int64_t{0} : int64_t{8 * 4 * 2 * kWave}, winv, dx, ld_dx);
         } else {
-            hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, false>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+            hipLaunchKernelGGL((dense_weight_grad_split_kernel<128, false, false>), dim3(n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
                                n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<const float*>(nullptr),
-                               typed_rows_out(nullptr), int64_t{0}, 0);
+                               typed_rows_out(nullptr), int64_t{0});
         }
         return n_seq;
     }
     const int n_seq = 128;
-    hipLaunchKernelGGL((dense_weight_grad_split_kernel<256, false>), dim3(2 * n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
+    hipLaunchKernelGGL((dense_weight_grad_split_kernel<256, false, false>), dim3(2 * n_seq, 1, n_types), dim3(kSplitThreads), 0, s, dout, ld_dout, x, ld_x, plan,
                        n_types == 1 ? 1 : 0, slabs, bias_slabs, static_cast<const v4u*>(nullptr), int64_t{0}, static_cast<const float*>(nullptr), typed_rows_out(nullptr),
-                       int64_t{0}, 0);
+                       int64_t{0});
     return n_seq;
 }
