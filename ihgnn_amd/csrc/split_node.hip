@@ -1582,15 +1582,13 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
     };
 
     if (n_my > 0) {
-        // rows of tile m in r<m % 3>: requested THREE tiles ahead and taken delivery of a phase later (round 5).  Two sets - delivery at the end of the requesting phase - made
-        // every phase sit out its own memory round trip behind a vmcnt(0); round 4 had measured three sets as no gain (15_ab_node_level_backward_three_row_sets.txt) while the
-        // loop still carried requests under branches (the dx reads under a run-time flag, the dx stores under `v < r_end`), which drain the counter whatever the row sets do.
-        // (THREE: where the registers allow it - d = 128 without accumulation; the accumulating instance and d = 256 spill with a third set and keep two)
-        constexpr bool THREE = D == 128 && !ACC;
-        Rows r0, r1, r2;
+        // rows of tile m in r<m & 1>: requested two tiles ahead, taken delivery of at the END of the requesting phase - where their exponents are published, a phase before the
+        // split.  This kernel is not sensitive to that wait: a third set of rows with delivery a phase later measured the same in round 4
+        // (15_ab_node_level_backward_three_row_sets.txt) and again in round 5 with every request of the loop unconditional and every wait an exact count (169 against 170 us at
+        // C3, 256 registers) - it is not the rows' latency this kernel waits for.
+        Rows r0, r1;
         load_rows(0, r0);
         load_rows(std::min(1, n_my - 1), r1);
-        if (THREE) load_rows(std::min(2, n_my - 1), r2);
         publish(0, r0);
         publish(1, r1);
         __syncthreads();
@@ -1621,9 +1619,8 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
         auto b_addr = [&](int r, int jt) { return r * 256 + (((8 * jh + 2 * jt + (pp >> 1)) ^ tr_swizzle(r)) << 4) + 8 * (pp & 1); };
         auto fragment = [&](const unsigned char* lo, const unsigned char* hi) { return __builtin_bit_cast(v8h, read_tr_fragment(lo, hi)); };
 
-        // phase k: contraction of tile k (images k & 1); images of tile k + 1 from `use`; request of tile k + 3 (`fill`); the rows of tile k + 2 (`arrive`, requested a phase
-        // ago) are delivered and their exponents published at the end
-        auto phase = [&](int k, Rows& use, Rows& arrive, Rows& fill) {
+        // phase k: contraction of tile k (images k & 1); images of tile k + 1 from `use`; request of tile k + 2 (`fill`), delivered and its exponents published at the end
+        auto phase = [&](int k, Rows& use, Rows& fill) {
             const int BUF = k & 1;
             // the accumulators to the scale tile k was split under (it includes tile k's own rows); then the running maximum moves on to tile k + 1 for the split
             if (l_split != l_acc) {
@@ -1653,7 +1650,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                     gold[rt] = *reinterpret_cast<const v4f*>(typed_base(dx, row_type(v)) + v * ld_dx + 16 * wave + 4 * (lane >> 4));
                 }
             }
-            load_rows(std::min(k + (THREE ? 3 : 2), n_my - 1), fill);    // (unconditional: a branch around requests makes the compiler wait for all of them)
+            load_rows(std::min(k + 2, n_my - 1), fill);                  // (unconditional: a branch around requests makes the compiler wait for all of them)
             const unsigned char* dp = &dplanes[0][0][0][0] + BUF * (2 * DPL);
             const unsigned char* xp = &xplanes[0][0][0][0] + BUF * (2 * XPL);
             v8h a[IT][2];
@@ -1705,7 +1702,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                     gx[rt] = gx[rt] * (wiv * rown[BUF][r]) + gold[rt];
                 }
             }
-            publish(k + 2, arrive);                                      // (takes delivery of the rows requested a phase ago: this phase's requests stay in flight)
+            publish(k + 2, fill);                                        // (takes delivery of the requested rows)
             if (DX) {                                                    // (after the delivery: the counter is in order)
                 const int arow = lane & 15, kq = lane >> 4;
                 const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
@@ -1722,20 +1719,9 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
             __syncthreads();
         };
         int k = 0;
-        if (THREE) {
-#pragma clang loop unroll(disable)
-            for (; k + 2 < n_my; k += 3) {                                // exactly three phases per trip: the register sets come back in place
-                phase(k, r1, r2, r0);
-                phase(k + 1, r2, r0, r1);
-                phase(k + 2, r0, r1, r2);
-            }
-            if (k < n_my) phase(k, r1, r2, r0);
-            if (k + 1 < n_my) phase(k + 1, r2, r0, r1);
-        } else {                                                         // two sets: the rows a phase requests are delivered at its end
-            for (; k < n_my; k += 2) {
-                phase(k, r1, r0, r0);
-                if (k + 1 < n_my) phase(k + 1, r0, r1, r1);
-            }
+        for (; k < n_my; k += 2) {
+            phase(k, r1, r0);
+            if (k + 1 < n_my) phase(k + 1, r0, r1);
         }
     }
     // slab [type][sequence][i][j]; accumulator tile (it, jt): row i = 16 (IT iq + it) + 4 (lane >> 4) + r, column j = 128 half + 64 jh + 16 jt + (lane & 15).
