@@ -287,13 +287,18 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             // (Round 5 tried the streaming form - config C5's kernel - with this phase's requests first and then the work on what was requested a PHASE AGO behind one exact
             // wait, every request unconditional: the loop's waits became vmcnt(11 .. 22) instead of two vmcnt(0) per trip, and the kernel went 29.7 -> 31.1 ms at C5: it does not
             // wait for latency - 78 GB of L2-miss traffic and a matrix pipe half busy share its 30 ms.  Reverted.)
+            // The id fetch of the tile four ahead comes FIRST and is unconditional (every lane, clamped tile - round 5): it used to sit behind the row requests under
+            // `k + 4 + AHEAD < n_my && st < 96`, the only requests younger than it were the epilogue's stores - themselves under `live` - and the wait for it at the top of the
+            // next phase was vmcnt(0): every other phase drained the queue, the previous phase's six stores included.  With the row requests behind it the wait is an exact
+            // count that leaves them (and the stores) in flight.
+            const int id_new = fetch_id(std::min(k + 4 + AHEAD, n_my - 1));
             // ids of tile k + 3 + AHEAD (requested in the previous phase) into the ring: a phase ahead of their first readers (the gathered rows of
             // that tile in the next phase)
             if (k >= 1 && k + 3 + AHEAD < n_my && st < 3 * TE) ids[(k + 3 + AHEAD) & 7][st] = id_carry;
             load_members(k, hm_cur);                                     // unconditional: a branch around requests costs whole-set register copies
             if (GATHER) load_gather(k + 3, raw_req);
             else load_dout(k + 2, fill);
-            if (k + 4 + AHEAD < n_my && st < 3 * TE) id_carry = fetch_id(k + 4 + AHEAD);
+            id_carry = id_new;
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
             // delivery of this phase's requests, THEN everything that stores: the memory counter is in order, a wait behind a store sits out
             // the store's round trip to memory
