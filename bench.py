@@ -215,13 +215,18 @@ def k7_roles(table, E, N, dim, layout, table_steps):
     # 4 B id + 4 B multiplicity) unless IHG_TWO_HOP_MERGED=0: fewer gathers than the 6 E of the plain list
     hop = layout.two_hop_merged()[0].nnz if _ops.TWO_HOP_MERGED else 6 * E
     hop_ids = 8 * hop if _ops.TWO_HOP_MERGED else 24 * E
+    # member-gradient buffers beyond ops.MEMBER_BUFFER_LIMIT_BYTES are produced and scattered in hyperedge chunks (config C5): a launch walks 1 / chunks of the rows
+    c3 = max(1, -(-(3 * E * row) // _ops.MEMBER_BUFFER_LIMIT_BYTES))
+    c2 = max(1, -(-(2 * E * row) // _ops.MEMBER_BUFFER_LIMIT_BYTES))
     roles = {
         # name: (source rows, gathers, id bytes, what)
         'k7.edges_to_nodes': (E, 3 * E, 12 * E, 'forward of the interactive layer: [E,d] hyperedge features -> [N,d] (x Dv^-1)'),
         'k7.first_order_gradient': (E, 3 * E, 12 * E, 'backward: [E,d] cotangent -> d P0 [N,d]'),
-        'k7.member_gradients': (3 * E, 3 * E, 12 * E, 'backward: [E,3,d] member gradients -> d H [N,d] (every row read exactly once)'),
-        'k7.member_gradients_rows': (2 * E, 2 * E, 8 * E, 'backward: [E,2,d] query / item member gradients -> d H rows of queries and items (the user slot '
-                                                          'was summed on chip by the member-gradient kernel); every row read exactly once'),
+        'k7.member_gradients': (3 * E // c3, 3 * E // c3, 12 * E // c3, 'backward: [E,3,d] member gradients -> d H [N,d] (every row read exactly once'
+                                + (f'; {c3} hyperedge chunks, bytes per launch' if c3 > 1 else '') + ')'),
+        'k7.member_gradients_rows': (2 * E // c2, 2 * E // c2, 8 * E // c2, 'backward: [E,2,d] query / item member gradients -> d H rows of queries and items (the user slot '
+                                                          'was summed on chip by the member-gradient kernel); every row read exactly once'
+                                     + (f'; {c2} hyperedge chunks, bytes per launch' if c2 > 1 else '')),
         'k7.two_hop': (N, hop + N, hop_ids, 'first-order layer forward: node table -> node table over the (merged) two-hop list (no [E,d] intermediate)'),
         'k7.two_hop_bwd': (N, hop + N, hop_ids, 'first-order layer backward (same operator, scalings swapped)'),
         'k7.two_hop_bwd_masked': (N, hop + N, hop_ids, 'backward of the LAST first-order layer: its cotangent is zero outside the 3B batch rows (the output feeds the batch '

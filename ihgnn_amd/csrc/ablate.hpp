@@ -107,5 +107,20 @@ constexpr bool d_no_stores = true;
 #else
 constexpr bool d_no_stores = false;
 #endif
-constexpr bool any = d_no_dw || d_no_dx || d_no_split || d_no_loads || d_no_stores || n_no_service || n_no_fragments || n_no_reload || n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
+#ifdef IHG_ABL_M_G_WINDOW          // member gradients: the member buffer's stores land in a 48 MB window (same instructions, no HBM write traffic) - round 5: same time
+constexpr bool m_g_window = true;
+#else
+constexpr bool m_g_window = false;
+#endif
+#ifdef IHG_ABL_M_G_PARTS           // member gradients: every column part writes a contiguous stream of its own ([part][e][slot][columns]) - round 5: same time
+constexpr bool m_g_parts = true;
+#else
+constexpr bool m_g_parts = false;
+#endif
+#ifdef IHG_ABL_M_G_PLAIN           // member gradients: plain instead of non-temporal stores of the member buffer - round 5: same time
+constexpr bool m_g_plain = true;
+#else
+constexpr bool m_g_plain = false;
+#endif
+constexpr bool any = m_g_window || m_g_parts || m_g_plain || d_no_dw || d_no_dx || d_no_split || d_no_loads || d_no_stores || n_no_service || n_no_fragments || n_no_reload || n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
 }  // namespace abl

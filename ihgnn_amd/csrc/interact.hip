@@ -1231,7 +1231,7 @@ __global__ __launch_bounds__(kWsThreads) void interact_bwd_members_strip_kernel(
 // that opens a user's run (the valid entry before it belongs to another user) walks on while the following entries carry the same
 // user - nearly always one or two - and writes dh[user]; every other workgroup leaves at once.  Same order of additions as a single
 // walk over the table.
-__global__ __launch_bounds__(128) void user_boundary_fixup_kernel(const float* __restrict__ bnd_val, const int32_t* __restrict__ bnd_user, int n_entries, int d,
+__global__ __launch_bounds__(256) void user_boundary_fixup_kernel(const float* __restrict__ bnd_val, const int32_t* __restrict__ bnd_user, int n_entries, int d,
                                                                   float* __restrict__ dh_user, int64_t ld_dh) {
     const int k0 = blockIdx.x, c = threadIdx.x;
     const int user = bnd_user[k0];
@@ -1890,7 +1890,7 @@ inline int weight_slabs(int dim) {
 constexpr int kFwdGrid = 256 * 3;
 constexpr int kPipeGrid = 256;          // wave-specialised and strip kernels: one 512-thread workgroup per CU
 // tile ranges of the user-reduced member-gradient kernels (two boundary-table entries each): one per workgroup at d = 64 / 128, one per wave at d = 32 (narrow.hip)
-inline int64_t boundary_ranges(int dim) { return dim == 128 || dim == 64 ? kPipeGrid : (dim == kNarrowDim ? kNarrowMemberRanges : 0); }
+inline int64_t boundary_ranges(int dim) { return dim == 128 || dim == 64 || dim == 256 ? kPipeGrid : (dim == kNarrowDim ? kNarrowMemberRanges : 0); }
 
 // Persistent grid of a plain (one role) tiling: as many workgroups as are resident at once - a larger grid runs in rounds, and
 // the workgroups of the last round start when the others have already walked their whole share of the tiles.
@@ -1989,7 +1989,7 @@ void launch_interact_bwd_mfma(int dim, const float* h, int64_t ld_h, const int32
         int entries = 0;
         launch_members_split(dim, NBLK == 4 ? 3 : 2, h, ld_h, i3, w_raw, ld_w, planes, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, &entries, s,
                              dy_scale, dout_store, ld_store);
-        if (dh_user != nullptr) hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(entries), dim3(128), 0, s, bnd_val, bnd_user, entries, dim, dh_user, ld_dh);
+        if (dh_user != nullptr) hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(entries), dim3(std::max(128, dim)), 0, s, bnd_val, bnd_user, entries, dim, dh_user, ld_dh);
         if (dout_store != nullptr) {
             dout = dout_store;
             ld_dout = ld_store;
@@ -2162,8 +2162,8 @@ int64_t ihg_interact_bwd_workspace_bytes(int64_t n_edges, int32_t dim, int32_t o
 }
 
 int32_t ihg_interact_bwd_user_reduced_supported(int32_t dim, int32_t order, int64_t ld_h) {
-    // d = 128: the split kernel or the fp32 strip kernel; d = 64: the split kernel only (its fp32-MFMA kernels have no user-reduced form); d = 32: narrow.hip (fp32 MFMA)
-    return (dim == 128 || dim == kNarrowDim || (dim == 64 && split_arith_enabled())) && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_h < (int64_t{1} << 30) ? 1 : 0;
+    // d = 128: the split kernel or the fp32 strip kernel; d = 64, 256: the split kernel only (their fp32-MFMA kernels have no user-reduced form); d = 32: narrow.hip (fp32 MFMA)
+    return (dim == 128 || dim == kNarrowDim || ((dim == 64 || dim == 256) && split_arith_enabled())) && (order == 2 || order == 3) && ld_h % 4 == 0 && ld_h < (int64_t{1} << 30) ? 1 : 0;
 }
 
 int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
@@ -2194,7 +2194,7 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
 }
 
 int32_t ihg_interact_bwd_gathered_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_dy) {
-    return ihg_interact_bwd_user_reduced_supported(dim, order, ld_h) && (split_arith_enabled() || dim == kNarrowDim) && ld_dy >= dim && ld_dy % 4 == 0 && ld_dy < (int64_t{1} << 30) ? 1 : 0;
+    return dim != 256 && ihg_interact_bwd_user_reduced_supported(dim, order, ld_h) && (split_arith_enabled() || dim == kNarrowDim) && ld_dy >= dim && ld_dy % 4 == 0 && ld_dy < (int64_t{1} << 30) ? 1 : 0;
 }
 
 int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,

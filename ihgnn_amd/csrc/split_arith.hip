@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
 // tile range here, shared by the two halves).  (First form: every wave scanned 16 columns of all 32 rows with a scalar reset factor and
 // wrote the inclusive sums back for an emit loop - four times the additions on a quarter of the lanes, three LDS round trips in series.)
 // D = 128: two column halves of 64 per tile range.  D = 256: eight parts of 32 columns (the weight planes are 1 MB), the dout tile is 32 KB
-// and every part splits it again.  D = 64: one workgroup holds all of it.  No user reduction at 256.
+// and every part splits it again (UR there: round 5 - 32 lanes of a matrix wave carry the part's columns, the other 32 mirror them).  D = 64: one workgroup holds all of it.
 // NBLK = 3 (order 2): matrix wave 3 has no block; it keeps the barriers and its window of the user sums.
 // GATHER (D = 128, UR): there is no dout tensor yet - the cotangent of a hyperedge is the scaled sum of its three members' rows of a
 // node-level cotangent dy ([N, d]; dout[e] = sum_m dy_scale[m] dy[m], the transpose of the hyperedge -> node pass that follows the
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                                                                                       int64_t ld_dh, float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user,
                                                                                       const float* __restrict__ dy_scale = nullptr,
                                                                                       float* __restrict__ dout_store = nullptr, int64_t ld_store = 0) {
-    static_assert(D == 128 || D == 64 || (D == 256 && !UR), "shapes");     // the user-slot reduction is written for column parts of 64 (d = 128: two, d = 64: one)
+    static_assert(D == 128 || D == 64 || D == 256, "shapes");
     static_assert(!GATHER || ((D == 128 || D == 64) && UR), "the gathering form exists where the layer's backward uses it");
     constexpr int TE = kSplitTE, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, KB = D / 32, RB = 2 * D;
     constexpr int SWZ = RB / 16 - 1 < 15 ? RB / 16 - 1 : 15;            // the row swizzle stays inside a row (D = 64: rows of 8 chunks)
@@ -248,13 +248,21 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 const bool live = e < n_edges;
                 if (UR) *reinterpret_cast<v4f*>(&utile[(k - 1) & 1][row][c]) = live ? g_u : v4f{0.f, 0.f, 0.f, 0.f};     // (rows past the end: zeros for the sums)
                 if (live && !abl::m_no_g_stores) {
-                    float* dst = g_out + e * (GS * D) + HC * half + c;
+                    // (where the stores land does not matter: into a 48 MB window, as one contiguous stream per column part or as plain stores the kernel takes the same
+                    // time - ablate.hpp, profiles/r5/22_abl_member_stores_d256.txt: removing them "saves" 10 of 18 ms only because the product rule goes with them)
+                    const int64_t er = abl::m_g_window ? (e & 0x3fff) : e;
+                    constexpr int SS = abl::m_g_parts ? HC : D;
+                    float* dst = abl::m_g_parts ? g_out + (static_cast<int64_t>(half) * n_edges + er) * (GS * HC) + c : g_out + er * (GS * D) + HC * half + c;
+                    auto put = [](float* p, v4f v) {
+                        if (abl::m_g_plain) *reinterpret_cast<v4f*>(p) = v;
+                        else store_stream4(p, v);
+                    };
                     if (!UR) {
-                        store_stream4(dst, g_u);
-                        dst += D;
+                        put(dst, g_u);
+                        dst += SS;
                     }
-                    store_stream4(dst, g_q);
-                    store_stream4(dst + D, g_i);
+                    put(dst, g_q);
+                    put(dst + SS, g_i);
                 }
             }
         };
@@ -349,7 +357,10 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     int cur_user = -1, first_user = -1;
     bool first_run_open = true;                                      // no run has ended yet in this range
     float* const first_slot = UR ? bnd_val + static_cast<int64_t>(2 * range) * D : nullptr;
-    const int colg = HC * half + lane, win = wave;
+    // (D = 256: parts of 32 columns - the upper half of a wave mirrors the lower one's column (ul) through the sums and leaves the stores to it (uw))
+    const int ul = lane & (HC - 1);
+    const bool uw = lane < HC;
+    const int colg = HC * half + ul, win = wave;
     uint64_t heads_prev = 0;                                         // run starts / user ids / rows of the tile whose windows were summed a phase ago
     int uid_prev = 0, rows_prev = 0;
     auto run_target = [&](int t, int r, int uid) {                   // destination of the run that starts at row r of tile t
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     };
     auto load_window = [&](int t, float (&v)[8]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = utile[t & 1][8 * win + i][lane];
+        for (int i = 0; i < 8; ++i) v[i] = utile[t & 1][8 * win + i][ul];
     };
     auto sum_window = [&](int t, const float (&v)[8]) {              // tile t, 0 <= t < n_my
         const int* idk = ids[t & 7];
@@ -376,21 +387,25 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             sum = sum * ((mw >> i) & 1 ? 0.f : 1.f) + v[i];
             pre[i] = sum;
         }
-        utail[t & 1][win][lane] = sum;
+        utail[t & 1][win][ul] = sum;
         if (mw != 0) {                                               // (0.85 run starts per window on C3)
-            auto before = [&](int i) {                               // running sum in front of window row i
-                float x = 0.f;
+            // Row i + 1 starts a run: the run row i belongs to ends at row i.  Begun inside the window (a start at or before i): its sum is pre[i] and goes to its user's
+            // row; begun earlier: pre[i] is the window's piece in front of its first start (uhead; a start at the window's row 0: nothing in front).  Unrolled over i with
+            // wave-uniform conditions - compile-time register indices, no selection chains.  (Round 4's form looped over the set bits and picked pre[next - 1] through seven
+            // selects per run: 310 instructions and 34 branches in a matrix wave's phase beside its 96 MFMAs.)
+            if (mw & 1u) uhead[t & 1][win][ul] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 7; ++j) x = i == j + 1 ? pre[j] : x;
-                return x;
-            };
-            unsigned left = mw;
-            int start = __builtin_ctz(left);
-            uhead[t & 1][win][lane] = before(start);
-            for (left &= left - 1; left != 0; left &= left - 1) {
-                const int next = __builtin_ctz(left);
-                run_target(t, 8 * win + start, uid)[colg] = before(next);
-                start = next;
+            for (int i = 0; i < 7; ++i) {
+                const unsigned upto = mw & ((2u << i) - 1u);         // starts at window rows 0 .. i
+                if ((mw >> (i + 1)) & 1u) {
+                    if (upto != 0) {
+                        float* dst = (t == 0 && win == 0 && upto == 1u) ? first_slot
+                                                                         : dh_user + static_cast<int64_t>(__builtin_amdgcn_readlane(uid, 8 * win + i)) * ld_dh;
+                        if (uw) dst[colg] = pre[i];
+                    } else {
+                        uhead[t & 1][win][ul] = pre[i];
+                    }
+                }
             }
         }
     };
@@ -399,9 +414,9 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     };
     auto load_chain = [&](int t, Chain& c) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) c.tail[w] = utail[t & 1][w][lane];
-        c.head = uhead[t & 1][win][lane];
-        c.carry = ucarry[t & 1][lane];
+        for (int w = 0; w < 4; ++w) c.tail[w] = utail[t & 1][w][ul];
+        c.head = uhead[t & 1][win][ul];
+        c.carry = ucarry[t & 1][ul];
     };
     auto chain_windows = [&](int t, const Chain& c) {                // tile t, a phase after sum_window(t)
         const unsigned m = static_cast<unsigned>(heads_prev);
@@ -413,11 +428,13 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             for (int w = 0; w < 3; ++w)
                 if (w < win && w >= p) sum += c.tail[w];
             if (((m >> (8 * win)) & 0xffu) != 0) {                   // the open run ends at this window's first run start
-                if (p >= 0) run_target(t, 31 - __builtin_clz(before_me), uid_prev)[colg] = sum + c.head;
-                else if (cur_user >= 0) (first_run_open ? first_slot : dh_user + static_cast<int64_t>(cur_user) * ld_dh)[colg] = sum + c.head;
+                float* dst = nullptr;
+                if (p >= 0) dst = run_target(t, 31 - __builtin_clz(before_me), uid_prev);
+                else if (cur_user >= 0) dst = first_run_open ? first_slot : dh_user + static_cast<int64_t>(cur_user) * ld_dh;
+                if (dst != nullptr && uw) dst[colg] = sum + c.head;
                 sum = 0.f;
             }
-            if (win == 3) ucarry[(t + 1) & 1][lane] = sum + c.tail[3];
+            if (win == 3) ucarry[(t + 1) & 1][ul] = sum + c.tail[3];
         }
         if (t == 0) first_user = __builtin_amdgcn_readlane(uid_prev, 0);
         if (m != 0) first_run_open = t == 0 && m == 1u;
@@ -477,8 +494,8 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     if (UR) {
         // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
         const bool one_run = first_run_open;
-        if (cur_user >= 0 && wave == 0) {
-            const float run_sum = ucarry[n_my & 1][lane];            // (written before the last barrier)
+        if (cur_user >= 0 && wave == 0 && uw) {
+            const float run_sum = ucarry[n_my & 1][ul];              // (written before the last barrier)
             if (one_run) first_slot[colg] = run_sum;
             else bnd_val[static_cast<int64_t>(2 * range + 1) * D + colg] = run_sum;
         }
@@ -1099,9 +1116,10 @@ bool split_arith_enabled() {                                             // read
     return v == nullptr || std::strcmp(v, "f32") != 0;
 }
 
-// dim 128: either form of g; dim 64, 256: the [E, 3, d] form only
+// either form of g at every width (the gathering form: dim 64 and 128, the caller asks ihg_interact_bwd_gathered_supported)
 bool split_members_ok(int dim, int order, const float* g, int64_t ld_h, int64_t ld_dout, const float* dout, bool user_reduced) {
-    return split_arith_enabled() && (dim == 128 || dim == 64 || (dim == 256 && !user_reduced)) && (order == 2 || order == 3) && aligned16(g) && aligned16(dout) &&
+    (void)user_reduced;
+    return split_arith_enabled() && (dim == 128 || dim == 64 || dim == 256) && (order == 2 || order == 3) && aligned16(g) && aligned16(dout) &&
            ld_ok(ld_h) && ld_ok(ld_dout);
 }
 
@@ -1116,11 +1134,11 @@ void launch_members_split_t(const float* h, int64_t ld_h, const int32_t* i3, con
                                n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store);
             return;
         }
-        if (dh_user != nullptr) {
-            hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, true, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges,
-                               dh_user, ld_dh, bnd_val, bnd_user);
-            return;
-        }
+    }
+    if (dh_user != nullptr) {
+        hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, true, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges,
+                           dh_user, ld_dh, bnd_val, bnd_user);
+        return;
     }
     hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, false, NBLK>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges,
                        static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr));
@@ -1146,7 +1164,7 @@ void launch_members_split(int dim, int order, const float* h, int64_t ld_h, cons
     }
     if (dim == 256) IHG_MEMBERS(256) else if (dim == 64) IHG_MEMBERS(64) else IHG_MEMBERS(128)
 #undef IHG_MEMBERS
-    if (n_boundary_entries != nullptr) *n_boundary_entries = 2 * (dim == 64 ? 256 : kSplitRanges);     // two per tile range (d = 64: one workgroup per range, 256 ranges)
+    if (n_boundary_entries != nullptr) *n_boundary_entries = 2 * (dim == 64 ? 256 : (dim == 128 ? kSplitRanges : 32));     // two per tile range (256 workgroups / column parts: 256, 128, 32 ranges)
 }
 
 bool split_weight_ok(int dim, int order, int64_t ld_h, int64_t ld_dout, const float* dout) {

@@ -1285,11 +1285,14 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_dense_h2_kernel(con
 // four shuffles), the weights by one per output column; the accumulators leave through the two inverse scales.  Half the MFMAs and two thirds of the weight / image
 // registers of the three-bf16 form - the registers pay for a THIRD set of row pieces: a tile's rows are requested three tiles ahead and taken delivery of a whole phase
 // after the request (two tiles of 16 KB in flight per workgroup instead of one: the kernel is a stream whose rate is bytes in flight over the memory round trip).
-template <int D>
+// ACC (out += ...) is a template parameter (round 5): as a run-time flag its two accumulator-shaped registers and the branch around their loads were in every instance - at
+// D = 256 the four registers the kernel spilled (256 VGPRs + 20 B of scratch per lane; now no scratch).
+template <int D, bool ACC>
 __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, int64_t ld_in, const v4u* __restrict__ pk,
                                                                              int64_t pk_type_stride, const float* __restrict__ winv, const float* __restrict__ bias, int bias_mask,
-                                                                             int64_t bias_type_stride, RowTiles plan, TypedRowsOut out, int64_t ld_out, int accumulate) {
+                                                                             int64_t bias_type_stride, RowTiles plan, TypedRowsOut out, int64_t ld_out) {
     constexpr int TE = 32, KB = D / 32, OCT = D / 128, HALVES = D / 128, RB = 2 * D, STEPS = 2 * KB;
+    constexpr bool EARLY_IMAGE = D == 256 && ACC;                        // the accumulating instance at D = 256 writes a finished 16-byte piece of the next tile's images at once: the registers that would hold it to the end of the phase are the ones it lacked
     constexpr int NBUF = D == 128 ? 6 : 3;                               // sets of row pieces: a tile's rows are requested NBUF tiles ahead, NBUF - 2 tiles (16 KB each) in flight
     __shared__ __attribute__((aligned(16))) unsigned char planes[2][2][TE][RB];
     __shared__ float sinv[2][TE];                                        // inverse row scales of the tile whose images are in planes[.]
@@ -1379,7 +1382,7 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
         // accumulate: `out` already holds another contribution to the same rows (out += ...): its rows of this tile are requested FIRST - older than the row requests
         // below, so the wait for them at the end of the phase leaves those in flight
         v4f gold[2] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};
-        if (accumulate) {
+        if (ACC) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const int64_t v = std::min(r_base + 16 * rt + arow, r_end - 1);
@@ -1405,16 +1408,22 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
                 split_pair_h2(use[2 * x + (pr >> 1)][2 * (pr & 1)] * sc_next, use[2 * x + (pr >> 1)][2 * (pr & 1) + 1] * sc_next, hh, ll);
                 sp[x][0][pr] = hh;
                 sp[x][1][pr] = ll;
+                if (EARLY_IMAGE && pr == 3) {                            // (the other image buffer was last read a phase ago)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk + 256 * x]) = sp[x][p];
+                }
             }
 #pragma unroll
             for (int term = 0; term < 3; ++term)
                 acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[kb][kTermB2[term]], a[kTermA2[term]], acc[rt], 0, 0, 0);
         }
         const float iv0 = sinv[k & 1][arow], iv1 = sinv[k & 1][16 + arow];
+        if (!EARLY_IMAGE) {
 #pragma unroll
-        for (int x = 0; x < OCT; ++x)
+            for (int x = 0; x < OCT; ++x)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk + 256 * x]) = sp[x][p];     // (past the last tile: nobody reads it)
+                for (int p = 0; p < 2; ++p) *reinterpret_cast<v4u*>(&planes[(k + 1) & 1][p][row][chunk + 256 * x]) = sp[x][p];     // (past the last tile: nobody reads it)
+        }
         if (o == 0) sinv[(k + 1) & 1][row] = inv_next;
         // delivery of the rows requested a phase ago, before the stores (the memory counter is in order: a wait behind a store sits out the store's round trip)
         if (OCT == 1) asm volatile("" : "+v"(arrive[0]), "+v"(arrive[1]));
@@ -1422,7 +1431,11 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const int64_t v = r_base + 16 * rt + arow;
-            if (v < r_end) *reinterpret_cast<v4f*>(typed_base(out, type) + v * ld_out + c4) = acc[rt] * (wiv * (rt == 0 ? iv0 : iv1)) + bv + gold[rt];
+            if (v < r_end) {
+                v4f y = acc[rt] * (wiv * (rt == 0 ? iv0 : iv1)) + bv;
+                if (ACC) y += gold[rt];
+                *reinterpret_cast<v4f*>(typed_base(out, type) + v * ld_out + c4) = y;
+            }
         }
         __syncthreads();
     };
@@ -1783,14 +1796,17 @@ void launch_row_gemm_split(int dim, TypedRows in, int64_t ld_in, const float* w,
     plan.tile_prefix[3] = acc;
     if (acc == 0) return;
     const int64_t pk_type_stride = n_types == 1 ? int64_t{0} : static_cast<int64_t>(dim / 16) * (dim / 32) * 2 * kWave;
+    const int n_seq = std::min((acc + 7) / 8 * 8, 256);                  // (d = 256) tile sequences: a multiple of 8, so that both halves of one land on one XCD
+#define IHG_ROW_GEMM(D, ACC, GRID) \
+    hipLaunchKernelGGL((row_gemm_split_kernel<D, ACC>), dim3(GRID), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, winv, bias, bias_mask, bias_type_stride, plan, out, ld_out)
     if (dim == 128) {
-        hipLaunchKernelGGL(row_gemm_split_kernel<128>, dim3(std::min(acc, 256)), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, winv, bias, bias_mask, bias_type_stride, plan,
-                           out, ld_out, accumulate);
+        if (accumulate) IHG_ROW_GEMM(128, true, std::min(acc, 256));
+        else IHG_ROW_GEMM(128, false, std::min(acc, 256));
     } else {
-        const int n_seq = std::min((acc + 7) / 8 * 8, 256);              // tile sequences: a multiple of 8, so that both halves of one land on one XCD
-        hipLaunchKernelGGL(row_gemm_split_kernel<256>, dim3(2 * n_seq), dim3(512), 0, s, in, ld_in, pk, pk_type_stride, winv, bias, bias_mask, bias_type_stride, plan, out,
-                           ld_out, accumulate);
+        if (accumulate) IHG_ROW_GEMM(256, true, 2 * n_seq);
+        else IHG_ROW_GEMM(256, false, 2 * n_seq);
     }
+#undef IHG_ROW_GEMM
 }
 
 // node-level forward of the interactive layer: node_interact_fwd_grouped_kernel (d = 128), node_interact_fwd_grouped256_kernel (d = 256), node_interact_fwd_q_kernel (d = 64)

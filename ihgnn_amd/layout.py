@@ -263,6 +263,40 @@ class IncidenceLayout:
             self._member_qi = (csr, torch.from_numpy(rows).to(self.device))
         return self._member_qi
 
+    def member_csr_qi_chunks(self, n_chunks: int):
+        """``[(e0, e1, Csr, rows)]``: ``member_csr_qi`` cut by hyperedge range for the user-reduced backward in pieces (config C5 on one GPU: ``[E, 2, d]`` is
+        102 GB), ids rebased to the chunk (``2 (e - e0) + slot - 1``).  The cuts fall where the USER changes (hyperedges are numbered by user: user ``u`` owns
+        ``[rowptr[u], rowptr[u + 1])``), so no user's run of hyperedges meets two launches and every launch writes its own users' rows of ``dh``."""
+        cache = self.__dict__.setdefault('_member_qi_chunks', {})
+        if n_chunks not in cache:
+            u, n, e = self.user_count, self.node_count, self.edge_count
+            ptr = self._rowptr_host.astype(np.int64)
+            starts = ptr[:u + 1]                                  # first hyperedge of every user (and E)
+            step = -(-e // n_chunks)
+            cuts = [0]
+            for c in range(1, n_chunks):
+                cut = int(starts[min(np.searchsorted(starts, c * step, side='left'), u)])
+                if cut > cuts[-1] and cut < e:
+                    cuts.append(cut)
+            cuts.append(e)
+            first = ptr[u]
+            edge_of_entry = self._edge_ids_host[first:].astype(np.int64)
+            slot = self._slot_of_entry[first:].astype(np.int64) - 1
+            lens_all = np.diff(ptr)[u:]
+            row_of_entry = np.repeat(np.arange(u, n, dtype=np.int64), lens_all)
+            chunks = []
+            for e0, e1 in zip(cuts[:-1], cuts[1:]):
+                pick = (edge_of_entry >= e0) & (edge_of_entry < e1)
+                counts = np.bincount(row_of_entry[pick], minlength=n)
+                ptr2 = np.zeros(n + 1, np.int64)
+                np.cumsum(counts, out=ptr2[1:])
+                ids2 = (edge_of_entry[pick] - e0) * 2 + slot[pick]
+                csr = Csr(ptr2.astype(np.int32), ids2.astype(np.int32), self.device, self.node_csr.heavy_threshold)
+                rows = (u + np.argsort(-counts[u:], kind='stable')).astype(np.int32)
+                chunks.append((e0, e1, csr, torch.from_numpy(rows).to(self.device)))
+            cache[n_chunks] = chunks
+        return cache[n_chunks]
+
     def member_csr_chunks(self, n_chunks: int):
         """``[(e0, e1, Csr)]``: the member lists of ``member_csr`` cut by hyperedge range, ids rebased to the chunk
         (``3 (e - e0) + type(v)``).  For the interactive backward when the ``[E, 3, d]`` member-gradient buffer has to be produced

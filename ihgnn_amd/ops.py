@@ -81,14 +81,14 @@ def node_segment_sum_raw(src: Tensor, csr: Union[Csr, CsrRows], src_scale: Optio
     """``role`` names the launch for the profiler (one kernel, several jobs with different byte counts: ``bench.py`` reports each).
     ``rows`` (int32, device): only these output rows are needed.  The split rows of the plan are always computed; of the
     others only the listed ones are, and the rest of ``out`` is left unwritten.  ``src_mask`` (uint8 per source row): rows with a 0
-    are all-zero and are not fetched.  ``accumulate``: ``out +=`` instead of ``out =`` (``out`` required; the hyperedge chunks of one scatter).
+    are all-zero and are not fetched.  ``accumulate``: ``out +=`` instead of ``out =`` (``out`` required; the hyperedge chunks of one scatter; with ``rows``: the listed rows and the plan's split rows).
     ``read_once``: every source row is read exactly once by this launch (non-temporal loads)."""
     lib = _lib.load()
     src = _rows(src, 'src')
     dim = int(src.shape[1])
     if accumulate:
-        if out is None or rows is not None:
-            raise ValueError('accumulate needs an existing `out` and all rows')
+        if out is None:
+            raise ValueError('accumulate needs an existing `out`')
         mode = mode | _lib.SCALE_ACCUMULATE
     if read_once:
         mode = mode | _lib.SRC_READ_ONCE
@@ -640,7 +640,7 @@ def node_linear(x, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, t
 MEMBER_BUFFER_LIMIT_BYTES = 48 << 30
 # use ihg_interact_bwd_user_reduced (user slot summed on chip, [E, 2, d] member buffer) where the library offers it (tests set this attribute to compare with the
 # [E, 3, d] form, which every shape without such a kernel runs anyway)
-USER_REDUCED_BACKWARD = True
+USER_REDUCED_BACKWARD = _os.environ.get('IHG_USER_REDUCED_BACKWARD', '1') != '0'
 # the last layer of a training step is told which rows of its output are read (node_two_hop's cotangent_rows): its backward pulls only those
 SPARSE_LAST_COTANGENT = _os.environ.get('IHG_SPARSE_LAST_COTANGENT', '1') != '0'
 CHECK_SPARSE_COTANGENT = _os.environ.get('IHG_CHECK_SPARSE_COTANGENT', '0') == '1'
@@ -681,23 +681,37 @@ def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: Incidence
     its own member lists (``IncidenceLayout.member_csr_chunks``): same sums, associated chunk by chunk."""
     lib = _lib.load()
     n_edges, dim = layout.edge_count, int(h.shape[1])
-    n_chunks = max(1, -(-(n_edges * 3 * dim * 4) // MEMBER_BUFFER_LIMIT_BYTES))
-    if (n_chunks == 1 and USER_REDUCED_BACKWARD and n_edges > 0 and getattr(layout, 'user_sorted', False)
+    if (USER_REDUCED_BACKWARD and n_edges > 0 and getattr(layout, 'user_sorted', False)
             and lib.ihg_interact_bwd_user_reduced_supported(dim, order, _ld(h)) and h.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
             and _ld(w) % 4 == 0 and _ld(grad_out) % 4 == 0 and grad_out.data_ptr() % 16 == 0):
         # hyperedges are numbered by user: the kernel sums the user slot on chip and writes dh[users] itself; only the query and item
-        # slots go through the member buffer ([E, 2, d]) and the K7 pass
-        csr_qi, qi_rows = layout.member_csr_qi()
-        g2 = torch.empty(n_edges, 2 * dim, dtype=torch.float32, device=h.device)
+        # slots go through the member buffer ([E, 2, d]) and the K7 pass.  Beyond MEMBER_BUFFER_LIMIT_BYTES the buffer is produced in hyperedge chunks
+        # cut where the user changes: every launch writes the rows of its own users, the K7 passes after the first add onto the query and item rows.
+        n_chunks = max(1, -(-(n_edges * 2 * dim * 4) // MEMBER_BUFFER_LIMIT_BYTES))
+        if n_chunks == 1:
+            csr_qi, qi_rows = layout.member_csr_qi()
+            parts = [(0, n_edges, csr_qi, qi_rows)]
+        else:
+            parts = layout.member_csr_qi_chunks(n_chunks)
         dh = torch.empty(layout.node_count, dim, dtype=torch.float32, device=h.device)
         _zero_isolated_users(dh, layout)
-        ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n_edges, dim, order)), h.device)
-        with profiler.kernel('interact_bwd', n_edges, dim):
-            _lib.check(lib.ihg_interact_bwd_user_reduced(_ptr(h), _ld(h), _ptr(layout.i3), _ptr(w), _ld(w), order, _ptr(grad_out), _ld(grad_out), _ptr(g2),
-                                                         _ptr(dh), dim, _ptr(dw), _ld(dw) if dw is not None else 0, _ptr(ws), ws.numel() * 4, n_edges, dim, _stream()),
-                       'ihg_interact_bwd_user_reduced')
-        node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients', read_once=True)
+        for index, (e0, e1, csr_qi, qi_rows) in enumerate(parts):
+            n = e1 - e0
+            g2 = torch.empty(n, 2 * dim, dtype=torch.float32, device=h.device)
+            dw_part = dw if index == 0 or dw is None else torch.empty_like(dw)
+            ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n, dim, order)), h.device)
+            go = grad_out[e0:e1]
+            with profiler.kernel('interact_bwd', n, dim):
+                _lib.check(lib.ihg_interact_bwd_user_reduced(_ptr(h), _ld(h), _ptr(layout.i3[e0:e1]), _ptr(w), _ld(w), order, _ptr(go), _ld(grad_out), _ptr(g2),
+                                                             _ptr(dh), dim, _ptr(dw_part), _ld(dw_part) if dw_part is not None else 0, _ptr(ws), ws.numel() * 4, n, dim,
+                                                             _stream()),
+                           'ihg_interact_bwd_user_reduced')
+            if index > 0 and dw is not None:
+                dw[:, 3 * dim:].add_(dw_part[:, 3 * dim:])
+            node_segment_sum_raw(g2.view(2 * n, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients', accumulate=index > 0, read_once=True)
+            del g2
         return dh
+    n_chunks = max(1, -(-(n_edges * 3 * dim * 4) // MEMBER_BUFFER_LIMIT_BYTES))
     if n_chunks == 1:
         parts = [(0, n_edges, layout.member_csr)]
     else:

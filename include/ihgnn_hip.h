@@ -236,7 +236,9 @@ int ihg_interact_bwd(const float* h, int64_t ld_h, const int32_t* i3,
  * rows [0, n_users) of dh receive, for every user with hyperedges, the sum of its user-slot gradients in hyperedge order - exactly
  * what ihg_node_segment_sum over the user's incidence list would have produced from the [n_edges, 3, dim] buffer.  Rows of users
  * without hyperedges are not written (pre-zero them).  A third less written here and a third less read by the K7 pass over g2.
- * Available where ihg_interact_bwd_user_reduced_supported says so (dim 128); workspace as for ihg_interact_bwd.
+ * Available where ihg_interact_bwd_user_reduced_supported says so (dim 32, 128; dim 64 and 256 with the split arithmetic on); workspace as
+ * for ihg_interact_bwd.  A caller that produces g2 in hyperedge chunks cuts them where the user changes: every call writes the rows
+ * of the users whose hyperedges it was given.
  */
 int32_t ihg_interact_bwd_user_reduced_supported(int32_t dim, int32_t order, int64_t ld_h);
 int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
@@ -248,7 +250,7 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
  * cotangent dout[e] = sum over the three members m of dy_scale[m] * dy[m] (dy_scale NULL: 1) - what ihg_edge_gather_sum would
  * have produced - is formed inside the member-gradient kernel from three gathered rows; it is left in `dout` [n_edges, dim]
  * (written, not read) for the weight gradients here and for the caller's first-order scatter.  Everything else as
- * ihg_interact_bwd_user_reduced.  Available where ihg_interact_bwd_gathered_supported says so (dim 128, split arithmetic on).
+ * ihg_interact_bwd_user_reduced.  Available where ihg_interact_bwd_gathered_supported says so (dim 32; dim 64 and 128 with the split arithmetic on).
  * dw == NULL: member gradients and dout only (the weight gradients come from ihg_node_interact_bwd_weight); then dout == NULL as well: the
  * hyperedges' cotangents are not stored at all (the caller takes the first-order gradient from dy by the two-hop operator).
  */

@@ -433,10 +433,10 @@ def test_interact_persistent_tiles_and_strided_rows(dim, order, edges):
     assert rel(hg.grad, hc.grad) <= RTOL and rel(wg.grad, wc.grad) <= RTOL
 
 
-@pytest.mark.parametrize('dim', [128, 64, 32])
+@pytest.mark.parametrize('dim', [128, 64, 32, 256])
 @pytest.mark.parametrize('order,edges,users', [(3, 700 * 32 + 5, 301), (2, 300 * 32, 7), (3, 40, 3), (3, 9000, 5000), (3, 2048 * 16 * 3 + 7, 1500)])
 def test_interact_backward_user_slot_reduced_on_chip(order, edges, users, dim, monkeypatch):
-    """d = 128 (two column halves per tile range), d = 64 (one workgroup per range) and d = 32 (narrow.hip: one WAVE per range of 16-hyperedge tiles, the runs summed by a
+    """d = 128 (two column halves per tile range), d = 64 (one workgroup per range), d = 256 (eight column parts of 32 per range, 32 ranges: round 5) and d = 32 (narrow.hip: one WAVE per range of 16-hyperedge tiles, the runs summed by a
     segmented scan over the 16 lanes of a DPP row; 98,311 hyperedges = three tiles per range of the 2,048 and a partial last tile) with hyperedges numbered by user: the member-gradient kernel sums the user slot on chip (runs inside a tile, across
     tiles, across workgroups - 7 users over 9,600 hyperedges put one user's run in several workgroups - users without hyperedges)
     and writes dh[users] itself, the [E, 2, d] buffer carries the other two slots.  Against the oracle and against the [E, 3, d] form."""
@@ -860,12 +860,15 @@ def test_weight_gradients_over_rows_of_very_different_magnitude(dim):
         assert rel(wd2.grad[:, blk * dim:(blk + 1) * dim], w64b.grad[:, blk * dim:(blk + 1) * dim]) <= RTOL, blk
 
 
+@pytest.mark.parametrize('edge_order', ['file', 'user'])
 @pytest.mark.parametrize('dim', [12, 64, 128, 256])
-def test_interact_backward_in_hyperedge_chunks(dim, monkeypatch):
-    """The [E, 3, d] member-gradient buffer produced in three hyperedge chunks (what config C5 needs on one GPU): gradients
-    equal the one-pass ones up to the association of the chunk sums."""
+def test_interact_backward_in_hyperedge_chunks(dim, edge_order, monkeypatch):
+    """The member-gradient buffer produced in hyperedge chunks (what config C5 needs on one GPU): gradients equal the one-pass ones up to the
+    association of the chunk sums.  Hyperedges in file order: [E, 3, d] in three chunks; numbered by user (where the width has the user-reduced
+    kernel): [E, 2, d] in two chunks cut where the user changes, every launch writing its own users' rows, the second scatter adding onto the
+    query and item rows."""
     from ihgnn_amd import ops
-    w_, lay = make_layout(150, 9, 120, 2000, seed=dim)
+    w_, lay = make_layout(150, 9, 120, 2000, seed=dim, edge_order=edge_order)
     gen = torch.Generator().manual_seed(dim)
     h = torch.randn(lay.node_count, dim, generator=gen).to(dev())
     p = torch.randn(lay.node_count, dim, generator=gen).to(dev())
@@ -877,7 +880,11 @@ def test_interact_backward_in_hyperedge_chunks(dim, monkeypatch):
         hg, pg, wg = (t.clone().requires_grad_(True) for t in (h, p, w))
         ops.interact(hg, pg, wg, lay, 3).backward(cot)
         grads.append((hg.grad, pg.grad, wg.grad))
-    assert len(lay.member_csr_chunks(3)) == 3
+    if edge_order == 'user' and dim != 12:
+        cuts = lay.member_csr_qi_chunks(2)
+        assert len(cuts) == 2 and lay.i3_host[cuts[0][1] - 1, 0] != lay.i3_host[cuts[0][1], 0]
+    else:
+        assert len(lay.member_csr_chunks(3)) == 3
     for one, many in zip(*grads):
         assert rel(many, one) <= 2e-6
     # and against the oracle (the first-order part enters through p, which is an independent input here)
@@ -1452,10 +1459,10 @@ def test_heaviest_rows_against_the_oracle_over_all_their_hyperedges(config, n_ed
         assert err_y <= RTOL and err_g <= RTOL, (config, v, n_inc, err_y, err_g)
 
 
-def test_full_size_c5_interact_in_three_chunks():
+def test_full_size_c5_interact_in_chunks():
     """BASELINE configs[4] at FULL size on one GPU: N = 10 M, E = 50 M, d = 256.  The interactive step forward (chunk kernel) and its
-    backward with the 154 GB member-gradient buffer produced in three hyperedge chunks, each scattered through its own member lists
-    (150 M entries in all).  Oracle on sampled hyperedges (forward) and sampled nodes (d h); Euler identity for d W over all 50 M
+    backward with the member-gradient buffer produced in hyperedge chunks (round 5: the user slot summed on chip, [E, 2, d] = 102 GB in two chunks
+    cut at a user boundary; before: [E, 3, d] = 154 GB in three), each scattered through its own member lists.  Oracle on sampled hyperedges (forward) and sampled nodes (d h); Euler identity for d W over all 50 M
     hyperedges; first-order gradient = K7 of the cotangent.  Needs ~210 GB of HBM: skipped on a smaller device."""
     import gc
     gc.collect()
@@ -1480,18 +1487,18 @@ def test_full_size_c5_interact_in_three_chunks():
     for lo in range(0, E, 10_000_000):                                   # filled in slices: randn's own temporaries stay small
         cot[lo:lo + 10_000_000].normal_(generator=gen).div_(8)
     out = ops.interact(h, p, wgt, lay, order)
-    n_chunks = -(-(E * 3 * d * 4) // ops.MEMBER_BUFFER_LIMIT_BYTES)
-    assert n_chunks == 3
+    assert lay.user_sorted                                                # the user slot is summed on chip: [E, 2, d] = 102 GB in two chunks cut at a user boundary
+    n_chunks = -(-(E * 2 * d * 4) // ops.MEMBER_BUFFER_LIMIT_BYTES)
+    assert n_chunks == 2
     profiler.start()
     out.backward(cot)
     launched = profiler.summary()
     profiler.stop()
-    assert launched['interact_bwd']['launches'] == 3 and launched['k7.member_gradients']['launches'] == 3, sorted(launched)
+    assert launched['interact_bwd']['launches'] == 2 and launched['k7.member_gradients_rows']['launches'] == 2, sorted(launched)
 
     # forward against the oracle on sampled hyperedges (first tile, last partial tile, chunk seams, random)
-    step = lay.member_csr_chunks(3)[0][1]
-    pick = torch.cat([torch.arange(0, 64), torch.arange(E - 70, E), torch.arange(step - 40, step + 40), torch.arange(2 * step - 40, 2 * step + 40),
-                      torch.randint(0, E, (4096,))]).unique()
+    step = lay.member_csr_qi_chunks(2)[0][1]
+    pick = torch.cat([torch.arange(0, 64), torch.arange(E - 70, E), torch.arange(step - 40, step + 40), torch.randint(0, E, (4096,))]).unique()
     i3s = torch.from_numpy(lay.i3_host[pick.numpy()].astype(np.int64))
     members, local = torch.unique(i3s, return_inverse=True)
     hm, pm = h.detach()[members.to(dev())].cpu(), p.detach()[members.to(dev())].cpu()
@@ -1777,13 +1784,20 @@ def test_driver_end_to_end(tmp_path, monkeypatch):
     (_, m_e), (_, m_r) = list(eager.iter_epoch_test())[-1], list(recorded.iter_epoch_test())[-1]
     assert abs(m_e.NDCG_at10 - m_r.NDCG_at10) <= 2e-3 and abs(m_e.HitRatio_at10 - m_r.HitRatio_at10) <= 2e-3
     assert eager.training_step_recorded is False and recorded.training_step_recorded is True
-    # the DEFAULT (auto): this model's eager step is launch-bound (a few hundred microseconds of kernels behind ~ 70 launches), so after seven eager steps - three to
-    # warm up, four timed - the loop records the step by itself; same metrics
+    # the DEFAULT (auto): after seven eager steps - three to warm up, four timed - the loop decides by the measured step time.  This model's eager step is launch-bound
+    # (a few hundred microseconds of kernels behind ~ 70 launches: 1.35 ms on an idle host, 2.5 ms with the test suite's other workers on its cores), so the decision
+    # itself is the host's: the test holds the loop to its own rule and then pins the rule on either side of the measured time; same metrics on every path
+    from ihgnn_amd.Helpers import TrainTestHelper as tth
     random.seed(11); torch.manual_seed(11)
     auto = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '3', '--est', '2', '--etf', '1'])
-    assert auto.training_step_recorded is True and auto.eager_step_ms < 1.5
-    m_a = dict(auto.iter_epoch_test())[2]
-    assert abs(m_e.NDCG_at10 - m_a.NDCG_at10) <= 2e-3 and abs(m_e.HitRatio_at10 - m_a.HitRatio_at10) <= 2e-3
+    assert auto.training_step_recorded is (auto.eager_step_ms < tth.AUTO_RECORD_BELOW_MS) and 0 < auto.eager_step_ms < 1e3
+    for bar, want in ((1e6, True), (0.0, False)):
+        monkeypatch.setattr(tth, 'AUTO_RECORD_BELOW_MS', bar)
+        random.seed(11); torch.manual_seed(11)
+        run = driver.main(['--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '3', '--est', '2', '--etf', '1'])
+        assert run.training_step_recorded is want
+        m_a = dict(run.iter_epoch_test())[2]
+        assert abs(m_e.NDCG_at10 - m_a.NDCG_at10) <= 2e-3 and abs(m_e.HitRatio_at10 - m_a.HitRatio_at10) <= 2e-3
 
 
 @pytest.mark.parametrize('tag,d,mode', [('tiny_uqi', 8, 'uqi'), ('small_uqi', 64, 'uqi'), ('small_ui', 32, 'ui'), ('tiny_qi', 8, 'qi')])

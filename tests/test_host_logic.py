@@ -475,3 +475,38 @@ def test_two_fp16_split_bound_on_random_and_wide_range_rows():
     assert (np.abs(got - exact) / norm_wise).max() <= 2.0 ** -36                             # tiny against |a|_inf |b|_1 ...
     component_wise = np.abs(got - exact) / (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64).T)
     assert component_wise.max() > 1e-5                                                       # ... and NOT against sum |a_k b_k|: the stated limit of a per-row scale
+
+
+def test_user_reduced_member_lists_in_chunks_are_cut_where_the_user_changes():
+    """``IncidenceLayout.member_csr_qi_chunks``: the query / item member lists of the user-reduced backward cut by hyperedge range for buffers beyond
+    ``ops.MEMBER_BUFFER_LIMIT_BYTES`` (config C5).  Every cut sits between two users (hyperedges are numbered by user), the chunks' lists are a partition of
+    ``member_csr_qi``'s entries with ids rebased to the chunk, user rows are empty, and one user owning most hyperedges gives fewer, uneven chunks - never a cut
+    inside its run."""
+    w = synth.draw(300, 12, 200, 10, 9000, seed=5, distribution='powerlaw', exponent=1.2)
+    lay = IncidenceLayout(w.triples, 300, 12, 200, CPU, edge_order='user')
+    assert lay.user_sorted
+    whole, _ = lay.member_csr_qi()
+    wp, wi = whole.ptr_host.astype(np.int64), whole.ids_host.astype(np.int64)
+    for n_chunks in (2, 3, 7):
+        parts = lay.member_csr_qi_chunks(n_chunks)
+        assert parts[0][0] == 0 and parts[-1][1] == lay.edge_count and 2 <= len(parts) <= n_chunks
+        users = lay.i3_host[:, 0]
+        gathered = [[] for _ in range(lay.node_count)]
+        for (e0, e1, csr, rows), nxt in zip(parts, parts[1:] + [None]):
+            assert e0 < e1 and (nxt is None or (nxt[0] == e1 and users[e1 - 1] != users[e1]))
+            p, ids = csr.ptr_host.astype(np.int64), csr.ids_host.astype(np.int64)
+            assert p[lay.user_count] == 0 and ids.size == 2 * (e1 - e0) and (ids.size == 0 or (ids.min() >= 0 and ids.max() < 2 * (e1 - e0)))
+            np.testing.assert_array_equal(np.sort(rows.numpy()), np.arange(lay.user_count, lay.node_count))
+            lens = np.diff(p)[rows.numpy()]
+            assert (np.diff(lens) <= 0).all()                            # longest list first
+            for v in range(lay.user_count, lay.node_count):
+                gathered[v].append(ids[p[v]:p[v + 1]] + 2 * e0)
+        for v in range(lay.user_count, lay.node_count):
+            np.testing.assert_array_equal(np.sort(np.concatenate(gathered[v])), np.sort(wi[wp[v]:wp[v + 1]]))
+    # one user in 90 % of the hyperedges: its run is never cut
+    t = w.triples.copy()
+    t[:8100, 0] = 7
+    heavy = IncidenceLayout(t, 300, 12, 200, CPU, edge_order='user')
+    parts = heavy.member_csr_qi_chunks(4)
+    users = heavy.i3_host[:, 0]
+    assert all(users[e1 - 1] != users[e1] for _, e1, _, _ in parts[:-1]) and sum(e1 - e0 for e0, e1, _, _ in parts) == heavy.edge_count

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_ab/obj
-for f in host aggregate interact dense tail eval; do
+for f in host aggregate interact dense tail eval narrow; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -Wno-unused-function -I include -I ihgnn_amd/csrc -o build_ab/obj/$f.o ihgnn_amd/csrc/$f.hip &
 done
 wait

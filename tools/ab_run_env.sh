@@ -5,7 +5,7 @@ envs=$1; pat=$2; shift 2
 export TMPDIR=/tmp
 for name in "$@"; do
   out=/tmp/abe_$name; rm -rf $out
-  (cd /tmp && env $envs IHG_ALLOW_ABLATION_BUILD=1 IHGNN_HIP_LIBRARY=$REPO/build_ab/lib_$name.so rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $REPO/tools/kbench.py --config C3 --rounds ${ROUNDS:-4} --ops ${OPS:-interact} > /dev/null 2>&1)
+  (cd /tmp && env $envs IHG_ALLOW_ABLATION_BUILD=1 IHGNN_HIP_LIBRARY=$REPO/build_ab/lib_$name.so rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $REPO/tools/kbench.py --config ${CONFIG:-C3} --scale ${SCALE:-1} --dim ${DIM:-0} --rounds ${ROUNDS:-4} --ops ${OPS:-interact} > /dev/null 2>&1)
   python3 - "$out" "$name" "$pat" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True)
