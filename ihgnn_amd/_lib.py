@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # IHGNN_HIP_LIBRARY points at another build of the same ABI (A/B timing of kernel variants); default: the in-tree library
 LIB_PATH = os.environ.get('IHGNN_HIP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
@@ -47,6 +47,8 @@ SIGNATURES = {
     'ihg_merge_id_lists': (ctypes.c_int, [_i32p, _i32p, c_int64, _i32p, _i32p, _f32p, _i64p]),
     'ihg_edge_gather_sum': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float,
                                            c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    'ihg_edge_gather_sum_planes_supported': (c_int32, [c_int32, c_int64]),
+    'ihg_edge_gather_sum_planes': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     'ihg_node_segment_sum': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                             c_void_p, c_int64, c_int64, c_int32, c_int32,
                                             c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -63,6 +65,9 @@ SIGNATURES = {
     'ihg_interact_bwd_user_reduced_supported': (c_int32, [c_int32, c_int32, c_int64]),
     'ihg_interact_bwd_user_reduced': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                                      c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    'ihg_interact_bwd_user_reduced_planes_supported': (c_int32, [c_int32, c_int32, c_int64]),
+    'ihg_interact_bwd_user_reduced_planes': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                                            c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'ihg_interact_bwd_gathered_supported': (c_int32, [c_int32, c_int32, c_int64, c_int64]),
     'ihg_interact_bwd_gathered': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                                  c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),

@@ -7,6 +7,7 @@
 // fetched once per wave with a single coalesced load and handed to their group with wavefront shuffles (ds_bpermute), so the
 // dependent row gathers of several hyperedges are in flight together.
 #include "common.hpp"
+#include "split_common.hpp"
 
 namespace {
 
@@ -392,6 +393,84 @@ __global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5 with its result laid down as the member-gradient kernel's operand (d = 256; round 5): the hyperedges' cotangents are read by exactly one consumer, the
+// member-gradient kernel, whose eight column parts each scaled and took apart the same row again (a seventh of that kernel's time at config C5).  Here the row is
+// formed as in edge_gather_sum_kernel (one wave per hyperedge row, four consecutive hyperedges per iteration, the shared user row fetched once), scaled by the power of
+// two of its largest magnitude and written as the two fp16 terms of split_common.hpp - [e][plane][d] fp16, 4 d bytes per row like the fp32 row it replaces - with the
+// inverse scale beside it.  Same sums, same split: the consumer's results are bit-identical to those from the fp32 rows.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+template <int U>
+__global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_planes256_kernel(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ i3,
+                                                                                  const float* __restrict__ node_scale, v2u* __restrict__ planes,
+                                                                                  float* __restrict__ inv_out, int64_t n_edges) {
+    constexpr int D = 256, EPW = U;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t n_ids = n_edges * 3;
+    const int64_t stride = global_wave_count() * EPW;
+    int64_t e0 = global_wave_id() * EPW;
+    int next_id = (lane < EPW * 3 && e0 * 3 + lane < n_ids) ? i3[e0 * 3 + lane] : 0;
+    for (; e0 < n_edges; e0 += stride) {
+        const int64_t pos = e0 * 3 + lane;
+        const bool have = lane < EPW * 3 && pos < n_ids;
+        const int my_id = next_id;
+        {
+            const int64_t npos = pos + stride * 3;
+            next_id = (lane < EPW * 3 && npos < n_ids) ? i3[npos] : 0;
+        }
+        const float my_scale = (node_scale != nullptr && have) ? node_scale[my_id] : 1.f;
+        int ids[U][3];
+        float sc[U][3];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                ids[t][m] = __builtin_amdgcn_readlane(my_id, t * 3 + m);
+                sc[t][m] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_scale), t * 3 + m));
+            }
+        }
+        Frag<4> rows[U][3];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const bool live = e0 + t < n_edges;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (m == 0 && t > 0 && ids[t][0] == ids[t - 1][0]) {
+                    rows[t][0] = rows[t - 1][0];                        // same user as the previous hyperedge: row already here
+                    continue;
+                }
+                rows[t][m] = live ? Frag<4>::load(src + static_cast<int64_t>(ids[t][m]) * ld_src + lane * 4) : Frag<4>::zero();
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const int64_t e = e0 + t;
+            if (e >= n_edges) continue;
+            Frag<4> acc = Frag<4>::zero();
+            acc.add_scaled(rows[t][0], sc[t][0]);          // (u + q) + i, as in edge_gather_sum_kernel
+            acc.add_scaled(rows[t][1], sc[t][1]);
+            acc.add_scaled(rows[t][2], sc[t][2]);
+            // the row's largest magnitude: 16 lanes by DPP, the four 16-lane rows through scalar registers (unsigned order = float order for m >= 0)
+            float m = abs_max3(acc.v.z, acc.v.w, abs_max3(acc.v.x, acc.v.y, 0.f));
+            m = row_lanes_max<16>(m);
+            const unsigned mu = __float_as_uint(m);
+            const unsigned m0 = __builtin_amdgcn_readlane(mu, 0), m1 = __builtin_amdgcn_readlane(mu, 16), m2 = __builtin_amdgcn_readlane(mu, 32),
+                           m3 = __builtin_amdgcn_readlane(mu, 48);
+            const unsigned ma = m0 > m1 ? m0 : m1, mb = m2 > m3 ? m2 : m3;
+            float inv;
+            const float s = scale_up_for(__uint_as_float(ma > mb ? ma : mb), inv);
+            unsigned h0, l0, h1, l1;
+            split_pair_h2(acc.v.x * s, acc.v.y * s, h0, l0);
+            split_pair_h2(acc.v.z * s, acc.v.w * s, h1, l1);
+            v2u* dst = planes + e * (D / 2);                             // a row: D / 2 pairs of dwords (two planes of D / 4 each)
+            __builtin_nontemporal_store(v2u{h0, h1}, dst + lane);
+            __builtin_nontemporal_store(v2u{l0, l1}, dst + D / 4 + lane);
+            if (lane == 0) inv_out[e] = inv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dispatch helpers
 // ------------------------------------------------------------------------------------------------
 
@@ -497,6 +576,22 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, con
     const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out) && (bias == nullptr || aligned16(bias));
     return wide ? launch_edge_gather_sum<4>(src, ld_src, i3, node_scale, bias, alpha, out, ld_out, n_edges, dim, s)
                 : launch_edge_gather_sum<1>(src, ld_src, i3, node_scale, bias, alpha, out, ld_out, n_edges, dim, s);
+}
+
+int32_t ihg_edge_gather_sum_planes_supported(int32_t dim, int64_t ld_src) { return dim == 256 && ld_src >= dim && ld_src % 4 == 0 ? 1 : 0; }
+
+int ihg_edge_gather_sum_planes(const float* src, int64_t ld_src, const int32_t* i3, const float* node_scale, void* planes, float* inv_scale, int64_t n_edges,
+                               int32_t dim, ihg_stream_t stream) {
+    if (!ihg_edge_gather_sum_planes_supported(dim, ld_src)) return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum_planes: shape not supported (ask ihg_edge_gather_sum_planes_supported)");
+    if (n_edges < 0) return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum_planes: bad size");
+    if (n_edges == 0) return IHG_OK;
+    if (src == nullptr || i3 == nullptr || planes == nullptr || inv_scale == nullptr || !aligned16(src) || !aligned16(planes))
+        return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum_planes: null or unaligned pointer");
+    constexpr int U = 4;
+    const int grid = grid_for_waves((n_edges + U - 1) / U);
+    hipLaunchKernelGGL((edge_gather_sum_planes256_kernel<U>), dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), src, ld_src, i3, node_scale,
+                       static_cast<v2u*>(planes), inv_scale, n_edges);
+    return check_launch("ihg_edge_gather_sum_planes");
 }
 
 int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* ids, const int32_t* row_order,

@@ -2193,6 +2193,35 @@ int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i
     return check_launch("ihg_interact_bwd_user_reduced");
 }
 
+int32_t ihg_interact_bwd_user_reduced_planes_supported(int32_t dim, int32_t order, int64_t ld_h) {
+    return dim == 256 && split_arith_enabled() && ihg_interact_bwd_user_reduced_supported(dim, order, ld_h) ? 1 : 0;
+}
+
+int ihg_interact_bwd_user_reduced_planes(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order, const void* planes_rows,
+                                         const float* inv_scale, float* g2, float* dh, int64_t ld_dh, void* workspace, int64_t workspace_bytes, int64_t n_edges,
+                                         int32_t dim, ihg_stream_t stream) {
+    if (!ihg_interact_bwd_user_reduced_planes_supported(dim, order, ld_h))
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced_planes: shape or arithmetic mode not supported (ask ihg_interact_bwd_user_reduced_planes_supported)");
+    const int k = order == 3 ? 7 : 6;
+    if (n_edges <= 0 || ld_h < dim || ld_dh < dim || ld_w < static_cast<int64_t>(k) * dim) return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced_planes: bad size");
+    if (h == nullptr || i3 == nullptr || w == nullptr || planes_rows == nullptr || inv_scale == nullptr || g2 == nullptr || dh == nullptr || workspace == nullptr)
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced_planes: null pointer");
+    if (ld_w % 4 || !aligned16(h) || !aligned16(w) || !aligned16(planes_rows) || !aligned16(g2) || !aligned16(workspace))
+        return fail(IHG_ERR_INVALID, "ihg_interact_bwd_user_reduced_planes: rows must be 16-byte aligned");
+    if (workspace_bytes < ihg_interact_bwd_workspace_bytes(n_edges, dim, order)) return fail(IHG_ERR_WORKSPACE, "ihg_interact_bwd_user_reduced_planes: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* wq = static_cast<float*>(workspace);
+    float* slabs = wq + packed_weight_floats(dim, order);
+    float* bnd_val = slabs + static_cast<int64_t>(weight_slabs(dim)) * packed_weight_floats(dim, order);
+    int32_t* bnd_user = reinterpret_cast<int32_t*>(bnd_val + 2LL * boundary_ranges(dim) * dim);
+    void* planes = bnd_user + 2LL * boundary_ranges(dim);
+    int entries = 0;
+    launch_members_split(dim, order, h, ld_h, i3, w, ld_w, planes, static_cast<const float*>(planes_rows), dim, g2, n_edges, dh, ld_dh, bnd_val, bnd_user, &entries, s, nullptr,
+                         nullptr, 0, inv_scale);
+    hipLaunchKernelGGL(user_boundary_fixup_kernel, dim3(entries), dim3(std::max(128, dim)), 0, s, bnd_val, bnd_user, entries, dim, dh, ld_dh);
+    return check_launch("ihg_interact_bwd_user_reduced_planes");
+}
+
 int32_t ihg_interact_bwd_gathered_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_dy) {
     return dim != 256 && ihg_interact_bwd_user_reduced_supported(dim, order, ld_h) && (split_arith_enabled() || dim == kNarrowDim) && ld_dy >= dim && ld_dy % 4 == 0 && ld_dy < (int64_t{1} << 30) ? 1 : 0;
 }

@@ -24,7 +24,8 @@ IHG_INTERNAL bool split_members_ok(int dim, int order, const float* g, int64_t l
 // of dy_scale[m] dout[m] (dy_scale == nullptr: 1) itself and leaves it in dout_store [E, ld_store]
 IHG_INTERNAL void launch_members_split(int dim, int order, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
                                        int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
-                                       int* n_boundary_entries, hipStream_t s, const float* dy_scale = nullptr, float* dout_store = nullptr, int64_t ld_store = 0);
+                                       int* n_boundary_entries, hipStream_t s, const float* dy_scale = nullptr, float* dout_store = nullptr, int64_t ld_store = 0,
+                                       const float* inv_src = nullptr);     // inv_src != nullptr (dim 256): `dout` rows are fp16 planes with these inverse scales (ihg_edge_gather_sum_planes)
 
 // forward (first-order rows p required); planes: split_plane_floats(dim, order) floats of workspace
 IHG_INTERNAL bool split_fwd_ok(int dim, int order, const float* p, int64_t ld_p, const float* out, int64_t ld_out, int64_t ld_h);

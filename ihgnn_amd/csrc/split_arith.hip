@@ -90,15 +90,20 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
 // the node -> hyperedge kernel (K5) and store it to dout_store (each column half its 64 columns) for the weight-gradient kernel and the
 // first-order scatter: K5's launch - memory-bound, on a chip whose issue slots it leaves idle - disappears into a kernel that is
 // issue-bound and leaves the memory pipes idle.
-template <int D, bool UR, int NBLK, bool GATHER = false>
+// PLANES (round 5; D = 256): `dout` holds the hyperedges' cotangents already scaled and taken apart - rows of [plane][D] fp16, 4 D bytes like the fp32 row, written by
+// edge_gather_sum_planes256_kernel (aggregate.hip) with the inverse scales in inv_src - so the service waves copy 16-byte pieces into the images instead of finding each
+// row's maximum, scaling and splitting it in every one of the eight column parts (15 % of the kernel at config C5).
+template <int D, bool UR, int NBLK, bool GATHER = false, bool PLANES = false>
 __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_kernel(const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ i3,
                                                                                       const v4u* __restrict__ wsp, const float* __restrict__ winv,
                                                                                       const float* __restrict__ dout, int64_t ld_dout,
                                                                                       float* __restrict__ g_out, int64_t n_edges, float* __restrict__ dh_user,
                                                                                       int64_t ld_dh, float* __restrict__ bnd_val, int32_t* __restrict__ bnd_user,
                                                                                       const float* __restrict__ dy_scale = nullptr,
-                                                                                      float* __restrict__ dout_store = nullptr, int64_t ld_store = 0) {
+                                                                                      float* __restrict__ dout_store = nullptr, int64_t ld_store = 0,
+                                                                                      const float* __restrict__ inv_src = nullptr) {
     static_assert(D == 128 || D == 64 || D == 256, "shapes");
+    static_assert(!PLANES || !GATHER, "the gathering form makes its cotangents itself");
     static_assert(!GATHER || ((D == 128 || D == 64) && UR), "the gathering form exists where the layer's backward uses it");
     constexpr int TE = kSplitTE, PARTS = D == 64 ? 1 : (D == 128 ? 2 : 8), RANGES = 256 / PARTS, HC = D / PARTS, CT = HC / 16, KB = D / 32, RB = 2 * D;
     constexpr int SWZ = RB / 16 - 1 < 15 ? RB / 16 - 1 : 15;            // the row swizzle stays inside a row (D = 64: rows of 8 chunks)
@@ -125,225 +130,6 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     }
     const int n_phases = n_my + (UR ? 3 : 1);
 
-    role_priority(wave >= 4);
-    if (wave >= 4) {
-        // ---------------- service waves: 256 threads, thread -> hyperedge row, dout octets o and o + 8, member / gradient columns 4 o .. and 32 + 4 o ..
-        const int st = tid - 256, row = st >> 3, o = st & 7;
-        constexpr int AHEAD = GATHER ? 1 : 0;                            // the gathering form requests its rows a tile further ahead: its ids travel a phase earlier
-        const int64_t last_pos = n_edges * 3 - 1;
-        const uint32_t ldh = static_cast<uint32_t>(ld_h), ldd = static_cast<uint32_t>(ld_dout);
-        // tile bases and the clamps at the end of the hyperedge list are scalar (the tile number is uniform); per lane: one min, one multiply
-        auto fetch_id = [&](int k) {                                     // (st < 96; the tile exists)
-            const int64_t first = (t0 + k) * (3 * TE);
-            const int lim = static_cast<int>(std::min<int64_t>(last_pos - first, 3 * TE - 1));
-            return (i3 + first)[std::min(st, lim)];
-        };
-        auto load_dout = [&](int k, v4f (&dr)[2 * DOCT]) {               // (tiles past the end: the last row, dropped)
-            const int64_t first = std::min<int64_t>((t0 + k) * TE, n_edges - 1);
-            const int lim = static_cast<int>(std::min<int64_t>(n_edges - 1 - first, TE - 1));
-            const float* src = row_at(dout + first * ld_dout, std::min(row, lim), ldd) + 8 * o;
-#pragma unroll
-            for (int x = 0; x < DOCT; ++x) {
-                if (abl::m_no_dy_loads) {
-                    dr[2 * x] = dr[2 * x + 1] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(lim + x);
-                    continue;
-                }
-                dr[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
-                dr[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
-            }
-        };
-        // GATHER: `dout` is the node-level cotangent dy; rows of the three members of hyperedge `row` of tile k, and their scales
-        struct Raw {
-            v4f r[3][2 * DOCT];
-            float s[3];
-        };
-        auto load_gather = [&](int k, Raw& raw) {
-            const int* idk = ids[k & 7] + row * 3;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const int id = idk[m];
-                const float* src = row_at(dout, id, ldd) + 8 * o;
-#pragma unroll
-                for (int x = 0; x < DOCT; ++x) {
-                    if (abl::m_no_dy_loads) {
-                        raw.r[m][2 * x] = raw.r[m][2 * x + 1] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(id + x);
-                        continue;
-                    }
-                    raw.r[m][2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
-                    raw.r[m][2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
-                }
-                raw.s[m] = abl::m_no_dy_loads ? 0.5f : (dy_scale != nullptr ? dy_scale[id] : 1.f);
-            }
-        };
-        auto combine = [&](int k, const Raw& raw, v4f (&dr)[2 * DOCT]) {   // K5's order: ((0 + s_u u) + s_q q) + s_i i; the half's columns go to dout_store
-#pragma unroll
-            for (int j = 0; j < 2 * DOCT; ++j) {
-                v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int m = 0; m < 3; ++m) acc += raw.s[m] * raw.r[m][j];
-                dr[j] = acc;
-            }
-            const int64_t e0 = (t0 + k) * TE;
-            if (!abl::m_no_dout_store && ld_store > 0 && k < n_my && e0 + row < n_edges) {       // (ld_store <= 0: nobody reads the hyperedges' cotangents after this kernel)
-                float* dst = dout_store + (e0 + row) * ld_store + 64 * half + 8 * o;
-                store_stream4(dst, dr[2 * half]);
-                store_stream4(dst + 4, dr[2 * half + 1]);
-            }
-        };
-        auto load_members = [&](int k, v4f (&hm)[EX][3]) {
-            const int* idk = ids[k & 7] + row * 3;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const float* hp = row_at(h, idk[m], ldh) + HC * half + 4 * o;
-#pragma unroll
-                for (int x = 0; x < EX; ++x) hm[x][m] = abl::m_no_member_loads ? v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(idk[m] + x) : *reinterpret_cast<const v4f*>(hp + 32 * x);
-            }
-        };
-        const int swz = row & SWZ;
-        // a row's cotangent goes in scaled by ONE power of two: its eight staging threads (consecutive lanes) agree on its largest magnitude with three shuffles
-        auto split_tile = [&](const v4f (&dr)[2 * DOCT], int buf) {
-            float m = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2 * DOCT; ++j) m = abs_max3(dr[j][2], dr[j][3], abs_max3(dr[j][0], dr[j][1], m));
-            m = row_lanes_max<8>(m);
-            float inv;
-            const float sc = abl::m_no_split ? 1.f : scale_up_for(m, inv);
-#pragma unroll
-            for (int x = 0; x < DOCT; ++x) {
-                v4u hi, lo;
-                if (abl::m_no_split) {
-                    hi = __builtin_bit_cast(v4u, dr[2 * x]);
-                    lo = __builtin_bit_cast(v4u, dr[2 * x + 1]);
-                } else {
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) {
-                        unsigned hh, ll;
-                        split_pair_h2(dr[2 * x + (pr >> 1)][2 * (pr & 1)] * sc, dr[2 * x + (pr >> 1)][2 * (pr & 1) + 1] * sc, hh, ll);
-                        hi[pr] = hh;
-                        lo[pr] = ll;
-                    }
-                }
-                *reinterpret_cast<v4u*>(&planes[buf][0][row][((o + 8 * x) ^ swz) << 4]) = hi;
-                *reinterpret_cast<v4u*>(&planes[buf][1][row][((o + 8 * x) ^ swz) << 4]) = lo;
-            }
-            if (o == 0) sinv[buf][row] = abl::m_no_split ? 1.f : inv;
-        };
-        // product rule of tile k - 1 (its contractions in dzimg[(k - 1) & 1], its member values in hm) and the stores
-        auto epilogue = [&](int k, const v4f (&hm)[EX][3]) {
-            const float (*dz)[TE][DZ] = dzimg[(k - 1) & 1];
-            const int64_t e = (t0 + k - 1) * TE + row;
-#pragma unroll
-            for (int x = 0; x < EX; ++x) {
-                const int c = 4 * o + 32 * x;
-                const v4f z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][c]), z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][c]);
-                const v4f z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][c]);
-                const v4f hu = hm[x][0], hq = hm[x][1], hi = hm[x][2];
-                v4f g_u = z_uq * hq + z_iu * hi, g_q = z_uq * hu + z_qi * hi, g_i = z_qi * hq + z_iu * hu;
-                if (NBLK == 4) {
-                    const v4f z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][c]);
-                    g_u += z_uqi * (hq * hi);
-                    g_q += z_uqi * (hu * hi);
-                    g_i += z_uqi * (hu * hq);
-                }
-                const bool live = e < n_edges;
-                if (UR) *reinterpret_cast<v4f*>(&utile[(k - 1) & 1][row][c]) = live ? g_u : v4f{0.f, 0.f, 0.f, 0.f};     // (rows past the end: zeros for the sums)
-                if (live && !abl::m_no_g_stores) {
-                    // (where the stores land does not matter: into a 48 MB window, as one contiguous stream per column part or as plain stores the kernel takes the same
-                    // time - ablate.hpp, profiles/r5/22_abl_member_stores_d256.txt: removing them "saves" 10 of 18 ms only because the product rule goes with them)
-                    const int64_t er = abl::m_g_window ? (e & 0x3fff) : e;
-                    constexpr int SS = abl::m_g_parts ? HC : D;
-                    float* dst = abl::m_g_parts ? g_out + (static_cast<int64_t>(half) * n_edges + er) * (GS * HC) + c : g_out + er * (GS * D) + HC * half + c;
-                    auto put = [](float* p, v4f v) {
-                        if (abl::m_g_plain) *reinterpret_cast<v4f*>(p) = v;
-                        else store_stream4(p, v);
-                    };
-                    if (!UR) {
-                        put(dst, g_u);
-                        dst += SS;
-                    }
-                    put(dst, g_q);
-                    put(dst + SS, g_i);
-                }
-            }
-        };
-        if (UR && st < HC) ucarry[0][st] = 0.f;
-        if (st < 3 * TE) {
-            ids[0][st] = fetch_id(0);
-#pragma unroll
-            for (int k = 1; k < 8; ++k) ids[k][st] = k < 4 + AHEAD && k < n_my ? fetch_id(k) : 0;       // (slots of tiles past the end: row 0, requested and dropped)
-        }
-        __syncthreads();
-        v4f dr0[2 * DOCT], dr1[2 * DOCT], hm0[EX][3], hm1[EX][3];                        // dout values of tile m in dr<m & 1>, member values in hm<m & 1>
-        // (GATHER) the rows behind the dout values: TWO sets - the rows of tile k + 3 are requested in phase k and summed at the end of phase k + 1 (one set, requested and
-        // summed inside one phase, made every phase wait out a loaded memory round trip)
-        Raw raw0, raw1;
-        if (GATHER) {                                                    // one set of dout values: a tile's sum is formed after the previous one was split
-            load_gather(0, raw0);
-            combine(0, raw0, dr0);
-            split_tile(dr0, 0);
-            load_gather(1, raw0);
-            load_gather(2, raw1);
-            combine(1, raw0, dr0);
-        } else {
-            load_dout(0, dr0);
-            if (n_my > 1) load_dout(1, dr1);
-            split_tile(dr0, 0);
-        }
-        __syncthreads();
-        int id_carry = 0;
-        auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3], Raw& raw_use, Raw& raw_req) {
-            // (Round 5 tried the streaming form - config C5's kernel - with this phase's requests first and then the work on what was requested a PHASE AGO behind one exact
-            // wait, every request unconditional: the loop's waits became vmcnt(11 .. 22) instead of two vmcnt(0) per trip, and the kernel went 29.7 -> 31.1 ms at C5: it does not
-            // wait for latency - 78 GB of L2-miss traffic and a matrix pipe half busy share its 30 ms.  Reverted.)
-            // The id fetch of the tile four ahead comes FIRST and is unconditional (every lane, clamped tile - round 5): it used to sit behind the row requests under
-            // `k + 4 + AHEAD < n_my && st < 96`, the only requests younger than it were the epilogue's stores - themselves under `live` - and the wait for it at the top of the
-            // next phase was vmcnt(0): every other phase drained the queue, the previous phase's six stores included.  With the row requests behind it the wait is an exact
-            // count that leaves them (and the stores) in flight.
-            const int id_new = fetch_id(std::min(k + 4 + AHEAD, n_my - 1));
-            // ids of tile k + 3 + AHEAD (requested in the previous phase) into the ring: a phase ahead of their first readers (the gathered rows of
-            // that tile in the next phase)
-            if (k >= 1 && k + 3 + AHEAD < n_my && st < 3 * TE) ids[(k + 3 + AHEAD) & 7][st] = id_carry;
-            load_members(k, hm_cur);                                     // unconditional: a branch around requests costs whole-set register copies
-            if (GATHER) load_gather(k + 3, raw_req);
-            else load_dout(k + 2, fill);
-            id_carry = id_new;
-            if (k + 1 < n_my) split_tile(use, (k + 1) & 1);
-            // delivery of this phase's requests, THEN everything that stores: the memory counter is in order, a wait behind a store sits out
-            // the store's round trip to memory
-            if (GATHER) {                                                // (the rows requested a phase ago: this phase's requests stay in flight)
-                asm volatile("" : "+v"(raw_use.r[2][2 * DOCT - 2]), "+v"(raw_use.r[2][2 * DOCT - 1]), "+v"(raw_use.s[2]));
-            } else {
-                asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * DOCT - 2]), "+v"(fill[2 * DOCT - 1]));     // (in order: the last delivered = all delivered)
-            }
-            asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));       // (left to where the next phase reads them: no gain)
-            if (GATHER) combine(k + 2, raw_use, fill);
-            if (k >= 1 && k - 1 < n_my && !abl::m_no_product_rule) epilogue(k, hm_prev);
-            __syncthreads();
-        };
-        int k = 0;
-#pragma clang loop unroll(disable)
-        for (; k + 1 < n_phases; k += 2) {                                // exactly two phases per trip: the register sets come back in place
-            phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1, raw1, raw0);
-            phase(k + 1, dr0, GATHER ? dr0 : dr1, hm1, hm0, raw0, raw1);
-        }
-        if (k < n_phases) phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1, raw1, raw0);
-        return;
-    }
-
-    // ---------------- matrix waves: wave = product block, the half's four 16-column tiles, both row tiles
-    const int blk = wave;
-    const int arow = lane & 15, kq = lane >> 4;
-    v8h wreg[KB][CT][2];
-    v4f wiv[CT];                                                         // inverse scales of this lane's output columns 16 ct + 4 kq ..
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)      // 32-column group of column tile ct: (HC / 32) half + (ct >> 1)
-                wreg[kb][ct][p] = __builtin_bit_cast(v8h, wsp[(static_cast<int64_t>((((HC / 32) * half + (ct >> 1)) * 4 + blk) * (KB * 2) + kb * 2 + (ct & 1)) * 2 + p) * kWave + lane]);
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) wiv[ct] = blk < NBLK ? *reinterpret_cast<const v4f*>(winv + blk * D + HC * half + 16 * ct + 4 * kq) : v4f{0.f, 0.f, 0.f, 0.f};
     // UR, lane = column of the half (64 lanes, 256-byte stores); a run = the rows of one user, its starts come from one ballot over the
     // tile's user ids.  The sums ride on the MATRIX waves: with two fp16 terms a tile's contraction keeps the matrix pipe busy for a quarter of
     // a phase, the service waves are the ones on the kernel's critical path (without the sums: - 320 us of 1,900, profiles/r4/01_abl_member_gradients.txt),
@@ -360,7 +146,9 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     // (D = 256: parts of 32 columns - the upper half of a wave mirrors the lower one's column (ul) through the sums and leaves the stores to it (uw))
     const int ul = lane & (HC - 1);
     const bool uw = lane < HC;
-    const int colg = HC * half + ul, win = wave;
+    const int colg = HC * half + ul, win = wave & 3;
+    // (Round 5, PLANES: with the cotangents delivered scaled and split the sums were tried on the service waves again - C5 332.9 against 329.3 ms with them on the
+    // matrix waves: the service role is still the longer one.)
     uint64_t heads_prev = 0;                                         // run starts / user ids / rows of the tile whose windows were summed a phase ago
     int uid_prev = 0, rows_prev = 0;
     auto run_target = [&](int t, int r, int uid) {                   // destination of the run that starts at row r of tile t
@@ -440,6 +228,259 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         if (m != 0) first_run_open = t == 0 && m == 1u;
         cur_user = __builtin_amdgcn_readlane(uid_prev, rows_prev - 1);
     };
+    auto close_range = [&]() {                                       // after the last phase (matrix waves)
+        // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
+        const bool one_run = first_run_open;
+        if (cur_user >= 0 && win == 0 && uw) {
+            const float run_sum = ucarry[n_my & 1][ul];              // (written before the last barrier)
+            if (one_run) first_slot[colg] = run_sum;
+            else bnd_val[static_cast<int64_t>(2 * range + 1) * D + colg] = run_sum;
+        }
+        if (half == 0 && win == 0 && lane == 0) {
+            bnd_user[2 * range] = first_user;
+            bnd_user[2 * range + 1] = (cur_user >= 0 && !one_run) ? cur_user : -1;
+        }
+    };
+    role_priority(wave >= 4);
+    if (wave >= 4) {
+        // ---------------- service waves: 256 threads, thread -> hyperedge row, dout octets o and o + 8, member / gradient columns 4 o .. and 32 + 4 o ..
+        const int st = tid - 256, row = st >> 3, o = st & 7;
+        constexpr int AHEAD = GATHER ? 1 : 0;                            // the gathering form requests its rows a tile further ahead: its ids travel a phase earlier
+        const int64_t last_pos = n_edges * 3 - 1;
+        const uint32_t ldh = static_cast<uint32_t>(ld_h), ldd = static_cast<uint32_t>(ld_dout);
+        // tile bases and the clamps at the end of the hyperedge list are scalar (the tile number is uniform); per lane: one min, one multiply
+        auto fetch_id = [&](int k) {                                     // (st < 96; the tile exists)
+            const int64_t first = (t0 + k) * (3 * TE);
+            const int lim = static_cast<int>(std::min<int64_t>(last_pos - first, 3 * TE - 1));
+            return (i3 + first)[std::min(st, lim)];
+        };
+        auto load_dout = [&](int k, v4f (&dr)[2 * DOCT], float& iv) {    // (tiles past the end: the last row, dropped)
+            const int64_t first = std::min<int64_t>((t0 + k) * TE, n_edges - 1);
+            const int lim = static_cast<int>(std::min<int64_t>(n_edges - 1 - first, TE - 1));
+            if (PLANES) {                                                // 16-byte piece o + 8 x of either plane, as it goes into the image; the row's inverse scale first (the oldest request)
+                iv = (inv_src + first)[std::min(row, lim)];
+                const float* src = row_at(dout + first * ld_dout, std::min(row, lim), ldd) + 4 * o;
+#pragma unroll
+                for (int x = 0; x < DOCT; ++x) {
+                    dr[2 * x] = *reinterpret_cast<const v4f*>(src + 32 * x);
+                    dr[2 * x + 1] = *reinterpret_cast<const v4f*>(src + D / 2 + 32 * x);
+                }
+                return;
+            }
+            const float* src = row_at(dout + first * ld_dout, std::min(row, lim), ldd) + 8 * o;
+#pragma unroll
+            for (int x = 0; x < DOCT; ++x) {
+                if (abl::m_no_dy_loads) {
+                    dr[2 * x] = dr[2 * x + 1] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(lim + x);
+                    continue;
+                }
+                dr[2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
+                dr[2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
+            }
+        };
+        // GATHER: `dout` is the node-level cotangent dy; rows of the three members of hyperedge `row` of tile k, and their scales
+        struct Raw {
+            v4f r[3][2 * DOCT];
+            float s[3];
+        };
+        auto load_gather = [&](int k, Raw& raw) {
+            const int* idk = ids[k & 7] + row * 3;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int id = idk[m];
+                const float* src = row_at(dout, id, ldd) + 8 * o;
+#pragma unroll
+                for (int x = 0; x < DOCT; ++x) {
+                    if (abl::m_no_dy_loads) {
+                        raw.r[m][2 * x] = raw.r[m][2 * x + 1] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(id + x);
+                        continue;
+                    }
+                    raw.r[m][2 * x] = *reinterpret_cast<const v4f*>(src + 64 * x);
+                    raw.r[m][2 * x + 1] = *reinterpret_cast<const v4f*>(src + 64 * x + 4);
+                }
+                raw.s[m] = abl::m_no_dy_loads ? 0.5f : (dy_scale != nullptr ? dy_scale[id] : 1.f);
+            }
+        };
+        auto combine = [&](int k, const Raw& raw, v4f (&dr)[2 * DOCT]) {   // K5's order: ((0 + s_u u) + s_q q) + s_i i; the half's columns go to dout_store
+#pragma unroll
+            for (int j = 0; j < 2 * DOCT; ++j) {
+                v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 3; ++m) acc += raw.s[m] * raw.r[m][j];
+                dr[j] = acc;
+            }
+            const int64_t e0 = (t0 + k) * TE;
+            if (!abl::m_no_dout_store && ld_store > 0 && k < n_my && e0 + row < n_edges) {       // (ld_store <= 0: nobody reads the hyperedges' cotangents after this kernel)
+                float* dst = dout_store + (e0 + row) * ld_store + 64 * half + 8 * o;
+                store_stream4(dst, dr[2 * half]);
+                store_stream4(dst + 4, dr[2 * half + 1]);
+            }
+        };
+        auto load_members = [&](int k, v4f (&hm)[EX][3]) {
+            const int* idk = ids[k & 7] + row * 3;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float* hp = row_at(h, idk[m], ldh) + HC * half + 4 * o;
+#pragma unroll
+                for (int x = 0; x < EX; ++x) hm[x][m] = abl::m_no_member_loads ? v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(idk[m] + x) : *reinterpret_cast<const v4f*>(hp + 32 * x);
+            }
+        };
+        const int swz = row & SWZ;
+        // a row's cotangent goes in scaled by ONE power of two: its eight staging threads (consecutive lanes) agree on its largest magnitude with three shuffles
+        auto split_tile = [&](const v4f (&dr)[2 * DOCT], int buf, float iv) {
+            if (PLANES) {
+#pragma unroll
+                for (int x = 0; x < DOCT; ++x) {
+                    *reinterpret_cast<v4f*>(&planes[buf][0][row][((o + 8 * x) ^ swz) << 4]) = dr[2 * x];
+                    *reinterpret_cast<v4f*>(&planes[buf][1][row][((o + 8 * x) ^ swz) << 4]) = dr[2 * x + 1];
+                }
+                if (o == 0) sinv[buf][row] = iv;
+                return;
+            }
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2 * DOCT; ++j) m = abs_max3(dr[j][2], dr[j][3], abs_max3(dr[j][0], dr[j][1], m));
+            m = row_lanes_max<8>(m);
+            float inv;
+            const float sc = abl::m_no_split ? 1.f : scale_up_for(m, inv);
+#pragma unroll
+            for (int x = 0; x < DOCT; ++x) {
+                v4u hi, lo;
+                if (abl::m_no_split) {
+                    hi = __builtin_bit_cast(v4u, dr[2 * x]);
+                    lo = __builtin_bit_cast(v4u, dr[2 * x + 1]);
+                } else {
+#pragma unroll
+                    for (int pr = 0; pr < 4; ++pr) {
+                        unsigned hh, ll;
+                        split_pair_h2(dr[2 * x + (pr >> 1)][2 * (pr & 1)] * sc, dr[2 * x + (pr >> 1)][2 * (pr & 1) + 1] * sc, hh, ll);
+                        hi[pr] = hh;
+                        lo[pr] = ll;
+                    }
+                }
+                *reinterpret_cast<v4u*>(&planes[buf][0][row][((o + 8 * x) ^ swz) << 4]) = hi;
+                *reinterpret_cast<v4u*>(&planes[buf][1][row][((o + 8 * x) ^ swz) << 4]) = lo;
+            }
+            if (o == 0) sinv[buf][row] = abl::m_no_split ? 1.f : inv;
+        };
+        // product rule of tile k - 1 (its contractions in dzimg[(k - 1) & 1], its member values in hm) and the stores
+        auto epilogue = [&](int k, const v4f (&hm)[EX][3]) {
+            const float (*dz)[TE][DZ] = dzimg[(k - 1) & 1];
+            const int64_t e = (t0 + k - 1) * TE + row;
+#pragma unroll
+            for (int x = 0; x < EX; ++x) {
+                const int c = 4 * o + 32 * x;
+                const v4f z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][c]), z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][c]);
+                const v4f z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][c]);
+                const v4f hu = hm[x][0], hq = hm[x][1], hi = hm[x][2];
+                v4f g_u = z_uq * hq + z_iu * hi, g_q = z_uq * hu + z_qi * hi, g_i = z_qi * hq + z_iu * hu;
+                if (NBLK == 4) {
+                    const v4f z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][c]);
+                    g_u += z_uqi * (hq * hi);
+                    g_q += z_uqi * (hu * hi);
+                    g_i += z_uqi * (hu * hq);
+                }
+                const bool live = e < n_edges;
+                if (UR) *reinterpret_cast<v4f*>(&utile[(k - 1) & 1][row][c]) = live ? g_u : v4f{0.f, 0.f, 0.f, 0.f};     // (rows past the end: zeros for the sums)
+                if (live && !abl::m_no_g_stores) {
+                    // (where the stores land does not matter: into a 48 MB window, as one contiguous stream per column part or as plain stores the kernel takes the same
+                    // time - ablate.hpp, profiles/r5/22_abl_member_stores_d256.txt: removing them "saves" 10 of 18 ms only because the product rule goes with them)
+                    const int64_t er = abl::m_g_window ? (e & 0x3fff) : e;
+                    constexpr int SS = abl::m_g_parts ? HC : D;
+                    float* dst = abl::m_g_parts ? g_out + (static_cast<int64_t>(half) * n_edges + er) * (GS * HC) + c : g_out + er * (GS * D) + HC * half + c;
+                    auto put = [](float* p, v4f v) {
+                        if (abl::m_g_plain) *reinterpret_cast<v4f*>(p) = v;
+                        else store_stream4(p, v);
+                    };
+                    if (!UR) {
+                        put(dst, g_u);
+                        dst += SS;
+                    }
+                    put(dst, g_q);
+                    put(dst + SS, g_i);
+                }
+            }
+        };
+        if (UR && st < HC) ucarry[0][st] = 0.f;
+        if (st < 3 * TE) {
+            ids[0][st] = fetch_id(0);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) ids[k][st] = k < 4 + AHEAD && k < n_my ? fetch_id(k) : 0;       // (slots of tiles past the end: row 0, requested and dropped)
+        }
+        __syncthreads();
+        v4f dr0[2 * DOCT], dr1[2 * DOCT], hm0[EX][3], hm1[EX][3];                        // dout values of tile m in dr<m & 1>, member values in hm<m & 1>
+        // (GATHER) the rows behind the dout values: TWO sets - the rows of tile k + 3 are requested in phase k and summed at the end of phase k + 1 (one set, requested and
+        // summed inside one phase, made every phase wait out a loaded memory round trip)
+        Raw raw0, raw1;
+        float iv0 = 1.f, iv1 = 1.f;                                      // (PLANES) inverse row scales beside dr0 / dr1
+        if (GATHER) {                                                    // one set of dout values: a tile's sum is formed after the previous one was split
+            load_gather(0, raw0);
+            combine(0, raw0, dr0);
+            split_tile(dr0, 0, 1.f);
+            load_gather(1, raw0);
+            load_gather(2, raw1);
+            combine(1, raw0, dr0);
+        } else {
+            load_dout(0, dr0, iv0);
+            if (n_my > 1) load_dout(1, dr1, iv1);
+            split_tile(dr0, 0, iv0);
+        }
+        __syncthreads();
+        int id_carry = 0;
+        auto phase = [&](int k, v4f (&use)[2 * DOCT], v4f (&fill)[2 * DOCT], v4f (&hm_cur)[EX][3], v4f (&hm_prev)[EX][3], Raw& raw_use, Raw& raw_req, float& iv_use,
+                         float& iv_fill) {
+            // (Round 5 tried the streaming form - config C5's kernel - with this phase's requests first and then the work on what was requested a PHASE AGO behind one exact
+            // wait, every request unconditional: the loop's waits became vmcnt(11 .. 22) instead of two vmcnt(0) per trip, and the kernel went 29.7 -> 31.1 ms at C5: it does not
+            // wait for latency - 78 GB of L2-miss traffic and a matrix pipe half busy share its 30 ms.  Reverted.)
+            // The id fetch of the tile four ahead comes FIRST and is unconditional (every lane, clamped tile - round 5): it used to sit behind the row requests under
+            // `k + 4 + AHEAD < n_my && st < 96`, the only requests younger than it were the epilogue's stores - themselves under `live` - and the wait for it at the top of the
+            // next phase was vmcnt(0): every other phase drained the queue, the previous phase's six stores included.  With the row requests behind it the wait is an exact
+            // count that leaves them (and the stores) in flight.
+            const int id_new = fetch_id(std::min(k + 4 + AHEAD, n_my - 1));
+            // ids of tile k + 3 + AHEAD (requested in the previous phase) into the ring: a phase ahead of their first readers (the gathered rows of
+            // that tile in the next phase)
+            if (k >= 1 && k + 3 + AHEAD < n_my && st < 3 * TE) ids[(k + 3 + AHEAD) & 7][st] = id_carry;
+            load_members(k, hm_cur);                                     // unconditional: a branch around requests costs whole-set register copies
+            if (GATHER) load_gather(k + 3, raw_req);
+            else load_dout(k + 2, fill, iv_fill);
+            id_carry = id_new;
+            if (k + 1 < n_my) split_tile(use, (k + 1) & 1, iv_use);
+            // delivery of this phase's requests, THEN everything that stores: the memory counter is in order, a wait behind a store sits out
+            // the store's round trip to memory
+            if (GATHER) {                                                // (the rows requested a phase ago: this phase's requests stay in flight)
+                asm volatile("" : "+v"(raw_use.r[2][2 * DOCT - 2]), "+v"(raw_use.r[2][2 * DOCT - 1]), "+v"(raw_use.s[2]));
+            } else {
+                asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * DOCT - 2]), "+v"(fill[2 * DOCT - 1]));     // (in order: the last delivered = all delivered)
+            }
+            asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));       // (left to where the next phase reads them: no gain)
+            if (GATHER) combine(k + 2, raw_use, fill);
+            if (k >= 1 && k - 1 < n_my && !abl::m_no_product_rule) epilogue(k, hm_prev);
+            __syncthreads();
+        };
+        int k = 0;
+#pragma clang loop unroll(disable)
+        for (; k + 1 < n_phases; k += 2) {                                // exactly two phases per trip: the register sets come back in place
+            phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1, raw1, raw0, iv1, iv0);
+            phase(k + 1, dr0, GATHER ? dr0 : dr1, hm1, hm0, raw0, raw1, iv0, iv1);
+        }
+        if (k < n_phases) phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1, raw1, raw0, iv1, iv0);
+        return;
+    }
+
+    // ---------------- matrix waves: wave = product block, the half's four 16-column tiles, both row tiles
+    const int blk = wave;
+    const int arow = lane & 15, kq = lane >> 4;
+    v8h wreg[KB][CT][2];
+    v4f wiv[CT];                                                         // inverse scales of this lane's output columns 16 ct + 4 kq ..
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)      // 32-column group of column tile ct: (HC / 32) half + (ct >> 1)
+                wreg[kb][ct][p] = __builtin_bit_cast(v8h, wsp[(static_cast<int64_t>((((HC / 32) * half + (ct >> 1)) * 4 + blk) * (KB * 2) + kb * 2 + (ct & 1)) * 2 + p) * kWave + lane]);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) wiv[ct] = blk < NBLK ? *reinterpret_cast<const v4f*>(winv + blk * D + HC * half + 16 * ct + 4 * kq) : v4f{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     __syncthreads();
     for (int k = 0; k < n_phases; ++k) {
@@ -491,19 +532,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         }
         __syncthreads();
     }
-    if (UR) {
-        // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
-        const bool one_run = first_run_open;
-        if (cur_user >= 0 && wave == 0 && uw) {
-            const float run_sum = ucarry[n_my & 1][ul];              // (written before the last barrier)
-            if (one_run) first_slot[colg] = run_sum;
-            else bnd_val[static_cast<int64_t>(2 * range + 1) * D + colg] = run_sum;
-        }
-        if (half == 0 && tid == 0) {
-            bnd_user[2 * range] = first_user;
-            bnd_user[2 * range + 1] = (cur_user >= 0 && !one_run) ? cur_user : -1;
-        }
-    }
+    if (UR) close_range();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1127,7 +1156,19 @@ namespace {
 template <int D, int NBLK>
 void launch_members_split_t(const float* h, int64_t ld_h, const int32_t* i3, const v4u* wsp, const float* winv, const float* dout, int64_t ld_dout, float* g, int64_t n_edges,
                             float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user, const float* dy_scale, float* dout_store, int64_t ld_store,
-                            hipStream_t s) {
+                            const float* inv_src, hipStream_t s) {
+    if constexpr (D == 256) {
+        if (inv_src != nullptr) {                                        // `dout` holds fp16 planes (ihg_edge_gather_sum_planes)
+            if (dh_user != nullptr)
+                hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, true, NBLK, false, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, winv, dout, ld_dout,
+                                   g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, static_cast<const float*>(nullptr), static_cast<float*>(nullptr), int64_t{0}, inv_src);
+            else
+                hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, false, NBLK, false, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, winv, dout, ld_dout,
+                                   g, n_edges, static_cast<float*>(nullptr), int64_t{0}, static_cast<float*>(nullptr), static_cast<int32_t*>(nullptr),
+                                   static_cast<const float*>(nullptr), static_cast<float*>(nullptr), int64_t{0}, inv_src);
+            return;
+        }
+    }
     if constexpr (D == 128 || D == 64) {
         if (dh_user != nullptr && dout_store != nullptr) {              // `dout` is the node-level cotangent: gathered, summed, stored
             hipLaunchKernelGGL((interact_bwd_members_split_ws_kernel<D, true, NBLK, true>), dim3(256), dim3(kSplitThreads), 0, s, h, ld_h, i3, wsp, winv, dout, ld_dout, g,
@@ -1147,7 +1188,7 @@ void launch_members_split_t(const float* h, int64_t ld_h, const int32_t* i3, con
 
 void launch_members_split(int dim, int order, const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, void* planes, const float* dout,
                           int64_t ld_dout, float* g, int64_t n_edges, float* dh_user, int64_t ld_dh, float* bnd_val, int32_t* bnd_user,
-                          int* n_boundary_entries, hipStream_t s, const float* dy_scale, float* dout_store, int64_t ld_store) {
+                          int* n_boundary_entries, hipStream_t s, const float* dy_scale, float* dout_store, int64_t ld_store, const float* inv_src) {
     v4u* wsp = static_cast<v4u*>(planes);
     const int nblk = order == 3 ? 4 : 3;
     const int items = (dim / 32) * 4 * (dim / 32) * 2 * kWave;
@@ -1159,8 +1200,8 @@ void launch_members_split(int dim, int order, const float* h, int64_t ld_h, cons
     hipLaunchKernelGGL(pack_planes_members_kernel, dim3((items + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, s, w, ld_w, dim, nblk, wsc, wsp);
 #define IHG_MEMBERS(D)                                                                                                                       \
     {                                                                                                                                        \
-        if (nblk == 4) launch_members_split_t<D, 4>(h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store, s); \
-        else launch_members_split_t<D, 3>(h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store, s);           \
+        if (nblk == 4) launch_members_split_t<D, 4>(h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store, inv_src, s); \
+        else launch_members_split_t<D, 3>(h, ld_h, i3, wsp, winv, dout, ld_dout, g, n_edges, dh_user, ld_dh, bnd_val, bnd_user, dy_scale, dout_store, ld_store, inv_src, s);           \
     }
     if (dim == 256) IHG_MEMBERS(256) else if (dim == 64) IHG_MEMBERS(64) else IHG_MEMBERS(128)
 #undef IHG_MEMBERS

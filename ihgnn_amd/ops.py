@@ -667,6 +667,14 @@ NODE_TABLES = _os.environ.get('IHG_NODE_TABLES', '1') != '0'
 
 
 
+def _user_reduced_ok(h: Tensor, w: Tensor, grad_out: Tensor, layout: IncidenceLayout, order: int) -> bool:
+    """The interactive backward can run ``ihg_interact_bwd_user_reduced`` on these operands."""
+    lib = _lib.load()
+    return bool(USER_REDUCED_BACKWARD and layout.edge_count > 0 and getattr(layout, 'user_sorted', False)
+                and lib.ihg_interact_bwd_user_reduced_supported(int(h.shape[1]), order, _ld(h)) and h.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+                and _ld(w) % 4 == 0 and _ld(grad_out) % 4 == 0 and grad_out.data_ptr() % 16 == 0)
+
+
 def _zero_isolated_users(dh: Tensor, layout: IncidenceLayout) -> None:
     """Users without hyperedges are not written by the user-reduced kernels: their rows of ``dh`` are zeroed here (an index fill of those
     rows; a fill of the whole user block is 118 MB at C3)."""
@@ -675,15 +683,21 @@ def _zero_isolated_users(dh: Tensor, layout: IncidenceLayout) -> None:
         _lib.check(_lib.load().ihg_zero_rows(_ptr(dh), _ld(dh), int(dh.shape[1]), _ptr(idx), int(idx.numel()), _stream()), 'ihg_zero_rows')
 
 
-def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: IncidenceLayout, order: int, dw: Optional[Tensor]) -> Tensor:
+# the hyperedges' cotangents of the interactive layer's backward written by K5 as the member-gradient kernel's operand (two fp16 planes per row + the row's inverse scale)
+# where nothing else reads them (d = 256 beyond FIRST_ORDER_TWO_HOP_BYTES: config C5); IHG_COTANGENT_PLANES=0: fp32 rows, scaled and split by every column part of the kernel
+COTANGENT_PLANES = _os.environ.get('IHG_COTANGENT_PLANES', '1') != '0'
+
+
+def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: IncidenceLayout, order: int, dw: Optional[Tensor], inv_scale: Optional[Tensor] = None) -> Tensor:
     """Product-block weight gradient into ``dw`` (its columns from ``3 d`` on; ``None``: not wanted - the caller has it from the node-level
     kernel) and the member gradients scattered to nodes (returned).  One pass when the ``[E, 3, d]`` buffer fits ``MEMBER_BUFFER_LIMIT_BYTES``, otherwise hyperedge chunks, each with
-    its own member lists (``IncidenceLayout.member_csr_chunks``): same sums, associated chunk by chunk."""
+    its own member lists (``IncidenceLayout.member_csr_chunks``): same sums, associated chunk by chunk.  ``inv_scale`` (``[E]``): ``grad_out`` holds fp16 planes
+    (``ihg_edge_gather_sum_planes``), not fp32 rows; the caller has checked ``_cotangent_planes_ok``."""
     lib = _lib.load()
     n_edges, dim = layout.edge_count, int(h.shape[1])
-    if (USER_REDUCED_BACKWARD and n_edges > 0 and getattr(layout, 'user_sorted', False)
-            and lib.ihg_interact_bwd_user_reduced_supported(dim, order, _ld(h)) and h.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
-            and _ld(w) % 4 == 0 and _ld(grad_out) % 4 == 0 and grad_out.data_ptr() % 16 == 0):
+    if inv_scale is not None and (dw is not None or not _user_reduced_ok(h, w, grad_out, layout, order)):
+        raise RuntimeError('cotangent planes are read by the user-reduced member-gradient kernel only')
+    if _user_reduced_ok(h, w, grad_out, layout, order):
         # hyperedges are numbered by user: the kernel sums the user slot on chip and writes dh[users] itself; only the query and item
         # slots go through the member buffer ([E, 2, d]) and the K7 pass.  Beyond MEMBER_BUFFER_LIMIT_BYTES the buffer is produced in hyperedge chunks
         # cut where the user changes: every launch writes the rows of its own users, the K7 passes after the first add onto the query and item rows.
@@ -702,10 +716,15 @@ def _interact_backward(h: Tensor, w: Tensor, grad_out: Tensor, layout: Incidence
             ws = _workspace(int(lib.ihg_interact_bwd_workspace_bytes(n, dim, order)), h.device)
             go = grad_out[e0:e1]
             with profiler.kernel('interact_bwd', n, dim):
-                _lib.check(lib.ihg_interact_bwd_user_reduced(_ptr(h), _ld(h), _ptr(layout.i3[e0:e1]), _ptr(w), _ld(w), order, _ptr(go), _ld(grad_out), _ptr(g2),
-                                                             _ptr(dh), dim, _ptr(dw_part), _ld(dw_part) if dw_part is not None else 0, _ptr(ws), ws.numel() * 4, n, dim,
-                                                             _stream()),
-                           'ihg_interact_bwd_user_reduced')
+                if inv_scale is not None:
+                    _lib.check(lib.ihg_interact_bwd_user_reduced_planes(_ptr(h), _ld(h), _ptr(layout.i3[e0:e1]), _ptr(w), _ld(w), order, _ptr(go), _ptr(inv_scale[e0:e1]),
+                                                                        _ptr(g2), _ptr(dh), dim, _ptr(ws), ws.numel() * 4, n, dim, _stream()),
+                               'ihg_interact_bwd_user_reduced_planes')
+                else:
+                    _lib.check(lib.ihg_interact_bwd_user_reduced(_ptr(h), _ld(h), _ptr(layout.i3[e0:e1]), _ptr(w), _ld(w), order, _ptr(go), _ld(grad_out), _ptr(g2),
+                                                                 _ptr(dh), dim, _ptr(dw_part), _ld(dw_part) if dw_part is not None else 0, _ptr(ws), ws.numel() * 4, n, dim,
+                                                                 _stream()),
+                               'ihg_interact_bwd_user_reduced')
             if index > 0 and dw is not None:
                 dw[:, 3 * dim:].add_(dw_part[:, 3 * dim:])
             node_segment_sum_raw(g2.view(2 * n, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients', accumulate=index > 0, read_once=True)
@@ -918,8 +937,23 @@ class _InteractLayer(torch.autograd.Function):
             else:
                 dp = _two_hop_first_order_gradient(dy, layout, out_scale)
         else:
-            dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
-            if n_edges * dim * 4 > FIRST_ORDER_TWO_HOP_BYTES:
+            two_hop_first = n_edges * dim * 4 > FIRST_ORDER_TWO_HOP_BYTES
+            inv = None
+            if (COTANGENT_PLANES and node_weight and two_hop_first and dy.data_ptr() % 16 == 0 and bool(lib.ihg_edge_gather_sum_planes_supported(dim, _ld(dy)))
+                    and bool(lib.ihg_interact_bwd_user_reduced_planes_supported(dim, order, _ld(h)))):
+                # only the member-gradient kernel reads the hyperedges' cotangents here: K5 writes them as that kernel's operand (same bytes per row), scaled and split once
+                # instead of once per column part of the kernel
+                dout = torch.empty(n_edges, dim, dtype=torch.float32, device=h.device)
+                if _user_reduced_ok(h, w, dout, layout, order):
+                    inv = torch.empty(n_edges, dtype=torch.float32, device=h.device)
+                    with profiler.kernel('edge_gather_sum', n_edges, dim):
+                        _lib.check(lib.ihg_edge_gather_sum_planes(_ptr(dy), _ld(dy), _ptr(layout.i3), _ptr(out_scale), _ptr(dout), _ptr(inv), n_edges, dim, _stream()),
+                                   'ihg_edge_gather_sum_planes')
+                else:
+                    del dout
+            if inv is None:
+                dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
+            if two_hop_first:
                 # a [E, d] table far beyond the caches (config C5: 51 GB): its scatter reads HBM at random, the two-hop operator on the node-level
                 # cotangent (10 GB) gathers twice the rows and is still the shorter launch (22 against 32 ms)
                 dp = _two_hop_first_order_gradient(dy, layout, out_scale)
@@ -927,7 +961,8 @@ class _InteractLayer(torch.autograd.Function):
                 # the scatter of dout goes first: K5 has just written it, so most of its rows are still in the Infinity Cache for these random
                 # reads; the interact kernels read it as a stream and do not care
                 dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
-            dh = _interact_backward(h, w, dout, layout, order, None if node_weight else dw)
+            dh = _interact_backward(h, w, dout, layout, order, None if node_weight else dw, inv_scale=inv)
+            del inv
         del dout
         dbias = torch.empty(dim, dtype=torch.float32, device=h.device) if ctx.has_bias else None
         ws2 = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)

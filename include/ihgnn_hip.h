@@ -138,6 +138,15 @@ int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3,
                         const float* node_scale, const float* bias, float alpha,
                         float* out, int64_t ld_out, int64_t n_edges, int32_t dim, ihg_stream_t stream);
 
+/* The same sum (alpha = 1, no bias) written as the member-gradient kernel's operand instead of fp32 rows (the backward of thsp.matmul(incidence, .), GnnLayers.py:233, whose
+ * result only ihg_interact_bwd_user_reduced_planes reads): row e of `planes` is [2][dim] fp16 - the row scaled by the power of two that brings its largest magnitude
+ * to [2^13, 2^14), as hi = fp16(x) and lo = fp16(x - hi) - and inv_scale[e] the inverse of that power.  4 dim bytes per row, like the fp32 row.  dim 256
+ * (ihg_edge_gather_sum_planes_supported).
+ */
+int32_t ihg_edge_gather_sum_planes_supported(int32_t dim, int64_t ld_src);
+int ihg_edge_gather_sum_planes(const float* src, int64_t ld_src, const int32_t* i3, const float* node_scale,
+                               void* planes, float* inv_scale, int64_t n_edges, int32_t dim, ihg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * DEVICE: hyperedge -> node segment-sum (K7 + K8).
  *   out[r,:] = scale_op( sum_{k in [rowptr[r], rowptr[r+1])} w(ids[k]) * src[ids[k],:] , out_scale[r] )
@@ -244,6 +253,16 @@ int32_t ihg_interact_bwd_user_reduced_supported(int32_t dim, int32_t order, int6
 int ihg_interact_bwd_user_reduced(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
                                   const float* dout, int64_t ld_dout, float* g2, float* dh, int64_t ld_dh, float* dw, int64_t ld_dw,
                                   void* workspace, int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream);
+
+/* The user-reduced member gradients (no weight gradients: dw as NULL above) from cotangent rows that were written ALREADY SCALED AND TAKEN APART by
+ * ihg_edge_gather_sum_planes: planes_rows is [n_edges][2][dim] fp16 (4 dim bytes per row, like the fp32 row it stands for), inv_scale [n_edges] the rows' inverse
+ * powers of two.  The kernel's eight column parts (dim 256) then copy the row's pieces instead of each finding its maximum, scaling and splitting it again; results
+ * are bit-identical to ihg_interact_bwd_user_reduced on the fp32 rows.  Reference: the same lines as ihg_interact_bwd (Models/CommonLayers.py:70-85, autograd's backward).
+ */
+int32_t ihg_interact_bwd_user_reduced_planes_supported(int32_t dim, int32_t order, int64_t ld_h);
+int ihg_interact_bwd_user_reduced_planes(const float* h, int64_t ld_h, const int32_t* i3, const float* w, int64_t ld_w, int32_t order,
+                                         const void* planes_rows, const float* inv_scale, float* g2, float* dh, int64_t ld_dh,
+                                         void* workspace, int64_t workspace_bytes, int64_t n_edges, int32_t dim, ihg_stream_t stream);
 
 /* The user-reduced backward fused with the transpose of the hyperedge -> node pass that follows the interactive step in an IHGNN layer
  * (Models/GnnLayers.py:229-236: Y = Dv^-1 H Ef): the caller has the NODE-level cotangent dy [n_nodes, dim], and the hyperedge

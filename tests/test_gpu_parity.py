@@ -54,6 +54,45 @@ def make_layout(U, Q, I, E, seed, distribution='uniform', heavy_threshold=1024, 
 # ---------------------------------------------------------------------------------------------
 # kernel level
 # ---------------------------------------------------------------------------------------------
+def test_edge_gather_sum_written_as_planes():
+    """``ihg_edge_gather_sum_planes`` (d = 256): K5's rows scaled by a power of two and written as two fp16 terms + the inverse scale.  Against the fp32 K5 rows: the
+    scale is the one ``scale_up_for`` gives the row's largest magnitude (2^13 <= scaled maximum < 2^14), ``hi`` is the rounded scaled value, ``hi + lo`` reproduces it to
+    2^-11 of ``hi``'s last place (exactly, in the emulation of tests/split_emulation.py), rows of zeros, huge and tiny rows, a partial last group of four hyperedges."""
+    import ctypes
+    from ihgnn_amd import _lib, ops
+    from split_emulation import split_two_fp16
+    lib = _lib.load()
+    dim = 256
+    _, lay = make_layout(300, 17, 211, 4003, seed=5, edge_order='user')
+    gen = torch.Generator().manual_seed(9)
+    src = torch.randn(lay.node_count, dim, generator=gen)
+    src[5] = 0
+    src[7] *= 2.0 ** 40
+    src[11] *= 2.0 ** -60
+    src[lay.i3_host[17]] = 0                                             # a hyperedge whose row is all zeros
+    scale = torch.rand(lay.node_count, generator=gen) + 0.5
+    want = ops.edge_gather_sum_raw(src.to(dev()), lay.i3, scale.to(dev())).cpu()
+    planes = torch.empty(lay.edge_count, dim, dtype=torch.float32, device=dev())
+    inv = torch.empty(lay.edge_count, dtype=torch.float32, device=dev())
+    s_dev, sc_dev = src.to(dev()), scale.to(dev())
+    assert lib.ihg_edge_gather_sum_planes_supported(dim, dim) == 1 and lib.ihg_edge_gather_sum_planes_supported(128, 128) == 0
+    _lib.check(lib.ihg_edge_gather_sum_planes(ops._ptr(s_dev), dim, ops._ptr(lay.i3), ops._ptr(sc_dev), ops._ptr(planes), ops._ptr(inv), lay.edge_count, dim,
+                                              ops._stream()), 'planes')
+    torch.cuda.synchronize()
+    halves = planes.cpu().view(torch.float16).view(lay.edge_count, 2, dim).float().numpy()
+    inv_np, want_np = inv.cpu().numpy(), want.numpy()
+    row_max = np.abs(want_np).max(1)
+    expo = np.clip(((row_max.astype(np.float32).view(np.uint32) >> 23) & 0xff).astype(np.int64), 27, 227)      # biased exponent of the row's largest magnitude, clamped as scale_up_for does
+    np.testing.assert_array_equal(inv_np, np.ldexp(1.0, expo - 13 - 127).astype(np.float32))
+    scaled = want_np / inv_np[:, None]
+    live = row_max > 2.0 ** -100
+    assert (np.abs(scaled[live]).max(1) >= 2.0 ** 13).all() and (np.abs(scaled[live]).max(1) < 2.0 ** 14).all()
+    hi, lo = split_two_fp16(scaled.astype(np.float32))
+    np.testing.assert_array_equal(halves[:, 0], hi.astype(np.float32))
+    np.testing.assert_array_equal(halves[:, 1], lo.astype(np.float32))
+    assert (halves[17] == 0).all()
+
+
 @pytest.mark.parametrize('dim', [4, 8, 12, 16, 20, 32, 64, 100, 128, 256, 320, 7, 33])
 @pytest.mark.parametrize('scaled', [False, True])
 def test_edge_gather_sum(dim, scaled):
@@ -671,9 +710,21 @@ def test_interactive_layer_without_hyperedge_rows(order, dim, monkeypatch):
                 monkeypatch.setattr(ops, 'FIRST_ORDER_TWO_HOP_BYTES', 0)
                 hd, wd = h.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True)
                 bd = bias.to(dev()).requires_grad_(True) if bias is not None else None
+                from ihgnn_amd import profiler
+                profiler.start()
                 ops.interact_layer(hd, wd, bd, lay, order, scale).backward(cot.to(dev()))
+                ran = profiler.summary()
+                profiler.stop()
                 for a, c in zip([hd.grad, wd.grad] + ([bd.grad] if bd is not None else []), want_grads):
                     assert rel(a, c) <= RTOL, ('two-hop first-order gradient', edges, scaled)
+                # ... there the hyperedges' cotangents reach the member-gradient kernel as fp16 planes written by K5 (ihg_edge_gather_sum_planes; round 5): the same
+                # sums split the same way once instead of once per column part - bit-identical to the fp32 rows (IHG_COTANGENT_PLANES=0)
+                assert ops.COTANGENT_PLANES and 'edge_gather_sum' in ran and 'interact_bwd' in ran
+                monkeypatch.setattr(ops, 'COTANGENT_PLANES', False)
+                h2, w2 = h.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True)
+                b2 = bias.to(dev()).requires_grad_(True) if bias is not None else None
+                ops.interact_layer(h2, w2, b2, lay, order, scale).backward(cot.to(dev()))
+                assert torch.equal(h2.grad, hd.grad) and torch.equal(w2.grad, wd.grad)
                 monkeypatch.undo()
             wide = torch.full((lay.node_count, 2 * dim), 7.0, device=dev())
             with torch.no_grad():
@@ -1201,6 +1252,38 @@ def test_c5_scaled_weight_gradients_whole_matrix_against_the_oracle():
     assert rel(wd.grad, w64.grad) <= RTOL and row_rel(wd.grad, w64.grad) <= ROW_RTOL
     for blk in range(k):                                                  # every block on its own: a small block must not hide behind a large one
         assert rel(wd.grad[:, blk * d:(blk + 1) * d], w64.grad[:, blk * d:(blk + 1) * d]) <= RTOL, blk
+    # C5's own backward at this scale (what the 51 GB cotangent table takes at full size: IHG_FIRST_ORDER_TWO_HOP_BYTES): the first-order gradient by the two-hop operator, the
+    # hyperedges' cotangents written by K5 as fp16 planes for the member-gradient kernel, the member buffer in two chunks cut
+    # where the user changes - bit-identical to the fp32 rows chunked the same way, and d h of sampled nodes against the float64 oracle over all their hyperedges
+    mp = pytest.MonkeyPatch()
+    try:
+        mp.setattr(ops, 'FIRST_ORDER_TWO_HOP_BYTES', 0)
+        grads = {}
+        two_chunks = lay.edge_count * d * 4 + 1
+        for planes, limit in ((True, two_chunks), (False, two_chunks), (False, ops.MEMBER_BUFFER_LIMIT_BYTES)):
+            mp.setattr(ops, 'COTANGENT_PLANES', planes)
+            mp.setattr(ops, 'MEMBER_BUFFER_LIMIT_BYTES', limit)
+            h2, w2, b2 = h.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+            ops.interact_layer(h2, w2, b2, lay, order, lay.inv_deg).backward(cot.to(dev()))
+            grads[(planes, limit == two_chunks)] = (h2.grad, w2.grad, b2.grad)
+        assert len(lay.member_csr_qi_chunks(2)) == 2
+        for a, c in zip(grads[(True, True)], grads[(False, True)]):        # planes against fp32 rows, both in two chunks: the same bits
+            assert torch.equal(a, c)
+        for a, c in zip(grads[(True, True)], grads[(False, False)]):       # ... against one piece: the sums associate chunk by chunk (and tile range by tile range)
+            assert rel(a, c) <= 2e-6
+        grads = {True: grads[(True, True)]}
+    finally:
+        mp.undo()
+    rng = np.random.default_rng(3)
+    nodes = np.unique(np.concatenate([rng.integers(0, lay.user_count, 40), lay.user_count + rng.integers(0, lay.node_count - lay.user_count, 40)]))
+    deg = np.diff(lay.node_csr.ptr_host.astype(np.int64))
+    nodes = nodes[(deg[nodes] > 0) & (deg[nodes] <= 2000)]
+    hs = h.double().requires_grad_(True)
+    edges = np.unique(np.concatenate([lay.node_csr.ids_host[lay.node_csr.ptr_host[v]:lay.node_csr.ptr_host[v + 1]] for v in nodes])).astype(np.int64)
+    idx = i3[edges]
+    dF = sdy[idx[:, 0]] + sdy[idx[:, 1]] + sdy[idx[:, 2]]
+    (ref.feature_interactor(hs, idx, w.double(), b.double(), order) * dF).sum().backward()
+    assert rel(grads[True][0][torch.from_numpy(nodes).to(dev())], hs.grad[nodes]) <= RTOL
     assert rel(bd.grad, b64.grad) <= RTOL
 
 
