@@ -122,5 +122,20 @@ constexpr bool m_g_plain = true;
 #else
 constexpr bool m_g_plain = false;
 #endif
-constexpr bool any = m_g_window || m_g_parts || m_g_plain || d_no_dw || d_no_dx || d_no_split || d_no_loads || d_no_stores || n_no_service || n_no_fragments || n_no_reload || n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
+#ifdef IHG_ABL_M_UNCOND            // member gradients: every store of the service loop unconditional (rows past the end and the phases without a tile store too: wrong there) and no forced delivery
+constexpr bool m_uncond = true;
+#else
+constexpr bool m_uncond = false;
+#endif
+#ifdef IHG_ABL_M_TRACE             // member gradients: clock stamps at marks inside the phases of one workgroup (results stay correct; still not the product build)
+constexpr bool m_trace = true;
+#else
+constexpr bool m_trace = false;
+#endif
+#ifdef IHG_ABL_M_EPI_NOMATH        // member gradients: the product rule stores the contraction values as they are (image reads, no arithmetic).  (Storing values that do not come from the image removes the MFMA loop with it: the compiler drops LDS writes nobody reads - an ablation that reads nothing of the image measures an empty matrix role)
+constexpr bool m_epi_nomath = true;
+#else
+constexpr bool m_epi_nomath = false;
+#endif
+constexpr bool any = m_epi_nomath || m_trace || m_uncond || m_g_window || m_g_parts || m_g_plain || d_no_dw || d_no_dx || d_no_split || d_no_loads || d_no_stores || n_no_service || n_no_fragments || n_no_reload || n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
 }  // namespace abl

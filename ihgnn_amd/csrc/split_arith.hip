@@ -55,6 +55,16 @@ __global__ __launch_bounds__(kBlockThreads) void pack_planes_members_kernel(cons
     wsp[(static_cast<int64_t>(idx >> 6) * 2 + 1) * kWave + lane] = lo;
 }
 
+// Timeline probe of the member-gradient kernel (an ablation build's: -DIHG_ABL_M_TRACE; tools/phase_trace.py): lane 0 of matrix wave 0 and of service wave 4 of one
+// workgroup stamp the clock at marks inside 1,024 phases; ihg_ablation_trace() copies the stamps out.
+#ifdef IHG_ABL_M_TRACE
+__device__ unsigned long long g_phase_trace[2][1024][4];
+#define IHG_TRACE(role, k, mark)                                                                                   \
+    if (blockIdx.x == 40 && lane == 0 && (k) >= 200 && (k) < 1224) g_phase_trace[role][(k) - 200][mark] = clock64();
+#else
+#define IHG_TRACE(role, k, mark)
+#endif
+
 // Member gradients dz_b = dout W_b, then the product rule.  A workgroup owns HALF of the columns (its weight planes: 128 KB) and its eight
 // waves have two jobs, one of each per SIMD:
 //   - waves 0-3, the matrix waves: wave = product block b, the half's 64 columns x the tile's 32 hyperedges, 96 MFMAs per tile (two fp16 terms per
@@ -147,10 +157,21 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     const int ul = lane & (HC - 1);
     const bool uw = lane < HC;
     const int colg = HC * half + ul, win = wave & 3;
-    // (Round 5, PLANES: with the cotangents delivered scaled and split the sums were tried on the service waves again - C5 332.9 against 329.3 ms with them on the
-    // matrix waves: the service role is still the longer one.)
+    // D = 256 (round 5): the second step - closing the runs that cross windows - is the SERVICE waves' (window = wave & 3 there too; they carry the open run's user
+    // and rebuild a tile's run starts from the id ring with the same ballot).  A clock probe inside the kernel (tools/phase_trace.py) showed a phase of 4,050 cycles with the
+    // matrix waves at its end: 2,790 for the 96 MFMAs (their fragments wait for an LDS pipe that the eight parts' re-reads of the cotangent tile keep busy) + 970 for the two
+    // steps of the sums, the service waves done after 3,010.  (All of the sums on the service waves: C5 332.9 against 329.3 ms.)
+    constexpr bool CHAIN_SVC = UR && D == 256;
     uint64_t heads_prev = 0;                                         // run starts / user ids / rows of the tile whose windows were summed a phase ago
     int uid_prev = 0, rows_prev = 0;
+    auto tile_heads = [&](int t, int last_user, int& uid, int& rows) {   // run starts of tile t (bit r: row r begins a run), given the user of the row in front of it
+        const int* idk = ids[t & 7];
+        rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + t) * TE));
+        const int r = lane < rows ? lane : rows - 1;
+        uid = idk[r * 3];
+        const int prev_uid = r == 0 ? last_user : idk[(r - 1) * 3];
+        return __ballot(lane < rows && uid != prev_uid);
+    };
     auto run_target = [&](int t, int r, int uid) {                   // destination of the run that starts at row r of tile t
         return (t == 0 && r == 0) ? first_slot : dh_user + static_cast<int64_t>(__builtin_amdgcn_readlane(uid, r)) * ld_dh;
     };
@@ -159,12 +180,9 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         for (int i = 0; i < 8; ++i) v[i] = utile[t & 1][8 * win + i][ul];
     };
     auto sum_window = [&](int t, const float (&v)[8]) {              // tile t, 0 <= t < n_my
-        const int* idk = ids[t & 7];
-        const int rows = static_cast<int>(std::min<int64_t>(TE, n_edges - (t0 + t) * TE));
-        const int r = lane < rows ? lane : rows - 1;
-        const int uid = idk[r * 3];
-        const int prev_uid = r == 0 ? cur_user : idk[(r - 1) * 3];
-        const uint64_t m = __ballot(lane < rows && uid != prev_uid);
+        int uid, rows;
+        // (CHAIN_SVC: this role does not carry the open run's user - the last row of the tile before, full by construction, is still in the id ring)
+        const uint64_t m = tile_heads(t, CHAIN_SVC ? (t == 0 ? -1 : ids[(t - 1) & 7][(TE - 1) * 3]) : cur_user, uid, rows);
         heads_prev = m;
         uid_prev = uid;
         rows_prev = rows;
@@ -197,6 +215,9 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             }
         }
     };
+    // (Round 5, D = 256, tools/phase_trace.py: this step costs 830 of a phase's 3,900 cycles behind the MFMA loop.  Cut into ten pieces riding INSIDE the loop - one per k-step
+    // between the request of the next step's fragments and the first MFMA of this one - the loop grew from 2,680 to 3,830 cycles: its lost cycles are not waits an in-order wave
+    // could fill.  With the id reads sent out at the phase's start and the rest behind the loop: 2,910 + 860.  Both removed.)
     struct Chain {
         float tail[4], head, carry;
     };
@@ -207,6 +228,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         c.carry = ucarry[t & 1][ul];
     };
     auto chain_windows = [&](int t, const Chain& c) {                // tile t, a phase after sum_window(t)
+        if (CHAIN_SVC) heads_prev = tile_heads(t, cur_user, uid_prev, rows_prev);
         const unsigned m = static_cast<unsigned>(heads_prev);
         const unsigned before_me = m & ((1u << (8 * win)) - 1u);     // run starts in earlier windows of the tile
         const int p = before_me != 0 ? (31 - __builtin_clz(before_me)) >> 3 : -1;            // the last earlier window that has one
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
         if (m != 0) first_run_open = t == 0 && m == 1u;
         cur_user = __builtin_amdgcn_readlane(uid_prev, rows_prev - 1);
     };
-    auto close_range = [&]() {                                       // after the last phase (matrix waves)
+    auto close_range = [&]() {                                       // after the last phase, by the role that closes the runs
         // the last run of the range may continue in the next one: second boundary slot - unless it IS the first run
         const bool one_run = first_run_open;
         if (cur_user >= 0 && win == 0 && uw) {
@@ -258,6 +280,12 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             const int64_t first = std::min<int64_t>((t0 + k) * TE, n_edges - 1);
             const int lim = static_cast<int>(std::min<int64_t>(n_edges - 1 - first, TE - 1));
             if (PLANES) {                                                // 16-byte piece o + 8 x of either plane, as it goes into the image; the row's inverse scale first (the oldest request)
+                if (abl::m_no_dy_loads) {
+                    iv = 1.f;
+#pragma unroll
+                    for (int x = 0; x < 2 * DOCT; ++x) dr[x] = v4f{1.f, 2.f, 3.f, 4.f} * static_cast<float>(lim + x);
+                    return;
+                }
                 iv = (inv_src + first)[std::min(row, lim)];
                 const float* src = row_at(dout + first * ld_dout, std::min(row, lim), ldd) + 4 * o;
 #pragma unroll
@@ -380,9 +408,14 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                     g_q += z_uqi * (hu * hi);
                     g_i += z_uqi * (hu * hq);
                 }
+                if (abl::m_epi_nomath) {                                 // the image reads and the stores, no arithmetic
+                    g_u = z_iu;
+                    g_q = z_uq;
+                    g_i = z_qi;
+                }
                 const bool live = e < n_edges;
                 if (UR) *reinterpret_cast<v4f*>(&utile[(k - 1) & 1][row][c]) = live ? g_u : v4f{0.f, 0.f, 0.f, 0.f};     // (rows past the end: zeros for the sums)
-                if (live && !abl::m_no_g_stores) {
+                if ((live || abl::m_uncond) && !abl::m_no_g_stores) {
                     // (where the stores land does not matter: into a 48 MB window, as one contiguous stream per column part or as plain stores the kernel takes the same
                     // time - ablate.hpp, profiles/r5/22_abl_member_stores_d256.txt: removing them "saves" 10 of 18 ms only because the product rule goes with them)
                     const int64_t er = abl::m_g_window ? (e & 0x3fff) : e;
@@ -436,7 +469,10 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             // `k + 4 + AHEAD < n_my && st < 96`, the only requests younger than it were the epilogue's stores - themselves under `live` - and the wait for it at the top of the
             // next phase was vmcnt(0): every other phase drained the queue, the previous phase's six stores included.  With the row requests behind it the wait is an exact
             // count that leaves them (and the stores) in flight.
+            if (wave == 4) { IHG_TRACE(1, k, 0) }
             const int id_new = fetch_id(std::min(k + 4 + AHEAD, n_my - 1));
+            Chain chain;
+            if (CHAIN_SVC && !abl::m_no_user_sums && k >= 3) load_chain(k - 3, chain);      // LDS reads of the run sums this phase closes, used at its end
             // ids of tile k + 3 + AHEAD (requested in the previous phase) into the ring: a phase ahead of their first readers (the gathered rows of
             // that tile in the next phase)
             if (k >= 1 && k + 3 + AHEAD < n_my && st < 3 * TE) ids[(k + 3 + AHEAD) & 7][st] = id_carry;
@@ -444,17 +480,22 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             if (GATHER) load_gather(k + 3, raw_req);
             else load_dout(k + 2, fill, iv_fill);
             id_carry = id_new;
+            if (wave == 4) { IHG_TRACE(1, k, 1) }
             if (k + 1 < n_my) split_tile(use, (k + 1) & 1, iv_use);
+            if (wave == 4) { IHG_TRACE(1, k, 2) }
             // delivery of this phase's requests, THEN everything that stores: the memory counter is in order, a wait behind a store sits out
             // the store's round trip to memory
             if (GATHER) {                                                // (the rows requested a phase ago: this phase's requests stay in flight)
                 asm volatile("" : "+v"(raw_use.r[2][2 * DOCT - 2]), "+v"(raw_use.r[2][2 * DOCT - 1]), "+v"(raw_use.s[2]));
-            } else {
+            } else if (!abl::m_uncond) {
                 asm volatile("" : "+v"(fill[0]), "+v"(fill[1]), "+v"(fill[2 * DOCT - 2]), "+v"(fill[2 * DOCT - 1]));     // (in order: the last delivered = all delivered)
             }
-            asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));       // (left to where the next phase reads them: no gain)
+            if (!abl::m_uncond) asm volatile("" : "+v"(hm_cur[EX - 1][0]), "+v"(hm_cur[EX - 1][1]), "+v"(hm_cur[EX - 1][2]));       // (left to where the next phase reads them: no gain)
             if (GATHER) combine(k + 2, raw_use, fill);
-            if (k >= 1 && k - 1 < n_my && !abl::m_no_product_rule) epilogue(k, hm_prev);
+            if (abl::m_uncond) epilogue(std::min(std::max(k, 1), n_my), hm_prev);
+            else if (k >= 1 && k - 1 < n_my && !abl::m_no_product_rule) epilogue(k, hm_prev);
+            if (CHAIN_SVC && !abl::m_no_user_sums && k >= 3) chain_windows(k - 3, chain);
+            if (wave == 4) { IHG_TRACE(1, k, 3) }
             __syncthreads();
         };
         int k = 0;
@@ -464,6 +505,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             phase(k + 1, dr0, GATHER ? dr0 : dr1, hm1, hm0, raw0, raw1, iv0, iv1);
         }
         if (k < n_phases) phase(k, GATHER ? dr0 : dr1, dr0, hm0, hm1, raw1, raw0, iv1, iv0);
+        if (CHAIN_SVC) close_range();
         return;
     }
 
@@ -486,22 +528,27 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
     for (int k = 0; k < n_phases; ++k) {
         float wrows[8];
         Chain chain;
+        if (wave == 0) { IHG_TRACE(0, k, 0) }
+        const bool sums_now = UR && !abl::m_no_user_sums && k >= 2 && k - 2 < n_my;
         if (UR && !abl::m_no_user_sums) {                                // LDS reads of this phase's run sums, used at its end
-            if (k >= 2 && k - 2 < n_my) load_window(k - 2, wrows);
-            if (k >= 3) load_chain(k - 3, chain);
+            if (sums_now) load_window(k - 2, wrows);
+            if (!CHAIN_SVC && k >= 3) load_chain(k - 3, chain);
         }
-        if (k < n_my && blk < NBLK && !abl::m_no_mfma) {
+        const bool mfma_now = k < n_my && blk < NBLK && !abl::m_no_mfma;
+        if (mfma_now) {
             const unsigned char* pbase = &planes[k & 1][0][0][0];
-            // row tile after row tile (one set of CT accumulator tiles live), the fragments of step s + 1 requested in front of the MFMAs of step s
+            // row tile after row tile (one set of CT accumulator tiles live), the fragments of step s + 1 requested in front of the MFMAs of step s.  (D = 256, round 5, clock
+            // probe: the loop takes 2,680 cycles for 96 MFMAs = 1,536 cycles of matrix pipe.  Fragments two steps ahead: 2,710.  Both row tiles at once - four accumulator
+            // chains instead of two: 2,640.  Neither the LDS latency nor the accumulator dependency is what it loses; the same loop beside a service role that only copies: see DESIGN.)
             auto fragment = [&](int step, v8h (&a)[2]) {
                 const int rt = step / KB, kb = step % KB;
                 const unsigned char* src = pbase + (16 * rt + arow) * RB + (((4 * kb + kq) ^ (arow & SWZ)) << 4);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) a[p] = *reinterpret_cast<const v8h*>(src + p * (TE * RB));
             };
+            const float iv[2] = {sinv[k & 1][arow], sinv[k & 1][16 + arow]};
             v8h a[2], an[2];
             v4f acc[CT];
-            const float iv[2] = {sinv[k & 1][arow], sinv[k & 1][16 + arow]};
             fragment(0, a);
 #pragma unroll
             for (int step = 0; step < 2 * KB; ++step) {
@@ -526,13 +573,15 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 }
             }
         }
+        if (wave == 0) { IHG_TRACE(0, k, 1) }
         if (UR && !abl::m_no_user_sums) {
-            if (k >= 3) chain_windows(k - 3, chain);                     // (before the next tile's ballot: it compares with the open run's user)
-            if (k >= 2 && k - 2 < n_my) sum_window(k - 2, wrows);
+            if (!CHAIN_SVC && k >= 3) chain_windows(k - 3, chain);       // (before the next tile's ballot: it compares with the open run's user)
+            if (sums_now) sum_window(k - 2, wrows);
         }
+        if (wave == 0) { IHG_TRACE(0, k, 2) }
         __syncthreads();
     }
-    if (UR) close_range();
+    if (UR && !CHAIN_SVC) close_range();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1139,6 +1188,11 @@ int64_t split_plane_floats(int dim, int order) { return (dim == 64 || dim == 128
 
 // the translation unit the ablation macros reach (tools/ab_variant.sh): include/ihgnn_hip.h
 extern "C" int32_t ihg_ablation_build(void) { return abl::any ? 1 : 0; }
+#ifdef IHG_ABL_M_TRACE
+extern "C" int ihg_ablation_trace(unsigned long long* out) {             // [2][1024][4] clock stamps of the last member-gradient launch (tools/phase_trace.py)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_trace), sizeof(g_phase_trace), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 
 bool split_arith_enabled() {                                             // read at every call: tests and the bench switch it in-process
     const char* v = std::getenv("IHG_INTERACT_ARITH");
