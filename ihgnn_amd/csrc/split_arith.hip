@@ -401,6 +401,7 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
                 const v4f z_uq = *reinterpret_cast<const v4f*>(&dz[0][row][c]), z_qi = *reinterpret_cast<const v4f*>(&dz[1][row][c]);
                 const v4f z_iu = *reinterpret_cast<const v4f*>(&dz[2][row][c]);
                 const v4f hu = hm[x][0], hq = hm[x][1], hi = hm[x][2];
+                // (round 5: the same rule element by element - no packed fp32 instructions beside the matrix waves' MFMAs - measured the same: phase 3,900 against 3,880 cycles)
                 v4f g_u = z_uq * hq + z_iu * hi, g_q = z_uq * hu + z_qi * hi, g_i = z_qi * hq + z_iu * hu;
                 if (NBLK == 4) {
                     const v4f z_uqi = *reinterpret_cast<const v4f*>(&dz[3][row][c]);
