@@ -50,6 +50,12 @@ def main():
     out = np.zeros((2, 1024, 4), np.uint64)
     assert fn(out.ctypes.data) == 0
     t = out.astype(np.int64)
+    ok = (t[0] > 0).all(1) | (t[1] > 0).all(1)
+    ok &= (t[0][:, :3] > 0).all(1) & (t[1] > 0).all(1)                  # (a workgroup with fewer phases than the stamped window leaves zeros)
+    n_ok = int(np.argmin(ok)) if not ok.all() else len(ok)
+    if n_ok < 8:
+        sys.exit(f'only {n_ok} stamped phases: workgroup 40 has fewer than 208 phases at this size')
+    t = t[:, :n_ok]
     m, s = t[0], t[1]
     phase = np.diff(m[:, 0])
     print(f'{args.config} x {args.scale}: E = {E}, d = {d}; {len(phase)} phases, clock ticks (clock64)')
