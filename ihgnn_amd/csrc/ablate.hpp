@@ -137,5 +137,10 @@ constexpr bool m_epi_nomath = true;
 #else
 constexpr bool m_epi_nomath = false;
 #endif
-constexpr bool any = m_epi_nomath || m_trace || m_uncond || m_g_window || m_g_parts || m_g_plain || d_no_dw || d_no_dx || d_no_split || d_no_loads || d_no_stores || n_no_service || n_no_fragments || n_no_reload || n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
+#ifdef IHG_ABL_D_TRACE             // node-level linear backward: clock stamps inside the phases of one workgroup (results stay correct)
+constexpr bool d_trace = true;
+#else
+constexpr bool d_trace = false;
+#endif
+constexpr bool any = d_trace || m_epi_nomath || m_trace || m_uncond || m_g_window || m_g_parts || m_g_plain || d_no_dw || d_no_dx || d_no_split || d_no_loads || d_no_stores || n_no_service || n_no_fragments || n_no_reload || n_no_mfma || n_no_split || n_no_first || n_no_shuffle || m_no_g_stores || m_no_dout_store || m_no_member_loads || m_no_dy_loads || m_no_mfma || m_no_split || m_no_user_sums || m_no_product_rule;
 }  // namespace abl

@@ -1466,6 +1466,14 @@ __global__ __launch_bounds__(512, 2) void row_gemm_split_kernel(TypedRows in, in
 // Round 5: every vector-memory request of the loop is unconditional (narrow.hip has the argument: the memory counter is in order and the compiler waits by count; a request
 // under a branch makes the next wait vmcnt(0)).  ACC (dx += instead of dx =) is a template parameter - its reads of dx were loads under a run-time flag -, and a lane whose dx
 // row lies past the type's end stores to a dump piece inside the workgroup's own slab (written for good only at the kernel's end) through a global-address-space pointer.
+// (-DIHG_ABL_D_TRACE: clock stamps of wave 0 of one workgroup at marks inside its phases, as in split_arith.hip; tools/phase_trace.py --kernel linear)
+#ifdef IHG_ABL_D_TRACE
+__device__ unsigned long long g_dense_trace[64][6];
+#define IHG_DTRACE(k, mark) \
+    if (blockIdx.x == 40 && blockIdx.z == 0 && tid == 0 && (k) < 64) g_dense_trace[k][mark] = clock64();
+#else
+#define IHG_DTRACE(k, mark)
+#endif
 template <int D, bool DX, bool ACC>
 __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(const float* __restrict__ dout, int64_t ld_dout, TypedRows x,
                                                                                 int64_t ld_x, RowTiles plan, int single_weight, float* __restrict__ slabs,
@@ -1635,6 +1643,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
         // phase k: contraction of tile k (images k & 1); images of tile k + 1 from `use`; request of tile k + 2 (`fill`), delivered and its exponents published at the end
         auto phase = [&](int k, Rows& use, Rows& fill) {
             const int BUF = k & 1;
+            IHG_DTRACE(k, 0)
             // the accumulators to the scale tile k was split under (it includes tile k's own rows); then the running maximum moves on to tile k + 1 for the split
             if (l_split != l_acc) {
                 if (l_acc >= 0) {
@@ -1664,6 +1673,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                 }
             }
             load_rows(std::min(k + 2, n_my - 1), fill);                  // (unconditional: a branch around requests makes the compiler wait for all of them)
+            IHG_DTRACE(k, 1)
             const unsigned char* dp = &dplanes[0][0][0][0] + BUF * (2 * DPL);
             const unsigned char* xp = &xplanes[0][0][0][0] + BUF * (2 * XPL);
             v8h a[IT][2];
@@ -1695,6 +1705,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
 #pragma unroll
                 for (int p = 0; p < 2; ++p) b[p] = bn[p];
             }
+            IHG_DTRACE(k, 2)
             v4f gx[2];
             if (DX) {                                                    // row reads of the row-scaled dout images: chunk 4 kb + (lane >> 4) of row 16 rt + (lane & 15)
                 const unsigned char* np = &nplanes[0][0][0][0] + BUF * (2 * DPL);
@@ -1715,7 +1726,9 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                     gx[rt] = gx[rt] * (wiv * rown[BUF][r]) + gold[rt];
                 }
             }
+            IHG_DTRACE(k, 3)
             publish(k + 2, fill);                                        // (takes delivery of the requested rows)
+            IHG_DTRACE(k, 4)
             if (DX) {                                                    // (after the delivery: the counter is in order)
                 const int arow = lane & 15, kq = lane >> 4;
                 const int64_t r_base = r_begin + (static_cast<int64_t>(seq) + static_cast<int64_t>(k) * n_seq) * TE;
@@ -1729,6 +1742,7 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                     if (!abl::d_no_stores || gx[rt][0] == 1.2345e30f) *reinterpret_cast<__attribute__((address_space(1))) v4f*>(dst) = gx[rt];
                 }
             }
+            IHG_DTRACE(k, 5)
             __syncthreads();
         };
         int k = 0;
@@ -1982,3 +1996,9 @@ int launch_dense_weight_split(int dim, const float* dout, int64_t ld_dout, Typed
                        int64_t{0});
     return n_seq;
 }
+
+#ifdef IHG_ABL_D_TRACE
+extern "C" int ihg_ablation_trace_dense(unsigned long long* out) {       // [64][6] clock stamps of the last node-level linear backward (tools/phase_trace.py --kernel linear)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dense_trace), sizeof(g_dense_trace), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif

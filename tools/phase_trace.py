@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--scale', type=float, default=0.2)
     ap.add_argument('--op', default='layer', choices=['layer', 'interact'])
     ap.add_argument('--order', type=int, default=3)
+    ap.add_argument('--kernel', default='members', choices=['members', 'linear'], help='linear: the node-level linear backward (-DIHG_ABL_D_TRACE)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     d = synth.CONFIGS[args.config]['dim']
@@ -44,6 +45,26 @@ def main():
             ops.interact(hr, x, wa, lay, args.order).backward(torch.randn(E, d, device=dev))
     torch.cuda.synchronize()
     lib = _lib.load()
+    if args.kernel == 'linear':
+        wt = (torch.randn(d, d, device=dev) / d ** 0.5).requires_grad_(True)
+        for _ in range(2):
+            xr = x.detach().requires_grad_(True)
+            ops.node_linear(xr, wt, b, lay).backward(dy)
+        torch.cuda.synchronize()
+        fn = lib.ihg_ablation_trace_dense
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p]
+        out = np.zeros((64, 6), np.uint64)
+        assert fn(out.ctypes.data) == 0
+        t = out.astype(np.int64)
+        n_ok = int(np.argmin((t > 0).all(1))) if not (t > 0).all() else 64
+        t = t[2:n_ok - 1]
+        print(f'{args.config} x {args.scale}: N = {N}, d = {d}; node-level linear backward, wave 0 of workgroup 40, {len(t)} phases, clock ticks from the phase\'s start')
+        names = ['rows requested', 'dW contraction + next tile split', 'dx contraction', 'rows delivered + exponents published', 'dx stored (barrier reached)']
+        for i, name in enumerate(names):
+            print(f'  {name:44s} {np.mean(t[:, i + 1] - t[:, 0]):9.1f}')
+        print(f'  phase length                                 {np.mean(np.diff(t[:, 0])):9.1f}')
+        return
     fn = lib.ihg_ablation_trace
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_void_p]
