@@ -1672,8 +1672,8 @@ __global__ __launch_bounds__(kSplitThreads) void dense_weight_grad_split_kernel(
                     gold[rt] = *reinterpret_cast<const v4f*>(typed_base(dx, row_type(v)) + v * ld_dx + 16 * wave + 4 * (lane >> 4));
                 }
             }
-            load_rows(std::min(k + 2, n_my - 1), fill);                  // (unconditional: a branch around requests makes the compiler wait for all of them)
-            IHG_DTRACE(k, 1)
+            load_rows(std::min(k + 2, n_my - 1), fill);                  // (unconditional: a branch around requests makes the compiler wait for all of them; round 5, clock
+            IHG_DTRACE(k, 1)                                             //  probe: the requests stand 785 cycles into the phase, behind the bookkeeping above - moved to its top: 150 -> 168 us)
             const unsigned char* dp = &dplanes[0][0][0][0] + BUF * (2 * DPL);
             const unsigned char* xp = &xplanes[0][0][0][0] + BUF * (2 * XPL);
             v8h a[IT][2];
