@@ -215,6 +215,9 @@ __global__ __launch_bounds__(kSplitThreads) void interact_bwd_members_split_ws_k
             }
         }
     };
+    // (Round 5, D = 256: a "run plan" - the service waves work out a tile's run starts, reset factors and destination addresses a phase ahead (lane = row) and this step reads
+    // them instead of rebuilding them with scalar instructions: the two steps 980 -> 550 cycles, the MFMA loop 2,680 -> 3,140, the phase 3,880 -> 4,060: the SIMD's issue port
+    // is shared, what the plan's LDS traffic and the service waves' extra instructions cost lands on the same phase.  Removed.)
     // (Round 5, D = 256, tools/phase_trace.py: this step costs 830 of a phase's 3,900 cycles behind the MFMA loop.  Cut into ten pieces riding INSIDE the loop - one per k-step
     // between the request of the next step's fragments and the first MFMA of this one - the loop grew from 2,680 to 3,830 cycles: its lost cycles are not waits an in-order wave
     // could fill.  With the id reads sent out at the phase's start and the rest behind the loop: 2,910 + 860.  Both removed.)
