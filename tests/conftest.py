@@ -50,7 +50,7 @@ def f8_case(tag, fixture='f8_wide_models.npz'):
     return (L, order, d), seeded_state(shapes, seed), z
 
 
-F10_TAGS = ('d128_l3_o3', 'd64_l2_o3', 'd32_l2_o3', 'd128_l3_o2')
+F10_TAGS = ('d128_l3_o3', 'd64_l2_o3', 'd32_l2_o3', 'd128_l3_o2', 'd256_l2_o3')
 
 
 def f10_case(tag):

@@ -253,7 +253,7 @@ def test_f6_training_curve_and_metrics(tag):
     np.testing.assert_allclose(acc / len(w['test_uq']), z[f'{tag}.metrics'], atol=2e-3)
 
 
-@pytest.mark.parametrize('tag', ['d128_l3_o3', 'd64_l2_o3', 'd32_l2_o3', 'd128_l3_o2'])
+@pytest.mark.parametrize('tag', ['d128_l3_o3', 'd64_l2_o3', 'd32_l2_o3', 'd128_l3_o2', 'd256_l2_o3'])
 def test_f10_training_curve_and_metrics_at_the_headline_widths(tag):
     """F10: the reference's 48-step curve and ranking metrics at d = 128 x 3 layers (orders 3, 2), d = 64 x 2 and d = 32 x 2 (the reference's default
     width) on a power-law graph with split rows - the oracle replays it."""
