@@ -1675,6 +1675,18 @@ def test_full_size_c5_node_level_layer():
     rhs_prod = (dy.double() * y_prod.double()).sum()
     assert abs(lhs_prod - rhs_prod) / abs(rhs_prod) <= 1e-4
 
+    # d h of the sampled nodes against the oracle over exactly their incident hyperedges (round 5: this backward is C5's own - the hyperedges' cotangents written by K5 as
+    # fp16 planes, the member gradients with the user slot summed on chip in two chunks cut where the user changes, the first-order gradient by the two-hop operator)
+    assert 'k7.two_hop_first_order_gradient' in launched and launched['interact_bwd']['launches'] == 2 and 'k7.member_gradients_rows' in launched, sorted(launched)
+    i3_dev = lay.i3.long()
+
+    def edge_cotangent(edges):                                           # dF[e] = sum over e's members m of Dv^-1[m] dY[m]
+        idx = i3_dev[torch.from_numpy(edges).to(dev())]
+        return sum(dy[idx[:, j]] * scale[idx[:, j]][:, None] for j in range(3)).cpu()
+
+    want_dh = _oracle_on_sampled_nodes(lay, nodes, h, wgt.detach().cpu(), order, edge_cotangent)
+    assert rel(h.grad[torch.from_numpy(nodes).to(dev())], want_dh) <= RTOL
+
 
 def test_integration_md_binding_stub_runs():
     """The ctypes stub INTEGRATION.md shows a maintainer of the reference (section 2) is executed as written, against the
