@@ -1393,10 +1393,11 @@ def _sample_nodes(lay, rng, per_type=40, max_degree=64):
     return np.unique(nodes[deg[nodes] <= 20_000])
 
 
-@pytest.mark.parametrize('config,order', [('C3', 3), ('C3', 2), ('C4', 3)])
-def test_full_size_layer0_path_of_the_headline_step(config, order):
+@pytest.mark.parametrize('config,order,dim', [('C3', 3, 0), ('C3', 2, 0), ('C4', 3, 0), ('C2', 3, 32), ('C2', 2, 32)])
+def test_full_size_layer0_path_of_the_headline_step(config, order, dim):
     """The kernels the bench headline times, at the headline's size: ``ops.interact_to_nodes`` at d = 128 over the full C3 / C4
-    hypergraph - forward = interact + the hyperedge -> node pass, backward = the GATHERING member-gradient kernel
+    hypergraph (and, round 5, at the reference's default width d = 32 over the full C2 hypergraph: ``csrc/narrow.hip`` - one wave per tile range, 2,048 ranges,
+    the runs' boundary table and its fix-up at a real size) - forward = interact + the hyperedge -> node pass, backward = the GATHERING member-gradient kernel
     (``interact_bwd_members_split_ws_kernel<128, true, NBLK, true>``: user slot reduced on chip across hundreds of tiles per
     workgroup, hyperedge cotangents formed from ``dy`` inside the kernel, no node -> hyperedge launch), weight gradients, first-order
     scatter.  Against the ORACLE on sampled node rows (forward and d h, each over exactly the incident hyperedges of the node), the
@@ -1407,7 +1408,7 @@ def test_full_size_layer0_path_of_the_headline_step(config, order):
     w_ = synth.draw_config(config)
     lay = IncidenceLayout(w_.triples, w_.user_count, w_.query_count, w_.item_count, dev())
     assert lay.user_sorted
-    d = synth.CONFIGS[config]['dim']
+    d = dim or synth.CONFIGS[config]['dim']
     k = 7 if order == 3 else 6
     gen = torch.Generator(device=dev()).manual_seed(17)
     h = (torch.randn(lay.node_count, d, device=dev(), generator=gen) / 4).requires_grad_(True)
