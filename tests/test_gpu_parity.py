@@ -1516,8 +1516,8 @@ def _oracle_row_over_all_its_hyperedges(lay, v, h_dev, w_c, bias_c, order, inv_d
     return inv_deg_c[v].double() * total, grad, int(edges.shape[0])
 
 
-@pytest.mark.parametrize('config,n_edges', [('C3', None), ('C4', None), ('C5', 1_000_000)])
-def test_heaviest_rows_against_the_oracle_over_all_their_hyperedges(config, n_edges):
+@pytest.mark.parametrize('config,n_edges,dim', [('C3', None, 0), ('C4', None, 0), ('C5', 1_000_000, 0), ('C2', None, 32), ('C3', None, 32)])
+def test_heaviest_rows_against_the_oracle_over_all_their_hyperedges(config, n_edges, dim):
     """The node-level form adds up S_ab = sum h[a] * h[b] over ALL of a node's hyperedges - through the split-row tree - before the linear maps: for the
     top-degree node of every type (C3 / C4 at full size: up to a few 10^5 hyperedges; C5: the layout rebuilt on the first 10^6 hyperedges, whose top node is
     in ~ 19 % of them) the layer's output row AND its input gradient row are compared with the float64 oracle over all incident hyperedges, PER ROW
@@ -1525,7 +1525,7 @@ def test_heaviest_rows_against_the_oracle_over_all_their_hyperedges(config, n_ed
     from ihgnn_amd import ops, synth
     from ihgnn_amd.layout import IncidenceLayout
     cfg = synth.CONFIGS[config]
-    d, order = cfg['dim'], 3
+    d, order = dim or cfg['dim'], 3                                       # (dim 32: the reference's default width - narrow.hip, fp32 MFMA - on the C2 and C3 graphs)
     w = synth.draw_config(config)
     triples = w.triples if n_edges is None else w.triples[:n_edges]
     lay = IncidenceLayout(triples, w.user_count, w.query_count, w.item_count, dev())
