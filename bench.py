@@ -81,7 +81,7 @@ def parse():
     ap.add_argument('--dim', type=int, default=0, help='embedding width instead of the config\'s (the reference\'s default is --emb 32, Helpers/GlobalSettings.py:30)')
     ap.add_argument('--layer', default='ihgnn', choices=['ihgnn', 'hgcn'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-scale', type=float, default=0.25, help='fraction of the workload the CPU baseline runs on')
+    ap.add_argument('--cpu-scale', type=float, default=0.125, help='fraction of the workload the CPU baseline runs on (C3: ~3 s per oracle step on 32 threads; 7 steps)')
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--no-extras', action='store_true', help='skip the untimed extra passes (per-kernel table, restricted last layer, forward only)')
     ap.add_argument('--scale', type=float, default=1.0, help='shrink every count of the workload (exploratory runs of the big configs)')
@@ -130,63 +130,58 @@ def build_model(ds, dev, layer, layers, order, dim):
     return RawGnn(dev, ds, dim, layer_t, layers, order, False, HemPredictionLayer, 0.5).to(dev)
 
 
-def cpu_baseline(config, layer, layers, order, dim, scale, budget_s=10.0):
-    """Time the oracle's full training step on the host cores, on a `scale` sub-sample of the SAME config (every count scaled).
+CPU_BASELINE_THREADS = 32     # torch threads of the CPU leg: min(this, host cores).  FIXED per host (rounds 4 / 5 chose it with a one-step probe and printed 3.05e5 on 32 threads,
+                              # then 2.58e5 on 8: the probe's noise moved the stated baseline by 15 %); PyTorch-CPU does not scale past a few dozen threads on this op mix
 
-    PyTorch-CPU does not scale to hundreds of threads on this op mix, so a few thread counts are probed with one step
-    each and the fastest is used for the timed run (`cores` reports that count)."""
+
+def cpu_baseline(config, layer, layers, order, dim, scale, runs=3, steps_per_run=2):
+    """Time the oracle's full training step on the host cores, on a `scale` sub-sample of the SAME config (every count scaled): one warm-up step, then `runs` timed runs
+    of `steps_per_run` steps each; `value` is the MEDIAN run, the spread (slowest / fastest run) is printed beside it.  The thread count is a function of the host's core
+    count alone (min(cores, CPU_BASELINE_THREADS))."""
     import numpy as np
     import torch
     from ihgnn_amd import synth
     from oracle import ihgnn_ref as ref
     host = os.cpu_count() or 1
+    cores = min(host, CPU_BASELINE_THREADS)
     rng = np.random.default_rng(1)
+    w = synth.draw_config(config, scale=scale)
+    g = ref.HyperGraph(w.triples, w.user_count, w.query_count, w.item_count)
+    torch.manual_seed(0)
+    m = ref.OracleRawGnn(g, torch.from_numpy(w.bag_words + 1), torch.from_numpy(w.bag_offsets), w.vocab_size, dim, layer, layers, order)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.uniform_(-0.1, 0.1)
+    opt = torch.optim.Adam(m.parameters(), 1e-3)
+    lossf = torch.nn.BCEWithLogitsLoss()
 
-    def build(sample_scale):
-        w = synth.draw_config(config, scale=sample_scale)
-        g = ref.HyperGraph(w.triples, w.user_count, w.query_count, w.item_count)
-        torch.manual_seed(0)
-        m = ref.OracleRawGnn(g, torch.from_numpy(w.bag_words + 1), torch.from_numpy(w.bag_offsets), w.vocab_size, dim, layer, layers, order)
-        with torch.no_grad():
-            for p in m.parameters():
-                p.uniform_(-0.1, 0.1)
-        opt = torch.optim.Adam(m.parameters(), 1e-3)
-        lossf = torch.nn.BCEWithLogitsLoss()
+    def step():
+        u = torch.from_numpy(rng.integers(0, w.user_count, 1100)); q = torch.from_numpy(rng.integers(0, w.query_count, 1100))
+        i = torch.from_numpy(rng.integers(0, w.item_count, 1100))
+        y = torch.cat([torch.ones(100), torch.zeros(1000)])
+        loss = lossf(m(u, q, i), y)
+        loss.backward(); opt.step(); opt.zero_grad()
 
-        def step():
-            u = torch.from_numpy(rng.integers(0, w.user_count, 1100)); q = torch.from_numpy(rng.integers(0, w.query_count, 1100))
-            i = torch.from_numpy(rng.integers(0, w.item_count, 1100))
-            y = torch.cat([torch.ones(100), torch.zeros(1000)])
-            loss = lossf(m(u, q, i), y)
-            loss.backward(); opt.step(); opt.zero_grad()
-        return w, step
-
-    # the thread count is chosen on a quarter of the sample (same op mix, a quarter of the time), the timed run uses the whole sample
-    probes = {}
-    if scale * 0.25 * synth.CONFIGS[config]['edge_count'] >= 20_000:
-        _, probe_step = build(scale * 0.25)
-    else:
-        _, probe_step = build(scale)
-    for threads in sorted({min(host, 8), min(host, 16), min(host, 32)}):     # more threads only get slower on this op mix
-        torch.set_num_threads(threads)
-        probe_step()                         # warm-up at this thread count
-        t0 = time.perf_counter(); probe_step()
-        probes[threads] = time.perf_counter() - t0
-        if probes[threads] > 2.5 * min(probes.values()):
-            break                            # clearly past the sweet spot
-    w, step = build(scale)
-    cores = min(probes, key=probes.get)
+    before = torch.get_num_threads()
     torch.set_num_threads(cores)
-    step()                                   # warm-up on the full sample
-    t0 = time.perf_counter(); n = 0
-    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 20):
-        step(); n += 1
-    dt = time.perf_counter() - t0
-    return dict(value=w.edge_count * layers * n / dt, unit='hyperedges/s', cores=cores, kind='port',
+    step()                                   # warm-up
+    rates, total_s = [], 0.0
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        for _ in range(steps_per_run):
+            step()
+        dt = time.perf_counter() - t0
+        total_s += dt
+        rates.append(w.edge_count * layers * steps_per_run / dt)
+    torch.set_num_threads(before)
+    rates.sort()
+    median = rates[len(rates) // 2]
+    n = runs * steps_per_run
+    return dict(value=median, unit='hyperedges/s', cores=cores, kind='port',
                 sample=f'{n} full training steps of the PyTorch-CPU oracle (reference op sequence) on a {scale:g}x sub-sample of '
-                       f'{config} (every count scaled: E={w.edge_count}, N={w.node_count}, d={dim}, {layers} layers); {cores} threads = fastest of '
-                       f'{sorted(probes)} probed (one step each, on a quarter of the sample) on a {host}-core host, torch {torch.__version__}',
-                ms_per_step=1e3 * dt / n)
+                       f'{config} (every count scaled: E={w.edge_count}, N={w.node_count}, d={dim}, {layers} layers), after one warm-up step; value = median of {runs} runs of '
+                       f'{steps_per_run} steps; {cores} threads = min(host cores, {CPU_BASELINE_THREADS}) on a {host}-core host, torch {torch.__version__}',
+                runs=[round(r, 1) for r in rates], spread=round(rates[-1] / rates[0], 3), ms_per_step=1e3 * total_s / n, cpu_seconds=round(total_s, 1))
 
 
 def mfma_pass_clocks(config):
@@ -207,33 +202,37 @@ def mfma_pass_clocks(config):
 def k7_roles(table, E, N, dim, layout, table_steps):
     """One roofline object per K7 launch role.  Bytes per launch:
          algorithmic  = every gathered row counted (12 d + 12 per incidence triple + (N/E)(4 d + 8) per output row)
-         compulsory   = every source row once + the ids + the output rows (what must cross the HBM pins at least once)."""
+         compulsory   = every source row once + the ids + the output rows (what must cross the HBM pins at least once).
+    E here = the ROWS the launches walk: the layout's distinct hyperedges (layout.edge_count; = the workload's E unless the layout carries multiplicities)."""
     row = 4 * dim
-    n_src_edges = E * row
     from ihgnn_amd import ops as _ops
+    weighted = layout.edge_weight is not None
     # the first-order layers' launches walk the MERGED two-hop list (layout.two_hop_merged: one weighted entry per distinct (destination, source) pair,
-    # 4 B id + 4 B multiplicity) unless IHG_TWO_HOP_MERGED=0: fewer gathers than the 6 E of the plain list
-    hop = layout.two_hop_merged()[0].nnz if _ops.TWO_HOP_MERGED else 6 * E
-    hop_ids = 8 * hop if _ops.TWO_HOP_MERGED else 24 * E
+    # 4 B id + 4 B weight) where the layout says so (>= 25 % repeats; ops.two_hop_merged_for): fewer gathers than the 6 E of the plain list
+    merged = _ops.two_hop_merged_for(layout)
+    hop = layout.two_hop_merged()[0].nnz if merged else 6 * E
+    hop_ids = 8 * hop if merged else 24 * E
     # member-gradient buffers beyond ops.MEMBER_BUFFER_LIMIT_BYTES are produced and scattered in hyperedge chunks (config C5): a launch walks 1 / chunks of the rows
     c3 = max(1, -(-(3 * E * row) // _ops.MEMBER_BUFFER_LIMIT_BYTES))
     c2 = max(1, -(-(2 * E * row) // _ops.MEMBER_BUFFER_LIMIT_BYTES))
+    w4 = 4 if weighted else 0                                 # a multiplicity per hyperedge row / per pair
     roles = {
         # name: (source rows, gathers, id bytes, what)
-        'k7.edges_to_nodes': (E, 3 * E, 12 * E, 'forward of the interactive layer: [E,d] hyperedge features -> [N,d] (x Dv^-1)'),
+        'k7.edges_to_nodes': (E, 3 * E, 12 * E + w4 * E, 'forward of the interactive layer: [E,d] hyperedge features -> [N,d] (x Dv^-1)'),
         'k7.first_order_gradient': (E, 3 * E, 12 * E, 'backward: [E,d] cotangent -> d P0 [N,d]'),
         'k7.member_gradients': (3 * E // c3, 3 * E // c3, 12 * E // c3, 'backward: [E,3,d] member gradients -> d H [N,d] (every row read exactly once'
                                 + (f'; {c3} hyperedge chunks, bytes per launch' if c3 > 1 else '') + ')'),
         'k7.member_gradients_rows': (2 * E // c2, 2 * E // c2, 8 * E // c2, 'backward: [E,2,d] query / item member gradients -> d H rows of queries and items (the user slot '
                                                           'was summed on chip by the member-gradient kernel); every row read exactly once'
                                      + (f'; {c2} hyperedge chunks, bytes per launch' if c2 > 1 else '')),
-        'k7.two_hop': (N, hop + N, hop_ids, 'first-order layer forward: node table -> node table over the (merged) two-hop list (no [E,d] intermediate)'),
+        'k7.two_hop': (N, hop + N, hop_ids, 'first-order layer forward: node table -> node table over the ' + ('MERGED (weighted) ' if merged else '') + 'two-hop list (no [E,d] intermediate)'),
         'k7.two_hop_bwd': (N, hop + N, hop_ids, 'first-order layer backward (same operator, scalings swapped)'),
         'k7.two_hop_bwd_masked': (N, hop + N, hop_ids, 'backward of the LAST first-order layer: its cotangent is zero outside the 3B batch rows (the output feeds the batch '
                                                           'tail only), the pull skips the gathers of the zero rows - same gradient; bytes as for the dense pull (an upper bound)'),
         'k7.edges_to_nodes_bwd_of_k5': (E, 3 * E, 12 * E, 'backward of a K5 launch'),
         'k7.two_hop_first_order_gradient': (N, hop + N, hop_ids, 'backward of the interactive layer, first-order part: the two-hop operator on the node-level cotangent ([E, d] tables beyond ops.FIRST_ORDER_TWO_HOP_BYTES: config C5)'),
-        'node_pair_sums': (N, 6 * E, 24 * E, 'interactive layer forward, node-level form: node table -> [N,3d] pair sums over hop2_csr (the output row is 3 d wide)', 3),
+        'node_pair_sums': (N, 6 * E, 24 * E + 3 * w4 * E, 'interactive layer forward, node-level form: node table -> [N,3d] pair sums over hop2_csr (the output row is 3 d wide'
+                                                            + ('; one weighted pair per DISTINCT hyperedge of a node' if weighted else '') + ')', 3),
     }
     out = {}
     for name, (src_rows, gathers, id_bytes, what, *rest) in roles.items():
@@ -249,15 +248,15 @@ def k7_roles(table, E, N, dim, layout, table_steps):
     return out
 
 
-def gather_stress(dev, rounds=6):
+def gather_stress(dev, dim=64, rounds=6):
     """K5 where every row gather really is an HBM access: uniform members over a node table far larger than the Infinity Cache
-    (4.2 M nodes x 64 floats = 1.07 GB, E = 4 M hyperedges, d = 64).  Here the SURVEY §8 d3 byte model (16 d + 12 B per hyperedge)
-    is also (almost) the compulsory traffic, so algorithmic rate = HBM rate; the microarch guide's figure for random whole rows
-    gathered into registers from a buffer far larger than the Infinity Cache is 5.5-5.8 TB/s."""
+    (1.07 GB: 4.2 M nodes at d = 64, 2.1 M at d = 128, 1.05 M at d = 256; one hyperedge per node-table row, about).  Here the SURVEY §8 d3 byte model
+    (16 d + 12 B per hyperedge) is also (almost) the compulsory traffic, so algorithmic rate = HBM rate; the microarch guide's figure for random whole rows
+    (>= 1 KiB: d = 256) gathered into registers from a buffer far larger than the Infinity Cache is 5.5-5.8 TB/s."""
     import numpy as np
     import torch
     from ihgnn_amd import ops
-    n_nodes, n_edges, dim = 4_200_000, 4_000_000, 64
+    n_nodes, n_edges = 4_200_000 * 64 // dim, 4_000_000 * 64 // dim
     rng = np.random.default_rng(77)
     i3 = torch.from_numpy(rng.integers(0, n_nodes, (n_edges, 3), dtype=np.int64).astype(np.int32)).to(dev)
     x = torch.randn(n_nodes, dim, device=dev)
@@ -280,8 +279,11 @@ def gather_stress(dev, rounds=6):
     return dict(bound='hbm', kernel='edge_gather_sum (K5) on an HBM-resident table', workload=f'uniform members, N={n_nodes} (table {n_nodes * dim * 4 / 1e9:.2f} GB), E={n_edges}, d={dim}',
                 avg_us=round(t * 1e6, 1), launches=len(times), algorithmic_bytes_per_launch=algorithmic, achieved=round(algorithmic / t / 1e9, 1),
                 peak=HBM_PEAK_GBS, unit='GB/s', frac=round(algorithmic / t / 1e9 / HBM_PEAK_GBS, 4), compulsory_bytes_per_launch=compulsory,
-                compulsory_gbs=round(compulsory / t / 1e9, 1), hyperedges_per_s=round(n_edges / t, 1),
-                note='every gathered row is counted: with 3 uniform draws per hyperedge from 4.2 M rows a row is re-read 2.9 times on average, at random '
+                compulsory_gbs=round(compulsory / t / 1e9, 1), frac_compulsory=round(compulsory / t / 1e9 / HBM_PEAK_GBS, 4), hyperedges_per_s=round(n_edges / t, 1),
+                target=0.40, target_met=bool(algorithmic / t / 1e9 / HBM_PEAK_GBS >= 0.40),
+                target_definition='north_star: >= 40 % of the HBM roofline on the node -> hyperedge gather-reduce, priced as SURVEY §8 d3 prices it: ALGORITHMIC bytes '
+                                  '(16 d + 12 B per hyperedge) / time >= 3.2 TB/s.  On this table the algorithmic bytes ARE HBM traffic (no cache residency), so frac is a true roofline fraction',
+                note=f'every gathered row is counted: with 3 uniform draws per hyperedge from {n_nodes / 1e6:.2f} M rows a row is re-read 2.9 times on average, at random '
                      'distances in a 1.07 GB table (Infinity Cache 256 MB): the algorithmic rate is an HBM + cache-hit mix, the compulsory rate the floor')
 
 
@@ -474,7 +476,7 @@ def main():
                 opt.zero_grad(set_to_none=True)
             except Exception as exc:                         # a recording is an extra: report why it is missing, keep the bench line
                 recorded_elapsed = f'{type(exc).__name__}: {exc}'
-        stress = gather_stress(dev) if rank == 0 else None
+        stress = {f'd{d_}': gather_stress(dev, d_) for d_ in (64, 128, 256)} if rank == 0 else None      # (rows of 256 B / 512 B / 1 KiB)
         # K5 at this workload, launched on its own (it is not part of a step whose layer-0 backward forms the hyperedges' cotangents in the
         # member-gradient kernel): the node -> hyperedge gather-sum of a [N, d] table with the layer's Dv^-1 scaling
         if rank == 0 and not args.no_kernel_events:
@@ -517,17 +519,18 @@ def main():
             dist.destroy_process_group()
         return
     E, N = w.edge_count, w.node_count
-    value = world * E * layers * args.steps / elapsed
+    value = world * E * layers * args.steps / elapsed      # the metric counts the reference's hyperedges: one per interaction, duplicates included (Helpers/Graph.py:107-118)
+    Er = layout.edge_count                                  # rows the kernels walk: the layout's DISTINCT hyperedges (= E unless it carries multiplicities, C5)
     row = 4 * dim
     touched = int((layout.degree > 0.5).sum().item())
-    k5_compulsory = touched * row + E * row + 12 * E          # every touched node row once + the [E,d] store + the ids
-    k5_algorithmic = E * (16 * dim + 12)                       # 3 ids + 3 row reads + 1 row write per hyperedge
+    k5_compulsory = touched * row + Er * row + 12 * Er        # every touched node row once + the [E,d] store + the ids
+    k5_algorithmic = Er * (16 * dim + 12)                      # 3 ids + 3 row reads + 1 row write per hyperedge (row of the launch)
     pmc = None                                                 # HBM bytes per launch from the committed PMC passes (profiles/), newest round first
     rounds = sorted((d for d in os.listdir(os.path.join(REPO, 'profiles')) if d.startswith('r') and d[1:].isdigit()), key=lambda d: -int(d[1:]))
     for pmc_file in [os.path.join(REPO, 'profiles', r, f'pmc_traffic_{args.config}.json') for r in rounds] + [os.path.join(REPO, 'profiles', 'r1', 'pmc_traffic.json')]:
         if os.path.exists(pmc_file):
             cand = json.load(open(pmc_file))
-            if (cand.get('workload'), cand.get('dim'), cand.get('edges')) == (args.config, dim, E):
+            if (cand.get('workload'), cand.get('dim'), cand.get('edges')) == (args.config, dim, E) and cand.get('rows', E) == Er:
                 pmc, pmc_name = cand, os.path.relpath(pmc_file, REPO)
                 break
 
@@ -557,7 +560,7 @@ def main():
                     traffic_refused=traffic_refused,
                     traffic_note='FETCH_SIZE / WRITE_SIZE count at the L2 <-> fabric boundary: L2-miss bytes, Infinity-Cache hits included - an upper '
                                  'bound of the HBM bytes; traffic above the compulsory bytes = rows re-fetched after leaving L2' if traffic else None,
-                    avg_us=round(rec['avg_us'], 2), launches=rec['launches'], hyperedges_per_s=round(E / t, 1), measured=measured)
+                    avg_us=round(rec['avg_us'], 2), launches=rec['launches'], hyperedges_per_s=round(E / t, 1), rows_per_launch=Er, measured=measured)
 
     k5_args = ('edge_gather_sum', 'K5 node->hyperedge gather-sum; first-order hyperedge features and the backward of K7', None, k5_compulsory, k5_algorithmic,
                'compulsory HBM bytes per launch: touched node rows once + [E,d] store + ids',
@@ -569,8 +572,8 @@ def main():
     elif 'k7.edges_to_nodes' in kernels:
         # no K5 launch in this step (the layer-0 backward forms the hyperedges' cotangents inside the member-gradient kernel): the bracketed
         # kernel is the hyperedge -> node launch of the interactive layer, the largest of the seven K7 launches that own 40 % of the step
-        k7_compulsory = E * row + 12 * E + N * (row + 8)       # every hyperedge row once + the member lists + the [N,d] store and its row pointers
-        k7_algorithmic = 3 * E * row + 12 * E + N * (row + 8)  # every (node, hyperedge) incidence reads its row
+        k7_compulsory = Er * row + 12 * Er + N * (row + 8)     # every hyperedge row once + the member lists + the [N,d] store and its row pointers
+        k7_algorithmic = 3 * Er * row + 12 * Er + N * (row + 8)  # every (node, hyperedge) incidence reads its row
         roofline = hbm_roofline('node_segment_sum, role k7.edges_to_nodes', 'K7 hyperedge->node: [E,d] hyperedge features -> [N,d] x Dv^-1, the forward of the interactive layer',
                                 kernels['k7.edges_to_nodes'], k7_compulsory, k7_algorithmic,
                                 'compulsory HBM bytes per launch: every hyperedge row once + member lists + [N,d] store',
@@ -580,8 +583,9 @@ def main():
     elif 'node_pair_sums' in kernels:
         # the interactive layer runs in its node-level form (no [E, d] tensor, no hyperedge -> node launch): its gather is the pair-sum launch - per node
         # the sums of h[a], h[b], h[a] h[b] over the other two members of its hyperedges - the largest gather launch of the step
-        ps_compulsory = N * row + 24 * E + N * (3 * row + 8)  # every node row once + the pair lists + the [N, 3 d] store and its row pointers
-        ps_algorithmic = 6 * E * row + 24 * E + N * (3 * row + 8)   # every incidence reads its two other members' rows
+        pw = 12 * Er if layout.edge_weight is not None else 0  # a weight per pair where the layout carries multiplicities
+        ps_compulsory = N * row + 24 * Er + pw + N * (3 * row + 8)  # every node row once + the pair lists + the [N, 3 d] store and its row pointers
+        ps_algorithmic = 6 * Er * row + 24 * Er + pw + N * (3 * row + 8)   # every incidence (of a distinct hyperedge) reads its two other members' rows
         roofline = hbm_roofline('node_pair_sums', 'pair sums of the interactive layer\'s node-level form: [N,d] node table -> [N,3d] (sum h[a] | sum h[b] | sum h[a] h[b] over each '
                                 'node\'s hyperedges) - the hyperedge aggregation of the layer\'s forward', kernels['node_pair_sums'], ps_compulsory, ps_algorithmic,
                                 'compulsory HBM bytes per launch: every node row once + pair lists (2 ids per incidence) + [N,3d] store',
@@ -592,8 +596,10 @@ def main():
         # HGCNLayer (GnnLayers.py:142-153) is the pure aggregation layer: Dv^-1/2 H De^-1 H^T Dv^-1/2 (X W + b) - node -> hyperedge scatter-reduce and hyperedge -> node
         # reduce with no per-hyperedge dense work.  The build applies H De^-1 H^T in ONE launch over the two-hop list (no [E, d] round trip), so that launch IS the
         # layer's node -> hyperedge + hyperedge -> node aggregation and it is the bracketed kernel
-        th_compulsory = N * row + 24 * E + N * (row + 8)      # every node row once + the two-hop lists (2 ids per incidence) + the [N, d] store and its row pointers
-        th_algorithmic = E * (16 * dim + 12) + E * (12 * dim + 12) + N * (row + 8)    # K5 (16 d + 12) + K7 (12 d + 12 + (N / E)(4 d + 8)) per hyperedge
+        hop_merged = ihg_ops.two_hop_merged_for(layout)
+        hop_entries = layout.two_hop_merged()[0].nnz if hop_merged else 6 * Er
+        th_compulsory = N * row + (8 if hop_merged else 4) * hop_entries + N * (row + 8)      # every node row once + the two-hop list (id, and weight when merged) + the [N, d] store and its row pointers
+        th_algorithmic = E * (16 * dim + 12) + E * (12 * dim + 12) + N * (row + 8)    # K5 (16 d + 12) + K7 (12 d + 12 + (N / E)(4 d + 8)) per hyperedge of the reference's formulation
         roofline = hbm_roofline('node_segment_sum, role k7.two_hop', 'HGCN layer: node -> hyperedge -> node aggregation H De^-1 H^T in one pass over the two-hop list', kernels['k7.two_hop'],
                                 th_compulsory, th_algorithmic, 'compulsory HBM bytes per launch: every node row once + two-hop lists (2 ids per incidence) + [N,d] store',
                                 'SURVEY §8 d3 for the two phases it replaces: K5 16 d + 12 B and K7 12 d + 12 B per hyperedge + (4 d + 8) B per node; the launch gathers 6 E + N rows '
@@ -609,14 +615,14 @@ def main():
         node_level = 'node_interact_fwd' in table
         # node-level form: the forward contracts 3 + m blocks per NODE (first-order blocks included), the product blocks' weight gradients m blocks per node;
         # the member gradients stay per hyperedge.  Hyperedge form: m blocks per hyperedge forward, 2 m backward (members + weights).
-        flops_fwd = 2.0 * (3 + m_blocks) * dim * dim * N if node_level else 2.0 * m_blocks * dim * dim * E
+        flops_fwd = 2.0 * (3 + m_blocks) * dim * dim * N if node_level else 2.0 * m_blocks * dim * dim * Er
         f, bw = table['node_interact_fwd' if node_level else 'interact_fwd'], table['interact_bwd']
         bwd_us = bw['avg_us'] * bw['launches'] / table_steps        # the backward may run in several hyperedge chunks
-        flops_bwd = 2 * 2.0 * m_blocks * dim * dim * E
+        flops_bwd = 2 * 2.0 * m_blocks * dim * dim * Er
         if 'node_interact_bwd_weight' in table:
             nw = table['node_interact_bwd_weight']
             bwd_us += nw['avg_us'] * nw['launches'] / table_steps
-            flops_bwd = 2.0 * m_blocks * dim * dim * E + 2.0 * m_blocks * dim * dim * N
+            flops_bwd = 2.0 * m_blocks * dim * dim * Er + 2.0 * m_blocks * dim * dim * N
         dtype_by_products = {
             3: ('f32 operands scaled by a power of two and taken apart into two fp16 terms (22 significand bits), three v_mfma_f32_16x16x32_f16 products per multiply '
                 '(hi lo + lo hi + hi hi), f32 accumulate: peak = dense 16-bit MFMA peak / 3, flops counted as fp32 multiply-adds'),
@@ -641,7 +647,7 @@ def main():
                         vs_f32_mfma_peak=round(flops_all / (us_all * 1e-6) / (MFMA_F32_PEAK_TF * 1e12), 3), **extra)
 
         fwd_pieces = [('node_interact_fwd' if node_level else 'interact_fwd', flops_fwd, f['avg_us'], 3 if node_level else 6)]
-        bwd_pieces = [('interact_bwd (member gradients)', 2.0 * m_blocks * dim * dim * E, bw['avg_us'] * bw['launches'] / table_steps, 3)]
+        bwd_pieces = [('interact_bwd (member gradients)', 2.0 * m_blocks * dim * dim * Er, bw['avg_us'] * bw['launches'] / table_steps, 3)]
         if 'node_interact_bwd_weight' in table:
             bwd_pieces.append(('node_interact_bwd_weight', 2.0 * m_blocks * dim * dim * N, nw['avg_us'] * nw['launches'] / table_steps, 3))
         else:
@@ -659,7 +665,8 @@ def main():
     out = {
         'metric': 'hyperedges_aggregated_per_sec', 'value': round(value, 1), 'unit': 'hyperedges/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': ('f32 (contraction operands 2xfp16, 22-bit; f32 accumulate)' if split_arithmetic(dim, args.order) and args.layer == 'ihgnn' else 'f32'), 'data': 'synthetic',
         'config': {'workload': WORKLOAD_NOTES.get(args.config, args.config) + (f' SCALED x{args.scale:g};' if args.scale != 1.0 else '') +
                                (f' WIDTH OVERRIDE --dim {dim};' if args.dim else '') +
                                f' U={w.user_count} Q={w.query_count} I={w.item_count} E={E}, {cfg["distribution"]} members, '
@@ -668,7 +675,10 @@ def main():
                            (f' + RCCL gradient exchange ({args.sync})' if world > 1 else ''),
                    'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
                    # share of the two-hop list's 6 E entries that repeat a (destination, source) pair of their row: merged into weighted entries for the first-order launches
-                   'two_hop_duplicates': round(layout.two_hop_merged()[2], 4), 'two_hop_merged': bool(__import__('ihgnn_amd.ops', fromlist=['x']).TWO_HOP_MERGED),
+                   'two_hop_duplicates': round(layout.two_hop_duplicate_share, 4), 'two_hop_merged': bool(ihg_ops.two_hop_merged_for(layout)),
+                   # interactions that repeat an earlier (user, query, item) triple; where the layout collapses them (>= 25 %: layout.MULTIPLICITY_MIN_SHARE) the kernels walk
+                   # distinct_hyperedges rows with a multiplicity each - the metric, the degrees and PpsHyperGraph keep counting every copy (Helpers/Graph.py:107-118)
+                   'duplicate_hyperedges': round(layout.duplicate_share, 4), 'hyperedge_multiplicities': layout.edge_weight is not None, 'distinct_hyperedges': Er,
                    'arithmetic': ('f32 results; f32 accumulation everywhere.  Row contractions (node-level contraction and member gradients at d = 64 / 128 / 256, node-level linear '
                                   'maps and their input gradients at d = 128 / 256): operands scaled by a power of two and taken apart into two fp16 terms, three fp16 MFMA products '
                                   'per multiply (error <= 3 x 2^-22 per product) - also the node-level weight gradients of the product blocks (a row\'s two operands scaled against each other); '
@@ -678,7 +688,7 @@ def main():
         'final_loss': round(final_loss, 6),
         'gradient_exchange': exchange,
         'roofline': roofline,
-        'roofline_hyperedge_to_node': k7_roles(table, E, N, dim, layout, table_steps) or None,
+        'roofline_hyperedge_to_node': k7_roles(table, Er, N, dim, layout, table_steps) or None,
         'roofline_interaction': mfma_roof,
     }
     if restricted_elapsed is not None:
@@ -707,6 +717,11 @@ def main():
         # byte model counts every gathered row, which at these node-table sizes is a cache rate and can exceed the HBM peak
         k5_outside['target'] = 0.40
         k5_outside['target_met'] = bool(k5_outside['frac'] >= 0.40)
+        k5_outside['target_met_algorithmic'] = bool(k5_outside['algorithmic_gbs'] >= 0.40 * HBM_PEAK_GBS)
+        k5_outside['target_definition'] = ('north_star: >= 40 % of the HBM roofline on the node -> hyperedge gather-reduce.  SURVEY §8 d3 prices it on ALGORITHMIC bytes '
+                                           '(16 d + 12 B per hyperedge, >= 3.2 TB/s): target_met_algorithmic.  At this workload the node table fits the Infinity Cache, so that rate '
+                                           'is a cache rate (it may exceed the HBM peak; frac_algorithmic is null then): target_met is the STRICTER reading - compulsory bytes '
+                                           '(every row once) / time >= 0.40 of 8 TB/s.  The HBM-resident reading of the same kernel is roofline_gather_stress')
         out['roofline_node_to_hyperedge'] = k5_outside
     # SURVEY §8 d3's byte model against what the step really moves: the model prices the reference's two-phase formulation (K5 + K7 per layer, training ~ 3 x forward);
     # the build's re-associations (two-hop fusion, node-level form of the interactive layer) move fewer bytes for the same result, so model / time can exceed the HBM peak
@@ -762,7 +777,7 @@ def main():
                 rec_ms = 1e3 * (time.perf_counter() - t7) / 50
             except Exception:
                 rec_ms = None
-            leg = cpu_baseline('C1', args.layer, c1['layers'], args.order, c1['dim'], 1.0, budget_s=4.0)
+            leg = cpu_baseline('C1', args.layer, c1['layers'], args.order, c1['dim'], 1.0, runs=3, steps_per_run=8)
             leg['gpu_same_input'] = dict(ms_per_step=round(gpu_ms, 4), value=round(w1.edge_count * c1['layers'] / (gpu_ms * 1e-3), 1), unit='hyperedges/s',
                                          recorded_step_ms_per_step=round(rec_ms, 4) if rec_ms else None,
                                          recorded_step_value=round(w1.edge_count * c1['layers'] / (rec_ms * 1e-3), 1) if rec_ms else None,

@@ -34,7 +34,7 @@ class PpsHyperGraph(PpsGraph):
         g = cls()
         item_count = node_count - user_count - query_count
         g.layout = IncidenceLayout(triples, user_count, query_count, item_count, device)
-        g.EdgeCount = g.layout.edge_count
+        g.EdgeCount = g.layout.hyperedge_count            # the reference's count: one hyperedge per positive interaction, duplicates included (Graph.py:133)
         return g
 
     @classmethod

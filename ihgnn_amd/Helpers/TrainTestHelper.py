@@ -138,7 +138,8 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
     from ..optim import Adam as _HipAdam
     can_record = mode != 'off' and grad_sync is None and device.type == 'cuda' and isinstance(optimizer, _HipAdam)
     decision = getattr(model, '_record_decision', None) if can_record else False       # None: undecided (auto, still measuring); True / False
-    if can_record and mode == 'on' and decision is None:
+    if can_record and mode == 'on' and decision is not True and not getattr(model, '_record_refused', False):
+        # an explicit 'on' overrides what an earlier 'auto' epoch measured (False = "not launch-bound"); only a REFUSED recording (the capture raised) stays off
         decision = model._record_decision = True
     if decision and getattr(model, '_recorded_step', None) is not None and model._recorded_step.stale(full=True):
         model._recorded_step = None                          # an IHG_* switch or ops flag changed since the recording (checked once per epoch; the per-step check is the cheap one)
@@ -154,10 +155,16 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
                 from ..captured_step import CapturedTrainingStep
                 try:
                     recorded = model._recorded_step = CapturedTrainingStep(model, optimizer, int(users.shape[0]), warmup_batch=(users, queries, items, flags))
-                except ValueError as refused:
-                    IOHelper.LogPrint(f'training step not recorded ({refused}); training eagerly')
+                except (ValueError, RuntimeError) as refused:
+                    # ValueError: the recording's own refusal (a parameter without gradient, ...); RuntimeError: the stream capture failed (an op that synchronises,
+                    # an allocation the capture cannot hold) - under 'auto' nobody asked for a recording, so either way the run goes on eagerly; under 'on' a
+                    # capture failure is the caller's to see
+                    if mode == 'on' and isinstance(refused, RuntimeError):
+                        raise
+                    IOHelper.LogPrint(f'training step not recorded ({type(refused).__name__}: {refused}); training eagerly')
                     recorded, decision = None, False
-                    model._recorded_step, model._record_decision = None, False
+                    model._recorded_step, model._record_decision, model._record_refused = None, False, True
+                    optimizer.zero_grad(set_to_none=True)
             if recorded is not None and recorded.batch_rows == int(users.shape[0]):
                 loss_sum += recorded.step(users, queries, items, flags)
                 batches += 1

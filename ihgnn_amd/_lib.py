@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # IHGNN_HIP_LIBRARY points at another build of the same ABI (A/B timing of kernel variants); default: the in-tree library
 LIB_PATH = os.environ.get('IHGNN_HIP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
@@ -44,11 +44,12 @@ SIGNATURES = {
     'ihg_build_pair_csr': (ctypes.c_int, [_i64p, c_int64, c_int64, c_int64, c_int64, c_int32, c_int32, _i32p, _i32p, _f32p, _f32p,
                                           c_int64, _i64p]),
     'ihg_transpose_csr': (ctypes.c_int, [_i32p, _i32p, c_int64, c_int64, _i32p, _i32p]),
-    'ihg_merge_id_lists': (ctypes.c_int, [_i32p, _i32p, c_int64, _i32p, _i32p, _f32p, _i64p]),
-    'ihg_edge_gather_sum': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float,
+    'ihg_merge_id_lists': (ctypes.c_int, [_i32p, _i32p, _f32p, c_int64, _i32p, _i32p, _f32p, _i64p]),
+    'ihg_unique_triples': (ctypes.c_int, [_i64p, c_int64, c_int64, c_int64, c_int64, _i64p, _f32p, _i32p, _i64p]),
+    'ihg_edge_gather_sum': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
                                            c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'ihg_edge_gather_sum_planes_supported': (c_int32, [c_int32, c_int64]),
-    'ihg_edge_gather_sum_planes': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    'ihg_edge_gather_sum_planes': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     'ihg_node_segment_sum': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                             c_void_p, c_int64, c_int64, c_int32, c_int32,
                                             c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -72,7 +73,7 @@ SIGNATURES = {
     'ihg_interact_bwd_gathered': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                                  c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'ihg_node_pair_sums': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
-                                          c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'ihg_node_interact_fwd_supported': (c_int32, [c_int32, c_int32, c_int64, c_int64, c_int64]),
     'ihg_node_interact_fwd_workspace_bytes': (c_int64, [c_int32]),
     'ihg_node_interact_fwd': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, _i64p,

@@ -105,8 +105,9 @@ class CapturedTrainingStep:
         import os
         switches = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith('IHG_')))
         from . import ops
-        flags = tuple((name, getattr(ops, name)) for name in ('USER_REDUCED_BACKWARD', 'SPARSE_LAST_COTANGENT', 'NODE_LEVEL_FORWARD', 'NODE_LEVEL_WEIGHT', 'NODE_TABLES',
-                                                              'FIRST_ORDER_TWO_HOP_BYTES', 'MEMBER_BUFFER_LIMIT_BYTES') if hasattr(ops, name))
+        # every path switch of ihgnn_amd.ops: its module-level UPPER_CASE scalars, found by name - a switch added to ops is baked in here without this list being touched
+        # (COTANGENT_PLANES, TWO_HOP_MERGED, ... : tests and bench.py toggle these attributes between steps)
+        flags = tuple((name, value) for name, value in sorted(vars(ops).items()) if name.isupper() and not name.startswith('_') and (value is None or isinstance(value, (bool, int, float, str))))
         return self._baked_hyperparameters() + (switches, flags)
 
     def stale(self, full: bool = False) -> bool:
@@ -139,8 +140,9 @@ class CapturedTrainingStep:
         if users.shape[0] != self.batch_rows:
             raise ValueError(f'this step was recorded for batches of {self.batch_rows} rows, got {users.shape[0]}')
         if self.stale():
-            raise RuntimeError('CapturedTrainingStep: a setting baked into the recording changed (Adam betas / eps / weight_decay, batch_rows_only_last_layer or an '
-                               'IHG_* switch); record a new step')
+            raise RuntimeError('CapturedTrainingStep: a setting baked into the recording changed (Adam betas / eps / weight_decay or batch_rows_only_last_layer - the values '
+                               'every step() compares; the IHG_* environment and the switches of ihgnn_amd.ops are compared by stale(full=True), which the training loop '
+                               'asks once per epoch); record a new step')
         self.users.copy_(users, non_blocking=True)
         self.queries.copy_(queries, non_blocking=True)
         self.items.copy_(items, non_blocking=True)

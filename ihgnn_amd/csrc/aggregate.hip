@@ -24,7 +24,7 @@ namespace {
 template <int VEC, int G, int U>
 __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
     const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ i3,
-    const float* __restrict__ node_scale, const float* __restrict__ bias, float alpha,
+    const float* __restrict__ node_scale, const float* __restrict__ bias, float alpha, const float* __restrict__ edge_scale,
     float* __restrict__ out, int64_t ld_out, int64_t n_edges, int dim_vec) {
     constexpr int GPW = kWave / G;
     constexpr int EPW = GPW * U;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
                 acc.add_scaled(rows[t][0], sc[t][0]);      // (u + q) + i, the order of a row-major SpMM row
                 acc.add_scaled(rows[t][1], sc[t][1]);
                 acc.add_scaled(rows[t][2], sc[t][2]);
-                acc.mul(alpha);
+                acc.mul(edge_scale != nullptr ? alpha * edge_scale[e] : alpha);      // edge_scale: the hyperedge's multiplicity (a layout with duplicate triples collapsed)
                 acc.add(b);
                 acc.store_stream(out + e * ld_out + c * VEC);
             }
@@ -269,12 +269,12 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
 #ifndef IHG_PAIR_UNR
 #define IHG_PAIR_UNR 16
 #endif
-template <int G>
+template <int G, bool WEIGHTED = false>
 __global__ __launch_bounds__(kBlockThreads) void node_pair_sums_kernel(
     const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ids,
     const int32_t* __restrict__ row_order, float* __restrict__ out, int64_t ld_out, int64_t n_rows, int dim, int dim_vec,
     int heavy_threshold, const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, const float* __restrict__ pair_weight) {
     constexpr int GPW = kWave / G;
     constexpr int UNR = G < 8 ? G : (G >= 32 ? IHG_PAIR_UNR : 8);      // ids in flight per lane: UNR / 2 pairs
     const int lane = threadIdx.x & (kWave - 1);
@@ -304,6 +304,39 @@ __global__ __launch_bounds__(kBlockThreads) void node_pair_sums_kernel(
             const int c = ci * G + lig;
             const bool col_ok = c < dim_vec;
             Frag<4> sa = Frag<4>::zero(), sb = Frag<4>::zero(), sab = Frag<4>::zero();
+            if (WEIGHTED) {
+                // a layout with duplicate (user, query, item) triples collapsed: pair p of the list (ids 2 p, 2 p + 1; the lists start at even offsets) stands for
+                // pair_weight[p] hyperedges - every sum takes the pair that many times
+                for (int base = 0; base < wave_len; base += G) {
+                    const bool have = base + lig < len;
+                    const int my_id = have ? ids[begin + base + lig] : -1;
+                    const float my_w = have ? pair_weight[(begin + base + lig) >> 1] : 0.f;
+#pragma unroll 1
+                    for (int j = 0; j < G; j += UNR) {
+                        if (base + j >= wave_len) break;          // wave-uniform
+                        int id[UNR];
+                        float w[UNR / 2];
+                        Frag<4> row[UNR];
+#pragma unroll
+                        for (int k = 0; k < UNR; ++k) id[k] = __shfl(my_id, group_base + j + k);
+#pragma unroll
+                        for (int k = 0; k < UNR; k += 2) w[k / 2] = __shfl(my_w, group_base + j + k);
+#pragma unroll
+                        for (int k = 0; k < UNR; ++k)
+                            row[k] = (id[k] >= 0 && col_ok) ? Frag<4>::load(h + static_cast<int64_t>(id[k]) * ld_h + c * 4) : Frag<4>::zero();
+#pragma unroll
+                        for (int k = 0; k < UNR; k += 2) {
+                            const float m = w[k / 2];
+                            sa.add_scaled(row[k], m);
+                            sb.add_scaled(row[k + 1], m);
+                            sab.v.x += m * (row[k].v.x * row[k + 1].v.x);
+                            sab.v.y += m * (row[k].v.y * row[k + 1].v.y);
+                            sab.v.z += m * (row[k].v.z * row[k + 1].v.z);
+                            sab.v.w += m * (row[k].v.w * row[k + 1].v.w);
+                        }
+                    }
+                }
+            } else
             for (int base = 0; base < wave_len; base += G) {
                 const int my_id = base + lig < len ? ids[begin + base + lig] : -1;
 #pragma unroll 1
@@ -402,8 +435,8 @@ __global__ __launch_bounds__(kBlockThreads) void heavy_finish_kernel(
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 template <int U>
 __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_planes256_kernel(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ i3,
-                                                                                  const float* __restrict__ node_scale, v2u* __restrict__ planes,
-                                                                                  float* __restrict__ inv_out, int64_t n_edges) {
+                                                                                  const float* __restrict__ node_scale, const float* __restrict__ edge_scale,
+                                                                                  v2u* __restrict__ planes, float* __restrict__ inv_out, int64_t n_edges) {
     constexpr int D = 256, EPW = U;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t n_ids = n_edges * 3;
@@ -450,6 +483,7 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_planes256_kerne
             acc.add_scaled(rows[t][0], sc[t][0]);          // (u + q) + i, as in edge_gather_sum_kernel
             acc.add_scaled(rows[t][1], sc[t][1]);
             acc.add_scaled(rows[t][2], sc[t][2]);
+            if (edge_scale != nullptr) acc.mul(edge_scale[e]);      // the hyperedge's multiplicity (duplicate triples collapsed): the cotangent of all its copies
             // the row's largest magnitude: 16 lanes by DPP, the four 16-lane rows through scalar registers (unsigned order = float order for m >= 0)
             float m = abs_max3(acc.v.z, acc.v.w, abs_max3(acc.v.x, acc.v.y, 0.f));
             m = row_lanes_max<16>(m);
@@ -483,7 +517,7 @@ inline int group_lanes(int n) {
 
 template <int VEC>
 int launch_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, const float* node_scale, const float* bias,
-                           float alpha, float* out, int64_t ld_out, int64_t n_edges, int dim, hipStream_t stream) {
+                           float alpha, const float* edge_scale, float* out, int64_t ld_out, int64_t n_edges, int dim, hipStream_t stream) {
     const int dim_vec = dim / VEC;
     const int g = group_lanes(dim_vec);
 #define IHG_LAUNCH_K5(G, U)                                                                                         \
@@ -491,7 +525,7 @@ int launch_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, 
         constexpr int EPW = (kWave / G) * U;                                                                        \
         const int grid = grid_for_waves((n_edges + EPW - 1) / EPW);                                                 \
         hipLaunchKernelGGL((edge_gather_sum_kernel<VEC, G, U>), dim3(grid), dim3(kBlockThreads), 0, stream, src,    \
-                           ld_src, i3, node_scale, bias, alpha, out, ld_out, n_edges, dim_vec);                     \
+                           ld_src, i3, node_scale, bias, alpha, edge_scale, out, ld_out, n_edges, dim_vec);         \
     }
     switch (g) {
         case 4: IHG_LAUNCH_K5(4, 1) break;
@@ -568,20 +602,20 @@ inline bool scale_mode_ok(int mode, const float* scale) {
 extern "C" {
 
 int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, const float* node_scale, const float* bias,
-                        float alpha, float* out, int64_t ld_out, int64_t n_edges, int32_t dim, ihg_stream_t stream) {
+                        float alpha, const float* edge_scale, float* out, int64_t ld_out, int64_t n_edges, int32_t dim, ihg_stream_t stream) {
     if (n_edges < 0 || dim <= 0 || ld_src < dim || ld_out < dim) return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum: bad size (E=%lld dim=%d ld_src=%lld ld_out=%lld)", (long long)n_edges, dim, (long long)ld_src, (long long)ld_out);
     if (n_edges == 0) return IHG_OK;
     if (src == nullptr || i3 == nullptr || out == nullptr) return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool wide = dim % 4 == 0 && ld_src % 4 == 0 && ld_out % 4 == 0 && aligned16(src) && aligned16(out) && (bias == nullptr || aligned16(bias));
-    return wide ? launch_edge_gather_sum<4>(src, ld_src, i3, node_scale, bias, alpha, out, ld_out, n_edges, dim, s)
-                : launch_edge_gather_sum<1>(src, ld_src, i3, node_scale, bias, alpha, out, ld_out, n_edges, dim, s);
+    return wide ? launch_edge_gather_sum<4>(src, ld_src, i3, node_scale, bias, alpha, edge_scale, out, ld_out, n_edges, dim, s)
+                : launch_edge_gather_sum<1>(src, ld_src, i3, node_scale, bias, alpha, edge_scale, out, ld_out, n_edges, dim, s);
 }
 
 int32_t ihg_edge_gather_sum_planes_supported(int32_t dim, int64_t ld_src) { return dim == 256 && ld_src >= dim && ld_src % 4 == 0 ? 1 : 0; }
 
-int ihg_edge_gather_sum_planes(const float* src, int64_t ld_src, const int32_t* i3, const float* node_scale, void* planes, float* inv_scale, int64_t n_edges,
-                               int32_t dim, ihg_stream_t stream) {
+int ihg_edge_gather_sum_planes(const float* src, int64_t ld_src, const int32_t* i3, const float* node_scale, const float* edge_scale, void* planes, float* inv_scale,
+                               int64_t n_edges, int32_t dim, ihg_stream_t stream) {
     if (!ihg_edge_gather_sum_planes_supported(dim, ld_src)) return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum_planes: shape not supported (ask ihg_edge_gather_sum_planes_supported)");
     if (n_edges < 0) return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum_planes: bad size");
     if (n_edges == 0) return IHG_OK;
@@ -590,7 +624,7 @@ int ihg_edge_gather_sum_planes(const float* src, int64_t ld_src, const int32_t* 
     constexpr int U = 4;
     const int grid = grid_for_waves((n_edges + U - 1) / U);
     hipLaunchKernelGGL((edge_gather_sum_planes256_kernel<U>), dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), src, ld_src, i3, node_scale,
-                       static_cast<v2u*>(planes), inv_scale, n_edges);
+                       edge_scale, static_cast<v2u*>(planes), inv_scale, n_edges);
     return check_launch("ihg_edge_gather_sum_planes");
 }
 
@@ -619,7 +653,7 @@ int ihg_node_segment_sum(const float* src, int64_t ld_src, const int32_t* rowptr
 int ihg_node_pair_sums(const float* h, int64_t ld_h, const int32_t* pair_ptr, const int32_t* pair_ids, const int32_t* row_order, float* out,
                        int64_t ld_out, int64_t n_rows, int32_t dim, int32_t heavy_threshold, const int32_t* seg_begin, const int32_t* seg_end,
                        int64_t n_segments, const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy, float* partials,
-                       ihg_stream_t stream) {
+                       const float* pair_weight, ihg_stream_t stream) {
     if (n_rows < 0 || dim <= 0 || dim % 4 != 0 || ld_h < dim || ld_h % 4 != 0 || ld_out < 3 * static_cast<int64_t>(dim) || ld_out % 4 != 0 || n_segments < 0 || n_heavy < 0)
         return fail(IHG_ERR_INVALID, "ihg_node_pair_sums: bad size (rows=%lld dim=%d ld_h=%lld ld_out=%lld)", (long long)n_rows, dim, (long long)ld_h, (long long)ld_out);
     if (n_rows == 0) return IHG_OK;
@@ -637,8 +671,12 @@ int ihg_node_pair_sums(const float* h, int64_t ld_h, const int32_t* pair_ptr, co
     {                                                                                                                                       \
         constexpr int GPW = kWave / G;                                                                                                      \
         const int grid = grid_for_waves((n_rows + n_segments + GPW - 1) / GPW);                                                             \
-        hipLaunchKernelGGL((node_pair_sums_kernel<G>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, pair_ptr, pair_ids, row_order, out,  \
-                           ld_out, n_rows, dim, dim_vec, heavy_threshold, seg_begin, seg_end, n_segments, partials);                        \
+        if (pair_weight != nullptr)                                                                                                         \
+            hipLaunchKernelGGL((node_pair_sums_kernel<G, true>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, pair_ptr, pair_ids, row_order, out, \
+                               ld_out, n_rows, dim, dim_vec, heavy_threshold, seg_begin, seg_end, n_segments, partials, pair_weight);       \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((node_pair_sums_kernel<G>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, pair_ptr, pair_ids, row_order, out, \
+                               ld_out, n_rows, dim, dim_vec, heavy_threshold, seg_begin, seg_end, n_segments, partials, pair_weight);       \
         if (n_heavy > 0)                                                                                                                    \
             hipLaunchKernelGGL((heavy_finish_kernel<4, G>), dim3(static_cast<int>(std::min<int64_t>(n_heavy, kMaxBlocks * 4)), (3 * dim_vec + G - 1) / G), \
                                dim3(kBlockThreads), 0, s, partials, heavy_rows, heavy_segptr, n_heavy, nullptr, IHG_SCALE_NONE, out, ld_out, \

@@ -757,6 +757,9 @@ int ihg_node_linear_bwd_weight(const float* dout, int64_t ld_dout, const float* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int n_types = dw_type_stride == 0 ? 1 : 3;
     if (!tiled_node_linear(dim, ld_dout, ld_x, dout, workspace) || !aligned16(x) || (dx != nullptr && ld_dx % 4)) {
+        // the any-width kernels OVERWRITE dx: a caller that asked for dx += (the member gradients are already in it) on rows this branch takes - unaligned dout / x
+        // at a width ihg_node_linear_bwd_accumulates said yes to - is refused, not silently given a dx without its first addend
+        if (dx_accumulate) return fail(IHG_ERR_INVALID, "ihg_node_linear_bwd_weight: dx_accumulate needs 16-byte aligned dout and x rows (the any-width kernels overwrite dx)");
         if (dx != nullptr) launch_row_gemm_generic(dim, dout, ld_dout, w, ld_w, dw_type_stride, 1, nullptr, 0, 0, type_begin, dx, ld_dx, s);
         // row-slab partials at the front of the workspace (every width's workspace holds at least kGenericSlabs of them), then a fixed-order sum
         const int64_t need = 3LL * kGenericSlabs * (static_cast<int64_t>(dim) * dim + dim) * static_cast<int64_t>(sizeof(float));

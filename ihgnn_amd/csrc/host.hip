@@ -28,7 +28,7 @@ bool parse_int_list(const char* p, const char* end, std::vector<int64_t>& out) {
 
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 31; }
+int32_t ihg_abi_version(void) { return 32; }
 
 const char* ihg_last_error_string(void) { return ihg_error_buffer; }
 
@@ -342,13 +342,17 @@ int ihg_transpose_csr(const int32_t* ptr, const int32_t* ids, int64_t n_rows, in
     return IHG_OK;
 }
 
-int ihg_merge_id_lists(const int32_t* ptr, const int32_t* ids, int64_t n_rows, int32_t* out_ptr, int32_t* out_ids, float* out_counts, int64_t* nnz_out) {
+int ihg_merge_id_lists(const int32_t* ptr, const int32_t* ids, const float* weights, int64_t n_rows, int32_t* out_ptr, int32_t* out_ids, float* out_counts,
+                       int64_t* nnz_out) {
     if (n_rows < 0 || ptr == nullptr || out_ptr == nullptr || nnz_out == nullptr) return fail(IHG_ERR_INVALID, "ihg_merge_id_lists: bad argument");
     const int64_t nnz = n_rows > 0 ? ptr[n_rows] : 0;
-    if (nnz > 0 && (ids == nullptr || out_ids == nullptr || out_counts == nullptr)) return fail(IHG_ERR_INVALID, "ihg_merge_id_lists: null buffer");
+    if (nnz > 0 && ids == nullptr) return fail(IHG_ERR_INVALID, "ihg_merge_id_lists: null buffer");
     // every row sorted on its own (rows are short; the few long ones of a power-law graph sort in place too), rows dealt to threads in contiguous ranges of about
-    // equal entry counts; then distinct ids are counted per row, the counts prefix-summed, and the (id, multiplicity) pairs written - ascending id inside a row
-    std::vector<int32_t> sorted(ids, ids + nnz);
+    // equal entry counts; then distinct ids are counted per row, the counts prefix-summed, and the (id, multiplicity) pairs written - ascending id inside a row.
+    // An entry is the 64-bit key (id << 32 | bits of its weight): one sort orders the ids and carries the weights (positive floats order like their bit patterns;
+    // the order of equal ids only fixes the order their weights are added in - exact for the integer weights a multiplicity is).
+    // out_ids == nullptr: COUNT ONLY (out_ptr and *nnz_out are written): what a caller needs to decide whether the merged list is worth building.
+    std::vector<uint64_t> sorted(static_cast<size_t>(nnz));
     const int n_threads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(std::thread::hardware_concurrency()), int64_t{32}, nnz / 200000 + 1})));
     std::vector<int64_t> cut(static_cast<size_t>(n_threads) + 1, n_rows);
     cut[0] = 0;
@@ -362,32 +366,127 @@ int ihg_merge_id_lists(const int32_t* ptr, const int32_t* ids, int64_t n_rows, i
     };
     out_ptr[0] = 0;
     over_ranges([&](int64_t r0, int64_t r1) {
+        for (int64_t k = ptr[r0]; k < ptr[r1]; ++k) {
+            uint32_t wbits = 0x3f800000u;                    // 1.0f
+            if (weights != nullptr) std::memcpy(&wbits, weights + k, sizeof(wbits));
+            sorted[static_cast<size_t>(k)] = (static_cast<uint64_t>(static_cast<uint32_t>(ids[k])) << 32) | wbits;
+        }
         for (int64_t r = r0; r < r1; ++r) {
-            int32_t* b = sorted.data() + ptr[r];
-            int32_t* e = sorted.data() + ptr[r + 1];
+            uint64_t* b = sorted.data() + ptr[r];
+            uint64_t* e = sorted.data() + ptr[r + 1];
             std::sort(b, e);
             int32_t distinct = 0;
-            for (int32_t* p = b; p < e; ++p) distinct += (p == b || p[0] != p[-1]) ? 1 : 0;
+            for (uint64_t* p = b; p < e; ++p) distinct += (p == b || (p[0] >> 32) != (p[-1] >> 32)) ? 1 : 0;
             out_ptr[r + 1] = distinct;
         }
     });
     for (int64_t r = 0; r < n_rows; ++r) out_ptr[r + 1] += out_ptr[r];
+    *nnz_out = n_rows > 0 ? out_ptr[n_rows] : 0;
+    if (out_ids == nullptr) return IHG_OK;
+    if (nnz > 0 && out_counts == nullptr) return fail(IHG_ERR_INVALID, "ihg_merge_id_lists: null buffer");
     over_ranges([&](int64_t r0, int64_t r1) {
         for (int64_t r = r0; r < r1; ++r) {
-            const int32_t* b = sorted.data() + ptr[r];
-            const int32_t* e = sorted.data() + ptr[r + 1];
+            const uint64_t* b = sorted.data() + ptr[r];
+            const uint64_t* e = sorted.data() + ptr[r + 1];
             int64_t k = out_ptr[r];
-            for (const int32_t* p = b; p < e;) {
-                const int32_t* q = p;
-                while (q < e && *q == *p) ++q;
-                out_ids[k] = *p;
-                out_counts[k] = static_cast<float>(q - p);
+            for (const uint64_t* p = b; p < e;) {
+                const uint64_t* q = p;
+                float total = 0.f;
+                while (q < e && (*q >> 32) == (*p >> 32)) {
+                    const uint32_t wbits = static_cast<uint32_t>(*q);
+                    float w;
+                    std::memcpy(&w, &wbits, sizeof(w));
+                    total += w;
+                    ++q;
+                }
+                out_ids[k] = static_cast<int32_t>(*p >> 32);
+                out_counts[k] = total;
                 ++k;
                 p = q;
             }
         }
     });
-    *nnz_out = n_rows > 0 ? out_ptr[n_rows] : 0;
+    return IHG_OK;
+}
+
+int ihg_unique_triples(const int64_t* triples, int64_t n_edges, int64_t n_users, int64_t n_queries, int64_t n_items, int64_t* unique_out, float* count_out,
+                       int32_t* file_to_unique, int64_t* n_unique_out) {
+    if (n_edges < 0 || n_users < 0 || n_queries < 0 || n_items < 0 || n_unique_out == nullptr) return fail(IHG_ERR_INVALID, "ihg_unique_triples: bad argument");
+    if (n_edges >= INT32_MAX) return fail(IHG_ERR_INVALID, "ihg_unique_triples: more than 2^31 interactions");
+    *n_unique_out = 0;
+    if (n_edges == 0) return IHG_OK;
+    if (triples == nullptr) return fail(IHG_ERR_INVALID, "ihg_unique_triples: null buffer");
+    const int64_t limit[3] = {n_users, n_queries, n_items};
+    // bucket by user (a counting sort that keeps file order inside a user), then every user's run sorted by (query, item, file position) on the threads;
+    // equal (query, item) neighbours of a run are one distinct hyperedge
+    std::vector<int64_t> uptr(static_cast<size_t>(n_users) + 1, 0);
+    for (int64_t e = 0; e < n_edges; ++e) {
+        for (int m = 0; m < 3; ++m) {
+            const int64_t local = triples[e * 3 + m];
+            if (local < 0 || local >= limit[m])
+                return fail(IHG_ERR_INVALID, "ihg_unique_triples: interaction %lld member %d id %lld out of range [0,%lld)", static_cast<long long>(e), m,
+                            static_cast<long long>(local), static_cast<long long>(limit[m]));
+        }
+        ++uptr[static_cast<size_t>(triples[e * 3]) + 1];
+    }
+    for (int64_t u = 0; u < n_users; ++u) uptr[u + 1] += uptr[u];
+    struct Entry {
+        int64_t key;        // query * n_items + item
+        int32_t file;       // position in the caller's array
+        bool operator<(const Entry& o) const { return key != o.key ? key < o.key : file < o.file; }
+    };
+    std::vector<Entry> entries(static_cast<size_t>(n_edges));
+    {
+        std::vector<int64_t> cursor(uptr.begin(), uptr.end() - 1);
+        for (int64_t e = 0; e < n_edges; ++e)
+            entries[static_cast<size_t>(cursor[triples[e * 3]]++)] = Entry{triples[e * 3 + 1] * n_items + triples[e * 3 + 2], static_cast<int32_t>(e)};
+    }
+    const int n_threads = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(std::thread::hardware_concurrency()), int64_t{32}, n_edges / 200000 + 1})));
+    std::vector<int64_t> cut(static_cast<size_t>(n_threads) + 1, n_users);
+    cut[0] = 0;
+    for (int t = 1; t < n_threads; ++t)
+        cut[t] = std::upper_bound(uptr.begin(), uptr.end(), n_edges * t / n_threads) - uptr.begin() - 1;
+    auto over_ranges = [&](auto&& body) {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back([&, t] { body(cut[t], cut[t + 1]); });
+        body(cut[0], cut[1]);
+        for (auto& th : pool) th.join();
+    };
+    std::vector<int64_t> first(static_cast<size_t>(n_users) + 1, 0);       // distinct hyperedges of the users before u
+    over_ranges([&](int64_t u0, int64_t u1) {
+        for (int64_t u = u0; u < u1; ++u) {
+            Entry* b = entries.data() + uptr[u];
+            Entry* e = entries.data() + uptr[u + 1];
+            std::sort(b, e);
+            int64_t distinct = 0;
+            for (Entry* p = b; p < e; ++p) distinct += (p == b || p[0].key != p[-1].key) ? 1 : 0;
+            first[u + 1] = distinct;
+        }
+    });
+    for (int64_t u = 0; u < n_users; ++u) first[u + 1] += first[u];
+    *n_unique_out = first[n_users];
+    if (unique_out == nullptr) return IHG_OK;                                // count only
+    if (count_out == nullptr) return fail(IHG_ERR_INVALID, "ihg_unique_triples: null buffer");
+    over_ranges([&](int64_t u0, int64_t u1) {
+        for (int64_t u = u0; u < u1; ++u) {
+            const Entry* b = entries.data() + uptr[u];
+            const Entry* e = entries.data() + uptr[u + 1];
+            int64_t k = first[u];
+            for (const Entry* p = b; p < e;) {
+                const Entry* q = p;
+                while (q < e && q->key == p->key) {
+                    if (file_to_unique != nullptr) file_to_unique[q->file] = static_cast<int32_t>(k);
+                    ++q;
+                }
+                unique_out[k * 3] = u;
+                unique_out[k * 3 + 1] = p->key / n_items;
+                unique_out[k * 3 + 2] = p->key % n_items;
+                count_out[k] = static_cast<float>(q - p);
+                ++k;
+                p = q;
+            }
+        }
+    });
     return IHG_OK;
 }
 }  // extern "C"

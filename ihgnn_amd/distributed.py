@@ -48,7 +48,11 @@ class GradientSync:
     owns_optimizer = False
 
     def __init__(self, parameters: Iterable[torch.nn.Parameter], group=None):
-        self.params: List[torch.nn.Parameter] = [p for p in parameters if p.requires_grad]
+        everything = list(parameters)
+        self.params: List[torch.nn.Parameter] = [p for p in everything if p.requires_grad]
+        # position of every exchanged parameter in the caller's full list (frozen ones included): torch.optim.Adam(model.parameters()) numbers its state entries that way
+        self.param_index: List[int] = [i for i, p in enumerate(everything) if p.requires_grad]
+        self.n_all_params = len(everything)
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.distributed = dist.is_initialized() and (self.world_size > 1 or force_collectives())      # collectives are issued
@@ -235,7 +239,7 @@ class _ShardOptimizer:
 
     def state_dict(self):
         """Adam state of ALL parameters in ``torch.optim.Adam``'s own layout - ``{'state': {i: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}``, parameter i = the i-th of
-        ``model.parameters()`` - what the reference writes (``Main.py:144-147``) and what the flat / bucketed modes' optimizers write and read: a checkpoint taken under one
+        ``model.parameters()``, frozen parameters counted - what the reference writes (``Main.py:255-259``) and reads (``Main.py:208-212``) and what the flat / bucketed modes' optimizers write and read: a checkpoint taken under one
         ``--grad_sync`` mode (or world size, or by the reference) resumes under another.  Every rank's shard of ``exp_avg`` / ``exp_avg_sq`` is gathered, so rank 0's file is complete.
 
         COLLECTIVE: it issues ``all_gather_into_tensor`` - EVERY rank of the group must call it, at the same point of the program.  The
@@ -246,11 +250,11 @@ class _ShardOptimizer:
         full = self._gather_full()
         groups = [dict(g) for g in self.inner.state_dict()['param_groups']]
         for g in groups:
-            g['params'] = list(range(len(sync.params)))
+            g['params'] = list(range(sync.n_all_params))
         state = {}
         if full is not None:
             offset = 0
-            for index, p in enumerate(sync.params):
+            for index, p in zip(sync.param_index, sync.params):
                 n = p.numel()
                 state[index] = {'step': full['step'].clone() if torch.is_tensor(full['step']) else full['step'],
                                 'exp_avg': full['exp_avg'][offset:offset + n].view_as(p).clone(), 'exp_avg_sq': full['exp_avg_sq'][offset:offset + n].view_as(p).clone()}
@@ -274,17 +278,26 @@ class _ShardOptimizer:
             if not entries:
                 full = {}
             else:
-                if len(entries) != len(sync.params):
-                    raise ValueError(f'checkpoint holds Adam state for {len(entries)} parameters, the model has {len(sync.params)}')
-                ordered = [entries[k] for k in sorted(entries)]
-                for e, p in zip(ordered, sync.params):
-                    if tuple(e['exp_avg'].shape) != tuple(p.shape):
-                        raise ValueError(f"checkpoint Adam state of shape {tuple(e['exp_avg'].shape)} does not fit parameter of shape {tuple(p.shape)}")
-                steps = {float(e['step']) for e in ordered}
+                # entries are keyed by the parameter's position in model.parameters() (torch.optim.Adam's numbering).  A parameter that never received a gradient has
+                # no entry there (Adam creates state at a parameter's first step): it gets zero moments and the common step count; a frozen one is not exchanged at all
+                stray = sorted(k for k in entries if k not in set(sync.param_index))
+                if stray:
+                    raise ValueError(f'checkpoint holds Adam state for parameter(s) {stray} that this model does not train (frozen or out of range: {sync.n_all_params} parameters)')
+                steps = {float(e['step']) for e in entries.values()}
                 if len(steps) != 1:
                     raise ValueError(f'the sharded optimizer keeps ONE step count; the checkpoint holds {sorted(steps)}')
-                full = {'exp_avg': torch.cat([e['exp_avg'].reshape(-1) for e in ordered]), 'exp_avg_sq': torch.cat([e['exp_avg_sq'].reshape(-1) for e in ordered]),
-                        'step': ordered[0]['step']}
+                ordered = []
+                for index, p in zip(sync.param_index, sync.params):
+                    e = entries.get(index)
+                    if e is None:
+                        ordered.append({'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)})
+                    elif tuple(e['exp_avg'].shape) != tuple(p.shape):
+                        raise ValueError(f"checkpoint Adam state {index} of shape {tuple(e['exp_avg'].shape)} does not fit parameter of shape {tuple(p.shape)}")
+                    else:
+                        ordered.append(e)
+                device = sync.param_shard.device
+                full = {'exp_avg': torch.cat([e['exp_avg'].reshape(-1).to(device) for e in ordered]), 'exp_avg_sq': torch.cat([e['exp_avg_sq'].reshape(-1).to(device) for e in ordered]),
+                        'step': next(iter(entries.values()))['step']}
         else:
             raise ValueError('not an Adam checkpoint (expected torch.optim.Adam\'s state_dict layout or the dict written by _ShardOptimizer.state_dict of rounds 3 - 4)')
         if not full:
@@ -378,7 +391,7 @@ class ShardedGradientSync(GradientSync):
 
 
 def checkpoint_state(epoch: int, model: torch.nn.Module, optimizer) -> dict:
-    """The dict a training checkpoint holds (``Main.py:144-147`` of the reference: epoch, model, optimizer).  Call it on EVERY rank: a sharded
+    """The dict a training checkpoint holds (written at ``Main.py:255-259`` of the reference, read at ``Main.py:208-212``: epoch, model, optimizer).  Call it on EVERY rank: a sharded
     optimizer's ``state_dict()`` gathers the ranks' Adam shards with a collective, and a chief-only call would deadlock.  Every rank gets the
     same complete dict back; only the chief writes it."""
     return {'epoch_count': int(epoch), 'model': model.state_dict(), 'optimizer': optimizer.state_dict()}

@@ -137,28 +137,82 @@ class CsrRows:
         self.row_order = None
 
 
+# IHG_EDGE_MULTIPLICITY = auto | 0 | 1: keep every DISTINCT (user, query, item) triple once and carry its number of occurrences as a per-hyperedge weight.  The reference
+# makes one hyperedge per interaction, duplicates included (Helpers/Graph.py:107-118); m identical hyperedges contribute m times one hyperedge's value to every sum the path
+# forms, so the collapsed layout computes the same function on E' <= E rows.  auto: on when at least MULTIPLICITY_MIN_SHARE of the interactions repeat an earlier triple
+# of a graph of at least MULTIPLICITY_MIN_EDGES (config C5's power-law draw: 48.7 %; the C2 - C4 stand-ins: < 1 %, off - their kernels and bits stay what they were).
+EDGE_MULTIPLICITY = os.environ.get('IHG_EDGE_MULTIPLICITY', 'auto')
+MULTIPLICITY_MIN_SHARE = float(os.environ.get('IHG_MULTIPLICITY_MIN_SHARE', 0.25))
+MULTIPLICITY_MIN_EDGES = int(os.environ.get('IHG_MULTIPLICITY_MIN_EDGES', 1 << 16))      # auto leaves small graphs alone (nothing to gain; '1' collapses any graph)
+# the first-order launches walk the two-hop list with a row's repeated (destination, source) entries merged into one weighted entry when at least this share of
+# the 6 E entries are repeats (C5: 79 %; C3 / C4 / C2: 8.6 / 13.6 / 17.9 %, where round 5 measured no gain - the repeats were cache hits); ops.TWO_HOP_MERGED overrides
+TWO_HOP_MERGED_MIN_SHARE = float(os.environ.get('IHG_TWO_HOP_MERGED_MIN_SHARE', 0.25))
+
+
+def unique_triples(triples: np.ndarray, user_count: int, query_count: int, item_count: int, count_only: bool = False):
+    """``(distinct [E', 3] int64 ascending by (user, query, item), multiplicity [E'] float32, file_to_unique [E] int32)`` of an ``[E, 3]`` triple array
+    (native ``ihg_unique_triples``); ``count_only``: just ``E'``."""
+    lib = _lib.load()
+    triples = np.ascontiguousarray(np.asarray(triples, dtype=np.int64).reshape(-1, 3))
+    e = int(triples.shape[0])
+    n = ctypes.c_int64(0)
+    if count_only:
+        _lib.check(lib.ihg_unique_triples(_as_ptr(triples, ctypes.c_int64), e, int(user_count), int(query_count), int(item_count), None, None, None, ctypes.byref(n)),
+                   'ihg_unique_triples')
+        return int(n.value)
+    uniq = np.empty((max(e, 1), 3), np.int64)
+    counts = np.empty(max(e, 1), np.float32)
+    where = np.empty(max(e, 1), np.int32)
+    _lib.check(lib.ihg_unique_triples(_as_ptr(triples, ctypes.c_int64), e, int(user_count), int(query_count), int(item_count), _as_ptr(uniq, ctypes.c_int64),
+                                      _as_ptr(counts, ctypes.c_float), _as_ptr(where, ctypes.c_int32), ctypes.byref(n)), 'ihg_unique_triples')
+    k = int(n.value)
+    return np.ascontiguousarray(uniq[:k]), counts[:k].copy(), where[:e]
+
+
 class IncidenceLayout:
     """The (user, query, item) hypergraph in kernel layout."""
 
     def __init__(self, triples: np.ndarray, user_count: int, query_count: int, item_count: int, device: torch.device,
-                 heavy_threshold: int = HEAVY_THRESHOLD, edge_order: str = os.environ.get('IHG_EDGE_ORDER', 'user')):
+                 heavy_threshold: int = HEAVY_THRESHOLD, edge_order: str = os.environ.get('IHG_EDGE_ORDER', 'user'), edge_multiplicity: Optional[str] = None):
         """``edge_order='user'`` renumbers the hyperedges by (user, file position) inside this layout: consecutive
         hyperedges then share their user row (the largest node table) and every user's incidence list is one contiguous
         run of edge-feature rows.  Hyperedge numbering is internal to the kernels - nothing outside the layout sees it
-        (``triples_file_order`` keeps the caller's order); results are order-independent up to fp32 re-association of
-        the per-node sums.  ``edge_order='file'`` keeps the reference's numbering (Graph.py:107-118)."""
+        (``triples_file_order`` keeps the caller's order, ``file_to_edge`` maps a file position to its row here); results are order-independent up to fp32
+        re-association of the per-node sums.  ``edge_order='file'`` keeps the reference's numbering (Graph.py:107-118).
+
+        ``edge_multiplicity`` (``'auto'`` | ``'0'`` | ``'1'``; default: ``IHG_EDGE_MULTIPLICITY``): collapse identical triples into ONE row of weight ``m_e``
+        (``edge_weight``, ``None`` when off).  ``edge_count`` is then the number of DISTINCT hyperedges - the rows of every ``[E, d]`` buffer - while ``hyperedge_count``
+        stays the reference's count (``PpsHyperGraph.EdgeCount``, the metric's E); degrees count every copy.  Rows are ordered by (user, query, item)."""
         lib = _lib.load()
         triples = np.ascontiguousarray(np.asarray(triples, dtype=np.int64).reshape(-1, 3))
         self.triples_file_order = triples
-        if edge_order == 'user' and triples.shape[0] > 1:
-            self.edge_perm = np.argsort(triples[:, 0], kind='stable')        # new position -> file position
-            triples = np.ascontiguousarray(triples[self.edge_perm])
-        elif edge_order in ('user', 'file'):
-            self.edge_perm = None
-        else:
-            raise ValueError(f'unknown edge_order {edge_order!r}')
+        self.hyperedge_count = int(triples.shape[0])
         self.user_count, self.query_count, self.item_count = int(user_count), int(query_count), int(item_count)
         self.node_count = n = self.user_count + self.query_count + self.item_count
+        if edge_order not in ('user', 'file'):
+            raise ValueError(f'unknown edge_order {edge_order!r}')
+        mode = str(EDGE_MULTIPLICITY if edge_multiplicity is None else edge_multiplicity)
+        if mode not in ('auto', '0', '1'):
+            raise ValueError(f'edge_multiplicity: auto | 0 | 1, got {mode!r}')
+        if mode == '1' and edge_order == 'file':
+            raise ValueError('edge_multiplicity=1 renumbers the hyperedges by (user, query, item): it cannot keep edge_order="file"')
+        multiplicity = None
+        self.duplicate_share = 0.0
+        if mode != '0' and edge_order == 'user' and self.hyperedge_count > 1 and (mode == '1' or self.hyperedge_count >= MULTIPLICITY_MIN_EDGES):
+            distinct = unique_triples(triples, user_count, query_count, item_count, count_only=True)
+            self.duplicate_share = 1.0 - distinct / self.hyperedge_count
+            if mode == '1' or self.duplicate_share >= MULTIPLICITY_MIN_SHARE:
+                triples, multiplicity, self.file_to_edge = unique_triples(triples, user_count, query_count, item_count)
+                self.edge_perm = None
+        if multiplicity is None:
+            if edge_order == 'user' and triples.shape[0] > 1:
+                self.edge_perm = np.argsort(triples[:, 0], kind='stable')        # new position -> file position
+                triples = np.ascontiguousarray(triples[self.edge_perm])
+                self.file_to_edge = np.empty(self.hyperedge_count, np.int32)
+                self.file_to_edge[self.edge_perm] = np.arange(self.hyperedge_count, dtype=np.int32)
+            else:
+                self.edge_perm = None
+                self.file_to_edge = np.arange(self.hyperedge_count, dtype=np.int32)
         self.edge_count = e = int(triples.shape[0])
         self.device = device
         i3 = np.empty((max(e, 1), 3), np.int32)
@@ -172,6 +226,12 @@ class IncidenceLayout:
         self.i3_host = i3[:e]
         self.i3 = torch.from_numpy(self.i3_host).to(device)
         self.node_csr = Csr(rowptr, edge_ids[:3 * e], device, heavy_threshold)
+        self.edge_weight_host = multiplicity
+        self.edge_weight = None if multiplicity is None else torch.from_numpy(multiplicity).to(device)
+        if multiplicity is not None:
+            # degrees count every copy of a hyperedge (Graph.py:112: one increment per interaction); counts are exact in float32 below 2^24 like the reference's own
+            counted = np.bincount(i3[:e].reshape(-1), weights=np.repeat(multiplicity.astype(np.float64), 3), minlength=n)[:n]
+            degree[:n] = np.where(counted > 0, counted, 1e-8).astype(np.float32)
         deg = torch.from_numpy(degree[:n].copy())
         self.degree = deg.to(device)                       # Graph.py:120 semantics (isolated -> 1e-8)
         isolated = deg < 0.5
@@ -203,8 +263,19 @@ class IncidenceLayout:
         rows = np.arange(3 * e)
         others = np.stack([inc[rows, first], inc[rows, second]], axis=1).reshape(-1).astype(np.int32)
         self.hop2_csr = Csr((rowptr.astype(np.int64) * 2).astype(np.int32), others, device, heavy_threshold)
+        # one weight per PAIR of the two-hop list (= per incidence): its hyperedge's multiplicity (ihg_node_pair_sums); None: every pair once
+        self.pair_weight_host = None if multiplicity is None else multiplicity[edge_ids[:3 * e]]
+        self.pair_weight = None if multiplicity is None else torch.from_numpy(self.pair_weight_host).to(device)
         self.self_weight = torch.where(isolated, torch.zeros_like(deg), deg).to(device)
-
+        # share of the reference's 6 E two-hop entries that repeat a (destination, source) pair of their row (a count-only pass of the merge); the merged list itself
+        # is built when a launch first asks for it
+        nnz = ctypes.c_int64(0)
+        merged_ptr = np.empty(self.hop2_csr.n_rows + 1, np.int32)
+        _lib.check(lib.ihg_merge_id_lists(_as_ptr(self.hop2_csr.ptr_host, ctypes.c_int32), _as_ptr(self.hop2_csr.ids_host, ctypes.c_int32), None, self.hop2_csr.n_rows,
+                                          _as_ptr(merged_ptr, ctypes.c_int32), None, None, ctypes.byref(nnz)), 'ihg_merge_id_lists')
+        self.two_hop_duplicate_share = 1.0 - int(nnz.value) / max(6 * self.hyperedge_count, 1)
+        # a layout with multiplicities has no unweighted two-hop list to fall back to: its first-order launches always walk the merged one
+        self.two_hop_merged_default = bool(multiplicity is not None or self.two_hop_duplicate_share >= TWO_HOP_MERGED_MIN_SHARE)
 
     def row_mask(self) -> torch.Tensor:
         """A byte per node row, all zero between uses (``ops._TwoHop.backward`` sets the rows of a sparse cotangent before its pull and clears them after)."""
@@ -215,10 +286,11 @@ class IncidenceLayout:
 
     def two_hop_merged(self) -> Tuple[Csr, torch.Tensor, float]:
         """``(csr, weights, duplicate_ratio)``: the two-hop list with the repeated (destination, source) entries of a row MERGED - the distinct other members of a
-        node's hyperedges, ascending, and how often each occurs (``ihg_merge_id_lists``).  ``H H^T - diag(deg)`` as a weighted CSR: the first-order layers' gather
-        launches read one row per DISTINCT neighbour and scale it by the multiplicity (the per-entry weight the K7 kernel already takes for ``Pps2DGraph``) - 8.6 %
-        fewer gathers at C3, 13.6 % at C4, 17.9 % at C2 (a user meets the same query in several hyperedges); real search logs repeat (user, query) far more.  The pair
-        sums of the interactive layer need the PAIRS and keep ``hop2_csr``.  Built on first use (a per-row sort of 6 E ids)."""
+        node's hyperedges, ascending, and how often each occurs (``ihg_merge_id_lists``; with ``edge_weight``: the sum of the multiplicities).  ``H H^T - diag(deg)`` as
+        a weighted CSR: the first-order layers' gather launches read one row per DISTINCT neighbour and scale it by the weight (the per-entry weight the K7 kernel
+        already takes for ``Pps2DGraph``) - 8.6 % fewer gathers at C3, 13.6 % at C4, 17.9 % at C2, 79 % at C5 (a user meets the same query in several hyperedges).
+        The pair sums of the interactive layer need the PAIRS and keep ``hop2_csr``.  ``duplicate_ratio`` is against the reference's 6 E entries.  Built on first
+        use (a per-row sort of the list) - ``two_hop_duplicate_share`` is known from construction."""
         cached = self.__dict__.get('_two_hop_merged')
         if cached is None:
             src = self.hop2_csr
@@ -226,13 +298,15 @@ class IncidenceLayout:
             ids = np.empty(max(src.nnz, 1), np.int32)
             counts = np.empty(max(src.nnz, 1), np.float32)
             nnz = ctypes.c_int64(0)
-            _lib.check(_lib.load().ihg_merge_id_lists(_as_ptr(src.ptr_host, ctypes.c_int32), _as_ptr(src.ids_host, ctypes.c_int32), src.n_rows,
+            weights = None if self.pair_weight_host is None else np.ascontiguousarray(np.repeat(self.pair_weight_host, 2))
+            _lib.check(_lib.load().ihg_merge_id_lists(_as_ptr(src.ptr_host, ctypes.c_int32), _as_ptr(src.ids_host, ctypes.c_int32),
+                                                      None if weights is None else _as_ptr(weights, ctypes.c_float), src.n_rows,
                                                       _as_ptr(ptr, ctypes.c_int32), _as_ptr(ids, ctypes.c_int32), _as_ptr(counts, ctypes.c_float), ctypes.byref(nnz)),
                        'ihg_merge_id_lists')
             n = int(nnz.value)
             csr = Csr(ptr, ids[:n].copy(), self.device, src.heavy_threshold)
             weights = torch.from_numpy(counts[:n].copy()).to(self.device)
-            cached = self.__dict__['_two_hop_merged'] = (csr, weights, 1.0 - n / max(src.nnz, 1))
+            cached = self.__dict__['_two_hop_merged'] = (csr, weights, 1.0 - n / max(6 * self.hyperedge_count, 1))
         return cached
 
     def drop_row_mask(self) -> None:

@@ -61,14 +61,15 @@ def _workspace(n_bytes: int, device: torch.device) -> Tensor:
 # raw launches (no autograd)
 # ---------------------------------------------------------------------------------------------
 def edge_gather_sum_raw(src: Tensor, i3: Tensor, node_scale: Optional[Tensor] = None, bias: Optional[Tensor] = None,
-                        alpha: float = 1.0, out: Optional[Tensor] = None) -> Tensor:
+                        alpha: float = 1.0, out: Optional[Tensor] = None, edge_scale: Optional[Tensor] = None) -> Tensor:
+    """``edge_scale`` (``[E]``): every hyperedge's sum times its own factor - ``layout.edge_weight`` where the result is the cotangent of all copies of a hyperedge."""
     lib = _lib.load()
     src = _rows(src, 'src')
     n_edges, dim = int(i3.shape[0]), int(src.shape[1])
     if out is None:
         out = torch.empty(n_edges, dim, dtype=torch.float32, device=src.device)
     with profiler.kernel('edge_gather_sum', n_edges, dim):
-        _lib.check(lib.ihg_edge_gather_sum(_ptr(src), _ld(src), _ptr(i3), _ptr(node_scale), _ptr(bias), float(alpha),
+        _lib.check(lib.ihg_edge_gather_sum(_ptr(src), _ld(src), _ptr(i3), _ptr(node_scale), _ptr(bias), float(alpha), _ptr(edge_scale),
                                            _ptr(out), _ld(out), n_edges, dim, _stream()), 'ihg_edge_gather_sum')
     return out
 
@@ -123,7 +124,7 @@ def node_pair_sums_raw(h: Tensor, layout: IncidenceLayout, out: Optional[Tensor]
             _ptr(h), _ld(h), _ptr(csr.ptr), _ptr(csr.ids), _ptr(csr.row_order), _ptr(out), _ld(out), csr.n_rows, dim,
             csr.heavy_threshold if heavy else 0, _ptr(csr.seg_begin) if heavy else None, _ptr(csr.seg_end) if heavy else None,
             csr.n_segments if heavy else 0, _ptr(csr.heavy_rows) if heavy else None, _ptr(csr.heavy_segptr) if heavy else None, csr.n_heavy,
-            _ptr(csr.partials(3 * dim)) if heavy else None, _stream()), 'ihg_node_pair_sums')
+            _ptr(csr.partials(3 * dim)) if heavy else None, _ptr(layout.pair_weight), _stream()), 'ihg_node_pair_sums')
     return out
 
 
@@ -151,6 +152,7 @@ class _EdgeGatherSum(torch.autograd.Function):
             scale = (scale * ctx.alpha) if scale is not None else torch.full(
                 (ctx.layout.node_count,), ctx.alpha, dtype=torch.float32, device=grad_out.device)
         mode = _lib.SCALE_NONE if scale is None else _lib.SCALE_MULTIPLY
+        # (grad_out is the cotangent of the layout's rows - one per DISTINCT hyperedge under edge_weight -: each row is added once, whatever its multiplicity)
         return node_segment_sum_raw(grad_out, ctx.layout.node_csr, None, scale, mode, role='k7.edges_to_nodes_bwd_of_k5'), None, None, None
 
 
@@ -159,11 +161,12 @@ class _NodeSegmentSum(torch.autograd.Function):
     def forward(ctx, src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor], rows: Optional[Tensor], out: Optional[Tensor]) -> Tensor:
         ctx.layout, ctx.out_scale = layout, out_scale
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(src, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=_check_out(out, src))
+        # layout.edge_weight (duplicate triples collapsed): a row stands for m_e hyperedges of the reference's incidence and enters the sum m_e times
+        return node_segment_sum_raw(src, layout.node_csr, layout.edge_weight, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=_check_out(out, src))
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
-        return edge_gather_sum_raw(grad_out, ctx.layout.i3, ctx.out_scale, None, 1.0), None, None, None, None
+        return edge_gather_sum_raw(grad_out, ctx.layout.i3, ctx.out_scale, None, 1.0, edge_scale=ctx.layout.edge_weight), None, None, None, None
 
 
 def edge_gather_sum(src: Tensor, layout: IncidenceLayout, node_scale: Optional[Tensor] = None, alpha: float = 1.0) -> Tensor:
@@ -173,7 +176,8 @@ def edge_gather_sum(src: Tensor, layout: IncidenceLayout, node_scale: Optional[T
 
 def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[Tensor] = None, rows: Optional[Tensor] = None,
                      out: Optional[Tensor] = None) -> Tensor:
-    """hyperedge -> node: ``out[v] = out_scale[v] * sum_{e containing v} src[e]``  (``[E,d] -> [N,d]``).
+    """hyperedge -> node: ``out[v] = out_scale[v] * sum_{e containing v} src[e]``  (``[E,d] -> [N,d]``; over ALL hyperedges of the reference's incidence: a layout
+    that keeps a repeated triple once weights its row by the multiplicity).
 
     ``rows`` (int32): the caller reads only these rows of the result (the batch rows of the last layer's output in a training
     step); rows outside the list and outside the split-row plan are left UNWRITTEN.  The gradient must then be zero outside
@@ -181,16 +185,25 @@ def node_segment_sum(src: Tensor, layout: IncidenceLayout, out_scale: Optional[T
     return _NodeSegmentSum.apply(src, layout, out_scale, rows, out)
 
 
-# IHG_TWO_HOP_MERGED=1: the first-order layers' gather launches walk the two-hop list with the repeated (destination, source) entries of a row merged into one weighted
-# entry (layout.two_hop_merged).  Off by default: measured in round 5 on the synthetic stand-ins it removes 8.6 % (C3) / 13.6 % (C4) / 17.9 % (C2) of the gathers and
-# NOT A MICROSECOND of the step (C3 7.74 against 7.71 ms, C2 1.888 / 1.871, C4 10.35 / 10.33: profiles/r5) - a repeated id of one row is re-read while its first copy is
-# still in the CU's L1 / the XCD's L2, the gathers that cost are the FIRST touches, and those stay.  Kept as a switch for corpora whose logs repeat (user, query) pairs far more.
-TWO_HOP_MERGED = _os.environ.get('IHG_TWO_HOP_MERGED', '0') == '1'
+# The first-order layers' gather launches walk the two-hop list either as it is (two ids per incidence) or with the repeated (destination, source) entries of a row merged
+# into one weighted entry (layout.two_hop_merged).  The LAYOUT decides (IncidenceLayout.two_hop_merged_default: merged when >= 25 % of the entries are repeats, or when it
+# carries hyperedge multiplicities): measured in round 5 on the C2 - C4 stand-ins, 8.6 - 17.9 % fewer gathers bought NOT A MICROSECOND (the repeats were cache hits:
+# profiles/r5/01_ab_two_hop_merged.txt) - at C5 79 % of the entries are repeats, its 10 GB node table is far beyond the caches, and the three launches go from 22.5 / 14.4 /
+# 23.9 ms to 13.0 / 6.4 / 12.8 (profiles/r6/01_ab_two_hop_C5_*.json: 326.8 -> 297.7 ms per step).  IHG_TWO_HOP_MERGED=1 / 0 (or this attribute: True / False) overrides.
+_two_hop_env = _os.environ.get('IHG_TWO_HOP_MERGED', 'auto')
+TWO_HOP_MERGED = {'1': True, '0': False}.get(_two_hop_env)          # None: per layout
+
+
+def two_hop_merged_for(layout: IncidenceLayout) -> bool:
+    """Whether this layout's first-order launches walk the merged (weighted) two-hop list."""
+    if layout.edge_weight is not None:
+        return True                                           # (its plain list has one entry per DISTINCT hyperedge: not the operator without the weights)
+    return layout.two_hop_merged_default if TWO_HOP_MERGED is None else bool(TWO_HOP_MERGED)
 
 
 def _two_hop_list(layout: IncidenceLayout):
     """``(csr, entry weights or None)`` of the two-hop operator's off-diagonal part ``H H^T - diag(deg)``."""
-    if TWO_HOP_MERGED:
+    if two_hop_merged_for(layout):
         csr, weights, _ = layout.two_hop_merged()
         return csr, weights
     return layout.hop2_csr, None
@@ -787,7 +800,8 @@ class _Interact(torch.autograd.Function):
 def _gathered_backward_ok(h: Tensor, w: Tensor, dy: Tensor, layout: IncidenceLayout, order: int) -> bool:
     lib = _lib.load()
     n_edges, dim = layout.edge_count, int(h.shape[1])
-    return (USER_REDUCED_BACKWARD and n_edges > 0 and getattr(layout, 'user_sorted', False)
+    # (the gathering kernel forms sum_m scale[m] dy[m] itself and has no per-hyperedge factor: a layout with multiplicities takes the K5 + member-kernel sequence)
+    return (USER_REDUCED_BACKWARD and n_edges > 0 and getattr(layout, 'user_sorted', False) and layout.edge_weight is None
             and n_edges * 3 * dim * 4 <= MEMBER_BUFFER_LIMIT_BYTES
             and bool(lib.ihg_interact_bwd_gathered_supported(dim, order, _ld(h), _ld(dy)))
             and h.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and _ld(w) % 4 == 0)
@@ -814,7 +828,7 @@ class _InteractToNodes(torch.autograd.Function):
                                             _ptr(edge), _ld(edge), _ptr(ws), ws.numel() * 4, layout.edge_count, dim, _stream()),
                        'ihg_interact_fwd')
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        y = node_segment_sum_raw(edge, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=out)
+        y = node_segment_sum_raw(edge, layout.node_csr, layout.edge_weight, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=out)
         ctx.save_for_backward(h, w)
         ctx.layout, ctx.order, ctx.out_scale = layout, order, out_scale
         return y
@@ -840,7 +854,7 @@ class _InteractToNodes(torch.autograd.Function):
                                                          n_edges, dim, _stream()), 'ihg_interact_bwd_gathered')
             node_segment_sum_raw(g2.view(2 * n_edges, dim), csr_qi, out=dh, rows=qi_rows, role='k7.member_gradients', read_once=True)
         else:
-            dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
+            dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0, edge_scale=layout.edge_weight)      # (the cotangent of ALL copies of a row: x m_e)
             dh = _interact_backward(h, w, dout, layout, order, dw)
         dp = node_segment_sum_raw(dout, layout.node_csr, role='k7.first_order_gradient')
         return dh, dp, dw, None, None, None, None, None
@@ -893,7 +907,7 @@ class _InteractLayer(torch.autograd.Function):
                                             _ptr(edge), _ld(edge), _ptr(ws2), ws2.numel() * 4, layout.edge_count, dim, _stream()),
                        'ihg_interact_fwd')
         mode = _lib.SCALE_NONE if out_scale is None else _lib.SCALE_MULTIPLY
-        return node_segment_sum_raw(edge, layout.node_csr, None, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=out)
+        return node_segment_sum_raw(edge, layout.node_csr, layout.edge_weight, out_scale, mode, rows=rows, role='k7.edges_to_nodes', out=out)
 
     @staticmethod
     def backward(ctx, dy: Tensor):
@@ -947,12 +961,12 @@ class _InteractLayer(torch.autograd.Function):
                 if _user_reduced_ok(h, w, dout, layout, order):
                     inv = torch.empty(n_edges, dtype=torch.float32, device=h.device)
                     with profiler.kernel('edge_gather_sum', n_edges, dim):
-                        _lib.check(lib.ihg_edge_gather_sum_planes(_ptr(dy), _ld(dy), _ptr(layout.i3), _ptr(out_scale), _ptr(dout), _ptr(inv), n_edges, dim, _stream()),
-                                   'ihg_edge_gather_sum_planes')
+                        _lib.check(lib.ihg_edge_gather_sum_planes(_ptr(dy), _ld(dy), _ptr(layout.i3), _ptr(out_scale), _ptr(layout.edge_weight), _ptr(dout), _ptr(inv), n_edges,
+                                                                  dim, _stream()), 'ihg_edge_gather_sum_planes')
                 else:
                     del dout
             if inv is None:
-                dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0)
+                dout = edge_gather_sum_raw(dy, layout.i3, out_scale, None, 1.0, edge_scale=layout.edge_weight)      # (x m_e: the cotangent of all copies of the row)
             if two_hop_first:
                 # a [E, d] table far beyond the caches (config C5: 51 GB): its scatter reads HBM at random, the two-hop operator on the node-level
                 # cotangent (10 GB) gathers twice the rows and is still the shorter launch (22 against 32 ms)
@@ -966,7 +980,7 @@ class _InteractLayer(torch.autograd.Function):
         del dout
         dbias = torch.empty(dim, dtype=torch.float32, device=h.device) if ctx.has_bias else None
         ws2 = _workspace(int(lib.ihg_node_linear_workspace_bytes(dim)), h.device)
-        accumulate = bool(lib.ihg_node_linear_bwd_accumulates(dim, _ld(dp), _ld(h), _ld(dh))) and h.data_ptr() % 16 == 0 and dh.data_ptr() % 16 == 0
+        accumulate = bool(lib.ihg_node_linear_bwd_accumulates(dim, _ld(dp), _ld(h), _ld(dh))) and h.data_ptr() % 16 == 0 and dh.data_ptr() % 16 == 0 and dp.data_ptr() % 16 == 0
         dx = dh if accumulate else torch.empty_like(dh)
         with profiler.kernel('node_linear_bwd', h.shape[0], dim):
             _lib.check(lib.ihg_node_linear_bwd_weight(_ptr(dp), _ld(dp), _ptr(h), _ld(h), _type_begin(layout), _ptr(dw), int(dw.stride(0)), dim,

@@ -111,12 +111,25 @@ int ihg_build_pair_csr(const int64_t* triples, int64_t n_edges, int64_t n_users,
                        int32_t* rowptr, int32_t* cols, float* vals, float* degree, int64_t capacity, int64_t* nnz_out);
 
 /* HOST: merge the repeated ids of every row of a CSR: row r of (out_ptr, out_ids, out_counts) holds the DISTINCT ids of row r of (ptr, ids) in ascending
- * order with their multiplicities as floats (exact: a count).  Applied to the two-hop list of the hypergraph (node -> the other two members of each of
+ * order with their multiplicities as floats (exact: a count) - or, with `weights` (one float per input id), the SUM of the weights of each distinct id.
+ * Applied to the two-hop list of the hypergraph (node -> the other two members of each of
  * its hyperedges, Helpers/Graph.py:107-118 composed with itself as Models/GnnLayers.py:233-234 does through two SpMMs) it gives H H^T - diag(deg) as a
  * weighted CSR: a (user, query) pair that co-occurs in k hyperedges is ONE entry of weight k instead of k gathers (duplicate hyperedges stay distinct
- * hyperedges: the multiplicities carry them).  out_ids / out_counts hold ptr[n_rows] entries; *nnz_out = entries used.
+ * hyperedges: the multiplicities carry them).  out_ids / out_counts hold ptr[n_rows] entries; *nnz_out = entries used.  out_ids == NULL: count only
+ * (out_ptr and *nnz_out are written).
  */
-int ihg_merge_id_lists(const int32_t* ptr, const int32_t* ids, int64_t n_rows, int32_t* out_ptr, int32_t* out_ids, float* out_counts, int64_t* nnz_out);
+int ihg_merge_id_lists(const int32_t* ptr, const int32_t* ids, const float* weights, int64_t n_rows, int32_t* out_ptr, int32_t* out_ids, float* out_counts,
+                       int64_t* nnz_out);
+
+/* HOST: the DISTINCT (user, query, item) triples of `triples` [n_edges, 3] (0-based per type, as ihg_build_csr takes them), ascending by (user, query, item), with
+ * how often each occurs.  The reference makes one hyperedge per positive interaction, duplicates included (Helpers/Graph.py:107-118); every quantity the
+ * path computes from duplicates - vertex degrees, H Ef, H^T of a cotangent - is the distinct hyperedge's value times its multiplicity, so a layout may keep each triple
+ * once and carry count_out as a per-hyperedge weight (IncidenceLayout.edge_weight): same results, a fraction of the rows on search logs that repeat.
+ *   unique_out [n_edges, 3] (capacity), count_out [n_edges], file_to_unique [n_edges] (optional: index of the distinct triple of every input row);
+ *   *n_unique_out = distinct triples.  unique_out == NULL: count only.
+ */
+int ihg_unique_triples(const int64_t* triples, int64_t n_edges, int64_t n_users, int64_t n_queries, int64_t n_items,
+                       int64_t* unique_out, float* count_out, int32_t* file_to_unique, int64_t* n_unique_out);
 
 /* HOST: invert any CSR (row -> sorted list of column ids) into its transpose.  Used for the
  * EmbeddingBag backward (word -> bags containing it).  Replaces the autograd-generated
@@ -133,18 +146,21 @@ int ihg_transpose_csr(const int32_t* ptr, const int32_t* ids, int64_t n_rows, in
  * Replaces: node_features[I3] gather + Linear of FeatureInteractor order 1 (Models/CommonLayers.py:60-66,
  * after hoisting the Linear to node level), thsp.matmul(incidence_t, x) * De^-1 of HGCNLayer
  * (Models/GnnLayers.py:148-149), and the autograd backward of thsp.matmul(incidence, .) (GnnLayers.py:233).
+ * edge_scale (optional, [n_edges]): the sum of hyperedge e is multiplied by alpha * edge_scale[e] - a layout that keeps each DISTINCT (user, query, item) triple once
+ * passes the triple's multiplicity here where the result is the cotangent of all its copies (the backward of the hyperedge -> node pass; duplicates are distinct
+ * hyperedges in the reference, Helpers/Graph.py:107-118, and m identical rows of H sum to m times one of them).
  */
 int ihg_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3,
-                        const float* node_scale, const float* bias, float alpha,
+                        const float* node_scale, const float* bias, float alpha, const float* edge_scale,
                         float* out, int64_t ld_out, int64_t n_edges, int32_t dim, ihg_stream_t stream);
 
 /* The same sum (alpha = 1, no bias) written as the member-gradient kernel's operand instead of fp32 rows (the backward of thsp.matmul(incidence, .), GnnLayers.py:233, whose
  * result only ihg_interact_bwd_user_reduced_planes reads): row e of `planes` is [2][dim] fp16 - the row scaled by the power of two that brings its largest magnitude
  * to [2^13, 2^14), as hi = fp16(x) and lo = fp16(x - hi) - and inv_scale[e] the inverse of that power.  4 dim bytes per row, like the fp32 row.  dim 256
- * (ihg_edge_gather_sum_planes_supported).
+ * (ihg_edge_gather_sum_planes_supported).  edge_scale: as in ihg_edge_gather_sum (applied before the row is scaled and split).
  */
 int32_t ihg_edge_gather_sum_planes_supported(int32_t dim, int64_t ld_src);
-int ihg_edge_gather_sum_planes(const float* src, int64_t ld_src, const int32_t* i3, const float* node_scale,
+int ihg_edge_gather_sum_planes(const float* src, int64_t ld_src, const int32_t* i3, const float* node_scale, const float* edge_scale,
                                void* planes, float* inv_scale, int64_t n_edges, int32_t dim, ihg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -289,6 +305,8 @@ int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, c
  * ihg_node_pair_sums: sums[v] = [ sum_e h[a_e] | sum_e h[b_e] | sum_e h[a_e] * h[b_e] ]  (3 dim floats per node; * elementwise).
  *   pair_ptr / pair_ids: CSR over the nodes with 2 ids per incident hyperedge - (query, item) for a user, (user, item) for a query,
  *   (user, query) for an item; the split-row plan is ihg_node_segment_sum's, with segments of even length.  Any dim % 4 == 0.
+ *   pair_weight (optional, one float per PAIR, i.e. per two ids): the pair enters all three sums that many times - the multiplicity of its hyperedge in a
+ *   layout that keeps each distinct (user, query, item) triple once (duplicates are distinct hyperedges in the reference, Helpers/Graph.py:107-118).
  *
  * ihg_node_interact_fwd: out[v] = out_scale[v] * ( degree[v] (A_t h[v] + bias) + the typed blocks of w applied to the sums and their
  *   products with h[v] ), w = [A_u | A_q | A_i | W_uq | W_qi | W_iu (| W_uqi)] as in ihg_interact_fwd, rows grouped by type_begin[4]
@@ -299,7 +317,7 @@ int ihg_interact_bwd_gathered(const float* h, int64_t ld_h, const int32_t* i3, c
 int ihg_node_pair_sums(const float* h, int64_t ld_h, const int32_t* pair_ptr, const int32_t* pair_ids, const int32_t* row_order, float* sums,
                        int64_t ld_sums, int64_t n_rows, int32_t dim, int32_t heavy_threshold, const int32_t* seg_begin, const int32_t* seg_end,
                        int64_t n_segments, const int32_t* heavy_rows, const int32_t* heavy_segptr, int64_t n_heavy, float* partials,
-                       ihg_stream_t stream);
+                       const float* pair_weight, ihg_stream_t stream);
 int32_t ihg_node_interact_fwd_supported(int32_t dim, int32_t order, int64_t ld_h, int64_t ld_sums, int64_t ld_out);
 int64_t ihg_node_interact_fwd_workspace_bytes(int32_t dim);
 int ihg_node_interact_fwd(const float* h, int64_t ld_h, const float* sums, int64_t ld_sums, const float* degree, const float* out_scale, const float* bias,

@@ -43,9 +43,9 @@ def test_widest_scored_row_is_one_number_everywhere():
 
 def test_bad_arguments_return_codes_and_messages():
     lib = _lib.load()
-    assert lib.ihg_edge_gather_sum(None, 4, None, None, None, 1.0, None, 4, 5, 4, None) == _lib.ERR_INVALID
+    assert lib.ihg_edge_gather_sum(None, 4, None, None, None, 1.0, None, None, 4, 5, 4, None) == _lib.ERR_INVALID
     assert 'null pointer' in _lib.last_error()
-    assert lib.ihg_edge_gather_sum(None, 2, None, None, None, 1.0, None, 4, 5, 4, None) == _lib.ERR_INVALID   # ld < dim
+    assert lib.ihg_edge_gather_sum(None, 2, None, None, None, 1.0, None, None, 4, 5, 4, None) == _lib.ERR_INVALID   # ld < dim
     assert lib.ihg_node_segment_sum(None, 4, None, None, None, None, None, None, 7, None, 4, 3, 4, 0, None, None, 0, None, None, 0, None, None, None, None) == _lib.ERR_INVALID
     assert 'out_scale_mode' in _lib.last_error()
     assert lib.ihg_interact_fwd(None, 4, None, 4, None, None, 28, 1, None, 4, None, 0, 3, 4, None) == _lib.ERR_INVALID
@@ -56,7 +56,7 @@ def test_bad_arguments_return_codes_and_messages():
     assert lib.ihg_interact_fwd_workspace_bytes(1000, 64, 3) == (4 * 64 * 64 + 6 * 64 * 64) * 4 and lib.ihg_interact_fwd_workspace_bytes(1000, 32, 3) == 4 * 32 * 32 * 4
     assert lib.ihg_interact_bwd_workspace_bytes(1000, 64, 3) > lib.ihg_interact_fwd_workspace_bytes(1000, 64, 3)
     # empty problems are fine and launch nothing
-    assert lib.ihg_edge_gather_sum(None, 4, None, None, None, 1.0, None, 4, 0, 4, None) == _lib.OK
+    assert lib.ihg_edge_gather_sum(None, 4, None, None, None, 1.0, None, None, 4, 0, 4, None) == _lib.OK
     assert lib.ihg_node_segment_sum(None, 4, None, None, None, None, None, None, 0, None, 4, 0, 4, 0, None, None, 0, None, None, 0, None, None, None, None) == _lib.OK
     with pytest.raises(_lib.IhgnnHipError, match='status -1'):
         _lib.check(_lib.ERR_INVALID, 'probe')

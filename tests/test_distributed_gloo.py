@@ -175,3 +175,39 @@ def test_sharded_batch_sampler_covers_each_epoch_exactly_once():
         first = [list(ihg_dist.ShardedBatchSampler(n, batch, 0, world, seed=3))]
         s2 = ihg_dist.ShardedBatchSampler(n, batch, 0, world, seed=3); s2.set_epoch(1)
         assert n < 3 or first[0] != list(s2)                             # a fresh permutation per epoch
+
+
+def test_sharded_checkpoint_is_numbered_like_adam_over_all_parameters():
+    """The sharded optimizer's checkpoint uses ``torch.optim.Adam(model.parameters())``'s numbering (reference: written at Main.py:255-259, read at 208-212): a FROZEN
+    parameter keeps its index and has no entry, a parameter that never received a gradient has no entry in a plain Adam's checkpoint and loads as zero moments."""
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2)), torch.nn.Parameter(torch.randn(6))]
+    ps[1].requires_grad_(False)                              # frozen: index 1 stays in the numbering, is not exchanged
+    sync = ihg_dist.ShardedGradientSync(ps)
+    assert sync.param_index == [0, 2, 3] and sync.n_all_params == 4
+    opt = sync.optimizer(1e-2)
+    (ps[0].sum() * 2 + ps[2].pow(2).sum() + ps[3].sum()).backward()
+    sync.average_gradients(); opt.step(); sync.zero_grad()
+    state = opt.state_dict()
+    assert sorted(state['state']) == [0, 2, 3] and state['param_groups'][0]['params'] == [0, 1, 2, 3]
+    # a plain Adam over ALL parameters (what the reference / the flat mode builds) loads it, entry by entry on the right parameter
+    clones = [torch.nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad) for p in ps]
+    plain = torch.optim.Adam(clones, 1e-2)
+    plain.load_state_dict(state)
+    assert tuple(plain.state[clones[2]]['exp_avg'].shape) == (2, 2) and clones[1] not in plain.state
+    # a plain Adam's checkpoint in which parameter 3 never received a gradient (no entry): the sharded optimizer takes zeros for it
+    plain2 = torch.optim.Adam(clones, 1e-2)
+    (clones[0].sum() + clones[2].sum()).backward()
+    plain2.step()
+    partial = plain2.state_dict()
+    assert sorted(partial['state']) == [0, 2]
+    fresh = sync.optimizer(1e-2)
+    fresh.load_state_dict(partial)
+    got = fresh._gather_full()
+    n0, n2 = ps[0].numel(), ps[2].numel()
+    assert torch.equal(got['exp_avg'][:n0].view(3, 4), partial['state'][0]['exp_avg']) and torch.equal(got['exp_avg'][n0:n0 + n2].view(2, 2), partial['state'][2]['exp_avg'])
+    assert float(got['exp_avg'][n0 + n2:].abs().sum()) == 0.0
+    # state for a parameter this model does not train is refused, not paired with a neighbour
+    bad = {'state': {1: partial['state'][0]}, 'param_groups': partial['param_groups']}
+    with pytest.raises(ValueError, match='does not train'):
+        sync.optimizer(1e-2).load_state_dict(bad)

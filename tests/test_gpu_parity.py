@@ -76,7 +76,7 @@ def test_edge_gather_sum_written_as_planes():
     inv = torch.empty(lay.edge_count, dtype=torch.float32, device=dev())
     s_dev, sc_dev = src.to(dev()), scale.to(dev())
     assert lib.ihg_edge_gather_sum_planes_supported(dim, dim) == 1 and lib.ihg_edge_gather_sum_planes_supported(128, 128) == 0
-    _lib.check(lib.ihg_edge_gather_sum_planes(ops._ptr(s_dev), dim, ops._ptr(lay.i3), ops._ptr(sc_dev), ops._ptr(planes), ops._ptr(inv), lay.edge_count, dim,
+    _lib.check(lib.ihg_edge_gather_sum_planes(ops._ptr(s_dev), dim, ops._ptr(lay.i3), ops._ptr(sc_dev), None, ops._ptr(planes), ops._ptr(inv), lay.edge_count, dim,
                                               ops._stream()), 'planes')
     torch.cuda.synchronize()
     halves = planes.cpu().view(torch.float16).view(lay.edge_count, 2, dim).float().numpy()
@@ -267,6 +267,225 @@ def test_two_hop_over_the_merged_list(dim, monkeypatch):
         assert row_rel(got_m, w64, floor=0.0) <= RTOL
     again = ops._two_hop_first_order_gradient(cot.to(dev()), lay, lay.inv_deg)
     assert torch.equal(again, results[False][3])             # (the plain list is the last one set: bitwise repeatable)
+
+
+def _layouts_with_and_without_multiplicities(U, Q, I, E, seed, copies=2, heavy_threshold=96):
+    """A graph whose interactions repeat (a power-law draw over few queries / items, then whole blocks of it again): the layout that keeps every distinct triple once
+    with its multiplicity, the layout with one row per interaction, and the file-order global member ids the float64 references sum over."""
+    from ihgnn_amd import synth
+    from ihgnn_amd.layout import IncidenceLayout
+    w = synth.draw(U, Q, I, 10, E, seed=seed, distribution='powerlaw', exponent=1.3)
+    triples = np.concatenate([w.triples] + [w.triples[:E // (k + 2)] for k in range(copies)])
+    weighted = IncidenceLayout(triples, U, Q, I, dev(), heavy_threshold=heavy_threshold, edge_multiplicity='1')
+    plain = IncidenceLayout(triples, U, Q, I, dev(), heavy_threshold=heavy_threshold, edge_multiplicity='0')
+    assert weighted.edge_weight is not None and weighted.edge_count < 0.7 * weighted.hyperedge_count and float(weighted.edge_weight.max()) >= 3
+    i3_file = torch.from_numpy(triples + np.array([0, U, U + Q]))
+    return weighted, plain, i3_file
+
+
+@pytest.mark.parametrize('dim', [8, 64, 256])
+def test_layout_with_hyperedge_multiplicities_aggregations(dim):
+    """``IncidenceLayout(edge_multiplicity='1')``: identical (user, query, item) triples kept ONCE with their number of occurrences as a per-hyperedge weight.  The
+    reference makes a hyperedge per interaction, duplicates included (``Helpers/Graph.py:107-118``): every aggregation over the collapsed layout
+    must equal the float64 sum over ALL interactions in file order - hyperedge -> node (K7: a row enters m_e times) and its backward (K5 x m_e), node -> hyperedge
+    (K5: one row per distinct hyperedge) and its backward (each row added once), the two-hop operator (merged list, weights = summed multiplicities) forward /
+    backward / masked pull, and the pair sums of the interactive layer (pair weights) - and the one-row-per-interaction layout's results."""
+    from ihgnn_amd import ops
+    lay, plain, i3 = _layouts_with_and_without_multiplicities(300, 6, 200, 20000, seed=21)
+    n, e_distinct, e_file = lay.node_count, lay.edge_count, lay.hyperedge_count
+    where = torch.from_numpy(lay.file_to_edge.astype(np.int64))
+    gen = torch.Generator().manual_seed(dim)
+    inv = lay.inv_deg.cpu().double()
+    assert torch.equal(lay.inv_deg, plain.inv_deg)
+    # hyperedge -> node and back
+    ef = torch.randn(e_distinct, dim, generator=gen)
+    cot_n = torch.randn(n, dim, generator=gen)
+    efd = ef.to(dev()).requires_grad_(True)
+    y = ops.node_segment_sum(efd, lay, lay.inv_deg)
+    y.backward(cot_n.to(dev()))
+    per_interaction = ef.double()[where]                                     # the reference's [E, d]: every copy has its distinct row's value
+    want = torch.zeros(n, dim, dtype=torch.float64)
+    for slot in range(3):
+        want.index_add_(0, i3[:, slot], per_interaction)
+    want = want * inv[:, None]
+    assert rel(y, want) <= RTOL_SUM
+    pulled = (inv[:, None] * cot_n.double())[i3].sum(1)                       # d loss / d (row of interaction k)
+    want_def = torch.zeros(e_distinct, dim, dtype=torch.float64).index_add_(0, where, pulled)      # a distinct row collects its copies' cotangents
+    assert rel(efd.grad, want_def) <= RTOL_SUM
+    # node -> hyperedge and back: one row per DISTINCT hyperedge, whose cotangent is added once
+    x = torch.randn(n, dim, generator=gen)
+    cot_e = torch.randn(e_distinct, dim, generator=gen)
+    xd = x.to(dev()).requires_grad_(True)
+    g = ops.edge_gather_sum(xd, lay, lay.inv_sqrt_deg, alpha=0.5)
+    g.backward(cot_e.to(dev()))
+    i3_d = torch.from_numpy(lay.i3_host.astype(np.int64))
+    s64 = lay.inv_sqrt_deg.cpu().double()[:, None] * x.double()
+    assert rel(g, 0.5 * s64[i3_d].sum(1)) <= RTOL_SUM
+    want_dx = torch.zeros(n, dim, dtype=torch.float64)
+    for slot in range(3):
+        want_dx.index_add_(0, i3_d[:, slot], 0.5 * cot_e.double())
+    assert rel(xd.grad, want_dx * lay.inv_sqrt_deg.cpu().double()[:, None]) <= RTOL_SUM
+    # the two-hop operator H H^T over all interactions
+    def operator64(v):
+        v = v.double()
+        rows = v[i3].sum(1)
+        out = torch.zeros(n, dim, dtype=torch.float64)
+        for slot in range(3):
+            out.index_add_(0, i3[:, slot], rows)
+        return out
+    listed = torch.randperm(n, generator=gen)[:70]
+    sparse_cot = torch.zeros_like(cot_n)
+    sparse_cot[listed] = cot_n[listed]
+    assert ops.two_hop_merged_for(lay)
+    for layout in (lay, plain):
+        xd = x.to(dev()).requires_grad_(True)
+        y2 = ops.node_two_hop(xd, layout, None, layout.inv_deg)
+        y2.backward(cot_n.to(dev()))
+        xs = x.to(dev()).requires_grad_(True)
+        ops.node_two_hop(xs, layout, None, layout.inv_deg, cotangent_rows=listed.to(dev())).backward(sparse_cot.to(dev()))
+        first = ops._two_hop_first_order_gradient(cot_n.to(dev()), layout, layout.inv_deg)
+        for got, w64 in ((y2, inv[:, None] * operator64(x)), (xd.grad, operator64(inv[:, None] * cot_n.double())), (xs.grad, operator64(inv[:, None] * sparse_cot.double())),
+                         (first, operator64(inv[:, None] * cot_n.double()))):
+            assert rel(got, w64) <= RTOL_SUM and row_rel(got, w64, floor=0.0) <= RTOL, layout is lay
+    # pair sums: per node the sums over ALL its interactions' other two members
+    if dim % 4 == 0:
+        sums = ops.node_pair_sums_raw(x.to(dev()), lay)
+        sums_plain = ops.node_pair_sums_raw(x.to(dev()), plain)
+        x64 = x.double()
+        want_s = torch.zeros(n, 3 * dim, dtype=torch.float64)
+        for slot, (a, b) in enumerate(((1, 2), (0, 2), (0, 1))):
+            ha, hb = x64[i3[:, a]], x64[i3[:, b]]
+            want_s.index_add_(0, i3[:, slot], torch.cat([ha, hb, ha * hb], 1))
+        assert rel(sums, want_s) <= RTOL_SUM and rel(sums_plain, want_s) <= RTOL_SUM and row_rel(sums, want_s, floor=0.0) <= RTOL
+
+
+@pytest.mark.parametrize('order,dim', [(3, 128), (2, 128), (3, 64), (3, 256), (2, 256), (3, 32), (3, 12)])
+def test_layout_with_hyperedge_multiplicities_interactive_layer(order, dim, monkeypatch):
+    """The interactive layer over a layout with hyperedge multiplicities - node-level form (weighted pair sums), hyperedge form (weighted hyperedge -> node pass), the
+    backward through K5 x m_e + the user-reduced member-gradient kernel (the gathering kernel has no per-hyperedge factor and is not taken), at d = 256 also config
+    C5's backward (two-hop first-order gradient, cotangents as fp16 planes) and the member buffer in hyperedge chunks - against the oracle's FeatureInteractor +
+    segment sum in float64 over ALL interactions in file order (duplicates are distinct hyperedges there, ``Helpers/Graph.py:107-118``), and against the layout with
+    one row per interaction."""
+    from ihgnn_amd import ops, profiler
+    from oracle import ihgnn_ref as ref
+    k = 7 if order == 3 else 6
+    lay, plain, i3 = _layouts_with_and_without_multiplicities(301, 9, 150, 9000, seed=5 + order)
+    n = lay.node_count
+    gen = torch.Generator().manual_seed(dim + order)
+    h = torch.randn(n, dim, generator=gen)
+    w = torch.randn(dim, k * dim, generator=gen) / np.sqrt(k * dim)
+    b = torch.randn(dim, generator=gen)
+    cot = torch.randn(n, dim, generator=gen)
+    h64, w64, b64 = h.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    feats = ref.feature_interactor(h64, i3, w64, b64, order)
+    want = torch.zeros(n, dim, dtype=torch.float64)
+    for slot in range(3):
+        want = want.index_add(0, i3[:, slot], feats)
+    want = want * lay.inv_deg.cpu().double()[:, None]
+    want.backward(cot.double())
+    want_grads = (h64.grad, w64.grad, b64.grad)
+
+    def run(layout):
+        hd, wd, bd = h.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True), b.to(dev()).requires_grad_(True)
+        profiler.start()
+        y = ops.interact_layer(hd, wd, bd, layout, order, layout.inv_deg)
+        y.backward(cot.to(dev()))
+        ran = set(profiler.summary())
+        profiler.stop()
+        return (y.detach(), hd.grad, wd.grad, bd.grad), ran
+
+    cases = [(True, True), (True, False), (False, False)]
+    for forward_flag, weight_flag in cases:
+        monkeypatch.setattr(ops, 'NODE_LEVEL_FORWARD', forward_flag)
+        monkeypatch.setattr(ops, 'NODE_LEVEL_WEIGHT', weight_flag)
+        got, ran = run(lay)
+        assert rel(got[0], want) <= RTOL, (forward_flag, weight_flag)
+        for a, c in zip(got[1:], want_grads):
+            assert rel(a, c) <= RTOL, (forward_flag, weight_flag)
+        assert row_rel(got[1], want_grads[0]) <= ROW_RTOL
+        got_plain, _ = run(plain)
+        for a, c in zip(got, got_plain):
+            assert rel(a, c) <= RTOL
+        if dim % 32 == 0:
+            assert 'interact_bwd' in ran and 'edge_gather_sum' in ran      # K5 x m_e, then the member-gradient kernel: no gathering form under multiplicities
+    monkeypatch.setattr(ops, 'NODE_LEVEL_FORWARD', True)
+    monkeypatch.setattr(ops, 'NODE_LEVEL_WEIGHT', True)
+    if dim == 256:
+        monkeypatch.setattr(ops, 'FIRST_ORDER_TWO_HOP_BYTES', 0)              # config C5's backward: two-hop first-order gradient, cotangents as fp16 planes
+        got, ran = run(lay)
+        assert 'k7.two_hop_first_order_gradient' in ran and 'k7.first_order_gradient' not in ran
+        for a, c in zip(got[1:], want_grads):
+            assert rel(a, c) <= RTOL
+        monkeypatch.setattr(ops, 'COTANGENT_PLANES', False)
+        again, _ = run(lay)
+        assert torch.equal(again[1], got[1]) and torch.equal(again[2], got[2])
+        monkeypatch.setattr(ops, 'COTANGENT_PLANES', True)
+        monkeypatch.setattr(ops, 'MEMBER_BUFFER_LIMIT_BYTES', lay.edge_count * 2 * dim * 4 // 3 + 1)      # ... with the member buffer in three hyperedge chunks
+        chunked, _ = run(lay)
+        for a, c in zip(chunked[1:], want_grads):
+            assert rel(a, c) <= RTOL
+
+
+@pytest.mark.parametrize('kind,layers,order,dim', [('ihgnn', 2, 3, 64), ('ihgnn', 3, 3, 128), ('ihgnn', 2, 3, 256), ('ihgnn', 2, 3, 32), ('ihgnn', 1, 3, 64), ('ihgnn', 2, 1, 64), ('hgcn', 2, 1, 64)])
+def test_layout_with_hyperedge_multiplicities_training_steps(kind, layers, order, dim, monkeypatch):
+    """Whole training steps (fused batch tail, taps, restricted / masked last layer, HIP Adam) of a model over a dataset whose layout carries hyperedge multiplicities
+    against the same model over the one-row-per-interaction layout and against the float64 oracle on all interactions: losses over four steps, every parameter after
+    them, and the evaluation's top items.  ``PpsHyperGraph`` keeps presenting the reference's tensors (``EdgeCount``, ``I3``: one hyperedge per interaction)."""
+    from ihgnn_amd import layout as layout_mod, ops, synth
+    from ihgnn_amd.Dataset import GraphDataset
+    from ihgnn_amd.optim import Adam
+    from oracle import ihgnn_ref as ref
+    U, Q, I = 211, 7, 160
+    w = synth.draw(U, Q, I, 40, 7000, seed=77, distribution='powerlaw', exponent=1.3)
+    triples = np.concatenate([w.triples, w.triples[:3500], w.triples[:900]])
+    if dim == 256:
+        monkeypatch.setattr(ops, 'FIRST_ORDER_TWO_HOP_BYTES', 0)
+    results = {}
+    rng = np.random.default_rng(1)
+    batches = [tuple(torch.from_numpy(rng.integers(0, c, 330)) for c in (U, Q, I)) + (torch.from_numpy((rng.random(330) < 0.1).astype(np.float32)),) for _ in range(4)]
+    eu, eq = torch.from_numpy(rng.integers(0, U, 12)), torch.from_numpy(rng.integers(0, Q, 12))
+    for mode in ('1', '0'):
+        monkeypatch.setattr(layout_mod, 'EDGE_MULTIPLICITY', mode)
+        ds = GraphDataset.from_arrays(U, Q, I, w.vocab_size, w.bag_words, w.bag_offsets, triples, device=dev())
+        lay = ds.hypergraph.layout
+        assert (lay.edge_weight is not None) == (mode == '1') and ds.hypergraph.EdgeCount == len(triples) and tuple(ds.hypergraph.I3.shape) == (len(triples), 3)
+        m = build_model(ds, kind, layers, order, dim)
+        if mode == '1':
+            init = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        else:
+            m.load_state_dict(init)
+        opt = Adam(m.parameters(), 1e-3, weight_decay=0)
+        losses = []
+        for restrict, (u, q, i, y) in zip((False, True, False, True), batches):
+            m.batch_rows_only_last_layer = restrict
+            loss = m.bce_loss(u.to(dev()), q.to(dev()), i.to(dev()), y.to(dev()))
+            loss.backward(); opt.step(); opt.zero_grad()
+            losses.append(loss.item())
+        with torch.no_grad():
+            m.save_features_for_test()
+            top = m.top_items(eu.to(dev()), eq.to(dev()))
+            feats = m._saved_output_feature.clone()
+            m.clear_saved_feature()
+        results[mode] = (losses, {k: v.detach().cpu() for k, v in m.state_dict().items()}, top, feats)
+    g = ref.HyperGraph(triples, U, Q, I)
+    oracle = ref.OracleRawGnn(g, torch.from_numpy(w.bag_words + 1), torch.from_numpy(w.bag_offsets), w.vocab_size, dim, kind, layers, order)
+    oracle.load_reference_state({k: v.cpu().numpy() for k, v in init.items()})
+    oopt = torch.optim.Adam(oracle.parameters(), 1e-3)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    want_losses = []
+    for u, q, i, y in batches:
+        loss = lossf(oracle(u, q, i), y)
+        loss.backward(); oopt.step(); oopt.zero_grad()
+        want_losses.append(loss.item())
+    np.testing.assert_allclose(results['1'][0], want_losses, rtol=1e-4)
+    np.testing.assert_allclose(results['0'][0], want_losses, rtol=1e-4)
+    np.testing.assert_allclose(results['1'][0], results['0'][0], rtol=2e-5)
+    want_state = oracle.reference_state()
+    for name, value in results['1'][1].items():
+        assert rel(value, want_state[name]) <= 2e-4, name                   # (four Adam steps of 1e-3 on O(0.1) weights: an update-sized error would show as 1e-2)
+        assert rel(value, results['0'][1][name]) <= 2e-4, name
+    assert rel(results['1'][3], results['0'][3]) <= 1e-4
+    assert float((results['1'][2][0] == results['0'][2][0]).float().mean()) >= 0.9
 
 
 def test_user_ordered_hyperedge_numbering_is_equivalent():
@@ -1145,7 +1364,7 @@ F10_LAUNCHES = {
 }
 
 
-@pytest.mark.parametrize('path', ['module_calls', 'fused_step'])
+@pytest.mark.parametrize('path', ['module_calls', 'fused_step', 'fused_step_multiplicities'])
 @pytest.mark.parametrize('tag', ['d128_l3_o3', 'd64_l2_o3', 'd32_l2_o3', 'd128_l3_o2', 'd256_l2_o3'])
 def test_f10_training_curve_and_ranking_metrics_on_the_headline_arithmetic(tag, path, monkeypatch):
     """The north_star's acceptance clause on the arithmetic the headline runs: 48 Adam steps of the REFERENCE (fixture F10: d = 128 x 3 layers orders 3 / 2,
@@ -1156,6 +1375,13 @@ def test_f10_training_curve_and_ranking_metrics_on_the_headline_arithmetic(tag, 
     from ihgnn_amd import ops, profiler
     from ihgnn_amd.Helpers.Metrics import Metrics
     (L, order, d), sd, z, w = f10_case(tag)
+    multiplicities = path == 'fused_step_multiplicities'
+    if multiplicities:
+        # the same reference curves with the fixture's repeated (user, query, item) triples collapsed into weighted rows (IHG_EDGE_MULTIPLICITY=1; what config C5
+        # runs by default): the reference counts every copy as a hyperedge (Helpers/Graph.py:107-118) - so must the collapsed layout
+        from ihgnn_amd import layout as layout_mod
+        monkeypatch.setattr(layout_mod, 'EDGE_MULTIPLICITY', '1')
+        path = 'fused_step'
     c5_backward = d == 256 and path == 'fused_step'
     if c5_backward:
         # d = 256 on the fused path: config C5's own backward at fixture size - the first-order gradient by the two-hop operator (what its 51 GB cotangent table
@@ -1163,6 +1389,10 @@ def test_f10_training_curve_and_ranking_metrics_on_the_headline_arithmetic(tag, 
         monkeypatch.setattr(ops, 'FIRST_ORDER_TWO_HOP_BYTES', 0)
     ds = dataset_from_npz(w)
     assert ds.hypergraph.layout.node_csr.n_heavy > 0                    # split rows are on the path
+    if multiplicities:
+        lay = ds.hypergraph.layout
+        assert lay.edge_weight is not None and lay.edge_count < lay.hyperedge_count == ds.hypergraph.EdgeCount == len(w['triples'])
+        print(f'F10 {tag}: {lay.hyperedge_count} interactions, {lay.edge_count} distinct hyperedges')
     m = build_model(ds, 'ihgnn', L, order, d)
     assert set(sd) == set(m.state_dict())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -1184,6 +1414,8 @@ def test_f10_training_curve_and_ranking_metrics_on_the_headline_arithmetic(tag, 
     must, must_not = F10_LAUNCHES[tag]
     if c5_backward:
         must = must | {'k7.two_hop_first_order_gradient'}
+    if multiplicities:                                                  # no gathering member-gradient kernel under multiplicities: K5 (x m_e) forms the cotangents
+        must, must_not = (must - {'k7.two_hop_first_order_gradient'}) | {'edge_gather_sum'}, must_not - {'edge_gather_sum'}
     assert must <= set(launched) and not (must_not & set(launched)), sorted(launched)
     worst = float(np.abs(np.array(losses) / z[f'{tag}.losses'] - 1).max())
     print(f'F10 {tag} {path}: worst loss deviation over {len(losses)} steps {worst:.2e}')

@@ -59,6 +59,28 @@ def test_hypergraph_matches_reference(f1):
     assert (lay.inv_deg[~alive] == 0).all() and (~alive).sum() == 2
 
 
+def test_hypergraph_with_multiplicities_presents_the_reference_tensors(monkeypatch):
+    """Fixture F1 holds a duplicated (user, query, item) triple (duplicates are distinct hyperedges).  With the layout collapsing it into one weighted row
+    (``IHG_EDGE_MULTIPLICITY=1``) the graph object still presents the REFERENCE's tensors - ``EdgeCount``, ``I3``, ``Adjacency``, ``VertexDegrees``, ``EdgeDegrees`` in file
+    order, one hyperedge per interaction - and the kernel-side scale factors are the same bits."""
+    from ihgnn_amd import layout as layout_mod
+    monkeypatch.setattr(layout_mod, 'EDGE_MULTIPLICITY', '1')
+    z = np.load(os.path.join(GOLDEN, 'f1_graph.npz'))
+    ds = GraphDataset(os.path.join(F1, 'graph_info.txt'), os.path.join(F1, 'queries_multihot.txt'), os.path.join(F1, 'train_data.csv'), PpsHyperGraph, 10, 0, CPU)
+    g, lay = ds.hypergraph, ds.hypergraph.layout
+    assert lay.edge_weight is not None and lay.edge_count == len(np.unique(z['I3'], axis=0)) < int(z['EdgeCount']) and float(lay.edge_weight.sum()) == int(z['EdgeCount']) and float(lay.edge_weight.max()) == 2.0
+    assert g.EdgeCount == int(z['EdgeCount'])
+    np.testing.assert_array_equal(g.I3.numpy(), z['I3'])
+    np.testing.assert_array_equal(g.Adjacency.indices().numpy(), z['coo_indices'])
+    np.testing.assert_array_equal(g.Adjacency.values().numpy(), z['coo_values'])
+    np.testing.assert_array_equal(g.VertexDegrees.numpy(), z['VertexDegrees'])
+    np.testing.assert_array_equal(g.EdgeDegrees.numpy(), z['EdgeDegrees'])
+    deg = torch.from_numpy(z['VertexDegrees'][:, 0])
+    alive = deg > 0.5
+    assert torch.equal(lay.inv_deg[alive], deg.pow(-1)[alive]) and torch.equal(lay.inv_sqrt_deg[alive], deg.pow(-0.5)[alive]) and (lay.inv_deg[~alive] == 0).all()
+    np.testing.assert_array_equal(lay.i3_host[lay.file_to_edge].astype(np.int64), z['I3'])
+
+
 def test_csr_is_node_major_sorted_and_complete():
     w = synth.draw(50, 20, 70, 30, 2000, seed=3, distribution='powerlaw')
     lay = IncidenceLayout(w.triples, 50, 20, 70, CPU, heavy_threshold=64)
@@ -423,6 +445,63 @@ def test_merged_two_hop_list_is_the_pairwise_graph_with_multiplicities():
     # an empty graph and a graph of one hyperedge
     one = IncidenceLayout(np.array([[0, 0, 0]]), 2, 1, 1, CPU).two_hop_merged()
     assert one[0].nnz == 6 and one[2] == 0.0 and bool((one[1] == 1).all())
+
+
+def test_unique_triples_and_weighted_layout():
+    """``ihg_unique_triples`` + ``IncidenceLayout(edge_multiplicity='1')``: identical (user, query, item) triples kept once, ascending by (user, query, item), with their
+    number of occurrences - against numpy; and every quantity the layout derives counts the copies exactly as the one-row-per-interaction layout does (the reference
+    makes a hyperedge per interaction, duplicates included, ``Helpers/Graph.py:107-118``): degrees and scale factors bit for bit, the merged two-hop list entry for
+    entry, the pair weights, the file -> row map."""
+    from ihgnn_amd import layout as layout_mod
+    w = synth.draw(300, 12, 200, 10, 9000, seed=3, distribution='powerlaw', exponent=1.2)
+    triples = np.concatenate([w.triples, w.triples[:700], w.triples[:90]])       # on top of the draw's own repeats
+    uniq, counts, where = layout_mod.unique_triples(triples, 300, 12, 200)
+    want, want_inverse, want_counts = np.unique(triples, axis=0, return_inverse=True, return_counts=True)
+    np.testing.assert_array_equal(uniq, want)
+    np.testing.assert_array_equal(counts, want_counts.astype(np.float32))
+    np.testing.assert_array_equal(where, want_inverse.reshape(-1))
+    assert layout_mod.unique_triples(triples, 300, 12, 200, count_only=True) == len(want) < len(triples)
+    with pytest.raises(Exception, match='out of range'):
+        layout_mod.unique_triples(np.array([[0, 12, 0]]), 300, 12, 200)
+    plain = IncidenceLayout(triples, 300, 12, 200, CPU, edge_multiplicity='0')
+    lay = IncidenceLayout(triples, 300, 12, 200, CPU, edge_multiplicity='1')
+    assert plain.edge_weight is None and plain.edge_count == plain.hyperedge_count == len(triples)
+    assert lay.edge_count == len(want) and lay.hyperedge_count == len(triples) and abs(lay.duplicate_share - (1 - len(want) / len(triples))) < 1e-12
+    np.testing.assert_array_equal(lay.edge_weight.numpy(), want_counts.astype(np.float32))
+    np.testing.assert_array_equal(lay.file_to_edge, want_inverse.reshape(-1))
+    np.testing.assert_array_equal(plain.file_to_edge[plain.edge_perm], np.arange(len(triples)))
+    offs = np.array([0, 300, 312])
+    np.testing.assert_array_equal(lay.i3_host, (want + offs).astype(np.int32))
+    np.testing.assert_array_equal(lay.i3_host[lay.file_to_edge], (triples + offs).astype(np.int32))          # every interaction finds its row
+    for name in ('degree', 'inv_deg', 'inv_sqrt_deg', 'self_weight'):
+        assert torch.equal(getattr(lay, name), getattr(plain, name)), name
+    # pair weights: one per incidence of a distinct hyperedge = that hyperedge's multiplicity
+    np.testing.assert_array_equal(lay.pair_weight.numpy(), want_counts.astype(np.float32)[lay.node_csr.ids_host])
+    assert lay.hop2_csr.nnz == 6 * len(want) and plain.pair_weight is None
+    # the merged two-hop list (weights summed over the multiplicities) is the plain layout's merged list: H H^T - diag(deg) does not know how its entries were counted
+    a, aw, a_dup = lay.two_hop_merged()
+    b, bw, b_dup = plain.two_hop_merged()
+    np.testing.assert_array_equal(a.ptr_host, b.ptr_host)
+    np.testing.assert_array_equal(a.ids_host, b.ids_host)
+    np.testing.assert_array_equal(aw.numpy(), bw.numpy())
+    assert a_dup == b_dup == lay.two_hop_duplicate_share == plain.two_hop_duplicate_share
+    assert lay.two_hop_merged_default and plain.two_hop_merged_default == (plain.two_hop_duplicate_share >= layout_mod.TWO_HOP_MERGED_MIN_SHARE)
+    # auto: small graphs are left alone, large ones decide by the share of repeats
+    assert IncidenceLayout(triples, 300, 12, 200, CPU).edge_weight is None
+    big = np.concatenate([triples] * 8)
+    auto = IncidenceLayout(big, 300, 12, 200, CPU)
+    assert len(big) >= layout_mod.MULTIPLICITY_MIN_EDGES and auto.edge_weight is not None and auto.edge_count == len(want)
+    np.testing.assert_array_equal(auto.edge_weight.numpy(), 8 * want_counts.astype(np.float32))
+    sparse = synth.draw(30000, 3000, 30000, 10, 70000, seed=1)                   # uniform members: hardly a repeat
+    assert IncidenceLayout(sparse.triples, 30000, 3000, 30000, CPU).edge_weight is None
+    with pytest.raises(ValueError, match='edge_order'):
+        IncidenceLayout(triples, 300, 12, 200, CPU, edge_order='file', edge_multiplicity='1')
+    # the reference-shaped views keep presenting one hyperedge per interaction, in file order
+    from ihgnn_amd.Helpers.Graph import PpsHyperGraph
+    g = PpsHyperGraph()
+    g.layout, g.EdgeCount = lay, lay.hyperedge_count
+    assert tuple(g.I3.shape) == (len(triples), 3) and tuple(g.Adjacency.shape) == (512, len(triples)) and tuple(g.EdgeDegrees.shape) == (len(triples), 1)
+    np.testing.assert_array_equal(g.I3.numpy(), triples + offs)
 
 
 # ---------------------------------------------------------------------------------------------
