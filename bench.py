@@ -87,8 +87,10 @@ def parse():
     ap.add_argument('--scale', type=float, default=1.0, help='shrink every count of the workload (exploratory runs of the big configs)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for smoke tests)')
     ap.add_argument('--device', type=int, default=-1, help='force every rank onto this GPU ordinal (single-GPU smoke test of the N-rank path)')
-    ap.add_argument('--sync', default='bucketed', choices=['flat', 'bucketed', 'sharded'],
-                    help='gradient exchange for --gpus > 1: one flat all-reduce | per-bucket all-reduces from a side stream | reduce-scatter + sharded Adam + all-gather')
+    ap.add_argument('--sync', default='auto', choices=['auto', 'cotangent', 'flat', 'bucketed', 'sharded'],
+                    help='gradient exchange for --gpus > 1: auto (ihgnn_amd.distributed.choose_gradient_sync: cotangent wherever the fused batch tail runs) | cotangent: all-gather of '
+                         'the batch rows\' cotangents, propagation backward on the union, no dense exchange | one flat all-reduce | per-bucket all-reduces from a side stream | '
+                         'reduce-scatter + sharded Adam + all-gather')
     return ap.parse_args()
 
 
@@ -314,9 +316,14 @@ def main():
     from ihgnn_amd.optim import Adam
     lossf = torch.nn.BCEWithLogitsLoss()
     sync = None
+    sync_mode = args.sync
     if world > 1 or ihg_dist.force_collectives():            # (IHG_FORCE_COLLECTIVES=1: a one-rank process group that really issues the collectives)
-        sync = ihg_dist.make_gradient_sync(model, args.sync)
+        if sync_mode == 'auto':                              # by the gradient bytes and the loss path: cotangent for every BASELINE config (fused batch tail); C5's 9.4 GB
+            sync_mode = ihg_dist.choose_gradient_sync(4 * sum(p.numel() for p in model.parameters()), world, model.supports_fused_loss(lossf))      # of gradients otherwise: sharded
+        sync = ihg_dist.make_gradient_sync(model, sync_mode)
         sync.broadcast_parameters(0)
+        if sync_mode == 'cotangent':
+            sync.equal_batches, sync.time_exchanges = True, True      # (every rank draws batches of 1,100 rows)
     opt = sync.optimizer(1e-3) if (sync is not None and sync.owns_optimizer) else Adam(model.parameters(), 1e-3, weight_decay=0)
     if hasattr(opt, 'ensure_state'):
         # Adam's moment buffers exist BEFORE the first step: otherwise they are created at the end of step 1, step 2 meets a different memory pattern and the caching
@@ -328,10 +335,18 @@ def main():
     model.batch_rows_only_last_layer = False
 
     exchange_events = []                                     # (before, after) the gradient exchange on the step's stream, timed region only
+    cotangent = sync is not None and getattr(sync, 'mode', None) == 'cotangent'
+    if cotangent and not fused_loss:
+        raise SystemExit('--sync cotangent needs the fused batch tail (IHGNN / HGCN layers, BCEWithLogitsLoss)')
 
     def step(k, timed=False):
         u, q, i, y = batches[k]
-        loss = model.bce_loss(u, q, i, y) if fused_loss else lossf(model(u, q, i), y)       # what train_and_get_avg_loss does
+        if cotangent:
+            if timed:
+                sync.exchange_events = []
+            loss = model.bce_loss(u, q, i, y, cotangent_sync=sync)      # (the exchange - two all-gathers - happens inside: before the forward and in the tail's backward)
+        else:
+            loss = model.bce_loss(u, q, i, y) if fused_loss else lossf(model(u, q, i), y)       # what train_and_get_avg_loss does
         ihg_ops.backward(loss)                               # loss.backward() with a cached root gradient
         if sync is not None:
             if timed:
@@ -341,6 +356,8 @@ def main():
             if timed:
                 e1.record()
                 exchange_events.append((e0, e1))
+                if cotangent:
+                    exchange_events.extend(sync.exchange_events)
         opt.step()
         if sync is not None:
             sync.zero_grad()
@@ -378,7 +395,7 @@ def main():
     # step's stream around average_gradients(): what of the exchange is NOT hidden behind the backward)
     exchange = None
     if sync is not None:
-        exposed = sum(a.elapsed_time(b) for a, b in exchange_events) / max(len(exchange_events), 1)
+        exposed = sum(a.elapsed_time(b) for a, b in exchange_events) / max(args.steps, 1)
         mine = torch.tensor([1e3 * my_elapsed / args.steps, exposed], dtype=torch.float64, device=dev)
         table_ranks = [torch.zeros_like(mine) for _ in range(world)]
         if dist.is_initialized():
@@ -386,11 +403,19 @@ def main():
         else:
             table_ranks = [mine]
         flat = getattr(sync, '_grads_padded', None) if getattr(sync, '_grads_padded', None) is not None else sync.flat
-        exchange = dict(mode=args.sync, backend=dist.get_backend() if dist.is_initialized() else None, gradient_bytes_per_rank=int(flat.numel() * flat.element_size()),
+        dense_bytes = int(sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad))
+        exchange = dict(mode=sync_mode, requested=args.sync, backend=dist.get_backend() if dist.is_initialized() else None, ranks=world,
+                        gradient_bytes_per_rank=dense_bytes,
+                        # what this rank hands to the collective(s) of one step and what it receives from the other ranks
+                        bytes_sent_per_rank=int(sync.sent_bytes) if cotangent else int(flat.numel() * flat.element_size()),
+                        bytes_received_per_rank=int(sync.exchanged_bytes) if cotangent else int(2 * (world - 1) / max(world, 1) * flat.numel() * flat.element_size()),
+                        bytes_note=('cotangent: two all-gathers per step - the batch node rows (3 B int64) before the forward, the batch rows\' cotangents (3 B x (D + 4) f32) in the '
+                                    'tail\'s backward; received = (W - 1) x sent; the dense gradients (gradient_bytes_per_rank) never cross' if cotangent else
+                                    'dense gradients through a ring all-reduce / reduce-scatter + all-gather: 2 (W - 1) / W x the buffer in and out per rank'),
                         per_rank=[dict(rank=r, ms_per_step=round(float(t[0]), 4), exposed_exchange_ms_per_step=round(float(t[1]), 4)) for r, t in enumerate(table_ranks)],
                         exposed_exchange_ms_per_step_max=round(max(float(t[1]) for t in table_ranks), 4),
-                        note='exposed = HIP events on the step\'s stream around average_gradients(): the part of the exchange the stream waits for '
-                             '(bucketed: the dense bucket overlaps the backward, the embedding tables\' buckets are produced by its last kernels)')
+                        note='exposed = HIP events on the step\'s stream around average_gradients() (cotangent: around its two all-gathers): the part of the exchange the stream '
+                             'waits for (bucketed: the dense bucket overlaps the backward, the embedding tables\' buckets are produced by its last kernels)')
     profiler.stop()
     kernels = profiler.summary() if not args.no_kernel_events else {}
     final_loss = float(last.item())
@@ -672,7 +697,7 @@ def main():
                                f' U={w.user_count} Q={w.query_count} I={w.item_count} E={E}, {cfg["distribution"]} members, '
                                f'dim={dim}, {layers}x{args.layer} layers, interaction order {args.order}, batch 100 pos + 1000 neg',
                    'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd (the last layer\'s backward pulls the 3B non-zero rows of its cotangent) + Adam' +
-                           (f' + RCCL gradient exchange ({args.sync})' if world > 1 else ''),
+                           (f' + RCCL gradient exchange ({sync_mode})' if world > 1 else ''),
                    'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
                    # share of the two-hop list's 6 E entries that repeat a (destination, source) pair of their row: merged into weighted entries for the first-order launches
                    'two_hop_duplicates': round(layout.two_hop_duplicate_share, 4), 'two_hop_merged': bool(ihg_ops.two_hop_merged_for(layout)),

@@ -176,8 +176,11 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
             timed_from = time.perf_counter()
         if getattr(model, '_recorded_step', None) is not None:
             optimizer.zero_grad(set_to_none=True)           # the last replay's gradients (in the recording's pool) must not be accumulated onto
+        cotangent = getattr(grad_sync, 'mode', None) == 'cotangent'
+        if cotangent and not fused:
+            raise RuntimeError('--grad_sync cotangent exchanges the fused batch tail\'s row gradients: it needs the HIP model and a plain BCEWithLogitsLoss (use bucketed / sharded)')
         if fused:
-            loss = model.bce_loss(users, queries, items, flags)
+            loss = model.bce_loss(users, queries, items, flags, cotangent_sync=grad_sync) if cotangent else model.bce_loss(users, queries, items, flags)
         else:
             loss = loss_function(model(users, queries, items), flags)
         loss_sum += loss.detach()

@@ -108,9 +108,14 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
     from .optim import Adam
     grad_sync = None
     if world > 1:
-        # one exchange step per training step: flat all-reduce | per-bucket all-reduces overlapped with the backward |
-        # reduce-scatter + Adam on this rank's shard + all-gather.  Built BEFORE the optimizer: the sharded exchange owns it.
-        grad_sync = ihg_dist.make_gradient_sync(model, args.grad_sync)
+        # one exchange step per training step: the batch rows' cotangents (no dense exchange: the default where the fused batch tail runs) | flat
+        # all-reduce | per-bucket all-reduces overlapped with the backward | reduce-scatter + Adam on this rank's shard + all-gather.  Built BEFORE the optimizer: the
+        # sharded exchange owns it.
+        mode = args.grad_sync
+        if mode in ('auto', '', None):
+            mode = ihg_dist.choose_gradient_sync(4 * sum(p.numel() for p in model.parameters()), world, model.supports_fused_loss(loss_function))
+            say(f'gradient exchange: {mode}')
+        grad_sync = ihg_dist.make_gradient_sync(model, mode)
         grad_sync.broadcast_parameters(0)
     if grad_sync is not None and grad_sync.owns_optimizer:
         optimizer = grad_sync.optimizer(Gs.learning_rate, Gs.weight_decay)

@@ -150,14 +150,24 @@ class RawGnn(nn.Module):
         query_feature = features[query_indices + ds.query_start_index_in_graph]
         return self.prediction_layer(user_feature, query_feature, item_feature, item_indices)
 
-    def bce_loss(self, user_indices: Tensor, query_indices: Tensor, item_indices: Tensor, labels: Tensor) -> Tensor:
+    def bce_loss(self, user_indices: Tensor, query_indices: Tensor, item_indices: Tensor, labels: Tensor, cotangent_sync=None) -> Tensor:
         """``nn.BCEWithLogitsLoss()(self(u, q, i), labels)`` with scoring, loss and their backward fused into the batch-tail
-        kernels (the training loops use it when the loss function is a plain ``BCEWithLogitsLoss``)."""
+        kernels (the training loops use it when the loss function is a plain ``BCEWithLogitsLoss``).
+
+        ``cotangent_sync`` (an ``ihgnn_amd.distributed.CotangentSync``; data parallel): this rank's loss on ITS batch, with a backward that yields the gradient of the
+        MEAN of all ranks' losses - the ranks exchange the batch rows' cotangents (not the dense gradients) and every rank runs the propagation backward on their
+        union; the layers are told the union of the ranks' batch rows (where the last layer's output is read / its cotangent is non-zero).  A COLLECTIVE: every
+        rank calls it, with batches of the same size."""
         from .. import ops
         ds, head = self.dataset, self.prediction_layer
         rows = ops.batch_node_rows(user_indices, query_indices, item_indices, ds.query_start_index_in_graph, ds.item_start_index_in_graph)
-        holder = ops.TailGradients() if torch.is_grad_enabled() else None
-        return ops.hem_bce_loss(self.propagate_layers(holder, rows, self.batch_rows_only_last_layer), rows, item_indices, labels,
+        if cotangent_sync is not None and torch.is_grad_enabled():
+            holder = ops.TailGradients(exchange=cotangent_sync.exchange, grad_scale=1.0 / cotangent_sync.world_size)
+            read_rows = cotangent_sync.gather_rows(rows)           # the union of the ranks' batch rows (users | queries | items), int64 with .as_int32
+        else:
+            holder = ops.TailGradients() if torch.is_grad_enabled() else None
+            read_rows = rows
+        return ops.hem_bce_loss(self.propagate_layers(holder, read_rows, self.batch_rows_only_last_layer), rows, item_indices, labels,
                                 head.items_bias, head.lambda_muq,
                                 ds.item_start_index_in_graph, holder)
 

@@ -97,6 +97,7 @@ SIGNATURES = {
                                          c_void_p, c_int64, c_int64, c_void_p]),
     'ihg_bce_with_logits': (ctypes.c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     'ihg_batch_scatter_workspace_bytes': (c_int64, [c_int64]),
+    'ihg_batch_scatter_max_rows': (c_int32, []),
     'ihg_batch_scatter_add': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int64,
                                              c_void_p, c_int64, c_int64, c_void_p]),
     'ihg_compose_first_order_fwd': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p]),

@@ -106,7 +106,9 @@ __global__ __launch_bounds__(kScatterThreads) void bce_with_logits_kernel(const 
 // otherwise it is the leader of that destination, walks rows[k..n) in order and adds every matching batch row, then writes the
 // destination row once.  O(n^2 / 64) wave-steps in total - microseconds for the few thousand rows of a training batch; replaces
 // index_put_(accumulate=True) (bounds checks, device radix sort, scatter kernel).
-constexpr int kScatterMax = 16384;
+constexpr int kScatterMax = 16384;                      // ids of one launch in 64 KiB of LDS: any single-GPU batch (3 x 1,100 rows) ...
+constexpr int kScatterMaxWide = 32768;                  // ... and the wide instance (128 of gfx950's 160 KiB, one workgroup per CU) for the UNION of the ranks' batches in the
+                                                        // data-parallel cotangent exchange (8 ranks x 3,300 rows = 26,400; ihgnn_amd/distributed.py: CotangentSync)
 
 // Destination addressing: column c of batch row k goes to dense[(c / block_width) * block_stride + row * ld_dense + c % block_width]
 // (block_width = width, block_stride = 0 is a plain matrix; block_width = d, block_stride = N*d lands layer l's columns in its own
@@ -114,7 +116,7 @@ constexpr int kScatterMax = 16384;
 // COMBINE: nothing is scattered; the sum over a destination's batch rows replaces the FIRST of them in rowgrad itself (a row
 // is read by the wave of its destination's first occurrence only, which is also its only writer) and leader[k] says whether
 // batch row k is such a first occurrence.  batch_rows_add_kernel then adds leader rows wherever they are needed.
-template <bool COMBINE>
+template <bool COMBINE, int CAP = kScatterMax>
 __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(float* __restrict__ rowgrad, int64_t ld_rowgrad, int width,
                                                                       const int64_t* __restrict__ rows, int n, float* __restrict__ dense,
                                                                       int64_t ld_dense, int block_width, int64_t block_stride,
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(float* __r
                                                                       int32_t* __restrict__ leader, int block_rows) {
     // block_rows: rows of different consecutive blocks of this many batch rows never share a destination (the user / query / item
     // thirds of a batch address disjoint node ranges), so a wave only scans its own block; n = one block is the general case
-    __shared__ int32_t key[kScatterMax];                    // every workgroup keeps the whole id list in LDS (<= 64 KiB)
+    __shared__ int32_t key[CAP];                            // every workgroup keeps the whole id list in LDS (<= 64 KiB; the wide instance 128 KiB)
     for (int k = threadIdx.x; k < n; k += kBlockThreads) key[k] = static_cast<int32_t>(rows[k]);
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -427,32 +429,44 @@ int ihg_bce_with_logits(const float* scores, const float* labels, int64_t n, flo
 
 
 int64_t ihg_batch_scatter_workspace_bytes(int64_t n_rows) {
-    return (n_rows < 0 || n_rows > kScatterMax) ? -1 : 0;
+    return (n_rows < 0 || n_rows > kScatterMaxWide) ? -1 : 0;
 }
+
+int32_t ihg_batch_scatter_max_rows(void) { return kScatterMaxWide; }
 
 int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows, float* dense,
                           int64_t ld_dense, int32_t block_width, int64_t block_stride, float* tail, int64_t tail_row_offset,
                           int64_t tail_rows, ihg_stream_t stream) {
-    if (n_rows < 0 || n_rows > kScatterMax) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: 0..%d rows supported, got %lld", kScatterMax, (long long)n_rows);
+    if (n_rows < 0 || n_rows > kScatterMaxWide) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: 0..%d rows supported, got %lld", kScatterMaxWide, (long long)n_rows);
     if (width <= 0 || ld_rowgrad < width || block_width <= 0 || ld_dense < block_width) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: bad width / stride");
     if (n_rows == 0) return IHG_OK;
     if (rowgrad == nullptr || rows == nullptr || dense == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: null pointer");
-    hipLaunchKernelGGL(batch_scatter_kernel<false>, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
-                       const_cast<float*>(rowgrad), ld_rowgrad, width, rows, static_cast<int>(n_rows), dense, ld_dense, block_width, block_stride, tail,
-                       tail_row_offset, tail_rows, static_cast<int32_t*>(nullptr), static_cast<int>(n_rows));
+    if (n_rows > kScatterMax)
+        hipLaunchKernelGGL((batch_scatter_kernel<false, kScatterMaxWide>), dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+                           const_cast<float*>(rowgrad), ld_rowgrad, width, rows, static_cast<int>(n_rows), dense, ld_dense, block_width, block_stride, tail,
+                           tail_row_offset, tail_rows, static_cast<int32_t*>(nullptr), static_cast<int>(n_rows));
+    else
+        hipLaunchKernelGGL((batch_scatter_kernel<false>), dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+                           const_cast<float*>(rowgrad), ld_rowgrad, width, rows, static_cast<int>(n_rows), dense, ld_dense, block_width, block_stride, tail,
+                           tail_row_offset, tail_rows, static_cast<int32_t*>(nullptr), static_cast<int>(n_rows));
     return check_launch("ihg_batch_scatter_add");
 }
 
 int ihg_batch_combine(float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows, int64_t disjoint_block_rows,
                       int32_t* leader, ihg_stream_t stream) {
-    if (n_rows < 0 || n_rows > kScatterMax) return fail(IHG_ERR_INVALID, "ihg_batch_combine: 0..%d rows supported, got %lld", kScatterMax, (long long)n_rows);
+    if (n_rows < 0 || n_rows > kScatterMaxWide) return fail(IHG_ERR_INVALID, "ihg_batch_combine: 0..%d rows supported, got %lld", kScatterMaxWide, (long long)n_rows);
     if (width <= 0 || ld_rowgrad < width) return fail(IHG_ERR_INVALID, "ihg_batch_combine: bad width / stride");
     if (n_rows == 0) return IHG_OK;
     if (rowgrad == nullptr || rows == nullptr || leader == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_combine: null pointer");
     if (disjoint_block_rows <= 0 || disjoint_block_rows > n_rows) disjoint_block_rows = n_rows;
-    hipLaunchKernelGGL(batch_scatter_kernel<true>, dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad,
-                       ld_rowgrad, width, rows, static_cast<int>(n_rows), static_cast<float*>(nullptr), int64_t{0}, 1, int64_t{0},
-                       static_cast<float*>(nullptr), int64_t{0}, int64_t{0}, leader, static_cast<int>(disjoint_block_rows));
+    if (n_rows > kScatterMax)
+        hipLaunchKernelGGL((batch_scatter_kernel<true, kScatterMaxWide>), dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad,
+                           ld_rowgrad, width, rows, static_cast<int>(n_rows), static_cast<float*>(nullptr), int64_t{0}, 1, int64_t{0},
+                           static_cast<float*>(nullptr), int64_t{0}, int64_t{0}, leader, static_cast<int>(disjoint_block_rows));
+    else
+        hipLaunchKernelGGL((batch_scatter_kernel<true>), dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad,
+                           ld_rowgrad, width, rows, static_cast<int>(n_rows), static_cast<float*>(nullptr), int64_t{0}, 1, int64_t{0},
+                           static_cast<float*>(nullptr), int64_t{0}, int64_t{0}, leader, static_cast<int>(disjoint_block_rows));
     return check_launch("ihg_batch_combine");
 }
 

@@ -390,6 +390,123 @@ class ShardedGradientSync(GradientSync):
             dist.broadcast(self.flat_params, src=src, group=self.group)
 
 
+class CotangentSync:
+    """Data parallelism WITHOUT a dense gradient exchange: the ranks exchange the cotangents of the batch rows.
+
+    Every rank's full-graph propagation ``F(theta) [N, D]`` is the same function of the same parameters (that is what the replicas are), the batch tail of rank r reads
+    ``F`` at its 3B batch rows only (``Models/RawGnn.py:128-131`` of the reference), and the propagation's backward is LINEAR in the cotangent ``dL/dF``.  The averaged
+    gradient of all parameters is therefore ``J^T (1/W sum_r dL_r/dF)`` plus the sparse ``items_bias`` gradient: each rank computes its ``[3B, D + 1]`` row gradients
+    (scaled by 1 / W), ONE all-gather brings everybody's (``3B (D + 1) 4`` bytes per rank: 6.8 MB at config C3, 10 MB at C5 - the dense gradients are 194.6 MB and
+    9.42 GB), duplicates are summed in a fixed order by the combine kernel, and every rank runs the same propagation backward on the union.  No all-reduce; Adam is
+    the plain local one; the replicas stay identical because the kernels are bitwise deterministic and every rank sees the gathered rows in rank order
+    (``check_replicas()`` verifies it when asked to).
+
+    Cost against the dense exchange: the last layer's masked pull and the taps see ``3 B W`` rows instead of ``3 B``.  Use: ``model.bce_loss(u, q, i, y,
+    cotangent_sync=sync)``, ``loss.backward()``, ``optimizer.step()``, ``sync.zero_grad()``; ``average_gradients()`` has nothing left to do.  Every rank calls
+    ``bce_loss`` once per step (its two all-gathers are collectives); batches of different length are padded inside (``gather_rows``)."""
+
+    owns_optimizer = False
+    mode = 'cotangent'
+
+    def __init__(self, parameters: Iterable[torch.nn.Parameter], group=None):
+        self.params: List[torch.nn.Parameter] = [p for p in parameters if p.requires_grad]
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.distributed = dist.is_initialized() and (self.world_size > 1 or force_collectives())
+        self.flat = None
+        self.exchanged_bytes = 0                              # bytes this rank RECEIVED in the last step's exchanges (rows + row gradients of the other ranks)
+        self.sent_bytes = 0
+        self.equal_batches = False                            # True: the caller promises every rank's batch has the same size (no size exchange per step)
+        self.time_exchanges = False                           # True: HIP events around every all-gather on the step's stream land in exchange_events (bench.py)
+        self.exchange_events = []
+
+    # -- the two collectives of a step ----------------------------------------------------------
+    def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """``[W, *t.shape]``: every rank's ``t`` in rank order."""
+        t = t.contiguous()
+        if not self.distributed:
+            return t.unsqueeze(0)
+        out = torch.empty((self.world_size,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        timed = self.time_exchanges and t.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        dist.all_gather_into_tensor(out.view(-1), t.view(-1), group=self.group)      # (flat on both sides: gloo accepts nothing else)
+        if timed:
+            e1.record()
+            self.exchange_events.append((e0, e1))
+        self.exchanged_bytes += (self.world_size - 1) * t.numel() * t.element_size()
+        self.sent_bytes += t.numel() * t.element_size()
+        return out
+
+    def gather_rows(self, rows: torch.Tensor) -> torch.Tensor:
+        """The union of the ranks' batch node rows, ``[3 B W]`` int64 laid out as ``users of rank 0 .. W-1 | queries ... | items ...`` (the thirds address disjoint node
+        ranges: what the combine kernel's duplicate search relies on), with ``.as_int32`` beside it.  Called before the forward: the last layer computes / is
+        differentiated at these rows.  Ranks whose batches are shorter than the longest (the sharded sampler's differ by a row; ``equal_batches = True`` promises they
+        never do and saves the size exchange, a host round trip) repeat their last row here and contribute exact zeros for it in ``exchange``."""
+        self.exchanged_bytes = self.sent_bytes = 0
+        n = int(rows.shape[0])
+        if n % 3 or n == 0:
+            raise ValueError('batch node rows come as users | queries | items, at least one of each')
+        b = n // 3
+        longest = b
+        if self.distributed and not self.equal_batches:
+            t = torch.tensor([b], dtype=torch.int64, device=rows.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            longest = int(t.item())
+        thirds = rows.view(3, b)
+        if longest > b:
+            thirds = torch.cat([thirds, thirds[:, -1:].expand(3, longest - b)], 1)
+        self._local_rows, self._padded_rows = b, longest
+        everyone = self._all_gather(thirds)                                  # [W, 3, B]
+        union = everyone.permute(1, 0, 2).reshape(-1).contiguous()
+        union.as_int32 = union.to(torch.int32)
+        self._union_rows = union
+        return union
+
+    def exchange(self, rows: torch.Tensor, rowgrad: torch.Tensor):
+        """``(rows, rowgrad)`` of this rank's batch tail -> the union's, in ``gather_rows``' order (called by the batch tail's backward, ``ops._HemBceLoss``)."""
+        n, width = int(rowgrad.shape[0]), int(rowgrad.shape[1])
+        union_rows = getattr(self, '_union_rows', None)
+        if union_rows is None or n != 3 * self._local_rows:
+            raise RuntimeError('CotangentSync.exchange: gather_rows() was not called for this batch (use model.bce_loss(..., cotangent_sync=sync))')
+        mine = rowgrad.view(3, self._local_rows, width)
+        if self._padded_rows > self._local_rows:
+            mine = torch.cat([mine, mine.new_zeros(3, self._padded_rows - self._local_rows, width)], 1)
+        everyone = self._all_gather(mine)                                    # [W, 3, B, C]
+        union = everyone.permute(1, 0, 2, 3).reshape(-1, width).contiguous()
+        self._union_rows = None
+        return union_rows, union
+
+    # -- the GradientSync surface the training loops use ------------------------------------------
+    def average_gradients(self) -> None:
+        """Nothing to do: the backward already produced the gradient of the mean of the ranks' losses, identically on every rank."""
+
+    def zero_grad(self) -> None:
+        for p in self.params:
+            p.grad = None
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        if self.distributed:
+            for p in self.params:
+                dist.broadcast(p.data, src=src, group=self.group)
+
+    def check_replicas(self) -> float:
+        """Largest absolute difference of any parameter element between this rank and rank 0 (a collective; 0.0 is the contract: the replicas take bitwise
+        identical steps).  For tests and an occasional assertion in long runs - not part of a step."""
+        worst = 0.0
+        if not self.distributed:
+            return worst
+        for p in self.params:
+            ref = p.data.clone()
+            dist.broadcast(ref, src=0, group=self.group)
+            worst = max(worst, float((ref - p.data).abs().max()))
+        t = torch.tensor([worst], dtype=torch.float64, device=self.params[0].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+
 def checkpoint_state(epoch: int, model: torch.nn.Module, optimizer) -> dict:
     """The dict a training checkpoint holds (written at ``Main.py:255-259`` of the reference, read at ``Main.py:208-212``: epoch, model, optimizer).  Call it on EVERY rank: a sharded
     optimizer's ``state_dict()`` gathers the ranks' Adam shards with a collective, and a chief-only call would deadlock.  Every rank gets the
@@ -398,14 +515,26 @@ def checkpoint_state(epoch: int, model: torch.nn.Module, optimizer) -> dict:
 
 
 def make_gradient_sync(model: torch.nn.Module, mode: str = 'bucketed', group=None) -> GradientSync:
-    """``flat`` | ``bucketed`` | ``sharded`` gradient exchange for a model (see the three classes above)."""
+    """``flat`` | ``bucketed`` | ``sharded`` dense-gradient exchange, or ``cotangent`` (batch-row cotangents instead of gradients), for a model (see the classes above)."""
     if mode == 'flat':
         return GradientSync(model.parameters(), group)
     if mode == 'bucketed':
         return BucketedGradientSync(model.named_parameters(), group)
     if mode == 'sharded':
         return ShardedGradientSync(model.parameters(), group)
+    if mode == 'cotangent':
+        return CotangentSync(model.parameters(), group)
     raise ValueError(f'unknown gradient sync mode {mode!r}')
+
+
+def choose_gradient_sync(gradient_bytes: int, world_size: int, fused_loss: bool = True) -> str:
+    """The exchange a run takes when it is not told one: ``cotangent`` where the model trains through the fused batch tail (IHGNN / HGCN layers + HEM + BCE: every
+    configuration of BASELINE.json) - its 3 B (D + 1) floats per rank are 30 - 900 times fewer bytes than the dense gradient; otherwise ``bucketed`` while the flat
+    gradient fits comfortably beside the model (it overlaps the dense bucket with the backward) and ``sharded`` beyond 2 GiB (config C5: 9.4 GB of gradients, 2 x 9.4 GB of
+    Adam state per replica -> 1 / W of it)."""
+    if fused_loss:
+        return 'cotangent'
+    return 'sharded' if gradient_bytes > (2 << 30) else 'bucketed'
 
 
 class ShardedBatchSampler:

@@ -1093,7 +1093,7 @@ def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: f
     return rowgrad
 
 
-SCATTER_CHUNK_ROWS = 16384          # rows one ihg_batch_scatter_add launch combines (its id list lives in LDS)
+SCATTER_CHUNK_ROWS = 32768          # rows one ihg_batch_scatter_add / ihg_batch_combine launch takes (= ihg_batch_scatter_max_rows(): its id list lives in LDS; tests/test_abi.py)
 
 
 def _scatter_rows(rowgrad: Tensor, col0: int, width: int, rows: Tensor, dense: Optional[Tensor], tail: Optional[Tensor] = None, tail_offset: int = 0):
@@ -1141,10 +1141,14 @@ class TailGradients:
     backward leaves its ``[3B, .]`` row gradients here and every ``tap`` adds its own columns into the gradient that came
     down from the next layer, in place."""
 
-    def __init__(self):
+    def __init__(self, exchange=None, grad_scale: float = 1.0):
         self.rows: Optional[Tensor] = None
         self.rowgrad: Optional[Tensor] = None      # [3B, .], rows of equal destination already summed into their first occurrence
         self.leader: Optional[Tensor] = None       # int32 [3B]: 1 on those first occurrences (None: rowgrad is not combined)
+        # data parallel, cotangent exchange (ihgnn_amd.distributed.CotangentSync): ``exchange(rows, rowgrad) -> (rows, rowgrad)`` of ALL ranks' batches, called by the
+        # batch tail's backward between its row-gradient kernel and the combine; ``grad_scale`` = 1 / world size (the average over ranks) applied by that kernel
+        self.exchange = exchange
+        self.grad_scale = float(grad_scale)
 
     def put_into_typed(self, dense_rows, ld_dense: int, layout, col0: int, width: int) -> None:
         """``add_into`` for a destination whose node types start at their own addresses (``dense_rows``: host array of three device pointers)."""
@@ -1175,7 +1179,7 @@ class TailGradients:
 def _put_rows(holder: 'TailGradients', dense_rows, ld_dense: int, layout, col0: int, width: int, assign: bool) -> None:
     lib = _lib.load()
     if holder.leader is None:
-        raise _lib.IhgnnHipError('typed / assigning row scatter needs the combined row gradients (batches of at most 16,384 rows)')
+        raise _lib.IhgnnHipError('typed / assigning row scatter needs the combined row gradients (batches of at most 32,768 rows)')
     n = int(holder.rows.shape[0])
     src = holder.rowgrad[:, col0:]
     with profiler.kernel('batch_rows_add', n, width):
@@ -1301,7 +1305,12 @@ class _HemBceLoss(torch.autograd.Function):
             dbias, grads = _hem_backward(layers, rows, items, bias, ctx.lam, dscores * grad_loss, 1.0, ctx.offset)
             return (None, None, None, dbias, None, None, None, None) + grads
         holder = ctx.holder
-        rowgrad = _hem_row_gradients(layers, rows, items, bias, ctx.lam, dscores, 1.0, tables, grad_loss.contiguous())     # d loss stays on the device: no host read, no multiply launch
+        rowgrad = _hem_row_gradients(layers, rows, items, bias, ctx.lam, dscores, holder.grad_scale, tables, grad_loss.contiguous())     # d loss stays on the device: no host read, no multiply launch
+        if holder.exchange is not None:
+            # every rank's propagation is the same function of the same parameters and its backward is linear in the cotangent of the layer outputs, which is non-zero on
+            # the batch rows only: the ranks exchange THOSE rows (3B x (D + 1) floats each) and every rank runs the one propagation backward on the union - the averaged
+            # gradient of all parameters without a dense all-reduce (RawGnn.py:122-142: the batch reads F at 3B rows)
+            rows, rowgrad = holder.exchange(rows, rowgrad)
         holder.rows, holder.rowgrad, holder.leader = rows, rowgrad, None
         lib = _lib.load()
         n_layers = len(layers) + (1 if tables is not None else 0)

@@ -401,7 +401,9 @@ int ihg_hem_score_bwd(const float* const* layers, int32_t n_layers, int64_t ld, 
                       const int64_t* rows, const float* dscores, float grad_scale, float lambda_muq,
                       float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream);
 int ihg_bce_with_logits(const float* scores, const float* labels, int64_t n, float* loss, float* dscores, ihg_stream_t stream);
-int64_t ihg_batch_scatter_workspace_bytes(int64_t n_rows);      /* 0, or -1 if n_rows > 16384 (caller keeps its own scatter) */
+int64_t ihg_batch_scatter_workspace_bytes(int64_t n_rows);      /* 0, or -1 if n_rows > ihg_batch_scatter_max_rows() (caller scatters in row chunks) */
+int32_t ihg_batch_scatter_max_rows(void);                        /* 32768: rows of one ihg_batch_scatter_add / ihg_batch_combine launch (its id list lives in LDS: <= 16384 rows in 64 KiB,
+                                                                    beyond that - the union of the ranks' batches under the cotangent exchange - a 128 KiB instance) */
 int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t width, const int64_t* rows, int64_t n_rows,
                           float* dense, int64_t ld_dense, int32_t block_width, int64_t block_stride,
                           float* tail, int64_t tail_row_offset, int64_t tail_rows, ihg_stream_t stream);

@@ -128,6 +128,93 @@ def test_two_rank_training_equals_single_rank_on_union_batch(tmp_path, mode):
         np.testing.assert_allclose(r0[k].numpy(), v.numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
 
 
+def _cotangent_worker(rank, world, port, out_dir, unequal):
+    """The cotangent exchange with the CPU oracle under it: the fused batch tail's row gradients are emulated with torch (per-row cotangents of the propagation's output +
+    the items-bias column), ``CotangentSync`` gathers rows and row gradients, the one propagation backward runs on the union."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    ihg_dist.init_from_env('gloo')
+    torch.set_num_threads(1)
+    model = _make_model(seed=100 + rank)
+    sync = ihg_dist.make_gradient_sync(model, 'cotangent')
+    assert sync.mode == 'cotangent' and not sync.owns_optimizer and sync.world_size == world
+    sync.broadcast_parameters(0)
+    u, q, i, y = _batch()
+    cut = 35 if unequal else 32                              # rank 0: rows [0, cut), rank 1: [cut, 64)
+    sl = slice(0, cut) if rank == 0 else slice(cut, 64)
+    g = model.g
+    opt = torch.optim.Adam(model.parameters(), 1e-2)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    bias = model.P('prediction_layer.items_bias')
+    for step in range(2):
+        rows = torch.cat([u[sl], q[sl] + g.user_count, i[sl] + g.user_count + g.query_count])
+        union_rows = sync.gather_rows(rows)
+        b = rows.shape[0] // 3
+        feats = model.propagate()
+        picked = feats.detach()[rows].requires_grad_(True)
+        item_bias = bias.detach()[i[sl]].requires_grad_(True)
+        from oracle import ihgnn_ref as ref
+        loss = lossf(ref.hem_score(picked[:b], picked[b:2 * b], picked[2 * b:], item_bias, model.lam), y[sl])
+        loss.backward()
+        rowgrad = torch.zeros(3 * b, feats.shape[1] + 4)
+        rowgrad[:, :feats.shape[1]] = picked.grad / world
+        rowgrad[2 * b:, feats.shape[1]] = item_bias.grad / world
+        got_rows, union = sync.exchange(rows, rowgrad)
+        assert got_rows is union_rows and union.shape[0] == union_rows.shape[0] == 3 * world * max(cut, 64 - cut)
+        assert sync.sent_bytes == (3 * max(cut, 64 - cut)) * (8 + 4 * rowgrad.shape[1]) and sync.exchanged_bytes == (world - 1) * sync.sent_bytes
+        third = union_rows.shape[0] // 3
+        assert int(union_rows[:third].max()) < g.user_count <= int(union_rows[third:2 * third].min()) and int(union_rows[2 * third:].min()) >= g.user_count + g.query_count
+        cot = torch.zeros_like(feats).index_add_(0, union_rows, union[:, :feats.shape[1]])
+        feats.backward(cot)
+        bias.grad = torch.zeros_like(bias).index_add_(0, union_rows[2 * third:] - g.user_count - g.query_count, union[2 * third:, feats.shape[1]])
+        sync.average_gradients()                             # (nothing left to do)
+        opt.step()
+        sync.zero_grad()
+        assert all(p.grad is None for p in model.parameters())
+    assert sync.check_replicas() == 0.0                      # bitwise identical replicas without any parameter / gradient exchange
+    torch.save({k: v.clone() for k, v in model.reference_state().items()}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('unequal', [False, True])
+def test_two_rank_cotangent_exchange_equals_single_rank_on_union_batch(tmp_path, unequal):
+    """``--grad_sync cotangent``: the ranks all-gather the batch rows' cotangents (3B (D + 1) floats each) instead of all-reducing the dense gradients, and each runs the
+    propagation backward on the union: replicas stay bitwise identical and equal the 1-rank run on the mean of the ranks' losses (``Models/RawGnn.py:122-142``: the batch
+    reads F at 3B rows; ``Helpers/TrainTestHelper.py:126-143``: the loss is a mean over the batch).  ``unequal``: batches of 35 and 29 rows - the shorter is padded with
+    zero-cotangent rows inside the exchange."""
+    port = _free_port()
+    mp.spawn(_cotangent_worker, args=(2, port, str(tmp_path), unequal), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f'rank{k}.pt') for k in (0, 1))
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), f'replicas diverged on {k}'
+    model = _make_model(seed=100)
+    u, q, i, y = _batch()
+    cut = 35 if unequal else 32
+    opt = torch.optim.Adam(model.parameters(), 1e-2)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    for _ in range(2):
+        (0.5 * (lossf(model(u[:cut], q[:cut], i[:cut]), y[:cut]) + lossf(model(u[cut:], q[cut:], i[cut:]), y[cut:]))).backward()
+        opt.step(); opt.zero_grad()
+    for k, v in model.reference_state().items():
+        np.testing.assert_allclose(r0[k].numpy(), v.numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+def test_cotangent_sync_single_process_is_transparent():
+    """One rank, no process group: the exchange hands back what it was given (rows re-laid as thirds = unchanged), nothing is sent."""
+    lin = torch.nn.Linear(4, 3)
+    sync = ihg_dist.CotangentSync(lin.parameters())
+    rows = torch.tensor([0, 1, 5, 6, 9, 9])
+    union = sync.gather_rows(rows)
+    assert torch.equal(union, rows) and union.as_int32.dtype == torch.int32
+    rg = torch.randn(6, 7)
+    got_rows, got = sync.exchange(rows, rg)
+    assert got_rows is union and torch.equal(got, rg) and sync.exchanged_bytes == 0
+    with pytest.raises(RuntimeError, match='gather_rows'):
+        sync.exchange(rows, rg)
+    assert ihg_dist.choose_gradient_sync(10 << 30, 8, True) == 'cotangent' and ihg_dist.choose_gradient_sync(10 << 30, 8, False) == 'sharded'
+    assert ihg_dist.choose_gradient_sync(200 << 20, 8, False) == 'bucketed'
+
+
 def test_shard_range_partitions_exactly():
     for n in (0, 1, 7, 64, 1001):
         for world in (1, 2, 3, 8):

@@ -405,7 +405,7 @@ def test_layout_with_hyperedge_multiplicities_interactive_layer(order, dim, monk
         assert row_rel(got[1], want_grads[0]) <= ROW_RTOL
         got_plain, _ = run(plain)
         for a, c in zip(got, got_plain):
-            assert rel(a, c) <= RTOL
+            assert rel(a, c) <= 2 * RTOL                     # (two results that each hold RTOL against float64)
         if dim % 32 == 0:
             assert 'interact_bwd' in ran and 'edge_gather_sum' in ran      # K5 x m_e, then the member-gradient kernel: no gathering form under multiplicities
     monkeypatch.setattr(ops, 'NODE_LEVEL_FORWARD', True)
@@ -2257,10 +2257,10 @@ def test_general_hypergraph_kernels_at_scale():
 
 
 def test_scatter_rows_beyond_one_launch_goes_in_row_chunks():
-    """Batches larger than one ihg_batch_scatter_add launch takes (16,384 rows): ops._scatter_rows feeds it row chunks, in order."""
+    """Batches larger than one ihg_batch_scatter_add launch takes (32,768 rows): ops._scatter_rows feeds it row chunks, in order."""
     from ihgnn_amd import ops
     gen = torch.Generator().manual_seed(4)
-    n, width = 40000, 17
+    n, width = 70000, 17
     rows = torch.randint(0, 9000, (n,), generator=gen).to(dev())
     rowgrad = torch.randn(n, width + 3, generator=gen).to(dev())
     want = torch.zeros(9000, width, device=dev()).index_put_((rows,), rowgrad[:, 2:2 + width], accumulate=True)
@@ -2270,7 +2270,7 @@ def test_scatter_rows_beyond_one_launch_goes_in_row_chunks():
     assert rel(got[0], want) <= RTOL_SUM * 2 and torch.equal(got[0], got[1])
 
 
-@pytest.mark.parametrize('n,width', [(1, 5), (77, 33), (3300, 193), (8192, 64), (16384, 300)])
+@pytest.mark.parametrize('n,width', [(1, 5), (77, 33), (3300, 193), (8192, 64), (16384, 300), (26400, 129), (32768, 9)])
 def test_batch_scatter_add_matches_index_put(n, width):
     """Deterministic sort-free scatter: equals index_put_(accumulate=True), bitwise repeatable with duplicates; plain-matrix
     and per-layer-block + tail-column destination forms."""
@@ -2289,7 +2289,7 @@ def test_batch_scatter_add_matches_index_put(n, width):
                                              width, 0, None, 0, 0, ops._stream()), 'scatter')
         outs.append(dense)
     assert rel(outs[0], want) <= RTOL_SUM and torch.equal(outs[0], outs[1]) and (outs[0][:, width:] == 0).all()
-    assert lib.ihg_batch_scatter_workspace_bytes(16385) == -1
+    assert lib.ihg_batch_scatter_workspace_bytes(16385) == 0 and lib.ihg_batch_scatter_workspace_bytes(32769) == -1 and lib.ihg_batch_scatter_max_rows() == ops.SCATTER_CHUNK_ROWS
     if (width - 1) % 4 == 0:                                 # blocked form: 4 column blocks + a tail column for rows >= 100
         bw = (width - 1) // 4
         blocks = torch.zeros(4, n_dense, bw, device=dev())
@@ -2301,7 +2301,7 @@ def test_batch_scatter_add_matches_index_put(n, width):
         assert rel(tail, want[100:, width - 1]) <= RTOL_SUM
 
 
-@pytest.mark.parametrize('n,width', [(1, 5), (700, 65), (3300, 193), (16384, 33)])
+@pytest.mark.parametrize('n,width', [(1, 5), (700, 65), (3300, 193), (16384, 33), (26400, 517), (32768, 5)])      # (26,400 x 517: the union of eight ranks' batches at C3's width)
 def test_batch_combine_then_rows_add(n, width):
     """Two-stage form of the scatter: duplicates are summed into their first occurrence in place, then leader rows are added
     into (several) non-zero destinations; equals index_put_(accumulate=True) on top of the old contents, bitwise repeatable."""
@@ -2635,7 +2635,7 @@ def _run(cmd, timeout=600):
     return subprocess.run([sys.executable] + cmd, cwd=repo, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize('sync', ['flat', 'bucketed', 'sharded'])
+@pytest.mark.parametrize('sync', ['flat', 'bucketed', 'sharded', 'cotangent'])
 def test_two_ranks_of_the_hip_model_equal_one_rank_on_the_union_batch(sync):
     """Two processes on GPU 0 (gloo moves the buffers; RCCL refuses two ranks per GPU), each a full replica on its half of a
     global batch, gradient exchange `sync`: parameters after two steps equal the 1-rank run on the whole batch."""
@@ -2644,7 +2644,7 @@ def test_two_ranks_of_the_hip_model_equal_one_rank_on_the_union_batch(sync):
     assert 'OK' in r.stdout
 
 
-@pytest.mark.parametrize('sync', ['flat', 'bucketed', 'sharded'])
+@pytest.mark.parametrize('sync', ['flat', 'bucketed', 'sharded', 'cotangent'])
 def test_one_rank_rccl_group_drives_every_exchange(sync):
     """RCCL itself (backend ``nccl``) on the one GPU there is: a ONE-rank process group with the collectives forced on, so the code a multi-GPU
     run executes - ``ReduceOp.AVG`` all-reduce, bucket all-reduces launched with ``async_op=True`` from ``post_accumulate_grad`` hooks and
@@ -2654,14 +2654,28 @@ def test_one_rank_rccl_group_drives_every_exchange(sync):
     assert r.returncode == 0 and 'OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` without torchrun: the parent starts two rank processes and rank 0 prints the JSON line."""
+@pytest.mark.parametrize('sync', ['auto', 'cotangent', 'flat', 'bucketed', 'sharded'])
+def test_bench_launches_its_own_ranks(sync):
+    """`python bench.py --gpus 2` without torchrun, every gradient exchange: the parent starts two rank processes and rank 0 prints the JSON line, whose
+    `gradient_exchange` object names the mode that ran (`auto` resolves to the cotangent exchange for a model on the fused batch tail), the rank count, the bytes a rank
+    hands over and receives per step, and every rank's own step time and exposed exchange time."""
     import json
-    r = _run(['bench.py', '--gpus', '2', '--device', '0', '--backend', 'gloo', '--config', 'C1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'])
+    r = _run(['bench.py', '--gpus', '2', '--device', '0', '--backend', 'gloo', '--config', 'C1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-extras', '--sync', sync])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['parallelism'] == 'dp2' and line['value'] > 0
     assert 0 < line['roofline']['frac'] <= 1
+    ex = line['gradient_exchange']
+    assert ex['requested'] == sync and ex['mode'] == ('cotangent' if sync == 'auto' else sync) and ex['ranks'] == 2 and ex['backend'] == 'gloo'
+    assert [p['rank'] for p in ex['per_rank']] == [0, 1] and all(p['ms_per_step'] > 0 and p['exposed_exchange_ms_per_step'] >= 0 for p in ex['per_rank'])
+    n_params = (1001 + 1001 + 301) * 64 + 1000 + 64 * 64 + 64 + 64 * 7 * 64 + 64          # C1: three tables, items_bias, one IHGNN layer of order 3
+    assert ex['gradient_bytes_per_rank'] == 4 * n_params
+    if ex['mode'] == 'cotangent':
+        # 3 x 1,100 batch rows: their int64 node ids before the forward, their [D + 4] float cotangents in the backward (D = 2 x 64); the other rank's come back
+        assert ex['bytes_sent_per_rank'] == 3300 * (8 + 4 * (128 + 4)) == ex['bytes_received_per_rank'] and ex['bytes_sent_per_rank'] < ex['gradient_bytes_per_rank'] / 10
+        assert '(cotangent)' in line['config']['step']
+    else:
+        assert ex['bytes_sent_per_rank'] >= ex['gradient_bytes_per_rank'] and ex['bytes_received_per_rank'] >= ex['gradient_bytes_per_rank'] * 0.99
 
 
 def test_device_negative_sampling_has_random_sample_semantics():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """N ranks of the HIP model == 1 rank on the union batch, runnable on ONE GPU.
 
-    python tools/two_rank_check.py [--ranks 2] [--sync flat|bucketed|sharded] [--device 0] [--backend gloo]
+    python tools/two_rank_check.py [--ranks 2] [--sync flat|bucketed|sharded|cotangent] [--device 0] [--backend gloo]
 
 The parent starts the rank processes before touching the GPU (as bench.py does).  Every rank builds the same RawGnn replica on
 GPU `--device` (RCCL refuses two ranks on one GPU, so the single-GPU form uses gloo; on a multi-GPU node pass `--backend nccl
@@ -71,8 +71,11 @@ def main():
     rows = ihg_dist.shard_range(B, rank, world)
     sl = slice(rows.start, rows.stop)
     assert world > 1 or sync.distributed, 'a one-rank run must be forced through the collectives (IHG_FORCE_COLLECTIVES=1)'
+    cotangent = getattr(sync, 'mode', None) == 'cotangent'  # the ranks exchange the batch rows' cotangents inside the backward; no dense gradient exchange
     for step in range(2):
-        model.bce_loss(u[sl], q[sl], i[sl], y[sl]).backward()
+        (model.bce_loss(u[sl], q[sl], i[sl], y[sl], cotangent_sync=sync) if cotangent else model.bce_loss(u[sl], q[sl], i[sl], y[sl])).backward()
+        if cotangent:
+            assert sync.sent_bytes == 3 * (rows.stop - rows.start) * (8 + 4 * (args.dim * 3 + 4)), sync.sent_bytes
         sync.average_gradients()
         opt.step()
         sync.zero_grad()
@@ -82,6 +85,11 @@ def main():
             opt.load_state_dict(state)
     torch.cuda.synchronize()
     ok = True
+    if cotangent:
+        drift = sync.check_replicas()                        # nothing but row cotangents crossed between the ranks: the replicas must be bitwise identical
+        if drift != 0.0:
+            ok = False
+            print(f'REPLICAS DIVERGED under the cotangent exchange: {drift:.3e}', flush=True)
     if rank == 0:
         alone = replica()
         opt1 = Adam(alone.parameters(), 1e-3)
