@@ -319,7 +319,8 @@ def main():
     sync_mode = args.sync
     if world > 1 or ihg_dist.force_collectives():            # (IHG_FORCE_COLLECTIVES=1: a one-rank process group that really issues the collectives)
         if sync_mode == 'auto':                              # by the gradient bytes and the loss path: cotangent for every BASELINE config (fused batch tail); C5's 9.4 GB
-            sync_mode = ihg_dist.choose_gradient_sync(4 * sum(p.numel() for p in model.parameters()), world, model.supports_fused_loss(lossf))      # of gradients otherwise: sharded
+            sync_mode = ihg_dist.choose_gradient_sync(4 * sum(p.numel() for p in model.parameters()), world, model.supports_fused_loss(lossf),
+                                                      ihg_dist.cotangent_bytes_per_rank(1100, model.compute_width * (layers + 1)))      # of gradients otherwise: sharded
         sync = ihg_dist.make_gradient_sync(model, sync_mode)
         sync.broadcast_parameters(0)
         if sync_mode == 'cotangent':

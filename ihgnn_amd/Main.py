@@ -113,7 +113,9 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
         # sharded exchange owns it.
         mode = args.grad_sync
         if mode in ('auto', '', None):
-            mode = ihg_dist.choose_gradient_sync(4 * sum(p.numel() for p in model.parameters()), world, model.supports_fused_loss(loss_function))
+            batch_rows = Gs.batch_size * (1 + Gs.random_negative_sample_size + Gs.non_random_negative_sample_size)
+            mode = ihg_dist.choose_gradient_sync(4 * sum(p.numel() for p in model.parameters()), world, model.supports_fused_loss(loss_function),
+                                                 ihg_dist.cotangent_bytes_per_rank(batch_rows, model.compute_width * (layer_count + 1)))
             say(f'gradient exchange: {mode}')
         grad_sync = ihg_dist.make_gradient_sync(model, mode)
         grad_sync.broadcast_parameters(0)

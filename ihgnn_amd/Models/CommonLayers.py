@@ -30,8 +30,14 @@ class FeatureInteractor(nn.Module):
 
     def first_order(self, node_features: Tensor) -> Tensor:
         """Node-level image of the u / q / i blocks (+ bias, carried by the user rows: one user per hyperedge)."""
-        w, b = self.aggregation.weight, self.aggregation.bias
+        w, b = self._operands(node_features)
         return ops.node_linear(node_features, w, b, self.dataset.hypergraph.layout, typed=True, bias_mask=0b001)      # any width; no torch path
+
+    def _operands(self, node_features: Tensor):
+        """``(aggregation.weight, aggregation.bias)`` at the width of ``node_features``: themselves, or - features zero-padded to the next tiled width, ``ops.padded_width`` -
+        every ``[d, d]`` block in the top-left of a zero block of that width."""
+        wide = int(node_features.shape[1])
+        return ops.pad_blocks(self.aggregation.weight, wide), ops.pad_vector(self.aggregation.bias, wide)
 
     def to_nodes(self, node_features: Tensor, out_scale: Optional[Tensor] = None, rows: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
         """``out_scale * H forward(node_features)``: the hyperedge features taken on to the nodes (``GnnLayers.py:229-236``).  Orders 2 / 3
@@ -39,14 +45,16 @@ class FeatureInteractor(nn.Module):
         can and adds the first-order path's input gradient onto the member gradients inside the node-level kernel."""
         layout = self.dataset.hypergraph.layout
         if self.max_order > 1:
-            return ops.interact_layer(node_features, self.aggregation.weight, self.aggregation.bias, layout, self.max_order, out_scale, rows, out)
+            w, b = self._operands(node_features)
+            return ops.interact_layer(node_features, w, b, layout, self.max_order, out_scale, rows, out)
         return ops.node_segment_sum(self(node_features), layout, out_scale=out_scale, rows=rows, out=out)
 
     def forward(self, node_features: Tensor) -> Tensor:
         layout = self.dataset.hypergraph.layout
-        if self.max_order > 1 and ops.interact_from_nodes_supported(node_features, self.aggregation.weight):
-            return ops.interact_from_nodes(node_features, self.aggregation.weight, self.aggregation.bias, layout, self.max_order)
+        w, b = self._operands(node_features)
+        if self.max_order > 1 and ops.interact_from_nodes_supported(node_features, w):
+            return ops.interact_from_nodes(node_features, w, b, layout, self.max_order)
         hoisted = self.first_order(node_features)
         if self.max_order == 1:
             return ops.edge_gather_sum(hoisted, layout)
-        return ops.interact(node_features, hoisted, self.aggregation.weight, layout, self.max_order)
+        return ops.interact(node_features, hoisted, w, layout, self.max_order)

@@ -23,7 +23,15 @@ def _transform(linear: nn.Linear, x: Tensor, layout) -> Tensor:
     if linear.in_features != linear.out_features:
         raise NotImplementedError(f'feature_transform {linear.in_features} -> {linear.out_features}: the MI355X path has square node-level transforms only '
                                   '(RawGnn builds every layer with input_dimension == output_dimension)')
+    wide = _row_width(x)
+    if wide != linear.in_features:
+        # features zero-padded to the next tiled width (RawGnn at a width between 32 / 64 / 128 / 256, ops.padded_width): the weight as the top-left block of a zero matrix
+        return ops.node_linear(x, ops.pad_square(linear.weight, wide), ops.pad_vector(linear.bias, wide), layout)
     return ops.node_linear(x, linear.weight, linear.bias, layout)
+
+
+def _row_width(x) -> int:
+    return int(x.shape[1])
 
 
 class HGCNLayer(nn.Module):
@@ -107,7 +115,9 @@ class IHGNNLayer(nn.Module):
         lin, agg = self.feature_transform, self.feature_interactor.aggregation
         if lin.bias is None:
             return self.feature_interactor.first_order(_transform(lin, x, self.layout))
-        weight, bias = ops.compose_first_order(agg.weight, agg.bias, lin.weight, lin.bias)      # [d, 3 d]: A_t W side by side; [3, d]
+        wide = _row_width(x)                                 # (> in_features: zero-padded features, ops.padded_width)
+        weight, bias = ops.compose_first_order(ops.pad_blocks(agg.weight, wide), ops.pad_vector(agg.bias, wide), ops.pad_square(lin.weight, wide),
+                                               ops.pad_vector(lin.bias, wide))      # [d, 3 d]: A_t W side by side; [3, d]
         return ops.node_linear(x, weight, bias, self.layout, typed=True, bias_mask=0b111)
 
 

@@ -32,6 +32,13 @@ class RawGnn(nn.Module):
         self.phase2_attention = phase2_attention
         self.prediction_layer_type = predictions
         self.output_feature_size = embedding_size * (1 + gnn_layer_count)
+        # the width the kernels run at: the embedding size itself where it is one of the tiled widths (32 / 64 / 128 / 256), otherwise the next of them with zero columns
+        # appended to the features and zero rows / columns to the weights (ops.padded_width: 96 -> 128, 160 / 192 / 224 -> 256; the reference takes any --emb,
+        # Helpers/ArgsParser.py:94-95) - parameters and state-dict keep the embedding size
+        from .. import ops as _ops
+        self.compute_width = _ops.padded_width(embedding_size)
+        if self.compute_width * (1 + gnn_layer_count) > self.MAX_SCORED_WIDTH:
+            self.compute_width = embedding_size                  # (padding would push the scored row past the evaluation kernel's limit: the any-width kernels instead)
         if self.output_feature_size > self.MAX_SCORED_WIDTH:
             # refused HERE, not at the first evaluation after an epoch of training: the scoring kernel (ihg_score_topk) keeps the mixed rows of 32
             # (user, query) pairs in LDS for its whole run, which bounds the feature width d (L + 1)
@@ -75,11 +82,15 @@ class RawGnn(nn.Module):
         from .. import ops
         last = len(self.gnns)
         x = None
-        if tail_gradients is not None and last >= 1 and ops.NODE_TABLES and (batch_rows is None or int(batch_rows.shape[0]) <= ops.SCATTER_CHUNK_ROWS):
+        padded = self.compute_width != self.embedding_size
+        if (tail_gradients is not None and last >= 1 and ops.NODE_TABLES and not padded
+                and (batch_rows is None or int(batch_rows.shape[0]) <= ops.SCATTER_CHUNK_ROWS)):
             # a training step through the fused batch tail: X0 is not assembled - the first layer's transform and the tail read the embedding tables in place
             x = self.embeddings.node_tables(tail_gradients)
         if x is None:
             x = self.embeddings.all_nodes()
+            if padded:
+                x = ops.pad_columns(x, self.compute_width)   # zero columns up to the next tiled width; every layer keeps them zero (its weights are padded with zeros)
         outputs = []
         for depth in range(last + 1):
             sparse_top = None
@@ -113,12 +124,15 @@ class RawGnn(nn.Module):
         pass over ``[N, D]``.  Under autograd the outputs are separate tensors and are concatenated."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return torch.cat(self.propagate_layers(), 1)
-        d = self.embedding_size
+        d, cw = self.embedding_size, self.compute_width
         w = self.embeddings.embedding_bag_vocabulary.weight
-        features = torch.empty(self.dataset.node_count, self.output_feature_size, dtype=torch.float32, device=w.device)
-        x = self.embeddings.all_nodes(out=features[:, :d])
+        features = torch.empty(self.dataset.node_count, cw * (1 + self.gnn_layer_count), dtype=torch.float32, device=w.device)
+        self.embeddings.all_nodes(out=features[:, :d])
+        if cw != d:
+            features[:, d:cw].zero_()                        # (a width between the tiled ones: zero padding columns, kept zero by every layer; the scores do not see them)
+        x = features[:, :cw]
         for depth, layer in enumerate(self.gnns, 1):
-            x = layer(x, out=features[:, depth * d:(depth + 1) * d])
+            x = layer(x, out=features[:, depth * cw:(depth + 1) * cw])
         return features
 
     def forward(self, user_indices: Tensor, query_indices: Tensor, item_indices: Optional[Tensor] = None) -> Tensor:

@@ -527,12 +527,19 @@ def make_gradient_sync(model: torch.nn.Module, mode: str = 'bucketed', group=Non
     raise ValueError(f'unknown gradient sync mode {mode!r}')
 
 
-def choose_gradient_sync(gradient_bytes: int, world_size: int, fused_loss: bool = True) -> str:
-    """The exchange a run takes when it is not told one: ``cotangent`` where the model trains through the fused batch tail (IHGNN / HGCN layers + HEM + BCE: every
-    configuration of BASELINE.json) - its 3 B (D + 1) floats per rank are 30 - 900 times fewer bytes than the dense gradient; otherwise ``bucketed`` while the flat
-    gradient fits comfortably beside the model (it overlaps the dense bucket with the backward) and ``sharded`` beyond 2 GiB (config C5: 9.4 GB of gradients, 2 x 9.4 GB of
-    Adam state per replica -> 1 / W of it)."""
-    if fused_loss:
+def cotangent_bytes_per_rank(batch_rows: int, feature_width: int) -> int:
+    """Bytes one rank hands to the cotangent exchange per step: the 3 B int64 node rows of its batch and their ``[D + 4]`` float row gradients (``D`` = the width of the
+    propagation's output, d (L + 1); column D carries the items-bias gradient)."""
+    return 3 * int(batch_rows) * (8 + 4 * (int(feature_width) + 4))
+
+
+def choose_gradient_sync(gradient_bytes: int, world_size: int, fused_loss: bool = True, cotangent_bytes: Optional[int] = None) -> str:
+    """The exchange a run takes when it is not told one, by the bytes a rank receives per step: ``cotangent`` where the model trains through the fused batch tail (IHGNN /
+    HGCN layers + HEM + BCE: every configuration of BASELINE.json) and the other ranks' row cotangents - ``(W - 1) x cotangent_bytes`` - are fewer than the
+    ``2 (W - 1) / W x gradient_bytes`` of a ring all-reduce (C2 - C5: 7 - 230 times fewer; a toy model like C1, whose whole gradient is 0.7 MB, keeps the dense exchange);
+    otherwise ``bucketed`` while the flat gradient fits comfortably beside the model (it overlaps the dense bucket with the backward) and ``sharded`` beyond 2 GiB (config C5:
+    9.4 GB of gradients, 2 x 9.4 GB of Adam state per replica -> 1 / W of it)."""
+    if fused_loss and (cotangent_bytes is None or cotangent_bytes * max(world_size, 1) < 2 * gradient_bytes):
         return 'cotangent'
     return 'sharded' if gradient_bytes > (2 << 30) else 'bucketed'
 

@@ -647,6 +647,52 @@ def node_linear(x, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, t
 
 
 # ---------------------------------------------------------------------------------------------
+# Widths between the tiled ones: zero-padded to the next width the MFMA kernels take
+# ---------------------------------------------------------------------------------------------
+FAST_WIDTHS = (32, 64, 128, 256)
+# IHG_PAD_WIDTHS=1 (default): an embedding width that is a multiple of 4 below 256 and not one of FAST_WIDTHS - the reference takes any --emb (Helpers/ArgsParser.py:94-95,
+# Main.py:23): 48, 96, 160, 192, 224 ... - runs on the kernels of the NEXT fast width with zero columns appended: zero weight rows / columns and zero bias entries keep the
+# padding columns exactly zero through every layer (a linear map of zeros, products with zeros), so the first d columns are the d-wide model's values - the same sums with
+# exact zeros added - and the parameters keep their shapes.  0: the any-width kernels (one thread per output), which is what every width ran on before round 6.
+PAD_WIDTHS = _os.environ.get('IHG_PAD_WIDTHS', '1') != '0'
+
+
+def padded_width(dim: int) -> int:
+    """The width the kernels run a ``dim``-wide model at: ``dim`` itself when it is tiled (or padding is off / does not apply), else the next of ``FAST_WIDTHS``."""
+    dim = int(dim)
+    if not PAD_WIDTHS or dim in FAST_WIDTHS or dim > FAST_WIDTHS[-1] or dim < 1:
+        return dim
+    return next(wd for wd in FAST_WIDTHS if wd >= dim)
+
+
+def pad_columns(x: Tensor, width: int) -> Tensor:
+    """``[n, d] -> [n, width]`` with zero columns appended (differentiable; ``x`` itself when it is already that wide)."""
+    return x if int(x.shape[-1]) == width else torch.nn.functional.pad(x, (0, width - int(x.shape[-1])))
+
+
+def pad_square(w: Tensor, width: int) -> Tensor:
+    """A ``[d, d]`` weight as the top-left block of a zero ``[width, width]`` one."""
+    d = int(w.shape[0])
+    return w if d == width else torch.nn.functional.pad(w, (0, width - d, 0, width - d))
+
+
+def pad_blocks(w: Tensor, width: int) -> Tensor:
+    """A ``[d, k d]`` block weight (``aggregation.weight``: blocks u, q, i, uq, qi, iu, uqi side by side) as ``[width, k width]``: every ``[d, d]`` block in the top-left of its own
+    zero ``[width, width]`` block."""
+    d = int(w.shape[0])
+    if d == width:
+        return w
+    k = int(w.shape[1]) // d
+    return torch.nn.functional.pad(w.reshape(d, k, d), (0, width - d, 0, 0, 0, width - d)).reshape(width, k * width)
+
+
+def pad_vector(b: Optional[Tensor], width: int) -> Optional[Tensor]:
+    if b is None or int(b.shape[-1]) == width:
+        return b
+    return torch.nn.functional.pad(b, (0, width - int(b.shape[-1])))
+
+
+# ---------------------------------------------------------------------------------------------
 # K5+K6 interactive step (orders 2 and 3)
 # ---------------------------------------------------------------------------------------------
 # the [E, 3, d] member-gradient buffer of the interactive backward is produced in hyperedge chunks beyond this many bytes
@@ -997,6 +1043,14 @@ def interact_layer(h: Tensor, w: Tensor, bias: Optional[Tensor], layout: Inciden
     ``bias`` = the aggregation's bias: ``node_segment_sum(interact(h, first_order(h), w), out_scale, rows)`` as one differentiable op."""
     if order not in (2, 3):
         raise ValueError('interact_layer handles interaction orders 2 and 3')
+    dim, wide = int(h.shape[1]), padded_width(int(h.shape[1]))
+    if wide != dim and int(w.shape[0]) == dim and h.is_cuda:
+        # a width between the tiled ones: the same layer at the next tiled width on zero-padded operands (the padding columns of the result are exactly zero and are cut off)
+        if out is not None:
+            _check_out(out, h, w, bias)
+            out.copy_(_InteractLayer.apply(pad_columns(h, wide), pad_blocks(w, wide), pad_vector(bias, wide), layout, int(order), out_scale, rows, None)[:, :dim])
+            return out
+        return _InteractLayer.apply(pad_columns(h, wide), pad_blocks(w, wide), pad_vector(bias, wide), layout, int(order), out_scale, rows, None)[:, :dim]
     return _InteractLayer.apply(h, w, bias, layout, int(order), out_scale, rows, out)
 
 

@@ -213,6 +213,9 @@ def test_cotangent_sync_single_process_is_transparent():
         sync.exchange(rows, rg)
     assert ihg_dist.choose_gradient_sync(10 << 30, 8, True) == 'cotangent' and ihg_dist.choose_gradient_sync(10 << 30, 8, False) == 'sharded'
     assert ihg_dist.choose_gradient_sync(200 << 20, 8, False) == 'bucketed'
+    c3 = ihg_dist.cotangent_bytes_per_rank(1100, 512)
+    assert c3 == 3300 * (8 + 4 * 516) and ihg_dist.choose_gradient_sync(194_600_000, 8, True, c3) == 'cotangent'      # C3: 6.8 MB a rank against a 194.6 MB gradient
+    assert ihg_dist.choose_gradient_sync(725_152, 2, True, ihg_dist.cotangent_bytes_per_rank(1100, 128)) == 'bucketed'  # C1: the whole gradient is smaller than the cotangents
 
 
 def test_shard_range_partitions_exactly():
