@@ -547,6 +547,7 @@ def main():
     E, N = w.edge_count, w.node_count
     value = world * E * layers * args.steps / elapsed      # the metric counts the reference's hyperedges: one per interaction, duplicates included (Helpers/Graph.py:107-118)
     Er = layout.edge_count                                  # rows the kernels walk: the layout's DISTINCT hyperedges (= E unless it carries multiplicities, C5)
+    N_public, N = N, layout.node_count                      # node rows the kernels walk: the layout's nodes (= the graph's unless it leaves the isolated ones out, C5)
     row = 4 * dim
     touched = int((layout.degree > 0.5).sum().item())
     k5_compulsory = touched * row + Er * row + 12 * Er        # every touched node row once + the [E,d] store + the ids
@@ -699,12 +700,16 @@ def main():
                                f'dim={dim}, {layers}x{args.layer} layers, interaction order {args.order}, batch 100 pos + 1000 neg',
                    'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd (the last layer\'s backward pulls the 3B non-zero rows of its cotangent) + Adam' +
                            (f' + RCCL gradient exchange ({sync_mode})' if world > 1 else ''),
-                   'edges': E, 'nodes': N, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
+                   'edges': E, 'nodes': N_public, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
                    # share of the two-hop list's 6 E entries that repeat a (destination, source) pair of their row: merged into weighted entries for the first-order launches
                    'two_hop_duplicates': round(layout.two_hop_duplicate_share, 4), 'two_hop_merged': bool(ihg_ops.two_hop_merged_for(layout)),
                    # interactions that repeat an earlier (user, query, item) triple; where the layout collapses them (>= 25 %: layout.MULTIPLICITY_MIN_SHARE) the kernels walk
                    # distinct_hyperedges rows with a multiplicity each - the metric, the degrees and PpsHyperGraph keep counting every copy (Helpers/Graph.py:107-118)
                    'duplicate_hyperedges': round(layout.duplicate_share, 4), 'hyperedge_multiplicities': layout.edge_weight is not None, 'distinct_hyperedges': Er,
+                   # nodes that are in no hyperedge (every layer output exactly zero): where they are >= 25 % the layout leaves them out of its own numbering and the
+                   # per-node kernels run on nodes_in_hyperedges rows (layout.COMPACT_MIN_SHARE; RawGnn translates at its edges)
+                   'isolated_nodes': round(1.0 - int((layout.public_degree() > 0.5).sum().item()) / max(N_public, 1), 4), 'compact_nodes': bool(layout.compact),
+                   'nodes_in_hyperedges': N,
                    'arithmetic': ('f32 results; f32 accumulation everywhere.  Row contractions (node-level contraction and member gradients at d = 64 / 128 / 256, node-level linear '
                                   'maps and their input gradients at d = 128 / 256): operands scaled by a power of two and taken apart into two fp16 terms, three fp16 MFMA products '
                                   'per multiply (error <= 3 x 2^-22 per product) - also the node-level weight gradients of the product blocks (a row\'s two operands scaled against each other); '
@@ -751,7 +756,7 @@ def main():
         out['roofline_node_to_hyperedge'] = k5_outside
     # SURVEY §8 d3's byte model against what the step really moves: the model prices the reference's two-phase formulation (K5 + K7 per layer, training ~ 3 x forward);
     # the build's re-associations (two-hop fusion, node-level form of the interactive layer) move fewer bytes for the same result, so model / time can exceed the HBM peak
-    d3_fwd = (16 * dim + 12 + 12 * dim + 12) * E * layers + (4 * dim + 8) * N * layers
+    d3_fwd = (16 * dim + 12 + 12 * dim + 12) * E * layers + (4 * dim + 8) * N_public * layers      # (the reference formulation: every interaction a hyperedge, every node a row)
     step_s = elapsed / args.steps
     measured = measured_src = None
     if pmc is not None and pmc.get('step_l2_miss_bytes'):

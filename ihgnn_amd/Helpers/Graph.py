@@ -47,8 +47,8 @@ class PpsHyperGraph(PpsGraph):
     # -- reference-shaped views ---------------------------------------------------------------
     @property
     def VertexDegrees(self) -> Tensor:
-        """``[N,1]`` float degrees with isolated nodes at 1e-8 (``Graph.py:120,131``)."""
-        return self.layout.degree.view(-1, 1)
+        """``[N,1]`` float degrees with isolated nodes at 1e-8 (``Graph.py:120,131``), in the reference's node numbering (the layout's own may leave the isolated nodes out)."""
+        return self.layout.public_degree().view(-1, 1)
 
     @property
     def EdgeDegrees(self) -> Tensor:
@@ -61,7 +61,7 @@ class PpsHyperGraph(PpsGraph):
         """``[E,3]`` int64 global member ids in FILE order (``Graph.py:129``); the kernels' own copy is ``layout.i3``."""
         if self._i3_long is None:
             lay = self.layout
-            offs = np.array([0, lay.user_count, lay.user_count + lay.query_count], dtype=np.int64)
+            offs = np.array([0, lay.public_user_count, lay.public_user_count + lay.public_query_count], dtype=np.int64)
             self._i3_long = torch.from_numpy(lay.triples_file_order + offs).to(lay.device)
         return self._i3_long
 
@@ -73,7 +73,7 @@ class PpsHyperGraph(PpsGraph):
             rows = i3.reshape(-1)
             cols = torch.arange(self.EdgeCount, dtype=torch.int64).repeat_interleave(3)
             adj = torch.sparse_coo_tensor(torch.stack([rows, cols]), torch.ones(3 * self.EdgeCount, dtype=torch.float32),
-                                          (self.layout.node_count, self.EdgeCount)).coalesce()
+                                          (self.layout.public_node_count, self.EdgeCount)).coalesce()
             self._adjacency = adj.to(self.layout.device)
         return self._adjacency
 

@@ -34,6 +34,15 @@ def _row_width(x) -> int:
     return int(x.shape[1])
 
 
+def _check_rows(x, layout) -> None:
+    """A layer's input has one row per node of ITS layout - which, for a hypergraph whose isolated nodes the layout leaves out (``IncidenceLayout.compact``), is not the
+    public node count: ``RawGnn`` translates (``RawGnn._compact_layout``); a direct caller must pass ``x[layout.active_nodes]``."""
+    if int(x.shape[0]) != layout.node_count:
+        raise ValueError(f'layer input has {int(x.shape[0])} rows, the hypergraph layout {layout.node_count} nodes'
+                         + (f' (the layout leaves out the {layout.public_node_count - layout.node_count} isolated nodes of the graph: pass x[layout.active_nodes], or build the '
+                            'dataset under IHG_COMPACT_NODES=0)' if getattr(layout, 'compact', False) else ''))
+
+
 class HGCNLayer(nn.Module):
     """``Y = Dv^-1/2 H De^-1 H^T Dv^-1/2 (X W^T + b)``  (``GnnLayers.py:142-153``)."""
 
@@ -61,6 +70,7 @@ class HGCNLayer(nn.Module):
         (last layer of a training step); other rows may be left unwritten.  ``cotangent_rows``: every row is computed, but the caller
         promises that the gradient of the result is zero outside these rows (``ops.node_two_hop``)."""
         lay = self.layout
+        _check_rows(input_features, lay)
         if self.general:
             # general incidence: node -> hyperedge (x Dv^-1/2 in, De^-1 out), hyperedge -> node (x Dv^-1/2 out): two K7 launches
             h = _transform(self.feature_transform, input_features, lay)
@@ -99,6 +109,7 @@ class IHGNNLayer(nn.Module):
     def forward(self, input_features: Tensor, output_rows: Optional[Tensor] = None, cotangent_rows: Optional[Tensor] = None,
                 out: Optional[Tensor] = None) -> Tensor:
         """``output_rows`` / ``cotangent_rows`` / ``out``: as in ``HGCNLayer.forward``."""
+        _check_rows(input_features, self.layout)
         if self.feature_interaction_order == 1:
             # first-order layer: hoisted node-level blocks, then node -> hyperedge -> node fused into one two-hop pass
             return ops.node_two_hop(self._first_order_of_input(input_features), self.layout, out_scale=self.layout.inv_deg, rows=output_rows,

@@ -72,18 +72,30 @@ class RawGnn(nn.Module):
     batch_rows_only_last_layer = True
     MAX_SCORED_WIDTH = 1264                                   # = ihg_score_topk_max_dim() (tests/test_abi.py): 32 mixed rows as two fp16 planes in 160 KB of LDS
 
+    def _compact_layout(self):
+        """The hypergraph layout when it numbers its nodes WITHOUT the isolated ones (``IncidenceLayout.compact``: config C5, where two thirds of the nodes are in no
+        hyperedge), else ``None``.  Every layer output of an isolated node is exactly zero (an empty sum times ``Dv^-1``), so the layers run on the
+        layout's N' nodes and this class translates at its edges: X0 is gathered from the public ``[N, d]`` rows, the batch tail reads layer 0 by public row and the layers
+        above through ``layout.node_map``, public callers get ``[N, d]`` matrices with zero rows put back."""
+        lay = getattr(self.gnns[0], 'layout', None) if self.gnns else None
+        return lay if (lay is not None and getattr(lay, 'compact', False)) else None
+
     def propagate_layers(self, tail_gradients=None, batch_rows=None, restrict_last_layer=True):
         """Full-graph propagation: the list ``[X0, X1, ..., XL]`` of ``[N, d]`` node features (input embeddings and every
         layer's output).  With ``tail_gradients`` (an ``ops.TailGradients``) every output is tapped: the returned tensors
         are the batch tail's halves, whose gradients travel through the holder instead of dense ``[N, d]`` tensors.
         ``batch_rows`` (int64 node rows): nobody reads ``XL`` outside these rows (a training step scores the batch only).  With
         ``restrict_last_layer`` the last hypergraph layer computes just them (plus the split rows of its plan) and leaves the rest
-        unwritten; without it every row is computed and the layer is only told that its cotangent is zero outside them."""
+        unwritten; without it every row is computed and the layer is only told that its cotangent is zero outside them.
+
+        Over a layout without the isolated nodes (``_compact_layout``): with ``tail_gradients`` the halves above layer 0 are ``[N', d]`` in the LAYOUT's numbering (the
+        holder carries the row map; ``bce_loss`` is their only consumer), without it every output is returned in the public numbering."""
         from .. import ops
         last = len(self.gnns)
         x = None
         padded = self.compute_width != self.embedding_size
-        if (tail_gradients is not None and last >= 1 and ops.NODE_TABLES and not padded
+        compact = self._compact_layout()
+        if (tail_gradients is not None and last >= 1 and ops.NODE_TABLES and not padded and compact is None
                 and (batch_rows is None or int(batch_rows.shape[0]) <= ops.SCATTER_CHUNK_ROWS)):
             # a training step through the fused batch tail: X0 is not assembled - the first layer's transform and the tail read the embedding tables in place
             x = self.embeddings.node_tables(tail_gradients)
@@ -91,15 +103,19 @@ class RawGnn(nn.Module):
             x = self.embeddings.all_nodes()
             if padded:
                 x = ops.pad_columns(x, self.compute_width)   # zero columns up to the next tiled width; every layer keeps them zero (its weights are padded with zeros)
+        layer_rows = batch_rows
+        if compact is not None and batch_rows is not None:
+            # the rows the LAYERS are told (computed / differentiated rows of the last layer): the layout's own; an isolated batch node maps to row 0 - one more row listed
+            layer_rows = compact.compact_rows(batch_rows, isolated_to=0)
         outputs = []
         for depth in range(last + 1):
             sparse_top = None
             if depth > 0:
                 layer = self.gnns[depth - 1]
                 if depth == last and batch_rows is not None and isinstance(layer, (IHGNNLayer, HGCNLayer)):
-                    rows = getattr(batch_rows, 'as_int32', None)
+                    rows = getattr(layer_rows, 'as_int32', None)
                     if rows is None:
-                        rows = batch_rows.to(torch.int32)
+                        rows = layer_rows.to(torch.int32)
                     x = layer(x, output_rows=rows) if restrict_last_layer else layer(x, cotangent_rows=rows)
                     # the layer's backward pulls the listed rows of its cotangent only (the masked two-hop pull): the tap writes them and fills nothing
                     if ((restrict_last_layer or ops.SPARSE_LAST_COTANGENT) and not ops.CHECK_SPARSE_COTANGENT and layer.reads_cotangent_rows_only()
@@ -113,9 +129,18 @@ class RawGnn(nn.Module):
                     continue
                 x, for_tail = ops.tap(x, tail_gradients, depth, sparse_top)
                 outputs.append(for_tail)
+            elif compact is not None and depth > 0:
+                outputs.append(self._to_public_rows(x, compact))
             else:
                 outputs.append(x)
+            if compact is not None and depth == 0:
+                x = x.index_select(0, compact.active_nodes)  # X0 of the nodes that have hyperedges: what the layers run on
         return outputs
+
+    @staticmethod
+    def _to_public_rows(x: Tensor, compact) -> Tensor:
+        """``[N', d]`` in the layout's numbering -> ``[N, d]`` in the public one, zero rows for the isolated nodes (differentiable)."""
+        return torch.zeros(compact.public_node_count, x.shape[1], dtype=x.dtype, device=x.device).index_copy(0, compact.active_nodes, x)
 
     def propagate(self) -> Tensor:
         """``[N, d*(L+1)]``: all layer outputs side by side (``RawGnn.py:122``).  Outside autograd (the evaluation cache,
@@ -131,6 +156,15 @@ class RawGnn(nn.Module):
         if cw != d:
             features[:, d:cw].zero_()                        # (a width between the tiled ones: zero padding columns, kept zero by every layer; the scores do not see them)
         x = features[:, :cw]
+        compact = self._compact_layout()
+        if compact is not None:
+            # the layers run on the layout's N' nodes (the ones that have hyperedges); their rows go back to the public matrix, the isolated nodes' rows are zero
+            x = x.index_select(0, compact.active_nodes)
+            features[:, cw:].zero_()
+            for depth, layer in enumerate(self.gnns, 1):
+                x = layer(x)
+                features[:, depth * cw:(depth + 1) * cw].index_copy_(0, compact.active_nodes, x)
+            return features
         for depth, layer in enumerate(self.gnns, 1):
             x = layer(x, out=features[:, depth * cw:(depth + 1) * cw])
         return features
@@ -181,9 +215,17 @@ class RawGnn(nn.Module):
         else:
             holder = ops.TailGradients() if torch.is_grad_enabled() else None
             read_rows = rows
+        compact = self._compact_layout()
+        if compact is None:
+            return ops.hem_bce_loss(self.propagate_layers(holder, read_rows, self.batch_rows_only_last_layer), rows, item_indices, labels,
+                                    head.items_bias, head.lambda_muq, ds.item_start_index_in_graph, holder)
+        if holder is None:
+            # (no gradient wanted: the public matrices, the plain tail)
+            return nn.functional.binary_cross_entropy_with_logits(
+                ops.hem_score(self.propagate_layers(), rows, item_indices, head.items_bias, head.lambda_muq, ds.item_start_index_in_graph), labels.float())
+        holder.row_map = compact.node_map
         return ops.hem_bce_loss(self.propagate_layers(holder, read_rows, self.batch_rows_only_last_layer), rows, item_indices, labels,
-                                head.items_bias, head.lambda_muq,
-                                ds.item_start_index_in_graph, holder)
+                                head.items_bias, head.lambda_muq, ds.item_start_index_in_graph, holder, rows_upper=compact.compact_rows(rows))
 
     def supports_fused_loss(self, loss_function) -> bool:
         return (isinstance(loss_function, nn.BCEWithLogitsLoss) and loss_function.reduction == 'mean' and loss_function.weight is None

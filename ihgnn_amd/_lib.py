@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # IHGNN_HIP_LIBRARY points at another build of the same ABI (A/B timing of kernel variants); default: the in-tree library
 LIB_PATH = os.environ.get('IHGNN_HIP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libihgnn_hip.so')
 
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 OK, ERR_INVALID, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3
 SCALE_NONE, SCALE_MULTIPLY, SCALE_DIVIDE = 0, 1, 2
@@ -119,9 +119,9 @@ SIGNATURES = {
                                                  c_void_p, c_int64, c_int32, c_void_p]),
     'ihg_node_linear_bwd_weight_typed': (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, _i64p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_int64,
                                                         c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
-    'ihg_hem_score_fwd_typed0': (ctypes.c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64, _i64p, c_void_p, c_void_p, c_void_p, c_float,
+    'ihg_hem_score_fwd_typed0': (ctypes.c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64, _i64p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                                 c_void_p, c_int64, c_void_p]),
-    'ihg_hem_score_bwd_typed0': (ctypes.c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64, _i64p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+    'ihg_hem_score_bwd_typed0': (ctypes.c_int, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int64, _i64p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
                                                 c_void_p, c_int64, c_int64, c_void_p]),
     'ihg_batch_rows_put': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int64, _i64p, c_int32, c_void_p]),
     'ihg_zero_floats': (ctypes.c_int, [c_void_p, c_int64, c_void_p]),

@@ -28,7 +28,7 @@ bool parse_int_list(const char* p, const char* end, std::vector<int64_t>& out) {
 
 extern "C" {
 
-int32_t ihg_abi_version(void) { return 32; }
+int32_t ihg_abi_version(void) { return 33; }
 
 const char* ihg_last_error_string(void) { return ihg_error_buffer; }
 

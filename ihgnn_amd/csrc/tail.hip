@@ -20,20 +20,25 @@ struct LayerPtrs {
     int64_t ld[8];
 };
 
+// rows_upper (optional): the rows of the layers ABOVE layer 0 where they are numbered differently from layer 0's - a layout that leaves the isolated nodes out of its own
+// numbering (IncidenceLayout.node_map) while layer 0 is read from the embedding tables by public id; a negative entry is an isolated node: its rows above layer 0 are zero
 __global__ __launch_bounds__(kBlockThreads) void hem_score_fwd_kernel(LayerPtrs layers, int n_layers, int dim,
                                                                       const int64_t* __restrict__ rows, const int64_t* __restrict__ items,
                                                                       const float* __restrict__ bias, float lam, float* __restrict__ scores,
-                                                                      int64_t batch) {
+                                                                      int64_t batch, const int64_t* __restrict__ rows_upper = nullptr) {
     const int lane = threadIdx.x & 63;
     for (int64_t r = global_wave_id(); r < batch; r += global_wave_count()) {
-        const int64_t u = rows[r], q = rows[batch + r], it = rows[2 * batch + r];
         float acc = 0.f;
         for (int l = 0; l < n_layers; ++l) {
-            const float* xu = layers.x[l][0] + u * layers.ld[l];
-            const float* xq = layers.x[l][1] + q * layers.ld[l];
+            const int64_t* rr = (l > 0 && rows_upper != nullptr) ? rows_upper : rows;
+            const int64_t u = rr[r], q = rr[batch + r], it = rr[2 * batch + r];
+            if (it < 0 || (u < 0 && q < 0)) continue;       // an isolated item (or both other rows zero): the layer adds nothing
+            const float* xu = layers.x[l][0] + (u < 0 ? 0 : u) * layers.ld[l];
+            const float* xq = layers.x[l][1] + (q < 0 ? 0 : q) * layers.ld[l];
             const float* xi = layers.x[l][2] + it * layers.ld[l];
+            const float wu = u < 0 ? 0.f : 1.f - lam, wq = q < 0 ? 0.f : lam;
             for (int c = lane; c < dim; c += kWave) {
-                const float m = lam * xq[c] + (1.f - lam) * xu[c];
+                const float m = wq * xq[c] + wu * xu[c];
                 acc += xi[c] * m;
             }
         }
@@ -46,11 +51,11 @@ __global__ __launch_bounds__(kBlockThreads) void hem_score_fwd_kernel(LayerPtrs 
 __global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs layers, int n_layers, int dim,
                                                                       const int64_t* __restrict__ rows, const float* __restrict__ dscores,
                                                                       float grad_scale, float lam, float* __restrict__ rowgrad, int64_t width,
-                                                                      int64_t batch, const float* __restrict__ grad_scale_device = nullptr) {
+                                                                      int64_t batch, const float* __restrict__ grad_scale_device = nullptr,
+                                                                      const int64_t* __restrict__ rows_upper = nullptr) {
     const int lane = threadIdx.x & 63;
     if (grad_scale_device != nullptr) grad_scale *= *grad_scale_device;      // the upstream gradient of the loss, still on the device (no host read, no extra launch)
     for (int64_t r = global_wave_id(); r < batch; r += global_wave_count()) {
-        const int64_t u = rows[r], q = rows[batch + r], it = rows[2 * batch + r];
         const float ds = dscores[r] * grad_scale;
         if (lane == 0 && width > static_cast<int64_t>(n_layers) * dim) {       // optional extra column: d bias, carried by the item row
             const int64_t col = static_cast<int64_t>(n_layers) * dim;
@@ -59,11 +64,14 @@ __global__ __launch_bounds__(kBlockThreads) void hem_score_bwd_kernel(LayerPtrs 
             rowgrad[(2 * batch + r) * width + col] = ds;
         }
         for (int l = 0; l < n_layers; ++l) {
-            const float* pu = layers.x[l][0] + u * layers.ld[l];
-            const float* pq = layers.x[l][1] + q * layers.ld[l];
-            const float* pi = layers.x[l][2] + it * layers.ld[l];
+            const int64_t* rr = (l > 0 && rows_upper != nullptr) ? rows_upper : rows;
+            const int64_t u = rr[r], q = rr[batch + r], it = rr[2 * batch + r];
+            // (an isolated node's rows above layer 0 are zero constants: the row gradients written for them are never added anywhere - ihg_batch_rows_add / _put skip negative rows)
+            const float* pu = layers.x[l][0] + (u < 0 ? 0 : u) * layers.ld[l];
+            const float* pq = layers.x[l][1] + (q < 0 ? 0 : q) * layers.ld[l];
+            const float* pi = layers.x[l][2] + (it < 0 ? 0 : it) * layers.ld[l];
             for (int c = lane; c < dim; c += kWave) {
-                const float xu = pu[c], xq = pq[c], xi = pi[c];
+                const float xu = u < 0 ? 0.f : pu[c], xq = q < 0 ? 0.f : pq[c], xi = it < 0 ? 0.f : pi[c];
                 const int64_t col = static_cast<int64_t>(l) * dim + c;
                 rowgrad[r * width + col] = ds * (1.f - lam) * xi;
                 rowgrad[(batch + r) * width + col] = ds * lam * xi;
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_rows_add_kernel(const flo
     for (int64_t k = global_wave_id(); k < n; k += global_wave_count()) {
         if (leader[k] == 0) continue;
         const int64_t row = rows[k];
+        if (row < 0) continue;                               // (an isolated node under a compact layout: its rows above layer 0 are constants)
         if (tail != nullptr) {
             const int64_t tr = row - tail_row_offset;
             if (lane == 0 && tr >= 0 && tr < tail_rows) tail[tr] += src[k * ld_src];
@@ -394,21 +403,21 @@ int ihg_hem_score_bwd(const float* const* layers, int32_t n_layers, int64_t ld, 
 }
 
 int ihg_hem_score_fwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
-                             const int64_t* type_begin, const int64_t* rows, const int64_t* items, const float* bias, float lambda_muq, float* scores,
-                             int64_t batch, ihg_stream_t stream) {
+                             const int64_t* type_begin, const int64_t* rows, const int64_t* rows_upper, const int64_t* items, const float* bias, float lambda_muq,
+                             float* scores, int64_t batch, ihg_stream_t stream) {
     if (layer0_rows != nullptr && (type_begin == nullptr || ld0 < dim)) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd_typed0: type ranges / row stride of layer 0 missing");
     if (n_layers < 1 || n_layers > 8 || ld < dim || dim <= 0 || batch < 0 || layers == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd_typed0: bad size");
     if (batch == 0) return IHG_OK;
     if (rows == nullptr || items == nullptr || bias == nullptr || scores == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_fwd_typed0: null pointer");
     const LayerPtrs lp = layer_ptrs(layers, n_layers, ld, layer0_rows, ld0, type_begin);
     hipLaunchKernelGGL(hem_score_fwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers,
-                       dim, rows, items, bias, lambda_muq, scores, batch);
+                       dim, rows, items, bias, lambda_muq, scores, batch, rows_upper);
     return check_launch("ihg_hem_score_fwd_typed0");
 }
 
 int ihg_hem_score_bwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
-                             const int64_t* type_begin, const int64_t* rows, const float* dscores, const float* grad_scale_device, float grad_scale,
-                             float lambda_muq, float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream) {
+                             const int64_t* type_begin, const int64_t* rows, const int64_t* rows_upper, const float* dscores, const float* grad_scale_device,
+                             float grad_scale, float lambda_muq, float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream) {
     if (layer0_rows != nullptr && (type_begin == nullptr || ld0 < dim)) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd_typed0: type ranges / row stride of layer 0 missing");
     if (n_layers < 1 || n_layers > 8 || ld < dim || dim <= 0 || batch < 0 || layers == nullptr) return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd_typed0: bad size");
     if (batch == 0) return IHG_OK;
@@ -416,7 +425,7 @@ int ihg_hem_score_bwd_typed0(const float* const* layers, int32_t n_layers, int64
         return fail(IHG_ERR_INVALID, "ihg_hem_score_bwd_typed0: null pointer or short row stride");
     const LayerPtrs lp = layer_ptrs(layers, n_layers, ld, layer0_rows, ld0, type_begin);
     hipLaunchKernelGGL(hem_score_bwd_kernel, dim3(grid_for_waves(batch)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), lp, n_layers,
-                       dim, rows, dscores, grad_scale, lambda_muq, rowgrad, ld_rowgrad, batch, grad_scale_device);
+                       dim, rows, dscores, grad_scale, lambda_muq, rowgrad, ld_rowgrad, batch, grad_scale_device, rows_upper);
     return check_launch("ihg_hem_score_bwd_typed0");
 }
 

@@ -147,6 +147,15 @@ MULTIPLICITY_MIN_EDGES = int(os.environ.get('IHG_MULTIPLICITY_MIN_EDGES', 1 << 1
 # the first-order launches walk the two-hop list with a row's repeated (destination, source) entries merged into one weighted entry when at least this share of
 # the 6 E entries are repeats (C5: 79 %; C3 / C4 / C2: 8.6 / 13.6 / 17.9 %, where round 5 measured no gain - the repeats were cache hits); ops.TWO_HOP_MERGED overrides
 TWO_HOP_MERGED_MIN_SHARE = float(os.environ.get('IHG_TWO_HOP_MERGED_MIN_SHARE', 0.25))
+# IHG_COMPACT_NODES = auto | 0 | 1: number the nodes INSIDE the layout without the isolated ones (nodes that are in no hyperedge).  Every layer output of such a node is exactly
+# zero (an empty sum times Dv^-1, App. B 2) and nobody gathers its rows, so the propagation - pair sums, node-level contractions, linear maps and their backward - runs on
+# the N' nodes that have hyperedges; the public numbering (embedding tables, batch indices, evaluation, PpsHyperGraph's tensors) stays the reference's (Graph.py:110-111) and the
+# two meet in RawGnn: X0 is gathered from the tables' active rows, the batch tail reads layer 0 from the tables and the layers above through the map (isolated: zero), the
+# evaluation matrix is scattered back.  auto: on when at least COMPACT_MIN_SHARE of the nodes of a graph of >= COMPACT_MIN_NODES are isolated (config C5's power-law draw:
+# 64 % - two thirds of every per-node kernel's rows; the C2 - C4 stand-ins: < 4 %, off).
+COMPACT_NODES = os.environ.get('IHG_COMPACT_NODES', 'auto')
+COMPACT_MIN_SHARE = float(os.environ.get('IHG_COMPACT_MIN_SHARE', 0.25))
+COMPACT_MIN_NODES = int(os.environ.get('IHG_COMPACT_MIN_NODES', 1 << 16))
 
 
 def unique_triples(triples: np.ndarray, user_count: int, query_count: int, item_count: int, count_only: bool = False):
@@ -173,7 +182,8 @@ class IncidenceLayout:
     """The (user, query, item) hypergraph in kernel layout."""
 
     def __init__(self, triples: np.ndarray, user_count: int, query_count: int, item_count: int, device: torch.device,
-                 heavy_threshold: int = HEAVY_THRESHOLD, edge_order: str = os.environ.get('IHG_EDGE_ORDER', 'user'), edge_multiplicity: Optional[str] = None):
+                 heavy_threshold: int = HEAVY_THRESHOLD, edge_order: str = os.environ.get('IHG_EDGE_ORDER', 'user'), edge_multiplicity: Optional[str] = None,
+                 compact_nodes: Optional[str] = None):
         """``edge_order='user'`` renumbers the hyperedges by (user, file position) inside this layout: consecutive
         hyperedges then share their user row (the largest node table) and every user's incidence list is one contiguous
         run of edge-feature rows.  Hyperedge numbering is internal to the kernels - nothing outside the layout sees it
@@ -182,11 +192,51 @@ class IncidenceLayout:
 
         ``edge_multiplicity`` (``'auto'`` | ``'0'`` | ``'1'``; default: ``IHG_EDGE_MULTIPLICITY``): collapse identical triples into ONE row of weight ``m_e``
         (``edge_weight``, ``None`` when off).  ``edge_count`` is then the number of DISTINCT hyperedges - the rows of every ``[E, d]`` buffer - while ``hyperedge_count``
-        stays the reference's count (``PpsHyperGraph.EdgeCount``, the metric's E); degrees count every copy.  Rows are ordered by (user, query, item)."""
+        stays the reference's count (``PpsHyperGraph.EdgeCount``, the metric's E); degrees count every copy.  Rows are ordered by (user, query, item).
+
+        ``compact_nodes`` (``'auto'`` | ``'0'`` | ``'1'``; default: ``IHG_COMPACT_NODES``): number the nodes inside the layout without the isolated ones.  ``user_count`` /
+        ``query_count`` / ``item_count`` / ``node_count`` and every per-node array are then the COMPACT ones (what the kernels see); ``public_*`` are the reference's;
+        ``node_map`` (``[N]`` int64: public global node id -> compact id, -1 for an isolated node) and ``active_nodes`` (``[N']``: compact -> public) translate, ``None`` when off."""
         lib = _lib.load()
         triples = np.ascontiguousarray(np.asarray(triples, dtype=np.int64).reshape(-1, 3))
         self.triples_file_order = triples
         self.hyperedge_count = int(triples.shape[0])
+        self.public_user_count, self.public_query_count, self.public_item_count = int(user_count), int(query_count), int(item_count)
+        self.public_node_count = self.public_user_count + self.public_query_count + self.public_item_count
+        for m in range(3):
+            if triples.shape[0] and (triples[:, m].min() < 0 or triples[:, m].max() >= (user_count, query_count, item_count)[m]):
+                raise _lib.IhgnnHipError(f'hyperedge member {m} out of range [0, {(user_count, query_count, item_count)[m]})')
+        # -- compact node numbering (decided on the public ids, before anything is built) --
+        cmode = str(COMPACT_NODES if compact_nodes is None else compact_nodes)
+        if cmode not in ('auto', '0', '1'):
+            raise ValueError(f'compact_nodes: auto | 0 | 1, got {cmode!r}')
+        self.node_map_host = self.active_nodes_host = None
+        self.isolated_share = 0.0
+        if cmode != '0' and triples.shape[0] > 0 and (cmode == '1' or self.public_node_count >= COMPACT_MIN_NODES):
+            counts = (self.public_user_count, self.public_query_count, self.public_item_count)
+            alive = []
+            for m in range(3):
+                seen = np.zeros(counts[m], bool)
+                seen[triples[:, m]] = True
+                alive.append(seen)
+            n_alive = [int(a.sum()) for a in alive]
+            self.isolated_share = 1.0 - sum(n_alive) / max(self.public_node_count, 1)
+            if min(n_alive) > 0 and self.isolated_share > 0 and (cmode == '1' or self.isolated_share >= COMPACT_MIN_SHARE):
+                node_map = np.full(self.public_node_count, -1, np.int64)
+                active, pub0, cmp0 = [], 0, 0
+                remapped = np.empty_like(triples)
+                for m in range(3):
+                    ids = np.nonzero(alive[m])[0]
+                    local = np.full(counts[m], -1, np.int64)
+                    local[ids] = np.arange(ids.shape[0])
+                    remapped[:, m] = local[triples[:, m]]                # (monotone: an order by user stays an order by user)
+                    node_map[pub0 + ids] = cmp0 + np.arange(ids.shape[0])
+                    active.append(pub0 + ids)
+                    pub0, cmp0 = pub0 + counts[m], cmp0 + ids.shape[0]
+                self.node_map_host, self.active_nodes_host = node_map, np.concatenate(active)
+                self._public_triples_for_views = triples
+                triples = remapped
+                user_count, query_count, item_count = n_alive
         self.user_count, self.query_count, self.item_count = int(user_count), int(query_count), int(item_count)
         self.node_count = n = self.user_count + self.query_count + self.item_count
         if edge_order not in ('user', 'file'):
@@ -215,6 +265,8 @@ class IncidenceLayout:
                 self.file_to_edge = np.arange(self.hyperedge_count, dtype=np.int32)
         self.edge_count = e = int(triples.shape[0])
         self.device = device
+        self.node_map = None if self.node_map_host is None else torch.from_numpy(self.node_map_host).to(device)
+        self.active_nodes = None if self.active_nodes_host is None else torch.from_numpy(self.active_nodes_host).to(device)
         i3 = np.empty((max(e, 1), 3), np.int32)
         rowptr = np.empty(n + 1, np.int32)
         edge_ids = np.empty(max(3 * e, 1), np.int32)
@@ -276,6 +328,31 @@ class IncidenceLayout:
         self.two_hop_duplicate_share = 1.0 - int(nnz.value) / max(6 * self.hyperedge_count, 1)
         # a layout with multiplicities has no unweighted two-hop list to fall back to: its first-order launches always walk the merged one
         self.two_hop_merged_default = bool(multiplicity is not None or self.two_hop_duplicate_share >= TWO_HOP_MERGED_MIN_SHARE)
+
+    @property
+    def compact(self) -> bool:
+        """True when the layout numbers its nodes without the isolated ones (``node_map`` / ``active_nodes`` translate)."""
+        return self.node_map is not None
+
+    def public_degree(self) -> torch.Tensor:
+        """``[N]`` vertex degrees in the PUBLIC numbering with the reference's 1e-8 for isolated nodes (``Graph.py:120``): ``degree`` itself unless the layout is compact."""
+        if not self.compact:
+            return self.degree
+        cached = self.__dict__.get('_public_degree')
+        if cached is None:
+            cached = torch.full((self.public_node_count,), 1e-8, dtype=torch.float32, device=self.device)
+            cached[self.active_nodes] = self.degree
+            self.__dict__['_public_degree'] = cached
+        return cached
+
+    def compact_rows(self, public_rows: torch.Tensor, isolated_to: Optional[int] = None) -> torch.Tensor:
+        """Public global node rows -> the layout's rows (int64; -1 for an isolated node, or ``isolated_to``); the rows themselves when the layout is not compact."""
+        if not self.compact:
+            return public_rows
+        rows = self.node_map[public_rows]
+        if isolated_to is not None:
+            rows = torch.where(rows < 0, torch.full_like(rows, int(isolated_to)), rows)
+        return rows
 
     def row_mask(self) -> torch.Tensor:
         """A byte per node row, all zero between uses (``ops._TwoHop.backward`` sets the rows of a sparse cotangent before its pull and clears them after)."""

@@ -1123,7 +1123,7 @@ def interact(h: Tensor, p: Tensor, w: Tensor, layout: IncidenceLayout, order: in
 # ---------------------------------------------------------------------------------------------
 # Batch tail: HEM scores of a training batch straight from the layer outputs
 # ---------------------------------------------------------------------------------------------
-def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float, tables=None, grad_scale_device=None):
+def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, dscores: Tensor, grad_scale: float, tables=None, grad_scale_device=None, rows_upper=None):
     """Per-batch-row gradients of the tail: ``[3B, (L+1) d + 4]``, layer l in columns ``l d .. (l+1) d``, d bias in column ``(L+1) d``.  ``tables`` (a resolved
     ``NodeTables``): layer 0 is read from the embedding tables in place and ``layers`` are the outputs of the layers above it."""
     lib = _lib.load()
@@ -1137,12 +1137,12 @@ def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: f
     with profiler.kernel('hem_score_bwd', batch, dim):
         if tables is None:
             ptrs = (ctypes.c_void_p * n_layers)(*[x.data_ptr() for x in layers])
-            _lib.check(lib.ihg_hem_score_bwd_typed0(ptrs, n_layers, _ld(layers[0]), dim, None, 0, None, _ptr(rows), _ptr(dscores), _ptr(grad_scale_device), float(grad_scale),
-                                                    float(lam), _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd_typed0')
+            _lib.check(lib.ihg_hem_score_bwd_typed0(ptrs, n_layers, _ld(layers[0]), dim, None, 0, None, _ptr(rows), _ptr(rows_upper), _ptr(dscores), _ptr(grad_scale_device),
+                                                    float(grad_scale), float(lam), _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd_typed0')
         else:
             ptrs = (ctypes.c_void_p * n_layers)(tables.query_rows.data_ptr(), *[x.data_ptr() for x in layers])
             _lib.check(lib.ihg_hem_score_bwd_typed0(ptrs, n_layers, _ld(layers[0]) if layers else dim, dim, tables.row_pointers(), dim, _type_begin(tables.layout), _ptr(rows),
-                                                    _ptr(dscores), _ptr(grad_scale_device), float(grad_scale), float(lam), _ptr(rowgrad), width + 4, batch, _stream()),
+                                                    _ptr(rows_upper), _ptr(dscores), _ptr(grad_scale_device), float(grad_scale), float(lam), _ptr(rowgrad), width + 4, batch, _stream()),
                        'ihg_hem_score_bwd_typed0')
     return rowgrad
 
@@ -1203,41 +1203,53 @@ class TailGradients:
         # batch tail's backward between its row-gradient kernel and the combine; ``grad_scale`` = 1 / world size (the average over ranks) applied by that kernel
         self.exchange = exchange
         self.grad_scale = float(grad_scale)
+        # a layout that numbers its nodes without the isolated ones (IncidenceLayout.node_map): layer 0 is addressed by the public rows (``rows``), the layers above by
+        # ``rows_upper`` = row_map[rows] (-1: an isolated node, whose rows above layer 0 are zero constants - the add / put kernels skip it)
+        self.row_map: Optional[Tensor] = None
+        self.rows_upper: Optional[Tensor] = None
+
+    def _rows_of(self, upper: bool) -> Tensor:
+        return self.rows_upper if (upper and self.rows_upper is not None) else self.rows
 
     def put_into_typed(self, dense_rows, ld_dense: int, layout, col0: int, width: int) -> None:
         """``add_into`` for a destination whose node types start at their own addresses (``dense_rows``: host array of three device pointers)."""
         _put_rows(self, dense_rows, ld_dense, layout, col0, width, False)
 
-    def assign_into(self, dense: Tensor, layout, col0: int, width: int) -> None:
+    def assign_into(self, dense: Tensor, layout, col0: int, width: int, upper: bool = False) -> None:
         """``dense[rows[k]] = rowgrad[k, col0 : col0 + width]`` on the (combined) batch rows, nothing else written: a gradient that is zero outside the batch rows
         and READ at those rows only (the last layer's cotangent under the sparse pull) needs no ``[N, d]`` zero fill."""
         base = dense.data_ptr()
         tb = _type_begin(layout)
         step = _ld(dense) * 4
-        _put_rows(self, (ctypes.c_void_p * 3)(base + tb[0] * step, base + tb[1] * step, base + tb[2] * step), _ld(dense), layout, col0, width, True)
+        _put_rows(self, (ctypes.c_void_p * 3)(base + tb[0] * step, base + tb[1] * step, base + tb[2] * step), _ld(dense), layout, col0, width, True, upper)
 
-    def add_into(self, dense: Optional[Tensor], col0: int, width: int, tail: Optional[Tensor] = None, tail_offset: int = 0) -> None:
-        """``dense[rows[k]] += rowgrad[k, col0 : col0 + width]`` (or ``tail[rows[k] - tail_offset] += rowgrad[k, col0]``)."""
+    def add_into(self, dense: Optional[Tensor], col0: int, width: int, tail: Optional[Tensor] = None, tail_offset: int = 0, upper: bool = False) -> None:
+        """``dense[rows[k]] += rowgrad[k, col0 : col0 + width]`` (or ``tail[rows[k] - tail_offset] += rowgrad[k, col0]``); ``upper``: the destination is a layer above layer 0
+        (addressed by ``rows_upper`` where the layout's numbering differs from the public one)."""
+        rows = self._rows_of(upper)
         if self.leader is None:
-            _scatter_rows(self.rowgrad, col0, width, self.rows, dense, tail, tail_offset)
+            if upper and self.rows_upper is not None:
+                raise _lib.IhgnnHipError('a compact layout needs the combined row gradients (batches of at most 32,768 rows)')
+            _scatter_rows(self.rowgrad, col0, width, rows, dense, tail, tail_offset)
             return
         lib = _lib.load()
-        n = int(self.rows.shape[0])
+        n = int(rows.shape[0])
         src = self.rowgrad[:, col0:]
         with profiler.kernel('batch_rows_add', n, width):
-            _lib.check(lib.ihg_batch_rows_add(_ptr(src), int(self.rowgrad.stride(0)), width, _ptr(self.rows), _ptr(self.leader), n, _ptr(dense),
+            _lib.check(lib.ihg_batch_rows_add(_ptr(src), int(self.rowgrad.stride(0)), width, _ptr(rows), _ptr(self.leader), n, _ptr(dense),
                                               _ld(dense) if dense is not None else 0, _ptr(tail), int(tail_offset),
                                               int(tail.shape[0]) if tail is not None else 0, _stream()), 'ihg_batch_rows_add')
 
 
-def _put_rows(holder: 'TailGradients', dense_rows, ld_dense: int, layout, col0: int, width: int, assign: bool) -> None:
+def _put_rows(holder: 'TailGradients', dense_rows, ld_dense: int, layout, col0: int, width: int, assign: bool, upper: bool = False) -> None:
     lib = _lib.load()
     if holder.leader is None:
         raise _lib.IhgnnHipError('typed / assigning row scatter needs the combined row gradients (batches of at most 32,768 rows)')
-    n = int(holder.rows.shape[0])
+    rows = holder._rows_of(upper)
+    n = int(rows.shape[0])
     src = holder.rowgrad[:, col0:]
     with profiler.kernel('batch_rows_add', n, width):
-        _lib.check(lib.ihg_batch_rows_put(_ptr(src), int(holder.rowgrad.stride(0)), width, _ptr(holder.rows), _ptr(holder.leader), n, dense_rows, ld_dense,
+        _lib.check(lib.ihg_batch_rows_put(_ptr(src), int(holder.rowgrad.stride(0)), width, _ptr(rows), _ptr(holder.leader), n, dense_rows, ld_dense,
                                           _type_begin(layout), 1 if assign else 0, _stream()), 'ihg_batch_rows_put')
 
 
@@ -1261,13 +1273,17 @@ class _Tap(torch.autograd.Function):
             if ctx.sparse_layout is not None and holder.leader is not None:
                 # ... and that layer's backward READS it at those rows only (the masked pull of node_two_hop): the rows are written, nothing is filled
                 g = torch.empty(n, dim, dtype=torch.float32, device=ctx.device)
-                holder.assign_into(g, ctx.sparse_layout, ctx.index * dim, dim)
+                if ctx.index > 0 and holder.rows_upper is not None:
+                    # (a layout without the isolated nodes lists row 0 in place of every isolated batch node - RawGnn.propagate_layers -: the pull reads that row, so it
+                    #  holds zeros unless it is a batch row itself, in which case the assignment below overwrites it)
+                    _lib.check(_lib.load().ihg_zero_floats(_ptr(g), dim, _stream()), 'ihg_zero_floats')
+                holder.assign_into(g, ctx.sparse_layout, ctx.index * dim, dim, upper=ctx.index > 0)
                 return g, None, None, None
             g = torch.empty(n, dim, dtype=torch.float32, device=ctx.device)
             _lib.check(_lib.load().ihg_zero_floats(_ptr(g), n * dim, _stream()), 'ihg_zero_floats')
         else:
             g = g_next if (g_next.is_contiguous() and g_next.dtype == torch.float32) else g_next.contiguous().float()
-        holder.add_into(g, ctx.index * dim, dim)
+        holder.add_into(g, ctx.index * dim, dim, upper=ctx.index > 0)
         return g, None, None, None
 
 
@@ -1292,7 +1308,7 @@ def _zero_like_expanded(shape, device: torch.device) -> Tensor:
 def _same_layout(layers):
     layers = tuple(_rows(x, 'layer output') for x in layers)
     ld = _ld(layers[0])
-    if any(_ld(x) != ld or x.shape != layers[0].shape for x in layers):
+    if any(_ld(x) != ld or x.shape[1] != layers[0].shape[1] for x in layers):
         layers = tuple(x.contiguous() for x in layers)
     return layers
 
@@ -1325,7 +1341,7 @@ class _HemBceLoss(torch.autograd.Function):
     returned here); without one they are returned dense."""
 
     @staticmethod
-    def forward(ctx, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int, holder, tables, *layers: Tensor) -> Tensor:
+    def forward(ctx, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int, holder, tables, rows_upper, *layers: Tensor) -> Tensor:
         # tables (a resolved NodeTables): layer 0 is the embedding tables in place; layers[0] is then its token (the autograd edge), not a matrix
         lib = _lib.load()
         real = _same_layout(layers[1:] if tables is not None else layers)
@@ -1335,16 +1351,22 @@ class _HemBceLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=bias.device)
         labels = labels.to(torch.float32).contiguous()
         with profiler.kernel('hem_score_fwd', batch, dim):
-            if tables is None:
+            if tables is None and rows_upper is None:
                 ptrs = (ctypes.c_void_p * len(real))(*[x.data_ptr() for x in real])
                 _lib.check(lib.ihg_hem_score_fwd(ptrs, len(real), _ld(real[0]), dim, _ptr(rows), _ptr(items), _ptr(bias), float(lam), _ptr(scores),
                                                  batch, _stream()), 'ihg_hem_score_fwd')
+            elif tables is None:
+                # a layout without the isolated nodes: layer 0 is a matrix in the public numbering (rows), the layers above are in the layout's (rows_upper; -1: zero row)
+                ptrs = (ctypes.c_void_p * len(real))(*[x.data_ptr() for x in real])
+                _lib.check(lib.ihg_hem_score_fwd_typed0(ptrs, len(real), _ld(real[0]), dim, None, 0, None, _ptr(rows), _ptr(rows_upper), _ptr(items), _ptr(bias), float(lam),
+                                                        _ptr(scores), batch, _stream()), 'ihg_hem_score_fwd_typed0')
             else:
                 ptrs = (ctypes.c_void_p * (len(real) + 1))(tables.query_rows.data_ptr(), *[x.data_ptr() for x in real])     # (slot 0 is replaced by the typed rows)
                 _lib.check(lib.ihg_hem_score_fwd_typed0(ptrs, len(real) + 1, _ld(real[0]) if real else dim, dim, tables.row_pointers(), dim, _type_begin(tables.layout),
-                                                        _ptr(rows), _ptr(items), _ptr(bias), float(lam), _ptr(scores), batch, _stream()), 'ihg_hem_score_fwd_typed0')
+                                                        _ptr(rows), _ptr(rows_upper), _ptr(items), _ptr(bias), float(lam), _ptr(scores), batch, _stream()), 'ihg_hem_score_fwd_typed0')
             _lib.check(lib.ihg_bce_with_logits(_ptr(scores), _ptr(labels), batch, _ptr(loss), _ptr(dscores), _stream()), 'ihg_bce_with_logits')
         ctx.save_for_backward(rows, items, bias, dscores, *real)
+        ctx.rows_upper = rows_upper
         ctx.lam, ctx.offset, ctx.holder, ctx.tables = float(lam), int(item_row_offset), holder, tables
         ctx.token_shape = tuple(layers[0].shape) if tables is not None else None
         return loss
@@ -1354,18 +1376,20 @@ class _HemBceLoss(torch.autograd.Function):
         rows, items, bias, dscores, *layers = ctx.saved_tensors
         tables = ctx.tables
         if ctx.holder is None:
-            if tables is not None:
-                raise _lib.IhgnnHipError('hem_bce_loss over NodeTables needs a TailGradients holder')
+            if tables is not None or ctx.rows_upper is not None:
+                raise _lib.IhgnnHipError('hem_bce_loss over NodeTables / a compact layout needs a TailGradients holder')
             dbias, grads = _hem_backward(layers, rows, items, bias, ctx.lam, dscores * grad_loss, 1.0, ctx.offset)
-            return (None, None, None, dbias, None, None, None, None) + grads
+            return (None, None, None, dbias, None, None, None, None, None) + grads
         holder = ctx.holder
-        rowgrad = _hem_row_gradients(layers, rows, items, bias, ctx.lam, dscores, holder.grad_scale, tables, grad_loss.contiguous())     # d loss stays on the device: no host read, no multiply launch
+        rowgrad = _hem_row_gradients(layers, rows, items, bias, ctx.lam, dscores, holder.grad_scale, tables, grad_loss.contiguous(), ctx.rows_upper)     # d loss stays on the device: no host read, no multiply launch
         if holder.exchange is not None:
             # every rank's propagation is the same function of the same parameters and its backward is linear in the cotangent of the layer outputs, which is non-zero on
             # the batch rows only: the ranks exchange THOSE rows (3B x (D + 1) floats each) and every rank runs the one propagation backward on the union - the averaged
             # gradient of all parameters without a dense all-reduce (RawGnn.py:122-142: the batch reads F at 3B rows)
             rows, rowgrad = holder.exchange(rows, rowgrad)
         holder.rows, holder.rowgrad, holder.leader = rows, rowgrad, None
+        # (the union's rows after an exchange; this batch's otherwise - through the layout's map where it numbers its nodes without the isolated ones)
+        holder.rows_upper = None if holder.row_map is None else (ctx.rows_upper if holder.exchange is None and ctx.rows_upper is not None else holder.row_map[rows])
         lib = _lib.load()
         n_layers = len(layers) + (1 if tables is not None else 0)
         n, width = int(rows.shape[0]), n_layers * (int(layers[0].shape[1]) if layers else tables.dim)
@@ -1380,7 +1404,7 @@ class _HemBceLoss(torch.autograd.Function):
         placeholders = tuple(_zero_like_expanded(x.shape, x.device) for x in layers)
         if tables is not None:
             placeholders = (_zero_like_expanded(ctx.token_shape, bias.device),) + placeholders
-        return (None, None, None, dbias, None, None, None, None) + placeholders
+        return (None, None, None, dbias, None, None, None, None, None) + placeholders
 
 
 def score_topk_max_width() -> int:
@@ -1449,9 +1473,10 @@ def hem_score(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: float, ite
 
 
 def hem_bce_loss(layers, rows: Tensor, items: Tensor, labels: Tensor, bias: Tensor, lam: float, item_row_offset: int,
-                 holder: Optional[TailGradients] = None) -> Tensor:
+                 holder: Optional[TailGradients] = None, rows_upper: Optional[Tensor] = None) -> Tensor:
     """``nn.BCEWithLogitsLoss()(hem_score(...), labels)`` as one differentiable op (scalar).  ``holder``: the layers are the
-    tail halves of ``tap`` outputs made with this holder, and their gradients travel through it (see ``TailGradients``).  ``layers[0]`` may be a
+    tail halves of ``tap`` outputs made with this holder, and their gradients travel through it (see ``TailGradients``).  ``rows_upper`` (with ``holder.row_map``): the
+    layers above layer 0 are numbered by the layout's own node ids (a layout without the isolated nodes): their rows of the batch, -1 = isolated = zero.  ``layers[0]`` may be a
     ``NodeTables`` (resolved by the first layer's transform): the head reads its layer-0 rows from the embedding tables in place."""
     tables = None
     layers = list(layers)
@@ -1460,4 +1485,6 @@ def hem_bce_loss(layers, rows: Tensor, items: Tensor, labels: Tensor, bias: Tens
         if tables.query_rows is None or tables.token is None:
             raise RuntimeError('hem_bce_loss: the NodeTables were not consumed by a node-level transform (a model without layers?)')
         layers[0] = tables.token
-    return _HemBceLoss.apply(rows, items, labels, bias, float(lam), int(item_row_offset), holder, tables, *layers)
+    if rows_upper is not None and holder is not None and holder.row_map is None:
+        raise ValueError('rows_upper comes with holder.row_map (the layout\'s public -> own node map)')
+    return _HemBceLoss.apply(rows, items, labels, bias, float(lam), int(item_row_offset), holder, tables, rows_upper, *layers)

@@ -497,7 +497,10 @@ int ihg_score_topk(const float* features, int64_t ld, int32_t dim, int64_t query
  *                                      zero_row_before_mask: the row in front of dx_rows[t] (the padding row 0 of an embedding table's gradient) is zeroed
  *   ihg_hem_score_fwd_typed0 / ihg_hem_score_bwd_typed0   ihg_hem_score_fwd / _bwd with layer 0 given as typed rows (row stride ld0; layer0_rows NULL: every layer a
  *                                      plain matrix); _bwd multiplies the upstream gradient by *grad_scale_device (a DEVICE scalar, NULL: 1) as well - d loss of a
- *                                      backward pass, without a host read or a separate multiply launch
+ *                                      backward pass, without a host read or a separate multiply launch.  rows_upper (optional, [3 batch]): the rows of the layers ABOVE
+ *                                      layer 0 where those are numbered differently from layer 0's - a layout that leaves the isolated nodes (no hyperedge: every layer
+ *                                      output is zero, Graph.py:120 / App. B 2) out of its own numbering while layer 0 is read from the embedding tables by the reference's
+ *                                      node id; a negative entry = isolated: its rows above layer 0 count as zero (ihg_batch_rows_add / _put skip negative rows)
  *   ihg_batch_rows_put                 ihg_batch_rows_add into typed rows; assign != 0: dense[rows[k]] = src[k] on the leader rows (a gradient that is
  *                                      zero elsewhere and read at these rows only: no fill of the matrix)
  * Available where ihg_node_linear_typed_supported says so (dim 128 / 256 on the split-arithmetic kernels, row strides % 4 == 0, 16-byte aligned rows).
@@ -511,11 +514,11 @@ int ihg_node_linear_bwd_weight_typed(const float* dout, int64_t ld_dout, const f
                                      const float* w, int64_t ld_w, float* const* dx_rows, int64_t ld_dx, int32_t zero_row_before_mask,
                                      void* workspace, int64_t workspace_bytes, int32_t dim, ihg_stream_t stream);
 int ihg_hem_score_fwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
-                             const int64_t* type_begin, const int64_t* rows, const int64_t* items, const float* bias, float lambda_muq,
+                             const int64_t* type_begin, const int64_t* rows, const int64_t* rows_upper, const int64_t* items, const float* bias, float lambda_muq,
                              float* scores, int64_t batch, ihg_stream_t stream);
 int ihg_hem_score_bwd_typed0(const float* const* layers, int32_t n_layers, int64_t ld, int32_t dim, const float* const* layer0_rows, int64_t ld0,
-                             const int64_t* type_begin, const int64_t* rows, const float* dscores, const float* grad_scale_device, float grad_scale,
-                             float lambda_muq, float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream);
+                             const int64_t* type_begin, const int64_t* rows, const int64_t* rows_upper, const float* dscores, const float* grad_scale_device,
+                             float grad_scale, float lambda_muq, float* rowgrad, int64_t ld_rowgrad, int64_t batch, ihg_stream_t stream);
 int ihg_batch_rows_put(const float* src, int64_t ld_src, int32_t width, const int64_t* rows, const int32_t* leader, int64_t n_rows,
                        float* const* dense_rows, int64_t ld_dense, const int64_t* type_begin, int32_t assign, ihg_stream_t stream);
 

@@ -569,6 +569,91 @@ def test_models_at_widths_between_the_tiled_ones(kind, dim, monkeypatch):
     assert rel(results[True][2], results[False][2]) <= 1e-4 and float((results[True][3][0] == results[False][3][0]).float().mean()) >= 0.9
 
 
+@pytest.mark.parametrize('kind,layers,order,dim', [('ihgnn', 2, 3, 64), ('ihgnn', 3, 3, 128), ('ihgnn', 2, 3, 256), ('ihgnn', 2, 3, 32), ('ihgnn', 1, 3, 64), ('ihgnn', 2, 1, 64),
+                                                   ('hgcn', 2, 1, 64), ('ihgnn', 2, 3, 96)])
+def test_models_over_a_layout_without_the_isolated_nodes(kind, layers, order, dim, monkeypatch):
+    """``IHG_COMPACT_NODES=1``: the hypergraph layout numbers its nodes without the isolated ones (two thirds of config C5's nodes are in no hyperedge: every layer output of
+    such a node is exactly zero) and ``RawGnn`` translates at its edges.  Against the same model over the every-node-a-row layout and against the CPU
+    oracle on the public graph: four training steps whose batches are full of isolated nodes (fused tail, restricted and full last layer, the masked pull), every parameter
+    after them, the evaluation feature matrix (zero rows put back) and top items; also on top of hyperedge multiplicities, at a padded width, through the module-call path,
+    and with the layers refusing an input in the wrong numbering."""
+    from ihgnn_amd import layout as layout_mod, ops, synth
+    from ihgnn_amd.Dataset import GraphDataset
+    from ihgnn_amd.optim import Adam
+    from conftest import state_digest
+    from oracle import ihgnn_ref as ref
+    U, Q, I = 500, 24, 420
+    rng = np.random.default_rng(dim + layers)
+    live_u, live_q, live_i = rng.choice(U, 170, replace=False), rng.choice(Q, 15, replace=False), rng.choice(I, 150, replace=False)
+    base = np.stack([rng.choice(live_u, 5000), rng.choice(live_q, 5000), rng.choice(live_i, 5000)], 1)
+    triples = np.concatenate([base, base[:2500]])                        # repeats as well: the two collapses compose
+    w = synth.draw(U, Q, I, 40, 10, seed=3)                              # (only its query bags are used)
+    if dim == 256:
+        monkeypatch.setattr(ops, 'FIRST_ORDER_TWO_HOP_BYTES', 0)
+    batches = [tuple(torch.from_numpy(rng.integers(0, c, 330)) for c in (U, Q, I)) + (torch.from_numpy((rng.random(330) < 0.1).astype(np.float32)),) for _ in range(4)]
+    eu, eq = torch.from_numpy(rng.integers(0, U, 12)), torch.from_numpy(rng.integers(0, Q, 12))
+    results = {}
+    for mode in ('1', '0'):
+        monkeypatch.setattr(layout_mod, 'COMPACT_NODES', mode)
+        monkeypatch.setattr(layout_mod, 'EDGE_MULTIPLICITY', mode)
+        ds = GraphDataset.from_arrays(U, Q, I, w.vocab_size, w.bag_words, w.bag_offsets, triples, device=dev())
+        lay = ds.hypergraph.layout
+        assert lay.compact == (mode == '1') and ds.node_count == U + Q + I and tuple(ds.hypergraph.VertexDegrees.shape) == (U + Q + I, 1)
+        if mode == '1':
+            assert lay.node_count == 170 + 15 + 150 and lay.edge_weight is not None
+        m = build_model(ds, kind, layers, order, dim)
+        assert (m._compact_layout() is not None) == (mode == '1')
+        if mode == '1':
+            init = {k: v.detach().clone() for k, v in m.state_dict().items()}
+            with pytest.raises(ValueError, match='isolated nodes'):
+                m.gnns[0](torch.zeros(U + Q + I, m.compute_width, device=dev()))
+        else:
+            m.load_state_dict(init)
+        opt = Adam(m.parameters(), 1e-3, weight_decay=0)
+        losses = []
+        for restrict, (u, q, i, y) in zip((False, True, False, True), batches):
+            m.batch_rows_only_last_layer = restrict
+            loss = m.bce_loss(u.to(dev()), q.to(dev()), i.to(dev()), y.to(dev()))
+            loss.backward(); opt.step(); opt.zero_grad()
+            losses.append(loss.item())
+        u, q, i, y = batches[0]
+        scores = m(u.to(dev()), q.to(dev()), i.to(dev()))                 # the reference's call sequence (module path) after training
+        with torch.no_grad():
+            m.save_features_for_test()
+            top = m.top_items(eu.to(dev()), eq.to(dev()))
+            feats = m._saved_output_feature.clone()
+            m.clear_saved_feature()
+        results[mode] = (losses, {k: v.detach().cpu() for k, v in m.state_dict().items()}, top, feats, scores.detach())
+    g = ref.HyperGraph(triples, U, Q, I)
+    oracle = ref.OracleRawGnn(g, torch.from_numpy(w.bag_words + 1), torch.from_numpy(w.bag_offsets), w.vocab_size, dim, kind, layers, order)
+    oracle.load_reference_state({k: v.cpu().numpy() for k, v in init.items()})
+    oopt = torch.optim.Adam(oracle.parameters(), 1e-3)
+    lossf = torch.nn.BCEWithLogitsLoss()
+    want_losses = []
+    for u, q, i, y in batches:
+        loss = lossf(oracle(u, q, i), y)
+        loss.backward(); oopt.step(); oopt.zero_grad()
+        want_losses.append(loss.item())
+    with torch.no_grad():
+        want_feats = oracle.propagate()
+        want_scores = oracle(*batches[0][:3])
+    want_state = oracle.reference_state()
+    isolated = np.setdiff1d(np.arange(U + Q + I), np.concatenate([live_u, U + live_q, U + Q + live_i]))
+    for mode in ('1', '0'):
+        np.testing.assert_allclose(results[mode][0], want_losses, rtol=1e-4)
+        for name, value in results[mode][1].items():
+            assert float((value - want_state[name]).abs().max()) <= 1e-3, (mode, name)          # (see test_layout_with_hyperedge_multiplicities_training_steps)
+        digest = state_digest([v.numpy() for v in results[mode][1].values()])
+        np.testing.assert_allclose(digest[:, 1], state_digest([want_state[k].numpy() for k in results[mode][1]])[:, 1], rtol=1e-4)
+        cw = results[mode][3].shape[1] // (layers + 1)
+        got_feats = results[mode][3].view(-1, layers + 1, cw)[:, :, :dim].reshape(-1, (layers + 1) * dim).cpu()
+        assert rel(got_feats, want_feats) <= 5e-4
+        assert float(got_feats[isolated][:, dim:].abs().max()) == 0.0      # an isolated node's rows above layer 0 are exactly zero
+        assert rel(results[mode][4], want_scores) <= 5e-4
+    np.testing.assert_allclose(results['1'][0], results['0'][0], rtol=2e-5)
+    assert float((results['1'][2][0] == results['0'][2][0]).float().mean()) >= 0.9
+
+
 def test_user_ordered_hyperedge_numbering_is_equivalent():
     """The layout's internal renumbering (hyperedges sorted by user) only permutes edge-feature rows."""
     from ihgnn_amd import ops
@@ -1445,7 +1530,7 @@ F10_LAUNCHES = {
 }
 
 
-@pytest.mark.parametrize('path', ['module_calls', 'fused_step', 'fused_step_multiplicities'])
+@pytest.mark.parametrize('path', ['module_calls', 'fused_step', 'fused_step_multiplicities', 'fused_step_compact'])
 @pytest.mark.parametrize('tag', ['d128_l3_o3', 'd64_l2_o3', 'd32_l2_o3', 'd128_l3_o2', 'd256_l2_o3'])
 def test_f10_training_curve_and_ranking_metrics_on_the_headline_arithmetic(tag, path, monkeypatch):
     """The north_star's acceptance clause on the arithmetic the headline runs: 48 Adam steps of the REFERENCE (fixture F10: d = 128 x 3 layers orders 3 / 2,
@@ -1456,6 +1541,12 @@ def test_f10_training_curve_and_ranking_metrics_on_the_headline_arithmetic(tag, 
     from ihgnn_amd import ops, profiler
     from ihgnn_amd.Helpers.Metrics import Metrics
     (L, order, d), sd, z, w = f10_case(tag)
+    compact = path == 'fused_step_compact'
+    if compact:
+        # ... and with the isolated nodes left out of the layout's numbering (IHG_COMPACT_NODES=1; config C5's default): their layer outputs are exact zeros either way
+        from ihgnn_amd import layout as layout_mod
+        monkeypatch.setattr(layout_mod, 'COMPACT_NODES', '1')
+        path = 'fused_step'
     multiplicities = path == 'fused_step_multiplicities'
     if multiplicities:
         # the same reference curves with the fixture's repeated (user, query, item) triples collapsed into weighted rows (IHG_EDGE_MULTIPLICITY=1; what config C5
@@ -1474,6 +1565,9 @@ def test_f10_training_curve_and_ranking_metrics_on_the_headline_arithmetic(tag, 
         lay = ds.hypergraph.layout
         assert lay.edge_weight is not None and lay.edge_count < lay.hyperedge_count == ds.hypergraph.EdgeCount == len(w['triples'])
         print(f'F10 {tag}: {lay.hyperedge_count} interactions, {lay.edge_count} distinct hyperedges')
+    if compact:
+        lay = ds.hypergraph.layout
+        print(f'F10 {tag}: {lay.public_node_count} nodes, {lay.node_count} of them in a hyperedge' + ('' if lay.compact else ' (none isolated: the layout is the plain one)'))
     m = build_model(ds, 'ihgnn', L, order, d)
     assert set(sd) == set(m.state_dict())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -1495,6 +1589,8 @@ def test_f10_training_curve_and_ranking_metrics_on_the_headline_arithmetic(tag, 
     must, must_not = F10_LAUNCHES[tag]
     if c5_backward:
         must = must | {'k7.two_hop_first_order_gradient'}
+    if compact and ds.hypergraph.layout.compact:                        # X0 is assembled (no tables-in-place transform); the kernels of the layers are the same
+        must = must
     if multiplicities:                                                  # no gathering member-gradient kernel under multiplicities: K5 (x m_e) forms the cotangents
         must, must_not = (must - {'k7.two_hop_first_order_gradient'}) | {'edge_gather_sum'}, must_not - {'edge_gather_sum'}
     assert must <= set(launched) and not (must_not & set(launched)), sorted(launched)
@@ -1883,13 +1979,14 @@ def test_full_size_c5_interact_in_chunks():
     from ihgnn_amd.layout import IncidenceLayout
     from oracle import ihgnn_ref as ref
     w_ = synth.draw_config('C5')
-    # one row per interaction (IHG_EDGE_MULTIPLICITY=0; the default layout of this graph keeps its 25.6 M distinct triples - test_full_size_c5_node_level_layer runs that):
+    # one row per interaction and per node (IHG_EDGE_MULTIPLICITY=0, IHG_COMPACT_NODES=0; the default layout of this graph keeps its 25.6 M distinct triples and its 3.6 M
+    # nodes that have hyperedges - test_full_size_c5_node_level_layer runs that):
     # this test is about 50 M rows and a member buffer that must go through in chunks
-    lay = IncidenceLayout(w_.triples, w_.user_count, w_.query_count, w_.item_count, dev(), edge_multiplicity='0')
+    lay = IncidenceLayout(w_.triples, w_.user_count, w_.query_count, w_.item_count, dev(), edge_multiplicity='0', compact_nodes='0')
     del w_
     d, order, k = 256, 3, 7
     E = lay.edge_count
-    assert E == 50_000_000 and lay.node_count == 10_000_000 and lay.edge_weight is None
+    assert E == 50_000_000 and lay.node_count == 10_000_000 and lay.edge_weight is None and not lay.compact
     gen = torch.Generator(device=dev()).manual_seed(23)
     h = (torch.randn(lay.node_count, d, device=dev(), generator=gen) / 4).requires_grad_(True)
     p = torch.randn(lay.node_count, d, device=dev(), generator=gen).requires_grad_(True)
@@ -1977,6 +2074,8 @@ def test_full_size_c5_node_level_layer():
     ptr = lay.node_csr.ptr_host.astype(np.int64)
     # the DEFAULT layout of this graph: 48.7 % of its 50 M interactions repeat an earlier triple, so it keeps the 25.6 M distinct ones with their multiplicities
     assert lay.edge_weight is not None and lay.hyperedge_count == 50_000_000 and 25_000_000 < lay.edge_count < 26_000_000 and ops.two_hop_merged_for(lay)
+    # ... and 64 % of its 10 M nodes are in no hyperedge: the layout numbers the other 3.6 M
+    assert lay.compact and lay.public_node_count == 10_000_000 and 3_400_000 < lay.node_count < 3_800_000
     mult = edge_mult(lay)
     hc, wc, bc, scale_c = h.detach(), wgt.detach().cpu().double(), bias.detach().cpu().double(), scale.cpu().double()
     for v in np.concatenate([nodes[:8], nodes[(nodes >= u_) & (nodes < uq_)][:4], nodes[nodes >= uq_][:8]]):

@@ -504,6 +504,59 @@ def test_unique_triples_and_weighted_layout():
     np.testing.assert_array_equal(g.I3.numpy(), triples + offs)
 
 
+def test_layout_without_the_isolated_nodes():
+    """``IncidenceLayout(compact_nodes='1')``: the nodes that are in no hyperedge are left out of the layout's own numbering (their layer outputs are exactly zero, SURVEY
+    App. B 2): the compact graph is the public one renamed through ``node_map`` / ``active_nodes``, every per-node array is the public one restricted to the active nodes,
+    the reference-shaped views (``VertexDegrees`` with its 1e-8, ``I3``, ``Adjacency``) stay public.  auto: by the share of isolated nodes, large graphs only."""
+    from ihgnn_amd import layout as layout_mod
+    from ihgnn_amd.Helpers.Graph import PpsHyperGraph
+    rng = np.random.default_rng(5)
+    U, Q, I = 900, 40, 700
+    live_u, live_i = rng.choice(U, 300, replace=False), rng.choice(I, 250, replace=False)
+    triples = np.stack([rng.choice(live_u, 5000), rng.integers(0, Q, 5000), rng.choice(live_i, 5000)], 1)
+    full = IncidenceLayout(triples, U, Q, I, CPU, compact_nodes='0', edge_multiplicity='0')
+    lay = IncidenceLayout(triples, U, Q, I, CPU, compact_nodes='1', edge_multiplicity='0')
+    assert not full.compact and full.node_map is None and lay.compact
+    assert (lay.public_user_count, lay.public_query_count, lay.public_item_count, lay.public_node_count) == (U, Q, I, U + Q + I)
+    alive = np.zeros(U + Q + I, bool)
+    alive[np.unique(triples + np.array([0, U, U + Q]))] = True
+    assert lay.node_count == int(alive.sum()) < U + Q + I and abs(lay.isolated_share - (1 - alive.mean())) < 1e-12
+    assert lay.user_count == len(np.unique(triples[:, 0])) and lay.item_count == len(np.unique(triples[:, 2]))
+    node_map, active = lay.node_map.numpy(), lay.active_nodes.numpy()
+    np.testing.assert_array_equal(np.nonzero(alive)[0], active)
+    np.testing.assert_array_equal(node_map[active], np.arange(lay.node_count))
+    assert (node_map[~alive] == -1).all()
+    # the same hypergraph, renamed: members, lists, degrees
+    np.testing.assert_array_equal(active[lay.i3_host], full.i3_host)
+    for name in ('degree', 'inv_deg', 'inv_sqrt_deg', 'self_weight'):
+        assert torch.equal(getattr(lay, name), getattr(full, name)[lay.active_nodes]), name
+    fp, cp = full.node_csr.ptr_host.astype(np.int64), lay.node_csr.ptr_host.astype(np.int64)
+    np.testing.assert_array_equal(np.diff(cp), np.diff(fp)[active])
+    np.testing.assert_array_equal(lay.node_csr.ids_host, full.node_csr.ids_host)
+    np.testing.assert_array_equal(active[lay.hop2_csr.ids_host], full.hop2_csr.ids_host)
+    assert torch.equal(lay.compact_rows(torch.tensor([int(active[3]), int(np.nonzero(~alive)[0][0])])), torch.tensor([3, -1]))
+    assert torch.equal(lay.compact_rows(torch.tensor([int(np.nonzero(~alive)[0][0])]), isolated_to=0), torch.tensor([0]))
+    # reference-shaped views stay public
+    g = PpsHyperGraph()
+    g.layout, g.EdgeCount = lay, lay.hyperedge_count
+    want_deg = np.bincount((triples + np.array([0, U, U + Q])).reshape(-1), minlength=U + Q + I).astype(np.float32)
+    want_deg[want_deg == 0] = 1e-8
+    np.testing.assert_array_equal(g.VertexDegrees.numpy()[:, 0], want_deg)
+    np.testing.assert_array_equal(g.I3.numpy(), triples + np.array([0, U, U + Q]))
+    assert tuple(g.Adjacency.shape) == (U + Q + I, 5000)
+    # with multiplicities on top
+    both = IncidenceLayout(np.concatenate([triples, triples[:2000]]), U, Q, I, CPU, compact_nodes='1', edge_multiplicity='1')
+    assert both.compact and both.edge_weight is not None and both.node_count == lay.node_count and both.hyperedge_count == 7000
+    assert torch.equal(both.public_degree()[lay.active_nodes], both.degree) and float(both.degree.sum()) == 3 * 7000
+    # auto: small graphs and graphs with few isolated nodes are left alone
+    assert not IncidenceLayout(triples, U, Q, I, CPU).compact
+    big = synth.draw(60000, 2000, 60000, 10, 40000, seed=2)                    # 122 k nodes, most of them never drawn
+    assert IncidenceLayout(big.triples, 60000, 2000, 60000, CPU).compact
+    dense = synth.draw(30000, 2000, 34000, 10, 600000, seed=2)
+    auto = IncidenceLayout(dense.triples, 30000, 2000, 34000, CPU)
+    assert not auto.compact and 0 <= auto.isolated_share < layout_mod.COMPACT_MIN_SHARE
+
+
 # ---------------------------------------------------------------------------------------------
 # the operand splits of the contraction kernels, emulated (tests/split_emulation.py; csrc/split_common.hpp)
 # ---------------------------------------------------------------------------------------------

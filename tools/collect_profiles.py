@@ -44,7 +44,8 @@ def main():
                            '--no-extras --no-kernel-events   (one pass per counter, in situ: every kernel of the training step)',
                    notes='KiB counters; FETCH_SIZE doubled (gfx950 counts 128-B requests of wide reads as 64 B); both counters sit at the L2 <-> fabric '
                          'boundary, so Infinity-Cache hits are included: hbm_bytes_per_launch is L2-miss traffic, an upper bound of the HBM bytes',
-                   workload=config, dim=bench['config']['dim'], edges=bench['config']['edges'], commit=head_commit(), kernels=table)
+                   workload=config, dim=bench['config']['dim'], edges=bench['config']['edges'], rows=bench['config'].get('distinct_hyperedges', bench['config']['edges']),
+                   node_rows=bench['config'].get('nodes_in_hyperedges', bench['config']['nodes']), commit=head_commit(), kernels=table)
         for key, v in table.items():
             if key.startswith('edge_gather_sum_kernel'):
                 out['edge_gather_sum'] = dict(hbm_bytes_per_launch=v['hbm_bytes_per_launch'], avg_us_under_pmc=v['avg_us_under_pmc'])
