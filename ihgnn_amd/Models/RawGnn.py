@@ -99,6 +99,14 @@ class RawGnn(nn.Module):
                 and (batch_rows is None or int(batch_rows.shape[0]) <= ops.SCATTER_CHUNK_ROWS)):
             # a training step through the fused batch tail: X0 is not assembled - the first layer's transform and the tail read the embedding tables in place
             x = self.embeddings.node_tables(tail_gradients)
+        tables = None
+        if (tail_gradients is not None and last >= 1 and ops.NODE_TABLES and not padded and compact is not None
+                and (batch_rows is None or int(batch_rows.shape[0]) <= ops.SCATTER_CHUNK_ROWS)):
+            # ... over a layout without the isolated nodes: the active nodes' rows are gathered straight from the tables ([N', d]; the public [N, d] is never assembled), the
+            # tail reads its layer-0 rows from the tables in place and the gather's backward adds their gradients to the tables' gradients
+            tables = self.embeddings.node_tables(tail_gradients)
+            if tables is not None:
+                x = ops.gather_active_nodes(tables, compact)
         if x is None:
             x = self.embeddings.all_nodes()
             if padded:
@@ -127,13 +135,16 @@ class RawGnn(nn.Module):
                 if isinstance(x, ops.NodeTables):
                     outputs.append(x)                        # (no tap: the first layer's transform adds the tail's layer-0 gradients itself)
                     continue
+                if depth == 0 and tables is not None:
+                    outputs.append(tables)                   # (no tap either: the gather's backward adds them; x is already the layout's [N', d])
+                    continue
                 x, for_tail = ops.tap(x, tail_gradients, depth, sparse_top)
                 outputs.append(for_tail)
             elif compact is not None and depth > 0:
                 outputs.append(self._to_public_rows(x, compact))
             else:
                 outputs.append(x)
-            if compact is not None and depth == 0:
+            if compact is not None and depth == 0 and tables is None:
                 x = x.index_select(0, compact.active_nodes)  # X0 of the nodes that have hyperedges: what the layers run on
         return outputs
 

@@ -556,6 +556,12 @@ class NodeTables:
         step = self.dim * 4
         return (ctypes.c_void_p * 3)(self.user_table.data_ptr() + step, self.query_rows.data_ptr(), self.item_table.data_ptr() + step)
 
+    def type_begin(self):
+        """First row of every node type in the numbering the TABLES are addressed by (the public one: ``[0, U, U + Q, N]``) - the layout's own unless it leaves the isolated
+        nodes out (``gather_active_nodes`` sets it then)."""
+        tb = getattr(self, '_public_type_begin', None)
+        return tb if tb is not None else _type_begin(self.layout)
+
     @staticmethod
     def supported(user_table: Tensor, item_table: Tensor, word_table: Tensor) -> bool:
         lib = _lib.load()
@@ -632,6 +638,78 @@ class _LinearFromTables(torch.autograd.Function):
             _lib.check(lib.ihg_bag_mean_bwd(_ptr(d_query), dim, _ptr(bag.words_of.ptr), _ptr(bag.words_of.ids), _ptr(bag.inv_len), _ptr(d_word), dim, bag.table_rows, dim,
                                             _stream()), 'ihg_bag_mean_bwd')
         return d_user, d_item, d_word, dw, dbias, None, None, None, None
+
+
+class _GatherActiveNodes(torch.autograd.Function):
+    """``X0`` of the nodes that have hyperedges, ``[N', d]`` in the numbering of a layout that leaves the isolated nodes out (``IncidenceLayout.compact``), gathered from the
+    embedding tables' rows and the query bag means - the public ``[N, d]`` matrix is never assembled.  Resolves the ``NodeTables`` for the batch tail as the first
+    node-level transform does otherwise: the tail reads its layer-0 rows from the tables in place (public ids) and this op's backward adds their gradients to the tables'
+    gradients - dense ``[U + 1, d]`` / ``[I + 1, d]`` / ``[V + 1, d]`` tensors whose rows are zero for nodes that are neither active nor in the batch."""
+
+    @staticmethod
+    def forward(ctx, user_table: Tensor, item_table: Tensor, word_table: Tensor, nodes: NodeTables, layout: IncidenceLayout):
+        lib = _lib.load()
+        bag, dim = nodes.bag, nodes.dim
+        u_pub, q_pub = layout.public_user_count, layout.public_query_count
+        query_rows = torch.empty(bag.n_bags, dim, dtype=torch.float32, device=word_table.device)
+        if bag.n_bags > 0:
+            with profiler.kernel('bag_mean_fwd', bag.n_bags, dim):
+                _lib.check(lib.ihg_bag_mean_fwd(_ptr(word_table), dim, _ptr(bag.bags.ptr), _ptr(bag.bags.ids), _ptr(bag.bag_len), _ptr(query_rows), dim, bag.n_bags, dim,
+                                                _stream()), 'ihg_bag_mean_fwd')
+        nodes.query_rows, nodes.layout = query_rows, layout
+        nodes._public_type_begin = (ctypes.c_int64 * 4)(0, u_pub, u_pub + q_pub, layout.public_node_count)
+        nodes.token = torch.empty(1, dtype=torch.float32, device=word_table.device)
+        picks = getattr(layout, '_active_table_rows', None)
+        if picks is None:
+            act = layout.active_nodes
+            ua, qa = layout.user_count, layout.query_count
+            picks = layout._active_table_rows = (act[:ua] + 1, act[ua:ua + qa] - u_pub, act[ua + qa:] - (u_pub + q_pub) + 1)      # table rows (row 0 = padding), query ids
+        ua, qa = int(picks[0].shape[0]), int(picks[1].shape[0])
+        x = torch.empty(layout.node_count, dim, dtype=torch.float32, device=word_table.device)
+        torch.index_select(user_table, 0, picks[0], out=x[:ua])
+        torch.index_select(query_rows, 0, picks[1], out=x[ua:ua + qa])
+        torch.index_select(item_table, 0, picks[2], out=x[ua + qa:])
+        ctx.save_for_backward(user_table, item_table)
+        ctx.nodes, ctx.layout, ctx.picks = nodes, layout, picks
+        ctx.mark_non_differentiable(query_rows)
+        ctx.set_materialize_grads(False)
+        return x, nodes.token, query_rows
+
+    @staticmethod
+    def backward(ctx, grad_x: Tensor, _grad_token, _grad_rows):
+        lib = _lib.load()
+        user_table, item_table = ctx.saved_tensors
+        nodes, layout, picks = ctx.nodes, ctx.layout, ctx.picks
+        bag, dim = nodes.bag, nodes.dim
+        if grad_x is None:
+            raise RuntimeError('the gathered input features received no gradient')
+        g = _rows(grad_x, 'grad of the gathered input features')
+        ua, qa = int(picks[0].shape[0]), int(picks[1].shape[0])
+        d_user, d_item = torch.zeros_like(user_table), torch.zeros_like(item_table)
+        d_query = torch.zeros(bag.n_bags, dim, dtype=torch.float32, device=g.device)
+        d_user.index_copy_(0, picks[0], g[:ua])
+        d_query.index_copy_(0, picks[1], g[ua:ua + qa])
+        d_item.index_copy_(0, picks[2], g[ua + qa:])
+        holder = nodes.holder
+        if holder is not None and holder.rowgrad is not None:              # the batch tail's gradient of its layer-0 rows (public ids; isolated batch nodes included)
+            step = dim * 4
+            dx_rows = (ctypes.c_void_p * 3)(d_user.data_ptr() + step, d_query.data_ptr(), d_item.data_ptr() + step)
+            holder.put_into_typed(dx_rows, dim, layout, 0, dim, type_begin=nodes._public_type_begin)
+        d_word = torch.empty(bag.table_rows, dim, dtype=torch.float32, device=g.device)
+        with profiler.kernel('bag_mean_bwd', bag.table_rows, dim):
+            _lib.check(lib.ihg_bag_mean_bwd(_ptr(d_query), dim, _ptr(bag.words_of.ptr), _ptr(bag.words_of.ids), _ptr(bag.inv_len), _ptr(d_word), dim, bag.table_rows, dim,
+                                            _stream()), 'ihg_bag_mean_bwd')
+        return d_user, d_item, d_word, None, None
+
+
+def gather_active_nodes(nodes: NodeTables, layout: IncidenceLayout) -> Tensor:
+    """``[N', d]`` input features of the nodes of a compact layout straight from the embedding tables (``NodeTables``), which it resolves for the batch tail."""
+    if not getattr(layout, 'compact', False):
+        raise ValueError('gather_active_nodes is for a layout that leaves the isolated nodes out')
+    if nodes.query_rows is not None:
+        raise RuntimeError('NodeTables: the input features were already consumed (one per forward)')
+    x, _token, _rows_q = _GatherActiveNodes.apply(nodes.user_table, nodes.item_table, nodes.word_table, nodes, layout)
+    return x
 
 
 def node_linear(x, w: Tensor, bias: Optional[Tensor], layout: IncidenceLayout, typed: bool = False, bias_mask: int = 0b111) -> Tensor:
@@ -1141,7 +1219,7 @@ def _hem_row_gradients(layers, rows: Tensor, items: Tensor, bias: Tensor, lam: f
                                                     float(grad_scale), float(lam), _ptr(rowgrad), width + 4, batch, _stream()), 'ihg_hem_score_bwd_typed0')
         else:
             ptrs = (ctypes.c_void_p * n_layers)(tables.query_rows.data_ptr(), *[x.data_ptr() for x in layers])
-            _lib.check(lib.ihg_hem_score_bwd_typed0(ptrs, n_layers, _ld(layers[0]) if layers else dim, dim, tables.row_pointers(), dim, _type_begin(tables.layout), _ptr(rows),
+            _lib.check(lib.ihg_hem_score_bwd_typed0(ptrs, n_layers, _ld(layers[0]) if layers else dim, dim, tables.row_pointers(), dim, tables.type_begin(), _ptr(rows),
                                                     _ptr(rows_upper), _ptr(dscores), _ptr(grad_scale_device), float(grad_scale), float(lam), _ptr(rowgrad), width + 4, batch, _stream()),
                        'ihg_hem_score_bwd_typed0')
     return rowgrad
@@ -1211,9 +1289,10 @@ class TailGradients:
     def _rows_of(self, upper: bool) -> Tensor:
         return self.rows_upper if (upper and self.rows_upper is not None) else self.rows
 
-    def put_into_typed(self, dense_rows, ld_dense: int, layout, col0: int, width: int) -> None:
-        """``add_into`` for a destination whose node types start at their own addresses (``dense_rows``: host array of three device pointers)."""
-        _put_rows(self, dense_rows, ld_dense, layout, col0, width, False)
+    def put_into_typed(self, dense_rows, ld_dense: int, layout, col0: int, width: int, type_begin=None) -> None:
+        """``add_into`` for a destination whose node types start at their own addresses (``dense_rows``: host array of three device pointers; ``type_begin``: the first row
+        of every type in the destination's numbering when that is not the layout's - the embedding tables under a layout without the isolated nodes)."""
+        _put_rows(self, dense_rows, ld_dense, layout, col0, width, False, False, type_begin)
 
     def assign_into(self, dense: Tensor, layout, col0: int, width: int, upper: bool = False) -> None:
         """``dense[rows[k]] = rowgrad[k, col0 : col0 + width]`` on the (combined) batch rows, nothing else written: a gradient that is zero outside the batch rows
@@ -1241,7 +1320,7 @@ class TailGradients:
                                               int(tail.shape[0]) if tail is not None else 0, _stream()), 'ihg_batch_rows_add')
 
 
-def _put_rows(holder: 'TailGradients', dense_rows, ld_dense: int, layout, col0: int, width: int, assign: bool, upper: bool = False) -> None:
+def _put_rows(holder: 'TailGradients', dense_rows, ld_dense: int, layout, col0: int, width: int, assign: bool, upper: bool = False, type_begin=None) -> None:
     lib = _lib.load()
     if holder.leader is None:
         raise _lib.IhgnnHipError('typed / assigning row scatter needs the combined row gradients (batches of at most 32,768 rows)')
@@ -1250,7 +1329,7 @@ def _put_rows(holder: 'TailGradients', dense_rows, ld_dense: int, layout, col0: 
     src = holder.rowgrad[:, col0:]
     with profiler.kernel('batch_rows_add', n, width):
         _lib.check(lib.ihg_batch_rows_put(_ptr(src), int(holder.rowgrad.stride(0)), width, _ptr(rows), _ptr(holder.leader), n, dense_rows, ld_dense,
-                                          _type_begin(layout), 1 if assign else 0, _stream()), 'ihg_batch_rows_put')
+                                          type_begin if type_begin is not None else _type_begin(layout), 1 if assign else 0, _stream()), 'ihg_batch_rows_put')
 
 
 class _Tap(torch.autograd.Function):
@@ -1362,7 +1441,7 @@ class _HemBceLoss(torch.autograd.Function):
                                                         _ptr(scores), batch, _stream()), 'ihg_hem_score_fwd_typed0')
             else:
                 ptrs = (ctypes.c_void_p * (len(real) + 1))(tables.query_rows.data_ptr(), *[x.data_ptr() for x in real])     # (slot 0 is replaced by the typed rows)
-                _lib.check(lib.ihg_hem_score_fwd_typed0(ptrs, len(real) + 1, _ld(real[0]) if real else dim, dim, tables.row_pointers(), dim, _type_begin(tables.layout),
+                _lib.check(lib.ihg_hem_score_fwd_typed0(ptrs, len(real) + 1, _ld(real[0]) if real else dim, dim, tables.row_pointers(), dim, tables.type_begin(),
                                                         _ptr(rows), _ptr(rows_upper), _ptr(items), _ptr(bias), float(lam), _ptr(scores), batch, _stream()), 'ihg_hem_score_fwd_typed0')
             _lib.check(lib.ihg_bce_with_logits(_ptr(scores), _ptr(labels), batch, _ptr(loss), _ptr(dscores), _stream()), 'ihg_bce_with_logits')
         ctx.save_for_backward(rows, items, bias, dscores, *real)
