@@ -159,7 +159,7 @@ class RawGnn(nn.Module):
         strides, layer l reads columns ``(l-1) d ..`` and writes columns ``l d ..`` of the same buffer - so there is no concatenation
         pass over ``[N, D]``.  Under autograd the outputs are separate tensors and are concatenated."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return torch.cat(self.propagate_layers(), 1)
+            return self._without_padding_columns(torch.cat(self.propagate_layers(), 1))
         d, cw = self.embedding_size, self.compute_width
         w = self.embeddings.embedding_bag_vocabulary.weight
         features = torch.empty(self.dataset.node_count, cw * (1 + self.gnn_layer_count), dtype=torch.float32, device=w.device)
@@ -175,10 +175,18 @@ class RawGnn(nn.Module):
             for depth, layer in enumerate(self.gnns, 1):
                 x = layer(x)
                 features[:, depth * cw:(depth + 1) * cw].index_copy_(0, compact.active_nodes, x)
-            return features
+            return self._without_padding_columns(features)
         for depth, layer in enumerate(self.gnns, 1):
             x = layer(x, out=features[:, depth * cw:(depth + 1) * cw])
-        return features
+        return self._without_padding_columns(features)
+
+    def _without_padding_columns(self, features: Tensor) -> Tensor:
+        """``[N, cw (L + 1)]`` computed at a padded width -> the reference's ``[N, d (L + 1)]`` (``RawGnn.py:122``): the zero columns between the layers' blocks cut out."""
+        d, cw = self.embedding_size, self.compute_width
+        if cw == d:
+            return features
+        n = features.shape[0]
+        return features.view(n, 1 + self.gnn_layer_count, cw)[:, :, :d].reshape(n, self.output_feature_size)
 
     def forward(self, user_indices: Tensor, query_indices: Tensor, item_indices: Optional[Tensor] = None) -> Tensor:
         """Indices are 0-based per type.  ``item_indices=None`` scores the given (user, query) against every item."""

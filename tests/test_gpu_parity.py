@@ -543,12 +543,12 @@ def test_models_at_widths_between_the_tiled_ones(kind, dim, monkeypatch):
         with torch.no_grad():
             feats = m.propagate()
             top = m.top_items(batches[0][0][:9].to(dev()), batches[0][1][:9].to(dev()))
-        cw = m.compute_width
-        assert tuple(feats.shape) == (U + Q + I, 3 * cw)
-        blocks = feats.view(-1, 3, cw)
+        assert tuple(feats.shape) == (U + Q + I, 3 * dim)                 # the reference's [N, d (L + 1)] whatever width the kernels ran at
         if pad:
-            assert float(blocks[:, :, dim:].abs().max()) == 0.0           # the padding columns stay exactly zero through every layer
-        results[pad] = (losses, {k: v.detach().cpu() for k, v in m.state_dict().items()}, blocks[:, :, :dim].reshape(-1, 3 * dim).cpu(), top)
+            with torch.no_grad():
+                inner = m.gnns[1](m.gnns[0](ops.pad_columns(m.embeddings.all_nodes(), m.compute_width)))
+            assert tuple(inner.shape) == (U + Q + I, m.compute_width) and float(inner[:, dim:].abs().max()) == 0.0      # the padding columns stay exactly zero through the layers
+        results[pad] = (losses, {k: v.detach().cpu() for k, v in m.state_dict().items()}, feats.cpu(), top)
     g = ref.HyperGraph(w.triples, U, Q, I)
     oracle = ref.OracleRawGnn(g, torch.from_numpy(w.bag_words + 1), torch.from_numpy(w.bag_offsets), w.vocab_size, dim, kind, 2, 3)
     oracle.load_reference_state({k: v.cpu().numpy() for k, v in init.items()})
@@ -645,8 +645,8 @@ def test_models_over_a_layout_without_the_isolated_nodes(kind, layers, order, di
             assert float((value - want_state[name]).abs().max()) <= 1e-3, (mode, name)          # (see test_layout_with_hyperedge_multiplicities_training_steps)
         digest = state_digest([v.numpy() for v in results[mode][1].values()])
         np.testing.assert_allclose(digest[:, 1], state_digest([want_state[k].numpy() for k in results[mode][1]])[:, 1], rtol=1e-4)
-        cw = results[mode][3].shape[1] // (layers + 1)
-        got_feats = results[mode][3].view(-1, layers + 1, cw)[:, :, :dim].reshape(-1, (layers + 1) * dim).cpu()
+        got_feats = results[mode][3].cpu()
+        assert tuple(got_feats.shape) == tuple(want_feats.shape)
         assert rel(got_feats, want_feats) <= 5e-4
         assert float(got_feats[isolated][:, dim:].abs().max()) == 0.0      # an isolated node's rows above layer 0 are exactly zero
         assert rel(results[mode][4], want_scores) <= 5e-4
