@@ -35,7 +35,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # IHG_DIST_BACKEND=gloo: the driver's ranks on ONE GPU (RCCL refuses two ranks per device): how the multi-rank training loop is tested on a single-GPU box
+            backend = os.environ.get('IHG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl' and local < torch.cuda.device_count():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -2327,6 +2327,45 @@ def test_driver_end_to_end(tmp_path, monkeypatch):
         assert abs(m_e.NDCG_at10 - m_a.NDCG_at10) <= 2e-3 and abs(m_e.HitRatio_at10 - m_a.HitRatio_at10) <= 2e-3
 
 
+def test_driver_with_two_ranks_on_one_gpu(tmp_path):
+    """``python -m ihgnn_amd.Main`` as two ranks (both on GPU 0, gloo between them: ``IHG_DIST_BACKEND``): the data-parallel training loop end to end - the sharded batch
+    sampler (501 positives: the ranks' batches differ by a row, which the cotangent exchange pads), per-rank negatives, ``--grad_sync auto | cotangent | flat``, sharded
+    evaluation with all-reduced metric sums, the chief's checkpoint.  The exchanges are the same mathematics (the gradient of the mean of the ranks' losses): the
+    checkpoints of the cotangent and the flat run agree to the noise of their different summation orders."""
+    import socket
+    import subprocess
+    import sys
+    from ihgnn_amd import synth
+    w = synth.draw(60, 20, 80, 25, 501, seed=4, eval_logs=30)
+    synth.write_files(w, str(tmp_path / 'Data' / 'Synth' / 'Tiny'))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    states = {}
+    for sync in ('cotangent', 'flat', 'auto'):
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), IHG_DIST_BACKEND='gloo',
+                       HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=repo + os.pathsep + os.environ.get('PYTHONPATH', ''))
+            procs.append(subprocess.Popen([sys.executable, '-m', 'ihgnn_amd.Main', '--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '2',
+                                           '--est', '2', '--etf', '1', '-c', '--device', '0', '--grad_sync', sync], cwd=str(tmp_path), env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=600)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs[0][-3000:] + outs[1][-3000:]
+        if sync == 'auto':
+            assert 'gradient exchange: ' in outs[0]
+            continue
+        result_dir = tmp_path / 'Results' / 'Synth-Tiny-RawGnn-2IHGNNLayer-O3-emb32'
+        saved = sorted(n for n in os.listdir(result_dir) if n.startswith('checkpoint_'))
+        states[sync] = torch.load(os.path.join(result_dir, saved[-1]), map_location='cpu')['model']
+        for n in saved:
+            os.remove(os.path.join(result_dir, n))
+    for name, value in states['cotangent'].items():
+        assert torch.isfinite(value).all()
+        assert float((value - states['flat'][name]).abs().max()) <= 1e-3, name      # (six Adam steps of 1e-3 each: an exchange that dropped a rank's gradient would move entries by that much)
+
+
 @pytest.mark.parametrize('tag,d,mode', [('tiny_uqi', 8, 'uqi'), ('small_uqi', 64, 'uqi'), ('small_ui', 32, 'ui'), ('tiny_qi', 8, 'qi')])
 def test_f7_gcn_layer_matches_reference(tag, d, mode):
     """f3: GCNLayer over the pairwise graph = the K7 kernel on a weighted CSR with both D^-1/2 scalings fused."""
@@ -2833,6 +2872,13 @@ def test_two_ranks_of_the_hip_model_equal_one_rank_on_the_union_batch(sync):
     r = _run(['tools/two_rank_check.py', '--ranks', '2', '--sync', sync, '--device', '0', '--backend', 'gloo'])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'OK' in r.stdout
+
+
+def test_eight_ranks_exchange_cotangents_of_a_union_beyond_one_combine_instance():
+    """Eight processes on GPU 0 (gloo), 700 batch rows each, the cotangent exchange: the union of the ranks' batch rows is 16,800 - the wide (128 KiB of LDS) instance of the
+    combine kernel, what eight ranks of 1,100 rows (26,400) run on an 8-GPU node - and the replicas must stay bitwise identical and equal the one-rank run on all 5,600 rows."""
+    r = _run(['tools/two_rank_check.py', '--ranks', '8', '--sync', 'cotangent', '--device', '0', '--backend', 'gloo', '--batch', '700'])
+    assert r.returncode == 0 and 'OK' in r.stdout and 'DIVERGED' not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize('sync', ['flat', 'bucketed', 'sharded', 'cotangent'])

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--device', type=int, default=0)
     ap.add_argument('--backend', default='gloo')
     ap.add_argument('--dim', type=int, default=64)
+    ap.add_argument('--batch', type=int, default=64, help='batch rows per rank (8 ranks x 700: the union of the ranks\' 3 B batch rows exceeds 16,384 - the wide instance of the combine kernel)')
     args = ap.parse_args()
     if 'WORLD_SIZE' not in os.environ:
         import socket
@@ -60,7 +61,7 @@ def main():
         return RawGnn(dev, ds, args.dim, IHGNNLayer, 2, 3, False, HemPredictionLayer, 0.5).to(dev)
 
     rng = np.random.default_rng(8)
-    B = 64 * world
+    B = args.batch * world
     u, q, i = (torch.from_numpy(rng.integers(0, n, B)).to(dev) for n in (300, 40, 200))
     y = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32)).to(dev)
 
