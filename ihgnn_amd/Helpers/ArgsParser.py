@@ -24,6 +24,7 @@ _FLAGS = (
     # not in the reference: batches (positive permutation + negative sampling) produced on the GPU instead of by DataLoader + random.sample
     ('device_sampling', ('--device_sampling',), 'flag', False, 'draw training batches on the device (same distribution, different random stream)'),
     ('grad_sync', ('--grad_sync',), str, 'auto', 'gradient exchange under torchrun: auto | cotangent (batch-row cotangents: no dense exchange) | flat | bucketed | sharded (ihgnn_amd.distributed)'),
+    ('seed', ('--seed',), int, -1, 'seed torch / random / numpy before the model is built (the reference seeds nothing, Main.py: -1 leaves the generators alone)'),
     ('record_step', ('--record_step',), 'optional', 'auto', 'replay the training step as one recorded hipGraph (single process): auto (default: when an eager step measures launch-bound, '
                                                              '< 1.5 ms) | on (also a bare --record_step) | off'),
 )

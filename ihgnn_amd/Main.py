@@ -40,6 +40,11 @@ def main(argv: Optional[Sequence[str]] = None) -> MetricsCollection:
     rank, local_rank, world = ihg_dist.init_from_env()
     chief = rank == 0
 
+    if getattr(args, 'seed', -1) is not None and int(getattr(args, 'seed', -1)) >= 0:
+        # not in the reference (which seeds nothing): reproducible runs - the initial weights, the loader's shuffles and the sampled negatives follow from --seed
+        import random
+        import numpy
+        random.seed(int(args.seed)); numpy.random.seed(int(args.seed)); torch.manual_seed(int(args.seed))
     Gs.graph_completeness = args.completeness
     Gs.long_tail_stat_fn = args.long_tail_filename or None
     Gs.embedding_size = args.embedding_size or Gs.embedding_size

@@ -2349,7 +2349,7 @@ def test_driver_with_two_ranks_on_one_gpu(tmp_path):
             env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), IHG_DIST_BACKEND='gloo',
                        HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONPATH=repo + os.pathsep + os.environ.get('PYTHONPATH', ''))
             procs.append(subprocess.Popen([sys.executable, '-m', 'ihgnn_amd.Main', '--ds', 'Synth/Tiny/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '2',
-                                           '--est', '2', '--etf', '1', '-c', '--device', '0', '--grad_sync', sync], cwd=str(tmp_path), env=env,
+                                           '--est', '2', '--etf', '1', '-c', '--device', '0', '--grad_sync', sync, '--seed', '3'], cwd=str(tmp_path), env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         outs = [p.communicate(timeout=600)[0] for p in procs]
         assert all(p.returncode == 0 for p in procs), outs[0][-3000:] + outs[1][-3000:]
