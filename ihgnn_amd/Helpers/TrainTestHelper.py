@@ -210,6 +210,14 @@ def train_and_get_avg_loss(model, optimizer: optim.Optimizer, loss_function: nn.
                 IOHelper.LogPrint(f'eager training step {step_ms:.2f} ms: ' + ('launch-bound - from here on ONE recorded step (hipGraph) is replayed' if decision
                                                                               else 'GPU-bound - steps stay eager'))
     avg_loss = loss_sum.item() / max(batches, 1)
+    if getattr(grad_sync, 'mode', None) == 'cotangent' and grad_sync.world_size > 1:
+        # the cotangent exchange never moves a parameter or a dense gradient between the ranks: the replicas stay identical because every rank takes the same deterministic
+        # step.  Once per epoch that is CHECKED (one broadcast of the parameters); a drift - a non-deterministic kernel, a rank that skipped a step - is reported and
+        # healed from rank 0 instead of growing silently
+        drift = grad_sync.check_replicas()
+        if drift != 0.0:
+            IOHelper.LogPrint(f'WARNING: replicas drifted apart under --grad_sync cotangent (largest parameter difference {drift:.3e}); re-broadcasting rank 0\'s parameters')
+            grad_sync.broadcast_parameters(0)
     if grad_sync is not None and grad_sync.world_size > 1:  # every rank reports (and schedules its learning rate on) the global average
         from .. import distributed as ihg_dist
         total, count = ihg_dist.all_reduce_sums([avg_loss * batches, float(batches)], device)
