@@ -2874,6 +2874,15 @@ def test_two_ranks_of_the_hip_model_equal_one_rank_on_the_union_batch(sync):
     assert 'OK' in r.stdout
 
 
+@pytest.mark.parametrize('sync', ['cotangent', 'bucketed'])
+def test_two_ranks_over_a_collapsed_layout(sync):
+    """The same check over config C5's kind of layout at toy size - isolated nodes left out of the numbering, repeated triples kept once with a multiplicity
+    (``IHG_COMPACT_NODES=1``, ``IHG_EDGE_MULTIPLICITY=1``): under the cotangent exchange the union's public rows go through the layout's node map AFTER the all-gather
+    (isolated nodes of OTHER ranks' batches included)."""
+    r = _run(['tools/two_rank_check.py', '--ranks', '2', '--sync', sync, '--device', '0', '--backend', 'gloo', '--collapsed'])
+    assert r.returncode == 0 and 'OK' in r.stdout and 'DIVERGED' not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_eight_ranks_exchange_cotangents_of_a_union_beyond_one_combine_instance():
     """Eight processes on GPU 0 (gloo), 700 batch rows each, the cotangent exchange: the union of the ranks' batch rows is 16,800 - the wide (128 KiB of LDS) instance of the
     combine kernel, what eight ranks of 1,100 rows (26,400) run on an 8-GPU node - and the replicas must stay bitwise identical and equal the one-rank run on all 5,600 rows."""

@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--device', type=int, default=0)
     ap.add_argument('--backend', default='gloo')
     ap.add_argument('--dim', type=int, default=64)
+    ap.add_argument('--collapsed', action='store_true', help='a graph with isolated nodes and repeated triples under IHG_COMPACT_NODES=1 / IHG_EDGE_MULTIPLICITY=1: the layout numbers '
+                    'only the nodes that have hyperedges and keeps every distinct triple once (config C5\'s default) - the exchange maps the union\'s rows through the layout\'s node map')
     ap.add_argument('--batch', type=int, default=64, help='batch rows per rank (8 ranks x 700: the union of the ranks\' 3 B batch rows exceeds 16,384 - the wide instance of the combine kernel)')
     args = ap.parse_args()
     if 'WORLD_SIZE' not in os.environ:
@@ -54,7 +56,18 @@ def main():
     dev = torch.device(f'cuda:{args.device if args.device >= 0 else local}')
     torch.cuda.set_device(dev)
     w = synth.draw(300, 40, 200, 50, 4000, seed=21)
-    ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets, w.triples, device=dev)
+    triples = w.triples
+    if args.collapsed:
+        from ihgnn_amd import layout as layout_mod
+        layout_mod.COMPACT_NODES = layout_mod.EDGE_MULTIPLICITY = '1'
+        g = np.random.default_rng(4)
+        live = [g.choice(n, n // 3, replace=False) for n in (300, 40, 200)]           # two thirds of every type never appear: isolated nodes, which the batches do sample
+        base = np.stack([g.choice(live[k], 3000) for k in range(3)], 1)
+        triples = np.concatenate([base, base[:1500]])
+    ds = GraphDataset.from_arrays(w.user_count, w.query_count, w.item_count, w.vocab_size, w.bag_words, w.bag_offsets, triples, device=dev)
+    if args.collapsed:
+        lay = ds.hypergraph.layout
+        assert lay.compact and lay.edge_weight is not None and lay.node_count == sum(len(x) for x in live)
 
     def replica():
         torch.manual_seed(5)
