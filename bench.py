@@ -85,6 +85,8 @@ def parse():
     ap.add_argument('--no-kernel-events', action='store_true', help='do not bracket kernels with HIP events')
     ap.add_argument('--no-extras', action='store_true', help='skip the untimed extra passes (per-kernel table, restricted last layer, forward only)')
     ap.add_argument('--scale', type=float, default=1.0, help='shrink every count of the workload (exploratory runs of the big configs)')
+    ap.add_argument('--union-of-ranks', type=int, default=1, help='NOT the headline: batches of 1,100 x K rows on ONE GPU - what a rank\'s step costs under the cotangent exchange '
+                                                                  'at K ranks, whose backward runs on the union of the ranks\' batch rows (DESIGN.md section 7); prints union_of_ranks in config')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for smoke tests)')
     ap.add_argument('--device', type=int, default=-1, help='force every rank onto this GPU ordinal (single-GPU smoke test of the N-rank path)')
     ap.add_argument('--sync', default='auto', choices=['auto', 'cotangent', 'flat', 'bucketed', 'sharded'],
@@ -330,7 +332,7 @@ def main():
         # Adam's moment buffers exist BEFORE the first step: otherwise they are created at the end of step 1, step 2 meets a different memory pattern and the caching
         # allocator grows its pool again (C5: two more device allocations, 47 GB, and a second step of 1.6 s instead of 0.43 s) - with them in place ONE warm-up step is enough
         opt.ensure_state()
-    batches = list(ds.sample_batches(100, args.steps + args.warmup, seed=1000 + rank))
+    batches = list(ds.sample_batches(100 * max(args.union_of_ranks, 1), args.steps + args.warmup, seed=1000 + rank))
     fused_loss = model.supports_fused_loss(lossf)
     # headline = the step with every layer evaluated over ALL rows (each hyperedge through both phases of each layer)
     model.batch_rows_only_last_layer = False
@@ -697,7 +699,8 @@ def main():
         'config': {'workload': WORKLOAD_NOTES.get(args.config, args.config) + (f' SCALED x{args.scale:g};' if args.scale != 1.0 else '') +
                                (f' WIDTH OVERRIDE --dim {dim};' if args.dim else '') +
                                f' U={w.user_count} Q={w.query_count} I={w.item_count} E={E}, {cfg["distribution"]} members, '
-                               f'dim={dim}, {layers}x{args.layer} layers, interaction order {args.order}, batch 100 pos + 1000 neg',
+                               f'dim={dim}, {layers}x{args.layer} layers, interaction order {args.order}, batch 100 pos + 1000 neg' +
+                               (f' x {args.union_of_ranks} (--union-of-ranks: the per-rank cost of a {args.union_of_ranks}-rank cotangent-exchange step, NOT the headline)' if args.union_of_ranks > 1 else ''),
                    'step': 'full training step: propagate fwd (every layer over all rows) + BCE + bwd (the last layer\'s backward pulls the 3B non-zero rows of its cotangent) + Adam' +
                            (f' + RCCL gradient exchange ({sync_mode})' if world > 1 else ''),
                    'edges': E, 'nodes': N_public, 'dim': dim, 'layers': layers, 'parallelism': f'dp{world}',
