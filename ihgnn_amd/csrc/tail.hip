@@ -131,19 +131,27 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(float* __r
                                                                       float* __restrict__ tail, int64_t tail_row_offset, int64_t tail_rows,
                                                                       int32_t* __restrict__ leader, int block_rows) {
     // block_rows: rows of different consecutive blocks of this many batch rows never share a destination (the user / query / item
-    // thirds of a batch address disjoint node ranges), so a wave only scans its own block; n = one block is the general case
-    __shared__ int32_t key[CAP];                            // every workgroup keeps the whole id list in LDS (<= 64 KiB; the wide instance 128 KiB)
-    for (int k = threadIdx.x; k < n; k += kBlockThreads) key[k] = static_cast<int32_t>(rows[k]);
+    // thirds of a batch address disjoint node ranges), so a wave only scans its own block; n = one block is the general case.
+    // A WORKGROUP belongs to one block (blockIdx.y) and keeps only that block's ids in LDS (CAP >= block_rows): a third of the fill and of the LDS of the whole list - the
+    // union of eight ranks' batches (3 x 8,800 rows) runs on the 64 KiB instance, two workgroups per CU.  A NEGATIVE id is a row that takes no part (its gradient was
+    // already summed into another row - a rank's own duplicates, combined before the exchange): never a leader, never matched.
+    __shared__ int32_t key[CAP];
+    const int lo = static_cast<int>(blockIdx.y) * block_rows;
+    const int hi = lo + block_rows < n ? lo + block_rows : n;
+    for (int k = lo + threadIdx.x; k < hi; k += kBlockThreads) key[k - lo] = static_cast<int32_t>(rows[k]);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (int64_t k = global_wave_id(); k < n; k += global_wave_count()) {
-        const int32_t mine = key[k];
-        const int lo = static_cast<int>(k) / block_rows * block_rows;
-        const int hi = lo + block_rows < n ? lo + block_rows : n;
+    const int wave = static_cast<int>(blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
+    for (int64_t k = lo + wave; k < hi; k += static_cast<int64_t>(gridDim.x) * kWavesPerBlock) {
+        const int32_t mine = key[k - lo];
+        if (mine < 0) {
+            if (COMBINE && lane == 0) leader[k] = 0;
+            continue;
+        }
         bool follower = false;
         for (int base = lo; base < k; base += kWave) {
             const int j = base + lane;
-            if (__ballot(j < k && key[j] == mine) != 0ull) { follower = true; break; }
+            if (__ballot(j < k && key[j - lo] == mine) != 0ull) { follower = true; break; }
         }
         if (COMBINE && lane == 0) leader[k] = follower ? 0 : 1;
         if (follower) continue;
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_scatter_kernel(float* __r
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int base = static_cast<int>(k) & ~(kWave - 1); base < hi; base += kWave) {
                 const int j = base + lane;
-                unsigned long long mask = __ballot(j >= k && j < hi && key[j] == mine);
+                unsigned long long mask = __ballot(j >= k && j < hi && key[j - lo] == mine);
                 while (mask != 0ull) {
                     // up to 16 members per trip: all their loads are issued before the first add (a hot destination - a
                     // popular query - can own hundreds of batch rows); absent slots add an exact 0
@@ -450,12 +458,13 @@ int ihg_batch_scatter_add(const float* rowgrad, int64_t ld_rowgrad, int32_t widt
     if (width <= 0 || ld_rowgrad < width || block_width <= 0 || ld_dense < block_width) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: bad width / stride");
     if (n_rows == 0) return IHG_OK;
     if (rowgrad == nullptr || rows == nullptr || dense == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_scatter_add: null pointer");
+    const dim3 grid(grid_for_waves(n_rows), 1);              // one block: any two rows may share a destination
     if (n_rows > kScatterMax)
-        hipLaunchKernelGGL((batch_scatter_kernel<false, kScatterMaxWide>), dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+        hipLaunchKernelGGL((batch_scatter_kernel<false, kScatterMaxWide>), grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
                            const_cast<float*>(rowgrad), ld_rowgrad, width, rows, static_cast<int>(n_rows), dense, ld_dense, block_width, block_stride, tail,
                            tail_row_offset, tail_rows, static_cast<int32_t*>(nullptr), static_cast<int>(n_rows));
     else
-        hipLaunchKernelGGL((batch_scatter_kernel<false>), dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
+        hipLaunchKernelGGL((batch_scatter_kernel<false>), grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream),
                            const_cast<float*>(rowgrad), ld_rowgrad, width, rows, static_cast<int>(n_rows), dense, ld_dense, block_width, block_stride, tail,
                            tail_row_offset, tail_rows, static_cast<int32_t*>(nullptr), static_cast<int>(n_rows));
     return check_launch("ihg_batch_scatter_add");
@@ -468,12 +477,14 @@ int ihg_batch_combine(float* rowgrad, int64_t ld_rowgrad, int32_t width, const i
     if (n_rows == 0) return IHG_OK;
     if (rowgrad == nullptr || rows == nullptr || leader == nullptr) return fail(IHG_ERR_INVALID, "ihg_batch_combine: null pointer");
     if (disjoint_block_rows <= 0 || disjoint_block_rows > n_rows) disjoint_block_rows = n_rows;
-    if (n_rows > kScatterMax)
-        hipLaunchKernelGGL((batch_scatter_kernel<true, kScatterMaxWide>), dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad,
+    const int n_blocks = static_cast<int>((n_rows + disjoint_block_rows - 1) / disjoint_block_rows);
+    const dim3 grid(grid_for_waves(disjoint_block_rows), n_blocks);      // a workgroup works inside one block and holds that block's ids only
+    if (disjoint_block_rows > kScatterMax)
+        hipLaunchKernelGGL((batch_scatter_kernel<true, kScatterMaxWide>), grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad,
                            ld_rowgrad, width, rows, static_cast<int>(n_rows), static_cast<float*>(nullptr), int64_t{0}, 1, int64_t{0},
                            static_cast<float*>(nullptr), int64_t{0}, int64_t{0}, leader, static_cast<int>(disjoint_block_rows));
     else
-        hipLaunchKernelGGL((batch_scatter_kernel<true>), dim3(grid_for_waves(n_rows)), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad,
+        hipLaunchKernelGGL((batch_scatter_kernel<true>), grid, dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), rowgrad,
                            ld_rowgrad, width, rows, static_cast<int>(n_rows), static_cast<float*>(nullptr), int64_t{0}, 1, int64_t{0},
                            static_cast<float*>(nullptr), int64_t{0}, int64_t{0}, leader, static_cast<int>(disjoint_block_rows));
     return check_launch("ihg_batch_combine");

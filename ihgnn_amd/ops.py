@@ -1461,14 +1461,34 @@ class _HemBceLoss(torch.autograd.Function):
             return (None, None, None, dbias, None, None, None, None, None) + grads
         holder = ctx.holder
         rowgrad = _hem_row_gradients(layers, rows, items, bias, ctx.lam, dscores, holder.grad_scale, tables, grad_loss.contiguous(), ctx.rows_upper)     # d loss stays on the device: no host read, no multiply launch
+        lib = _lib.load()
         if holder.exchange is not None:
             # every rank's propagation is the same function of the same parameters and its backward is linear in the cotangent of the layer outputs, which is non-zero on
             # the batch rows only: the ranks exchange THOSE rows (3B x (D + 1) floats each) and every rank runs the one propagation backward on the union - the averaged
-            # gradient of all parameters without a dense all-reduce (RawGnn.py:122-142: the batch reads F at 3B rows)
+            # gradient of all parameters without a dense all-reduce (RawGnn.py:122-142: the batch reads F at 3B rows).
+            # A rank's own duplicates are summed BEFORE the exchange (a batch repeats every positive's user and query with its ten negatives: ~ 1,300 of 3,300 rows are
+            # first occurrences) and marked in a spare column of the row gradients, which travels with them: the union's combine then skips the other rows (and the
+            # zero rows that pad a shorter batch) - its duplicate search is quadratic in the rows that take part
+            n_own = int(rows.shape[0])
+            width_own = (len(layers) + (1 if tables is not None else 0)) * (int(layers[0].shape[1]) if layers else tables.dim)
+            if lib.ihg_batch_scatter_workspace_bytes(n_own) >= 0:
+                own = torch.empty(n_own, dtype=torch.int32, device=rows.device)
+                with profiler.kernel('batch_combine', n_own, width_own + 1):
+                    _lib.check(lib.ihg_batch_combine(_ptr(rowgrad), int(rowgrad.stride(0)), width_own + 1, _ptr(rows), n_own, n_own // 3, _ptr(own), _stream()), 'ihg_batch_combine')
+                rowgrad[:, width_own + 1] = own.to(torch.float32)
+            else:
+                rowgrad[:, width_own + 1] = 1.0
             rows, rowgrad = holder.exchange(rows, rowgrad)
+            rows = torch.where(rowgrad[:, width_own + 1] > 0, rows, torch.full_like(rows, -1))
         holder.rows, holder.rowgrad, holder.leader = rows, rowgrad, None
         # (the union's rows after an exchange; this batch's otherwise - through the layout's map where it numbers its nodes without the isolated ones)
-        holder.rows_upper = None if holder.row_map is None else (ctx.rows_upper if holder.exchange is None and ctx.rows_upper is not None else holder.row_map[rows])
+        if holder.row_map is None:
+            holder.rows_upper = None
+        elif holder.exchange is None and ctx.rows_upper is not None:
+            holder.rows_upper = ctx.rows_upper
+        else:
+            mapped = holder.row_map[rows.clamp_min(0)]
+            holder.rows_upper = torch.where(rows < 0, torch.full_like(mapped, -1), mapped)
         lib = _lib.load()
         n_layers = len(layers) + (1 if tables is not None else 0)
         n, width = int(rows.shape[0]), n_layers * (int(layers[0].shape[1]) if layers else tables.dim)
