@@ -2327,6 +2327,40 @@ def test_driver_end_to_end(tmp_path, monkeypatch):
         assert abs(m_e.NDCG_at10 - m_a.NDCG_at10) <= 2e-3 and abs(m_e.HitRatio_at10 - m_a.HitRatio_at10) <= 2e-3
 
 
+def test_driver_over_a_graph_whose_layout_collapses(tmp_path, monkeypatch):
+    """The reference's CLI over files whose graph makes the layout's `auto` switches fire (72 k nodes, 38 % of them in no hyperedge; every interaction written twice): the
+    dataset built from the FILES has a compact layout with multiplicities, the driver trains, evaluates (top items over the public item catalogue) and checkpoints tables of
+    the public shape - and the run's loss falls like the same run with the collapses off."""
+    import random
+    from ihgnn_amd import synth
+    from ihgnn_amd import Main as driver
+    from ihgnn_amd.Dataset import GraphDataset
+    from ihgnn_amd.Helpers.Graph import PpsHyperGraph
+    w = synth.draw(40000, 2000, 30000, 50, 33000, seed=4, eval_logs=40)
+    w.triples = np.concatenate([w.triples, w.triples])                       # 66,000 interactions, every (user, query, item) twice
+    data_root = tmp_path / 'Data' / 'Synth' / 'Sparse'
+    synth.write_files(w, str(data_root))
+    ds = GraphDataset(str(data_root / 'graph_info.txt'), str(data_root / 'queries_multihot.txt'), str(data_root / 'train_data.csv'), PpsHyperGraph, 10, 0, dev())
+    lay = ds.hypergraph.layout
+    assert lay.compact and lay.edge_weight is not None and lay.public_node_count == 72000 and lay.node_count < 0.7 * 72000 and lay.edge_count == 33000 and ds.hypergraph.EdgeCount == 66000
+    monkeypatch.chdir(tmp_path)
+    curves = {}
+    for collapse in ('auto', '0'):
+        from ihgnn_amd import layout as layout_mod
+        monkeypatch.setattr(layout_mod, 'COMPACT_NODES', collapse)
+        monkeypatch.setattr(layout_mod, 'EDGE_MULTIPLICITY', collapse)
+        hist = driver.main(['--ds', 'Synth/Sparse/', '--gnn', 'IHGNN', '--gnns', '2', '--fo', '3', '--emb', '32', '--ec', '2', '--est', '2', '--etf', '1', '-c', '--seed', '5',
+                            '--record_step', 'off'])
+        (_, metrics), = list(hist.iter_epoch_test())
+        curves[collapse] = metrics
+        assert 0.0 <= metrics.NDCG_at10 <= 1.0 and np.isfinite(metrics.NDCG_at10)
+    result_dir = tmp_path / 'Results' / 'Synth-Sparse-RawGnn-2IHGNNLayer-O3-emb32'
+    saved = sorted(n for n in os.listdir(result_dir) if n.startswith('checkpoint_'))
+    state = torch.load(os.path.join(result_dir, saved[-1]), map_location='cpu')['model']
+    assert tuple(state['embeddings.embedding_user.weight'].shape) == (40001, 32) and tuple(state['prediction_layer.items_bias'].shape) == (30000,)
+    assert abs(curves['auto'].NDCG_at10 - curves['0'].NDCG_at10) <= 0.02 and abs(curves['auto'].HitRatio_at10 - curves['0'].HitRatio_at10) <= 0.05
+
+
 def test_driver_with_two_ranks_on_one_gpu(tmp_path):
     """``python -m ihgnn_amd.Main`` as two ranks (both on GPU 0, gloo between them: ``IHG_DIST_BACKEND``): the data-parallel training loop end to end - the sharded batch
     sampler (501 positives: the ranks' batches differ by a row, which the cotangent exchange pads), per-rank negatives, ``--grad_sync auto | cotangent | flat``, sharded
