@@ -2917,6 +2917,15 @@ def test_two_ranks_over_a_collapsed_layout(sync):
     assert r.returncode == 0 and 'OK' in r.stdout and 'DIVERGED' not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize('collapsed', [False, True])
+def test_replicas_stay_bitwise_identical_over_many_steps(collapsed):
+    """Four ranks, sixty training steps under the cotangent exchange: no parameter and no dense gradient ever crosses between the ranks, so the replicas stay together
+    only because every kernel of the step is deterministic and every rank combines the gathered rows in the same order - checked bitwise after the last step (also over
+    a layout without isolated nodes / with multiplicities)."""
+    r = _run(['tools/two_rank_check.py', '--ranks', '4', '--sync', 'cotangent', '--device', '0', '--backend', 'gloo', '--steps', '60', '--batch', '96'] + (['--collapsed'] if collapsed else []))
+    assert r.returncode == 0 and 'replicas identical -> OK' in r.stdout and 'DIVERGED' not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_eight_ranks_exchange_cotangents_of_a_union_beyond_one_combine_instance():
     """Eight processes on GPU 0 (gloo), 700 batch rows each, the cotangent exchange: the union of the ranks' batch rows is 16,800 - the wide (128 KiB of LDS) instance of the
     combine kernel, what eight ranks of 1,100 rows (26,400) run on an 8-GPU node - and the replicas must stay bitwise identical and equal the one-rank run on all 5,600 rows."""

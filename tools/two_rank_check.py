@@ -30,6 +30,8 @@ def main():
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--collapsed', action='store_true', help='a graph with isolated nodes and repeated triples under IHG_COMPACT_NODES=1 / IHG_EDGE_MULTIPLICITY=1: the layout numbers '
                     'only the nodes that have hyperedges and keeps every distinct triple once (config C5\'s default) - the exchange maps the union\'s rows through the layout\'s node map')
+    ap.add_argument('--steps', type=int, default=2, help='training steps; beyond a handful the comparison with the one-rank run is dropped (Adam amplifies rounding noise entry by entry) and only the '
+                    'replicas are compared with each other: bitwise, under the cotangent exchange')
     ap.add_argument('--batch', type=int, default=64, help='batch rows per rank (8 ranks x 700: the union of the ranks\' 3 B batch rows exceeds 16,384 - the wide instance of the combine kernel)')
     args = ap.parse_args()
     if 'WORLD_SIZE' not in os.environ:
@@ -86,7 +88,7 @@ def main():
     sl = slice(rows.start, rows.stop)
     assert world > 1 or sync.distributed, 'a one-rank run must be forced through the collectives (IHG_FORCE_COLLECTIVES=1)'
     cotangent = getattr(sync, 'mode', None) == 'cotangent'  # the ranks exchange the batch rows' cotangents inside the backward; no dense gradient exchange
-    for step in range(2):
+    for step in range(args.steps):
         (model.bce_loss(u[sl], q[sl], i[sl], y[sl], cotangent_sync=sync) if cotangent else model.bce_loss(u[sl], q[sl], i[sl], y[sl])).backward()
         if cotangent:
             assert sync.sent_bytes == 3 * (rows.stop - rows.start) * (8 + 4 * (args.dim * 3 + 4)), sync.sent_bytes
@@ -104,7 +106,19 @@ def main():
         if drift != 0.0:
             ok = False
             print(f'REPLICAS DIVERGED under the cotangent exchange: {drift:.3e}', flush=True)
-    if rank == 0:
+    if args.steps > 4:
+        if not cotangent:                                    # the dense exchanges: the replicas hold the same averaged gradient, their parameters must agree bitwise as well
+            worst = 0.0
+            for p in model.parameters():
+                ref = p.data.clone()
+                dist.broadcast(ref, src=0)
+                worst = max(worst, float((ref - p.data).abs().max()))
+            if worst != 0.0:
+                ok = False
+                print(f'REPLICAS DIVERGED under the {args.sync} exchange: {worst:.3e}', flush=True)
+        if rank == 0:
+            print(f'two_rank_check: sync={args.sync} ranks={world} steps={args.steps}: replicas identical -> {"OK" if ok else "FAIL"}', flush=True)
+    elif rank == 0:
         alone = replica()
         opt1 = Adam(alone.parameters(), 1e-3)
         for _ in range(2):
