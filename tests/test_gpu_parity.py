@@ -2919,10 +2919,10 @@ def test_two_ranks_over_a_collapsed_layout(sync):
 
 @pytest.mark.parametrize('collapsed', [False, True])
 def test_replicas_stay_bitwise_identical_over_many_steps(collapsed):
-    """Four ranks, sixty training steps under the cotangent exchange: no parameter and no dense gradient ever crosses between the ranks, so the replicas stay together
+    """Four ranks, twenty-four training steps under the cotangent exchange: no parameter and no dense gradient ever crosses between the ranks, so the replicas stay together
     only because every kernel of the step is deterministic and every rank combines the gathered rows in the same order - checked bitwise after the last step (also over
     a layout without isolated nodes / with multiplicities)."""
-    r = _run(['tools/two_rank_check.py', '--ranks', '4', '--sync', 'cotangent', '--device', '0', '--backend', 'gloo', '--steps', '60', '--batch', '96'] + (['--collapsed'] if collapsed else []))
+    r = _run(['tools/two_rank_check.py', '--ranks', '4', '--sync', 'cotangent', '--device', '0', '--backend', 'gloo', '--steps', '24', '--batch', '96'] + (['--collapsed'] if collapsed else []))
     assert r.returncode == 0 and 'replicas identical -> OK' in r.stdout and 'DIVERGED' not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
