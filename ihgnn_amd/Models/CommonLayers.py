@@ -50,6 +50,9 @@ class FeatureInteractor(nn.Module):
         return ops.node_segment_sum(self(node_features), layout, out_scale=out_scale, rows=rows, out=out)
 
     def forward(self, node_features: Tensor) -> Tensor:
+        """Hyperedge features ``[E', d]``, one row per hyperedge OF THE LAYOUT, in the layout's own numbering (by user): every interaction's row unless the layout keeps
+        repeated (user, query, item) triples once (``layout.edge_weight``; ``layout.file_to_edge`` maps an interaction to its row) - the reference's ``[E, d]`` in file order
+        is ``out[layout.file_to_edge]``.  ``node_features`` has one row per node of the layout (``layout.node_count``: without the isolated nodes where it is compact)."""
         layout = self.dataset.hypergraph.layout
         w, b = self._operands(node_features)
         if self.max_order > 1 and ops.interact_from_nodes_supported(node_features, w):
