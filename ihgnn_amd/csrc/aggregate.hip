@@ -13,7 +13,7 @@ namespace {
 
 // ================================================================================================
 // K5  node -> hyperedge gather-sum
-//   G lanes own one hyperedge row; a wave works on EPW = (64/G)*U consecutive hyperedges per iteration:
+//   G lanes own one hyperedge row; a wave works on EPW = (64/G)*U consecutive hyperedges per iteration (U = 3 from d = 64 up):
 //   one coalesced load brings their 3*EPW member ids (<= 64 ints), shuffles hand each group its ids, then
 //   up to 3*U independent row gathers per lane are issued before the first add.  Group g takes the U CONSECUTIVE
 //   hyperedges e0 + g U .. + U - 1: the layout numbers hyperedges by user, so neighbours usually share their user
@@ -21,6 +21,22 @@ namespace {
 //   The [E, d] result is written once and not re-read by this kernel: non-temporal stores, so the stream does not
 //   evict the node table from L2 / Infinity Cache (C3: 540 -> 460 us; C2: 160 -> 131 us).
 // ================================================================================================
+// consecutive hyperedges per lane group (3 U row gathers in flight per lane); A/B: tools/ab_aggregate.sh NAME -DIHG_K5_U32=n.  Round 6 measured U = 2 / 3 / 4 / 5 at
+// d = 64 / 128 / 256 (profiles/r6/09_ab_k5_hyperedges_per_group.txt): THREE is the best everywhere - C2 (d = 64) 111 -> 90 us, C3 (d = 128) 418 -> 400, C4 684 -> 611,
+// C5 x 0.2 (d = 256) 2,333 -> 2,156 - nine gathers in flight leave the registers for one more resident wave than twelve; five is slower than four.  The fp16-plane form
+// (edge_gather_sum_planes256_kernel) stays at four: 11.3 ms against 12.0 (three) in the C5 step.
+#ifndef IHG_K5_U16
+#define IHG_K5_U16 3
+#endif
+#ifndef IHG_K5_U32
+#define IHG_K5_U32 3
+#endif
+#ifndef IHG_K5_U64
+#define IHG_K5_U64 3
+#endif
+#ifndef IHG_K5_UPLANES
+#define IHG_K5_UPLANES 4
+#endif
 template <int VEC, int G, int U>
 __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
     const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ i3,
@@ -530,9 +546,9 @@ int launch_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, 
     switch (g) {
         case 4: IHG_LAUNCH_K5(4, 1) break;
         case 8: IHG_LAUNCH_K5(8, 2) break;
-        case 16: IHG_LAUNCH_K5(16, 4) break;
-        case 32: IHG_LAUNCH_K5(32, 4) break;
-        default: IHG_LAUNCH_K5(64, 4) break;
+        case 16: IHG_LAUNCH_K5(16, IHG_K5_U16) break;
+        case 32: IHG_LAUNCH_K5(32, IHG_K5_U32) break;
+        default: IHG_LAUNCH_K5(64, IHG_K5_U64) break;
     }
 #undef IHG_LAUNCH_K5
     return check_launch("ihg_edge_gather_sum");
@@ -621,7 +637,7 @@ int ihg_edge_gather_sum_planes(const float* src, int64_t ld_src, const int32_t* 
     if (n_edges == 0) return IHG_OK;
     if (src == nullptr || i3 == nullptr || planes == nullptr || inv_scale == nullptr || !aligned16(src) || !aligned16(planes))
         return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum_planes: null or unaligned pointer");
-    constexpr int U = 4;
+    constexpr int U = IHG_K5_UPLANES;
     const int grid = grid_for_waves((n_edges + U - 1) / U);
     hipLaunchKernelGGL((edge_gather_sum_planes256_kernel<U>), dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), src, ld_src, i3, node_scale,
                        edge_scale, static_cast<v2u*>(planes), inv_scale, n_edges);
