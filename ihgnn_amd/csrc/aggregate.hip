@@ -116,12 +116,27 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_kernel(
 // ================================================================================================
 // STREAM: every source row is read exactly once by the launch (the member-gradient scatter): non-temporal loads, the rows do not displace what other
 // kernels keep in the caches (C3: 488 -> 436 us; the same on rows that ARE re-read - the two-hop launches - costs 50 %: 740 -> 1,120 us)
+#ifndef IHG_K7_UNR32
+#define IHG_K7_UNR32 16
+#endif
+#ifndef IHG_K7_WAVES
+#define IHG_K7_WAVES 1      // minimum resident waves per SIMD asked of the compiler for K7 / the pair sums (A/B: tools/ab_aggregate.sh NAME -DIHG_K7_WAVES=n -DIHG_PAIR_WAVES=n)
+#endif
+#ifndef IHG_PAIR_WAVES
+#define IHG_PAIR_WAVES 1
+#endif
+#ifndef IHG_PAIR_UNR_W
+#define IHG_PAIR_UNR_W 8      // the weighted pair sums (a multiplicity per pair: config C5) carry a weight per pair in flight as well: 8 ids, seven resident waves (13.06 -> 12.72 ms)
+#endif
 template <int VEC, int G, bool STREAM = false>
 __device__ __forceinline__ Frag<VEC> accumulate_list(const float* __restrict__ src, int64_t ld_src,
                                                      const int32_t* __restrict__ ids, const float* __restrict__ src_scale,
                                                      const float* __restrict__ entry_scale, const uint8_t* __restrict__ src_mask,
                                                      int begin, int len, int wave_max_len, int lane, int col) {
-    constexpr int UNR = G < 8 ? G : (G >= 32 ? 16 : 8);      // row gathers in flight per lane (G = 32, d = 128: 16 - 2-3 % on C3's launches over 8)
+    // row gathers in flight per lane: 16 at G = 32 (d = 128: 2-3 % on C3's launches over 8), 8 otherwise - at G = 64 (d = 256) eight leave the registers for six resident
+    // waves instead of four and C5's two-hop launches go 9.19 / 9.43 -> 8.71 / 8.96 ms (round 6: profiles/r6/09_ab_gather_occupancy.txt; asking the compiler for more
+    // waves than the loop's registers allow - launch bounds - spills and doubles the launch)
+    constexpr int UNR = G < 8 ? G : (G == 32 ? IHG_K7_UNR32 : 8);
     const int lig = lane & (G - 1);
     const int group_base = lane & ~(G - 1);
     Frag<VEC> acc = Frag<VEC>::zero();
@@ -219,7 +234,7 @@ __device__ __forceinline__ void apply_out_scale(Frag<VEC>& acc, const float* out
 // Work list of one launch: first the fixed-length segments of the split (heavy) rows, then the light rows in `row_order`
 // (decreasing length).  Unit u < n_segments writes partials[u]; unit u >= n_segments writes its output row.
 template <int VEC, int G, bool MASKED = false, bool STREAM = false>
-__global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
+__global__ __launch_bounds__(kBlockThreads, IHG_K7_WAVES) void node_segment_sum_kernel(
     const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ids,
     const int32_t* __restrict__ row_order, const float* __restrict__ src_scale, const float* __restrict__ entry_scale,
     const float* __restrict__ out_scale, int mode,
@@ -286,13 +301,13 @@ __global__ __launch_bounds__(kBlockThreads) void node_segment_sum_kernel(
 #define IHG_PAIR_UNR 16
 #endif
 template <int G, bool WEIGHTED = false>
-__global__ __launch_bounds__(kBlockThreads) void node_pair_sums_kernel(
+__global__ __launch_bounds__(kBlockThreads, IHG_PAIR_WAVES) void node_pair_sums_kernel(
     const float* __restrict__ h, int64_t ld_h, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ids,
     const int32_t* __restrict__ row_order, float* __restrict__ out, int64_t ld_out, int64_t n_rows, int dim, int dim_vec,
     int heavy_threshold, const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, int64_t n_segments,
     float* __restrict__ partials, const float* __restrict__ pair_weight) {
     constexpr int GPW = kWave / G;
-    constexpr int UNR = G < 8 ? G : (G >= 32 ? IHG_PAIR_UNR : 8);      // ids in flight per lane: UNR / 2 pairs
+    constexpr int UNR = G < 8 ? G : (G >= 32 ? (WEIGHTED ? IHG_PAIR_UNR_W : IHG_PAIR_UNR) : 8);      // ids in flight per lane: UNR / 2 pairs
     const int lane = threadIdx.x & (kWave - 1);
     const int lig = lane & (G - 1);
     const int grp = lane / G;
