@@ -21,8 +21,27 @@ from . import _lib
 
 import os
 
-HEAVY_THRESHOLD = int(os.environ.get('IHG_HEAVY_THRESHOLD', 256))   # rows longer than this are split ...
-HEAVY_CHUNK = int(os.environ.get('IHG_HEAVY_CHUNK', 128))           # ... into segments of this many ids (bounds every lane group's serial chain)
+# Split-row plan: rows longer than a THRESHOLD are cut into segments of CHUNK ids (each summed by a lane group of its own; the partial sums added in a fixed tree).
+# IHG_HEAVY_THRESHOLD / IHG_HEAVY_CHUNK fix them; unset, the plan follows the list's size: 256 / 128 below LARGE_LIST entries, 512 / 512 from there on - on the BASELINE-size
+# lists fewer, longer segments are worth a little everywhere (round 6, profiles/r6/09_ab_split_row_plan.txt: pair sums 772 -> 745 us at C3, 206 -> 187 at C2, 1,060 -> 1,003 at C4;
+# step C3 - 0.6 %, C2 - 1.0 %, C5 - 0.4 %, HGCN layers at C3 5.43 -> 5.30 ms), while the small graphs of tests and examples keep split rows on their path.
+_env_threshold, _env_chunk = os.environ.get('IHG_HEAVY_THRESHOLD'), os.environ.get('IHG_HEAVY_CHUNK')
+HEAVY_THRESHOLD = int(_env_threshold) if _env_threshold is not None else None      # None: by the list's size (split_row_plan_for)
+HEAVY_CHUNK = int(_env_chunk) if _env_chunk is not None else None
+LARGE_LIST = 1 << 20
+
+
+def split_row_plan_for(nnz: int, heavy_threshold: Optional[int] = None, heavy_chunk: Optional[int] = None) -> Tuple[int, int]:
+    """``(threshold, chunk)`` of a list of ``nnz`` entries: the caller's, else the environment's, else by size (256 / 128 below ``LARGE_LIST`` entries, 512 / 512 above)."""
+    threshold = heavy_threshold if heavy_threshold is not None else HEAVY_THRESHOLD
+    if threshold is None:
+        threshold = 512 if nnz >= LARGE_LIST else 256
+    chunk = heavy_chunk if heavy_chunk is not None else HEAVY_CHUNK
+    if chunk is None:
+        chunk = 512 if threshold >= 512 else 128
+    return int(threshold), int(chunk)
+
+
 HEAVY_MAX_SEGMENTS = int(os.environ.get('IHG_HEAVY_MAX_SEGMENTS', 4096))   # ... but never more than this many per row (longer segments instead; C5 step, ms: uncapped 683, 4096: 661, 1024: 667, 256: 691)
 
 
@@ -34,9 +53,10 @@ class Csr:
     """Device-resident CSR with an optional split-row plan."""
 
     def __init__(self, ptr_host: np.ndarray, ids_host: np.ndarray, device: torch.device,
-                 heavy_threshold: int = HEAVY_THRESHOLD, heavy_chunk: int = HEAVY_CHUNK):
+                 heavy_threshold: Optional[int] = None, heavy_chunk: Optional[int] = None):
         ptr_host = np.ascontiguousarray(ptr_host, dtype=np.int32)
         ids_host = np.ascontiguousarray(ids_host, dtype=np.int32)
+        heavy_threshold, heavy_chunk = split_row_plan_for(int(ids_host.shape[0]), heavy_threshold, heavy_chunk)
         self.n_rows = int(ptr_host.shape[0] - 1)
         self.nnz = int(ids_host.shape[0])
         self.device = device
@@ -182,7 +202,7 @@ class IncidenceLayout:
     """The (user, query, item) hypergraph in kernel layout."""
 
     def __init__(self, triples: np.ndarray, user_count: int, query_count: int, item_count: int, device: torch.device,
-                 heavy_threshold: int = HEAVY_THRESHOLD, edge_order: str = os.environ.get('IHG_EDGE_ORDER', 'user'), edge_multiplicity: Optional[str] = None,
+                 heavy_threshold: Optional[int] = None, edge_order: str = os.environ.get('IHG_EDGE_ORDER', 'user'), edge_multiplicity: Optional[str] = None,
                  compact_nodes: Optional[str] = None):
         """``edge_order='user'`` renumbers the hyperedges by (user, file position) inside this layout: consecutive
         hyperedges then share their user row (the largest node table) and every user's incidence list is one contiguous
@@ -479,7 +499,7 @@ class LogHyperLayout:
     degree-bucketed treatment of the long member / incidence lists.  Built by the native ``ihg_build_log_hypergraph``."""
 
     def __init__(self, triples: np.ndarray, pos_log: np.ndarray, user_count: int, query_count: int, item_count: int, device: torch.device,
-                 heavy_threshold: int = HEAVY_THRESHOLD):
+                 heavy_threshold: Optional[int] = None):
         lib = _lib.load()
         triples = np.ascontiguousarray(np.asarray(triples, dtype=np.int64).reshape(-1, 3))
         pos_log = np.ascontiguousarray(np.asarray(pos_log, dtype=np.int64).reshape(-1))
@@ -529,7 +549,7 @@ class PairLayout:
     """Pairwise (user-query-item) graph of the GCN baseline in kernel layout: symmetric weighted CSR + ``D^-1/2``."""
 
     def __init__(self, triples: np.ndarray, user_count: int, query_count: int, item_count: int, device: torch.device,
-                 completeness: str = 'uqi', self_loops: bool = False, heavy_threshold: int = HEAVY_THRESHOLD):
+                 completeness: str = 'uqi', self_loops: bool = False, heavy_threshold: Optional[int] = None):
         lib = _lib.load()
         if completeness not in COMPLETENESS:
             raise ValueError(f'unknown graph completeness {completeness!r}')
