@@ -539,6 +539,21 @@ __global__ __launch_bounds__(kBlockThreads) void edge_gather_sum_planes256_kerne
 // Dispatch helpers
 // ------------------------------------------------------------------------------------------------
 
+// workgroups of a gather launch: one wave per unit of work up to IHG_AGG_MAX_BLOCKS workgroups, grid-stride beyond (A/B: tools/ab_aggregate.sh NAME -DIHG_AGG_MAX_BLOCKS=n).
+// 256 CUs x 64: the launches' units differ in length (lists sorted longest first, split-row segments in front), and a grid of 2,048 persistent workgroups - what fits the
+// chip at once, the library's cap elsewhere - ends with a long tail of the few workgroups whose stride met the long units; with eight times as many, shorter-lived
+// workgroups the hardware scheduler evens that out.  Round 6, profiles/r6/09_ab_gather_grid.txt: step C3 7.53 -> 7.36 ms, C2 1.765 -> 1.717, C4 10.28 -> 10.04,
+// C5 158.5 -> 152.2, HGCN layers at C3 5.45 -> 5.12 (two-hop 748 -> 725 us, pair sums 768 -> 733, masked pull 166 -> 148); 1,024 is 2 % slower than 2,048, 65,536 no better than 16,384.
+#ifndef IHG_AGG_MAX_BLOCKS
+#define IHG_AGG_MAX_BLOCKS (256 * 64)
+#endif
+inline int agg_grid(int64_t waves) {
+    int64_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > IHG_AGG_MAX_BLOCKS) blocks = IHG_AGG_MAX_BLOCKS;
+    return static_cast<int>(blocks);
+}
+
 // Smallest power of two >= n, clamped to [4, 64].
 inline int group_lanes(int n) {
     int g = 4;
@@ -554,7 +569,7 @@ int launch_edge_gather_sum(const float* src, int64_t ld_src, const int32_t* i3, 
 #define IHG_LAUNCH_K5(G, U)                                                                                         \
     {                                                                                                               \
         constexpr int EPW = (kWave / G) * U;                                                                        \
-        const int grid = grid_for_waves((n_edges + EPW - 1) / EPW);                                                 \
+        const int grid = agg_grid((n_edges + EPW - 1) / EPW);                                                 \
         hipLaunchKernelGGL((edge_gather_sum_kernel<VEC, G, U>), dim3(grid), dim3(kBlockThreads), 0, stream, src,    \
                            ld_src, i3, node_scale, bias, alpha, edge_scale, out, ld_out, n_edges, dim_vec);         \
     }
@@ -586,7 +601,7 @@ void launch_segment_sum_g(const float* src, int64_t ld_src, const int32_t* rowpt
                           int heavy_threshold, const HeavyPlan& hp, const float* self_weight, hipStream_t stream) {
     constexpr int GPW = kWave / G;
     const int dim_vec = dim / VEC;
-    const int grid = grid_for_waves((n_rows + hp.n_segments + GPW - 1) / GPW);
+    const int grid = agg_grid((n_rows + hp.n_segments + GPW - 1) / GPW);
     if (hp.src_mask != nullptr)                               // the masked pull: its own instance (see accumulate_list)
         hipLaunchKernelGGL((node_segment_sum_kernel<VEC, G, true>), dim3(grid), dim3(kBlockThreads), 0, stream, src, ld_src, rowptr, ids, row_order,
                            src_scale, entry_scale, out_scale, mode, out, ld_out, n_rows, dim, dim_vec, heavy_threshold, hp.seg_begin, hp.seg_end,
@@ -653,7 +668,7 @@ int ihg_edge_gather_sum_planes(const float* src, int64_t ld_src, const int32_t* 
     if (src == nullptr || i3 == nullptr || planes == nullptr || inv_scale == nullptr || !aligned16(src) || !aligned16(planes))
         return fail(IHG_ERR_INVALID, "ihg_edge_gather_sum_planes: null or unaligned pointer");
     constexpr int U = IHG_K5_UPLANES;
-    const int grid = grid_for_waves((n_edges + U - 1) / U);
+    const int grid = agg_grid((n_edges + U - 1) / U);
     hipLaunchKernelGGL((edge_gather_sum_planes256_kernel<U>), dim3(grid), dim3(kBlockThreads), 0, static_cast<hipStream_t>(stream), src, ld_src, i3, node_scale,
                        edge_scale, static_cast<v2u*>(planes), inv_scale, n_edges);
     return check_launch("ihg_edge_gather_sum_planes");
@@ -701,7 +716,7 @@ int ihg_node_pair_sums(const float* h, int64_t ld_h, const int32_t* pair_ptr, co
 #define IHG_PAIRS(G)                                                                                                                        \
     {                                                                                                                                       \
         constexpr int GPW = kWave / G;                                                                                                      \
-        const int grid = grid_for_waves((n_rows + n_segments + GPW - 1) / GPW);                                                             \
+        const int grid = agg_grid((n_rows + n_segments + GPW - 1) / GPW);                                                             \
         if (pair_weight != nullptr)                                                                                                         \
             hipLaunchKernelGGL((node_pair_sums_kernel<G, true>), dim3(grid), dim3(kBlockThreads), 0, s, h, ld_h, pair_ptr, pair_ids, row_order, out, \
                                ld_out, n_rows, dim, dim_vec, heavy_threshold, seg_begin, seg_end, n_segments, partials, pair_weight);       \
