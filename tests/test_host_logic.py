@@ -504,6 +504,25 @@ def test_unique_triples_and_weighted_layout():
     np.testing.assert_array_equal(g.I3.numpy(), triples + offs)
 
 
+def test_split_row_plan_follows_the_lists_size():
+    """Unset, the split-row plan is by the list's size (``layout.split_row_plan_for``): 256 / 128 below 2^20 entries - the graphs of tests and examples keep split rows on
+    their path -, 512 / 512 from there on (every BASELINE config; ``profiles/r6/09_ab_split_row_plan.txt``); a caller's threshold or chunk always wins."""
+    from ihgnn_amd import layout as layout_mod
+    if layout_mod.HEAVY_THRESHOLD is None and layout_mod.HEAVY_CHUNK is None:
+        assert layout_mod.split_row_plan_for(1000) == (256, 128) and layout_mod.split_row_plan_for((1 << 20) - 1) == (256, 128)
+        assert layout_mod.split_row_plan_for(1 << 20) == (512, 512) and layout_mod.split_row_plan_for(300_000_000) == (512, 512)
+        assert layout_mod.split_row_plan_for(10, 64) == (64, 128) and layout_mod.split_row_plan_for(1 << 22, 1024) == (1024, 512) and layout_mod.split_row_plan_for(1 << 22, 300, 100) == (300, 100)
+    rng = np.random.default_rng(0)
+    lens = np.concatenate([np.full(10, 700), rng.integers(0, 40, 5000)])
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ids = rng.integers(0, 1000, int(ptr[-1])).astype(np.int32)
+    small = layout_mod.Csr(ptr, ids, CPU)
+    threshold, chunk = layout_mod.split_row_plan_for(int(ids.shape[0]))
+    assert small.heavy_threshold == threshold and small.n_heavy == int((lens > threshold).sum()) and small.n_segments == int(sum(-(-l // chunk) for l in lens if l > threshold))
+    derived = layout_mod.Csr(ptr, ids, CPU, small.heavy_threshold)          # (a list derived from another: its threshold, the chunk that goes with it)
+    assert derived.n_segments == small.n_segments
+
+
 def test_layout_without_the_isolated_nodes():
     """``IncidenceLayout(compact_nodes='1')``: the nodes that are in no hyperedge are left out of the layout's own numbering (their layer outputs are exactly zero, SURVEY
     App. B 2): the compact graph is the public one renamed through ``node_map`` / ``active_nodes``, every per-node array is the public one restricted to the active nodes,
